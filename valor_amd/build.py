@@ -1,0 +1,76 @@
+"""Build libvalor_hip.so (the C-ABI drop-in library) for gfx950 with hipcc, in-tree.
+
+hipcc cross-compiles without a GPU; the resulting .so travels to the GPU box with the
+repo snapshot (it is git-ignored, not gpurun-ignored).
+"""
+import hashlib
+import os
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+LIB = os.path.join(HERE, "libvalor_hip.so")
+OBJDIR = os.path.join(CSRC, "_obj")
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value", "-Wno-unused-result"]
+
+
+def _sources():
+    return sorted(f for f in os.listdir(CSRC) if f.endswith(".hip"))
+
+
+def _headers_digest():
+    h = hashlib.sha1()
+    for f in sorted(os.listdir(CSRC)):
+        if f.endswith(".h"):
+            with open(os.path.join(CSRC, f), "rb") as fh:
+                h.update(fh.read())
+    return h.hexdigest()
+
+
+def _compile_one(src, hdig, verbose):
+    path = os.path.join(CSRC, src)
+    obj = os.path.join(OBJDIR, src[:-4] + ".o")
+    stamp = obj + ".sha1"
+    with open(path, "rb") as fh:
+        dig = hashlib.sha1(fh.read() + hdig.encode() + " ".join(FLAGS).encode()).hexdigest()
+    if os.path.exists(obj) and os.path.exists(stamp) and open(stamp).read() == dig:
+        return obj, False
+    cmd = [HIPCC] + FLAGS + ["-c", path, "-o", obj]
+    if verbose:
+        print("[valor_amd.build]", " ".join(cmd), flush=True)
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        sys.stderr.write(r.stdout + r.stderr)
+        raise RuntimeError(f"hipcc failed on {src}")
+    with open(stamp, "w") as fh:
+        fh.write(dig)
+    return obj, True
+
+
+def build(verbose=True, force=False):
+    os.makedirs(OBJDIR, exist_ok=True)
+    if force:
+        for f in os.listdir(OBJDIR):
+            os.remove(os.path.join(OBJDIR, f))
+    hdig = _headers_digest()
+    srcs = _sources()
+    with ThreadPoolExecutor(max_workers=min(8, len(srcs))) as ex:
+        res = list(ex.map(lambda s: _compile_one(s, hdig, verbose), srcs))
+    objs = [o for o, _ in res]
+    changed = any(c for _, c in res)
+    if changed or not os.path.exists(LIB):
+        cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
+        if verbose:
+            print("[valor_amd.build]", " ".join(cmd), flush=True)
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            sys.stderr.write(r.stdout + r.stderr)
+            raise RuntimeError("link failed")
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv))

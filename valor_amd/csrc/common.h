@@ -1,0 +1,168 @@
+// valor_amd device-side common definitions (gfx950 / CDNA4 only).
+//
+// Element types: the whole kernel library is templated on the storage type T:
+//   bf16  (perf mode: bf16 storage, fp32 accumulate on v_mfma_f32_16x16x32_bf16)
+//   float (parity mode: fp32 storage, exact fp32 on v_mfma_f32_16x16x4_f32)
+// Everything is wave64.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define VALOR_DT_BF16 0
+#define VALOR_DT_F32 1
+
+#define VALOR_OK 0
+#define VALOR_ERR_ARG (-1)
+#define VALOR_ERR_LAUNCH (-2)
+
+typedef __bf16 bf16_t;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4_t;
+typedef __attribute__((ext_vector_type(4))) float f32x4_t;
+typedef __attribute__((ext_vector_type(4))) uint32_t u32x4_t;
+typedef __attribute__((ext_vector_type(2))) uint32_t u32x2_t;
+
+#define WAVE 64
+
+#define DEVINL __device__ __forceinline__
+
+// ---------------------------------------------------------------- conversions
+DEVINL float bf16_bits_to_f32(uint32_t bits16) { return __uint_as_float(bits16 << 16); }
+
+// round-to-nearest-even fp32 -> bf16 bits (NaN preserved as quiet NaN)
+DEVINL uint32_t f32_to_bf16_bits(float f) {
+    uint32_t u = __float_as_uint(f);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (u >> 16) | 0x40u;
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return u >> 16;
+}
+
+template <typename T> struct ElemTraits;
+template <> struct ElemTraits<bf16_t> {
+    static constexpr int VEC = 8;   // elements per 16-byte chunk
+    static constexpr int DT = VALOR_DT_BF16;
+};
+template <> struct ElemTraits<float> {
+    static constexpr int VEC = 4;
+    static constexpr int DT = VALOR_DT_F32;
+};
+
+template <typename T> DEVINL float to_f32(T v);
+template <> DEVINL float to_f32<float>(float v) { return v; }
+template <> DEVINL float to_f32<bf16_t>(bf16_t v) { return (float)v; }
+
+template <typename T> DEVINL T from_f32(float v);
+template <> DEVINL float from_f32<float>(float v) { return v; }
+template <> DEVINL bf16_t from_f32<bf16_t>(float v) { return (bf16_t)v; }
+
+// load / store 4 consecutive elements as fp32 (8-byte access for bf16, 16-byte for f32)
+template <typename T> DEVINL f32x4_t load4(const T* p);
+template <> DEVINL f32x4_t load4<float>(const float* p) { return *(const f32x4_t*)p; }
+template <> DEVINL f32x4_t load4<bf16_t>(const bf16_t* p) {
+    u32x2_t r = *(const u32x2_t*)p;
+    f32x4_t o;
+    o[0] = __uint_as_float(r[0] << 16);
+    o[1] = __uint_as_float(r[0] & 0xffff0000u);
+    o[2] = __uint_as_float(r[1] << 16);
+    o[3] = __uint_as_float(r[1] & 0xffff0000u);
+    return o;
+}
+template <typename T> DEVINL void store4(T* p, f32x4_t v);
+template <> DEVINL void store4<float>(float* p, f32x4_t v) { *(f32x4_t*)p = v; }
+template <> DEVINL void store4<bf16_t>(bf16_t* p, f32x4_t v) {
+    u32x2_t r;
+    r[0] = f32_to_bf16_bits(v[0]) | (f32_to_bf16_bits(v[1]) << 16);
+    r[1] = f32_to_bf16_bits(v[2]) | (f32_to_bf16_bits(v[3]) << 16);
+    *(u32x2_t*)p = r;
+}
+
+// ---------------------------------------------------------------- wave reductions
+DEVINL float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+DEVINL float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+// reductions across the 16 lanes that share (lane >> 4)
+DEVINL float group16_sum(float v) {
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+DEVINL float group16_max(float v) {
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+// ---------------------------------------------------------------- Philox4x32-10
+// Counter-based RNG so that dropout masks are re-generated (not stored) in backward.
+struct Philox4 {
+    uint32_t v[4];
+};
+DEVINL Philox4 philox4x32_10(uint64_t seed, uint64_t ctr) {
+    uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+    uint32_t c0 = (uint32_t)ctr, c1 = (uint32_t)(ctr >> 32), c2 = 0x9E3779B9u, c3 = 0xBB67AE85u;
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        uint32_t hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
+        uint32_t hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+        uint32_t n0 = hi1 ^ c1 ^ k0, n1 = lo1, n2 = hi0 ^ c3 ^ k1, n3 = lo0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    Philox4 o;
+    o.v[0] = c0; o.v[1] = c1; o.v[2] = c2; o.v[3] = c3;
+    return o;
+}
+// keep-probability threshold compare: keep iff u32 >= p * 2^32
+DEVINL uint32_t drop_threshold(float p) {
+    double t = (double)p * 4294967296.0;
+    if (t <= 0.0) return 0u;
+    if (t >= 4294967295.0) return 0xffffffffu;
+    return (uint32_t)t;
+}
+
+// ---------------------------------------------------------------- activations
+#define VALOR_ACT_NONE 0
+#define VALOR_ACT_GELU_ERF 1    // x*0.5*(1+erf(x/sqrt2))      bert.py:52-57, transformer.py:32-38
+#define VALOR_ACT_QUICK_GELU 2  // x*sigmoid(1.702x)           clip.py:167-169
+#define VALOR_ACT_RELU 3        // fine-weight MLP             pretrain.py:104-112
+#define VALOR_ACT_TANH 4
+
+DEVINL float act_fwd(int act, float x) {
+    switch (act) {
+        case VALOR_ACT_GELU_ERF: return x * 0.5f * (1.0f + erff(x * 0.70710678118654752440f));
+        case VALOR_ACT_QUICK_GELU: return x / (1.0f + __expf(-1.702f * x));
+        case VALOR_ACT_RELU: return x > 0.f ? x : 0.f;
+        case VALOR_ACT_TANH: return tanhf(x);
+        default: return x;
+    }
+}
+// derivative wrt the pre-activation x
+DEVINL float act_bwd(int act, float x) {
+    switch (act) {
+        case VALOR_ACT_GELU_ERF: {
+            float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752440f));
+            float pdf = 0.39894228040143267794f * __expf(-0.5f * x * x);
+            return cdf + x * pdf;
+        }
+        case VALOR_ACT_QUICK_GELU: {
+            float s = 1.0f / (1.0f + __expf(-1.702f * x));
+            return s + 1.702f * x * s * (1.0f - s);
+        }
+        case VALOR_ACT_RELU: return x > 0.f ? 1.f : 0.f;
+        case VALOR_ACT_TANH: { float t = tanhf(x); return 1.f - t * t; }
+        default: return 1.0f;
+    }
+}
+
+// ---------------------------------------------------------------- launch check
+static inline int valor_launch_status() {
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? VALOR_OK : VALOR_ERR_LAUNCH;
+}

@@ -1,0 +1,309 @@
+// valor_gemm: C[M,N] = epilogue( alpha * op(A)[M,K] . op(B)[N,K]^T )   on gfx950 MFMA.
+//
+// Replaces every nn.Linear / torch.matmul projection of the VALOR step
+// (reference: model/bert.py:233-235,245-247,303-305,352,366,404,417; model/clip.py:176-182;
+//  model/transformer.py:109,117-118,136-142; model/modeling.py:249-253; model/pretrain.py:36-38)
+// and their autograd backward GEMMs (dX = dY.W, dW = dY^T.X).
+//
+// Layout flags (contraction index k is always the one summed over):
+//   transA = 0: A(m,k) = A[m*lda + k]      transA = 1: A(m,k) = A[k*lda + m]
+//   transB = 0: B(n,k) = B[n*ldb + k]      transB = 1: B(n,k) = B[k*ldb + n]
+//   forward  Y = X W^T      : transA=0 (X[M,K])      transB=0 (W[N,K])
+//   dgrad    dX = dY W      : transA=0 (dY[M,N_])    transB=1 (W[N_,K_] : k = n_)
+//   wgrad    dW = dY^T X    : transA=1 (dY[M_,N] : k = m_)  transB=1 (X[M_,K_])
+//
+// Tile: 128x128 per 256-thread workgroup (4 waves as 2x2, 64x64 each = 4x4 MFMA 16x16
+// tiles), K-step 128 B per operand row (64 bf16 / 32 fp32), double-buffered XOR-swizzled
+// LDS (64 KiB -> 2 workgroups per CU), register-staged global loads issued before and
+// committed after the MFMA block of the previous K-step (one barrier per K-step).
+// MFMA operand roles are swapped (first operand = B tile) so every lane owns 4 CONSECUTIVE
+// n of one m: the epilogue works on 8-byte (bf16) / 16-byte (fp32) vectors.
+// Split-K (gridDim.y > 1) writes fp32 partial tiles to a workspace; valor_gemm launches a
+// second kernel that sums the slices and applies the epilogue.
+#include "mma.h"
+
+struct GemmArgs {
+    const void* A; const void* B; void* C;
+    const void* bias;      // [N] (T) or null
+    void* preact;          // [M,N] ldc (T) or null: pre-activation copy (saved for backward)
+    const void* dact_aux;  // [M,N] ldaux (T) or null: multiply result by act'(aux)
+    float* ws;             // split-K partials [S][M][N] fp32
+    int64_t lda, ldb, ldc, ldaux;
+    int M, N, K;
+    int act;
+    int accumulate;        // C += result
+    int out_f32;           // C / preact stored as fp32 regardless of T
+    int kslices;           // split-K factor (gridDim.y)
+    int ksteps_per_slice;
+    float alpha;
+};
+
+template <typename T>
+DEVINL void epilogue_store(const GemmArgs& p, int m, int n0, f32x4_t acc) {
+    // 4 consecutive n (n0 .. n0+3) of row m
+    if (m >= p.M || n0 >= p.N) return;
+    const int nvalid = p.N - n0 < 4 ? p.N - n0 : 4;
+    const int64_t off = (int64_t)m * p.ldc + n0;
+    const bool vec = nvalid == 4 && ((p.ldc & 3) == 0);
+    f32x4_t v;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) v[r] = acc[r] * p.alpha;
+    if (p.bias) {
+        const T* b = (const T*)p.bias + n0;
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            if (r < nvalid) v[r] += to_f32<T>(b[r]);
+    }
+    if (p.preact) {
+        if (p.out_f32) {
+            float* q = (float*)p.preact + off;
+            if (vec) *(f32x4_t*)q = v;
+            else for (int r = 0; r < nvalid; ++r) q[r] = v[r];
+        } else {
+            T* q = (T*)p.preact + off;
+            if (vec) store4<T>(q, v);
+            else for (int r = 0; r < nvalid; ++r) q[r] = from_f32<T>(v[r]);
+        }
+    }
+    if (p.act != VALOR_ACT_NONE && !p.dact_aux) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = act_fwd(p.act, v[r]);
+    }
+    if (p.dact_aux) {
+        const T* a = (const T*)p.dact_aux + (int64_t)m * p.ldaux + n0;
+        if (vec && (p.ldaux & 3) == 0) {
+            f32x4_t u = load4<T>(a);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] *= act_bwd(p.act, u[r]);
+        } else {
+            for (int r = 0; r < nvalid; ++r) v[r] *= act_bwd(p.act, to_f32<T>(a[r]));
+        }
+    }
+    if (p.out_f32) {
+        float* c = (float*)p.C + off;
+        if (vec) {
+            if (p.accumulate) { f32x4_t o = *(f32x4_t*)c; v += o; }
+            *(f32x4_t*)c = v;
+        } else {
+            for (int r = 0; r < nvalid; ++r) c[r] = (p.accumulate ? c[r] : 0.f) + v[r];
+        }
+    } else {
+        T* c = (T*)p.C + off;
+        if (vec) {
+            if (p.accumulate) { f32x4_t o = load4<T>(c); v += o; }
+            store4<T>(c, v);
+        } else {
+            for (int r = 0; r < nvalid; ++r)
+                c[r] = from_f32<T>((p.accumulate ? to_f32<T>(c[r]) : 0.f) + v[r]);
+        }
+    }
+}
+
+template <typename T, bool TA, bool TB>
+__global__ __launch_bounds__(256) void gemm_kernel(GemmArgs p) {
+    constexpr int VEC = ElemTraits<T>::VEC;
+    constexpr int BK = 8 * VEC;
+    constexpr int TILE_BYTES = 128 * TILE_ROW_BYTES;  // 16 KiB per operand tile
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+
+    const int tiles_n = (p.N + 127) >> 7;
+    const int tiles_m = (p.M + 127) >> 7;
+    const int logical = xcd_remap(blockIdx.x, tiles_m * tiles_n);
+    const int tm = logical / tiles_n, tn = logical - tm * tiles_n;
+    const int m0 = tm << 7, n0 = tn << 7;
+
+    const int nk_total = (p.K + BK - 1) / BK;
+    int ks_begin = 0, ks_end = nk_total;
+    if (p.kslices > 1) {
+        ks_begin = blockIdx.y * p.ksteps_per_slice;
+        ks_end = ks_begin + p.ksteps_per_slice;
+        if (ks_end > nk_total) ks_end = nk_total;
+    }
+
+    const T* A = (const T*)p.A;
+    const T* B = (const T*)p.B;
+
+    f32x4_t acc[4][4];  // [ni][mi]
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+
+    // staging registers. Transposed operands are owned by half the workgroup each when both
+    // are transposed (waves 0-1: A, waves 2-3: B) so the 8-deep load bursts stay balanced.
+    DirectStage<T, 128, 256> dA, dB;
+    TransStage<T, 128, 128> tH;   // TA && TB: half-workgroup owner
+    TransStage<T, 128, 256> tF;   // exactly one transposed operand: all threads
+    const bool lowhalf = wave < 2;
+
+    auto issue = [&](int ks) {
+        const int k0 = ks * BK;
+        if constexpr (!TA && !TB) {
+            dA.issue(A, p.lda, m0, p.M, k0, p.K, tid);
+            dB.issue(B, p.ldb, n0, p.N, k0, p.K, tid);
+        } else if constexpr (!TA && TB) {
+            dA.issue(A, p.lda, m0, p.M, k0, p.K, tid);
+            tF.issue(B, p.ldb, n0, p.N, k0, p.K, tid);
+        } else if constexpr (TA && !TB) {
+            tF.issue(A, p.lda, m0, p.M, k0, p.K, tid);
+            dB.issue(B, p.ldb, n0, p.N, k0, p.K, tid);
+        } else {
+            if (lowhalf) tH.issue(A, p.lda, m0, p.M, k0, p.K, tid);
+            else tH.issue(B, p.ldb, n0, p.N, k0, p.K, tid - 128);
+        }
+    };
+    auto commit = [&](int buf) {
+        char* sA = smem + buf * 2 * TILE_BYTES;
+        char* sB = sA + TILE_BYTES;
+        if constexpr (!TA && !TB) { dA.commit(sA, tid); dB.commit(sB, tid); }
+        else if constexpr (!TA && TB) { dA.commit(sA, tid); tF.commit(sB, tid); }
+        else if constexpr (TA && !TB) { tF.commit(sA, tid); dB.commit(sB, tid); }
+        else { if (lowhalf) tH.commit(sA, tid); else tH.commit(sB, tid - 128); }
+    };
+
+    if (ks_begin < ks_end) {
+        issue(ks_begin);
+        commit(0);
+    }
+    __syncthreads();
+
+    const int fr = lane & 15, fg = lane >> 4;
+    int buf = 0;
+    for (int ks = ks_begin; ks < ks_end; ++ks) {
+        const bool has_next = ks + 1 < ks_end;
+        if (has_next) issue(ks + 1);
+        const char* sA = smem + buf * 2 * TILE_BYTES;
+        const char* sB = sA + TILE_BYTES;
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            typename Mma<T>::frag_t fn[4], fm[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                fn[i] = read_frag<T>(sB, wn * 64 + i * 16 + fr, kk * 4 + fg);
+                fm[i] = read_frag<T>(sA, wm * 64 + i * 16 + fr, kk * 4 + fg);
+            }
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+                for (int mi = 0; mi < 4; ++mi) acc[ni][mi] = Mma<T>::mma(fn[ni], fm[mi], acc[ni][mi]);
+        }
+        if (has_next) commit(buf ^ 1);
+        __syncthreads();
+        buf ^= 1;
+    }
+
+    // epilogue: acc[ni][mi][r] = C[m = m0 + wm*64 + mi*16 + (lane&15)][n = n0 + wn*64 + ni*16 + 4*(lane>>4) + r]
+    if (p.kslices > 1) {
+        float* ws = p.ws + (int64_t)blockIdx.y * p.M * p.N;
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi) {
+                const int m = m0 + wm * 64 + mi * 16 + fr;
+                const int n = n0 + wn * 64 + ni * 16 + fg * 4;
+                if (m < p.M) {
+                    float* q = ws + (int64_t)m * p.N + n;
+                    if (n + 3 < p.N && (p.N & 3) == 0) *(f32x4_t*)q = acc[ni][mi];
+                    else for (int r = 0; r < 4; ++r) if (n + r < p.N) q[r] = acc[ni][mi][r];
+                }
+            }
+    } else {
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi)
+                epilogue_store<T>(p, m0 + wm * 64 + mi * 16 + fr, n0 + wn * 64 + ni * 16 + fg * 4, acc[ni][mi]);
+    }
+}
+
+// split-K second stage: sum the fp32 slices and run the normal epilogue (4 n per thread).
+template <typename T>
+__global__ __launch_bounds__(256) void gemm_splitk_reduce(GemmArgs p) {
+    const int64_t nquads = ((int64_t)p.N + 3) >> 2;
+    const int64_t total = (int64_t)p.M * nquads;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int m = (int)(i / nquads);
+        const int n = (int)(i - (int64_t)m * nquads) << 2;
+        f32x4_t s = {0.f, 0.f, 0.f, 0.f};
+        for (int k = 0; k < p.kslices; ++k) {
+            const float* q = p.ws + ((int64_t)k * p.M + m) * p.N + n;
+            if (n + 3 < p.N && (p.N & 3) == 0) s += *(const f32x4_t*)q;
+            else for (int r = 0; r < 4; ++r) if (n + r < p.N) s[r] += q[r];
+        }
+        epilogue_store<T>(p, m, n, s);
+    }
+}
+
+template <typename T>
+static int launch_gemm(hipStream_t st, int transA, int transB, GemmArgs p) {
+    const int tiles = ((p.M + 127) / 128) * ((p.N + 127) / 128);
+    dim3 grid(tiles, p.kslices > 1 ? p.kslices : 1);
+    const size_t lds = 2 * 2 * 128 * TILE_ROW_BYTES;
+#define VALOR_GEMM_LAUNCH(TA_, TB_)                                                               \
+    do {                                                                                          \
+        static bool attr_set = false;                                                             \
+        if (!attr_set) {                                                                          \
+            hipFuncSetAttribute((const void*)gemm_kernel<T, TA_, TB_>,                            \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);            \
+            attr_set = true;                                                                      \
+        }                                                                                         \
+        hipLaunchKernelGGL((gemm_kernel<T, TA_, TB_>), grid, dim3(256), lds, st, p);              \
+    } while (0)
+    if (!transA && !transB) VALOR_GEMM_LAUNCH(false, false);
+    else if (!transA && transB) VALOR_GEMM_LAUNCH(false, true);
+    else if (transA && !transB) VALOR_GEMM_LAUNCH(true, false);
+    else VALOR_GEMM_LAUNCH(true, true);
+#undef VALOR_GEMM_LAUNCH
+    if (p.kslices > 1) {
+        const int64_t total = (int64_t)p.M * ((p.N + 3) / 4);
+        int blocks = (int)((total + 255) / 256);
+        if (blocks > 4096) blocks = 4096;
+        hipLaunchKernelGGL((gemm_splitk_reduce<T>), dim3(blocks), dim3(256), 0, st, p);
+    }
+    return valor_launch_status();
+}
+
+extern "C" int valor_gemm(void* stream, int dtype, int transA, int transB, int M, int N, int K,
+                          const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc,
+                          const void* bias, int act, void* preact, const void* dact_aux, int64_t ldaux,
+                          float alpha, int accumulate, int out_f32, void* workspace, int64_t workspace_bytes) {
+    if (M <= 0 || N <= 0) return VALOR_OK;
+    if (K < 0 || !A || !B || !C) return VALOR_ERR_ARG;
+    const int vec = dtype == VALOR_DT_BF16 ? 8 : 4;
+    // 16-byte chunk loads: leading dims and bases must be chunk aligned
+    if ((lda % vec) || (ldb % vec)) return VALOR_ERR_ARG;
+    if (((uintptr_t)A & 15) || ((uintptr_t)B & 15)) return VALOR_ERR_ARG;
+    GemmArgs p;
+    p.A = A; p.B = B; p.C = C; p.bias = bias; p.preact = preact; p.dact_aux = dact_aux;
+    p.ws = (float*)workspace;
+    p.lda = lda; p.ldb = ldb; p.ldc = ldc; p.ldaux = ldaux;
+    p.M = M; p.N = N; p.K = K; p.act = act; p.accumulate = accumulate; p.out_f32 = out_f32;
+    p.alpha = alpha;
+    const int bk = 8 * vec;
+    const int nk = (K + bk - 1) / bk;
+    // split-K heuristic: fill >= 2 waves of 256 CUs x 2 workgroups when the output is small
+    // and the contraction long (weight-gradient GEMMs: contraction = tokens).
+    const int tiles = ((M + 127) / 128) * ((N + 127) / 128);
+    int slices = 1;
+    if (workspace && tiles < 512 && nk >= 32) {
+        slices = (1024 + tiles - 1) / tiles;
+        int maxs = nk / 8; if (maxs < 1) maxs = 1;
+        if (slices > maxs) slices = maxs;
+        if (slices > 64) slices = 64;
+        while (slices > 1 && (int64_t)slices * M * N * 4 > workspace_bytes) --slices;
+    }
+    p.kslices = slices;
+    p.ksteps_per_slice = (nk + slices - 1) / slices;
+    if (p.kslices > 1) {  // recompute so no slice is empty
+        p.kslices = (nk + p.ksteps_per_slice - 1) / p.ksteps_per_slice;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == VALOR_DT_BF16) return launch_gemm<bf16_t>(st, transA, transB, p);
+    if (dtype == VALOR_DT_F32) return launch_gemm<float>(st, transA, transB, p);
+    return VALOR_ERR_ARG;
+}

@@ -1,0 +1,360 @@
+// Fused bias + dropout + residual + LayerNorm, forward and backward (gfx950, wave64).
+//
+// Replaces apex FusedLayerNorm (apex/csrc/layer_norm_cuda_kernel.cu:279-322 cuApplyLayerNorm,
+// :403-520 gamma/beta grads, :522-634 cuComputeGradInput) together with the elementwise ops
+// the reference runs around it:
+//   post-LN BERT  (model/bert.py:351-355,365-371,416-420):  y = LN(dropout(dense(x)+b) + res)
+//   pre-LN  AST   (model/transformer.py:74-85):             z = res + dropout(attn+b); y = LN(z)
+//   pre-LN  CLIP  (model/clip.py:194-197):                  z = res + (proj+b);        y = LN(z)
+//   plain LN      (embeddings bert.py:216, heads modeling.py:252, ln_pre/ln_post clip.py:266,272)
+//
+//   z = dropout_p(x + bias) / (1-p) + residual        (bias / residual / dropout optional)
+//   y = (z - mean(z)) * rsqrt(var(z) + eps) * gamma + beta     (gamma/beta optional)
+// One wave per row, row held in registers (cols <= 2048 and cols % 4 == 0), two-pass
+// mean / variance in fp32 (the apex kernel uses Welford; both agree to fp32 rounding).
+// z may alias x (in-place), so the pre-LN sum costs no extra buffer.
+// Dropout masks come from Philox4x32-10 keyed on (seed, element index / 4) and are
+// re-generated in backward instead of being stored.
+//
+// Backward: given dy (grad of y) and optionally dz_in (grad arriving at z from the
+// residual stream), produces
+//   dz  = LN'(dy) + dz_in            -> dres (grad of residual; also the stream grad)
+//   dx  = dz * mask / (1-p)          -> dx   (grad of x == grad of the GEMM output)
+//   dgamma, dbeta, dbias as per-workgroup fp32 partial sums (deterministic two-stage
+//   column reduction; valor_colsum_finalize sums the partials).
+#include "common.h"
+
+#define LN_MAX_V 8          // 4-element vectors per lane: cols <= 64*4*8 = 2048
+#define LN_PART_BLOCKS 512  // fixed workgroup count of the backward / colsum partial stage
+
+struct LnArgs {
+    const void* x; const void* bias; const void* residual; const void* gamma; const void* beta;
+    void* z; void* y; float* mean; float* rstd;
+    int64_t rows; int cols;
+    float eps, p_drop;
+    uint64_t seed, offset;
+};
+
+template <typename T, int NV>
+__global__ __launch_bounds__(256) void ln_fwd_kernel(LnArgs p) {
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const T* X = (const T*)p.x; const T* Bi = (const T*)p.bias; const T* R = (const T*)p.residual;
+    const T* G = (const T*)p.gamma; const T* Be = (const T*)p.beta;
+    T* Z = (T*)p.z; T* Y = (T*)p.y;
+    const int cols = p.cols;
+    const uint32_t thr = drop_threshold(p.p_drop);
+    const float keep_scale = p.p_drop > 0.f ? 1.0f / (1.0f - p.p_drop) : 1.0f;
+    const float inv_n = 1.0f / (float)cols;
+    for (int64_t row = (int64_t)blockIdx.x * 4 + wave; row < p.rows; row += (int64_t)gridDim.x * 4) {
+        const int64_t base = row * cols;
+        f32x4_t v[NV];
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int c = (i * 64 + lane) * 4;
+            f32x4_t t = {0.f, 0.f, 0.f, 0.f};
+            if (c < cols) {
+                t = load4<T>(X + base + c);
+                if (Bi) t += load4<T>(Bi + c);
+                if (thr) {
+                    Philox4 rnd = philox4x32_10(p.seed, p.offset + (uint64_t)((base + c) >> 2));
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) t[k] = rnd.v[k] >= thr ? t[k] * keep_scale : 0.f;
+                }
+                if (R) t += load4<T>(R + base + c);
+                if (Z) store4<T>(Z + base + c, t);
+                // LN statistics use the value that backward will re-read from z
+                if (Z && ElemTraits<T>::DT == VALOR_DT_BF16) {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) t[k] = bf16_bits_to_f32(f32_to_bf16_bits(t[k]));
+                }
+                s += t[0] + t[1] + t[2] + t[3];
+            }
+            v[i] = t;
+        }
+        if (!Y) continue;
+        const float mu = wave_sum(s) * inv_n;
+        float q = 0.f;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int c = (i * 64 + lane) * 4;
+            if (c < cols) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) { float d = v[i][k] - mu; q += d * d; }
+            }
+        }
+        const float rs = rsqrtf(wave_sum(q) * inv_n + p.eps);
+        if (lane == 0) {
+            if (p.mean) p.mean[row] = mu;
+            if (p.rstd) p.rstd[row] = rs;
+        }
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int c = (i * 64 + lane) * 4;
+            if (c < cols) {
+                f32x4_t o;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) o[k] = (v[i][k] - mu) * rs;
+                if (G) o *= load4<T>(G + c);
+                if (Be) o += load4<T>(Be + c);
+                store4<T>(Y + base + c, o);
+            }
+        }
+    }
+}
+
+struct LnBwdArgs {
+    const void* dy; const void* dz_in; const void* z; const float* mean; const float* rstd;
+    const void* gamma;
+    void* dx; void* dres;
+    float* part_dgamma; float* part_dbeta; float* part_dbias;   // [LN_PART_BLOCKS][cols] or null
+    int64_t rows; int cols;
+    float p_drop;
+    uint64_t seed, offset;
+};
+
+template <typename T, int NV>
+__global__ __launch_bounds__(256) void ln_bwd_kernel(LnBwdArgs p) {
+    __shared__ float red[3][4][64 * 4];  // [which][wave][lane*4 + k], reused per vector i
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const T* DY = (const T*)p.dy; const T* DZI = (const T*)p.dz_in; const T* Z = (const T*)p.z;
+    const T* G = (const T*)p.gamma;
+    T* DX = (T*)p.dx; T* DR = (T*)p.dres;
+    const int cols = p.cols;
+    const uint32_t thr = drop_threshold(p.p_drop);
+    const float keep_scale = p.p_drop > 0.f ? 1.0f / (1.0f - p.p_drop) : 1.0f;
+    const float inv_n = 1.0f / (float)cols;
+    const bool has_ln = DY != nullptr;
+
+    f32x4_t gsum[NV], bsum[NV], xsum[NV];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        gsum[i] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+        bsum[i] = gsum[i]; xsum[i] = gsum[i];
+    }
+    f32x4_t gam[NV];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int c = (i * 64 + lane) * 4;
+        gam[i] = (f32x4_t){1.f, 1.f, 1.f, 1.f};
+        if (G && c < cols) gam[i] = load4<T>(G + c);
+    }
+
+    for (int64_t row = (int64_t)blockIdx.x * 4 + wave; row < p.rows; row += (int64_t)gridDim.x * 4) {
+        const int64_t base = row * cols;
+        f32x4_t dzv[NV];
+        if (has_ln) {
+            const float mu = p.mean[row], rs = p.rstd[row];
+            f32x4_t xh[NV], gy[NV];
+            float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+            for (int i = 0; i < NV; ++i) {
+                const int c = (i * 64 + lane) * 4;
+                xh[i] = (f32x4_t){0.f, 0.f, 0.f, 0.f}; gy[i] = xh[i];
+                if (c < cols) {
+                    f32x4_t zz = load4<T>(Z + base + c);
+                    f32x4_t d = load4<T>(DY + base + c);
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        xh[i][k] = (zz[k] - mu) * rs;
+                        gsum[i][k] += d[k] * xh[i][k];
+                        bsum[i][k] += d[k];
+                        gy[i][k] = d[k] * gam[i][k];
+                        s1 += gy[i][k];
+                        s2 += gy[i][k] * xh[i][k];
+                    }
+                }
+            }
+            s1 = wave_sum(s1) * inv_n;
+            s2 = wave_sum(s2) * inv_n;
+#pragma unroll
+            for (int i = 0; i < NV; ++i)
+#pragma unroll
+                for (int k = 0; k < 4; ++k) dzv[i][k] = rs * (gy[i][k] - s1 - xh[i][k] * s2);
+        } else {
+#pragma unroll
+            for (int i = 0; i < NV; ++i) dzv[i] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+        }
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int c = (i * 64 + lane) * 4;
+            if (c < cols) {
+                f32x4_t dz = dzv[i];
+                if (DZI) dz += load4<T>(DZI + base + c);
+                if (DR) store4<T>(DR + base + c, dz);
+                f32x4_t dx = dz;
+                if (thr) {
+                    Philox4 rnd = philox4x32_10(p.seed, p.offset + (uint64_t)((base + c) >> 2));
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) dx[k] = rnd.v[k] >= thr ? dz[k] * keep_scale : 0.f;
+                }
+                if (DX && (thr || DX != DR)) store4<T>(DX + base + c, dx);
+                xsum[i] += dx;
+            }
+        }
+    }
+
+    // cross-wave reduction of the column partials, one vector slot at a time
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            red[0][wave][lane * 4 + k] = gsum[i][k];
+            red[1][wave][lane * 4 + k] = bsum[i][k];
+            red[2][wave][lane * 4 + k] = xsum[i][k];
+        }
+        __syncthreads();
+        // 256 threads: thread t sums column (i*256 + t) over the 4 waves
+        const int c = i * 256 + threadIdx.x;
+        if (c < cols) {
+            const int64_t o = (int64_t)blockIdx.x * cols + c;
+            float a0 = 0.f, a1 = 0.f, a2 = 0.f;
+#pragma unroll
+            for (int w = 0; w < 4; ++w) {
+                a0 += red[0][w][threadIdx.x]; a1 += red[1][w][threadIdx.x]; a2 += red[2][w][threadIdx.x];
+            }
+            if (p.part_dgamma) p.part_dgamma[o] = a0;
+            if (p.part_dbeta) p.part_dbeta[o] = a1;
+            if (p.part_dbias) p.part_dbias[o] = a2;
+        }
+    }
+}
+
+// sum `nparts` partial rows [nparts][cols] (fp32) -> out[cols] (T or fp32), optional accumulate
+template <typename T>
+__global__ void colsum_finalize_kernel(const float* part, int nparts, int cols, void* out, int out_f32, int accumulate) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= cols) return;
+    float s = 0.f;
+    for (int i = 0; i < nparts; ++i) s += part[(int64_t)i * cols + c];
+    if (out_f32) {
+        float* o = (float*)out;
+        o[c] = (accumulate ? o[c] : 0.f) + s;
+    } else {
+        T* o = (T*)out;
+        o[c] = from_f32<T>((accumulate ? to_f32<T>(o[c]) : 0.f) + s);
+    }
+}
+
+// column sums of X[rows, cols] (ld) -> partial[LN_PART_BLOCKS][cols]; used for linear-bias grads
+// (autograd of nn.Linear bias: sum over tokens).
+template <typename T>
+__global__ __launch_bounds__(256) void colsum_partial_kernel(const T* X, int64_t rows, int cols, int64_t ld, float* part) {
+    // workgroup = 4 waves; each wave strides over rows; lane handles 4 consecutive columns of a
+    // 256-column panel (blockIdx.y selects the panel).
+    __shared__ float red[4][256];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int c = blockIdx.y * 256 + lane * 4;
+    f32x4_t s = {0.f, 0.f, 0.f, 0.f};
+    const bool vec_ok = (ld & 3) == 0 && c + 3 < cols;
+    for (int64_t row = (int64_t)blockIdx.x * 4 + wave; row < rows; row += (int64_t)gridDim.x * 4) {
+        if (vec_ok) s += load4<T>(X + row * ld + c);
+        else for (int k = 0; k < 4; ++k) if (c + k < cols) s[k] += to_f32<T>(X[row * ld + c + k]);
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) red[wave][lane * 4 + k] = s[k];
+    __syncthreads();
+    const int cc = blockIdx.y * 256 + threadIdx.x;
+    if (cc < cols) part[(int64_t)blockIdx.x * cols + cc] = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+}
+
+template <typename T, int NV>
+static void launch_ln_fwd_nv(hipStream_t st, const LnArgs& p) {
+    int64_t blocks = (p.rows + 3) / 4;
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL((ln_fwd_kernel<T, NV>), dim3((unsigned)blocks), dim3(256), 0, st, p);
+}
+template <typename T>
+static int launch_ln_fwd(hipStream_t st, const LnArgs& p) {
+    const int nv = (p.cols + 255) / 256;
+    switch (nv) {
+        case 1: launch_ln_fwd_nv<T, 1>(st, p); break;
+        case 2: launch_ln_fwd_nv<T, 2>(st, p); break;
+        case 3: launch_ln_fwd_nv<T, 3>(st, p); break;
+        case 4: launch_ln_fwd_nv<T, 4>(st, p); break;
+        case 5: case 6: launch_ln_fwd_nv<T, 6>(st, p); break;
+        case 7: case 8: launch_ln_fwd_nv<T, 8>(st, p); break;
+        default: return VALOR_ERR_ARG;
+    }
+    return valor_launch_status();
+}
+template <typename T, int NV>
+static void launch_ln_bwd_nv(hipStream_t st, const LnBwdArgs& p) {
+    hipLaunchKernelGGL((ln_bwd_kernel<T, NV>), dim3(LN_PART_BLOCKS), dim3(256), 0, st, p);
+}
+template <typename T>
+static int launch_ln_bwd(hipStream_t st, const LnBwdArgs& p) {
+    const int nv = (p.cols + 255) / 256;
+    switch (nv) {
+        case 1: launch_ln_bwd_nv<T, 1>(st, p); break;
+        case 2: launch_ln_bwd_nv<T, 2>(st, p); break;
+        case 3: launch_ln_bwd_nv<T, 3>(st, p); break;
+        case 4: launch_ln_bwd_nv<T, 4>(st, p); break;
+        case 5: case 6: launch_ln_bwd_nv<T, 6>(st, p); break;
+        case 7: case 8: launch_ln_bwd_nv<T, 8>(st, p); break;
+        default: return VALOR_ERR_ARG;
+    }
+    return valor_launch_status();
+}
+
+extern "C" int valor_ln_part_blocks() { return LN_PART_BLOCKS; }
+
+extern "C" int valor_bdrln_fwd(void* stream, int dtype, const void* x, const void* bias, const void* residual,
+                               const void* gamma, const void* beta, void* z, void* y, float* mean, float* rstd,
+                               int64_t rows, int cols, float eps, float p_drop, uint64_t seed, uint64_t offset) {
+    if (rows <= 0) return VALOR_OK;
+    if (!x || cols <= 0 || (cols & 3) || cols > 64 * 4 * LN_MAX_V) return VALOR_ERR_ARG;
+    if (p_drop < 0.f || p_drop >= 1.f) return VALOR_ERR_ARG;
+    LnArgs p{x, bias, residual, gamma, beta, z, y, mean, rstd, rows, cols, eps, p_drop, seed, offset};
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == VALOR_DT_BF16) return launch_ln_fwd<bf16_t>(st, p);
+    if (dtype == VALOR_DT_F32) return launch_ln_fwd<float>(st, p);
+    return VALOR_ERR_ARG;
+}
+
+// part_* : fp32 workspaces of valor_ln_part_blocks() * cols floats each (or null)
+extern "C" int valor_bdrln_bwd(void* stream, int dtype, const void* dy, const void* dz_in, const void* z,
+                               const float* mean, const float* rstd, const void* gamma, void* dx, void* dres,
+                               float* part_dgamma, float* part_dbeta, float* part_dbias, int64_t rows, int cols,
+                               float p_drop, uint64_t seed, uint64_t offset) {
+    if (rows <= 0) return VALOR_OK;
+    if (cols <= 0 || (cols & 3) || cols > 64 * 4 * LN_MAX_V) return VALOR_ERR_ARG;
+    if (dy && (!z || !mean || !rstd)) return VALOR_ERR_ARG;
+    if (!dy && !dz_in) return VALOR_ERR_ARG;
+    LnBwdArgs p{dy, dz_in, z, mean, rstd, gamma, dx, dres, part_dgamma, part_dbeta, part_dbias, rows, cols, p_drop, seed, offset};
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == VALOR_DT_BF16) return launch_ln_bwd<bf16_t>(st, p);
+    if (dtype == VALOR_DT_F32) return launch_ln_bwd<float>(st, p);
+    return VALOR_ERR_ARG;
+}
+
+extern "C" int valor_colsum_finalize(void* stream, int dtype, const float* part, int nparts, int cols, void* out,
+                                     int out_f32, int accumulate) {
+    if (cols <= 0) return VALOR_OK;
+    hipStream_t st = (hipStream_t)stream;
+    dim3 grid((cols + 255) / 256);
+    if (dtype == VALOR_DT_BF16)
+        hipLaunchKernelGGL((colsum_finalize_kernel<bf16_t>), grid, dim3(256), 0, st, part, nparts, cols, out, out_f32, accumulate);
+    else if (dtype == VALOR_DT_F32)
+        hipLaunchKernelGGL((colsum_finalize_kernel<float>), grid, dim3(256), 0, st, part, nparts, cols, out, out_f32, accumulate);
+    else return VALOR_ERR_ARG;
+    return valor_launch_status();
+}
+
+// out[cols] (+)= sum over rows of X[rows, cols]; `part` = fp32 workspace [valor_ln_part_blocks()*cols]
+extern "C" int valor_colsum(void* stream, int dtype, const void* x, int64_t rows, int cols, int64_t ld, float* part,
+                            void* out, int out_f32, int accumulate) {
+    if (cols <= 0) return VALOR_OK;
+    if (!x || !part || !out) return VALOR_ERR_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    dim3 grid(LN_PART_BLOCKS, (cols + 255) / 256);
+    if (dtype == VALOR_DT_BF16)
+        hipLaunchKernelGGL((colsum_partial_kernel<bf16_t>), grid, dim3(256), 0, st, (const bf16_t*)x, rows, cols, ld, part);
+    else if (dtype == VALOR_DT_F32)
+        hipLaunchKernelGGL((colsum_partial_kernel<float>), grid, dim3(256), 0, st, (const float*)x, rows, cols, ld, part);
+    else return VALOR_ERR_ARG;
+    return valor_colsum_finalize(stream, dtype, part, LN_PART_BLOCKS, cols, out, out_f32, accumulate);
+}

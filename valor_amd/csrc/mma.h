@@ -1,0 +1,175 @@
+// MFMA wrappers + LDS tile staging shared by the GEMM, attention and contrastive kernels.
+//
+// Fragment abstraction (identical for both element types): a fragment is ONE 16-byte
+// LDS read per lane holding VEC consecutive contraction (k) elements of one operand row:
+//   lane l reads operand row (l & 15), 16-byte chunk (l >> 4) of a 4-chunk k-group.
+//   bf16 : chunk = 8 k  -> one v_mfma_f32_16x16x32_bf16 consumes a whole 32-k group
+//   fp32 : chunk = 4 k  -> four v_mfma_f32_16x16x4_f32 (element j of every lane) consume
+//          a 16-k group; the k-permutation is the same for both operands so the
+//          contraction is exact.
+// Result (both): acc[r] = C[row = 4*(l>>4) + r][col = l & 15], "row" indexes the FIRST
+// operand's rows, "col" the second operand's rows.
+//
+// LDS tile image: ROWS x 128 bytes (8 chunks of 16 B = one K-step of 8*VEC elements per
+// operand row); chunk c of row r lives at  r*128 + ((c ^ (r & 7)) << 4)   (XOR swizzle:
+// the 16 lanes of every ds_read_b128 service group hit 16 distinct 16-B slots, and the
+// 8-lane ds_write_b128 groups of both stagers below write 8 distinct slots).
+#pragma once
+#include "common.h"
+
+template <typename T> struct Mma;
+template <> struct Mma<bf16_t> {
+    typedef bf16x8_t frag_t;
+    static DEVINL f32x4_t mma(frag_t a, frag_t b, f32x4_t c) {
+        return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+    }
+};
+template <> struct Mma<float> {
+    typedef f32x4_t frag_t;
+    static DEVINL f32x4_t mma(frag_t a, frag_t b, f32x4_t c) {
+        c = __builtin_amdgcn_mfma_f32_16x16x4f32(a[0], b[0], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_16x16x4f32(a[1], b[1], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_16x16x4f32(a[2], b[2], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_16x16x4f32(a[3], b[3], c, 0, 0, 0);
+        return c;
+    }
+};
+
+#define TILE_ROW_BYTES 128
+DEVINL int tile_off(int row, int chunk) { return row * TILE_ROW_BYTES + ((chunk ^ (row & 7)) << 4); }
+
+template <typename T>
+DEVINL typename Mma<T>::frag_t read_frag(const char* tile, int row, int chunk) {
+    return *(const typename Mma<T>::frag_t*)(tile + tile_off(row, chunk));
+}
+
+// ---------------------------------------------------------------------------------------
+// DirectStage: operand stored row-major with the contraction dim contiguous:
+//   elem(row, k) = base[row*ld + k].   Tile = ROWS x (8*VEC) elements.
+// NT threads cooperate; each owns ROWS*8/NT chunks, held in registers between issue()
+// (global loads, early) and commit() (LDS writes, late) so HBM latency hides under MFMA.
+// Out-of-range rows / k are zero filled; a chunk straddling K is tail-masked.
+// ---------------------------------------------------------------------------------------
+template <typename T, int ROWS, int NT>
+struct DirectStage {
+    static constexpr int VEC = ElemTraits<T>::VEC;
+    static constexpr int N = (ROWS * 8 + NT - 1) / NT;
+    u32x4_t v[N];
+
+    DEVINL void issue(const T* __restrict__ base, int64_t ld, int row0, int R, int k0, int K, int tid) {
+#pragma unroll
+        for (int j = 0; j < N; ++j) {
+            int idx = tid + j * NT;
+            int c = idx & 7, r = idx >> 3;
+            int gr = row0 + r, gk = k0 + c * VEC;
+            u32x4_t val = {0u, 0u, 0u, 0u};
+            if ((ROWS * 8 % NT == 0 || r < ROWS) && gr < R && gk < K) {
+                val = *(const u32x4_t*)(base + (int64_t)gr * ld + gk);
+                if (gk + VEC > K) {  // tail chunk: zero the elements >= K
+                    int valid = K - gk;
+                    if (VEC == 8) {
+#pragma unroll
+                        for (int d = 0; d < 4; ++d) {
+                            if (2 * d >= valid) val[d] = 0u;
+                            else if (2 * d + 1 >= valid) val[d] &= 0xffffu;
+                        }
+                    } else {
+#pragma unroll
+                        for (int d = 0; d < 4; ++d)
+                            if (d >= valid) val[d] = 0u;
+                    }
+                }
+            }
+            v[j] = val;
+        }
+    }
+    DEVINL void commit(char* tile, int tid) {
+#pragma unroll
+        for (int j = 0; j < N; ++j) {
+            int idx = tid + j * NT;
+            int c = idx & 7, r = idx >> 3;
+            if (ROWS * 8 % NT == 0 || r < ROWS) *(u32x4_t*)(tile + tile_off(r, c)) = v[j];
+        }
+    }
+};
+
+// ---------------------------------------------------------------------------------------
+// TransStage: operand stored with the contraction dim as the SLOW dim:
+//   elem(row, k) = base[k*ld + row]    (row = output index, contiguous in memory)
+// A task = VEC k-rows x VEC output-rows block: VEC 16-byte loads (coalesced along `row`),
+// transposed in registers (bf16: 8x8 16-bit transpose by dword packing; fp32: 4x4 register
+// renaming) and written as VEC 16-byte chunks of the k-contiguous LDS tile image.
+// Task id t: kg = t & 7 (chunk / k-group), rc = t >> 3 (row group).
+// The allocation behind `base` must cover whole 16-B chunks of a row (ld % VEC == 0);
+// rows >= R inside a chunk may hold garbage: they only reach output rows that are
+// never stored.
+// ---------------------------------------------------------------------------------------
+template <int VEC> struct Transposer;
+template <> struct Transposer<8> {
+    static DEVINL void run(const u32x4_t (&in)[8], u32x4_t (&out)[8]) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int d = i >> 1;
+#pragma unroll
+            for (int w = 0; w < 4; ++w) {
+                uint32_t a = in[2 * w][d], b = in[2 * w + 1][d];
+                out[i][w] = (i & 1) ? ((a >> 16) | (b & 0xffff0000u)) : ((a & 0xffffu) | (b << 16));
+            }
+        }
+    }
+};
+template <> struct Transposer<4> {
+    static DEVINL void run(const u32x4_t (&in)[4], u32x4_t (&out)[4]) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int w = 0; w < 4; ++w) out[i][w] = in[w][i];
+    }
+};
+
+template <typename T, int ROWS, int NT>
+struct TransStage {
+    static constexpr int VEC = ElemTraits<T>::VEC;
+    static constexpr int NTASK = 8 * (ROWS / VEC);
+    static constexpr int N = (NTASK + NT - 1) / NT;
+    u32x4_t v[N][VEC];
+
+    DEVINL void issue(const T* __restrict__ base, int64_t ld, int row0, int R, int k0, int K, int tid) {
+#pragma unroll
+        for (int j = 0; j < N; ++j) {
+            int t = tid + j * NT;
+            int kg = t & 7, rc = t >> 3;
+            int gr = row0 + rc * VEC;
+            bool rok = (NTASK % NT == 0 || t < NTASK) && gr < R;
+#pragma unroll
+            for (int i = 0; i < VEC; ++i) {
+                int gk = k0 + kg * VEC + i;
+                u32x4_t val = {0u, 0u, 0u, 0u};
+                if (rok && gk < K) val = *(const u32x4_t*)(base + (int64_t)gk * ld + gr);
+                v[j][i] = val;
+            }
+        }
+    }
+    DEVINL void commit(char* tile, int tid) {
+#pragma unroll
+        for (int j = 0; j < N; ++j) {
+            int t = tid + j * NT;
+            int kg = t & 7, rc = t >> 3;
+            if (NTASK % NT == 0 || t < NTASK) {
+                u32x4_t o[VEC];
+                Transposer<VEC>::run(v[j], o);
+#pragma unroll
+                for (int i = 0; i < VEC; ++i) *(u32x4_t*)(tile + tile_off(rc * VEC + i, kg)) = o[i];
+            }
+        }
+    }
+};
+
+// XCD-aware bijective block remap (8 XCDs, block b runs on XCD b % 8): gives every XCD a
+// contiguous range of logical tile ids so neighbouring tiles share operand panels in one L2.
+DEVINL int xcd_remap(int bid, int nwg) {
+    const int q = nwg >> 3, r = nwg & 7;
+    const int xcd = bid & 7, loc = bid >> 3;
+    const int start = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    return start + loc;
+}

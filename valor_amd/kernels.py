@@ -1,0 +1,142 @@
+"""Tensor-level wrappers over the C-ABI (no autograd here; see ops.py).
+
+torch is used for device memory, streams and shapes only; every computation below is a
+HIP kernel in libvalor_hip.so. All tensors must live on the GPU: a CPU tensor is an error.
+"""
+import torch
+
+from . import lib
+from .lib import ACT_NONE, DT_BF16, DT_F32
+
+_WS = {}
+_WS_BYTES = 256 << 20
+
+
+def dt_of(t):
+    if t.dtype == torch.bfloat16:
+        return DT_BF16
+    if t.dtype == torch.float32:
+        return DT_F32
+    raise TypeError(f"valor_amd kernels support bf16 / fp32 only, got {t.dtype}")
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _ptr(t):
+    return 0 if t is None else t.data_ptr()
+
+
+def _check_gpu(*ts):
+    for t in ts:
+        if t is not None and not t.is_cuda:
+            raise lib.ValorHipError("valor_amd kernels need GPU tensors (no CPU fallback)")
+
+
+def workspace(device, nbytes=_WS_BYTES):
+    """Persistent fp32 scratch (split-K partials, column-sum partials)."""
+    key = (device.index if device.index is not None else torch.cuda.current_device())
+    ws = _WS.get(key)
+    if ws is None or ws.numel() * 4 < nbytes:
+        ws = torch.empty(nbytes // 4, dtype=torch.float32, device=device)
+        _WS[key] = ws
+    return ws
+
+
+def _rowmajor(t):
+    assert t.dim() == 2 and t.stride(1) == 1, "need a 2-D tensor with unit inner stride"
+    return t.stride(0)
+
+
+def gemm(a, b, *, trans_a=False, trans_b=False, bias=None, act=ACT_NONE, want_preact=False,
+         dact_aux=None, alpha=1.0, out=None, accumulate=False, out_dtype=None, splitk=True):
+    """C[M,N] = epi(alpha * op(A) . op(B)^T).  A: [M,K] ([K,M] if trans_a); B: [N,K] ([K,N] if trans_b)."""
+    _check_gpu(a, b, bias, dact_aux, out)
+    M, K = (a.shape[1], a.shape[0]) if trans_a else (a.shape[0], a.shape[1])
+    N, Kb = (b.shape[1], b.shape[0]) if trans_b else (b.shape[0], b.shape[1])
+    assert K == Kb, f"contraction mismatch {K} vs {Kb}"
+    assert a.dtype == b.dtype
+    lda, ldb = _rowmajor(a), _rowmajor(b)
+    odt = out_dtype or a.dtype
+    if out is None:
+        out = torch.empty((M, N), dtype=odt, device=a.device)
+    assert out.shape == (M, N) and out.dtype == odt
+    ldc = _rowmajor(out)
+    out_f32 = 1 if (odt == torch.float32 and a.dtype != torch.float32) else 0
+    preact = None
+    if want_preact:
+        preact = torch.empty((M, N), dtype=odt, device=a.device)
+        assert _rowmajor(preact) == ldc
+    ldaux = _rowmajor(dact_aux) if dact_aux is not None else 0
+    ws = workspace(a.device) if splitk else None
+    lib.call("valor_gemm", _stream(), dt_of(a), int(trans_a), int(trans_b), M, N, K,
+             _ptr(a), lda, _ptr(b), ldb, _ptr(out), ldc, _ptr(bias), act, _ptr(preact), _ptr(dact_aux), ldaux,
+             float(alpha), int(accumulate), out_f32, _ptr(ws), (ws.numel() * 4 if ws is not None else 0))
+    return (out, preact) if want_preact else out
+
+
+def part_blocks():
+    return lib.load().valor_ln_part_blocks()
+
+
+def bdrln_fwd(x, bias, residual, gamma, beta, eps, *, p_drop=0.0, seed=0, offset=0, write_z=True, inplace_z=False,
+              want_y=True):
+    """z = dropout(x + bias)/(1-p) + residual ; y = LN(z).  Returns (z, y, mean, rstd)."""
+    _check_gpu(x, bias, residual, gamma, beta)
+    cols = x.shape[-1]
+    rows = x.numel() // cols
+    assert x.is_contiguous() and (residual is None or residual.is_contiguous())
+    z = None
+    if write_z:
+        z = x if inplace_z else torch.empty_like(x)
+    y = torch.empty_like(x) if want_y else None
+    mean = torch.empty(rows, dtype=torch.float32, device=x.device) if want_y else None
+    rstd = torch.empty(rows, dtype=torch.float32, device=x.device) if want_y else None
+    lib.call("valor_bdrln_fwd", _stream(), dt_of(x), _ptr(x), _ptr(bias), _ptr(residual), _ptr(gamma), _ptr(beta),
+             _ptr(z), _ptr(y), _ptr(mean), _ptr(rstd), rows, cols, float(eps), float(p_drop), int(seed), int(offset))
+    return z, y, mean, rstd
+
+
+def bdrln_bwd(dy, dz_in, z, mean, rstd, gamma, *, p_drop=0.0, seed=0, offset=0, want_dgamma=True, want_dbeta=True,
+              want_dbias=False, separate_dx=False):
+    """Returns (dx, dres, dgamma, dbeta, dbias) ; dx is dres when there is no dropout."""
+    ref = dy if dy is not None else dz_in
+    _check_gpu(dy, dz_in, z, gamma)
+    cols = ref.shape[-1]
+    rows = ref.numel() // cols
+    nb = part_blocks()
+    ws = workspace(ref.device)
+    need = 3 * nb * cols
+    assert ws.numel() >= need
+    pg = ws[0:nb * cols] if (want_dgamma and dy is not None) else None
+    pb = ws[nb * cols:2 * nb * cols] if (want_dbeta and dy is not None) else None
+    px = ws[2 * nb * cols:3 * nb * cols] if want_dbias else None
+    dres = torch.empty_like(ref)
+    dx = torch.empty_like(ref) if (p_drop > 0.0 or separate_dx) else dres
+    lib.call("valor_bdrln_bwd", _stream(), dt_of(ref), _ptr(dy), _ptr(dz_in), _ptr(z), _ptr(mean), _ptr(rstd),
+             _ptr(gamma), _ptr(dx), _ptr(dres), _ptr(pg), _ptr(pb), _ptr(px), rows, cols, float(p_drop), int(seed),
+             int(offset))
+    outs = []
+    for part in (pg, pb, px):
+        if part is None:
+            outs.append(None)
+            continue
+        o = torch.empty(cols, dtype=ref.dtype, device=ref.device)
+        lib.call("valor_colsum_finalize", _stream(), dt_of(ref), _ptr(part), nb, cols, _ptr(o), 0, 0)
+        outs.append(o)
+    return dx, dres, outs[0], outs[1], outs[2]
+
+
+def colsum(x, out=None, accumulate=False):
+    """out[cols] (+)= sum over rows of the 2-D tensor x (unit inner stride)."""
+    _check_gpu(x, out)
+    rows, cols = x.shape
+    ld = _rowmajor(x)
+    if out is None:
+        out = torch.empty(cols, dtype=x.dtype, device=x.device)
+        accumulate = False
+    ws = workspace(x.device)
+    assert ws.numel() >= part_blocks() * cols
+    lib.call("valor_colsum", _stream(), dt_of(x), _ptr(x), rows, cols, ld, _ptr(ws), _ptr(out), 0, int(accumulate))
+    return out

@@ -1,0 +1,61 @@
+"""ctypes binding of the C-ABI library ``libvalor_hip.so`` (declared in include/valor_hip.h).
+
+There is NO fallback: if the library is missing or a call returns an error code the
+caller gets an exception. Raw device pointers + the current HIP stream are passed; the
+kernels never allocate.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libvalor_hip.so")
+
+DT_BF16 = 0
+DT_F32 = 1
+
+ACT_NONE, ACT_GELU_ERF, ACT_QUICK_GELU, ACT_RELU, ACT_TANH = 0, 1, 2, 3, 4
+
+_c = ctypes
+_vp, _i, _i64, _u64, _f = _c.c_void_p, _c.c_int, _c.c_int64, _c.c_uint64, _c.c_float
+
+# name -> argtypes (restype is always int: 0 ok, <0 error)
+SIGNATURES = {
+    "valor_gemm": [_vp, _i, _i, _i, _i, _i, _i, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _i, _vp, _vp, _i64,
+                   _f, _i, _i, _vp, _i64],
+    "valor_ln_part_blocks": [],
+    "valor_bdrln_fwd": [_vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i, _f, _f, _u64, _u64],
+    "valor_bdrln_bwd": [_vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i, _f, _u64, _u64],
+    "valor_colsum_finalize": [_vp, _i, _vp, _i, _i, _vp, _i, _i],
+    "valor_colsum": [_vp, _i, _vp, _i64, _i, _i64, _vp, _vp, _i, _i],
+}
+
+_lib = None
+
+
+class ValorHipError(RuntimeError):
+    pass
+
+
+def load():
+    """Load the library (once). Raises if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ValorHipError(
+            f"{LIB_PATH} not found: run `python -m valor_amd.build` (hipcc --offload-arch=gfx950). "
+            "valor_amd has no CPU / eager fallback by design.")
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, argtypes in SIGNATURES.items():
+        fn = getattr(lib, name)
+        fn.argtypes = argtypes
+        fn.restype = _i
+    _lib = lib
+    return lib
+
+
+def call(name, *args):
+    rc = getattr(load(), name)(*args)
+    if rc != 0:
+        raise ValorHipError(f"{name} failed with code {rc}")
+    return rc
