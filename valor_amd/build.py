@@ -38,13 +38,23 @@ def _compile_one(src, hdig, verbose):
         dig = hashlib.sha1(fh.read() + hdig.encode() + " ".join(FLAGS).encode()).hexdigest()
     if os.path.exists(obj) and os.path.exists(stamp) and open(stamp).read() == dig:
         return obj, False
-    cmd = [HIPCC] + FLAGS + ["-c", path, "-o", obj]
+    cmd = [HIPCC] + FLAGS + ["-Rpass-analysis=kernel-resource-usage", "-c", path, "-o", obj]
     if verbose:
         print("[valor_amd.build]", " ".join(cmd), flush=True)
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
         sys.stderr.write(r.stdout + r.stderr)
         raise RuntimeError(f"hipcc failed on {src}")
+    # a kernel that touches scratch (register arrays demoted to private memory, spills) is a
+    # performance bug on this library: report it loudly.
+    fn = None
+    for line in r.stderr.splitlines():
+        if "Function Name:" in line:
+            fn = line.split("Function Name:")[1].split()[0]
+        elif "ScratchSize [bytes/lane]:" in line:
+            n = int(line.split("ScratchSize [bytes/lane]:")[1].split()[0])
+            if n:
+                print(f"[valor_amd.build] WARNING: {src}: kernel {fn} uses {n} B/lane of scratch", flush=True)
     with open(stamp, "w") as fh:
         fh.write(dig)
     return obj, True

@@ -1,0 +1,616 @@
+// Scaled-dot-product attention (self / modality-grouped cross), forward + backward, head_dim 64.
+//
+// Replaces BertSelfAttention (model/bert.py:272-288: QK^T/sqrt(d) + additive mask, softmax,
+// dropout, PV), BertCrossAttention (model/bert.py:314-340, K/V = [video | audio] tokens, no mask),
+// AST MultiHeadAttention (model/transformer.py:115-130) and CLIP's nn.MultiheadAttention
+// (model/clip.py:186-192; text: causal + pad mask clip.py:407-414) with a flash-style kernel:
+// the S x S score matrix never reaches HBM; K / V tiles are staged in LDS; softmax row
+// reductions are wave64 shuffles.
+//
+// Data layout: q / k / v / o are addressed as  base + b*bs + row*rs + h*64 + d  (element strides),
+// so the fused QKV GEMM output [tokens, 3*E] and the shared cross K/V buffer [tokens, 2*E] are
+// consumed in place (no head-major scatter, no transposes).
+// Modality grouping: kv_range[b] = (start, len) selects the slice of the concatenated
+// [video | audio] K/V rows a query batch attends to, and kv batch = b % kv_bmod lets the
+// caption-tva / -tv / -ta query batches share ONE projected K/V set (bert.py:448-455 projects
+// the same tokens once per pass; here once per layer).
+//
+// MFMA layout trick used throughout: scores are produced TRANSPOSED (first operand = keys,
+// second = queries), so lane l owns query (l & 15) and 4 CONSECUTIVE keys 4*(l>>4)+r of each
+// 16-key tile: softmax statistics are per-lane scalars (+2 shuffles), and the probabilities feed
+// the P.V MFMA directly from registers as its second operand, with the V^T fragment read from
+// LDS in the matching k-slot order (two 8-byte reads for bf16) -- no P round trip through LDS.
+#include "mma.h"
+
+#define ATT_D 64
+#define IMG_BYTES (64 * TILE_ROW_BYTES)   // one 64-row LDS tile image = 8 KiB
+
+struct AttnArgs {
+    const void* q; const void* k; const void* v; void* o; float* lse;
+    const void* dout; void* dq; void* dk; void* dv; float* delta;   // backward only
+    const float* mask; const int* kv_range;
+    int B, H, Sq, Skv;
+    int64_t q_bs, q_rs, k_bs, k_rs, v_bs, v_rs, o_bs, o_rs;
+    int64_t do_bs, do_rs, dq_bs, dq_rs, dk_bs, dk_rs, dv_bs, dv_rs;
+    int64_t mask_bs, mask_rs;
+    int kv_bmod;
+    float scale, p_drop;
+    uint64_t seed, offset;
+};
+
+template <typename T> DEVINL float fexp(float x);
+template <> DEVINL float fexp<float>(float x) { return expf(x); }
+template <> DEVINL float fexp<bf16_t>(float x) { return __expf(x); }
+
+// fragment chunk c (0 .. 8*NIMG-1) of `row` from a multi-image tile
+template <typename T>
+DEVINL typename Mma<T>::frag_t read_frag_mi(const char* imgs, int row, int c) {
+    return read_frag<T>(imgs + (c >> 3) * IMG_BYTES, row, c & 7);
+}
+
+// bf16 "natural k-slot" fragment: slot (g, j<4) <- element 32kk+4g+j ; slot (g, 4+j) <- 32kk+16+4g+j
+DEVINL bf16x8_t read_frag_nat_bf16(const char* img, int row, int kk, int g) {
+    const int c0 = 4 * kk + (g >> 1), sub = (g & 1) * 8;
+    u32x2_t lo = *(const u32x2_t*)(img + tile_off(row, c0) + sub);
+    u32x2_t hi = *(const u32x2_t*)(img + tile_off(row, c0 + 2) + sub);
+    u32x4_t r = {lo[0], lo[1], hi[0], hi[1]};
+    return __builtin_bit_cast(bf16x8_t, r);
+}
+DEVINL bf16x8_t pack_bf16x8(f32x4_t a, f32x4_t b) {
+    u32x4_t r;
+    r[0] = f32_to_bf16_bits(a[0]) | (f32_to_bf16_bits(a[1]) << 16);
+    r[1] = f32_to_bf16_bits(a[2]) | (f32_to_bf16_bits(a[3]) << 16);
+    r[2] = f32_to_bf16_bits(b[0]) | (f32_to_bf16_bits(b[1]) << 16);
+    r[3] = f32_to_bf16_bits(b[2]) | (f32_to_bf16_bits(b[3]) << 16);
+    return __builtin_bit_cast(bf16x8_t, r);
+}
+
+// acc[dt] += sum over 64 contraction slots of  X^T[d][slot] * p[slot]   (X^T image rows = d)
+//   p4[t] (t=0..3): this lane's 4 consecutive contraction values of 16-slot tile t (natural layout)
+template <typename T>
+DEVINL void nat_mma_64(const char* imgs, const f32x4_t (&p4)[4], f32x4_t (&acc)[4], int lane) {
+    const int fr = lane & 15, g = lane >> 4;
+    if constexpr (ElemTraits<T>::DT == VALOR_DT_BF16) {
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            bf16x8_t pf = pack_bf16x8(p4[2 * kk], p4[2 * kk + 1]);
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) {
+                bf16x8_t xf = read_frag_nat_bf16(imgs, dt * 16 + fr, kk, g);
+                acc[dt] = Mma<bf16_t>::mma(xf, pf, acc[dt]);
+            }
+        }
+    } else {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) {
+                f32x4_t xf = read_frag_mi<float>(imgs, dt * 16 + fr, t * 4 + g);
+                acc[dt] = Mma<float>::mma(xf, p4[t], acc[dt]);
+            }
+        }
+    }
+}
+
+struct KvSel { int kb; int start; int len; };
+DEVINL KvSel kv_select(const AttnArgs& p, int b) {
+    KvSel s;
+    s.kb = p.kv_bmod > 0 ? b % p.kv_bmod : b;
+    s.start = 0; s.len = p.Skv;
+    if (p.kv_range) { s.start = p.kv_range[2 * b]; s.len = p.kv_range[2 * b + 1]; }
+    return s;
+}
+
+// ------------------------------------------------------------------------------------------
+// forward.  grid = (ceil(Sq / (64*RT)), H, B), 256 threads; wave w owns 16*RT query rows.
+// ------------------------------------------------------------------------------------------
+template <typename T, int RT>
+__global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs p) {
+    constexpr int VEC = ElemTraits<T>::VEC;
+    constexpr int NIMG = 64 * (int)sizeof(T) / TILE_ROW_BYTES;   // 1 (bf16) / 2 (fp32)
+    constexpr int NDG = ATT_D / (4 * VEC);                       // d-groups of 4 chunks: 2 / 4
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* sK = smem;                       // NIMG images [64 keys][128 B of d]
+    char* sV = smem + NIMG * IMG_BYTES;    // NIMG images [64 d][128 B of keys]  (V^T)
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int fr = lane & 15, g = lane >> 4;
+    const int b = blockIdx.z, h = blockIdx.y;
+    const int q0 = blockIdx.x * (64 * RT) + wave * (16 * RT);
+    const KvSel kv = kv_select(p, b);
+
+    const T* Q = (const T*)p.q + (int64_t)b * p.q_bs + h * ATT_D;
+    const T* Kp = (const T*)p.k + (int64_t)kv.kb * p.k_bs + (int64_t)kv.start * p.k_rs + h * ATT_D;
+    const T* Vp = (const T*)p.v + (int64_t)kv.kb * p.v_bs + (int64_t)kv.start * p.v_rs + h * ATT_D;
+
+    typename Mma<T>::frag_t qf[RT][NDG];
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) {
+        const int qr = q0 + rt * 16 + fr;
+#pragma unroll
+        for (int dg = 0; dg < NDG; ++dg) {
+            u32x4_t z = {0u, 0u, 0u, 0u};
+            if (qr < p.Sq) z = *(const u32x4_t*)(Q + (int64_t)qr * p.q_rs + dg * 4 * VEC + g * VEC);
+            qf[rt][dg] = __builtin_bit_cast(typename Mma<T>::frag_t, z);
+        }
+    }
+
+    f32x4_t oacc[RT][4];
+    float mrow[RT], lrow[RT];
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) {
+        mrow[rt] = -1e30f; lrow[rt] = 0.f;
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) oacc[rt][dt] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+    }
+
+    const uint32_t thr = drop_threshold(p.p_drop);
+    const float keep_scale = p.p_drop > 0.f ? 1.0f / (1.0f - p.p_drop) : 1.0f;
+    const int kq4 = (p.Skv + 3) >> 2;   // RNG row pitch in 4-key groups
+
+    DirectStage<T, 64, 256> stK[NIMG];
+    TransStage<T, 64, 256> stV[NIMG];
+    auto issue = [&](int kv0) {
+#pragma unroll
+        for (int im = 0; im < NIMG; ++im) {
+            stK[im].issue(Kp, p.k_rs, kv0, kv.len, im * 8 * VEC, ATT_D, tid);
+            stV[im].issue(Vp, p.v_rs, 0, ATT_D, kv0 + im * 8 * VEC, kv.len, tid);
+        }
+    };
+    auto commit = [&]() {
+#pragma unroll
+        for (int im = 0; im < NIMG; ++im) {
+            stK[im].commit(sK + im * IMG_BYTES, tid);
+            stV[im].commit(sV + im * IMG_BYTES, tid);
+        }
+    };
+
+    const int ntiles = (kv.len + 63) >> 6;
+    if (ntiles > 0) { issue(0); commit(); }
+    __syncthreads();
+
+    for (int t = 0; t < ntiles; ++t) {
+        const int kv0 = t << 6;
+        const bool has_next = t + 1 < ntiles;
+        if (has_next) issue(kv0 + 64);
+
+        // ---- S^T = K . Q^T : sacc[rt][kt][r] = S[q = fr][key = kv0 + kt*16 + 4g + r]
+        f32x4_t sacc[RT][4];
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+            for (int kt = 0; kt < 4; ++kt) sacc[rt][kt] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+            for (int dg = 0; dg < NDG; ++dg) {
+                typename Mma<T>::frag_t kf = read_frag_mi<T>(sK, kt * 16 + fr, dg * 4 + g);
+#pragma unroll
+                for (int rt = 0; rt < RT; ++rt) sacc[rt][kt] = Mma<T>::mma(kf, qf[rt][dg], sacc[rt][kt]);
+            }
+
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) {
+            const int qr = q0 + rt * 16 + fr;
+            const float* mrowp = (p.mask && qr < p.Sq) ? p.mask + (int64_t)b * p.mask_bs + (int64_t)qr * p.mask_rs : nullptr;
+            float mx = -INFINITY;
+#pragma unroll
+            for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int key = kv0 + kt * 16 + 4 * g + r;
+                    float s = sacc[rt][kt][r] * p.scale;
+                    if (key < kv.len) { if (mrowp) s += mrowp[key]; }
+                    else s = -INFINITY;
+                    sacc[rt][kt][r] = s;
+                    mx = fmaxf(mx, s);
+                }
+            mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+            const float mnew = fmaxf(mrow[rt], mx);
+            const float alpha = fexp<T>(mrow[rt] - mnew);
+            mrow[rt] = mnew;
+            float ps = 0.f;
+#pragma unroll
+            for (int kt = 0; kt < 4; ++kt) {
+                f32x4_t pv;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { pv[r] = fexp<T>(sacc[rt][kt][r] - mnew); ps += pv[r]; }
+                if (thr) {
+                    const int key4 = (kv0 + kt * 16 + 4 * g) >> 2;
+                    const uint64_t ctr = p.offset + ((uint64_t)((int64_t)(b * p.H + h) * p.Sq + qr)) * kq4 + key4;
+                    Philox4 rnd = philox4x32_10(p.seed, ctr);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) pv[r] = rnd.v[r] >= thr ? pv[r] * keep_scale : 0.f;
+                }
+                sacc[rt][kt] = pv;
+            }
+            lrow[rt] = lrow[rt] * alpha + ps;
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) oacc[rt][dt] *= alpha;
+            // ---- O^T += V^T . P^T  (contraction over this tile's 64 keys)
+            nat_mma_64<T>(sV, sacc[rt], oacc[rt], lane);
+        }
+
+        __syncthreads();
+        if (has_next) { commit(); __syncthreads(); }
+    }
+
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) {
+        const int qr = q0 + rt * 16 + fr;
+        float l = lrow[rt];
+        l += __shfl_xor(l, 16, 64);
+        l += __shfl_xor(l, 32, 64);
+        const float inv = l > 0.f ? 1.0f / l : 0.f;
+        if (qr < p.Sq) {
+            T* O = (T*)p.o + (int64_t)b * p.o_bs + (int64_t)qr * p.o_rs + h * ATT_D;
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) store4<T>(O + dt * 16 + 4 * g, oacc[rt][dt] * inv);
+            if (g == 0 && p.lse) p.lse[((int64_t)b * p.H + h) * p.Sq + qr] = mrow[rt] + logf(l);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// backward, dQ.  grid = (ceil(Sq/64), H, B); wave w owns 16 query rows. Also writes
+// delta[b,h,q] = sum_d dO*O for the dK/dV kernel.
+// ------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnArgs p) {
+    constexpr int VEC = ElemTraits<T>::VEC;
+    constexpr int NIMG = 64 * (int)sizeof(T) / TILE_ROW_BYTES;
+    constexpr int NDG = ATT_D / (4 * VEC);
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* sK = smem;                          // [key][d]
+    char* sV = smem + NIMG * IMG_BYTES;       // [key][d]
+    char* sKT = smem + 2 * NIMG * IMG_BYTES;  // [d][key]
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int fr = lane & 15, g = lane >> 4;
+    const int b = blockIdx.z, h = blockIdx.y;
+    const int qr = blockIdx.x * 64 + wave * 16 + fr;
+    const bool qok = qr < p.Sq;
+    const KvSel kv = kv_select(p, b);
+
+    const T* Q = (const T*)p.q + (int64_t)b * p.q_bs + (int64_t)qr * p.q_rs + h * ATT_D;
+    const T* DO = (const T*)p.dout + (int64_t)b * p.do_bs + (int64_t)qr * p.do_rs + h * ATT_D;
+    const T* O = (const T*)p.o + (int64_t)b * p.o_bs + (int64_t)qr * p.o_rs + h * ATT_D;
+    const T* Kp = (const T*)p.k + (int64_t)kv.kb * p.k_bs + (int64_t)kv.start * p.k_rs + h * ATT_D;
+    const T* Vp = (const T*)p.v + (int64_t)kv.kb * p.v_bs + (int64_t)kv.start * p.v_rs + h * ATT_D;
+
+    typename Mma<T>::frag_t qf[NDG], dof[NDG];
+    float dsum = 0.f;
+#pragma unroll
+    for (int dg = 0; dg < NDG; ++dg) {
+        u32x4_t zq = {0u, 0u, 0u, 0u}, zd = zq, zo = zq;
+        if (qok) {
+            const int off = dg * 4 * VEC + g * VEC;
+            zq = *(const u32x4_t*)(Q + off);
+            zd = *(const u32x4_t*)(DO + off);
+            zo = *(const u32x4_t*)(O + off);
+        }
+        qf[dg] = __builtin_bit_cast(typename Mma<T>::frag_t, zq);
+        dof[dg] = __builtin_bit_cast(typename Mma<T>::frag_t, zd);
+        typename Mma<T>::frag_t of = __builtin_bit_cast(typename Mma<T>::frag_t, zo);
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) dsum += (float)dof[dg][e] * (float)of[e];
+    }
+    dsum += __shfl_xor(dsum, 16, 64);
+    dsum += __shfl_xor(dsum, 32, 64);
+    const int64_t statidx = ((int64_t)b * p.H + h) * p.Sq + qr;
+    if (qok && g == 0) p.delta[statidx] = dsum;
+    const float lse = qok ? p.lse[statidx] : 0.f;
+
+    f32x4_t dqacc[4];
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) dqacc[dt] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+
+    const uint32_t thr = drop_threshold(p.p_drop);
+    const float keep_scale = p.p_drop > 0.f ? 1.0f / (1.0f - p.p_drop) : 1.0f;
+    const int kq4 = (p.Skv + 3) >> 2;
+    const float* mrowp = (p.mask && qok) ? p.mask + (int64_t)b * p.mask_bs + (int64_t)qr * p.mask_rs : nullptr;
+
+    DirectStage<T, 64, 256> stK[NIMG], stV[NIMG];
+    TransStage<T, 64, 256> stKT[NIMG];
+    auto issue = [&](int kv0) {
+#pragma unroll
+        for (int im = 0; im < NIMG; ++im) {
+            stK[im].issue(Kp, p.k_rs, kv0, kv.len, im * 8 * VEC, ATT_D, tid);
+            stV[im].issue(Vp, p.v_rs, kv0, kv.len, im * 8 * VEC, ATT_D, tid);
+            stKT[im].issue(Kp, p.k_rs, 0, ATT_D, kv0 + im * 8 * VEC, kv.len, tid);
+        }
+    };
+    auto commit = [&]() {
+#pragma unroll
+        for (int im = 0; im < NIMG; ++im) {
+            stK[im].commit(sK + im * IMG_BYTES, tid);
+            stV[im].commit(sV + im * IMG_BYTES, tid);
+            stKT[im].commit(sKT + im * IMG_BYTES, tid);
+        }
+    };
+
+    const int ntiles = (kv.len + 63) >> 6;
+    if (ntiles > 0) { issue(0); commit(); }
+    __syncthreads();
+
+    for (int t = 0; t < ntiles; ++t) {
+        const int kv0 = t << 6;
+        const bool has_next = t + 1 < ntiles;
+        if (has_next) issue(kv0 + 64);
+
+        f32x4_t sacc[4], pacc[4];
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt) { sacc[kt] = (f32x4_t){0.f, 0.f, 0.f, 0.f}; pacc[kt] = sacc[kt]; }
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+            for (int dg = 0; dg < NDG; ++dg) {
+                typename Mma<T>::frag_t kf = read_frag_mi<T>(sK, kt * 16 + fr, dg * 4 + g);
+                typename Mma<T>::frag_t vf = read_frag_mi<T>(sV, kt * 16 + fr, dg * 4 + g);
+                sacc[kt] = Mma<T>::mma(kf, qf[dg], sacc[kt]);
+                pacc[kt] = Mma<T>::mma(vf, dof[dg], pacc[kt]);
+            }
+        f32x4_t ds[4];
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt) {
+            Philox4 rnd;
+            if (thr) {
+                const int key4 = (kv0 + kt * 16 + 4 * g) >> 2;
+                rnd = philox4x32_10(p.seed, p.offset + ((uint64_t)statidx) * kq4 + key4);
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int key = kv0 + kt * 16 + 4 * g + r;
+                float s = sacc[kt][r] * p.scale;
+                if (mrowp && key < kv.len) s += mrowp[key];
+                const float pr = (key < kv.len && qok) ? fexp<T>(s - lse) : 0.f;
+                float dp = pacc[kt][r];
+                if (thr) dp = rnd.v[r] >= thr ? dp * keep_scale : 0.f;
+                ds[kt][r] = pr * (dp - dsum);
+            }
+        }
+        nat_mma_64<T>(sKT, ds, dqacc, lane);
+
+        __syncthreads();
+        if (has_next) { commit(); __syncthreads(); }
+    }
+    if (qok) {
+        T* DQ = (T*)p.dq + (int64_t)b * p.dq_bs + (int64_t)qr * p.dq_rs + h * ATT_D;
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) store4<T>(DQ + dt * 16 + 4 * g, dqacc[dt] * p.scale);
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// backward, dK / dV.  grid = (ceil(kv_rows/64), H, B_kv); wave w owns 16 keys (absolute rows of
+// the K/V buffer). Loops over every query batch that maps onto this K/V batch (kv_bmod) and over
+// its query tiles; scores are produced as S[q = 4g+r][key = l&15] so the softmax terms feed the
+// dV / dK MFMAs from registers (contraction over queries).
+// ------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnArgs p) {
+    constexpr int VEC = ElemTraits<T>::VEC;
+    constexpr int NIMG = 64 * (int)sizeof(T) / TILE_ROW_BYTES;
+    constexpr int NDG = ATT_D / (4 * VEC);
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* sQ = smem;                            // [q][d]
+    char* sDO = smem + NIMG * IMG_BYTES;        // [q][d]
+    char* sQT = smem + 2 * NIMG * IMG_BYTES;    // [d][q]
+    char* sDOT = smem + 3 * NIMG * IMG_BYTES;   // [d][q]
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int fr = lane & 15, g = lane >> 4;
+    const int kb = blockIdx.z, h = blockIdx.y;
+    const int key_abs = blockIdx.x * 64 + wave * 16 + fr;   // row of the K/V buffer owned by this lane
+    const int kv_rows = p.Skv;                              // rows per batch of the K/V buffer
+    const bool kok = key_abs < kv_rows;
+
+    const T* Kp = (const T*)p.k + (int64_t)kb * p.k_bs + (int64_t)key_abs * p.k_rs + h * ATT_D;
+    const T* Vp = (const T*)p.v + (int64_t)kb * p.v_bs + (int64_t)key_abs * p.v_rs + h * ATT_D;
+    typename Mma<T>::frag_t kf[NDG], vf[NDG];
+#pragma unroll
+    for (int dg = 0; dg < NDG; ++dg) {
+        u32x4_t zk = {0u, 0u, 0u, 0u}, zv = zk;
+        if (kok) {
+            zk = *(const u32x4_t*)(Kp + dg * 4 * VEC + g * VEC);
+            zv = *(const u32x4_t*)(Vp + dg * 4 * VEC + g * VEC);
+        }
+        kf[dg] = __builtin_bit_cast(typename Mma<T>::frag_t, zk);
+        vf[dg] = __builtin_bit_cast(typename Mma<T>::frag_t, zv);
+    }
+
+    f32x4_t dkacc[4], dvacc[4];
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) { dkacc[dt] = (f32x4_t){0.f, 0.f, 0.f, 0.f}; dvacc[dt] = dkacc[dt]; }
+
+    const uint32_t thr = drop_threshold(p.p_drop);
+    const float keep_scale = p.p_drop > 0.f ? 1.0f / (1.0f - p.p_drop) : 1.0f;
+    const int kq4 = (p.Skv + 3) >> 2;
+    const int bstep = p.kv_bmod > 0 ? p.kv_bmod : p.B;
+    const int tile_lo = blockIdx.x * 64, tile_hi = tile_lo + 64;
+
+    DirectStage<T, 64, 256> stQ[NIMG], stDO[NIMG];
+    TransStage<T, 64, 256> stQT[NIMG], stDOT[NIMG];
+
+    for (int b = kb; b < p.B; b += bstep) {
+        int start = 0, len = p.Skv;
+        if (p.kv_range) { start = p.kv_range[2 * b]; len = p.kv_range[2 * b + 1]; }
+        if (start >= tile_hi || start + len <= tile_lo) continue;     // block-uniform
+        const int key_loc = key_abs - start;
+        const bool key_in = kok && key_loc >= 0 && key_loc < len;
+        const T* Qb = (const T*)p.q + (int64_t)b * p.q_bs + h * ATT_D;
+        const T* DOb = (const T*)p.dout + (int64_t)b * p.do_bs + h * ATT_D;
+        const int64_t statbase = ((int64_t)b * p.H + h) * p.Sq;
+
+        const int nqt = (p.Sq + 63) >> 6;
+        for (int qt64 = 0; qt64 < nqt; ++qt64) {
+            const int qb0 = qt64 << 6;
+            __syncthreads();   // previous tile's LDS reads done
+#pragma unroll
+            for (int im = 0; im < NIMG; ++im) {
+                stQ[im].issue(Qb, p.q_rs, qb0, p.Sq, im * 8 * VEC, ATT_D, tid);
+                stDO[im].issue(DOb, p.do_rs, qb0, p.Sq, im * 8 * VEC, ATT_D, tid);
+                stQT[im].issue(Qb, p.q_rs, 0, ATT_D, qb0 + im * 8 * VEC, p.Sq, tid);
+                stDOT[im].issue(DOb, p.do_rs, 0, ATT_D, qb0 + im * 8 * VEC, p.Sq, tid);
+            }
+#pragma unroll
+            for (int im = 0; im < NIMG; ++im) {
+                stQ[im].commit(sQ + im * IMG_BYTES, tid);
+                stDO[im].commit(sDO + im * IMG_BYTES, tid);
+                stQT[im].commit(sQT + im * IMG_BYTES, tid);
+                stDOT[im].commit(sDOT + im * IMG_BYTES, tid);
+            }
+            __syncthreads();
+
+            f32x4_t pd[4], ds[4];   // [q-subtile of 16][r] : q = qb0 + qs*16 + 4g + r, key = this lane's
+#pragma unroll
+            for (int qs = 0; qs < 4; ++qs) {
+                f32x4_t sacc = {0.f, 0.f, 0.f, 0.f}, pacc = sacc;
+#pragma unroll
+                for (int dg = 0; dg < NDG; ++dg) {
+                    typename Mma<T>::frag_t qfr = read_frag_mi<T>(sQ, qs * 16 + fr, dg * 4 + g);
+                    typename Mma<T>::frag_t dfr = read_frag_mi<T>(sDO, qs * 16 + fr, dg * 4 + g);
+                    sacc = Mma<T>::mma(qfr, kf[dg], sacc);
+                    pacc = Mma<T>::mma(dfr, vf[dg], pacc);
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int qr = qb0 + qs * 16 + 4 * g + r;
+                    float pr = 0.f, dsv = 0.f, pdv = 0.f;
+                    if (qr < p.Sq && key_in) {
+                        float s = sacc[r] * p.scale;
+                        if (p.mask) s += p.mask[(int64_t)b * p.mask_bs + (int64_t)qr * p.mask_rs + key_loc];
+                        pr = fexp<T>(s - p.lse[statbase + qr]);
+                        float dp = pacc[r];
+                        pdv = pr;
+                        if (thr) {
+                            Philox4 rnd = philox4x32_10(p.seed, p.offset + ((uint64_t)(statbase + qr)) * kq4 + (key_loc >> 2));
+                            const int comp = key_loc & 3;   // select, not index: a runtime index sends the struct to scratch
+                            const uint32_t rv = comp == 0 ? rnd.v[0] : comp == 1 ? rnd.v[1] : comp == 2 ? rnd.v[2] : rnd.v[3];
+                            const bool keep = rv >= thr;
+                            dp = keep ? dp * keep_scale : 0.f;
+                            pdv = keep ? pr * keep_scale : 0.f;
+                        }
+                        dsv = pr * (dp - p.delta[statbase + qr]);
+                    }
+                    pd[qs][r] = pdv; ds[qs][r] = dsv;
+                }
+            }
+            nat_mma_64<T>(sDOT, pd, dvacc, lane);   // dV^T[d][key] += dO^T[d][q] * Pdrop[q][key]
+            nat_mma_64<T>(sQT, ds, dkacc, lane);    // dK^T[d][key] += Q^T[d][q]  * dS[q][key]
+        }
+    }
+    if (kok) {
+        T* DK = (T*)p.dk + (int64_t)kb * p.dk_bs + (int64_t)key_abs * p.dk_rs + h * ATT_D;
+        T* DV = (T*)p.dv + (int64_t)kb * p.dv_bs + (int64_t)key_abs * p.dv_rs + h * ATT_D;
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) {
+            store4<T>(DK + dt * 16 + 4 * g, dkacc[dt] * p.scale);
+            store4<T>(DV + dt * 16 + 4 * g, dvacc[dt]);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+template <typename T>
+static int attn_fwd_launch(hipStream_t st, const AttnArgs& p) {
+    constexpr int NIMG = 64 * (int)sizeof(T) / TILE_ROW_BYTES;
+    const size_t lds = 2 * NIMG * IMG_BYTES;
+    if (p.Sq > 64) {
+        dim3 grid((p.Sq + 127) / 128, p.H, p.B);
+        hipLaunchKernelGGL((attn_fwd_kernel<T, 2>), grid, dim3(256), lds, st, p);
+    } else {
+        dim3 grid((p.Sq + 63) / 64, p.H, p.B);
+        hipLaunchKernelGGL((attn_fwd_kernel<T, 1>), grid, dim3(256), lds, st, p);
+    }
+    return valor_launch_status();
+}
+template <typename T>
+static int attn_bwd_launch(hipStream_t st, const AttnArgs& p) {
+    constexpr int NIMG = 64 * (int)sizeof(T) / TILE_ROW_BYTES;
+    {
+        const size_t lds = 3 * NIMG * IMG_BYTES;
+        dim3 grid((p.Sq + 63) / 64, p.H, p.B);
+        hipLaunchKernelGGL((attn_bwd_dq_kernel<T>), grid, dim3(256), lds, st, p);
+    }
+    {
+        const size_t lds = 4 * NIMG * IMG_BYTES;
+        static bool attr_set = false;
+        if (!attr_set) {
+            hipFuncSetAttribute((const void*)attn_bwd_dkv_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            attr_set = true;
+        }
+        const int bkv = p.kv_bmod > 0 ? p.kv_bmod : p.B;
+        dim3 grid((p.Skv + 63) / 64, p.H, bkv);
+        hipLaunchKernelGGL((attn_bwd_dkv_kernel<T>), grid, dim3(256), lds, st, p);
+    }
+    return valor_launch_status();
+}
+
+static int attn_check(const AttnArgs& p, int dtype) {
+    const int vec = dtype == VALOR_DT_BF16 ? 8 : 4;
+    if (p.B <= 0 || p.H <= 0 || p.Sq <= 0 || p.Skv <= 0) return VALOR_ERR_ARG;
+    if ((p.q_rs % vec) || (p.k_rs % vec) || (p.v_rs % vec) || (p.q_bs % vec) || (p.k_bs % vec) || (p.v_bs % vec)) return VALOR_ERR_ARG;
+    if (((uintptr_t)p.q & 15) || ((uintptr_t)p.k & 15) || ((uintptr_t)p.v & 15)) return VALOR_ERR_ARG;
+    if ((p.o_rs & 3) || (p.o_bs & 3)) return VALOR_ERR_ARG;
+    if (p.p_drop < 0.f || p.p_drop >= 1.f) return VALOR_ERR_ARG;
+    return VALOR_OK;
+}
+
+// head_dim is fixed at 64 (BERT-base 768/12, CLIP ViT-B 768/12, CLIP text 512/8, AST 768/12).
+// Skv = rows per batch of the K/V buffers (and the RNG pitch); kv_range (int32 [B][2], device)
+// optionally restricts batch b to rows [start, start+len) and kv_bmod > 0 maps query batch b onto
+// K/V batch b % kv_bmod.  mask: additive fp32 [.., Sq, >=len], indexed by the LOCAL key index.
+extern "C" int valor_attn_fwd(void* stream, int dtype, const void* q, const void* k, const void* v, void* o, float* lse,
+                              int B, int H, int Sq, int Skv, int64_t q_bs, int64_t q_rs, int64_t k_bs, int64_t k_rs,
+                              int64_t v_bs, int64_t v_rs, int64_t o_bs, int64_t o_rs, const float* mask, int64_t mask_bs,
+                              int64_t mask_rs, const int* kv_range, int kv_bmod, float scale, float p_drop,
+                              uint64_t seed, uint64_t offset) {
+    AttnArgs p = {};
+    p.q = q; p.k = k; p.v = v; p.o = o; p.lse = lse; p.mask = mask; p.kv_range = kv_range;
+    p.B = B; p.H = H; p.Sq = Sq; p.Skv = Skv;
+    p.q_bs = q_bs; p.q_rs = q_rs; p.k_bs = k_bs; p.k_rs = k_rs; p.v_bs = v_bs; p.v_rs = v_rs; p.o_bs = o_bs; p.o_rs = o_rs;
+    p.mask_bs = mask_bs; p.mask_rs = mask_rs; p.kv_bmod = kv_bmod; p.scale = scale; p.p_drop = p_drop;
+    p.seed = seed; p.offset = offset;
+    int rc = attn_check(p, dtype);
+    if (rc) return rc;
+    if (!q || !k || !v || !o) return VALOR_ERR_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == VALOR_DT_BF16) return attn_fwd_launch<bf16_t>(st, p);
+    if (dtype == VALOR_DT_F32) return attn_fwd_launch<float>(st, p);
+    return VALOR_ERR_ARG;
+}
+
+// dq/dk/dv use the same (bs, rs) conventions; dk/dv are fully overwritten (rows no query batch
+// attends to receive zeros). delta: fp32 scratch [B*H*Sq].
+extern "C" int valor_attn_bwd(void* stream, int dtype, const void* q, const void* k, const void* v, const void* o,
+                              const float* lse, const void* dout, void* dq, void* dk, void* dv, float* delta,
+                              int B, int H, int Sq, int Skv, int64_t q_bs, int64_t q_rs, int64_t k_bs, int64_t k_rs,
+                              int64_t v_bs, int64_t v_rs, int64_t o_bs, int64_t o_rs, int64_t do_bs, int64_t do_rs,
+                              int64_t dq_bs, int64_t dq_rs, int64_t dk_bs, int64_t dk_rs, int64_t dv_bs, int64_t dv_rs,
+                              const float* mask, int64_t mask_bs, int64_t mask_rs, const int* kv_range, int kv_bmod,
+                              float scale, float p_drop, uint64_t seed, uint64_t offset) {
+    AttnArgs p = {};
+    p.q = q; p.k = k; p.v = v; p.o = (void*)o; p.lse = (float*)lse; p.dout = dout; p.dq = dq; p.dk = dk; p.dv = dv;
+    p.delta = delta; p.mask = mask; p.kv_range = kv_range;
+    p.B = B; p.H = H; p.Sq = Sq; p.Skv = Skv;
+    p.q_bs = q_bs; p.q_rs = q_rs; p.k_bs = k_bs; p.k_rs = k_rs; p.v_bs = v_bs; p.v_rs = v_rs; p.o_bs = o_bs; p.o_rs = o_rs;
+    p.do_bs = do_bs; p.do_rs = do_rs; p.dq_bs = dq_bs; p.dq_rs = dq_rs; p.dk_bs = dk_bs; p.dk_rs = dk_rs;
+    p.dv_bs = dv_bs; p.dv_rs = dv_rs;
+    p.mask_bs = mask_bs; p.mask_rs = mask_rs; p.kv_bmod = kv_bmod; p.scale = scale; p.p_drop = p_drop;
+    p.seed = seed; p.offset = offset;
+    int rc = attn_check(p, dtype);
+    if (rc) return rc;
+    const int vec = dtype == VALOR_DT_BF16 ? 8 : 4;
+    if (!q || !k || !v || !o || !lse || !dout || !dq || !dk || !dv || !delta) return VALOR_ERR_ARG;
+    if ((do_rs % vec) || (do_bs % vec) || ((uintptr_t)dout & 15) || (o_rs % vec) || (o_bs % vec) || ((uintptr_t)o & 15)) return VALOR_ERR_ARG;
+    if ((dq_rs & 3) || (dk_rs & 3) || (dv_rs & 3) || (dq_bs & 3) || (dk_bs & 3) || (dv_bs & 3)) return VALOR_ERR_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == VALOR_DT_BF16) return attn_bwd_launch<bf16_t>(st, p);
+    if (dtype == VALOR_DT_F32) return attn_bwd_launch<float>(st, p);
+    return VALOR_ERR_ARG;
+}

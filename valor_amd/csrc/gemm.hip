@@ -197,27 +197,36 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs p) {
         buf ^= 1;
     }
 
-    // epilogue: acc[ni][mi][r] = C[m = m0 + wm*64 + mi*16 + (lane&15)][n = n0 + wn*64 + ni*16 + 4*(lane>>4) + r]
-    if (p.kslices > 1) {
-        float* ws = p.ws + (int64_t)blockIdx.y * p.M * p.N;
+    // ---- epilogue: accumulators -> LDS (fp32, XOR-swizzled 16-B chunks) -> row-contiguous stores.
+    // acc[ni][mi][r] = C[m = wm*64 + mi*16 + (lane&15)][n = wn*64 + ni*16 + 4*(lane>>4) + r].
+    // Static register indices only (a runtime-indexed accumulator array would be demoted to
+    // scratch); the store loop below is a plain runtime loop over LDS rows, 32 lanes per
+    // 128-column row = 256 B (bf16) / 512 B (fp32) contiguous per row.
+    float* sC = (float*)smem;   // 128 x 128 fp32 = 64 KiB; the operand tiles are dead after the last barrier
 #pragma unroll
-        for (int ni = 0; ni < 4; ++ni)
+    for (int ni = 0; ni < 4; ++ni)
 #pragma unroll
-            for (int mi = 0; mi < 4; ++mi) {
-                const int m = m0 + wm * 64 + mi * 16 + fr;
-                const int n = n0 + wn * 64 + ni * 16 + fg * 4;
-                if (m < p.M) {
-                    float* q = ws + (int64_t)m * p.N + n;
-                    if (n + 3 < p.N && (p.N & 3) == 0) *(f32x4_t*)q = acc[ni][mi];
-                    else for (int r = 0; r < 4; ++r) if (n + r < p.N) q[r] = acc[ni][mi][r];
-                }
+        for (int mi = 0; mi < 4; ++mi) {
+            const int ml = wm * 64 + mi * 16 + fr;
+            const int ch = (wn * 16 + ni * 4 + fg) ^ (ml & 7);
+            *(f32x4_t*)(sC + ml * 128 + ch * 4) = acc[ni][mi];
+        }
+    __syncthreads();
+    float* wsl = p.kslices > 1 ? p.ws + (int64_t)blockIdx.y * p.M * p.N : nullptr;
+    for (int it = 0; it < 16; ++it) {
+        const int ml = it * 8 + (tid >> 5);
+        const int cl = tid & 31;
+        const f32x4_t v = *(const f32x4_t*)(sC + ml * 128 + ((cl ^ (ml & 7)) << 2));
+        const int m = m0 + ml, n = n0 + cl * 4;
+        if (wsl) {
+            if (m < p.M) {
+                float* q = wsl + (int64_t)m * p.N + n;
+                if (n + 3 < p.N && (p.N & 3) == 0) *(f32x4_t*)q = v;
+                else for (int r = 0; r < 4; ++r) if (n + r < p.N) q[r] = v[r];
             }
-    } else {
-#pragma unroll
-        for (int ni = 0; ni < 4; ++ni)
-#pragma unroll
-            for (int mi = 0; mi < 4; ++mi)
-                epilogue_store<T>(p, m0 + wm * 64 + mi * 16 + fr, n0 + wn * 64 + ni * 16 + fg * 4, acc[ni][mi]);
+        } else {
+            epilogue_store<T>(p, m, n, v);
+        }
     }
 }
 

@@ -55,32 +55,21 @@ struct DirectStage {
     static constexpr int VEC = ElemTraits<T>::VEC;
     static constexpr int N = (ROWS * 8 + NT - 1) / NT;
     u32x4_t v[N];
+    int nvalid[N];   // elements of the chunk that are in range (0 .. VEC); applied at commit()
 
+    // Loads are UNCONDITIONAL (out-of-range chunks read a clamped, valid address) so the
+    // compiler keeps all N loads in flight; range masking happens in commit().
     DEVINL void issue(const T* __restrict__ base, int64_t ld, int row0, int R, int k0, int K, int tid) {
 #pragma unroll
         for (int j = 0; j < N; ++j) {
             int idx = tid + j * NT;
             int c = idx & 7, r = idx >> 3;
             int gr = row0 + r, gk = k0 + c * VEC;
-            u32x4_t val = {0u, 0u, 0u, 0u};
-            if ((ROWS * 8 % NT == 0 || r < ROWS) && gr < R && gk < K) {
-                val = *(const u32x4_t*)(base + (int64_t)gr * ld + gk);
-                if (gk + VEC > K) {  // tail chunk: zero the elements >= K
-                    int valid = K - gk;
-                    if (VEC == 8) {
-#pragma unroll
-                        for (int d = 0; d < 4; ++d) {
-                            if (2 * d >= valid) val[d] = 0u;
-                            else if (2 * d + 1 >= valid) val[d] &= 0xffffu;
-                        }
-                    } else {
-#pragma unroll
-                        for (int d = 0; d < 4; ++d)
-                            if (d >= valid) val[d] = 0u;
-                    }
-                }
-            }
-            v[j] = val;
+            bool ok = (ROWS * 8 % NT == 0 || r < ROWS) && gr < R && gk < K;
+            int nv = K - gk;
+            nvalid[j] = ok ? (nv > VEC ? VEC : nv) : 0;
+            const T* ptr = base + (ok ? (int64_t)gr * ld + gk : (int64_t)0);
+            v[j] = *(const u32x4_t*)ptr;
         }
     }
     DEVINL void commit(char* tile, int tid) {
@@ -88,7 +77,22 @@ struct DirectStage {
         for (int j = 0; j < N; ++j) {
             int idx = tid + j * NT;
             int c = idx & 7, r = idx >> 3;
-            if (ROWS * 8 % NT == 0 || r < ROWS) *(u32x4_t*)(tile + tile_off(r, c)) = v[j];
+            u32x4_t val = v[j];
+            const int valid = nvalid[j];
+            if (valid < VEC) {   // rare: out of range or K tail
+                if (VEC == 8) {
+#pragma unroll
+                    for (int d = 0; d < 4; ++d) {
+                        if (2 * d >= valid) val[d] = 0u;
+                        else if (2 * d + 1 >= valid) val[d] &= 0xffffu;
+                    }
+                } else {
+#pragma unroll
+                    for (int d = 0; d < 4; ++d)
+                        if (d >= valid) val[d] = 0u;
+                }
+            }
+            if (ROWS * 8 % NT == 0 || r < ROWS) *(u32x4_t*)(tile + tile_off(r, c)) = val;
         }
     }
 };
@@ -133,6 +137,7 @@ struct TransStage {
     static constexpr int NTASK = 8 * (ROWS / VEC);
     static constexpr int N = (NTASK + NT - 1) / NT;
     u32x4_t v[N][VEC];
+    int kvalid[N];   // number of valid k-rows of the task (0 .. VEC); applied at commit()
 
     DEVINL void issue(const T* __restrict__ base, int64_t ld, int row0, int R, int k0, int K, int tid) {
 #pragma unroll
@@ -141,12 +146,14 @@ struct TransStage {
             int kg = t & 7, rc = t >> 3;
             int gr = row0 + rc * VEC;
             bool rok = (NTASK % NT == 0 || t < NTASK) && gr < R;
+            int kv = K - (k0 + kg * VEC);
+            kv = kv > VEC ? VEC : (kv < 0 ? 0 : kv);
+            kvalid[j] = rok ? kv : 0;
 #pragma unroll
             for (int i = 0; i < VEC; ++i) {
                 int gk = k0 + kg * VEC + i;
-                u32x4_t val = {0u, 0u, 0u, 0u};
-                if (rok && gk < K) val = *(const u32x4_t*)(base + (int64_t)gk * ld + gr);
-                v[j][i] = val;
+                const T* ptr = base + ((rok && i < kv) ? (int64_t)gk * ld + gr : (int64_t)0);
+                v[j][i] = *(const u32x4_t*)ptr;
             }
         }
     }
@@ -156,6 +163,12 @@ struct TransStage {
             int t = tid + j * NT;
             int kg = t & 7, rc = t >> 3;
             if (NTASK % NT == 0 || t < NTASK) {
+                const int kv = kvalid[j];
+                if (kv < VEC) {
+#pragma unroll
+                    for (int i = 0; i < VEC; ++i)
+                        if (i >= kv) v[j][i] = (u32x4_t){0u, 0u, 0u, 0u};
+                }
                 u32x4_t o[VEC];
                 Transposer<VEC>::run(v[j], o);
 #pragma unroll

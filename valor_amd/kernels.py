@@ -140,3 +140,59 @@ def colsum(x, out=None, accumulate=False):
     assert ws.numel() >= part_blocks() * cols
     lib.call("valor_colsum", _stream(), dt_of(x), _ptr(x), rows, cols, ld, _ptr(ws), _ptr(out), 0, int(accumulate))
     return out
+
+
+def _bsr(t):
+    """(batch stride, row stride) of a [B, S, E] view with unit inner stride."""
+    assert t.dim() == 3 and t.stride(2) == 1
+    return t.stride(0), t.stride(1)
+
+
+def attn_fwd(q, k, v, n_heads, *, mask=None, kv_range=None, kv_bmod=0, scale=None, p_drop=0.0, seed=0, offset=0):
+    """q: [B,Sq,H*64] view, k/v: [Bkv,Skv,H*64] views (unit inner stride). Returns (o [B,Sq,H*64], lse [B,H,Sq])."""
+    _check_gpu(q, k, v, mask, kv_range)
+    B, Sq, E = q.shape
+    Skv = k.shape[1]
+    assert E == n_heads * 64, "head_dim is fixed at 64"
+    if scale is None:
+        scale = 0.125
+    o = torch.empty((B, Sq, E), dtype=q.dtype, device=q.device)
+    lse = torch.empty((B, n_heads, Sq), dtype=torch.float32, device=q.device)
+    qb, qr = _bsr(q); kb, kr = _bsr(k); vb, vr = _bsr(v); ob, orr = _bsr(o)
+    mb = mr = 0
+    if mask is not None:
+        assert mask.dtype == torch.float32 and mask.dim() == 3 and mask.stride(2) == 1
+        mb, mr = (mask.stride(0) if mask.shape[0] > 1 else 0), mask.stride(1)
+    if kv_range is not None:
+        assert kv_range.dtype == torch.int32 and kv_range.shape == (B, 2) and kv_range.is_contiguous()
+    lib.call("valor_attn_fwd", _stream(), dt_of(q), _ptr(q), _ptr(k), _ptr(v), _ptr(o), _ptr(lse), B, n_heads, Sq, Skv,
+             qb, qr, kb, kr, vb, vr, ob, orr, _ptr(mask), mb, mr, _ptr(kv_range), int(kv_bmod), float(scale),
+             float(p_drop), int(seed), int(offset))
+    return o, lse
+
+
+def attn_bwd(q, k, v, o, lse, dout, n_heads, *, dq=None, dk=None, dv=None, mask=None, kv_range=None, kv_bmod=0,
+             scale=None, p_drop=0.0, seed=0, offset=0):
+    """Returns (dq, dk, dv) shaped like q, k, v (or writes into the given [B,S,H*64] views)."""
+    _check_gpu(q, k, v, o, dout, mask, kv_range)
+    B, Sq, E = q.shape
+    Skv = k.shape[1]
+    if scale is None:
+        scale = 0.125
+    if dq is None:
+        dq = torch.empty((B, Sq, E), dtype=q.dtype, device=q.device)
+    if dk is None:
+        dk = torch.empty((k.shape[0], Skv, E), dtype=q.dtype, device=q.device)
+    if dv is None:
+        dv = torch.empty((v.shape[0], Skv, E), dtype=q.dtype, device=q.device)
+    delta = torch.empty((B, n_heads, Sq), dtype=torch.float32, device=q.device)
+    qb, qr = _bsr(q); kb, kr = _bsr(k); vb, vr = _bsr(v); ob, orr = _bsr(o); gb, gr = _bsr(dout)
+    dqb, dqr = _bsr(dq); dkb, dkr = _bsr(dk); dvb, dvr = _bsr(dv)
+    mb = mr = 0
+    if mask is not None:
+        mb, mr = (mask.stride(0) if mask.shape[0] > 1 else 0), mask.stride(1)
+    lib.call("valor_attn_bwd", _stream(), dt_of(q), _ptr(q), _ptr(k), _ptr(v), _ptr(o), _ptr(lse), _ptr(dout), _ptr(dq),
+             _ptr(dk), _ptr(dv), _ptr(delta), B, n_heads, Sq, Skv, qb, qr, kb, kr, vb, vr, ob, orr, gb, gr,
+             dqb, dqr, dkb, dkr, dvb, dvr, _ptr(mask), mb, mr, _ptr(kv_range), int(kv_bmod), float(scale),
+             float(p_drop), int(seed), int(offset))
+    return dq, dk, dv
