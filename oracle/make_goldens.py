@@ -1,0 +1,83 @@
+"""TEST INFRASTRUCTURE: generate tests/golden/*.pt by running the UNMODIFIED reference (/root/reference)
+on CPU fp32 with seeded synthetic weights/inputs (valor_amd/synth.py), dropout 0. Run in the build
+container only:  python oracle/make_goldens.py
+Each fixture holds inputs' recipe (spec, seeds, shapes), the masked token tensors the reference's
+TokenMasker produced, losses, score matrices, argmax ids, activation slices, per-parameter gradient
+norms + a few gradient slices, and the parameters after 2 reference optimizer steps
+(optim/misc.py build_optimizer + optim/adamw.py AdamW + clip_grad_norm_ 5.0 + warmup_linear)."""
+import os
+import random
+import sys
+
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+sys.path.insert(0, HERE)
+sys.path.insert(0, ROOT)
+
+import ref_harness  # noqa: E402
+from valor_amd import synth  # noqa: E402
+
+TASK = "pt_contra%tva%tv%ta_caption%tva%tv%ta_mlm%tva"
+SLICE_KEYS = ["clip_model.visual.transformer.resblocks.0.attn.in_proj_weight", "clip_model.visual.conv1.weight",
+              "audio_encoder.layer.11.ff_layer.linear2.weight", "multimodal_encoder.encoder.layer.0.cross_attn.cross.key.weight",
+              "multimodal_encoder.embeddings.word_embeddings.weight", "cls.decoder.bias", "clip_model.logit_scale",
+              "text_fine_weight.0.weight", "video_frame_embedding", "clip_model.token_embedding.weight"]
+
+
+def run(name, batch_size, frames, audio_slices, wseed, bseed, mseed):
+    spec = synth.base_spec()
+    sd = synth.make_state_dict(spec, seed=wseed)
+    ref = ref_harness.build_reference(state_dict=sd, dropout=0.0)
+    batch = synth.make_batch(spec, batch=batch_size, frames=frames, audio_slices=audio_slices, txt_len=32, seed=bseed)
+    g = {"recipe": dict(spec=spec.to_dict(), weight_seed=wseed, batch_seed=bseed, masker_seed=mseed, batch=batch_size,
+                        frames=frames, audio_slices=audio_slices, txt_len=32, task=TASK)}
+    # ---- eval pass (compute_loss=False): argmax ids + features
+    with torch.no_grad():
+        random.seed(mseed)
+        ev = ref(batch, task=TASK, compute_loss=False)
+    g["eval"] = {k: ev[k].argmax(-1) for k in ev if "scores" in k}
+    g["eval"]["top2_margin_min"] = {k: float((ev[k].topk(2, -1).values[:, 0] - ev[k].topk(2, -1).values[:, 1]).min()) for k in ev if "scores" in k}
+    g["eval"].update(feat_t=ev["feat_t"], feat_v=ev["feat_v"], feat_a=ev["feat_a"], txt_labels_caption=ev["txt_labels_caption"],
+                     txt_labels_mlm=ev["txt_labels_mlm"])
+    # ---- training pass + 2 optimizer steps
+    from easydict import EasyDict
+    from optim.misc import build_optimizer
+    from optim.sched import get_lr_sched
+    opts = EasyDict(learning_rate=1e-4, weight_decay=0.01, clip_lr=5e-7, clip_lr_text=5e-7, new_lr=0.0, decoder_lr=-1,
+                    new_params_name=[], optim="adamw", betas=[0.9, 0.98], warmup_ratio=0.1, num_train_steps=10,
+                    scheduler="warmup_linear", grad_norm=5.0)
+    opt = build_optimizer(ref, opts)
+    g["steps"] = []
+    for step in range(2):
+        opt.zero_grad()
+        random.seed(mseed + step)
+        out = ref(batch, task=TASK, compute_loss=True)
+        loss = sum(out.values())
+        loss.backward()
+        rec = {"losses": {k: float(v) for k, v in out.items()}}
+        if step == 0:
+            rec["grad_norm"] = {n: float(p.grad.norm()) for n, p in ref.named_parameters() if p.grad is not None}
+            rec["no_grad"] = [n for n, p in ref.named_parameters() if p.grad is None]
+            rec["grad_slices"] = {n: dict(ref.named_parameters())[n].grad.reshape(-1)[:64].clone() for n in SLICE_KEYS}
+        lr_ratio = get_lr_sched(step + 1, opts)
+        for pg in opt.param_groups:
+            pg["lr"] = pg["init_lr"] * lr_ratio
+        rec["lr_ratio"] = lr_ratio
+        rec["total_grad_norm"] = float(torch.nn.utils.clip_grad_norm_(ref.parameters(), opts.grad_norm))
+        opt.step()
+        g["steps"].append(rec)
+    g["after_2_steps"] = {"param_norm": {n: float(p.detach().double().norm()) for n, p in ref.named_parameters()},
+                          "param_slices": {n: dict(ref.named_parameters())[n].detach().reshape(-1)[:64].clone() for n in SLICE_KEYS},
+                          "delta_norm": {n: float((p.detach() - sd[n]).double().norm()) for n, p in ref.named_parameters()}}
+    os.makedirs(os.path.join(ROOT, "tests", "golden"), exist_ok=True)
+    path = os.path.join(ROOT, "tests", "golden", name + ".pt")
+    torch.save(g, path)
+    print(name, {k: round(v, 6) for k, v in g["steps"][0]["losses"].items()}, "->", path, os.path.getsize(path) // 1024, "KiB")
+
+
+if __name__ == "__main__":
+    assert ref_harness.available()
+    run("ref_base_b2f2a1", batch_size=2, frames=2, audio_slices=1, wseed=50, bseed=51, mseed=50)
+    run("ref_base_b3f1a2", batch_size=3, frames=1, audio_slices=2, wseed=7, bseed=8, mseed=9)

@@ -1,0 +1,456 @@
+"""TEST INFRASTRUCTURE -- CPU oracle: a plain-PyTorch fp32 restatement of the reference VALOR
+pretraining step (CLIP-ViT variant). NOT product code: only tests/, __graft_entry__.smoke() and
+bench.py's cpu_baseline leg may import it. The product (valor_amd) never does.
+
+Every function cites the reference file:line it follows (/root/reference). The restatement is
+pinned against the unmodified reference in this container by tests/test_oracle_vs_reference.py
+(runs only where /root/reference exists) and against the committed golden vectors
+tests/golden/*.pt (generated from the REFERENCE by oracle/make_goldens.py) everywhere.
+
+Weights: a flat dict with the reference's state-dict keys (valor_amd/synth.py layout); tensors may
+require grad so torch autograd provides the reference gradients.
+"""
+import math
+import random
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+
+# ----------------------------------------------------------------------------- small pieces
+def gelu_erf(x):
+    """model/bert.py:52-57, model/transformer.py:32-38"""
+    return x * 0.5 * (1.0 + torch.erf(x / math.sqrt(2.0)))
+
+
+def quick_gelu(x):
+    """model/clip.py:167-169"""
+    return x * torch.sigmoid(1.702 * x)
+
+
+def layer_norm(x, w, b, eps):
+    return F.layer_norm(x, (x.shape[-1],), w, b, eps)
+
+
+def dropout(x, p, training=True):
+    return F.dropout(x, p, training) if p > 0 else x
+
+
+class Oracle:
+    def __init__(self, spec, sd, *, dropout_p=0.0, use_task_prompt=False, contra_loss_ratio=1.0, vocab_tokens=None,
+                 masker_range=(106, None)):
+        self.spec = spec
+        self.sd = sd
+        self.p = dropout_p
+        self.use_task_prompt = use_task_prompt
+        self.contra_loss_ratio = contra_loss_ratio
+        self.vocab = {t: i for i, t in enumerate(vocab_tokens)} if vocab_tokens is not None else None
+        self.masker_range = (masker_range[0], masker_range[1] if masker_range[1] is not None else spec.vocab)
+        self.mask_token = 103
+
+    def w(self, k):
+        return self.sd[k]
+
+    # ------------------------------------------------------------------------- CLIP
+    def clip_block(self, x, prefix, heads, attn_mask):
+        """ResidualAttentionBlock.forward, model/clip.py:186-197 (nn.MultiheadAttention, QuickGELU MLP). x: [N, L, E]"""
+        w = self.w
+        E = x.shape[-1]
+        h = layer_norm(x, w(prefix + "ln_1.weight"), w(prefix + "ln_1.bias"), 1e-5)
+        qkv = F.linear(h, w(prefix + "attn.in_proj_weight"), w(prefix + "attn.in_proj_bias"))
+        q, k, v = qkv.split(E, dim=-1)
+        N, L, _ = q.shape
+        hd = E // heads
+        q = q.view(N, L, heads, hd).transpose(1, 2) * (hd ** -0.5)
+        k = k.view(N, L, heads, hd).transpose(1, 2)
+        v = v.view(N, L, heads, hd).transpose(1, 2)
+        s = q @ k.transpose(-1, -2)
+        if attn_mask is not None:
+            s = s + attn_mask[:, None]
+        a = torch.softmax(s, dim=-1) @ v
+        a = a.transpose(1, 2).reshape(N, L, E)
+        x = x + F.linear(a, w(prefix + "attn.out_proj.weight"), w(prefix + "attn.out_proj.bias"))
+        h = layer_norm(x, w(prefix + "ln_2.weight"), w(prefix + "ln_2.bias"), 1e-5)
+        h = quick_gelu(F.linear(h, w(prefix + "mlp.c_fc.weight"), w(prefix + "mlp.c_fc.bias")))
+        return x + F.linear(h, w(prefix + "mlp.c_proj.weight"), w(prefix + "mlp.c_proj.bias"))
+
+    def clip_visual(self, images):
+        """VisionTransformer.forward, model/clip.py:259-274: all tokens returned, ln_post on all tokens."""
+        w, sp = self.w, self.spec
+        x = F.conv2d(images, w("clip_model.visual.conv1.weight"), None, stride=sp.patch)
+        x = x.reshape(x.shape[0], x.shape[1], -1).permute(0, 2, 1)
+        cls = w("clip_model.visual.class_embedding") + torch.zeros(x.shape[0], 1, x.shape[-1])
+        x = torch.cat([cls, x], dim=1) + w("clip_model.visual.positional_embedding")
+        x = layer_norm(x, w("clip_model.visual.ln_pre.weight"), w("clip_model.visual.ln_pre.bias"), 1e-5)
+        for i in range(sp.vis_layers):
+            x = self.clip_block(x, f"clip_model.visual.transformer.resblocks.{i}.", sp.vis_heads, None)
+        return layer_norm(x, w("clip_model.visual.ln_post.weight"), w("clip_model.visual.ln_post.bias"), 1e-5)
+
+    def clip_text(self, tokens):
+        """CLIP.encode_text(casual=True), model/clip.py:372-427: causal AND pad additive mask (1-m)*-1e4."""
+        w, sp = self.w, self.spec
+        x = w("clip_model.token_embedding.weight")[tokens]
+        L = x.shape[1]
+        x = x + w("clip_model.positional_embedding")[:L]
+        m = (tokens != 0).long()
+        m = m.unsqueeze(1).expand(-1, L, -1).clone()
+        m = torch.tril(m)
+        am = (1.0 - m.float()) * -10000.0
+        for i in range(sp.txt_layers):
+            x = self.clip_block(x, f"clip_model.transformer.resblocks.{i}.", sp.txt_heads, am)
+        return layer_norm(x, w("clip_model.ln_final.weight"), w("clip_model.ln_final.bias"), 1e-5)
+
+    def forward_video_encoder(self, video_pixels):
+        """model/modeling.py:449-465 (clip branch)"""
+        b, n, _, h, ww = video_pixels.shape
+        out = self.clip_visual(video_pixels.reshape(b * n, 3, h, ww))
+        return out.reshape(b, -1, *out.shape[-2:])
+
+    # ------------------------------------------------------------------------- AST
+    def forward_audio_encoder(self, audio):
+        """model/modeling.py:468-480, AudioEmbeddings :750-762, TransformerEncoder prenorm transformer.py:74-85,156-170"""
+        w, sp = self.w, self.spec
+        b, n, hh, ww = audio.shape
+        x = audio.reshape(-1, hh, ww).unsqueeze(1)
+        x = F.conv2d(x, w("audio_embeddings.first_conv.weight"), w("audio_embeddings.first_conv.bias"), stride=sp.aud_patch)
+        bb, c = x.shape[0], x.shape[1]
+        x = x.permute(0, 2, 3, 1).reshape(bb, -1, c)
+        x = torch.cat((w("audio_embeddings.cls_token").expand(bb, -1, -1), x), dim=1)
+        x = x + w("audio_embeddings.position_embeddings.weight")[None]
+        x = dropout(x, self.p)
+        H = sp.aud_heads
+        for i in range(sp.aud_layers):
+            p = f"audio_encoder.layer.{i}."
+            res = x
+            h = layer_norm(x, w(p + "layernorm1.weight"), w(p + "layernorm1.bias"), 1e-12)
+            q, k, v = [F.linear(h, w(p + f"attention.linears.{j}.weight"), w(p + f"attention.linears.{j}.bias"))
+                       .view(bb, -1, H, sp.aud_width // H).transpose(1, 2) for j in range(3)]
+            att = torch.softmax(q @ k.transpose(-2, -1) / math.sqrt(q.shape[-1]), dim=-1)
+            att = dropout(att, self.p)
+            a = (att @ v).transpose(1, 2).contiguous().view(bb, -1, sp.aud_width)
+            a = F.linear(a, w(p + "attention.linears.3.weight"), w(p + "attention.linears.3.bias"))
+            x = res + dropout(a, self.p)
+            res = x
+            h = layer_norm(x, w(p + "layernorm2.weight"), w(p + "layernorm2.bias"), 1e-12)
+            h = F.linear(gelu_erf(F.linear(h, w(p + "ff_layer.linear1.weight"), w(p + "ff_layer.linear1.bias"))),
+                         w(p + "ff_layer.linear2.weight"), w(p + "ff_layer.linear2.bias"))
+            x = res + dropout(h, self.p)
+        x = layer_norm(x, w("audio_encoder.last_layernorm.weight"), w("audio_encoder.last_layernorm.bias"), 1e-12)
+        return x.reshape(b, n, -1, x.shape[-1])
+
+    # ------------------------------------------------------------------------- BERT decoder
+    def bert_embeddings(self, ids, token_type):
+        """BertEmbeddings.forward, model/bert.py:190-218"""
+        w = self.w
+        e = "multimodal_encoder.embeddings."
+        L = ids.shape[1]
+        x = w(e + "word_embeddings.weight")[ids] + w(e + "position_embeddings.weight")[:L][None]
+        if token_type == "prompt":
+            x = x + w(e + "prompt_embedding.weight")[0]
+        else:
+            x = x + w(e + "token_type_embeddings.weight")[0]
+        x = layer_norm(x, w(e + "LayerNorm.weight"), w(e + "LayerNorm.bias"), 1e-12)
+        return dropout(x, self.p)
+
+    def bert_attn(self, x, kv_src, p, blk, mask):
+        """BertSelfAttention bert.py:244-289 / BertCrossAttention :314-340 + BertSelfOutput/CrossOutput :351-355,365-371"""
+        w, H = self.w, self.spec.heads
+        B, T, E = x.shape
+        q = F.linear(x, w(p + f"{blk}.query.weight"), w(p + f"{blk}.query.bias"))
+        k = F.linear(kv_src, w(p + f"{blk}.key.weight"), w(p + f"{blk}.key.bias"))
+        v = F.linear(kv_src, w(p + f"{blk}.value.weight"), w(p + f"{blk}.value.bias"))
+        sh = lambda t: t.view(B, -1, H, E // H).permute(0, 2, 1, 3)
+        s = sh(q) @ sh(k).transpose(-1, -2) / math.sqrt(E // H)
+        if mask is not None:
+            s = s + mask
+        a = dropout(torch.softmax(s, dim=-1), self.p)
+        ctx = (a @ sh(v)).permute(0, 2, 1, 3).contiguous().view(B, T, E)
+        out = blk.split(".")[0] + ".output."
+        h = dropout(F.linear(ctx, w(p + out + "dense.weight"), w(p + out + "dense.bias")), self.p)
+        return layer_norm(h + x, w(p + out + "LayerNorm.weight"), w(p + out + "LayerNorm.bias"), 1e-12)
+
+    def bert_model(self, tokens, task_prompt, video_feat, audio_feat, casual):
+        """BertModel.forward, has_cross_attn branch, model/bert.py:848-896 ; BertLayer :440-496 (va_concate)"""
+        w, sp = self.w, self.spec
+        x = self.bert_embeddings(tokens, None)
+        token_len = x.shape[1]
+        am = (tokens != 0).long()
+        if task_prompt is not None:
+            x = torch.cat((x, self.bert_embeddings(task_prompt, "prompt")), dim=1)
+            am = torch.cat((am, (task_prompt != 0).long()), dim=1)
+        total = am.shape[1]
+        am = am.unsqueeze(1).expand(-1, total, -1).clone()
+        if casual:
+            am[:, :token_len, :token_len] = torch.tril(am[:, :token_len, :token_len])
+            am[:, token_len:, :token_len] = 0
+        am = ((1.0 - am.unsqueeze(1).float()) * -10000.0)
+        if video_feat is not None and audio_feat is not None:
+            cross = torch.cat((video_feat, audio_feat), dim=1)
+        elif video_feat is not None:
+            cross = video_feat
+        else:
+            cross = audio_feat
+        for i in range(sp.layers):
+            p = f"multimodal_encoder.encoder.layer.{i}."
+            x = self.bert_attn(x, x, p, "attention.self", am)
+            if cross is not None:
+                x = self.bert_attn(x, cross, p, "cross_attn.cross", None)
+            h = gelu_erf(F.linear(x, w(p + "intermediate.dense.weight"), w(p + "intermediate.dense.bias")))
+            h = dropout(F.linear(h, w(p + "output.dense.weight"), w(p + "output.dense.bias")), self.p)
+            x = layer_norm(h + x, w(p + "output.LayerNorm.weight"), w(p + "output.LayerNorm.bias"), 1e-12)
+        return x
+
+    def cls_head(self, x):
+        """BERTPredictionHead.forward, model/modeling.py:245-254 (decoder weight tied to word embeddings :241)"""
+        w = self.w
+        x = gelu_erf(F.linear(x, w("cls.dense.weight"), w("cls.dense.bias")))
+        x = layer_norm(x, w("cls.layernorm.weight"), w("cls.layernorm.bias"), 1e-12)
+        return F.linear(x, w("multimodal_encoder.embeddings.word_embeddings.weight"), w("cls.decoder.bias"))
+
+    # ------------------------------------------------------------------------- host-side text helpers
+    def text_masker(self, tokens, mask_prob):
+        """TokenMasker.perform_mask, model/modeling.py:134-174 (CPU numpy + python `random`, >= 1 mask per row)."""
+        tokens = np.array(tokens.cpu().numpy())
+        ind = np.zeros(tokens.shape, dtype=np.int64)
+        for i in range(len(ind)):
+            while all(ind[i] == 0):
+                for j in range(1, len(ind[0])):
+                    if tokens[i][j] != 0 and random.random() < mask_prob:
+                        ind[i][j] = 1
+        labels = -np.ones(tokens.shape, dtype=np.int64)
+        rng = list(range(*self.masker_range))
+        for i in range(tokens.shape[0]):
+            for j in range(tokens.shape[1]):
+                if ind[i][j] == 1:
+                    src = tokens[i][j]
+                    prob = random.random()
+                    if prob < 0.8:
+                        tokens[i][j] = self.mask_token
+                    elif prob < 0.9:
+                        tokens[i][j] = random.choice(rng)
+                    labels[i][j] = src
+        return torch.from_numpy(tokens).long(), torch.from_numpy(labels).long()
+
+    def get_task_prompt(self, sentence, batch_size):
+        """VALORModel.get_task_prompt, model/modeling.py:355-369 (bert tokenizer branch): whole-word vocab lookup."""
+        ids = [101] + [self.vocab.get(t, 100) for t in sentence.lower().split()] + [102]
+        return torch.tensor(ids).unsqueeze(0).expand(batch_size, -1).long()
+
+    # ------------------------------------------------------------------------- contrastive
+    @staticmethod
+    def compute_fine_matrix(featA, featB, maskA, maskB, weightA, weightB):
+        """VALOR.compute_fine_matrix_slice, model/pretrain.py:191-211"""
+        weightA = weightA.masked_fill((1 - maskA).bool(), float("-inf"))
+        weightA = torch.softmax(weightA, dim=-1)
+        weightB = weightB.masked_fill((1 - maskB).bool(), float("-inf"))
+        weightB = torch.softmax(weightB, dim=-1)
+        logits = torch.einsum("atd,bvd->abtv", featA, featB)
+        logits = torch.einsum("abtv,at->abtv", logits, maskA.to(logits.dtype))
+        logits = torch.einsum("abtv,bv->abtv", logits, maskB.to(logits.dtype))
+        a2b = logits.max(dim=-1)[0]
+        b2a = logits.max(dim=-2)[0]
+        a2b = torch.einsum("abt,at->ab", a2b, weightA)
+        b2a = torch.einsum("abv,bv->ab", b2a, weightB)
+        return (a2b + b2a) / 2.0
+
+    def contrastive_loss(self, score):
+        """VALORModel.contrastive_loss, model/modeling.py:418-433 (clip video encoder: temp = 1/exp(logit_scale))"""
+        temp = 1.0 / self.w("clip_model.logit_scale").exp()
+        s = score / temp
+        l1 = (-F.log_softmax(s, dim=1)).diag()
+        l2 = (-F.log_softmax(s, dim=0)).diag()
+        return torch.mean(torch.cat((l1, l2), dim=0))
+
+    def fine_weight(self, name, feat):
+        """nn.Sequential(Linear, ReLU, Linear(->1)), model/pretrain.py:104-116"""
+        w = self.w
+        h = F.relu(F.linear(feat, w(f"{name}_fine_weight.0.weight"), w(f"{name}_fine_weight.0.bias")))
+        return F.linear(h, w(f"{name}_fine_weight.2.weight"), w(f"{name}_fine_weight.2.bias")).squeeze(2)
+
+    # ------------------------------------------------------------------------- the hot path
+    def forward_pt(self, batch, task, compute_loss=True, gather=None, collect=None):
+        """VALOR.forward_pt, model/pretrain.py:214-541 (contra_type='fine', caption_type='unimlm', va_concate).
+        gather: optional callables (feat -> gathered feat, tokens -> gathered tokens) emulating
+        ddp_allgather_with_grads / ddp_allgather (utils/distributed.py:38-93) for multi-rank tests."""
+        w = self.w
+        mlm_task, caption_task, contra_task = [], [], []
+        for i in task.split("_"):
+            if "mlm" in i:
+                mlm_task = i.split("%")[1:]
+            elif "caption" in i:
+                caption_task = i.split("%")[1:]
+            elif "contra" in i:
+                contra_task = i.split("%")[1:]
+        out = {}
+        col = collect if collect is not None else {}
+        txt_tokens = batch["txt_tokens"]
+        alltasks = "".join(mlm_task + caption_task + contra_task)
+        video_output = audio_output = None
+        if "v" in alltasks:
+            video_output = self.forward_video_encoder(batch["video_pixels"])
+            col["video_output"] = video_output
+        if "a" in alltasks:
+            audio_output = self.forward_audio_encoder(batch["audio_spectrograms"])
+            col["audio_output"] = audio_output
+        if "t" in "".join(contra_task):
+            txt_tokens_contra = txt_tokens["clip_tokens"]
+            txt_output = self.clip_text(txt_tokens_contra)
+            col["txt_output"] = txt_output
+
+        if contra_task:
+            feat_t = feat_v = feat_a = None
+            if "t" in "".join(contra_task):
+                feat_t = F.normalize(txt_output @ w("clip_model.text_projection"), dim=-1)       # pretrain.py:90,274-276
+                if compute_loss and gather:
+                    feat_t = gather[0](feat_t); txt_tokens_contra = gather[1](txt_tokens_contra)
+            if "v" in "".join(contra_task):
+                feat_v = F.normalize(video_output[:, :, 0] @ w("clip_model.visual.proj"), dim=-1)  # :91, modeling.py:387
+                if compute_loss and gather:
+                    feat_v = gather[0](feat_v)
+            if "a" in "".join(contra_task):
+                feat_a = F.normalize(F.linear(audio_output[:, :, 0], w("contra_head_a.linear.weight")), dim=-1)
+                if compute_loss and gather:
+                    feat_a = gather[0](feat_a)
+            col.update(feat_t=feat_t, feat_v=feat_v, feat_a=feat_a)
+            if compute_loss:
+                losses = []
+                maskA = (txt_tokens_contra != 0).long()
+                if "tva" in contra_task:                                                         # pretrain.py:311-336
+                    feat_va = torch.cat((feat_v, feat_a), dim=1)
+                    maskB = torch.ones(*feat_va.shape[:2]).long()
+                    wA = self.fine_weight("text", feat_t)
+                    wB = torch.cat((self.fine_weight("video", feat_v), self.fine_weight("audio", feat_a)), dim=1)
+                    sm = self.compute_fine_matrix(feat_t, feat_va, maskA, maskB, wA, wB)
+                    col["score_tva"] = sm
+                    losses.append(self.contrastive_loss(sm))
+                if "tv" in contra_task:                                                          # :303-309
+                    maskB = torch.ones(*feat_v.shape[:2]).long()
+                    sm = self.compute_fine_matrix(feat_t, feat_v, maskA, maskB, self.fine_weight("text", feat_t),
+                                                  self.fine_weight("video", feat_v))
+                    col["score_tv"] = sm
+                    losses.append(self.contrastive_loss(sm))
+                if "ta" in contra_task:                                                          # :339-345
+                    maskB = torch.ones(*feat_a.shape[:2]).long()
+                    sm = self.compute_fine_matrix(feat_t, feat_a, maskA, maskB, self.fine_weight("text", feat_t),
+                                                  self.fine_weight("audio", feat_a))
+                    col["score_ta"] = sm
+                    losses.append(self.contrastive_loss(sm))
+                out["contra_loss"] = sum(losses) / len(losses) * self.contra_loss_ratio
+            else:
+                out.update(feat_t=feat_t, feat_v=feat_v, feat_a=feat_a, txt_tokens=txt_tokens_contra)
+
+        txt = txt_tokens["bert_tokens"]
+        bs = txt.shape[0]
+        video_input = audio_input = None
+        if video_output is not None:                                                             # modeling.py:485-493
+            vo = video_output + w("video_frame_embedding")[:, :video_output.shape[1], :].unsqueeze(-2)
+            video_input = vo.reshape(bs, -1, self.spec.hidden) + w("video_type_embeddings")
+        if audio_output is not None:                                                             # modeling.py:495-502
+            ao = audio_output + w("audio_frame_embedding")[:, :audio_output.shape[1], :].unsqueeze(-2)
+            audio_input = ao.reshape(bs, -1, self.spec.hidden) + w("audio_type_embeddings")
+
+        def run_group(txt_input, txt_labels, prompt, g, casual, tag):
+            vi = video_input if "v" in g else None
+            ai = audio_input if "a" in g else None
+            o = self.bert_model(txt_input, prompt, vi, ai, casual)[:, :txt_input.shape[1], :]
+            o = o[txt_labels != -1]
+            scores = self.cls_head(o)
+            col[f"{tag}_scores_{g}"] = scores
+            if compute_loss:
+                return F.cross_entropy(scores, txt_labels[txt_labels != -1])
+            out[f"{tag}_scores_{g}"] = scores
+            return None
+
+        if caption_task:                                                                         # pretrain.py:419-481
+            txt_input, txt_labels = self.text_masker(txt, 0.6)
+            col["caption_txt_input"], col["caption_txt_labels"] = txt_input, txt_labels
+            lo = []
+            for g in ("tva", "tv", "ta"):
+                if g in caption_task:
+                    prompt = self.get_task_prompt("describe the video with natural language", bs) if self.use_task_prompt else None
+                    l = run_group(txt_input, txt_labels, prompt, g, True, "caption")
+                    if l is not None:
+                        lo.append(l)
+            if compute_loss:
+                out["caption_loss"] = sum(lo) / len(lo)
+            else:
+                out["txt_labels_caption"] = txt_labels
+        if mlm_task:                                                                             # pretrain.py:483-535
+            txt_input, txt_labels = self.text_masker(txt, 0.15)
+            col["mlm_txt_input"], col["mlm_txt_labels"] = txt_input, txt_labels
+            sent = {"tva": "predict masked tokens with visual and audio cues", "tv": "predict masked tokens with visual cues",
+                    "ta": "predict masked tokens with audio cues"}
+            lo = []
+            for g in ("tva", "tv", "ta"):
+                if g in mlm_task:
+                    l = run_group(txt_input, txt_labels, self.get_task_prompt(sent[g], bs), g, False, "mlm")
+                    if l is not None:
+                        lo.append(l)
+            if compute_loss:
+                out["mlm_loss"] = sum(lo) / len(lo)
+            else:
+                out["txt_labels_mlm"] = txt_labels
+        return out
+
+
+# ----------------------------------------------------------------------------- optimizer
+def param_group_of(name, new_params_name=()):
+    """optim/misc.py:13-64 group assignment -> (group_index 0..9, decayed?)."""
+    no_decay = ["bias", "LayerNorm.bias", "LayerNorm.weight"]
+    nd = any(t in name for t in no_decay)
+    if "clip" in name and "visual" in name:
+        base = 4
+    elif "clip" in name:
+        base = 6
+    elif "multimodal_encoder.decoder" in name:
+        base = 8
+    elif any(t in name for t in new_params_name):
+        base = 2
+    else:
+        base = 0
+    return base + (1 if nd else 0)
+
+
+def group_hparams(learning_rate, weight_decay, clip_lr=5e-7, clip_lr_text=5e-7, new_lr=0.0, decoder_lr=-1):
+    """optim/misc.py:66-77 ; train_utils.py:614-615 defaults."""
+    if decoder_lr == -1:
+        decoder_lr = learning_rate
+    lrs = [learning_rate, learning_rate, new_lr, new_lr, clip_lr, clip_lr, clip_lr_text, clip_lr_text, decoder_lr, decoder_lr]
+    wds = [weight_decay if i % 2 == 0 else 0.0 for i in range(10)]
+    return lrs, wds
+
+
+def warmup_linear(x, warmup_ratio):
+    """optim/sched.py:27-34"""
+    if x < warmup_ratio:
+        return x / warmup_ratio
+    return max((x - 1.0) / (warmup_ratio - 1.0), 0)
+
+
+def adamw_step(params, grads, state, lrs, wds, groups, betas=(0.9, 0.98), eps=1e-6):
+    """optim/adamw.py:40-103 on dicts name -> tensor (in place). state[name] = dict(step, exp_avg, exp_avg_sq)."""
+    b1, b2 = betas
+    for name, p in params.items():
+        g = grads.get(name)
+        if g is None:
+            continue
+        st = state.setdefault(name, {"step": 0, "exp_avg": torch.zeros_like(p), "exp_avg_sq": torch.zeros_like(p)})
+        st["step"] += 1
+        st["exp_avg"].mul_(b1).add_(g, alpha=1.0 - b1)
+        st["exp_avg_sq"].mul_(b2).addcmul_(g, g, value=1.0 - b2)
+        denom = st["exp_avg_sq"].sqrt().add_(eps)
+        lr, wd = lrs[groups[name]], wds[groups[name]]
+        step_size = lr * math.sqrt(1.0 - b2 ** st["step"]) / (1.0 - b1 ** st["step"])
+        p.addcdiv_(st["exp_avg"], denom, value=-step_size)
+        if wd > 0.0:
+            p.add_(p, alpha=-lr * wd)
+
+
+def clip_grad_norm(grads, max_norm):
+    """torch.nn.utils.clip_grad_norm_ semantics (train_utils.py:358-360). Returns total norm; scales in place."""
+    total = torch.sqrt(sum((g.double() ** 2).sum() for g in grads.values())).float()
+    coef = min(1.0, float(max_norm / (total + 1e-6)))
+    for g in grads.values():
+        g.mul_(coef)
+    return total

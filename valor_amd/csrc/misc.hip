@@ -1,0 +1,368 @@
+// Small HBM-bound kernels around the GEMM / attention core: patchify (conv-as-GEMM gather),
+// token assembly (cls + patches + positional), BERT embedding sums, frame/type embedding adds,
+// L2 normalisation, row gather / scatter. All vectorised 4 elements per lane.
+#include "common.h"
+
+// ---------------------------------------------------------------------------------------------
+// patchify: non-overlapping PxP patches of fp32 images -> GEMM operand rows (dtype T).
+//   out[(n*gh + py)*gw + px][c*P*P + i*P + j] = in[n][c][py*P + i][px*P + j]
+// Replaces the im2col inside nn.Conv2d(kernel = stride = P): clip.py:227,261 (CLIP conv1, P=16, C=3)
+// and modeling.py:744,752 (AST first_conv, P=16, C=1); the cast to the compute dtype is fused.
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void patchify_kernel(const float* in, T* out, int N, int C, int H, int W, int P) {
+    const int gh = H / P, gw = W / P, K = C * P * P;
+    const int64_t total4 = (int64_t)N * gh * gw * K / 4;
+    for (int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; q < total4; q += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t e = q * 4;
+        const int k = (int)(e % K);
+        const int64_t tok = e / K;
+        const int px = (int)(tok % gw), py = (int)((tok / gw) % gh), n = (int)(tok / ((int64_t)gw * gh));
+        const int c = k / (P * P), ij = k % (P * P), i = ij / P, j = ij % P;   // j % 4 == 0 (P % 4 == 0)
+        const float* src = in + (((int64_t)n * C + c) * H + (py * P + i)) * W + px * P + j;
+        store4<T>(out + e, *(const f32x4_t*)src);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// token assembly: out[n][0] = cls + pos[0] ; out[n][1+p] = patches[n][p] (+ bias) + pos[1+p]
+// (clip.py:264-265 class_embedding / positional_embedding; modeling.py:755-760 AST cls_token /
+//  position_embeddings). Backward: dpatches = dout[:,1:], dpos = sum_n dout, (dcls = dpos[0]).
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void assemble_fwd_kernel(const T* patches, const T* cls, const T* pos, const T* bias, T* out, int N, int Pn, int E) {
+    const int E4 = E / 4;
+    const int64_t total = (int64_t)N * (Pn + 1) * E4;
+    for (int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; q < total; q += (int64_t)gridDim.x * blockDim.x) {
+        const int e = (int)(q % E4) * 4;
+        const int64_t r = q / E4;
+        const int t = (int)(r % (Pn + 1));
+        const int64_t n = r / (Pn + 1);
+        f32x4_t v = load4<T>(pos + (int64_t)t * E + e);
+        if (t == 0) v += load4<T>(cls + e);
+        else {
+            v += load4<T>(patches + (n * Pn + (t - 1)) * E + e);
+            if (bias) v += load4<T>(bias + e);
+        }
+        store4<T>(out + r * E + e, v);
+    }
+}
+template <typename T>
+__global__ void assemble_bwd_patches_kernel(const T* dout, T* dpatches, int N, int Pn, int E) {
+    const int E4 = E / 4;
+    const int64_t total = (int64_t)N * Pn * E4;
+    for (int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; q < total; q += (int64_t)gridDim.x * blockDim.x) {
+        const int e = (int)(q % E4) * 4;
+        const int64_t r = q / E4;
+        const int p = (int)(r % Pn);
+        const int64_t n = r / Pn;
+        store4<T>(dpatches + r * E + e, load4<T>(dout + (n * (Pn + 1) + 1 + p) * E + e));
+    }
+}
+// dsum[t][e] = sum_n x[n][t][e]   (x: [N, Tn, E]); one thread per 4 columns of one t
+template <typename T>
+__global__ void sum_over_batch_kernel(const T* x, T* dsum, int N, int Tn, int E) {
+    const int E4 = E / 4;
+    const int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= (int64_t)Tn * E4) return;
+    const int e = (int)(q % E4) * 4, t = (int)(q / E4);
+    f32x4_t s = {0.f, 0.f, 0.f, 0.f};
+    for (int n = 0; n < N; ++n) s += load4<T>(x + ((int64_t)n * Tn + t) * E + e);
+    store4<T>(dsum + (int64_t)t * E + e, s);
+}
+
+// ---------------------------------------------------------------------------------------------
+// BERT / CLIP-text embedding sum: out[i] = word[ids[i]] + pos[i % L] (+ typevec)
+// (bert.py:211-215 words + position + token_type|prompt embeddings; clip.py:377-379).
+// Backward for the word table is a deterministic scatter: the first occurrence of an id sums
+// all rows with that id (no atomics), rows of ids that do not occur stay zero.
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void embed_fwd_kernel(const int64_t* ids, const T* word, const T* pos, const T* typevec, T* out, int64_t n, int L, int E) {
+    const int E4 = E / 4;
+    for (int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; q < n * E4; q += (int64_t)gridDim.x * blockDim.x) {
+        const int e = (int)(q % E4) * 4;
+        const int64_t i = q / E4;
+        f32x4_t v = load4<T>(word + ids[i] * E + e);
+        if (pos) v += load4<T>(pos + (i % L) * E + e);
+        if (typevec) v += load4<T>(typevec + e);
+        store4<T>(out + i * E + e, v);
+    }
+}
+template <typename T>
+__global__ __launch_bounds__(256) void embed_bwd_word_kernel(const int64_t* ids, const T* dout, T* dword, int64_t n, int E) {
+    __shared__ int first;
+    const int64_t i = blockIdx.x;
+    const int64_t id = ids[i];
+    if (threadIdx.x == 0) first = 1;
+    __syncthreads();
+    for (int64_t j = threadIdx.x; j < i; j += 256)
+        if (ids[j] == id) first = 0;
+    __syncthreads();
+    if (!first) return;
+    for (int e = threadIdx.x * 4; e < E; e += 1024) {
+        f32x4_t s = load4<T>(dout + i * E + e);
+        for (int64_t j = i + 1; j < n; ++j)
+            if (ids[j] == id) s += load4<T>(dout + j * E + e);
+        store4<T>(dword + id * E + e, s);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// modality tokens for the decoder: out[b][row_off + f*X + x] = in[b][f][x] + frame_emb[f] + type_emb
+// (modeling.py:485-502). Writes straight into the concatenated [video | audio] buffer.
+// Backward: din = dout slice (copy), dframe[f] = sum_{b,x} dout, dtype = sum of everything.
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void add_frame_type_fwd_kernel(const T* in, const T* frame_emb, const T* type_emb, T* out, int Bn, int F, int X,
+                                          int E, int64_t out_bs, int64_t out_row_off) {
+    const int E4 = E / 4;
+    const int64_t total = (int64_t)Bn * F * X * E4;
+    for (int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; q < total; q += (int64_t)gridDim.x * blockDim.x) {
+        const int e = (int)(q % E4) * 4;
+        const int64_t r = q / E4;
+        const int x = (int)(r % X), f = (int)((r / X) % F);
+        const int64_t b = r / ((int64_t)X * F);
+        f32x4_t v = load4<T>(in + r * E + e) + load4<T>(frame_emb + (int64_t)f * E + e) + load4<T>(type_emb + e);
+        store4<T>(out + b * out_bs + (out_row_off + (int64_t)f * X + x) * E + e, v);
+    }
+}
+template <typename T>
+__global__ void add_frame_type_bwd_kernel(const T* dout, T* din, int Bn, int F, int X, int E, int64_t out_bs, int64_t out_row_off) {
+    const int E4 = E / 4;
+    const int64_t total = (int64_t)Bn * F * X * E4;
+    for (int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; q < total; q += (int64_t)gridDim.x * blockDim.x) {
+        const int e = (int)(q % E4) * 4;
+        const int64_t r = q / E4;
+        const int64_t fx = r % ((int64_t)X * F), b = r / ((int64_t)X * F);
+        store4<T>(din + r * E + e, load4<T>(dout + b * out_bs + (out_row_off + fx) * E + e));
+    }
+}
+// dframe[f][e] = sum_{b,x} din[b][f][x][e]
+template <typename T>
+__global__ void frame_sum_kernel(const T* din, T* dframe, int Bn, int F, int X, int E) {
+    const int E4 = E / 4;
+    const int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= (int64_t)F * E4) return;
+    const int e = (int)(q % E4) * 4, f = (int)(q / E4);
+    f32x4_t s = {0.f, 0.f, 0.f, 0.f};
+    for (int b = 0; b < Bn; ++b)
+        for (int x = 0; x < X; ++x) s += load4<T>(din + (((int64_t)b * F + f) * X + x) * E + e);
+    store4<T>(dframe + (int64_t)f * E + e, s);
+}
+
+// ---------------------------------------------------------------------------------------------
+// L2 normalise rows (F.normalize(dim=-1), eps 1e-12; pretrain.py:276,283,290). one wave per row.
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void l2norm_fwd_kernel(const T* x, T* y, float* norm, int64_t rows, int cols) {
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (row >= rows) return;
+    float s = 0.f;
+    for (int c = lane * 4; c < cols; c += 256) { f32x4_t v = load4<T>(x + row * cols + c); s += v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3]; }
+    const float nrm = fmaxf(sqrtf(wave_sum(s)), 1e-12f);
+    if (lane == 0) norm[row] = nrm;
+    const float inv = 1.0f / nrm;
+    for (int c = lane * 4; c < cols; c += 256) store4<T>(y + row * cols + c, load4<T>(x + row * cols + c) * inv);
+}
+// dx = (dy - y * <y, dy>) / norm
+template <typename T>
+__global__ void l2norm_bwd_kernel(const T* y, const T* dy, const float* norm, T* dx, int64_t rows, int cols) {
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (row >= rows) return;
+    float s = 0.f;
+    for (int c = lane * 4; c < cols; c += 256) {
+        f32x4_t a = load4<T>(y + row * cols + c), b = load4<T>(dy + row * cols + c);
+        s += a[0] * b[0] + a[1] * b[1] + a[2] * b[2] + a[3] * b[3];
+    }
+    s = wave_sum(s);
+    const float inv = 1.0f / norm[row];
+    for (int c = lane * 4; c < cols; c += 256) {
+        f32x4_t a = load4<T>(y + row * cols + c), b = load4<T>(dy + row * cols + c);
+        store4<T>(dx + row * cols + c, (b - a * s) * inv);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// row gather / scatter by index (masked-token rows pretrain.py:441,495; cls-token pooling
+// modeling.py:387,399). scatter: dst rows named by idx are overwritten (idx unique), others untouched.
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void gather_rows_kernel(const T* src, const int64_t* idx, T* out, int64_t n, int E, int64_t src_ld) {
+    const int E4 = E / 4;
+    for (int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; q < n * E4; q += (int64_t)gridDim.x * blockDim.x) {
+        const int e = (int)(q % E4) * 4;
+        const int64_t i = q / E4;
+        store4<T>(out + i * E + e, load4<T>(src + idx[i] * src_ld + e));
+    }
+}
+template <typename T>
+__global__ void scatter_rows_kernel(const T* src, const int64_t* idx, T* dst, int64_t n, int E, int64_t dst_ld) {
+    const int E4 = E / 4;
+    for (int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; q < n * E4; q += (int64_t)gridDim.x * blockDim.x) {
+        const int e = (int)(q % E4) * 4;
+        const int64_t i = q / E4;
+        store4<T>(dst + idx[i] * dst_ld + e, load4<T>(src + i * E + e));
+    }
+}
+// fp32 -> T cast / copy (master -> model params, input casts)
+template <typename T>
+__global__ void cast_from_f32_kernel(const float* in, T* out, int64_t n4) {
+    for (int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; q < n4; q += (int64_t)gridDim.x * blockDim.x)
+        store4<T>(out + q * 4, *(const f32x4_t*)(in + q * 4));
+}
+
+static inline int grid_for(int64_t work, int block = 256, int cap = 8192) {
+    int64_t g = (work + block - 1) / block;
+    if (g < 1) g = 1;
+    if (g > cap) g = cap;
+    return (int)g;
+}
+#define DISPATCH_T(dtype, CALL_BF16, CALL_F32)              \
+    if ((dtype) == VALOR_DT_BF16) { CALL_BF16; }            \
+    else if ((dtype) == VALOR_DT_F32) { CALL_F32; }         \
+    else return VALOR_ERR_ARG;
+
+extern "C" int valor_patchify(void* stream, int dtype, const float* in, void* out, int N, int C, int H, int W, int P) {
+    if (N <= 0) return VALOR_OK;
+    if (!in || !out || (P & 3) || H % P || W % P) return VALOR_ERR_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    const int64_t work = (int64_t)N * C * H * W / 4;
+    DISPATCH_T(dtype,
+        hipLaunchKernelGGL((patchify_kernel<bf16_t>), dim3(grid_for(work)), dim3(256), 0, st, in, (bf16_t*)out, N, C, H, W, P),
+        hipLaunchKernelGGL((patchify_kernel<float>), dim3(grid_for(work)), dim3(256), 0, st, in, (float*)out, N, C, H, W, P));
+    return valor_launch_status();
+}
+
+extern "C" int valor_assemble_tokens_fwd(void* stream, int dtype, const void* patches, const void* cls, const void* pos,
+                                         const void* bias, void* out, int N, int Pn, int E) {
+    if (N <= 0) return VALOR_OK;
+    if (E & 3) return VALOR_ERR_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    const int64_t work = (int64_t)N * (Pn + 1) * E / 4;
+    DISPATCH_T(dtype,
+        hipLaunchKernelGGL((assemble_fwd_kernel<bf16_t>), dim3(grid_for(work)), dim3(256), 0, st, (const bf16_t*)patches, (const bf16_t*)cls, (const bf16_t*)pos, (const bf16_t*)bias, (bf16_t*)out, N, Pn, E),
+        hipLaunchKernelGGL((assemble_fwd_kernel<float>), dim3(grid_for(work)), dim3(256), 0, st, (const float*)patches, (const float*)cls, (const float*)pos, (const float*)bias, (float*)out, N, Pn, E));
+    return valor_launch_status();
+}
+// dpatches [N*Pn, E] ; dpos [Pn+1, E] (sum over n; dcls = dpos[0])
+extern "C" int valor_assemble_tokens_bwd(void* stream, int dtype, const void* dout, void* dpatches, void* dpos, int N, int Pn, int E) {
+    if (N <= 0) return VALOR_OK;
+    if (E & 3) return VALOR_ERR_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    const int64_t work = (int64_t)N * Pn * E / 4, work2 = (int64_t)(Pn + 1) * E / 4;
+    DISPATCH_T(dtype,
+        { hipLaunchKernelGGL((assemble_bwd_patches_kernel<bf16_t>), dim3(grid_for(work)), dim3(256), 0, st, (const bf16_t*)dout, (bf16_t*)dpatches, N, Pn, E);
+          hipLaunchKernelGGL((sum_over_batch_kernel<bf16_t>), dim3(grid_for(work2, 256, 1 << 20)), dim3(256), 0, st, (const bf16_t*)dout, (bf16_t*)dpos, N, Pn + 1, E); },
+        { hipLaunchKernelGGL((assemble_bwd_patches_kernel<float>), dim3(grid_for(work)), dim3(256), 0, st, (const float*)dout, (float*)dpatches, N, Pn, E);
+          hipLaunchKernelGGL((sum_over_batch_kernel<float>), dim3(grid_for(work2, 256, 1 << 20)), dim3(256), 0, st, (const float*)dout, (float*)dpos, N, Pn + 1, E); });
+    return valor_launch_status();
+}
+// dsum[Tn, E] = sum over n of x[N, Tn, E]
+extern "C" int valor_sum_over_batch(void* stream, int dtype, const void* x, void* dsum, int N, int Tn, int E) {
+    if (Tn <= 0) return VALOR_OK;
+    if (E & 3) return VALOR_ERR_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    const int64_t work = (int64_t)Tn * E / 4;
+    DISPATCH_T(dtype,
+        hipLaunchKernelGGL((sum_over_batch_kernel<bf16_t>), dim3(grid_for(work, 256, 1 << 20)), dim3(256), 0, st, (const bf16_t*)x, (bf16_t*)dsum, N, Tn, E),
+        hipLaunchKernelGGL((sum_over_batch_kernel<float>), dim3(grid_for(work, 256, 1 << 20)), dim3(256), 0, st, (const float*)x, (float*)dsum, N, Tn, E));
+    return valor_launch_status();
+}
+
+extern "C" int valor_embed_fwd(void* stream, int dtype, const int64_t* ids, const void* word, const void* pos,
+                               const void* typevec, void* out, int64_t n, int L, int E) {
+    if (n <= 0) return VALOR_OK;
+    if ((E & 3) || !ids || !word || !out || L <= 0) return VALOR_ERR_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    const int64_t work = n * E / 4;
+    DISPATCH_T(dtype,
+        hipLaunchKernelGGL((embed_fwd_kernel<bf16_t>), dim3(grid_for(work)), dim3(256), 0, st, ids, (const bf16_t*)word, (const bf16_t*)pos, (const bf16_t*)typevec, (bf16_t*)out, n, L, E),
+        hipLaunchKernelGGL((embed_fwd_kernel<float>), dim3(grid_for(work)), dim3(256), 0, st, ids, (const float*)word, (const float*)pos, (const float*)typevec, (float*)out, n, L, E));
+    return valor_launch_status();
+}
+// dword [V, E] must be zero-initialised by the caller; rows of occurring ids are written.
+extern "C" int valor_embed_bwd_word(void* stream, int dtype, const int64_t* ids, const void* dout, void* dword, int64_t n, int E) {
+    if (n <= 0) return VALOR_OK;
+    if (E & 3) return VALOR_ERR_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    DISPATCH_T(dtype,
+        hipLaunchKernelGGL((embed_bwd_word_kernel<bf16_t>), dim3((unsigned)n), dim3(256), 0, st, ids, (const bf16_t*)dout, (bf16_t*)dword, n, E),
+        hipLaunchKernelGGL((embed_bwd_word_kernel<float>), dim3((unsigned)n), dim3(256), 0, st, ids, (const float*)dout, (float*)dword, n, E));
+    return valor_launch_status();
+}
+
+extern "C" int valor_add_frame_type_fwd(void* stream, int dtype, const void* in, const void* frame_emb, const void* type_emb,
+                                        void* out, int Bn, int F, int X, int E, int64_t out_bs, int64_t out_row_off) {
+    if (Bn <= 0) return VALOR_OK;
+    if (E & 3) return VALOR_ERR_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    const int64_t work = (int64_t)Bn * F * X * E / 4;
+    DISPATCH_T(dtype,
+        hipLaunchKernelGGL((add_frame_type_fwd_kernel<bf16_t>), dim3(grid_for(work)), dim3(256), 0, st, (const bf16_t*)in, (const bf16_t*)frame_emb, (const bf16_t*)type_emb, (bf16_t*)out, Bn, F, X, E, out_bs, out_row_off),
+        hipLaunchKernelGGL((add_frame_type_fwd_kernel<float>), dim3(grid_for(work)), dim3(256), 0, st, (const float*)in, (const float*)frame_emb, (const float*)type_emb, (float*)out, Bn, F, X, E, out_bs, out_row_off));
+    return valor_launch_status();
+}
+// din [Bn,F,X,E] = slice of dout ; dframe [F,E] = sum_{b,x} din
+extern "C" int valor_add_frame_type_bwd(void* stream, int dtype, const void* dout, void* din, void* dframe, int Bn, int F, int X,
+                                        int E, int64_t out_bs, int64_t out_row_off) {
+    if (Bn <= 0) return VALOR_OK;
+    if (E & 3) return VALOR_ERR_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    const int64_t work = (int64_t)Bn * F * X * E / 4, work2 = (int64_t)F * E / 4;
+    DISPATCH_T(dtype,
+        { hipLaunchKernelGGL((add_frame_type_bwd_kernel<bf16_t>), dim3(grid_for(work)), dim3(256), 0, st, (const bf16_t*)dout, (bf16_t*)din, Bn, F, X, E, out_bs, out_row_off);
+          hipLaunchKernelGGL((frame_sum_kernel<bf16_t>), dim3(grid_for(work2, 256, 1 << 20)), dim3(256), 0, st, (const bf16_t*)din, (bf16_t*)dframe, Bn, F, X, E); },
+        { hipLaunchKernelGGL((add_frame_type_bwd_kernel<float>), dim3(grid_for(work)), dim3(256), 0, st, (const float*)dout, (float*)din, Bn, F, X, E, out_bs, out_row_off);
+          hipLaunchKernelGGL((frame_sum_kernel<float>), dim3(grid_for(work2, 256, 1 << 20)), dim3(256), 0, st, (const float*)din, (float*)dframe, Bn, F, X, E); });
+    return valor_launch_status();
+}
+
+extern "C" int valor_l2norm_fwd(void* stream, int dtype, const void* x, void* y, float* norm, int64_t rows, int cols) {
+    if (rows <= 0) return VALOR_OK;
+    if (cols & 3) return VALOR_ERR_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    DISPATCH_T(dtype,
+        hipLaunchKernelGGL((l2norm_fwd_kernel<bf16_t>), dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, (const bf16_t*)x, (bf16_t*)y, norm, rows, cols),
+        hipLaunchKernelGGL((l2norm_fwd_kernel<float>), dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, (const float*)x, (float*)y, norm, rows, cols));
+    return valor_launch_status();
+}
+extern "C" int valor_l2norm_bwd(void* stream, int dtype, const void* y, const void* dy, const float* norm, void* dx, int64_t rows, int cols) {
+    if (rows <= 0) return VALOR_OK;
+    if (cols & 3) return VALOR_ERR_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    DISPATCH_T(dtype,
+        hipLaunchKernelGGL((l2norm_bwd_kernel<bf16_t>), dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, (const bf16_t*)y, (const bf16_t*)dy, norm, (bf16_t*)dx, rows, cols),
+        hipLaunchKernelGGL((l2norm_bwd_kernel<float>), dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, (const float*)y, (const float*)dy, norm, (float*)dx, rows, cols));
+    return valor_launch_status();
+}
+
+extern "C" int valor_gather_rows(void* stream, int dtype, const void* src, const int64_t* idx, void* out, int64_t n, int E, int64_t src_ld) {
+    if (n <= 0) return VALOR_OK;
+    if ((E & 3) || (src_ld & 3)) return VALOR_ERR_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    DISPATCH_T(dtype,
+        hipLaunchKernelGGL((gather_rows_kernel<bf16_t>), dim3(grid_for(n * E / 4)), dim3(256), 0, st, (const bf16_t*)src, idx, (bf16_t*)out, n, E, src_ld),
+        hipLaunchKernelGGL((gather_rows_kernel<float>), dim3(grid_for(n * E / 4)), dim3(256), 0, st, (const float*)src, idx, (float*)out, n, E, src_ld));
+    return valor_launch_status();
+}
+extern "C" int valor_scatter_rows(void* stream, int dtype, const void* src, const int64_t* idx, void* dst, int64_t n, int E, int64_t dst_ld) {
+    if (n <= 0) return VALOR_OK;
+    if ((E & 3) || (dst_ld & 3)) return VALOR_ERR_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    DISPATCH_T(dtype,
+        hipLaunchKernelGGL((scatter_rows_kernel<bf16_t>), dim3(grid_for(n * E / 4)), dim3(256), 0, st, (const bf16_t*)src, idx, (bf16_t*)dst, n, E, dst_ld),
+        hipLaunchKernelGGL((scatter_rows_kernel<float>), dim3(grid_for(n * E / 4)), dim3(256), 0, st, (const float*)src, idx, (float*)dst, n, E, dst_ld));
+    return valor_launch_status();
+}
+extern "C" int valor_cast_from_f32(void* stream, int dtype, const float* in, void* out, int64_t n) {
+    if (n <= 0) return VALOR_OK;
+    if (n & 3) return VALOR_ERR_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    DISPATCH_T(dtype,
+        hipLaunchKernelGGL((cast_from_f32_kernel<bf16_t>), dim3(grid_for(n / 4)), dim3(256), 0, st, in, (bf16_t*)out, n / 4),
+        hipLaunchKernelGGL((cast_from_f32_kernel<float>), dim3(grid_for(n / 4)), dim3(256), 0, st, in, (float*)out, n / 4));
+    return valor_launch_status();
+}

@@ -1,0 +1,198 @@
+"""Synthetic, seeded inputs and random-init weights of the VALOR architecture (no network here for
+checkpoints or datasets). The state dict uses the reference's key names and shapes
+(probed from model/pretrain.py::VALOR.state_dict()), so the same tensors load
+into the reference (strict), the oracle and valor_amd.
+"""
+from dataclasses import dataclass, asdict
+
+import torch
+
+
+@dataclass
+class ValorSpec:
+    """Architecture hyper-parameters (defaults = VALOR-base, CLIP-ViT-B/16 variant,
+    config/pretrain-VALOR-base.json). head_dim is 64 everywhere (width = 64 * heads)."""
+    # CLIP visual (model/clip.py:220-274)
+    vis_width: int = 768
+    vis_layers: int = 12
+    patch: int = 16
+    resolution: int = 224
+    # CLIP text (model/clip.py:317-331)
+    txt_width: int = 512
+    txt_layers: int = 12
+    ctx_len: int = 77
+    clip_vocab: int = 49408
+    embed_dim: int = 512          # CLIP joint dim == contra_dim; text heads = embed_dim // 64 (clip.py:508)
+    # AST (model/modeling.py:270-278, 738-762)
+    aud_width: int = 768
+    aud_layers: int = 12
+    aud_inter: int = 3072
+    melbins: int = 64
+    target_len: int = 512
+    aud_patch: int = 16
+    # BERT multimodal decoder (model/bert.py:70-81)
+    hidden: int = 768
+    layers: int = 12
+    inter: int = 3072
+    vocab: int = 30522
+    max_pos: int = 512
+
+    @property
+    def vis_heads(self):
+        return self.vis_width // 64
+
+    @property
+    def txt_heads(self):
+        return self.embed_dim // 64
+
+    @property
+    def aud_heads(self):
+        return self.aud_width // 64
+
+    @property
+    def heads(self):
+        return self.hidden // 64
+
+    @property
+    def vis_tokens(self):
+        return (self.resolution // self.patch) ** 2 + 1
+
+    @property
+    def aud_tokens(self):
+        return (self.melbins // self.aud_patch) * (self.target_len // self.aud_patch) + 1
+
+    def to_dict(self):
+        return asdict(self)
+
+
+def base_spec():
+    return ValorSpec()
+
+
+def tiny_spec():
+    """Small architecture for fast unit tests (same code paths, every dim a multiple of 64)."""
+    return ValorSpec(vis_width=128, vis_layers=2, patch=16, resolution=64, txt_width=128, txt_layers=2, ctx_len=77,
+                     clip_vocab=1200, embed_dim=128, aud_width=128, aud_layers=2, aud_inter=256, melbins=32,
+                     target_len=64, aud_patch=16, hidden=128, layers=2, inter=256, vocab=1200, max_pos=64)
+
+
+def state_dict_layout(spec: ValorSpec):
+    """Ordered (key, shape, kind) of the CLIP-variant VALOR state dict. kind: w (weight), b (bias), g (LN gain), s (scalar)."""
+    H, W, TW, AW, E = spec.hidden, spec.vis_width, spec.txt_width, spec.aud_width, spec.embed_dim
+    L = []
+    add = lambda k, s, kind="w": L.append((k, tuple(s), kind))
+    add("video_type_embeddings", (1, 1, H)); add("audio_type_embeddings", (1, 1, H))
+    add("video_frame_embedding", (1, 32, H)); add("audio_frame_embedding", (1, 32, H))
+    add("contra_temp", (), "s")
+    add("clip_model.positional_embedding", (spec.ctx_len, TW)); add("clip_model.text_projection", (TW, E))
+    add("clip_model.logit_scale", (), "s")
+    add("clip_model.visual.class_embedding", (W,)); add("clip_model.visual.positional_embedding", (spec.vis_tokens, W))
+    add("clip_model.visual.proj", (W, E)); add("clip_model.visual.conv1.weight", (W, 3, spec.patch, spec.patch))
+    add("clip_model.visual.ln_pre.weight", (W,), "g"); add("clip_model.visual.ln_pre.bias", (W,), "b")
+
+    def clip_blocks(prefix, width, n):
+        for i in range(n):
+            p = f"{prefix}.resblocks.{i}."
+            add(p + "attn.in_proj_weight", (3 * width, width)); add(p + "attn.in_proj_bias", (3 * width,), "b")
+            add(p + "attn.out_proj.weight", (width, width)); add(p + "attn.out_proj.bias", (width,), "b")
+            add(p + "ln_1.weight", (width,), "g"); add(p + "ln_1.bias", (width,), "b")
+            add(p + "mlp.c_fc.weight", (4 * width, width)); add(p + "mlp.c_fc.bias", (4 * width,), "b")
+            add(p + "mlp.c_proj.weight", (width, 4 * width)); add(p + "mlp.c_proj.bias", (width,), "b")
+            add(p + "ln_2.weight", (width,), "g"); add(p + "ln_2.bias", (width,), "b")
+    clip_blocks("clip_model.visual.transformer", W, spec.vis_layers)
+    add("clip_model.visual.ln_post.weight", (W,), "g"); add("clip_model.visual.ln_post.bias", (W,), "b")
+    clip_blocks("clip_model.transformer", TW, spec.txt_layers)
+    add("clip_model.token_embedding.weight", (spec.clip_vocab, TW))
+    add("clip_model.ln_final.weight", (TW,), "g"); add("clip_model.ln_final.bias", (TW,), "b")
+    add("clip_model.prompt_embedding.weight", (1, TW))
+
+    add("audio_embeddings.cls_token", (1, 1, AW))
+    add("audio_embeddings.first_conv.weight", (AW, 1, spec.aud_patch, spec.aud_patch)); add("audio_embeddings.first_conv.bias", (AW,), "b")
+    add("audio_embeddings.position_embeddings.weight", (spec.aud_tokens, AW))
+    for i in range(spec.aud_layers):
+        p = f"audio_encoder.layer.{i}."
+        for j in range(4):
+            add(p + f"attention.linears.{j}.weight", (AW, AW)); add(p + f"attention.linears.{j}.bias", (AW,), "b")
+        add(p + "ff_layer.linear1.weight", (spec.aud_inter, AW)); add(p + "ff_layer.linear1.bias", (spec.aud_inter,), "b")
+        add(p + "ff_layer.linear2.weight", (AW, spec.aud_inter)); add(p + "ff_layer.linear2.bias", (AW,), "b")
+        add(p + "layernorm1.weight", (AW,), "g"); add(p + "layernorm1.bias", (AW,), "b")
+        add(p + "layernorm2.weight", (AW,), "g"); add(p + "layernorm2.bias", (AW,), "b")
+    add("audio_encoder.last_layernorm.weight", (AW,), "g"); add("audio_encoder.last_layernorm.bias", (AW,), "b")
+
+    e = "multimodal_encoder.embeddings."
+    add(e + "word_embeddings.weight", (spec.vocab, H)); add(e + "position_embeddings.weight", (spec.max_pos, H))
+    add(e + "token_type_embeddings.weight", (2, H)); add(e + "prompt_embedding.weight", (1, H))
+    add(e + "LayerNorm.weight", (H,), "g"); add(e + "LayerNorm.bias", (H,), "b")
+    for i in range(spec.layers):
+        p = f"multimodal_encoder.encoder.layer.{i}."
+        for blk in ("attention.self", "cross_attn.cross"):
+            for n in ("query", "key", "value"):
+                add(p + f"{blk}.{n}.weight", (H, H)); add(p + f"{blk}.{n}.bias", (H,), "b")
+            out = blk.split(".")[0] + ".output."
+            add(p + out + "dense.weight", (H, H)); add(p + out + "dense.bias", (H,), "b")
+            add(p + out + "LayerNorm.weight", (H,), "g"); add(p + out + "LayerNorm.bias", (H,), "b")
+        add(p + "intermediate.dense.weight", (spec.inter, H)); add(p + "intermediate.dense.bias", (spec.inter,), "b")
+        add(p + "output.dense.weight", (H, spec.inter)); add(p + "output.dense.bias", (H,), "b")
+        add(p + "output.LayerNorm.weight", (H,), "g"); add(p + "output.LayerNorm.bias", (H,), "b")
+    add("multimodal_encoder.pooler.dense.weight", (H, H)); add("multimodal_encoder.pooler.dense.bias", (H,), "b")
+    add("cls.dense.weight", (H, H)); add("cls.dense.bias", (H,), "b")
+    add("cls.layernorm.weight", (H,), "g"); add("cls.layernorm.bias", (H,), "b")
+    add("cls.decoder.weight", (spec.vocab, H), "tied"); add("cls.decoder.bias", (spec.vocab,), "b")
+    add("contra_head_a.linear.weight", (E, AW))
+    for m in ("text", "video", "audio"):
+        add(f"{m}_fine_weight.0.weight", (E, E)); add(f"{m}_fine_weight.0.bias", (E,), "b")
+        add(f"{m}_fine_weight.2.weight", (1, E)); add(f"{m}_fine_weight.2.bias", (1,), "b")
+    return L
+
+
+def make_state_dict(spec: ValorSpec, seed: int = 50, w_std: float = 0.02):
+    """Seeded random-init state dict (fp32, CPU). LN gains 1 + 0.1 N(0,1), biases 0.02 N(0,1),
+    weights w_std N(0,1); logit_scale = ln(1/0.07), contra_temp = 0.07; cls.decoder.weight is tied."""
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    sd = {}
+    import math
+    for k, shape, kind in state_dict_layout(spec):
+        if kind == "tied":
+            sd[k] = sd["multimodal_encoder.embeddings.word_embeddings.weight"]
+        elif kind == "s":
+            sd[k] = torch.tensor(math.log(1 / 0.07) if "logit_scale" in k else 0.07)
+        elif kind == "g":
+            sd[k] = 1.0 + 0.1 * torch.randn(shape, generator=g)
+        elif kind == "b":
+            sd[k] = 0.02 * torch.randn(shape, generator=g)
+        else:
+            sd[k] = w_std * torch.randn(shape, generator=g)
+    return sd
+
+
+def make_batch(spec: ValorSpec, batch: int, frames: int = 8, audio_slices: int = 2, txt_len: int = 32, seed: int = 50):
+    """Synthetic batch with the schema of data/data.py:423-428 (valor_collate), CPU tensors."""
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    video = torch.randn((batch, frames, 3, spec.resolution, spec.resolution), generator=g)
+    audio = torch.randn((batch, audio_slices, spec.melbins, spec.target_len), generator=g)
+    bert = torch.zeros((batch, txt_len), dtype=torch.long)
+    clip = torch.zeros((batch, txt_len), dtype=torch.long)
+    lo = min(1000, spec.vocab // 2)
+    for i in range(batch):
+        n = int(torch.randint(5, txt_len - 1, (1,), generator=g))
+        bert[i, 0] = 101; bert[i, 1:1 + n] = torch.randint(lo, spec.vocab, (n,), generator=g); bert[i, 1 + n] = 102
+        clip[i, 0] = spec.clip_vocab - 2
+        clip[i, 1:1 + n] = torch.randint(min(1000, spec.clip_vocab // 2), spec.clip_vocab - 2, (n,), generator=g)
+        clip[i, 1 + n] = spec.clip_vocab - 1
+    return {"ids": list(range(batch)), "txt_tokens": {"bert_tokens": bert, "clip_tokens": clip},
+            "video_pixels": video, "audio_spectrograms": audio}
+
+
+PROMPT_WORDS = ("describe the video with natural language predict masked tokens visual and audio cues project "
+                "in common space").split()
+
+
+def synthetic_vocab(size: int = 30522):
+    """WordPiece vocab with [PAD]=0 [UNK]=100 [CLS]=101 [SEP]=102 [MASK]=103 and the task-prompt words
+    (model/pretrain.py:438,492,505,516) as whole tokens at 2000+ (or 200+ for tiny vocabularies)."""
+    toks = [f"[unused{i}]" for i in range(size)]
+    toks[0] = "[PAD]"; toks[100] = "[UNK]"; toks[101] = "[CLS]"; toks[102] = "[SEP]"; toks[103] = "[MASK]"
+    base = 2000 if size > 4000 else 200
+    for i, w in enumerate(dict.fromkeys(PROMPT_WORDS)):
+        toks[base + i] = w
+    return toks
