@@ -366,3 +366,102 @@ extern "C" int valor_cast_from_f32(void* stream, int dtype, const float* in, voi
         hipLaunchKernelGGL((cast_from_f32_kernel<float>), dim3(grid_for(n / 4)), dim3(256), 0, st, in, (float*)out, n / 4));
     return valor_launch_status();
 }
+
+// du = dh * act'(u)   (backward of a fused bias+activation epilogue when no following GEMM can absorb it:
+// BERTPredictionHead dense -> GELU -> LN, modeling.py:249-252)
+template <typename T>
+__global__ void dact_mul_kernel(const T* dh, const T* u, T* du, int64_t n4, int act) {
+    for (int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; q < n4; q += (int64_t)gridDim.x * blockDim.x) {
+        f32x4_t a = load4<T>(dh + q * 4), b = load4<T>(u + q * 4);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) a[k] *= act_bwd(act, b[k]);
+        store4<T>(du + q * 4, a);
+    }
+}
+extern "C" int valor_dact_mul(void* stream, int dtype, const void* dh, const void* u, void* du, int64_t n, int act) {
+    if (n <= 0) return VALOR_OK;
+    if (n & 3) return VALOR_ERR_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    DISPATCH_T(dtype,
+        hipLaunchKernelGGL((dact_mul_kernel<bf16_t>), dim3(grid_for(n / 4)), dim3(256), 0, st, (const bf16_t*)dh, (const bf16_t*)u, (bf16_t*)du, n / 4, act),
+        hipLaunchKernelGGL((dact_mul_kernel<float>), dim3(grid_for(n / 4)), dim3(256), 0, st, (const float*)dh, (const float*)u, (float*)du, n / 4, act));
+    return valor_launch_status();
+}
+// mean of n fp32 values -> out[0] (single workgroup; n is small: masked-token rows)
+__global__ __launch_bounds__(256) void mean_f32_kernel(const float* x, int64_t n, float* out) {
+    __shared__ float red[4];
+    float s = 0.f;
+    for (int64_t i = threadIdx.x; i < n; i += 256) s += x[i];
+    s = wave_sum(s);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) *out = (red[0] + red[1] + red[2] + red[3]) / (float)n;
+}
+extern "C" int valor_mean_f32(void* stream, const float* x, int64_t n, float* out) {
+    if (n <= 0 || !x || !out) return VALOR_ERR_ARG;
+    hipLaunchKernelGGL(mean_f32_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, x, n, out);
+    return valor_launch_status();
+}
+
+// ---------------------------------------------------------------------------------------------
+// row dot: y[m] = <x[m,:], w> + b   (second Linear(E -> 1) of the fine-weight MLPs, pretrain.py:104-112)
+// backward: dx[m,k] = dy[m] w[k] ; dw[k] = sum_m dy[m] x[m,k] ; db = sum_m dy[m]
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void rowdot_fwd_kernel(const T* x, const T* w, const T* b, T* y, int64_t rows, int cols) {
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (row >= rows) return;
+    float s = 0.f;
+    for (int c = lane * 4; c < cols; c += 256) {
+        f32x4_t a = load4<T>(x + row * cols + c), ww = load4<T>(w + c);
+        s += a[0] * ww[0] + a[1] * ww[1] + a[2] * ww[2] + a[3] * ww[3];
+    }
+    s = wave_sum(s);
+    if (lane == 0) y[row] = from_f32<T>(s + (b ? to_f32<T>(b[0]) : 0.f));
+}
+template <typename T>
+__global__ void rowdot_bwd_dx_kernel(const T* dy, const T* w, T* dx, int64_t rows, int cols) {
+    const int C4 = cols / 4;
+    for (int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; q < rows * C4; q += (int64_t)gridDim.x * blockDim.x) {
+        const int c = (int)(q % C4) * 4;
+        const int64_t r = q / C4;
+        store4<T>(dx + r * cols + c, load4<T>(w + c) * to_f32<T>(dy[r]));
+    }
+}
+// one thread per 4 columns; loops over all rows (rows is small: global batch x tokens)
+template <typename T>
+__global__ void rowdot_bwd_dw_kernel(const T* dy, const T* x, T* dw, T* db, int64_t rows, int cols) {
+    const int q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q * 4 >= cols) return;
+    f32x4_t s = {0.f, 0.f, 0.f, 0.f};
+    float sb = 0.f;
+    for (int64_t r = 0; r < rows; ++r) {
+        const float g = to_f32<T>(dy[r]);
+        s += load4<T>(x + r * cols + q * 4) * g;
+        sb += g;
+    }
+    store4<T>(dw + q * 4, s);
+    if (q == 0 && db) db[0] = from_f32<T>(sb);
+}
+extern "C" int valor_rowdot_fwd(void* stream, int dtype, const void* x, const void* w, const void* b, void* y, int64_t rows, int cols) {
+    if (rows <= 0) return VALOR_OK;
+    if (cols & 3) return VALOR_ERR_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    DISPATCH_T(dtype,
+        hipLaunchKernelGGL((rowdot_fwd_kernel<bf16_t>), dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, (const bf16_t*)x, (const bf16_t*)w, (const bf16_t*)b, (bf16_t*)y, rows, cols),
+        hipLaunchKernelGGL((rowdot_fwd_kernel<float>), dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, (const float*)x, (const float*)w, (const float*)b, (float*)y, rows, cols));
+    return valor_launch_status();
+}
+extern "C" int valor_rowdot_bwd(void* stream, int dtype, const void* dy, const void* x, const void* w, void* dx, void* dw, void* db,
+                                int64_t rows, int cols) {
+    if (rows <= 0) return VALOR_OK;
+    if (cols & 3) return VALOR_ERR_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    DISPATCH_T(dtype,
+        { hipLaunchKernelGGL((rowdot_bwd_dx_kernel<bf16_t>), dim3(grid_for(rows * cols / 4)), dim3(256), 0, st, (const bf16_t*)dy, (const bf16_t*)w, (bf16_t*)dx, rows, cols);
+          hipLaunchKernelGGL((rowdot_bwd_dw_kernel<bf16_t>), dim3((cols / 4 + 63) / 64), dim3(64), 0, st, (const bf16_t*)dy, (const bf16_t*)x, (bf16_t*)dw, (bf16_t*)db, rows, cols); },
+        { hipLaunchKernelGGL((rowdot_bwd_dx_kernel<float>), dim3(grid_for(rows * cols / 4)), dim3(256), 0, st, (const float*)dy, (const float*)w, (float*)dx, rows, cols);
+          hipLaunchKernelGGL((rowdot_bwd_dw_kernel<float>), dim3((cols / 4 + 63) / 64), dim3(64), 0, st, (const float*)dy, (const float*)x, (float*)dw, (float*)db, rows, cols); });
+    return valor_launch_status();
+}

@@ -1,0 +1,140 @@
+"""Data-parallel pieces: one process per GPU, torch.distributed over RCCL/xGMI ('nccl' backend on ROCm;
+'gloo' on CPU for tests). Replaces utils/distributed.py + torch DDP (train_utils.py:232).
+
+  * packed_allgather_with_grads: ONE all_gather of a packed [feat_t | feat_v | feat_a | tokens] buffer
+    instead of the reference's 8 collectives + 4 host syncs per step (ddp_allgather_with_grads ->
+    size all_gather + .item() + padded all_gather, utils/distributed.py:38-93, x4). Training uses
+    drop_last=True (train_utils.py:591) so per-rank sizes are equal. Backward returns the LOCAL slice of
+    the incoming gradient and performs no collective -- exactly utils/distributed.py:62-72.
+  * Reducer: gradient all-reduce (SUM; the 1/world mean is folded into the optimizer's gradient scale)
+    straight on contiguous ranges of the flat gradient arena, bucketed in reverse execution order and
+    launched from post-accumulate-grad hooks on a side stream so it overlaps the rest of backward.
+    Parameters that receive no gradient for the current task (find_unused_parameters semantics) are
+    learnt on the first (synchronous) step; their arena ranges stay zero and ride along in the buckets.
+"""
+import torch
+import torch.distributed as dist
+from torch.autograd import Function
+
+
+def is_dist():
+    return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+
+
+class _PackedGather(Function):
+    @staticmethod
+    def forward(ctx, *feats):
+        world, rank = dist.get_world_size(), dist.get_rank()
+        ctx.meta = [(f.shape, f.numel()) for f in feats]
+        ctx.rank, ctx.world = rank, world
+        flat = torch.cat([f.reshape(-1) for f in feats])
+        out = torch.empty(world * flat.numel(), dtype=flat.dtype, device=flat.device)
+        dist.all_gather_into_tensor(out, flat) if flat.is_cuda else dist.all_gather(list(out.chunk(world)), flat)
+        out = out.view(world, -1)
+        res, o = [], 0
+        for shape, n in ctx.meta:
+            res.append(out[:, o:o + n].reshape(world * shape[0], *shape[1:]).contiguous())
+            o += n
+        return tuple(res)
+
+    @staticmethod
+    def backward(ctx, *grads):
+        outs = []
+        for g, (shape, _) in zip(grads, ctx.meta):
+            b = shape[0]
+            outs.append(g[ctx.rank * b:(ctx.rank + 1) * b] if g is not None else None)   # local slice, no collective
+        return tuple(outs)
+
+
+def packed_allgather_with_grads(feat_t, feat_v, feat_a, tokens_cpu):
+    """Gather contrastive features (with local-slice backward) and the text tokens across ranks."""
+    feats = [f for f in (feat_t, feat_v, feat_a) if f is not None]
+    dev, dt = feats[0].device, feats[0].dtype
+    # tokens ride in the same buffer as exact small integers split into two 8-bit-safe halves
+    tok = tokens_cpu.to(dev)
+    tok_parts = torch.stack(((tok // 256).to(dt), (tok % 256).to(dt)), dim=-1)      # exact in bf16 (<= 256 each... up to 49408/256 = 193)
+    gathered = _PackedGather.apply(*feats, tok_parts)
+    gi = iter(gathered[:-1])
+    ft = next(gi) if feat_t is not None else None
+    fv = next(gi) if feat_v is not None else None
+    fa = next(gi) if feat_a is not None else None
+    tp = gathered[-1].detach().float()
+    tokens = (tp[..., 0] * 256 + tp[..., 1]).round().long().cpu()
+    return ft, fv, fa, tokens
+
+
+class Reducer:
+    def __init__(self, arena, bucket_bytes=48 << 20):
+        self.arena = arena
+        self.world = dist.get_world_size() if is_dist() else 1
+        esz = arena.flat.element_size()
+        # buckets = contiguous arena ranges, walked from the END (gradients become ready in reverse order)
+        names = list(arena.offsets)
+        self.buckets, cur, cur_bytes = [], [], 0
+        for n in reversed(names):
+            s, e = arena.range_of(n)
+            cur.append(n); cur_bytes += (e - s) * esz
+            if cur_bytes >= bucket_bytes:
+                self.buckets.append(cur); cur, cur_bytes = [], 0
+        if cur:
+            self.buckets.append(cur)
+        self.bucket_range = [(min(arena.range_of(n)[0] for n in b), max(arena.range_of(n)[1] for n in b)) for b in self.buckets]
+        self.bucket_of = {n: i for i, b in enumerate(self.buckets) for n in b}
+        self.expected = None           # per-bucket set of names that get a grad for the current task
+        self.touched = set()
+        self.pending, self.works = None, []
+        self.comm_stream = torch.cuda.Stream() if arena.flat.is_cuda else None
+        for name, p in arena.params.items():
+            p.register_post_accumulate_grad_hook(self._make_hook(name))
+
+    def _make_hook(self, name):
+        def hook(param):
+            self.touched.add(name)
+            if self.pending is None:
+                return
+            i = self.bucket_of[name]
+            s = self.pending[i]
+            s.discard(name)
+            if not s and self.expected[i]:
+                self._launch(i)
+        return hook
+
+    def _launch(self, i):
+        if self.world == 1:
+            return
+        s, e = self.bucket_range[i]
+        buf = self.arena.grad[s:e]
+        if self.comm_stream is not None:
+            ev = torch.cuda.Event(); ev.record()
+            with torch.cuda.stream(self.comm_stream):
+                self.comm_stream.wait_event(ev)
+                self.works.append(dist.all_reduce(buf, op=dist.ReduceOp.SUM, async_op=True))
+        else:
+            self.works.append(dist.all_reduce(buf, op=dist.ReduceOp.SUM, async_op=True))
+
+    def prepare_backward(self):
+        self.touched = set()
+        self.works = []
+        self.pending = [set(x) for x in self.expected] if self.expected is not None else None
+
+    def finish_backward(self):
+        """Wait for the bucket all-reduces (or, on the first step of a task, reduce everything at once and
+        learn which parameters are used)."""
+        if self.expected is None or self.touched != set().union(*self.expected):
+            if self.pending is not None:       # the used-parameter set changed (new task): redo synchronously
+                for w in self.works:
+                    w.wait()
+                raise RuntimeError("used-parameter set changed between steps; call reset_task() when switching tasks")
+            self.expected = [set(n for n in b if n in self.touched) for b in self.buckets]
+            if self.world > 1:
+                dist.all_reduce(self.arena.grad, op=dist.ReduceOp.SUM)
+        else:
+            for w in self.works:
+                w.wait()
+            if self.comm_stream is not None:
+                torch.cuda.current_stream().wait_stream(self.comm_stream)
+        self.pending = None
+        return set(self.touched)
+
+    def reset_task(self):
+        self.expected = None

@@ -31,6 +31,34 @@ SIGNATURES = {
     "valor_attn_bwd": [_vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i,
                        _i64, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _i64,
                        _vp, _i64, _i64, _vp, _i, _f, _f, _u64, _u64],
+    "valor_xent_fwd": [_vp, _i, _vp, _vp, _vp, _vp, _i64, _i, _i64],
+    "valor_xent_bwd": [_vp, _i, _vp, _vp, _vp, _vp, _f, _i64, _i, _i64],
+    "valor_fine_weight_softmax": [_vp, _vp, _vp, _vp, _i, _i],
+    "valor_fine_weight_softmax_bwd": [_vp, _vp, _vp, _vp, _i, _i],
+    "valor_fine_reduce_fwd": [_vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i],
+    "valor_infonce_fwd": [_vp, _vp, _vp, _vp, _vp, _vp, _i],
+    "valor_infonce_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i],
+    "valor_fine_reduce_bwd": [_vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _i, _i, _i],
+    "valor_adamw_chunk": [],
+    "valor_adamw": [_vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _c.POINTER(_f), _c.POINTER(_f), _i, _f, _f, _f, _i, _i, _vp, _i],
+    "valor_grad_norm_clip": [_vp, _i, _vp, _vp, _i64, _f, _f, _vp, _vp, _vp],
+    "valor_patchify": [_vp, _i, _vp, _vp, _i, _i, _i, _i, _i],
+    "valor_assemble_tokens_fwd": [_vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i],
+    "valor_assemble_tokens_bwd": [_vp, _i, _vp, _vp, _vp, _i, _i, _i],
+    "valor_sum_over_batch": [_vp, _i, _vp, _vp, _i, _i, _i],
+    "valor_embed_fwd": [_vp, _i, _vp, _vp, _vp, _vp, _vp, _i64, _i, _i],
+    "valor_embed_bwd_word": [_vp, _i, _vp, _vp, _vp, _i64, _i],
+    "valor_add_frame_type_fwd": [_vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i64, _i64],
+    "valor_add_frame_type_bwd": [_vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i64, _i64],
+    "valor_l2norm_fwd": [_vp, _i, _vp, _vp, _vp, _i64, _i],
+    "valor_l2norm_bwd": [_vp, _i, _vp, _vp, _vp, _vp, _i64, _i],
+    "valor_gather_rows": [_vp, _i, _vp, _vp, _vp, _i64, _i, _i64],
+    "valor_scatter_rows": [_vp, _i, _vp, _vp, _vp, _i64, _i, _i64],
+    "valor_cast_from_f32": [_vp, _i, _vp, _vp, _i64],
+    "valor_dact_mul": [_vp, _i, _vp, _vp, _vp, _i64, _i],
+    "valor_mean_f32": [_vp, _vp, _i64, _vp],
+    "valor_rowdot_fwd": [_vp, _i, _vp, _vp, _vp, _vp, _i64, _i],
+    "valor_rowdot_bwd": [_vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i],
     "valor_colsum": [_vp, _i, _vp, _i64, _i, _i64, _vp, _vp, _i, _i],
 }
 

@@ -1,0 +1,481 @@
+"""MI355X-native VALOR pretraining model: host-side mirror of the reference interface
+(model/pretrain.py::VALOR / model/modeling.py::VALORModel) whose arithmetic is entirely HIP kernels
+(valor_amd.ops -> libvalor_hip.so).
+
+Drop-in surface kept from the reference:
+  * VALOR.from_pretrained(opts, state_dict)          (modeling.py:107-115, strict=False semantics)
+  * VALOR.forward(batch, task, compute_loss=True)    (pretrain.py:125-134; 'pt_*' tasks -> forward_pt :214-541)
+  * batch schema of valor_collate                    (data/data.py:423-428)
+  * state_dict() / load_state_dict() key names       (utils/save.py:45-64 checkpoints)
+Design differences (MI355X-first, results identical):
+  * token-major [N, L, E] activations everywhere, fused QKV / KV projections from packed weights,
+    flash attention reading the fused GEMM output in place;
+  * cross-attention K/V of the concatenated [video | audio] tokens are projected ONCE per decoder
+    layer and shared by all caption / mlm passes (the reference re-projects them in every pass,
+    bert.py:316-317,450); the caption-tva/-tv/-ta passes run as ONE batched decoder pass whose
+    query groups attend to different K/V row ranges;
+  * pre-LN blocks fuse residual-add + next LayerNorm (+ dropout) in one kernel; post-LN BERT fuses
+    bias + dropout + residual + LayerNorm;
+  * masked-row gather indices and attention masks come from the host-side TokenMasker (no device
+    round trip, modeling.py:134-174 runs on CPU in the reference too).
+"""
+import math
+import random
+
+import numpy as np
+import torch
+from torch import nn
+
+from .. import ops
+from ..arena import ParamArena
+from ..lib import ACT_GELU_ERF, ACT_QUICK_GELU, ACT_RELU
+from ..synth import ValorSpec, base_spec, synthetic_vocab
+from .params import optimizer_group, param_table
+
+PROMPTS = {
+    "caption": "describe the video with natural language",                     # pretrain.py:438
+    "mlm_tva": "predict masked tokens with visual and audio cues",             # pretrain.py:492
+    "mlm_tv": "predict masked tokens with visual cues",                        # pretrain.py:505
+    "mlm_ta": "predict masked tokens with audio cues",                         # pretrain.py:516
+    "contra": "project language in common space",                              # pretrain.py:256
+}
+
+
+class TokenMasker:
+    """Host-side BERT-style masking, same python-`random` draw order as the reference
+    (modeling.py:122-174): >= 1 masked token per row, 80/10/10 mask/random/keep, labels -1 elsewhere."""
+
+    def __init__(self, mask_token, range_start, range_end):
+        self.mask_token = mask_token
+        self.range = [range_start, range_end]
+
+    def __call__(self, tokens, mask_prob):
+        tokens = np.array(tokens.cpu().numpy())
+        ind = np.zeros(tokens.shape, dtype=np.int64)
+        for i in range(len(ind)):
+            while all(ind[i] == 0):
+                for j in range(1, len(ind[0])):
+                    if tokens[i][j] != 0 and random.random() < mask_prob:
+                        ind[i][j] = 1
+        labels = -np.ones(tokens.shape, dtype=np.int64)
+        choices = list(range(*self.range))
+        for i in range(tokens.shape[0]):
+            for j in range(tokens.shape[1]):
+                if ind[i][j] == 1:
+                    src = tokens[i][j]
+                    prob = random.random()
+                    if prob < 0.8:
+                        tokens[i][j] = self.mask_token
+                    elif prob < 0.9:
+                        tokens[i][j] = random.choice(choices)
+                    labels[i][j] = src
+        return torch.from_numpy(tokens).long(), torch.from_numpy(labels).long()
+
+
+def _opt(opts, name, default):
+    if opts is None:
+        return default
+    if isinstance(opts, dict):
+        return opts.get(name, default)
+    return getattr(opts, name, default)
+
+
+class VALOR(nn.Module):
+    def __init__(self, opts=None, spec: ValorSpec = None, dtype=torch.bfloat16, device="cuda", vocab_tokens=None):
+        super().__init__()
+        self.opts = opts
+        vtype = _opt(opts, "video_encoder_type", "clip_vit_base_16")
+        ttype = _opt(opts, "txt_encoder_type", "clip_vit_base_16")
+        if not (vtype.startswith("clip_vit_base") and ttype.startswith("clip_vit_base")):
+            raise NotImplementedError("round 1 covers the CLIP-ViT-B variant (config/pretrain-VALOR-base.json); "
+                                      f"got video={vtype} text={ttype}")
+        if _opt(opts, "contra_type", "fine") != "fine" or _opt(opts, "caption_type", "unimlm") != "unimlm":
+            raise NotImplementedError("contra_type='fine' and caption_type='unimlm' only")
+        if _opt(opts, "cross_attn_type", "va_concate") != "va_concate" or _opt(opts, "late_fusion", False) or _opt(opts, "full_masker", False):
+            raise NotImplementedError("cross_attn_type='va_concate', late_fusion=False, full_masker=False only")
+        if _opt(opts, "fineweight_type", "one") == "none":
+            raise NotImplementedError("fineweight_type='none' is a TypeError in the reference too (pretrain.py:330)")
+        self.spec = spec or base_spec()
+        self.dtype = dtype
+        self.device = torch.device(device)
+        self.use_task_prompt = bool(_opt(opts, "use_task_prompt", False))
+        self.contra_loss_ratio = float(_opt(opts, "contra_loss_ratio", 1.0))
+        self.p_drop = float(_opt(opts, "dropout", 0.1))          # bert json / base_cfg 0.1, train_utils.py:617
+        new_names = tuple(_opt(opts, "new_params_name", ()) or ())
+        self.table = param_table(self.spec)
+        entries = [(n, s, optimizer_group(refs[0], new_names)) for n, s, refs in self.table]
+        self.arena = ParamArena(entries, dtype, self.device)
+        self.P = self.arena.params
+        for name, p in self.P.items():
+            self.register_parameter(name.replace(".", "__"), p)
+        self.vocab_tokens = vocab_tokens if vocab_tokens is not None else synthetic_vocab(self.spec.vocab)
+        self.vocab = {t: i for i, t in enumerate(self.vocab_tokens)}
+        self.bos_token, self.eos_token, self.text_mask_token = self.vocab["[CLS]"], self.vocab["[SEP]"], self.vocab["[MASK]"]
+        self.text_masker = TokenMasker(self.text_mask_token, 106, self.spec.vocab)     # modeling.py:673
+        self.reducer = None
+        self.gather_fn = None          # set by valor_amd.dist for world_size > 1
+        self.collect = None            # optional dict: intermediate tensors for parity tests
+
+    # ------------------------------------------------------------------ checkpoint layout
+    @classmethod
+    def from_pretrained(cls, opts, state_dict, **kw):
+        model = cls(opts, **kw)
+        if state_dict:
+            model.load_state_dict(state_dict, strict=False)
+        return model
+
+    def state_dict(self, *a, **k):
+        """Reference-keyed state dict (fp32 CPU-agnostic views of the arena parameters)."""
+        out = {}
+        for name, shape, refs in self.table:
+            p = self.P[name].detach()
+            if len(refs) == 1 or refs[1] == "cls.decoder.weight":
+                for r in refs:
+                    out[r] = p
+            else:
+                rows = shape[0] // len(refs)
+                for i, r in enumerate(refs):
+                    out[r] = p[i * rows:(i + 1) * rows]
+        return out
+
+    def load_state_dict(self, sd, strict=True):
+        missing, used = [], set()
+        with torch.no_grad():
+            for name, shape, refs in self.table:
+                p = self.P[name]
+                if len(refs) == 1 or refs[1] == "cls.decoder.weight":
+                    if refs[0] in sd:
+                        p.copy_(sd[refs[0]].to(p.dtype).view(shape)); used.update(r for r in refs if r in sd)
+                    else:
+                        missing.append(refs[0])
+                else:
+                    rows = shape[0] // len(refs)
+                    for i, r in enumerate(refs):
+                        if r in sd:
+                            p[i * rows:(i + 1) * rows].copy_(sd[r].to(p.dtype)); used.add(r)
+                        else:
+                            missing.append(r)
+        unexpected = [k for k in sd if k not in used]
+        if strict and (missing or unexpected):
+            raise RuntimeError(f"load_state_dict: missing {missing[:5]} unexpected {unexpected[:5]}")
+        return missing, unexpected
+
+    def ref_named_groups(self):
+        """(internal name, optimizer group id) -- used by valor_amd.optim."""
+        return {n: self.arena.groups[n] for n, _, _ in self.table}
+
+    # ------------------------------------------------------------------ host helpers
+    def get_task_prompt(self, sentence, batch_size):
+        """modeling.py:355-369 (bert tokenizer branch): whole-word / greedy WordPiece lookup."""
+        ids = [self.bos_token]
+        for wd in sentence.lower().split():
+            if wd in self.vocab:
+                ids.append(self.vocab[wd]); continue
+            start, pieces, bad = 0, [], False
+            while start < len(wd):
+                end, cur = len(wd), None
+                while start < end:
+                    sub = wd[start:end] if start == 0 else "##" + wd[start:end]
+                    if sub in self.vocab:
+                        cur = sub; break
+                    end -= 1
+                if cur is None:
+                    bad = True; break
+                pieces.append(self.vocab[cur]); start = end
+            ids.extend([self.vocab.get("[UNK]", 100)] if bad else pieces)
+        ids.append(self.eos_token)
+        return torch.tensor(ids, dtype=torch.long).unsqueeze(0).expand(batch_size, -1).contiguous()
+
+    @staticmethod
+    def _bert_mask(tokens_cpu, prompt_cpu, casual):
+        """additive attention mask of BertModel.forward, bert.py:854-885 -> fp32 [B, T, T]"""
+        am = (tokens_cpu != 0).long()
+        token_len = am.shape[1]
+        if prompt_cpu is not None:
+            am = torch.cat((am, (prompt_cpu != 0).long()), dim=1)
+        total = am.shape[1]
+        am = am.unsqueeze(1).expand(-1, total, -1).clone()
+        if casual:
+            am[:, :token_len, :token_len] = torch.tril(am[:, :token_len, :token_len])
+            am[:, token_len:, :token_len] = 0
+        return ((1.0 - am.float()) * -10000.0).contiguous()
+
+    @staticmethod
+    def _clip_text_mask(tokens_cpu):
+        """clip.py:382-414 with casual=True -> fp32 [B, L, L]"""
+        L = tokens_cpu.shape[1]
+        m = (tokens_cpu != 0).long().unsqueeze(1).expand(-1, L, -1).clone()
+        m = torch.tril(m)
+        return ((1.0 - m.float()) * -10000.0).contiguous()
+
+    def _dev(self, t, dtype=None):
+        t = t.to(self.device, non_blocking=True)
+        return t.to(dtype) if dtype is not None else t
+
+    # ------------------------------------------------------------------ encoders
+    def _clip_blocks(self, x, prefix, n_layers, heads, mask, final_g, final_b):
+        """pre-LN CLIP transformer (clip.py:194-214) + final LayerNorm; x: [N, L, E] residual stream."""
+        P = self.P
+        y = ops.layer_norm(x, P[f"{prefix}.resblocks.0.ln_1.weight"], P[f"{prefix}.resblocks.0.ln_1.bias"], 1e-5)
+        for i in range(n_layers):
+            p = f"{prefix}.resblocks.{i}."
+            qkv = ops.linear(y, P[p + "attn.in_proj_weight"], P[p + "attn.in_proj_bias"])
+            a = ops.self_attention(qkv, heads, mask, 0.0)
+            o = ops.linear(a, P[p + "attn.out_proj.weight"], None)
+            x, y = ops.bias_dropout_residual_ln(o, P[p + "attn.out_proj.bias"], x, P[p + "ln_2.weight"], P[p + "ln_2.bias"], 1e-5, 0.0, True)
+            m = ops.mlp(y, P[p + "mlp.c_fc.weight"], P[p + "mlp.c_fc.bias"], P[p + "mlp.c_proj.weight"], P[p + "mlp.c_proj.bias"], ACT_QUICK_GELU)
+            if i + 1 < n_layers:
+                q = f"{prefix}.resblocks.{i + 1}."
+                x, y = ops.bias_dropout_residual_ln(m, None, x, P[q + "ln_1.weight"], P[q + "ln_1.bias"], 1e-5, 0.0, True)
+            else:
+                y = ops.bias_dropout_residual_ln(m, None, x, final_g, final_b, 1e-5, 0.0, False)
+        return y
+
+    def forward_video_encoder(self, video_pixels):
+        """modeling.py:449-465 (clip) -> VisionTransformer.forward clip.py:259-274. Returns [b, F, 197, W]."""
+        P, sp = self.P, self.spec
+        b, n, c, h, w = video_pixels.shape
+        imgs = self._dev(video_pixels.reshape(b * n, c, h, w).float())
+        patches = ops.patchify(imgs, sp.patch, self.dtype)
+        tok = ops.linear(patches, P["clip_model.visual.conv1.weight"].view(sp.vis_width, -1), None)
+        Pn = sp.vis_tokens - 1
+        x = ops.assemble_tokens(tok, P["clip_model.visual.class_embedding"], P["clip_model.visual.positional_embedding"], None, b * n, Pn)
+        x = ops.layer_norm(x, P["clip_model.visual.ln_pre.weight"], P["clip_model.visual.ln_pre.bias"], 1e-5)
+        y = self._clip_blocks(x, "clip_model.visual.transformer", sp.vis_layers, sp.vis_heads, None,
+                              P["clip_model.visual.ln_post.weight"], P["clip_model.visual.ln_post.bias"])
+        return y.view(b, n, sp.vis_tokens, sp.vis_width)
+
+    def forward_txt_encoder(self, clip_tokens_cpu):
+        """modeling.py:437-446 -> CLIP.encode_text(casual=True) clip.py:372-427. Returns [b, L, TW]."""
+        P, sp = self.P, self.spec
+        L = clip_tokens_cpu.shape[1]
+        ids = self._dev(clip_tokens_cpu)
+        x = ops.embed(ids, P["clip_model.token_embedding.weight"], P["clip_model.positional_embedding"], None, L)
+        mask = self._dev(self._clip_text_mask(clip_tokens_cpu))
+        return self._clip_blocks(x, "clip_model.transformer", sp.txt_layers, sp.txt_heads, mask,
+                                 P["clip_model.ln_final.weight"], P["clip_model.ln_final.bias"])
+
+    def forward_audio_encoder(self, audio):
+        """modeling.py:468-480; AudioEmbeddings :750-762; pre-LN TransformerEncoder transformer.py:74-85,156-170.
+        Returns [b, A, 129, AW]."""
+        P, sp, p = self.P, self.spec, (self.p_drop if self.training else 0.0)
+        b, n, hh, ww = audio.shape
+        spec_in = self._dev(audio.reshape(b * n, 1, hh, ww).float())
+        patches = ops.patchify(spec_in, sp.aud_patch, self.dtype)
+        tok = ops.linear(patches, P["audio_embeddings.first_conv.weight"].view(sp.aud_width, -1), None)
+        Pn = sp.aud_tokens - 1
+        x = ops.assemble_tokens(tok, P["audio_embeddings.cls_token"], P["audio_embeddings.position_embeddings.weight"],
+                                P["audio_embeddings.first_conv.bias"], b * n, Pn)
+        if p > 0:
+            x = ops.bias_dropout_residual(x, None, None, p)
+        y = ops.layer_norm(x, P["audio_encoder.layer.0.layernorm1.weight"], P["audio_encoder.layer.0.layernorm1.bias"], 1e-12)
+        for i in range(sp.aud_layers):
+            q = f"audio_encoder.layer.{i}."
+            qkv = ops.linear(y, P[q + "attention.qkv.weight"], P[q + "attention.qkv.bias"])
+            a = ops.self_attention(qkv, sp.aud_heads, None, p)
+            o = ops.linear(a, P[q + "attention.linears.3.weight"], None)
+            x, y = ops.bias_dropout_residual_ln(o, P[q + "attention.linears.3.bias"], x, P[q + "layernorm2.weight"], P[q + "layernorm2.bias"], 1e-12, p, True)
+            m = ops.mlp(y, P[q + "ff_layer.linear1.weight"], P[q + "ff_layer.linear1.bias"], P[q + "ff_layer.linear2.weight"],
+                        P[q + "ff_layer.linear2.bias"], ACT_GELU_ERF)
+            if i + 1 < sp.aud_layers:
+                r = f"audio_encoder.layer.{i + 1}."
+                x, y = ops.bias_dropout_residual_ln(m, None, x, P[r + "layernorm1.weight"], P[r + "layernorm1.bias"], 1e-12, p, True)
+            else:
+                y = ops.bias_dropout_residual_ln(m, None, x, P["audio_encoder.last_layernorm.weight"], P["audio_encoder.last_layernorm.bias"], 1e-12, p, False)
+        return y.view(b, n, sp.aud_tokens, sp.aud_width)
+
+    # ------------------------------------------------------------------ multimodal decoder
+    def _bert_embed(self, ids_dev, L, token_type):
+        """BertEmbeddings.forward bert.py:190-218: word + position + (token_type[0] | prompt) -> LN -> dropout"""
+        P, e = self.P, "multimodal_encoder.embeddings."
+        tv = P[e + "prompt_embedding.weight"][0] if token_type == "prompt" else P[e + "token_type_embeddings.weight"][0]
+        x = ops.embed(ids_dev, P[e + "word_embeddings.weight"], P[e + "position_embeddings.weight"], tv, L)
+        x = ops.layer_norm(x, P[e + "LayerNorm.weight"], P[e + "LayerNorm.bias"], 1e-12)
+        p = self.p_drop if self.training else 0.0
+        if p > 0:
+            x = ops.bias_dropout_residual(x, None, None, p)
+        return x
+
+    def project_cross_kv(self, va_input):
+        """K|V of the concatenated [video | audio] tokens, ONCE per decoder layer (shared by every pass)."""
+        P = self.P
+        return [ops.linear(va_input, P[f"multimodal_encoder.encoder.layer.{i}.cross_attn.cross.kv.weight"],
+                           P[f"multimodal_encoder.encoder.layer.{i}.cross_attn.cross.kv.bias"]) for i in range(self.spec.layers)]
+
+    def bert_encoder(self, x, mask, kv_layers, kv_range, kv_bmod):
+        """BertEncoder / BertLayer.forward bert.py:440-518 (post-LN; va_concate cross-attention)."""
+        P, H, p = self.P, self.spec.heads, (self.p_drop if self.training else 0.0)
+        for i in range(self.spec.layers):
+            q = f"multimodal_encoder.encoder.layer.{i}."
+            qkv = ops.linear(x, P[q + "attention.self.qkv.weight"], P[q + "attention.self.qkv.bias"])
+            a = ops.self_attention(qkv, H, mask, p)
+            o = ops.linear(a, P[q + "attention.output.dense.weight"], None)
+            x = ops.bias_dropout_residual_ln(o, P[q + "attention.output.dense.bias"], x, P[q + "attention.output.LayerNorm.weight"],
+                                             P[q + "attention.output.LayerNorm.bias"], 1e-12, p, False)
+            if kv_layers is not None:
+                cq = ops.linear(x, P[q + "cross_attn.cross.query.weight"], P[q + "cross_attn.cross.query.bias"])
+                c = ops.cross_attention(cq, kv_layers[i], H, kv_range, kv_bmod, p)
+                o = ops.linear(c, P[q + "cross_attn.output.dense.weight"], None)
+                x = ops.bias_dropout_residual_ln(o, P[q + "cross_attn.output.dense.bias"], x, P[q + "cross_attn.output.LayerNorm.weight"],
+                                                 P[q + "cross_attn.output.LayerNorm.bias"], 1e-12, p, False)
+            m = ops.mlp(x, P[q + "intermediate.dense.weight"], P[q + "intermediate.dense.bias"], P[q + "output.dense.weight"],
+                        P[q + "output.dense.bias"], ACT_GELU_ERF)
+            x = ops.bias_dropout_residual_ln(m, None, x, P[q + "output.LayerNorm.weight"], P[q + "output.LayerNorm.bias"], 1e-12, p, False)
+        return x
+
+    def cls_transform(self, rows):
+        """BERTPredictionHead dense -> GELU -> LayerNorm (modeling.py:249-252); the decoder GEMM follows."""
+        P = self.P
+        h = ops.linear(rows, P["cls.dense.weight"], P["cls.dense.bias"], ACT_GELU_ERF)
+        return ops.layer_norm(h, P["cls.layernorm.weight"], P["cls.layernorm.bias"], 1e-12)
+
+    def _decoder_groups(self, txt_input, txt_labels, groups, prompt_cpu, casual, kv_layers, ranges, b, compute_loss, tag, out):
+        """Run the decoder for len(groups) query groups as ONE batch (same text input, different K/V rows)."""
+        G, T = len(groups), txt_input.shape[1]
+        ids = self._dev(txt_input)
+        x = self._bert_embed(ids, T, None)
+        if prompt_cpu is not None:
+            xp = self._bert_embed(self._dev(prompt_cpu), prompt_cpu.shape[1], "prompt")
+            x = torch.cat((x, xp), dim=1)
+        Ttot = x.shape[1]
+        mask = self._dev(self._bert_mask(txt_input, prompt_cpu, casual))
+        if G > 1:
+            x = x.repeat(G, 1, 1)
+            mask = mask.repeat(G, 1, 1)
+        kv_range = None
+        if kv_layers is not None:
+            kv_range = torch.tensor([list(ranges[g]) for g in groups for _ in range(b)], dtype=torch.int32).to(self.device)
+        hidden = self.bert_encoder(x, mask, kv_layers, kv_range, b if kv_layers is not None else 0)
+        sel = (txt_labels != -1)
+        bi, tj = sel.nonzero(as_tuple=True)                      # host tensors, row-major order == boolean indexing order
+        n = bi.numel()
+        idx = torch.cat([(g * b + bi) * Ttot + tj for g in range(G)]).to(self.device)
+        rows = ops.gather_rows(hidden.reshape(-1, hidden.shape[-1]), idx)
+        h = self.cls_transform(rows)
+        P = self.P
+        labels = txt_labels[sel].repeat(G).to(self.device)
+        if compute_loss:
+            # equal row counts per group: the mean over all G*n rows == mean of the per-group means (pretrain.py:473-479)
+            return ops.decoder_xent(h, P["multimodal_encoder.embeddings.word_embeddings.weight"], P["cls.decoder.bias"], labels)
+        scores = ops.decoder_logits(h, P["multimodal_encoder.embeddings.word_embeddings.weight"], P["cls.decoder.bias"])
+        for gi, g in enumerate(groups):
+            out[f"{tag}_scores_{g}"] = scores[gi * n:(gi + 1) * n]
+        return None
+
+    # ------------------------------------------------------------------ the hot path
+    def forward(self, batch, task, compute_loss=True):
+        if task.startswith("pt"):
+            return self.forward_pt(batch, task, compute_loss=compute_loss)
+        raise NotImplementedError("only the pretraining path ('pt_*' tasks) is in scope (SURVEY.md section 8)")
+
+    def forward_pt(self, batch, task, compute_loss=True):
+        """VALOR.forward_pt, model/pretrain.py:214-541."""
+        P, sp = self.P, self.spec
+        mlm_task, caption_task, contra_task = [], [], []
+        for i in task.split("_"):
+            if "mlm" in i:
+                mlm_task = i.split("%")[1:]
+            elif "caption" in i:
+                caption_task = i.split("%")[1:]
+            elif "contra" in i:
+                contra_task = i.split("%")[1:]
+        out = {}
+        col = self.collect
+        txt_tokens = batch.get("txt_tokens")
+        alltasks = "".join(mlm_task + caption_task + contra_task)
+        video_output = audio_output = txt_output = None
+        if "v" in alltasks:
+            video_output = self.forward_video_encoder(batch["video_pixels"])
+        if "a" in alltasks:
+            audio_output = self.forward_audio_encoder(batch["audio_spectrograms"])
+        if "t" in "".join(contra_task):
+            clip_tokens = txt_tokens["clip_tokens"].cpu()
+            txt_output = self.forward_txt_encoder(clip_tokens)
+        if col is not None:
+            col.update(video_output=video_output, audio_output=audio_output, txt_output=txt_output)
+
+        # ---------------- MGA contrastive (pretrain.py:266-407)
+        if contra_task:
+            feat_t = feat_v = feat_a = None
+            tok_contra = None
+            if txt_output is not None:
+                feat_t = ops.l2_normalize(ops.linear(txt_output, P["clip_model.text_projection"], None, w_is_kn=True))
+                tok_contra = clip_tokens
+            if "v" in "".join(contra_task):
+                b, F = video_output.shape[:2]
+                idx = (torch.arange(b * F) * sp.vis_tokens).to(self.device)
+                cls_v = ops.gather_rows(video_output.reshape(-1, sp.vis_width), idx)
+                feat_v = ops.l2_normalize(ops.linear(cls_v, P["clip_model.visual.proj"], None, w_is_kn=True)).view(b, F, -1)
+            if "a" in "".join(contra_task):
+                b, A = audio_output.shape[:2]
+                idx = (torch.arange(b * A) * sp.aud_tokens).to(self.device)
+                cls_a = ops.gather_rows(audio_output.reshape(-1, sp.aud_width), idx)
+                feat_a = ops.l2_normalize(ops.linear(cls_a, P["contra_head_a.linear.weight"], None)).view(b, A, -1)
+            if compute_loss and self.gather_fn is not None:       # ddp_allgather_with_grads / ddp_allgather (pretrain.py:278-291)
+                feat_t, feat_v, feat_a, tok_contra = self.gather_fn(feat_t, feat_v, feat_a, tok_contra)
+            if col is not None:
+                col.update(feat_t=feat_t, feat_v=feat_v, feat_a=feat_a)
+            if compute_loss:
+                k = P["clip_model.logit_scale"].float().exp()                    # 1/temp, modeling.py:420-426
+                maskA = self._dev((tok_contra != 0).float()).contiguous()
+                fw = lambda name, f: ops.rowdot(ops.linear(f, P[f"{name}_fine_weight.0.weight"], P[f"{name}_fine_weight.0.bias"], ACT_RELU),
+                                                P[f"{name}_fine_weight.2.weight"], P[f"{name}_fine_weight.2.bias"]).float().squeeze(-1)
+                wt = fw("text", feat_t)
+                wv = fw("video", feat_v) if feat_v is not None else None
+                wa = fw("audio", feat_a) if feat_a is not None else None
+                ones = lambda f: torch.ones(f.shape[:2], dtype=torch.float32, device=self.device)
+                losses = []
+                if "tva" in contra_task:
+                    fB, wB = torch.cat((feat_v, feat_a), dim=1), torch.cat((wv, wa), dim=1)
+                    losses.append(ops.fine_contrastive(feat_t, fB, wt.contiguous(), wB.contiguous(), maskA, ones(fB), k))
+                if "tv" in contra_task:
+                    losses.append(ops.fine_contrastive(feat_t, feat_v, wt.contiguous(), wv.contiguous(), maskA, ones(feat_v), k))
+                if "ta" in contra_task:
+                    losses.append(ops.fine_contrastive(feat_t, feat_a, wt.contiguous(), wa.contiguous(), maskA, ones(feat_a), k))
+                for g in contra_task:
+                    if g not in ("tva", "tv", "ta"):
+                        raise NotImplementedError(f"contrastive group {g}")
+                out["contra_loss"] = sum(losses) / len(losses) * self.contra_loss_ratio
+            else:
+                out.update(feat_t=feat_t, feat_v=feat_v, feat_a=feat_a, txt_tokens=tok_contra)
+
+        # ---------------- decoder inputs (pretrain.py:410-416, modeling.py:485-502)
+        if not (caption_task or mlm_task):
+            return out
+        txt = txt_tokens["bert_tokens"].cpu()
+        bs = txt.shape[0]
+        kv_layers, ranges = None, {}
+        if video_output is not None or audio_output is not None:
+            Sv = video_output.shape[1] * video_output.shape[2] if video_output is not None else 0
+            Sa = audio_output.shape[1] * audio_output.shape[2] if audio_output is not None else 0
+            if video_output is not None and audio_output is not None:
+                va = ops.cross_input(video_output, audio_output, P["video_frame_embedding"], P["video_type_embeddings"],
+                                     P["audio_frame_embedding"], P["audio_type_embeddings"])
+            else:
+                raise NotImplementedError("single-modality decoder input (video-only / audio-only datasets) comes next")
+            kv_layers = self.project_cross_kv(va)
+            ranges = {"tva": (0, Sv + Sa), "tv": (0, Sv), "ta": (Sv, Sa)}
+
+        if caption_task:                                                          # pretrain.py:419-481
+            txt_input, txt_labels = self.text_masker(txt, 0.6)
+            groups = [g for g in ("tva", "tv", "ta") if g in caption_task]
+            prompt = self.get_task_prompt(PROMPTS["caption"], bs) if self.use_task_prompt else None
+            loss = self._decoder_groups(txt_input, txt_labels, groups, prompt, True, kv_layers, ranges, bs, compute_loss, "caption", out)
+            if compute_loss:
+                out["caption_loss"] = loss
+            else:
+                out["txt_labels_caption"] = txt_labels
+        if mlm_task:                                                              # pretrain.py:483-535
+            txt_input, txt_labels = self.text_masker(txt, 0.15)
+            losses = []
+            for g in ("tva", "tv", "ta"):
+                if g in mlm_task:
+                    prompt = self.get_task_prompt(PROMPTS["mlm_" + g], bs)
+                    l = self._decoder_groups(txt_input, txt_labels, [g], prompt, False, kv_layers, ranges, bs, compute_loss, "mlm", out)
+                    if l is not None:
+                        losses.append(l)
+            if compute_loss:
+                out["mlm_loss"] = sum(losses) / len(losses)
+            else:
+                out["txt_labels_mlm"] = txt_labels
+        return out

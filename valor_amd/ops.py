@@ -1,0 +1,544 @@
+"""Autograd operators of the VALOR step: every forward AND backward below is a HIP kernel call
+through the C-ABI (valor_amd.kernels / valor_amd.lib). torch.autograd only sequences them.
+
+There is no eager / CPU implementation of any op here: tensors must be on the GPU and
+libvalor_hip.so must be built, otherwise lib.ValorHipError is raised.
+"""
+import math
+
+import torch
+from torch.autograd import Function
+
+from . import kernels as K
+from . import lib
+from .lib import ACT_NONE
+
+_st = K._stream
+_p = K._ptr
+_dt = K.dt_of
+
+
+class DropoutState:
+    """Counter-based dropout RNG bookkeeping: every op draws a fresh (seed, offset) window; kernels
+    re-generate masks in backward from the same window (nothing is stored)."""
+    seed = 1234
+    offset = 0
+
+    @classmethod
+    def reset(cls, seed, offset=0):
+        cls.seed, cls.offset = int(seed), int(offset)
+
+    @classmethod
+    def draw(cls, n_elements):
+        off = cls.offset
+        cls.offset += (int(n_elements) + 3) // 4 + 1
+        return cls.seed, off
+
+
+def _2d(x):
+    return x.reshape(-1, x.shape[-1])
+
+
+# ------------------------------------------------------------------------------------------------
+class LinearFn(Function):
+    """y = act(x W^T + b).  W: [N,K] (or, with w_is_kn, a [K,N] matrix used as x @ W: CLIP projections
+    clip.py:237,329 / pretrain.py:90-91). Backward: dX = dY.W (dgrad GEMM), dW = dY^T.X (wgrad GEMM,
+    split-K), db = column sums."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, act, w_is_kn):
+        x2 = _2d(x)
+        want_pre = act != ACT_NONE
+        if w_is_kn:
+            res = K.gemm(x2, w, trans_b=True, bias=b, act=act, want_preact=want_pre)
+        else:
+            res = K.gemm(x2, w, bias=b, act=act, want_preact=want_pre)
+        y, pre = res if want_pre else (res, None)
+        ctx.save_for_backward(x2, w, pre)
+        ctx.act, ctx.w_is_kn, ctx.has_b, ctx.xshape = act, w_is_kn, b is not None, x.shape
+        return y.view(*x.shape[:-1], y.shape[-1])
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, w, pre = ctx.saved_tensors
+        dy2 = _2d(dy.contiguous())
+        if ctx.act != ACT_NONE:
+            du = torch.empty_like(dy2)
+            lib.call("valor_dact_mul", _st(), _dt(dy2), _p(dy2), _p(pre), _p(du), dy2.numel(), ctx.act)
+            dy2 = du
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            dx = (K.gemm(dy2, w) if ctx.w_is_kn else K.gemm(dy2, w, trans_b=True)).view(ctx.xshape)
+        if ctx.needs_input_grad[1]:
+            dw = K.gemm(x2, dy2, trans_a=True, trans_b=True) if ctx.w_is_kn else K.gemm(dy2, x2, trans_a=True, trans_b=True)
+        if ctx.has_b and ctx.needs_input_grad[2]:
+            db = K.colsum(dy2)
+        return dx, dw, db, None, None
+
+
+def linear(x, w, b=None, act=ACT_NONE, w_is_kn=False):
+    return LinearFn.apply(x, w, b, act, w_is_kn)
+
+
+class MlpFn(Function):
+    """y = act(x W1^T + b1) W2^T + b2  (BertIntermediate+BertOutput.dense bert.py:403-406,417; CLIP mlp
+    clip.py:178-182; AST FeedForward transformer.py:141-142; fine-weight MLP pretrain.py:104-112).
+    The activation derivative is fused into the dgrad GEMM epilogue: dU = (dY.W2) * act'(u)."""
+
+    @staticmethod
+    def forward(ctx, x, w1, b1, w2, b2, act):
+        x2 = _2d(x)
+        h, u = K.gemm(x2, w1, bias=b1, act=act, want_preact=True)
+        y = K.gemm(h, w2, bias=b2)
+        ctx.save_for_backward(x2, w1, w2, u, h)
+        ctx.act, ctx.xshape = act, x.shape
+        return y.view(*x.shape[:-1], y.shape[-1])
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, w1, w2, u, h = ctx.saved_tensors
+        dy2 = _2d(dy.contiguous())
+        du = K.gemm(dy2, w2, trans_b=True, act=ctx.act, dact_aux=u)
+        dw2 = K.gemm(dy2, h, trans_a=True, trans_b=True)
+        db2 = K.colsum(dy2)
+        dx = K.gemm(du, w1, trans_b=True).view(ctx.xshape) if ctx.needs_input_grad[0] else None
+        dw1 = K.gemm(du, x2, trans_a=True, trans_b=True)
+        db1 = K.colsum(du)
+        return dx, dw1, db1, dw2, db2, None
+
+
+def mlp(x, w1, b1, w2, b2, act):
+    return MlpFn.apply(x, w1, b1, w2, b2, act)
+
+
+# ------------------------------------------------------------------------------------------------
+class BdrLnFn(Function):
+    """(z, y) = fused bias + dropout + residual + LayerNorm (see csrc/layernorm.hip).
+    mode flags: want_z -> return the pre-LN sum z (pre-LN residual stream); otherwise only y."""
+
+    @staticmethod
+    def forward(ctx, x, bias, residual, gamma, beta, eps, p_drop, want_z):
+        x = x.contiguous()
+        ctx.set_materialize_grads(False)
+        seed = off = 0
+        if p_drop > 0:
+            seed, off = DropoutState.draw(x.numel())
+        plain = bias is None and residual is None and p_drop == 0
+        assert not (plain and want_z), "want_z needs a bias / residual / dropout stage"
+        z, y, mean, rstd = K.bdrln_fwd(x, bias, residual.contiguous() if residual is not None else None, gamma, beta,
+                                       eps, p_drop=p_drop, seed=seed, offset=off, write_z=not plain)
+        ctx.save_for_backward(x if plain else z, mean, rstd, gamma)
+        ctx.cfg = (p_drop, seed, off, bias is not None, residual is not None, beta is not None)
+        if want_z:
+            return z, y
+        return y
+
+    @staticmethod
+    def backward(ctx, *grads):
+        zs, mean, rstd, gamma = ctx.saved_tensors
+        p_drop, seed, off, has_b, has_r, has_beta = ctx.cfg
+        if len(grads) == 2:
+            dz_in, dy = grads
+        else:
+            dz_in, dy = None, grads[0]
+        dy = dy.contiguous() if dy is not None else None
+        dz_in = dz_in.contiguous() if dz_in is not None else None
+        if dy is None and dz_in is None:
+            return (None,) * 8
+        if dy is None:   # only the residual stream was used downstream
+            dy_eff, mean_e, rstd_e, z_e = None, None, None, None
+        else:
+            dy_eff, mean_e, rstd_e, z_e = dy, mean, rstd, zs
+        dx, dres, dg, dbeta, dbias = K.bdrln_bwd(dy_eff, dz_in, z_e, mean_e, rstd_e, gamma, p_drop=p_drop, seed=seed,
+                                                 offset=off, want_dgamma=gamma is not None, want_dbeta=has_beta,
+                                                 want_dbias=has_b)
+        return dx, dbias, (dres if has_r else None), dg, dbeta, None, None, None
+
+
+def layer_norm(x, gamma, beta, eps):
+    return BdrLnFn.apply(x, None, None, gamma, beta, eps, 0.0, False)
+
+
+def bias_dropout_residual_ln(x, bias, residual, gamma, beta, eps, p_drop, want_z):
+    return BdrLnFn.apply(x, bias, residual, gamma, beta, eps, p_drop, want_z)
+
+
+class BiasDropResFn(Function):
+    """z = dropout(x + bias)/(1-p) + residual  without a LayerNorm (last residual add of a pre-LN block)."""
+
+    @staticmethod
+    def forward(ctx, x, bias, residual, p_drop):
+        x = x.contiguous()
+        seed = off = 0
+        if p_drop > 0:
+            seed, off = DropoutState.draw(x.numel())
+        z, _, _, _ = K.bdrln_fwd(x, bias, residual.contiguous() if residual is not None else None, None, None, 0.0,
+                                 p_drop=p_drop, seed=seed, offset=off, write_z=True, want_y=False)
+        ctx.cfg = (p_drop, seed, off, bias is not None, residual is not None)
+        return z
+
+    @staticmethod
+    def backward(ctx, dz):
+        p_drop, seed, off, has_b, has_r = ctx.cfg
+        dx, dres, _, _, dbias = K.bdrln_bwd(None, dz.contiguous(), None, None, None, None, p_drop=p_drop, seed=seed,
+                                            offset=off, want_dgamma=False, want_dbeta=False, want_dbias=has_b)
+        return dx, dbias, (dres if has_r else None), None
+
+
+def bias_dropout_residual(x, bias, residual, p_drop):
+    return BiasDropResFn.apply(x, bias, residual, p_drop)
+
+
+# ------------------------------------------------------------------------------------------------
+class SelfAttnFn(Function):
+    """Self-attention on the fused QKV GEMM output qkv [B,S,3E] (q | k | v column blocks)."""
+
+    @staticmethod
+    def forward(ctx, qkv, n_heads, mask, p_drop):
+        B, S, E3 = qkv.shape
+        E = E3 // 3
+        seed = off = 0
+        if p_drop > 0:
+            seed, off = DropoutState.draw(B * n_heads * S * ((S + 3) // 4) * 4)
+        q, k, v = qkv[:, :, :E], qkv[:, :, E:2 * E], qkv[:, :, 2 * E:]
+        o, lse = K.attn_fwd(q, k, v, n_heads, mask=mask, scale=1.0 / math.sqrt(64), p_drop=p_drop, seed=seed, offset=off)
+        ctx.save_for_backward(qkv, o, lse, mask)
+        ctx.cfg = (n_heads, p_drop, seed, off)
+        return o
+
+    @staticmethod
+    def backward(ctx, do):
+        qkv, o, lse, mask = ctx.saved_tensors
+        n_heads, p_drop, seed, off = ctx.cfg
+        E = qkv.shape[2] // 3
+        dqkv = torch.empty_like(qkv)
+        q, k, v = qkv[:, :, :E], qkv[:, :, E:2 * E], qkv[:, :, 2 * E:]
+        K.attn_bwd(q, k, v, o, lse, do.contiguous(), n_heads, dq=dqkv[:, :, :E], dk=dqkv[:, :, E:2 * E], dv=dqkv[:, :, 2 * E:],
+                   mask=mask, scale=1.0 / math.sqrt(64), p_drop=p_drop, seed=seed, offset=off)
+        return dqkv, None, None, None
+
+
+def self_attention(qkv, n_heads, mask=None, p_drop=0.0):
+    return SelfAttnFn.apply(qkv, n_heads, mask, p_drop)
+
+
+class CrossAttnFn(Function):
+    """Modality-grouped cross-attention: q [B,T,E]; kv [Bkv,Skv,2E] = ONE projected K|V set of the
+    concatenated [video | audio] tokens shared by every query group; kv_range[b] = (start, len)."""
+
+    @staticmethod
+    def forward(ctx, q, kv, n_heads, kv_range, kv_bmod, p_drop):
+        B, T, E = q.shape
+        seed = off = 0
+        if p_drop > 0:
+            seed, off = DropoutState.draw(B * n_heads * T * ((kv.shape[1] + 3) // 4) * 4)
+        k, v = kv[:, :, :E], kv[:, :, E:]
+        q = q.contiguous()
+        o, lse = K.attn_fwd(q, k, v, n_heads, kv_range=kv_range, kv_bmod=kv_bmod, scale=1.0 / math.sqrt(64),
+                            p_drop=p_drop, seed=seed, offset=off)
+        ctx.save_for_backward(q, kv, o, lse, kv_range)
+        ctx.cfg = (n_heads, kv_bmod, p_drop, seed, off)
+        return o
+
+    @staticmethod
+    def backward(ctx, do):
+        q, kv, o, lse, kv_range = ctx.saved_tensors
+        n_heads, kv_bmod, p_drop, seed, off = ctx.cfg
+        E = q.shape[2]
+        dkv = torch.empty_like(kv)
+        dq, _, _ = K.attn_bwd(q, kv[:, :, :E], kv[:, :, E:], o, lse, do.contiguous(), n_heads, dk=dkv[:, :, :E],
+                              dv=dkv[:, :, E:], kv_range=kv_range, kv_bmod=kv_bmod, scale=1.0 / math.sqrt(64),
+                              p_drop=p_drop, seed=seed, offset=off)
+        return dq, dkv, None, None, None, None
+
+
+def cross_attention(q, kv, n_heads, kv_range=None, kv_bmod=0, p_drop=0.0):
+    return CrossAttnFn.apply(q, kv, n_heads, kv_range, kv_bmod, p_drop)
+
+
+# ------------------------------------------------------------------------------------------------
+class DecoderXentFn(Function):
+    """loss = mean CE(h W_emb^T + b, labels): tied-decoder GEMM (modeling.py:253, weight = word embeddings
+    :241) + fused softmax cross-entropy (pretrain.py:444). Logits live in a zero-padded [n, Vpad] buffer that
+    backward overwrites in place with d(logits)."""
+
+    @staticmethod
+    def forward(ctx, h, w_emb, dec_bias, labels, want_logits):
+        n, V = h.shape[0], w_emb.shape[0]
+        Vpad = (V + 31) // 32 * 32
+        buf = torch.empty((n, Vpad), dtype=h.dtype, device=h.device)
+        logits = buf[:, :V]
+        K.gemm(h, w_emb, bias=dec_bias, out=logits)
+        loss_rows = torch.empty(n, dtype=torch.float32, device=h.device)
+        lse = torch.empty(n, dtype=torch.float32, device=h.device)
+        lib.call("valor_xent_fwd", _st(), _dt(h), _p(buf), _p(labels), _p(loss_rows), _p(lse), n, V, Vpad)
+        loss = torch.empty((), dtype=torch.float32, device=h.device)
+        lib.call("valor_mean_f32", _st(), _p(loss_rows), n, _p(loss))
+        ctx.save_for_backward(h, w_emb, labels, lse, buf)
+        ctx.V = V
+        if want_logits:
+            ctx.mark_non_differentiable(logits)
+            return loss, logits
+        return loss
+
+    @staticmethod
+    def backward(ctx, dloss, *_):
+        h, w_emb, labels, lse, buf = ctx.saved_tensors
+        n, V, Vpad = h.shape[0], ctx.V, buf.shape[1]
+        g = dloss.to(torch.float32).contiguous()
+        lib.call("valor_xent_bwd", _st(), _dt(h), _p(buf), _p(labels), _p(lse), _p(g), 1.0 / n, n, V, Vpad)
+        dlog = buf[:, :V]
+        dh = K.gemm(dlog, w_emb, trans_b=True)
+        dw = K.gemm(dlog, h, trans_a=True, trans_b=True)
+        db = K.colsum(dlog)
+        return dh, dw, db, None, None
+
+
+def decoder_xent(h, w_emb, dec_bias, labels, want_logits=False):
+    return DecoderXentFn.apply(h, w_emb, dec_bias, labels, want_logits)
+
+
+def decoder_logits(h, w_emb, dec_bias):
+    """prediction scores only (compute_loss=False branch, pretrain.py:445-446)."""
+    return K.gemm(h, w_emb, bias=dec_bias)
+
+
+# ------------------------------------------------------------------------------------------------
+class FineContrastFn(Function):
+    """loss = InfoNCE(fine_matrix(featA, featB, masks, token weights) * k)  -- pretrain.py:191-211, modeling.py:418-433.
+    featA [B,T,D], featB [B,Nv,D] (L2-normalised), wA_raw [B,T], wB_raw [B,Nv] (fp32), maskA/maskB fp32 0/1,
+    k = 1/temperature (0-dim fp32 tensor, differentiable)."""
+
+    @staticmethod
+    def forward(ctx, featA, featB, wA_raw, wB_raw, maskA, maskB, k):
+        B, T, D = featA.shape
+        Nv = featB.shape[1]
+        dev = featA.device
+        f32 = dict(dtype=torch.float32, device=dev)
+        fa, fb = featA.contiguous().view(B * T, D), featB.contiguous().view(B * Nv, D)
+        ldS = (B * Nv + 7) // 8 * 8
+        S = torch.empty((B * T, ldS), **f32)
+        K.gemm(fa, fb, out=S[:, :B * Nv], out_dtype=torch.float32)
+        wA, wB = torch.empty((B, T), **f32), torch.empty((B, Nv), **f32)
+        lib.call("valor_fine_weight_softmax", _st(), _p(wA_raw), _p(maskA), _p(wA), B, T)
+        lib.call("valor_fine_weight_softmax", _st(), _p(wB_raw), _p(maskB), _p(wB), B, Nv)
+        score = torch.empty((B, B), **f32)
+        A2B, B2A = torch.empty((B, B, T), **f32), torch.empty((B, B, Nv), **f32)
+        idxA = torch.empty((B, B, T), dtype=torch.uint8, device=dev)
+        idxB = torch.empty((B, B, Nv), dtype=torch.uint8, device=dev)
+        lib.call("valor_fine_reduce_fwd", _st(), _p(S), ldS, _p(maskA), _p(maskB), _p(wA), _p(wB), _p(score), _p(A2B),
+                 _p(B2A), _p(idxA), _p(idxB), B, T, Nv)
+        lse_r, lse_c = torch.empty(B, **f32), torch.empty(B, **f32)
+        loss = torch.empty((), **f32)
+        kk = k.detach().to(torch.float32).contiguous()
+        lib.call("valor_infonce_fwd", _st(), _p(score), _p(kk), _p(lse_r), _p(lse_c), _p(loss), B)
+        ctx.save_for_backward(fa, fb, maskA, maskB, wA, wB, score, A2B, B2A, idxA, idxB, lse_r, lse_c, kk)
+        ctx.dims = (B, T, Nv, D, ldS, featA.dtype)
+        ctx.score = score
+        return loss
+
+    @staticmethod
+    def backward(ctx, dloss):
+        fa, fb, maskA, maskB, wA, wB, score, A2B, B2A, idxA, idxB, lse_r, lse_c, kk = ctx.saved_tensors
+        B, T, Nv, D, ldS, fdt = ctx.dims
+        dev = fa.device
+        f32 = dict(dtype=torch.float32, device=dev)
+        g = dloss.to(torch.float32).contiguous()
+        dscore, dk = torch.empty((B, B), **f32), torch.empty((), **f32)
+        part = torch.empty(256, **f32)
+        lib.call("valor_infonce_bwd", _st(), _p(score), _p(kk), _p(lse_r), _p(lse_c), _p(g), _p(dscore), _p(dk), _p(part), B)
+        dS = torch.zeros((B * T, ldS), dtype=fdt, device=dev)
+        dwA, dwB = torch.empty((B, T), **f32), torch.empty((B, Nv), **f32)
+        lib.call("valor_fine_reduce_bwd", _st(), _dt(dS), _p(dscore), _p(maskA), _p(maskB), _p(wA), _p(wB), _p(A2B), _p(B2A),
+                 _p(idxA), _p(idxB), _p(dS), ldS, _p(dwA), _p(dwB), B, T, Nv)
+        dwA_raw, dwB_raw = torch.empty_like(dwA), torch.empty_like(dwB)
+        lib.call("valor_fine_weight_softmax_bwd", _st(), _p(wA), _p(dwA), _p(dwA_raw), B, T)
+        lib.call("valor_fine_weight_softmax_bwd", _st(), _p(wB), _p(dwB), _p(dwB_raw), B, Nv)
+        dSv = dS[:, :B * Nv]
+        dfa = K.gemm(dSv, fb, trans_b=True).view(B, T, D)                      # dS . featB
+        dfb = K.gemm(dSv, fa, trans_a=True, trans_b=True).view(B, Nv, D)       # dS^T . featA
+        return dfa, dfb, dwA_raw, dwB_raw, None, None, dk
+
+
+def fine_contrastive(featA, featB, wA_raw, wB_raw, maskA, maskB, k):
+    return FineContrastFn.apply(featA, featB, wA_raw, wB_raw, maskA, maskB, k)
+
+
+# ------------------------------------------------------------------------------------------------
+class EmbedFn(Function):
+    """out[i] = word[ids[i]] + pos[i % L] + typevec   (bert.py:211-215, clip.py:377-379)"""
+
+    @staticmethod
+    def forward(ctx, ids, word, pos, typevec, L):
+        n, E = ids.numel(), word.shape[1]
+        out = torch.empty((n, E), dtype=word.dtype, device=word.device)
+        lib.call("valor_embed_fwd", _st(), _dt(word), _p(ids), _p(word), _p(pos), _p(typevec), _p(out), n, L, E)
+        ctx.save_for_backward(ids)
+        ctx.cfg = (word.shape, pos.shape if pos is not None else None, typevec is not None, L)
+        return out.view(*ids.shape, E)
+
+    @staticmethod
+    def backward(ctx, dout):
+        (ids,) = ctx.saved_tensors
+        wshape, pshape, has_type, L = ctx.cfg
+        d2 = _2d(dout.contiguous())
+        n, E = d2.shape
+        dword = torch.zeros(wshape, dtype=d2.dtype, device=d2.device)
+        lib.call("valor_embed_bwd_word", _st(), _dt(d2), _p(ids), _p(d2), _p(dword), n, E)
+        dpos = None
+        if pshape is not None:
+            dpos = torch.zeros(pshape, dtype=d2.dtype, device=d2.device)
+            lib.call("valor_sum_over_batch", _st(), _dt(d2), _p(d2), _p(dpos), n // L, L, E)
+        dtype_vec = K.colsum(d2) if has_type else None
+        return None, dword, dpos, dtype_vec, None
+
+
+def embed(ids, word, pos, typevec, L):
+    return EmbedFn.apply(ids.contiguous(), word, pos, typevec, L)
+
+
+class AssembleFn(Function):
+    """tokens = [cls ; patches (+bias)] + pos   (clip.py:264-265 ; modeling.py:755-760)"""
+
+    @staticmethod
+    def forward(ctx, patches, cls, pos, bias, N, Pn):
+        E = patches.shape[-1]
+        out = torch.empty((N, Pn + 1, E), dtype=patches.dtype, device=patches.device)
+        lib.call("valor_assemble_tokens_fwd", _st(), _dt(patches), _p(patches), _p(cls), _p(pos), _p(bias), _p(out), N, Pn, E)
+        ctx.cfg = (N, Pn, E, bias is not None, cls.shape, pos.shape)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        N, Pn, E, has_bias, cshape, pshape = ctx.cfg
+        dout = dout.contiguous()
+        dpatch = torch.empty((N * Pn, E), dtype=dout.dtype, device=dout.device)
+        dpos = torch.empty((Pn + 1, E), dtype=dout.dtype, device=dout.device)
+        lib.call("valor_assemble_tokens_bwd", _st(), _dt(dout), _p(dout), _p(dpatch), _p(dpos), N, Pn, E)
+        dbias = K.colsum(dpatch) if has_bias else None
+        return dpatch, dpos[0].clone().view(cshape), dpos.view(pshape), dbias, None, None
+
+
+def assemble_tokens(patches, cls, pos, bias, N, Pn):
+    return AssembleFn.apply(patches, cls, pos, bias, N, Pn)
+
+
+def patchify(images_f32, P, out_dtype):
+    """[N,C,H,W] fp32 -> [N*(H/P)*(W/P), C*P*P] GEMM operand rows in the compute dtype (no grad)."""
+    N, C, H, W = images_f32.shape
+    images_f32 = images_f32.contiguous()
+    out = torch.empty((N * (H // P) * (W // P), C * P * P), dtype=out_dtype, device=images_f32.device)
+    lib.call("valor_patchify", _st(), _dt(out), _p(images_f32), _p(out), N, C, H, W, P)
+    return out
+
+
+class CrossInputFn(Function):
+    """va = [video_out + frame_emb + type | audio_out + frame_emb + type]  -> [b, F*X + A*Y, E]
+    (modeling.py:485-502 + the torch.cat of bert.py:450)."""
+
+    @staticmethod
+    def forward(ctx, vid, aud, vfe, vte, afe, ate):
+        b, F, X, E = vid.shape
+        _, A, Y, _ = aud.shape
+        Sv, Sa = F * X, A * Y
+        out = torch.empty((b, Sv + Sa, E), dtype=vid.dtype, device=vid.device)
+        lib.call("valor_add_frame_type_fwd", _st(), _dt(vid), _p(vid.contiguous()), _p(vfe), _p(vte), _p(out), b, F, X, E, (Sv + Sa) * E, 0)
+        lib.call("valor_add_frame_type_fwd", _st(), _dt(aud), _p(aud.contiguous()), _p(afe), _p(ate), _p(out), b, A, Y, E, (Sv + Sa) * E, Sv)
+        ctx.cfg = (b, F, X, A, Y, E, vfe.shape, afe.shape, vte.shape)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        b, F, X, A, Y, E, vfs, afs, ts = ctx.cfg
+        dout = dout.contiguous()
+        Sv, Sa = F * X, A * Y
+        dvid = torch.empty((b, F, X, E), dtype=dout.dtype, device=dout.device)
+        daud = torch.empty((b, A, Y, E), dtype=dout.dtype, device=dout.device)
+        dvf = torch.zeros(vfs, dtype=dout.dtype, device=dout.device)
+        daf = torch.zeros(afs, dtype=dout.dtype, device=dout.device)
+        lib.call("valor_add_frame_type_bwd", _st(), _dt(dout), _p(dout), _p(dvid), _p(dvf), b, F, X, E, (Sv + Sa) * E, 0)
+        lib.call("valor_add_frame_type_bwd", _st(), _dt(dout), _p(dout), _p(daud), _p(daf), b, A, Y, E, (Sv + Sa) * E, Sv)
+        dvt = K.colsum(dvf.view(-1, E)[:F]).view(ts)
+        dat = K.colsum(daf.view(-1, E)[:A]).view(ts)
+        return dvid, daud, dvf, dvt, daf, dat
+
+
+def cross_input(vid, aud, vfe, vte, afe, ate):
+    return CrossInputFn.apply(vid, aud, vfe, vte, afe, ate)
+
+
+class L2NormFn(Function):
+    @staticmethod
+    def forward(ctx, x):
+        x2 = _2d(x.contiguous())
+        y = torch.empty_like(x2)
+        norm = torch.empty(x2.shape[0], dtype=torch.float32, device=x.device)
+        lib.call("valor_l2norm_fwd", _st(), _dt(x2), _p(x2), _p(y), _p(norm), x2.shape[0], x2.shape[1])
+        ctx.save_for_backward(y, norm)
+        return y.view(x.shape)
+
+    @staticmethod
+    def backward(ctx, dy):
+        y, norm = ctx.saved_tensors
+        d2 = _2d(dy.contiguous())
+        dx = torch.empty_like(d2)
+        lib.call("valor_l2norm_bwd", _st(), _dt(d2), _p(y), _p(d2), _p(norm), _p(dx), d2.shape[0], d2.shape[1])
+        return dx.view(dy.shape)
+
+
+def l2_normalize(x):
+    return L2NormFn.apply(x)
+
+
+class GatherRowsFn(Function):
+    """out[i] = x2d[idx[i]]  (masked-token row selection pretrain.py:441; cls-token pooling modeling.py:387,399)."""
+
+    @staticmethod
+    def forward(ctx, x2d, idx):
+        x2d = x2d.contiguous()
+        n, E = idx.numel(), x2d.shape[1]
+        out = torch.empty((n, E), dtype=x2d.dtype, device=x2d.device)
+        lib.call("valor_gather_rows", _st(), _dt(x2d), _p(x2d), _p(idx), _p(out), n, E, x2d.stride(0))
+        ctx.save_for_backward(idx)
+        ctx.shape = x2d.shape
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        (idx,) = ctx.saved_tensors
+        dout = dout.contiguous()
+        dx = torch.zeros(ctx.shape, dtype=dout.dtype, device=dout.device)
+        lib.call("valor_scatter_rows", _st(), _dt(dout), _p(dout), _p(idx), _p(dx), idx.numel(), dout.shape[1], dx.stride(0))
+        return dx, None
+
+
+def gather_rows(x2d, idx):
+    return GatherRowsFn.apply(x2d, idx)
+
+
+class RowDotFn(Function):
+    """y[..., 0] = <x[..., :], w[0, :]> + b   (Linear(E -> 1) of the fine-weight heads, pretrain.py:104-112)"""
+
+    @staticmethod
+    def forward(ctx, x, w, b):
+        x2 = _2d(x.contiguous())
+        y = torch.empty(x2.shape[0], dtype=x.dtype, device=x.device)
+        lib.call("valor_rowdot_fwd", _st(), _dt(x2), _p(x2), _p(w), _p(b), _p(y), x2.shape[0], x2.shape[1])
+        ctx.save_for_backward(x2, w)
+        ctx.cfg = (x.shape, b is not None)
+        return y.view(*x.shape[:-1], 1)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, w = ctx.saved_tensors
+        xshape, has_b = ctx.cfg
+        dy = dy.contiguous()
+        dx = torch.empty_like(x2)
+        dw = torch.empty_like(w)
+        db = torch.empty(1, dtype=w.dtype, device=w.device) if has_b else None
+        lib.call("valor_rowdot_bwd", _st(), _dt(x2), _p(dy), _p(x2), _p(w), _p(dx), _p(dw), _p(db), x2.shape[0], x2.shape[1])
+        return dx.view(xshape), dw, db
+
+
+def rowdot(x, w, b):
+    return RowDotFn.apply(x, w, b)

@@ -1,0 +1,151 @@
+"""Fused multi-tensor AdamW over the flat arenas + LR schedule + global-norm clipping.
+
+Replaces optim/adamw.py (HF AdamW python loop), optim/misc.py::build_optimizer (10 param groups with
+per-group init_lr / weight decay), optim/sched.py (warmup_linear / warmup_cosine) and the apex-amp
+fp32-master bookkeeping. Keeps the attributes conduct_train reads (train_utils.py:237-242,344-347):
+param_groups[i]['init_lr'|'lr'|'weight_decay'], basic_lr, clip_lr_visual, clip_lr_text, decoder_lr,
+new_lr, new_params_name; state_dict() uses the HF per-parameter layout {step, exp_avg, exp_avg_sq}.
+"""
+import ctypes
+import math
+
+import torch
+
+from .. import lib
+from ..kernels import _ptr, _stream, dt_of, workspace
+
+
+def warmup_cosine(x, warmup_ratio):
+    """optim/sched.py:15-18"""
+    if x < warmup_ratio:
+        return x / warmup_ratio
+    return 0.5 * (1.0 + math.cos(math.pi * x))
+
+
+def warmup_linear(x, warmup_ratio):
+    """optim/sched.py:27-34"""
+    if x < warmup_ratio:
+        return x / warmup_ratio
+    return max((x - 1.0) / (warmup_ratio - 1.0), 0)
+
+
+_SCHED = {"warmup_linear": warmup_linear, "warmup_cosine": warmup_cosine}
+
+
+def get_lr_sched(global_step, opts):
+    """optim/sched.py:37-41"""
+    return _SCHED[getattr(opts, "scheduler", "warmup_linear")](global_step / opts.num_train_steps, opts.warmup_ratio)
+
+
+def _get(opts, name, default):
+    if isinstance(opts, dict):
+        return opts.get(name, default)
+    return getattr(opts, name, default)
+
+
+class FusedAdamW:
+    N_GROUPS = 10
+
+    def __init__(self, model, opts):
+        self.model, self.arena = model, model.arena
+        lr = float(_get(opts, "learning_rate", 1e-4))
+        wd = float(_get(opts, "weight_decay", 0.01))
+        dec = float(_get(opts, "decoder_lr", -1))
+        if dec == -1:
+            dec = lr
+        new_lr = float(_get(opts, "new_lr", 0.0))
+        clip_lr, clip_lr_text = float(_get(opts, "clip_lr", 5e-7)), float(_get(opts, "clip_lr_text", 5e-7))
+        lrs = [lr, lr, new_lr, new_lr, clip_lr, clip_lr, clip_lr_text, clip_lr_text, dec, dec]     # optim/misc.py:66-77
+        self.param_groups = [{"init_lr": l, "lr": l, "weight_decay": (wd if i % 2 == 0 else 0.0), "group": i}
+                             for i, l in enumerate(lrs)]
+        self.betas = tuple(float(b) for b in _get(opts, "betas", (0.9, 0.98)))
+        self.eps = 1e-6
+        self.correct_bias = True
+        self.basic_lr, self.clip_lr_visual, self.clip_lr_text = lr, clip_lr, clip_lr_text
+        self.decoder_lr, self.new_lr = dec, new_lr
+        self.new_params_name = list(_get(opts, "new_params_name", []) or [])
+        a = self.arena
+        f32 = dict(dtype=torch.float32, device=a.device)
+        self.separate_master = a.dtype != torch.float32
+        self.master = a.flat.float() if self.separate_master else a.flat      # fp32 parity mode: params ARE the masters
+        self.exp_avg = torch.zeros(a.numel, **f32)
+        self.exp_avg_sq = torch.zeros(a.numel, **f32)
+        self.steps = {n: 0 for n in a.offsets}                # per-parameter Adam step (adamw.py:62-72)
+        self.total_norm = torch.zeros((), **f32)
+        self.gscale = torch.ones((), **f32)
+        self._tables = {}
+
+    def init_master_from(self, state_dict_fp32):
+        """Seed the fp32 masters from full-precision weights (instead of the rounded bf16 parameters)."""
+        if not self.separate_master:
+            return
+        saved = self.arena.flat
+        tmp_flat = self.master
+        for name, shape, refs in self.model.table:
+            o, n, _ = self.arena.offsets[name]
+            if len(refs) == 1 or refs[1] == "cls.decoder.weight":
+                if refs[0] in state_dict_fp32:
+                    tmp_flat[o:o + n].copy_(state_dict_fp32[refs[0]].reshape(-1))
+            else:
+                rows = n // len(refs)
+                for i, r in enumerate(refs):
+                    if r in state_dict_fp32:
+                        tmp_flat[o + i * rows:o + (i + 1) * rows].copy_(state_dict_fp32[r].reshape(-1))
+        del saved
+
+    def zero_grad(self):
+        """Gradients are zeroed by the fused update itself; an explicit call clears the whole arena."""
+        self.arena.grad.zero_()
+
+    def _table(self, active_names):
+        key = frozenset(active_names)
+        t = self._tables.get(key)
+        if t is None:
+            t = self.arena.chunk_group_table(active=key)
+            self._tables = {key: t}
+        return t
+
+    def step(self, active_names=None, max_grad_norm=-1.0, world_size=1):
+        """One optimizer step over the parameters that received a gradient (`active_names`; None = all).
+        The arena holds gradients SUMMED over ranks: they are scaled by 1/world_size (DDP mean) and by the
+        clip coefficient inside the update kernel."""
+        a = self.arena
+        names = list(a.offsets) if active_names is None else [n for n in a.offsets if n in active_names]
+        table = self._table(names)
+        dt = dt_of(a.grad)
+        ws = workspace(a.device)
+        lib.call("valor_grad_norm_clip", _stream(), dt, _ptr(a.grad), _ptr(table), a.numel, 1.0 / world_size,
+                 float(max_grad_norm), _ptr(ws), _ptr(self.total_norm), _ptr(self.gscale))
+        for n in names:
+            self.steps[n] += 1
+        by_step = {}
+        for n in names:
+            by_step.setdefault(self.steps[n], []).append(n)
+        lr = (ctypes.c_float * self.N_GROUPS)(*[g["lr"] for g in self.param_groups])
+        wd = (ctypes.c_float * self.N_GROUPS)(*[g["weight_decay"] for g in self.param_groups])
+        for st, ns in by_step.items():
+            tb = table if len(by_step) == 1 else a.chunk_group_table(active=set(ns))
+            lib.call("valor_adamw", _stream(), dt, _ptr(self.master), _ptr(self.exp_avg), _ptr(self.exp_avg_sq), _ptr(a.grad),
+                     _ptr(a.flat) if self.separate_master else None, _ptr(tb), a.numel, lr, wd, self.N_GROUPS,
+                     self.betas[0], self.betas[1], self.eps, int(st), int(self.correct_bias), _ptr(self.gscale), 1)
+        return self.total_norm
+
+    # ---- HF / reference optimizer checkpoint layout (optimizer_step_N.pt, utils/save.py:57-64)
+    def state_dict(self):
+        state = {}
+        for i, (name, (o, n, shape)) in enumerate(self.arena.offsets.items()):
+            if self.steps[name] > 0:
+                state[i] = {"step": self.steps[name], "exp_avg": self.exp_avg[o:o + n].view(shape).clone(),
+                            "exp_avg_sq": self.exp_avg_sq[o:o + n].view(shape).clone()}
+        return {"state": state, "param_groups": [dict(g) for g in self.param_groups], "names": list(self.arena.offsets)}
+
+    def load_state_dict(self, sd):
+        names = sd.get("names", list(self.arena.offsets))
+        for i, st in sd["state"].items():
+            name = names[int(i)]
+            o, n, _ = self.arena.offsets[name]
+            self.steps[name] = int(st["step"])
+            self.exp_avg[o:o + n].copy_(st["exp_avg"].reshape(-1))
+            self.exp_avg_sq[o:o + n].copy_(st["exp_avg_sq"].reshape(-1))
+        for g, s in zip(self.param_groups, sd.get("param_groups", [])):
+            g.update({k: s[k] for k in ("init_lr", "lr", "weight_decay") if k in s})
