@@ -1,0 +1,215 @@
+"""bench.py -- VALOR-base tri-modal pretraining step on N MI355X of one node (data parallel, weak scaling).
+
+  python bench.py --gpus N --steps K --warmup W          (N > 1: launched by torch.distributed.run, one rank per GPU)
+
+Workload (BASELINE.json configs[1]/[2]): CLIP-ViT-B/16 + CLIP-text + AST + BERT-base decoder, bf16 compute
+with fp32 master weights, task pt_contra%tva%tv%ta_caption%tva%tv%ta_mlm%tva (MGA + MGC + MLM), per-GPU batch
+64, 8 frames x 224^2, 2 x 5.12 s audio slices, 32 text tokens, dropout 0.1 (the reference's training setting),
+synthetic inputs resident in HBM, random-init weights. A step = forward + backward + gradient all-reduce +
+global-norm clip + fused AdamW. Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import random
+import sys
+import time
+from types import SimpleNamespace
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+TASK = "pt_contra%tva%tv%ta_caption%tva%tv%ta_mlm%tva"
+PEAK_BF16_TFLOPS = 2500.0     # dense bf16 MFMA peak, /opt/skills/guides/MI355X_MICROARCH.md
+
+
+def necessary_flops_per_sample(spec, frames, audio_slices, txt_len, n_cap_groups=3, mlm_prompt=10, mask_cap=0.6, mask_mlm=0.15):
+    """fwd+bwd matmul FLOPs per sample with shared cross-K/V (SURVEY.md 8d formula); bwd = 2 x fwd."""
+    W, H = spec.vis_width, spec.hidden
+    Lv, La = spec.vis_tokens, spec.aud_tokens
+    p_vit = spec.vis_layers * 12 * W * W + 3 * spec.patch ** 2 * W
+    vit = frames * (2 * Lv * p_vit + spec.vis_layers * 4 * Lv * Lv * W)
+    p_ast = spec.aud_layers * (4 * spec.aud_width ** 2 + 2 * spec.aud_width * spec.aud_inter) + spec.aud_patch ** 2 * spec.aud_width
+    ast = audio_slices * (2 * La * p_ast + spec.aud_layers * 4 * La * La * spec.aud_width)
+    p_txt = spec.txt_layers * 12 * spec.txt_width ** 2
+    txt = 2 * txt_len * p_txt + spec.txt_layers * 4 * txt_len ** 2 * spec.txt_width
+    Sv, Sa = frames * Lv, audio_slices * La
+
+    def dec(T, Skv):
+        return spec.layers * (2 * T * (4 * H * H + 2 * H * H + 2 * H * spec.inter) + 4 * T * T * H + 4 * T * Skv * H)
+    decoder = dec(txt_len, Sv + Sa) + dec(txt_len, Sv) + dec(txt_len, Sa) + dec(txt_len + mlm_prompt, Sv + Sa)
+    cross_kv = spec.layers * 2 * (Sv + Sa) * 2 * H * H
+    n_mask = (n_cap_groups * mask_cap + mask_mlm) * (txt_len * 0.55)
+    head = n_mask * 2 * (H * H + H * spec.vocab)
+    fwd = vit + ast + txt + decoder + cross_kv + head
+    return 3.0 * fwd
+
+
+def cpu_baseline(sample_batch=2, frames=8, audio_slices=2):
+    """Reference CPU path as restated by the oracle (kind 'port'), fp32, all host cores, one full step."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import valor_oracle as VO
+    from valor_amd import synth
+    spec = synth.base_spec()
+    sd = synth.make_state_dict(spec, seed=50)
+    sd_o = {k: v.clone().requires_grad_(True) for k, v in sd.items() if k != "cls.decoder.weight"}
+    sd_o["cls.decoder.weight"] = sd_o["multimodal_encoder.embeddings.word_embeddings.weight"]
+    orc = VO.Oracle(spec, sd_o, dropout_p=0.0, vocab_tokens=synth.synthetic_vocab(spec.vocab))
+    batch = synth.make_batch(spec, batch=sample_batch, frames=frames, audio_slices=audio_slices, txt_len=32, seed=50)
+    params = {k: v for k, v in sd_o.items() if k != "cls.decoder.weight"}
+    groups = {k: VO.param_group_of(k) for k in params}
+    lrs, wds = VO.group_hparams(1e-4, 0.01)
+    state = {}
+    t0 = time.time()
+    random.seed(50)
+    out = orc.forward_pt(batch, TASK, compute_loss=True)
+    sum(out.values()).backward()
+    grads = {k: p.grad for k, p in params.items() if p.grad is not None}
+    VO.clip_grad_norm(grads, 5.0)
+    with torch.no_grad():
+        VO.adamw_step(params, grads, state, lrs, wds, groups)
+    dt = time.time() - t0
+    return {"value": round(sample_batch / dt, 4), "unit": "samples/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"1 full step (fwd+bwd+clip+AdamW) of oracle/valor_oracle.py, fp32, batch {sample_batch}, "
+                      f"{frames} frames, {audio_slices} audio slices, 32 tokens, {dt:.1f} s"}
+
+
+class GemmTimer:
+    """HIP-event timing of every valor_gemm launch on its own stream, grouped by kernel variant."""
+
+    def __init__(self):
+        self.records = []
+        self.enabled = False
+
+    def install(self):
+        from valor_amd import kernels as K
+        orig = K.gemm
+        timer = self
+
+        def timed(a, b, *, trans_a=False, trans_b=False, **kw):
+            if not timer.enabled:
+                return orig(a, b, trans_a=trans_a, trans_b=trans_b, **kw)
+            M, Kd = (a.shape[1], a.shape[0]) if trans_a else (a.shape[0], a.shape[1])
+            N = b.shape[1] if trans_b else b.shape[0]
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            r = orig(a, b, trans_a=trans_a, trans_b=trans_b, **kw)
+            e1.record()
+            timer.records.append((("T" if trans_a else "N") + ("T" if trans_b else "N"), 2.0 * M * N * Kd, e0, e1))
+            return r
+        K.gemm = timed
+
+    def summary(self):
+        agg = {}
+        for var, fl, e0, e1 in self.records:
+            d = agg.setdefault(var, [0.0, 0.0, 0])
+            d[0] += fl; d[1] += e0.elapsed_time(e1) * 1e-3; d[2] += 1
+        return {v: {"flops": f, "seconds": s, "launches": n, "TFLOPs": f / s / 1e12, "avg_us": s / n * 1e6} for v, (f, s, n) in agg.items()}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--batch", type=int, default=64, help="per-GPU batch (config: 512 global / 8 GPUs)")
+    ap.add_argument("--frames", type=int, default=8)
+    ap.add_argument("--audio-slices", type=int, default=2)
+    ap.add_argument("--dropout", type=float, default=0.1)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.distributed.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    from valor_amd import synth
+    from valor_amd.engine import TrainEngine
+    from valor_amd.model.valor import VALOR
+    from valor_amd.ops import DropoutState
+
+    spec = synth.base_spec()
+    model = VALOR({"dropout": args.dropout}, spec=spec, dtype=torch.bfloat16, device=dev)
+    sd = synth.make_state_dict(spec, seed=50)                   # same weights on every rank (DDP broadcast equivalent)
+    model.load_state_dict(sd, strict=True)
+    opts = SimpleNamespace(learning_rate=1e-4, weight_decay=0.01, clip_lr=5e-7, clip_lr_text=5e-7, new_lr=0.0, decoder_lr=-1,
+                           betas=[0.9, 0.98], warmup_ratio=0.1, num_train_steps=100000, scheduler="warmup_linear", grad_norm=5.0)
+    engine = TrainEngine(model, opts)
+    engine.optimizer.init_master_from(sd)
+    del sd
+    batch = synth.make_batch(spec, batch=args.batch, frames=args.frames, audio_slices=args.audio_slices, txt_len=32, seed=50 + rank)
+    batch["video_pixels"] = batch["video_pixels"].to(dev)
+    batch["audio_spectrograms"] = batch["audio_spectrograms"].to(dev)
+    random.seed(50 + rank)
+    DropoutState.reset(1234 + rank)
+
+    timer = GemmTimer()
+    timer.install()
+
+    def sync():
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        engine.train_step(batch, TASK)
+    sync()
+    timer.enabled = True
+    t0 = time.perf_counter()
+    last = None
+    for _ in range(args.steps):
+        last = engine.train_step(batch, TASK)
+    sync()
+    elapsed = time.perf_counter() - t0
+    timer.enabled = False
+    t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    if world > 1:
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+    elapsed = float(t.item())
+
+    if rank == 0:
+        ms = elapsed / args.steps * 1e3
+        sps = world * args.batch * args.steps / elapsed
+        gs = timer.summary()
+        dom = max(gs, key=lambda v: gs[v]["seconds"]) if gs else None
+        nf = necessary_flops_per_sample(spec, args.frames, args.audio_slices, 32)
+        roof = None
+        if dom:
+            names = {"NN": "gemm_kernel<bf16,false,false> (forward x.W^T)", "NT": "gemm_kernel<bf16,false,true> (dgrad dY.W)",
+                     "TT": "gemm_kernel<bf16,true,true> (wgrad dY^T.X)", "TN": "gemm_kernel<bf16,true,false>"}
+            roof = {"bound": "mfma", "kernel": names[dom], "achieved": round(gs[dom]["TFLOPs"], 1), "peak": PEAK_BF16_TFLOPS,
+                    "unit": "TFLOP/s", "frac": round(gs[dom]["TFLOPs"] / PEAK_BF16_TFLOPS, 4), "traffic": None,
+                    "avg_launch_us": round(gs[dom]["avg_us"], 1), "launches": gs[dom]["launches"],
+                    "all_gemm_variants": {v: {"TFLOPs": round(d["TFLOPs"], 1), "avg_us": round(d["avg_us"], 1), "launches": d["launches"],
+                                              "share_of_step_time": round(d["seconds"] / elapsed, 3)} for v, d in gs.items()},
+                    "step_mfu": round(nf * sps / world / 1e12 / PEAK_BF16_TFLOPS, 4),
+                    "necessary_gflop_per_sample": round(nf / 1e9, 1)}
+        res = {"metric": "pretrain samples/sec (V+A+T clip)", "value": round(sps, 2), "unit": "samples/s", "n_gpus": world,
+               "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 2), "higher_is_better": True,
+               "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+               "config": {"workload": "VALOR-base tri-modal (CLIP-B/16 + AST + BERT-base) pretrain step, MGA+MGC+MLM, "
+                                      f"{args.frames} frames x 224^2, {args.audio_slices} x 5.12 s audio, 32 tokens",
+                          "per_gpu_batch": args.batch, "global_batch": world * args.batch, "parallelism": f"dp{world}",
+                          "dropout": args.dropout, "task": TASK},
+               "losses": {k: round(float(v), 4) for k, v in last.items()},
+               "peak_mem_gb": round(torch.cuda.max_memory_allocated() / 2 ** 30, 1),
+               "roofline": roof}
+        if world == 1 and not args.no_cpu_baseline:
+            try:
+                res["cpu_baseline"] = cpu_baseline()
+            except Exception as e:      # the baseline is a reported number only; never fail the bench on it
+                res["cpu_baseline"] = {"value": None, "error": repr(e)}
+        print(json.dumps(res), flush=True)
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
