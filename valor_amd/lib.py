@@ -78,6 +78,9 @@ def load():
         raise ValorHipError(
             f"{LIB_PATH} not found: run `python -m valor_amd.build` (hipcc --offload-arch=gfx950). "
             "valor_amd has no CPU / eager fallback by design.")
+    # torch ships its own libamdhip64; it must be the (single) HIP runtime of the process, otherwise
+    # streams / device pointers created by torch are foreign to the runtime our kernels launch on.
+    import torch  # noqa: F401  (loads torch/lib/libamdhip64.so under its SONAME before our DT_NEEDED resolves)
     lib = ctypes.CDLL(LIB_PATH)
     for name, argtypes in SIGNATURES.items():
         fn = getattr(lib, name)
