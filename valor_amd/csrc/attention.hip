@@ -102,16 +102,21 @@ DEVINL KvSel kv_select(const AttnArgs& p, int b) {
 }
 
 // ------------------------------------------------------------------------------------------
-// forward.  grid = (ceil(Sq / (64*RT)), H, B), 256 threads; wave w owns 16*RT query rows.
+// Staging scheme shared by the three kernels: every 64-row LDS image of a K/V (or Q/dO) tile is staged
+// by ONE wave (Stage64: 8 x 16-B global loads per lane, issued one tile ahead of the MFMAs that consume
+// it and committed to the OTHER LDS buffer after them), so the loads of tile t+1 fly under the math of
+// tile t and there is one barrier per tile.
 // ------------------------------------------------------------------------------------------
+
+// forward.  grid = (ceil(Sq / (64*RT)), H, B), 256 threads; wave w owns 16*RT query rows.
+// roles: wave 0 stages K [key][d], wave 1 stages V^T [d][key].
 template <typename T, int RT>
 __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs p) {
     constexpr int VEC = ElemTraits<T>::VEC;
     constexpr int NIMG = 64 * (int)sizeof(T) / TILE_ROW_BYTES;   // 1 (bf16) / 2 (fp32)
     constexpr int NDG = ATT_D / (4 * VEC);                       // d-groups of 4 chunks: 2 / 4
+    constexpr int BUF = 2 * NIMG * IMG_BYTES;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    char* sK = smem;                       // NIMG images [64 keys][128 B of d]
-    char* sV = smem + NIMG * IMG_BYTES;    // NIMG images [64 d][128 B of keys]  (V^T)
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -149,31 +154,38 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs p) {
     const float keep_scale = p.p_drop > 0.f ? 1.0f / (1.0f - p.p_drop) : 1.0f;
     const int kq4 = (p.Skv + 3) >> 2;   // RNG row pitch in 4-key groups
 
-    DirectStage<T, 64, 256> stK[NIMG];
-    TransStage<T, 64, 256> stV[NIMG];
+    Stage64<T> st[NIMG];
     auto issue = [&](int kv0) {
+        if (wave == 0) {
 #pragma unroll
-        for (int im = 0; im < NIMG; ++im) {
-            stK[im].issue(Kp, p.k_rs, kv0, kv.len, im * 8 * VEC, ATT_D, tid);
-            stV[im].issue(Vp, p.v_rs, 0, ATT_D, kv0 + im * 8 * VEC, kv.len, tid);
+            for (int im = 0; im < NIMG; ++im) st[im].issue_direct(Kp, p.k_rs, kv0, kv.len, im * 8 * VEC, ATT_D, lane);
+        } else if (wave == 1) {
+#pragma unroll
+            for (int im = 0; im < NIMG; ++im) st[im].issue_trans(Vp, p.v_rs, 0, ATT_D, kv0 + im * 8 * VEC, kv.len, lane);
         }
     };
-    auto commit = [&]() {
+    auto commit = [&](int buf) {
+        char* base = smem + buf * BUF;
+        if (wave == 0) {
 #pragma unroll
-        for (int im = 0; im < NIMG; ++im) {
-            stK[im].commit(sK + im * IMG_BYTES, tid);
-            stV[im].commit(sV + im * IMG_BYTES, tid);
+            for (int im = 0; im < NIMG; ++im) st[im].commit_direct(base + im * IMG_BYTES, lane);
+        } else if (wave == 1) {
+#pragma unroll
+            for (int im = 0; im < NIMG; ++im) st[im].commit_trans(base + (NIMG + im) * IMG_BYTES, lane);
         }
     };
 
     const int ntiles = (kv.len + 63) >> 6;
-    if (ntiles > 0) { issue(0); commit(); }
+    if (ntiles > 0) { issue(0); commit(0); }
     __syncthreads();
 
+    int buf = 0;
     for (int t = 0; t < ntiles; ++t) {
         const int kv0 = t << 6;
         const bool has_next = t + 1 < ntiles;
         if (has_next) issue(kv0 + 64);
+        const char* sK = smem + buf * BUF;
+        const char* sV = sK + NIMG * IMG_BYTES;
 
         // ---- S^T = K . Q^T : sacc[rt][kt][r] = S[q = fr][key = kv0 + kt*16 + 4g + r]
         f32x4_t sacc[RT][4];
@@ -233,8 +245,9 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs p) {
             nat_mma_64<T>(sV, sacc[rt], oacc[rt], lane);
         }
 
+        if (has_next) commit(buf ^ 1);
         __syncthreads();
-        if (has_next) { commit(); __syncthreads(); }
+        buf ^= 1;
     }
 
 #pragma unroll
@@ -256,16 +269,15 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs p) {
 // ------------------------------------------------------------------------------------------
 // backward, dQ.  grid = (ceil(Sq/64), H, B); wave w owns 16 query rows. Also writes
 // delta[b,h,q] = sum_d dO*O for the dK/dV kernel.
+// roles: wave 0 stages K [key][d], wave 1 V [key][d], wave 2 K^T [d][key].
 // ------------------------------------------------------------------------------------------
 template <typename T>
 __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnArgs p) {
     constexpr int VEC = ElemTraits<T>::VEC;
     constexpr int NIMG = 64 * (int)sizeof(T) / TILE_ROW_BYTES;
     constexpr int NDG = ATT_D / (4 * VEC);
+    constexpr int BUF = 3 * NIMG * IMG_BYTES;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    char* sK = smem;                          // [key][d]
-    char* sV = smem + NIMG * IMG_BYTES;       // [key][d]
-    char* sKT = smem + 2 * NIMG * IMG_BYTES;  // [d][key]
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -313,33 +325,45 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnArgs p) {
     const int kq4 = (p.Skv + 3) >> 2;
     const float* mrowp = (p.mask && qok) ? p.mask + (int64_t)b * p.mask_bs + (int64_t)qr * p.mask_rs : nullptr;
 
-    DirectStage<T, 64, 256> stK[NIMG], stV[NIMG];
-    TransStage<T, 64, 256> stKT[NIMG];
+    Stage64<T> st[NIMG];
     auto issue = [&](int kv0) {
+        if (wave == 0) {
 #pragma unroll
-        for (int im = 0; im < NIMG; ++im) {
-            stK[im].issue(Kp, p.k_rs, kv0, kv.len, im * 8 * VEC, ATT_D, tid);
-            stV[im].issue(Vp, p.v_rs, kv0, kv.len, im * 8 * VEC, ATT_D, tid);
-            stKT[im].issue(Kp, p.k_rs, 0, ATT_D, kv0 + im * 8 * VEC, kv.len, tid);
+            for (int im = 0; im < NIMG; ++im) st[im].issue_direct(Kp, p.k_rs, kv0, kv.len, im * 8 * VEC, ATT_D, lane);
+        } else if (wave == 1) {
+#pragma unroll
+            for (int im = 0; im < NIMG; ++im) st[im].issue_direct(Vp, p.v_rs, kv0, kv.len, im * 8 * VEC, ATT_D, lane);
+        } else if (wave == 2) {
+#pragma unroll
+            for (int im = 0; im < NIMG; ++im) st[im].issue_trans(Kp, p.k_rs, 0, ATT_D, kv0 + im * 8 * VEC, kv.len, lane);
         }
     };
-    auto commit = [&]() {
+    auto commit = [&](int buf) {
+        char* base = smem + buf * BUF;
+        if (wave == 0) {
 #pragma unroll
-        for (int im = 0; im < NIMG; ++im) {
-            stK[im].commit(sK + im * IMG_BYTES, tid);
-            stV[im].commit(sV + im * IMG_BYTES, tid);
-            stKT[im].commit(sKT + im * IMG_BYTES, tid);
+            for (int im = 0; im < NIMG; ++im) st[im].commit_direct(base + im * IMG_BYTES, lane);
+        } else if (wave == 1) {
+#pragma unroll
+            for (int im = 0; im < NIMG; ++im) st[im].commit_direct(base + (NIMG + im) * IMG_BYTES, lane);
+        } else if (wave == 2) {
+#pragma unroll
+            for (int im = 0; im < NIMG; ++im) st[im].commit_trans(base + (2 * NIMG + im) * IMG_BYTES, lane);
         }
     };
 
     const int ntiles = (kv.len + 63) >> 6;
-    if (ntiles > 0) { issue(0); commit(); }
+    if (ntiles > 0) { issue(0); commit(0); }
     __syncthreads();
 
+    int buf = 0;
     for (int t = 0; t < ntiles; ++t) {
         const int kv0 = t << 6;
         const bool has_next = t + 1 < ntiles;
         if (has_next) issue(kv0 + 64);
+        const char* sK = smem + buf * BUF;
+        const char* sV = sK + NIMG * IMG_BYTES;
+        const char* sKT = sK + 2 * NIMG * IMG_BYTES;
 
         f32x4_t sacc[4], pacc[4];
 #pragma unroll
@@ -374,8 +398,9 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnArgs p) {
         }
         nat_mma_64<T>(sKT, ds, dqacc, lane);
 
+        if (has_next) commit(buf ^ 1);
         __syncthreads();
-        if (has_next) { commit(); __syncthreads(); }
+        buf ^= 1;
     }
     if (qok) {
         T* DQ = (T*)p.dq + (int64_t)b * p.dq_bs + (int64_t)qr * p.dq_rs + h * ATT_D;
@@ -389,17 +414,15 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnArgs p) {
 // the K/V buffer). Loops over every query batch that maps onto this K/V batch (kv_bmod) and over
 // its query tiles; scores are produced as S[q = 4g+r][key = l&15] so the softmax terms feed the
 // dV / dK MFMAs from registers (contraction over queries).
+// roles: wave 0 stages Q [q][d], wave 1 dO [q][d], wave 2 Q^T [d][q], wave 3 dO^T [d][q].
 // ------------------------------------------------------------------------------------------
 template <typename T>
 __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnArgs p) {
     constexpr int VEC = ElemTraits<T>::VEC;
     constexpr int NIMG = 64 * (int)sizeof(T) / TILE_ROW_BYTES;
     constexpr int NDG = ATT_D / (4 * VEC);
+    constexpr int BUF = 4 * NIMG * IMG_BYTES;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    char* sQ = smem;                            // [q][d]
-    char* sDO = smem + NIMG * IMG_BYTES;        // [q][d]
-    char* sQT = smem + 2 * NIMG * IMG_BYTES;    // [d][q]
-    char* sDOT = smem + 3 * NIMG * IMG_BYTES;   // [d][q]
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -432,77 +455,108 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnArgs p) {
     const int kq4 = (p.Skv + 3) >> 2;
     const int bstep = p.kv_bmod > 0 ? p.kv_bmod : p.B;
     const int tile_lo = blockIdx.x * 64, tile_hi = tile_lo + 64;
+    const int nqt = (p.Sq + 63) >> 6;
 
-    DirectStage<T, 64, 256> stQ[NIMG], stDO[NIMG];
-    TransStage<T, 64, 256> stQT[NIMG], stDOT[NIMG];
+    // work items = (query batch b mapping onto this K/V batch, 64-row query tile qt); block-uniform iteration
+    // returns the next item packed as (b << 16 | qt), or -1 (by value: address-taken locals would go to scratch)
+    auto advance = [&](int b, int qt) -> int {
+        for (;;) {
+            if (b >= p.B) return -1;
+            ++qt;
+            if (qt < nqt) {
+                int start = 0, len = p.Skv;
+                if (p.kv_range) { start = p.kv_range[2 * b]; len = p.kv_range[2 * b + 1]; }
+                if (start < tile_hi && start + len > tile_lo) return (b << 16) | qt;
+            }
+            b += bstep; qt = -1;
+        }
+    };
 
-    for (int b = kb; b < p.B; b += bstep) {
-        int start = 0, len = p.Skv;
-        if (p.kv_range) { start = p.kv_range[2 * b]; len = p.kv_range[2 * b + 1]; }
-        if (start >= tile_hi || start + len <= tile_lo) continue;     // block-uniform
-        const int key_loc = key_abs - start;
-        const bool key_in = kok && key_loc >= 0 && key_loc < len;
+    Stage64<T> st[NIMG];
+    auto issue = [&](int b, int qt) {
+        const int qb0 = qt << 6;
         const T* Qb = (const T*)p.q + (int64_t)b * p.q_bs + h * ATT_D;
         const T* DOb = (const T*)p.dout + (int64_t)b * p.do_bs + h * ATT_D;
+#pragma unroll
+        for (int im = 0; im < NIMG; ++im) {
+            if (wave == 0) st[im].issue_direct(Qb, p.q_rs, qb0, p.Sq, im * 8 * VEC, ATT_D, lane);
+            else if (wave == 1) st[im].issue_direct(DOb, p.do_rs, qb0, p.Sq, im * 8 * VEC, ATT_D, lane);
+            else if (wave == 2) st[im].issue_trans(Qb, p.q_rs, 0, ATT_D, qb0 + im * 8 * VEC, p.Sq, lane);
+            else st[im].issue_trans(DOb, p.do_rs, 0, ATT_D, qb0 + im * 8 * VEC, p.Sq, lane);
+        }
+    };
+    auto commit = [&](int buf) {
+        char* base = smem + buf * BUF + wave * NIMG * IMG_BYTES;
+#pragma unroll
+        for (int im = 0; im < NIMG; ++im) {
+            if (wave < 2) st[im].commit_direct(base + im * IMG_BYTES, lane);
+            else st[im].commit_trans(base + im * IMG_BYTES, lane);
+        }
+    };
+
+    int item = advance(kb, -1);
+    if (item >= 0) { issue(item >> 16, item & 0xffff); commit(0); }
+    __syncthreads();
+
+    int buf = 0;
+    while (item >= 0) {
+        const int cb = item >> 16, cqt = item & 0xffff;
+        const int next = advance(cb, cqt);
+        const bool have_next = next >= 0;
+        if (have_next) issue(next >> 16, next & 0xffff);
+
+        const char* sQ = smem + buf * BUF;
+        const char* sDO = sQ + NIMG * IMG_BYTES;
+        const char* sQT = sQ + 2 * NIMG * IMG_BYTES;
+        const char* sDOT = sQ + 3 * NIMG * IMG_BYTES;
+        const int b = cb, qb0 = cqt << 6;
+        int start = 0, len = p.Skv;
+        if (p.kv_range) { start = p.kv_range[2 * b]; len = p.kv_range[2 * b + 1]; }
+        const int key_loc = key_abs - start;
+        const bool key_in = kok && key_loc >= 0 && key_loc < len;
         const int64_t statbase = ((int64_t)b * p.H + h) * p.Sq;
 
-        const int nqt = (p.Sq + 63) >> 6;
-        for (int qt64 = 0; qt64 < nqt; ++qt64) {
-            const int qb0 = qt64 << 6;
-            __syncthreads();   // previous tile's LDS reads done
+        f32x4_t pd[4], ds[4];   // [q-subtile of 16][r] : q = qb0 + qs*16 + 4g + r, key = this lane's
 #pragma unroll
-            for (int im = 0; im < NIMG; ++im) {
-                stQ[im].issue(Qb, p.q_rs, qb0, p.Sq, im * 8 * VEC, ATT_D, tid);
-                stDO[im].issue(DOb, p.do_rs, qb0, p.Sq, im * 8 * VEC, ATT_D, tid);
-                stQT[im].issue(Qb, p.q_rs, 0, ATT_D, qb0 + im * 8 * VEC, p.Sq, tid);
-                stDOT[im].issue(DOb, p.do_rs, 0, ATT_D, qb0 + im * 8 * VEC, p.Sq, tid);
+        for (int qs = 0; qs < 4; ++qs) {
+            f32x4_t sacc = {0.f, 0.f, 0.f, 0.f}, pacc = sacc;
+#pragma unroll
+            for (int dg = 0; dg < NDG; ++dg) {
+                typename Mma<T>::frag_t qfr = read_frag_mi<T>(sQ, qs * 16 + fr, dg * 4 + g);
+                typename Mma<T>::frag_t dfr = read_frag_mi<T>(sDO, qs * 16 + fr, dg * 4 + g);
+                sacc = Mma<T>::mma(qfr, kf[dg], sacc);
+                pacc = Mma<T>::mma(dfr, vf[dg], pacc);
             }
 #pragma unroll
-            for (int im = 0; im < NIMG; ++im) {
-                stQ[im].commit(sQ + im * IMG_BYTES, tid);
-                stDO[im].commit(sDO + im * IMG_BYTES, tid);
-                stQT[im].commit(sQT + im * IMG_BYTES, tid);
-                stDOT[im].commit(sDOT + im * IMG_BYTES, tid);
-            }
-            __syncthreads();
-
-            f32x4_t pd[4], ds[4];   // [q-subtile of 16][r] : q = qb0 + qs*16 + 4g + r, key = this lane's
-#pragma unroll
-            for (int qs = 0; qs < 4; ++qs) {
-                f32x4_t sacc = {0.f, 0.f, 0.f, 0.f}, pacc = sacc;
-#pragma unroll
-                for (int dg = 0; dg < NDG; ++dg) {
-                    typename Mma<T>::frag_t qfr = read_frag_mi<T>(sQ, qs * 16 + fr, dg * 4 + g);
-                    typename Mma<T>::frag_t dfr = read_frag_mi<T>(sDO, qs * 16 + fr, dg * 4 + g);
-                    sacc = Mma<T>::mma(qfr, kf[dg], sacc);
-                    pacc = Mma<T>::mma(dfr, vf[dg], pacc);
-                }
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int qr = qb0 + qs * 16 + 4 * g + r;
-                    float pr = 0.f, dsv = 0.f, pdv = 0.f;
-                    if (qr < p.Sq && key_in) {
-                        float s = sacc[r] * p.scale;
-                        if (p.mask) s += p.mask[(int64_t)b * p.mask_bs + (int64_t)qr * p.mask_rs + key_loc];
-                        pr = fexp<T>(s - p.lse[statbase + qr]);
-                        float dp = pacc[r];
-                        pdv = pr;
-                        if (thr) {
-                            Philox4 rnd = philox4x32_10(p.seed, p.offset + ((uint64_t)(statbase + qr)) * kq4 + (key_loc >> 2));
-                            const int comp = key_loc & 3;   // select, not index: a runtime index sends the struct to scratch
-                            const uint32_t rv = comp == 0 ? rnd.v[0] : comp == 1 ? rnd.v[1] : comp == 2 ? rnd.v[2] : rnd.v[3];
-                            const bool keep = rv >= thr;
-                            dp = keep ? dp * keep_scale : 0.f;
-                            pdv = keep ? pr * keep_scale : 0.f;
-                        }
-                        dsv = pr * (dp - p.delta[statbase + qr]);
+            for (int r = 0; r < 4; ++r) {
+                const int qr = qb0 + qs * 16 + 4 * g + r;
+                float dsv = 0.f, pdv = 0.f;
+                if (qr < p.Sq && key_in) {
+                    float s = sacc[r] * p.scale;
+                    if (p.mask) s += p.mask[(int64_t)b * p.mask_bs + (int64_t)qr * p.mask_rs + key_loc];
+                    const float pr = fexp<T>(s - p.lse[statbase + qr]);
+                    float dp = pacc[r];
+                    pdv = pr;
+                    if (thr) {
+                        Philox4 rnd = philox4x32_10(p.seed, p.offset + ((uint64_t)(statbase + qr)) * kq4 + (key_loc >> 2));
+                        const int comp = key_loc & 3;   // select, not index: a runtime index sends the struct to scratch
+                        const uint32_t rv = comp == 0 ? rnd.v[0] : comp == 1 ? rnd.v[1] : comp == 2 ? rnd.v[2] : rnd.v[3];
+                        const bool keep = rv >= thr;
+                        dp = keep ? dp * keep_scale : 0.f;
+                        pdv = keep ? pr * keep_scale : 0.f;
                     }
-                    pd[qs][r] = pdv; ds[qs][r] = dsv;
+                    dsv = pr * (dp - p.delta[statbase + qr]);
                 }
+                pd[qs][r] = pdv; ds[qs][r] = dsv;
             }
-            nat_mma_64<T>(sDOT, pd, dvacc, lane);   // dV^T[d][key] += dO^T[d][q] * Pdrop[q][key]
-            nat_mma_64<T>(sQT, ds, dkacc, lane);    // dK^T[d][key] += Q^T[d][q]  * dS[q][key]
         }
+        nat_mma_64<T>(sDOT, pd, dvacc, lane);   // dV^T[d][key] += dO^T[d][q] * Pdrop[q][key]
+        nat_mma_64<T>(sQT, ds, dkacc, lane);    // dK^T[d][key] += Q^T[d][q]  * dS[q][key]
+
+        if (have_next) commit(buf ^ 1);
+        __syncthreads();
+        buf ^= 1;
+        item = next;
     }
     if (kok) {
         T* DK = (T*)p.dk + (int64_t)kb * p.dk_bs + (int64_t)key_abs * p.dk_rs + h * ATT_D;
@@ -519,7 +573,13 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnArgs p) {
 template <typename T>
 static int attn_fwd_launch(hipStream_t st, const AttnArgs& p) {
     constexpr int NIMG = 64 * (int)sizeof(T) / TILE_ROW_BYTES;
-    const size_t lds = 2 * NIMG * IMG_BYTES;
+    const size_t lds = 2 * 2 * NIMG * IMG_BYTES;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipFuncSetAttribute((const void*)attn_fwd_kernel<T, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipFuncSetAttribute((const void*)attn_fwd_kernel<T, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_set = true;
+    }
     if (p.Sq > 64) {
         dim3 grid((p.Sq + 127) / 128, p.H, p.B);
         hipLaunchKernelGGL((attn_fwd_kernel<T, 2>), grid, dim3(256), lds, st, p);
@@ -533,12 +593,17 @@ template <typename T>
 static int attn_bwd_launch(hipStream_t st, const AttnArgs& p) {
     constexpr int NIMG = 64 * (int)sizeof(T) / TILE_ROW_BYTES;
     {
-        const size_t lds = 3 * NIMG * IMG_BYTES;
+        const size_t lds = 2 * 3 * NIMG * IMG_BYTES;
+        static bool attr_set_dq = false;
+        if (!attr_set_dq) {
+            hipFuncSetAttribute((const void*)attn_bwd_dq_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            attr_set_dq = true;
+        }
         dim3 grid((p.Sq + 63) / 64, p.H, p.B);
         hipLaunchKernelGGL((attn_bwd_dq_kernel<T>), grid, dim3(256), lds, st, p);
     }
     {
-        const size_t lds = 4 * NIMG * IMG_BYTES;
+        const size_t lds = 2 * 4 * NIMG * IMG_BYTES;
         static bool attr_set = false;
         if (!attr_set) {
             hipFuncSetAttribute((const void*)attn_bwd_dkv_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);

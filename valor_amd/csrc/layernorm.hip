@@ -223,19 +223,29 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(LnBwdArgs p) {
     }
 }
 
-// sum `nparts` partial rows [nparts][cols] (fp32) -> out[cols] (T or fp32), optional accumulate
+// sum `nparts` partial rows [nparts][cols] (fp32) -> out[cols] (T or fp32), optional accumulate.
+// workgroup = 64 columns x 16 row-groups (1024 threads): coalesced 256-B row reads, 16-way split of the
+// partial rows, LDS tree over the row groups.
 template <typename T>
-__global__ void colsum_finalize_kernel(const float* part, int nparts, int cols, void* out, int out_f32, int accumulate) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= cols) return;
+__global__ __launch_bounds__(1024) void colsum_finalize_kernel(const float* part, int nparts, int cols, void* out, int out_f32, int accumulate) {
+    __shared__ float red[16][64];
+    const int cx = threadIdx.x & 63, ry = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + cx;
     float s = 0.f;
-    for (int i = 0; i < nparts; ++i) s += part[(int64_t)i * cols + c];
-    if (out_f32) {
-        float* o = (float*)out;
-        o[c] = (accumulate ? o[c] : 0.f) + s;
-    } else {
-        T* o = (T*)out;
-        o[c] = from_f32<T>((accumulate ? to_f32<T>(o[c]) : 0.f) + s);
+    if (c < cols)
+        for (int i = ry; i < nparts; i += 16) s += part[(int64_t)i * cols + c];
+    red[ry][cx] = s;
+    __syncthreads();
+    if (ry == 0 && c < cols) {
+#pragma unroll
+        for (int j = 1; j < 16; ++j) s += red[j][cx];
+        if (out_f32) {
+            float* o = (float*)out;
+            o[c] = (accumulate ? o[c] : 0.f) + s;
+        } else {
+            T* o = (T*)out;
+            o[c] = from_f32<T>((accumulate ? to_f32<T>(o[c]) : 0.f) + s);
+        }
     }
 }
 
@@ -335,11 +345,11 @@ extern "C" int valor_colsum_finalize(void* stream, int dtype, const float* part,
                                      int out_f32, int accumulate) {
     if (cols <= 0) return VALOR_OK;
     hipStream_t st = (hipStream_t)stream;
-    dim3 grid((cols + 255) / 256);
+    dim3 grid((cols + 63) / 64);
     if (dtype == VALOR_DT_BF16)
-        hipLaunchKernelGGL((colsum_finalize_kernel<bf16_t>), grid, dim3(256), 0, st, part, nparts, cols, out, out_f32, accumulate);
+        hipLaunchKernelGGL((colsum_finalize_kernel<bf16_t>), grid, dim3(1024), 0, st, part, nparts, cols, out, out_f32, accumulate);
     else if (dtype == VALOR_DT_F32)
-        hipLaunchKernelGGL((colsum_finalize_kernel<float>), grid, dim3(256), 0, st, part, nparts, cols, out, out_f32, accumulate);
+        hipLaunchKernelGGL((colsum_finalize_kernel<float>), grid, dim3(1024), 0, st, part, nparts, cols, out, out_f32, accumulate);
     else return VALOR_ERR_ARG;
     return valor_launch_status();
 }

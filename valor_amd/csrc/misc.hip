@@ -138,17 +138,37 @@ __global__ void add_frame_type_bwd_kernel(const T* dout, T* din, int Bn, int F, 
         store4<T>(din + r * E + e, load4<T>(dout + b * out_bs + (out_row_off + fx) * E + e));
     }
 }
-// dframe[f][e] = sum_{b,x} din[b][f][x][e]
+// dframe[f][e] = sum_{b,x} din[b][f][x][e] : grid (F, 64 slices); each wave strides over the (b,x) pairs of
+// frame f, fp32 partials per slice are summed by the last stage (one thread per column of a frame).
+#define FRAME_SLICES 64
 template <typename T>
-__global__ void frame_sum_kernel(const T* din, T* dframe, int Bn, int F, int X, int E) {
-    const int E4 = E / 4;
-    const int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (q >= (int64_t)F * E4) return;
-    const int e = (int)(q % E4) * 4, f = (int)(q / E4);
-    f32x4_t s = {0.f, 0.f, 0.f, 0.f};
-    for (int b = 0; b < Bn; ++b)
-        for (int x = 0; x < X; ++x) s += load4<T>(din + (((int64_t)b * F + f) * X + x) * E + e);
-    store4<T>(dframe + (int64_t)f * E + e, s);
+__global__ __launch_bounds__(256) void frame_sum_partial_kernel(const T* din, float* part, int Bn, int F, int X, int E) {
+    __shared__ float red[4][256];
+    const int f = blockIdx.x, sl = blockIdx.y, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t npairs = (int64_t)Bn * X;
+    for (int c0 = 0; c0 < E; c0 += 256) {
+        const int c = c0 + lane * 4;
+        f32x4_t s = {0.f, 0.f, 0.f, 0.f};
+        if (c < E)
+            for (int64_t pr = (int64_t)sl * 4 + wave; pr < npairs; pr += FRAME_SLICES * 4) {
+                const int64_t b = pr / X, x = pr - b * X;
+                s += load4<T>(din + ((b * F + f) * X + x) * E + c);
+            }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < 4; ++k) red[wave][lane * 4 + k] = s[k];
+        __syncthreads();
+        const int cc = c0 + threadIdx.x;
+        if (cc < E) part[((int64_t)sl * F + f) * E + cc] = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+    }
+}
+template <typename T>
+__global__ void frame_sum_final_kernel(const float* part, T* dframe, int F, int E) {
+    const int q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= F * E) return;
+    float s = 0.f;
+    for (int sl = 0; sl < FRAME_SLICES; ++sl) s += part[(int64_t)sl * F * E + q];
+    dframe[q] = from_f32<T>(s);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -306,17 +326,20 @@ extern "C" int valor_add_frame_type_fwd(void* stream, int dtype, const void* in,
     return valor_launch_status();
 }
 // din [Bn,F,X,E] = slice of dout ; dframe [F,E] = sum_{b,x} din
-extern "C" int valor_add_frame_type_bwd(void* stream, int dtype, const void* dout, void* din, void* dframe, int Bn, int F, int X,
+extern "C" int valor_add_frame_type_bwd(void* stream, int dtype, const void* dout, void* din, void* dframe, float* part, int Bn, int F, int X,
                                         int E, int64_t out_bs, int64_t out_row_off) {
     if (Bn <= 0) return VALOR_OK;
     if (E & 3) return VALOR_ERR_ARG;
     hipStream_t st = (hipStream_t)stream;
-    const int64_t work = (int64_t)Bn * F * X * E / 4, work2 = (int64_t)F * E / 4;
+    const int64_t work = (int64_t)Bn * F * X * E / 4;
+    if (!part) return VALOR_ERR_ARG;   // fp32 scratch >= 64 * F * E floats
     DISPATCH_T(dtype,
         { hipLaunchKernelGGL((add_frame_type_bwd_kernel<bf16_t>), dim3(grid_for(work)), dim3(256), 0, st, (const bf16_t*)dout, (bf16_t*)din, Bn, F, X, E, out_bs, out_row_off);
-          hipLaunchKernelGGL((frame_sum_kernel<bf16_t>), dim3(grid_for(work2, 256, 1 << 20)), dim3(256), 0, st, (const bf16_t*)din, (bf16_t*)dframe, Bn, F, X, E); },
+          hipLaunchKernelGGL((frame_sum_partial_kernel<bf16_t>), dim3(F, FRAME_SLICES), dim3(256), 0, st, (const bf16_t*)din, part, Bn, F, X, E);
+          hipLaunchKernelGGL((frame_sum_final_kernel<bf16_t>), dim3((F * E + 255) / 256), dim3(256), 0, st, part, (bf16_t*)dframe, F, E); },
         { hipLaunchKernelGGL((add_frame_type_bwd_kernel<float>), dim3(grid_for(work)), dim3(256), 0, st, (const float*)dout, (float*)din, Bn, F, X, E, out_bs, out_row_off);
-          hipLaunchKernelGGL((frame_sum_kernel<float>), dim3(grid_for(work2, 256, 1 << 20)), dim3(256), 0, st, (const float*)din, (float*)dframe, Bn, F, X, E); });
+          hipLaunchKernelGGL((frame_sum_partial_kernel<float>), dim3(F, FRAME_SLICES), dim3(256), 0, st, (const float*)din, part, Bn, F, X, E);
+          hipLaunchKernelGGL((frame_sum_final_kernel<float>), dim3((F * E + 255) / 256), dim3(256), 0, st, part, (float*)dframe, F, E); });
     return valor_launch_status();
 }
 

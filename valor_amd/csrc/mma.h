@@ -186,3 +186,82 @@ DEVINL int xcd_remap(int bid, int nwg) {
     const int start = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
     return start + loc;
 }
+
+// ---------------------------------------------------------------------------------------
+// Stage64: a 64-row x 128-byte LDS image staged by ONE wave (64 lanes), 8 x 16 B per lane, either
+// "direct" (rows = image rows, k contiguous in memory) or "transposed" (k = slow dim in memory).
+// Both modes use the SAME register array, so a kernel can give each of its waves a different image
+// (wave-uniform role switch) without multiplying the staging registers.
+// ---------------------------------------------------------------------------------------
+template <typename T>
+struct Stage64 {
+    static constexpr int VEC = ElemTraits<T>::VEC;
+    u32x4_t v[8];
+    int valid[8];   // direct: elements valid per chunk ; trans: k-rows valid per task (index j*VEC)
+
+    // direct: lane handles chunks idx = lane + 64*j : c = idx & 7, r = idx >> 3  (r = lane/8 + 8*j)
+    DEVINL void issue_direct(const T* __restrict__ base, int64_t ld, int row0, int R, int k0, int K, int lane) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int idx = lane + 64 * j, c = idx & 7, r = idx >> 3;
+            const int gr = row0 + r, gk = k0 + c * VEC;
+            const bool ok = gr < R && gk < K;
+            const int nv = K - gk;
+            valid[j] = ok ? (nv > VEC ? VEC : nv) : 0;
+            v[j] = *(const u32x4_t*)(base + (ok ? (int64_t)gr * ld + gk : (int64_t)0));
+        }
+    }
+    DEVINL void commit_direct(char* img, int lane) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int idx = lane + 64 * j, c = idx & 7, r = idx >> 3;
+            u32x4_t val = v[j];
+            const int nvl = valid[j];
+            if (nvl < VEC) {
+                if (VEC == 8) {
+#pragma unroll
+                    for (int d = 0; d < 4; ++d) {
+                        if (2 * d >= nvl) val[d] = 0u;
+                        else if (2 * d + 1 >= nvl) val[d] &= 0xffffu;
+                    }
+                } else {
+#pragma unroll
+                    for (int d = 0; d < 4; ++d)
+                        if (d >= nvl) val[d] = 0u;
+                }
+            }
+            *(u32x4_t*)(img + tile_off(r, c)) = val;
+        }
+    }
+    // transposed: tasks t = lane + 64*j (j < 8/VEC): kg = t & 7, rc = t >> 3 ; VEC loads per task
+    DEVINL void issue_trans(const T* __restrict__ base, int64_t ld, int row0, int R, int k0, int K, int lane) {
+#pragma unroll
+        for (int j = 0; j < 8 / VEC; ++j) {
+            const int t = lane + 64 * j, kg = t & 7, rc = t >> 3;
+            const int gr = row0 + rc * VEC;
+            const bool rok = gr < R;
+            int kv = K - (k0 + kg * VEC);
+            kv = kv > VEC ? VEC : (kv < 0 ? 0 : kv);
+            kv = rok ? kv : 0;
+            valid[j * VEC] = kv;
+#pragma unroll
+            for (int i = 0; i < VEC; ++i) {
+                const int gk = k0 + kg * VEC + i;
+                v[j * VEC + i] = *(const u32x4_t*)(base + ((i < kv) ? (int64_t)gk * ld + gr : (int64_t)0));
+            }
+        }
+    }
+    DEVINL void commit_trans(char* img, int lane) {
+#pragma unroll
+        for (int j = 0; j < 8 / VEC; ++j) {
+            const int t = lane + 64 * j, kg = t & 7, rc = t >> 3;
+            const int kv = valid[j * VEC];
+            u32x4_t in[VEC], o[VEC];
+#pragma unroll
+            for (int i = 0; i < VEC; ++i) in[i] = (i < kv) ? v[j * VEC + i] : (u32x4_t){0u, 0u, 0u, 0u};
+            Transposer<VEC>::run(in, o);
+#pragma unroll
+            for (int i = 0; i < VEC; ++i) *(u32x4_t*)(img + tile_off(rc * VEC + i, kg)) = o[i];
+        }
+    }
+};

@@ -49,7 +49,7 @@ SIGNATURES = {
     "valor_embed_fwd": [_vp, _i, _vp, _vp, _vp, _vp, _vp, _i64, _i, _i],
     "valor_embed_bwd_word": [_vp, _i, _vp, _vp, _vp, _i64, _i],
     "valor_add_frame_type_fwd": [_vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i64, _i64],
-    "valor_add_frame_type_bwd": [_vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i64, _i64],
+    "valor_add_frame_type_bwd": [_vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i64, _i64],
     "valor_l2norm_fwd": [_vp, _i, _vp, _vp, _vp, _i64, _i],
     "valor_l2norm_bwd": [_vp, _i, _vp, _vp, _vp, _vp, _i64, _i],
     "valor_gather_rows": [_vp, _i, _vp, _vp, _vp, _i64, _i, _i64],

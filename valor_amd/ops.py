@@ -456,8 +456,9 @@ class CrossInputFn(Function):
         daud = torch.empty((b, A, Y, E), dtype=dout.dtype, device=dout.device)
         dvf = torch.zeros(vfs, dtype=dout.dtype, device=dout.device)
         daf = torch.zeros(afs, dtype=dout.dtype, device=dout.device)
-        lib.call("valor_add_frame_type_bwd", _st(), _dt(dout), _p(dout), _p(dvid), _p(dvf), b, F, X, E, (Sv + Sa) * E, 0)
-        lib.call("valor_add_frame_type_bwd", _st(), _dt(dout), _p(dout), _p(daud), _p(daf), b, A, Y, E, (Sv + Sa) * E, Sv)
+        ws = K.workspace(dout.device)
+        lib.call("valor_add_frame_type_bwd", _st(), _dt(dout), _p(dout), _p(dvid), _p(dvf), _p(ws), b, F, X, E, (Sv + Sa) * E, 0)
+        lib.call("valor_add_frame_type_bwd", _st(), _dt(dout), _p(dout), _p(daud), _p(daf), _p(ws), b, A, Y, E, (Sv + Sa) * E, Sv)
         dvt = K.colsum(dvf.view(-1, E)[:F]).view(ts)
         dat = K.colsum(daf.view(-1, E)[:A]).view(ts)
         return dvid, daud, dvf, dvt, daf, dat
