@@ -111,7 +111,7 @@ DEVINL KvSel kv_select(const AttnArgs& p, int b) {
 // forward.  grid = (ceil(Sq / (64*RT)), H, B), 256 threads; wave w owns 16*RT query rows.
 // roles: wave 0 stages K [key][d], wave 1 stages V^T [d][key].
 template <typename T, int RT>
-__global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs p) {
+__global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs p) {
     constexpr int VEC = ElemTraits<T>::VEC;
     constexpr int NIMG = 64 * (int)sizeof(T) / TILE_ROW_BYTES;   // 1 (bf16) / 2 (fp32)
     constexpr int NDG = ATT_D / (4 * VEC);                       // d-groups of 4 chunks: 2 / 4
@@ -272,7 +272,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs p) {
 // roles: wave 0 stages K [key][d], wave 1 V [key][d], wave 2 K^T [d][key].
 // ------------------------------------------------------------------------------------------
 template <typename T>
-__global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnArgs p) {
+__global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnArgs p) {
     constexpr int VEC = ElemTraits<T>::VEC;
     constexpr int NIMG = 64 * (int)sizeof(T) / TILE_ROW_BYTES;
     constexpr int NDG = ATT_D / (4 * VEC);
@@ -417,7 +417,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnArgs p) {
 // roles: wave 0 stages Q [q][d], wave 1 dO [q][d], wave 2 Q^T [d][q], wave 3 dO^T [d][q].
 // ------------------------------------------------------------------------------------------
 template <typename T>
-__global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnArgs p) {
+__global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnArgs p) {
     constexpr int VEC = ElemTraits<T>::VEC;
     constexpr int NIMG = 64 * (int)sizeof(T) / TILE_ROW_BYTES;
     constexpr int NDG = ATT_D / (4 * VEC);
