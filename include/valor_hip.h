@@ -1,0 +1,154 @@
+/* valor_hip.h -- C ABI of libvalor_hip.so: the MI355X (gfx950) kernels of the VALOR pretraining step.
+ *
+ * The reference (TXH-mercury/VALOR) has no native plugin ABI for this path: its only native boundary is the
+ * pybind module of apex's FusedLayerNorm (apex/csrc/layer_norm_cuda.cpp:235-240, at::Tensor arguments) and
+ * amp_C (apex/csrc/amp_C_frontend.cpp:116-134); everything else is torch ops called from Python
+ * (model/pretrain.py, model/modeling.py, model/bert.py, model/clip.py, model/transformer.py, optim/adamw.py).
+ * This header DEFINES the boundary a maintainer binds instead (ctypes / pybind / cgo alike): plain C, raw
+ * device pointers, sizes and strides -- no torch types. Each entry cites the reference code it replaces.
+ *
+ * Conventions
+ *   - every function is asynchronous on `stream` (a hipStream_t passed as void*), returns 0 on success,
+ *     VALOR_ERR_ARG (-1) on a bad argument, VALOR_ERR_LAUNCH (-2) if the launch failed; nothing throws;
+ *   - the caller owns all memory (kernels never allocate); workspaces are explicit arguments;
+ *   - dtype: VALOR_DT_BF16 (0) = bf16 storage / fp32 accumulate (perf mode), VALOR_DT_F32 (1) = fp32 storage,
+ *     exact fp32 MFMA (parity mode). Pointers typed `void*` hold elements of `dtype`;
+ *   - all functions are re-entrant (autograd may call from a worker thread); no global state.
+ *   - dropout masks are Philox4x32-10 streams keyed by (seed, offset + element index / 4) and are regenerated
+ *     in backward from the same (seed, offset) -- nothing is stored.
+ */
+#ifndef VALOR_HIP_H
+#define VALOR_HIP_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VALOR_DT_BF16 0
+#define VALOR_DT_F32 1
+#define VALOR_OK 0
+#define VALOR_ERR_ARG (-1)
+#define VALOR_ERR_LAUNCH (-2)
+/* activations of the GEMM epilogue */
+#define VALOR_ACT_NONE 0
+#define VALOR_ACT_GELU_ERF 1   /* bert.py:52-57, transformer.py:32-38 */
+#define VALOR_ACT_QUICK_GELU 2 /* clip.py:167-169 */
+#define VALOR_ACT_RELU 3       /* pretrain.py:104-112 */
+#define VALOR_ACT_TANH 4
+
+/* ---- GEMM: C[M,N] = epi(alpha * op(A)[M,K] . op(B)[N,K]^T).  Replaces every nn.Linear / matmul projection and its
+ * autograd GEMMs: bert.py:233-235,245-247,303-305,352,366,404,417; clip.py:176-182,237,329; transformer.py:109-142;
+ * modeling.py:249-253; pretrain.py:36-38,90-91.  transX=0: X(row,k)=X[row*ldx+k]; transX=1: X(row,k)=X[k*ldx+row].
+ * epilogue: + bias[N]; optional copy of the pre-activation to `preact`; act; or multiply by act'(dact_aux) (backward of a
+ * fused activation); C += result when `accumulate`; out_f32 stores C/preact as fp32 for bf16 inputs.
+ * workspace: fp32 scratch for split-K partial tiles (may be NULL = no split-K). */
+int valor_gemm(void* stream, int dtype, int transA, int transB, int M, int N, int K, const void* A, int64_t lda,
+               const void* B, int64_t ldb, void* C, int64_t ldc, const void* bias, int act, void* preact,
+               const void* dact_aux, int64_t ldaux, float alpha, int accumulate, int out_f32, void* workspace,
+               int64_t workspace_bytes);
+
+/* ---- fused bias + dropout + residual + LayerNorm.  Replaces apex FusedLayerNorm (apex/csrc/layer_norm_cuda_kernel.cu
+ * :279-322 forward, :403-634 backward; wrapper apex/apex/normalization/fused_layer_norm.py:14-37) plus the elementwise ops
+ * around it: bert.py:351-355,365-371,416-420 (post-LN), transformer.py:74-85 (pre-LN AST), clip.py:194-197 (pre-LN CLIP).
+ *   z = dropout(x + bias)/(1-p) + residual ; y = LN(z; gamma, beta, eps).  z may alias x; any of bias/residual/gamma/beta/
+ *   z/y may be NULL. mean/rstd: fp32 [rows]. */
+int valor_ln_part_blocks(void);
+int valor_bdrln_fwd(void* stream, int dtype, const void* x, const void* bias, const void* residual, const void* gamma,
+                    const void* beta, void* z, void* y, float* mean, float* rstd, int64_t rows, int cols, float eps,
+                    float p_drop, uint64_t seed, uint64_t offset);
+/* backward: dz = LN'(dy) + dz_in -> dres ; dx = dz * dropmask/(1-p). part_*: fp32 [valor_ln_part_blocks() * cols]
+ * per-workgroup column partials of dgamma / dbeta / dbias (finish with valor_colsum_finalize). */
+int valor_bdrln_bwd(void* stream, int dtype, const void* dy, const void* dz_in, const void* z, const float* mean,
+                    const float* rstd, const void* gamma, void* dx, void* dres, float* part_dgamma, float* part_dbeta,
+                    float* part_dbias, int64_t rows, int cols, float p_drop, uint64_t seed, uint64_t offset);
+int valor_colsum_finalize(void* stream, int dtype, const float* part, int nparts, int cols, void* out, int out_f32,
+                          int accumulate);
+/* out[cols] (+)= column sums of x[rows, cols] (ld): nn.Linear bias gradients. part: fp32 [valor_ln_part_blocks()*cols]. */
+int valor_colsum(void* stream, int dtype, const void* x, int64_t rows, int cols, int64_t ld, float* part, void* out,
+                 int out_f32, int accumulate);
+
+/* ---- flash attention, head_dim 64.  Replaces BertSelfAttention (bert.py:272-288), BertCrossAttention (bert.py:314-340,
+ * K/V = [video|audio] tokens, grouping bert.py:448-455), AST MultiHeadAttention (transformer.py:115-130) and CLIP's
+ * nn.MultiheadAttention (clip.py:186-192, mask clip.py:407-414).  Element (b,row,h,d) of q/k/v/o lives at
+ * base + b*bs + row*rs + h*64 + d.  mask: additive fp32 [*, Sq, >=len] indexed (b*mask_bs + q*mask_rs + local key).
+ * kv_range: int32 [B][2] (start,len) rows of the K/V buffer batch b attends to; kv_bmod>0: K/V batch = b % kv_bmod
+ * (modality-grouped cross-attention with ONE shared K/V projection). lse: fp32 [B,H,Sq]. */
+int valor_attn_fwd(void* stream, int dtype, const void* q, const void* k, const void* v, void* o, float* lse, int B,
+                   int H, int Sq, int Skv, int64_t q_bs, int64_t q_rs, int64_t k_bs, int64_t k_rs, int64_t v_bs,
+                   int64_t v_rs, int64_t o_bs, int64_t o_rs, const float* mask, int64_t mask_bs, int64_t mask_rs,
+                   const int* kv_range, int kv_bmod, float scale, float p_drop, uint64_t seed, uint64_t offset);
+int valor_attn_bwd(void* stream, int dtype, const void* q, const void* k, const void* v, const void* o, const float* lse,
+                   const void* dout, void* dq, void* dk, void* dv, float* delta, int B, int H, int Sq, int Skv,
+                   int64_t q_bs, int64_t q_rs, int64_t k_bs, int64_t k_rs, int64_t v_bs, int64_t v_rs, int64_t o_bs,
+                   int64_t o_rs, int64_t do_bs, int64_t do_rs, int64_t dq_bs, int64_t dq_rs, int64_t dk_bs, int64_t dk_rs,
+                   int64_t dv_bs, int64_t dv_rs, const float* mask, int64_t mask_bs, int64_t mask_rs, const int* kv_range,
+                   int kv_bmod, float scale, float p_drop, uint64_t seed, uint64_t offset);
+
+/* ---- softmax cross-entropy over the vocabulary: F.cross_entropy on the masked rows (pretrain.py:444,457,469,498).
+ * logits [rows, V] with leading dim ld; backward overwrites the logits (and zero-fills the ld padding) with
+ * (softmax - onehot) * (*gscale_dev) * gmul. */
+int valor_xent_fwd(void* stream, int dtype, const void* logits, const int64_t* labels, float* loss_rows, float* lse,
+                   int64_t rows, int V, int64_t ld);
+int valor_xent_bwd(void* stream, int dtype, void* logits_inout, const int64_t* labels, const float* lse,
+                   const float* gscale_dev, float gmul, int64_t rows, int V, int64_t ld);
+int valor_mean_f32(void* stream, const float* x, int64_t n, float* out);
+
+/* ---- MGA fine-grained contrastive: compute_fine_matrix_slice (pretrain.py:191-211) + contrastive_loss
+ * (modeling.py:418-433). S = featA . featB^T comes from valor_gemm (fp32 [B*T, ldS]). */
+int valor_fine_weight_softmax(void* stream, const float* raw, const float* mask, float* w, int rows, int n);
+int valor_fine_weight_softmax_bwd(void* stream, const float* w, const float* dw, float* draw, int rows, int n);
+int valor_fine_reduce_fwd(void* stream, const float* S, int64_t ldS, const float* maskA, const float* maskB,
+                          const float* wA, const float* wB, float* score, float* A2B, float* B2A, uint8_t* idxA,
+                          uint8_t* idxB, int B, int T, int Nv);
+int valor_infonce_fwd(void* stream, const float* score, const float* k_dev, float* lse_r, float* lse_c, float* loss, int B);
+int valor_infonce_bwd(void* stream, const float* score, const float* k_dev, const float* lse_r, const float* lse_c,
+                      const float* g_dev, float* dscore, float* dk, float* part, int B);
+int valor_fine_reduce_bwd(void* stream, int dtype, const float* dscore, const float* maskA, const float* maskB,
+                          const float* wA, const float* wB, const float* A2B, const float* B2A, const uint8_t* idxA,
+                          const uint8_t* idxB, void* dS, int64_t ldS, float* dwA, float* dwB, int B, int T, int Nv);
+
+/* ---- fused multi-tensor AdamW + global-norm clip over flat arenas.  Replaces optim/adamw.py:40-103, optim/misc.py:66-77
+ * (10 param groups), torch clip_grad_norm_ (train_utils.py:358-360) and apex-amp's master<->model copies
+ * (apex/apex/amp/_process_optimizer.py:14-22). n % valor_adamw_chunk() == 0; chunk_group: int8 [n/chunk], -1 = skip. */
+int valor_adamw_chunk(void);
+int valor_adamw(void* stream, int dtype, float* master, float* exp_avg, float* exp_avg_sq, void* grad, void* param,
+                const int8_t* chunk_group, int64_t n, const float* lr, const float* wd, int ngroups, float beta1,
+                float beta2, float eps, int step, int correct_bias, const float* gscale_dev, int zero_grad);
+int valor_grad_norm_clip(void* stream, int dtype, const void* grad, const int8_t* chunk_group, int64_t n, float norm_mul,
+                         float max_norm, float* partial, float* total_norm, float* gscale);
+
+/* ---- data-movement kernels around the core */
+/* conv(kernel=stride=P) as GEMM: clip.py:227,261 ; modeling.py:744,752 */
+int valor_patchify(void* stream, int dtype, const float* in, void* out, int N, int C, int H, int W, int P);
+/* [cls ; patches (+bias)] + pos: clip.py:264-265 ; modeling.py:755-760 */
+int valor_assemble_tokens_fwd(void* stream, int dtype, const void* patches, const void* cls, const void* pos,
+                              const void* bias, void* out, int N, int Pn, int E);
+int valor_assemble_tokens_bwd(void* stream, int dtype, const void* dout, void* dpatches, void* dpos, int N, int Pn, int E);
+int valor_sum_over_batch(void* stream, int dtype, const void* x, void* dsum, int N, int Tn, int E);
+/* word + position + type embeddings: bert.py:211-215 ; clip.py:377-379 */
+int valor_embed_fwd(void* stream, int dtype, const int64_t* ids, const void* word, const void* pos, const void* typevec,
+                    void* out, int64_t n, int L, int E);
+int valor_embed_bwd_word(void* stream, int dtype, const int64_t* ids, const void* dout, void* dword, int64_t n, int E);
+/* decoder inputs: + frame embedding + type embedding, written into the concatenated [video|audio] buffer: modeling.py:485-502 */
+int valor_add_frame_type_fwd(void* stream, int dtype, const void* in, const void* frame_emb, const void* type_emb, void* out,
+                             int Bn, int F, int X, int E, int64_t out_bs, int64_t out_row_off);
+int valor_add_frame_type_bwd(void* stream, int dtype, const void* dout, void* din, void* dframe, float* part, int Bn, int F,
+                             int X, int E, int64_t out_bs, int64_t out_row_off);
+/* F.normalize(dim=-1): pretrain.py:276,283,290 */
+int valor_l2norm_fwd(void* stream, int dtype, const void* x, void* y, float* norm, int64_t rows, int cols);
+int valor_l2norm_bwd(void* stream, int dtype, const void* y, const void* dy, const float* norm, void* dx, int64_t rows, int cols);
+/* masked-token / cls-token row selection: pretrain.py:441,495 ; modeling.py:387,399 */
+int valor_gather_rows(void* stream, int dtype, const void* src, const int64_t* idx, void* out, int64_t n, int E, int64_t src_ld);
+int valor_scatter_rows(void* stream, int dtype, const void* src, const int64_t* idx, void* dst, int64_t n, int E, int64_t dst_ld);
+int valor_cast_from_f32(void* stream, int dtype, const float* in, void* out, int64_t n);
+/* backward of a fused activation when no GEMM can absorb it: modeling.py:249-252 */
+int valor_dact_mul(void* stream, int dtype, const void* dh, const void* u, void* du, int64_t n, int act);
+/* Linear(E -> 1) of the fine-weight heads: pretrain.py:104-112 */
+int valor_rowdot_fwd(void* stream, int dtype, const void* x, const void* w, const void* b, void* y, int64_t rows, int cols);
+int valor_rowdot_bwd(void* stream, int dtype, const void* dy, const void* x, const void* w, void* dx, void* dw, void* db,
+                     int64_t rows, int cols);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VALOR_HIP_H */

@@ -1,0 +1,103 @@
+"""CPU, world_size 2 over gloo: the data-parallel pieces (valor_amd/dist.py).
+  * packed all-gather: values/ordering equal to the reference's ddp_allgather_with_grads + ddp_allgather and
+    backward returns the LOCAL slice only (utils/distributed.py:62-72);
+  * reducer: bucketed all-reduce over the flat gradient arena == sum over ranks, learnt unused-parameter set,
+    overlapped launches from the grad hooks on later steps."""
+import os
+import sys
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _worker(rank, world, port, fn, ret):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    sys.path.insert(0, ROOT)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        ret[rank] = fn(rank, world)
+    finally:
+        dist.destroy_process_group()
+
+
+def _run(fn, world=2):
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    port = 29500 + (os.getpid() % 1000)
+    mp.spawn(_worker, args=(world, port, fn, ret), nprocs=world, join=True)
+    return [ret[r] for r in range(world)]
+
+
+def _gather_case(rank, world):
+    from valor_amd.dist import packed_allgather_with_grads
+    g = torch.Generator().manual_seed(100 + rank)
+    b = 3
+    ft = torch.randn(b, 4, 8, generator=g, requires_grad=True)
+    fv = torch.randn(b, 2, 8, generator=g, requires_grad=True)
+    fa = torch.randn(b, 1, 8, generator=g, requires_grad=True)
+    tok = torch.randint(0, 49408, (b, 4), generator=g)
+    Ft, Fv, Fa, Tok = packed_allgather_with_grads(ft, fv, fa, tok)
+    # a loss every rank computes identically on the gathered tensors (like the contrastive loss)
+    w = torch.arange(Ft.numel(), dtype=torch.float32).view_as(Ft)
+    loss = (Ft * w).sum() + (Fv ** 2).sum() + Fa.sum()
+    loss.backward()
+    return dict(Ft=Ft.detach(), Fv=Fv.detach(), Fa=Fa.detach(), Tok=Tok, ft=ft.detach(), fv=fv.detach(), fa=fa.detach(), tok=tok,
+                gft=ft.grad, gfv=fv.grad, gfa=fa.grad, w=w)
+
+
+def test_packed_allgather_forward_and_local_slice_backward():
+    r = _run(_gather_case)
+    for k, kk in (("Ft", "ft"), ("Fv", "fv"), ("Fa", "fa"), ("Tok", "tok")):
+        want = torch.cat([r[0][kk], r[1][kk]], dim=0)              # rank-major concat == utils/distributed.py:55-57
+        for rank in range(2):
+            assert torch.equal(r[rank][k], want), k
+    for rank in range(2):
+        b = 3
+        assert torch.allclose(r[rank]["gft"], r[rank]["w"][rank * b:(rank + 1) * b])       # local slice of dL/dFt
+        assert torch.allclose(r[rank]["gfv"], 2 * r[rank]["fv"])
+        assert torch.allclose(r[rank]["gfa"], torch.ones_like(r[rank]["fa"]))
+
+
+def _reducer_case(rank, world):
+    from valor_amd.arena import ParamArena
+    from valor_amd.dist import Reducer
+    entries = [(f"p{i}", (300 + 7 * i,), 0) for i in range(12)]
+    arena = ParamArena(entries, torch.float32, "cpu")
+    red = Reducer(arena, bucket_bytes=4096)
+    assert len(red.buckets) > 2
+    outs = []
+    for step in range(3):
+        arena.grad.zero_()
+        red.prepare_backward()
+        loss = 0
+        for i, (name, p) in enumerate(arena.params.items()):
+            if i % 4 == 3:
+                continue                                  # unused parameters (find_unused_parameters semantics)
+            loss = loss + (p * (rank + 1) * (i + 1 + step)).sum()
+        loss.backward()
+        active = red.finish_backward()
+        outs.append((arena.grad.clone(), sorted(active), len(red.works)))
+    return outs
+
+
+def test_reducer_sums_arena_and_learns_unused_parameters():
+    r = _run(_reducer_case)
+    for step in range(3):
+        g0, act0, nworks0 = r[0][step]
+        g1, act1, _ = r[1][step]
+        assert torch.equal(g0, g1) and act0 == act1
+        assert all(f"p{i}" not in act0 for i in (3, 7, 11)) and len(act0) == 9
+        # expected: d/dp_i sum_ranks (rank+1)*(i+1+step) = 3*(i+1+step)
+        from valor_amd.arena import ParamArena
+        arena = ParamArena([(f"p{i}", (300 + 7 * i,), 0) for i in range(12)], torch.float32, "cpu")
+        for i in range(12):
+            o, n, _ = arena.offsets[f"p{i}"]
+            want = 0.0 if i % 4 == 3 else 3.0 * (i + 1 + step)
+            assert torch.allclose(g0[o:o + n], torch.full((n,), want)), (step, i)
+        if step > 0:
+            assert nworks0 > 1          # bucketed, hook-launched all-reduces after the first (learning) step

@@ -1,0 +1,126 @@
+"""CPU: host-side logic of the native model (no kernels): parameter table <-> reference checkpoint layout, optimizer
+param groups, LR schedule, TokenMasker draw order, attention masks, task prompts, arena layout, FLOP model."""
+import os
+import random
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+
+from valor_amd import synth  # noqa: E402
+from valor_amd.model.params import optimizer_group, param_table  # noqa: E402
+from valor_amd.model.valor import VALOR, TokenMasker  # noqa: E402
+import valor_oracle as VO  # noqa: E402
+
+
+def test_param_table_covers_reference_layout_exactly():
+    spec = synth.base_spec()
+    layout = synth.state_dict_layout(spec)
+    ref_keys = {k: s for k, s, _ in layout}
+    seen = {}
+    n_params = 0
+    for name, shape, refs in param_table(spec):
+        numel = 1
+        for s in shape:
+            numel *= s
+        n_params += numel
+        if len(refs) == 1 or refs[1] == "cls.decoder.weight":
+            for r in refs:
+                seen[r] = shape
+        else:
+            rows = shape[0] // len(refs)
+            for r in refs:
+                seen[r] = (rows,) + tuple(shape[1:])
+    assert set(seen) == set(ref_keys)
+    for k, s in seen.items():
+        assert tuple(s) == tuple(ref_keys[k]), (k, s, ref_keys[k])
+    assert len(ref_keys) == 845 and n_params == 374680383      # 845 tensors, 374.68 M parameters
+
+
+def test_state_dict_roundtrip_and_packing():
+    spec = synth.tiny_spec()
+    sd = synth.make_state_dict(spec, seed=1)
+    m = VALOR(None, spec=spec, dtype=torch.float32, device="cpu")
+    assert m.load_state_dict(sd, strict=True) == ([], [])
+    out = m.state_dict()
+    assert set(out) == set(sd) and all(torch.equal(out[k], sd[k]) for k in sd)
+    p = "multimodal_encoder.encoder.layer.1.attention.self."
+    packed = m.P[p + "qkv.weight"]
+    H = spec.hidden
+    assert torch.equal(packed[H:2 * H], sd[p + "key.weight"])          # fused-QKV view is the checkpoint's q|k|v
+    assert out["cls.decoder.weight"].data_ptr() == out["multimodal_encoder.embeddings.word_embeddings.weight"].data_ptr()
+    # arena: every tensor starts on an optimizer chunk, grads alias the flat gradient buffer
+    for name, (off, n, shape) in m.arena.offsets.items():
+        assert off % m.arena.chunk == 0
+        assert m.P[name].grad.data_ptr() == m.arena.grad[off:].data_ptr()
+
+
+def test_optimizer_groups_match_reference_rules():
+    """optim/misc.py:13-64, including its case-sensitive quirks."""
+    g = optimizer_group
+    assert g("multimodal_encoder.encoder.layer.0.attention.self.query.weight") == 0
+    assert g("multimodal_encoder.encoder.layer.0.attention.output.LayerNorm.weight") == 1
+    assert g("audio_encoder.layer.0.layernorm1.weight") == 0            # lower-case 'layernorm' IS decayed
+    assert g("cls.layernorm.weight") == 0 and g("cls.layernorm.bias") == 1
+    assert g("clip_model.visual.ln_pre.weight") == 4 and g("clip_model.visual.ln_pre.bias") == 5
+    assert g("clip_model.transformer.resblocks.0.attn.in_proj_bias") == 7 and g("clip_model.logit_scale") == 6
+    assert g("contra_head_a.linear.weight", ("contra_head",)) == 2
+    for k, _, _ in synth.state_dict_layout(synth.base_spec()):
+        assert g(k) == VO.param_group_of(k), k
+
+
+def test_lr_schedule():
+    from valor_amd.optim import warmup_linear
+    for x in (0.0, 0.05, 0.1, 0.5, 1.0, 1.2):
+        assert warmup_linear(x, 0.1) == VO.warmup_linear(x, 0.1)
+    assert warmup_linear(0.05, 0.1) == 0.5 and warmup_linear(1.0, 0.1) == 0.0
+
+
+def test_token_masker_matches_reference_draw_order():
+    spec = synth.base_spec()
+    batch = synth.make_batch(spec, batch=5, frames=1, audio_slices=1, seed=3)
+    toks = batch["txt_tokens"]["bert_tokens"]
+    orc = VO.Oracle(spec, {}, vocab_tokens=synth.synthetic_vocab(spec.vocab))
+    mk = TokenMasker(103, 106, spec.vocab)
+    for prob in (0.6, 0.15):
+        random.seed(42); a = orc.text_masker(toks, prob)
+        random.seed(42); b = mk(toks, prob)
+        assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+        assert ((b[1] != -1).sum(1) >= 1).all() and (b[1][:, 0] == -1).all()
+
+
+def test_masks_and_prompts():
+    spec = synth.tiny_spec()
+    m = VALOR(None, spec=spec, dtype=torch.float32, device="cpu")
+    toks = torch.tensor([[101, 5, 6, 102, 0, 0], [101, 7, 102, 0, 0, 0]])
+    prompt = m.get_task_prompt("predict masked tokens with visual and audio cues", 2)
+    assert prompt.shape == (2, 10) and prompt[0, 0] == 101 and prompt[0, -1] == 102 and (prompt != 100).all()
+    am = m._bert_mask(toks, prompt, casual=True)
+    assert am.shape == (2, 16, 16)
+    assert am[0, 1, 2] == -10000.0 and am[0, 2, 1] == 0.0          # causal inside the text block
+    assert (am[0, 6:, :6] == -10000.0).all()                       # prompt rows cannot see text (bert.py:882)
+    assert am[0, 0, 4] == -10000.0 and am[0, 0, 6] == 0.0          # padding masked, prompt visible
+    am2 = m._bert_mask(toks, prompt, casual=False)
+    assert am2[0, 1, 2] == 0.0 and am2[0, 7, 1] == 0.0 and am2[0, 1, 5] == -10000.0
+    cm = m._clip_text_mask(toks)
+    assert cm[1, 2, 1] == 0.0 and cm[1, 1, 2] == -10000.0 and cm[1, 4, 3] == -10000.0
+
+
+def test_unsupported_configs_fail_loudly():
+    import pytest
+    with pytest.raises(NotImplementedError):
+        VALOR({"video_encoder_type": "videoswin_base_k600_22k"}, spec=synth.tiny_spec(), dtype=torch.float32, device="cpu")
+    with pytest.raises(NotImplementedError):
+        VALOR({"fineweight_type": "none"}, spec=synth.tiny_spec(), dtype=torch.float32, device="cpu")
+    m = VALOR(None, spec=synth.tiny_spec(), dtype=torch.float32, device="cpu")
+    with pytest.raises(NotImplementedError):
+        m({}, task="ret%tv")
+
+
+def test_flop_model_matches_survey():
+    sys.path.insert(0, ROOT)
+    import bench
+    nf = bench.necessary_flops_per_sample(synth.base_spec(), 8, 2, 32)
+    assert 1.15e12 < nf < 1.30e12          # ~1218 GFLOP fwd+bwd per sample with shared cross-K/V

@@ -36,10 +36,23 @@ struct GemmArgs {
     int kslices;           // split-K factor (gridDim.y)
     int ksteps_per_slice;
     float alpha;
+    uint32_t bytesA, bytesB;   // extent of each operand for the buffer-descriptor range check
 };
 
 template <typename T>
-DEVINL void epilogue_store(const GemmArgs& p, int m, int n0, f32x4_t acc) {
+DEVINL f32x4_t load_bias4(const GemmArgs& p, int n0) {
+    f32x4_t b = {0.f, 0.f, 0.f, 0.f};
+    if (p.bias) {
+        const T* q = (const T*)p.bias + n0;
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            if (n0 + r < p.N) b[r] = to_f32<T>(q[r]);
+    }
+    return b;
+}
+
+template <typename T>
+DEVINL void epilogue_store(const GemmArgs& p, int m, int n0, f32x4_t acc, f32x4_t bias4) {
     // 4 consecutive n (n0 .. n0+3) of row m
     if (m >= p.M || n0 >= p.N) return;
     const int nvalid = p.N - n0 < 4 ? p.N - n0 : 4;
@@ -47,13 +60,7 @@ DEVINL void epilogue_store(const GemmArgs& p, int m, int n0, f32x4_t acc) {
     const bool vec = nvalid == 4 && ((p.ldc & 3) == 0);
     f32x4_t v;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) v[r] = acc[r] * p.alpha;
-    if (p.bias) {
-        const T* b = (const T*)p.bias + n0;
-#pragma unroll
-        for (int r = 0; r < 4; ++r)
-            if (r < nvalid) v[r] += to_f32<T>(b[r]);
-    }
+    for (int r = 0; r < 4; ++r) v[r] = acc[r] * p.alpha + bias4[r];
     if (p.preact) {
         if (p.out_f32) {
             float* q = (float*)p.preact + off;
@@ -134,41 +141,45 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs p) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
 
-    // staging registers. Transposed operands are owned by half the workgroup each when both
-    // are transposed (waves 0-1: A, waves 2-3: B) so the 8-deep load bursts stay balanced.
-    DirectStage<T, 128, 256> dA, dB;
-    TransStage<T, 128, 128> tH;   // TA && TB: half-workgroup owner
-    TransStage<T, 128, 256> tF;   // exactly one transposed operand: all threads
+    // staging through buffer descriptors (hardware range check = zero fill; see mma.h). Transposed operands
+    // are owned by half the workgroup each when both are transposed (waves 0-1: A, waves 2-3: B).
+    const rsrc_t rsA = make_rsrc(p.A, p.bytesA), rsB = make_rsrc(p.B, p.bytesB);
+    BufDirectStage<T, 128, 256> dA, dB;
+    BufTransStage<T, 128, 128> tH;   // TA && TB: half-workgroup owner
+    BufTransStage<T, 128, 256> tF;   // exactly one transposed operand: all threads
     const bool lowhalf = wave < 2;
+    const int k_first = ks_begin * BK;
+    const int ldA_b = (int)(p.lda * (int64_t)sizeof(T)), ldB_b = (int)(p.ldb * (int64_t)sizeof(T));
+    // per-K-step byte strides
+    const int stepA = TA ? BK * ldA_b : BK * (int)sizeof(T);
+    const int stepB = TB ? BK * ldB_b : BK * (int)sizeof(T);
+    if constexpr (!TA && !TB) { dA.init(p.lda, m0, k_first, tid); dB.init(p.ldb, n0, k_first, tid); }
+    else if constexpr (!TA && TB) { dA.init(p.lda, m0, k_first, tid); tF.init(p.ldb, n0, k_first, tid); }
+    else if constexpr (TA && !TB) { tF.init(p.lda, m0, k_first, tid); dB.init(p.ldb, n0, k_first, tid); }
+    else { if (lowhalf) tH.init(p.lda, m0, k_first, tid); else tH.init(p.ldb, n0, k_first, tid - 128); }
 
-    auto issue = [&](int ks) {
-        const int k0 = ks * BK;
-        if constexpr (!TA && !TB) {
-            dA.issue(A, p.lda, m0, p.M, k0, p.K, tid);
-            dB.issue(B, p.ldb, n0, p.N, k0, p.K, tid);
-        } else if constexpr (!TA && TB) {
-            dA.issue(A, p.lda, m0, p.M, k0, p.K, tid);
-            tF.issue(B, p.ldb, n0, p.N, k0, p.K, tid);
-        } else if constexpr (TA && !TB) {
-            tF.issue(A, p.lda, m0, p.M, k0, p.K, tid);
-            dB.issue(B, p.ldb, n0, p.N, k0, p.K, tid);
-        } else {
-            if (lowhalf) tH.issue(A, p.lda, m0, p.M, k0, p.K, tid);
-            else tH.issue(B, p.ldb, n0, p.N, k0, p.K, tid - 128);
+    auto issue = [&]() {   // loads of the next K-step, then bump the offsets
+        if constexpr (!TA && !TB) { dA.issue(rsA); dB.issue(rsB); dA.advance(stepA); dB.advance(stepB); }
+        else if constexpr (!TA && TB) { dA.issue(rsA); tF.issue(rsB, ldB_b); dA.advance(stepA); tF.advance(stepB); }
+        else if constexpr (TA && !TB) { tF.issue(rsA, ldA_b); dB.issue(rsB); tF.advance(stepA); dB.advance(stepB); }
+        else {
+            if (lowhalf) { tH.issue(rsA, ldA_b); tH.advance(stepA); }
+            else { tH.issue(rsB, ldB_b); tH.advance(stepB); }
         }
     };
-    auto commit = [&](int buf) {
+    auto commit = [&](int buf, int ks) {
         char* sA = smem + buf * 2 * TILE_BYTES;
         char* sB = sA + TILE_BYTES;
-        if constexpr (!TA && !TB) { dA.commit(sA, tid); dB.commit(sB, tid); }
-        else if constexpr (!TA && TB) { dA.commit(sA, tid); tF.commit(sB, tid); }
-        else if constexpr (TA && !TB) { tF.commit(sA, tid); dB.commit(sB, tid); }
+        const int kvalid = p.K - ks * BK;   // < BK only on the final partial K-step
+        if constexpr (!TA && !TB) { dA.commit(sA, tid, kvalid); dB.commit(sB, tid, kvalid); }
+        else if constexpr (!TA && TB) { dA.commit(sA, tid, kvalid); tF.commit(sB, tid); }
+        else if constexpr (TA && !TB) { tF.commit(sA, tid); dB.commit(sB, tid, kvalid); }
         else { if (lowhalf) tH.commit(sA, tid); else tH.commit(sB, tid - 128); }
     };
 
     if (ks_begin < ks_end) {
-        issue(ks_begin);
-        commit(0);
+        issue();
+        commit(0, ks_begin);
     }
     __syncthreads();
 
@@ -176,7 +187,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs p) {
     int buf = 0;
     for (int ks = ks_begin; ks < ks_end; ++ks) {
         const bool has_next = ks + 1 < ks_end;
-        if (has_next) issue(ks + 1);
+        if (has_next) issue();
         const char* sA = smem + buf * 2 * TILE_BYTES;
         const char* sB = sA + TILE_BYTES;
 #pragma unroll
@@ -192,7 +203,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs p) {
 #pragma unroll
                 for (int mi = 0; mi < 4; ++mi) acc[ni][mi] = Mma<T>::mma(fn[ni], fm[mi], acc[ni][mi]);
         }
-        if (has_next) commit(buf ^ 1);
+        if (has_next) commit(buf ^ 1, ks + 1);
         __syncthreads();
         buf ^= 1;
     }
@@ -213,6 +224,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs p) {
         }
     __syncthreads();
     float* wsl = p.kslices > 1 ? p.ws + (int64_t)blockIdx.y * p.M * p.N : nullptr;
+    const f32x4_t bias4 = load_bias4<T>(p, n0 + (tid & 31) * 4);   // this thread's 4 columns are the same in every row pass
     for (int it = 0; it < 16; ++it) {
         const int ml = it * 8 + (tid >> 5);
         const int cl = tid & 31;
@@ -225,7 +237,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs p) {
                 else for (int r = 0; r < 4; ++r) if (n + r < p.N) q[r] = v[r];
             }
         } else {
-            epilogue_store<T>(p, m, n, v);
+            epilogue_store<T>(p, m, n, v, bias4);
         }
     }
 }
@@ -244,7 +256,7 @@ __global__ __launch_bounds__(256) void gemm_splitk_reduce(GemmArgs p) {
             if (n + 3 < p.N && (p.N & 3) == 0) s += *(const f32x4_t*)q;
             else for (int r = 0; r < 4; ++r) if (n + r < p.N) s[r] += q[r];
         }
-        epilogue_store<T>(p, m, n, s);
+        epilogue_store<T>(p, m, n, s, load_bias4<T>(p, n));
     }
 }
 
@@ -293,6 +305,15 @@ extern "C" int valor_gemm(void* stream, int dtype, int transA, int transB, int M
     p.lda = lda; p.ldb = ldb; p.ldc = ldc; p.ldaux = ldaux;
     p.M = M; p.N = N; p.K = K; p.act = act; p.accumulate = accumulate; p.out_f32 = out_f32;
     p.alpha = alpha;
+    {
+        const int64_t esz = dtype == VALOR_DT_BF16 ? 2 : 4;
+        // direct: rows x ld with K valid in the last row; transposed: K rows of ld elements (caller guarantees
+        // whole 16-B chunks of a row are readable, i.e. the ld padding exists)
+        const int64_t extA = transA ? (int64_t)K * lda : ((int64_t)(M - 1) * lda + K);
+        const int64_t extB = transB ? (int64_t)K * ldb : ((int64_t)(N - 1) * ldb + K);
+        if (extA * esz >= (1ll << 31) || extB * esz >= (1ll << 31)) return VALOR_ERR_ARG;   // buffer offsets are 32-bit
+        p.bytesA = (uint32_t)(extA * esz); p.bytesB = (uint32_t)(extB * esz);
+    }
     const int bk = 8 * vec;
     const int nk = (K + bk - 1) / bk;
     // split-K heuristic: fill >= 2 waves of 256 CUs x 2 workgroups when the output is small

@@ -265,3 +265,105 @@ struct Stage64 {
         }
     }
 };
+
+// ---------------------------------------------------------------------------------------
+// Buffer-descriptor stagers for the GEMM main loop. Global loads go through a raw buffer resource
+// whose hardware range check returns 0 for every dword beyond num_records, so out-of-range rows cost NO
+// clamping / masking instructions; per-lane byte offsets are computed once and bumped by one v_add per
+// K-step. (Direct operands only need a software mask on a final partial K-step, where k runs into the
+// next row instead of past the buffer end.) Operands must be < 2 GiB.
+// ---------------------------------------------------------------------------------------
+typedef __amdgpu_buffer_rsrc_t rsrc_t;
+DEVINL rsrc_t make_rsrc(const void* base, uint32_t num_bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, (int)num_bytes, 0x00020000);
+}
+
+template <typename T, int ROWS, int NT>
+struct BufDirectStage {
+    static constexpr int VEC = ElemTraits<T>::VEC;
+    static constexpr int N = ROWS * 8 / NT;
+    static_assert(ROWS * 8 % NT == 0, "tile must divide evenly");
+    u32x4_t v[N];
+    int voff[N];
+
+    DEVINL void init(int64_t ld, int row0, int k0, int tid) {
+#pragma unroll
+        for (int j = 0; j < N; ++j) {
+            const int idx = tid + j * NT, c = idx & 7, r = idx >> 3;
+            voff[j] = (int)(((int64_t)(row0 + r) * ld + k0 + c * VEC) * (int64_t)sizeof(T));
+        }
+    }
+    DEVINL void issue(rsrc_t rs) {
+#pragma unroll
+        for (int j = 0; j < N; ++j) v[j] = __builtin_amdgcn_raw_buffer_load_b128(rs, voff[j], 0, 0);
+    }
+    DEVINL void advance(int step_bytes) {
+#pragma unroll
+        for (int j = 0; j < N; ++j) voff[j] += step_bytes;
+    }
+    // kvalid = number of valid k elements in this K-step (>= 8*VEC for a full step)
+    DEVINL void commit(char* tile, int tid, int kvalid) {
+#pragma unroll
+        for (int j = 0; j < N; ++j) {
+            const int idx = tid + j * NT, c = idx & 7, r = idx >> 3;
+            u32x4_t val = v[j];
+            if (kvalid < 8 * VEC) {   // block-uniform: only the final partial K-step
+                const int nv = kvalid - c * VEC;
+                if (VEC == 8) {
+#pragma unroll
+                    for (int d = 0; d < 4; ++d) {
+                        if (2 * d >= nv) val[d] = 0u;
+                        else if (2 * d + 1 >= nv) val[d] &= 0xffffu;
+                    }
+                } else {
+#pragma unroll
+                    for (int d = 0; d < 4; ++d)
+                        if (d >= nv) val[d] = 0u;
+                }
+            }
+            *(u32x4_t*)(tile + tile_off(r, c)) = val;
+        }
+    }
+};
+
+template <typename T, int ROWS, int NT>
+struct BufTransStage {
+    static constexpr int VEC = ElemTraits<T>::VEC;
+    static constexpr int NTASK = 8 * (ROWS / VEC);
+    static constexpr int N = (NTASK + NT - 1) / NT;
+    u32x4_t v[N][VEC];
+    int voff[N];            // offset of the task's first k-row; row i adds i*ld_bytes
+
+    DEVINL void init(int64_t ld, int row0, int k0, int tid) {
+#pragma unroll
+        for (int j = 0; j < N; ++j) {
+            const int t = tid + j * NT, kg = t & 7, rc = t >> 3;
+            voff[j] = (NTASK % NT == 0 || t < NTASK)
+                          ? (int)(((int64_t)(k0 + kg * VEC) * ld + row0 + rc * VEC) * (int64_t)sizeof(T))
+                          : 0x7fffff00;   // no task: permanently out of range
+        }
+    }
+    DEVINL void issue(rsrc_t rs, int ld_bytes) {
+#pragma unroll
+        for (int j = 0; j < N; ++j)
+#pragma unroll
+            for (int i = 0; i < VEC; ++i) v[j][i] = __builtin_amdgcn_raw_buffer_load_b128(rs, voff[j] + i * ld_bytes, 0, 0);
+    }
+    DEVINL void advance(int step_bytes) {
+#pragma unroll
+        for (int j = 0; j < N; ++j)
+            if (NTASK % NT == 0 || voff[j] != 0x7fffff00) voff[j] += step_bytes;
+    }
+    DEVINL void commit(char* tile, int tid) {
+#pragma unroll
+        for (int j = 0; j < N; ++j) {
+            const int t = tid + j * NT, kg = t & 7, rc = t >> 3;
+            if (NTASK % NT == 0 || t < NTASK) {
+                u32x4_t o[VEC];
+                Transposer<VEC>::run(v[j], o);
+#pragma unroll
+                for (int i = 0; i < VEC; ++i) *(u32x4_t*)(tile + tile_off(rc * VEC + i, kg)) = o[i];
+            }
+        }
+    }
+};
