@@ -47,6 +47,10 @@ int valor_gemm(void* stream, int dtype, int transA, int transB, int M, int N, in
                const void* dact_aux, int64_t ldaux, float alpha, int accumulate, int out_f32, void* workspace,
                int64_t workspace_bytes);
 
+/* selects the bf16 kernel of valor_gemm: 0 = register-staged tiles, 1 = LDS-DMA (buffer_load ... lds) single stage,
+ * 2 = LDS-DMA double stage (default). Returns the previous value; v < 0 only queries. Tuning / A-B measurement hook. */
+int valor_gemm_set_variant(int v);
+
 /* ---- fused bias + dropout + residual + LayerNorm.  Replaces apex FusedLayerNorm (apex/csrc/layer_norm_cuda_kernel.cu
  * :279-322 forward, :403-634 backward; wrapper apex/apex/normalization/fused_layer_norm.py:14-37) plus the elementwise ops
  * around it: bert.py:351-355,365-371,416-420 (post-LN), transformer.py:74-85 (pre-LN AST), clip.py:194-197 (pre-LN CLIP).

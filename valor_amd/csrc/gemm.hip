@@ -242,6 +242,253 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs p) {
     }
 }
 
+// =======================================================================================
+// bf16 fast path: direct-to-LDS staging (buffer_load_dwordx4 ... lds), no staging registers, no
+// ds_write pass, no register transposes.
+//
+//   direct operand  (k contiguous in memory): LDS image [128 rows][128 B], 16-B chunk c of row r at
+//       r*128 + ((c ^ (r & 7)) << 4)  -- the same XOR-swizzled image read_frag() expects. An LDS-DMA
+//       piece is 64 lanes x 16 B = 1 KiB = 8 rows and lands lane-linear, so the swizzle is applied to
+//       the per-lane SOURCE address (lane l -> row l>>3, chunk (l&7) ^ (l>>3)); every 128-B row is
+//       still fetched whole by 8 neighbouring lanes.
+//   k-slow operand (k is the slow dim in memory: dgrad weights, both wgrad operands): LDS image
+//       [64 k][256 B] in memory order (no transpose on the way in); 16-B granule c8 (8 tile rows) of
+//       k-row k sits at  k*256 + 16*((c8 + 2*(k&3) + 8*((k>>3)&1)) & 15).  MFMA fragments are
+//       gathered with ds_read_b64_tr_b16 (hardware 4x4 transpose: a 16-lane group reads a [4 k][16 row]
+//       block, lane i supplies 4 consecutive rows of k-row i>>2 and receives 4 consecutive k of row i);
+//       the granule rotation makes the 16 granules of every 32-lane service group (k-rows
+//       {0..3} + {8..11}, 2 granules each) hit 16 distinct 16-B slots = all 64 banks, conflict free.
+//
+// NSTAGE = 1: one 32 KiB stage, two barriers per K-step, 4 workgroups per CU hide each other's loads.
+// NSTAGE = 2: two stages (64 KiB, 2 workgroups per CU): the DMA of K-step t+1 flies under the MFMAs
+//             of step t, one barrier per K-step.
+// M/N tails and the k tail of k-slow operands are zero-filled by the buffer range check; the k tail of
+// a direct operand (k runs into the next row, not past the buffer) is masked in registers on the final
+// partial K-step only.
+typedef __attribute__((ext_vector_type(4))) short s16x4_t;
+#define LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
+
+DEVINL void glds16(rsrc_t rs, char* lds_dst, int voff) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, LDS_PTR(lds_dst), 16, voff, 0, 0, 0);
+}
+// k-slow image fragment: `off` = per-lane byte offset (k-row 8g + (i>>2), half granule, slot of this 16-row block)
+DEVINL bf16x8_t read_frag_tr(const char* img, int off, int kk) {
+    const char* a = img + off + kk * (32 * 256);
+    s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)LDS_PTR(a));
+    s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)LDS_PTR(a + 4 * 256));
+    typedef __attribute__((ext_vector_type(8))) short s16x8_t;
+    s16x8_t r = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+    return __builtin_bit_cast(bf16x8_t, r);
+}
+template <bool TA, bool TB, int NSTAGE>
+__global__ __launch_bounds__(256, NSTAGE == 1 ? 4 : 2) void gemm_glds_kernel(GemmArgs p) {
+    typedef bf16_t T;
+    constexpr int BK = 64;
+    constexpr int IMG = 16384;              // one operand image
+    constexpr int STAGE = 2 * IMG;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+
+    const int tiles_n = (p.N + 127) >> 7;
+    const int tiles_m = (p.M + 127) >> 7;
+    // tile / K-slice of this workgroup. Without split-K: XCD-contiguous tile ranges (neighbouring tiles share
+    // operand panels in one L2). With split-K (kslices = 8*s): workgroup b runs on XCD b % 8, and XCD x owns the
+    // K-slices x*s .. x*s+s-1 of EVERY tile, so the tiles of a slice march through k together and each operand
+    // row is fetched from HBM once per XCD-slice instead of once per tile.
+    int logical, slice = 0;
+    if (p.kslices > 1) {
+        const int ntiles = tiles_m * tiles_n, xcd = blockIdx.x & 7, loc = blockIdx.x >> 3;
+        const int sub = loc / ntiles;
+        logical = loc - sub * ntiles;
+        slice = xcd * (p.kslices >> 3) + sub;
+    } else {
+        logical = xcd_remap(blockIdx.x, tiles_m * tiles_n);
+    }
+    const int tm = logical / tiles_n, tn = logical - tm * tiles_n;
+    const int m0 = tm << 7, n0 = tn << 7;
+
+    const int nk_total = (p.K + BK - 1) / BK;
+    int ks_begin = 0, ks_end = nk_total;
+    if (p.kslices > 1) {
+        ks_begin = slice * p.ksteps_per_slice;
+        ks_end = ks_begin + p.ksteps_per_slice;
+        if (ks_end > nk_total) ks_end = nk_total;
+        if (ks_begin > nk_total) ks_begin = nk_total;
+    }
+    const int k_first = ks_begin * BK;
+
+    f32x4_t acc[4][4];  // [ni][mi]
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+
+    const rsrc_t rsA = make_rsrc(p.A, p.bytesA), rsB = make_rsrc(p.B, p.bytesB);
+    // ---- staging offsets: 4 pieces per operand per wave (piece = wave*4 + j), bumped once per K-step
+    int voA[4], voB[4];
+    int stepA, stepB;
+    {
+        const int ldA_b = (int)(p.lda * 2), ldB_b = (int)(p.ldb * 2);
+        if constexpr (!TA) {
+            const int r = lane >> 3, c = (lane & 7) ^ (r & 7);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) voA[j] = (m0 + wave * 32 + j * 8 + r) * ldA_b + (k_first + c * 8) * 2;
+            stepA = BK * 2;
+        } else {
+            const int kq = lane >> 4, s = lane & 15;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int c8 = (s - 2 * kq - 8 * ((j >> 1) & 1)) & 15;
+                voA[j] = (k_first + wave * 16 + j * 4 + kq) * ldA_b + (m0 + c8 * 8) * 2;
+            }
+            stepA = BK * ldA_b;
+        }
+        if constexpr (!TB) {
+            const int r = lane >> 3, c = (lane & 7) ^ (r & 7);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) voB[j] = (n0 + wave * 32 + j * 8 + r) * ldB_b + (k_first + c * 8) * 2;
+            stepB = BK * 2;
+        } else {
+            const int kq = lane >> 4, s = lane & 15;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int c8 = (s - 2 * kq - 8 * ((j >> 1) & 1)) & 15;
+                voB[j] = (k_first + wave * 16 + j * 4 + kq) * ldB_b + (n0 + c8 * 8) * 2;
+            }
+            stepB = BK * ldB_b;
+        }
+    }
+    auto issue = [&](int stage) {
+        char* sA = smem + stage * STAGE + wave * 4096;
+        char* sB = sA + IMG;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) glds16(rsA, sA + j * 1024, voA[j]);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) glds16(rsB, sB + j * 1024, voB[j]);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { voA[j] += stepA; voB[j] += stepB; }
+    };
+
+    // ---- fragment read offsets
+    const int fr = lane & 15, fg = lane >> 4;
+    int trA[4], trB[4];   // k-slow images: per 16-row block byte offsets
+    {
+        const int base = (8 * fg + (fr >> 2)) * 256 + 8 * (fr & 1);
+        const int rot = 2 * (fr >> 2) + 8 * (fg & 1);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int cbA = wm * 4 + i, cbB = wn * 4 + i;
+            trA[i] = base + 16 * ((2 * cbA + ((fr >> 1) & 1) + rot) & 15);
+            trB[i] = base + 16 * ((2 * cbB + ((fr >> 1) & 1) + rot) & 15);
+        }
+    }
+
+    auto compute = [&](int stage) {
+        const char* sA = smem + stage * STAGE;
+        const char* sB = sA + IMG;
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            bf16x8_t fn[4], fm[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                if constexpr (TB) fn[i] = read_frag_tr(sB, trB[i], kk);
+                else fn[i] = read_frag<T>(sB, wn * 64 + i * 16 + fr, kk * 4 + fg);
+                if constexpr (TA) fm[i] = read_frag_tr(sA, trA[i], kk);
+                else fm[i] = read_frag<T>(sA, wm * 64 + i * 16 + fr, kk * 4 + fg);
+            }
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+                for (int mi = 0; mi < 4; ++mi) acc[ni][mi] = Mma<T>::mma(fn[ni], fm[mi], acc[ni][mi]);
+        }
+    };
+    // k tail of a DIRECT operand (k runs into the next row instead of past the buffer): on the single K-step that
+    // contains K the landed images are patched in LDS (chunks with k >= K zeroed) before anyone reads them.
+    // Both images are patched (0 * NaN garbage would poison the accumulators otherwise). Block uniform, rare.
+    auto patch_ktail = [&](int stage, int kvalid) {
+        char* sA = smem + stage * STAGE;
+        for (int idx = tid; idx < 2 * 128 * 8; idx += 256) {
+            const int op = idx >> 10, r = (idx >> 3) & 127, c = idx & 7;
+            if ((op == 0 && TA) || (op == 1 && TB)) continue;      // k-slow images are zero-filled by the range check
+            const int nv = kvalid - c * 8;
+            if (nv >= 8) continue;
+            u32x4_t* q = (u32x4_t*)(sA + op * IMG + tile_off(r, c));
+            u32x4_t v = *q;
+#pragma unroll
+            for (int d = 0; d < 4; ++d) v[d] &= (2 * d + 1 < nv) ? 0xffffffffu : ((2 * d < nv) ? 0x0000ffffu : 0u);
+            *q = v;
+        }
+        if (TA != TB) {   // the k-slow partner holds zeros beyond K already (range check) -- nothing to do
+        }
+        __syncthreads();
+    };
+    const bool ktail = (!TA || !TB) && (p.K & (BK - 1)) != 0;
+    const int ks_tail = ktail ? nk_total - 1 : -1;
+
+    if constexpr (NSTAGE == 1) {
+        for (int ks = ks_begin; ks < ks_end; ++ks) {
+            issue(0);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (ks == ks_tail) patch_ktail(0, p.K - ks * BK);
+            compute(0);
+            __syncthreads();
+        }
+    } else {
+        if (ks_begin < ks_end) issue(0);
+        for (int ks = ks_begin; ks < ks_end; ++ks) {
+            const int cur = (ks - ks_begin) & 1;
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();       // K-step ks landed for every wave; everyone is done reading stage cur^1
+            if (ks + 1 < ks_end) issue(cur ^ 1);
+            if (ks == ks_tail) patch_ktail(cur, p.K - ks * BK);
+            compute(cur);
+        }
+        __syncthreads();
+    }
+
+    // ---- epilogue: accumulators -> LDS (fp32, XOR-swizzled 16-B chunks) -> row-contiguous stores,
+    // EPI_ROWS tile rows per pass (the operand stages are dead: all waves are past the last barrier).
+    constexpr int EPI_ROWS = NSTAGE == 1 ? 64 : 128;
+    float* sC = (float*)smem;
+    float* wsl = p.kslices > 1 ? p.ws + (int64_t)slice * p.M * p.N : nullptr;
+    const f32x4_t bias4 = load_bias4<T>(p, n0 + (tid & 31) * 4);
+#pragma unroll
+    for (int pass = 0; pass < 128 / EPI_ROWS; ++pass) {
+        if (pass) __syncthreads();
+        if (EPI_ROWS == 128 || wm == pass) {
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+                for (int mi = 0; mi < 4; ++mi) {
+                    const int ml = (EPI_ROWS == 128 ? wm * 64 : 0) + mi * 16 + fr;
+                    const int ch = (wn * 16 + ni * 4 + fg) ^ (ml & 7);
+                    *(f32x4_t*)(sC + ml * 128 + ch * 4) = acc[ni][mi];
+                }
+        }
+        __syncthreads();
+        for (int it = 0; it < EPI_ROWS / 8; ++it) {
+            const int ml = it * 8 + (tid >> 5);
+            const int cl = tid & 31;
+            const f32x4_t v = *(const f32x4_t*)(sC + ml * 128 + ((cl ^ (ml & 7)) << 2));
+            const int m = m0 + pass * EPI_ROWS + ml, n = n0 + cl * 4;
+            if (wsl) {
+                if (m < p.M) {
+                    float* q = wsl + (int64_t)m * p.N + n;
+                    if (n + 3 < p.N && (p.N & 3) == 0) *(f32x4_t*)q = v;
+                    else for (int r = 0; r < 4; ++r) if (n + r < p.N) q[r] = v[r];
+                }
+            } else {
+                epilogue_store<T>(p, m, n, v, bias4);
+            }
+        }
+    }
+}
+
 // split-K second stage: sum the fp32 slices and run the normal epilogue (4 n per thread).
 template <typename T>
 __global__ __launch_bounds__(256) void gemm_splitk_reduce(GemmArgs p) {
@@ -260,10 +507,46 @@ __global__ __launch_bounds__(256) void gemm_splitk_reduce(GemmArgs p) {
     }
 }
 
+// kernel variant of the bf16 path: 0 = register-staged (gemm_kernel), 1 = LDS-DMA single stage, 2 = LDS-DMA double stage
+static int g_gemm_variant = 1;
+extern "C" int valor_gemm_set_variant(int v) { const int o = g_gemm_variant; if (v >= 0 && v <= 2) g_gemm_variant = v; return o; }
+
+template <int NSTAGE>
+static void launch_gemm_glds(hipStream_t st, int transA, int transB, const GemmArgs& p, dim3 grid) {
+    const size_t lds = NSTAGE * 32768;
+#define VALOR_GLDS_LAUNCH(TA_, TB_)                                                                 \
+    do {                                                                                            \
+        static bool attr_set = false;                                                               \
+        if (!attr_set) {                                                                            \
+            hipFuncSetAttribute((const void*)gemm_glds_kernel<TA_, TB_, NSTAGE>,                    \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);              \
+            attr_set = true;                                                                        \
+        }                                                                                           \
+        hipLaunchKernelGGL((gemm_glds_kernel<TA_, TB_, NSTAGE>), grid, dim3(256), lds, st, p);      \
+    } while (0)
+    if (!transA && !transB) VALOR_GLDS_LAUNCH(false, false);
+    else if (!transA && transB) VALOR_GLDS_LAUNCH(false, true);
+    else if (transA && !transB) VALOR_GLDS_LAUNCH(true, false);
+    else VALOR_GLDS_LAUNCH(true, true);
+#undef VALOR_GLDS_LAUNCH
+}
+
 template <typename T>
 static int launch_gemm(hipStream_t st, int transA, int transB, GemmArgs p) {
     const int tiles = ((p.M + 127) / 128) * ((p.N + 127) / 128);
     dim3 grid(tiles, p.kslices > 1 ? p.kslices : 1);
+    if (ElemTraits<T>::DT == VALOR_DT_BF16 && g_gemm_variant > 0) {
+        if (p.kslices > 1) grid = dim3(tiles * p.kslices, 1);     // XCD-sliced split-K: 1-D grid, kslices % 8 == 0
+        if (g_gemm_variant == 1) launch_gemm_glds<1>(st, transA, transB, p, grid);
+        else launch_gemm_glds<2>(st, transA, transB, p, grid);
+        if (p.kslices > 1) {
+            const int64_t total = (int64_t)p.M * ((p.N + 3) / 4);
+            int blocks = (int)((total + 255) / 256);
+            if (blocks > 4096) blocks = 4096;
+            hipLaunchKernelGGL((gemm_splitk_reduce<T>), dim3(blocks), dim3(256), 0, st, p);
+        }
+        return valor_launch_status();
+    }
     const size_t lds = 2 * 2 * 128 * TILE_ROW_BYTES;
 #define VALOR_GEMM_LAUNCH(TA_, TB_)                                                               \
     do {                                                                                          \
@@ -327,10 +610,25 @@ extern "C" int valor_gemm(void* stream, int dtype, int transA, int transB, int M
         if (slices > 64) slices = 64;
         while (slices > 1 && (int64_t)slices * M * N * 4 > workspace_bytes) --slices;
     }
-    p.kslices = slices;
-    p.ksteps_per_slice = (nk + slices - 1) / slices;
-    if (p.kslices > 1) {  // recompute so no slice is empty
-        p.kslices = (nk + p.ksteps_per_slice - 1) / p.ksteps_per_slice;
+    if (dtype == VALOR_DT_BF16 && g_gemm_variant > 0) {
+        // XCD-sliced split-K of the LDS-DMA kernels: 8*s slices, s = sub-slices per XCD chosen to fill (not
+        // overflow) the 128 workgroup slots of an XCD (32 CUs x 4); >= 8 K-steps per workgroup.
+        slices = 1;
+        if (workspace && tiles < 512 && nk >= 64) {
+            int sub = 128 / tiles; if (sub < 1) sub = 1;
+            while (sub > 1 && nk / (8 * sub) < 8) --sub;
+            if (sub > 8) sub = 8;
+            while (sub > 1 && (int64_t)8 * sub * M * N * 4 > workspace_bytes) --sub;
+            if ((int64_t)8 * sub * M * N * 4 <= workspace_bytes) slices = 8 * sub;
+        }
+        p.kslices = slices;
+        p.ksteps_per_slice = (nk + slices - 1) / slices;     // trailing slices may be short or empty (they add zeros)
+    } else {
+        p.kslices = slices;
+        p.ksteps_per_slice = (nk + slices - 1) / slices;
+        if (p.kslices > 1) {  // recompute so no slice is empty
+            p.kslices = (nk + p.ksteps_per_slice - 1) / p.ksteps_per_slice;
+        }
     }
     hipStream_t st = (hipStream_t)stream;
     if (dtype == VALOR_DT_BF16) return launch_gemm<bf16_t>(st, transA, transB, p);

@@ -22,6 +22,7 @@ _vp, _i, _i64, _u64, _f = _c.c_void_p, _c.c_int, _c.c_int64, _c.c_uint64, _c.c_f
 SIGNATURES = {
     "valor_gemm": [_vp, _i, _i, _i, _i, _i, _i, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _i, _vp, _vp, _i64,
                    _f, _i, _i, _vp, _i64],
+    "valor_gemm_set_variant": [_i],
     "valor_ln_part_blocks": [],
     "valor_bdrln_fwd": [_vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i, _f, _f, _u64, _u64],
     "valor_bdrln_bwd": [_vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i, _f, _u64, _u64],
