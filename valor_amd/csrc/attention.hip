@@ -58,10 +58,10 @@ DEVINL bf16x8_t read_frag_nat_bf16(const char* img, int row, int kk, int g) {
 }
 DEVINL bf16x8_t pack_bf16x8(f32x4_t a, f32x4_t b) {
     u32x4_t r;
-    r[0] = f32_to_bf16_bits(a[0]) | (f32_to_bf16_bits(a[1]) << 16);
-    r[1] = f32_to_bf16_bits(a[2]) | (f32_to_bf16_bits(a[3]) << 16);
-    r[2] = f32_to_bf16_bits(b[0]) | (f32_to_bf16_bits(b[1]) << 16);
-    r[3] = f32_to_bf16_bits(b[2]) | (f32_to_bf16_bits(b[3]) << 16);
+    r[0] = pack2_bf16(a[0], a[1]);
+    r[1] = pack2_bf16(a[2], a[3]);
+    r[2] = pack2_bf16(b[0], b[1]);
+    r[3] = pack2_bf16(b[2], b[3]);
     return __builtin_bit_cast(bf16x8_t, r);
 }
 

@@ -29,13 +29,15 @@ typedef __attribute__((ext_vector_type(2))) uint32_t u32x2_t;
 // ---------------------------------------------------------------- conversions
 DEVINL float bf16_bits_to_f32(uint32_t bits16) { return __uint_as_float(bits16 << 16); }
 
-// round-to-nearest-even fp32 -> bf16 bits (NaN preserved as quiet NaN)
-DEVINL uint32_t f32_to_bf16_bits(float f) {
-    uint32_t u = __float_as_uint(f);
-    if ((u & 0x7fffffffu) > 0x7f800000u) return (u >> 16) | 0x40u;
-    u += 0x7fffu + ((u >> 16) & 1u);
-    return u >> 16;
+// round-to-nearest-even fp32 -> bf16: gfx950 has a native packed convert (v_cvt_pk_bf16_f32); the compiler
+// selects it for these vector / scalar casts.
+typedef __attribute__((ext_vector_type(2))) float f32x2_t;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
+DEVINL uint32_t pack2_bf16(float lo, float hi) {
+    f32x2_t v = {lo, hi};
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2_t));
 }
+DEVINL uint32_t f32_to_bf16_bits(float f) { return (uint32_t)__builtin_bit_cast(uint16_t, (__bf16)f); }
 
 template <typename T> struct ElemTraits;
 template <> struct ElemTraits<bf16_t> {
@@ -71,8 +73,8 @@ template <typename T> DEVINL void store4(T* p, f32x4_t v);
 template <> DEVINL void store4<float>(float* p, f32x4_t v) { *(f32x4_t*)p = v; }
 template <> DEVINL void store4<bf16_t>(bf16_t* p, f32x4_t v) {
     u32x2_t r;
-    r[0] = f32_to_bf16_bits(v[0]) | (f32_to_bf16_bits(v[1]) << 16);
-    r[1] = f32_to_bf16_bits(v[2]) | (f32_to_bf16_bits(v[3]) << 16);
+    r[0] = pack2_bf16(v[0], v[1]);
+    r[1] = pack2_bf16(v[2], v[3]);
     *(u32x2_t*)p = r;
 }
 

@@ -224,21 +224,31 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(LnBwdArgs p) {
 }
 
 // sum `nparts` partial rows [nparts][cols] (fp32) -> out[cols] (T or fp32), optional accumulate.
-// workgroup = 64 columns x 16 row-groups (1024 threads): coalesced 256-B row reads, 16-way split of the
-// partial rows, LDS tree over the row groups.
+// workgroup = 16 columns x 16 row-groups (256 threads), cols/16 workgroups (48 for 768 columns: the partials were
+// just written and sit in L2, so this is latency bound -- many small workgroups, 4 independent loads in flight per
+// thread, LDS tree over the row groups).
 template <typename T>
-__global__ __launch_bounds__(1024) void colsum_finalize_kernel(const float* part, int nparts, int cols, void* out, int out_f32, int accumulate) {
-    __shared__ float red[16][64];
-    const int cx = threadIdx.x & 63, ry = threadIdx.x >> 6;
-    const int c = blockIdx.x * 64 + cx;
-    float s = 0.f;
-    if (c < cols)
-        for (int i = ry; i < nparts; i += 16) s += part[(int64_t)i * cols + c];
-    red[ry][cx] = s;
+__global__ __launch_bounds__(256) void colsum_finalize_kernel(const float* part, int nparts, int cols, void* out, int out_f32, int accumulate) {
+    __shared__ float red[16][17];
+    const int cx = threadIdx.x & 15, ry = threadIdx.x >> 4;
+    const int c = blockIdx.x * 16 + cx;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    if (c < cols) {
+        int i = ry;
+        for (; i + 48 < nparts; i += 64) {
+            s0 += part[(int64_t)i * cols + c];
+            s1 += part[(int64_t)(i + 16) * cols + c];
+            s2 += part[(int64_t)(i + 32) * cols + c];
+            s3 += part[(int64_t)(i + 48) * cols + c];
+        }
+        for (; i < nparts; i += 16) s0 += part[(int64_t)i * cols + c];
+    }
+    red[ry][cx] = (s0 + s1) + (s2 + s3);
     __syncthreads();
     if (ry == 0 && c < cols) {
+        float s = 0.f;
 #pragma unroll
-        for (int j = 1; j < 16; ++j) s += red[j][cx];
+        for (int j = 0; j < 16; ++j) s += red[j][cx];
         if (out_f32) {
             float* o = (float*)out;
             o[c] = (accumulate ? o[c] : 0.f) + s;
@@ -345,11 +355,11 @@ extern "C" int valor_colsum_finalize(void* stream, int dtype, const float* part,
                                      int out_f32, int accumulate) {
     if (cols <= 0) return VALOR_OK;
     hipStream_t st = (hipStream_t)stream;
-    dim3 grid((cols + 63) / 64);
+    dim3 grid((cols + 15) / 16);
     if (dtype == VALOR_DT_BF16)
-        hipLaunchKernelGGL((colsum_finalize_kernel<bf16_t>), grid, dim3(1024), 0, st, part, nparts, cols, out, out_f32, accumulate);
+        hipLaunchKernelGGL((colsum_finalize_kernel<bf16_t>), grid, dim3(256), 0, st, part, nparts, cols, out, out_f32, accumulate);
     else if (dtype == VALOR_DT_F32)
-        hipLaunchKernelGGL((colsum_finalize_kernel<float>), grid, dim3(1024), 0, st, part, nparts, cols, out, out_f32, accumulate);
+        hipLaunchKernelGGL((colsum_finalize_kernel<float>), grid, dim3(256), 0, st, part, nparts, cols, out, out_f32, accumulate);
     else return VALOR_ERR_ARG;
     return valor_launch_status();
 }

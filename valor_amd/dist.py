@@ -81,23 +81,31 @@ class Reducer:
         self.bucket_range = [(min(arena.range_of(n)[0] for n in b), max(arena.range_of(n)[1] for n in b)) for b in self.buckets]
         self.bucket_of = {n: i for i, b in enumerate(self.buckets) for n in b}
         self.expected = None           # per-bucket set of names that get a grad for the current task
-        self.touched = set()
+        self.uses = None               # name -> number of gradient writes per backward (learnt on the first step)
+        self.touched = {}              # name -> writes seen in the current backward
         self.pending, self.works = None, []
         self.comm_stream = torch.cuda.Stream() if arena.flat.is_cuda else None
         for name, p in arena.params.items():
             p.register_post_accumulate_grad_hook(self._make_hook(name))
+        from . import ops
+        ops.GradSink.listener = self._on_grad      # kernels that accumulate straight into the arena report here
 
     def _make_hook(self, name):
         def hook(param):
-            self.touched.add(name)
-            if self.pending is None:
-                return
-            i = self.bucket_of[name]
-            s = self.pending[i]
-            s.discard(name)
-            if not s and self.expected[i]:
-                self._launch(i)
+            self._on_grad(name)
         return hook
+
+    def _on_grad(self, name):
+        """one gradient contribution to `name` has been enqueued (autograd AccumulateGrad or a direct arena write)."""
+        n = self.touched.get(name, 0) + 1
+        self.touched[name] = n
+        if self.pending is None or n < self.uses.get(name, 1):
+            return
+        i = self.bucket_of[name]
+        s = self.pending[i]
+        s.discard(name)
+        if not s and self.expected[i]:
+            self._launch(i)
 
     def _launch(self, i):
         if self.world == 1:
@@ -113,18 +121,19 @@ class Reducer:
             self.works.append(dist.all_reduce(buf, op=dist.ReduceOp.SUM, async_op=True))
 
     def prepare_backward(self):
-        self.touched = set()
+        self.touched = {}
         self.works = []
         self.pending = [set(x) for x in self.expected] if self.expected is not None else None
 
     def finish_backward(self):
         """Wait for the bucket all-reduces (or, on the first step of a task, reduce everything at once and
-        learn which parameters are used)."""
-        if self.expected is None or self.touched != set().union(*self.expected):
+        learn which parameters are used and how many gradient writes each receives)."""
+        if self.expected is None or self.touched != self.uses:
             if self.pending is not None:       # the used-parameter set changed (new task): redo synchronously
                 for w in self.works:
                     w.wait()
                 raise RuntimeError("used-parameter set changed between steps; call reset_task() when switching tasks")
+            self.uses = dict(self.touched)
             self.expected = [set(n for n in b if n in self.touched) for b in self.buckets]
             if self.world > 1:
                 dist.all_reduce(self.arena.grad, op=dist.ReduceOp.SUM)
@@ -138,3 +147,4 @@ class Reducer:
 
     def reset_task(self):
         self.expected = None
+        self.uses = None

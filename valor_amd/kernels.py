@@ -99,8 +99,9 @@ def bdrln_fwd(x, bias, residual, gamma, beta, eps, *, p_drop=0.0, seed=0, offset
 
 
 def bdrln_bwd(dy, dz_in, z, mean, rstd, gamma, *, p_drop=0.0, seed=0, offset=0, want_dgamma=True, want_dbeta=True,
-              want_dbias=False, separate_dx=False):
-    """Returns (dx, dres, dgamma, dbeta, dbias) ; dx is dres when there is no dropout."""
+              want_dbias=False, separate_dx=False, sinks=(None, None, None)):
+    """Returns (dx, dres, dgamma, dbeta, dbias) ; dx is dres when there is no dropout.
+    sinks = (dgamma, dbeta, dbias) tensors to ACCUMULATE the parameter gradients into (the result slot is None then)."""
     ref = dy if dy is not None else dz_in
     _check_gpu(dy, dz_in, z, gamma)
     cols = ref.shape[-1]
@@ -118,8 +119,12 @@ def bdrln_bwd(dy, dz_in, z, mean, rstd, gamma, *, p_drop=0.0, seed=0, offset=0, 
              _ptr(gamma), _ptr(dx), _ptr(dres), _ptr(pg), _ptr(pb), _ptr(px), rows, cols, float(p_drop), int(seed),
              int(offset))
     outs = []
-    for part in (pg, pb, px):
+    for part, sink in zip((pg, pb, px), sinks):
         if part is None:
+            outs.append(None)
+            continue
+        if sink is not None:
+            lib.call("valor_colsum_finalize", _stream(), dt_of(ref), _ptr(part), nb, cols, _ptr(sink), 0, 1)
             outs.append(None)
             continue
         o = torch.empty(cols, dtype=ref.dtype, device=ref.device)

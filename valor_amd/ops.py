@@ -39,6 +39,27 @@ def _2d(x):
     return x.reshape(-1, x.shape[-1])
 
 
+class GradSink:
+    """Parameter gradients are accumulated by the producing kernel straight into the flat gradient arena
+    (wgrad GEMM epilogue `C += ...`, column-sum finalize with accumulate) instead of being returned to autograd,
+    which would materialise a temporary and launch one `grad += tmp` kernel per parameter (AccumulateGrad).
+    `listener(name)` (set by valor_amd.dist.Reducer) is told about every such write so that used-parameter tracking
+    and bucket launches work exactly as with autograd's post-accumulate hooks."""
+    enabled = True
+    listener = None
+
+
+def _sink(p):
+    if not GradSink.enabled or p is None or getattr(p, "_arena_name", None) is None or p.grad is None or not p.requires_grad:
+        return None
+    return p.grad
+
+
+def _sunk(p):
+    if GradSink.listener is not None:
+        GradSink.listener(p._arena_name)
+
+
 # ------------------------------------------------------------------------------------------------
 class LinearFn(Function):
     """y = act(x W^T + b).  W: [N,K] (or, with w_is_kn, a [K,N] matrix used as x @ W: CLIP projections
@@ -56,6 +77,7 @@ class LinearFn(Function):
         y, pre = res if want_pre else (res, None)
         ctx.save_for_backward(x2, w, pre)
         ctx.act, ctx.w_is_kn, ctx.has_b, ctx.xshape = act, w_is_kn, b is not None, x.shape
+        ctx.params = (w, b)
         return y.view(*x.shape[:-1], y.shape[-1])
 
     @staticmethod
@@ -69,10 +91,19 @@ class LinearFn(Function):
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
             dx = (K.gemm(dy2, w) if ctx.w_is_kn else K.gemm(dy2, w, trans_b=True)).view(ctx.xshape)
+        pw, pb = ctx.params
         if ctx.needs_input_grad[1]:
-            dw = K.gemm(x2, dy2, trans_a=True, trans_b=True) if ctx.w_is_kn else K.gemm(dy2, x2, trans_a=True, trans_b=True)
+            sw = _sink(pw)
+            kw = dict(out=sw, accumulate=True) if sw is not None else {}
+            dw = K.gemm(x2, dy2, trans_a=True, trans_b=True, **kw) if ctx.w_is_kn else K.gemm(dy2, x2, trans_a=True, trans_b=True, **kw)
+            if sw is not None:
+                dw = None; _sunk(pw)
         if ctx.has_b and ctx.needs_input_grad[2]:
-            db = K.colsum(dy2)
+            sb = _sink(pb)
+            if sb is not None:
+                K.colsum(dy2, out=sb, accumulate=True); _sunk(pb)
+            else:
+                db = K.colsum(dy2)
         return dx, dw, db, None, None
 
 
@@ -92,6 +123,7 @@ class MlpFn(Function):
         y = K.gemm(h, w2, bias=b2)
         ctx.save_for_backward(x2, w1, w2, u, h)
         ctx.act, ctx.xshape = act, x.shape
+        ctx.params = (w1, b1, w2, b2)
         return y.view(*x.shape[:-1], y.shape[-1])
 
     @staticmethod
@@ -99,11 +131,27 @@ class MlpFn(Function):
         x2, w1, w2, u, h = ctx.saved_tensors
         dy2 = _2d(dy.contiguous())
         du = K.gemm(dy2, w2, trans_b=True, act=ctx.act, dact_aux=u)
-        dw2 = K.gemm(dy2, h, trans_a=True, trans_b=True)
-        db2 = K.colsum(dy2)
+        pw1, pb1, pw2, pb2 = ctx.params
+
+        def wgrad(dyy, xx, pw):
+            sw = _sink(pw)
+            if sw is None:
+                return K.gemm(dyy, xx, trans_a=True, trans_b=True)
+            K.gemm(dyy, xx, trans_a=True, trans_b=True, out=sw, accumulate=True); _sunk(pw)
+            return None
+
+        def bgrad(dyy, pb):
+            sb = _sink(pb)
+            if sb is None:
+                return K.colsum(dyy)
+            K.colsum(dyy, out=sb, accumulate=True); _sunk(pb)
+            return None
+
+        dw2 = wgrad(dy2, h, pw2)
+        db2 = bgrad(dy2, pb2)
         dx = K.gemm(du, w1, trans_b=True).view(ctx.xshape) if ctx.needs_input_grad[0] else None
-        dw1 = K.gemm(du, x2, trans_a=True, trans_b=True)
-        db1 = K.colsum(du)
+        dw1 = wgrad(du, x2, pw1)
+        db1 = bgrad(du, pb1)
         return dx, dw1, db1, dw2, db2, None
 
 
@@ -129,6 +177,7 @@ class BdrLnFn(Function):
                                        eps, p_drop=p_drop, seed=seed, offset=off, write_z=not plain)
         ctx.save_for_backward(x if plain else z, mean, rstd, gamma)
         ctx.cfg = (p_drop, seed, off, bias is not None, residual is not None, beta is not None)
+        ctx.params = (gamma, beta, bias)
         if want_z:
             return z, y
         return y
@@ -149,9 +198,14 @@ class BdrLnFn(Function):
             dy_eff, mean_e, rstd_e, z_e = None, None, None, None
         else:
             dy_eff, mean_e, rstd_e, z_e = dy, mean, rstd, zs
+        pg, pbeta, pbias = ctx.params
+        sinks = (_sink(pg) if dy_eff is not None else None, _sink(pbeta) if dy_eff is not None else None, _sink(pbias))
         dx, dres, dg, dbeta, dbias = K.bdrln_bwd(dy_eff, dz_in, z_e, mean_e, rstd_e, gamma, p_drop=p_drop, seed=seed,
                                                  offset=off, want_dgamma=gamma is not None, want_dbeta=has_beta,
-                                                 want_dbias=has_b)
+                                                 want_dbias=has_b, sinks=sinks)
+        for prm, sk, want in ((pg, sinks[0], gamma is not None), (pbeta, sinks[1], has_beta), (pbias, sinks[2], has_b)):
+            if sk is not None and want:
+                _sunk(prm)
         return dx, dbias, (dres if has_r else None), dg, dbeta, None, None, None
 
 
@@ -175,13 +229,18 @@ class BiasDropResFn(Function):
         z, _, _, _ = K.bdrln_fwd(x, bias, residual.contiguous() if residual is not None else None, None, None, 0.0,
                                  p_drop=p_drop, seed=seed, offset=off, write_z=True, want_y=False)
         ctx.cfg = (p_drop, seed, off, bias is not None, residual is not None)
+        ctx.params = (bias,)
         return z
 
     @staticmethod
     def backward(ctx, dz):
         p_drop, seed, off, has_b, has_r = ctx.cfg
+        sb = _sink(ctx.params[0]) if has_b else None
         dx, dres, _, _, dbias = K.bdrln_bwd(None, dz.contiguous(), None, None, None, None, p_drop=p_drop, seed=seed,
-                                            offset=off, want_dgamma=False, want_dbeta=False, want_dbias=has_b)
+                                            offset=off, want_dgamma=False, want_dbeta=False, want_dbias=has_b,
+                                            sinks=(None, None, sb))
+        if sb is not None:
+            _sunk(ctx.params[0])
         return dx, dbias, (dres if has_r else None), None
 
 
@@ -276,6 +335,7 @@ class DecoderXentFn(Function):
         lib.call("valor_mean_f32", _st(), _p(loss_rows), n, _p(loss))
         ctx.save_for_backward(h, w_emb, labels, lse, buf)
         ctx.V = V
+        ctx.params = (w_emb, dec_bias)
         if want_logits:
             ctx.mark_non_differentiable(logits)
             return loss, logits
@@ -289,8 +349,16 @@ class DecoderXentFn(Function):
         lib.call("valor_xent_bwd", _st(), _dt(h), _p(buf), _p(labels), _p(lse), _p(g), 1.0 / n, n, V, Vpad)
         dlog = buf[:, :V]
         dh = K.gemm(dlog, w_emb, trans_b=True)
-        dw = K.gemm(dlog, h, trans_a=True, trans_b=True)
-        db = K.colsum(dlog)
+        pw, pb = ctx.params
+        sw, sb = _sink(pw), _sink(pb)
+        if sw is not None:
+            K.gemm(dlog, h, trans_a=True, trans_b=True, out=sw, accumulate=True); _sunk(pw); dw = None
+        else:
+            dw = K.gemm(dlog, h, trans_a=True, trans_b=True)
+        if sb is not None:
+            K.colsum(dlog, out=sb, accumulate=True); _sunk(pb); db = None
+        else:
+            db = K.colsum(dlog)
         return dh, dw, db, None, None
 
 
