@@ -71,6 +71,10 @@ int valor_colsum_finalize(void* stream, int dtype, const float* part, int nparts
 int valor_colsum(void* stream, int dtype, const void* x, int64_t rows, int cols, int64_t ld, float* part, void* out,
                  int out_f32, int accumulate);
 
+/* attention kernel selection (tuning / A-B hook): bit 0 = LDS-resident short-sequence self-attention kernels for
+ * bf16 (S = Sq = Skv <= 256, no kv_range); 0 = streaming kernels only. Returns the previous value; v < 0 queries. */
+int valor_attn_set_variant(int v);
+
 /* ---- flash attention, head_dim 64.  Replaces BertSelfAttention (bert.py:272-288), BertCrossAttention (bert.py:314-340,
  * K/V = [video|audio] tokens, grouping bert.py:448-455), AST MultiHeadAttention (transformer.py:115-130) and CLIP's
  * nn.MultiheadAttention (clip.py:186-192, mask clip.py:407-414).  Element (b,row,h,d) of q/k/v/o lives at

@@ -20,27 +20,9 @@
 // 16-key tile: softmax statistics are per-lane scalars (+2 shuffles), and the probabilities feed
 // the P.V MFMA directly from registers as its second operand, with the V^T fragment read from
 // LDS in the matching k-slot order (two 8-byte reads for bf16) -- no P round trip through LDS.
-#include "mma.h"
+#include "attn_common.h"
 
-#define ATT_D 64
 #define IMG_BYTES (64 * TILE_ROW_BYTES)   // one 64-row LDS tile image = 8 KiB
-
-struct AttnArgs {
-    const void* q; const void* k; const void* v; void* o; float* lse;
-    const void* dout; void* dq; void* dk; void* dv; float* delta;   // backward only
-    const float* mask; const int* kv_range;
-    int B, H, Sq, Skv;
-    int64_t q_bs, q_rs, k_bs, k_rs, v_bs, v_rs, o_bs, o_rs;
-    int64_t do_bs, do_rs, dq_bs, dq_rs, dk_bs, dk_rs, dv_bs, dv_rs;
-    int64_t mask_bs, mask_rs;
-    int kv_bmod;
-    float scale, p_drop;
-    uint64_t seed, offset;
-};
-
-template <typename T> DEVINL float fexp(float x);
-template <> DEVINL float fexp<float>(float x) { return expf(x); }
-template <> DEVINL float fexp<bf16_t>(float x) { return __expf(x); }
 
 // fragment chunk c (0 .. 8*NIMG-1) of `row` from a multi-image tile
 template <typename T>
@@ -56,15 +38,6 @@ DEVINL bf16x8_t read_frag_nat_bf16(const char* img, int row, int kk, int g) {
     u32x4_t r = {lo[0], lo[1], hi[0], hi[1]};
     return __builtin_bit_cast(bf16x8_t, r);
 }
-DEVINL bf16x8_t pack_bf16x8(f32x4_t a, f32x4_t b) {
-    u32x4_t r;
-    r[0] = pack2_bf16(a[0], a[1]);
-    r[1] = pack2_bf16(a[2], a[3]);
-    r[2] = pack2_bf16(b[0], b[1]);
-    r[3] = pack2_bf16(b[2], b[3]);
-    return __builtin_bit_cast(bf16x8_t, r);
-}
-
 // acc[dt] += sum over 64 contraction slots of  X^T[d][slot] * p[slot]   (X^T image rows = d)
 //   p4[t] (t=0..3): this lane's 4 consecutive contraction values of 16-slot tile t (natural layout)
 template <typename T>
@@ -570,9 +543,14 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnArgs p) {
 }
 
 // ------------------------------------------------------------------------------------------
+// bit 0: LDS-resident short-sequence kernels (attention_res.hip) allowed for bf16
+static int g_attn_variant = 1;
+extern "C" int valor_attn_set_variant(int v) { const int o = g_attn_variant; if (v >= 0) g_attn_variant = v; return o; }
+
 template <typename T>
 static int attn_fwd_launch(hipStream_t st, const AttnArgs& p) {
     constexpr int NIMG = 64 * (int)sizeof(T) / TILE_ROW_BYTES;
+    if (ElemTraits<T>::DT == VALOR_DT_BF16 && (g_attn_variant & 1) && attn_res_fwd_launch(st, p)) return valor_launch_status();
     const size_t lds = 2 * 2 * NIMG * IMG_BYTES;
     static bool attr_set = false;
     if (!attr_set) {
@@ -592,6 +570,7 @@ static int attn_fwd_launch(hipStream_t st, const AttnArgs& p) {
 template <typename T>
 static int attn_bwd_launch(hipStream_t st, const AttnArgs& p) {
     constexpr int NIMG = 64 * (int)sizeof(T) / TILE_ROW_BYTES;
+    if (ElemTraits<T>::DT == VALOR_DT_BF16 && (g_attn_variant & 1) && attn_res_bwd_launch(st, p)) return valor_launch_status();
     {
         const size_t lds = 2 * 3 * NIMG * IMG_BYTES;
         static bool attr_set_dq = false;

@@ -1,0 +1,449 @@
+// LDS-resident self-attention for short sequences (S = Sq = Skv <= 256, head_dim 64, bf16): CLIP ViT frames
+// (S = 197, clip.py:186-192), AST slices (S = 129, transformer.py:115-130), BERT / CLIP text (S = 32 / 42,
+// bert.py:272-288, clip.py:407-414).  One workgroup per (batch, head).
+//
+// Why a second kernel family: at these lengths a streaming flash kernel is latency bound (4 K/V tiles, a barrier
+// and a staging round trip per tile, two of four waves staging). Here the whole K / V (forward) or Q / dO / K / V
+// (backward) head slices are DMA'd into LDS ONCE (buffer_load ... lds, all waves, no staging registers), after
+// which every wave runs barrier-free over its own query (or key) rows.
+//
+// LDS images are all the standard XOR image of mma.h ([row][128 B], 16-B chunk c at slot c ^ (row & 7)). The same
+// image serves both MFMA operand shapes conflict free:
+//   * contraction over d   (S = K.Q^T, dP = V.dO^T, ...): ds_read_b128 fragments (read_frag);
+//   * contraction over rows (O^T += V^T.P^T, dQ^T += K^T.dS^T, dV^T += dO^T.P, dK^T += Q^T.dS): hardware transposing
+//     ds_read_b64_tr_b16 fragments (read_frag_tr_nat) -- no transposed copy of anything is ever built.
+// Rows >= S of every image are zero (the per-head buffer descriptor ends at row S-1, so the DMA range check
+// zero-fills them); a transposing read of the last 32-row group may run up to 16 rows past an image into the NEXT
+// image (finite data), where it only ever meets probabilities that are exactly zero.
+//
+// Score layout (as in attention.hip): S^T tiles, lane l owns query (l & 15) and 4 consecutive keys 4*(l>>4)+r, so
+// softmax statistics are per-lane scalars (+2 shuffles) and P feeds the next MFMA from registers.
+// Softmax runs in the exp2 domain (scale * log2 e folded into one multiply, v_exp_f32 directly).
+#include "attn_common.h"
+
+DEVINL float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
+
+// stage rows [0, SP) of one head slice (row stride rs elements, 64 columns) into an XOR image
+DEVINL void stage_image(rsrc_t rs, char* img, int SP, int rs_bytes, int wave, int nwaves, int lane) {
+    const int prow = lane >> 3, pch = (lane & 7) ^ prow;    // lane -> (row within the 8-row piece, source chunk)
+    for (int j = wave; j < (SP >> 3); j += nwaves) glds16(rs, img + j * 1024, (j * 8 + prow) * rs_bytes + pch * 16);
+}
+
+DEVINL rsrc_t head_rsrc(const void* base, int64_t elem_off, int S, int64_t rs) {
+    return make_rsrc((const bf16_t*)base + elem_off, (uint32_t)(((int64_t)(S - 1) * rs + ATT_D) * 2));
+}
+
+// ------------------------------------------------------------------------------------------ forward
+// grid (H, B), 256 threads. LDS: [V image][K image], SP = ceil16(S) rows each.  Wave w owns the 32-query-row
+// blocks w, w+4, ... (two 16-row MFMA tiles sharing every K / V fragment read).
+__global__ __launch_bounds__(256, 3) void attn_res_fwd_kernel(AttnArgs p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int fr = lane & 15, g = lane >> 4;
+    const int h = blockIdx.x, b = blockIdx.y;
+    const int S = p.Skv, SP = (S + 15) & ~15;
+    char* sV = smem;
+    char* sK = smem + SP * TILE_ROW_BYTES;
+
+    stage_image(head_rsrc(p.k, (int64_t)b * p.k_bs + h * ATT_D, S, p.k_rs), sK, SP, (int)p.k_rs * 2, wave, 4, lane);
+    stage_image(head_rsrc(p.v, (int64_t)b * p.v_bs + h * ATT_D, S, p.v_rs), sV, SP, (int)p.v_rs * 2, wave, 4, lane);
+
+    const bf16_t* Q = (const bf16_t*)p.q + (int64_t)b * p.q_bs + h * ATT_D;
+    const float sl2 = p.scale * LOG2E_F;
+    const uint32_t thr = drop_threshold(p.p_drop);
+    const float keep_scale = p.p_drop > 0.f ? 1.0f / (1.0f - p.p_drop) : 1.0f;
+    const int kq4 = (p.Skv + 3) >> 2;
+    int troff[4];
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) troff[dt] = tr_lane_off(lane, dt);
+    const int NP = (S + 31) >> 5, NT = (S + 63) >> 6;
+
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    for (int pr = wave; pr < NP; pr += 4) {
+        bf16x8_t qf[2][2];
+        int qr[2];
+#pragma unroll
+        for (int rt = 0; rt < 2; ++rt) {
+            qr[rt] = pr * 32 + rt * 16 + fr;
+#pragma unroll
+            for (int dg = 0; dg < 2; ++dg) {
+                u32x4_t z = {0u, 0u, 0u, 0u};
+                if (qr[rt] < S) z = *(const u32x4_t*)(Q + (int64_t)qr[rt] * p.q_rs + dg * 32 + g * 8);
+                qf[rt][dg] = __builtin_bit_cast(bf16x8_t, z);
+            }
+        }
+        f32x4_t oacc[2][4];
+        float mrow[2], lrow[2];
+#pragma unroll
+        for (int rt = 0; rt < 2; ++rt) {
+            mrow[rt] = -1e30f; lrow[rt] = 0.f;
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) oacc[rt][dt] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+        }
+        for (int t = 0; t < NT; ++t) {
+            const int kv0 = t << 6;
+            int nkt = (S - kv0 + 15) >> 4;
+            nkt = nkt > 4 ? 4 : nkt;
+            f32x4_t sacc[2][4];
+#pragma unroll
+            for (int kt = 0; kt < 4; ++kt) {
+                sacc[0][kt] = (f32x4_t){0.f, 0.f, 0.f, 0.f}; sacc[1][kt] = sacc[0][kt];
+                if (kt < nkt) {
+#pragma unroll
+                    for (int dg = 0; dg < 2; ++dg) {
+                        const bf16x8_t kf = read_frag<bf16_t>(sK, kv0 + kt * 16 + fr, dg * 4 + g);
+                        sacc[0][kt] = Mma<bf16_t>::mma(kf, qf[0][dg], sacc[0][kt]);
+                        sacc[1][kt] = Mma<bf16_t>::mma(kf, qf[1][dg], sacc[1][kt]);
+                    }
+                }
+            }
+#pragma unroll
+            for (int rt = 0; rt < 2; ++rt) {
+                const float* mrowp = (p.mask && qr[rt] < S) ? p.mask + (int64_t)b * p.mask_bs + (int64_t)qr[rt] * p.mask_rs : nullptr;
+                float mx = -INFINITY;
+#pragma unroll
+                for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int key = kv0 + kt * 16 + 4 * g + r;
+                        float s = sacc[rt][kt][r] * sl2;
+                        if (key < S) { if (mrowp) s += mrowp[key] * LOG2E_F; }
+                        else s = -INFINITY;
+                        sacc[rt][kt][r] = s;
+                        mx = fmaxf(mx, s);
+                    }
+                mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+                mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+                const float mnew = fmaxf(mrow[rt], mx);
+                const float alpha = fast_exp2(mrow[rt] - mnew);
+                mrow[rt] = mnew;
+                float ps = 0.f;
+#pragma unroll
+                for (int kt = 0; kt < 4; ++kt) {
+                    f32x4_t pv;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) { pv[r] = fast_exp2(sacc[rt][kt][r] - mnew); ps += pv[r]; }
+                    if (thr && kt < nkt) {
+                        const int key4 = (kv0 + kt * 16 + 4 * g) >> 2;
+                        const uint64_t ctr = p.offset + ((uint64_t)((int64_t)(b * p.H + h) * p.Sq + qr[rt])) * kq4 + key4;
+                        Philox4 rnd = philox4x32_10(p.seed, ctr);
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) pv[r] = rnd.v[r] >= thr ? pv[r] * keep_scale : 0.f;
+                    }
+                    sacc[rt][kt] = pv;
+                }
+                lrow[rt] = lrow[rt] * alpha + ps;
+#pragma unroll
+                for (int dt = 0; dt < 4; ++dt) oacc[rt][dt] *= alpha;
+            }
+            // O^T += V^T . P^T over this tile's keys (32 keys per MFMA; the V fragment is a transposing LDS read)
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) {
+                if (2 * kk < nkt) {
+                    const bf16x8_t pf0 = pack_bf16x8(sacc[0][2 * kk], sacc[0][2 * kk + 1]);
+                    const bf16x8_t pf1 = pack_bf16x8(sacc[1][2 * kk], sacc[1][2 * kk + 1]);
+#pragma unroll
+                    for (int dt = 0; dt < 4; ++dt) {
+                        const bf16x8_t vf = read_frag_tr_nat(sV, kv0 + 32 * kk, troff[dt]);
+                        oacc[0][dt] = Mma<bf16_t>::mma(vf, pf0, oacc[0][dt]);
+                        oacc[1][dt] = Mma<bf16_t>::mma(vf, pf1, oacc[1][dt]);
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int rt = 0; rt < 2; ++rt) {
+            float l = lrow[rt];
+            l += __shfl_xor(l, 16, 64);
+            l += __shfl_xor(l, 32, 64);
+            const float inv = l > 0.f ? 1.0f / l : 0.f;
+            if (qr[rt] < S) {
+                bf16_t* O = (bf16_t*)p.o + (int64_t)b * p.o_bs + (int64_t)qr[rt] * p.o_rs + h * ATT_D;
+#pragma unroll
+                for (int dt = 0; dt < 4; ++dt) store4<bf16_t>(O + dt * 16 + 4 * g, oacc[rt][dt] * inv);
+                if (g == 0 && p.lse) p.lse[((int64_t)b * p.H + h) * p.Sq + qr[rt]] = (mrow[rt] + __log2f(l)) * LN2_F;
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------ backward
+// grid (H, B), 512 threads (8 waves). LDS: [Q][dO][K][V] images (SP rows each) + lse (log2 domain) + delta.
+// Phase 1: wave w owns the 32-query-row block w -> dQ.   Phase 2: wave w owns the 32-key block w -> dK, dV.
+// Both phases only READ LDS, so there is no barrier between them.
+__global__ __launch_bounds__(512, 2) void attn_res_bwd_kernel(AttnArgs p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int fr = lane & 15, g = lane >> 4;
+    const int h = blockIdx.x, b = blockIdx.y;
+    const int S = p.Skv, SP = (S + 15) & ~15;
+    const int IMG = SP * TILE_ROW_BYTES;
+    char* sQ = smem;
+    char* sDO = smem + IMG;
+    char* sK = smem + 2 * IMG;
+    char* sV = smem + 3 * IMG;
+    float* sLse = (float*)(smem + 4 * IMG);
+    float* sDelta = sLse + SP;
+
+    stage_image(head_rsrc(p.q, (int64_t)b * p.q_bs + h * ATT_D, S, p.q_rs), sQ, SP, (int)p.q_rs * 2, wave, 8, lane);
+    stage_image(head_rsrc(p.dout, (int64_t)b * p.do_bs + h * ATT_D, S, p.do_rs), sDO, SP, (int)p.do_rs * 2, wave, 8, lane);
+    stage_image(head_rsrc(p.k, (int64_t)b * p.k_bs + h * ATT_D, S, p.k_rs), sK, SP, (int)p.k_rs * 2, wave, 8, lane);
+    stage_image(head_rsrc(p.v, (int64_t)b * p.v_bs + h * ATT_D, S, p.v_rs), sV, SP, (int)p.v_rs * 2, wave, 8, lane);
+
+    const int64_t statbase = ((int64_t)b * p.H + h) * p.Sq;
+    {   // delta[q] = sum_d dO*O ; lse -> log2 domain.  8 rows per wave iteration, 8 lanes x 16 B per row.
+        const bf16_t* Ob = (const bf16_t*)p.o + (int64_t)b * p.o_bs + h * ATT_D;
+        const bf16_t* DOb = (const bf16_t*)p.dout + (int64_t)b * p.do_bs + h * ATT_D;
+        for (int r0 = wave * 8; r0 < SP; r0 += 64) {
+            const int row = r0 + (lane >> 3), c = lane & 7;
+            float d = 0.f;
+            if (row < S) {
+                const bf16x8_t ov = __builtin_bit_cast(bf16x8_t, *(const u32x4_t*)(Ob + (int64_t)row * p.o_rs + c * 8));
+                const bf16x8_t dv = __builtin_bit_cast(bf16x8_t, *(const u32x4_t*)(DOb + (int64_t)row * p.do_rs + c * 8));
+#pragma unroll
+                for (int e = 0; e < 8; ++e) d += (float)ov[e] * (float)dv[e];
+            }
+            d += __shfl_xor(d, 1, 64); d += __shfl_xor(d, 2, 64); d += __shfl_xor(d, 4, 64);
+            if (c == 0) { sDelta[row] = d; sLse[row] = row < S ? p.lse[statbase + row] * LOG2E_F : 0.f; }
+        }
+    }
+    const float sl2 = p.scale * LOG2E_F;
+    const uint32_t thr = drop_threshold(p.p_drop);
+    const float keep_scale = p.p_drop > 0.f ? 1.0f / (1.0f - p.p_drop) : 1.0f;
+    const int kq4 = (p.Skv + 3) >> 2;
+    int troff[4];
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) troff[dt] = tr_lane_off(lane, dt);
+    const int NP = (S + 31) >> 5, NT = (S + 63) >> 6;
+
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    // ---------------- phase 1: dQ
+    for (int pr = wave; pr < NP; pr += 8) {
+        bf16x8_t qf[2][2], dof[2][2];
+        int qr[2];
+        float lse2[2], dlt[2];
+#pragma unroll
+        for (int rt = 0; rt < 2; ++rt) {
+            qr[rt] = pr * 32 + rt * 16 + fr;       // < SP + 16: rows >= SP of the LAST image pair read the next image (never used: qok)
+            const int qrc = qr[rt] < SP ? qr[rt] : SP - 1;
+#pragma unroll
+            for (int dg = 0; dg < 2; ++dg) {
+                qf[rt][dg] = read_frag<bf16_t>(sQ, qrc, dg * 4 + g);
+                dof[rt][dg] = read_frag<bf16_t>(sDO, qrc, dg * 4 + g);
+            }
+            lse2[rt] = sLse[qrc]; dlt[rt] = sDelta[qrc];
+        }
+        f32x4_t dqacc[2][4];
+#pragma unroll
+        for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) dqacc[rt][dt] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+        for (int t = 0; t < NT; ++t) {
+            const int kv0 = t << 6;
+            int nkt = (S - kv0 + 15) >> 4;
+            nkt = nkt > 4 ? 4 : nkt;
+            f32x4_t sacc[2][4], pacc[2][4];
+#pragma unroll
+            for (int kt = 0; kt < 4; ++kt) {
+                sacc[0][kt] = (f32x4_t){0.f, 0.f, 0.f, 0.f}; sacc[1][kt] = sacc[0][kt]; pacc[0][kt] = sacc[0][kt]; pacc[1][kt] = sacc[0][kt];
+                if (kt < nkt) {
+#pragma unroll
+                    for (int dg = 0; dg < 2; ++dg) {
+                        const bf16x8_t kf = read_frag<bf16_t>(sK, kv0 + kt * 16 + fr, dg * 4 + g);
+                        const bf16x8_t vf = read_frag<bf16_t>(sV, kv0 + kt * 16 + fr, dg * 4 + g);
+                        sacc[0][kt] = Mma<bf16_t>::mma(kf, qf[0][dg], sacc[0][kt]);
+                        sacc[1][kt] = Mma<bf16_t>::mma(kf, qf[1][dg], sacc[1][kt]);
+                        pacc[0][kt] = Mma<bf16_t>::mma(vf, dof[0][dg], pacc[0][kt]);
+                        pacc[1][kt] = Mma<bf16_t>::mma(vf, dof[1][dg], pacc[1][kt]);
+                    }
+                }
+            }
+#pragma unroll
+            for (int rt = 0; rt < 2; ++rt) {
+                const bool qok = qr[rt] < S;
+                const float* mrowp = (p.mask && qok) ? p.mask + (int64_t)b * p.mask_bs + (int64_t)qr[rt] * p.mask_rs : nullptr;
+#pragma unroll
+                for (int kt = 0; kt < 4; ++kt) {
+                    Philox4 rnd;
+                    if (thr) {
+                        const int key4 = (kv0 + kt * 16 + 4 * g) >> 2;
+                        rnd = philox4x32_10(p.seed, p.offset + ((uint64_t)(statbase + qr[rt])) * kq4 + key4);
+                    }
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int key = kv0 + kt * 16 + 4 * g + r;
+                        float s = sacc[rt][kt][r] * sl2;
+                        if (mrowp && key < S) s += mrowp[key] * LOG2E_F;
+                        const float prb = (key < S && qok) ? fast_exp2(s - lse2[rt]) : 0.f;
+                        float dp = pacc[rt][kt][r];
+                        if (thr) dp = rnd.v[r] >= thr ? dp * keep_scale : 0.f;
+                        sacc[rt][kt][r] = prb * (dp - dlt[rt]);       // dS
+                    }
+                }
+            }
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) {
+                if (2 * kk < nkt) {
+                    const bf16x8_t d0 = pack_bf16x8(sacc[0][2 * kk], sacc[0][2 * kk + 1]);
+                    const bf16x8_t d1 = pack_bf16x8(sacc[1][2 * kk], sacc[1][2 * kk + 1]);
+#pragma unroll
+                    for (int dt = 0; dt < 4; ++dt) {
+                        const bf16x8_t ktf = read_frag_tr_nat(sK, kv0 + 32 * kk, troff[dt]);   // K^T[d][key]
+                        dqacc[0][dt] = Mma<bf16_t>::mma(ktf, d0, dqacc[0][dt]);
+                        dqacc[1][dt] = Mma<bf16_t>::mma(ktf, d1, dqacc[1][dt]);
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int rt = 0; rt < 2; ++rt)
+            if (qr[rt] < S) {
+                bf16_t* DQ = (bf16_t*)p.dq + (int64_t)b * p.dq_bs + (int64_t)qr[rt] * p.dq_rs + h * ATT_D;
+#pragma unroll
+                for (int dt = 0; dt < 4; ++dt) store4<bf16_t>(DQ + dt * 16 + 4 * g, dqacc[rt][dt] * p.scale);
+            }
+    }
+
+    // ---------------- phase 2: dK, dV   (scores as S[q = 4g+r][key = l & 15])
+    for (int pr = wave; pr < NP; pr += 8) {
+        bf16x8_t kf[2][2], vf[2][2];
+        int key[2];
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt) {
+            key[kt] = pr * 32 + kt * 16 + fr;
+            const int kc = key[kt] < SP ? key[kt] : SP - 1;
+#pragma unroll
+            for (int dg = 0; dg < 2; ++dg) {
+                kf[kt][dg] = read_frag<bf16_t>(sK, kc, dg * 4 + g);
+                vf[kt][dg] = read_frag<bf16_t>(sV, kc, dg * 4 + g);
+            }
+        }
+        f32x4_t dkacc[2][4], dvacc[2][4];
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) { dkacc[kt][dt] = (f32x4_t){0.f, 0.f, 0.f, 0.f}; dvacc[kt][dt] = dkacc[kt][dt]; }
+        for (int t = 0; t < NT; ++t) {
+            const int qb0 = t << 6;
+            int nqs = (S - qb0 + 15) >> 4;
+            nqs = nqs > 4 ? 4 : nqs;
+            f32x4_t sacc[2][4], pacc[2][4];     // [kt][qs]
+#pragma unroll
+            for (int qs = 0; qs < 4; ++qs) {
+                sacc[0][qs] = (f32x4_t){0.f, 0.f, 0.f, 0.f}; sacc[1][qs] = sacc[0][qs]; pacc[0][qs] = sacc[0][qs]; pacc[1][qs] = sacc[0][qs];
+                if (qs < nqs) {
+#pragma unroll
+                    for (int dg = 0; dg < 2; ++dg) {
+                        const bf16x8_t qfr = read_frag<bf16_t>(sQ, qb0 + qs * 16 + fr, dg * 4 + g);
+                        const bf16x8_t dfr = read_frag<bf16_t>(sDO, qb0 + qs * 16 + fr, dg * 4 + g);
+                        sacc[0][qs] = Mma<bf16_t>::mma(qfr, kf[0][dg], sacc[0][qs]);
+                        sacc[1][qs] = Mma<bf16_t>::mma(qfr, kf[1][dg], sacc[1][qs]);
+                        pacc[0][qs] = Mma<bf16_t>::mma(dfr, vf[0][dg], pacc[0][qs]);
+                        pacc[1][qs] = Mma<bf16_t>::mma(dfr, vf[1][dg], pacc[1][qs]);
+                    }
+                }
+            }
+#pragma unroll
+            for (int qs = 0; qs < 4; ++qs) {
+                const int q4 = qb0 + qs * 16 + 4 * g;                       // < SP when qs < nqs
+                f32x4_t l4 = {0.f, 0.f, 0.f, 0.f}, d4 = l4;
+                if (qs < nqs) { l4 = *(const f32x4_t*)(sLse + q4); d4 = *(const f32x4_t*)(sDelta + q4); }
+#pragma unroll
+                for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int qr = q4 + r;
+                        float dsv = 0.f, pdv = 0.f;
+                        if (qs < nqs && qr < S && key[kt] < S) {
+                            float s = sacc[kt][qs][r] * sl2;
+                            if (p.mask) s += p.mask[(int64_t)b * p.mask_bs + (int64_t)qr * p.mask_rs + key[kt]] * LOG2E_F;
+                            const float prb = fast_exp2(s - l4[r]);
+                            float dp = pacc[kt][qs][r];
+                            pdv = prb;
+                            if (thr) {
+                                Philox4 rnd = philox4x32_10(p.seed, p.offset + ((uint64_t)(statbase + qr)) * kq4 + (key[kt] >> 2));
+                                const int comp = key[kt] & 3;
+                                const uint32_t rv = comp == 0 ? rnd.v[0] : comp == 1 ? rnd.v[1] : comp == 2 ? rnd.v[2] : rnd.v[3];
+                                const bool keep = rv >= thr;
+                                dp = keep ? dp * keep_scale : 0.f;
+                                pdv = keep ? prb * keep_scale : 0.f;
+                            }
+                            dsv = prb * (dp - d4[r]);
+                        }
+                        pacc[kt][qs][r] = pdv; sacc[kt][qs][r] = dsv;
+                    }
+            }
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) {
+                if (2 * kk < nqs) {
+                    const bf16x8_t p0 = pack_bf16x8(pacc[0][2 * kk], pacc[0][2 * kk + 1]);
+                    const bf16x8_t p1 = pack_bf16x8(pacc[1][2 * kk], pacc[1][2 * kk + 1]);
+                    const bf16x8_t s0 = pack_bf16x8(sacc[0][2 * kk], sacc[0][2 * kk + 1]);
+                    const bf16x8_t s1 = pack_bf16x8(sacc[1][2 * kk], sacc[1][2 * kk + 1]);
+#pragma unroll
+                    for (int dt = 0; dt < 4; ++dt) {
+                        const bf16x8_t dotf = read_frag_tr_nat(sDO, qb0 + 32 * kk, troff[dt]);   // dO^T[d][q]
+                        const bf16x8_t qtf = read_frag_tr_nat(sQ, qb0 + 32 * kk, troff[dt]);     // Q^T[d][q]
+                        dvacc[0][dt] = Mma<bf16_t>::mma(dotf, p0, dvacc[0][dt]);
+                        dvacc[1][dt] = Mma<bf16_t>::mma(dotf, p1, dvacc[1][dt]);
+                        dkacc[0][dt] = Mma<bf16_t>::mma(qtf, s0, dkacc[0][dt]);
+                        dkacc[1][dt] = Mma<bf16_t>::mma(qtf, s1, dkacc[1][dt]);
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt)
+            if (key[kt] < S) {
+                bf16_t* DK = (bf16_t*)p.dk + (int64_t)b * p.dk_bs + (int64_t)key[kt] * p.dk_rs + h * ATT_D;
+                bf16_t* DV = (bf16_t*)p.dv + (int64_t)b * p.dv_bs + (int64_t)key[kt] * p.dv_rs + h * ATT_D;
+#pragma unroll
+                for (int dt = 0; dt < 4; ++dt) {
+                    store4<bf16_t>(DK + dt * 16 + 4 * g, dkacc[kt][dt] * p.scale);
+                    store4<bf16_t>(DV + dt * 16 + 4 * g, dvacc[kt][dt]);
+                }
+            }
+    }
+}
+
+// ------------------------------------------------------------------------------------------ launch
+static bool res_eligible(const AttnArgs& p) {
+    if (p.kv_range || p.kv_bmod > 0 || p.Sq != p.Skv || p.Skv > 256) return false;
+    const int64_t lim = (int64_t)1 << 31;
+    return (int64_t)p.Skv * p.k_rs * 2 < lim && (int64_t)p.Skv * p.v_rs * 2 < lim && (int64_t)p.Sq * p.q_rs * 2 < lim;
+}
+
+bool attn_res_fwd_launch(hipStream_t st, const AttnArgs& p) {
+    if (!res_eligible(p)) return false;
+    const int SP = (p.Skv + 15) & ~15;
+    const size_t lds = 2 * (size_t)SP * TILE_ROW_BYTES;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipFuncSetAttribute((const void*)attn_res_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 256 * TILE_ROW_BYTES);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(attn_res_fwd_kernel, dim3(p.H, p.B), dim3(256), lds, st, p);
+    return true;
+}
+
+bool attn_res_bwd_launch(hipStream_t st, const AttnArgs& p) {
+    // one workgroup of 8 waves per head needs >= 2 32-row blocks to be worth it; shorter sequences stay on the
+    // streaming kernels (measured: S = 32 / 42 are slower here)
+    if (!res_eligible(p) || p.Skv <= 64 || (int64_t)p.Sq * p.do_rs * 2 >= ((int64_t)1 << 31)) return false;
+    const int SP = (p.Skv + 15) & ~15;
+    const size_t lds = 4 * (size_t)SP * TILE_ROW_BYTES + 2 * (size_t)SP * sizeof(float);
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipFuncSetAttribute((const void*)attn_res_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                            4 * 256 * TILE_ROW_BYTES + 2 * 256 * (int)sizeof(float));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(attn_res_bwd_kernel, dim3(p.H, p.B), dim3(512), lds, st, p);
+    return true;
+}

@@ -1,0 +1,39 @@
+// shared by attention.hip (streaming kernels, any shape, bf16 + fp32) and attention_res.hip (LDS-resident
+// bf16 kernels for short self-attention).
+#pragma once
+#include "mma.h"
+
+#define ATT_D 64
+#define LOG2E_F 1.44269504088896340736f
+#define LN2_F 0.69314718055994530942f
+
+struct AttnArgs {
+    const void* q; const void* k; const void* v; void* o; float* lse;
+    const void* dout; void* dq; void* dk; void* dv; float* delta;   // backward only
+    const float* mask; const int* kv_range;
+    int B, H, Sq, Skv;
+    int64_t q_bs, q_rs, k_bs, k_rs, v_bs, v_rs, o_bs, o_rs;
+    int64_t do_bs, do_rs, dq_bs, dq_rs, dk_bs, dk_rs, dv_bs, dv_rs;
+    int64_t mask_bs, mask_rs;
+    int kv_bmod;
+    float scale, p_drop;
+    uint64_t seed, offset;
+};
+
+template <typename T> DEVINL float fexp(float x);
+template <> DEVINL float fexp<float>(float x) { return expf(x); }
+template <> DEVINL float fexp<bf16_t>(float x) { return __expf(x); }
+
+DEVINL bf16x8_t pack_bf16x8(f32x4_t a, f32x4_t b) {
+    u32x4_t r;
+    r[0] = pack2_bf16(a[0], a[1]);
+    r[1] = pack2_bf16(a[2], a[3]);
+    r[2] = pack2_bf16(b[0], b[1]);
+    r[3] = pack2_bf16(b[2], b[3]);
+    return __builtin_bit_cast(bf16x8_t, r);
+}
+
+
+// LDS-resident fast paths (attention_res.hip). Return true if the shape was handled.
+bool attn_res_fwd_launch(hipStream_t st, const AttnArgs& p);
+bool attn_res_bwd_launch(hipStream_t st, const AttnArgs& p);

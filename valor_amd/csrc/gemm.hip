@@ -265,18 +265,11 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs p) {
 // M/N tails and the k tail of k-slow operands are zero-filled by the buffer range check; the k tail of
 // a direct operand (k runs into the next row, not past the buffer) is masked in registers on the final
 // partial K-step only.
-typedef __attribute__((ext_vector_type(4))) short s16x4_t;
-#define LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
-
-DEVINL void glds16(rsrc_t rs, char* lds_dst, int voff) {
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, LDS_PTR(lds_dst), 16, voff, 0, 0, 0);
-}
 // k-slow image fragment: `off` = per-lane byte offset (k-row 8g + (i>>2), half granule, slot of this 16-row block)
 DEVINL bf16x8_t read_frag_tr(const char* img, int off, int kk) {
     const char* a = img + off + kk * (32 * 256);
     s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)LDS_PTR(a));
     s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)LDS_PTR(a + 4 * 256));
-    typedef __attribute__((ext_vector_type(8))) short s16x8_t;
     s16x8_t r = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
     return __builtin_bit_cast(bf16x8_t, r);
 }

@@ -367,3 +367,34 @@ struct BufTransStage {
         }
     }
 };
+
+// ---------------------------------------------------------------------------------------
+// LDS-DMA (buffer_load_dwordx4 ... lds): 64 lanes x 16 B land lane-linear at a wave-uniform LDS address; the
+// per-lane SOURCE offset is free, so swizzled images are built by permuting the source.
+// ds_read_b64_tr_b16: a 16-lane group reads a [4 rows][16 cols] bf16 block (lane i supplies 4 consecutive cols
+// of row i>>2 at its own 8-B aligned address) and lane i receives the 4 rows of col i  (hardware transpose).
+// ---------------------------------------------------------------------------------------
+typedef __attribute__((ext_vector_type(4))) short s16x4_t;
+#define LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
+
+DEVINL void glds16(rsrc_t rs, char* lds_dst, int voff) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, LDS_PTR(lds_dst), 16, voff, 0, 0, 0);
+}
+typedef __attribute__((ext_vector_type(8))) short s16x8_t;
+DEVINL s16x4_t lds_read_tr4(const char* a) {
+    return __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)LDS_PTR(a));
+}
+// Standard XOR image (tile_off): per-lane byte offset of the tr-read for the 16-column block `cb`, relative to
+// (row0 * 128) with row0 a multiple of 8.  Lane (g = l>>4, i = l&15) reads row row0 + 4g + (i>>2), cols 16cb + 4(i&3)..+3.
+DEVINL int tr_lane_off(int lane, int cb) {
+    const int g = lane >> 4, i = lane & 15;
+    const int rl = 4 * g + (i >> 2);
+    return rl * TILE_ROW_BYTES + ((((2 * cb) | ((i >> 1) & 1)) ^ (rl & 7)) << 4) + 8 * (i & 1);
+}
+// fragment with the "natural k-slot" order: slots 0-3 <- rows row0 + 4g + j, slots 4-7 <- rows row0 + 16 + 4g + j
+// of column (l & 15) of block cb  (the second MFMA operand then packs two 16-row groups of per-lane values).
+DEVINL bf16x8_t read_frag_tr_nat(const char* img, int row0, int lane_off) {
+    const char* a = img + row0 * TILE_ROW_BYTES + lane_off;
+    s16x4_t lo = lds_read_tr4(a), hi = lds_read_tr4(a + 16 * TILE_ROW_BYTES);
+    return __builtin_bit_cast(bf16x8_t, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+}
