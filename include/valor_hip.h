@@ -72,7 +72,8 @@ int valor_colsum(void* stream, int dtype, const void* x, int64_t rows, int cols,
                  int out_f32, int accumulate);
 
 /* attention kernel selection (tuning / A-B hook): bit 0 = LDS-resident short-sequence self-attention kernels for
- * bf16 (S = Sq = Skv <= 256, no kv_range); 0 = streaming kernels only. Returns the previous value; v < 0 queries. */
+ * bf16 (S = Sq = Skv <= 256, no kv_range); bit 1 = key-stationary cross-attention kernels (few query rows, many keys,
+ * grouped kv_range); 0 = streaming kernels only. Returns the previous value; v < 0 queries. */
 int valor_attn_set_variant(int v);
 
 /* ---- flash attention, head_dim 64.  Replaces BertSelfAttention (bert.py:272-288), BertCrossAttention (bert.py:314-340,

@@ -125,7 +125,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs p) {
 
     const uint32_t thr = drop_threshold(p.p_drop);
     const float keep_scale = p.p_drop > 0.f ? 1.0f / (1.0f - p.p_drop) : 1.0f;
-    const int kq4 = (p.Skv + 3) >> 2;   // RNG row pitch in 4-key groups
+    const uint32_t hk = attn_drop_headkey(p.seed, p.offset, b * p.H + h);
 
     Stage64<T> st[NIMG];
     auto issue = [&](int kv0) {
@@ -203,11 +203,9 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs p) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) { pv[r] = fexp<T>(sacc[rt][kt][r] - mnew); ps += pv[r]; }
                 if (thr) {
-                    const int key4 = (kv0 + kt * 16 + 4 * g) >> 2;
-                    const uint64_t ctr = p.offset + ((uint64_t)((int64_t)(b * p.H + h) * p.Sq + qr)) * kq4 + key4;
-                    Philox4 rnd = philox4x32_10(p.seed, ctr);
+                    const uint32_t e0 = (uint32_t)qr * (uint32_t)p.Skv + (uint32_t)(kv0 + kt * 16 + 4 * g);
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) pv[r] = rnd.v[r] >= thr ? pv[r] * keep_scale : 0.f;
+                    for (int r = 0; r < 4; ++r) pv[r] = attn_drop_bits(hk, e0 + r) >= thr ? pv[r] * keep_scale : 0.f;
                 }
                 sacc[rt][kt] = pv;
             }
@@ -295,7 +293,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnArgs p) {
 
     const uint32_t thr = drop_threshold(p.p_drop);
     const float keep_scale = p.p_drop > 0.f ? 1.0f / (1.0f - p.p_drop) : 1.0f;
-    const int kq4 = (p.Skv + 3) >> 2;
+    const uint32_t hk = attn_drop_headkey(p.seed, p.offset, b * p.H + h);
     const float* mrowp = (p.mask && qok) ? p.mask + (int64_t)b * p.mask_bs + (int64_t)qr * p.mask_rs : nullptr;
 
     Stage64<T> st[NIMG];
@@ -353,11 +351,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnArgs p) {
         f32x4_t ds[4];
 #pragma unroll
         for (int kt = 0; kt < 4; ++kt) {
-            Philox4 rnd;
-            if (thr) {
-                const int key4 = (kv0 + kt * 16 + 4 * g) >> 2;
-                rnd = philox4x32_10(p.seed, p.offset + ((uint64_t)statidx) * kq4 + key4);
-            }
+            const uint32_t e0 = (uint32_t)qr * (uint32_t)p.Skv + (uint32_t)(kv0 + kt * 16 + 4 * g);
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int key = kv0 + kt * 16 + 4 * g + r;
@@ -365,7 +359,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnArgs p) {
                 if (mrowp && key < kv.len) s += mrowp[key];
                 const float pr = (key < kv.len && qok) ? fexp<T>(s - lse) : 0.f;
                 float dp = pacc[kt][r];
-                if (thr) dp = rnd.v[r] >= thr ? dp * keep_scale : 0.f;
+                if (thr) dp = attn_drop_bits(hk, e0 + r) >= thr ? dp * keep_scale : 0.f;
                 ds[kt][r] = pr * (dp - dsum);
             }
         }
@@ -425,7 +419,6 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnArgs p) {
 
     const uint32_t thr = drop_threshold(p.p_drop);
     const float keep_scale = p.p_drop > 0.f ? 1.0f / (1.0f - p.p_drop) : 1.0f;
-    const int kq4 = (p.Skv + 3) >> 2;
     const int bstep = p.kv_bmod > 0 ? p.kv_bmod : p.B;
     const int tile_lo = blockIdx.x * 64, tile_hi = tile_lo + 64;
     const int nqt = (p.Sq + 63) >> 6;
@@ -511,10 +504,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnArgs p) {
                     float dp = pacc[r];
                     pdv = pr;
                     if (thr) {
-                        Philox4 rnd = philox4x32_10(p.seed, p.offset + ((uint64_t)(statbase + qr)) * kq4 + (key_loc >> 2));
-                        const int comp = key_loc & 3;   // select, not index: a runtime index sends the struct to scratch
-                        const uint32_t rv = comp == 0 ? rnd.v[0] : comp == 1 ? rnd.v[1] : comp == 2 ? rnd.v[2] : rnd.v[3];
-                        const bool keep = rv >= thr;
+                        const bool keep = attn_drop_bits(attn_drop_headkey(p.seed, p.offset, b * p.H + h), (uint32_t)qr * (uint32_t)p.Skv + (uint32_t)key_loc) >= thr;
                         dp = keep ? dp * keep_scale : 0.f;
                         pdv = keep ? pr * keep_scale : 0.f;
                     }
@@ -543,14 +533,16 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnArgs p) {
 }
 
 // ------------------------------------------------------------------------------------------
-// bit 0: LDS-resident short-sequence kernels (attention_res.hip) allowed for bf16
-static int g_attn_variant = 1;
+// bit 0: LDS-resident short-sequence kernels (attention_res.hip), bit 1: key-stationary cross-attention kernels
+// (attention_x.hip) allowed for bf16
+static int g_attn_variant = 3;
 extern "C" int valor_attn_set_variant(int v) { const int o = g_attn_variant; if (v >= 0) g_attn_variant = v; return o; }
 
 template <typename T>
 static int attn_fwd_launch(hipStream_t st, const AttnArgs& p) {
     constexpr int NIMG = 64 * (int)sizeof(T) / TILE_ROW_BYTES;
     if (ElemTraits<T>::DT == VALOR_DT_BF16 && (g_attn_variant & 1) && attn_res_fwd_launch(st, p)) return valor_launch_status();
+    if (ElemTraits<T>::DT == VALOR_DT_BF16 && (g_attn_variant & 2) && attn_x_fwd_launch(st, p)) return valor_launch_status();
     const size_t lds = 2 * 2 * NIMG * IMG_BYTES;
     static bool attr_set = false;
     if (!attr_set) {
@@ -571,6 +563,7 @@ template <typename T>
 static int attn_bwd_launch(hipStream_t st, const AttnArgs& p) {
     constexpr int NIMG = 64 * (int)sizeof(T) / TILE_ROW_BYTES;
     if (ElemTraits<T>::DT == VALOR_DT_BF16 && (g_attn_variant & 1) && attn_res_bwd_launch(st, p)) return valor_launch_status();
+    if (ElemTraits<T>::DT == VALOR_DT_BF16 && (g_attn_variant & 2) && attn_x_bwd_launch(st, p)) return valor_launch_status();
     {
         const size_t lds = 2 * 3 * NIMG * IMG_BYTES;
         static bool attr_set_dq = false;

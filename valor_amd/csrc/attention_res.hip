@@ -36,6 +36,7 @@ DEVINL rsrc_t head_rsrc(const void* base, int64_t elem_off, int S, int64_t rs) {
 // ------------------------------------------------------------------------------------------ forward
 // grid (H, B), 256 threads. LDS: [V image][K image], SP = ceil16(S) rows each.  Wave w owns the 32-query-row
 // blocks w, w+4, ... (two 16-row MFMA tiles sharing every K / V fragment read).
+template <bool DROP>
 __global__ __launch_bounds__(256, 3) void attn_res_fwd_kernel(AttnArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -53,7 +54,7 @@ __global__ __launch_bounds__(256, 3) void attn_res_fwd_kernel(AttnArgs p) {
     const float sl2 = p.scale * LOG2E_F;
     const uint32_t thr = drop_threshold(p.p_drop);
     const float keep_scale = p.p_drop > 0.f ? 1.0f / (1.0f - p.p_drop) : 1.0f;
-    const int kq4 = (p.Skv + 3) >> 2;
+    const uint32_t hk = attn_drop_headkey(p.seed, p.offset, b * p.H + h);
     int troff[4];
 #pragma unroll
     for (int dt = 0; dt < 4; ++dt) troff[dt] = tr_lane_off(lane, dt);
@@ -126,12 +127,10 @@ __global__ __launch_bounds__(256, 3) void attn_res_fwd_kernel(AttnArgs p) {
                     f32x4_t pv;
 #pragma unroll
                     for (int r = 0; r < 4; ++r) { pv[r] = fast_exp2(sacc[rt][kt][r] - mnew); ps += pv[r]; }
-                    if (thr && kt < nkt) {
-                        const int key4 = (kv0 + kt * 16 + 4 * g) >> 2;
-                        const uint64_t ctr = p.offset + ((uint64_t)((int64_t)(b * p.H + h) * p.Sq + qr[rt])) * kq4 + key4;
-                        Philox4 rnd = philox4x32_10(p.seed, ctr);
+                    if (DROP && kt < nkt) {
+                        const uint32_t e0 = (uint32_t)qr[rt] * (uint32_t)p.Skv + (uint32_t)(kv0 + kt * 16 + 4 * g);
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) pv[r] = rnd.v[r] >= thr ? pv[r] * keep_scale : 0.f;
+                        for (int r = 0; r < 4; ++r) pv[r] = attn_drop_bits(hk, e0 + r) >= thr ? pv[r] * keep_scale : 0.f;
                     }
                     sacc[rt][kt] = pv;
                 }
@@ -174,6 +173,7 @@ __global__ __launch_bounds__(256, 3) void attn_res_fwd_kernel(AttnArgs p) {
 // grid (H, B), 512 threads (8 waves). LDS: [Q][dO][K][V] images (SP rows each) + lse (log2 domain) + delta.
 // Phase 1: wave w owns the 32-query-row block w -> dQ.   Phase 2: wave w owns the 32-key block w -> dK, dV.
 // Both phases only READ LDS, so there is no barrier between them.
+template <bool DROP>
 __global__ __launch_bounds__(512, 2) void attn_res_bwd_kernel(AttnArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -214,7 +214,7 @@ __global__ __launch_bounds__(512, 2) void attn_res_bwd_kernel(AttnArgs p) {
     const float sl2 = p.scale * LOG2E_F;
     const uint32_t thr = drop_threshold(p.p_drop);
     const float keep_scale = p.p_drop > 0.f ? 1.0f / (1.0f - p.p_drop) : 1.0f;
-    const int kq4 = (p.Skv + 3) >> 2;
+    const uint32_t hk = attn_drop_headkey(p.seed, p.offset, b * p.H + h);
     int troff[4];
 #pragma unroll
     for (int dt = 0; dt < 4; ++dt) troff[dt] = tr_lane_off(lane, dt);
@@ -248,56 +248,50 @@ __global__ __launch_bounds__(512, 2) void attn_res_bwd_kernel(AttnArgs p) {
             const int kv0 = t << 6;
             int nkt = (S - kv0 + 15) >> 4;
             nkt = nkt > 4 ? 4 : nkt;
-            f32x4_t sacc[2][4], pacc[2][4];
-#pragma unroll
-            for (int kt = 0; kt < 4; ++kt) {
-                sacc[0][kt] = (f32x4_t){0.f, 0.f, 0.f, 0.f}; sacc[1][kt] = sacc[0][kt]; pacc[0][kt] = sacc[0][kt]; pacc[1][kt] = sacc[0][kt];
-                if (kt < nkt) {
-#pragma unroll
-                    for (int dg = 0; dg < 2; ++dg) {
-                        const bf16x8_t kf = read_frag<bf16_t>(sK, kv0 + kt * 16 + fr, dg * 4 + g);
-                        const bf16x8_t vf = read_frag<bf16_t>(sV, kv0 + kt * 16 + fr, dg * 4 + g);
-                        sacc[0][kt] = Mma<bf16_t>::mma(kf, qf[0][dg], sacc[0][kt]);
-                        sacc[1][kt] = Mma<bf16_t>::mma(kf, qf[1][dg], sacc[1][kt]);
-                        pacc[0][kt] = Mma<bf16_t>::mma(vf, dof[0][dg], pacc[0][kt]);
-                        pacc[1][kt] = Mma<bf16_t>::mma(vf, dof[1][dg], pacc[1][kt]);
-                    }
-                }
-            }
-#pragma unroll
-            for (int rt = 0; rt < 2; ++rt) {
-                const bool qok = qr[rt] < S;
-                const float* mrowp = (p.mask && qok) ? p.mask + (int64_t)b * p.mask_bs + (int64_t)qr[rt] * p.mask_rs : nullptr;
-#pragma unroll
-                for (int kt = 0; kt < 4; ++kt) {
-                    Philox4 rnd;
-                    if (thr) {
-                        const int key4 = (kv0 + kt * 16 + 4 * g) >> 2;
-                        rnd = philox4x32_10(p.seed, p.offset + ((uint64_t)(statbase + qr[rt])) * kq4 + key4);
-                    }
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const int key = kv0 + kt * 16 + 4 * g + r;
-                        float s = sacc[rt][kt][r] * sl2;
-                        if (mrowp && key < S) s += mrowp[key] * LOG2E_F;
-                        const float prb = (key < S && qok) ? fast_exp2(s - lse2[rt]) : 0.f;
-                        float dp = pacc[rt][kt][r];
-                        if (thr) dp = rnd.v[r] >= thr ? dp * keep_scale : 0.f;
-                        sacc[rt][kt][r] = prb * (dp - dlt[rt]);       // dS
-                    }
-                }
-            }
 #pragma unroll
             for (int kk = 0; kk < 2; ++kk) {
-                if (2 * kk < nkt) {
-                    const bf16x8_t d0 = pack_bf16x8(sacc[0][2 * kk], sacc[0][2 * kk + 1]);
-                    const bf16x8_t d1 = pack_bf16x8(sacc[1][2 * kk], sacc[1][2 * kk + 1]);
+                if (2 * kk >= nkt) continue;
+                f32x4_t ds[2][2];      // [rt][kt2]
 #pragma unroll
-                    for (int dt = 0; dt < 4; ++dt) {
-                        const bf16x8_t ktf = read_frag_tr_nat(sK, kv0 + 32 * kk, troff[dt]);   // K^T[d][key]
-                        dqacc[0][dt] = Mma<bf16_t>::mma(ktf, d0, dqacc[0][dt]);
-                        dqacc[1][dt] = Mma<bf16_t>::mma(ktf, d1, dqacc[1][dt]);
+                for (int k2 = 0; k2 < 2; ++k2) {
+                    const int kt = 2 * kk + k2;
+                    f32x4_t sa[2], pa[2];
+                    sa[0] = (f32x4_t){0.f, 0.f, 0.f, 0.f}; sa[1] = sa[0]; pa[0] = sa[0]; pa[1] = sa[0];
+                    if (kt < nkt) {
+#pragma unroll
+                        for (int dg = 0; dg < 2; ++dg) {
+                            const bf16x8_t kf = read_frag<bf16_t>(sK, kv0 + kt * 16 + fr, dg * 4 + g);
+                            const bf16x8_t vf = read_frag<bf16_t>(sV, kv0 + kt * 16 + fr, dg * 4 + g);
+                            sa[0] = Mma<bf16_t>::mma(kf, qf[0][dg], sa[0]);
+                            sa[1] = Mma<bf16_t>::mma(kf, qf[1][dg], sa[1]);
+                            pa[0] = Mma<bf16_t>::mma(vf, dof[0][dg], pa[0]);
+                            pa[1] = Mma<bf16_t>::mma(vf, dof[1][dg], pa[1]);
+                        }
                     }
+#pragma unroll
+                    for (int rt = 0; rt < 2; ++rt) {
+                        const bool qok = qr[rt] < S;
+                        const float* mrowp = (p.mask && qok) ? p.mask + (int64_t)b * p.mask_bs + (int64_t)qr[rt] * p.mask_rs : nullptr;
+                        const uint32_t e0 = (uint32_t)qr[rt] * (uint32_t)p.Skv + (uint32_t)(kv0 + kt * 16 + 4 * g);
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const int key = kv0 + kt * 16 + 4 * g + r;
+                            float sc = sa[rt][r] * sl2;
+                            if (mrowp && key < S) sc += mrowp[key] * LOG2E_F;
+                            const float prb = (key < S && qok) ? fast_exp2(sc - lse2[rt]) : 0.f;
+                            float dp = pa[rt][r];
+                            if (DROP) dp = attn_drop_bits(hk, e0 + r) >= thr ? dp * keep_scale : 0.f;
+                            ds[rt][k2][r] = prb * (dp - dlt[rt]);
+                        }
+                    }
+                }
+                const bf16x8_t d0 = pack_bf16x8(ds[0][0], ds[0][1]);
+                const bf16x8_t d1 = pack_bf16x8(ds[1][0], ds[1][1]);
+#pragma unroll
+                for (int dt = 0; dt < 4; ++dt) {
+                    const bf16x8_t ktf = read_frag_tr_nat(sK, kv0 + 32 * kk, troff[dt]);   // K^T[d][key]
+                    dqacc[0][dt] = Mma<bf16_t>::mma(ktf, d0, dqacc[0][dt]);
+                    dqacc[1][dt] = Mma<bf16_t>::mma(ktf, d1, dqacc[1][dt]);
                 }
             }
         }
@@ -333,68 +327,63 @@ __global__ __launch_bounds__(512, 2) void attn_res_bwd_kernel(AttnArgs p) {
             const int qb0 = t << 6;
             int nqs = (S - qb0 + 15) >> 4;
             nqs = nqs > 4 ? 4 : nqs;
-            f32x4_t sacc[2][4], pacc[2][4];     // [kt][qs]
-#pragma unroll
-            for (int qs = 0; qs < 4; ++qs) {
-                sacc[0][qs] = (f32x4_t){0.f, 0.f, 0.f, 0.f}; sacc[1][qs] = sacc[0][qs]; pacc[0][qs] = sacc[0][qs]; pacc[1][qs] = sacc[0][qs];
-                if (qs < nqs) {
-#pragma unroll
-                    for (int dg = 0; dg < 2; ++dg) {
-                        const bf16x8_t qfr = read_frag<bf16_t>(sQ, qb0 + qs * 16 + fr, dg * 4 + g);
-                        const bf16x8_t dfr = read_frag<bf16_t>(sDO, qb0 + qs * 16 + fr, dg * 4 + g);
-                        sacc[0][qs] = Mma<bf16_t>::mma(qfr, kf[0][dg], sacc[0][qs]);
-                        sacc[1][qs] = Mma<bf16_t>::mma(qfr, kf[1][dg], sacc[1][qs]);
-                        pacc[0][qs] = Mma<bf16_t>::mma(dfr, vf[0][dg], pacc[0][qs]);
-                        pacc[1][qs] = Mma<bf16_t>::mma(dfr, vf[1][dg], pacc[1][qs]);
-                    }
-                }
-            }
-#pragma unroll
-            for (int qs = 0; qs < 4; ++qs) {
-                const int q4 = qb0 + qs * 16 + 4 * g;                       // < SP when qs < nqs
-                f32x4_t l4 = {0.f, 0.f, 0.f, 0.f}, d4 = l4;
-                if (qs < nqs) { l4 = *(const f32x4_t*)(sLse + q4); d4 = *(const f32x4_t*)(sDelta + q4); }
-#pragma unroll
-                for (int kt = 0; kt < 2; ++kt)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const int qr = q4 + r;
-                        float dsv = 0.f, pdv = 0.f;
-                        if (qs < nqs && qr < S && key[kt] < S) {
-                            float s = sacc[kt][qs][r] * sl2;
-                            if (p.mask) s += p.mask[(int64_t)b * p.mask_bs + (int64_t)qr * p.mask_rs + key[kt]] * LOG2E_F;
-                            const float prb = fast_exp2(s - l4[r]);
-                            float dp = pacc[kt][qs][r];
-                            pdv = prb;
-                            if (thr) {
-                                Philox4 rnd = philox4x32_10(p.seed, p.offset + ((uint64_t)(statbase + qr)) * kq4 + (key[kt] >> 2));
-                                const int comp = key[kt] & 3;
-                                const uint32_t rv = comp == 0 ? rnd.v[0] : comp == 1 ? rnd.v[1] : comp == 2 ? rnd.v[2] : rnd.v[3];
-                                const bool keep = rv >= thr;
-                                dp = keep ? dp * keep_scale : 0.f;
-                                pdv = keep ? prb * keep_scale : 0.f;
-                            }
-                            dsv = prb * (dp - d4[r]);
-                        }
-                        pacc[kt][qs][r] = pdv; sacc[kt][qs][r] = dsv;
-                    }
-            }
 #pragma unroll
             for (int kk = 0; kk < 2; ++kk) {
-                if (2 * kk < nqs) {
-                    const bf16x8_t p0 = pack_bf16x8(pacc[0][2 * kk], pacc[0][2 * kk + 1]);
-                    const bf16x8_t p1 = pack_bf16x8(pacc[1][2 * kk], pacc[1][2 * kk + 1]);
-                    const bf16x8_t s0 = pack_bf16x8(sacc[0][2 * kk], sacc[0][2 * kk + 1]);
-                    const bf16x8_t s1 = pack_bf16x8(sacc[1][2 * kk], sacc[1][2 * kk + 1]);
+                if (2 * kk >= nqs) continue;
+                f32x4_t pd[2][2], ds[2][2];      // [kt][q2]
 #pragma unroll
-                    for (int dt = 0; dt < 4; ++dt) {
-                        const bf16x8_t dotf = read_frag_tr_nat(sDO, qb0 + 32 * kk, troff[dt]);   // dO^T[d][q]
-                        const bf16x8_t qtf = read_frag_tr_nat(sQ, qb0 + 32 * kk, troff[dt]);     // Q^T[d][q]
-                        dvacc[0][dt] = Mma<bf16_t>::mma(dotf, p0, dvacc[0][dt]);
-                        dvacc[1][dt] = Mma<bf16_t>::mma(dotf, p1, dvacc[1][dt]);
-                        dkacc[0][dt] = Mma<bf16_t>::mma(qtf, s0, dkacc[0][dt]);
-                        dkacc[1][dt] = Mma<bf16_t>::mma(qtf, s1, dkacc[1][dt]);
+                for (int q2 = 0; q2 < 2; ++q2) {
+                    const int qs = 2 * kk + q2;
+                    f32x4_t sa[2], pa[2];
+                    sa[0] = (f32x4_t){0.f, 0.f, 0.f, 0.f}; sa[1] = sa[0]; pa[0] = sa[0]; pa[1] = sa[0];
+                    f32x4_t l4 = sa[0], d4 = sa[0];
+                    const int q4 = qb0 + qs * 16 + 4 * g;                       // < SP when qs < nqs
+                    if (qs < nqs) {
+#pragma unroll
+                        for (int dg = 0; dg < 2; ++dg) {
+                            const bf16x8_t qfr = read_frag<bf16_t>(sQ, qb0 + qs * 16 + fr, dg * 4 + g);
+                            const bf16x8_t dfr = read_frag<bf16_t>(sDO, qb0 + qs * 16 + fr, dg * 4 + g);
+                            sa[0] = Mma<bf16_t>::mma(qfr, kf[0][dg], sa[0]);
+                            sa[1] = Mma<bf16_t>::mma(qfr, kf[1][dg], sa[1]);
+                            pa[0] = Mma<bf16_t>::mma(dfr, vf[0][dg], pa[0]);
+                            pa[1] = Mma<bf16_t>::mma(dfr, vf[1][dg], pa[1]);
+                        }
+                        l4 = *(const f32x4_t*)(sLse + q4); d4 = *(const f32x4_t*)(sDelta + q4);
                     }
+#pragma unroll
+                    for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const int qr = q4 + r;
+                            float dsv = 0.f, pdv = 0.f;
+                            if (qs < nqs && qr < S && key[kt] < S) {
+                                float sc = sa[kt][r] * sl2;
+                                if (p.mask) sc += p.mask[(int64_t)b * p.mask_bs + (int64_t)qr * p.mask_rs + key[kt]] * LOG2E_F;
+                                const float prb = fast_exp2(sc - l4[r]);
+                                float dp = pa[kt][r];
+                                pdv = prb;
+                                if (DROP) {
+                                    const bool keep = attn_drop_bits(hk, (uint32_t)qr * (uint32_t)p.Skv + (uint32_t)key[kt]) >= thr;
+                                    dp = keep ? dp * keep_scale : 0.f;
+                                    pdv = keep ? prb * keep_scale : 0.f;
+                                }
+                                dsv = prb * (dp - d4[r]);
+                            }
+                            pd[kt][q2][r] = pdv; ds[kt][q2][r] = dsv;
+                        }
+                }
+                const bf16x8_t p0 = pack_bf16x8(pd[0][0], pd[0][1]);
+                const bf16x8_t p1 = pack_bf16x8(pd[1][0], pd[1][1]);
+                const bf16x8_t s0 = pack_bf16x8(ds[0][0], ds[0][1]);
+                const bf16x8_t s1 = pack_bf16x8(ds[1][0], ds[1][1]);
+#pragma unroll
+                for (int dt = 0; dt < 4; ++dt) {
+                    const bf16x8_t dotf = read_frag_tr_nat(sDO, qb0 + 32 * kk, troff[dt]);   // dO^T[d][q]
+                    const bf16x8_t qtf = read_frag_tr_nat(sQ, qb0 + 32 * kk, troff[dt]);     // Q^T[d][q]
+                    dvacc[0][dt] = Mma<bf16_t>::mma(dotf, p0, dvacc[0][dt]);
+                    dvacc[1][dt] = Mma<bf16_t>::mma(dotf, p1, dvacc[1][dt]);
+                    dkacc[0][dt] = Mma<bf16_t>::mma(qtf, s0, dkacc[0][dt]);
+                    dkacc[1][dt] = Mma<bf16_t>::mma(qtf, s1, dkacc[1][dt]);
                 }
             }
         }
@@ -425,10 +414,12 @@ bool attn_res_fwd_launch(hipStream_t st, const AttnArgs& p) {
     const size_t lds = 2 * (size_t)SP * TILE_ROW_BYTES;
     static bool attr_set = false;
     if (!attr_set) {
-        hipFuncSetAttribute((const void*)attn_res_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 256 * TILE_ROW_BYTES);
+        hipFuncSetAttribute((const void*)attn_res_fwd_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 256 * TILE_ROW_BYTES);
+        hipFuncSetAttribute((const void*)attn_res_fwd_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 256 * TILE_ROW_BYTES);
         attr_set = true;
     }
-    hipLaunchKernelGGL(attn_res_fwd_kernel, dim3(p.H, p.B), dim3(256), lds, st, p);
+    if (p.p_drop > 0.f) hipLaunchKernelGGL(attn_res_fwd_kernel<true>, dim3(p.H, p.B), dim3(256), lds, st, p);
+    else hipLaunchKernelGGL(attn_res_fwd_kernel<false>, dim3(p.H, p.B), dim3(256), lds, st, p);
     return true;
 }
 
@@ -440,10 +431,12 @@ bool attn_res_bwd_launch(hipStream_t st, const AttnArgs& p) {
     const size_t lds = 4 * (size_t)SP * TILE_ROW_BYTES + 2 * (size_t)SP * sizeof(float);
     static bool attr_set = false;
     if (!attr_set) {
-        hipFuncSetAttribute((const void*)attn_res_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                            4 * 256 * TILE_ROW_BYTES + 2 * 256 * (int)sizeof(float));
+        const int mx = 4 * 256 * TILE_ROW_BYTES + 2 * 256 * (int)sizeof(float);
+        hipFuncSetAttribute((const void*)attn_res_bwd_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, mx);
+        hipFuncSetAttribute((const void*)attn_res_bwd_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, mx);
         attr_set = true;
     }
-    hipLaunchKernelGGL(attn_res_bwd_kernel, dim3(p.H, p.B), dim3(512), lds, st, p);
+    if (p.p_drop > 0.f) hipLaunchKernelGGL(attn_res_bwd_kernel<true>, dim3(p.H, p.B), dim3(512), lds, st, p);
+    else hipLaunchKernelGGL(attn_res_bwd_kernel<false>, dim3(p.H, p.B), dim3(512), lds, st, p);
     return true;
 }

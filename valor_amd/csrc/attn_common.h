@@ -34,6 +34,31 @@ DEVINL bf16x8_t pack_bf16x8(f32x4_t a, f32x4_t b) {
 }
 
 
+// Dropout decision bits of one attention probability: a 32-bit integer hash of the element's position inside its
+// (batch, head) score matrix, keyed per head.  Per ELEMENT and layout free, so every kernel -- whatever its register
+// layout of the score tile -- regenerates the same mask at the same cost (a 4-wide Philox call only amortises when a
+// lane owns 4 consecutive keys of one query row), and there is no 64-bit arithmetic per element.
+//   hk    = attn_drop_headkey(seed, offset, b*H + h)        once per (batch, head): wave-uniform
+//   bits  = attn_drop_bits(hk, q * Skv + local_key)         keep iff bits >= thr
+DEVINL uint32_t mix32(uint32_t x) {
+    x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
+    return x;
+}
+DEVINL uint32_t attn_drop_headkey(uint64_t seed, uint64_t offset, int head) {
+    uint32_t k = mix32((uint32_t)offset + (uint32_t)head * 0x9E3779B9u);
+    k = mix32(k ^ (uint32_t)(offset >> 32) ^ (uint32_t)seed);
+    return mix32(k + (uint32_t)(seed >> 32));
+}
+DEVINL uint32_t attn_drop_bits(uint32_t hk, uint32_t local) {
+    uint32_t x = mix32(local ^ hk);
+    x += hk;
+    x ^= x >> 15; x *= 0x2c1b3c6du; x ^= x >> 12;
+    return x;
+}
+
 // LDS-resident fast paths (attention_res.hip). Return true if the shape was handled.
 bool attn_res_fwd_launch(hipStream_t st, const AttnArgs& p);
 bool attn_res_bwd_launch(hipStream_t st, const AttnArgs& p);
+// key-stationary cross-attention fast paths (attention_x.hip)
+bool attn_x_fwd_launch(hipStream_t st, const AttnArgs& p);
+bool attn_x_bwd_launch(hipStream_t st, const AttnArgs& p);

@@ -30,8 +30,16 @@ class DropoutState:
 
     @classmethod
     def draw(cls, n_elements):
+        """window for a Philox4x32 stream (4 elements per counter): LayerNorm-side dropout"""
         off = cls.offset
         cls.offset += (int(n_elements) + 3) // 4 + 1
+        return cls.seed, off
+
+    @classmethod
+    def draw_elems(cls, n_elements):
+        """window for the per-element attention hash (one index per probability)"""
+        off = cls.offset
+        cls.offset += int(n_elements) + 1
         return cls.seed, off
 
 
@@ -258,7 +266,7 @@ class SelfAttnFn(Function):
         E = E3 // 3
         seed = off = 0
         if p_drop > 0:
-            seed, off = DropoutState.draw(B * n_heads * S * ((S + 3) // 4) * 4)
+            seed, off = DropoutState.draw_elems(B * n_heads * S * S)
         q, k, v = qkv[:, :, :E], qkv[:, :, E:2 * E], qkv[:, :, 2 * E:]
         o, lse = K.attn_fwd(q, k, v, n_heads, mask=mask, scale=1.0 / math.sqrt(64), p_drop=p_drop, seed=seed, offset=off)
         ctx.save_for_backward(qkv, o, lse, mask)
@@ -290,7 +298,7 @@ class CrossAttnFn(Function):
         B, T, E = q.shape
         seed = off = 0
         if p_drop > 0:
-            seed, off = DropoutState.draw(B * n_heads * T * ((kv.shape[1] + 3) // 4) * 4)
+            seed, off = DropoutState.draw_elems(B * n_heads * T * kv.shape[1])
         k, v = kv[:, :, :E], kv[:, :, E:]
         q = q.contiguous()
         o, lse = K.attn_fwd(q, k, v, n_heads, kv_range=kv_range, kv_bmod=kv_bmod, scale=1.0 / math.sqrt(64),
