@@ -47,8 +47,9 @@ int valor_gemm(void* stream, int dtype, int transA, int transB, int M, int N, in
                const void* dact_aux, int64_t ldaux, float alpha, int accumulate, int out_f32, void* workspace,
                int64_t workspace_bytes);
 
-/* selects the bf16 kernel of valor_gemm: 0 = register-staged tiles, 1 = LDS-DMA (buffer_load ... lds) single stage,
- * 2 = LDS-DMA double stage (default). Returns the previous value; v < 0 only queries. Tuning / A-B measurement hook. */
+/* selects the bf16 kernel of valor_gemm: 0 = register-staged 128x128 tiles, 1 = LDS-DMA (buffer_load ... lds) 128x128
+ * single stage, 2 = LDS-DMA 128x128 double stage, 3 = 256x256 8-phase pipeline wherever eligible, 4 = measured per-shape
+ * policy between 1 and 3 (default). Returns the previous value; v < 0 only queries. Tuning / A-B measurement hook. */
 int valor_gemm_set_variant(int v);
 
 /* ---- fused bias + dropout + residual + LayerNorm.  Replaces apex FusedLayerNorm (apex/csrc/layer_norm_cuda_kernel.cu

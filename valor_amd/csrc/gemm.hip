@@ -20,91 +20,7 @@
 // n of one m: the epilogue works on 8-byte (bf16) / 16-byte (fp32) vectors.
 // Split-K (gridDim.y > 1) writes fp32 partial tiles to a workspace; valor_gemm launches a
 // second kernel that sums the slices and applies the epilogue.
-#include "mma.h"
-
-struct GemmArgs {
-    const void* A; const void* B; void* C;
-    const void* bias;      // [N] (T) or null
-    void* preact;          // [M,N] ldc (T) or null: pre-activation copy (saved for backward)
-    const void* dact_aux;  // [M,N] ldaux (T) or null: multiply result by act'(aux)
-    float* ws;             // split-K partials [S][M][N] fp32
-    int64_t lda, ldb, ldc, ldaux;
-    int M, N, K;
-    int act;
-    int accumulate;        // C += result
-    int out_f32;           // C / preact stored as fp32 regardless of T
-    int kslices;           // split-K factor (gridDim.y)
-    int ksteps_per_slice;
-    float alpha;
-    uint32_t bytesA, bytesB;   // extent of each operand for the buffer-descriptor range check
-};
-
-template <typename T>
-DEVINL f32x4_t load_bias4(const GemmArgs& p, int n0) {
-    f32x4_t b = {0.f, 0.f, 0.f, 0.f};
-    if (p.bias) {
-        const T* q = (const T*)p.bias + n0;
-#pragma unroll
-        for (int r = 0; r < 4; ++r)
-            if (n0 + r < p.N) b[r] = to_f32<T>(q[r]);
-    }
-    return b;
-}
-
-template <typename T>
-DEVINL void epilogue_store(const GemmArgs& p, int m, int n0, f32x4_t acc, f32x4_t bias4) {
-    // 4 consecutive n (n0 .. n0+3) of row m
-    if (m >= p.M || n0 >= p.N) return;
-    const int nvalid = p.N - n0 < 4 ? p.N - n0 : 4;
-    const int64_t off = (int64_t)m * p.ldc + n0;
-    const bool vec = nvalid == 4 && ((p.ldc & 3) == 0);
-    f32x4_t v;
-#pragma unroll
-    for (int r = 0; r < 4; ++r) v[r] = acc[r] * p.alpha + bias4[r];
-    if (p.preact) {
-        if (p.out_f32) {
-            float* q = (float*)p.preact + off;
-            if (vec) *(f32x4_t*)q = v;
-            else for (int r = 0; r < nvalid; ++r) q[r] = v[r];
-        } else {
-            T* q = (T*)p.preact + off;
-            if (vec) store4<T>(q, v);
-            else for (int r = 0; r < nvalid; ++r) q[r] = from_f32<T>(v[r]);
-        }
-    }
-    if (p.act != VALOR_ACT_NONE && !p.dact_aux) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) v[r] = act_fwd(p.act, v[r]);
-    }
-    if (p.dact_aux) {
-        const T* a = (const T*)p.dact_aux + (int64_t)m * p.ldaux + n0;
-        if (vec && (p.ldaux & 3) == 0) {
-            f32x4_t u = load4<T>(a);
-#pragma unroll
-            for (int r = 0; r < 4; ++r) v[r] *= act_bwd(p.act, u[r]);
-        } else {
-            for (int r = 0; r < nvalid; ++r) v[r] *= act_bwd(p.act, to_f32<T>(a[r]));
-        }
-    }
-    if (p.out_f32) {
-        float* c = (float*)p.C + off;
-        if (vec) {
-            if (p.accumulate) { f32x4_t o = *(f32x4_t*)c; v += o; }
-            *(f32x4_t*)c = v;
-        } else {
-            for (int r = 0; r < nvalid; ++r) c[r] = (p.accumulate ? c[r] : 0.f) + v[r];
-        }
-    } else {
-        T* c = (T*)p.C + off;
-        if (vec) {
-            if (p.accumulate) { f32x4_t o = load4<T>(c); v += o; }
-            store4<T>(c, v);
-        } else {
-            for (int r = 0; r < nvalid; ++r)
-                c[r] = from_f32<T>((p.accumulate ? to_f32<T>(c[r]) : 0.f) + v[r]);
-        }
-    }
-}
+#include "gemm_common.h"
 
 template <typename T, bool TA, bool TB>
 __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs p) {
@@ -288,16 +204,15 @@ __global__ __launch_bounds__(256, NSTAGE == 1 ? 4 : 2) void gemm_glds_kernel(Gem
 
     const int tiles_n = (p.N + 127) >> 7;
     const int tiles_m = (p.M + 127) >> 7;
-    // tile / K-slice of this workgroup. Without split-K: XCD-contiguous tile ranges (neighbouring tiles share
-    // operand panels in one L2). With split-K (kslices = 8*s): workgroup b runs on XCD b % 8, and XCD x owns the
-    // K-slices x*s .. x*s+s-1 of EVERY tile, so the tiles of a slice march through k together and each operand
-    // row is fetched from HBM once per XCD-slice instead of once per tile.
+    // tile / K-slice of this workgroup: XCD-contiguous ranges of tiles (no split-K) or of (slice, tile) work items
     int logical, slice = 0;
     if (p.kslices > 1) {
-        const int ntiles = tiles_m * tiles_n, xcd = blockIdx.x & 7, loc = blockIdx.x >> 3;
-        const int sub = loc / ntiles;
-        logical = loc - sub * ntiles;
-        slice = xcd * (p.kslices >> 3) + sub;
+        // work items (K-slice, tile) in slice-major order, a contiguous range per XCD (workgroup b runs on XCD b % 8):
+        // an XCD meets one or two K-slices of every tile, whose tiles march through k together
+        const int ntiles = tiles_m * tiles_n;
+        const int item = xcd_remap(blockIdx.x, ntiles * p.kslices);
+        slice = item / ntiles;
+        logical = item - slice * ntiles;
     } else {
         logical = xcd_remap(blockIdx.x, tiles_m * tiles_n);
     }
@@ -501,8 +416,20 @@ __global__ __launch_bounds__(256) void gemm_splitk_reduce(GemmArgs p) {
 }
 
 // kernel variant of the bf16 path: 0 = register-staged (gemm_kernel), 1 = LDS-DMA single stage, 2 = LDS-DMA double stage
-static int g_gemm_variant = 1;
-extern "C" int valor_gemm_set_variant(int v) { const int o = g_gemm_variant; if (v >= 0 && v <= 2) g_gemm_variant = v; return o; }
+static int g_gemm_variant = 4;
+extern "C" int valor_gemm_set_variant(int v) { const int o = g_gemm_variant; if (v >= 0 && v <= 4) g_gemm_variant = v; return o; }
+// variant 3: 256x256 8-phase kernel (gemm8.hip) wherever eligible, otherwise variant 1.
+// variant 4 (default): measured policy -- the 8-phase kernel for long contractions with both operands in one layout
+//   (wgrad: both k-slow, K = tokens; forward with K >= 1536), the 128x128 kernel (4 workgroups per CU hiding each
+//   other's prologue / epilogue) for short K, small M and the mixed-layout dgrad GEMMs.
+static bool use_8ph(int dtype, int transA, int transB, int M, int N, int K) {
+    if (dtype != VALOR_DT_BF16 || g_gemm_variant < 3) return false;
+    if ((K % 64) != 0 || K < 128 || M < 256 || N < 256) return false;
+    if (g_gemm_variant == 3) return true;
+    if (transA && transB) return K >= 4096;
+    if (!transA && !transB) return K >= 1536 && (int64_t)M * N >= (int64_t)256 * 256 * 512;
+    return false;
+}
 
 template <int NSTAGE>
 static void launch_gemm_glds(hipStream_t st, int transA, int transB, const GemmArgs& p, dim3 grid) {
@@ -529,9 +456,10 @@ static int launch_gemm(hipStream_t st, int transA, int transB, GemmArgs p) {
     const int tiles = ((p.M + 127) / 128) * ((p.N + 127) / 128);
     dim3 grid(tiles, p.kslices > 1 ? p.kslices : 1);
     if (ElemTraits<T>::DT == VALOR_DT_BF16 && g_gemm_variant > 0) {
-        if (p.kslices > 1) grid = dim3(tiles * p.kslices, 1);     // XCD-sliced split-K: 1-D grid, kslices % 8 == 0
-        if (g_gemm_variant == 1) launch_gemm_glds<1>(st, transA, transB, p, grid);
-        else launch_gemm_glds<2>(st, transA, transB, p, grid);
+        if (p.kslices > 1) grid = dim3(tiles * p.kslices, 1);     // split-K: 1-D grid over (slice, tile) work items
+        if (use_8ph(VALOR_DT_BF16, transA, transB, p.M, p.N, p.K)) launch_gemm_8ph(st, transA, transB, p);
+        else if (g_gemm_variant == 2) launch_gemm_glds<2>(st, transA, transB, p, grid);
+        else launch_gemm_glds<1>(st, transA, transB, p, grid);
         if (p.kslices > 1) {
             const int64_t total = (int64_t)p.M * ((p.N + 3) / 4);
             int blocks = (int)((total + 255) / 256);
@@ -606,13 +534,18 @@ extern "C" int valor_gemm(void* stream, int dtype, int transA, int transB, int M
     if (dtype == VALOR_DT_BF16 && g_gemm_variant > 0) {
         // XCD-sliced split-K of the LDS-DMA kernels: 8*s slices, s = sub-slices per XCD chosen to fill (not
         // overflow) the 128 workgroup slots of an XCD (32 CUs x 4); >= 8 K-steps per workgroup.
+        // split-K of the LDS-DMA kernels: as many K-slices as fill -- without overflowing -- ONE round of workgroup
+        // slots (128x128 kernel: 4 per CU = 1024; 256x256 kernel: 1 per CU = 256); >= 8 K-steps per workgroup.
         slices = 1;
-        if (workspace && tiles < 512 && nk >= 64) {
-            int sub = 128 / tiles; if (sub < 1) sub = 1;
-            while (sub > 1 && nk / (8 * sub) < 8) --sub;
-            if (sub > 8) sub = 8;
-            while (sub > 1 && (int64_t)8 * sub * M * N * 4 > workspace_bytes) --sub;
-            if ((int64_t)8 * sub * M * N * 4 <= workspace_bytes) slices = 8 * sub;
+        const bool big = use_8ph(dtype, transA, transB, M, N, K);
+        const int tiles_x = big ? ((M + 255) / 256) * ((N + 255) / 256) : tiles;
+        const int slots = big ? 256 : 1024;
+        if (workspace && 2 * tiles_x <= slots && nk >= 64) {
+            int sl = slots / tiles_x;
+            if (sl > nk / 8) sl = nk / 8;
+            if (sl > 64) sl = 64;
+            while (sl > 1 && (int64_t)sl * M * N * 4 > workspace_bytes) --sl;
+            if (sl >= 2) slices = sl;
         }
         p.kslices = slices;
         p.ksteps_per_slice = (nk + slices - 1) / slices;     // trailing slices may be short or empty (they add zeros)

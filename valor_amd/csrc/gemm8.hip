@@ -1,0 +1,285 @@
+// valor_gemm, bf16, large-tile path: 256x256 tile per 512-thread workgroup (8 waves as 2(M) x 4(N), 128x64 outputs
+// each = 8x4 v_mfma_f32_16x16x32_bf16 tiles, 128 accumulator VGPRs), BK = 64, one workgroup per CU, and an explicit
+// 8-barrier-per-K-tile software pipeline instead of relying on several workgroups per CU to hide each other's loads.
+//
+// Pipeline (per K-tile "c", 4 phases j = 0..3, each phase = a LOAD segment and a MATH segment separated by s_barrier):
+//   LOAD(j): ds_read the register sub-tile(s) of this phase; issue ONE 16 KiB half-tile of LDS-DMA (2 x
+//            buffer_load_dwordx4..lds per wave); s_waitcnt vmcnt(8) (this wave's loads of 4 phases ago have landed);
+//            s_barrier.
+//   MATH(j): 16 MFMAs = one 64x32 quadrant of the wave's 128x64 outputs over K = 64, under s_setprio(1); s_barrier.
+//   quadrants  j0: (A'0,B'0)  j1: (A'0,B'1)  j2: (A'1,B'1)  j3: (A'1,B'0)        (B'0 stays in registers j0 -> j3)
+//   LDS reads  j0: B'0 + A'0 (12 x ds_read_b128)   j1: B'1 (4)   j2: A'1 (8)   j3: none
+//   DMA issue  j0: B'1 of tile c+1   j1: A'1 of c+1   j2: B'0 of c+2   j3: A'0 of c+2
+// The waves of the second wave row (waves 4-7, one per SIMD next to a wave 0-3) run ONE barrier late: while one wave
+// of a SIMD is in MATH(j) its partner is in LOAD, so the matrix pipe always has exactly one issuing wave per SIMD
+// and LDS / DMA issue overlaps the MFMAs of the partner.
+//
+// LDS: 2 K-tile buffers x 4 half-tiles x 16 KiB = 128 KiB. A half-tile is NOT a contiguous half of the tile: "A'0"
+// holds the rows that ALL waves consume in the phases using A'0 (rows 0-63 of both wave rows), B'0 the columns
+// 0-31 of every wave column, etc., so a half-tile's LDS slot is dead -- for every wave -- right after the phase that
+// reads it and can be re-filled two phases later (WAR) for the tile two ahead; its data is waited for 4 phases after
+// issue and read at the earliest 5 phases after issue (RAW: own vmcnt + a barrier every reader has passed).
+// Half-tile images are the two image formats of gemm.hip (XOR image for k-contiguous operands, rotated [64 k][256 B]
+// image + ds_read_b64_tr_b16 for k-slow operands), so all four layouts run on the same schedule.
+//
+// Requirements (otherwise valor_gemm uses the 128x128 kernels): K % 64 == 0.  M/N tails are handled by the buffer
+// range check (zero fill) and masked stores.
+#include "gemm_common.h"
+
+#define HT_BYTES 16384
+#define BUF_BYTES (4 * HT_BYTES)
+#define OFF_A0 0
+#define OFF_A1 HT_BYTES
+#define OFF_B0 (2 * HT_BYTES)
+#define OFF_B1 (3 * HT_BYTES)
+
+DEVINL bf16x8_t read_frag_tr8(const char* img, int off, int kk) {
+    const char* a = img + off + kk * (32 * 256);
+    s16x4_t lo = lds_read_tr4(a), hi = lds_read_tr4(a + 4 * 256);
+    return __builtin_bit_cast(bf16x8_t, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+}
+
+template <bool TA, bool TB>
+__global__ __launch_bounds__(512, 2) void gemm_8ph_kernel(GemmArgs p) {
+    typedef bf16_t T;
+    constexpr int BK = 64;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 2, wn = wave & 3;
+    const int fr = lane & 15, fg = lane >> 4;
+
+    const int tiles_n = (p.N + 255) >> 8;
+    const int tiles_m = (p.M + 255) >> 8;
+    int logical, slice = 0;
+    if (p.kslices > 1) {
+        // work items (K-slice, tile) in slice-major order, a contiguous range per XCD (workgroup b runs on XCD b % 8):
+        // an XCD meets one or two K-slices of every tile, whose tiles march through k together
+        const int ntiles = tiles_m * tiles_n;
+        const int item = xcd_remap(blockIdx.x, ntiles * p.kslices);
+        slice = item / ntiles;
+        logical = item - slice * ntiles;
+    } else {
+        logical = xcd_remap(blockIdx.x, tiles_m * tiles_n);
+    }
+    const int tm = logical / tiles_n, tn = logical - tm * tiles_n;
+    const int m0 = tm << 8, n0 = tn << 8;
+
+    const int nk_total = p.K / BK;
+    int ks_begin = 0, ks_end = nk_total;
+    if (p.kslices > 1) {
+        ks_begin = slice * p.ksteps_per_slice;
+        ks_end = ks_begin + p.ksteps_per_slice;
+        if (ks_end > nk_total) ks_end = nk_total;
+        if (ks_begin > nk_total) ks_begin = nk_total;
+    }
+    const int k_first = ks_begin * BK;
+
+    f32x4_t acc[8][4];   // [mh*4+mt][nh*2+nt]
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+
+    const rsrc_t rsA = make_rsrc(p.A, p.bytesA), rsB = make_rsrc(p.B, p.bytesB);
+    // ---- DMA source offsets: half-tile kinds (A'0, A'1, B'0, B'1) x 2 pieces per wave (piece = wave*2 + i)
+    int voA[2][2], voB[2][2];     // [half][i]
+    int stepA, stepB;
+    {
+        const int ldA_b = (int)(p.lda * 2), ldB_b = (int)(p.ldb * 2);
+#pragma unroll
+        for (int hf = 0; hf < 2; ++hf)
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int pc = wave * 2 + i;
+                if constexpr (!TA) {
+                    const int r = pc * 8 + (lane >> 3), c = (lane & 7) ^ ((lane >> 3) & 7);
+                    const int trow = (r >> 6) * 128 + hf * 64 + (r & 63);
+                    voA[hf][i] = (m0 + trow) * ldA_b + (k_first + c * 8) * 2;
+                } else {
+                    const int k = pc * 4 + (lane >> 4), s = lane & 15;
+                    const int ic = ((s - 2 * (k & 3) - 8 * ((k >> 3) & 1)) & 15) * 8;
+                    const int trow = (ic >> 6) * 128 + hf * 64 + (ic & 63);
+                    voA[hf][i] = (k_first + k) * ldA_b + (m0 + trow) * 2;
+                }
+                if constexpr (!TB) {
+                    const int r = pc * 8 + (lane >> 3), c = (lane & 7) ^ ((lane >> 3) & 7);
+                    const int tcol = (r >> 5) * 64 + hf * 32 + (r & 31);
+                    voB[hf][i] = (n0 + tcol) * ldB_b + (k_first + c * 8) * 2;
+                } else {
+                    const int k = pc * 4 + (lane >> 4), s = lane & 15;
+                    const int ic = ((s - 2 * (k & 3) - 8 * ((k >> 3) & 1)) & 15) * 8;
+                    const int tcol = (ic >> 5) * 64 + hf * 32 + (ic & 31);
+                    voB[hf][i] = (k_first + k) * ldB_b + (n0 + tcol) * 2;
+                }
+            }
+        stepA = TA ? BK * ldA_b : BK * 2;
+        stepB = TB ? BK * ldB_b : BK * 2;
+    }
+    // issue one half-tile (this wave's 2 pieces) into buffer `buf`, then advance that kind to the next K-tile
+    auto issueA = [&](int hf, char* buf) {
+        char* d = buf + (hf ? OFF_A1 : OFF_A0) + wave * 2048;
+        glds16(rsA, d, voA[hf][0]);
+        glds16(rsA, d + 1024, voA[hf][1]);
+        voA[hf][0] += stepA; voA[hf][1] += stepA;
+    };
+    auto issueB = [&](int hf, char* buf) {
+        char* d = buf + (hf ? OFF_B1 : OFF_B0) + wave * 2048;
+        glds16(rsB, d, voB[hf][0]);
+        glds16(rsB, d + 1024, voB[hf][1]);
+        voB[hf][0] += stepB; voB[hf][1] += stepB;
+    };
+
+    // ---- fragment read offsets
+    int trA[4], trB[2];   // k-slow images: byte offset of the 16-row block (A: wm*4 + mt, B: wn*2 + nt)
+    {
+        const int base = (8 * fg + (fr >> 2)) * 256 + 8 * (fr & 1);
+        const int rot = 2 * (fr >> 2) + 8 * (fg & 1);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) trA[i] = base + 16 * ((2 * (wm * 4 + i) + ((fr >> 1) & 1) + rot) & 15);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) trB[i] = base + 16 * ((2 * (wn * 2 + i) + ((fr >> 1) & 1) + rot) & 15);
+    }
+    bf16x8_t fa[4][2], fb0[2][2], fb1[2][2];   // [tile][kk]
+    auto readA = [&](const char* img) {
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) {
+                if constexpr (TA) fa[mt][kk] = read_frag_tr8(img, trA[mt], kk);
+                else fa[mt][kk] = read_frag<T>(img, wm * 64 + mt * 16 + fr, kk * 4 + fg);
+            }
+    };
+    auto readB = [&](const char* img, bf16x8_t (&fb)[2][2]) {
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) {
+                if constexpr (TB) fb[nt][kk] = read_frag_tr8(img, trB[nt], kk);
+                else fb[nt][kk] = read_frag<T>(img, wn * 32 + nt * 16 + fr, kk * 4 + fg);
+            }
+    };
+#define QUADRANT(MH_, NH_, FB_)                                                                                   \
+    do {                                                                                                          \
+        __builtin_amdgcn_s_setprio(1);                                                                            \
+        _Pragma("unroll") for (int kk = 0; kk < 2; ++kk)                                                          \
+            _Pragma("unroll") for (int mt = 0; mt < 4; ++mt)                                                      \
+                _Pragma("unroll") for (int nt = 0; nt < 2; ++nt)                                                  \
+                    acc[(MH_) * 4 + mt][(NH_) * 2 + nt] = Mma<T>::mma(FB_[nt][kk], fa[mt][kk], acc[(MH_) * 4 + mt][(NH_) * 2 + nt]); \
+        __builtin_amdgcn_s_setprio(0);                                                                            \
+    } while (0)
+#define LOAD_END()                                                                                                \
+    do {                                                                                                          \
+        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");                                                          \
+        __builtin_amdgcn_s_barrier();                                                                             \
+        __builtin_amdgcn_sched_barrier(0);                                                                        \
+    } while (0)
+#define MATH_END()                                                                                                \
+    do {                                                                                                          \
+        __builtin_amdgcn_sched_barrier(0);                                                                        \
+        __builtin_amdgcn_s_barrier();                                                                             \
+        __builtin_amdgcn_sched_barrier(0);                                                                        \
+    } while (0)
+
+    char* const buf0 = smem;
+    char* const buf1 = smem + BUF_BYTES;
+    const int ntile = ks_end - ks_begin;
+
+    if (ntile > 0) {
+        // prologue = the virtual phases before tile 0: B'0(0) A'0(0) B'1(0) A'1(0) B'0(1) A'0(1); 4 loads may stay in flight
+        issueB(0, buf0); issueA(0, buf0); issueB(1, buf0); issueA(1, buf0); issueB(0, buf1); issueA(0, buf1);
+        LOAD_END();
+        if (wm == 1) __builtin_amdgcn_s_barrier();      // second wave row runs one barrier late
+        for (int rel = 0; rel < ntile; ++rel) {
+            char* const cur = (rel & 1) ? buf1 : buf0;
+            char* const nxt = (rel & 1) ? buf0 : buf1;
+            // ---- j0
+            readB(cur + OFF_B0, fb0);
+            readA(cur + OFF_A0);
+            issueB(1, nxt);
+            LOAD_END();
+            QUADRANT(0, 0, fb0);
+            MATH_END();
+            // ---- j1
+            readB(cur + OFF_B1, fb1);
+            issueA(1, nxt);
+            LOAD_END();
+            QUADRANT(0, 1, fb1);
+            MATH_END();
+            // ---- j2
+            readA(cur + OFF_A1);
+            issueB(0, cur);
+            LOAD_END();
+            QUADRANT(1, 1, fb1);
+            MATH_END();
+            // ---- j3
+            issueA(0, cur);
+            LOAD_END();
+            QUADRANT(1, 0, fb0);
+            MATH_END();
+        }
+        if (wm == 0) __builtin_amdgcn_s_barrier();
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // drain the look-ahead loads before LDS is reused
+    __syncthreads();
+#undef QUADRANT
+#undef LOAD_END
+#undef MATH_END
+
+    // ---- epilogue: two passes (wave rows) through LDS: 128 rows x 256 cols fp32 (swizzled 16-B chunks) -> row stores
+    float* sC = (float*)smem;
+    float* wsl = p.kslices > 1 ? p.ws + (int64_t)slice * p.M * p.N : nullptr;
+    const f32x4_t bias4 = load_bias4<T>(p, n0 + (tid & 63) * 4);
+#pragma unroll
+    for (int pass = 0; pass < 2; ++pass) {
+        if (pass) __syncthreads();
+        if (wm == pass) {
+#pragma unroll
+            for (int mi = 0; mi < 8; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < 4; ++ni) {
+                    const int ml = mi * 16 + fr;                                  // row inside this wave row
+                    const int ch = (wn * 16 + (ni >> 1) * 8 + (ni & 1) * 4 + fg) ^ (ml & 7);
+                    *(f32x4_t*)(sC + ml * 256 + ch * 4) = acc[mi][ni];
+                }
+        }
+        __syncthreads();
+        for (int it = 0; it < 16; ++it) {
+            const int ml = it * 8 + (tid >> 6);
+            const int cl = tid & 63;
+            const f32x4_t v = *(const f32x4_t*)(sC + ml * 256 + ((cl ^ (ml & 7)) << 2));
+            const int m = m0 + pass * 128 + ml, n = n0 + cl * 4;
+            if (wsl) {
+                if (m < p.M) {
+                    float* q = wsl + (int64_t)m * p.N + n;
+                    if (n + 3 < p.N && (p.N & 3) == 0) *(f32x4_t*)q = v;
+                    else for (int r = 0; r < 4; ++r) if (n + r < p.N) q[r] = v[r];
+                }
+            } else {
+                epilogue_store<T>(p, m, n, v, bias4);
+            }
+        }
+    }
+}
+
+void launch_gemm_8ph(hipStream_t st, int transA, int transB, const GemmArgs& p) {
+    const int tiles = ((p.M + 255) / 256) * ((p.N + 255) / 256);
+    dim3 grid(tiles * (p.kslices > 1 ? p.kslices : 1));
+    const size_t lds = 2 * BUF_BYTES;
+#define VALOR_8PH_LAUNCH(TA_, TB_)                                                                              \
+    do {                                                                                                        \
+        static bool attr_set = false;                                                                           \
+        if (!attr_set) {                                                                                        \
+            hipFuncSetAttribute((const void*)gemm_8ph_kernel<TA_, TB_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+            attr_set = true;                                                                                    \
+        }                                                                                                       \
+        hipLaunchKernelGGL((gemm_8ph_kernel<TA_, TB_>), grid, dim3(512), lds, st, p);                           \
+    } while (0)
+    if (!transA && !transB) VALOR_8PH_LAUNCH(false, false);
+    else if (!transA && transB) VALOR_8PH_LAUNCH(false, true);
+    else if (transA && !transB) VALOR_8PH_LAUNCH(true, false);
+    else VALOR_8PH_LAUNCH(true, true);
+#undef VALOR_8PH_LAUNCH
+}

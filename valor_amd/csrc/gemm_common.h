@@ -1,0 +1,91 @@
+// shared by gemm.hip (128x128 kernels) and gemm8.hip (256x256 8-phase kernel)
+#pragma once
+#include "mma.h"
+
+struct GemmArgs {
+    const void* A; const void* B; void* C;
+    const void* bias;      // [N] (T) or null
+    void* preact;          // [M,N] ldc (T) or null: pre-activation copy (saved for backward)
+    const void* dact_aux;  // [M,N] ldaux (T) or null: multiply result by act'(aux)
+    float* ws;             // split-K partials [S][M][N] fp32
+    int64_t lda, ldb, ldc, ldaux;
+    int M, N, K;
+    int act;
+    int accumulate;        // C += result
+    int out_f32;           // C / preact stored as fp32 regardless of T
+    int kslices;           // split-K factor (gridDim.y)
+    int ksteps_per_slice;
+    float alpha;
+    uint32_t bytesA, bytesB;   // extent of each operand for the buffer-descriptor range check
+};
+
+template <typename T>
+DEVINL f32x4_t load_bias4(const GemmArgs& p, int n0) {
+    f32x4_t b = {0.f, 0.f, 0.f, 0.f};
+    if (p.bias) {
+        const T* q = (const T*)p.bias + n0;
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            if (n0 + r < p.N) b[r] = to_f32<T>(q[r]);
+    }
+    return b;
+}
+
+template <typename T>
+DEVINL void epilogue_store(const GemmArgs& p, int m, int n0, f32x4_t acc, f32x4_t bias4) {
+    // 4 consecutive n (n0 .. n0+3) of row m
+    if (m >= p.M || n0 >= p.N) return;
+    const int nvalid = p.N - n0 < 4 ? p.N - n0 : 4;
+    const int64_t off = (int64_t)m * p.ldc + n0;
+    const bool vec = nvalid == 4 && ((p.ldc & 3) == 0);
+    f32x4_t v;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) v[r] = acc[r] * p.alpha + bias4[r];
+    if (p.preact) {
+        if (p.out_f32) {
+            float* q = (float*)p.preact + off;
+            if (vec) *(f32x4_t*)q = v;
+            else for (int r = 0; r < nvalid; ++r) q[r] = v[r];
+        } else {
+            T* q = (T*)p.preact + off;
+            if (vec) store4<T>(q, v);
+            else for (int r = 0; r < nvalid; ++r) q[r] = from_f32<T>(v[r]);
+        }
+    }
+    if (p.act != VALOR_ACT_NONE && !p.dact_aux) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = act_fwd(p.act, v[r]);
+    }
+    if (p.dact_aux) {
+        const T* a = (const T*)p.dact_aux + (int64_t)m * p.ldaux + n0;
+        if (vec && (p.ldaux & 3) == 0) {
+            f32x4_t u = load4<T>(a);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] *= act_bwd(p.act, u[r]);
+        } else {
+            for (int r = 0; r < nvalid; ++r) v[r] *= act_bwd(p.act, to_f32<T>(a[r]));
+        }
+    }
+    if (p.out_f32) {
+        float* c = (float*)p.C + off;
+        if (vec) {
+            if (p.accumulate) { f32x4_t o = *(f32x4_t*)c; v += o; }
+            *(f32x4_t*)c = v;
+        } else {
+            for (int r = 0; r < nvalid; ++r) c[r] = (p.accumulate ? c[r] : 0.f) + v[r];
+        }
+    } else {
+        T* c = (T*)p.C + off;
+        if (vec) {
+            if (p.accumulate) { f32x4_t o = load4<T>(c); v += o; }
+            store4<T>(c, v);
+        } else {
+            for (int r = 0; r < nvalid; ++r)
+                c[r] = from_f32<T>((p.accumulate ? to_f32<T>(c[r]) : 0.f) + v[r]);
+        }
+    }
+}
+
+
+// 256x256 8-phase bf16 kernel (gemm8.hip). grid.x = tiles(256) * max(kslices, 1).
+void launch_gemm_8ph(hipStream_t st, int transA, int transB, const GemmArgs& p);
