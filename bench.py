@@ -77,29 +77,44 @@ def cpu_baseline(sample_batch=2, frames=8, audio_slices=2):
 
 
 class GemmTimer:
-    """HIP-event timing of every valor_gemm launch on its own stream, grouped by kernel variant."""
+    """HIP-event timing of valor_gemm launches on their own stream, grouped by (kernel family, layout).
+    Every launch bracketed by an event pair would serialise the whole pipeline (an event is a barrier packet; ~1.9k
+    GEMM launches per step), inflating every duration. So only every `stride`-th launch is timed, with a rotating
+    offset per instrumented step; a timed launch carries a few microseconds of event overhead, nothing else changes."""
+    FAMILY = {0: "gemm_kernel(128x128 reg-staged)", 1: "gemm_glds_kernel(128x128 LDS-DMA)", 2: "gemm_glds_kernel(128x128 LDS-DMA x2)",
+              3: "gemm_8ph_kernel(256x256 8-phase)"}
 
-    def __init__(self):
+    def __init__(self, stride=4):
         self.records = []
         self.enabled = False
+        self.stride, self.count, self.phase = stride, 0, 0
 
     def install(self):
-        from valor_amd import kernels as K
+        from valor_amd import kernels as K, lib
+        so = lib.load()
         orig = K.gemm
         timer = self
 
         def timed(a, b, *, trans_a=False, trans_b=False, **kw):
             if not timer.enabled:
                 return orig(a, b, trans_a=trans_a, trans_b=trans_b, **kw)
+            timer.count += 1
+            if (timer.count + timer.phase) % timer.stride:
+                return orig(a, b, trans_a=trans_a, trans_b=trans_b, **kw)
             M, Kd = (a.shape[1], a.shape[0]) if trans_a else (a.shape[0], a.shape[1])
             N = b.shape[1] if trans_b else b.shape[0]
+            fam = so.valor_gemm_kernel_for(0 if a.dtype == torch.bfloat16 else 1, int(trans_a), int(trans_b), M, N, Kd)
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
             r = orig(a, b, trans_a=trans_a, trans_b=trans_b, **kw)
             e1.record()
-            timer.records.append((("T" if trans_a else "N") + ("T" if trans_b else "N"), 2.0 * M * N * Kd, e0, e1))
+            timer.records.append(((fam, ("T" if trans_a else "N") + ("T" if trans_b else "N")), 2.0 * M * N * Kd, e0, e1))
             return r
         K.gemm = timed
+
+    def next_step(self):
+        self.phase += 1
+        self.count = 0
 
     def summary(self):
         agg = {}
@@ -167,15 +182,16 @@ def main():
         last = engine.train_step(batch, TASK)
     sync()
     elapsed = time.perf_counter() - t0
-    # roofline pass: the SAME step, run right after the timed region with one HIP-event pair around every
-    # valor_gemm launch (recorded on the launch stream). Kept out of the timed region because ~5.6k timing
-    # events per step insert queue markers that cost ~10 % of the step.
+    # roofline pass: the SAME step, run right after the timed region, with a HIP-event pair (recorded on the launch
+    # stream) around every 4th valor_gemm launch; 4 instrumented steps with a rotating offset cover every launch once.
     timer.enabled = True
+    n_inst = 4
     t1 = time.perf_counter()
-    for _ in range(min(args.steps, 2)):
+    for _ in range(n_inst):
         engine.train_step(batch, TASK)
+        timer.next_step()
     sync()
-    inst_elapsed = (time.perf_counter() - t1) / min(args.steps, 2)
+    inst_elapsed = (time.perf_counter() - t1) / n_inst
     timer.enabled = False
     t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
     if world > 1:
@@ -190,15 +206,19 @@ def main():
         nf = necessary_flops_per_sample(spec, args.frames, args.audio_slices, 32)
         roof = None
         if dom:
-            names = {"NN": "gemm_kernel<bf16,false,false> (forward x.W^T)", "NT": "gemm_kernel<bf16,false,true> (dgrad dY.W)",
-                     "TT": "gemm_kernel<bf16,true,true> (wgrad dY^T.X)", "TN": "gemm_kernel<bf16,true,false>"}
-            roof = {"bound": "mfma", "kernel": names[dom], "achieved": round(gs[dom]["TFLOPs"], 1), "peak": PEAK_BF16_TFLOPS,
+            layout = {"NN": "forward x.W^T", "NT": "dgrad dY.W", "TT": "wgrad dY^T.X", "TN": "A^T.B^T"}
+            name = lambda v: f"{GemmTimer.FAMILY[v[0]]} {v[1]} ({layout[v[1]]})"
+            tot_f, tot_s = sum(d["flops"] for d in gs.values()), sum(d["seconds"] for d in gs.values())
+            roof = {"bound": "mfma", "kernel": name(dom), "achieved": round(gs[dom]["TFLOPs"], 1), "peak": PEAK_BF16_TFLOPS,
                     "unit": "TFLOP/s", "frac": round(gs[dom]["TFLOPs"] / PEAK_BF16_TFLOPS, 4), "traffic": None,
-                    "avg_launch_us": round(gs[dom]["avg_us"], 1), "launches": gs[dom]["launches"],
-                    "all_gemm_variants": {v: {"TFLOPs": round(d["TFLOPs"], 1), "avg_us": round(d["avg_us"], 1), "launches": d["launches"],
-                                              "share_of_step_time": round(d["seconds"] / (inst_elapsed * min(args.steps, 2)), 3)} for v, d in gs.items()},
-                    "measured": "HIP events around every valor_gemm launch in %d instrumented step(s) run right after the timed region "
-                                "(instrumented step %.1f ms)" % (min(args.steps, 2), inst_elapsed * 1e3),
+                    "avg_launch_us": round(gs[dom]["avg_us"], 1), "launches_per_step": gs[dom]["launches"],
+                    "all_gemm_kernels": {name(v): {"TFLOPs": round(d["TFLOPs"], 1), "avg_us": round(d["avg_us"], 1), "launches_per_step": d["launches"],
+                                                   "share_of_step_time": round(d["seconds"] / inst_elapsed, 3)} for v, d in sorted(gs.items(), key=lambda kv: -kv[1]["seconds"])},
+                    "all_gemms": {"TFLOPs": round(tot_f / tot_s / 1e12, 1), "frac": round(tot_f / tot_s / 1e12 / PEAK_BF16_TFLOPS, 4),
+                                  "share_of_step_time": round(tot_s / inst_elapsed, 3)},
+                    "measured": "algorithmic 2MNK FLOP / HIP-event duration, one event pair (on the launch stream) around every 4th valor_gemm "
+                                "launch in %d instrumented steps with rotating offset run right after the timed region (each launch of a step "
+                                "timed once; instrumented step %.1f ms)" % (n_inst, inst_elapsed * 1e3),
                     "step_mfu": round(nf * sps / world / 1e12 / PEAK_BF16_TFLOPS, 4),
                     "necessary_gflop_per_sample": round(nf / 1e9, 1)}
         res = {"metric": "pretrain samples/sec (V+A+T clip)", "value": round(sps, 2), "unit": "samples/s", "n_gpus": world,

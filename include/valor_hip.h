@@ -51,6 +51,9 @@ int valor_gemm(void* stream, int dtype, int transA, int transB, int M, int N, in
  * single stage, 2 = LDS-DMA 128x128 double stage, 3 = 256x256 8-phase pipeline wherever eligible, 4 = measured per-shape
  * policy between 1 and 3 (default). Returns the previous value; v < 0 only queries. Tuning / A-B measurement hook. */
 int valor_gemm_set_variant(int v);
+/* kernel family valor_gemm picks for a problem under the current variant: 0 = register-staged 128x128 (and every fp32
+ * problem), 1 / 2 = LDS-DMA 128x128 single / double stage, 3 = 256x256 8-phase */
+int valor_gemm_kernel_for(int dtype, int transA, int transB, int M, int N, int K);
 
 /* ---- fused bias + dropout + residual + LayerNorm.  Replaces apex FusedLayerNorm (apex/csrc/layer_norm_cuda_kernel.cu
  * :279-322 forward, :403-634 backward; wrapper apex/apex/normalization/fused_layer_norm.py:14-37) plus the elementwise ops

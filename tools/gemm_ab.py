@@ -80,6 +80,27 @@ SHAPES = [
     ("dec_fc1_wgrad", 3072, 768, 3 * b * 32, 1, 1),
     ("head_decoder", 2400, 30522, 768, 0, 0),
 ]
+SMALL = [
+    ("dec_qkv_fwd", 6144, 2304, 768, 0, 0),
+    ("dec_proj_fwd", 6144, 768, 768, 0, 0),
+    ("dec_fc2_fwd", 6144, 768, 3072, 0, 0),
+    ("mlm_proj_fwd", 2688, 768, 768, 0, 0),
+    ("mlm_fc1_fwd", 2688, 3072, 768, 0, 0),
+    ("mlm_fc2_fwd", 2688, 768, 3072, 0, 0),
+    ("dec_proj_dgrad", 6144, 768, 768, 0, 1),
+    ("dec_fc1_dgrad", 6144, 768, 3072, 0, 1),
+    ("dec_fc2_dgrad", 6144, 3072, 768, 0, 1),
+    ("mlm_fc2_dgrad", 2688, 3072, 768, 0, 1),
+    ("dec_proj_wgrad", 768, 768, 6144, 1, 1),
+    ("dec_fc1_wgrad", 3072, 768, 6144, 1, 1),
+    ("mlm_proj_wgrad", 768, 768, 2688, 1, 1),
+    ("mlm_fc1_wgrad", 3072, 768, 2688, 1, 1),
+    ("txt_qkv_fwd", 2048, 1536, 512, 0, 0),
+    ("ast_proj_fwd", 16512, 768, 768, 0, 0),
+    ("ast_fc2_dgrad", 16512, 3072, 768, 0, 1),
+]
+if len(sys.argv) > 3 and sys.argv[3] == "small":
+    SHAPES = SMALL
 
 
 def bench(rounds=3, n=8):

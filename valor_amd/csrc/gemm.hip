@@ -364,7 +364,6 @@ __global__ __launch_bounds__(256, NSTAGE == 1 ? 4 : 2) void gemm_glds_kernel(Gem
     constexpr int EPI_ROWS = NSTAGE == 1 ? 64 : 128;
     float* sC = (float*)smem;
     float* wsl = p.kslices > 1 ? p.ws + (int64_t)slice * p.M * p.N : nullptr;
-    const f32x4_t bias4 = load_bias4<T>(p, n0 + (tid & 31) * 4);
 #pragma unroll
     for (int pass = 0; pass < 128 / EPI_ROWS; ++pass) {
         if (pass) __syncthreads();
@@ -379,19 +378,21 @@ __global__ __launch_bounds__(256, NSTAGE == 1 ? 4 : 2) void gemm_glds_kernel(Gem
                 }
         }
         __syncthreads();
-        for (int it = 0; it < EPI_ROWS / 8; ++it) {
-            const int ml = it * 8 + (tid >> 5);
-            const int cl = tid & 31;
-            const f32x4_t v = *(const f32x4_t*)(sC + ml * 128 + ((cl ^ (ml & 7)) << 2));
-            const int m = m0 + pass * EPI_ROWS + ml, n = n0 + cl * 4;
+#pragma unroll 1
+        for (int it = 0; it < EPI_ROWS / 16; ++it) {       // 16 lanes x 8 columns per row: 16-byte bf16 stores
+            const int ml = it * 16 + (tid >> 4);
+            const int c8 = tid & 15;
+            const f32x4_t v0 = *(const f32x4_t*)(sC + ml * 128 + (((2 * c8) ^ (ml & 7)) << 2));
+            const f32x4_t v1 = *(const f32x4_t*)(sC + ml * 128 + (((2 * c8 + 1) ^ (ml & 7)) << 2));
+            const int m = m0 + pass * EPI_ROWS + ml, n = n0 + c8 * 8;
             if (wsl) {
                 if (m < p.M) {
                     float* q = wsl + (int64_t)m * p.N + n;
-                    if (n + 3 < p.N && (p.N & 3) == 0) *(f32x4_t*)q = v;
-                    else for (int r = 0; r < 4; ++r) if (n + r < p.N) q[r] = v[r];
+                    if (n + 7 < p.N && (p.N & 3) == 0) { *(f32x4_t*)q = v0; *(f32x4_t*)(q + 4) = v1; }
+                    else for (int r = 0; r < 8; ++r) if (n + r < p.N) q[r] = r < 4 ? v0[r] : v1[r - 4];
                 }
             } else {
-                epilogue_store<T>(p, m, n, v, bias4);
+                epilogue_store8(p, m, n, v0, v1, load_bias4<T>(p, n), load_bias4<T>(p, n + 4));
             }
         }
     }
@@ -419,16 +420,26 @@ __global__ __launch_bounds__(256) void gemm_splitk_reduce(GemmArgs p) {
 static int g_gemm_variant = 4;
 extern "C" int valor_gemm_set_variant(int v) { const int o = g_gemm_variant; if (v >= 0 && v <= 4) g_gemm_variant = v; return o; }
 // variant 3: 256x256 8-phase kernel (gemm8.hip) wherever eligible, otherwise variant 1.
-// variant 4 (default): measured policy -- the 8-phase kernel for long contractions with both operands in one layout
-//   (wgrad: both k-slow, K = tokens; forward with K >= 1536), the 128x128 kernel (4 workgroups per CU hiding each
-//   other's prologue / epilogue) for short K, small M and the mixed-layout dgrad GEMMs.
+// variant 4 (default): measured policy (tools/gemm_ab.py, profiles/r01_gemm_variants_*.json) -- the 8-phase kernel for
+//   the big-M forward GEMMs, long-K dgrad and the wgrad GEMMs; the 128x128 kernel (4 workgroups per CU hiding each
+//   other's prologue / epilogue) for small grids, short-K dgrad and everything with a K tail.
 static bool use_8ph(int dtype, int transA, int transB, int M, int N, int K) {
     if (dtype != VALOR_DT_BF16 || g_gemm_variant < 3) return false;
     if ((K % 64) != 0 || K < 128 || M < 256 || N < 256) return false;
     if (g_gemm_variant == 3) return true;
-    if (transA && transB) return K >= 4096;
-    if (!transA && !transB) return K >= 1536 && (int64_t)M * N >= (int64_t)256 * 256 * 512;
+    const int64_t tiles256 = (int64_t)((M + 255) / 256) * ((N + 255) / 256);
+    if (transA && transB) return K >= 4096;                           // wgrad: K = tokens, split-K fills one round
+    if (!transA && !transB) return tiles256 >= 1024 && K >= 512;      // forward: >= 4 rounds of 256 workgroups
+    if (!transA && transB) return tiles256 >= 1024 && K >= 1536;      // dgrad: the 128x128 kernel wins at K = 768
     return false;
+}
+
+// which kernel family valor_gemm uses for a problem: 0 = register-staged 128x128 (also all fp32), 1 / 2 = LDS-DMA 128x128
+// single / double stage, 3 = 256x256 8-phase.  (bench.py groups its roofline numbers by this.)
+extern "C" int valor_gemm_kernel_for(int dtype, int transA, int transB, int M, int N, int K) {
+    if (dtype != VALOR_DT_BF16 || g_gemm_variant == 0) return 0;
+    if (use_8ph(dtype, transA, transB, M, N, K)) return 3;
+    return g_gemm_variant == 2 ? 2 : 1;
 }
 
 template <int NSTAGE>
@@ -535,14 +546,14 @@ extern "C" int valor_gemm(void* stream, int dtype, int transA, int transB, int M
         // XCD-sliced split-K of the LDS-DMA kernels: 8*s slices, s = sub-slices per XCD chosen to fill (not
         // overflow) the 128 workgroup slots of an XCD (32 CUs x 4); >= 8 K-steps per workgroup.
         // split-K of the LDS-DMA kernels: as many K-slices as fill -- without overflowing -- ONE round of workgroup
-        // slots (128x128 kernel: 4 per CU = 1024; 256x256 kernel: 1 per CU = 256); >= 8 K-steps per workgroup.
+        // slots (128x128 kernel: 4 per CU = 1024; 256x256 kernel: 1 per CU = 256); >= 6 K-steps per workgroup.
         slices = 1;
         const bool big = use_8ph(dtype, transA, transB, M, N, K);
         const int tiles_x = big ? ((M + 255) / 256) * ((N + 255) / 256) : tiles;
         const int slots = big ? 256 : 1024;
-        if (workspace && 2 * tiles_x <= slots && nk >= 64) {
+        if (workspace && 2 * tiles_x <= slots && nk >= 24) {
             int sl = slots / tiles_x;
-            if (sl > nk / 8) sl = nk / 8;
+            if (sl > nk / 6) sl = nk / 6;
             if (sl > 64) sl = 64;
             while (sl > 1 && (int64_t)sl * M * N * 4 > workspace_bytes) --sl;
             if (sl >= 2) slices = sl;

@@ -14,11 +14,15 @@
 // of a SIMD is in MATH(j) its partner is in LOAD, so the matrix pipe always has exactly one issuing wave per SIMD
 // and LDS / DMA issue overlaps the MFMAs of the partner.
 //
-// LDS: 2 K-tile buffers x 4 half-tiles x 16 KiB = 128 KiB. A half-tile is NOT a contiguous half of the tile: "A'0"
-// holds the rows that ALL waves consume in the phases using A'0 (rows 0-63 of both wave rows), B'0 the columns
-// 0-31 of every wave column, etc., so a half-tile's LDS slot is dead -- for every wave -- right after the phase that
-// reads it and can be re-filled two phases later (WAR) for the tile two ahead; its data is waited for 4 phases after
-// issue and read at the earliest 5 phases after issue (RAW: own vmcnt + a barrier every reader has passed).
+// LDS: 2 K-tile buffers x 4 half-tiles x 16 KiB = 128 KiB. Half-tile A'h = tile rows [128h, 128h+128), B'h = tile
+// columns [128h, 128h+128) (contiguous, so every DMA segment is a full 128-B / 256-B line). The WAVE owns a
+// non-contiguous output set instead: rows {128*mh + 64*wm + [0,64)}, columns {128*nh + 32*wn + [0,32)}, i.e. its four
+// quadrants (mh, nh) live in the four (A'mh, B'nh) combinations. So a half-tile is consumed by ALL waves in the same
+// phase, its LDS slot is dead right after that phase and is re-filled two or three phases later (WAR) for the tile
+// two ahead; its data is waited for 4 phases after issue and read at the earliest 5 phases after issue (RAW: own
+// vmcnt + a barrier every reader has passed).
+// (A persistent variant with DMA look-ahead across tiles and a start skew was built and measured SLOWER: the per-tile
+// fixed cost is the epilogue itself -- ~10k cycles of store issue + ~13k of LDS staging -- not the prologue.)
 // Half-tile images are the two image formats of gemm.hip (XOR image for k-contiguous operands, rotated [64 k][256 B]
 // image + ds_read_b64_tr_b16 for k-slow operands), so all four layouts run on the same schedule.
 //
@@ -96,22 +100,22 @@ __global__ __launch_bounds__(512, 2) void gemm_8ph_kernel(GemmArgs p) {
                 const int pc = wave * 2 + i;
                 if constexpr (!TA) {
                     const int r = pc * 8 + (lane >> 3), c = (lane & 7) ^ ((lane >> 3) & 7);
-                    const int trow = (r >> 6) * 128 + hf * 64 + (r & 63);
+                    const int trow = hf * 128 + r;
                     voA[hf][i] = (m0 + trow) * ldA_b + (k_first + c * 8) * 2;
                 } else {
                     const int k = pc * 4 + (lane >> 4), s = lane & 15;
                     const int ic = ((s - 2 * (k & 3) - 8 * ((k >> 3) & 1)) & 15) * 8;
-                    const int trow = (ic >> 6) * 128 + hf * 64 + (ic & 63);
+                    const int trow = hf * 128 + ic;
                     voA[hf][i] = (k_first + k) * ldA_b + (m0 + trow) * 2;
                 }
                 if constexpr (!TB) {
                     const int r = pc * 8 + (lane >> 3), c = (lane & 7) ^ ((lane >> 3) & 7);
-                    const int tcol = (r >> 5) * 64 + hf * 32 + (r & 31);
+                    const int tcol = hf * 128 + r;
                     voB[hf][i] = (n0 + tcol) * ldB_b + (k_first + c * 8) * 2;
                 } else {
                     const int k = pc * 4 + (lane >> 4), s = lane & 15;
                     const int ic = ((s - 2 * (k & 3) - 8 * ((k >> 3) & 1)) & 15) * 8;
-                    const int tcol = (ic >> 5) * 64 + hf * 32 + (ic & 31);
+                    const int tcol = hf * 128 + ic;
                     voB[hf][i] = (k_first + k) * ldB_b + (n0 + tcol) * 2;
                 }
             }
@@ -228,37 +232,39 @@ __global__ __launch_bounds__(512, 2) void gemm_8ph_kernel(GemmArgs p) {
 #undef LOAD_END
 #undef MATH_END
 
-    // ---- epilogue: two passes (wave rows) through LDS: 128 rows x 256 cols fp32 (swizzled 16-B chunks) -> row stores
+    // ---- epilogue: two passes (tile row halves mh) through LDS: 128 rows x 256 cols fp32 (swizzled 16-B chunks) ->
+    // row-contiguous 16-byte bf16 stores.
+    // acc[mh*4+mt][nh*2+nt][r] = C[mh*128 + wm*64 + mt*16 + fr][nh*128 + wn*32 + nt*16 + 4*fg + r]
     float* sC = (float*)smem;
     float* wsl = p.kslices > 1 ? p.ws + (int64_t)slice * p.M * p.N : nullptr;
-    const f32x4_t bias4 = load_bias4<T>(p, n0 + (tid & 63) * 4);
+    const f32x4_t bias0 = load_bias4<T>(p, n0 + (tid & 31) * 8), bias1 = load_bias4<T>(p, n0 + (tid & 31) * 8 + 4);
 #pragma unroll
     for (int pass = 0; pass < 2; ++pass) {
         if (pass) __syncthreads();
-        if (wm == pass) {
 #pragma unroll
-            for (int mi = 0; mi < 8; ++mi)
+        for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
-                for (int ni = 0; ni < 4; ++ni) {
-                    const int ml = mi * 16 + fr;                                  // row inside this wave row
-                    const int ch = (wn * 16 + (ni >> 1) * 8 + (ni & 1) * 4 + fg) ^ (ml & 7);
-                    *(f32x4_t*)(sC + ml * 256 + ch * 4) = acc[mi][ni];
-                }
-        }
+            for (int ni = 0; ni < 4; ++ni) {
+                const int ml = wm * 64 + mt * 16 + fr;                        // row inside this 128-row half
+                const int ch = ((ni >> 1) * 32 + wn * 8 + (ni & 1) * 4 + fg) ^ (ml & 7);
+                *(f32x4_t*)(sC + ml * 256 + ch * 4) = acc[pass * 4 + mt][ni];
+            }
         __syncthreads();
-        for (int it = 0; it < 16; ++it) {
-            const int ml = it * 8 + (tid >> 6);
-            const int cl = tid & 63;
-            const f32x4_t v = *(const f32x4_t*)(sC + ml * 256 + ((cl ^ (ml & 7)) << 2));
-            const int m = m0 + pass * 128 + ml, n = n0 + cl * 4;
+#pragma unroll 2
+        for (int it = 0; it < 8; ++it) {
+            const int ml = it * 16 + (tid >> 5);
+            const int c8 = tid & 31;                                   // 8 columns = fp32 chunks 2*c8, 2*c8+1
+            const f32x4_t v0 = *(const f32x4_t*)(sC + ml * 256 + (((2 * c8) ^ (ml & 7)) << 2));
+            const f32x4_t v1 = *(const f32x4_t*)(sC + ml * 256 + (((2 * c8 + 1) ^ (ml & 7)) << 2));
+            const int m = m0 + pass * 128 + ml, n = n0 + c8 * 8;
             if (wsl) {
                 if (m < p.M) {
-                    float* q = wsl + (int64_t)m * p.N + n;
-                    if (n + 3 < p.N && (p.N & 3) == 0) *(f32x4_t*)q = v;
-                    else for (int r = 0; r < 4; ++r) if (n + r < p.N) q[r] = v[r];
+                    float* qq = wsl + (int64_t)m * p.N + n;
+                    if (n + 7 < p.N && (p.N & 3) == 0) { *(f32x4_t*)qq = v0; *(f32x4_t*)(qq + 4) = v1; }
+                    else for (int r = 0; r < 8; ++r) if (n + r < p.N) qq[r] = r < 4 ? v0[r] : v1[r - 4];
                 }
             } else {
-                epilogue_store<T>(p, m, n, v, bias4);
+                epilogue_store8(p, m, n, v0, v1, bias0, bias1);
             }
         }
     }

@@ -87,5 +87,40 @@ DEVINL void epilogue_store(const GemmArgs& p, int m, int n0, f32x4_t acc, f32x4_
 }
 
 
+// 8 consecutive n (n0 .. n0+7) of row m, bf16 only: one 16-byte store per lane (the epilogue is store-ISSUE bound:
+// half as many, twice as wide store instructions). Falls back to two 4-wide stores on tails / odd leading dims.
+DEVINL void epilogue_store8(const GemmArgs& p, int m, int n0, f32x4_t a0, f32x4_t a1, f32x4_t b0, f32x4_t b1) {
+    typedef bf16_t T;
+    if (m >= p.M || n0 >= p.N) return;
+    const bool vec8 = n0 + 8 <= p.N && (p.ldc & 7) == 0 && !p.out_f32 && (!p.dact_aux || (p.ldaux & 7) == 0);
+    if (!vec8) {
+        epilogue_store<T>(p, m, n0, a0, b0);
+        epilogue_store<T>(p, m, n0 + 4, a1, b1);
+        return;
+    }
+    const int64_t off = (int64_t)m * p.ldc + n0;
+    f32x4_t v0, v1;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { v0[r] = a0[r] * p.alpha + b0[r]; v1[r] = a1[r] * p.alpha + b1[r]; }
+    if (p.preact) {
+        u32x4_t q = {pack2_bf16(v0[0], v0[1]), pack2_bf16(v0[2], v0[3]), pack2_bf16(v1[0], v1[1]), pack2_bf16(v1[2], v1[3])};
+        *(u32x4_t*)((T*)p.preact + off) = q;
+    }
+    if (p.act != VALOR_ACT_NONE && !p.dact_aux) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { v0[r] = act_fwd(p.act, v0[r]); v1[r] = act_fwd(p.act, v1[r]); }
+    }
+    if (p.dact_aux) {
+        const T* a = (const T*)p.dact_aux + (int64_t)m * p.ldaux + n0;
+        const f32x4_t u0 = load4<T>(a), u1 = load4<T>(a + 4);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { v0[r] *= act_bwd(p.act, u0[r]); v1[r] *= act_bwd(p.act, u1[r]); }
+    }
+    T* c = (T*)p.C + off;
+    if (p.accumulate) { v0 += load4<T>(c); v1 += load4<T>(c + 4); }
+    u32x4_t o = {pack2_bf16(v0[0], v0[1]), pack2_bf16(v0[2], v0[3]), pack2_bf16(v1[0], v1[1]), pack2_bf16(v1[2], v1[3])};
+    *(u32x4_t*)c = o;
+}
+
 // 256x256 8-phase bf16 kernel (gemm8.hip). grid.x = tiles(256) * max(kslices, 1).
 void launch_gemm_8ph(hipStream_t st, int transA, int transB, const GemmArgs& p);

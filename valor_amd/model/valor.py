@@ -28,6 +28,7 @@ from torch import nn
 
 from .. import ops
 from ..arena import ParamArena
+from ..hoststage import HostStage
 from ..lib import ACT_GELU_ERF, ACT_QUICK_GELU, ACT_RELU
 from ..synth import ValorSpec, base_spec, synthetic_vocab
 from .params import optimizer_group, param_table
@@ -113,6 +114,8 @@ class VALOR(nn.Module):
         self.bos_token, self.eos_token, self.text_mask_token = self.vocab["[CLS]"], self.vocab["[SEP]"], self.vocab["[MASK]"]
         self.text_masker = TokenMasker(self.text_mask_token, 106, self.spec.vocab)     # modeling.py:673
         self.reducer = None
+        self.stage = HostStage(self.device)
+        self._const = {}
         self.gather_fn = None          # set by valor_amd.dist for world_size > 1
         self.collect = None            # optional dict: intermediate tensors for parity tests
 
@@ -188,29 +191,39 @@ class VALOR(nn.Module):
 
     @staticmethod
     def _bert_mask(tokens_cpu, prompt_cpu, casual):
-        """additive attention mask of BertModel.forward, bert.py:854-885 -> fp32 [B, T, T]"""
-        am = (tokens_cpu != 0).long()
+        """additive attention mask of BertModel.forward, bert.py:854-885 -> fp32 [B, T, T].
+        numpy on purpose: these are tiny tensors and a torch CPU op would wake the whole intra-op thread pool."""
+        am = (tokens_cpu.numpy() != 0).astype(np.int64)
         token_len = am.shape[1]
         if prompt_cpu is not None:
-            am = torch.cat((am, (prompt_cpu != 0).long()), dim=1)
+            am = np.concatenate((am, (prompt_cpu.numpy() != 0).astype(np.int64)), axis=1)
         total = am.shape[1]
-        am = am.unsqueeze(1).expand(-1, total, -1).clone()
+        am = np.repeat(am[:, None, :], total, axis=1)
         if casual:
-            am[:, :token_len, :token_len] = torch.tril(am[:, :token_len, :token_len])
+            am[:, :token_len, :token_len] = np.tril(am[:, :token_len, :token_len])
             am[:, token_len:, :token_len] = 0
-        return ((1.0 - am.float()) * -10000.0).contiguous()
+        return torch.from_numpy(((1.0 - am.astype(np.float32)) * -10000.0).astype(np.float32))
 
     @staticmethod
     def _clip_text_mask(tokens_cpu):
         """clip.py:382-414 with casual=True -> fp32 [B, L, L]"""
-        L = tokens_cpu.shape[1]
-        m = (tokens_cpu != 0).long().unsqueeze(1).expand(-1, L, -1).clone()
-        m = torch.tril(m)
-        return ((1.0 - m.float()) * -10000.0).contiguous()
+        m = (tokens_cpu.numpy() != 0).astype(np.int64)
+        L = m.shape[1]
+        m = np.tril(np.repeat(m[:, None, :], L, axis=1))
+        return torch.from_numpy(((1.0 - m.astype(np.float32)) * -10000.0).astype(np.float32))
 
     def _dev(self, t, dtype=None):
-        t = t.to(self.device, non_blocking=True)
-        return t.to(dtype) if dtype is not None else t
+        """host tensor -> device through the pinned staging ring (asynchronous); device tensors pass through."""
+        return self.stage.put(t, dtype)
+
+    def _const_idx(self, n, stride):
+        """cached device tensor arange(n) * stride (cls-token row indices)"""
+        key = (n, stride)
+        t = self._const.get(key)
+        if t is None:
+            t = (torch.arange(n) * stride).to(self.device)
+            self._const[key] = t
+        return t
 
     # ------------------------------------------------------------------ encoders
     def _clip_blocks(self, x, prefix, n_layers, heads, mask, final_g, final_b):
@@ -344,16 +357,16 @@ class VALOR(nn.Module):
             mask = mask.repeat(G, 1, 1)
         kv_range = None
         if kv_layers is not None:
-            kv_range = torch.tensor([list(ranges[g]) for g in groups for _ in range(b)], dtype=torch.int32).to(self.device)
+            kv_range = self._dev(torch.tensor([list(ranges[g]) for g in groups for _ in range(b)], dtype=torch.int32))
         hidden = self.bert_encoder(x, mask, kv_layers, kv_range, b if kv_layers is not None else 0)
         sel = (txt_labels != -1)
         bi, tj = sel.nonzero(as_tuple=True)                      # host tensors, row-major order == boolean indexing order
         n = bi.numel()
-        idx = torch.cat([(g * b + bi) * Ttot + tj for g in range(G)]).to(self.device)
+        idx = self._dev(torch.cat([(g * b + bi) * Ttot + tj for g in range(G)]))
         rows = ops.gather_rows(hidden.reshape(-1, hidden.shape[-1]), idx)
         h = self.cls_transform(rows)
         P = self.P
-        labels = txt_labels[sel].repeat(G).to(self.device)
+        labels = self._dev(txt_labels[sel].repeat(G))
         if compute_loss:
             # equal row counts per group: the mean over all G*n rows == mean of the per-group means (pretrain.py:473-479)
             return ops.decoder_xent(h, P["multimodal_encoder.embeddings.word_embeddings.weight"], P["cls.decoder.bias"], labels)
@@ -371,6 +384,7 @@ class VALOR(nn.Module):
     def forward_pt(self, batch, task, compute_loss=True):
         """VALOR.forward_pt, model/pretrain.py:214-541."""
         P, sp = self.P, self.spec
+        self.stage.begin_step()
         mlm_task, caption_task, contra_task = [], [], []
         for i in task.split("_"):
             if "mlm" in i:
@@ -403,12 +417,12 @@ class VALOR(nn.Module):
                 tok_contra = clip_tokens
             if "v" in "".join(contra_task):
                 b, F = video_output.shape[:2]
-                idx = (torch.arange(b * F) * sp.vis_tokens).to(self.device)
+                idx = self._const_idx(b * F, sp.vis_tokens)
                 cls_v = ops.gather_rows(video_output.reshape(-1, sp.vis_width), idx)
                 feat_v = ops.l2_normalize(ops.linear(cls_v, P["clip_model.visual.proj"], None, w_is_kn=True)).view(b, F, -1)
             if "a" in "".join(contra_task):
                 b, A = audio_output.shape[:2]
-                idx = (torch.arange(b * A) * sp.aud_tokens).to(self.device)
+                idx = self._const_idx(b * A, sp.aud_tokens)
                 cls_a = ops.gather_rows(audio_output.reshape(-1, sp.aud_width), idx)
                 feat_a = ops.l2_normalize(ops.linear(cls_a, P["contra_head_a.linear.weight"], None)).view(b, A, -1)
             if compute_loss and self.gather_fn is not None:       # ddp_allgather_with_grads / ddp_allgather (pretrain.py:278-291)
