@@ -124,3 +124,41 @@ def test_flop_model_matches_survey():
     import bench
     nf = bench.necessary_flops_per_sample(synth.base_spec(), 8, 2, 32)
     assert 1.15e12 < nf < 1.30e12          # ~1218 GFLOP fwd+bwd per sample with shared cross-K/V
+
+
+def test_attention_masks_match_reference_construction():
+    """numpy mask builders == the torch construction of bert.py:854-885 / clip.py:382-414"""
+    import torch
+    from valor_amd.model.valor import VALOR
+
+    def ref_bert(tokens, prompt, casual):
+        am = (tokens != 0).long()
+        token_len = am.shape[1]
+        if prompt is not None:
+            am = torch.cat((am, (prompt != 0).long()), dim=1)
+        total = am.shape[1]
+        am = am.unsqueeze(1).expand(-1, total, -1).clone()
+        if casual:
+            am[:, :token_len, :token_len] = torch.tril(am[:, :token_len, :token_len])
+            am[:, token_len:, :token_len] = 0
+        return (1.0 - am.float()) * -10000.0
+
+    g = torch.Generator().manual_seed(0)
+    tok = torch.randint(0, 4, (5, 32), generator=g)
+    pr = torch.randint(0, 3, (5, 10), generator=g)
+    for casual in (True, False):
+        for p in (None, pr):
+            assert torch.equal(ref_bert(tok, p, casual), VALOR._bert_mask(tok, p, casual))
+    L = tok.shape[1]
+    m = torch.tril((tok != 0).long().unsqueeze(1).expand(-1, L, -1).clone())
+    assert torch.equal((1.0 - m.float()) * -10000.0, VALOR._clip_text_mask(tok))
+
+
+def test_host_stage_passthrough_on_cpu():
+    """without a GPU the staging ring is a no-op that still honours dtype conversion"""
+    import torch
+    from valor_amd.hoststage import HostStage
+    st = HostStage("cpu")
+    st.begin_step()
+    t = torch.arange(6).view(2, 3)
+    assert torch.equal(st.put(t), t) and st.put(t, torch.float32).dtype == torch.float32

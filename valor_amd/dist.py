@@ -46,21 +46,23 @@ class _PackedGather(Function):
         return tuple(outs)
 
 
-def packed_allgather_with_grads(feat_t, feat_v, feat_a, tokens_cpu):
-    """Gather contrastive features (with local-slice backward) and the text tokens across ranks."""
+def packed_allgather_with_grads(feat_t, feat_v, feat_a, tokens):
+    """Gather contrastive features (with local-slice backward) and the text tokens across ranks.
+    `tokens` may live on the host or the device; the gathered tokens are returned ON THE FEATURES' DEVICE (the caller only
+    needs `tokens != 0`, so there is no device -> host round trip in the middle of the forward pass)."""
     feats = [f for f in (feat_t, feat_v, feat_a) if f is not None]
     dev, dt = feats[0].device, feats[0].dtype
-    # tokens ride in the same buffer as exact small integers split into two 8-bit-safe halves
-    tok = tokens_cpu.to(dev)
-    tok_parts = torch.stack(((tok // 256).to(dt), (tok % 256).to(dt)), dim=-1)      # exact in bf16 (<= 256 each... up to 49408/256 = 193)
+    # tokens ride in the same buffer as exact small integers split into two halves (< 256 and < 256: exact in bf16)
+    tok = tokens.to(dev)
+    tok_parts = torch.stack(((tok // 256).to(dt), (tok % 256).to(dt)), dim=-1)
     gathered = _PackedGather.apply(*feats, tok_parts)
     gi = iter(gathered[:-1])
     ft = next(gi) if feat_t is not None else None
     fv = next(gi) if feat_v is not None else None
     fa = next(gi) if feat_a is not None else None
     tp = gathered[-1].detach().float()
-    tokens = (tp[..., 0] * 256 + tp[..., 1]).round().long().cpu()
-    return ft, fv, fa, tokens
+    tokens_all = (tp[..., 0] * 256 + tp[..., 1]).round().long()
+    return ft, fv, fa, tokens_all
 
 
 class Reducer:

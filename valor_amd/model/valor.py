@@ -426,12 +426,12 @@ class VALOR(nn.Module):
                 cls_a = ops.gather_rows(audio_output.reshape(-1, sp.aud_width), idx)
                 feat_a = ops.l2_normalize(ops.linear(cls_a, P["contra_head_a.linear.weight"], None)).view(b, A, -1)
             if compute_loss and self.gather_fn is not None:       # ddp_allgather_with_grads / ddp_allgather (pretrain.py:278-291)
-                feat_t, feat_v, feat_a, tok_contra = self.gather_fn(feat_t, feat_v, feat_a, tok_contra)
+                feat_t, feat_v, feat_a, tok_contra = self.gather_fn(feat_t, feat_v, feat_a, self._dev(tok_contra))
             if col is not None:
                 col.update(feat_t=feat_t, feat_v=feat_v, feat_a=feat_a)
             if compute_loss:
                 k = P["clip_model.logit_scale"].float().exp()                    # 1/temp, modeling.py:420-426
-                maskA = self._dev((tok_contra != 0).float()).contiguous()
+                maskA = (tok_contra != 0).float().contiguous() if tok_contra.is_cuda else self._dev((tok_contra != 0).float()).contiguous()
                 fw = lambda name, f: ops.rowdot(ops.linear(f, P[f"{name}_fine_weight.0.weight"], P[f"{name}_fine_weight.0.bias"], ACT_RELU),
                                                 P[f"{name}_fine_weight.2.weight"], P[f"{name}_fine_weight.2.bias"]).float().squeeze(-1)
                 wt = fw("text", feat_t)
