@@ -209,8 +209,16 @@ def main():
             layout = {"NN": "forward x.W^T", "NT": "dgrad dY.W", "TT": "wgrad dY^T.X", "TN": "A^T.B^T"}
             name = lambda v: f"{GemmTimer.FAMILY[v[0]]} {v[1]} ({layout[v[1]]})"
             tot_f, tot_s = sum(d["flops"] for d in gs.values()), sum(d["seconds"] for d in gs.values())
+            traffic = None
+            try:    # HBM-side traffic of this kernel from the committed PMC passes (rocprofv3 cannot run inside the bench)
+                pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_gemm_traffic.json")))["kernels"].get(name(dom))
+                if pmc:
+                    traffic = {"bytes_per_launch": pmc["traffic_bytes"], "algorithmic_bytes": pmc["algorithmic_bytes"], "shape": pmc["shape"],
+                               "source": "profiles/r01_pmc_gemm_traffic.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE)"}
+            except Exception:
+                traffic = None
             roof = {"bound": "mfma", "kernel": name(dom), "achieved": round(gs[dom]["TFLOPs"], 1), "peak": PEAK_BF16_TFLOPS,
-                    "unit": "TFLOP/s", "frac": round(gs[dom]["TFLOPs"] / PEAK_BF16_TFLOPS, 4), "traffic": None,
+                    "unit": "TFLOP/s", "frac": round(gs[dom]["TFLOPs"] / PEAK_BF16_TFLOPS, 4), "traffic": traffic,
                     "avg_launch_us": round(gs[dom]["avg_us"], 1), "launches_per_step": gs[dom]["launches"],
                     "all_gemm_kernels": {name(v): {"TFLOPs": round(d["TFLOPs"], 1), "avg_us": round(d["avg_us"], 1), "launches_per_step": d["launches"],
                                                    "share_of_step_time": round(d["seconds"] / inst_elapsed, 3)} for v, d in sorted(gs.items(), key=lambda kv: -kv[1]["seconds"])},
