@@ -90,12 +90,13 @@ int valor_attn_fwd(void* stream, int dtype, const void* q, const void* k, const 
                    int H, int Sq, int Skv, int64_t q_bs, int64_t q_rs, int64_t k_bs, int64_t k_rs, int64_t v_bs,
                    int64_t v_rs, int64_t o_bs, int64_t o_rs, const float* mask, int64_t mask_bs, int64_t mask_rs,
                    const int* kv_range, int kv_bmod, float scale, float p_drop, uint64_t seed, uint64_t offset);
+/* accumulate_dkdv != 0: dk/dv += (several query passes share one K/V set; gradients meet in one buffer) */
 int valor_attn_bwd(void* stream, int dtype, const void* q, const void* k, const void* v, const void* o, const float* lse,
                    const void* dout, void* dq, void* dk, void* dv, float* delta, int B, int H, int Sq, int Skv,
                    int64_t q_bs, int64_t q_rs, int64_t k_bs, int64_t k_rs, int64_t v_bs, int64_t v_rs, int64_t o_bs,
                    int64_t o_rs, int64_t do_bs, int64_t do_rs, int64_t dq_bs, int64_t dq_rs, int64_t dk_bs, int64_t dk_rs,
                    int64_t dv_bs, int64_t dv_rs, const float* mask, int64_t mask_bs, int64_t mask_rs, const int* kv_range,
-                   int kv_bmod, float scale, float p_drop, uint64_t seed, uint64_t offset);
+                   int kv_bmod, float scale, float p_drop, uint64_t seed, uint64_t offset, int accumulate_dkdv);
 
 /* ---- softmax cross-entropy over the vocabulary: F.cross_entropy on the masked rows (pretrain.py:444,457,469,498).
  * logits [rows, V] with leading dim ld; backward overwrites the logits (and zero-fills the ld padding) with

@@ -526,8 +526,10 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnArgs p) {
         T* DV = (T*)p.dv + (int64_t)kb * p.dv_bs + (int64_t)key_abs * p.dv_rs + h * ATT_D;
 #pragma unroll
         for (int dt = 0; dt < 4; ++dt) {
-            store4<T>(DK + dt * 16 + 4 * g, dkacc[dt] * p.scale);
-            store4<T>(DV + dt * 16 + 4 * g, dvacc[dt]);
+            f32x4_t ok = dkacc[dt] * p.scale, ov = dvacc[dt];
+            if (p.acc_dkv) { ok += load4<T>(DK + dt * 16 + 4 * g); ov += load4<T>(DV + dt * 16 + 4 * g); }
+            store4<T>(DK + dt * 16 + 4 * g, ok);
+            store4<T>(DV + dt * 16 + 4 * g, ov);
         }
     }
 }
@@ -630,8 +632,9 @@ extern "C" int valor_attn_bwd(void* stream, int dtype, const void* q, const void
                               int64_t v_bs, int64_t v_rs, int64_t o_bs, int64_t o_rs, int64_t do_bs, int64_t do_rs,
                               int64_t dq_bs, int64_t dq_rs, int64_t dk_bs, int64_t dk_rs, int64_t dv_bs, int64_t dv_rs,
                               const float* mask, int64_t mask_bs, int64_t mask_rs, const int* kv_range, int kv_bmod,
-                              float scale, float p_drop, uint64_t seed, uint64_t offset) {
+                              float scale, float p_drop, uint64_t seed, uint64_t offset, int accumulate_dkdv) {
     AttnArgs p = {};
+    p.acc_dkv = accumulate_dkdv;
     p.q = q; p.k = k; p.v = v; p.o = (void*)o; p.lse = (float*)lse; p.dout = dout; p.dq = dq; p.dk = dk; p.dv = dv;
     p.delta = delta; p.mask = mask; p.kv_range = kv_range;
     p.B = B; p.H = H; p.Sq = Sq; p.Skv = Skv;

@@ -403,7 +403,7 @@ __global__ __launch_bounds__(512, 2) void attn_res_bwd_kernel(AttnArgs p) {
 
 // ------------------------------------------------------------------------------------------ launch
 static bool res_eligible(const AttnArgs& p) {
-    if (p.kv_range || p.kv_bmod > 0 || p.Sq != p.Skv || p.Skv > 256) return false;
+    if (p.kv_range || p.kv_bmod > 0 || p.Sq != p.Skv || p.Skv > 256 || p.acc_dkv) return false;
     const int64_t lim = (int64_t)1 << 31;
     return (int64_t)p.Skv * p.k_rs * 2 < lim && (int64_t)p.Skv * p.v_rs * 2 < lim && (int64_t)p.Sq * p.q_rs * 2 < lim;
 }

@@ -405,8 +405,10 @@ __global__ __launch_bounds__(256, 2) void attn_x_bwd_kernel(AttnArgs p) {
                     bf16_t* DV = (bf16_t*)p.dv + (int64_t)kvb * p.dv_bs + (int64_t)key * p.dv_rs + h * ATT_D;
 #pragma unroll
                     for (int dt = 0; dt < 4; ++dt) {
-                        store4<bf16_t>(DK + dt * 16 + 4 * g, dkacc[kt][dt] * p.scale);
-                        store4<bf16_t>(DV + dt * 16 + 4 * g, dvacc[kt][dt]);
+                        f32x4_t ok = dkacc[kt][dt] * p.scale, ov = dvacc[kt][dt];
+                        if (p.acc_dkv) { ok += load4<bf16_t>(DK + dt * 16 + 4 * g); ov += load4<bf16_t>(DV + dt * 16 + 4 * g); }
+                        store4<bf16_t>(DK + dt * 16 + 4 * g, ok);
+                        store4<bf16_t>(DV + dt * 16 + 4 * g, ov);
                     }
                 }
             }

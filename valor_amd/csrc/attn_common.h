@@ -16,6 +16,7 @@ struct AttnArgs {
     int64_t do_bs, do_rs, dq_bs, dq_rs, dk_bs, dk_rs, dv_bs, dv_rs;
     int64_t mask_bs, mask_rs;
     int kv_bmod;
+    int acc_dkv;          // backward: dK/dV += (the K/V set is shared by several passes; their gradients meet in one buffer)
     float scale, p_drop;
     uint64_t seed, offset;
 };

@@ -91,19 +91,42 @@ __global__ void embed_fwd_kernel(const int64_t* ids, const T* word, const T* pos
 }
 template <typename T>
 __global__ __launch_bounds__(256) void embed_bwd_word_kernel(const int64_t* ids, const T* dout, T* dword, int64_t n, int E) {
+    // one workgroup per token position i: if i is the FIRST occurrence of its id, sum dout over every occurrence (in
+    // position order: deterministic) and write the row. The occurrence list is built cooperatively in LDS (each thread
+    // scans n/256 ids) instead of every thread scanning all n ids.
     __shared__ int first;
+    __shared__ int cnt;
+    __shared__ int occ[1024];
     const int64_t i = blockIdx.x;
     const int64_t id = ids[i];
-    if (threadIdx.x == 0) first = 1;
+    if (threadIdx.x == 0) { first = 1; cnt = 0; }
     __syncthreads();
     for (int64_t j = threadIdx.x; j < i; j += 256)
         if (ids[j] == id) first = 0;
     __syncthreads();
     if (!first) return;
+    for (int64_t j0 = i + 1; j0 < n; j0 += 256) {
+        const int64_t j = j0 + threadIdx.x;
+        if (j < n && ids[j] == id) { const int k = atomicAdd(&cnt, 1); if (k < 1024) occ[k] = (int)j; }
+    }
+    __syncthreads();
+    const int nocc = cnt;
+    if (nocc > 1024) {      // pathological: fall back to the scan
+        for (int e = threadIdx.x * 4; e < E; e += 1024) {
+            f32x4_t s = load4<T>(dout + i * E + e);
+            for (int64_t j = i + 1; j < n; ++j)
+                if (ids[j] == id) s += load4<T>(dout + j * E + e);
+            store4<T>(dword + id * E + e, s);
+        }
+        return;
+    }
+    // positions ascending (the atomics above append in arbitrary order): tiny insertion sort by one thread
+    if (threadIdx.x == 0)
+        for (int a = 1; a < nocc; ++a) { const int v = occ[a]; int c = a - 1; while (c >= 0 && occ[c] > v) { occ[c + 1] = occ[c]; --c; } occ[c + 1] = v; }
+    __syncthreads();
     for (int e = threadIdx.x * 4; e < E; e += 1024) {
         f32x4_t s = load4<T>(dout + i * E + e);
-        for (int64_t j = i + 1; j < n; ++j)
-            if (ids[j] == id) s += load4<T>(dout + j * E + e);
+        for (int k = 0; k < nocc; ++k) s += load4<T>(dout + (int64_t)occ[k] * E + e);
         store4<T>(dword + id * E + e, s);
     }
 }
@@ -452,20 +475,36 @@ __global__ void rowdot_bwd_dx_kernel(const T* dy, const T* w, T* dx, int64_t row
         store4<T>(dx + r * cols + c, load4<T>(w + c) * to_f32<T>(dy[r]));
     }
 }
-// one thread per 4 columns; loops over all rows (rows is small: global batch x tokens)
+// dw[c] = sum_r dy[r] * x[r, c], db = sum_r dy[r].  Workgroup = 16 row groups x 64 lanes (4 columns each): the rows are
+// split 16 ways, partial sums meet in LDS (fixed order: deterministic).
 template <typename T>
-__global__ void rowdot_bwd_dw_kernel(const T* dy, const T* x, T* dw, T* db, int64_t rows, int cols) {
-    const int q = blockIdx.x * blockDim.x + threadIdx.x;
-    if (q * 4 >= cols) return;
+__global__ __launch_bounds__(1024) void rowdot_bwd_dw_kernel(const T* dy, const T* x, T* dw, T* db, int64_t rows, int cols) {
+    __shared__ float red[16][64 * 4 + 1];
+    const int lane = threadIdx.x & 63, rg = threadIdx.x >> 6;
+    const int q = blockIdx.x * 64 + lane;
+    const bool ok = q * 4 < cols;
     f32x4_t s = {0.f, 0.f, 0.f, 0.f};
     float sb = 0.f;
-    for (int64_t r = 0; r < rows; ++r) {
+    for (int64_t r = rg; r < rows; r += 16) {
         const float g = to_f32<T>(dy[r]);
-        s += load4<T>(x + r * cols + q * 4) * g;
+        if (ok) s += load4<T>(x + r * cols + q * 4) * g;
         sb += g;
     }
-    store4<T>(dw + q * 4, s);
-    if (q == 0 && db) db[0] = from_f32<T>(sb);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) red[rg][lane * 4 + k] = s[k];
+    if (lane == 0) red[rg][256] = sb;
+    __syncthreads();
+    if (rg == 0) {
+        f32x4_t t = {0.f, 0.f, 0.f, 0.f};
+        float tb = 0.f;
+        for (int g2 = 0; g2 < 16; ++g2) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) t[k] += red[g2][lane * 4 + k];
+            tb += red[g2][256];
+        }
+        if (ok) store4<T>(dw + q * 4, t);
+        if (q == 0 && db) db[0] = from_f32<T>(tb);
+    }
 }
 extern "C" int valor_rowdot_fwd(void* stream, int dtype, const void* x, const void* w, const void* b, void* y, int64_t rows, int cols) {
     if (rows <= 0) return VALOR_OK;
@@ -483,8 +522,8 @@ extern "C" int valor_rowdot_bwd(void* stream, int dtype, const void* dy, const v
     hipStream_t st = (hipStream_t)stream;
     DISPATCH_T(dtype,
         { hipLaunchKernelGGL((rowdot_bwd_dx_kernel<bf16_t>), dim3(grid_for(rows * cols / 4)), dim3(256), 0, st, (const bf16_t*)dy, (const bf16_t*)w, (bf16_t*)dx, rows, cols);
-          hipLaunchKernelGGL((rowdot_bwd_dw_kernel<bf16_t>), dim3((cols / 4 + 63) / 64), dim3(64), 0, st, (const bf16_t*)dy, (const bf16_t*)x, (bf16_t*)dw, (bf16_t*)db, rows, cols); },
+          hipLaunchKernelGGL((rowdot_bwd_dw_kernel<bf16_t>), dim3((cols / 4 + 63) / 64), dim3(1024), 0, st, (const bf16_t*)dy, (const bf16_t*)x, (bf16_t*)dw, (bf16_t*)db, rows, cols); },
         { hipLaunchKernelGGL((rowdot_bwd_dx_kernel<float>), dim3(grid_for(rows * cols / 4)), dim3(256), 0, st, (const float*)dy, (const float*)w, (float*)dx, rows, cols);
-          hipLaunchKernelGGL((rowdot_bwd_dw_kernel<float>), dim3((cols / 4 + 63) / 64), dim3(64), 0, st, (const float*)dy, (const float*)x, (float*)dw, (float*)db, rows, cols); });
+          hipLaunchKernelGGL((rowdot_bwd_dw_kernel<float>), dim3((cols / 4 + 63) / 64), dim3(1024), 0, st, (const float*)dy, (const float*)x, (float*)dw, (float*)db, rows, cols); });
     return valor_launch_status();
 }

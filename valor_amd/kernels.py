@@ -177,7 +177,7 @@ def attn_fwd(q, k, v, n_heads, *, mask=None, kv_range=None, kv_bmod=0, scale=Non
 
 
 def attn_bwd(q, k, v, o, lse, dout, n_heads, *, dq=None, dk=None, dv=None, mask=None, kv_range=None, kv_bmod=0,
-             scale=None, p_drop=0.0, seed=0, offset=0):
+             scale=None, p_drop=0.0, seed=0, offset=0, accumulate_kv=False):
     """Returns (dq, dk, dv) shaped like q, k, v (or writes into the given [B,S,H*64] views)."""
     _check_gpu(q, k, v, o, dout, mask, kv_range)
     B, Sq, E = q.shape
@@ -199,5 +199,5 @@ def attn_bwd(q, k, v, o, lse, dout, n_heads, *, dq=None, dk=None, dv=None, mask=
     lib.call("valor_attn_bwd", _stream(), dt_of(q), _ptr(q), _ptr(k), _ptr(v), _ptr(o), _ptr(lse), _ptr(dout), _ptr(dq),
              _ptr(dk), _ptr(dv), _ptr(delta), B, n_heads, Sq, Skv, qb, qr, kb, kr, vb, vr, ob, orr, gb, gr,
              dqb, dqr, dkb, dkr, dvb, dvr, _ptr(mask), mb, mr, _ptr(kv_range), int(kv_bmod), float(scale),
-             float(p_drop), int(seed), int(offset))
+             float(p_drop), int(seed), int(offset), int(accumulate_kv))
     return dq, dk, dv

@@ -33,7 +33,7 @@ SIGNATURES = {
                        _vp, _i64, _i64, _vp, _i, _f, _f, _u64, _u64],
     "valor_attn_bwd": [_vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i,
                        _i64, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _i64,
-                       _vp, _i64, _i64, _vp, _i, _f, _f, _u64, _u64],
+                       _vp, _i64, _i64, _vp, _i, _f, _f, _u64, _u64, _i],
     "valor_xent_fwd": [_vp, _i, _vp, _vp, _vp, _vp, _i64, _i, _i64],
     "valor_xent_bwd": [_vp, _i, _vp, _vp, _vp, _vp, _f, _i64, _i, _i64],
     "valor_fine_weight_softmax": [_vp, _vp, _vp, _vp, _i, _i],

@@ -236,12 +236,14 @@ class VALOR(nn.Module):
             a = ops.self_attention(qkv, heads, mask, 0.0)
             o = ops.linear(a, P[p + "attn.out_proj.weight"], None)
             x, y = ops.bias_dropout_residual_ln(o, P[p + "attn.out_proj.bias"], x, P[p + "ln_2.weight"], P[p + "ln_2.bias"], 1e-5, 0.0, True)
-            m = ops.mlp(y, P[p + "mlp.c_fc.weight"], P[p + "mlp.c_fc.bias"], P[p + "mlp.c_proj.weight"], P[p + "mlp.c_proj.bias"], ACT_QUICK_GELU)
+            # the c_proj bias is added by the fused residual+LayerNorm kernel (its gradient then falls out of that kernel's
+            # backward for free instead of a separate column-sum pass over dY)
+            m = ops.mlp(y, P[p + "mlp.c_fc.weight"], P[p + "mlp.c_fc.bias"], P[p + "mlp.c_proj.weight"], None, ACT_QUICK_GELU)
             if i + 1 < n_layers:
                 q = f"{prefix}.resblocks.{i + 1}."
-                x, y = ops.bias_dropout_residual_ln(m, None, x, P[q + "ln_1.weight"], P[q + "ln_1.bias"], 1e-5, 0.0, True)
+                x, y = ops.bias_dropout_residual_ln(m, P[p + "mlp.c_proj.bias"], x, P[q + "ln_1.weight"], P[q + "ln_1.bias"], 1e-5, 0.0, True)
             else:
-                y = ops.bias_dropout_residual_ln(m, None, x, final_g, final_b, 1e-5, 0.0, False)
+                y = ops.bias_dropout_residual_ln(m, P[p + "mlp.c_proj.bias"], x, final_g, final_b, 1e-5, 0.0, False)
         return y
 
     def forward_video_encoder(self, video_pixels):
@@ -288,13 +290,13 @@ class VALOR(nn.Module):
             a = ops.self_attention(qkv, sp.aud_heads, None, p)
             o = ops.linear(a, P[q + "attention.linears.3.weight"], None)
             x, y = ops.bias_dropout_residual_ln(o, P[q + "attention.linears.3.bias"], x, P[q + "layernorm2.weight"], P[q + "layernorm2.bias"], 1e-12, p, True)
-            m = ops.mlp(y, P[q + "ff_layer.linear1.weight"], P[q + "ff_layer.linear1.bias"], P[q + "ff_layer.linear2.weight"],
-                        P[q + "ff_layer.linear2.bias"], ACT_GELU_ERF)
+            m = ops.mlp(y, P[q + "ff_layer.linear1.weight"], P[q + "ff_layer.linear1.bias"], P[q + "ff_layer.linear2.weight"], None, ACT_GELU_ERF)
+            b2 = P[q + "ff_layer.linear2.bias"]
             if i + 1 < sp.aud_layers:
                 r = f"audio_encoder.layer.{i + 1}."
-                x, y = ops.bias_dropout_residual_ln(m, None, x, P[r + "layernorm1.weight"], P[r + "layernorm1.bias"], 1e-12, p, True)
+                x, y = ops.bias_dropout_residual_ln(m, b2, x, P[r + "layernorm1.weight"], P[r + "layernorm1.bias"], 1e-12, p, True)
             else:
-                y = ops.bias_dropout_residual_ln(m, None, x, P["audio_encoder.last_layernorm.weight"], P["audio_encoder.last_layernorm.bias"], 1e-12, p, False)
+                y = ops.bias_dropout_residual_ln(m, b2, x, P["audio_encoder.last_layernorm.weight"], P["audio_encoder.last_layernorm.bias"], 1e-12, p, False)
         return y.view(b, n, sp.aud_tokens, sp.aud_width)
 
     # ------------------------------------------------------------------ multimodal decoder
@@ -310,10 +312,14 @@ class VALOR(nn.Module):
         return x
 
     def project_cross_kv(self, va_input):
-        """K|V of the concatenated [video | audio] tokens, ONCE per decoder layer (shared by every pass)."""
+        """K|V of the concatenated [video | audio] tokens, ONCE per decoder layer (shared by every pass). The 12 projections
+        read the same input: their input gradients meet in one buffer (ops.GradSlot); each layer's K|V buffer gets a slot
+        of its own for the decoder passes that attend to it."""
         P = self.P
+        va_slot = ops.GradSlot()
+        self._kv_slots = [ops.GradSlot() for _ in range(self.spec.layers)]
         return [ops.linear(va_input, P[f"multimodal_encoder.encoder.layer.{i}.cross_attn.cross.kv.weight"],
-                           P[f"multimodal_encoder.encoder.layer.{i}.cross_attn.cross.kv.bias"]) for i in range(self.spec.layers)]
+                           P[f"multimodal_encoder.encoder.layer.{i}.cross_attn.cross.kv.bias"], grad_slot=va_slot) for i in range(self.spec.layers)]
 
     def bert_encoder(self, x, mask, kv_layers, kv_range, kv_bmod):
         """BertEncoder / BertLayer.forward bert.py:440-518 (post-LN; va_concate cross-attention)."""
@@ -327,13 +333,12 @@ class VALOR(nn.Module):
                                              P[q + "attention.output.LayerNorm.bias"], 1e-12, p, False)
             if kv_layers is not None:
                 cq = ops.linear(x, P[q + "cross_attn.cross.query.weight"], P[q + "cross_attn.cross.query.bias"])
-                c = ops.cross_attention(cq, kv_layers[i], H, kv_range, kv_bmod, p)
+                c = ops.cross_attention(cq, kv_layers[i], H, kv_range, kv_bmod, p, grad_slot=self._kv_slots[i])
                 o = ops.linear(c, P[q + "cross_attn.output.dense.weight"], None)
                 x = ops.bias_dropout_residual_ln(o, P[q + "cross_attn.output.dense.bias"], x, P[q + "cross_attn.output.LayerNorm.weight"],
                                                  P[q + "cross_attn.output.LayerNorm.bias"], 1e-12, p, False)
-            m = ops.mlp(x, P[q + "intermediate.dense.weight"], P[q + "intermediate.dense.bias"], P[q + "output.dense.weight"],
-                        P[q + "output.dense.bias"], ACT_GELU_ERF)
-            x = ops.bias_dropout_residual_ln(m, None, x, P[q + "output.LayerNorm.weight"], P[q + "output.LayerNorm.bias"], 1e-12, p, False)
+            m = ops.mlp(x, P[q + "intermediate.dense.weight"], P[q + "intermediate.dense.bias"], P[q + "output.dense.weight"], None, ACT_GELU_ERF)
+            x = ops.bias_dropout_residual_ln(m, P[q + "output.dense.bias"], x, P[q + "output.LayerNorm.weight"], P[q + "output.LayerNorm.bias"], 1e-12, p, False)
         return x
 
     def cls_transform(self, rows):

@@ -57,6 +57,18 @@ class GradSink:
     listener = None
 
 
+class GradSlot:
+    """Meeting point for the gradients of ONE activation that feeds several ops (the shared cross K/V buffer of a decoder
+    layer used by the caption and mlm passes; the [video|audio] decoder input feeding 12 K/V projections). The first
+    backward to run writes its gradient into a fresh buffer and returns it to autograd; later ones accumulate INTO that
+    buffer inside their own kernel (GEMM epilogue `C +=`, attention dK/dV +=) and return nothing. Autograd still sees the
+    right total whichever subset of the consumers takes part in a backward pass, and the separate add kernels are gone."""
+    __slots__ = ("buf",)
+
+    def __init__(self):
+        self.buf = None
+
+
 def _sink(p):
     if not GradSink.enabled or p is None or getattr(p, "_arena_name", None) is None or p.grad is None or not p.requires_grad:
         return None
@@ -75,7 +87,8 @@ class LinearFn(Function):
     split-K), db = column sums."""
 
     @staticmethod
-    def forward(ctx, x, w, b, act, w_is_kn):
+    def forward(ctx, x, w, b, act, w_is_kn, slot=None):
+        ctx.slot = slot
         x2 = _2d(x)
         want_pre = act != ACT_NONE
         if w_is_kn:
@@ -98,7 +111,14 @@ class LinearFn(Function):
             dy2 = du
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
-            dx = (K.gemm(dy2, w) if ctx.w_is_kn else K.gemm(dy2, w, trans_b=True)).view(ctx.xshape)
+            slot = ctx.slot
+            if slot is not None and slot.buf is not None:          # a sibling already produced a gradient buffer: add into it
+                out2 = _2d(slot.buf)
+                K.gemm(dy2, w, out=out2, accumulate=True) if ctx.w_is_kn else K.gemm(dy2, w, trans_b=True, out=out2, accumulate=True)
+            else:
+                dx = (K.gemm(dy2, w) if ctx.w_is_kn else K.gemm(dy2, w, trans_b=True)).view(ctx.xshape)
+                if slot is not None:
+                    slot.buf = dx
         pw, pb = ctx.params
         if ctx.needs_input_grad[1]:
             sw = _sink(pw)
@@ -112,11 +132,11 @@ class LinearFn(Function):
                 K.colsum(dy2, out=sb, accumulate=True); _sunk(pb)
             else:
                 db = K.colsum(dy2)
-        return dx, dw, db, None, None
+        return dx, dw, db, None, None, None
 
 
-def linear(x, w, b=None, act=ACT_NONE, w_is_kn=False):
-    return LinearFn.apply(x, w, b, act, w_is_kn)
+def linear(x, w, b=None, act=ACT_NONE, w_is_kn=False, grad_slot=None):
+    return LinearFn.apply(x, w, b, act, w_is_kn, grad_slot)
 
 
 class MlpFn(Function):
@@ -156,7 +176,7 @@ class MlpFn(Function):
             return None
 
         dw2 = wgrad(dy2, h, pw2)
-        db2 = bgrad(dy2, pb2)
+        db2 = bgrad(dy2, pb2) if pb2 is not None else None
         dx = K.gemm(du, w1, trans_b=True).view(ctx.xshape) if ctx.needs_input_grad[0] else None
         dw1 = wgrad(du, x2, pw1)
         db1 = bgrad(du, pb1)
@@ -294,7 +314,8 @@ class CrossAttnFn(Function):
     concatenated [video | audio] tokens shared by every query group; kv_range[b] = (start, len)."""
 
     @staticmethod
-    def forward(ctx, q, kv, n_heads, kv_range, kv_bmod, p_drop):
+    def forward(ctx, q, kv, n_heads, kv_range, kv_bmod, p_drop, slot=None):
+        ctx.slot = slot
         B, T, E = q.shape
         seed = off = 0
         if p_drop > 0:
@@ -312,15 +333,19 @@ class CrossAttnFn(Function):
         q, kv, o, lse, kv_range = ctx.saved_tensors
         n_heads, kv_bmod, p_drop, seed, off = ctx.cfg
         E = q.shape[2]
-        dkv = torch.empty_like(kv)
+        slot = ctx.slot
+        acc = slot is not None and slot.buf is not None
+        dkv = slot.buf if acc else torch.empty_like(kv)
         dq, _, _ = K.attn_bwd(q, kv[:, :, :E], kv[:, :, E:], o, lse, do.contiguous(), n_heads, dk=dkv[:, :, :E],
                               dv=dkv[:, :, E:], kv_range=kv_range, kv_bmod=kv_bmod, scale=1.0 / math.sqrt(64),
-                              p_drop=p_drop, seed=seed, offset=off)
-        return dq, dkv, None, None, None, None
+                              p_drop=p_drop, seed=seed, offset=off, accumulate_kv=acc)
+        if slot is not None and not acc:
+            slot.buf = dkv
+        return dq, (None if acc else dkv), None, None, None, None, None
 
 
-def cross_attention(q, kv, n_heads, kv_range=None, kv_bmod=0, p_drop=0.0):
-    return CrossAttnFn.apply(q, kv, n_heads, kv_range, kv_bmod, p_drop)
+def cross_attention(q, kv, n_heads, kv_range=None, kv_bmod=0, p_drop=0.0, grad_slot=None):
+    return CrossAttnFn.apply(q, kv, n_heads, kv_range, kv_bmod, p_drop, grad_slot)
 
 
 # ------------------------------------------------------------------------------------------------
