@@ -204,7 +204,7 @@ __global__ __launch_bounds__(256, 2) void attn_x_fwd_kernel(AttnArgs p) {
 
 // ------------------------------------------------------------------------------------------ backward
 // NQS even. LDS: [Q image NQS*16 rows][dO image][K tile][V tile][dS^T scratch 4 x 1 KiB][lse][delta]
-template <int NQS, bool DROP>
+template <int NQS, bool DROP, bool ACC>
 __global__ __launch_bounds__(256, 2) void attn_x_bwd_kernel(AttnArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int QIMG = NQS * 16 * TILE_ROW_BYTES;
@@ -397,18 +397,40 @@ __global__ __launch_bounds__(256, 2) void attn_x_bwd_kernel(AttnArgs p) {
                     }
                 }
             }
+            {   // dK / dV rows of this wave's 32 keys: complete after this tile. With acc_dkv the old values are fetched
+                // first, all 16 loads in flight at once (one memory round trip per tile instead of sixteen).
+                u32x2_t oldk[2][4], oldv[2][4];
+                if (ACC) {
 #pragma unroll
-            for (int kt = 0; kt < 2; ++kt) {
-                const int key = ka + kt * 16 + fr;
-                if (key < p.Skv) {
-                    bf16_t* DK = (bf16_t*)p.dk + (int64_t)kvb * p.dk_bs + (int64_t)key * p.dk_rs + h * ATT_D;
-                    bf16_t* DV = (bf16_t*)p.dv + (int64_t)kvb * p.dv_bs + (int64_t)key * p.dv_rs + h * ATT_D;
+                    for (int kt = 0; kt < 2; ++kt) {
+                        const int key = ka + kt * 16 + fr;
+                        const int kc = key < p.Skv ? key : p.Skv - 1;
+                        const bf16_t* DK = (const bf16_t*)p.dk + (int64_t)kvb * p.dk_bs + (int64_t)kc * p.dk_rs + h * ATT_D;
+                        const bf16_t* DV = (const bf16_t*)p.dv + (int64_t)kvb * p.dv_bs + (int64_t)kc * p.dv_rs + h * ATT_D;
 #pragma unroll
-                    for (int dt = 0; dt < 4; ++dt) {
-                        f32x4_t ok = dkacc[kt][dt] * p.scale, ov = dvacc[kt][dt];
-                        if (p.acc_dkv) { ok += load4<bf16_t>(DK + dt * 16 + 4 * g); ov += load4<bf16_t>(DV + dt * 16 + 4 * g); }
-                        store4<bf16_t>(DK + dt * 16 + 4 * g, ok);
-                        store4<bf16_t>(DV + dt * 16 + 4 * g, ov);
+                        for (int dt = 0; dt < 4; ++dt) {
+                            oldk[kt][dt] = *(const u32x2_t*)(DK + dt * 16 + 4 * g);
+                            oldv[kt][dt] = *(const u32x2_t*)(DV + dt * 16 + 4 * g);
+                        }
+                    }
+                }
+#pragma unroll
+                for (int kt = 0; kt < 2; ++kt) {
+                    const int key = ka + kt * 16 + fr;
+                    if (key < p.Skv) {
+                        bf16_t* DK = (bf16_t*)p.dk + (int64_t)kvb * p.dk_bs + (int64_t)key * p.dk_rs + h * ATT_D;
+                        bf16_t* DV = (bf16_t*)p.dv + (int64_t)kvb * p.dv_bs + (int64_t)key * p.dv_rs + h * ATT_D;
+#pragma unroll
+                        for (int dt = 0; dt < 4; ++dt) {
+                            f32x4_t ok = dkacc[kt][dt] * p.scale, ov = dvacc[kt][dt];
+                            if (ACC) {
+                                const u32x2_t a = oldk[kt][dt], b2 = oldv[kt][dt];
+                                ok += (f32x4_t){__uint_as_float(a[0] << 16), __uint_as_float(a[0] & 0xffff0000u), __uint_as_float(a[1] << 16), __uint_as_float(a[1] & 0xffff0000u)};
+                                ov += (f32x4_t){__uint_as_float(b2[0] << 16), __uint_as_float(b2[0] & 0xffff0000u), __uint_as_float(b2[1] << 16), __uint_as_float(b2[1] & 0xffff0000u)};
+                            }
+                            store4<bf16_t>(DK + dt * 16 + 4 * g, ok);
+                            store4<bf16_t>(DV + dt * 16 + 4 * g, ov);
+                        }
                     }
                 }
             }
@@ -476,19 +498,23 @@ bool attn_x_bwd_launch(hipStream_t st, const AttnArgs& p) {
     if (n <= 0 || n > 6 || p.Skv < 128 || (int64_t)p.Sq * p.do_rs * 2 >= ((int64_t)1 << 31)) return false;
     const int bmod = p.kv_bmod > 0 ? p.kv_bmod : p.B;
     dim3 grid(p.H, bmod);
-#define X_BWD(N_)                                                                                                   \
+#define X_BWD_I(N_, D_, A_)                                                                                         \
     do {                                                                                                            \
         const size_t lds = N_ * 4096 + 32768 + 4096 + N_ * 128;                                                     \
         static bool attr_set = false;                                                                               \
         if (!attr_set) {                                                                                            \
-            hipFuncSetAttribute((const void*)attn_x_bwd_kernel<N_, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-            hipFuncSetAttribute((const void*)attn_x_bwd_kernel<N_, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+            hipFuncSetAttribute((const void*)attn_x_bwd_kernel<N_, D_, A_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
             attr_set = true;                                                                                        \
         }                                                                                                           \
-        if (p.p_drop > 0.f) hipLaunchKernelGGL((attn_x_bwd_kernel<N_, true>), grid, dim3(256), lds, st, p);         \
-        else hipLaunchKernelGGL((attn_x_bwd_kernel<N_, false>), grid, dim3(256), lds, st, p);                       \
+        hipLaunchKernelGGL((attn_x_bwd_kernel<N_, D_, A_>), grid, dim3(256), lds, st, p);                           \
+    } while (0)
+#define X_BWD(N_)                                                                                                   \
+    do {                                                                                                            \
+        if (p.p_drop > 0.f) { if (p.acc_dkv) X_BWD_I(N_, true, true); else X_BWD_I(N_, true, false); }              \
+        else { if (p.acc_dkv) X_BWD_I(N_, false, true); else X_BWD_I(N_, false, false); }                           \
     } while (0)
     if (n <= 2) X_BWD(2); else if (n <= 4) X_BWD(4); else X_BWD(6);
 #undef X_BWD
+#undef X_BWD_I
     return true;
 }

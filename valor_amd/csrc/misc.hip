@@ -91,43 +91,64 @@ __global__ void embed_fwd_kernel(const int64_t* ids, const T* word, const T* pos
 }
 template <typename T>
 __global__ __launch_bounds__(256) void embed_bwd_word_kernel(const int64_t* ids, const T* dout, T* dword, int64_t n, int E) {
-    // one workgroup per token position i: if i is the FIRST occurrence of its id, sum dout over every occurrence (in
-    // position order: deterministic) and write the row. The occurrence list is built cooperatively in LDS (each thread
-    // scans n/256 ids) instead of every thread scanning all n ids.
+    // one workgroup per token position i: if i is the FIRST occurrence of its id, sum dout over every occurrence in
+    // position order (deterministic) and write the row. Occurrences are found cooperatively, 2048 positions at a time:
+    // LDS bitmap -> ordered position list (prefix popcounts) -> every thread sums its 4 columns over the list with
+    // independent loads (the pad id occurs thousands of times; a dependent load per occurrence would serialise).
     __shared__ int first;
-    __shared__ int cnt;
-    __shared__ int occ[1024];
+    __shared__ uint32_t bits[64];
+    __shared__ int pref[65];
+    __shared__ int list[2048];
     const int64_t i = blockIdx.x;
     const int64_t id = ids[i];
-    if (threadIdx.x == 0) { first = 1; cnt = 0; }
+    if (threadIdx.x == 0) first = 1;
     __syncthreads();
     for (int64_t j = threadIdx.x; j < i; j += 256)
         if (ids[j] == id) first = 0;
     __syncthreads();
     if (!first) return;
-    for (int64_t j0 = i + 1; j0 < n; j0 += 256) {
-        const int64_t j = j0 + threadIdx.x;
-        if (j < n && ids[j] == id) { const int k = atomicAdd(&cnt, 1); if (k < 1024) occ[k] = (int)j; }
-    }
-    __syncthreads();
-    const int nocc = cnt;
-    if (nocc > 1024) {      // pathological: fall back to the scan
-        for (int e = threadIdx.x * 4; e < E; e += 1024) {
-            f32x4_t s = load4<T>(dout + i * E + e);
-            for (int64_t j = i + 1; j < n; ++j)
-                if (ids[j] == id) s += load4<T>(dout + j * E + e);
-            store4<T>(dword + id * E + e, s);
+    const int e = threadIdx.x * 4;
+    for (int e0 = 0; e0 < E; e0 += 1024) {
+        const bool eok = e0 + e < E;
+        f32x4_t s = eok ? load4<T>(dout + i * E + e0 + e) : (f32x4_t){0.f, 0.f, 0.f, 0.f};
+        for (int64_t j0 = i + 1; j0 < n; j0 += 2048) {
+            if (threadIdx.x < 64) bits[threadIdx.x] = 0u;
+            __syncthreads();
+            bool mine[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const int off = k * 256 + threadIdx.x;
+                const int64_t j = j0 + off;
+                mine[k] = j < n && ids[j] == id;
+                if (mine[k]) atomicOr(&bits[off >> 5], 1u << (off & 31));
+            }
+            __syncthreads();
+            if (threadIdx.x == 0) {
+                int acc = 0;
+                for (int w = 0; w < 64; ++w) { pref[w] = acc; acc += __builtin_popcount(bits[w]); }
+                pref[64] = acc;
+            }
+            __syncthreads();
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const int off = k * 256 + threadIdx.x;
+                if (mine[k]) list[pref[off >> 5] + __builtin_popcount(bits[off >> 5] & ((1u << (off & 31)) - 1u))] = off;
+            }
+            __syncthreads();
+            const int nocc = pref[64];
+            if (eok) {
+                const T* base = dout + j0 * E + e0 + e;
+                int k = 0;
+                for (; k + 4 <= nocc; k += 4) {
+                    const f32x4_t a0 = load4<T>(base + (int64_t)list[k] * E), a1 = load4<T>(base + (int64_t)list[k + 1] * E);
+                    const f32x4_t a2 = load4<T>(base + (int64_t)list[k + 2] * E), a3 = load4<T>(base + (int64_t)list[k + 3] * E);
+                    s += a0; s += a1; s += a2; s += a3;
+                }
+                for (; k < nocc; ++k) s += load4<T>(base + (int64_t)list[k] * E);
+            }
+            __syncthreads();
         }
-        return;
-    }
-    // positions ascending (the atomics above append in arbitrary order): tiny insertion sort by one thread
-    if (threadIdx.x == 0)
-        for (int a = 1; a < nocc; ++a) { const int v = occ[a]; int c = a - 1; while (c >= 0 && occ[c] > v) { occ[c + 1] = occ[c]; --c; } occ[c + 1] = v; }
-    __syncthreads();
-    for (int e = threadIdx.x * 4; e < E; e += 1024) {
-        f32x4_t s = load4<T>(dout + i * E + e);
-        for (int k = 0; k < nocc; ++k) s += load4<T>(dout + (int64_t)occ[k] * E + e);
-        store4<T>(dword + id * E + e, s);
+        if (eok) store4<T>(dword + id * E + e0 + e, s);
     }
 }
 

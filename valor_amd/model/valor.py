@@ -475,26 +475,32 @@ class VALOR(nn.Module):
             kv_layers = self.project_cross_kv(va)
             ranges = {"tva": (0, Sv + Sa), "tv": (0, Sv), "ta": (Sv, Sa)}
 
-        if caption_task:                                                          # pretrain.py:419-481
-            txt_input, txt_labels = self.text_masker(txt, 0.6)
-            groups = [g for g in ("tva", "tv", "ta") if g in caption_task]
-            prompt = self.get_task_prompt(PROMPTS["caption"], bs) if self.use_task_prompt else None
-            loss = self._decoder_groups(txt_input, txt_labels, groups, prompt, True, kv_layers, ranges, bs, compute_loss, "caption", out)
-            if compute_loss:
-                out["caption_loss"] = loss
-            else:
-                out["txt_labels_caption"] = txt_labels
+        # host side first, in the reference's order (the masker consumes the python RNG: caption :428, then mlm :488)
+        cap_in = cap_lab = mlm_in = mlm_lab = None
+        if caption_task:
+            cap_in, cap_lab = self.text_masker(txt, 0.6)
+        if mlm_task:
+            mlm_in, mlm_lab = self.text_masker(txt, 0.15)
+        # device passes: mlm BEFORE caption, so that in backward (reverse order) the big caption pass produces the shared
+        # K/V gradient buffers and the small mlm pass accumulates into them (ops.GradSlot)
         if mlm_task:                                                              # pretrain.py:483-535
-            txt_input, txt_labels = self.text_masker(txt, 0.15)
             losses = []
             for g in ("tva", "tv", "ta"):
                 if g in mlm_task:
                     prompt = self.get_task_prompt(PROMPTS["mlm_" + g], bs)
-                    l = self._decoder_groups(txt_input, txt_labels, [g], prompt, False, kv_layers, ranges, bs, compute_loss, "mlm", out)
+                    l = self._decoder_groups(mlm_in, mlm_lab, [g], prompt, False, kv_layers, ranges, bs, compute_loss, "mlm", out)
                     if l is not None:
                         losses.append(l)
             if compute_loss:
                 out["mlm_loss"] = sum(losses) / len(losses)
             else:
-                out["txt_labels_mlm"] = txt_labels
+                out["txt_labels_mlm"] = mlm_lab
+        if caption_task:                                                          # pretrain.py:419-481
+            groups = [g for g in ("tva", "tv", "ta") if g in caption_task]
+            prompt = self.get_task_prompt(PROMPTS["caption"], bs) if self.use_task_prompt else None
+            loss = self._decoder_groups(cap_in, cap_lab, groups, prompt, True, kv_layers, ranges, bs, compute_loss, "caption", out)
+            if compute_loss:
+                out["caption_loss"] = loss
+            else:
+                out["txt_labels_caption"] = cap_lab
         return out
