@@ -138,12 +138,16 @@ def main():
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0")) % max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.distributed.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        backend = os.environ.get("VALOR_DIST_BACKEND", "nccl")      # "gloo" only to exercise the DP path where RCCL cannot run
+        if backend == "nccl":
+            torch.distributed.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            torch.distributed.init_process_group(backend, rank=rank, world_size=world)
 
     from valor_amd import synth
     from valor_amd.engine import TrainEngine

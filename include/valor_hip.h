@@ -71,6 +71,9 @@ int valor_bdrln_bwd(void* stream, int dtype, const void* dy, const void* dz_in, 
                     float* part_dbias, int64_t rows, int cols, float p_drop, uint64_t seed, uint64_t offset);
 int valor_colsum_finalize(void* stream, int dtype, const float* part, int nparts, int cols, void* out, int out_f32,
                           int accumulate);
+/* up to three finalizations in ONE launch (NULL part = skip): dgamma / dbeta / dbias of valor_bdrln_bwd */
+int valor_colsum_finalize3(void* stream, int dtype, const float* part0, void* out0, int acc0, const float* part1, void* out1,
+                           int acc1, const float* part2, void* out2, int acc2, int nparts, int cols);
 /* out[cols] (+)= column sums of x[rows, cols] (ld): nn.Linear bias gradients. part: fp32 [valor_ln_part_blocks()*cols]. */
 int valor_colsum(void* stream, int dtype, const void* x, int64_t rows, int cols, int64_t ld, float* part, void* out,
                  int out_f32, int accumulate);

@@ -259,6 +259,39 @@ __global__ __launch_bounds__(256) void colsum_finalize_kernel(const float* part,
     }
 }
 
+// up to three finalizations in one launch (blockIdx.y selects the job): LayerNorm backward's dgamma / dbeta / dbias
+struct Fin3Args { const float* part[3]; void* out[3]; int acc[3]; int nparts, cols; };
+template <typename T>
+__global__ __launch_bounds__(256) void colsum_finalize3_kernel(Fin3Args a) {
+    __shared__ float red[16][17];
+    const int job = blockIdx.y;
+    const float* part = a.part[job];
+    if (!part) return;
+    const int cx = threadIdx.x & 15, ry = threadIdx.x >> 4;
+    const int c = blockIdx.x * 16 + cx;
+    const int cols = a.cols, nparts = a.nparts;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    if (c < cols) {
+        int i = ry;
+        for (; i + 48 < nparts; i += 64) {
+            s0 += part[(int64_t)i * cols + c];
+            s1 += part[(int64_t)(i + 16) * cols + c];
+            s2 += part[(int64_t)(i + 32) * cols + c];
+            s3 += part[(int64_t)(i + 48) * cols + c];
+        }
+        for (; i < nparts; i += 16) s0 += part[(int64_t)i * cols + c];
+    }
+    red[ry][cx] = (s0 + s1) + (s2 + s3);
+    __syncthreads();
+    if (ry == 0 && c < cols) {
+        float s = 0.f;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) s += red[j][cx];
+        T* o = (T*)a.out[job];
+        o[c] = from_f32<T>((a.acc[job] ? to_f32<T>(o[c]) : 0.f) + s);
+    }
+}
+
 // column sums of X[rows, cols] (ld) -> partial[LN_PART_BLOCKS][cols]; used for linear-bias grads
 // (autograd of nn.Linear bias: sum over tokens).
 template <typename T>
@@ -360,6 +393,21 @@ extern "C" int valor_colsum_finalize(void* stream, int dtype, const float* part,
         hipLaunchKernelGGL((colsum_finalize_kernel<bf16_t>), grid, dim3(256), 0, st, part, nparts, cols, out, out_f32, accumulate);
     else if (dtype == VALOR_DT_F32)
         hipLaunchKernelGGL((colsum_finalize_kernel<float>), grid, dim3(256), 0, st, part, nparts, cols, out, out_f32, accumulate);
+    else return VALOR_ERR_ARG;
+    return valor_launch_status();
+}
+
+extern "C" int valor_colsum_finalize3(void* stream, int dtype, const float* part0, void* out0, int acc0, const float* part1, void* out1,
+                                      int acc1, const float* part2, void* out2, int acc2, int nparts, int cols) {
+    if (cols <= 0 || (!part0 && !part1 && !part2)) return VALOR_OK;
+    if ((part0 && !out0) || (part1 && !out1) || (part2 && !out2)) return VALOR_ERR_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    Fin3Args a;
+    a.part[0] = part0; a.part[1] = part1; a.part[2] = part2; a.out[0] = out0; a.out[1] = out1; a.out[2] = out2;
+    a.acc[0] = acc0; a.acc[1] = acc1; a.acc[2] = acc2; a.nparts = nparts; a.cols = cols;
+    dim3 grid((cols + 15) / 16, 3);
+    if (dtype == VALOR_DT_BF16) hipLaunchKernelGGL((colsum_finalize3_kernel<bf16_t>), grid, dim3(256), 0, st, a);
+    else if (dtype == VALOR_DT_F32) hipLaunchKernelGGL((colsum_finalize3_kernel<float>), grid, dim3(256), 0, st, a);
     else return VALOR_ERR_ARG;
     return valor_launch_status();
 }

@@ -118,18 +118,17 @@ def bdrln_bwd(dy, dz_in, z, mean, rstd, gamma, *, p_drop=0.0, seed=0, offset=0, 
     lib.call("valor_bdrln_bwd", _stream(), dt_of(ref), _ptr(dy), _ptr(dz_in), _ptr(z), _ptr(mean), _ptr(rstd),
              _ptr(gamma), _ptr(dx), _ptr(dres), _ptr(pg), _ptr(pb), _ptr(px), rows, cols, float(p_drop), int(seed),
              int(offset))
-    outs = []
+    outs, args = [], []
     for part, sink in zip((pg, pb, px), sinks):
         if part is None:
-            outs.append(None)
-            continue
-        if sink is not None:
-            lib.call("valor_colsum_finalize", _stream(), dt_of(ref), _ptr(part), nb, cols, _ptr(sink), 0, 1)
-            outs.append(None)
-            continue
-        o = torch.empty(cols, dtype=ref.dtype, device=ref.device)
-        lib.call("valor_colsum_finalize", _stream(), dt_of(ref), _ptr(part), nb, cols, _ptr(o), 0, 0)
-        outs.append(o)
+            outs.append(None); args += [0, 0, 0]
+        elif sink is not None:
+            outs.append(None); args += [_ptr(part), _ptr(sink), 1]
+        else:
+            o = torch.empty(cols, dtype=ref.dtype, device=ref.device)
+            outs.append(o); args += [_ptr(part), _ptr(o), 0]
+    if any(a for a in args[0::3]):
+        lib.call("valor_colsum_finalize3", _stream(), dt_of(ref), *args, nb, cols)
     return dx, dres, outs[0], outs[1], outs[2]
 
 

@@ -59,7 +59,7 @@ class TokenMasker:
                     if tokens[i][j] != 0 and random.random() < mask_prob:
                         ind[i][j] = 1
         labels = -np.ones(tokens.shape, dtype=np.int64)
-        choices = list(range(*self.range))
+        choices = range(*self.range)         # random.choice(range) draws exactly like random.choice(list(range))
         for i in range(tokens.shape[0]):
             for j in range(tokens.shape[1]):
                 if ind[i][j] == 1:
@@ -401,6 +401,16 @@ class VALOR(nn.Module):
         out = {}
         col = self.collect
         txt_tokens = batch.get("txt_tokens")
+        # Host-side token masking FIRST, in the reference's order (the masker consumes the python RNG: caption
+        # pretrain.py:428, then mlm :488; nothing else on this path does). Done before any kernel of this step is queued,
+        # its Python loops overlap the GPU's tail of the previous step instead of draining the pipeline mid-forward.
+        cap_in = cap_lab = mlm_in = mlm_lab = None
+        if caption_task or mlm_task:
+            txt = txt_tokens["bert_tokens"].cpu()
+            if caption_task:
+                cap_in, cap_lab = self.text_masker(txt, 0.6)
+            if mlm_task:
+                mlm_in, mlm_lab = self.text_masker(txt, 0.15)
         alltasks = "".join(mlm_task + caption_task + contra_task)
         video_output = audio_output = txt_output = None
         if "v" in alltasks:
@@ -475,12 +485,6 @@ class VALOR(nn.Module):
             kv_layers = self.project_cross_kv(va)
             ranges = {"tva": (0, Sv + Sa), "tv": (0, Sv), "ta": (Sv, Sa)}
 
-        # host side first, in the reference's order (the masker consumes the python RNG: caption :428, then mlm :488)
-        cap_in = cap_lab = mlm_in = mlm_lab = None
-        if caption_task:
-            cap_in, cap_lab = self.text_masker(txt, 0.6)
-        if mlm_task:
-            mlm_in, mlm_lab = self.text_masker(txt, 0.15)
         # device passes: mlm BEFORE caption, so that in backward (reverse order) the big caption pass produces the shared
         # K/V gradient buffers and the small mlm pass accumulates into them (ops.GradSlot)
         if mlm_task:                                                              # pretrain.py:483-535
