@@ -152,7 +152,7 @@ def _bsr(t):
     return t.stride(0), t.stride(1)
 
 
-def attn_fwd(q, k, v, n_heads, *, mask=None, kv_range=None, kv_bmod=0, scale=None, p_drop=0.0, seed=0, offset=0):
+def attn_fwd(q, k, v, n_heads, *, mask=None, kv_range=None, kv_bmod=0, scale=None, p_drop=0.0, seed=0, offset=0, o=None, lse=None):
     """q: [B,Sq,H*64] view, k/v: [Bkv,Skv,H*64] views (unit inner stride). Returns (o [B,Sq,H*64], lse [B,H,Sq])."""
     _check_gpu(q, k, v, mask, kv_range)
     B, Sq, E = q.shape
@@ -160,8 +160,11 @@ def attn_fwd(q, k, v, n_heads, *, mask=None, kv_range=None, kv_bmod=0, scale=Non
     assert E == n_heads * 64, "head_dim is fixed at 64"
     if scale is None:
         scale = 0.125
-    o = torch.empty((B, Sq, E), dtype=q.dtype, device=q.device)
-    lse = torch.empty((B, n_heads, Sq), dtype=torch.float32, device=q.device)
+    if o is None:
+        o = torch.empty((B, Sq, E), dtype=q.dtype, device=q.device)
+    if lse is None:
+        lse = torch.empty((B, n_heads, Sq), dtype=torch.float32, device=q.device)
+    assert o.shape == (B, Sq, E) and lse.shape == (B, n_heads, Sq) and lse.is_contiguous()
     qb, qr = _bsr(q); kb, kr = _bsr(k); vb, vr = _bsr(v); ob, orr = _bsr(o)
     mb = mr = 0
     if mask is not None:

@@ -380,6 +380,61 @@ class VALOR(nn.Module):
             out[f"{tag}_scores_{g}"] = scores[gi * n:(gi + 1) * n]
         return None
 
+    def _decoder_fused(self, passes, kv_layers, ranges, b):
+        """Training path: ALL decoder passes (caption groups, every mlm group) as one row-batched stack -- every GEMM /
+        LayerNorm of a BertLayer (bert.py:440-496) runs once on the concatenated rows; self- and cross-attention run per
+        pass on row segments. passes = [(tag, txt_input, txt_labels, groups, prompt_cpu, casual)]. Returns {tag: [loss]}."""
+        P, H, E = self.P, self.spec.heads, self.spec.hidden
+        p = self.p_drop if self.training else 0.0
+        xs, ssegs, xsegs, idxs, labs, seg_rows, r0 = [], [], [], [], [], [], 0
+        for (tag, txt_input, txt_labels, groups, prompt_cpu, casual) in passes:
+            G, T = len(groups), txt_input.shape[1]
+            x = self._bert_embed(self._dev(txt_input), T, None)
+            if prompt_cpu is not None:
+                x = torch.cat((x, self._bert_embed(self._dev(prompt_cpu), prompt_cpu.shape[1], "prompt")), dim=1)
+            Ttot = x.shape[1]
+            mask = self._dev(self._bert_mask(txt_input, prompt_cpu, casual))
+            if G > 1:
+                x = x.repeat(G, 1, 1)
+                mask = mask.repeat(G, 1, 1)
+            Bp = G * b
+            ssegs.append((r0, Bp, Ttot, mask))
+            if kv_layers is not None:
+                kvr = self._dev(torch.tensor([list(ranges[g]) for g in groups for _ in range(b)], dtype=torch.int32))
+                xsegs.append((r0, Bp, Ttot, kvr, b))
+            sel = (txt_labels != -1)
+            bi, tj = sel.nonzero(as_tuple=True)
+            idxs.append(torch.cat([r0 + (g * b + bi) * Ttot + tj for g in range(G)]))
+            labs.append(txt_labels[sel].repeat(G))
+            seg_rows.append(G * bi.numel())
+            xs.append(x.reshape(-1, E))
+            r0 += Bp * Ttot
+        # the bigger pass first: in backward it writes the shared dK|dV buffer, the others accumulate into it
+        X = torch.cat(xs, dim=0) if len(xs) > 1 else xs[0]
+        for i in range(self.spec.layers):
+            q = f"multimodal_encoder.encoder.layer.{i}."
+            qkv = ops.linear(X, P[q + "attention.self.qkv.weight"], P[q + "attention.self.qkv.bias"])
+            a = ops.seg_self_attention(qkv, H, ssegs, p)
+            o = ops.linear(a, P[q + "attention.output.dense.weight"], None)
+            X = ops.bias_dropout_residual_ln(o, P[q + "attention.output.dense.bias"], X, P[q + "attention.output.LayerNorm.weight"],
+                                             P[q + "attention.output.LayerNorm.bias"], 1e-12, p, False)
+            if kv_layers is not None:
+                cq = ops.linear(X, P[q + "cross_attn.cross.query.weight"], P[q + "cross_attn.cross.query.bias"])
+                c = ops.seg_cross_attention(cq, kv_layers[i], H, xsegs, p)
+                o = ops.linear(c, P[q + "cross_attn.output.dense.weight"], None)
+                X = ops.bias_dropout_residual_ln(o, P[q + "cross_attn.output.dense.bias"], X, P[q + "cross_attn.output.LayerNorm.weight"],
+                                                 P[q + "cross_attn.output.LayerNorm.bias"], 1e-12, p, False)
+            m = ops.mlp(X, P[q + "intermediate.dense.weight"], P[q + "intermediate.dense.bias"], P[q + "output.dense.weight"], None, ACT_GELU_ERF)
+            X = ops.bias_dropout_residual_ln(m, P[q + "output.dense.bias"], X, P[q + "output.LayerNorm.weight"], P[q + "output.LayerNorm.bias"], 1e-12, p, False)
+        rows = ops.gather_rows(X, self._dev(torch.cat(idxs)))
+        h = self.cls_transform(rows)
+        losses = ops.decoder_xent_segments(h, P["multimodal_encoder.embeddings.word_embeddings.weight"], P["cls.decoder.bias"],
+                                           self._dev(torch.cat(labs)), seg_rows)
+        res = {}
+        for (tag, *_), l in zip(passes, losses):
+            res.setdefault(tag, []).append(l)
+        return res
+
     # ------------------------------------------------------------------ the hot path
     def forward(self, batch, task, compute_loss=True):
         if task.startswith("pt"):
@@ -485,26 +540,32 @@ class VALOR(nn.Module):
             kv_layers = self.project_cross_kv(va)
             ranges = {"tva": (0, Sv + Sa), "tv": (0, Sv), "ta": (Sv, Sa)}
 
-        # device passes: mlm BEFORE caption, so that in backward (reverse order) the big caption pass produces the shared
-        # K/V gradient buffers and the small mlm pass accumulates into them (ops.GradSlot)
+        if compute_loss:
+            # training: every decoder pass row-batched into one stack (caption groups first: the biggest segment)
+            passes = []
+            if caption_task:
+                groups = [g for g in ("tva", "tv", "ta") if g in caption_task]
+                prompt = self.get_task_prompt(PROMPTS["caption"], bs) if self.use_task_prompt else None
+                passes.append(("caption", cap_in, cap_lab, groups, prompt, True))
+            for g in ("tva", "tv", "ta"):
+                if g in mlm_task:
+                    passes.append(("mlm", mlm_in, mlm_lab, [g], self.get_task_prompt(PROMPTS["mlm_" + g], bs), False))
+            res = self._decoder_fused(passes, kv_layers, ranges, bs)
+            if "caption" in res:
+                out["caption_loss"] = res["caption"][0]                                  # pretrain.py:473-479
+            if "mlm" in res:
+                out["mlm_loss"] = sum(res["mlm"]) / len(res["mlm"])                      # pretrain.py:524-532
+            return out
+        # evaluation (compute_loss=False, pretrain.py:445-446,499-500): per-pass scores
         if mlm_task:                                                              # pretrain.py:483-535
-            losses = []
             for g in ("tva", "tv", "ta"):
                 if g in mlm_task:
                     prompt = self.get_task_prompt(PROMPTS["mlm_" + g], bs)
-                    l = self._decoder_groups(mlm_in, mlm_lab, [g], prompt, False, kv_layers, ranges, bs, compute_loss, "mlm", out)
-                    if l is not None:
-                        losses.append(l)
-            if compute_loss:
-                out["mlm_loss"] = sum(losses) / len(losses)
-            else:
-                out["txt_labels_mlm"] = mlm_lab
+                    self._decoder_groups(mlm_in, mlm_lab, [g], prompt, False, kv_layers, ranges, bs, False, "mlm", out)
+            out["txt_labels_mlm"] = mlm_lab
         if caption_task:                                                          # pretrain.py:419-481
             groups = [g for g in ("tva", "tv", "ta") if g in caption_task]
             prompt = self.get_task_prompt(PROMPTS["caption"], bs) if self.use_task_prompt else None
-            loss = self._decoder_groups(cap_in, cap_lab, groups, prompt, True, kv_layers, ranges, bs, compute_loss, "caption", out)
-            if compute_loss:
-                out["caption_loss"] = loss
-            else:
-                out["txt_labels_caption"] = cap_lab
+            self._decoder_groups(cap_in, cap_lab, groups, prompt, True, kv_layers, ranges, bs, False, "caption", out)
+            out["txt_labels_caption"] = cap_lab
         return out

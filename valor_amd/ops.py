@@ -349,6 +349,146 @@ def cross_attention(q, kv, n_heads, kv_range=None, kv_bmod=0, p_drop=0.0, grad_s
 
 
 # ------------------------------------------------------------------------------------------------
+# Row-batched decoder passes: several decoder passes (caption groups with T = 32, mlm with T = 42 ...) share the same
+# weights, so their rows are stacked into ONE [R, E] activation matrix for every GEMM / LayerNorm of the layer; only the
+# attention calls (different sequence length / mask / K-V ranges per pass) work on row segments of it, in place.
+class SegSelfAttnFn(Function):
+    """qkv2d [R, 3E]; segs = [(r0, B, T, mask), ...] with rows r0 .. r0+B*T of pass-major [B, T] layout."""
+
+    @staticmethod
+    def forward(ctx, qkv2d, n_heads, segs, p_drop):
+        R, E3 = qkv2d.shape
+        E = E3 // 3
+        o = torch.empty((R, E), dtype=qkv2d.dtype, device=qkv2d.device)
+        lses, rng = [], []
+        for (r0, B, T, mask) in segs:
+            seed = off = 0
+            if p_drop > 0:
+                seed, off = DropoutState.draw_elems(B * n_heads * T * T)
+            v3 = qkv2d[r0:r0 + B * T].view(B, T, E3)
+            lse = torch.empty((B, n_heads, T), dtype=torch.float32, device=qkv2d.device)
+            K.attn_fwd(v3[:, :, :E], v3[:, :, E:2 * E], v3[:, :, 2 * E:], n_heads, mask=mask, scale=1.0 / math.sqrt(64), p_drop=p_drop,
+                       seed=seed, offset=off, o=o[r0:r0 + B * T].view(B, T, E), lse=lse)
+            lses.append(lse); rng.append((seed, off))
+        ctx.save_for_backward(qkv2d, o, *lses)
+        ctx.cfg = (n_heads, segs, p_drop, rng)
+        return o
+
+    @staticmethod
+    def backward(ctx, do):
+        qkv2d, o, *lses = ctx.saved_tensors
+        n_heads, segs, p_drop, rng = ctx.cfg
+        E = qkv2d.shape[1] // 3
+        do = do.contiguous()
+        dqkv = torch.empty_like(qkv2d)
+        for (r0, B, T, mask), lse, (seed, off) in zip(segs, lses, rng):
+            v3 = qkv2d[r0:r0 + B * T].view(B, T, 3 * E)
+            d3 = dqkv[r0:r0 + B * T].view(B, T, 3 * E)
+            K.attn_bwd(v3[:, :, :E], v3[:, :, E:2 * E], v3[:, :, 2 * E:], o[r0:r0 + B * T].view(B, T, E), lse,
+                       do[r0:r0 + B * T].view(B, T, E), n_heads, dq=d3[:, :, :E], dk=d3[:, :, E:2 * E], dv=d3[:, :, 2 * E:],
+                       mask=mask, scale=1.0 / math.sqrt(64), p_drop=p_drop, seed=seed, offset=off)
+        return dqkv, None, None, None
+
+
+def seg_self_attention(qkv2d, n_heads, segs, p_drop=0.0):
+    return SegSelfAttnFn.apply(qkv2d, n_heads, segs, p_drop)
+
+
+class SegCrossAttnFn(Function):
+    """q2d [R, E]; kv [Bkv, Skv, 2E] shared; segs = [(r0, B, T, kv_range, kv_bmod), ...].  In backward the first segment
+    writes dK|dV and the others accumulate into the same buffer inside the kernel."""
+
+    @staticmethod
+    def forward(ctx, q2d, kv, n_heads, segs, p_drop):
+        R, E = q2d.shape
+        q2d = q2d.contiguous()
+        o = torch.empty((R, E), dtype=q2d.dtype, device=q2d.device)
+        lses, rng = [], []
+        for (r0, B, T, kv_range, kv_bmod) in segs:
+            seed = off = 0
+            if p_drop > 0:
+                seed, off = DropoutState.draw_elems(B * n_heads * T * kv.shape[1])
+            lse = torch.empty((B, n_heads, T), dtype=torch.float32, device=q2d.device)
+            K.attn_fwd(q2d[r0:r0 + B * T].view(B, T, E), kv[:, :, :E], kv[:, :, E:], n_heads, kv_range=kv_range, kv_bmod=kv_bmod,
+                       scale=1.0 / math.sqrt(64), p_drop=p_drop, seed=seed, offset=off, o=o[r0:r0 + B * T].view(B, T, E), lse=lse)
+            lses.append(lse); rng.append((seed, off))
+        ctx.save_for_backward(q2d, kv, o, *lses)
+        ctx.cfg = (n_heads, segs, p_drop, rng)
+        return o
+
+    @staticmethod
+    def backward(ctx, do):
+        q2d, kv, o, *lses = ctx.saved_tensors
+        n_heads, segs, p_drop, rng = ctx.cfg
+        E = q2d.shape[1]
+        do = do.contiguous()
+        dq = torch.empty_like(q2d)
+        dkv = torch.empty_like(kv)
+        for i, ((r0, B, T, kv_range, kv_bmod), lse, (seed, off)) in enumerate(zip(segs, lses, rng)):
+            sl = slice(r0, r0 + B * T)
+            K.attn_bwd(q2d[sl].view(B, T, E), kv[:, :, :E], kv[:, :, E:], o[sl].view(B, T, E), lse, do[sl].view(B, T, E), n_heads,
+                       dq=dq[sl].view(B, T, E), dk=dkv[:, :, :E], dv=dkv[:, :, E:], kv_range=kv_range, kv_bmod=kv_bmod,
+                       scale=1.0 / math.sqrt(64), p_drop=p_drop, seed=seed, offset=off, accumulate_kv=i > 0)
+        return dq, dkv, None, None, None
+
+
+def seg_cross_attention(q2d, kv, n_heads, segs, p_drop=0.0):
+    return SegCrossAttnFn.apply(q2d, kv, n_heads, segs, p_drop)
+
+
+class DecoderXentSegFn(Function):
+    """per-segment mean CE over ONE tied-decoder GEMM: rows of segment i are h[sum(n[:i]) : sum(n[:i+1])]; returns one
+    loss per segment (caption / mlm passes share the prediction head, modeling.py:245-254, pretrain.py:444,498)."""
+
+    @staticmethod
+    def forward(ctx, h, w_emb, dec_bias, labels, seg_rows):
+        n, V = h.shape[0], w_emb.shape[0]
+        Vpad = (V + 31) // 32 * 32
+        buf = torch.empty((n, Vpad), dtype=h.dtype, device=h.device)
+        K.gemm(h, w_emb, bias=dec_bias, out=buf[:, :V])
+        loss_rows = torch.empty(n, dtype=torch.float32, device=h.device)
+        lse = torch.empty(n, dtype=torch.float32, device=h.device)
+        lib.call("valor_xent_fwd", _st(), _dt(h), _p(buf), _p(labels), _p(loss_rows), _p(lse), n, V, Vpad)
+        losses, r0 = [], 0
+        for nr in seg_rows:
+            l = torch.empty((), dtype=torch.float32, device=h.device)
+            lib.call("valor_mean_f32", _st(), _p(loss_rows[r0:r0 + nr]), nr, _p(l))
+            losses.append(l); r0 += nr
+        ctx.save_for_backward(h, w_emb, labels, lse, buf)
+        ctx.V, ctx.seg_rows = V, tuple(seg_rows)
+        ctx.params = (w_emb, dec_bias)
+        return tuple(losses)
+
+    @staticmethod
+    def backward(ctx, *dlosses):
+        h, w_emb, labels, lse, buf = ctx.saved_tensors
+        V, Vpad = ctx.V, buf.shape[1]
+        r0 = 0
+        for nr, dl in zip(ctx.seg_rows, dlosses):
+            g = dl.to(torch.float32).contiguous() if dl is not None else torch.zeros((), dtype=torch.float32, device=h.device)
+            lib.call("valor_xent_bwd", _st(), _dt(h), _p(buf[r0:r0 + nr]), _p(labels[r0:r0 + nr]), _p(lse[r0:r0 + nr]), _p(g), 1.0 / nr,
+                     nr, V, Vpad)
+            r0 += nr
+        dlog = buf[:, :V]
+        dh = K.gemm(dlog, w_emb, trans_b=True)
+        pw, pb = ctx.params
+        sw, sb = _sink(pw), _sink(pb)
+        if sw is not None:
+            K.gemm(dlog, h, trans_a=True, trans_b=True, out=sw, accumulate=True); _sunk(pw); dw = None
+        else:
+            dw = K.gemm(dlog, h, trans_a=True, trans_b=True)
+        if sb is not None:
+            K.colsum(dlog, out=sb, accumulate=True); _sunk(pb); db = None
+        else:
+            db = K.colsum(dlog)
+        return dh, dw, db, None, None
+
+
+def decoder_xent_segments(h, w_emb, dec_bias, labels, seg_rows):
+    return DecoderXentSegFn.apply(h, w_emb, dec_bias, labels, seg_rows)
+
+
+# ------------------------------------------------------------------------------------------------
 class DecoderXentFn(Function):
     """loss = mean CE(h W_emb^T + b, labels): tied-decoder GEMM (modeling.py:253, weight = word embeddings
     :241) + fused softmax cross-entropy (pretrain.py:444). Logits live in a zero-padded [n, Vpad] buffer that
