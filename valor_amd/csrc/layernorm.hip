@@ -25,7 +25,7 @@
 #include "common.h"
 
 #define LN_MAX_V 8          // 4-element vectors per lane: cols <= 64*4*8 = 2048
-#define LN_PART_BLOCKS 512  // fixed workgroup count of the backward / colsum partial stage
+#define LN_PART_BLOCKS 1024  // fixed workgroup count of the backward / colsum partial stage
 
 struct LnArgs {
     const void* x; const void* bias; const void* residual; const void* gamma; const void* beta;
