@@ -41,11 +41,15 @@ extern "C" {
  * modeling.py:249-253; pretrain.py:36-38,90-91.  transX=0: X(row,k)=X[row*ldx+k]; transX=1: X(row,k)=X[k*ldx+row].
  * epilogue: + bias[N]; optional copy of the pre-activation to `preact`; act; or multiply by act'(dact_aux) (backward of a
  * fused activation); C += result when `accumulate`; out_f32 stores C/preact as fp32 for bf16 inputs.
- * workspace: fp32 scratch for split-K partial tiles (may be NULL = no split-K). */
+ * workspace: fp32 scratch for split-K partial tiles (may be NULL = no split-K).
+ * rowsum_out (may be NULL): [M] values of C's element type, the sums over k of op(A) -- the bias gradient of a wgrad GEMM (sum over tokens of dY) computed on
+ * the matrix pipe beside the GEMM instead of a separate pass over dY; only where valor_gemm_kernel_for() returns 3 and
+ * transA = 1 (VALOR_ERR_ARG otherwise). */
 int valor_gemm(void* stream, int dtype, int transA, int transB, int M, int N, int K, const void* A, int64_t lda,
                const void* B, int64_t ldb, void* C, int64_t ldc, const void* bias, int act, void* preact,
                const void* dact_aux, int64_t ldaux, float alpha, int accumulate, int out_f32, void* workspace,
-               int64_t workspace_bytes);
+               int64_t workspace_bytes, void* rowsum_out,
+               int rowsum_accumulate);
 
 /* selects the bf16 kernel of valor_gemm: 0 = register-staged 128x128 tiles, 1 = LDS-DMA (buffer_load ... lds) 128x128
  * single stage, 2 = LDS-DMA 128x128 double stage, 3 = 256x256 8-phase pipeline wherever eligible, 4 = measured per-shape

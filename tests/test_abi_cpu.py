@@ -50,8 +50,8 @@ def test_argument_validation_without_gpu():
     """entry points validate arguments before touching the device (callable on a CPU-only host)."""
     from valor_amd import lib
     so = lib.load()
-    assert so.valor_gemm(None, 0, 0, 0, 4, 4, 8, None, 8, None, 8, None, 4, None, 0, None, None, 0, 1.0, 0, 0, None, 0) == -1
-    assert so.valor_gemm(None, 0, 0, 0, 0, 4, 8, None, 8, None, 8, None, 4, None, 0, None, None, 0, 1.0, 0, 0, None, 0) == 0   # M = 0: no-op
+    assert so.valor_gemm(None, 0, 0, 0, 4, 4, 8, None, 8, None, 8, None, 4, None, 0, None, None, 0, 1.0, 0, 0, None, 0, None, 0) == -1
+    assert so.valor_gemm(None, 0, 0, 0, 0, 4, 8, None, 8, None, 8, None, 4, None, 0, None, None, 0, 1.0, 0, 0, None, 0, None, 0) == 0   # M = 0: no-op
     assert so.valor_bdrln_fwd(None, 0, None, None, None, None, None, None, None, None, None, 4, 768, 1e-5, 0.0, 0, 0) == -1
 
 

@@ -81,6 +81,31 @@ def test_gemm_families(dev, gemm_variant, variant):
     assert _rel(C2, Ab[:, :Kd].double() @ Bt.double()) < 6e-3
 
 
+def test_gemm_fused_rowsum(dev, gemm_variant):
+    """bias gradient beside the wgrad GEMM (valor_gemm's rowsum_out): sum over tokens of dY computed on the matrix pipe in the
+    8-phase k-slow kernel, with and without split-K, plain and accumulating, fp32 and bf16 outputs; refused elsewhere."""
+    from valor_amd import kernels as K, lib
+    gemm_variant.valor_gemm_set_variant(3)
+    for (M, N, Kd) in [(768, 768, 4096), (3072, 768, 12608), (520, 264, 192), (256, 3072, 1024)]:
+        dY, X = _mk((Kd, M), 11, dev), _mk((Kd, N), 12, dev)
+        assert K.gemm_fuses_rowsum(dY, X, True, True)
+        ref = dY.double().sum(0)
+        for sk, odt in itertools.product((False, True), (torch.float32, torch.bfloat16)):
+            rs = torch.full((M,), 2.0, dtype=odt, device=dev)
+            C = K.gemm(dY, X, trans_a=True, trans_b=True, splitk=sk, out_dtype=odt, rowsum_out=rs, rowsum_accumulate=True)
+            assert _rel(C, dY.double().t() @ X.double()) < 6e-3
+            tol = 2e-5 if odt == torch.float32 else 6e-3
+            assert _rel(rs, ref + 2.0) < tol, (M, N, Kd, sk, odt, _rel(rs, ref + 2.0))
+            rs2 = torch.full((M,), float("nan"), dtype=odt, device=dev)
+            K.gemm(dY, X, trans_a=True, trans_b=True, splitk=sk, out_dtype=odt, rowsum_out=rs2)
+            assert _rel(rs2, ref) < tol
+    gemm_variant.valor_gemm_set_variant(1)
+    dY, X = _mk((4096, 768), 11, dev), _mk((4096, 768), 12, dev)
+    assert not K.gemm_fuses_rowsum(dY, X, True, True)
+    with pytest.raises(lib.ValorHipError):
+        K.gemm(dY, X, trans_a=True, trans_b=True, rowsum_out=torch.zeros(768, dtype=torch.bfloat16, device=dev))
+
+
 @pytest.mark.parametrize("variant", [0, 3])
 def test_attention_families_self(dev, attn_variant, variant):
     from valor_amd import kernels as K

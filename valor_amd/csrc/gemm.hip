@@ -414,6 +414,13 @@ __global__ __launch_bounds__(256) void gemm_splitk_reduce(GemmArgs p) {
         }
         epilogue_store<T>(p, m, n, s, load_bias4<T>(p, n));
     }
+    if (p.rowsum_out) {      // fused bias gradient: sum the K-slices' row sums
+        for (int m = blockIdx.x * blockDim.x + threadIdx.x; m < p.M; m += gridDim.x * blockDim.x) {
+            float t = 0.f;
+            for (int k = 0; k < p.kslices; ++k) t += p.rowsum_ws[(int64_t)k * p.M + m];
+            rowsum_store<T>(p, m, t);
+        }
+    }
 }
 
 // kernel variant of the bf16 path: 0 = register-staged (gemm_kernel), 1 = LDS-DMA single stage, 2 = LDS-DMA double stage
@@ -507,8 +514,11 @@ static int launch_gemm(hipStream_t st, int transA, int transB, GemmArgs p) {
 extern "C" int valor_gemm(void* stream, int dtype, int transA, int transB, int M, int N, int K,
                           const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc,
                           const void* bias, int act, void* preact, const void* dact_aux, int64_t ldaux,
-                          float alpha, int accumulate, int out_f32, void* workspace, int64_t workspace_bytes) {
+                          float alpha, int accumulate, int out_f32, void* workspace, int64_t workspace_bytes,
+                          void* rowsum_out, int rowsum_accumulate) {
     if (M <= 0 || N <= 0) return VALOR_OK;
+    // fused row sums only exist in the 8-phase kernel with a k-slow A operand (ask valor_gemm_kernel_for first)
+    if (rowsum_out && !(transA && use_8ph(dtype, transA, transB, M, N, K))) return VALOR_ERR_ARG;
     if (K < 0 || !A || !B || !C) return VALOR_ERR_ARG;
     const int vec = dtype == VALOR_DT_BF16 ? 8 : 4;
     // 16-byte chunk loads: leading dims and bases must be chunk aligned
@@ -520,6 +530,7 @@ extern "C" int valor_gemm(void* stream, int dtype, int transA, int transB, int M
     p.lda = lda; p.ldb = ldb; p.ldc = ldc; p.ldaux = ldaux;
     p.M = M; p.N = N; p.K = K; p.act = act; p.accumulate = accumulate; p.out_f32 = out_f32;
     p.alpha = alpha;
+    p.rowsum_out = rowsum_out; p.rowsum_acc = rowsum_accumulate; p.rowsum_ws = nullptr;
     {
         const int64_t esz = dtype == VALOR_DT_BF16 ? 2 : 4;
         // direct: rows x ld with K valid in the last row; transposed: K rows of ld elements (caller guarantees
@@ -557,6 +568,10 @@ extern "C" int valor_gemm(void* stream, int dtype, int transA, int transB, int M
             if (sl > 64) sl = 64;
             while (sl > 1 && (int64_t)sl * M * N * 4 > workspace_bytes) --sl;
             if (sl >= 2) slices = sl;
+        }
+        if (rowsum_out && slices > 1) {      // room for the [slices][M] row-sum partials behind the tile partials
+            while (slices > 1 && ((int64_t)slices * M * N + (int64_t)slices * M) * 4 > workspace_bytes) --slices;
+            if (slices > 1) p.rowsum_ws = (float*)workspace + (int64_t)slices * M * N;
         }
         p.kslices = slices;
         p.ksteps_per_slice = (nk + slices - 1) / slices;     // trailing slices may be short or empty (they add zeros)

@@ -87,6 +87,12 @@ __global__ __launch_bounds__(512, 2) void gemm_8ph_kernel(GemmArgs p) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
 
+    // fused row sums of A (TA only): the tile column 0 workgroups add  ones . A^T  on the matrix pipe, one 16-row block per
+    // wave and row half (wave wn takes block mt = wn): 2 extra MFMAs in phases j0 and j2.
+    const bool do_rs = TA && p.rowsum_out != nullptr && tn == 0;
+    f32x4_t racc[2] = {(f32x4_t){0.f, 0.f, 0.f, 0.f}, (f32x4_t){0.f, 0.f, 0.f, 0.f}};
+    const bf16x8_t ones = __builtin_bit_cast(bf16x8_t, (u32x4_t){0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u});
+
     const rsrc_t rsA = make_rsrc(p.A, p.bytesA), rsB = make_rsrc(p.B, p.bytesB);
     // ---- DMA source offsets: half-tile kinds (A'0, A'1, B'0, B'1) x 2 pieces per wave (piece = wave*2 + i)
     int voA[2][2], voB[2][2];     // [half][i]
@@ -174,6 +180,15 @@ __global__ __launch_bounds__(512, 2) void gemm_8ph_kernel(GemmArgs p) {
                     acc[(MH_) * 4 + mt][(NH_) * 2 + nt] = Mma<T>::mma(FB_[nt][kk], fa[mt][kk], acc[(MH_) * 4 + mt][(NH_) * 2 + nt]); \
         __builtin_amdgcn_s_setprio(0);                                                                            \
     } while (0)
+#define ROWSUM(H_)                                                                                                \
+    do {                                                                                                          \
+        if (do_rs) {                                                                                              \
+            _Pragma("unroll") for (int kk = 0; kk < 2; ++kk) {                                                    \
+                const bf16x8_t f_ = wn == 0 ? fa[0][kk] : wn == 1 ? fa[1][kk] : wn == 2 ? fa[2][kk] : fa[3][kk];  \
+                racc[H_] = Mma<T>::mma(ones, f_, racc[H_]);                                                       \
+            }                                                                                                     \
+        }                                                                                                         \
+    } while (0)
 #define LOAD_END()                                                                                                \
     do {                                                                                                          \
         asm volatile("s_waitcnt vmcnt(8)" ::: "memory");                                                          \
@@ -205,6 +220,7 @@ __global__ __launch_bounds__(512, 2) void gemm_8ph_kernel(GemmArgs p) {
             issueB(1, nxt);
             LOAD_END();
             QUADRANT(0, 0, fb0);
+            ROWSUM(0);
             MATH_END();
             // ---- j1
             readB(cur + OFF_B1, fb1);
@@ -217,6 +233,7 @@ __global__ __launch_bounds__(512, 2) void gemm_8ph_kernel(GemmArgs p) {
             issueB(0, cur);
             LOAD_END();
             QUADRANT(1, 1, fb1);
+            ROWSUM(1);
             MATH_END();
             // ---- j3
             issueA(0, cur);
@@ -229,8 +246,19 @@ __global__ __launch_bounds__(512, 2) void gemm_8ph_kernel(GemmArgs p) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // drain the look-ahead loads before LDS is reused
     __syncthreads();
 #undef QUADRANT
+#undef ROWSUM
 #undef LOAD_END
 #undef MATH_END
+    if (do_rs && fg == 0) {     // racc[h][*] = sum_k A(m, k) for m = m0 + 128h + 64wm + 16wn + fr (every r / fg lane holds the same value)
+#pragma unroll
+        for (int hh = 0; hh < 2; ++hh) {
+            const int m = m0 + hh * 128 + wm * 64 + wn * 16 + fr;
+            if (m < p.M) {
+                if (p.kslices > 1) p.rowsum_ws[(int64_t)slice * p.M + m] = racc[hh][0];
+                else rowsum_store<T>(p, m, racc[hh][0]);
+            }
+        }
+    }
 
     // ---- epilogue: two passes (tile row halves mh) through LDS: 128 rows x 256 cols fp32 (swizzled 16-B chunks) ->
     // row-contiguous 16-byte bf16 stores.

@@ -17,6 +17,10 @@ struct GemmArgs {
     int ksteps_per_slice;
     float alpha;
     uint32_t bytesA, bytesB;   // extent of each operand for the buffer-descriptor range check
+    // fused row sums of op(A) (bias gradient of a wgrad GEMM: sum over tokens of dY), 8-phase k-slow-A kernels only
+    void* rowsum_out;          // [M], C's element type (fp32 when out_f32), or null
+    float* rowsum_ws;          // split-K partials [kslices][M] fp32
+    int rowsum_acc;            // out += sums
 };
 
 template <typename T>
@@ -29,6 +33,18 @@ DEVINL f32x4_t load_bias4(const GemmArgs& p, int n0) {
             if (n0 + r < p.N) b[r] = to_f32<T>(q[r]);
     }
     return b;
+}
+
+// one element of the fused row sums (bias gradient), in C's element type
+template <typename T>
+DEVINL void rowsum_store(const GemmArgs& p, int m, float v) {
+    if (p.out_f32) {
+        float* o = (float*)p.rowsum_out + m;
+        *o = (p.rowsum_acc ? *o : 0.f) + v;
+    } else {
+        T* o = (T*)p.rowsum_out + m;
+        *o = from_f32<T>((p.rowsum_acc ? to_f32<T>(*o) : 0.f) + v);
+    }
 }
 
 template <typename T>

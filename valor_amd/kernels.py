@@ -50,7 +50,7 @@ def _rowmajor(t):
 
 
 def gemm(a, b, *, trans_a=False, trans_b=False, bias=None, act=ACT_NONE, want_preact=False,
-         dact_aux=None, alpha=1.0, out=None, accumulate=False, out_dtype=None, splitk=True):
+         dact_aux=None, alpha=1.0, out=None, accumulate=False, out_dtype=None, splitk=True, rowsum_out=None, rowsum_accumulate=False):
     """C[M,N] = epi(alpha * op(A) . op(B)^T).  A: [M,K] ([K,M] if trans_a); B: [N,K] ([K,N] if trans_b)."""
     _check_gpu(a, b, bias, dact_aux, out)
     M, K = (a.shape[1], a.shape[0]) if trans_a else (a.shape[0], a.shape[1])
@@ -72,8 +72,18 @@ def gemm(a, b, *, trans_a=False, trans_b=False, bias=None, act=ACT_NONE, want_pr
     ws = workspace(a.device) if splitk else None
     lib.call("valor_gemm", _stream(), dt_of(a), int(trans_a), int(trans_b), M, N, K,
              _ptr(a), lda, _ptr(b), ldb, _ptr(out), ldc, _ptr(bias), act, _ptr(preact), _ptr(dact_aux), ldaux,
-             float(alpha), int(accumulate), out_f32, _ptr(ws), (ws.numel() * 4 if ws is not None else 0))
+             float(alpha), int(accumulate), out_f32, _ptr(ws), (ws.numel() * 4 if ws is not None else 0),
+             _ptr(rowsum_out), int(rowsum_accumulate))
     return (out, preact) if want_preact else out
+
+
+def gemm_fuses_rowsum(a, b, trans_a, trans_b):
+    """True if valor_gemm can produce the row sums of op(A) (bias gradient) beside this GEMM."""
+    if not (trans_a and a.dtype == torch.bfloat16):
+        return False
+    M, Kd = a.shape[1], a.shape[0]
+    N = b.shape[1] if trans_b else b.shape[0]
+    return lib.load().valor_gemm_kernel_for(DT_BF16, 1, int(trans_b), M, N, Kd) == 3
 
 
 def part_blocks():

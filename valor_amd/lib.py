@@ -21,7 +21,7 @@ _vp, _i, _i64, _u64, _f = _c.c_void_p, _c.c_int, _c.c_int64, _c.c_uint64, _c.c_f
 # name -> argtypes (restype is always int: 0 ok, <0 error)
 SIGNATURES = {
     "valor_gemm": [_vp, _i, _i, _i, _i, _i, _i, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _i, _vp, _vp, _i64,
-                   _f, _i, _i, _vp, _i64],
+                   _f, _i, _i, _vp, _i64, _vp, _i],
     "valor_gemm_set_variant": [_i],
     "valor_gemm_kernel_for": [_i, _i, _i, _i, _i, _i],
     "valor_ln_part_blocks": [],

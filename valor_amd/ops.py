@@ -120,15 +120,23 @@ class LinearFn(Function):
                 if slot is not None:
                     slot.buf = dx
         pw, pb = ctx.params
+        sb = _sink(pb) if (ctx.has_b and ctx.needs_input_grad[2]) else None
+        fused_b = False
         if ctx.needs_input_grad[1]:
             sw = _sink(pw)
             kw = dict(out=sw, accumulate=True) if sw is not None else {}
-            dw = K.gemm(x2, dy2, trans_a=True, trans_b=True, **kw) if ctx.w_is_kn else K.gemm(dy2, x2, trans_a=True, trans_b=True, **kw)
+            if ctx.w_is_kn:
+                dw = K.gemm(x2, dy2, trans_a=True, trans_b=True, **kw)
+            else:
+                if sb is not None and K.gemm_fuses_rowsum(dy2, x2, True, True):      # bias gradient on the matrix pipe beside dW
+                    kw.update(rowsum_out=sb, rowsum_accumulate=True); fused_b = True
+                dw = K.gemm(dy2, x2, trans_a=True, trans_b=True, **kw)
             if sw is not None:
                 dw = None; _sunk(pw)
         if ctx.has_b and ctx.needs_input_grad[2]:
-            sb = _sink(pb)
-            if sb is not None:
+            if fused_b:
+                _sunk(pb)
+            elif sb is not None:
                 K.colsum(dy2, out=sb, accumulate=True); _sunk(pb)
             else:
                 db = K.colsum(dy2)
@@ -161,25 +169,29 @@ class MlpFn(Function):
         du = K.gemm(dy2, w2, trans_b=True, act=ctx.act, dact_aux=u)
         pw1, pb1, pw2, pb2 = ctx.params
 
-        def wgrad(dyy, xx, pw):
+        def wgrad_bgrad(dyy, xx, pw, pb):
+            """dW (+ db fused on the matrix pipe where the kernel offers it), accumulated straight into the arena"""
             sw = _sink(pw)
+            sb = _sink(pb) if pb is not None else None
+            kw, fused = {}, False
+            if sb is not None and K.gemm_fuses_rowsum(dyy, xx, True, True):
+                kw.update(rowsum_out=sb, rowsum_accumulate=True); fused = True
             if sw is None:
-                return K.gemm(dyy, xx, trans_a=True, trans_b=True)
-            K.gemm(dyy, xx, trans_a=True, trans_b=True, out=sw, accumulate=True); _sunk(pw)
-            return None
-
-        def bgrad(dyy, pb):
-            sb = _sink(pb)
+                dw = K.gemm(dyy, xx, trans_a=True, trans_b=True, **kw)
+            else:
+                K.gemm(dyy, xx, trans_a=True, trans_b=True, out=sw, accumulate=True, **kw); _sunk(pw); dw = None
+            if pb is None:
+                return dw, None
+            if fused:
+                _sunk(pb); return dw, None
             if sb is None:
-                return K.colsum(dyy)
+                return dw, K.colsum(dyy)
             K.colsum(dyy, out=sb, accumulate=True); _sunk(pb)
-            return None
+            return dw, None
 
-        dw2 = wgrad(dy2, h, pw2)
-        db2 = bgrad(dy2, pb2) if pb2 is not None else None
+        dw2, db2 = wgrad_bgrad(dy2, h, pw2, pb2)
         dx = K.gemm(du, w1, trans_b=True).view(ctx.xshape) if ctx.needs_input_grad[0] else None
-        dw1 = wgrad(du, x2, pw1)
-        db1 = bgrad(du, pb1)
+        dw1, db1 = wgrad_bgrad(du, x2, pw1, pb1)
         return dx, dw1, db1, dw2, db2, None
 
 
