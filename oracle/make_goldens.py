@@ -1,5 +1,5 @@
 """TEST INFRASTRUCTURE: generate tests/golden/*.pt by running the UNMODIFIED reference (/root/reference)
-on CPU fp32 with seeded synthetic weights/inputs (valor_amd/synth.py), dropout 0. Run in the build
+on CPU fp32 with seeded synthetic weights/inputs (valor_amd/synth.py), dropout 0 (and VideoSwin drop-path 0). Run in the build
 container only:  python oracle/make_goldens.py
 Each fixture holds inputs' recipe (spec, seeds, shapes), the masked token tensors the reference's
 TokenMasker produced, losses, score matrices, argmax ids, activation slices, per-parameter gradient
@@ -26,10 +26,24 @@ SLICE_KEYS = ["clip_model.visual.transformer.resblocks.0.attn.in_proj_weight", "
               "text_fine_weight.0.weight", "video_frame_embedding", "clip_model.token_embedding.weight"]
 
 
-def run(name, batch_size, frames, audio_slices, wseed, bseed, mseed):
-    spec = synth.base_spec()
+SWIN_SLICE_KEYS = ["video_encoder.patch_embed.proj.weight", "video_encoder.layers.0.blocks.1.attn.relative_position_bias_table",
+                   "video_encoder.layers.2.blocks.17.attn.qkv.weight", "video_encoder.layers.1.downsample.reduction.weight",
+                   "video_encoder.layers.3.blocks.1.mlp.fc2.weight", "hidden_trans_video_multimodal.0.weight",
+                   "contra_head_v.linear.weight", "contra_head_t.linear.weight", "contra_temp",
+                   "audio_encoder.layer.11.ff_layer.linear2.weight", "multimodal_encoder.encoder.layer.0.cross_attn.cross.key.weight",
+                   "multimodal_encoder.embeddings.word_embeddings.weight", "cls.decoder.bias", "video_frame_embedding"]
+
+
+def run(name, batch_size, frames, audio_slices, wseed, bseed, mseed, variant="clip"):
+    global SLICE_KEYS
+    if variant == "swin":                  # scripts/pretrain.sh:3-8
+        spec = synth.swin_spec()
+        ropts = ref_harness.default_opts(video_encoder_type="videoswin_base_k400_22k", txt_encoder_type="bert_base_uncased")
+        SLICE_KEYS = SWIN_SLICE_KEYS
+    else:
+        spec, ropts = synth.base_spec(), None
     sd = synth.make_state_dict(spec, seed=wseed)
-    ref = ref_harness.build_reference(state_dict=sd, dropout=0.0)
+    ref = ref_harness.build_reference(ropts, state_dict=sd, dropout=0.0)
     batch = synth.make_batch(spec, batch=batch_size, frames=frames, audio_slices=audio_slices, txt_len=32, seed=bseed)
     g = {"recipe": dict(spec=spec.to_dict(), weight_seed=wseed, batch_seed=bseed, masker_seed=mseed, batch=batch_size,
                         frames=frames, audio_slices=audio_slices, txt_len=32, task=TASK)}
@@ -81,3 +95,4 @@ if __name__ == "__main__":
     assert ref_harness.available()
     run("ref_base_b2f2a1", batch_size=2, frames=2, audio_slices=1, wseed=50, bseed=51, mseed=50)
     run("ref_base_b3f1a2", batch_size=3, frames=1, audio_slices=2, wseed=7, bseed=8, mseed=9)
+    run("ref_swin_b2f2a1", batch_size=2, frames=2, audio_slices=1, wseed=50, bseed=51, mseed=50, variant="swin")

@@ -47,6 +47,7 @@ def _install():
 
 
 def default_opts(**over):
+    _install()
     from easydict import EasyDict
     o = dict(
         video_resolution=224, audio_melbins=64, audio_patch_size=16, audio_frame_shift=10, audio_target_length=512,
@@ -177,6 +178,8 @@ def build_reference(opts=None, state_dict=None, dropout=0.0):
     for m in model.modules():
         if isinstance(m, torch.nn.Dropout):
             m.p = dropout
+        if type(m).__name__ == "DropPath":          # videoswin.py:50-55 stochastic depth: off whenever dropout is off
+            m.drop_prob = m.drop_prob if dropout > 0 else 0.0
     return model
 
 

@@ -1,5 +1,5 @@
 """TEST INFRASTRUCTURE -- CPU oracle: a plain-PyTorch fp32 restatement of the reference VALOR
-pretraining step (CLIP-ViT variant). NOT product code: only tests/, __graft_entry__.smoke() and
+pretraining step (CLIP-ViT variant and VideoSwin + BERT-text variant). NOT product code: only tests/, __graft_entry__.smoke() and
 bench.py's cpu_baseline leg may import it. The product (valor_amd) never does.
 
 Every function cites the reference file:line it follows (/root/reference). The restatement is
@@ -39,10 +39,11 @@ def dropout(x, p, training=True):
 
 class Oracle:
     def __init__(self, spec, sd, *, dropout_p=0.0, use_task_prompt=False, contra_loss_ratio=1.0, vocab_tokens=None,
-                 masker_range=(106, None)):
+                 masker_range=(106, None), drop_path=0.0):
         self.spec = spec
         self.sd = sd
         self.p = dropout_p
+        self.drop_path = drop_path          # VideoSwin stochastic depth rate (videoswin.py:393,418); 0 for parity runs
         self.use_task_prompt = use_task_prompt
         self.contra_loss_ratio = contra_loss_ratio
         self.vocab = {t: i for i, t in enumerate(vocab_tokens)} if vocab_tokens is not None else None
@@ -101,8 +102,123 @@ class Oracle:
             x = self.clip_block(x, f"clip_model.transformer.resblocks.{i}.", sp.txt_heads, am)
         return layer_norm(x, w("clip_model.ln_final.weight"), w("clip_model.ln_final.bias"), 1e-5)
 
+    # ------------------------------------------------------------------------- VideoSwin
+    @staticmethod
+    def swin_windows(x, win):
+        """window_partition, model/videoswin.py:75-79: [B, D, H, W, C] -> [B*nW, wd*wh*ww, C] (window-major, d/h/w order inside)"""
+        B, D, H, W, C = x.shape
+        wd, wh, ww = win
+        x = x.reshape(B, D // wd, wd, H // wh, wh, W // ww, ww, C)
+        return x.permute(0, 1, 3, 5, 2, 4, 6, 7).reshape(-1, wd * wh * ww, C)
+
+    @staticmethod
+    def swin_unwindows(xw, win, B, D, H, W):
+        """window_reverse, model/videoswin.py:81-84"""
+        wd, wh, ww = win
+        x = xw.reshape(B, D // wd, H // wh, W // ww, wd, wh, ww, -1)
+        return x.permute(0, 1, 4, 2, 5, 3, 6, 7).reshape(B, D, H, W, -1)
+
+    @staticmethod
+    def swin_effective_window(size, window, shift):
+        """get_window_size, model/videoswin.py:86-99: a dim no larger than the window gets window = dim, shift = 0"""
+        win = tuple(s if s <= w else w for s, w in zip(size, window))
+        sh = tuple(0 if s <= w else f for s, w, f in zip(size, window, shift))
+        return win, sh
+
+    @staticmethod
+    def swin_shift_mask(size, win, shift):
+        """compute_mask, model/videoswin.py:272-285 -> [nW, N, N] additive 0 / -100. Region ids per dim: the three slices
+        [0, X-w), [X-w, X-s), [X-s, X) written in that order (a zero shift makes the last slice cover, and so relabel, the
+        whole dim); two tokens may attend to each other iff all three of their region ids agree."""
+        ids = []
+        for X, w, s_ in zip(size, win, shift):
+            r = torch.zeros(X, dtype=torch.long)
+            r[X - w:X - s_ if s_ > 0 else X - w] = 1
+            r[X - s_ if s_ > 0 else 0:] = 2
+            ids.append(r)
+        lab = (ids[0][:, None, None] * 9 + ids[1][None, :, None] * 3 + ids[2][None, None, :]).float()
+        lw = Oracle.swin_windows(lab[None, ..., None], win).squeeze(-1)
+        diff = lw[:, None, :] - lw[:, :, None]
+        return torch.where(diff != 0, torch.full_like(diff, -100.0), torch.zeros_like(diff))
+
+    def swin_attention(self, xw, p, heads, mask):
+        """WindowAttention3D.forward, model/videoswin.py:137-163. xw: [B*nW, N, C]"""
+        w = self.w
+        Bw, N, C = xw.shape
+        hd = C // heads
+        qkv = F.linear(xw, w(p + "qkv.weight"), w(p + "qkv.bias")).reshape(Bw, N, 3, heads, hd).permute(2, 0, 3, 1, 4)
+        q, k, v = qkv[0] * hd ** -0.5, qkv[1], qkv[2]
+        s = q @ k.transpose(-2, -1)
+        idx = w(p + "relative_position_index")[:N, :N].reshape(-1)
+        bias = w(p + "relative_position_bias_table")[idx].reshape(N, N, heads).permute(2, 0, 1)
+        s = s + bias[None]
+        if mask is not None:
+            nW = mask.shape[0]
+            s = (s.view(Bw // nW, nW, heads, N, N) + mask[None, :, None]).view(Bw, heads, N, N)
+        a = torch.softmax(s, dim=-1)
+        o = (a @ v).transpose(1, 2).reshape(Bw, N, C)
+        return F.linear(o, w(p + "proj.weight"), w(p + "proj.bias"))
+
+    def swin_drop_path(self, x, rate):
+        """drop_path, model/videoswin.py:40-49 (per-sample stochastic depth, training only)"""
+        if rate == 0.0:
+            return x
+        keep = 1.0 - rate
+        m = torch.floor(keep + torch.rand((x.shape[0],) + (1,) * (x.ndim - 1), dtype=x.dtype))
+        return x / keep * m
+
+    def swin_block(self, x, p, heads, window, shift, rate):
+        """SwinTransformerBlock3D.forward, model/videoswin.py:191-245. x: [B, D, H, W, C]. Sizes that need window padding
+        (videoswin.py:199-203) are not restated: 224 px inputs never pad."""
+        w = self.w
+        B, D, H, W, C = x.shape
+        win, sh = self.swin_effective_window((D, H, W), window, shift)
+        assert D % win[0] == 0 and H % win[1] == 0 and W % win[2] == 0, "window padding is not restated"
+        h = layer_norm(x, w(p + "norm1.weight"), w(p + "norm1.bias"), 1e-5)
+        mask = None
+        if any(sh):
+            h = torch.roll(h, shifts=(-sh[0], -sh[1], -sh[2]), dims=(1, 2, 3))
+            mask = self.swin_shift_mask((D, H, W), win, sh)
+        a = self.swin_attention(self.swin_windows(h, win), p + "attn.", heads, mask)
+        a = self.swin_unwindows(a, win, B, D, H, W)
+        if any(sh):
+            a = torch.roll(a, shifts=sh, dims=(1, 2, 3))
+        x = x + self.swin_drop_path(a, rate)
+        h = layer_norm(x, w(p + "norm2.weight"), w(p + "norm2.bias"), 1e-5)
+        h = F.linear(F.gelu(F.linear(h, w(p + "mlp.fc1.weight"), w(p + "mlp.fc1.bias"))), w(p + "mlp.fc2.weight"), w(p + "mlp.fc2.bias"))
+        return x + self.swin_drop_path(h, rate)
+
+    def swin_visual(self, video):
+        """SwinTransformer3D.forward, model/videoswin.py:441-458; PatchEmbed3D :361-376 (one zero frame appended, conv3d
+        kernel (2,4,4) stride (1,4,4), LayerNorm); BasicLayer :329-345 (shift = window // 2 on odd blocks); PatchMerging
+        :254-270. video: [b, 3, F, H, W] -> [b, F, H/32 * W/32, C_out]"""
+        w, sp = self.w, self.spec
+        x = F.pad(video, (0, 0, 0, 0, 0, 1))
+        x = F.conv3d(x, w("video_encoder.patch_embed.proj.weight"), w("video_encoder.patch_embed.proj.bias"), stride=(1, 4, 4))
+        x = x.permute(0, 2, 3, 4, 1)                                        # [b, D, H/4, W/4, C]
+        x = layer_norm(x, w("video_encoder.patch_embed.norm.weight"), w("video_encoder.patch_embed.norm.bias"), 1e-5)
+        total = sum(sp.swin_depths)
+        rates = [self.drop_path * i / max(total - 1, 1) for i in range(total)]      # torch.linspace(0, rate, total), :418
+        shift = tuple(v // 2 for v in sp.swin_window)
+        k = 0
+        for li, (depth, heads) in enumerate(zip(sp.swin_depths, sp.swin_heads)):
+            for bi in range(depth):
+                x = self.swin_block(x, f"video_encoder.layers.{li}.blocks.{bi}.", heads, sp.swin_window,
+                                    (0, 0, 0) if bi % 2 == 0 else shift, rates[k])
+                k += 1
+            if li + 1 < len(sp.swin_depths):
+                p = f"video_encoder.layers.{li}.downsample."
+                assert x.shape[2] % 2 == 0 and x.shape[3] % 2 == 0, "odd-size PatchMerging padding is not restated"
+                x = torch.cat([x[:, :, 0::2, 0::2], x[:, :, 1::2, 0::2], x[:, :, 0::2, 1::2], x[:, :, 1::2, 1::2]], dim=-1)
+                x = layer_norm(x, w(p + "norm.weight"), w(p + "norm.bias"), 1e-5)
+                x = F.linear(x, w(p + "reduction.weight"))
+        x = layer_norm(x, w("video_encoder.norm.weight"), w("video_encoder.norm.bias"), 1e-5)
+        return x.reshape(x.shape[0], x.shape[1], -1, x.shape[-1])
+
     def forward_video_encoder(self, video_pixels):
-        """model/modeling.py:449-465 (clip branch)"""
+        """model/modeling.py:449-465"""
+        if self.spec.video_encoder == "swin":
+            return self.swin_visual(video_pixels.transpose(1, 2))
         b, n, _, h, ww = video_pixels.shape
         out = self.clip_visual(video_pixels.reshape(b * n, 3, h, ww))
         return out.reshape(b, -1, *out.shape[-2:])
@@ -255,8 +371,8 @@ class Oracle:
         return (a2b + b2a) / 2.0
 
     def contrastive_loss(self, score):
-        """VALORModel.contrastive_loss, model/modeling.py:418-433 (clip video encoder: temp = 1/exp(logit_scale))"""
-        temp = 1.0 / self.w("clip_model.logit_scale").exp()
+        """VALORModel.contrastive_loss, model/modeling.py:418-433 (clip video encoder: temp = 1/exp(logit_scale), else contra_temp)"""
+        temp = 1.0 / self.w("clip_model.logit_scale").exp() if self.spec.video_encoder == "clip" else self.w("contra_temp")
         s = score / temp
         l1 = (-F.log_softmax(s, dim=1)).diag()
         l2 = (-F.log_softmax(s, dim=0)).diag()
@@ -294,18 +410,29 @@ class Oracle:
             audio_output = self.forward_audio_encoder(batch["audio_spectrograms"])
             col["audio_output"] = audio_output
         if "t" in "".join(contra_task):
-            txt_tokens_contra = txt_tokens["clip_tokens"]
-            txt_output = self.clip_text(txt_tokens_contra)
+            if self.spec.txt_encoder == "bert":                        # pretrain.py:252-263, modeling.py:439-440 (casual=False)
+                txt_tokens_contra = txt_tokens["bert_tokens"]
+                prompt = self.get_task_prompt("project language in common space", txt_tokens_contra.shape[0]) if self.use_task_prompt else None
+                txt_output = self.bert_model(txt_tokens_contra, prompt, None, None, False)[:, :txt_tokens_contra.shape[1]]
+            else:
+                txt_tokens_contra = txt_tokens["clip_tokens"]
+                txt_output = self.clip_text(txt_tokens_contra)
             col["txt_output"] = txt_output
 
         if contra_task:
             feat_t = feat_v = feat_a = None
             if "t" in "".join(contra_task):
-                feat_t = F.normalize(txt_output @ w("clip_model.text_projection"), dim=-1)       # pretrain.py:90,274-276
+                if self.spec.txt_encoder == "bert":                                              # Contra_head, pretrain.py:33-38,94-95
+                    feat_t = F.normalize(F.linear(txt_output, w("contra_head_t.linear.weight")), dim=-1)
+                else:
+                    feat_t = F.normalize(txt_output @ w("clip_model.text_projection"), dim=-1)   # pretrain.py:90,274-276
                 if compute_loss and gather:
                     feat_t = gather[0](feat_t); txt_tokens_contra = gather[1](txt_tokens_contra)
             if "v" in "".join(contra_task):
-                feat_v = F.normalize(video_output[:, :, 0] @ w("clip_model.visual.proj"), dim=-1)  # :91, modeling.py:387
+                if self.spec.video_encoder == "swin":                                            # modeling.py:388-389 mean over tokens
+                    feat_v = F.normalize(F.linear(video_output.mean(dim=2), w("contra_head_v.linear.weight")), dim=-1)
+                else:
+                    feat_v = F.normalize(video_output[:, :, 0] @ w("clip_model.visual.proj"), dim=-1)  # :91, modeling.py:387
                 if compute_loss and gather:
                     feat_v = gather[0](feat_v)
             if "a" in "".join(contra_task):
@@ -344,6 +471,9 @@ class Oracle:
         bs = txt.shape[0]
         video_input = audio_input = None
         if video_output is not None:                                                             # modeling.py:485-493
+            if "hidden_trans_video_multimodal.0.weight" in self.sd:                              # modeling.py:348-349,487-488
+                video_output = layer_norm(F.linear(video_output, w("hidden_trans_video_multimodal.0.weight"), w("hidden_trans_video_multimodal.0.bias")),
+                                          w("hidden_trans_video_multimodal.1.weight"), w("hidden_trans_video_multimodal.1.bias"), 1e-12)
             vo = video_output + w("video_frame_embedding")[:, :video_output.shape[1], :].unsqueeze(-2)
             video_input = vo.reshape(bs, -1, self.spec.hidden) + w("video_type_embeddings")
         if audio_output is not None:                                                             # modeling.py:495-502
@@ -392,6 +522,24 @@ class Oracle:
             else:
                 out["txt_labels_mlm"] = txt_labels
         return out
+
+
+# ----------------------------------------------------------------------------- state-dict helpers
+def is_alias_key(k):
+    """keys of the reference state dict that share storage with another key: the tied decoder weight (modeling.py:241) and the
+    txt_encoder.* view of the shared multimodal encoder (modeling.py:689-691)"""
+    return k == "cls.decoder.weight" or k.startswith("txt_encoder.")
+
+
+def trainable_copy(sd):
+    """leaf copies (requires_grad) of a synthetic state dict for the oracle; aliases point at their owners, integer buffers
+    (relative_position_index) are passed through"""
+    out = {k: (v.clone().requires_grad_(True) if v.is_floating_point() else v) for k, v in sd.items() if not is_alias_key(k)}
+    out["cls.decoder.weight"] = out["multimodal_encoder.embeddings.word_embeddings.weight"]
+    for k in sd:
+        if k.startswith("txt_encoder."):
+            out[k] = out["multimodal_encoder." + k[len("txt_encoder."):]]
+    return out
 
 
 # ----------------------------------------------------------------------------- optimizer

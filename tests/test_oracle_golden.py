@@ -21,15 +21,14 @@ GOLD = os.path.join(ROOT, "tests", "golden")
 def _oracle(recipe):
     spec = synth.ValorSpec(**recipe["spec"])
     sd = synth.make_state_dict(spec, seed=recipe["weight_seed"])
-    sd_o = {k: v.clone().requires_grad_(True) for k, v in sd.items() if k != "cls.decoder.weight"}
-    sd_o["cls.decoder.weight"] = sd_o["multimodal_encoder.embeddings.word_embeddings.weight"]
+    sd_o = VO.trainable_copy(sd)
     orc = VO.Oracle(spec, sd_o, vocab_tokens=synth.synthetic_vocab(spec.vocab))
     batch = synth.make_batch(spec, batch=recipe["batch"], frames=recipe["frames"], audio_slices=recipe["audio_slices"],
                              txt_len=recipe["txt_len"], seed=recipe["batch_seed"])
     return spec, sd_o, orc, batch
 
 
-@pytest.mark.parametrize("name", ["ref_base_b2f2a1", "ref_base_b3f1a2"])
+@pytest.mark.parametrize("name", ["ref_base_b2f2a1", "ref_base_b3f1a2", "ref_swin_b2f2a1"])
 def test_oracle_reproduces_reference_goldens(name):
     g = torch.load(os.path.join(GOLD, name + ".pt"), weights_only=False)
     rc = g["recipe"]
@@ -46,7 +45,7 @@ def test_oracle_reproduces_reference_goldens(name):
     for k in ("feat_t", "feat_v", "feat_a"):
         assert torch.allclose(ev[k], g["eval"][k], atol=2e-5), k
     # two training steps with the restated optimizer
-    params = {k: v for k, v in sd_o.items() if k != "cls.decoder.weight"}
+    params = {k: v for k, v in sd_o.items() if v.requires_grad and not VO.is_alias_key(k)}
     groups = {k: VO.param_group_of(k) for k in params}
     lrs0, wds = VO.group_hparams(1e-4, 0.01)
     state = {}

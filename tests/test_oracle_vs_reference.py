@@ -17,15 +17,24 @@ pytestmark = pytest.mark.skipif(not ref_harness.available(), reason="/root/refer
 TASK = "pt_contra%tva%tv%ta_caption%tva%tv%ta_mlm%tva"
 
 
-@pytest.fixture(scope="module")
-def setup():
+@pytest.fixture(scope="module", params=["clip", "swin"])
+def setup(request):
+    """clip: config/pretrain-VALOR-base.json; swin: scripts/pretrain.sh:3-8 (VideoSwin-B + BERT text)"""
     from valor_amd import synth
-    from valor_oracle import Oracle
-    spec = synth.base_spec()
+    from valor_oracle import Oracle, trainable_copy
+    if request.param == "swin":
+        spec = synth.swin_spec()
+        ropts = ref_harness.default_opts(video_encoder_type="videoswin_base_k400_22k", txt_encoder_type="bert_base_uncased")
+    else:
+        spec, ropts = synth.base_spec(), None
     sd = synth.make_state_dict(spec, seed=50)
-    ref = ref_harness.build_reference(state_dict=sd, dropout=0.0)
-    sd_o = {k: v.clone().requires_grad_(True) for k, v in sd.items() if k != "cls.decoder.weight"}
-    sd_o["cls.decoder.weight"] = sd_o["multimodal_encoder.embeddings.word_embeddings.weight"]
+    ref = ref_harness.build_reference(ropts, state_dict=None, dropout=0.0)
+    if request.param == "swin":        # the synthetic integer buffer is the reference's own
+        own = ref.state_dict()["video_encoder.layers.0.blocks.0.attn.relative_position_index"]
+        assert torch.equal(own, synth.swin_relative_position_index(spec.swin_window))
+    missing, unexpected = ref.load_state_dict(sd, strict=False)
+    assert not missing and not unexpected
+    sd_o = trainable_copy(sd)
     orc = Oracle(spec, sd_o, vocab_tokens=synth.synthetic_vocab(spec.vocab))
     batch = synth.make_batch(spec, batch=2, frames=2, audio_slices=1, txt_len=32, seed=51)
     return spec, ref, orc, sd_o, batch
@@ -58,6 +67,22 @@ def test_losses_and_grads_match_reference(setup):
     assert checked > 800
 
 
+def test_swin_shifted_block_with_depth_shift():
+    """16-frame inputs shift windows along time too (window 8, shift 4): one reference block vs the restatement"""
+    ref_harness._install()
+    from model.videoswin import SwinTransformerBlock3D, compute_mask
+    from valor_amd import synth
+    from valor_oracle import Oracle
+    torch.manual_seed(0)
+    blk = SwinTransformerBlock3D(dim=64, num_heads=2, window_size=(8, 7, 7), shift_size=(4, 3, 3)).float().eval()
+    x = torch.randn(2, 16, 14, 14, 64)
+    m = compute_mask(16, 14, 14, (8, 7, 7), (4, 3, 3), x.device)
+    assert torch.equal(m, Oracle.swin_shift_mask((16, 14, 14), (8, 7, 7), (4, 3, 3)))
+    o = Oracle(synth.swin_spec(), {"b." + k: v for k, v in blk.state_dict().items()})
+    with torch.no_grad():
+        assert float((blk(x, m) - o.swin_block(x, "b.", 2, (8, 7, 7), (4, 3, 3), 0.0)).abs().max()) < 1e-5
+
+
 def test_eval_argmax_matches_reference(setup):
     spec, ref, orc, sd_o, batch = setup
     with torch.no_grad():
@@ -69,3 +94,4 @@ def test_eval_argmax_matches_reference(setup):
         assert torch.equal(r[k].argmax(-1), o[k].argmax(-1)), k
     assert torch.equal(r["txt_labels_caption"], o["txt_labels_caption"])
     assert torch.allclose(r["feat_t"], o["feat_t"], atol=1e-5)
+    assert torch.allclose(r["feat_v"], o["feat_v"], atol=1e-5)

@@ -36,6 +36,35 @@ class ValorSpec:
     inter: int = 3072
     vocab: int = 30522
     max_pos: int = 512
+    # variant (scripts/pretrain.sh:3-8): video "clip" (CLIP-ViT) | "swin" (VideoSwin, model/videoswin.py:378-458);
+    # text "clip" (CLIP text tower) | "bert" (the shared multimodal BERT run without cross-attention, modeling.py:688-691)
+    video_encoder: str = "clip"
+    txt_encoder: str = "clip"
+    # VideoSwin (model/modeling.py:585-587, model/videoswin.py:378-399); head_dim is 32 everywhere
+    swin_embed: int = 128
+    swin_depths: tuple = (2, 2, 18, 2)
+    swin_heads: tuple = (4, 8, 16, 32)
+    swin_window: tuple = (8, 7, 7)
+    swin_drop_path: float = 0.2
+
+    @property
+    def swin_out(self):
+        return self.swin_embed * 2 ** (len(self.swin_depths) - 1)
+
+    @property
+    def video_dim(self):
+        """modeling.py:314,587"""
+        return self.swin_out if self.video_encoder == "swin" else self.vis_width
+
+    @property
+    def txt_dim(self):
+        """modeling.py:691,718"""
+        return self.hidden if self.txt_encoder == "bert" else self.txt_width
+
+    @property
+    def swin_table(self):
+        wd, wh, ww = self.swin_window
+        return (2 * wd - 1) * (2 * wh - 1) * (2 * ww - 1)
 
     @property
     def vis_heads(self):
@@ -69,6 +98,27 @@ def base_spec():
     return ValorSpec()
 
 
+def swin_spec():
+    """scripts/pretrain.sh "VALOR-base": VideoSwin-B + BERT text (shared with the decoder) + AST + BERT decoder."""
+    return ValorSpec(video_encoder="swin", txt_encoder="bert")
+
+
+def tiny_swin_spec():
+    """3-stage VideoSwin (28 -> 14 -> 7 at 112 px: no padding anywhere) on the tiny BERT/AST of tiny_spec()."""
+    return ValorSpec(video_encoder="swin", txt_encoder="bert", resolution=112, swin_embed=32, swin_depths=(2, 2, 2),
+                     swin_heads=(1, 2, 4), swin_drop_path=0.2, embed_dim=128, aud_width=128, aud_layers=2, aud_inter=256,
+                     melbins=32, target_len=64, aud_patch=16, hidden=128, layers=2, inter=256, vocab=1200, max_pos=64)
+
+
+def swin_relative_position_index(window):
+    """videoswin.py:112-126: index into the (2wd-1)(2wh-1)(2ww-1) bias table for every token pair of a FULL window;
+    with lin(t) = d*(2wh-1)(2ww-1) + h*(2ww-1) + w it is lin(i) - lin(j) + lin(last token)."""
+    wd, wh, ww = window
+    d, h, w = torch.meshgrid(torch.arange(wd), torch.arange(wh), torch.arange(ww), indexing="ij")
+    lin = (d * (2 * wh - 1) * (2 * ww - 1) + h * (2 * ww - 1) + w).reshape(-1)
+    return lin[:, None] - lin[None, :] + int(lin[-1])
+
+
 def tiny_spec():
     """Small architecture for fast unit tests (same code paths, every dim a multiple of 64)."""
     return ValorSpec(vis_width=128, vis_layers=2, patch=16, resolution=64, txt_width=128, txt_layers=2, ctx_len=77,
@@ -76,36 +126,9 @@ def tiny_spec():
                      target_len=64, aud_patch=16, hidden=128, layers=2, inter=256, vocab=1200, max_pos=64)
 
 
-def state_dict_layout(spec: ValorSpec):
-    """Ordered (key, shape, kind) of the CLIP-variant VALOR state dict. kind: w (weight), b (bias), g (LN gain), s (scalar)."""
-    H, W, TW, AW, E = spec.hidden, spec.vis_width, spec.txt_width, spec.aud_width, spec.embed_dim
-    L = []
-    add = lambda k, s, kind="w": L.append((k, tuple(s), kind))
-    add("video_type_embeddings", (1, 1, H)); add("audio_type_embeddings", (1, 1, H))
-    add("video_frame_embedding", (1, 32, H)); add("audio_frame_embedding", (1, 32, H))
-    add("contra_temp", (), "s")
-    add("clip_model.positional_embedding", (spec.ctx_len, TW)); add("clip_model.text_projection", (TW, E))
-    add("clip_model.logit_scale", (), "s")
-    add("clip_model.visual.class_embedding", (W,)); add("clip_model.visual.positional_embedding", (spec.vis_tokens, W))
-    add("clip_model.visual.proj", (W, E)); add("clip_model.visual.conv1.weight", (W, 3, spec.patch, spec.patch))
-    add("clip_model.visual.ln_pre.weight", (W,), "g"); add("clip_model.visual.ln_pre.bias", (W,), "b")
-
-    def clip_blocks(prefix, width, n):
-        for i in range(n):
-            p = f"{prefix}.resblocks.{i}."
-            add(p + "attn.in_proj_weight", (3 * width, width)); add(p + "attn.in_proj_bias", (3 * width,), "b")
-            add(p + "attn.out_proj.weight", (width, width)); add(p + "attn.out_proj.bias", (width,), "b")
-            add(p + "ln_1.weight", (width,), "g"); add(p + "ln_1.bias", (width,), "b")
-            add(p + "mlp.c_fc.weight", (4 * width, width)); add(p + "mlp.c_fc.bias", (4 * width,), "b")
-            add(p + "mlp.c_proj.weight", (width, 4 * width)); add(p + "mlp.c_proj.bias", (width,), "b")
-            add(p + "ln_2.weight", (width,), "g"); add(p + "ln_2.bias", (width,), "b")
-    clip_blocks("clip_model.visual.transformer", W, spec.vis_layers)
-    add("clip_model.visual.ln_post.weight", (W,), "g"); add("clip_model.visual.ln_post.bias", (W,), "b")
-    clip_blocks("clip_model.transformer", TW, spec.txt_layers)
-    add("clip_model.token_embedding.weight", (spec.clip_vocab, TW))
-    add("clip_model.ln_final.weight", (TW,), "g"); add("clip_model.ln_final.bias", (TW,), "b")
-    add("clip_model.prompt_embedding.weight", (1, TW))
-
+def _audio_bert_heads(spec, add):
+    """AST + multimodal BERT + prediction head keys (both variants)."""
+    H, AW = spec.hidden, spec.aud_width
     add("audio_embeddings.cls_token", (1, 1, AW))
     add("audio_embeddings.first_conv.weight", (AW, 1, spec.aud_patch, spec.aud_patch)); add("audio_embeddings.first_conv.bias", (AW,), "b")
     add("audio_embeddings.position_embeddings.weight", (spec.aud_tokens, AW))
@@ -138,6 +161,76 @@ def state_dict_layout(spec: ValorSpec):
     add("cls.dense.weight", (H, H)); add("cls.dense.bias", (H,), "b")
     add("cls.layernorm.weight", (H,), "g"); add("cls.layernorm.bias", (H,), "b")
     add("cls.decoder.weight", (spec.vocab, H), "tied"); add("cls.decoder.bias", (spec.vocab,), "b")
+
+
+def state_dict_layout(spec: ValorSpec):
+    """Ordered (key, shape, kind) of the VALOR state dict (CLIP or VideoSwin variant). kind: w (weight), b (bias), g (LN gain),
+    s (scalar), tied / alias (same storage as another key), relidx (integer buffer)."""
+    H, W, TW, AW, E = spec.hidden, spec.vis_width, spec.txt_width, spec.aud_width, spec.embed_dim
+    L = []
+    add = lambda k, s, kind="w": L.append((k, tuple(s), kind))
+    add("video_type_embeddings", (1, 1, H)); add("audio_type_embeddings", (1, 1, H))
+    add("video_frame_embedding", (1, 32, H)); add("audio_frame_embedding", (1, 32, H))
+    add("contra_temp", (), "s")
+    if spec.video_encoder == "swin":
+        assert spec.txt_encoder == "bert", "the reference loads CLIP as a whole: swin video + clip text is not a shipped combination"
+        C0 = spec.swin_embed
+        add("video_encoder.patch_embed.proj.weight", (C0, 3, 2, 4, 4)); add("video_encoder.patch_embed.proj.bias", (C0,), "b")
+        add("video_encoder.patch_embed.norm.weight", (C0,), "g"); add("video_encoder.patch_embed.norm.bias", (C0,), "b")
+        for li, (depth, nh) in enumerate(zip(spec.swin_depths, spec.swin_heads)):
+            C = C0 * 2 ** li
+            for bi in range(depth):
+                p = f"video_encoder.layers.{li}.blocks.{bi}."
+                add(p + "norm1.weight", (C,), "g"); add(p + "norm1.bias", (C,), "b")
+                add(p + "attn.relative_position_bias_table", (spec.swin_table, nh))
+                add(p + "attn.relative_position_index", (0,), "relidx")
+                add(p + "attn.qkv.weight", (3 * C, C)); add(p + "attn.qkv.bias", (3 * C,), "b")
+                add(p + "attn.proj.weight", (C, C)); add(p + "attn.proj.bias", (C,), "b")
+                add(p + "norm2.weight", (C,), "g"); add(p + "norm2.bias", (C,), "b")
+                add(p + "mlp.fc1.weight", (4 * C, C)); add(p + "mlp.fc1.bias", (4 * C,), "b")
+                add(p + "mlp.fc2.weight", (C, 4 * C)); add(p + "mlp.fc2.bias", (C,), "b")
+            if li + 1 < len(spec.swin_depths):
+                p = f"video_encoder.layers.{li}.downsample."
+                add(p + "reduction.weight", (2 * C, 4 * C)); add(p + "norm.weight", (4 * C,), "g"); add(p + "norm.bias", (4 * C,), "b")
+        add("video_encoder.norm.weight", (spec.swin_out,), "g"); add("video_encoder.norm.bias", (spec.swin_out,), "b")
+        _audio_bert_heads(spec, add)
+        if spec.video_dim != H:                                                       # modeling.py:348-349
+            add("hidden_trans_video_multimodal.0.weight", (H, spec.video_dim)); add("hidden_trans_video_multimodal.0.bias", (H,), "b")
+            add("hidden_trans_video_multimodal.1.weight", (H,), "g"); add("hidden_trans_video_multimodal.1.bias", (H,), "b")
+        add("contra_head_t.linear.weight", (E, spec.txt_dim)); add("contra_head_v.linear.weight", (E, spec.video_dim))
+        add("contra_head_a.linear.weight", (E, AW))
+        for m in ("text", "video", "audio"):
+            add(f"{m}_fine_weight.0.weight", (E, E)); add(f"{m}_fine_weight.0.bias", (E,), "b")
+            add(f"{m}_fine_weight.2.weight", (1, E)); add(f"{m}_fine_weight.2.bias", (1,), "b")
+        # share_txt_and_multimodal (modeling.py:689-691): the text encoder IS the multimodal encoder, so the reference state
+        # dict lists every multimodal_encoder.* tensor a second time under txt_encoder.* (same storage)
+        for k, shape, kind in list(L):
+            if k.startswith("multimodal_encoder."):
+                L.append(("txt_encoder." + k[len("multimodal_encoder."):], shape, "alias"))
+        return L
+    add("clip_model.positional_embedding", (spec.ctx_len, TW)); add("clip_model.text_projection", (TW, E))
+    add("clip_model.logit_scale", (), "s")
+    add("clip_model.visual.class_embedding", (W,)); add("clip_model.visual.positional_embedding", (spec.vis_tokens, W))
+    add("clip_model.visual.proj", (W, E)); add("clip_model.visual.conv1.weight", (W, 3, spec.patch, spec.patch))
+    add("clip_model.visual.ln_pre.weight", (W,), "g"); add("clip_model.visual.ln_pre.bias", (W,), "b")
+
+    def clip_blocks(prefix, width, n):
+        for i in range(n):
+            p = f"{prefix}.resblocks.{i}."
+            add(p + "attn.in_proj_weight", (3 * width, width)); add(p + "attn.in_proj_bias", (3 * width,), "b")
+            add(p + "attn.out_proj.weight", (width, width)); add(p + "attn.out_proj.bias", (width,), "b")
+            add(p + "ln_1.weight", (width,), "g"); add(p + "ln_1.bias", (width,), "b")
+            add(p + "mlp.c_fc.weight", (4 * width, width)); add(p + "mlp.c_fc.bias", (4 * width,), "b")
+            add(p + "mlp.c_proj.weight", (width, 4 * width)); add(p + "mlp.c_proj.bias", (width,), "b")
+            add(p + "ln_2.weight", (width,), "g"); add(p + "ln_2.bias", (width,), "b")
+    clip_blocks("clip_model.visual.transformer", W, spec.vis_layers)
+    add("clip_model.visual.ln_post.weight", (W,), "g"); add("clip_model.visual.ln_post.bias", (W,), "b")
+    clip_blocks("clip_model.transformer", TW, spec.txt_layers)
+    add("clip_model.token_embedding.weight", (spec.clip_vocab, TW))
+    add("clip_model.ln_final.weight", (TW,), "g"); add("clip_model.ln_final.bias", (TW,), "b")
+    add("clip_model.prompt_embedding.weight", (1, TW))
+
+    _audio_bert_heads(spec, add)
     add("contra_head_a.linear.weight", (E, AW))
     for m in ("text", "video", "audio"):
         add(f"{m}_fine_weight.0.weight", (E, E)); add(f"{m}_fine_weight.0.bias", (E,), "b")
@@ -154,6 +247,10 @@ def make_state_dict(spec: ValorSpec, seed: int = 50, w_std: float = 0.02):
     for k, shape, kind in state_dict_layout(spec):
         if kind == "tied":
             sd[k] = sd["multimodal_encoder.embeddings.word_embeddings.weight"]
+        elif kind == "alias":
+            sd[k] = sd["multimodal_encoder." + k[len("txt_encoder."):]]
+        elif kind == "relidx":
+            sd[k] = swin_relative_position_index(spec.swin_window)
         elif kind == "s":
             sd[k] = torch.tensor(math.log(1 / 0.07) if "logit_scale" in k else 0.07)
         elif kind == "g":
