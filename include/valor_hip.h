@@ -63,16 +63,20 @@ int valor_gemm_kernel_for(int dtype, int transA, int transB, int M, int N, int K
  * :279-322 forward, :403-634 backward; wrapper apex/apex/normalization/fused_layer_norm.py:14-37) plus the elementwise ops
  * around it: bert.py:351-355,365-371,416-420 (post-LN), transformer.py:74-85 (pre-LN AST), clip.py:194-197 (pre-LN CLIP).
  *   z = dropout(x + bias)/(1-p) + residual ; y = LN(z; gamma, beta, eps).  z may alias x; any of bias/residual/gamma/beta/
- *   z/y may be NULL. mean/rstd: fp32 [rows]. */
+ *   z/y may be NULL. mean/rstd: fp32 [rows].
+ *   row_scale (may be NULL): fp32 [rows / rows_per_scale], (x + bias) is multiplied by row_scale[row / rows_per_scale] before the
+ *   residual add -- VideoSwin's per-sample stochastic depth, drop_path (videoswin.py:40-49, 243-244), with
+ *   row_scale = floor(keep + U[0,1)) / keep drawn by the caller. backward: dx = dz * row_scale (dx must not alias dres). */
 int valor_ln_part_blocks(void);
 int valor_bdrln_fwd(void* stream, int dtype, const void* x, const void* bias, const void* residual, const void* gamma,
                     const void* beta, void* z, void* y, float* mean, float* rstd, int64_t rows, int cols, float eps,
-                    float p_drop, uint64_t seed, uint64_t offset);
+                    float p_drop, uint64_t seed, uint64_t offset, const float* row_scale, int64_t rows_per_scale);
 /* backward: dz = LN'(dy) + dz_in -> dres ; dx = dz * dropmask/(1-p). part_*: fp32 [valor_ln_part_blocks() * cols]
  * per-workgroup column partials of dgamma / dbeta / dbias (finish with valor_colsum_finalize). */
 int valor_bdrln_bwd(void* stream, int dtype, const void* dy, const void* dz_in, const void* z, const float* mean,
                     const float* rstd, const void* gamma, void* dx, void* dres, float* part_dgamma, float* part_dbeta,
-                    float* part_dbias, int64_t rows, int cols, float p_drop, uint64_t seed, uint64_t offset);
+                    float* part_dbias, int64_t rows, int cols, float p_drop, uint64_t seed, uint64_t offset, const float* row_scale,
+                    int64_t rows_per_scale);
 int valor_colsum_finalize(void* stream, int dtype, const float* part, int nparts, int cols, void* out, int out_f32,
                           int accumulate);
 /* up to three finalizations in ONE launch (NULL part = skip): dgamma / dbeta / dbias of valor_bdrln_bwd */
@@ -104,6 +108,24 @@ int valor_attn_bwd(void* stream, int dtype, const void* q, const void* k, const 
                    int64_t o_rs, int64_t do_bs, int64_t do_rs, int64_t dq_bs, int64_t dq_rs, int64_t dk_bs, int64_t dk_rs,
                    int64_t dv_bs, int64_t dv_rs, const float* mask, int64_t mask_bs, int64_t mask_rs, const int* kv_range,
                    int kv_bmod, float scale, float p_drop, uint64_t seed, uint64_t offset, int accumulate_dkdv);
+
+/* ---- VideoSwin 3-D shifted-window attention, head_dim 32 (videoswin.py:137-163 with the roll / window_partition /
+ * window_reverse around it :205-220, relative position bias :146-148, shift mask :150-154,272-285), in place on the fused QKV
+ * GEMM output in natural token order. qkv [B*rows_per_sample][3C] (C = heads*32; q | k | v), o [B*rows_per_sample][C].
+ * rowmap int32 [nW*N]: token row (inside a sample) of slot n of window w (roll + partition; outputs are scattered back through
+ * it). rel int32 [N]: linearised (d,h,w) of a slot in the FULL window, bias(i,j) = table[rel[i]-rel[j]+relc][head]; table
+ * [table_rows][heads]. label uint8 [nW*N] region ids of the shift mask (NULL = unshifted): -100 where labels differ.
+ * lse fp32 [B*nW][heads][N]. bf16: N <= 448; fp32 (parity mode): forward N <= 448, backward N <= 192 (the window is LDS resident; VALOR_ERR_ARG beyond). */
+int valor_win_attn_workspace_floats(int B, int nW, int heads, int table_rows);   /* fp32 elements the backward needs */
+int valor_win_attn_fwd(void* stream, int dtype, const void* qkv, void* o, float* lse, const int* rowmap, const int* rel,
+                       const uint8_t* label, const void* table, int B, int nW, int N, int heads, int table_rows, int relc,
+                       int rows_per_sample, float scale);
+/* dqkv [rows][3C] (every row of every window is written); dtable [table_rows][heads] (+= if accumulate_dtable); delta fp32
+ * like lse; workspace: valor_win_attn_workspace_floats() fp32 per-workgroup bias-gradient histograms */
+int valor_win_attn_bwd(void* stream, int dtype, const void* qkv, const void* o, const float* lse, const void* dout, void* dqkv,
+                       float* delta, const int* rowmap, const int* rel, const uint8_t* label, const void* table, void* dtable,
+                       int accumulate_dtable, void* workspace, int64_t workspace_bytes, int B, int nW, int N, int heads,
+                       int table_rows, int relc, int rows_per_sample, float scale);
 
 /* ---- softmax cross-entropy over the vocabulary: F.cross_entropy on the masked rows (pretrain.py:444,457,469,498).
  * logits [rows, V] with leading dim ld; backward overwrites the logits (and zero-fills the ld padding) with
@@ -141,6 +163,14 @@ int valor_grad_norm_clip(void* stream, int dtype, const void* grad, const int8_t
 /* ---- data-movement kernels around the core */
 /* conv(kernel=stride=P) as GEMM: clip.py:227,261 ; modeling.py:744,752 */
 int valor_patchify(void* stream, int dtype, const float* in, void* out, int N, int C, int H, int W, int P);
+/* VideoSwin PatchEmbed3D (videoswin.py:361-369): Conv3d(kernel (2,P,P), stride (1,P,P)) over the clip with one zero frame
+ * appended, as a GEMM operand. in: fp32 [B, F, C, H, W] (the batch layout of data/data.py:423-428, no transpose);
+ * out [B*F*(H/P)*(W/P)][C*2*P*P], column (c*2 + kd)*P*P + i*P + j = in[b][d + kd][c][py*P + i][px*P + j] (0 for d + kd == F) */
+int valor_patchify3d(void* stream, int dtype, const float* in, void* out, int B, int F, int C, int H, int W, int P);
+/* mean over groups of X consecutive rows (VideoSwin pooling, modeling.py:388-389): out[g] = mean_x in[g*X + x]; backward
+ * din[g*X + x] = dout[g] / X */
+int valor_group_mean_fwd(void* stream, int dtype, const void* in, void* out, int64_t groups, int X, int E);
+int valor_group_mean_bwd(void* stream, int dtype, const void* dout, void* din, int64_t groups, int X, int E);
 /* [cls ; patches (+bias)] + pos: clip.py:264-265 ; modeling.py:755-760 */
 int valor_assemble_tokens_fwd(void* stream, int dtype, const void* patches, const void* cls, const void* pos,
                               const void* bias, void* out, int N, int Pn, int E);

@@ -52,7 +52,7 @@ def test_argument_validation_without_gpu():
     so = lib.load()
     assert so.valor_gemm(None, 0, 0, 0, 4, 4, 8, None, 8, None, 8, None, 4, None, 0, None, None, 0, 1.0, 0, 0, None, 0, None, 0) == -1
     assert so.valor_gemm(None, 0, 0, 0, 0, 4, 8, None, 8, None, 8, None, 4, None, 0, None, None, 0, 1.0, 0, 0, None, 0, None, 0) == 0   # M = 0: no-op
-    assert so.valor_bdrln_fwd(None, 0, None, None, None, None, None, None, None, None, None, 4, 768, 1e-5, 0.0, 0, 0) == -1
+    assert so.valor_bdrln_fwd(None, 0, None, None, None, None, None, None, None, None, None, 4, 768, 1e-5, 0.0, 0, 0, None, 0) == -1
 
 
 @pytest.mark.skipif(torch.cuda.is_available(), reason="CPU-only check")

@@ -4,6 +4,7 @@ import os
 import random
 import sys
 
+import pytest
 import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -110,13 +111,62 @@ def test_masks_and_prompts():
 
 def test_unsupported_configs_fail_loudly():
     import pytest
-    with pytest.raises(NotImplementedError):
+    with pytest.raises(NotImplementedError):       # opts and spec disagree
         VALOR({"video_encoder_type": "videoswin_base_k600_22k"}, spec=synth.tiny_spec(), dtype=torch.float32, device="cpu")
+    with pytest.raises(NotImplementedError):       # not a shipped combination (the reference loads CLIP as a whole)
+        VALOR({"video_encoder_type": "videoswin_small_k400_1k"}, spec=synth.tiny_swin_spec(), dtype=torch.float32, device="cpu")
+    with pytest.raises(NotImplementedError):
+        VALOR({"video_encoder_type": "clip_vit_large_14_336px"}, spec=synth.tiny_spec(), dtype=torch.float32, device="cpu")
     with pytest.raises(NotImplementedError):
         VALOR({"fineweight_type": "none"}, spec=synth.tiny_spec(), dtype=torch.float32, device="cpu")
     m = VALOR(None, spec=synth.tiny_spec(), dtype=torch.float32, device="cpu")
     with pytest.raises(NotImplementedError):
         m({}, task="ret%tv")
+
+
+def test_swin_variant_host_side():
+    """VideoSwin + BERT-text variant (scripts/pretrain.sh:3-8): reference-keyed state dict round trip (integer buffers and the
+    txt_encoder.* aliases included), window index maps == roll + window_partition / compute_mask of the oracle, PatchMerging
+    gather rows, optimizer groups of the new tensors."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    from valor_oracle import Oracle
+    from valor_amd.model.params import optimizer_group
+    spec = synth.tiny_swin_spec()
+    m = VALOR({"video_encoder_type": "videoswin_base_k600_22k", "txt_encoder_type": "bert_base_uncased", "dropout": 0.0}, spec=spec,
+              dtype=torch.float32, device="cpu")
+    sd = synth.make_state_dict(spec, seed=3)
+    assert m.load_state_dict(sd, strict=True) == ([], [])
+    out = m.state_dict()
+    assert set(out) == set(sd)
+    for k in sd:
+        assert torch.equal(out[k].cpu(), sd[k]), k
+    assert out["txt_encoder.embeddings.word_embeddings.weight"].data_ptr() == out["multimodal_encoder.embeddings.word_embeddings.weight"].data_ptr()
+    for size, shifted in (((16, 14, 14), True), ((8, 14, 14), True), ((8, 14, 14), False), ((2, 28, 28), True), ((8, 7, 7), True)):
+        D, H, W = size
+        geo = m._swin_geometry(D, H, W, shifted)
+        win, sh = Oracle.swin_effective_window(size, spec.swin_window, tuple(v // 2 for v in spec.swin_window) if shifted else (0, 0, 0))
+        ids = torch.arange(D * H * W, dtype=torch.float32).reshape(1, D, H, W, 1)
+        if any(sh):
+            ids = torch.roll(ids, shifts=(-sh[0], -sh[1], -sh[2]), dims=(1, 2, 3))
+        assert torch.equal(Oracle.swin_windows(ids, win).reshape(-1).long(), geo["rowmap"].long())
+        assert geo["N"] == win[0] * win[1] * win[2] and geo["nW"] * geo["N"] == D * H * W
+        if any(sh):
+            lab = geo["label"].long().view(geo["nW"], geo["N"])
+            assert torch.equal(torch.where(lab[:, None, :] != lab[:, :, None], -100.0, 0.0), Oracle.swin_shift_mask(size, win, sh))
+        else:
+            assert geo["label"] is None
+        full = synth.swin_relative_position_index(spec.swin_window)[:geo["N"], :geo["N"]]
+        rel = geo["rel"].long()
+        assert torch.equal(rel[:, None] - rel[None, :] + geo["relc"], full)
+    with pytest.raises(NotImplementedError):
+        m._swin_geometry(8, 16, 16, False)                     # would need window padding
+    x = torch.arange(2 * 2 * 4 * 4).float().view(2, 2, 4, 4, 1)
+    ref = torch.cat([x[:, :, 0::2, 0::2], x[:, :, 1::2, 0::2], x[:, :, 0::2, 1::2], x[:, :, 1::2, 1::2]], -1).reshape(-1)
+    assert torch.equal(ref.long(), m._swin_merge_idx(2, 2, 4, 4))
+    # optim/misc.py:14: the bias TABLE matches "bias" (no decay), Swin norm weights are decayed, everything is in the basic family
+    assert optimizer_group("video_encoder.layers.0.blocks.0.attn.relative_position_bias_table") == 1
+    assert optimizer_group("video_encoder.layers.0.blocks.0.norm1.weight") == 0
+    assert optimizer_group("hidden_trans_video_multimodal.1.weight") == 0 and optimizer_group("contra_head_v.linear.weight") == 0
 
 
 def test_flop_model_matches_survey():

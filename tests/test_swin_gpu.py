@@ -1,0 +1,179 @@
+"""GPU parity of the VideoSwin kernels behind the C-ABI against fp64 torch math that follows model/videoswin.py:
+valor_win_attn_fwd/bwd (roll + window_partition + WindowAttention3D + window_reverse + roll back, relative position bias,
+shift mask, bias-table gradient), valor_patchify3d (PatchEmbed3D's conv3d as a GEMM), valor_group_mean_*, and the
+stochastic-depth row scale of valor_bdrln_fwd/bwd."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+
+pytestmark = pytest.mark.gpu
+
+
+def _rel(a, b):
+    a, b = a.double().cpu(), b.double().cpu()
+    return ((a - b).norm() / max(b.norm().item(), 1e-9)).item()
+
+
+def _model(dev, dtype):
+    from valor_amd import synth
+    from valor_amd.model.valor import VALOR
+    return VALOR({"dropout": 0.0, "drop_path_rate": 0.0}, spec=synth.tiny_swin_spec(), dtype=dtype, device=dev)
+
+
+def _ref_window_attention(qkv, table, heads, size, window, shifted):
+    """fp64 restatement through the oracle's window helpers. qkv [B, D, H, W, 3C] -> o [B, D, H, W, C]"""
+    from valor_amd import synth
+    from valor_oracle import Oracle
+    B, D, H, W, C3 = qkv.shape
+    C = C3 // 3
+    win, sh = Oracle.swin_effective_window(size, window, tuple(v // 2 for v in window) if shifted else (0, 0, 0))
+    x, mask = qkv, None
+    if any(sh):
+        x = torch.roll(x, shifts=(-sh[0], -sh[1], -sh[2]), dims=(1, 2, 3))
+        mask = Oracle.swin_shift_mask(size, win, sh).double().to(qkv.device)
+    xw = Oracle.swin_windows(x, win)
+    Bw, N, _ = xw.shape
+    q, k, v = xw.reshape(Bw, N, 3, heads, 32).permute(2, 0, 3, 1, 4)
+    s = (q * 32 ** -0.5) @ k.transpose(-2, -1)
+    idx = synth.swin_relative_position_index(window)[:N, :N].reshape(-1).to(qkv.device)
+    s = s + table[idx].reshape(N, N, heads).permute(2, 0, 1)[None]
+    if mask is not None:
+        nW = mask.shape[0]
+        s = (s.view(Bw // nW, nW, heads, N, N) + mask[None, :, None]).view(Bw, heads, N, N)
+    o = (torch.softmax(s, dim=-1) @ v).transpose(1, 2).reshape(Bw, N, C)
+    o = Oracle.swin_unwindows(o, win, B, D, H, W)
+    if any(sh):
+        o = torch.roll(o, shifts=sh, dims=(1, 2, 3))
+    return o
+
+
+@pytest.mark.parametrize("dtype,size,shifted", [
+    (torch.bfloat16, (8, 14, 14), False), (torch.bfloat16, (8, 14, 14), True),     # N = 392: the production window
+    (torch.bfloat16, (16, 7, 7), True),                                            # two windows along time, shift (4,0,0)
+    (torch.bfloat16, (16, 14, 14), True),                                          # shift in all three dims
+    (torch.bfloat16, (2, 7, 7), False),                                            # one small window, N = 98 (sliced bias index)
+    (torch.float32, (2, 14, 14), True), (torch.float32, (1, 7, 7), False),         # parity-mode instantiation
+])
+def test_window_attention(dev, dtype, size, shifted):
+    from valor_amd import ops
+    model = _model(dev, dtype)
+    window = model.spec.swin_window
+    B, heads = 3, 2
+    C = heads * 32
+    D, H, W = size
+    g = torch.Generator().manual_seed(1)
+    qkv = torch.randn((B, D, H, W, 3 * C), generator=g).to(dtype).to(dev)
+    table = (0.5 * torch.randn((model.spec.swin_table, heads), generator=g)).to(dtype).to(dev)
+    dout = torch.randn((B, D, H, W, C), generator=g).to(dtype).to(dev)
+    geo = model._swin_geometry(D, H, W, shifted)
+    q2 = qkv.reshape(-1, 3 * C).clone().requires_grad_(True)
+    t2 = table.clone().requires_grad_(True)
+    o = ops.window_attention(q2, t2, geo, heads, B)
+    o.backward(dout.reshape(-1, C))
+    qr = qkv.double().requires_grad_(True)
+    tr = table.double().requires_grad_(True)
+    oref = _ref_window_attention(qr, tr, heads, size, window, shifted)
+    oref.backward(dout.double())
+    tol = 1.5e-2 if dtype == torch.bfloat16 else 2e-5
+    assert _rel(o, oref.reshape(-1, C)) < tol
+    assert _rel(q2.grad, qr.grad.reshape(-1, 3 * C)) < tol
+    assert _rel(t2.grad, tr.grad) < tol
+    # accumulate-into-arena form of the bias-table gradient
+    from valor_amd import kernels as K
+    acc = torch.ones_like(table)
+    lse = torch.empty((B * geo["nW"], heads, geo["N"]), dtype=torch.float32, device=dev)
+    o2, lse = K.win_attn_fwd(qkv.reshape(-1, 3 * C), geo, table, heads, B)
+    _, none = K.win_attn_bwd(qkv.reshape(-1, 3 * C), o2, lse, dout.reshape(-1, C).contiguous(), geo, table, heads, B, dtable=acc)
+    assert none is None and _rel(acc, tr.grad + 1.0) < tol
+
+
+def test_window_attention_rejects_oversized_window(dev):
+    """the window is LDS resident: the fp32 (parity) backward of a 392-slot window does not fit and says so (no fallback)"""
+    from valor_amd import kernels as K, lib
+    model = _model(dev, torch.float32)
+    geo = model._swin_geometry(8, 7, 7, False)
+    qkv = torch.zeros((8 * 49, 3 * 64), dtype=torch.float32, device=dev)
+    table = torch.zeros((model.spec.swin_table, 2), dtype=torch.float32, device=dev)
+    o, lse = K.win_attn_fwd(qkv, geo, table, 2, 1)                # the forward (K + V^T only) still fits
+    with pytest.raises(lib.ValorHipError):
+        K.win_attn_bwd(qkv, o, lse, torch.zeros_like(o), geo, table, 2, 1)
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+def test_patchify3d_is_conv3d(dev, dtype):
+    """PatchEmbed3D.forward (videoswin.py:361-369) = pad one frame + Conv3d(k (2,4,4), s (1,4,4)) == patchify3d rows . W^T + b"""
+    from valor_amd import kernels as K
+    g = torch.Generator().manual_seed(2)
+    B, Fr, H, W, Co = 2, 3, 16, 24, 32
+    vid = torch.randn((B, Fr, 3, H, W), generator=g)
+    w = (0.1 * torch.randn((Co, 3, 2, 4, 4), generator=g)).to(dtype)
+    b = torch.randn((Co,), generator=g).to(dtype)
+    rows = K.patchify3d(vid.to(dev), 4, dtype)
+    y = K.gemm(rows, w.to(dev).view(Co, -1), bias=b.to(dev))
+    ref = F.conv3d(F.pad(vid.transpose(1, 2).double(), (0, 0, 0, 0, 0, 1)), w.double(), b.double(), stride=(1, 4, 4))
+    ref = ref.permute(0, 2, 3, 4, 1).reshape(-1, Co)
+    assert _rel(y, ref) < (1e-2 if dtype == torch.bfloat16 else 1e-5)
+
+
+def test_group_mean_and_row_scale(dev):
+    from valor_amd import ops
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn((6 * 49, 128), generator=g, dtype=torch.float32).to(dev).requires_grad_(True)
+    y = ops.group_mean(x, 49)
+    gy = torch.randn(y.shape, generator=g).to(dev)
+    y.backward(gy)
+    xr = x.detach().double().cpu().requires_grad_(True)
+    yr = xr.view(6, 49, 128).mean(1)
+    yr.backward(gy.double().cpu())
+    assert _rel(y, yr) < 1e-6 and _rel(x.grad, xr.grad) < 1e-6
+    # stochastic depth: z = residual + scale[sample] * (x + bias); y = LN(z)   (videoswin.py:40-49, 243-244)
+    rows_per, nb, cols = 10, 4, 256
+    a = torch.randn((nb * rows_per, cols), generator=g).to(dev).requires_grad_(True)
+    res = torch.randn((nb * rows_per, cols), generator=g).to(dev).requires_grad_(True)
+    bias = torch.randn((cols,), generator=g).to(dev).requires_grad_(True)
+    gam = torch.randn((cols,), generator=g).to(dev).requires_grad_(True)
+    bet = torch.randn((cols,), generator=g).to(dev).requires_grad_(True)
+    scale = torch.tensor([0.0, 1.25, 1.25, 0.0], device=dev)
+    from valor_amd.ops import GradSink
+    GradSink.enabled = False
+    try:
+        z, yl = ops.bias_dropout_residual_ln(a, bias, res, gam, bet, 1e-5, 0.0, True, scale, rows_per)
+        gz, gl = torch.randn(z.shape, generator=g).to(dev), torch.randn(z.shape, generator=g).to(dev)
+        (z * gz + yl * gl).sum().backward()
+        z1 = ops.bias_dropout_residual(a.detach(), bias.detach(), res.detach(), 0.0, scale, rows_per)
+    finally:
+        GradSink.enabled = True
+    ar, rr, br, gr, ber = [t.detach().double().cpu().requires_grad_(True) for t in (a, res, bias, gam, bet)]
+    zr = rr + scale.double().cpu().repeat_interleave(rows_per)[:, None] * (ar + br)
+    ylr = F.layer_norm(zr, (cols,), gr, ber, 1e-5)
+    (zr * gz.double().cpu() + ylr * gl.double().cpu()).sum().backward()
+    assert _rel(z, zr) < 1e-6 and _rel(yl, ylr) < 1e-5 and _rel(z1, zr) < 1e-6
+    for got, ref in ((a.grad, ar.grad), (res.grad, rr.grad), (bias.grad, br.grad), (gam.grad, gr.grad), (bet.grad, ber.grad)):
+        assert _rel(got, ref) < 2e-5
+
+
+def test_swin_geometry_matches_reference_partition(dev):
+    """the kernel's index maps reproduce roll + window_partition and compute_mask (videoswin.py:75-79,205-206,272-285)"""
+    from valor_oracle import Oracle
+    model = _model(dev, torch.float32)
+    for size, shifted in (((16, 14, 14), True), ((8, 14, 14), True), ((8, 14, 14), False), ((2, 28, 28), True)):
+        D, H, W = size
+        geo = model._swin_geometry(D, H, W, shifted)
+        win, sh = Oracle.swin_effective_window(size, model.spec.swin_window, tuple(v // 2 for v in model.spec.swin_window) if shifted else (0, 0, 0))
+        ids = torch.arange(D * H * W, dtype=torch.float32).reshape(1, D, H, W, 1)
+        if any(sh):
+            ids = torch.roll(ids, shifts=(-sh[0], -sh[1], -sh[2]), dims=(1, 2, 3))
+        assert torch.equal(Oracle.swin_windows(ids, win).reshape(-1).long(), geo["rowmap"].cpu().long())
+        if any(sh):
+            lab = geo["label"].cpu().long().view(geo["nW"], geo["N"])
+            mine = torch.where(lab[:, None, :] != lab[:, :, None], -100.0, 0.0)
+            assert torch.equal(mine, Oracle.swin_shift_mask(size, win, sh))
+        else:
+            assert geo["label"] is None

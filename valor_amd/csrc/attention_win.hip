@@ -1,0 +1,526 @@
+// 3-D shifted-window attention of VideoSwin (model/videoswin.py:137-163 WindowAttention3D.forward; the roll /
+// window_partition / window_reverse / roll-back around it, :205-220 and :75-84; the relative position bias gather
+// :146-148; the shift mask :150-154 / compute_mask :272-285), forward + backward, head_dim 32.
+//
+// What the reference does with six materialised tensors per block (rolled copy, window copy, [B_, h, N, N] scores, the
+// gathered [h, N, N] bias, un-windowed copy, rolled-back copy) is ONE kernel here, working in place on the fused QKV GEMM
+// output in its NATURAL token order [b, D, H, W, 3C]:
+//   * roll + window_partition are an index map   rowmap[w*N + n] = token row (inside one sample) of slot n of window w;
+//     K / V / Q rows are gathered through it on their way into LDS / registers and O (dQ, dK, dV) rows are scattered back
+//     through the same map, which IS window_reverse + the roll back (a permutation and its inverse).
+//   * the relative position bias is never expanded: bias(i, j) = table[rel[i] - rel[j] + relc][head] with
+//     rel[t] = d*(2wh-1)(2ww-1) + h*(2ww-1) + w of slot t in the FULL window (videoswin.py:112-126 is exactly this
+//     difference), so a workgroup keeps its head's table column (2535 floats) and rel[] in LDS and gathers per score.
+//   * the shift mask is (label[i] != label[j]) ? -100 : 0 with one region label per slot (compute_mask's img_mask).
+//   * backward: d(table) is a histogram of dS over rel[i] - rel[j]: accumulated in LDS per workgroup (over all the windows
+//     the workgroup walks), written as per-workgroup partials and summed by win_table_grad_kernel (deterministic, no
+//     global atomics).
+// One workgroup = one (window, head): the whole window's K and V^T (forward), K, V, K^T (dQ pass) or Q, dO, Q^T, dO^T
+// (dK/dV pass) are LDS resident, every wave then runs barrier free over its own 16-row tiles with the same register
+// layouts as the streaming kernels (attention.hip): scores transposed, so softmax statistics are per-lane scalars and the
+// probabilities feed the next MFMA from registers.
+// Both element types: bf16 (windows up to 448 slots) and the exact-fp32 parity instantiation (up to 192 slots: LDS).
+#include "attn_common.h"
+
+#define WIN_D 32
+
+struct WinArgs {
+    const void* qkv;            // [rows][3C]  q | k | v, head h at columns h*32 (+C, +2C)
+    void* o;                    // [rows][C]
+    float* lse;                 // [B*nW][heads][N]
+    const void* dout;           // [rows][C]
+    void* dqkv;                 // [rows][3C]
+    float* delta;               // [B*nW][heads][N]
+    const int* rowmap;          // [nW*N]
+    const int* rel;             // [N]
+    const uint8_t* label;       // [nW*N] or null (no shift)
+    const void* table;          // [R][heads]
+    float* dtable_part;         // [gridDim.y][heads][R]
+    int B, nW, N, heads, C, R, relc, rows_per_sample, wpb;
+    float scale;
+};
+
+template <typename T> struct WinGeo {
+    static constexpr int VEC = ElemTraits<T>::VEC;
+    static constexpr int CH = WIN_D / VEC;                    // 16-B chunks per row: 4 / 8
+    static constexpr int NDG = CH / 4;                        // fragment k-groups over d: 1 / 2
+    static constexpr int RS = WIN_D * (int)sizeof(T) + 16;    // row image: stride of one token row (80 / 144 B: conflict free b128 reads)
+    DEVINL static int ts(int npad) { return npad * (int)sizeof(T) + 16; }   // transposed image: stride of one d row
+    DEVINL static int img_a(int npad) { return npad * RS; }
+    DEVINL static int img_b(int npad) { return WIN_D * ts(npad); }
+};
+
+// ---- staging: gathered token rows -> row image [slot][d] and / or transposed image [d][slot]; pad slots are zero
+template <typename T, bool ROWIMG, bool TRIMG>
+DEVINL void win_stage(const T* __restrict__ src, int64_t ld, int col, const int* rows, int N, int npad, char* imgA, char* imgB,
+                      int tid, int nthreads) {
+    typedef WinGeo<T> G;
+    const int ts = G::ts(npad);
+    for (int idx = tid; idx < npad * G::CH; idx += nthreads) {
+        const int n = idx / G::CH, c = idx % G::CH;
+        u32x4_t v = {0u, 0u, 0u, 0u};
+        if (n < N) v = *(const u32x4_t*)(src + (int64_t)rows[n] * ld + col + c * G::VEC);
+        if (ROWIMG) *(u32x4_t*)(imgA + n * G::RS + c * 16) = v;
+        if (TRIMG) {
+            if constexpr (G::VEC == 8) {
+#pragma unroll
+                for (int i = 0; i < 8; ++i)
+                    *(uint16_t*)(imgB + (c * 8 + i) * ts + n * 2) = (uint16_t)(v[i >> 1] >> ((i & 1) * 16));
+            } else {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) *(uint32_t*)(imgB + (c * 4 + i) * ts + n * 4) = v[i];
+            }
+        }
+    }
+}
+
+template <typename T>
+DEVINL typename Mma<T>::frag_t win_frag(const char* imgA, int row, int dg, int g) {
+    return *(const typename Mma<T>::frag_t*)(imgA + row * WinGeo<T>::RS + (dg * 4 + g) * 16);
+}
+template <typename T>
+DEVINL typename Mma<T>::frag_t win_load_frag(const T* rowp, int dg, int g, bool ok) {
+    u32x4_t z = {0u, 0u, 0u, 0u};
+    if (ok) z = *(const u32x4_t*)(rowp + (dg * 4 + g) * ElemTraits<T>::VEC);
+    return __builtin_bit_cast(typename Mma<T>::frag_t, z);
+}
+
+// acc[dt] += sum over the 64 slots tok0 .. tok0+63 of  X^T[d][slot] * p[slot]   (imgB rows = d, 2 tiles of 16 d).
+// p4[t]: this lane's values for slots tok0 + 16t + 4g + (0..3)  ->  acc[dt][r] = out[d = 16dt + 4g + r][this lane's fr].
+template <typename T>
+DEVINL void win_nat_mma(const char* imgB, int ts, int tok0, const f32x4_t (&p4)[4], f32x4_t (&acc)[2], int fr, int g) {
+    if constexpr (ElemTraits<T>::DT == VALOR_DT_BF16) {
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            const bf16x8_t pf = pack_bf16x8(p4[2 * kk], p4[2 * kk + 1]);
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt) {
+                const char* a = imgB + (dt * 16 + fr) * ts + (tok0 + 32 * kk + 4 * g) * 2;
+                const u32x2_t lo = *(const u32x2_t*)a, hi = *(const u32x2_t*)(a + 32);
+                const u32x4_t x = {lo[0], lo[1], hi[0], hi[1]};
+                acc[dt] = Mma<bf16_t>::mma(__builtin_bit_cast(bf16x8_t, x), pf, acc[dt]);
+            }
+        }
+    } else {
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt) {
+                const f32x4_t x = *(const f32x4_t*)(imgB + (dt * 16 + fr) * ts + (tok0 + 16 * t + 4 * g) * 4);
+                acc[dt] = Mma<float>::mma(x, p4[t], acc[dt]);
+            }
+    }
+}
+
+// store this lane's 4 consecutive d values (d = 16dt + 4g .. +3) of its row
+template <typename T>
+DEVINL void win_store4(T* rowp, int dt, int g, f32x4_t v) {
+    T* d = rowp + dt * 16 + 4 * g;
+    if constexpr (ElemTraits<T>::DT == VALOR_DT_BF16) {
+        u32x2_t w = {pack2_bf16(v[0], v[1]), pack2_bf16(v[2], v[3])};
+        *(u32x2_t*)d = w;
+    } else {
+        *(f32x4_t*)d = v;
+    }
+}
+
+struct WinSmem {
+    float* tb; int* rel; int* lab; int* rows; char* img;
+};
+// per-window bookkeeping arrays: global row of every slot, rel[], labels (pad slots: row 0 / never used)
+DEVINL void win_fill_slots(const WinArgs& p, const WinSmem& s, int b, int w, int npad, int tid, int nthreads) {
+    for (int n = tid; n < npad; n += nthreads) {
+        const bool ok = n < p.N;
+        s.rows[n] = ok ? b * p.rows_per_sample + p.rowmap[w * p.N + n] : 0;
+        s.rel[n] = ok ? p.rel[n] : 0;
+        s.lab[n] = (ok && p.label) ? (int)p.label[w * p.N + n] : 0;
+    }
+}
+template <typename T>
+DEVINL void win_fill_table(const WinArgs& p, float* tb, int h, int tid, int nthreads) {
+    const T* t = (const T*)p.table;
+    for (int r = tid; r < p.R; r += nthreads) tb[r] = to_f32<T>(t[(int64_t)r * p.heads + h]);
+}
+DEVINL WinSmem win_carve(char* smem, int R, int npad, bool hist, float** hist_out) {
+    WinSmem s;
+    s.tb = (float*)smem; smem += ((R + 3) & ~3) * 4;
+    if (hist) { *hist_out = (float*)smem; smem += ((R + 3) & ~3) * 4; }
+    s.rel = (int*)smem; smem += npad * 4;
+    s.lab = (int*)smem; smem += npad * 4;
+    s.rows = (int*)smem; smem += npad * 4;
+    s.img = smem;
+    return s;
+}
+static int win_small_bytes(int R, int npad, bool hist) { return ((R + 3) & ~3) * 4 * (hist ? 2 : 1) + 3 * npad * 4; }
+
+// ------------------------------------------------------------------------------------------ forward
+// grid (heads, B*nW), 256 threads. LDS: K row image, V^T image.
+template <typename T>
+__global__ __launch_bounds__(256) void win_fwd_kernel(WinArgs p) {
+    typedef WinGeo<T> G;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, fr = lane & 15, g = lane >> 4;
+    const int h = blockIdx.x, gw = blockIdx.y, b = gw / p.nW, w = gw % p.nW;
+    const int N = p.N, npad = (N + 63) & ~63, ts = G::ts(npad);
+    WinSmem s = win_carve(smem, p.R, npad, false, nullptr);
+    char* sK = s.img;
+    char* sVt = sK + G::img_a(npad);
+    win_fill_slots(p, s, b, w, npad, tid, 256);
+    win_fill_table<T>(p, s.tb, h, tid, 256);
+    __syncthreads();
+    const T* qkv = (const T*)p.qkv;
+    const int64_t ld = 3 * (int64_t)p.C;
+    win_stage<T, true, false>(qkv, ld, p.C + h * WIN_D, s.rows, N, npad, sK, nullptr, tid, 256);
+    win_stage<T, false, true>(qkv, ld, 2 * p.C + h * WIN_D, s.rows, N, npad, nullptr, sVt, tid, 256);
+    __syncthreads();
+
+    for (int qt = wave; qt * 16 < N; qt += 4) {
+        const int qr = qt * 16 + fr;
+        const bool qok = qr < N;
+        const int qrow = s.rows[qok ? qr : 0];
+        typename Mma<T>::frag_t qf[G::NDG];
+#pragma unroll
+        for (int dg = 0; dg < G::NDG; ++dg) qf[dg] = win_load_frag<T>(qkv + (int64_t)qrow * ld + h * WIN_D, dg, g, qok);
+        const int relq = s.rel[qr] + p.relc, labq = s.lab[qr];
+        float m = -1e30f, l = 0.f;
+        f32x4_t oacc[2] = {(f32x4_t){0.f, 0.f, 0.f, 0.f}, (f32x4_t){0.f, 0.f, 0.f, 0.f}};
+        for (int k0 = 0; k0 < npad; k0 += 64) {
+            f32x4_t sacc[4];
+#pragma unroll
+            for (int kt = 0; kt < 4; ++kt) {
+                sacc[kt] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int dg = 0; dg < G::NDG; ++dg) sacc[kt] = Mma<T>::mma(win_frag<T>(sK, k0 + kt * 16 + fr, dg, g), qf[dg], sacc[kt]);
+            }
+            float mx = -INFINITY;
+#pragma unroll
+            for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int key = k0 + kt * 16 + 4 * g + r;
+                    float v = sacc[kt][r] * p.scale + s.tb[relq - s.rel[key]];
+                    if (s.lab[key] != labq) v -= 100.0f;
+                    if (key >= N) v = -INFINITY;
+                    sacc[kt][r] = v;
+                    mx = fmaxf(mx, v);
+                }
+            mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+            const float mnew = fmaxf(m, mx);
+            const float alpha = fexp<T>(m - mnew);
+            m = mnew;
+            float ps = 0.f;
+#pragma unroll
+            for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float e = fexp<T>(sacc[kt][r] - mnew);
+                    sacc[kt][r] = e;
+                    ps += e;
+                }
+            ps += __shfl_xor(ps, 16, 64);
+            ps += __shfl_xor(ps, 32, 64);
+            l = l * alpha + ps;
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) oacc[dt][r] *= alpha;
+            win_nat_mma<T>(sVt, ts, k0, sacc, oacc, fr, g);
+        }
+        if (qok) {
+            const float inv = 1.0f / l;
+            T* orow = (T*)p.o + (int64_t)qrow * p.C + h * WIN_D;
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt) {
+                f32x4_t v = oacc[dt];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] *= inv;
+                win_store4<T>(orow, dt, g, v);
+            }
+            if (g == 0) p.lse[((int64_t)gw * p.heads + h) * N + qr] = m + logf(l);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------ backward 1: dQ, delta, d(table)
+// grid (heads, ceil(B*nW / wpb)), 512 threads; the workgroup walks wpb consecutive windows with one bias histogram.
+// LDS: K, V row images, K^T image.
+template <typename T>
+__global__ __launch_bounds__(512) void win_bwd_dq_kernel(WinArgs p) {
+    typedef WinGeo<T> G;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, fr = lane & 15, g = lane >> 4;
+    const int h = blockIdx.x;
+    const int N = p.N, npad = (N + 63) & ~63, ts = G::ts(npad);
+    float* hist;
+    WinSmem s = win_carve(smem, p.R, npad, true, &hist);
+    char* sK = s.img;
+    char* sV = sK + G::img_a(npad);
+    char* sKt = sV + G::img_a(npad);
+    win_fill_table<T>(p, s.tb, h, tid, 512);
+    for (int r = tid; r < p.R; r += 512) hist[r] = 0.f;
+    const T* qkv = (const T*)p.qkv;
+    const int64_t ld = 3 * (int64_t)p.C;
+
+    for (int wi = 0; wi < p.wpb; ++wi) {
+        const int gw = blockIdx.y * p.wpb + wi;
+        if (gw >= p.B * p.nW) break;
+        const int b = gw / p.nW, w = gw % p.nW;
+        __syncthreads();                                   // previous window's images / slot arrays are done with
+        win_fill_slots(p, s, b, w, npad, tid, 512);
+        __syncthreads();
+        win_stage<T, true, true>(qkv, ld, p.C + h * WIN_D, s.rows, N, npad, sK, sKt, tid, 512);
+        win_stage<T, true, false>(qkv, ld, 2 * p.C + h * WIN_D, s.rows, N, npad, sV, nullptr, tid, 512);
+        __syncthreads();
+
+        for (int qt = wave; qt * 16 < N; qt += 8) {
+            const int qr = qt * 16 + fr;
+            const bool qok = qr < N;
+            const int qrow = s.rows[qok ? qr : 0];
+            typename Mma<T>::frag_t qf[G::NDG], dof[G::NDG];
+            float dl = 0.f;
+#pragma unroll
+            for (int dg = 0; dg < G::NDG; ++dg) {
+                qf[dg] = win_load_frag<T>(qkv + (int64_t)qrow * ld + h * WIN_D, dg, g, qok);
+                dof[dg] = win_load_frag<T>((const T*)p.dout + (int64_t)qrow * p.C + h * WIN_D, dg, g, qok);
+                typename Mma<T>::frag_t of = win_load_frag<T>((const T*)p.o + (int64_t)qrow * p.C + h * WIN_D, dg, g, qok);
+#pragma unroll
+                for (int i = 0; i < G::VEC; ++i) dl += (float)dof[dg][i] * (float)of[i];
+            }
+            dl += __shfl_xor(dl, 16, 64);
+            dl += __shfl_xor(dl, 32, 64);
+            const int64_t stat = ((int64_t)gw * p.heads + h) * N + qr;
+            const float lse = qok ? p.lse[stat] : 0.f;
+            if (qok && g == 0) p.delta[stat] = dl;
+            const int relq = s.rel[qr] + p.relc, labq = s.lab[qr];
+            f32x4_t dqacc[2] = {(f32x4_t){0.f, 0.f, 0.f, 0.f}, (f32x4_t){0.f, 0.f, 0.f, 0.f}};
+            for (int k0 = 0; k0 < npad; k0 += 64) {
+                f32x4_t sacc[4], dpacc[4];
+#pragma unroll
+                for (int kt = 0; kt < 4; ++kt) {
+                    sacc[kt] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+                    dpacc[kt] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int dg = 0; dg < G::NDG; ++dg) {
+                        sacc[kt] = Mma<T>::mma(win_frag<T>(sK, k0 + kt * 16 + fr, dg, g), qf[dg], sacc[kt]);
+                        dpacc[kt] = Mma<T>::mma(win_frag<T>(sV, k0 + kt * 16 + fr, dg, g), dof[dg], dpacc[kt]);
+                    }
+                }
+#pragma unroll
+                for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int key = k0 + kt * 16 + 4 * g + r;
+                        const int bi = relq - s.rel[key];
+                        float v = sacc[kt][r] * p.scale + s.tb[bi];
+                        if (s.lab[key] != labq) v -= 100.0f;
+                        float ds = 0.f;
+                        if (qok && key < N) {
+                            ds = fexp<T>(v - lse) * (dpacc[kt][r] - dl);
+                            atomicAdd(&hist[bi], ds);
+                        }
+                        sacc[kt][r] = ds;
+                    }
+                win_nat_mma<T>(sKt, ts, k0, sacc, dqacc, fr, g);
+            }
+            if (qok) {
+                T* drow = (T*)p.dqkv + (int64_t)qrow * ld + h * WIN_D;
+#pragma unroll
+                for (int dt = 0; dt < 2; ++dt) {
+                    f32x4_t v = dqacc[dt];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] *= p.scale;
+                    win_store4<T>(drow, dt, g, v);
+                }
+            }
+        }
+    }
+    __syncthreads();
+    float* part = p.dtable_part + ((int64_t)blockIdx.y * p.heads + h) * p.R;
+    for (int r = tid; r < p.R; r += 512) part[r] = hist[r];
+}
+
+// ------------------------------------------------------------------------------------------ backward 2: dK, dV
+// grid (heads, B*nW), 512 threads. LDS: Q, dO row images, Q^T, dO^T images, lse / delta of the window.
+template <typename T>
+__global__ __launch_bounds__(512) void win_bwd_dkv_kernel(WinArgs p) {
+    typedef WinGeo<T> G;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, fr = lane & 15, g = lane >> 4;
+    const int h = blockIdx.x, gw = blockIdx.y, b = gw / p.nW, w = gw % p.nW;
+    const int N = p.N, npad = (N + 63) & ~63, ts = G::ts(npad);
+    WinSmem s = win_carve(smem, p.R, npad, false, nullptr);
+    float* s_lse = (float*)s.img;
+    float* s_dl = s_lse + npad;
+    char* sQ = (char*)(s_dl + npad);
+    char* sdO = sQ + G::img_a(npad);
+    char* sQt = sdO + G::img_a(npad);
+    char* sdOt = sQt + G::img_b(npad);
+    win_fill_slots(p, s, b, w, npad, tid, 512);
+    win_fill_table<T>(p, s.tb, h, tid, 512);
+    for (int n = tid; n < npad; n += 512) {
+        const int64_t stat = ((int64_t)gw * p.heads + h) * N + n;
+        s_lse[n] = n < N ? p.lse[stat] : 0.f;
+        s_dl[n] = n < N ? p.delta[stat] : 0.f;
+    }
+    __syncthreads();
+    const T* qkv = (const T*)p.qkv;
+    const int64_t ld = 3 * (int64_t)p.C;
+    win_stage<T, true, true>(qkv, ld, h * WIN_D, s.rows, N, npad, sQ, sQt, tid, 512);
+    win_stage<T, true, true>((const T*)p.dout, (int64_t)p.C, h * WIN_D, s.rows, N, npad, sdO, sdOt, tid, 512);
+    __syncthreads();
+
+    for (int kt = wave; kt * 16 < N; kt += 8) {
+        const int kr = kt * 16 + fr;
+        const bool kok = kr < N;
+        const int krow = s.rows[kok ? kr : 0];
+        typename Mma<T>::frag_t kf[G::NDG], vf[G::NDG];
+#pragma unroll
+        for (int dg = 0; dg < G::NDG; ++dg) {
+            kf[dg] = win_load_frag<T>(qkv + (int64_t)krow * ld + p.C + h * WIN_D, dg, g, kok);
+            vf[dg] = win_load_frag<T>(qkv + (int64_t)krow * ld + 2 * p.C + h * WIN_D, dg, g, kok);
+        }
+        const int relk = s.rel[kr] - p.relc, labk = s.lab[kr];
+        f32x4_t dkacc[2] = {(f32x4_t){0.f, 0.f, 0.f, 0.f}, (f32x4_t){0.f, 0.f, 0.f, 0.f}};
+        f32x4_t dvacc[2] = {(f32x4_t){0.f, 0.f, 0.f, 0.f}, (f32x4_t){0.f, 0.f, 0.f, 0.f}};
+        for (int q0 = 0; q0 < npad; q0 += 64) {
+            // sacc[t][r] = S[q = q0 + 16t + 4g + r][key = fr] ; dpacc likewise
+            f32x4_t sacc[4], dpacc[4];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                sacc[t] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+                dpacc[t] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int dg = 0; dg < G::NDG; ++dg) {
+                    sacc[t] = Mma<T>::mma(win_frag<T>(sQ, q0 + t * 16 + fr, dg, g), kf[dg], sacc[t]);
+                    dpacc[t] = Mma<T>::mma(win_frag<T>(sdO, q0 + t * 16 + fr, dg, g), vf[dg], dpacc[t]);
+                }
+            }
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int q = q0 + t * 16 + 4 * g + r;
+                    float v = sacc[t][r] * p.scale + s.tb[s.rel[q] - relk];
+                    if (s.lab[q] != labk) v -= 100.0f;
+                    float pr = 0.f, ds = 0.f;
+                    if (kok && q < N) {
+                        pr = fexp<T>(v - s_lse[q]);
+                        ds = pr * (dpacc[t][r] - s_dl[q]);
+                    }
+                    sacc[t][r] = pr;
+                    dpacc[t][r] = ds;
+                }
+            win_nat_mma<T>(sdOt, ts, q0, sacc, dvacc, fr, g);
+            win_nat_mma<T>(sQt, ts, q0, dpacc, dkacc, fr, g);
+        }
+        if (kok) {
+            T* drow = (T*)p.dqkv + (int64_t)krow * ld + h * WIN_D;
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt) {
+                f32x4_t v = dkacc[dt];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] *= p.scale;
+                win_store4<T>(drow + p.C, dt, g, v);
+                win_store4<T>(drow + 2 * p.C, dt, g, dvacc[dt]);
+            }
+        }
+    }
+}
+
+// d(table)[r][h] (+)= sum over workgroup partials part[j][h][r]
+template <typename T>
+__global__ __launch_bounds__(256) void win_table_grad_kernel(const float* part, int nparts, int heads, int R, T* dtable, int accumulate) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= heads * R) return;
+    const int h = i / R, r = i % R;
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    const int64_t stride = (int64_t)heads * R;
+    const float* src = part + (int64_t)h * R + r;
+    int j = 0;
+    for (; j + 4 <= nparts; j += 4) {
+        a0 += src[(j + 0) * stride]; a1 += src[(j + 1) * stride]; a2 += src[(j + 2) * stride]; a3 += src[(j + 3) * stride];
+    }
+    for (; j < nparts; ++j) a0 += src[j * stride];
+    const float v = (a0 + a1) + (a2 + a3);
+    T* o = dtable + (int64_t)r * heads + h;
+    *o = from_f32<T>((accumulate ? to_f32<T>(*o) : 0.f) + v);
+}
+
+// ------------------------------------------------------------------------------------------ launchers
+template <typename T> static int win_lds_fwd(int R, int npad) { return win_small_bytes(R, npad, false) + WinGeo<T>::RS * npad + WIN_D * (npad * (int)sizeof(T) + 16); }
+template <typename T> static int win_lds_dq(int R, int npad) { return win_small_bytes(R, npad, true) + 2 * WinGeo<T>::RS * npad + WIN_D * (npad * (int)sizeof(T) + 16); }
+template <typename T> static int win_lds_dkv(int R, int npad) { return win_small_bytes(R, npad, false) + 2 * npad * 4 + 2 * WinGeo<T>::RS * npad + 2 * WIN_D * (npad * (int)sizeof(T) + 16); }
+#define WIN_LDS_MAX (160 * 1024)
+
+static bool win_check(const WinArgs& p) {
+    return p.B > 0 && p.nW > 0 && p.N > 0 && p.heads > 0 && p.C == p.heads * WIN_D && p.R > 0 && p.rowmap && p.rel && p.table && p.qkv &&
+           (int64_t)p.B * p.nW <= 65535;
+}
+
+template <typename T>
+static int win_fwd_launch(hipStream_t st, const WinArgs& p) {
+    const int npad = (p.N + 63) & ~63, lds = win_lds_fwd<T>(p.R, npad);
+    if (lds > WIN_LDS_MAX) return VALOR_ERR_ARG;
+    hipFuncSetAttribute((const void*)win_fwd_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    hipLaunchKernelGGL(win_fwd_kernel<T>, dim3(p.heads, p.B * p.nW), dim3(256), lds, st, p);
+    return hipGetLastError() == hipSuccess ? VALOR_OK : VALOR_ERR_LAUNCH;
+}
+template <typename T>
+static int win_bwd_launch(hipStream_t st, const WinArgs& p, void* dtable, int accumulate, int nparts) {
+    const int npad = (p.N + 63) & ~63, l1 = win_lds_dq<T>(p.R, npad), l2 = win_lds_dkv<T>(p.R, npad);
+    if (l1 > WIN_LDS_MAX || l2 > WIN_LDS_MAX) return VALOR_ERR_ARG;
+    hipFuncSetAttribute((const void*)win_bwd_dq_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, l1);
+    hipFuncSetAttribute((const void*)win_bwd_dkv_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, l2);
+    hipLaunchKernelGGL(win_bwd_dq_kernel<T>, dim3(p.heads, nparts), dim3(512), l1, st, p);
+    hipLaunchKernelGGL(win_bwd_dkv_kernel<T>, dim3(p.heads, p.B * p.nW), dim3(512), l2, st, p);
+    hipLaunchKernelGGL(win_table_grad_kernel<T>, dim3((p.heads * p.R + 255) / 256), dim3(256), 0, st, p.dtable_part, nparts, p.heads, p.R,
+                       (T*)dtable, accumulate);
+    return hipGetLastError() == hipSuccess ? VALOR_OK : VALOR_ERR_LAUNCH;
+}
+
+// windows one dQ workgroup walks: enough workgroups to fill the chip several times over, as few histogram partials as that allows
+static int win_wpb(int B, int nW, int heads) {
+    const int total = B * nW;
+    int wpb = (int)(((int64_t)total * heads) / 4096);
+    if (wpb < 1) wpb = 1;
+    if (wpb > 16) wpb = 16;
+    return wpb;
+}
+
+extern "C" int valor_win_attn_workspace_floats(int B, int nW, int heads, int table_rows) {
+    const int wpb = win_wpb(B, nW, heads);
+    const int nparts = (B * nW + wpb - 1) / wpb;
+    const int64_t n = (int64_t)nparts * heads * table_rows;
+    return n > 0x7fffffff ? VALOR_ERR_ARG : (int)n;
+}
+
+extern "C" int valor_win_attn_fwd(void* stream, int dtype, const void* qkv, void* o, float* lse, const int* rowmap, const int* rel,
+                                  const uint8_t* label, const void* table, int B, int nW, int N, int heads, int table_rows, int relc,
+                                  int rows_per_sample, float scale) {
+    WinArgs p = {};
+    p.qkv = qkv; p.o = o; p.lse = lse; p.rowmap = rowmap; p.rel = rel; p.label = label; p.table = table;
+    p.B = B; p.nW = nW; p.N = N; p.heads = heads; p.C = heads * WIN_D; p.R = table_rows; p.relc = relc; p.rows_per_sample = rows_per_sample;
+    p.wpb = 1; p.scale = scale;
+    if (!win_check(p) || !o || !lse) return VALOR_ERR_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    return dtype == VALOR_DT_BF16 ? win_fwd_launch<bf16_t>(st, p) : dtype == VALOR_DT_F32 ? win_fwd_launch<float>(st, p) : VALOR_ERR_ARG;
+}
+
+extern "C" int valor_win_attn_bwd(void* stream, int dtype, const void* qkv, const void* o, const float* lse, const void* dout, void* dqkv,
+                                  float* delta, const int* rowmap, const int* rel, const uint8_t* label, const void* table, void* dtable,
+                                  int accumulate_dtable, void* workspace, int64_t workspace_bytes, int B, int nW, int N, int heads,
+                                  int table_rows, int relc, int rows_per_sample, float scale) {
+    WinArgs p = {};
+    p.qkv = qkv; p.o = (void*)o; p.lse = (float*)lse; p.dout = dout; p.dqkv = dqkv; p.delta = delta; p.rowmap = rowmap; p.rel = rel;
+    p.label = label; p.table = table; p.dtable_part = (float*)workspace;
+    p.B = B; p.nW = nW; p.N = N; p.heads = heads; p.C = heads * WIN_D; p.R = table_rows; p.relc = relc; p.rows_per_sample = rows_per_sample;
+    p.scale = scale;
+    if (!win_check(p) || !o || !lse || !dout || !dqkv || !delta || !dtable || !workspace) return VALOR_ERR_ARG;
+    p.wpb = win_wpb(B, nW, heads);
+    const int nparts = (B * nW + p.wpb - 1) / p.wpb;
+    if (workspace_bytes < (int64_t)nparts * heads * table_rows * 4) return VALOR_ERR_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    return dtype == VALOR_DT_BF16 ? win_bwd_launch<bf16_t>(st, p, dtable, accumulate_dtable, nparts)
+         : dtype == VALOR_DT_F32 ? win_bwd_launch<float>(st, p, dtable, accumulate_dtable, nparts) : VALOR_ERR_ARG;
+}

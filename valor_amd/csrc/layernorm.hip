@@ -33,6 +33,7 @@ struct LnArgs {
     int64_t rows; int cols;
     float eps, p_drop;
     uint64_t seed, offset;
+    const float* row_scale; int64_t rows_per_scale;   // stochastic depth: (x + bias) *= row_scale[row / rows_per_scale] (or null)
 };
 
 template <typename T, int NV>
@@ -50,6 +51,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(LnArgs p) {
         const int64_t base = row * cols;
         f32x4_t v[NV];
         float s = 0.f;
+        const float rsc = p.row_scale ? p.row_scale[row / p.rows_per_scale] : 1.0f;
 #pragma unroll
         for (int i = 0; i < NV; ++i) {
             const int c = (i * 64 + lane) * 4;
@@ -62,6 +64,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(LnArgs p) {
 #pragma unroll
                     for (int k = 0; k < 4; ++k) t[k] = rnd.v[k] >= thr ? t[k] * keep_scale : 0.f;
                 }
+                if (p.row_scale) t *= rsc;
                 if (R) t += load4<T>(R + base + c);
                 if (Z) store4<T>(Z + base + c, t);
                 // LN statistics use the value that backward will re-read from z
@@ -112,6 +115,7 @@ struct LnBwdArgs {
     int64_t rows; int cols;
     float p_drop;
     uint64_t seed, offset;
+    const float* row_scale; int64_t rows_per_scale;
 };
 
 template <typename T, int NV>
@@ -144,6 +148,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(LnBwdArgs p) {
 
     for (int64_t row = (int64_t)blockIdx.x * 4 + wave; row < p.rows; row += (int64_t)gridDim.x * 4) {
         const int64_t base = row * cols;
+        const float rsc = p.row_scale ? p.row_scale[row / p.rows_per_scale] : 1.0f;
         f32x4_t dzv[NV];
         if (has_ln) {
             const float mu = p.mean[row], rs = p.rstd[row];
@@ -190,7 +195,8 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(LnBwdArgs p) {
 #pragma unroll
                     for (int k = 0; k < 4; ++k) dx[k] = rnd.v[k] >= thr ? dz[k] * keep_scale : 0.f;
                 }
-                if (DX && (thr || DX != DR)) store4<T>(DX + base + c, dx);
+                if (p.row_scale) dx *= rsc;
+                if (DX && (thr || p.row_scale || DX != DR)) store4<T>(DX + base + c, dx);
                 xsum[i] += dx;
             }
         }
@@ -357,11 +363,12 @@ extern "C" int valor_ln_part_blocks() { return LN_PART_BLOCKS; }
 
 extern "C" int valor_bdrln_fwd(void* stream, int dtype, const void* x, const void* bias, const void* residual,
                                const void* gamma, const void* beta, void* z, void* y, float* mean, float* rstd,
-                               int64_t rows, int cols, float eps, float p_drop, uint64_t seed, uint64_t offset) {
+                               int64_t rows, int cols, float eps, float p_drop, uint64_t seed, uint64_t offset,
+                               const float* row_scale, int64_t rows_per_scale) {
     if (rows <= 0) return VALOR_OK;
     if (!x || cols <= 0 || (cols & 3) || cols > 64 * 4 * LN_MAX_V) return VALOR_ERR_ARG;
-    if (p_drop < 0.f || p_drop >= 1.f) return VALOR_ERR_ARG;
-    LnArgs p{x, bias, residual, gamma, beta, z, y, mean, rstd, rows, cols, eps, p_drop, seed, offset};
+    if (p_drop < 0.f || p_drop >= 1.f || (row_scale && rows_per_scale <= 0)) return VALOR_ERR_ARG;
+    LnArgs p{x, bias, residual, gamma, beta, z, y, mean, rstd, rows, cols, eps, p_drop, seed, offset, row_scale, rows_per_scale};
     hipStream_t st = (hipStream_t)stream;
     if (dtype == VALOR_DT_BF16) return launch_ln_fwd<bf16_t>(st, p);
     if (dtype == VALOR_DT_F32) return launch_ln_fwd<float>(st, p);
@@ -372,12 +379,14 @@ extern "C" int valor_bdrln_fwd(void* stream, int dtype, const void* x, const voi
 extern "C" int valor_bdrln_bwd(void* stream, int dtype, const void* dy, const void* dz_in, const void* z,
                                const float* mean, const float* rstd, const void* gamma, void* dx, void* dres,
                                float* part_dgamma, float* part_dbeta, float* part_dbias, int64_t rows, int cols,
-                               float p_drop, uint64_t seed, uint64_t offset) {
+                               float p_drop, uint64_t seed, uint64_t offset, const float* row_scale, int64_t rows_per_scale) {
     if (rows <= 0) return VALOR_OK;
     if (cols <= 0 || (cols & 3) || cols > 64 * 4 * LN_MAX_V) return VALOR_ERR_ARG;
     if (dy && (!z || !mean || !rstd)) return VALOR_ERR_ARG;
     if (!dy && !dz_in) return VALOR_ERR_ARG;
-    LnBwdArgs p{dy, dz_in, z, mean, rstd, gamma, dx, dres, part_dgamma, part_dbeta, part_dbias, rows, cols, p_drop, seed, offset};
+    if (row_scale && (rows_per_scale <= 0 || dx == dres)) return VALOR_ERR_ARG;
+    LnBwdArgs p{dy, dz_in, z, mean, rstd, gamma, dx, dres, part_dgamma, part_dbeta, part_dbias, rows, cols, p_drop, seed, offset,
+                row_scale, rows_per_scale};
     hipStream_t st = (hipStream_t)stream;
     if (dtype == VALOR_DT_BF16) return launch_ln_bwd<bf16_t>(st, p);
     if (dtype == VALOR_DT_F32) return launch_ln_bwd<float>(st, p);

@@ -24,6 +24,52 @@ __global__ void patchify_kernel(const float* in, T* out, int N, int C, int H, in
     }
 }
 
+// patchify3d: VideoSwin PatchEmbed3D (videoswin.py:361-369) = Conv3d(kernel (2,P,P), stride (1,P,P)) after one zero frame is
+// appended: every output token (b, d, py, px) sees frames d and d+1. in: fp32 [B][F][C][H][W] (batch layout, no transpose);
+//   out[((b*F + d)*gh + py)*gw + px][((c*2 + kd)*P + i)*P + j] = d + kd < F ? in[b][d + kd][c][py*P + i][px*P + j] : 0
+template <typename T>
+__global__ void patchify3d_kernel(const float* in, T* out, int B, int F, int C, int H, int W, int P) {
+    const int gh = H / P, gw = W / P, K = C * 2 * P * P;
+    const int64_t total4 = (int64_t)B * F * gh * gw * K / 4;
+    for (int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; q < total4; q += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t e = q * 4;
+        const int k = (int)(e % K);
+        const int64_t tok = e / K;
+        const int px = (int)(tok % gw), py = (int)((tok / gw) % gh);
+        const int64_t bd = tok / ((int64_t)gw * gh);
+        const int d = (int)(bd % F);
+        const int64_t b = bd / F;
+        const int j = k % P, i = (k / P) % P, kd = (k / (P * P)) % 2, c = k / (2 * P * P);   // j % 4 == 0 (P % 4 == 0)
+        f32x4_t v = {0.f, 0.f, 0.f, 0.f};
+        if (d + kd < F) v = *(const f32x4_t*)(in + ((((int64_t)b * F + d + kd) * C + c) * H + (py * P + i)) * W + px * P + j);
+        store4<T>(out + e, v);
+    }
+}
+
+// group mean over X consecutive rows and its backward (VideoSwin token pooling, modeling.py:388-389)
+template <typename T>
+__global__ void group_mean_fwd_kernel(const T* in, T* out, int64_t groups, int X, int E) {
+    const int E4 = E / 4;
+    const float inv = 1.0f / (float)X;
+    for (int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; q < groups * E4; q += (int64_t)gridDim.x * blockDim.x) {
+        const int e = (int)(q % E4) * 4;
+        const int64_t gidx = q / E4;
+        f32x4_t a = {0.f, 0.f, 0.f, 0.f};
+        for (int x = 0; x < X; ++x) a += load4<T>(in + (gidx * X + x) * E + e);
+        store4<T>(out + gidx * E + e, a * inv);
+    }
+}
+template <typename T>
+__global__ void group_mean_bwd_kernel(const T* dout, T* din, int64_t groups, int X, int E) {
+    const int E4 = E / 4;
+    const float inv = 1.0f / (float)X;
+    for (int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; q < groups * X * E4; q += (int64_t)gridDim.x * blockDim.x) {
+        const int e = (int)(q % E4) * 4;
+        const int64_t row = q / E4;
+        store4<T>(din + row * E + e, load4<T>(dout + (row / X) * E + e) * inv);
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // token assembly: out[n][0] = cls + pos[0] ; out[n][1+p] = patches[n][p] (+ bias) + pos[1+p]
 // (clip.py:264-265 class_embedding / positional_embedding; modeling.py:755-760 AST cls_token /
@@ -297,6 +343,38 @@ extern "C" int valor_patchify(void* stream, int dtype, const float* in, void* ou
     DISPATCH_T(dtype,
         hipLaunchKernelGGL((patchify_kernel<bf16_t>), dim3(grid_for(work)), dim3(256), 0, st, in, (bf16_t*)out, N, C, H, W, P),
         hipLaunchKernelGGL((patchify_kernel<float>), dim3(grid_for(work)), dim3(256), 0, st, in, (float*)out, N, C, H, W, P));
+    return valor_launch_status();
+}
+
+extern "C" int valor_patchify3d(void* stream, int dtype, const float* in, void* out, int B, int F, int C, int H, int W, int P) {
+    if (B <= 0 || F <= 0) return VALOR_OK;
+    if (!in || !out || (P & 3) || H % P || W % P) return VALOR_ERR_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    const int64_t work = (int64_t)B * F * C * 2 * H * W / 4;
+    DISPATCH_T(dtype,
+        hipLaunchKernelGGL((patchify3d_kernel<bf16_t>), dim3(grid_for(work)), dim3(256), 0, st, in, (bf16_t*)out, B, F, C, H, W, P),
+        hipLaunchKernelGGL((patchify3d_kernel<float>), dim3(grid_for(work)), dim3(256), 0, st, in, (float*)out, B, F, C, H, W, P));
+    return valor_launch_status();
+}
+
+extern "C" int valor_group_mean_fwd(void* stream, int dtype, const void* in, void* out, int64_t groups, int X, int E) {
+    if (groups <= 0) return VALOR_OK;
+    if (!in || !out || X <= 0 || (E & 3)) return VALOR_ERR_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    const int64_t work = groups * E / 4;
+    DISPATCH_T(dtype,
+        hipLaunchKernelGGL((group_mean_fwd_kernel<bf16_t>), dim3(grid_for(work)), dim3(256), 0, st, (const bf16_t*)in, (bf16_t*)out, groups, X, E),
+        hipLaunchKernelGGL((group_mean_fwd_kernel<float>), dim3(grid_for(work)), dim3(256), 0, st, (const float*)in, (float*)out, groups, X, E));
+    return valor_launch_status();
+}
+extern "C" int valor_group_mean_bwd(void* stream, int dtype, const void* dout, void* din, int64_t groups, int X, int E) {
+    if (groups <= 0) return VALOR_OK;
+    if (!dout || !din || X <= 0 || (E & 3)) return VALOR_ERR_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    const int64_t work = groups * X * E / 4;
+    DISPATCH_T(dtype,
+        hipLaunchKernelGGL((group_mean_bwd_kernel<bf16_t>), dim3(grid_for(work)), dim3(256), 0, st, (const bf16_t*)dout, (bf16_t*)din, groups, X, E),
+        hipLaunchKernelGGL((group_mean_bwd_kernel<float>), dim3(grid_for(work)), dim3(256), 0, st, (const float*)dout, (float*)din, groups, X, E));
     return valor_launch_status();
 }
 

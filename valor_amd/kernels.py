@@ -91,8 +91,8 @@ def part_blocks():
 
 
 def bdrln_fwd(x, bias, residual, gamma, beta, eps, *, p_drop=0.0, seed=0, offset=0, write_z=True, inplace_z=False,
-              want_y=True):
-    """z = dropout(x + bias)/(1-p) + residual ; y = LN(z).  Returns (z, y, mean, rstd)."""
+              want_y=True, row_scale=None, rows_per_scale=0):
+    """z = dropout(x + bias)/(1-p) [* row_scale[row // rows_per_scale]] + residual ; y = LN(z).  Returns (z, y, mean, rstd)."""
     _check_gpu(x, bias, residual, gamma, beta)
     cols = x.shape[-1]
     rows = x.numel() // cols
@@ -104,13 +104,14 @@ def bdrln_fwd(x, bias, residual, gamma, beta, eps, *, p_drop=0.0, seed=0, offset
     mean = torch.empty(rows, dtype=torch.float32, device=x.device) if want_y else None
     rstd = torch.empty(rows, dtype=torch.float32, device=x.device) if want_y else None
     lib.call("valor_bdrln_fwd", _stream(), dt_of(x), _ptr(x), _ptr(bias), _ptr(residual), _ptr(gamma), _ptr(beta),
-             _ptr(z), _ptr(y), _ptr(mean), _ptr(rstd), rows, cols, float(eps), float(p_drop), int(seed), int(offset))
+             _ptr(z), _ptr(y), _ptr(mean), _ptr(rstd), rows, cols, float(eps), float(p_drop), int(seed), int(offset),
+             _ptr(row_scale), int(rows_per_scale))
     return z, y, mean, rstd
 
 
 def bdrln_bwd(dy, dz_in, z, mean, rstd, gamma, *, p_drop=0.0, seed=0, offset=0, want_dgamma=True, want_dbeta=True,
-              want_dbias=False, separate_dx=False, sinks=(None, None, None)):
-    """Returns (dx, dres, dgamma, dbeta, dbias) ; dx is dres when there is no dropout.
+              want_dbias=False, separate_dx=False, sinks=(None, None, None), row_scale=None, rows_per_scale=0):
+    """Returns (dx, dres, dgamma, dbeta, dbias) ; dx is dres when there is no dropout / row scale.
     sinks = (dgamma, dbeta, dbias) tensors to ACCUMULATE the parameter gradients into (the result slot is None then)."""
     ref = dy if dy is not None else dz_in
     _check_gpu(dy, dz_in, z, gamma)
@@ -124,10 +125,10 @@ def bdrln_bwd(dy, dz_in, z, mean, rstd, gamma, *, p_drop=0.0, seed=0, offset=0, 
     pb = ws[nb * cols:2 * nb * cols] if (want_dbeta and dy is not None) else None
     px = ws[2 * nb * cols:3 * nb * cols] if want_dbias else None
     dres = torch.empty_like(ref)
-    dx = torch.empty_like(ref) if (p_drop > 0.0 or separate_dx) else dres
+    dx = torch.empty_like(ref) if (p_drop > 0.0 or separate_dx or row_scale is not None) else dres
     lib.call("valor_bdrln_bwd", _stream(), dt_of(ref), _ptr(dy), _ptr(dz_in), _ptr(z), _ptr(mean), _ptr(rstd),
              _ptr(gamma), _ptr(dx), _ptr(dres), _ptr(pg), _ptr(pb), _ptr(px), rows, cols, float(p_drop), int(seed),
-             int(offset))
+             int(offset), _ptr(row_scale), int(rows_per_scale))
     outs, args = [], []
     for part, sink in zip((pg, pb, px), sinks):
         if part is None:
@@ -213,3 +214,62 @@ def attn_bwd(q, k, v, o, lse, dout, n_heads, *, dq=None, dk=None, dv=None, mask=
              dqb, dqr, dkb, dkr, dvb, dvr, _ptr(mask), mb, mr, _ptr(kv_range), int(kv_bmod), float(scale),
              float(p_drop), int(seed), int(offset), int(accumulate_kv))
     return dq, dk, dv
+
+
+# ---------------------------------------------------------------------------------------------- VideoSwin
+def win_attn_fwd(qkv, geo, table, n_heads, B):
+    """3-D shifted-window attention (head_dim 32) in place on the fused QKV rows [B*rows_per_sample, 3C].
+    geo: dict(rowmap int32 [nW*N], rel int32 [N], label uint8 [nW*N] | None, nW, N, relc, rows). Returns (o, lse)."""
+    _check_gpu(qkv, table, geo["rowmap"], geo["rel"], geo["label"])
+    C = n_heads * 32
+    assert qkv.is_contiguous() and qkv.shape == (B * geo["rows"], 3 * C) and table.is_contiguous() and table.shape[1] == n_heads
+    o = torch.empty((qkv.shape[0], C), dtype=qkv.dtype, device=qkv.device)
+    lse = torch.empty((B * geo["nW"], n_heads, geo["N"]), dtype=torch.float32, device=qkv.device)
+    lib.call("valor_win_attn_fwd", _stream(), dt_of(qkv), _ptr(qkv), _ptr(o), _ptr(lse), _ptr(geo["rowmap"]), _ptr(geo["rel"]),
+             _ptr(geo["label"]), _ptr(table), B, geo["nW"], geo["N"], n_heads, table.shape[0], geo["relc"], geo["rows"], 32 ** -0.5)
+    return o, lse
+
+
+def win_attn_bwd(qkv, o, lse, dout, geo, table, n_heads, B, dtable=None):
+    """Returns (dqkv, dtable); dtable given -> accumulated into (and None returned in its place)."""
+    _check_gpu(qkv, o, dout, table, dtable)
+    assert dout.is_contiguous() and dout.shape == o.shape
+    dqkv = torch.empty_like(qkv)
+    delta = torch.empty_like(lse)
+    acc = dtable is not None
+    if dtable is None:
+        dtable = torch.empty_like(table)
+    need = lib.load().valor_win_attn_workspace_floats(B, geo["nW"], n_heads, table.shape[0])
+    if need < 0:
+        raise lib.ValorHipError("window attention workspace too large")
+    ws = workspace(qkv.device, max(_WS_BYTES, need * 4))
+    lib.call("valor_win_attn_bwd", _stream(), dt_of(qkv), _ptr(qkv), _ptr(o), _ptr(lse), _ptr(dout), _ptr(dqkv), _ptr(delta),
+             _ptr(geo["rowmap"]), _ptr(geo["rel"]), _ptr(geo["label"]), _ptr(table), _ptr(dtable), int(acc), _ptr(ws), ws.numel() * 4,
+             B, geo["nW"], geo["N"], n_heads, table.shape[0], geo["relc"], geo["rows"], 32 ** -0.5)
+    return dqkv, (None if acc else dtable)
+
+
+def patchify3d(video_f32, P, out_dtype):
+    """video [B, F, C, H, W] fp32 -> [B*F*(H/P)*(W/P), C*2*P*P] rows of PatchEmbed3D's conv (one zero frame appended)."""
+    _check_gpu(video_f32)
+    assert video_f32.dtype == torch.float32 and video_f32.is_contiguous()
+    B, F, C, H, W = video_f32.shape
+    out = torch.empty((B * F * (H // P) * (W // P), C * 2 * P * P), dtype=out_dtype, device=video_f32.device)
+    lib.call("valor_patchify3d", _stream(), dt_of(out), _ptr(video_f32), _ptr(out), B, F, C, H, W, P)
+    return out
+
+
+def group_mean_fwd(x2d, X):
+    _check_gpu(x2d)
+    assert x2d.is_contiguous() and x2d.shape[0] % X == 0
+    out = torch.empty((x2d.shape[0] // X, x2d.shape[1]), dtype=x2d.dtype, device=x2d.device)
+    lib.call("valor_group_mean_fwd", _stream(), dt_of(x2d), _ptr(x2d), _ptr(out), out.shape[0], X, x2d.shape[1])
+    return out
+
+
+def group_mean_bwd(dout, X):
+    _check_gpu(dout)
+    dout = dout.contiguous()
+    din = torch.empty((dout.shape[0] * X, dout.shape[1]), dtype=dout.dtype, device=dout.device)
+    lib.call("valor_group_mean_bwd", _stream(), dt_of(dout), _ptr(dout), _ptr(din), dout.shape[0], X, dout.shape[1])
+    return din

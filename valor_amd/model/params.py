@@ -8,8 +8,10 @@ projections are stored PACKED so the fused-QKV GEMM consumes them in place:
         -> ...cross_attn.cross.kv.{weight [2H,H], bias [2H]}
   audio_encoder.layer.N.attention.linears.{0,1,2}.{weight,bias}                        (transformer.py:109)
         -> ...attention.qkv.{weight,bias}
-CLIP's in_proj_weight is packed already (clip.py:176). cls.decoder.weight is tied to the word
-embeddings (modeling.py:241) and is not a separate parameter.
+CLIP's in_proj_weight is packed already (clip.py:176), and so is VideoSwin's attn.qkv (videoswin.py:129).
+The VideoSwin + BERT-text variant (scripts/pretrain.sh:3-8) has video_encoder.* / contra_head_{t,v} / hidden_trans_video_multimodal
+instead of clip_model.*; its shared text encoder appears in the reference state dict a second time as txt_encoder.* (same storage).
+cls.decoder.weight is tied to the word embeddings (modeling.py:241) and is not a separate parameter.
 state_dict()/load_state_dict() of the model translate to/from the reference keys, so checkpoints
 (utils/save.py:45-64 `model_step_N.pt`) stay drop-in.
 """
@@ -55,13 +57,36 @@ def param_table(spec: ValorSpec):
             add(p + "mlp.c_fc.weight", (4 * width, width)); add(p + "mlp.c_fc.bias", (4 * width,))
             add(p + "mlp.c_proj.weight", (width, 4 * width)); add(p + "mlp.c_proj.bias", (width,))
 
-    # ---- CLIP visual
-    add("clip_model.visual.conv1.weight", (W, 3, spec.patch, spec.patch))
-    add("clip_model.visual.class_embedding", (W,)); add("clip_model.visual.positional_embedding", (spec.vis_tokens, W))
-    add("clip_model.visual.ln_pre.weight", (W,)); add("clip_model.visual.ln_pre.bias", (W,))
-    clip_blocks("clip_model.visual.transformer", W, spec.vis_layers)
-    add("clip_model.visual.ln_post.weight", (W,)); add("clip_model.visual.ln_post.bias", (W,))
-    add("clip_model.visual.proj", (W, E))
+    swin = spec.video_encoder == "swin"
+    if swin:
+        # ---- VideoSwin (videoswin.py:378-458; keys of SwinTransformer3D.state_dict(); relative_position_index is a buffer
+        # that the model regenerates, see VALOR.state_dict)
+        C0 = spec.swin_embed
+        add("video_encoder.patch_embed.proj.weight", (C0, 3, 2, 4, 4)); add("video_encoder.patch_embed.proj.bias", (C0,))
+        add("video_encoder.patch_embed.norm.weight", (C0,)); add("video_encoder.patch_embed.norm.bias", (C0,))
+        for li, (depth, nh) in enumerate(zip(spec.swin_depths, spec.swin_heads)):
+            C = C0 * 2 ** li
+            for bi in range(depth):
+                p = f"video_encoder.layers.{li}.blocks.{bi}."
+                add(p + "norm1.weight", (C,)); add(p + "norm1.bias", (C,))
+                add(p + "attn.qkv.weight", (3 * C, C)); add(p + "attn.qkv.bias", (3 * C,))
+                add(p + "attn.relative_position_bias_table", (spec.swin_table, nh))
+                add(p + "attn.proj.weight", (C, C)); add(p + "attn.proj.bias", (C,))
+                add(p + "norm2.weight", (C,)); add(p + "norm2.bias", (C,))
+                add(p + "mlp.fc1.weight", (4 * C, C)); add(p + "mlp.fc1.bias", (4 * C,))
+                add(p + "mlp.fc2.weight", (C, 4 * C)); add(p + "mlp.fc2.bias", (C,))
+            if li + 1 < len(spec.swin_depths):
+                p = f"video_encoder.layers.{li}.downsample."
+                add(p + "norm.weight", (4 * C,)); add(p + "norm.bias", (4 * C,)); add(p + "reduction.weight", (2 * C, 4 * C))
+        add("video_encoder.norm.weight", (spec.swin_out,)); add("video_encoder.norm.bias", (spec.swin_out,))
+    else:
+        # ---- CLIP visual
+        add("clip_model.visual.conv1.weight", (W, 3, spec.patch, spec.patch))
+        add("clip_model.visual.class_embedding", (W,)); add("clip_model.visual.positional_embedding", (spec.vis_tokens, W))
+        add("clip_model.visual.ln_pre.weight", (W,)); add("clip_model.visual.ln_pre.bias", (W,))
+        clip_blocks("clip_model.visual.transformer", W, spec.vis_layers)
+        add("clip_model.visual.ln_post.weight", (W,)); add("clip_model.visual.ln_post.bias", (W,))
+        add("clip_model.visual.proj", (W, E))
     # ---- AST
     add("audio_embeddings.first_conv.weight", (AW, 1, spec.aud_patch, spec.aud_patch)); add("audio_embeddings.first_conv.bias", (AW,))
     add("audio_embeddings.cls_token", (1, 1, AW)); add("audio_embeddings.position_embeddings.weight", (spec.aud_tokens, AW))
@@ -75,19 +100,25 @@ def param_table(spec: ValorSpec):
         add(p + "ff_layer.linear1.weight", (spec.aud_inter, AW)); add(p + "ff_layer.linear1.bias", (spec.aud_inter,))
         add(p + "ff_layer.linear2.weight", (AW, spec.aud_inter)); add(p + "ff_layer.linear2.bias", (AW,))
     add("audio_encoder.last_layernorm.weight", (AW,)); add("audio_encoder.last_layernorm.bias", (AW,))
-    # ---- CLIP text
-    add("clip_model.token_embedding.weight", (spec.clip_vocab, TW)); add("clip_model.positional_embedding", (spec.ctx_len, TW))
-    add("clip_model.prompt_embedding.weight", (1, TW))
-    clip_blocks("clip_model.transformer", TW, spec.txt_layers)
-    add("clip_model.ln_final.weight", (TW,)); add("clip_model.ln_final.bias", (TW,))
-    add("clip_model.text_projection", (TW, E)); add("clip_model.logit_scale", ())
+    if not swin:
+        # ---- CLIP text
+        add("clip_model.token_embedding.weight", (spec.clip_vocab, TW)); add("clip_model.positional_embedding", (spec.ctx_len, TW))
+        add("clip_model.prompt_embedding.weight", (1, TW))
+        clip_blocks("clip_model.transformer", TW, spec.txt_layers)
+        add("clip_model.ln_final.weight", (TW,)); add("clip_model.ln_final.bias", (TW,))
+        add("clip_model.text_projection", (TW, E)); add("clip_model.logit_scale", ())
     # ---- contrastive heads
+    if swin:                                                   # Contra_head, pretrain.py:33-38,94-95 (no bias)
+        add("contra_head_t.linear.weight", (E, spec.txt_dim)); add("contra_head_v.linear.weight", (E, spec.video_dim))
     add("contra_head_a.linear.weight", (E, AW))
     for m in ("text", "video", "audio"):
         add(f"{m}_fine_weight.0.weight", (E, E)); add(f"{m}_fine_weight.0.bias", (E,))
         add(f"{m}_fine_weight.2.weight", (1, E)); add(f"{m}_fine_weight.2.bias", (1,))
     add("contra_temp", ())
     # ---- decoder inputs
+    if spec.video_dim != H:                                    # modeling.py:348-349
+        add("hidden_trans_video_multimodal.0.weight", (H, spec.video_dim)); add("hidden_trans_video_multimodal.0.bias", (H,))
+        add("hidden_trans_video_multimodal.1.weight", (H,)); add("hidden_trans_video_multimodal.1.bias", (H,))
     add("video_frame_embedding", (1, 32, H)); add("video_type_embeddings", (1, 1, H))
     add("audio_frame_embedding", (1, 32, H)); add("audio_type_embeddings", (1, 1, H))
     # ---- BERT multimodal decoder

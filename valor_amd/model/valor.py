@@ -30,7 +30,7 @@ from .. import ops
 from ..arena import ParamArena
 from ..hoststage import HostStage
 from ..lib import ACT_GELU_ERF, ACT_QUICK_GELU, ACT_RELU
-from ..synth import ValorSpec, base_spec, synthetic_vocab
+from ..synth import ValorSpec, base_spec, swin_relative_position_index, swin_spec, synthetic_vocab
 from .params import optimizer_group, param_table
 
 PROMPTS = {
@@ -85,18 +85,35 @@ class VALOR(nn.Module):
     def __init__(self, opts=None, spec: ValorSpec = None, dtype=torch.bfloat16, device="cuda", vocab_tokens=None):
         super().__init__()
         self.opts = opts
-        vtype = _opt(opts, "video_encoder_type", "clip_vit_base_16")
-        ttype = _opt(opts, "txt_encoder_type", "clip_vit_base_16")
-        if not (vtype.startswith("clip_vit_base") and ttype.startswith("clip_vit_base")):
-            raise NotImplementedError("round 1 covers the CLIP-ViT-B variant (config/pretrain-VALOR-base.json); "
-                                      f"got video={vtype} text={ttype}")
+        # the two shipped base configurations: config/pretrain-VALOR-base.json (CLIP-ViT-B/16 video + CLIP text) and
+        # scripts/pretrain.sh:3-8 (VideoSwin-B video + the shared BERT as text encoder)
+        vtype = _opt(opts, "video_encoder_type", None)
+        ttype = _opt(opts, "txt_encoder_type", None)
+        want = None
+        if vtype is not None or ttype is not None:
+            vtype = vtype or "clip_vit_base_16"
+            ttype = ttype or ("bert_base_uncased" if vtype.startswith("videoswin") else "clip_vit_base_16")
+            if vtype.startswith("clip_vit_base") and ttype.startswith("clip_vit_base"):
+                want = ("clip", "clip")
+            elif vtype.startswith("videoswin_base") and ttype.startswith("bert") and _opt(opts, "share_txt_and_multimodal", True):
+                want = ("swin", "bert")
+            else:
+                raise NotImplementedError("covered: clip_vit_base video + clip_vit_base text, videoswin_base video + shared bert "
+                                          f"text; got video={vtype} text={ttype}")
+        if spec is None:
+            spec = swin_spec() if want == ("swin", "bert") else base_spec()
+        elif want is not None and want != (spec.video_encoder, spec.txt_encoder):
+            raise NotImplementedError(f"opts ask for {want} encoders, the spec describes {(spec.video_encoder, spec.txt_encoder)}")
+        if (spec.video_encoder, spec.txt_encoder) not in (("clip", "clip"), ("swin", "bert")):
+            raise NotImplementedError("the reference loads CLIP as a whole: video/text encoders come as clip+clip or swin+bert")
         if _opt(opts, "contra_type", "fine") != "fine" or _opt(opts, "caption_type", "unimlm") != "unimlm":
             raise NotImplementedError("contra_type='fine' and caption_type='unimlm' only")
         if _opt(opts, "cross_attn_type", "va_concate") != "va_concate" or _opt(opts, "late_fusion", False) or _opt(opts, "full_masker", False):
             raise NotImplementedError("cross_attn_type='va_concate', late_fusion=False, full_masker=False only")
         if _opt(opts, "fineweight_type", "one") == "none":
             raise NotImplementedError("fineweight_type='none' is a TypeError in the reference too (pretrain.py:330)")
-        self.spec = spec or base_spec()
+        self.spec = spec
+        self.drop_path = float(_opt(opts, "drop_path_rate", spec.swin_drop_path))   # videoswin.py:393 (active in training)
         self.dtype = dtype
         self.device = torch.device(device)
         self.use_task_prompt = bool(_opt(opts, "use_task_prompt", False))
@@ -139,6 +156,15 @@ class VALOR(nn.Module):
                 rows = shape[0] // len(refs)
                 for i, r in enumerate(refs):
                     out[r] = p[i * rows:(i + 1) * rows]
+        if self.spec.video_encoder == "swin":
+            # the integer buffer of every WindowAttention3D (videoswin.py:126) and the txt_encoder.* view of the shared
+            # multimodal encoder (modeling.py:689-691) are part of the reference's state dict
+            relidx = swin_relative_position_index(self.spec.swin_window)
+            for name, _, _ in self.table:
+                if name.endswith("attn.relative_position_bias_table"):
+                    out[name.replace("relative_position_bias_table", "relative_position_index")] = relidx
+            for k in [k for k in out if k.startswith("multimodal_encoder.")]:
+                out["txt_encoder." + k[len("multimodal_encoder."):]] = out[k]
         return out
 
     def load_state_dict(self, sd, strict=True):
@@ -158,7 +184,8 @@ class VALOR(nn.Module):
                             p[i * rows:(i + 1) * rows].copy_(sd[r].to(p.dtype)); used.add(r)
                         else:
                             missing.append(r)
-        unexpected = [k for k in sd if k not in used]
+        unexpected = [k for k in sd if k not in used and not (self.spec.video_encoder == "swin" and (
+            k.endswith("relative_position_index") or (k.startswith("txt_encoder.") and "multimodal_encoder." + k[12:] in used)))]
         if strict and (missing or unexpected):
             raise RuntimeError(f"load_state_dict: missing {missing[:5]} unexpected {unexpected[:5]}")
         return missing, unexpected
@@ -246,8 +273,123 @@ class VALOR(nn.Module):
                 y = ops.bias_dropout_residual_ln(m, P[p + "mlp.c_proj.bias"], x, final_g, final_b, 1e-5, 0.0, False)
         return y
 
+    # ------------------------------------------------------------------ VideoSwin
+    def _swin_geometry(self, D, H, W, shifted):
+        """Device-resident index maps of one block geometry (cached): roll + window_partition as a row map, the shift mask as
+        per-slot region labels (compute_mask, videoswin.py:272-285), rel[] of the relative position bias (:112-126)."""
+        key = ("swin", D, H, W, shifted)
+        geo = self._const.get(key)
+        if geo is not None:
+            return geo
+        full = self.spec.swin_window
+        win = tuple(s if s <= w else w for s, w in zip((D, H, W), full))                  # get_window_size :86-99
+        sh = tuple(0 if (s <= w or not shifted) else w // 2 for s, w in zip((D, H, W), full))
+        if D % win[0] or H % win[1] or W % win[2]:
+            raise NotImplementedError(f"VideoSwin window padding (feature map {D}x{H}x{W}, window {win}): 224-px inputs never pad")
+        wd, wh, ww = win
+        part = lambda a: a.reshape(D // wd, wd, H // wh, wh, W // ww, ww).transpose(0, 2, 4, 1, 3, 5).reshape(-1)
+        idx = np.arange(D * H * W).reshape(D, H, W)
+        label = None
+        if any(sh):
+            idx = np.roll(idx, (-sh[0], -sh[1], -sh[2]), axis=(0, 1, 2))                  # shifted_x[pos] = x[pos + shift]
+            ids = []
+            for X, w, s_ in zip((D, H, W), win, sh):
+                r = np.zeros(X, dtype=np.int64)
+                if s_ > 0:
+                    r[X - w:X - s_] = 1; r[X - s_:] = 2
+                else:
+                    r[:] = 2
+                ids.append(r)
+            lab = ids[0][:, None, None] * 9 + ids[1][None, :, None] * 3 + ids[2][None, None, :]
+            label = torch.from_numpy(part(lab).astype(np.uint8)).to(self.device)
+        N = wd * wh * ww
+        fd, fh, fw = np.meshgrid(np.arange(full[0]), np.arange(full[1]), np.arange(full[2]), indexing="ij")
+        lin = (fd * (2 * full[1] - 1) * (2 * full[2] - 1) + fh * (2 * full[2] - 1) + fw).reshape(-1)
+        geo = dict(rowmap=torch.from_numpy(part(idx).astype(np.int32)).to(self.device), label=label,
+                   rel=torch.from_numpy(lin[:N].astype(np.int32)).to(self.device), relc=int(lin[-1]),
+                   nW=(D // wd) * (H // wh) * (W // ww), N=N, rows=D * H * W)
+        self._const[key] = geo
+        return geo
+
+    def _swin_merge_idx(self, b, D, H, W):
+        """PatchMerging's 2x2 neighbour gather (videoswin.py:262-266) as source rows of the [.., 4C] output viewed as 4 C-rows"""
+        key = ("merge", b, D, H, W)
+        t = self._const.get(key)
+        if t is None:
+            if H % 2 or W % 2:
+                raise NotImplementedError("odd-size PatchMerging padding: 224-px inputs never pad")
+            g = np.arange(b * D * H * W).reshape(b, D, H, W)
+            q = np.stack([g[:, :, 0::2, 0::2], g[:, :, 1::2, 0::2], g[:, :, 0::2, 1::2], g[:, :, 1::2, 1::2]], axis=-1)
+            t = torch.from_numpy(q.reshape(-1).astype(np.int64)).to(self.device)
+            self._const[key] = t
+        return t
+
+    def forward_video_encoder_swin(self, video_pixels):
+        """modeling.py:452-455 -> SwinTransformer3D.forward videoswin.py:441-458. Returns [b, F, H/32 * W/32, C_out].
+        Tokens stay in natural [b, D, H, W] row order through the whole encoder: roll / window_partition / window_reverse
+        live in the attention kernel's index map, PatchMerging is one row gather."""
+        P, sp = self.P, self.spec
+        b, F, c, h, w = video_pixels.shape
+        vid = self._dev(video_pixels.float().contiguous())
+        C = sp.swin_embed
+        e = "video_encoder.patch_embed."
+        tok = ops.linear(ops.patchify3d(vid, 4, self.dtype), P[e + "proj.weight"].view(C, -1), P[e + "proj.bias"])
+        D, H, W = F, h // 4, w // 4
+        x = ops.layer_norm(tok, P[e + "norm.weight"], P[e + "norm.bias"], 1e-5)                 # patch_norm; pos_drop p = 0
+        total = sum(sp.swin_depths)
+        rate = self.drop_path if self.training else 0.0
+        scales = None
+        if rate > 0:                    # stochastic depth, videoswin.py:40-49: one per-sample keep decision per residual branch
+            keep = 1.0 - np.linspace(0.0, rate, total)                                          # dpr, videoswin.py:418
+            u = np.random.random_sample((total, 2, b))
+            scales = self._dev(torch.from_numpy((np.floor(keep[:, None, None] + u) / keep[:, None, None]).astype(np.float32)))
+        k = 0
+        for li, (depth, heads) in enumerate(zip(sp.swin_depths, sp.swin_heads)):
+            rows = D * H * W
+            y = None
+            for bi in range(depth):
+                p = f"video_encoder.layers.{li}.blocks.{bi}."
+                if y is None:
+                    y = ops.layer_norm(x, P[p + "norm1.weight"], P[p + "norm1.bias"], 1e-5)
+                s1 = scales[k, 0] if (scales is not None and k > 0) else None
+                s2 = scales[k, 1] if (scales is not None and k > 0) else None
+                qkv = ops.linear(y, P[p + "attn.qkv.weight"], P[p + "attn.qkv.bias"])
+                a = ops.window_attention(qkv, P[p + "attn.relative_position_bias_table"], self._swin_geometry(D, H, W, bi % 2 == 1), heads, b)
+                o = ops.linear(a, P[p + "attn.proj.weight"], None)
+                x, y2 = ops.bias_dropout_residual_ln(o, P[p + "attn.proj.bias"], x, P[p + "norm2.weight"], P[p + "norm2.bias"], 1e-5, 0.0, True, s1, rows)
+                m = ops.mlp(y2, P[p + "mlp.fc1.weight"], P[p + "mlp.fc1.bias"], P[p + "mlp.fc2.weight"], None, ACT_GELU_ERF)
+                if bi + 1 < depth:
+                    q = f"video_encoder.layers.{li}.blocks.{bi + 1}."
+                    x, y = ops.bias_dropout_residual_ln(m, P[p + "mlp.fc2.bias"], x, P[q + "norm1.weight"], P[q + "norm1.bias"], 1e-5, 0.0, True, s2, rows)
+                elif li + 1 < len(sp.swin_depths):
+                    x = ops.bias_dropout_residual(m, P[p + "mlp.fc2.bias"], x, 0.0, s2, rows)
+                else:
+                    y = ops.bias_dropout_residual_ln(m, P[p + "mlp.fc2.bias"], x, P["video_encoder.norm.weight"], P["video_encoder.norm.bias"], 1e-5, 0.0, False, s2, rows)
+                k += 1
+            if li + 1 < len(sp.swin_depths):
+                d = f"video_encoder.layers.{li}.downsample."
+                xm = ops.gather_rows(x, self._swin_merge_idx(b, D, H, W)).view(-1, 4 * C)
+                xm = ops.layer_norm(xm, P[d + "norm.weight"], P[d + "norm.bias"], 1e-5)
+                x = ops.linear(xm, P[d + "reduction.weight"], None)
+                C, H, W = 2 * C, H // 2, W // 2
+        return y.view(b, D, H * W, C)
+
+    def forward_txt_encoder_bert(self, bert_tokens_cpu):
+        """modeling.py:439-440: the shared multimodal BERT run on the text alone (no cross-attention input), casual=False;
+        pretrain.py:254-263 appends the task prompt when use_task_prompt and drops its rows again. Returns [b, L, hidden]."""
+        L = bert_tokens_cpu.shape[1]
+        prompt = self.get_task_prompt(PROMPTS["contra"], bert_tokens_cpu.shape[0]) if self.use_task_prompt else None
+        x = self._bert_embed(self._dev(bert_tokens_cpu), L, None)
+        if prompt is not None:
+            x = torch.cat((x, self._bert_embed(self._dev(prompt), prompt.shape[1], "prompt")), dim=1)
+        mask = self._dev(self._bert_mask(bert_tokens_cpu, prompt, False))
+        out = self.bert_encoder(x, mask, None, None, 0)
+        return out[:, :L].contiguous() if prompt is not None else out
+
     def forward_video_encoder(self, video_pixels):
         """modeling.py:449-465 (clip) -> VisionTransformer.forward clip.py:259-274. Returns [b, F, 197, W]."""
+        if self.spec.video_encoder == "swin":
+            return self.forward_video_encoder_swin(video_pixels)
         P, sp = self.P, self.spec
         b, n, c, h, w = video_pixels.shape
         imgs = self._dev(video_pixels.reshape(b * n, c, h, w).float())
@@ -473,8 +615,12 @@ class VALOR(nn.Module):
         if "a" in alltasks:
             audio_output = self.forward_audio_encoder(batch["audio_spectrograms"])
         if "t" in "".join(contra_task):
-            clip_tokens = txt_tokens["clip_tokens"].cpu()
-            txt_output = self.forward_txt_encoder(clip_tokens)
+            if sp.txt_encoder == "bert":                          # get_text_tokens: the bert ids (pretrain.py:252)
+                clip_tokens = txt_tokens["bert_tokens"].cpu()
+                txt_output = self.forward_txt_encoder_bert(clip_tokens)
+            else:
+                clip_tokens = txt_tokens["clip_tokens"].cpu()
+                txt_output = self.forward_txt_encoder(clip_tokens)
         if col is not None:
             col.update(video_output=video_output, audio_output=audio_output, txt_output=txt_output)
 
@@ -483,9 +629,16 @@ class VALOR(nn.Module):
             feat_t = feat_v = feat_a = None
             tok_contra = None
             if txt_output is not None:
-                feat_t = ops.l2_normalize(ops.linear(txt_output, P["clip_model.text_projection"], None, w_is_kn=True))
+                if sp.txt_encoder == "bert":                      # Contra_head (pretrain.py:33-38,94)
+                    feat_t = ops.l2_normalize(ops.linear(txt_output, P["contra_head_t.linear.weight"], None))
+                else:
+                    feat_t = ops.l2_normalize(ops.linear(txt_output, P["clip_model.text_projection"], None, w_is_kn=True))
                 tok_contra = clip_tokens
-            if "v" in "".join(contra_task):
+            if "v" in "".join(contra_task) and sp.video_encoder == "swin":
+                b, F, X = video_output.shape[:3]                  # mean over the frame's tokens (modeling.py:388-389)
+                pooled = ops.group_mean(video_output.reshape(-1, sp.video_dim), X)
+                feat_v = ops.l2_normalize(ops.linear(pooled, P["contra_head_v.linear.weight"], None)).view(b, F, -1)
+            elif "v" in "".join(contra_task):
                 b, F = video_output.shape[:2]
                 idx = self._const_idx(b * F, sp.vis_tokens)
                 cls_v = ops.gather_rows(video_output.reshape(-1, sp.vis_width), idx)
@@ -500,7 +653,10 @@ class VALOR(nn.Module):
             if col is not None:
                 col.update(feat_t=feat_t, feat_v=feat_v, feat_a=feat_a)
             if compute_loss:
-                k = P["clip_model.logit_scale"].float().exp()                    # 1/temp, modeling.py:420-426
+                if sp.video_encoder == "clip":
+                    k = P["clip_model.logit_scale"].float().exp()                # 1/temp, modeling.py:420-426
+                else:
+                    k = 1.0 / P["contra_temp"].float()
                 maskA = (tok_contra != 0).float().contiguous() if tok_contra.is_cuda else self._dev((tok_contra != 0).float()).contiguous()
                 fw = lambda name, f: ops.rowdot(ops.linear(f, P[f"{name}_fine_weight.0.weight"], P[f"{name}_fine_weight.0.bias"], ACT_RELU),
                                                 P[f"{name}_fine_weight.2.weight"], P[f"{name}_fine_weight.2.bias"]).float().squeeze(-1)
@@ -532,6 +688,11 @@ class VALOR(nn.Module):
         if video_output is not None or audio_output is not None:
             Sv = video_output.shape[1] * video_output.shape[2] if video_output is not None else 0
             Sa = audio_output.shape[1] * audio_output.shape[2] if audio_output is not None else 0
+            if video_output is not None and "hidden_trans_video_multimodal.0.weight" in P:       # modeling.py:348-349,487-488
+                hv = ops.linear(video_output.reshape(-1, sp.video_dim), P["hidden_trans_video_multimodal.0.weight"],
+                                P["hidden_trans_video_multimodal.0.bias"])
+                hv = ops.layer_norm(hv, P["hidden_trans_video_multimodal.1.weight"], P["hidden_trans_video_multimodal.1.bias"], 1e-12)
+                video_output = hv.view(*video_output.shape[:3], sp.hidden)
             if video_output is not None and audio_output is not None:
                 va = ops.cross_input(video_output, audio_output, P["video_frame_embedding"], P["video_type_embeddings"],
                                      P["audio_frame_embedding"], P["audio_type_embeddings"])

@@ -205,17 +205,19 @@ class BdrLnFn(Function):
     mode flags: want_z -> return the pre-LN sum z (pre-LN residual stream); otherwise only y."""
 
     @staticmethod
-    def forward(ctx, x, bias, residual, gamma, beta, eps, p_drop, want_z):
+    def forward(ctx, x, bias, residual, gamma, beta, eps, p_drop, want_z, row_scale=None, rows_per_scale=0):
         x = x.contiguous()
         ctx.set_materialize_grads(False)
         seed = off = 0
         if p_drop > 0:
             seed, off = DropoutState.draw(x.numel())
-        plain = bias is None and residual is None and p_drop == 0
+        plain = bias is None and residual is None and p_drop == 0 and row_scale is None
         assert not (plain and want_z), "want_z needs a bias / residual / dropout stage"
         z, y, mean, rstd = K.bdrln_fwd(x, bias, residual.contiguous() if residual is not None else None, gamma, beta,
-                                       eps, p_drop=p_drop, seed=seed, offset=off, write_z=not plain)
+                                       eps, p_drop=p_drop, seed=seed, offset=off, write_z=not plain, row_scale=row_scale,
+                                       rows_per_scale=rows_per_scale)
         ctx.save_for_backward(x if plain else z, mean, rstd, gamma)
+        ctx.rs = (row_scale, rows_per_scale)
         ctx.cfg = (p_drop, seed, off, bias is not None, residual is not None, beta is not None)
         ctx.params = (gamma, beta, bias)
         if want_z:
@@ -233,7 +235,7 @@ class BdrLnFn(Function):
         dy = dy.contiguous() if dy is not None else None
         dz_in = dz_in.contiguous() if dz_in is not None else None
         if dy is None and dz_in is None:
-            return (None,) * 8
+            return (None,) * 10
         if dy is None:   # only the residual stream was used downstream
             dy_eff, mean_e, rstd_e, z_e = None, None, None, None
         else:
@@ -242,32 +244,35 @@ class BdrLnFn(Function):
         sinks = (_sink(pg) if dy_eff is not None else None, _sink(pbeta) if dy_eff is not None else None, _sink(pbias))
         dx, dres, dg, dbeta, dbias = K.bdrln_bwd(dy_eff, dz_in, z_e, mean_e, rstd_e, gamma, p_drop=p_drop, seed=seed,
                                                  offset=off, want_dgamma=gamma is not None, want_dbeta=has_beta,
-                                                 want_dbias=has_b, sinks=sinks)
+                                                 want_dbias=has_b, sinks=sinks, row_scale=ctx.rs[0], rows_per_scale=ctx.rs[1])
         for prm, sk, want in ((pg, sinks[0], gamma is not None), (pbeta, sinks[1], has_beta), (pbias, sinks[2], has_b)):
             if sk is not None and want:
                 _sunk(prm)
-        return dx, dbias, (dres if has_r else None), dg, dbeta, None, None, None
+        return dx, dbias, (dres if has_r else None), dg, dbeta, None, None, None, None, None
 
 
 def layer_norm(x, gamma, beta, eps):
     return BdrLnFn.apply(x, None, None, gamma, beta, eps, 0.0, False)
 
 
-def bias_dropout_residual_ln(x, bias, residual, gamma, beta, eps, p_drop, want_z):
-    return BdrLnFn.apply(x, bias, residual, gamma, beta, eps, p_drop, want_z)
+def bias_dropout_residual_ln(x, bias, residual, gamma, beta, eps, p_drop, want_z, row_scale=None, rows_per_scale=0):
+    """row_scale fp32 [rows / rows_per_scale]: per-sample stochastic-depth factor on (x + bias) (videoswin.py:40-49)"""
+    return BdrLnFn.apply(x, bias, residual, gamma, beta, eps, p_drop, want_z, row_scale, rows_per_scale)
 
 
 class BiasDropResFn(Function):
     """z = dropout(x + bias)/(1-p) + residual  without a LayerNorm (last residual add of a pre-LN block)."""
 
     @staticmethod
-    def forward(ctx, x, bias, residual, p_drop):
+    def forward(ctx, x, bias, residual, p_drop, row_scale=None, rows_per_scale=0):
         x = x.contiguous()
         seed = off = 0
         if p_drop > 0:
             seed, off = DropoutState.draw(x.numel())
         z, _, _, _ = K.bdrln_fwd(x, bias, residual.contiguous() if residual is not None else None, None, None, 0.0,
-                                 p_drop=p_drop, seed=seed, offset=off, write_z=True, want_y=False)
+                                 p_drop=p_drop, seed=seed, offset=off, write_z=True, want_y=False, row_scale=row_scale,
+                                 rows_per_scale=rows_per_scale)
+        ctx.rs = (row_scale, rows_per_scale)
         ctx.cfg = (p_drop, seed, off, bias is not None, residual is not None)
         ctx.params = (bias,)
         return z
@@ -278,14 +283,14 @@ class BiasDropResFn(Function):
         sb = _sink(ctx.params[0]) if has_b else None
         dx, dres, _, _, dbias = K.bdrln_bwd(None, dz.contiguous(), None, None, None, None, p_drop=p_drop, seed=seed,
                                             offset=off, want_dgamma=False, want_dbeta=False, want_dbias=has_b,
-                                            sinks=(None, None, sb))
+                                            sinks=(None, None, sb), row_scale=ctx.rs[0], rows_per_scale=ctx.rs[1])
         if sb is not None:
             _sunk(ctx.params[0])
-        return dx, dbias, (dres if has_r else None), None
+        return dx, dbias, (dres if has_r else None), None, None, None
 
 
-def bias_dropout_residual(x, bias, residual, p_drop):
-    return BiasDropResFn.apply(x, bias, residual, p_drop)
+def bias_dropout_residual(x, bias, residual, p_drop, row_scale=None, rows_per_scale=0):
+    return BiasDropResFn.apply(x, bias, residual, p_drop, row_scale, rows_per_scale)
 
 
 # ------------------------------------------------------------------------------------------------
@@ -796,3 +801,55 @@ class RowDotFn(Function):
 
 def rowdot(x, w, b):
     return RowDotFn.apply(x, w, b)
+
+
+# ------------------------------------------------------------------------------------------------ VideoSwin
+class WinAttnFn(Function):
+    """WindowAttention3D core (videoswin.py:137-160) + roll / window_partition / window_reverse (:205-220) on the fused QKV rows
+    in natural token order; the relative position bias table gets its gradient from the kernel's histogram."""
+
+    @staticmethod
+    def forward(ctx, qkv, table, geo, n_heads, B):
+        qkv = qkv.contiguous()
+        o, lse = K.win_attn_fwd(qkv, geo, table, n_heads, B)
+        ctx.save_for_backward(qkv, o, lse, table)
+        ctx.cfg = (geo, n_heads, B)
+        ctx.params = (table,)
+        return o
+
+    @staticmethod
+    def backward(ctx, do):
+        qkv, o, lse, table = ctx.saved_tensors
+        geo, n_heads, B = ctx.cfg
+        pt = ctx.params[0]
+        st = _sink(pt)
+        dqkv, dtable = K.win_attn_bwd(qkv, o, lse, do.contiguous(), geo, table, n_heads, B, dtable=st)
+        if st is not None:
+            _sunk(pt)
+        return dqkv, dtable, None, None, None
+
+
+def window_attention(qkv, table, geo, n_heads, B):
+    return WinAttnFn.apply(qkv, table, geo, n_heads, B)
+
+
+def patchify3d(video_f32, P, out_dtype):
+    """PatchEmbed3D's conv3d input as GEMM rows (videoswin.py:361-369); pixels carry no gradient"""
+    return K.patchify3d(video_f32, P, out_dtype)
+
+
+class GroupMeanFn(Function):
+    """mean over X consecutive rows (VideoSwin token pooling for the contrastive head, modeling.py:388-389)"""
+
+    @staticmethod
+    def forward(ctx, x2d, X):
+        ctx.X = X
+        return K.group_mean_fwd(x2d.contiguous(), X)
+
+    @staticmethod
+    def backward(ctx, dout):
+        return K.group_mean_bwd(dout, ctx.X), None
+
+
+def group_mean(x2d, X):
+    return GroupMeanFn.apply(x2d, X)

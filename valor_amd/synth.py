@@ -105,8 +105,8 @@ def swin_spec():
 
 def tiny_swin_spec():
     """3-stage VideoSwin (28 -> 14 -> 7 at 112 px: no padding anywhere) on the tiny BERT/AST of tiny_spec()."""
-    return ValorSpec(video_encoder="swin", txt_encoder="bert", resolution=112, swin_embed=32, swin_depths=(2, 2, 2),
-                     swin_heads=(1, 2, 4), swin_drop_path=0.2, embed_dim=128, aud_width=128, aud_layers=2, aud_inter=256,
+    return ValorSpec(video_encoder="swin", txt_encoder="bert", resolution=112, swin_embed=64, swin_depths=(2, 2, 2),
+                     swin_heads=(2, 4, 8), swin_drop_path=0.2, embed_dim=128, aud_width=128, aud_layers=2, aud_inter=256,
                      melbins=32, target_len=64, aud_patch=16, hidden=128, layers=2, inter=256, vocab=1200, max_pos=64)
 
 
