@@ -16,6 +16,7 @@ import sys
 import time
 from types import SimpleNamespace
 
+import numpy as np
 import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -27,14 +28,33 @@ PEAK_BF16_TFLOPS = 2500.0     # dense bf16 MFMA peak, /opt/skills/guides/MI355X_
 
 def necessary_flops_per_sample(spec, frames, audio_slices, txt_len, n_cap_groups=3, mlm_prompt=10, mask_cap=0.6, mask_mlm=0.15):
     """fwd+bwd matmul FLOPs per sample with shared cross-K/V (SURVEY.md 8d formula); bwd = 2 x fwd."""
-    W, H = spec.vis_width, spec.hidden
-    Lv, La = spec.vis_tokens, spec.aud_tokens
-    p_vit = spec.vis_layers * 12 * W * W + 3 * spec.patch ** 2 * W
-    vit = frames * (2 * Lv * p_vit + spec.vis_layers * 4 * Lv * Lv * W)
+    H = spec.hidden
+    La = spec.aud_tokens
+    if spec.video_encoder == "swin":
+        # VideoSwin (videoswin.py): patch embed K = 3*2*4*4, per block 12 C^2 MACs per token + window attention over
+        # N = min(F, wd) * wh * ww slots, PatchMerging 4C -> 2C, then Linear(C_out -> hidden) of modeling.py:348
+        side = spec.resolution // 4
+        C = spec.swin_embed
+        vit = 2 * frames * side * side * 96 * C
+        N = min(frames, spec.swin_window[0]) * spec.swin_window[1] * spec.swin_window[2]
+        for li, depth in enumerate(spec.swin_depths):
+            tokens = frames * side * side
+            vit += depth * (2 * tokens * 12 * C * C + 4 * tokens * min(N, tokens) * C)
+            if li + 1 < len(spec.swin_depths):
+                vit += 2 * (tokens // 4) * 4 * C * 2 * C
+                C, side = 2 * C, side // 2
+        Lv = side * side
+        vit += 2 * frames * Lv * C * H
+        txt = spec.layers * (2 * txt_len * (4 * H * H + 2 * H * spec.inter) + 4 * txt_len ** 2 * H)   # BERT text pass, no cross-attention
+    else:
+        W = spec.vis_width
+        Lv = spec.vis_tokens
+        p_vit = spec.vis_layers * 12 * W * W + 3 * spec.patch ** 2 * W
+        vit = frames * (2 * Lv * p_vit + spec.vis_layers * 4 * Lv * Lv * W)
+        p_txt = spec.txt_layers * 12 * spec.txt_width ** 2
+        txt = 2 * txt_len * p_txt + spec.txt_layers * 4 * txt_len ** 2 * spec.txt_width
     p_ast = spec.aud_layers * (4 * spec.aud_width ** 2 + 2 * spec.aud_width * spec.aud_inter) + spec.aud_patch ** 2 * spec.aud_width
     ast = audio_slices * (2 * La * p_ast + spec.aud_layers * 4 * La * La * spec.aud_width)
-    p_txt = spec.txt_layers * 12 * spec.txt_width ** 2
-    txt = 2 * txt_len * p_txt + spec.txt_layers * 4 * txt_len ** 2 * spec.txt_width
     Sv, Sa = frames * Lv, audio_slices * La
 
     def dec(T, Skv):
@@ -47,18 +67,17 @@ def necessary_flops_per_sample(spec, frames, audio_slices, txt_len, n_cap_groups
     return 3.0 * fwd
 
 
-def cpu_baseline(sample_batch=2, frames=8, audio_slices=2):
+def cpu_baseline(sample_batch=2, frames=8, audio_slices=2, variant="clip"):
     """Reference CPU path as restated by the oracle (kind 'port'), fp32, all host cores, one full step."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import valor_oracle as VO
     from valor_amd import synth
-    spec = synth.base_spec()
+    spec = synth.swin_spec() if variant == "swin" else synth.base_spec()
     sd = synth.make_state_dict(spec, seed=50)
-    sd_o = {k: v.clone().requires_grad_(True) for k, v in sd.items() if k != "cls.decoder.weight"}
-    sd_o["cls.decoder.weight"] = sd_o["multimodal_encoder.embeddings.word_embeddings.weight"]
+    sd_o = VO.trainable_copy(sd)
     orc = VO.Oracle(spec, sd_o, dropout_p=0.0, vocab_tokens=synth.synthetic_vocab(spec.vocab))
     batch = synth.make_batch(spec, batch=sample_batch, frames=frames, audio_slices=audio_slices, txt_len=32, seed=50)
-    params = {k: v for k, v in sd_o.items() if k != "cls.decoder.weight"}
+    params = {k: v for k, v in sd_o.items() if v.requires_grad and not VO.is_alias_key(k)}
     groups = {k: VO.param_group_of(k) for k in params}
     lrs, wds = VO.group_hparams(1e-4, 0.01)
     state = {}
@@ -134,6 +153,9 @@ def main():
     ap.add_argument("--audio-slices", type=int, default=2)
     ap.add_argument("--dropout", type=float, default=0.1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--variant", choices=["clip", "swin"], default="clip",
+                    help="clip: config/pretrain-VALOR-base.json (BASELINE configs[1], the headline); swin: scripts/pretrain.sh "
+                         "(VideoSwin-B + BERT text)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -154,7 +176,8 @@ def main():
     from valor_amd.model.valor import VALOR
     from valor_amd.ops import DropoutState
 
-    spec = synth.base_spec()
+    spec = synth.swin_spec() if args.variant == "swin" else synth.base_spec()
+    np.random.seed(50 + rank)        # VideoSwin stochastic-depth draws
     model = VALOR({"dropout": args.dropout}, spec=spec, dtype=torch.bfloat16, device=dev)
     sd = synth.make_state_dict(spec, seed=50)                   # same weights on every rank (DDP broadcast equivalent)
     model.load_state_dict(sd, strict=True)
@@ -233,10 +256,11 @@ def main():
                                 "timed once; instrumented step %.1f ms)" % (n_inst, inst_elapsed * 1e3),
                     "step_mfu": round(nf * sps / world / 1e12 / PEAK_BF16_TFLOPS, 4),
                     "necessary_gflop_per_sample": round(nf / 1e9, 1)}
-        res = {"metric": "pretrain samples/sec (V+A+T clip)", "value": round(sps, 2), "unit": "samples/s", "n_gpus": world,
+        arch = "CLIP-B/16 + AST + BERT-base" if args.variant == "clip" else "VideoSwin-B + BERT text + AST + BERT-base"
+        res = {"metric": f"pretrain samples/sec (V+A+T {args.variant})", "value": round(sps, 2), "unit": "samples/s", "n_gpus": world,
                "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 2), "higher_is_better": True,
                "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
-               "config": {"workload": "VALOR-base tri-modal (CLIP-B/16 + AST + BERT-base) pretrain step, MGA+MGC+MLM, "
+               "config": {"workload": f"VALOR-base tri-modal ({arch}) pretrain step, MGA+MGC+MLM, "
                                       f"{args.frames} frames x 224^2, {args.audio_slices} x 5.12 s audio, 32 tokens",
                           "per_gpu_batch": args.batch, "global_batch": world * args.batch, "parallelism": f"dp{world}",
                           "dropout": args.dropout, "task": TASK},
@@ -245,7 +269,7 @@ def main():
                "roofline": roof}
         if world == 1 and not args.no_cpu_baseline:
             try:
-                res["cpu_baseline"] = cpu_baseline()
+                res["cpu_baseline"] = cpu_baseline(variant=args.variant)
             except Exception as e:      # the baseline is a reported number only; never fail the bench on it
                 res["cpu_baseline"] = {"value": None, "error": repr(e)}
         print(json.dumps(res), flush=True)

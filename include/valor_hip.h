@@ -116,15 +116,16 @@ int valor_attn_bwd(void* stream, int dtype, const void* q, const void* k, const 
  * it). rel int32 [N]: linearised (d,h,w) of a slot in the FULL window, bias(i,j) = table[rel[i]-rel[j]+relc][head]; table
  * [table_rows][heads]. label uint8 [nW*N] region ids of the shift mask (NULL = unshifted): -100 where labels differ.
  * lse fp32 [B*nW][heads][N]. bf16: N <= 448; fp32 (parity mode): forward N <= 448, backward N <= 192 (the window is LDS resident; VALOR_ERR_ARG beyond). */
-int valor_win_attn_workspace_floats(int B, int nW, int heads, int table_rows);   /* fp32 elements the backward needs */
+int valor_win_attn_workspace_floats(int B, int nW, int N, int heads);   /* fp32 elements the backward needs */
 int valor_win_attn_fwd(void* stream, int dtype, const void* qkv, void* o, float* lse, const int* rowmap, const int* rel,
                        const uint8_t* label, const void* table, int B, int nW, int N, int heads, int table_rows, int relc,
                        int rows_per_sample, float scale);
 /* dqkv [rows][3C] (every row of every window is written); dtable [table_rows][heads] (+= if accumulate_dtable); delta fp32
- * like lse; workspace: valor_win_attn_workspace_floats() fp32 per-workgroup bias-gradient histograms */
+ * like lse; rel_inv int32 [relc + 1]: slot whose rel is m (or -1); workspace: valor_win_attn_workspace_floats() fp32 (dense
+ * per-window-group sums of dS, reduced and gathered into the table after the dQ pass) */
 int valor_win_attn_bwd(void* stream, int dtype, const void* qkv, const void* o, const float* lse, const void* dout, void* dqkv,
-                       float* delta, const int* rowmap, const int* rel, const uint8_t* label, const void* table, void* dtable,
-                       int accumulate_dtable, void* workspace, int64_t workspace_bytes, int B, int nW, int N, int heads,
+                       float* delta, const int* rowmap, const int* rel, const int* rel_inv, const uint8_t* label, const void* table,
+                       void* dtable, int accumulate_dtable, void* workspace, int64_t workspace_bytes, int B, int nW, int N, int heads,
                        int table_rows, int relc, int rows_per_sample, float scale);
 
 /* ---- softmax cross-entropy over the vocabulary: F.cross_entropy on the masked rows (pretrain.py:444,457,469,498).

@@ -1,0 +1,11 @@
+#!/bin/bash
+# VideoSwin variant: bench + rocprofv3 kernel trace
+R=${GRAFT_REPO_ROOT:-/root/repo}
+cd $R; mkdir -p gpurun_out
+timeout 400 python bench.py --variant swin --no-cpu-baseline > gpurun_out/bench_swin.log 2>&1; echo "bench rc=$?"; tail -1 gpurun_out/bench_swin.log | cut -c1-200
+cd /tmp; export TMPDIR=/tmp
+timeout 400 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof_swin -o r01s -- python $R/bench.py --variant swin --steps 3 --warmup 1 --no-cpu-baseline > $R/gpurun_out/prof_swin.log 2>&1; echo "prof rc=$?"
+cd $R
+DB=$(find gpurun_out/prof_swin -name '*.db' | head -1)
+[ -n "$DB" ] && python tools/rocpd_stats.py $DB gpurun_out/kernel_stats_swin.md 45 | head -40 | cut -c1-130
+find gpurun_out/prof_swin -name '*.db' -size +40M -delete

@@ -12,9 +12,12 @@
 //     rel[t] = d*(2wh-1)(2ww-1) + h*(2ww-1) + w of slot t in the FULL window (videoswin.py:112-126 is exactly this
 //     difference), so a workgroup keeps its head's table column (2535 floats) and rel[] in LDS and gathers per score.
 //   * the shift mask is (label[i] != label[j]) ? -100 : 0 with one region label per slot (compute_mask's img_mask).
-//   * backward: d(table) is a histogram of dS over rel[i] - rel[j]: accumulated in LDS per workgroup (over all the windows
-//     the workgroup walks), written as per-workgroup partials and summed by win_table_grad_kernel (deterministic, no
-//     global atomics).
+//   * backward: d(table) is a histogram of dS over rel[i] - rel[j]. LDS float atomics run at about a quarter lane per
+//     clock on this part (measured: the histogram version of the dQ pass took 5 ms per layer, 14x its arithmetic), so
+//     there are none: a dQ workgroup owns a quarter of a window's query rows and walks MANY windows (same head), each
+//     wave summing the dS strip of its 16 queries x all keys over those windows IN REGISTERS (7 x 16 fp32 per lane);
+//     the strips are stored once at the end as dense per-workgroup-group partials [G][head][N][N], summed over G by a
+//     streaming kernel and gathered into the table by win_table_grad_kernel through the inverse of rel[] (deterministic).
 // One workgroup = one (window, head): the whole window's K and V^T (forward), K, V, K^T (dQ pass) or Q, dO, Q^T, dO^T
 // (dK/dV pass) are LDS resident, every wave then runs barrier free over its own 16-row tiles with the same register
 // layouts as the streaming kernels (attention.hip): scores transposed, so softmax statistics are per-lane scalars and the
@@ -23,6 +26,7 @@
 #include "attn_common.h"
 
 #define WIN_D 32
+typedef __attribute__((ext_vector_type(4))) int i32x4_t;
 
 struct WinArgs {
     const void* qkv;            // [rows][3C]  q | k | v, head h at columns h*32 (+C, +2C)
@@ -35,7 +39,8 @@ struct WinArgs {
     const int* rel;             // [N]
     const uint8_t* label;       // [nW*N] or null (no shift)
     const void* table;          // [R][heads]
-    float* dtable_part;         // [gridDim.y][heads][R]
+    float* dbias_part;          // [G][heads][N][npad] dense dS sums of the dQ pass
+    const int* rel_inv;         // [relc + 1]: slot with rel[slot] == m, or -1
     int B, nW, N, heads, C, R, relc, rows_per_sample, wpb;
     float scale;
 };
@@ -141,17 +146,16 @@ DEVINL void win_fill_table(const WinArgs& p, float* tb, int h, int tid, int nthr
     const T* t = (const T*)p.table;
     for (int r = tid; r < p.R; r += nthreads) tb[r] = to_f32<T>(t[(int64_t)r * p.heads + h]);
 }
-DEVINL WinSmem win_carve(char* smem, int R, int npad, bool hist, float** hist_out) {
+DEVINL WinSmem win_carve(char* smem, int R, int npad) {
     WinSmem s;
     s.tb = (float*)smem; smem += ((R + 3) & ~3) * 4;
-    if (hist) { *hist_out = (float*)smem; smem += ((R + 3) & ~3) * 4; }
     s.rel = (int*)smem; smem += npad * 4;
     s.lab = (int*)smem; smem += npad * 4;
     s.rows = (int*)smem; smem += npad * 4;
     s.img = smem;
     return s;
 }
-static int win_small_bytes(int R, int npad, bool hist) { return ((R + 3) & ~3) * 4 * (hist ? 2 : 1) + 3 * npad * 4; }
+static int win_small_bytes(int R, int npad) { return ((R + 3) & ~3) * 4 + 3 * npad * 4; }
 
 // ------------------------------------------------------------------------------------------ forward
 // grid (heads, B*nW), 256 threads. LDS: K row image, V^T image.
@@ -162,7 +166,7 @@ __global__ __launch_bounds__(256) void win_fwd_kernel(WinArgs p) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, fr = lane & 15, g = lane >> 4;
     const int h = blockIdx.x, gw = blockIdx.y, b = gw / p.nW, w = gw % p.nW;
     const int N = p.N, npad = (N + 63) & ~63, ts = G::ts(npad);
-    WinSmem s = win_carve(smem, p.R, npad, false, nullptr);
+    WinSmem s = win_carve(smem, p.R, npad);
     char* sK = s.img;
     char* sVt = sK + G::img_a(npad);
     win_fill_slots(p, s, b, w, npad, tid, 256);
@@ -192,18 +196,23 @@ __global__ __launch_bounds__(256) void win_fwd_kernel(WinArgs p) {
 #pragma unroll
                 for (int dg = 0; dg < G::NDG; ++dg) sacc[kt] = Mma<T>::mma(win_frag<T>(sK, k0 + kt * 16 + fr, dg, g), qf[dg], sacc[kt]);
             }
+            // branch free: every select below is a v_cndmask, the LDS reads of a chunk (4 keys' rel / labels as one 16-B read
+            // each, then the 16 table gathers) are independent and pipeline
             float mx = -INFINITY;
 #pragma unroll
-            for (int kt = 0; kt < 4; ++kt)
+            for (int kt = 0; kt < 4; ++kt) {
+                const int kb = k0 + kt * 16 + 4 * g;
+                const i32x4_t rk = *(const i32x4_t*)&s.rel[kb];
+                const i32x4_t lk = *(const i32x4_t*)&s.lab[kb];
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const int key = k0 + kt * 16 + 4 * g + r;
-                    float v = sacc[kt][r] * p.scale + s.tb[relq - s.rel[key]];
-                    if (s.lab[key] != labq) v -= 100.0f;
-                    if (key >= N) v = -INFINITY;
+                    float v = sacc[kt][r] * p.scale + s.tb[relq - rk[r]];
+                    v = lk[r] != labq ? v - 100.0f : v;
+                    v = kb + r < N ? v : -INFINITY;
                     sacc[kt][r] = v;
                     mx = fmaxf(mx, v);
                 }
+            }
             mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
             mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
             const float mnew = fmaxf(m, mx);
@@ -242,28 +251,39 @@ __global__ __launch_bounds__(256) void win_fwd_kernel(WinArgs p) {
     }
 }
 
-// ------------------------------------------------------------------------------------------ backward 1: dQ, delta, d(table)
-// grid (heads, ceil(B*nW / wpb)), 512 threads; the workgroup walks wpb consecutive windows with one bias histogram.
-// LDS: K, V row images, K^T image.
+// ------------------------------------------------------------------------------------------ backward 1: dQ, delta, dS sums
+// grid (heads, 4 query quarters, G window groups), 512 threads. Wave w of quarter qq owns query tile qq*QT + w (QT = tiles per
+// quarter <= 8) of EVERY window of the group and keeps sum_windows dS[16 queries][all keys] in registers.
+// LDS: K, V row images, K^T image of the current window.
+#define WIN_MAXCH 7      // key chunks of 64: windows up to 448 slots
 template <typename T>
 __global__ __launch_bounds__(512) void win_bwd_dq_kernel(WinArgs p) {
     typedef WinGeo<T> G;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, fr = lane & 15, g = lane >> 4;
-    const int h = blockIdx.x;
+    const int h = blockIdx.x, qq = blockIdx.y, grp = blockIdx.z;
     const int N = p.N, npad = (N + 63) & ~63, ts = G::ts(npad);
-    float* hist;
-    WinSmem s = win_carve(smem, p.R, npad, true, &hist);
+    const int ntile = (N + 15) >> 4, QT = (ntile + 3) >> 2;
+    const int qt = qq * QT + wave;
+    const bool active = wave < QT && qt < ntile;                 // wave uniform
+    WinSmem s = win_carve(smem, p.R, npad);
     char* sK = s.img;
     char* sV = sK + G::img_a(npad);
     char* sKt = sV + G::img_a(npad);
     win_fill_table<T>(p, s.tb, h, tid, 512);
-    for (int r = tid; r < p.R; r += 512) hist[r] = 0.f;
     const T* qkv = (const T*)p.qkv;
     const int64_t ld = 3 * (int64_t)p.C;
+    const int qr = qt * 16 + fr;
+    const bool qok = active && qr < N;
+
+    f32x4_t bacc[WIN_MAXCH][4];
+#pragma unroll
+    for (int c = 0; c < WIN_MAXCH; ++c)
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt) bacc[c][kt] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
 
     for (int wi = 0; wi < p.wpb; ++wi) {
-        const int gw = blockIdx.y * p.wpb + wi;
+        const int gw = grp * p.wpb + wi;
         if (gw >= p.B * p.nW) break;
         const int b = gw / p.nW, w = gw % p.nW;
         __syncthreads();                                   // previous window's images / slot arrays are done with
@@ -272,29 +292,30 @@ __global__ __launch_bounds__(512) void win_bwd_dq_kernel(WinArgs p) {
         win_stage<T, true, true>(qkv, ld, p.C + h * WIN_D, s.rows, N, npad, sK, sKt, tid, 512);
         win_stage<T, true, false>(qkv, ld, 2 * p.C + h * WIN_D, s.rows, N, npad, sV, nullptr, tid, 512);
         __syncthreads();
+        if (!active) continue;
 
-        for (int qt = wave; qt * 16 < N; qt += 8) {
-            const int qr = qt * 16 + fr;
-            const bool qok = qr < N;
-            const int qrow = s.rows[qok ? qr : 0];
-            typename Mma<T>::frag_t qf[G::NDG], dof[G::NDG];
-            float dl = 0.f;
+        const int qrow = s.rows[qok ? qr : 0];
+        typename Mma<T>::frag_t qf[G::NDG], dof[G::NDG];
+        float dl = 0.f;
 #pragma unroll
-            for (int dg = 0; dg < G::NDG; ++dg) {
-                qf[dg] = win_load_frag<T>(qkv + (int64_t)qrow * ld + h * WIN_D, dg, g, qok);
-                dof[dg] = win_load_frag<T>((const T*)p.dout + (int64_t)qrow * p.C + h * WIN_D, dg, g, qok);
-                typename Mma<T>::frag_t of = win_load_frag<T>((const T*)p.o + (int64_t)qrow * p.C + h * WIN_D, dg, g, qok);
+        for (int dg = 0; dg < G::NDG; ++dg) {
+            qf[dg] = win_load_frag<T>(qkv + (int64_t)qrow * ld + h * WIN_D, dg, g, qok);
+            dof[dg] = win_load_frag<T>((const T*)p.dout + (int64_t)qrow * p.C + h * WIN_D, dg, g, qok);
+            typename Mma<T>::frag_t of = win_load_frag<T>((const T*)p.o + (int64_t)qrow * p.C + h * WIN_D, dg, g, qok);
 #pragma unroll
-                for (int i = 0; i < G::VEC; ++i) dl += (float)dof[dg][i] * (float)of[i];
-            }
-            dl += __shfl_xor(dl, 16, 64);
-            dl += __shfl_xor(dl, 32, 64);
-            const int64_t stat = ((int64_t)gw * p.heads + h) * N + qr;
-            const float lse = qok ? p.lse[stat] : 0.f;
-            if (qok && g == 0) p.delta[stat] = dl;
-            const int relq = s.rel[qr] + p.relc, labq = s.lab[qr];
-            f32x4_t dqacc[2] = {(f32x4_t){0.f, 0.f, 0.f, 0.f}, (f32x4_t){0.f, 0.f, 0.f, 0.f}};
-            for (int k0 = 0; k0 < npad; k0 += 64) {
+            for (int i = 0; i < G::VEC; ++i) dl += (float)dof[dg][i] * (float)of[i];
+        }
+        dl += __shfl_xor(dl, 16, 64);
+        dl += __shfl_xor(dl, 32, 64);
+        const int64_t stat = ((int64_t)gw * p.heads + h) * N + qr;
+        const float lse = qok ? p.lse[stat] : INFINITY;      // rows past the window: exp(s - inf) = 0, no select per element
+        if (qok && g == 0) p.delta[stat] = dl;
+        const int relq = s.rel[qr] + p.relc, labq = s.lab[qr];
+        f32x4_t dqacc[2] = {(f32x4_t){0.f, 0.f, 0.f, 0.f}, (f32x4_t){0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+        for (int c = 0; c < WIN_MAXCH; ++c) {
+            const int k0 = c * 64;
+            if (k0 < npad) {
                 f32x4_t sacc[4], dpacc[4];
 #pragma unroll
                 for (int kt = 0; kt < 4; ++kt) {
@@ -306,38 +327,46 @@ __global__ __launch_bounds__(512) void win_bwd_dq_kernel(WinArgs p) {
                         dpacc[kt] = Mma<T>::mma(win_frag<T>(sV, k0 + kt * 16 + fr, dg, g), dof[dg], dpacc[kt]);
                     }
                 }
+                // branch free (see the forward)
 #pragma unroll
-                for (int kt = 0; kt < 4; ++kt)
+                for (int kt = 0; kt < 4; ++kt) {
+                    const int kb = k0 + kt * 16 + 4 * g;
+                    const i32x4_t rk = *(const i32x4_t*)&s.rel[kb];
+                    const i32x4_t lk = *(const i32x4_t*)&s.lab[kb];
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        const int key = k0 + kt * 16 + 4 * g + r;
-                        const int bi = relq - s.rel[key];
-                        float v = sacc[kt][r] * p.scale + s.tb[bi];
-                        if (s.lab[key] != labq) v -= 100.0f;
-                        float ds = 0.f;
-                        if (qok && key < N) {
-                            ds = fexp<T>(v - lse) * (dpacc[kt][r] - dl);
-                            atomicAdd(&hist[bi], ds);
-                        }
+                        float v = sacc[kt][r] * p.scale + s.tb[relq - rk[r]];
+                        v = lk[r] != labq ? v - 100.0f : v;
+                        float ds = fexp<T>(v - lse) * (dpacc[kt][r] - dl);
+                        ds = kb + r < N ? ds : 0.f;
                         sacc[kt][r] = ds;
+                        bacc[c][kt][r] += ds;
                     }
-                win_nat_mma<T>(sKt, ts, k0, sacc, dqacc, fr, g);
-            }
-            if (qok) {
-                T* drow = (T*)p.dqkv + (int64_t)qrow * ld + h * WIN_D;
-#pragma unroll
-                for (int dt = 0; dt < 2; ++dt) {
-                    f32x4_t v = dqacc[dt];
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) v[r] *= p.scale;
-                    win_store4<T>(drow, dt, g, v);
                 }
+                win_nat_mma<T>(sKt, ts, k0, sacc, dqacc, fr, g);
+                __builtin_amdgcn_sched_barrier(0);         // keep the chunks apart: 112 accumulator registers leave no room for hoisting
+            }
+        }
+        if (qok) {
+            T* drow = (T*)p.dqkv + (int64_t)qrow * ld + h * WIN_D;
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt) {
+                f32x4_t v = dqacc[dt];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] *= p.scale;
+                win_store4<T>(drow, dt, g, v);
             }
         }
     }
-    __syncthreads();
-    float* part = p.dtable_part + ((int64_t)blockIdx.y * p.heads + h) * p.R;
-    for (int r = tid; r < p.R; r += 512) part[r] = hist[r];
+    if (qok) {          // this lane: query qr, keys 64c + 16kt + 4g .. +3 of every chunk
+        float* part = p.dbias_part + (((int64_t)grp * p.heads + h) * N + qr) * npad;
+#pragma unroll
+        for (int c = 0; c < WIN_MAXCH; ++c)
+            if (c * 64 < npad) {
+#pragma unroll
+                for (int kt = 0; kt < 4; ++kt) *(f32x4_t*)(part + c * 64 + kt * 16 + 4 * g) = bacc[c][kt];
+            }
+    }
 }
 
 // ------------------------------------------------------------------------------------------ backward 2: dK, dV
@@ -349,7 +378,7 @@ __global__ __launch_bounds__(512) void win_bwd_dkv_kernel(WinArgs p) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, fr = lane & 15, g = lane >> 4;
     const int h = blockIdx.x, gw = blockIdx.y, b = gw / p.nW, w = gw % p.nW;
     const int N = p.N, npad = (N + 63) & ~63, ts = G::ts(npad);
-    WinSmem s = win_carve(smem, p.R, npad, false, nullptr);
+    WinSmem s = win_carve(smem, p.R, npad);
     float* s_lse = (float*)s.img;
     float* s_dl = s_lse + npad;
     char* sQ = (char*)(s_dl + npad);
@@ -360,7 +389,7 @@ __global__ __launch_bounds__(512) void win_bwd_dkv_kernel(WinArgs p) {
     win_fill_table<T>(p, s.tb, h, tid, 512);
     for (int n = tid; n < npad; n += 512) {
         const int64_t stat = ((int64_t)gw * p.heads + h) * N + n;
-        s_lse[n] = n < N ? p.lse[stat] : 0.f;
+        s_lse[n] = n < N ? p.lse[stat] : INFINITY;       // slots past the window: p = exp(s - inf) = 0
         s_dl[n] = n < N ? p.delta[stat] : 0.f;
     }
     __syncthreads();
@@ -397,20 +426,21 @@ __global__ __launch_bounds__(512) void win_bwd_dkv_kernel(WinArgs p) {
                 }
             }
 #pragma unroll
-            for (int t = 0; t < 4; ++t)
+            for (int t = 0; t < 4; ++t) {
+                const int qb = q0 + t * 16 + 4 * g;
+                const i32x4_t rq = *(const i32x4_t*)&s.rel[qb];
+                const i32x4_t lq = *(const i32x4_t*)&s.lab[qb];
+                const f32x4_t ls = *(const f32x4_t*)&s_lse[qb];
+                const f32x4_t dl = *(const f32x4_t*)&s_dl[qb];
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const int q = q0 + t * 16 + 4 * g + r;
-                    float v = sacc[t][r] * p.scale + s.tb[s.rel[q] - relk];
-                    if (s.lab[q] != labk) v -= 100.0f;
-                    float pr = 0.f, ds = 0.f;
-                    if (kok && q < N) {
-                        pr = fexp<T>(v - s_lse[q]);
-                        ds = pr * (dpacc[t][r] - s_dl[q]);
-                    }
+                    float v = sacc[t][r] * p.scale + s.tb[rq[r] - relk];
+                    v = lq[r] != labk ? v - 100.0f : v;
+                    const float pr = fexp<T>(v - ls[r]);          // key lanes past the window compute garbage-free zeros' worth: never stored
                     sacc[t][r] = pr;
-                    dpacc[t][r] = ds;
+                    dpacc[t][r] = pr * (dpacc[t][r] - dl[r]);
                 }
+            }
             win_nat_mma<T>(sdOt, ts, q0, sacc, dvacc, fr, g);
             win_nat_mma<T>(sQt, ts, q0, dpacc, dkacc, fr, g);
         }
@@ -428,29 +458,48 @@ __global__ __launch_bounds__(512) void win_bwd_dkv_kernel(WinArgs p) {
     }
 }
 
-// d(table)[r][h] (+)= sum over workgroup partials part[j][h][r]
-template <typename T>
-__global__ __launch_bounds__(256) void win_table_grad_kernel(const float* part, int nparts, int heads, int R, T* dtable, int accumulate) {
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= heads * R) return;
-    const int h = i / R, r = i % R;
-    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
-    const int64_t stride = (int64_t)heads * R;
-    const float* src = part + (int64_t)h * R + r;
-    int j = 0;
-    for (; j + 4 <= nparts; j += 4) {
-        a0 += src[(j + 0) * stride]; a1 += src[(j + 1) * stride]; a2 += src[(j + 2) * stride]; a3 += src[(j + 3) * stride];
+// dB[0][..] = sum over the G window groups of the dense dS partials (in place into group 0), streaming
+__global__ __launch_bounds__(256) void win_dbias_reduce_kernel(float* part, int G, int64_t n4) {
+    const int64_t stride = n4 * 4;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+        f32x4_t a = *(const f32x4_t*)(part + i * 4);
+        for (int j = 1; j < G; ++j) a += *(const f32x4_t*)(part + j * stride + i * 4);
+        *(f32x4_t*)(part + i * 4) = a;
     }
-    for (; j < nparts; ++j) a0 += src[j * stride];
-    const float v = (a0 + a1) + (a2 + a3);
+}
+// d(table)[r][h] (+)= sum_i dB[h][i][j(i, r)] with j(i, r) the slot whose rel is rel[i] + relc - r (videoswin.py:146-148 backward)
+template <typename T>
+__global__ __launch_bounds__(256) void win_table_grad_kernel(const float* dB, const int* rel, const int* rel_inv, int heads, int R, int N,
+                                                             int npad, int relc, T* dtable, int accumulate) {
+    const int i0 = blockIdx.x * 256 + threadIdx.x;
+    if (i0 >= heads * R) return;
+    const int h = i0 / R, r = i0 % R;
+    const float* src = dB + (int64_t)h * N * npad;
+    float a0 = 0.f, a1 = 0.f;
+    for (int i = 0; i < N; ++i) {
+        const int m = rel[i] + relc - r;
+        const int j = (m >= 0 && m <= relc) ? rel_inv[m] : -1;
+        const float v = (j >= 0 && j < N) ? src[(int64_t)i * npad + j] : 0.f;
+        if (i & 1) a1 += v; else a0 += v;
+    }
     T* o = dtable + (int64_t)r * heads + h;
-    *o = from_f32<T>((accumulate ? to_f32<T>(*o) : 0.f) + v);
+    *o = from_f32<T>((accumulate ? to_f32<T>(*o) : 0.f) + (a0 + a1));
 }
 
 // ------------------------------------------------------------------------------------------ launchers
-template <typename T> static int win_lds_fwd(int R, int npad) { return win_small_bytes(R, npad, false) + WinGeo<T>::RS * npad + WIN_D * (npad * (int)sizeof(T) + 16); }
-template <typename T> static int win_lds_dq(int R, int npad) { return win_small_bytes(R, npad, true) + 2 * WinGeo<T>::RS * npad + WIN_D * (npad * (int)sizeof(T) + 16); }
-template <typename T> static int win_lds_dkv(int R, int npad) { return win_small_bytes(R, npad, false) + 2 * npad * 4 + 2 * WinGeo<T>::RS * npad + 2 * WIN_D * (npad * (int)sizeof(T) + 16); }
+template <typename T> static int win_lds_fwd(int R, int npad) { return win_small_bytes(R, npad) + WinGeo<T>::RS * npad + WIN_D * (npad * (int)sizeof(T) + 16); }
+template <typename T> static int win_lds_dq(int R, int npad) { return win_small_bytes(R, npad) + 2 * WinGeo<T>::RS * npad + WIN_D * (npad * (int)sizeof(T) + 16); }
+// window groups of the dQ pass: ~1024 workgroups (heads x 4 quarters x G), as few dense partials as that allows
+static int win_groups(int B, int nW, int heads, int* wpb_out) {
+    const int total = B * nW;
+    int G = 256 / heads;
+    if (G < 1) G = 1;
+    if (G > total) G = total;
+    const int wpb = (total + G - 1) / G;
+    if (wpb_out) *wpb_out = wpb;
+    return (total + wpb - 1) / wpb;
+}
+template <typename T> static int win_lds_dkv(int R, int npad) { return win_small_bytes(R, npad) + 2 * npad * 4 + 2 * WinGeo<T>::RS * npad + 2 * WIN_D * (npad * (int)sizeof(T) + 16); }
 #define WIN_LDS_MAX (160 * 1024)
 
 static bool win_check(const WinArgs& p) {
@@ -467,31 +516,23 @@ static int win_fwd_launch(hipStream_t st, const WinArgs& p) {
     return hipGetLastError() == hipSuccess ? VALOR_OK : VALOR_ERR_LAUNCH;
 }
 template <typename T>
-static int win_bwd_launch(hipStream_t st, const WinArgs& p, void* dtable, int accumulate, int nparts) {
+static int win_bwd_launch(hipStream_t st, const WinArgs& p, void* dtable, int accumulate, int G) {
     const int npad = (p.N + 63) & ~63, l1 = win_lds_dq<T>(p.R, npad), l2 = win_lds_dkv<T>(p.R, npad);
-    if (l1 > WIN_LDS_MAX || l2 > WIN_LDS_MAX) return VALOR_ERR_ARG;
+    if (l1 > WIN_LDS_MAX || l2 > WIN_LDS_MAX || npad > 64 * WIN_MAXCH) return VALOR_ERR_ARG;
     hipFuncSetAttribute((const void*)win_bwd_dq_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, l1);
     hipFuncSetAttribute((const void*)win_bwd_dkv_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, l2);
-    hipLaunchKernelGGL(win_bwd_dq_kernel<T>, dim3(p.heads, nparts), dim3(512), l1, st, p);
+    hipLaunchKernelGGL(win_bwd_dq_kernel<T>, dim3(p.heads, 4, G), dim3(512), l1, st, p);
     hipLaunchKernelGGL(win_bwd_dkv_kernel<T>, dim3(p.heads, p.B * p.nW), dim3(512), l2, st, p);
-    hipLaunchKernelGGL(win_table_grad_kernel<T>, dim3((p.heads * p.R + 255) / 256), dim3(256), 0, st, p.dtable_part, nparts, p.heads, p.R,
-                       (T*)dtable, accumulate);
+    const int64_t n4 = (int64_t)p.heads * p.N * npad / 4;
+    if (G > 1) hipLaunchKernelGGL(win_dbias_reduce_kernel, dim3((unsigned)((n4 + 255) / 256 > 4096 ? 4096 : (n4 + 255) / 256)), dim3(256), 0, st, p.dbias_part, G, n4);
+    hipLaunchKernelGGL(win_table_grad_kernel<T>, dim3((p.heads * p.R + 255) / 256), dim3(256), 0, st, p.dbias_part, p.rel, p.rel_inv, p.heads, p.R,
+                       p.N, npad, p.relc, (T*)dtable, accumulate);
     return hipGetLastError() == hipSuccess ? VALOR_OK : VALOR_ERR_LAUNCH;
 }
 
-// windows one dQ workgroup walks: enough workgroups to fill the chip several times over, as few histogram partials as that allows
-static int win_wpb(int B, int nW, int heads) {
-    const int total = B * nW;
-    int wpb = (int)(((int64_t)total * heads) / 4096);
-    if (wpb < 1) wpb = 1;
-    if (wpb > 16) wpb = 16;
-    return wpb;
-}
-
-extern "C" int valor_win_attn_workspace_floats(int B, int nW, int heads, int table_rows) {
-    const int wpb = win_wpb(B, nW, heads);
-    const int nparts = (B * nW + wpb - 1) / wpb;
-    const int64_t n = (int64_t)nparts * heads * table_rows;
+extern "C" int valor_win_attn_workspace_floats(int B, int nW, int N, int heads) {
+    const int G = win_groups(B, nW, heads, nullptr), npad = (N + 63) & ~63;
+    const int64_t n = (int64_t)G * heads * N * npad;
     return n > 0x7fffffff ? VALOR_ERR_ARG : (int)n;
 }
 
@@ -508,19 +549,18 @@ extern "C" int valor_win_attn_fwd(void* stream, int dtype, const void* qkv, void
 }
 
 extern "C" int valor_win_attn_bwd(void* stream, int dtype, const void* qkv, const void* o, const float* lse, const void* dout, void* dqkv,
-                                  float* delta, const int* rowmap, const int* rel, const uint8_t* label, const void* table, void* dtable,
-                                  int accumulate_dtable, void* workspace, int64_t workspace_bytes, int B, int nW, int N, int heads,
-                                  int table_rows, int relc, int rows_per_sample, float scale) {
+                                  float* delta, const int* rowmap, const int* rel, const int* rel_inv, const uint8_t* label, const void* table,
+                                  void* dtable, int accumulate_dtable, void* workspace, int64_t workspace_bytes, int B, int nW, int N,
+                                  int heads, int table_rows, int relc, int rows_per_sample, float scale) {
     WinArgs p = {};
     p.qkv = qkv; p.o = (void*)o; p.lse = (float*)lse; p.dout = dout; p.dqkv = dqkv; p.delta = delta; p.rowmap = rowmap; p.rel = rel;
-    p.label = label; p.table = table; p.dtable_part = (float*)workspace;
+    p.rel_inv = rel_inv; p.label = label; p.table = table; p.dbias_part = (float*)workspace;
     p.B = B; p.nW = nW; p.N = N; p.heads = heads; p.C = heads * WIN_D; p.R = table_rows; p.relc = relc; p.rows_per_sample = rows_per_sample;
     p.scale = scale;
-    if (!win_check(p) || !o || !lse || !dout || !dqkv || !delta || !dtable || !workspace) return VALOR_ERR_ARG;
-    p.wpb = win_wpb(B, nW, heads);
-    const int nparts = (B * nW + p.wpb - 1) / p.wpb;
-    if (workspace_bytes < (int64_t)nparts * heads * table_rows * 4) return VALOR_ERR_ARG;
+    if (!win_check(p) || !o || !lse || !dout || !dqkv || !delta || !dtable || !workspace || !rel_inv) return VALOR_ERR_ARG;
+    const int G = win_groups(B, nW, heads, &p.wpb);
+    if (workspace_bytes < (int64_t)G * heads * N * ((N + 63) & ~63) * 4) return VALOR_ERR_ARG;
     hipStream_t st = (hipStream_t)stream;
-    return dtype == VALOR_DT_BF16 ? win_bwd_launch<bf16_t>(st, p, dtable, accumulate_dtable, nparts)
-         : dtype == VALOR_DT_F32 ? win_bwd_launch<float>(st, p, dtable, accumulate_dtable, nparts) : VALOR_ERR_ARG;
+    return dtype == VALOR_DT_BF16 ? win_bwd_launch<bf16_t>(st, p, dtable, accumulate_dtable, G)
+         : dtype == VALOR_DT_F32 ? win_bwd_launch<float>(st, p, dtable, accumulate_dtable, G) : VALOR_ERR_ARG;
 }

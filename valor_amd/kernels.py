@@ -219,7 +219,8 @@ def attn_bwd(q, k, v, o, lse, dout, n_heads, *, dq=None, dk=None, dv=None, mask=
 # ---------------------------------------------------------------------------------------------- VideoSwin
 def win_attn_fwd(qkv, geo, table, n_heads, B):
     """3-D shifted-window attention (head_dim 32) in place on the fused QKV rows [B*rows_per_sample, 3C].
-    geo: dict(rowmap int32 [nW*N], rel int32 [N], label uint8 [nW*N] | None, nW, N, relc, rows). Returns (o, lse)."""
+    geo: dict(rowmap int32 [nW*N], rel int32 [N], rel_inv int32 [relc+1], label uint8 [nW*N] | None, nW, N, relc, rows).
+    Returns (o, lse)."""
     _check_gpu(qkv, table, geo["rowmap"], geo["rel"], geo["label"])
     C = n_heads * 32
     assert qkv.is_contiguous() and qkv.shape == (B * geo["rows"], 3 * C) and table.is_contiguous() and table.shape[1] == n_heads
@@ -239,12 +240,13 @@ def win_attn_bwd(qkv, o, lse, dout, geo, table, n_heads, B, dtable=None):
     acc = dtable is not None
     if dtable is None:
         dtable = torch.empty_like(table)
-    need = lib.load().valor_win_attn_workspace_floats(B, geo["nW"], n_heads, table.shape[0])
+    need = lib.load().valor_win_attn_workspace_floats(B, geo["nW"], geo["N"], n_heads)
     if need < 0:
         raise lib.ValorHipError("window attention workspace too large")
     ws = workspace(qkv.device, max(_WS_BYTES, need * 4))
     lib.call("valor_win_attn_bwd", _stream(), dt_of(qkv), _ptr(qkv), _ptr(o), _ptr(lse), _ptr(dout), _ptr(dqkv), _ptr(delta),
-             _ptr(geo["rowmap"]), _ptr(geo["rel"]), _ptr(geo["label"]), _ptr(table), _ptr(dtable), int(acc), _ptr(ws), ws.numel() * 4,
+             _ptr(geo["rowmap"]), _ptr(geo["rel"]), _ptr(geo["rel_inv"]), _ptr(geo["label"]), _ptr(table), _ptr(dtable), int(acc), _ptr(ws),
+             ws.numel() * 4,
              B, geo["nW"], geo["N"], n_heads, table.shape[0], geo["relc"], geo["rows"], 32 ** -0.5)
     return dqkv, (None if acc else dtable)
 

@@ -32,7 +32,7 @@ SIGNATURES = {
     "valor_group_mean_bwd": [_vp, _i, _vp, _vp, _i64, _i, _i],
     "valor_win_attn_workspace_floats": [_i, _i, _i, _i],
     "valor_win_attn_fwd": [_vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _f],
-    "valor_win_attn_bwd": [_vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _i64, _i, _i, _i, _i, _i, _i, _i, _f],
+    "valor_win_attn_bwd": [_vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _i64, _i, _i, _i, _i, _i, _i, _i, _f],
     "valor_colsum_finalize": [_vp, _i, _vp, _i, _i, _vp, _i, _i],
     "valor_colsum_finalize3": [_vp, _i, _vp, _vp, _i, _vp, _vp, _i, _vp, _vp, _i, _i, _i],
     "valor_attn_set_variant": [_i],

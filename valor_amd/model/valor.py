@@ -305,8 +305,11 @@ class VALOR(nn.Module):
         N = wd * wh * ww
         fd, fh, fw = np.meshgrid(np.arange(full[0]), np.arange(full[1]), np.arange(full[2]), indexing="ij")
         lin = (fd * (2 * full[1] - 1) * (2 * full[2] - 1) + fh * (2 * full[2] - 1) + fw).reshape(-1)
+        inv = -np.ones(int(lin[-1]) + 1, dtype=np.int32)
+        inv[lin[:N]] = np.arange(N, dtype=np.int32)                                          # slot whose rel is m (bias-table gradient)
         geo = dict(rowmap=torch.from_numpy(part(idx).astype(np.int32)).to(self.device), label=label,
                    rel=torch.from_numpy(lin[:N].astype(np.int32)).to(self.device), relc=int(lin[-1]),
+                   rel_inv=torch.from_numpy(inv).to(self.device),
                    nW=(D // wd) * (H // wh) * (W // ww), N=N, rows=D * H * W)
         self._const[key] = geo
         return geo
