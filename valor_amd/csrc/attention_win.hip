@@ -24,9 +24,15 @@
 // probabilities feed the next MFMA from registers.
 // Both element types: bf16 (windows up to 448 slots) and the exact-fp32 parity instantiation (up to 192 slots: LDS).
 #include "attn_common.h"
+#include <type_traits>
 
 #define WIN_D 32
 typedef __attribute__((ext_vector_type(4))) int i32x4_t;
+// softmax runs in the log2 domain (v_exp_f32 is 2^x): the table column and the scale are pre-multiplied by log2(e)
+template <typename T> DEVINL float fexp2(float x);
+template <> DEVINL float fexp2<float>(float x) { return exp2f(x); }
+template <> DEVINL float fexp2<bf16_t>(float x) { return __builtin_amdgcn_exp2f(x); }
+#define WIN_MASK2 (100.0f * LOG2E_F)     // the shift mask's -100 (videoswin.py:284) in the log2 domain
 
 struct WinArgs {
     const void* qkv;            // [rows][3C]  q | k | v, head h at columns h*32 (+C, +2C)
@@ -144,7 +150,7 @@ DEVINL void win_fill_slots(const WinArgs& p, const WinSmem& s, int b, int w, int
 template <typename T>
 DEVINL void win_fill_table(const WinArgs& p, float* tb, int h, int tid, int nthreads) {
     const T* t = (const T*)p.table;
-    for (int r = tid; r < p.R; r += nthreads) tb[r] = to_f32<T>(t[(int64_t)r * p.heads + h]);
+    for (int r = tid; r < p.R; r += nthreads) tb[r] = to_f32<T>(t[(int64_t)r * p.heads + h]) * LOG2E_F;
 }
 DEVINL WinSmem win_carve(char* smem, int R, int npad) {
     WinSmem s;
@@ -158,9 +164,10 @@ DEVINL WinSmem win_carve(char* smem, int R, int npad) {
 static int win_small_bytes(int R, int npad) { return ((R + 3) & ~3) * 4 + 3 * npad * 4; }
 
 // ------------------------------------------------------------------------------------------ forward
-// grid (heads, B*nW), 256 threads. LDS: K row image, V^T image.
-template <typename T>
-__global__ __launch_bounds__(256) void win_fwd_kernel(WinArgs p) {
+// grid (heads, B*nW), 512 threads (2 workgroups per CU = 4 waves per SIMD: the elementwise softmax is latency bound). LDS: K row
+// image, V^T image.
+template <typename T, bool SHIFT>
+__global__ __launch_bounds__(512) void win_fwd_kernel(WinArgs p) {
     typedef WinGeo<T> G;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, fr = lane & 15, g = lane >> 4;
@@ -169,16 +176,16 @@ __global__ __launch_bounds__(256) void win_fwd_kernel(WinArgs p) {
     WinSmem s = win_carve(smem, p.R, npad);
     char* sK = s.img;
     char* sVt = sK + G::img_a(npad);
-    win_fill_slots(p, s, b, w, npad, tid, 256);
-    win_fill_table<T>(p, s.tb, h, tid, 256);
+    win_fill_slots(p, s, b, w, npad, tid, 512);
+    win_fill_table<T>(p, s.tb, h, tid, 512);
     __syncthreads();
     const T* qkv = (const T*)p.qkv;
     const int64_t ld = 3 * (int64_t)p.C;
-    win_stage<T, true, false>(qkv, ld, p.C + h * WIN_D, s.rows, N, npad, sK, nullptr, tid, 256);
-    win_stage<T, false, true>(qkv, ld, 2 * p.C + h * WIN_D, s.rows, N, npad, nullptr, sVt, tid, 256);
+    win_stage<T, true, false>(qkv, ld, p.C + h * WIN_D, s.rows, N, npad, sK, nullptr, tid, 512);
+    win_stage<T, false, true>(qkv, ld, 2 * p.C + h * WIN_D, s.rows, N, npad, nullptr, sVt, tid, 512);
     __syncthreads();
 
-    for (int qt = wave; qt * 16 < N; qt += 4) {
+    for (int qt = wave; qt * 16 < N; qt += 8) {
         const int qr = qt * 16 + fr;
         const bool qok = qr < N;
         const int qrow = s.rows[qok ? qr : 0];
@@ -186,9 +193,14 @@ __global__ __launch_bounds__(256) void win_fwd_kernel(WinArgs p) {
 #pragma unroll
         for (int dg = 0; dg < G::NDG; ++dg) qf[dg] = win_load_frag<T>(qkv + (int64_t)qrow * ld + h * WIN_D, dg, g, qok);
         const int relq = s.rel[qr] + p.relc, labq = s.lab[qr];
+        const float scale2 = p.scale * LOG2E_F;
         float m = -1e30f, l = 0.f;
         f32x4_t oacc[2] = {(f32x4_t){0.f, 0.f, 0.f, 0.f}, (f32x4_t){0.f, 0.f, 0.f, 0.f}};
-        for (int k0 = 0; k0 < npad; k0 += 64) {
+        // one 64-key chunk; TAIL: the chunk reaches past the window (wave-uniform), only then keys need a validity select.
+        // Branch free inside: the LDS reads of a chunk (4 keys' rel / labels as one 16-B read each, then the 16 table
+        // gathers) are independent and pipeline.
+        auto chunk = [&](const int k0, auto tail) {
+            constexpr bool TAIL = decltype(tail)::value;
             f32x4_t sacc[4];
 #pragma unroll
             for (int kt = 0; kt < 4; ++kt) {
@@ -196,19 +208,18 @@ __global__ __launch_bounds__(256) void win_fwd_kernel(WinArgs p) {
 #pragma unroll
                 for (int dg = 0; dg < G::NDG; ++dg) sacc[kt] = Mma<T>::mma(win_frag<T>(sK, k0 + kt * 16 + fr, dg, g), qf[dg], sacc[kt]);
             }
-            // branch free: every select below is a v_cndmask, the LDS reads of a chunk (4 keys' rel / labels as one 16-B read
-            // each, then the 16 table gathers) are independent and pipeline
             float mx = -INFINITY;
 #pragma unroll
             for (int kt = 0; kt < 4; ++kt) {
                 const int kb = k0 + kt * 16 + 4 * g;
                 const i32x4_t rk = *(const i32x4_t*)&s.rel[kb];
-                const i32x4_t lk = *(const i32x4_t*)&s.lab[kb];
+                i32x4_t lk;
+                if (SHIFT) lk = *(const i32x4_t*)&s.lab[kb];
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    float v = sacc[kt][r] * p.scale + s.tb[relq - rk[r]];
-                    v = lk[r] != labq ? v - 100.0f : v;
-                    v = kb + r < N ? v : -INFINITY;
+                    float v = sacc[kt][r] * scale2 + s.tb[relq - rk[r]];
+                    if (SHIFT) v = lk[r] != labq ? v - WIN_MASK2 : v;
+                    if (TAIL) v = kb + r < N ? v : -INFINITY;
                     sacc[kt][r] = v;
                     mx = fmaxf(mx, v);
                 }
@@ -216,14 +227,14 @@ __global__ __launch_bounds__(256) void win_fwd_kernel(WinArgs p) {
             mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
             mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
             const float mnew = fmaxf(m, mx);
-            const float alpha = fexp<T>(m - mnew);
+            const float alpha = fexp2<T>(m - mnew);
             m = mnew;
             float ps = 0.f;
 #pragma unroll
             for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const float e = fexp<T>(sacc[kt][r] - mnew);
+                    const float e = fexp2<T>(sacc[kt][r] - mnew);
                     sacc[kt][r] = e;
                     ps += e;
                 }
@@ -235,6 +246,10 @@ __global__ __launch_bounds__(256) void win_fwd_kernel(WinArgs p) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) oacc[dt][r] *= alpha;
             win_nat_mma<T>(sVt, ts, k0, sacc, oacc, fr, g);
+        };
+        for (int k0 = 0; k0 < npad; k0 += 64) {
+            if (k0 + 64 <= N) chunk(k0, std::false_type{});
+            else chunk(k0, std::true_type{});
         }
         if (qok) {
             const float inv = 1.0f / l;
@@ -246,7 +261,7 @@ __global__ __launch_bounds__(256) void win_fwd_kernel(WinArgs p) {
                 for (int r = 0; r < 4; ++r) v[r] *= inv;
                 win_store4<T>(orow, dt, g, v);
             }
-            if (g == 0) p.lse[((int64_t)gw * p.heads + h) * N + qr] = m + logf(l);
+            if (g == 0) p.lse[((int64_t)gw * p.heads + h) * N + qr] = (m + log2f(l)) * LN2_F;
         }
     }
 }
@@ -256,7 +271,7 @@ __global__ __launch_bounds__(256) void win_fwd_kernel(WinArgs p) {
 // quarter <= 8) of EVERY window of the group and keeps sum_windows dS[16 queries][all keys] in registers.
 // LDS: K, V row images, K^T image of the current window.
 #define WIN_MAXCH 7      // key chunks of 64: windows up to 448 slots
-template <typename T>
+template <typename T, bool SHIFT>
 __global__ __launch_bounds__(512) void win_bwd_dq_kernel(WinArgs p) {
     typedef WinGeo<T> G;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -308,7 +323,8 @@ __global__ __launch_bounds__(512) void win_bwd_dq_kernel(WinArgs p) {
         dl += __shfl_xor(dl, 16, 64);
         dl += __shfl_xor(dl, 32, 64);
         const int64_t stat = ((int64_t)gw * p.heads + h) * N + qr;
-        const float lse = qok ? p.lse[stat] : INFINITY;      // rows past the window: exp(s - inf) = 0, no select per element
+        const float lse2 = qok ? p.lse[stat] * LOG2E_F : INFINITY;   // rows past the window: 2^(s - inf) = 0, no select per element
+        const float scale2 = p.scale * LOG2E_F;
         if (qok && g == 0) p.delta[stat] = dl;
         const int relq = s.rel[qr] + p.relc, labq = s.lab[qr];
         f32x4_t dqacc[2] = {(f32x4_t){0.f, 0.f, 0.f, 0.f}, (f32x4_t){0.f, 0.f, 0.f, 0.f}};
@@ -332,19 +348,19 @@ __global__ __launch_bounds__(512) void win_bwd_dq_kernel(WinArgs p) {
                 for (int kt = 0; kt < 4; ++kt) {
                     const int kb = k0 + kt * 16 + 4 * g;
                     const i32x4_t rk = *(const i32x4_t*)&s.rel[kb];
-                    const i32x4_t lk = *(const i32x4_t*)&s.lab[kb];
+                    i32x4_t lk;
+                    if (SHIFT) lk = *(const i32x4_t*)&s.lab[kb];
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        float v = sacc[kt][r] * p.scale + s.tb[relq - rk[r]];
-                        v = lk[r] != labq ? v - 100.0f : v;
-                        float ds = fexp<T>(v - lse) * (dpacc[kt][r] - dl);
+                        float v = sacc[kt][r] * scale2 + s.tb[relq - rk[r]];
+                        if (SHIFT) v = lk[r] != labq ? v - WIN_MASK2 : v;
+                        float ds = fexp2<T>(v - lse2) * (dpacc[kt][r] - dl);
                         ds = kb + r < N ? ds : 0.f;
                         sacc[kt][r] = ds;
                         bacc[c][kt][r] += ds;
                     }
                 }
                 win_nat_mma<T>(sKt, ts, k0, sacc, dqacc, fr, g);
-                __builtin_amdgcn_sched_barrier(0);         // keep the chunks apart: 112 accumulator registers leave no room for hoisting
             }
         }
         if (qok) {
@@ -370,9 +386,9 @@ __global__ __launch_bounds__(512) void win_bwd_dq_kernel(WinArgs p) {
 }
 
 // ------------------------------------------------------------------------------------------ backward 2: dK, dV
-// grid (heads, B*nW), 512 threads. LDS: Q, dO row images, Q^T, dO^T images, lse / delta of the window.
-template <typename T>
-__global__ __launch_bounds__(512) void win_bwd_dkv_kernel(WinArgs p) {
+// grid (heads, B*nW), 1024 threads (one workgroup per CU: 16 waves share the four images). LDS: Q, dO row images, Q^T, dO^T images, lse / delta of the window.
+template <typename T, bool SHIFT>
+__global__ __launch_bounds__(1024) void win_bwd_dkv_kernel(WinArgs p) {
     typedef WinGeo<T> G;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, fr = lane & 15, g = lane >> 4;
@@ -385,21 +401,21 @@ __global__ __launch_bounds__(512) void win_bwd_dkv_kernel(WinArgs p) {
     char* sdO = sQ + G::img_a(npad);
     char* sQt = sdO + G::img_a(npad);
     char* sdOt = sQt + G::img_b(npad);
-    win_fill_slots(p, s, b, w, npad, tid, 512);
-    win_fill_table<T>(p, s.tb, h, tid, 512);
-    for (int n = tid; n < npad; n += 512) {
+    win_fill_slots(p, s, b, w, npad, tid, 1024);
+    win_fill_table<T>(p, s.tb, h, tid, 1024);
+    for (int n = tid; n < npad; n += 1024) {
         const int64_t stat = ((int64_t)gw * p.heads + h) * N + n;
-        s_lse[n] = n < N ? p.lse[stat] : INFINITY;       // slots past the window: p = exp(s - inf) = 0
+        s_lse[n] = n < N ? p.lse[stat] * LOG2E_F : INFINITY;       // log2 domain; slots past the window: p = 2^(s - inf) = 0
         s_dl[n] = n < N ? p.delta[stat] : 0.f;
     }
     __syncthreads();
     const T* qkv = (const T*)p.qkv;
     const int64_t ld = 3 * (int64_t)p.C;
-    win_stage<T, true, true>(qkv, ld, h * WIN_D, s.rows, N, npad, sQ, sQt, tid, 512);
-    win_stage<T, true, true>((const T*)p.dout, (int64_t)p.C, h * WIN_D, s.rows, N, npad, sdO, sdOt, tid, 512);
+    win_stage<T, true, true>(qkv, ld, h * WIN_D, s.rows, N, npad, sQ, sQt, tid, 1024);
+    win_stage<T, true, true>((const T*)p.dout, (int64_t)p.C, h * WIN_D, s.rows, N, npad, sdO, sdOt, tid, 1024);
     __syncthreads();
 
-    for (int kt = wave; kt * 16 < N; kt += 8) {
+    for (int kt = wave; kt * 16 < N; kt += 16) {
         const int kr = kt * 16 + fr;
         const bool kok = kr < N;
         const int krow = s.rows[kok ? kr : 0];
@@ -410,6 +426,7 @@ __global__ __launch_bounds__(512) void win_bwd_dkv_kernel(WinArgs p) {
             vf[dg] = win_load_frag<T>(qkv + (int64_t)krow * ld + 2 * p.C + h * WIN_D, dg, g, kok);
         }
         const int relk = s.rel[kr] - p.relc, labk = s.lab[kr];
+        const float scale2 = p.scale * LOG2E_F;
         f32x4_t dkacc[2] = {(f32x4_t){0.f, 0.f, 0.f, 0.f}, (f32x4_t){0.f, 0.f, 0.f, 0.f}};
         f32x4_t dvacc[2] = {(f32x4_t){0.f, 0.f, 0.f, 0.f}, (f32x4_t){0.f, 0.f, 0.f, 0.f}};
         for (int q0 = 0; q0 < npad; q0 += 64) {
@@ -429,14 +446,15 @@ __global__ __launch_bounds__(512) void win_bwd_dkv_kernel(WinArgs p) {
             for (int t = 0; t < 4; ++t) {
                 const int qb = q0 + t * 16 + 4 * g;
                 const i32x4_t rq = *(const i32x4_t*)&s.rel[qb];
-                const i32x4_t lq = *(const i32x4_t*)&s.lab[qb];
+                i32x4_t lq;
+                if (SHIFT) lq = *(const i32x4_t*)&s.lab[qb];
                 const f32x4_t ls = *(const f32x4_t*)&s_lse[qb];
                 const f32x4_t dl = *(const f32x4_t*)&s_dl[qb];
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    float v = sacc[t][r] * p.scale + s.tb[rq[r] - relk];
-                    v = lq[r] != labk ? v - 100.0f : v;
-                    const float pr = fexp<T>(v - ls[r]);          // key lanes past the window compute garbage-free zeros' worth: never stored
+                    float v = sacc[t][r] * scale2 + s.tb[rq[r] - relk];
+                    if (SHIFT) v = lq[r] != labk ? v - WIN_MASK2 : v;
+                    const float pr = fexp2<T>(v - ls[r]);          // key lanes past the window compute garbage-free zeros' worth: never stored
                     sacc[t][r] = pr;
                     dpacc[t][r] = pr * (dpacc[t][r] - dl[r]);
                 }
@@ -467,23 +485,35 @@ __global__ __launch_bounds__(256) void win_dbias_reduce_kernel(float* part, int 
         *(f32x4_t*)(part + i * 4) = a;
     }
 }
-// d(table)[r][h] (+)= sum_i dB[h][i][j(i, r)] with j(i, r) the slot whose rel is rel[i] + relc - r (videoswin.py:146-148 backward)
+// d(table)[r][h] (+)= sum_i dB[h][i][j(i, r)] with j(i, r) the slot whose rel is rel[i] + relc - r (videoswin.py:146-148 backward).
+// Workgroup = 32 bins x 8 row slices (every thread a chain of dependent L2 reads: keep many short chains in flight), LDS tree.
 template <typename T>
 __global__ __launch_bounds__(256) void win_table_grad_kernel(const float* dB, const int* rel, const int* rel_inv, int heads, int R, int N,
                                                              int npad, int relc, T* dtable, int accumulate) {
-    const int i0 = blockIdx.x * 256 + threadIdx.x;
-    if (i0 >= heads * R) return;
-    const int h = i0 / R, r = i0 % R;
+    __shared__ float red[8][32];
+    const int bin = blockIdx.x * 32 + (threadIdx.x & 31), sl = threadIdx.x >> 5;
+    const bool ok = bin < heads * R;
+    const int h = ok ? bin / R : 0, r = ok ? bin % R : 0;
     const float* src = dB + (int64_t)h * N * npad;
-    float a0 = 0.f, a1 = 0.f;
-    for (int i = 0; i < N; ++i) {
-        const int m = rel[i] + relc - r;
-        const int j = (m >= 0 && m <= relc) ? rel_inv[m] : -1;
-        const float v = (j >= 0 && j < N) ? src[(int64_t)i * npad + j] : 0.f;
-        if (i & 1) a1 += v; else a0 += v;
+    float a[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int i0 = sl; i0 < N; i0 += 32) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int i = i0 + 8 * u;
+            const int m = (i < N ? rel[i] : -1 - relc) + relc - r;
+            const int j = (m >= 0 && m <= relc) ? rel_inv[m] : -1;
+            a[u] += (j >= 0 && j < N) ? src[(int64_t)i * npad + j] : 0.f;
+        }
     }
-    T* o = dtable + (int64_t)r * heads + h;
-    *o = from_f32<T>((accumulate ? to_f32<T>(*o) : 0.f) + (a0 + a1));
+    red[sl][threadIdx.x & 31] = (a[0] + a[1]) + (a[2] + a[3]);
+    __syncthreads();
+    if (sl == 0 && ok) {
+        float v = 0.f;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v += red[k][threadIdx.x];
+        T* o = dtable + (int64_t)r * heads + h;
+        *o = from_f32<T>((accumulate ? to_f32<T>(*o) : 0.f) + v);
+    }
 }
 
 // ------------------------------------------------------------------------------------------ launchers
@@ -511,21 +541,33 @@ template <typename T>
 static int win_fwd_launch(hipStream_t st, const WinArgs& p) {
     const int npad = (p.N + 63) & ~63, lds = win_lds_fwd<T>(p.R, npad);
     if (lds > WIN_LDS_MAX) return VALOR_ERR_ARG;
-    hipFuncSetAttribute((const void*)win_fwd_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    hipLaunchKernelGGL(win_fwd_kernel<T>, dim3(p.heads, p.B * p.nW), dim3(256), lds, st, p);
+    if (p.label) {
+        hipFuncSetAttribute((const void*)win_fwd_kernel<T, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        hipLaunchKernelGGL((win_fwd_kernel<T, true>), dim3(p.heads, p.B * p.nW), dim3(512), lds, st, p);
+    } else {
+        hipFuncSetAttribute((const void*)win_fwd_kernel<T, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        hipLaunchKernelGGL((win_fwd_kernel<T, false>), dim3(p.heads, p.B * p.nW), dim3(512), lds, st, p);
+    }
     return hipGetLastError() == hipSuccess ? VALOR_OK : VALOR_ERR_LAUNCH;
 }
 template <typename T>
 static int win_bwd_launch(hipStream_t st, const WinArgs& p, void* dtable, int accumulate, int G) {
     const int npad = (p.N + 63) & ~63, l1 = win_lds_dq<T>(p.R, npad), l2 = win_lds_dkv<T>(p.R, npad);
     if (l1 > WIN_LDS_MAX || l2 > WIN_LDS_MAX || npad > 64 * WIN_MAXCH) return VALOR_ERR_ARG;
-    hipFuncSetAttribute((const void*)win_bwd_dq_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, l1);
-    hipFuncSetAttribute((const void*)win_bwd_dkv_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, l2);
-    hipLaunchKernelGGL(win_bwd_dq_kernel<T>, dim3(p.heads, 4, G), dim3(512), l1, st, p);
-    hipLaunchKernelGGL(win_bwd_dkv_kernel<T>, dim3(p.heads, p.B * p.nW), dim3(512), l2, st, p);
+    if (p.label) {
+        hipFuncSetAttribute((const void*)win_bwd_dq_kernel<T, true>, hipFuncAttributeMaxDynamicSharedMemorySize, l1);
+        hipFuncSetAttribute((const void*)win_bwd_dkv_kernel<T, true>, hipFuncAttributeMaxDynamicSharedMemorySize, l2);
+        hipLaunchKernelGGL((win_bwd_dq_kernel<T, true>), dim3(p.heads, 4, G), dim3(512), l1, st, p);
+        hipLaunchKernelGGL((win_bwd_dkv_kernel<T, true>), dim3(p.heads, p.B * p.nW), dim3(1024), l2, st, p);
+    } else {
+        hipFuncSetAttribute((const void*)win_bwd_dq_kernel<T, false>, hipFuncAttributeMaxDynamicSharedMemorySize, l1);
+        hipFuncSetAttribute((const void*)win_bwd_dkv_kernel<T, false>, hipFuncAttributeMaxDynamicSharedMemorySize, l2);
+        hipLaunchKernelGGL((win_bwd_dq_kernel<T, false>), dim3(p.heads, 4, G), dim3(512), l1, st, p);
+        hipLaunchKernelGGL((win_bwd_dkv_kernel<T, false>), dim3(p.heads, p.B * p.nW), dim3(1024), l2, st, p);
+    }
     const int64_t n4 = (int64_t)p.heads * p.N * npad / 4;
     if (G > 1) hipLaunchKernelGGL(win_dbias_reduce_kernel, dim3((unsigned)((n4 + 255) / 256 > 4096 ? 4096 : (n4 + 255) / 256)), dim3(256), 0, st, p.dbias_part, G, n4);
-    hipLaunchKernelGGL(win_table_grad_kernel<T>, dim3((p.heads * p.R + 255) / 256), dim3(256), 0, st, p.dbias_part, p.rel, p.rel_inv, p.heads, p.R,
+    hipLaunchKernelGGL(win_table_grad_kernel<T>, dim3((p.heads * p.R + 31) / 32), dim3(256), 0, st, p.dbias_part, p.rel, p.rel_inv, p.heads, p.R,
                        p.N, npad, p.relc, (T*)dtable, accumulate);
     return hipGetLastError() == hipSuccess ? VALOR_OK : VALOR_ERR_LAUNCH;
 }
