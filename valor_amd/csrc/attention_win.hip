@@ -11,7 +11,9 @@
 //   * the relative position bias is never expanded: bias(i, j) = table[rel[i] - rel[j] + relc][head] with
 //     rel[t] = d*(2wh-1)(2ww-1) + h*(2ww-1) + w of slot t in the FULL window (videoswin.py:112-126 is exactly this
 //     difference), so a workgroup keeps its head's table column (2535 floats) and rel[] in LDS and gathers per score.
-//   * the shift mask is (label[i] != label[j]) ? -100 : 0 with one region label per slot (compute_mask's img_mask).
+//   * the shift mask is (label[i] != label[j]) ? -100 : 0 with one region label per slot (compute_mask's img_mask); the
+//     label rides in bits 16+ of the slot's rel value, so ONE subtraction X = relx[i] + relc - relx[j] yields the table index
+//     (X & 0xffff: the rel difference is in [0, 2 relc], no borrow) and the mismatch flag (X > 0xffff as unsigned).
 //   * backward: d(table) is a histogram of dS over rel[i] - rel[j]. LDS float atomics run at about a quarter lane per
 //     clock on this part (measured: the histogram version of the dQ pass took 5 ms per layer, 14x its arithmetic), so
 //     there are none: a dQ workgroup owns a quarter of a window's query rows and walks MANY windows (same head), each
@@ -136,15 +138,14 @@ DEVINL void win_store4(T* rowp, int dt, int g, f32x4_t v) {
 }
 
 struct WinSmem {
-    float* tb; int* rel; int* lab; int* rows; char* img;
+    float* tb; int* rel; int* rows; char* img;       // rel: rel[slot] | label[slot] << 16
 };
 // per-window bookkeeping arrays: global row of every slot, rel[], labels (pad slots: row 0 / never used)
 DEVINL void win_fill_slots(const WinArgs& p, const WinSmem& s, int b, int w, int npad, int tid, int nthreads) {
     for (int n = tid; n < npad; n += nthreads) {
         const bool ok = n < p.N;
         s.rows[n] = ok ? b * p.rows_per_sample + p.rowmap[w * p.N + n] : 0;
-        s.rel[n] = ok ? p.rel[n] : 0;
-        s.lab[n] = (ok && p.label) ? (int)p.label[w * p.N + n] : 0;
+        s.rel[n] = ok ? (p.rel[n] | (p.label ? (int)p.label[w * p.N + n] << 16 : 0)) : 0;
     }
 }
 template <typename T>
@@ -156,12 +157,11 @@ DEVINL WinSmem win_carve(char* smem, int R, int npad) {
     WinSmem s;
     s.tb = (float*)smem; smem += ((R + 3) & ~3) * 4;
     s.rel = (int*)smem; smem += npad * 4;
-    s.lab = (int*)smem; smem += npad * 4;
     s.rows = (int*)smem; smem += npad * 4;
     s.img = smem;
     return s;
 }
-static int win_small_bytes(int R, int npad) { return ((R + 3) & ~3) * 4 + 3 * npad * 4; }
+static int win_small_bytes(int R, int npad) { return ((R + 3) & ~3) * 4 + 2 * npad * 4; }
 
 // ------------------------------------------------------------------------------------------ forward
 // grid (heads, B*nW), 512 threads (2 workgroups per CU = 4 waves per SIMD: the elementwise softmax is latency bound). LDS: K row
@@ -192,7 +192,7 @@ __global__ __launch_bounds__(512) void win_fwd_kernel(WinArgs p) {
         typename Mma<T>::frag_t qf[G::NDG];
 #pragma unroll
         for (int dg = 0; dg < G::NDG; ++dg) qf[dg] = win_load_frag<T>(qkv + (int64_t)qrow * ld + h * WIN_D, dg, g, qok);
-        const int relq = s.rel[qr] + p.relc, labq = s.lab[qr];
+        const int relq = s.rel[qr] + p.relc;
         const float scale2 = p.scale * LOG2E_F;
         float m = -1e30f, l = 0.f;
         f32x4_t oacc[2] = {(f32x4_t){0.f, 0.f, 0.f, 0.f}, (f32x4_t){0.f, 0.f, 0.f, 0.f}};
@@ -213,12 +213,11 @@ __global__ __launch_bounds__(512) void win_fwd_kernel(WinArgs p) {
             for (int kt = 0; kt < 4; ++kt) {
                 const int kb = k0 + kt * 16 + 4 * g;
                 const i32x4_t rk = *(const i32x4_t*)&s.rel[kb];
-                i32x4_t lk;
-                if (SHIFT) lk = *(const i32x4_t*)&s.lab[kb];
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    float v = sacc[kt][r] * scale2 + s.tb[relq - rk[r]];
-                    if (SHIFT) v = lk[r] != labq ? v - WIN_MASK2 : v;
+                    const int X = relq - rk[r];
+                    float v = sacc[kt][r] * scale2 + s.tb[SHIFT ? (X & 0xffff) : X];
+                    if (SHIFT) v = (uint32_t)X > 0xffffu ? v - WIN_MASK2 : v;
                     if (TAIL) v = kb + r < N ? v : -INFINITY;
                     sacc[kt][r] = v;
                     mx = fmaxf(mx, v);
@@ -326,7 +325,7 @@ __global__ __launch_bounds__(512) void win_bwd_dq_kernel(WinArgs p) {
         const float lse2 = qok ? p.lse[stat] * LOG2E_F : INFINITY;   // rows past the window: 2^(s - inf) = 0, no select per element
         const float scale2 = p.scale * LOG2E_F;
         if (qok && g == 0) p.delta[stat] = dl;
-        const int relq = s.rel[qr] + p.relc, labq = s.lab[qr];
+        const int relq = s.rel[qr] + p.relc;
         f32x4_t dqacc[2] = {(f32x4_t){0.f, 0.f, 0.f, 0.f}, (f32x4_t){0.f, 0.f, 0.f, 0.f}};
 #pragma unroll
         for (int c = 0; c < WIN_MAXCH; ++c) {
@@ -348,12 +347,11 @@ __global__ __launch_bounds__(512) void win_bwd_dq_kernel(WinArgs p) {
                 for (int kt = 0; kt < 4; ++kt) {
                     const int kb = k0 + kt * 16 + 4 * g;
                     const i32x4_t rk = *(const i32x4_t*)&s.rel[kb];
-                    i32x4_t lk;
-                    if (SHIFT) lk = *(const i32x4_t*)&s.lab[kb];
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        float v = sacc[kt][r] * scale2 + s.tb[relq - rk[r]];
-                        if (SHIFT) v = lk[r] != labq ? v - WIN_MASK2 : v;
+                        const int X = relq - rk[r];
+                        float v = sacc[kt][r] * scale2 + s.tb[SHIFT ? (X & 0xffff) : X];
+                        if (SHIFT) v = (uint32_t)X > 0xffffu ? v - WIN_MASK2 : v;
                         float ds = fexp2<T>(v - lse2) * (dpacc[kt][r] - dl);
                         ds = kb + r < N ? ds : 0.f;
                         sacc[kt][r] = ds;
@@ -425,7 +423,7 @@ __global__ __launch_bounds__(1024) void win_bwd_dkv_kernel(WinArgs p) {
             kf[dg] = win_load_frag<T>(qkv + (int64_t)krow * ld + p.C + h * WIN_D, dg, g, kok);
             vf[dg] = win_load_frag<T>(qkv + (int64_t)krow * ld + 2 * p.C + h * WIN_D, dg, g, kok);
         }
-        const int relk = s.rel[kr] - p.relc, labk = s.lab[kr];
+        const int kneg = p.relc - s.rel[kr];           // X = relx[q] + relc - relx[key]
         const float scale2 = p.scale * LOG2E_F;
         f32x4_t dkacc[2] = {(f32x4_t){0.f, 0.f, 0.f, 0.f}, (f32x4_t){0.f, 0.f, 0.f, 0.f}};
         f32x4_t dvacc[2] = {(f32x4_t){0.f, 0.f, 0.f, 0.f}, (f32x4_t){0.f, 0.f, 0.f, 0.f}};
@@ -446,14 +444,13 @@ __global__ __launch_bounds__(1024) void win_bwd_dkv_kernel(WinArgs p) {
             for (int t = 0; t < 4; ++t) {
                 const int qb = q0 + t * 16 + 4 * g;
                 const i32x4_t rq = *(const i32x4_t*)&s.rel[qb];
-                i32x4_t lq;
-                if (SHIFT) lq = *(const i32x4_t*)&s.lab[qb];
                 const f32x4_t ls = *(const f32x4_t*)&s_lse[qb];
                 const f32x4_t dl = *(const f32x4_t*)&s_dl[qb];
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    float v = sacc[t][r] * scale2 + s.tb[rq[r] - relk];
-                    if (SHIFT) v = lq[r] != labk ? v - WIN_MASK2 : v;
+                    const int X = rq[r] + kneg;
+                    float v = sacc[t][r] * scale2 + s.tb[SHIFT ? (X & 0xffff) : X];
+                    if (SHIFT) v = (uint32_t)X > 0xffffu ? v - WIN_MASK2 : v;
                     const float pr = fexp2<T>(v - ls[r]);          // key lanes past the window compute garbage-free zeros' worth: never stored
                     sacc[t][r] = pr;
                     dpacc[t][r] = pr * (dpacc[t][r] - dl[r]);
