@@ -384,6 +384,18 @@ class Oracle:
         h = F.relu(F.linear(feat, w(f"{name}_fine_weight.0.weight"), w(f"{name}_fine_weight.0.bias")))
         return F.linear(h, w(f"{name}_fine_weight.2.weight"), w(f"{name}_fine_weight.2.bias")).squeeze(2)
 
+    # ------------------------------------------------------------------------- BASELINE configs[0]
+    def text_mlm(self, bert_tokens, compute_loss=True):
+        """The reference's CPU-runnable plumbing case (forward_pt cannot express text-only MLM): TokenMasker
+        p = 0.15 (modeling.py:134-174) -> multimodal_encoder(txt, None, None, None, casual=False) (bert.py:848-896, no
+        cross-attention input) -> BERTPredictionHead on the masked rows (modeling.py:245-254) -> F.cross_entropy."""
+        txt_input, txt_labels = self.text_masker(bert_tokens, 0.15)
+        o = self.bert_model(txt_input, None, None, None, False)
+        scores = self.cls_head(o[txt_labels != -1])
+        if compute_loss:
+            return {"mlm_loss": F.cross_entropy(scores, txt_labels[txt_labels != -1])}
+        return {"mlm_scores_t": scores, "txt_labels_mlm": txt_labels}
+
     # ------------------------------------------------------------------------- the hot path
     def forward_pt(self, batch, task, compute_loss=True, gather=None, collect=None):
         """VALOR.forward_pt, model/pretrain.py:214-541 (contra_type='fine', caption_type='unimlm', va_concate).
@@ -477,6 +489,9 @@ class Oracle:
             vo = video_output + w("video_frame_embedding")[:, :video_output.shape[1], :].unsqueeze(-2)
             video_input = vo.reshape(bs, -1, self.spec.hidden) + w("video_type_embeddings")
         if audio_output is not None:                                                             # modeling.py:495-502
+            if "hidden_trans_audio_multimodal.0.weight" in self.sd:                              # modeling.py:350-351,497-498
+                audio_output = layer_norm(F.linear(audio_output, w("hidden_trans_audio_multimodal.0.weight"), w("hidden_trans_audio_multimodal.0.bias")),
+                                          w("hidden_trans_audio_multimodal.1.weight"), w("hidden_trans_audio_multimodal.1.bias"), 1e-12)
             ao = audio_output + w("audio_frame_embedding")[:, :audio_output.shape[1], :].unsqueeze(-2)
             audio_input = ao.reshape(bs, -1, self.spec.hidden) + w("audio_type_embeddings")
 

@@ -124,6 +124,22 @@ def test_unsupported_configs_fail_loudly():
         m({}, task="ret%tv")
 
 
+def test_param_tables_of_the_swin_and_large_configurations():
+    """every variant's internal parameter table covers its reference-keyed layout exactly (scripts/pretrain.sh VideoSwin-B:
+    314.40 M parameters as probed from the reference; BASELINE configs[3] widths: both hidden_trans projections present)"""
+    import math
+    for spec, n_expected in ((synth.swin_spec(), 314404358), (synth.large_spec(), None), (synth.tiny_large_spec(), None), (synth.tiny_swin_spec(), None)):
+        T = param_table(spec)
+        refs = [r for _, _, rs in T for r in rs]
+        lay = [k for k, _, kind in synth.state_dict_layout(spec) if kind not in ("alias", "relidx")]
+        assert sorted(refs) == sorted(lay)
+        if n_expected:
+            assert sum(math.prod(s) for _, s, _ in T) == n_expected
+    names = {n for n, _, _ in param_table(synth.large_spec())}
+    assert "hidden_trans_audio_multimodal.0.weight" in names and "hidden_trans_video_multimodal.0.weight" in names
+    assert dict((n, s) for n, s, _ in param_table(synth.large_spec()))["video_encoder.layers.2.downsample.norm.weight"] == (3072,)
+
+
 def test_swin_variant_host_side():
     """VideoSwin + BERT-text variant (scripts/pretrain.sh:3-8): reference-keyed state dict round trip (integer buffers and the
     txt_encoder.* aliases included), window index maps == roll + window_partition / compute_mask of the oracle, PatchMerging

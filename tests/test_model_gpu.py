@@ -47,13 +47,16 @@ def _native_grads(model):
     return out
 
 
-@pytest.mark.parametrize("variant", ["clip", "swin"])
+@pytest.mark.parametrize("variant", ["clip", "swin", "large"])
 def test_tiny_fp32_matches_oracle(dev, variant):
+    """clip / swin: the two base configurations on small widths. large: the WIDTHS of BASELINE configs[3] (VideoSwin-L +
+    BERT-large: LayerNorm rows of 3072, hidden 1024 with both hidden_trans projections) on a shallow stack."""
     from valor_amd import synth
     import valor_oracle as VO
-    spec = synth.tiny_spec() if variant == "clip" else synth.tiny_swin_spec()
+    spec = {"clip": synth.tiny_spec, "swin": synth.tiny_swin_spec, "large": synth.tiny_large_spec}[variant]()
     sd = synth.make_state_dict(spec, seed=3, w_std=0.05)
-    batch = synth.make_batch(spec, batch=4, frames=2, audio_slices=2, txt_len=32, seed=4)
+    nb = 2 if variant == "large" else 4
+    batch = synth.make_batch(spec, batch=nb, frames=2, audio_slices=1 if variant == "large" else 2, txt_len=32, seed=4)
     orc, sd_o = _oracle(spec, sd)
     model = _native(spec, sd, torch.float32, dev)
     random.seed(11)
@@ -91,6 +94,33 @@ def test_tiny_fp32_matches_oracle(dev, variant):
             assert torch.equal(oe[k].argmax(-1), ne[k].argmax(-1).cpu()), k
             assert torch.allclose(oe[k], ne[k].cpu(), atol=2e-4, rtol=1e-4), k
     assert torch.equal(oe["txt_labels_caption"], ne["txt_labels_caption"])
+
+
+def test_text_only_mlm_matches_oracle(dev):
+    """BASELINE configs[0] (text-only MLM, batch 2; the reference's CPU plumbing case) through the HIP kernels: loss within 1e-4
+    of the oracle, argmax ids exact, BERT / head gradients."""
+    from valor_amd import synth
+    import valor_oracle as VO
+    spec = synth.base_spec()
+    sd = synth.make_state_dict(spec, seed=5)
+    batch = synth.make_batch(spec, batch=2, frames=1, audio_slices=1, txt_len=32, seed=6)
+    orc, sd_o = _oracle(spec, sd)
+    model = _native(spec, sd, torch.float32, dev)
+    random.seed(31); lo = orc.text_mlm(batch["txt_tokens"]["bert_tokens"])["mlm_loss"]; lo.backward()
+    random.seed(31); ln = model.text_mlm(batch)["mlm_loss"]; ln.backward()
+    assert abs(float(lo) - float(ln)) <= 1e-4 * abs(float(lo))
+    ng = _native_grads(model)
+    for k, p in sd_o.items():
+        if VO.is_alias_key(k) or not p.is_floating_point() or p.grad is None:
+            continue
+        go, gn = p.grad, ng[k].detach().cpu()
+        scale = max(float(go.norm()), 1e-5 * go.numel() ** 0.5)
+        assert float((gn.reshape(go.shape) - go).norm()) / scale < 2e-3, k
+    with torch.no_grad():
+        random.seed(32); oe = orc.text_mlm(batch["txt_tokens"]["bert_tokens"], compute_loss=False)
+        random.seed(32); ne = model.text_mlm(batch, compute_loss=False)
+    assert torch.equal(oe["mlm_scores_t"].argmax(-1), ne["mlm_scores_t"].argmax(-1).cpu())
+    assert torch.equal(oe["txt_labels_mlm"], ne["txt_labels_mlm"])
 
 
 @pytest.mark.parametrize("name", ["ref_base_b2f2a1", "ref_base_b3f1a2", "ref_swin_b2f2a1"])

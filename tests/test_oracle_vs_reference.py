@@ -95,3 +95,34 @@ def test_eval_argmax_matches_reference(setup):
     assert torch.equal(r["txt_labels_caption"], o["txt_labels_caption"])
     assert torch.allclose(r["feat_t"], o["feat_t"], atol=1e-5)
     assert torch.allclose(r["feat_v"], o["feat_v"], atol=1e-5)
+
+
+def test_text_only_mlm_plumbing_case(setup):
+    """BASELINE configs[0] / SURVEY 8d config 1: text-only MLM on CPU, batch 2 -- the reference modules composed by hand
+    (forward_pt cannot express it) against the oracle's restatement: loss and the gradients of every BERT / head tensor."""
+    import torch.nn.functional as F
+    spec, ref, orc, sd_o, batch = setup
+    toks = batch["txt_tokens"]["bert_tokens"]
+    for p in ref.parameters():
+        p.grad = None
+    for v in sd_o.values():
+        if v.is_floating_point():
+            v.grad = None
+    random.seed(21)
+    txt_input, txt_labels = ref.text_masker(toks, 0.15)
+    o = ref.multimodal_encoder(txt_input, None, None, None, casual=False)
+    loss_r = F.cross_entropy(ref.cls(o[txt_labels != -1]), txt_labels[txt_labels != -1])
+    loss_r.backward()
+    random.seed(21)
+    loss_o = orc.text_mlm(toks)["mlm_loss"]
+    loss_o.backward()
+    assert abs(float(loss_r) - float(loss_o)) <= 2e-5 * abs(float(loss_r))
+    n = 0
+    for name, p in ref.named_parameters():
+        if p.grad is None:
+            continue
+        g = sd_o[name].grad
+        scale = max(float(p.grad.norm()), 1e-5 * p.grad.numel() ** 0.5)
+        assert float((g - p.grad).norm()) / scale < 2e-4, name
+        n += 1
+    assert n > 150

@@ -159,6 +159,36 @@ def test_group_mean_and_row_scale(dev):
         assert _rel(got, ref) < 2e-5
 
 
+@pytest.mark.parametrize("dtype,cols", [(torch.float32, 3072), (torch.bfloat16, 3072), (torch.float32, 4096), (torch.float32, 2052)])
+def test_wide_layernorm(dev, dtype, cols):
+    """rows wider than 2048 (VideoSwin-L's last PatchMerging norm is 3072 wide): the four-waves-per-row kernels, forward and
+    backward incl. the fused bias / residual / row-scale stages and the column partials"""
+    from valor_amd import ops
+    from valor_amd.ops import GradSink
+    g = torch.Generator().manual_seed(5)
+    rows = 37
+    mk = lambda *sh: torch.randn(sh, generator=g).to(dtype).to(dev).requires_grad_(True)
+    a, res, bias, gam, bet = mk(rows, cols), mk(rows, cols), mk(cols), mk(cols), mk(cols)
+    scale = torch.tensor([1.0, 0.0, 1.25, 1.25] + [1.0] * 34, device=dev)[:rows].contiguous()
+    GradSink.enabled = False
+    try:
+        z, y = ops.bias_dropout_residual_ln(a, bias, res, gam, bet, 1e-5, 0.0, True, scale, 1)
+        gz, gy = torch.randn(z.shape, generator=g).to(dtype).to(dev), torch.randn(z.shape, generator=g).to(dtype).to(dev)
+        (z.float() * gz.float() + y.float() * gy.float()).sum().backward()
+        y0 = ops.layer_norm(a.detach(), gam.detach(), bet.detach(), 1e-5)
+    finally:
+        GradSink.enabled = True
+    ar, rr, br, gr, ber = [t.detach().double().cpu().requires_grad_(True) for t in (a, res, bias, gam, bet)]
+    zr = rr + scale.double().cpu()[:, None] * (ar + br)
+    yr = F.layer_norm(zr, (cols,), gr, ber, 1e-5)
+    (zr * gz.double().cpu() + yr * gy.double().cpu()).sum().backward()
+    tol = 2e-5 if dtype == torch.float32 else 2e-2
+    assert _rel(z, zr) < tol and _rel(y, yr) < tol
+    assert _rel(y0, F.layer_norm(ar.detach(), (cols,), gr.detach(), ber.detach(), 1e-5)) < tol
+    for got, ref in ((a.grad, ar.grad), (res.grad, rr.grad), (bias.grad, br.grad), (gam.grad, gr.grad), (bet.grad, ber.grad)):
+        assert _rel(got, ref) < tol
+
+
 def test_swin_geometry_matches_reference_partition(dev):
     """the kernel's index maps reproduce roll + window_partition and compute_mask (videoswin.py:75-79,205-206,272-285)"""
     from valor_oracle import Oracle

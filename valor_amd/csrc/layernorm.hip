@@ -10,7 +10,7 @@
 //
 //   z = dropout_p(x + bias) / (1-p) + residual        (bias / residual / dropout optional)
 //   y = (z - mean(z)) * rsqrt(var(z) + eps) * gamma + beta     (gamma/beta optional)
-// One wave per row, row held in registers (cols <= 2048 and cols % 4 == 0), two-pass
+// One wave per row, row held in registers (cols <= 2048 and cols % 4 == 0; up to 4096 with four waves per row), two-pass
 // mean / variance in fp32 (the apex kernel uses Welford; both agree to fp32 rounding).
 // z may alias x (in-place), so the pre-LN sum costs no extra buffer.
 // Dropout masks come from Philox4x32-10 keyed on (seed, element index / 4) and are
@@ -24,7 +24,8 @@
 //   column reduction; valor_colsum_finalize sums the partials).
 #include "common.h"
 
-#define LN_MAX_V 8          // 4-element vectors per lane: cols <= 64*4*8 = 2048
+#define LN_MAX_V 8          // 4-element vectors per lane, one wave per row: cols <= 64*4*8 = 2048
+#define LN_MAX_COLS 4096    // beyond LN_MAX_V: the wide kernels (4 waves per row)
 #define LN_PART_BLOCKS 1024  // fixed workgroup count of the backward / colsum partial stage
 
 struct LnArgs {
@@ -229,6 +230,178 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(LnBwdArgs p) {
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// Wide rows (2048 < cols <= 4096: the 4C = 3072 LayerNorm of VideoSwin-L's last PatchMerging, videoswin.py:247-270): the
+// four waves of a workgroup share ONE row, wave w owning columns [w*NVW*256, (w+1)*NVW*256); row statistics cross the waves
+// through LDS, the column partials need no cross-wave reduction (every column has one owner).
+// ---------------------------------------------------------------------------------------------
+DEVINL float block4_sum(float v, float* red, int wave, int lane) {
+    v = wave_sum(v);
+    __syncthreads();
+    if (lane == 0) red[wave] = v;
+    __syncthreads();
+    return (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+template <typename T, int NVW>
+__global__ __launch_bounds__(256) void ln_fwd_wide_kernel(LnArgs p) {
+    __shared__ float red[4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const T* X = (const T*)p.x; const T* Bi = (const T*)p.bias; const T* R = (const T*)p.residual;
+    const T* G = (const T*)p.gamma; const T* Be = (const T*)p.beta;
+    T* Z = (T*)p.z; T* Y = (T*)p.y;
+    const int cols = p.cols;
+    const uint32_t thr = drop_threshold(p.p_drop);
+    const float keep_scale = p.p_drop > 0.f ? 1.0f / (1.0f - p.p_drop) : 1.0f;
+    const float inv_n = 1.0f / (float)cols;
+    for (int64_t row = blockIdx.x; row < p.rows; row += gridDim.x) {
+        const int64_t base = row * cols;
+        const float rsc = p.row_scale ? p.row_scale[row / p.rows_per_scale] : 1.0f;
+        f32x4_t v[NVW];
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < NVW; ++i) {
+            const int c = ((wave * NVW + i) * 64 + lane) * 4;
+            f32x4_t t = {0.f, 0.f, 0.f, 0.f};
+            if (c < cols) {
+                t = load4<T>(X + base + c);
+                if (Bi) t += load4<T>(Bi + c);
+                if (thr) {
+                    Philox4 rnd = philox4x32_10(p.seed, p.offset + (uint64_t)((base + c) >> 2));
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) t[k] = rnd.v[k] >= thr ? t[k] * keep_scale : 0.f;
+                }
+                if (p.row_scale) t *= rsc;
+                if (R) t += load4<T>(R + base + c);
+                if (Z) store4<T>(Z + base + c, t);
+                if (Z && ElemTraits<T>::DT == VALOR_DT_BF16) {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) t[k] = bf16_bits_to_f32(f32_to_bf16_bits(t[k]));
+                }
+                s += t[0] + t[1] + t[2] + t[3];
+            }
+            v[i] = t;
+        }
+        if (!Y) continue;                       // block uniform
+        const float mu = block4_sum(s, red, wave, lane) * inv_n;
+        float q = 0.f;
+#pragma unroll
+        for (int i = 0; i < NVW; ++i) {
+            const int c = ((wave * NVW + i) * 64 + lane) * 4;
+            if (c < cols) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) { float d = v[i][k] - mu; q += d * d; }
+            }
+        }
+        const float rs = rsqrtf(block4_sum(q, red, wave, lane) * inv_n + p.eps);
+        if (threadIdx.x == 0) {
+            if (p.mean) p.mean[row] = mu;
+            if (p.rstd) p.rstd[row] = rs;
+        }
+#pragma unroll
+        for (int i = 0; i < NVW; ++i) {
+            const int c = ((wave * NVW + i) * 64 + lane) * 4;
+            if (c < cols) {
+                f32x4_t o;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) o[k] = (v[i][k] - mu) * rs;
+                if (G) o *= load4<T>(G + c);
+                if (Be) o += load4<T>(Be + c);
+                store4<T>(Y + base + c, o);
+            }
+        }
+    }
+}
+
+template <typename T, int NVW>
+__global__ __launch_bounds__(256) void ln_bwd_wide_kernel(LnBwdArgs p) {
+    __shared__ float red[4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const T* DY = (const T*)p.dy; const T* DZI = (const T*)p.dz_in; const T* Z = (const T*)p.z;
+    const T* G = (const T*)p.gamma;
+    T* DX = (T*)p.dx; T* DR = (T*)p.dres;
+    const int cols = p.cols;
+    const uint32_t thr = drop_threshold(p.p_drop);
+    const float keep_scale = p.p_drop > 0.f ? 1.0f / (1.0f - p.p_drop) : 1.0f;
+    const float inv_n = 1.0f / (float)cols;
+    const bool has_ln = DY != nullptr;
+    f32x4_t gsum[NVW], bsum[NVW], xsum[NVW], gam[NVW];
+#pragma unroll
+    for (int i = 0; i < NVW; ++i) {
+        const int c = ((wave * NVW + i) * 64 + lane) * 4;
+        gsum[i] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+        bsum[i] = gsum[i]; xsum[i] = gsum[i];
+        gam[i] = (f32x4_t){1.f, 1.f, 1.f, 1.f};
+        if (G && c < cols) gam[i] = load4<T>(G + c);
+    }
+    for (int64_t row = blockIdx.x; row < p.rows; row += gridDim.x) {
+        const int64_t base = row * cols;
+        const float rsc = p.row_scale ? p.row_scale[row / p.rows_per_scale] : 1.0f;
+        f32x4_t dzv[NVW];
+        if (has_ln) {
+            const float mu = p.mean[row], rs = p.rstd[row];
+            f32x4_t xh[NVW], gy[NVW];
+            float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+            for (int i = 0; i < NVW; ++i) {
+                const int c = ((wave * NVW + i) * 64 + lane) * 4;
+                xh[i] = (f32x4_t){0.f, 0.f, 0.f, 0.f}; gy[i] = xh[i];
+                if (c < cols) {
+                    f32x4_t zz = load4<T>(Z + base + c);
+                    f32x4_t d = load4<T>(DY + base + c);
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        xh[i][k] = (zz[k] - mu) * rs;
+                        gsum[i][k] += d[k] * xh[i][k];
+                        bsum[i][k] += d[k];
+                        gy[i][k] = d[k] * gam[i][k];
+                        s1 += gy[i][k];
+                        s2 += gy[i][k] * xh[i][k];
+                    }
+                }
+            }
+            s1 = block4_sum(s1, red, wave, lane) * inv_n;
+            s2 = block4_sum(s2, red, wave, lane) * inv_n;
+#pragma unroll
+            for (int i = 0; i < NVW; ++i)
+#pragma unroll
+                for (int k = 0; k < 4; ++k) dzv[i][k] = rs * (gy[i][k] - s1 - xh[i][k] * s2);
+        } else {
+#pragma unroll
+            for (int i = 0; i < NVW; ++i) dzv[i] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+        }
+#pragma unroll
+        for (int i = 0; i < NVW; ++i) {
+            const int c = ((wave * NVW + i) * 64 + lane) * 4;
+            if (c < cols) {
+                f32x4_t dz = dzv[i];
+                if (DZI) dz += load4<T>(DZI + base + c);
+                if (DR) store4<T>(DR + base + c, dz);
+                f32x4_t dx = dz;
+                if (thr) {
+                    Philox4 rnd = philox4x32_10(p.seed, p.offset + (uint64_t)((base + c) >> 2));
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) dx[k] = rnd.v[k] >= thr ? dz[k] * keep_scale : 0.f;
+                }
+                if (p.row_scale) dx *= rsc;
+                if (DX && (thr || p.row_scale || DX != DR)) store4<T>(DX + base + c, dx);
+                xsum[i] += dx;
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < NVW; ++i) {
+        const int c = ((wave * NVW + i) * 64 + lane) * 4;
+        if (c < cols) {
+            const int64_t o = (int64_t)blockIdx.x * cols + c;
+            if (p.part_dgamma) *(f32x4_t*)(p.part_dgamma + o) = gsum[i];
+            if (p.part_dbeta) *(f32x4_t*)(p.part_dbeta + o) = bsum[i];
+            if (p.part_dbias) *(f32x4_t*)(p.part_dbias + o) = xsum[i];
+        }
+    }
+}
+
 // sum `nparts` partial rows [nparts][cols] (fp32) -> out[cols] (T or fp32), optional accumulate.
 // workgroup = 16 columns x 16 row-groups (256 threads), cols/16 workgroups (48 for 768 columns: the partials were
 // just written and sit in L2, so this is latency bound -- many small workgroups, 4 independent loads in flight per
@@ -336,7 +509,12 @@ static int launch_ln_fwd(hipStream_t st, const LnArgs& p) {
         case 4: launch_ln_fwd_nv<T, 4>(st, p); break;
         case 5: case 6: launch_ln_fwd_nv<T, 6>(st, p); break;
         case 7: case 8: launch_ln_fwd_nv<T, 8>(st, p); break;
-        default: return VALOR_ERR_ARG;
+        default: {
+            int64_t blocks = p.rows > 8192 ? 8192 : p.rows;
+            if (nv <= 12) hipLaunchKernelGGL((ln_fwd_wide_kernel<T, 3>), dim3((unsigned)blocks), dim3(256), 0, st, p);
+            else if (nv <= 16) hipLaunchKernelGGL((ln_fwd_wide_kernel<T, 4>), dim3((unsigned)blocks), dim3(256), 0, st, p);
+            else return VALOR_ERR_ARG;
+        }
     }
     return valor_launch_status();
 }
@@ -354,7 +532,10 @@ static int launch_ln_bwd(hipStream_t st, const LnBwdArgs& p) {
         case 4: launch_ln_bwd_nv<T, 4>(st, p); break;
         case 5: case 6: launch_ln_bwd_nv<T, 6>(st, p); break;
         case 7: case 8: launch_ln_bwd_nv<T, 8>(st, p); break;
-        default: return VALOR_ERR_ARG;
+        default:
+            if (nv <= 12) hipLaunchKernelGGL((ln_bwd_wide_kernel<T, 3>), dim3(LN_PART_BLOCKS), dim3(256), 0, st, p);
+            else if (nv <= 16) hipLaunchKernelGGL((ln_bwd_wide_kernel<T, 4>), dim3(LN_PART_BLOCKS), dim3(256), 0, st, p);
+            else return VALOR_ERR_ARG;
     }
     return valor_launch_status();
 }
@@ -366,7 +547,7 @@ extern "C" int valor_bdrln_fwd(void* stream, int dtype, const void* x, const voi
                                int64_t rows, int cols, float eps, float p_drop, uint64_t seed, uint64_t offset,
                                const float* row_scale, int64_t rows_per_scale) {
     if (rows <= 0) return VALOR_OK;
-    if (!x || cols <= 0 || (cols & 3) || cols > 64 * 4 * LN_MAX_V) return VALOR_ERR_ARG;
+    if (!x || cols <= 0 || (cols & 3) || cols > LN_MAX_COLS) return VALOR_ERR_ARG;
     if (p_drop < 0.f || p_drop >= 1.f || (row_scale && rows_per_scale <= 0)) return VALOR_ERR_ARG;
     LnArgs p{x, bias, residual, gamma, beta, z, y, mean, rstd, rows, cols, eps, p_drop, seed, offset, row_scale, rows_per_scale};
     hipStream_t st = (hipStream_t)stream;
@@ -381,7 +562,7 @@ extern "C" int valor_bdrln_bwd(void* stream, int dtype, const void* dy, const vo
                                float* part_dgamma, float* part_dbeta, float* part_dbias, int64_t rows, int cols,
                                float p_drop, uint64_t seed, uint64_t offset, const float* row_scale, int64_t rows_per_scale) {
     if (rows <= 0) return VALOR_OK;
-    if (cols <= 0 || (cols & 3) || cols > 64 * 4 * LN_MAX_V) return VALOR_ERR_ARG;
+    if (cols <= 0 || (cols & 3) || cols > LN_MAX_COLS) return VALOR_ERR_ARG;
     if (dy && (!z || !mean || !rstd)) return VALOR_ERR_ARG;
     if (!dy && !dz_in) return VALOR_ERR_ARG;
     if (row_scale && (rows_per_scale <= 0 || dx == dres)) return VALOR_ERR_ARG;

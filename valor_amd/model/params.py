@@ -119,6 +119,9 @@ def param_table(spec: ValorSpec):
     if spec.video_dim != H:                                    # modeling.py:348-349
         add("hidden_trans_video_multimodal.0.weight", (H, spec.video_dim)); add("hidden_trans_video_multimodal.0.bias", (H,))
         add("hidden_trans_video_multimodal.1.weight", (H,)); add("hidden_trans_video_multimodal.1.bias", (H,))
+    if AW != H and swin:                                       # modeling.py:350-351 (the CLIP variant's key layout has AW == H)
+        add("hidden_trans_audio_multimodal.0.weight", (H, AW)); add("hidden_trans_audio_multimodal.0.bias", (H,))
+        add("hidden_trans_audio_multimodal.1.weight", (H,)); add("hidden_trans_audio_multimodal.1.bias", (H,))
     add("video_frame_embedding", (1, 32, H)); add("video_type_embeddings", (1, 1, H))
     add("audio_frame_embedding", (1, 32, H)); add("audio_type_embeddings", (1, 1, H))
     # ---- BERT multimodal decoder

@@ -580,6 +580,21 @@ class VALOR(nn.Module):
             res.setdefault(tag, []).append(l)
         return res
 
+    # ------------------------------------------------------------------ BASELINE configs[0]
+    def text_mlm(self, batch, compute_loss=True):
+        """Text-only MLM step (the reference's CPU-runnable plumbing case; forward_pt cannot express it):
+        TokenMasker p = 0.15 -> multimodal encoder without cross-attention input, casual=False -> prediction head on the masked
+        rows -> cross-entropy. Same kernels as the decoder passes of forward_pt."""
+        self.stage.begin_step()
+        txt = batch["txt_tokens"]["bert_tokens"].cpu()
+        mlm_in, mlm_lab = self.text_masker(txt, 0.15)
+        out = {}
+        loss = self._decoder_groups(mlm_in, mlm_lab, ["t"], None, False, None, {}, txt.shape[0], compute_loss, "mlm", out)
+        if compute_loss:
+            return {"mlm_loss": loss}
+        out["txt_labels_mlm"] = mlm_lab
+        return out
+
     # ------------------------------------------------------------------ the hot path
     def forward(self, batch, task, compute_loss=True):
         if task.startswith("pt"):
@@ -696,6 +711,11 @@ class VALOR(nn.Module):
                                 P["hidden_trans_video_multimodal.0.bias"])
                 hv = ops.layer_norm(hv, P["hidden_trans_video_multimodal.1.weight"], P["hidden_trans_video_multimodal.1.bias"], 1e-12)
                 video_output = hv.view(*video_output.shape[:3], sp.hidden)
+            if audio_output is not None and "hidden_trans_audio_multimodal.0.weight" in P:       # modeling.py:350-351,497-498
+                ha = ops.linear(audio_output.reshape(-1, sp.aud_width), P["hidden_trans_audio_multimodal.0.weight"],
+                                P["hidden_trans_audio_multimodal.0.bias"])
+                ha = ops.layer_norm(ha, P["hidden_trans_audio_multimodal.1.weight"], P["hidden_trans_audio_multimodal.1.bias"], 1e-12)
+                audio_output = ha.view(*audio_output.shape[:3], sp.hidden)
             if video_output is not None and audio_output is not None:
                 va = ops.cross_input(video_output, audio_output, P["video_frame_embedding"], P["video_type_embeddings"],
                                      P["audio_frame_embedding"], P["audio_type_embeddings"])

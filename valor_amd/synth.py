@@ -110,6 +110,22 @@ def tiny_swin_spec():
                      melbins=32, target_len=64, aud_patch=16, hidden=128, layers=2, inter=256, vocab=1200, max_pos=64)
 
 
+def large_spec():
+    """BASELINE configs[3]: "VALOR-large (VideoSwin-L + BERT-large)". Not a shipped reference config (load_videoswin_model /
+    load_bert_model accept base models only, modeling.py:578-587,618-625): the reference CLASSES with large hyper-parameters
+    (SURVEY 8d config 4): Swin-L embed 192, heads 6/12/24/48, out 1536; BERT-large 1024 / 24 layers / 16 heads / 4096; AST stays
+    768, so both hidden_trans_{video,audio}_multimodal exist (modeling.py:348-351)."""
+    return ValorSpec(video_encoder="swin", txt_encoder="bert", swin_embed=192, swin_heads=(6, 12, 24, 48), hidden=1024, layers=24,
+                     inter=4096)
+
+
+def tiny_large_spec():
+    """the WIDTHS of large_spec() (LayerNorm rows of 3072 in the last PatchMerging, hidden 1024 != audio 768 != video 1536) on a
+    shallow stack: parity tests of the large configuration's code paths that finish in seconds"""
+    return ValorSpec(video_encoder="swin", txt_encoder="bert", resolution=224, swin_embed=192, swin_depths=(1, 1, 2, 1),
+                     swin_heads=(6, 12, 24, 48), hidden=1024, layers=2, inter=4096, aud_layers=1, vocab=4000, max_pos=64)
+
+
 def swin_relative_position_index(window):
     """videoswin.py:112-126: index into the (2wd-1)(2wh-1)(2ww-1) bias table for every token pair of a FULL window;
     with lin(t) = d*(2wh-1)(2ww-1) + h*(2ww-1) + w it is lin(i) - lin(j) + lin(last token)."""
@@ -197,6 +213,9 @@ def state_dict_layout(spec: ValorSpec):
         if spec.video_dim != H:                                                       # modeling.py:348-349
             add("hidden_trans_video_multimodal.0.weight", (H, spec.video_dim)); add("hidden_trans_video_multimodal.0.bias", (H,), "b")
             add("hidden_trans_video_multimodal.1.weight", (H,), "g"); add("hidden_trans_video_multimodal.1.bias", (H,), "b")
+        if AW != H:                                                                   # modeling.py:350-351
+            add("hidden_trans_audio_multimodal.0.weight", (H, AW)); add("hidden_trans_audio_multimodal.0.bias", (H,), "b")
+            add("hidden_trans_audio_multimodal.1.weight", (H,), "g"); add("hidden_trans_audio_multimodal.1.bias", (H,), "b")
         add("contra_head_t.linear.weight", (E, spec.txt_dim)); add("contra_head_v.linear.weight", (E, spec.video_dim))
         add("contra_head_a.linear.weight", (E, AW))
         for m in ("text", "video", "audio"):
