@@ -58,6 +58,9 @@ int valor_gemm_set_variant(int v);
 /* kernel family valor_gemm picks for a problem under the current variant: 0 = register-staged 128x128 (and every fp32
  * problem), 1 / 2 = LDS-DMA 128x128 single / double stage, 3 = 256x256 8-phase */
 int valor_gemm_kernel_for(int dtype, int transA, int transB, int M, int N, int K);
+/* k-slow 8-phase kernels: transposing LDS reads as inline asm (keeps the counted LDS-DMA pipeline from being drained by
+ * compiler-inserted waits); returns the previous value, v < 0 only queries */
+int valor_gemm_set_tr_asm(int v);
 
 /* ---- fused bias + dropout + residual + LayerNorm.  Replaces apex FusedLayerNorm (apex/csrc/layer_norm_cuda_kernel.cu
  * :279-322 forward, :403-634 backward; wrapper apex/apex/normalization/fused_layer_norm.py:14-37) plus the elementwise ops
@@ -116,6 +119,8 @@ int valor_attn_bwd(void* stream, int dtype, const void* q, const void* k, const 
  * it). rel int32 [N]: linearised (d,h,w) of a slot in the FULL window, bias(i,j) = table[rel[i]-rel[j]+relc][head]; table
  * [table_rows][heads]. label uint8 [nW*N] region ids of the shift mask (NULL = unshifted): -100 where labels differ.
  * lse fp32 [B*nW][heads][N]. bf16: N <= 448; fp32 (parity mode): forward N <= 448, backward N <= 192 (the window is LDS resident; VALOR_ERR_ARG beyond). */
+/* kernel family switch for A/B tests (bit 0: LDS-DMA dQ pass); returns the previous value, v < 0 only queries */
+int valor_win_attn_set_variant(int v);
 int valor_win_attn_workspace_floats(int B, int nW, int N, int heads);   /* fp32 elements the backward needs */
 int valor_win_attn_fwd(void* stream, int dtype, const void* qkv, void* o, float* lse, const int* rowmap, const int* rel,
                        const uint8_t* label, const void* table, int B, int nW, int N, int heads, int table_rows, int relc,

@@ -81,6 +81,35 @@ def test_gemm_families(dev, gemm_variant, variant):
     assert _rel(C2, Ab[:, :Kd].double() @ Bt.double()) < 6e-3
 
 
+def test_gemm_8phase_transposing_reads_both_ways(dev, gemm_variant):
+    """k-slow 8-phase kernels with the transposing LDS reads as compiler builtins (0) and as inline asm (1, the default: keeps the
+    counted LDS-DMA pipeline from being drained): same results either way, fused row sums included"""
+    from valor_amd import kernels as K, lib
+    gemm_variant.valor_gemm_set_variant(3)
+    old = gemm_variant.valor_gemm_set_tr_asm(-1)
+    try:
+        outs = []
+        for mode in (0, 1):
+            gemm_variant.valor_gemm_set_tr_asm(mode)
+            res = []
+            for (M, N, Kd), ta, tb in itertools.product([(768, 520, 4096), (304, 1000, 192)], [False, True], [False, True]):
+                A = _mk((Kd, M) if ta else (M, Kd), 1, dev)
+                B = _mk((Kd, N) if tb else (N, Kd), 2, dev)
+                ref = (A.t() if ta else A).double() @ (B if tb else B.t()).double()
+                for sk in (False, True):
+                    C = K.gemm(A, B, trans_a=ta, trans_b=tb, splitk=sk)
+                    assert _rel(C, ref) < 6e-3, (mode, M, N, Kd, ta, tb, sk)
+                    res.append(C)
+            dY, X = _mk((4096, 768), 11, dev), _mk((4096, 768), 12, dev)
+            rs = torch.zeros(768, dtype=torch.bfloat16, device=dev)
+            res.append(K.gemm(dY, X, trans_a=True, trans_b=True, rowsum_out=rs)); res.append(rs)
+            outs.append(res)
+        for a, b in zip(*outs):
+            assert torch.equal(a, b)                    # the same arithmetic in the same order: bit identical
+    finally:
+        gemm_variant.valor_gemm_set_tr_asm(old)
+
+
 def test_gemm_fused_rowsum(dev, gemm_variant):
     """bias gradient beside the wgrad GEMM (valor_gemm's rowsum_out): sum over tokens of dY computed on the matrix pipe in the
     8-phase k-slow kernel, with and without split-K, plain and accumulating, fp32 and bf16 outputs; refused elsewhere."""

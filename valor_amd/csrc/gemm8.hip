@@ -29,6 +29,7 @@
 // Requirements (otherwise valor_gemm uses the 128x128 kernels): K % 64 == 0.  M/N tails are handled by the buffer
 // range check (zero fill) and masked stores.
 #include "gemm_common.h"
+#include <stdlib.h>
 
 #define HT_BYTES 16384
 #define BUF_BYTES (4 * HT_BYTES)
@@ -43,7 +44,29 @@ DEVINL bf16x8_t read_frag_tr8(const char* img, int off, int kk) {
     return __builtin_bit_cast(bf16x8_t, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
 }
 
-template <bool TA, bool TB>
+// The compiler gives the ds_read_b64_tr_b16 BUILTIN no memory operand, so it cannot tell the read from the LDS-DMA writes that are
+// in flight into the other half-tiles and puts `s_waitcnt vmcnt(0)` in front of the first transposing read of every phase: the
+// counted vmcnt(8) pipeline is drained three times per K-tile in the k-slow (wgrad / dgrad) kernels. With ASMTR the transposing
+// reads are inline asm (invisible to the waitcnt pass); their results are 64-bit halves that only become fragments after an explicit
+// `s_waitcnt lgkmcnt(0)` to which they are tied as in/out operands.
+struct TrPair { s16x4_t lo, hi; };
+DEVINL void tr_issue(TrPair& t, const char* a) {
+    const uint32_t addr = (uint32_t)(uintptr_t)LDS_PTR(a);
+    asm volatile("ds_read_b64_tr_b16 %0, %2\n\tds_read_b64_tr_b16 %1, %2 offset:1024" : "=&v"(t.lo), "=&v"(t.hi) : "v"(addr));
+}
+DEVINL bf16x8_t tr_frag(const TrPair& t) {
+    return __builtin_bit_cast(bf16x8_t, __builtin_shufflevector(t.lo, t.hi, 0, 1, 2, 3, 4, 5, 6, 7));
+}
+#define TR_TIE(t) "+v"((t).lo), "+v"((t).hi)
+DEVINL void tr_wait4(TrPair (&t)[2][2]) {
+    asm volatile("s_waitcnt lgkmcnt(0)" : TR_TIE(t[0][0]), TR_TIE(t[0][1]), TR_TIE(t[1][0]), TR_TIE(t[1][1]));
+}
+DEVINL void tr_wait8(TrPair (&t)[4][2]) {
+    asm volatile("s_waitcnt lgkmcnt(0)" : TR_TIE(t[0][0]), TR_TIE(t[0][1]), TR_TIE(t[1][0]), TR_TIE(t[1][1]), TR_TIE(t[2][0]),
+                 TR_TIE(t[2][1]), TR_TIE(t[3][0]), TR_TIE(t[3][1]));
+}
+
+template <bool TA, bool TB, bool ASMTR>
 __global__ __launch_bounds__(512, 2) void gemm_8ph_kernel(GemmArgs p) {
     typedef bf16_t T;
     constexpr int BK = 64;
@@ -153,12 +176,14 @@ __global__ __launch_bounds__(512, 2) void gemm_8ph_kernel(GemmArgs p) {
         for (int i = 0; i < 2; ++i) trB[i] = base + 16 * ((2 * (wn * 2 + i) + ((fr >> 1) & 1) + rot) & 15);
     }
     bf16x8_t fa[4][2], fb0[2][2], fb1[2][2];   // [tile][kk]
+    TrPair pa[4][2], pb[2][2];                 // ASMTR: transposing reads in flight (halves), fragments after FRAG_A / FRAG_B
     auto readA = [&](const char* img) {
 #pragma unroll
         for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
             for (int kk = 0; kk < 2; ++kk) {
-                if constexpr (TA) fa[mt][kk] = read_frag_tr8(img, trA[mt], kk);
+                if constexpr (TA && ASMTR) tr_issue(pa[mt][kk], img + trA[mt] + kk * (32 * 256));
+                else if constexpr (TA) fa[mt][kk] = read_frag_tr8(img, trA[mt], kk);
                 else fa[mt][kk] = read_frag<T>(img, wm * 64 + mt * 16 + fr, kk * 4 + fg);
             }
     };
@@ -167,9 +192,29 @@ __global__ __launch_bounds__(512, 2) void gemm_8ph_kernel(GemmArgs p) {
         for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
             for (int kk = 0; kk < 2; ++kk) {
-                if constexpr (TB) fb[nt][kk] = read_frag_tr8(img, trB[nt], kk);
+                if constexpr (TB && ASMTR) tr_issue(pb[nt][kk], img + trB[nt] + kk * (32 * 256));
+                else if constexpr (TB) fb[nt][kk] = read_frag_tr8(img, trB[nt], kk);
                 else fb[nt][kk] = read_frag<T>(img, wn * 32 + nt * 16 + fr, kk * 4 + fg);
             }
+    };
+    // after LOAD_END: wait for the asm reads and turn the halves into fragments
+    auto fragA = [&]() {
+        if constexpr (TA && ASMTR) {
+            tr_wait8(pa);
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+                for (int kk = 0; kk < 2; ++kk) fa[mt][kk] = tr_frag(pa[mt][kk]);
+        }
+    };
+    auto fragB = [&](bf16x8_t (&fb)[2][2]) {
+        if constexpr (TB && ASMTR) {
+            tr_wait4(pb);
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                for (int kk = 0; kk < 2; ++kk) fb[nt][kk] = tr_frag(pb[nt][kk]);
+        }
     };
 #define QUADRANT(MH_, NH_, FB_)                                                                                   \
     do {                                                                                                          \
@@ -219,6 +264,7 @@ __global__ __launch_bounds__(512, 2) void gemm_8ph_kernel(GemmArgs p) {
             readA(cur + OFF_A0);
             issueB(1, nxt);
             LOAD_END();
+            fragB(fb0); fragA();
             QUADRANT(0, 0, fb0);
             ROWSUM(0);
             MATH_END();
@@ -226,12 +272,14 @@ __global__ __launch_bounds__(512, 2) void gemm_8ph_kernel(GemmArgs p) {
             readB(cur + OFF_B1, fb1);
             issueA(1, nxt);
             LOAD_END();
+            fragB(fb1);
             QUADRANT(0, 1, fb1);
             MATH_END();
             // ---- j2
             readA(cur + OFF_A1);
             issueB(0, cur);
             LOAD_END();
+            fragA();
             QUADRANT(1, 1, fb1);
             ROWSUM(1);
             MATH_END();
@@ -298,6 +346,14 @@ __global__ __launch_bounds__(512, 2) void gemm_8ph_kernel(GemmArgs p) {
     }
 }
 
+// inline-asm transposing reads in the k-slow 8-phase kernels (see ASMTR above); VALOR_GEMM_TR_ASM=0/1 presets it for A/B runs
+static int g_8ph_tr_asm = [] { const char* e = getenv("VALOR_GEMM_TR_ASM"); return e ? atoi(e) : 1; }();
+extern "C" int valor_gemm_set_tr_asm(int v) {
+    const int old = g_8ph_tr_asm;
+    if (v >= 0) g_8ph_tr_asm = v;
+    return old;
+}
+
 void launch_gemm_8ph(hipStream_t st, int transA, int transB, const GemmArgs& p) {
     const int tiles = ((p.M + 255) / 256) * ((p.N + 255) / 256);
     dim3 grid(tiles * (p.kslices > 1 ? p.kslices : 1));
@@ -306,10 +362,12 @@ void launch_gemm_8ph(hipStream_t st, int transA, int transB, const GemmArgs& p) 
     do {                                                                                                        \
         static bool attr_set = false;                                                                           \
         if (!attr_set) {                                                                                        \
-            hipFuncSetAttribute((const void*)gemm_8ph_kernel<TA_, TB_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+            hipFuncSetAttribute((const void*)gemm_8ph_kernel<TA_, TB_, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+            hipFuncSetAttribute((const void*)gemm_8ph_kernel<TA_, TB_, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
             attr_set = true;                                                                                    \
         }                                                                                                       \
-        hipLaunchKernelGGL((gemm_8ph_kernel<TA_, TB_>), grid, dim3(512), lds, st, p);                           \
+        if (g_8ph_tr_asm && (TA_ || TB_)) hipLaunchKernelGGL((gemm_8ph_kernel<TA_, TB_, true>), grid, dim3(512), lds, st, p); \
+        else hipLaunchKernelGGL((gemm_8ph_kernel<TA_, TB_, false>), grid, dim3(512), lds, st, p);             \
     } while (0)
     if (!transA && !transB) VALOR_8PH_LAUNCH(false, false);
     else if (!transA && transB) VALOR_8PH_LAUNCH(false, true);

@@ -24,6 +24,7 @@ SIGNATURES = {
                    _f, _i, _i, _vp, _i64, _vp, _i],
     "valor_gemm_set_variant": [_i],
     "valor_gemm_kernel_for": [_i, _i, _i, _i, _i, _i],
+    "valor_gemm_set_tr_asm": [_i],
     "valor_ln_part_blocks": [],
     "valor_bdrln_fwd": [_vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i, _f, _f, _u64, _u64, _vp, _i64],
     "valor_bdrln_bwd": [_vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i, _f, _u64, _u64, _vp, _i64],
@@ -31,6 +32,7 @@ SIGNATURES = {
     "valor_group_mean_fwd": [_vp, _i, _vp, _vp, _i64, _i, _i],
     "valor_group_mean_bwd": [_vp, _i, _vp, _vp, _i64, _i, _i],
     "valor_win_attn_workspace_floats": [_i, _i, _i, _i],
+    "valor_win_attn_set_variant": [_i],
     "valor_win_attn_fwd": [_vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _f],
     "valor_win_attn_bwd": [_vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _i64, _i, _i, _i, _i, _i, _i, _i, _f],
     "valor_colsum_finalize": [_vp, _i, _vp, _i, _i, _vp, _i, _i],
