@@ -61,11 +61,12 @@ def _ref_window_attention(qkv, table, heads, size, window, shifted):
     (torch.bfloat16, (2, 7, 7), False),                                            # one small window, N = 98 (sliced bias index)
     (torch.float32, (2, 14, 14), True), (torch.float32, (1, 7, 7), False),         # parity-mode instantiation
 ])
-@pytest.mark.parametrize("win_variant", [1, 0])
+@pytest.mark.parametrize("win_variant", [7, 5, 0])
 def test_window_attention(dev, dtype, size, shifted, win_variant):
-    """win_variant 1: LDS-DMA double-buffered dQ pass (bf16 default); 0: the register-staged pass (always used for fp32)"""
+    """kernel family bits: 1 = LDS-DMA double-buffered dQ pass, 2 = LDS-DMA forward, 4 = LDS-DMA dK/dV pass; 0 = the
+    register-staged kernels (always used for fp32)"""
     from valor_amd import lib, ops
-    if dtype == torch.float32 and win_variant == 1:
+    if dtype == torch.float32 and win_variant != 0:
         pytest.skip("the fp32 instantiation has one dQ pass")
     old = lib.load().valor_win_attn_set_variant(win_variant)
     try:

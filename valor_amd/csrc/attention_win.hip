@@ -584,6 +584,241 @@ __global__ __launch_bounds__(512) void win_bwd_dq_dma_kernel(WinArgs p) {
 }
 static int win_lds_dq_dma(int R, int npad) { return ((R + 3) & ~3) * 4 + 2 * npad * 4 + 4 * npad * 64; }
 
+// ------------------------------------------------------------------------------------------ forward / dK,dV, LDS-DMA edition (bf16)
+// Same staging as win_bwd_dq_dma_kernel (unpadded swizzled row images landed by LDS-DMA, gather rows read straight from rowmap,
+// transposed fragments by ds_read_b64_tr_b16 instead of transposed images); one window per workgroup, so one buffer.
+// Two row images `img0` / `img1` of one window from two sources (K | V of the QKV rows, or Q of the QKV rows | dO rows).
+DEVINL void win_dma_stage2(const WinArgs& p, int b, int w, int N, int npad, const bf16_t* src0, int ld0b, int col0b, const bf16_t* src1,
+                           int ld1b, int col1b, char* img0, char* img1, int tid, int wave, int nthreads) {
+    const rsrc_t rs0 = make_rsrc(src0 + (int64_t)b * p.rows_per_sample * (ld0b / 2), (uint32_t)p.rows_per_sample * (uint32_t)ld0b);
+    const rsrc_t rs1 = make_rsrc(src1 + (int64_t)b * p.rows_per_sample * (ld1b / 2), (uint32_t)p.rows_per_sample * (uint32_t)ld1b);
+    const int IMG = npad * 64;
+    for (int k = 0; k * nthreads * 16 < IMG; ++k) {
+        const int idx = tid + nthreads * k, n = idx >> 2;
+        const int base = (wave * 64 + nthreads * k) * 16;           // wave-uniform LDS address; lanes land at + lane * 16
+        if (base < IMG) {
+            const int csrc = ((idx & 3) ^ ((n >> 2) & 3)) << 4;
+            const int row = n < N ? p.rowmap[w * N + n] : -1;
+            glds16(rs0, img0 + base, row >= 0 ? row * ld0b + col0b + csrc : 0x7fffff00);
+            glds16(rs1, img1 + base, row >= 0 ? row * ld1b + col1b + csrc : 0x7fffff00);
+        }
+    }
+}
+
+// grid (heads, B*nW), 512 threads, 2 workgroups per CU. LDS: table column, rel, K and V row images.
+template <bool SHIFT>
+__global__ __launch_bounds__(512) void win_fwd_dma_kernel(WinArgs p) {
+    typedef bf16_t T;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), fr = lane & 15, g = lane >> 4;
+    const int h = blockIdx.x, gw = blockIdx.y, b = gw / p.nW, w = gw % p.nW;
+    const int N = p.N, npad = (N + 63) & ~63, Rp = (p.R + 3) & ~3, IMG = npad * 64;
+    float* tb = (float*)smem;
+    int* rel = (int*)(smem + Rp * 4);
+    char* sK = (char*)(rel + npad);
+    char* sV = sK + IMG;
+    const T* qkv = (const T*)p.qkv;
+    const int64_t ld = 3 * (int64_t)p.C;
+    const int ldb = 3 * p.C * 2;
+    win_dma_stage2(p, b, w, N, npad, qkv, ldb, (p.C + h * WIN_D) * 2, qkv, ldb, (2 * p.C + h * WIN_D) * 2, sK, sV, tid, wave, 512);
+    win_fill_table<T>(p, tb, h, tid, 512);
+    if (tid < npad) rel[tid] = tid < N ? (p.rel[tid] | (p.label ? (int)p.label[w * N + tid] << 16 : 0)) : 0;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    const int tro0 = win_tr_off(lane, 0), tro1 = win_tr_off(lane, 1);
+    const float scale2 = p.scale * LOG2E_F;
+
+    for (int qt = wave; qt * 16 < N; qt += 8) {
+        const int qr = qt * 16 + fr;
+        const bool qok = qr < N;
+        const int qrow = qok ? b * p.rows_per_sample + p.rowmap[w * N + qr] : 0;
+        const bf16x8_t qf = win_load_frag<T>(qkv + (int64_t)qrow * ld + h * WIN_D, 0, g, qok);
+        const int relq = rel[qr] + p.relc;
+        float m = -1e30f, l = 0.f;
+        f32x4_t oacc[2] = {(f32x4_t){0.f, 0.f, 0.f, 0.f}, (f32x4_t){0.f, 0.f, 0.f, 0.f}};
+        auto chunk = [&](const int k0, auto tail) {
+            constexpr bool TAIL = decltype(tail)::value;
+            WinTr vtr[2][2];                                    // V^T fragments [kk][dt] of this chunk fly under the softmax math
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) {
+                win_tr_issue(vtr[kk][0], sV + (k0 + 32 * kk) * 64 + tro0);
+                win_tr_issue(vtr[kk][1], sV + (k0 + 32 * kk) * 64 + tro1);
+            }
+            f32x4_t sacc[4];
+#pragma unroll
+            for (int kt = 0; kt < 4; ++kt) {
+                const f32x4_t z = {0.f, 0.f, 0.f, 0.f};
+                sacc[kt] = Mma<T>::mma(win_frag_sw(sK, k0 + kt * 16 + fr, g), qf, z);
+            }
+            float mx = -INFINITY;
+#pragma unroll
+            for (int kt = 0; kt < 4; ++kt) {
+                const int kb = k0 + kt * 16 + 4 * g;
+                const i32x4_t rk = *(const i32x4_t*)&rel[kb];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int X = relq - rk[r];
+                    float v = sacc[kt][r] * scale2 + tb[SHIFT ? (X & 0xffff) : X];
+                    if (SHIFT) v = (uint32_t)X > 0xffffu ? v - WIN_MASK2 : v;
+                    if (TAIL) v = kb + r < N ? v : -INFINITY;
+                    sacc[kt][r] = v;
+                    mx = fmaxf(mx, v);
+                }
+            }
+            mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+            const float mnew = fmaxf(m, mx);
+            const float alpha = fexp2<T>(m - mnew);
+            m = mnew;
+            float ps = 0.f;
+#pragma unroll
+            for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float e = fexp2<T>(sacc[kt][r] - mnew);
+                    sacc[kt][r] = e;
+                    ps += e;
+                }
+            ps += __shfl_xor(ps, 16, 64);
+            ps += __shfl_xor(ps, 32, 64);
+            l = l * alpha + ps;
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) oacc[dt][r] *= alpha;
+            win_tr_wait(vtr);
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) {
+                const bf16x8_t pf = pack_bf16x8(sacc[2 * kk], sacc[2 * kk + 1]);
+                oacc[0] = Mma<T>::mma(win_tr_frag(vtr[kk][0]), pf, oacc[0]);
+                oacc[1] = Mma<T>::mma(win_tr_frag(vtr[kk][1]), pf, oacc[1]);
+            }
+        };
+        for (int k0 = 0; k0 < npad; k0 += 64) {
+            if (k0 + 64 <= N) chunk(k0, std::false_type{});
+            else chunk(k0, std::true_type{});
+        }
+        if (qok) {
+            const float inv = 1.0f / l;
+            T* orow = (T*)p.o + (int64_t)qrow * p.C + h * WIN_D;
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt) {
+                f32x4_t v = oacc[dt];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] *= inv;
+                win_store4<T>(orow, dt, g, v);
+            }
+            if (g == 0) p.lse[((int64_t)gw * p.heads + h) * N + qr] = (m + log2f(l)) * LN2_F;
+        }
+    }
+}
+static int win_lds_fwd_dma(int R, int npad) { return ((R + 3) & ~3) * 4 + npad * 4 + 2 * npad * 64; }
+
+// grid (heads, B*nW), 512 threads, 2 workgroups per CU. LDS: table column, rel, lse, delta, Q and dO row images.
+template <bool SHIFT>
+__global__ __launch_bounds__(512) void win_bwd_dkv_dma_kernel(WinArgs p) {
+    typedef bf16_t T;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), fr = lane & 15, g = lane >> 4;
+    const int h = blockIdx.x, gw = blockIdx.y, b = gw / p.nW, w = gw % p.nW;
+    const int N = p.N, npad = (N + 63) & ~63, Rp = (p.R + 3) & ~3, IMG = npad * 64;
+    float* tb = (float*)smem;
+    int* rel = (int*)(smem + Rp * 4);
+    float* s_lse = (float*)(rel + npad);
+    float* s_dl = s_lse + npad;
+    char* sQ = (char*)(s_dl + npad);
+    char* sdO = sQ + IMG;
+    const T* qkv = (const T*)p.qkv;
+    const int64_t ld = 3 * (int64_t)p.C;
+    win_dma_stage2(p, b, w, N, npad, qkv, 3 * p.C * 2, h * WIN_D * 2, (const T*)p.dout, p.C * 2, h * WIN_D * 2, sQ, sdO, tid, wave, 512);
+    win_fill_table<T>(p, tb, h, tid, 512);
+    if (tid < npad) {
+        const int64_t stat = ((int64_t)gw * p.heads + h) * N + tid;
+        rel[tid] = tid < N ? (p.rel[tid] | (p.label ? (int)p.label[w * N + tid] << 16 : 0)) : 0;
+        s_lse[tid] = tid < N ? p.lse[stat] * LOG2E_F : INFINITY;       // log2 domain; slots past the window: p = 2^(s - inf) = 0
+        s_dl[tid] = tid < N ? p.delta[stat] : 0.f;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    const int tro0 = win_tr_off(lane, 0), tro1 = win_tr_off(lane, 1);
+    const float scale2 = p.scale * LOG2E_F;
+
+    for (int kt = wave; kt * 16 < N; kt += 8) {
+        const int kr = kt * 16 + fr;
+        const bool kok = kr < N;
+        const int krow = kok ? b * p.rows_per_sample + p.rowmap[w * N + kr] : 0;
+        const bf16x8_t kf = win_load_frag<T>(qkv + (int64_t)krow * ld + p.C + h * WIN_D, 0, g, kok);
+        const bf16x8_t vf = win_load_frag<T>(qkv + (int64_t)krow * ld + 2 * p.C + h * WIN_D, 0, g, kok);
+        const int kneg = p.relc - rel[kr];           // X = relx[q] + relc - relx[key]
+        f32x4_t dkacc[2] = {(f32x4_t){0.f, 0.f, 0.f, 0.f}, (f32x4_t){0.f, 0.f, 0.f, 0.f}};
+        f32x4_t dvacc[2] = {(f32x4_t){0.f, 0.f, 0.f, 0.f}, (f32x4_t){0.f, 0.f, 0.f, 0.f}};
+        for (int q0 = 0; q0 < npad; q0 += 64) {
+            WinTr dtr[2][2];                                    // dO^T fragments [kk][dt] fly under the score math
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) {
+                win_tr_issue(dtr[kk][0], sdO + (q0 + 32 * kk) * 64 + tro0);
+                win_tr_issue(dtr[kk][1], sdO + (q0 + 32 * kk) * 64 + tro1);
+            }
+            // sacc[t][r] = S[q = q0 + 16t + 4g + r][key = fr] ; dpacc likewise
+            f32x4_t sacc[4], dpacc[4];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const f32x4_t z = {0.f, 0.f, 0.f, 0.f};
+                sacc[t] = Mma<T>::mma(win_frag_sw(sQ, q0 + t * 16 + fr, g), kf, z);
+                dpacc[t] = Mma<T>::mma(win_frag_sw(sdO, q0 + t * 16 + fr, g), vf, z);
+            }
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const int qb = q0 + t * 16 + 4 * g;
+                const i32x4_t rq = *(const i32x4_t*)&rel[qb];
+                const f32x4_t ls = *(const f32x4_t*)&s_lse[qb];
+                const f32x4_t dl = *(const f32x4_t*)&s_dl[qb];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int X = rq[r] + kneg;
+                    float v = sacc[t][r] * scale2 + tb[SHIFT ? (X & 0xffff) : X];
+                    if (SHIFT) v = (uint32_t)X > 0xffffu ? v - WIN_MASK2 : v;
+                    const float pr = fexp2<T>(v - ls[r]);
+                    sacc[t][r] = pr;
+                    dpacc[t][r] = pr * (dpacc[t][r] - dl[r]);
+                }
+            }
+            win_tr_wait(dtr);
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) {
+                const bf16x8_t pf = pack_bf16x8(sacc[2 * kk], sacc[2 * kk + 1]);
+                dvacc[0] = Mma<T>::mma(win_tr_frag(dtr[kk][0]), pf, dvacc[0]);
+                dvacc[1] = Mma<T>::mma(win_tr_frag(dtr[kk][1]), pf, dvacc[1]);
+            }
+            WinTr qtr[2][2];                                    // Q^T fragments for dK
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) {
+                win_tr_issue(qtr[kk][0], sQ + (q0 + 32 * kk) * 64 + tro0);
+                win_tr_issue(qtr[kk][1], sQ + (q0 + 32 * kk) * 64 + tro1);
+            }
+            win_tr_wait(qtr);
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) {
+                const bf16x8_t df = pack_bf16x8(dpacc[2 * kk], dpacc[2 * kk + 1]);
+                dkacc[0] = Mma<T>::mma(win_tr_frag(qtr[kk][0]), df, dkacc[0]);
+                dkacc[1] = Mma<T>::mma(win_tr_frag(qtr[kk][1]), df, dkacc[1]);
+            }
+        }
+        if (kok) {
+            T* drow = (T*)p.dqkv + (int64_t)krow * ld + h * WIN_D;
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt) {
+                f32x4_t v = dkacc[dt];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] *= p.scale;
+                win_store4<T>(drow + p.C, dt, g, v);
+                win_store4<T>(drow + 2 * p.C, dt, g, dvacc[dt]);
+            }
+        }
+    }
+}
+static int win_lds_dkv_dma(int R, int npad) { return ((R + 3) & ~3) * 4 + 3 * npad * 4 + 2 * npad * 64; }
+
 // ------------------------------------------------------------------------------------------ backward 2: dK, dV
 // grid (heads, B*nW), 1024 threads (one workgroup per CU: 16 waves share the four images). LDS: Q, dO row images, Q^T, dO^T images, lse / delta of the window.
 template <typename T, bool SHIFT>
@@ -735,10 +970,30 @@ static bool win_check(const WinArgs& p) {
            (int64_t)p.B * p.nW <= 65535;
 }
 
+// kernel family bits (bf16 only; fp32 always runs the register-staged kernels): 1 = LDS-DMA dQ pass (8-12 % faster backward),
+// 2 = LDS-DMA forward (measured equal to the register-staged forward: off), 4 = LDS-DMA dK/dV pass (a further 7-9 %). Default 5.
+static int g_win_variant = [] { const char* e = getenv("VALOR_WIN_VARIANT"); return e ? atoi(e) : 5; }();
+extern "C" int valor_win_attn_set_variant(int v) {
+    const int old = g_win_variant;
+    if (v >= 0) g_win_variant = v;
+    return old;
+}
+
 template <typename T>
 static int win_fwd_launch(hipStream_t st, const WinArgs& p) {
     const int npad = (p.N + 63) & ~63, lds = win_lds_fwd<T>(p.R, npad);
     if (lds > WIN_LDS_MAX) return VALOR_ERR_ARG;
+    if ((g_win_variant & 2) && ElemTraits<T>::DT == VALOR_DT_BF16 && (int64_t)p.rows_per_sample * 3 * p.C * 2 < 0x7fff0000ll) {
+        const int ld2 = win_lds_fwd_dma(p.R, npad);
+        if (p.label) {
+            hipFuncSetAttribute((const void*)win_fwd_dma_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, ld2);
+            hipLaunchKernelGGL((win_fwd_dma_kernel<true>), dim3(p.heads, p.B * p.nW), dim3(512), ld2, st, p);
+        } else {
+            hipFuncSetAttribute((const void*)win_fwd_dma_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, ld2);
+            hipLaunchKernelGGL((win_fwd_dma_kernel<false>), dim3(p.heads, p.B * p.nW), dim3(512), ld2, st, p);
+        }
+        return hipGetLastError() == hipSuccess ? VALOR_OK : VALOR_ERR_LAUNCH;
+    }
     if (p.label) {
         hipFuncSetAttribute((const void*)win_fwd_kernel<T, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         hipLaunchKernelGGL((win_fwd_kernel<T, true>), dim3(p.heads, p.B * p.nW), dim3(512), lds, st, p);
@@ -748,19 +1003,12 @@ static int win_fwd_launch(hipStream_t st, const WinArgs& p) {
     }
     return hipGetLastError() == hipSuccess ? VALOR_OK : VALOR_ERR_LAUNCH;
 }
-// bit 0: LDS-DMA dQ pass (bf16; default on: 8-12 % faster backward than the register-staged pass, which stays the fp32 path)
-static int g_win_variant = [] { const char* e = getenv("VALOR_WIN_VARIANT"); return e ? atoi(e) : 1; }();
-extern "C" int valor_win_attn_set_variant(int v) {
-    const int old = g_win_variant;
-    if (v >= 0) g_win_variant = v;
-    return old;
-}
-
 template <typename T>
 static int win_bwd_launch(hipStream_t st, const WinArgs& p, void* dtable, int accumulate, int G) {
     const int npad = (p.N + 63) & ~63, l1 = win_lds_dq<T>(p.R, npad), l2 = win_lds_dkv<T>(p.R, npad);
     if (l1 > WIN_LDS_MAX || l2 > WIN_LDS_MAX || npad > 64 * WIN_MAXCH) return VALOR_ERR_ARG;
-    const int l1d = win_lds_dq_dma(p.R, npad);
+    const int l1d = win_lds_dq_dma(p.R, npad), l2d = win_lds_dkv_dma(p.R, npad);
+    const bool dkv_dma = (g_win_variant & 4) && ElemTraits<T>::DT == VALOR_DT_BF16 && (int64_t)p.rows_per_sample * 3 * p.C * 2 < 0x7fff0000ll;
     const bool dma = (g_win_variant & 1) && ElemTraits<T>::DT == VALOR_DT_BF16 && l1d <= WIN_LDS_MAX &&
                      (int64_t)p.rows_per_sample * 3 * p.C * 2 < 0x7fff0000ll;
     if (dma) {
@@ -776,12 +1024,18 @@ static int win_bwd_launch(hipStream_t st, const WinArgs& p, void* dtable, int ac
         hipFuncSetAttribute((const void*)win_bwd_dq_kernel<T, true>, hipFuncAttributeMaxDynamicSharedMemorySize, l1);
         hipFuncSetAttribute((const void*)win_bwd_dkv_kernel<T, true>, hipFuncAttributeMaxDynamicSharedMemorySize, l2);
         if (!dma) hipLaunchKernelGGL((win_bwd_dq_kernel<T, true>), dim3(p.heads, 4, G), dim3(512), l1, st, p);
-        hipLaunchKernelGGL((win_bwd_dkv_kernel<T, true>), dim3(p.heads, p.B * p.nW), dim3(1024), l2, st, p);
+        if (dkv_dma) {
+            hipFuncSetAttribute((const void*)win_bwd_dkv_dma_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, l2d);
+            hipLaunchKernelGGL((win_bwd_dkv_dma_kernel<true>), dim3(p.heads, p.B * p.nW), dim3(512), l2d, st, p);
+        } else hipLaunchKernelGGL((win_bwd_dkv_kernel<T, true>), dim3(p.heads, p.B * p.nW), dim3(1024), l2, st, p);
     } else {
         hipFuncSetAttribute((const void*)win_bwd_dq_kernel<T, false>, hipFuncAttributeMaxDynamicSharedMemorySize, l1);
         hipFuncSetAttribute((const void*)win_bwd_dkv_kernel<T, false>, hipFuncAttributeMaxDynamicSharedMemorySize, l2);
         if (!dma) hipLaunchKernelGGL((win_bwd_dq_kernel<T, false>), dim3(p.heads, 4, G), dim3(512), l1, st, p);
-        hipLaunchKernelGGL((win_bwd_dkv_kernel<T, false>), dim3(p.heads, p.B * p.nW), dim3(1024), l2, st, p);
+        if (dkv_dma) {
+            hipFuncSetAttribute((const void*)win_bwd_dkv_dma_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, l2d);
+            hipLaunchKernelGGL((win_bwd_dkv_dma_kernel<false>), dim3(p.heads, p.B * p.nW), dim3(512), l2d, st, p);
+        } else hipLaunchKernelGGL((win_bwd_dkv_kernel<T, false>), dim3(p.heads, p.B * p.nW), dim3(1024), l2, st, p);
     }
     const int64_t n4 = (int64_t)p.heads * p.N * npad / 4;
     if (G > 1) hipLaunchKernelGGL(win_dbias_reduce_kernel, dim3((unsigned)((n4 + 255) / 256 > 4096 ? 4096 : (n4 + 255) / 256)), dim3(256), 0, st, p.dbias_part, G, n4);
