@@ -61,6 +61,9 @@ int valor_gemm_kernel_for(int dtype, int transA, int transB, int M, int N, int K
 /* k-slow 8-phase kernels: transposing LDS reads as inline asm (keeps the counted LDS-DMA pipeline from being drained by
  * compiler-inserted waits); returns the previous value, v < 0 only queries */
 int valor_gemm_set_tr_asm(int v);
+/* 8-phase kernels: one-pass bf16 epilogue for plain problems (bf16 C, no split-K / accumulate / pre-activation / dact, N % 8 == 0,
+ * ldc % 8 == 0); returns the previous value, v < 0 only queries */
+int valor_gemm_set_fast_epilogue(int v);
 
 /* ---- fused bias + dropout + residual + LayerNorm.  Replaces apex FusedLayerNorm (apex/csrc/layer_norm_cuda_kernel.cu
  * :279-322 forward, :403-634 backward; wrapper apex/apex/normalization/fused_layer_norm.py:14-37) plus the elementwise ops

@@ -110,6 +110,37 @@ def test_gemm_8phase_transposing_reads_both_ways(dev, gemm_variant):
         gemm_variant.valor_gemm_set_tr_asm(old)
 
 
+def test_gemm_8phase_fast_epilogue(dev, gemm_variant):
+    """one-pass bf16 epilogue of plain 8-phase problems (bias / activation in registers) against the general two-pass epilogue
+    and fp64 math: every layout, row tails, bias + GELU, alpha; problems it does not cover fall back untouched"""
+    from valor_amd import kernels as K, lib
+    gemm_variant.valor_gemm_set_variant(3)
+    old = gemm_variant.valor_gemm_set_fast_epilogue(-1)
+    try:
+        for (M, N, Kd), ta, tb in itertools.product([(1000, 520, 256), (512, 768, 4096), (304, 264, 192)], [False, True], [False, True]):
+            A = _mk((Kd, M) if ta else (M, Kd), 1, dev)
+            B = _mk((Kd, N) if tb else (N, Kd), 2, dev)
+            bias = _mk((N,), 3, dev)
+            ref = 0.5 * ((A.t() if ta else A).double() @ (B if tb else B.t()).double()) + bias.double()
+            outs = []
+            for mode in (0, 1):
+                gemm_variant.valor_gemm_set_fast_epilogue(mode)
+                outs.append(K.gemm(A, B, trans_a=ta, trans_b=tb, bias=bias, alpha=0.5, splitk=False))
+                assert _rel(outs[-1], ref) < 6e-3, (mode, M, N, Kd, ta, tb)
+            assert _rel(outs[1], outs[0]) < 1e-3
+        gemm_variant.valor_gemm_set_fast_epilogue(1)
+        X, W, b = _mk((512, 256), 6, dev), _mk((768, 256), 7, dev), _mk((768,), 8, dev)
+        y = K.gemm(X, W, bias=b, act=lib.ACT_GELU_ERF, splitk=False)
+        assert _rel(y, torch.nn.functional.gelu(X.double() @ W.double().t() + b.double())) < 6e-3
+        out, pre = K.gemm(X, W, bias=b, act=lib.ACT_GELU_ERF, want_preact=True, splitk=False)        # not plain: general path
+        assert _rel(pre, X.double() @ W.double().t() + b.double()) < 6e-3
+        Cacc = torch.ones((512, 768), dtype=torch.bfloat16, device=dev)
+        K.gemm(X, W, out=Cacc, accumulate=True, splitk=False)
+        assert _rel(Cacc, 1.0 + X.double() @ W.double().t()) < 6e-3
+    finally:
+        gemm_variant.valor_gemm_set_fast_epilogue(old)
+
+
 def test_gemm_fused_rowsum(dev, gemm_variant):
     """bias gradient beside the wgrad GEMM (valor_gemm's rowsum_out): sum over tokens of dY computed on the matrix pipe in the
     8-phase k-slow kernel, with and without split-K, plain and accumulating, fp32 and bf16 outputs; refused elsewhere."""

@@ -308,7 +308,42 @@ __global__ __launch_bounds__(512, 2) void gemm_8ph_kernel(GemmArgs p) {
         }
     }
 
-    // ---- epilogue: two passes (tile row halves mh) through LDS: 128 rows x 256 cols fp32 (swizzled 16-B chunks) ->
+    // ---- fast epilogue of a "plain" problem (host-checked, see GemmArgs::fast_epi): alpha / bias / activation on the accumulators in
+    // registers, the whole 256 x 256 tile as bf16 (128 KiB) through LDS in ONE pass -- half the LDS traffic and one barrier less than
+    // the general two-pass fp32 epilogue below. Image: [256 rows][512 B], 16-B chunk c of row r at position c ^ (r & 31): the 16
+    // lanes of a fragment column group write 16 distinct chunks, the row-contiguous reads are permutations inside a row.
+    if (p.fast_epi) {
+        char* sB = smem;
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) {
+            const int col = (ni >> 1) * 128 + wn * 32 + (ni & 1) * 16 + 4 * fg;
+            const f32x4_t bias4 = load_bias4<T>(p, n0 + col);
+#pragma unroll
+            for (int mi = 0; mi < 8; ++mi) {
+                const int row = (mi >> 2) * 128 + wm * 64 + (mi & 3) * 16 + fr;
+                f32x4_t v = acc[mi][ni];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = v[r] * p.alpha + bias4[r];
+                if (p.act != VALOR_ACT_NONE) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] = act_fwd(p.act, v[r]);
+                }
+                const u32x2_t w = {pack2_bf16(v[0], v[1]), pack2_bf16(v[2], v[3])};
+                *(u32x2_t*)(sB + row * 512 + (((col >> 3) ^ (row & 31)) << 4) + (fg & 1) * 8) = w;
+            }
+        }
+        __syncthreads();
+#pragma unroll 4
+        for (int it = 0; it < 16; ++it) {
+            const int ml = it * 16 + (tid >> 5), c = tid & 31;
+            const u32x4_t val = *(const u32x4_t*)(sB + ml * 512 + ((c ^ (ml & 31)) << 4));
+            const int m = m0 + ml, n = n0 + c * 8;
+            if (m < p.M && n < p.N) *(u32x4_t*)((T*)p.C + (int64_t)m * p.ldc + n) = val;
+        }
+        return;
+    }
+
+    // ---- general epilogue: two passes (tile row halves mh) through LDS: 128 rows x 256 cols fp32 (swizzled 16-B chunks) ->
     // row-contiguous 16-byte bf16 stores.
     // acc[mh*4+mt][nh*2+nt][r] = C[mh*128 + wm*64 + mt*16 + fr][nh*128 + wn*32 + nt*16 + 4*fg + r]
     float* sC = (float*)smem;
@@ -354,7 +389,18 @@ extern "C" int valor_gemm_set_tr_asm(int v) {
     return old;
 }
 
-void launch_gemm_8ph(hipStream_t st, int transA, int transB, const GemmArgs& p) {
+// one-pass bf16 epilogue for plain problems; VALOR_GEMM_FAST_EPI=0/1 presets it
+static int g_8ph_fast_epi = [] { const char* e = getenv("VALOR_GEMM_FAST_EPI"); return e ? atoi(e) : 0; }();
+extern "C" int valor_gemm_set_fast_epilogue(int v) {
+    const int old = g_8ph_fast_epi;
+    if (v >= 0) g_8ph_fast_epi = v;
+    return old;
+}
+
+void launch_gemm_8ph(hipStream_t st, int transA, int transB, const GemmArgs& p_in) {
+    GemmArgs p = p_in;
+    p.fast_epi = g_8ph_fast_epi && !p.out_f32 && !p.preact && !p.dact_aux && !p.accumulate && p.kslices <= 1 && (p.N & 7) == 0 &&
+                 (p.ldc & 7) == 0 && !p.rowsum_out;
     const int tiles = ((p.M + 255) / 256) * ((p.N + 255) / 256);
     dim3 grid(tiles * (p.kslices > 1 ? p.kslices : 1));
     const size_t lds = 2 * BUF_BYTES;
