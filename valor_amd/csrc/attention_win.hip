@@ -401,22 +401,8 @@ DEVINL int win_tr_off(int lane, int dt) {
     const int g = lane >> 4, i = lane & 15;
     return (4 * g + (i >> 2)) * 64 + ((((2 * dt) | ((i >> 1) & 1)) ^ g) << 4) + 8 * (i & 1);
 }
-// The transposing reads are inline asm: the compiler gives the ds_read_b64_tr_b16 builtin no memory operand and would put
-// `s_waitcnt vmcnt(0)` in front of every one of them while the next window's LDS-DMA is in flight (draining it). The 64-bit halves
-// become a fragment only after an explicit lgkmcnt wait they are tied to.
-struct WinTr { s16x4_t lo, hi; };
-DEVINL void win_tr_issue(WinTr& t, const char* a) {
-    const uint32_t addr = (uint32_t)(uintptr_t)LDS_PTR(a);
-    asm volatile("ds_read_b64_tr_b16 %0, %2\n\tds_read_b64_tr_b16 %1, %2 offset:1024" : "=&v"(t.lo), "=&v"(t.hi) : "v"(addr));
-}
-DEVINL void win_tr_wait(WinTr (&t)[2][2]) {
-    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(t[0][0].lo), "+v"(t[0][0].hi), "+v"(t[0][1].lo), "+v"(t[0][1].hi), "+v"(t[1][0].lo),
-                 "+v"(t[1][0].hi), "+v"(t[1][1].lo), "+v"(t[1][1].hi));
-}
-DEVINL bf16x8_t win_tr_frag(const WinTr& t) {
-    return __builtin_bit_cast(bf16x8_t, __builtin_shufflevector(t.lo, t.hi, 0, 1, 2, 3, 4, 5, 6, 7));
-}
-
+// The transposing reads are inline asm (mma.h: tr_issue / tr_wait4 / tr_frag): as compiler builtins they would drain the next
+// window's LDS-DMA at every chunk.
 template <bool SHIFT>
 __global__ __launch_bounds__(512) void win_bwd_dq_dma_kernel(WinArgs p) {
     typedef bf16_t T;
@@ -531,11 +517,11 @@ __global__ __launch_bounds__(512) void win_bwd_dq_dma_kernel(WinArgs p) {
                     sacc[kt] = Mma<T>::mma(win_frag_sw(sK, k0 + kt * 16 + fr, g), qf, z);
                     dpacc[kt] = Mma<T>::mma(win_frag_sw(sV, k0 + kt * 16 + fr, g), dof, z);
                 }
-                WinTr ktr[2][2];                               // K^T fragments [kk][dt] for the dQ contraction fly under the score math
+                TrPair ktr[2][2];                               // K^T fragments [kk][dt] for the dQ contraction fly under the score math
 #pragma unroll
                 for (int kk = 0; kk < 2; ++kk) {
-                    win_tr_issue(ktr[kk][0], sK + (k0 + 32 * kk) * 64 + tro0);
-                    win_tr_issue(ktr[kk][1], sK + (k0 + 32 * kk) * 64 + tro1);
+                    tr_issue(ktr[kk][0], sK + (k0 + 32 * kk) * 64 + tro0);
+                    tr_issue(ktr[kk][1], sK + (k0 + 32 * kk) * 64 + tro1);
                 }
 #pragma unroll
                 for (int kt = 0; kt < 4; ++kt) {
@@ -552,12 +538,12 @@ __global__ __launch_bounds__(512) void win_bwd_dq_dma_kernel(WinArgs p) {
                         bacc[c][kt][r] += ds;
                     }
                 }
-                win_tr_wait(ktr);
+                tr_wait4(ktr);
 #pragma unroll
                 for (int kk = 0; kk < 2; ++kk) {
                     const bf16x8_t pf = pack_bf16x8(sacc[2 * kk], sacc[2 * kk + 1]);
-                    dqacc[0] = Mma<T>::mma(win_tr_frag(ktr[kk][0]), pf, dqacc[0]);
-                    dqacc[1] = Mma<T>::mma(win_tr_frag(ktr[kk][1]), pf, dqacc[1]);
+                    dqacc[0] = Mma<T>::mma(tr_frag(ktr[kk][0]), pf, dqacc[0]);
+                    dqacc[1] = Mma<T>::mma(tr_frag(ktr[kk][1]), pf, dqacc[1]);
                 }
             }
         }
@@ -638,11 +624,11 @@ __global__ __launch_bounds__(512) void win_fwd_dma_kernel(WinArgs p) {
         f32x4_t oacc[2] = {(f32x4_t){0.f, 0.f, 0.f, 0.f}, (f32x4_t){0.f, 0.f, 0.f, 0.f}};
         auto chunk = [&](const int k0, auto tail) {
             constexpr bool TAIL = decltype(tail)::value;
-            WinTr vtr[2][2];                                    // V^T fragments [kk][dt] of this chunk fly under the softmax math
+            TrPair vtr[2][2];                                    // V^T fragments [kk][dt] of this chunk fly under the softmax math
 #pragma unroll
             for (int kk = 0; kk < 2; ++kk) {
-                win_tr_issue(vtr[kk][0], sV + (k0 + 32 * kk) * 64 + tro0);
-                win_tr_issue(vtr[kk][1], sV + (k0 + 32 * kk) * 64 + tro1);
+                tr_issue(vtr[kk][0], sV + (k0 + 32 * kk) * 64 + tro0);
+                tr_issue(vtr[kk][1], sV + (k0 + 32 * kk) * 64 + tro1);
             }
             f32x4_t sacc[4];
 #pragma unroll
@@ -686,12 +672,12 @@ __global__ __launch_bounds__(512) void win_fwd_dma_kernel(WinArgs p) {
             for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) oacc[dt][r] *= alpha;
-            win_tr_wait(vtr);
+            tr_wait4(vtr);
 #pragma unroll
             for (int kk = 0; kk < 2; ++kk) {
                 const bf16x8_t pf = pack_bf16x8(sacc[2 * kk], sacc[2 * kk + 1]);
-                oacc[0] = Mma<T>::mma(win_tr_frag(vtr[kk][0]), pf, oacc[0]);
-                oacc[1] = Mma<T>::mma(win_tr_frag(vtr[kk][1]), pf, oacc[1]);
+                oacc[0] = Mma<T>::mma(tr_frag(vtr[kk][0]), pf, oacc[0]);
+                oacc[1] = Mma<T>::mma(tr_frag(vtr[kk][1]), pf, oacc[1]);
             }
         };
         for (int k0 = 0; k0 < npad; k0 += 64) {
@@ -753,11 +739,11 @@ __global__ __launch_bounds__(512) void win_bwd_dkv_dma_kernel(WinArgs p) {
         f32x4_t dkacc[2] = {(f32x4_t){0.f, 0.f, 0.f, 0.f}, (f32x4_t){0.f, 0.f, 0.f, 0.f}};
         f32x4_t dvacc[2] = {(f32x4_t){0.f, 0.f, 0.f, 0.f}, (f32x4_t){0.f, 0.f, 0.f, 0.f}};
         for (int q0 = 0; q0 < npad; q0 += 64) {
-            WinTr dtr[2][2];                                    // dO^T fragments [kk][dt] fly under the score math
+            TrPair dtr[2][2];                                    // dO^T fragments [kk][dt] fly under the score math
 #pragma unroll
             for (int kk = 0; kk < 2; ++kk) {
-                win_tr_issue(dtr[kk][0], sdO + (q0 + 32 * kk) * 64 + tro0);
-                win_tr_issue(dtr[kk][1], sdO + (q0 + 32 * kk) * 64 + tro1);
+                tr_issue(dtr[kk][0], sdO + (q0 + 32 * kk) * 64 + tro0);
+                tr_issue(dtr[kk][1], sdO + (q0 + 32 * kk) * 64 + tro1);
             }
             // sacc[t][r] = S[q = q0 + 16t + 4g + r][key = fr] ; dpacc likewise
             f32x4_t sacc[4], dpacc[4];
@@ -783,25 +769,25 @@ __global__ __launch_bounds__(512) void win_bwd_dkv_dma_kernel(WinArgs p) {
                     dpacc[t][r] = pr * (dpacc[t][r] - dl[r]);
                 }
             }
-            win_tr_wait(dtr);
+            tr_wait4(dtr);
 #pragma unroll
             for (int kk = 0; kk < 2; ++kk) {
                 const bf16x8_t pf = pack_bf16x8(sacc[2 * kk], sacc[2 * kk + 1]);
-                dvacc[0] = Mma<T>::mma(win_tr_frag(dtr[kk][0]), pf, dvacc[0]);
-                dvacc[1] = Mma<T>::mma(win_tr_frag(dtr[kk][1]), pf, dvacc[1]);
+                dvacc[0] = Mma<T>::mma(tr_frag(dtr[kk][0]), pf, dvacc[0]);
+                dvacc[1] = Mma<T>::mma(tr_frag(dtr[kk][1]), pf, dvacc[1]);
             }
-            WinTr qtr[2][2];                                    // Q^T fragments for dK
+            TrPair qtr[2][2];                                    // Q^T fragments for dK
 #pragma unroll
             for (int kk = 0; kk < 2; ++kk) {
-                win_tr_issue(qtr[kk][0], sQ + (q0 + 32 * kk) * 64 + tro0);
-                win_tr_issue(qtr[kk][1], sQ + (q0 + 32 * kk) * 64 + tro1);
+                tr_issue(qtr[kk][0], sQ + (q0 + 32 * kk) * 64 + tro0);
+                tr_issue(qtr[kk][1], sQ + (q0 + 32 * kk) * 64 + tro1);
             }
-            win_tr_wait(qtr);
+            tr_wait4(qtr);
 #pragma unroll
             for (int kk = 0; kk < 2; ++kk) {
                 const bf16x8_t df = pack_bf16x8(dpacc[2 * kk], dpacc[2 * kk + 1]);
-                dkacc[0] = Mma<T>::mma(win_tr_frag(qtr[kk][0]), df, dkacc[0]);
-                dkacc[1] = Mma<T>::mma(win_tr_frag(qtr[kk][1]), df, dkacc[1]);
+                dkacc[0] = Mma<T>::mma(tr_frag(qtr[kk][0]), df, dkacc[0]);
+                dkacc[1] = Mma<T>::mma(tr_frag(qtr[kk][1]), df, dkacc[1]);
             }
         }
         if (kok) {

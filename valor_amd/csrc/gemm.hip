@@ -301,12 +301,34 @@ __global__ __launch_bounds__(256, NSTAGE == 1 ? 4 : 2) void gemm_glds_kernel(Gem
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
             bf16x8_t fn[4], fm[4];
+            if constexpr (NSTAGE == 2 && (TA || TB)) {
+                // the next K-step's LDS-DMA is in flight: transposing reads as inline asm (mma.h), or the compiler drains it here
+                TrPair pn[2][2], pm[2][2];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                if constexpr (TB) fn[i] = read_frag_tr(sB, trB[i], kk);
-                else fn[i] = read_frag<T>(sB, wn * 64 + i * 16 + fr, kk * 4 + fg);
-                if constexpr (TA) fm[i] = read_frag_tr(sA, trA[i], kk);
-                else fm[i] = read_frag<T>(sA, wm * 64 + i * 16 + fr, kk * 4 + fg);
+                for (int i = 0; i < 4; ++i) {
+                    if constexpr (TB) tr_issue(pn[i >> 1][i & 1], sB + trB[i] + kk * (32 * 256));
+                    else fn[i] = read_frag<T>(sB, wn * 64 + i * 16 + fr, kk * 4 + fg);
+                    if constexpr (TA) tr_issue(pm[i >> 1][i & 1], sA + trA[i] + kk * (32 * 256));
+                    else fm[i] = read_frag<T>(sA, wm * 64 + i * 16 + fr, kk * 4 + fg);
+                }
+                if constexpr (TB) {
+                    tr_wait4(pn);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) fn[i] = tr_frag(pn[i >> 1][i & 1]);
+                }
+                if constexpr (TA) {
+                    tr_wait4(pm);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) fm[i] = tr_frag(pm[i >> 1][i & 1]);
+                }
+            } else {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    if constexpr (TB) fn[i] = read_frag_tr(sB, trB[i], kk);
+                    else fn[i] = read_frag<T>(sB, wn * 64 + i * 16 + fr, kk * 4 + fg);
+                    if constexpr (TA) fm[i] = read_frag_tr(sA, trA[i], kk);
+                    else fm[i] = read_frag<T>(sA, wm * 64 + i * 16 + fr, kk * 4 + fg);
+                }
             }
 #pragma unroll
             for (int ni = 0; ni < 4; ++ni)

@@ -44,28 +44,8 @@ DEVINL bf16x8_t read_frag_tr8(const char* img, int off, int kk) {
     return __builtin_bit_cast(bf16x8_t, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
 }
 
-// The compiler gives the ds_read_b64_tr_b16 BUILTIN no memory operand, so it cannot tell the read from the LDS-DMA writes that are
-// in flight into the other half-tiles and puts `s_waitcnt vmcnt(0)` in front of the first transposing read of every phase: the
-// counted vmcnt(8) pipeline is drained three times per K-tile in the k-slow (wgrad / dgrad) kernels. With ASMTR the transposing
-// reads are inline asm (invisible to the waitcnt pass); their results are 64-bit halves that only become fragments after an explicit
-// `s_waitcnt lgkmcnt(0)` to which they are tied as in/out operands.
-struct TrPair { s16x4_t lo, hi; };
-DEVINL void tr_issue(TrPair& t, const char* a) {
-    const uint32_t addr = (uint32_t)(uintptr_t)LDS_PTR(a);
-    asm volatile("ds_read_b64_tr_b16 %0, %2\n\tds_read_b64_tr_b16 %1, %2 offset:1024" : "=&v"(t.lo), "=&v"(t.hi) : "v"(addr));
-}
-DEVINL bf16x8_t tr_frag(const TrPair& t) {
-    return __builtin_bit_cast(bf16x8_t, __builtin_shufflevector(t.lo, t.hi, 0, 1, 2, 3, 4, 5, 6, 7));
-}
-#define TR_TIE(t) "+v"((t).lo), "+v"((t).hi)
-DEVINL void tr_wait4(TrPair (&t)[2][2]) {
-    asm volatile("s_waitcnt lgkmcnt(0)" : TR_TIE(t[0][0]), TR_TIE(t[0][1]), TR_TIE(t[1][0]), TR_TIE(t[1][1]));
-}
-DEVINL void tr_wait8(TrPair (&t)[4][2]) {
-    asm volatile("s_waitcnt lgkmcnt(0)" : TR_TIE(t[0][0]), TR_TIE(t[0][1]), TR_TIE(t[1][0]), TR_TIE(t[1][1]), TR_TIE(t[2][0]),
-                 TR_TIE(t[2][1]), TR_TIE(t[3][0]), TR_TIE(t[3][1]));
-}
-
+// ASMTR: the transposing reads of the k-slow operands as inline asm (mma.h: tr_issue / tr_wait / tr_frag) -- as compiler builtins
+// they drained the counted vmcnt(8) LDS-DMA pipeline three times per K-tile.
 template <bool TA, bool TB, bool ASMTR>
 __global__ __launch_bounds__(512, 2) void gemm_8ph_kernel(GemmArgs p) {
     typedef bf16_t T;

@@ -398,3 +398,28 @@ DEVINL bf16x8_t read_frag_tr_nat(const char* img, int row0, int lane_off) {
     s16x4_t lo = lds_read_tr4(a), hi = lds_read_tr4(a + 16 * TILE_ROW_BYTES);
     return __builtin_bit_cast(bf16x8_t, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
 }
+
+// ---------------------------------------------------------------------------------------
+// Transposing reads as inline asm. hipcc gives the ds_read_b64_tr_b16 BUILTIN no memory operand, so its waitcnt pass cannot tell
+// the read from LDS-DMA writes that are in flight into ANOTHER part of LDS and puts `s_waitcnt vmcnt(0)` in front of it: every
+// look-ahead DMA pipeline is drained at the first transposing read. As `asm volatile` the reads are invisible to that pass; their
+// two 64-bit halves become a fragment only after an explicit `s_waitcnt lgkmcnt(0)` to which they are tied as in/out operands
+// (the halves are allocated as adjacent register pairs: no moves). The second half lives 1024 B further (4 rows of a 256-B
+// k-slow GEMM image, 16 rows of a 64-B attention row image).
+// ---------------------------------------------------------------------------------------
+struct TrPair { s16x4_t lo, hi; };
+DEVINL void tr_issue(TrPair& t, const char* a) {
+    const uint32_t addr = (uint32_t)(uintptr_t)LDS_PTR(a);
+    asm volatile("ds_read_b64_tr_b16 %0, %2\n\tds_read_b64_tr_b16 %1, %2 offset:1024" : "=&v"(t.lo), "=&v"(t.hi) : "v"(addr));
+}
+DEVINL bf16x8_t tr_frag(const TrPair& t) {
+    return __builtin_bit_cast(bf16x8_t, __builtin_shufflevector(t.lo, t.hi, 0, 1, 2, 3, 4, 5, 6, 7));
+}
+#define TR_TIE(t) "+v"((t).lo), "+v"((t).hi)
+DEVINL void tr_wait4(TrPair (&t)[2][2]) {
+    asm volatile("s_waitcnt lgkmcnt(0)" : TR_TIE(t[0][0]), TR_TIE(t[0][1]), TR_TIE(t[1][0]), TR_TIE(t[1][1]));
+}
+DEVINL void tr_wait8(TrPair (&t)[4][2]) {
+    asm volatile("s_waitcnt lgkmcnt(0)" : TR_TIE(t[0][0]), TR_TIE(t[0][1]), TR_TIE(t[1][0]), TR_TIE(t[1][1]), TR_TIE(t[2][0]),
+                 TR_TIE(t[2][1]), TR_TIE(t[3][0]), TR_TIE(t[3][1]));
+}
