@@ -101,3 +101,49 @@ def test_reducer_sums_arena_and_learns_unused_parameters():
             assert torch.allclose(g0[o:o + n], torch.full((n,), want)), (step, i)
         if step > 0:
             assert nworks0 > 1          # bucketed, hook-launched all-reduces after the first (learning) step
+
+
+def _reducer_multiuse_case(rank, world):
+    """gradients written straight into the arena by kernels (ops.GradSink.listener), some parameters TWICE per backward (the
+    shared BERT of the VideoSwin variant: text-encoder pass + decoder passes): a bucket may only fly after the last write."""
+    from valor_amd import ops
+    from valor_amd.arena import ParamArena
+    from valor_amd.dist import Reducer
+    entries = [(f"p{i}", (500 + 3 * i,), 0) for i in range(10)]
+    arena = ParamArena(entries, torch.float32, "cpu")
+    red = Reducer(arena, bucket_bytes=4096)
+    shared = {"p2", "p3", "p6"}
+    outs = []
+    try:
+        for step in range(3):
+            arena.grad.zero_()
+            red.prepare_backward()
+            names = list(arena.params)
+            for n in reversed(names):                     # "decoder passes": every parameter once
+                arena.params[n].grad += float(rank + 1)
+                ops.GradSink.listener(n)
+            for n in reversed(names):                     # "text-encoder pass": the shared ones again, later
+                if n in shared:
+                    arena.params[n].grad += 10.0 * (rank + 1) * (step + 1)
+                    ops.GradSink.listener(n)
+            red.finish_backward()
+            outs.append((arena.grad.clone(), dict(red.uses), len(red.works)))
+    finally:
+        ops.GradSink.listener = None
+    return outs
+
+
+def test_reducer_waits_for_every_write_of_a_shared_parameter():
+    r = _run(_reducer_multiuse_case)
+    from valor_amd.arena import ParamArena
+    arena = ParamArena([(f"p{i}", (500 + 3 * i,), 0) for i in range(10)], torch.float32, "cpu")
+    for step in range(3):
+        g0, uses, nworks = r[0][step]
+        assert torch.equal(g0, r[1][step][0])
+        assert uses["p2"] == 2 and uses["p0"] == 1
+        for i in range(10):
+            o, n, _ = arena.offsets[f"p{i}"]
+            want = 3.0 + (30.0 * (step + 1) if i in (2, 3, 6) else 0.0)        # sum over ranks 1 + 2 (+ 10 + 20 per step)
+            assert torch.allclose(g0[o:o + n], torch.full((n,), want)), (step, i, float(g0[o]))
+        if step > 0:
+            assert nworks > 1
