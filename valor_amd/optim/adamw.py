@@ -130,7 +130,74 @@ class FusedAdamW:
                      self.betas[0], self.betas[1], self.eps, int(st), int(self.correct_bias), _ptr(self.gscale), 1)
         return self.total_norm
 
-    # ---- HF / reference optimizer checkpoint layout (optimizer_step_N.pt, utils/save.py:57-64)
+    # ---- the reference's optimizer checkpoint (optimizer_step_N.pt: utils/save.py:57-64 saves torch's Optimizer.state_dict() of the
+    # AdamW built by optim/misc.py:13-100; train_utils.py:226-228 loads it on --resume)
+    def reference_param_groups(self):
+        """The 10 parameter groups of build_optimizer as lists of REFERENCE parameter names, in its order: model.named_parameters()
+        order (== the reference state-dict order without aliases / buffers) filtered by the group rules of optim/misc.py:33-64."""
+        from ..model.params import optimizer_group
+        from ..synth import state_dict_layout
+        groups = [[] for _ in range(self.N_GROUPS)]
+        # build_optimizer lists its groups as basic, new, clip visual, clip text, decoder (x decay / no decay): the same
+        # numbering as model.params.optimizer_group
+        for key, _, kind in state_dict_layout(self.model.spec):
+            if kind in ("alias", "relidx", "tied"):
+                continue
+            groups[optimizer_group(key, tuple(self.new_params_name))].append(key)
+        return groups
+
+    def _ref_slices(self):
+        """reference parameter name -> (arena offset, numel, shape) (packed q/k/v rows split back)"""
+        out = {}
+        for name, shape, refs in self.model.table:
+            o, n, _ = self.arena.offsets[name]
+            if len(refs) == 1 or refs[1] == "cls.decoder.weight":
+                out[refs[0]] = (o, n, tuple(shape), name)
+            else:
+                rows = shape[0] // len(refs)
+                sub = (rows,) + tuple(shape[1:])
+                per = n // len(refs)
+                for i, r in enumerate(refs):
+                    out[r] = (o + i * per, per, sub, name)
+        return out
+
+    def reference_state_dict(self):
+        """torch-Optimizer-format state dict with the reference's parameter indexing, loadable by the reference's
+        optimizer.load_state_dict (and by load_reference_state_dict below)."""
+        groups = self.reference_param_groups()
+        sl = self._ref_slices()
+        state, pgs, idx = {}, [], 0
+        for gi, names in enumerate(groups):
+            g = self.param_groups[gi]
+            pgs.append({"weight_decay": g["weight_decay"], "lr": g["lr"], "init_lr": g["init_lr"], "betas": self.betas, "eps": self.eps,
+                        "correct_bias": self.correct_bias, "params": list(range(idx, idx + len(names)))})
+            for r in names:
+                o, n, shape, owner = sl[r]
+                if self.steps[owner] > 0:
+                    state[idx] = {"step": self.steps[owner], "exp_avg": self.exp_avg[o:o + n].view(shape).clone().cpu(),
+                                  "exp_avg_sq": self.exp_avg_sq[o:o + n].view(shape).clone().cpu()}
+                idx += 1
+        return {"state": state, "param_groups": pgs}
+
+    def load_reference_state_dict(self, sd):
+        """Resume from the reference's optimizer_step_N.pt (or from reference_state_dict()). Packed q|k|v tensors take the
+        step count of their parts (the reference steps them together)."""
+        groups = self.reference_param_groups()
+        sl = self._ref_slices()
+        order = [r for names in groups for r in names]
+        assert len(sd["param_groups"]) == self.N_GROUPS and sum(len(g["params"]) for g in sd["param_groups"]) == len(order), \
+            "optimizer checkpoint does not match this model's parameter groups"
+        for names, g in zip(groups, sd["param_groups"]):
+            assert len(names) == len(g["params"])
+        for idx, st in sd["state"].items():
+            o, n, shape, owner = sl[order[int(idx)]]
+            self.steps[owner] = int(st["step"])
+            self.exp_avg[o:o + n].copy_(st["exp_avg"].reshape(-1))
+            self.exp_avg_sq[o:o + n].copy_(st["exp_avg_sq"].reshape(-1))
+        for g, s_ in zip(self.param_groups, sd["param_groups"]):
+            g.update({k: s_[k] for k in ("init_lr", "lr", "weight_decay") if k in s_})
+
+    # ---- compact native layout (one entry per arena tensor)
     def state_dict(self):
         state = {}
         for i, (name, (o, n, shape)) in enumerate(self.arena.offsets.items()):

@@ -210,6 +210,11 @@ def state_dict_layout(spec: ValorSpec):
                 add(p + "reduction.weight", (2 * C, 4 * C)); add(p + "norm.weight", (4 * C,), "g"); add(p + "norm.bias", (4 * C,), "b")
         add("video_encoder.norm.weight", (spec.swin_out,), "g"); add("video_encoder.norm.bias", (spec.swin_out,), "b")
         _audio_bert_heads(spec, add)
+        # share_txt_and_multimodal (modeling.py:689-691): the text encoder IS the multimodal encoder, so the reference state
+        # dict lists every multimodal_encoder.* tensor a second time under txt_encoder.* (same storage), right after cls.*
+        for k, shape, kind in list(L):
+            if k.startswith("multimodal_encoder."):
+                L.append(("txt_encoder." + k[len("multimodal_encoder."):], shape, "alias"))
         if spec.video_dim != H:                                                       # modeling.py:348-349
             add("hidden_trans_video_multimodal.0.weight", (H, spec.video_dim)); add("hidden_trans_video_multimodal.0.bias", (H,), "b")
             add("hidden_trans_video_multimodal.1.weight", (H,), "g"); add("hidden_trans_video_multimodal.1.bias", (H,), "b")
@@ -221,11 +226,6 @@ def state_dict_layout(spec: ValorSpec):
         for m in ("text", "video", "audio"):
             add(f"{m}_fine_weight.0.weight", (E, E)); add(f"{m}_fine_weight.0.bias", (E,), "b")
             add(f"{m}_fine_weight.2.weight", (1, E)); add(f"{m}_fine_weight.2.bias", (1,), "b")
-        # share_txt_and_multimodal (modeling.py:689-691): the text encoder IS the multimodal encoder, so the reference state
-        # dict lists every multimodal_encoder.* tensor a second time under txt_encoder.* (same storage)
-        for k, shape, kind in list(L):
-            if k.startswith("multimodal_encoder."):
-                L.append(("txt_encoder." + k[len("multimodal_encoder."):], shape, "alias"))
         return L
     add("clip_model.positional_embedding", (spec.ctx_len, TW)); add("clip_model.text_projection", (TW, E))
     add("clip_model.logit_scale", (), "s")
