@@ -126,3 +126,49 @@ def test_text_only_mlm_plumbing_case(setup):
         assert float((g - p.grad).norm()) / scale < 2e-4, name
         n += 1
     assert n > 150
+
+
+def test_large_configuration_components():
+    """BASELINE configs[3] ("VideoSwin-L + BERT-large") has no shipped reference config (modeling.py:578-587, 618-625 accept base
+    models only): the reference CLASSES with the large hyper-parameters against the oracle's restatement at
+    those widths -- SwinTransformer3D(embed 192, heads 6/12/24/48) on a 2-frame clip and a 2-layer slice of BertModel(1024 wide,
+    16 heads, 4096 inner) with cross-attention over [video | audio] features, outputs and input / weight gradients."""
+    ref_harness._install()
+    from model.bert import BertConfig, BertModel
+    from model.videoswin import SwinTransformer3D
+    from valor_amd import synth
+    from valor_oracle import Oracle
+    torch.manual_seed(1)
+    spec = synth.large_spec()
+    # ---- VideoSwin-L (shallow stage 3 to keep the CPU time down: depths are a free hyper-parameter of both sides)
+    depths = (1, 1, 2, 1)
+    swin = SwinTransformer3D(embed_dim=192, depths=list(depths), num_heads=[6, 12, 24, 48], drop_path_rate=0.0).float().train()
+    for p in swin.parameters():
+        torch.nn.init.normal_(p, std=0.05)
+    sd = {"video_encoder." + k: v.detach().clone().requires_grad_(v.is_floating_point()) for k, v in swin.state_dict().items()}
+    import dataclasses
+    orc = Oracle(dataclasses.replace(spec, swin_depths=depths), sd)
+    vid = torch.randn(1, 3, 2, 224, 224)
+    y_ref = swin(vid).permute(0, 2, 3, 4, 1)
+    y_orc = orc.swin_visual(vid)
+    assert y_orc.shape == (1, 2, 49, 1536)
+    assert torch.allclose(y_ref.reshape(y_orc.shape), y_orc, atol=2e-4, rtol=1e-4)
+    y_ref.square().mean().backward(); y_orc.square().mean().backward()
+    for k in ("layers.2.downsample.norm.weight", "layers.3.blocks.0.attn.relative_position_bias_table", "patch_embed.proj.weight"):
+        gr, go = dict(swin.named_parameters())[k].grad, sd["video_encoder." + k].grad
+        assert float((gr - go).norm()) <= 2e-3 * float(gr.norm()) + 1e-9, k
+    assert dict(swin.named_parameters())["layers.2.downsample.norm.weight"].shape == (3072,)      # the wide LayerNorm row
+    # ---- BERT-large decoder slice
+    cfg = BertConfig.from_dict(dict(attention_probs_dropout_prob=0.0, hidden_act="gelu", hidden_dropout_prob=0.0, hidden_size=1024,
+                                    initializer_range=0.02, intermediate_size=4096, max_position_embeddings=64, num_attention_heads=16,
+                                    num_hidden_layers=2, type_vocab_size=2, vocab_size=500))
+    cfg.checkpointing, cfg.has_cross_attn, cfg.cross_attn_type = False, True, "va_concate"
+    bert = BertModel(cfg).float().train()
+    bsd = {"multimodal_encoder." + k: v.detach().clone().requires_grad_(v.is_floating_point()) for k, v in bert.state_dict().items()}
+    borc = Oracle(dataclasses.replace(spec, layers=2, vocab=500, max_pos=64), bsd)
+    toks = torch.tensor([[101, 7, 8, 9, 102, 0, 0, 0], [101, 11, 12, 102, 0, 0, 0, 0]])
+    vfeat, afeat = torch.randn(2, 98, 1024), torch.randn(2, 129, 1024)
+    for casual in (True, False):
+        o_ref = bert(toks, None, vfeat, afeat, casual=casual)
+        o_orc = borc.bert_model(toks, None, vfeat, afeat, casual)
+        assert torch.allclose(o_ref, o_orc, atol=2e-4, rtol=1e-4), casual
