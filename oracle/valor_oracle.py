@@ -168,21 +168,27 @@ class Oracle:
         return x / keep * m
 
     def swin_block(self, x, p, heads, window, shift, rate):
-        """SwinTransformerBlock3D.forward, model/videoswin.py:191-245. x: [B, D, H, W, C]. Sizes that need window padding
-        (videoswin.py:199-203) are not restated: 224 px inputs never pad."""
+        """SwinTransformerBlock3D.forward, model/videoswin.py:191-245. x: [B, D, H, W, C]. Feature maps that are not a multiple of
+        the window are zero padded AFTER norm1 (:199-203), attend as ordinary slots (their K / V are the qkv bias) and are cropped
+        again (:222-223); the shift mask is computed on the padded size (BasicLayer :333-336)."""
         w = self.w
         B, D, H, W, C = x.shape
         win, sh = self.swin_effective_window((D, H, W), window, shift)
-        assert D % win[0] == 0 and H % win[1] == 0 and W % win[2] == 0, "window padding is not restated"
         h = layer_norm(x, w(p + "norm1.weight"), w(p + "norm1.bias"), 1e-5)
+        pd, pb, pr = (win[0] - D % win[0]) % win[0], (win[1] - H % win[1]) % win[1], (win[2] - W % win[2]) % win[2]
+        if pd or pb or pr:
+            h = F.pad(h, (0, 0, 0, pr, 0, pb, 0, pd))
+        Dp, Hp, Wp = D + pd, H + pb, W + pr
         mask = None
         if any(sh):
             h = torch.roll(h, shifts=(-sh[0], -sh[1], -sh[2]), dims=(1, 2, 3))
-            mask = self.swin_shift_mask((D, H, W), win, sh)
+            mask = self.swin_shift_mask((Dp, Hp, Wp), win, sh)
         a = self.swin_attention(self.swin_windows(h, win), p + "attn.", heads, mask)
-        a = self.swin_unwindows(a, win, B, D, H, W)
+        a = self.swin_unwindows(a, win, B, Dp, Hp, Wp)
         if any(sh):
             a = torch.roll(a, shifts=sh, dims=(1, 2, 3))
+        if pd or pb or pr:
+            a = a[:, :D, :H, :W]
         x = x + self.swin_drop_path(a, rate)
         h = layer_norm(x, w(p + "norm2.weight"), w(p + "norm2.bias"), 1e-5)
         h = F.linear(F.gelu(F.linear(h, w(p + "mlp.fc1.weight"), w(p + "mlp.fc1.bias"))), w(p + "mlp.fc2.weight"), w(p + "mlp.fc2.bias"))
@@ -208,7 +214,8 @@ class Oracle:
                 k += 1
             if li + 1 < len(sp.swin_depths):
                 p = f"video_encoder.layers.{li}.downsample."
-                assert x.shape[2] % 2 == 0 and x.shape[3] % 2 == 0, "odd-size PatchMerging padding is not restated"
+                if x.shape[2] % 2 or x.shape[3] % 2:                       # PatchMerging pads odd H / W with zeros, :257-259
+                    x = F.pad(x, (0, 0, 0, x.shape[3] % 2, 0, x.shape[2] % 2))
                 x = torch.cat([x[:, :, 0::2, 0::2], x[:, :, 1::2, 0::2], x[:, :, 0::2, 1::2], x[:, :, 1::2, 1::2]], dim=-1)
                 x = layer_norm(x, w(p + "norm.weight"), w(p + "norm.bias"), 1e-5)
                 x = F.linear(x, w(p + "reduction.weight"))

@@ -172,3 +172,31 @@ def test_large_configuration_components():
         o_ref = bert(toks, None, vfeat, afeat, casual=casual)
         o_orc = borc.bert_model(toks, None, vfeat, afeat, casual)
         assert torch.allclose(o_ref, o_orc, atol=2e-4, rtol=1e-4), casual
+
+
+@pytest.mark.parametrize("res,frames", [(96, 3), (160, 2)])
+def test_swin_padding_cases(res, frames):
+    """feature maps that are not multiples of the (7, 7) window and odd PatchMerging inputs (videoswin.py:199-203, 222-223,
+    257-259): 96 px -> 24 / 12 / 6 / 3, 160 px -> 40 / 20 / 10 / 5; reference SwinTransformer3D vs the oracle, output and gradients.
+    (The native path covers the 224-px geometry only and says so; the oracle is complete.)"""
+    ref_harness._install()
+    import dataclasses
+    from model.videoswin import SwinTransformer3D
+    from valor_amd import synth
+    from valor_oracle import Oracle
+    torch.manual_seed(2)
+    depths = (2, 2, 2, 2)
+    swin = SwinTransformer3D(embed_dim=32, depths=list(depths), num_heads=[1, 2, 4, 8], drop_path_rate=0.0).float().train()
+    for p in swin.parameters():
+        torch.nn.init.normal_(p, std=0.1)
+    sd = {"video_encoder." + k: v.detach().clone().requires_grad_(v.is_floating_point()) for k, v in swin.state_dict().items()}
+    spec = dataclasses.replace(synth.swin_spec(), swin_embed=32, swin_depths=depths, swin_heads=(1, 2, 4, 8), resolution=res)
+    orc = Oracle(spec, sd)
+    vid = torch.randn(2, 3, frames, res, res)
+    y_ref = swin(vid).permute(0, 2, 3, 4, 1)
+    y_orc = orc.swin_visual(vid)
+    assert torch.allclose(y_ref.reshape(y_orc.shape), y_orc, atol=1e-4, rtol=1e-4)
+    y_ref.square().mean().backward(); y_orc.square().mean().backward()
+    for k, p in swin.named_parameters():
+        go = sd["video_encoder." + k].grad
+        assert float((p.grad - go).norm()) <= 2e-3 * float(p.grad.norm()) + 1e-8, k
