@@ -34,8 +34,9 @@ SWIN_SLICE_KEYS = ["video_encoder.patch_embed.proj.weight", "video_encoder.layer
                    "multimodal_encoder.embeddings.word_embeddings.weight", "cls.decoder.bias", "video_frame_embedding"]
 
 
-def run(name, batch_size, frames, audio_slices, wseed, bseed, mseed, variant="clip"):
+def run(name, batch_size, frames, audio_slices, wseed, bseed, mseed, variant="clip", task=None):
     global SLICE_KEYS
+    TASK = task or globals()["TASK"]
     if variant == "swin":                  # scripts/pretrain.sh:3-8
         spec = synth.swin_spec()
         ropts = ref_harness.default_opts(video_encoder_type="videoswin_base_k400_22k", txt_encoder_type="bert_base_uncased")
@@ -74,7 +75,8 @@ def run(name, batch_size, frames, audio_slices, wseed, bseed, mseed, variant="cl
         if step == 0:
             rec["grad_norm"] = {n: float(p.grad.norm()) for n, p in ref.named_parameters() if p.grad is not None}
             rec["no_grad"] = [n for n, p in ref.named_parameters() if p.grad is None]
-            rec["grad_slices"] = {n: dict(ref.named_parameters())[n].grad.reshape(-1)[:64].clone() for n in SLICE_KEYS}
+            rec["grad_slices"] = {n: dict(ref.named_parameters())[n].grad.reshape(-1)[:64].clone() for n in SLICE_KEYS
+                                  if dict(ref.named_parameters())[n].grad is not None}      # single-modality tasks leave an encoder unused
         lr_ratio = get_lr_sched(step + 1, opts)
         for pg in opt.param_groups:
             pg["lr"] = pg["init_lr"] * lr_ratio
@@ -96,3 +98,6 @@ if __name__ == "__main__":
     run("ref_base_b2f2a1", batch_size=2, frames=2, audio_slices=1, wseed=50, bseed=51, mseed=50)
     run("ref_base_b3f1a2", batch_size=3, frames=1, audio_slices=2, wseed=7, bseed=8, mseed=9)
     run("ref_swin_b2f2a1", batch_size=2, frames=2, audio_slices=1, wseed=50, bseed=51, mseed=50, variant="swin")
+    # single-modality tasks (datasets without audio / without video): the decoder cross-attends to one modality only
+    run("ref_base_b2f2a1_tv", batch_size=2, frames=2, audio_slices=1, wseed=50, bseed=51, mseed=50, task="pt_contra%tv_caption%tv_mlm%tv")
+    run("ref_base_b2f2a1_ta", batch_size=2, frames=2, audio_slices=1, wseed=50, bseed=51, mseed=50, task="pt_contra%ta_caption%ta_mlm%ta")

@@ -28,7 +28,7 @@ def _oracle(recipe):
     return spec, sd_o, orc, batch
 
 
-@pytest.mark.parametrize("name", ["ref_base_b2f2a1", "ref_base_b3f1a2", "ref_swin_b2f2a1"])
+@pytest.mark.parametrize("name", ["ref_base_b2f2a1", "ref_base_b3f1a2", "ref_swin_b2f2a1", "ref_base_b2f2a1_tv", "ref_base_b2f2a1_ta"])
 def test_oracle_reproduces_reference_goldens(name):
     g = torch.load(os.path.join(GOLD, name + ".pt"), weights_only=False)
     rc = g["recipe"]
@@ -43,7 +43,10 @@ def test_oracle_reproduces_reference_goldens(name):
     assert torch.equal(ev["txt_labels_caption"], g["eval"]["txt_labels_caption"])
     assert torch.equal(ev["txt_labels_mlm"], g["eval"]["txt_labels_mlm"])
     for k in ("feat_t", "feat_v", "feat_a"):
-        assert torch.allclose(ev[k], g["eval"][k], atol=2e-5), k
+        if g["eval"][k] is None:                       # single-modality task: that encoder is not run
+            assert ev[k] is None
+        else:
+            assert torch.allclose(ev[k], g["eval"][k], atol=2e-5), k
     # two training steps with the restated optimizer
     params = {k: v for k, v in sd_o.items() if v.requires_grad and not VO.is_alias_key(k)}
     groups = {k: VO.param_group_of(k) for k in params}
@@ -62,7 +65,8 @@ def test_oracle_reproduces_reference_goldens(name):
         if step == 0:
             assert sorted(rec["no_grad"]) == sorted(k for k in params if k not in grads)
             for k, n in rec["grad_norm"].items():
-                assert abs(float(grads[k].norm()) - n) <= 3e-4 * max(n, 1e-5 * grads[k].numel() ** 0.5), k
+                # analytically zero gradients (softmax-shift-invariant biases) are rounding noise ~1e-8 on both sides: absolute floor
+                assert abs(float(grads[k].norm()) - n) <= 3e-4 * max(n, 1e-5 * grads[k].numel() ** 0.5) + 3e-8 * grads[k].numel() ** 0.5, k
             for k, sl in rec["grad_slices"].items():
                 assert torch.allclose(grads[k].reshape(-1)[:64], sl, rtol=2e-3, atol=1e-7), k
         ratio = VO.warmup_linear((step + 1) / 10, 0.1)
@@ -83,7 +87,7 @@ _SD_CACHE = {}
 
 
 def synth_ref(rc, key):
-    ck = rc["weight_seed"]
+    ck = (rc["weight_seed"], tuple(sorted((k, str(v)) for k, v in rc["spec"].items())))
     if ck not in _SD_CACHE:
         _SD_CACHE.clear()
         _SD_CACHE[ck] = synth.make_state_dict(synth.ValorSpec(**rc["spec"]), seed=rc["weight_seed"])

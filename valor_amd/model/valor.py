@@ -719,10 +719,14 @@ class VALOR(nn.Module):
             if video_output is not None and audio_output is not None:
                 va = ops.cross_input(video_output, audio_output, P["video_frame_embedding"], P["video_type_embeddings"],
                                      P["audio_frame_embedding"], P["audio_type_embeddings"])
+                ranges = {"tva": (0, Sv + Sa), "tv": (0, Sv), "ta": (Sv, Sa)}
+            elif video_output is not None:                        # a task string without audio groups: video rows only
+                va = ops.single_input(video_output, P["video_frame_embedding"], P["video_type_embeddings"])
+                ranges = {"tv": (0, Sv)}
             else:
-                raise NotImplementedError("single-modality decoder input (video-only / audio-only datasets) comes next")
+                va = ops.single_input(audio_output, P["audio_frame_embedding"], P["audio_type_embeddings"])
+                ranges = {"ta": (0, Sa)}
             kv_layers = self.project_cross_kv(va)
-            ranges = {"tva": (0, Sv + Sa), "tv": (0, Sv), "ta": (Sv, Sa)}
 
         if compute_loss:
             # training: every decoder pass row-batched into one stack (caption groups first: the biggest segment)

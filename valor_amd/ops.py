@@ -726,6 +726,32 @@ def cross_input(vid, aud, vfe, vte, afe, ate):
     return CrossInputFn.apply(vid, aud, vfe, vte, afe, ate)
 
 
+class SingleInputFn(Function):
+    """one modality only (a dataset without audio or without video): x + frame_emb + type -> [b, F*X, E]
+    (modeling.py:485-502; bert.py:452-455 cross-attends to that modality alone)."""
+
+    @staticmethod
+    def forward(ctx, x, fe, te):
+        b, F, X, E = x.shape
+        out = torch.empty((b, F * X, E), dtype=x.dtype, device=x.device)
+        lib.call("valor_add_frame_type_fwd", _st(), _dt(x), _p(x.contiguous()), _p(fe), _p(te), _p(out), b, F, X, E, F * X * E, 0)
+        ctx.cfg = (b, F, X, E, fe.shape, te.shape)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        b, F, X, E, fs, ts = ctx.cfg
+        dout = dout.contiguous()
+        dx = torch.empty((b, F, X, E), dtype=dout.dtype, device=dout.device)
+        dfe = torch.zeros(fs, dtype=dout.dtype, device=dout.device)
+        lib.call("valor_add_frame_type_bwd", _st(), _dt(dout), _p(dout), _p(dx), _p(dfe), _p(K.workspace(dout.device)), b, F, X, E, F * X * E, 0)
+        return dx, dfe, K.colsum(dfe.view(-1, E)[:F]).view(ts)
+
+
+def single_input(x, fe, te):
+    return SingleInputFn.apply(x, fe, te)
+
+
 class L2NormFn(Function):
     @staticmethod
     def forward(ctx, x):
