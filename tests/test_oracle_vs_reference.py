@@ -200,3 +200,37 @@ def test_swin_padding_cases(res, frames):
     for k, p in swin.named_parameters():
         go = sd["video_encoder." + k].grad
         assert float((p.grad - go).norm()) <= 2e-3 * float(p.grad.norm()) + 1e-8, k
+
+
+@pytest.mark.parametrize("variant", ["clip", "swin"])
+def test_use_task_prompt_matches_reference(variant):
+    """use_task_prompt=True (config/pretrain-VALOR-large.json:14): the caption passes get the 'describe the video ...' prompt
+    (pretrain.py:436-439) and, with the BERT text encoder, the contrastive text pass gets 'project language in common space' whose
+    rows are dropped again (pretrain.py:254-263): losses and all gradients against the reference."""
+    from valor_amd import synth
+    from valor_oracle import Oracle, trainable_copy
+    if variant == "swin":
+        spec = synth.swin_spec()
+        ropts = ref_harness.default_opts(video_encoder_type="videoswin_base_k400_22k", txt_encoder_type="bert_base_uncased", use_task_prompt=True)
+    else:
+        spec, ropts = synth.base_spec(), ref_harness.default_opts(use_task_prompt=True)
+    sd = synth.make_state_dict(spec, seed=13)
+    ref = ref_harness.build_reference(ropts, state_dict=None, dropout=0.0)
+    missing, unexpected = ref.load_state_dict(sd, strict=False)
+    assert not missing and not unexpected
+    sd_o = trainable_copy(sd)
+    orc = Oracle(spec, sd_o, vocab_tokens=synth.synthetic_vocab(spec.vocab), use_task_prompt=True)
+    batch = synth.make_batch(spec, batch=2, frames=1, audio_slices=1, txt_len=32, seed=14)
+    random.seed(3); r = ref(batch, task=TASK, compute_loss=True); sum(r.values()).backward()
+    random.seed(3); o = orc.forward_pt(batch, TASK, compute_loss=True); sum(o.values()).backward()
+    for k in ("contra_loss", "caption_loss", "mlm_loss"):
+        assert abs(float(r[k]) - float(o[k])) <= 2e-5 * abs(float(r[k])), (k, float(r[k]), float(o[k]))
+    n = 0
+    for name, p in ref.named_parameters():
+        if p.grad is None:
+            continue
+        g = sd_o[name].grad
+        scale = max(float(p.grad.norm()), 1e-4 * p.grad.numel() ** 0.5)      # analytically zero gradients are 1e-9 noise on both sides
+        assert float((g - p.grad).norm()) / scale < 2e-4, name
+        n += 1
+    assert n > 800
