@@ -13,7 +13,11 @@
  *   - the caller owns all memory (kernels never allocate); workspaces are explicit arguments;
  *   - dtype: VALOR_DT_BF16 (0) = bf16 storage / fp32 accumulate (perf mode), VALOR_DT_F32 (1) = fp32 storage,
  *     exact fp32 MFMA (parity mode). Pointers typed `void*` hold elements of `dtype`;
- *   - all functions are re-entrant (autograd may call from a worker thread); no global state.
+ *   - all compute entry points are re-entrant (autograd may call from a worker thread) and keep no state between calls.
+ *     The ONLY process-global state is the kernel-family selection of the tuning hooks (valor_gemm_set_variant,
+ *     valor_gemm_set_tr_asm, valor_gemm_set_fast_epilogue, valor_attn_set_variant, valor_win_attn_set_variant and their
+ *     VALOR_* environment presets): plain ints read at launch time, every setting selects a parity-tested kernel family
+ *     computing the same function, so a concurrent change can alter speed, never results beyond rounding.
  *   - dropout masks are Philox4x32-10 streams keyed by (seed, offset + element index / 4) and are regenerated
  *     in backward from the same (seed, offset) -- nothing is stored.
  */
@@ -64,6 +68,13 @@ int valor_gemm_set_tr_asm(int v);
 /* 8-phase kernels: one-pass bf16 epilogue for plain problems (bf16 C, no split-K / accumulate / pre-activation / dact, N % 8 == 0,
  * ldc % 8 == 0); returns the previous value, v < 0 only queries */
 int valor_gemm_set_fast_epilogue(int v);
+/* policy parameters of variant 4 and of the 8-phase launch (tuning / A-B hook; returns the previous value, value < 0 only queries):
+ *   key 0: smallest K for which a big-M dgrad (A row-major, B k-slow) runs on the 256x256 8-phase kernel
+ *   key 1: start skew of the 8-phase kernel, in units of ~4096 shader cycles: workgroup b of the FIRST round sleeps
+ *          ((b / 8) % 4) * value units before its first load, so the CUs' tile epilogues (128 KiB of stores each) stop
+ *          coinciding round after round (0 = off)
+ *   key 2: smallest number of 256x256 tiles for the 8-phase kernel on forward / dgrad problems */
+int valor_gemm_set_policy(int key, int value);
 
 /* ---- fused bias + dropout + residual + LayerNorm.  Replaces apex FusedLayerNorm (apex/csrc/layer_norm_cuda_kernel.cu
  * :279-322 forward, :403-634 backward; wrapper apex/apex/normalization/fused_layer_norm.py:14-37) plus the elementwise ops

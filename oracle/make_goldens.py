@@ -34,7 +34,7 @@ SWIN_SLICE_KEYS = ["video_encoder.patch_embed.proj.weight", "video_encoder.layer
                    "multimodal_encoder.embeddings.word_embeddings.weight", "cls.decoder.bias", "video_frame_embedding"]
 
 
-def run(name, batch_size, frames, audio_slices, wseed, bseed, mseed, variant="clip", task=None):
+def run(name, batch_size, frames, audio_slices, wseed, bseed, mseed, variant="clip", task=None, bf16_exact=False, steps=2):
     global SLICE_KEYS
     TASK = task or globals()["TASK"]
     if variant == "swin":                  # scripts/pretrain.sh:3-8
@@ -43,17 +43,20 @@ def run(name, batch_size, frames, audio_slices, wseed, bseed, mseed, variant="cl
         SLICE_KEYS = SWIN_SLICE_KEYS
     else:
         spec, ropts = synth.base_spec(), None
-    sd = synth.make_state_dict(spec, seed=wseed)
+    sd = synth.make_state_dict(spec, seed=wseed, bf16_exact=bf16_exact)
     ref = ref_harness.build_reference(ropts, state_dict=sd, dropout=0.0)
-    batch = synth.make_batch(spec, batch=batch_size, frames=frames, audio_slices=audio_slices, txt_len=32, seed=bseed)
+    batch = synth.make_batch(spec, batch=batch_size, frames=frames, audio_slices=audio_slices, txt_len=32, seed=bseed, bf16_exact=bf16_exact)
     g = {"recipe": dict(spec=spec.to_dict(), weight_seed=wseed, batch_seed=bseed, masker_seed=mseed, batch=batch_size,
-                        frames=frames, audio_slices=audio_slices, txt_len=32, task=TASK)}
+                        frames=frames, audio_slices=audio_slices, txt_len=32, task=TASK, bf16_exact=bf16_exact)}
     # ---- eval pass (compute_loss=False): argmax ids + features
     with torch.no_grad():
         random.seed(mseed)
         ev = ref(batch, task=TASK, compute_loss=False)
     g["eval"] = {k: ev[k].argmax(-1) for k in ev if "scores" in k}
     g["eval"]["top2_margin_min"] = {k: float((ev[k].topk(2, -1).values[:, 0] - ev[k].topk(2, -1).values[:, 1]).min()) for k in ev if "scores" in k}
+    # per-row top-1 / top-2 logit gap of the fp32 reference: a lower-precision run can only be held to the argmax on rows whose
+    # gap exceeds its logit error
+    g["eval"]["top2_margin"] = {k: (ev[k].topk(2, -1).values[:, 0] - ev[k].topk(2, -1).values[:, 1]).clone() for k in ev if "scores" in k}
     g["eval"].update(feat_t=ev["feat_t"], feat_v=ev["feat_v"], feat_a=ev["feat_a"], txt_labels_caption=ev["txt_labels_caption"],
                      txt_labels_mlm=ev["txt_labels_mlm"])
     # ---- training pass + 2 optimizer steps
@@ -65,7 +68,7 @@ def run(name, batch_size, frames, audio_slices, wseed, bseed, mseed, variant="cl
                     scheduler="warmup_linear", grad_norm=5.0)
     opt = build_optimizer(ref, opts)
     g["steps"] = []
-    for step in range(2):
+    for step in range(steps):
         opt.zero_grad()
         random.seed(mseed + step)
         out = ref(batch, task=TASK, compute_loss=True)
@@ -93,11 +96,23 @@ def run(name, batch_size, frames, audio_slices, wseed, bseed, mseed, variant="cl
     print(name, {k: round(v, 6) for k, v in g["steps"][0]["losses"].items()}, "->", path, os.path.getsize(path) // 1024, "KiB")
 
 
+FIXTURES = {
+    "ref_base_b2f2a1": dict(batch_size=2, frames=2, audio_slices=1, wseed=50, bseed=51, mseed=50),
+    "ref_base_b3f1a2": dict(batch_size=3, frames=1, audio_slices=2, wseed=7, bseed=8, mseed=9),
+    "ref_swin_b2f2a1": dict(batch_size=2, frames=2, audio_slices=1, wseed=50, bseed=51, mseed=50, variant="swin"),
+    # single-modality tasks (datasets without audio / without video): the decoder cross-attends to one modality only
+    "ref_base_b2f2a1_tv": dict(batch_size=2, frames=2, audio_slices=1, wseed=50, bseed=51, mseed=50, task="pt_contra%tv_caption%tv_mlm%tv"),
+    "ref_base_b2f2a1_ta": dict(batch_size=2, frames=2, audio_slices=1, wseed=50, bseed=51, mseed=50, task="pt_contra%ta_caption%ta_mlm%ta"),
+    # "_q": weights and inputs are bf16-representable fp32 values, so the bf16 native model and the fp32 reference run on
+    # IDENTICAL tensors; b2f8a2 = the geometry bench.py times (8 frames, 2 audio slices: 1834 cross-attention keys, frame
+    # embedding rows 0..7, three kv_range groups at F = 8)
+    "ref_base_b2f2a1_q": dict(batch_size=2, frames=2, audio_slices=1, wseed=50, bseed=51, mseed=50, bf16_exact=True),
+    "ref_base_b2f8a2_q": dict(batch_size=2, frames=8, audio_slices=2, wseed=21, bseed=22, mseed=23, bf16_exact=True),
+    "ref_swin_b2f8a2_q": dict(batch_size=2, frames=8, audio_slices=2, wseed=21, bseed=22, mseed=23, bf16_exact=True, variant="swin"),
+}
+
+
 if __name__ == "__main__":
     assert ref_harness.available()
-    run("ref_base_b2f2a1", batch_size=2, frames=2, audio_slices=1, wseed=50, bseed=51, mseed=50)
-    run("ref_base_b3f1a2", batch_size=3, frames=1, audio_slices=2, wseed=7, bseed=8, mseed=9)
-    run("ref_swin_b2f2a1", batch_size=2, frames=2, audio_slices=1, wseed=50, bseed=51, mseed=50, variant="swin")
-    # single-modality tasks (datasets without audio / without video): the decoder cross-attends to one modality only
-    run("ref_base_b2f2a1_tv", batch_size=2, frames=2, audio_slices=1, wseed=50, bseed=51, mseed=50, task="pt_contra%tv_caption%tv_mlm%tv")
-    run("ref_base_b2f2a1_ta", batch_size=2, frames=2, audio_slices=1, wseed=50, bseed=51, mseed=50, task="pt_contra%ta_caption%ta_mlm%ta")
+    for name in (sys.argv[1:] or list(FIXTURES)):
+        run(name, **FIXTURES[name])

@@ -61,3 +61,25 @@ def test_no_cpu_fallback():
     a = torch.zeros(8, 8)
     with pytest.raises(lib.ValorHipError):
         K.gemm(a, a)
+
+
+def test_integration_snippets_match_header(tmp_path):
+    """the C++ binding block compiles against include/valor_hip.h (stub torch headers, -fsyntax-only:
+    the compiler checks arity and argument types of every valor_* call) and the ctypes block's argtypes equal the loader's."""
+    from valor_amd import lib
+    doc = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    cpp = re.findall(r"```cpp\n(.*?)```", doc, flags=re.S)
+    assert cpp and "valor_bdrln_fwd" in cpp[0]
+    src = tmp_path / "snippet.cpp"
+    src.write_text(cpp[0])
+    r = subprocess.run(["g++", "-std=c++17", "-fsyntax-only", "-Wall", "-Werror", "-Wno-unused-function", "-I", os.path.join(ROOT, "tests", "stubs"),
+                        "-I", os.path.join(ROOT, "include"), str(src)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    py = [b for b in re.findall(r"```python\n(.*?)```", doc, flags=re.S) if "argtypes" in b]
+    assert py
+    m = re.search(r"lib\.(valor_\w+)\.argtypes = \[(.*?)\]", py[0])
+    names = dict(vp=ctypes.c_void_p, i64=ctypes.c_int64, f=ctypes.c_float, u64=ctypes.c_uint64, i=ctypes.c_int)
+    got = [names[t.strip()] for t in m.group(2).split(",")]
+    assert got == lib.SIGNATURES[m.group(1)], (m.group(1), len(got), len(lib.SIGNATURES[m.group(1)]))
+    call = re.search(r"lib\.valor_bdrln_fwd\((.*?)\)\s*#", py[0], flags=re.S) or re.search(r"rc = lib\.valor_bdrln_fwd\((.*?)\n\s*if rc", py[0], flags=re.S)
+    assert call is not None

@@ -33,6 +33,17 @@ def _native(spec, sd, dtype, dev, dropout=0.0, drop_path=0.0):
     return m
 
 
+def _recipe_tensors(rc):
+    """weights + batch of a golden fixture's recipe ("_q" fixtures: bf16-representable values, see synth.make_state_dict)"""
+    from valor_amd import synth
+    spec = synth.ValorSpec(**rc["spec"])
+    q = bool(rc.get("bf16_exact", False))
+    sd = synth.make_state_dict(spec, seed=rc["weight_seed"], bf16_exact=q)
+    batch = synth.make_batch(spec, batch=rc["batch"], frames=rc["frames"], audio_slices=rc["audio_slices"],
+                             txt_len=rc["txt_len"], seed=rc["batch_seed"], bf16_exact=q)
+    return spec, sd, batch
+
+
 def _native_grads(model):
     """reference-keyed gradient dict from the arena (packed q/k/v split back)."""
     out = {}
@@ -123,19 +134,18 @@ def test_text_only_mlm_matches_oracle(dev):
     assert torch.equal(oe["txt_labels_mlm"], ne["txt_labels_mlm"])
 
 
-@pytest.mark.parametrize("name", ["ref_base_b2f2a1", "ref_base_b3f1a2", "ref_swin_b2f2a1", "ref_base_b2f2a1_tv", "ref_base_b2f2a1_ta"])
+@pytest.mark.parametrize("name", ["ref_base_b2f2a1", "ref_base_b3f1a2", "ref_swin_b2f2a1", "ref_base_b2f2a1_tv", "ref_base_b2f2a1_ta",
+                                  "ref_base_b2f8a2_q", "ref_swin_b2f8a2_q"])
 def test_base_fp32_matches_reference_goldens(dev, name):
     """VALOR-base on the exact inputs the reference ran on: losses, argmax ids, per-parameter gradient norms,
-    and parameters after 2 fused optimizer steps vs the reference's (golden) values."""
+    and parameters after 2 fused optimizer steps vs the reference's (golden) values.
+    *_b2f8a2_q = the geometry bench.py times: 8 frames, 2 audio slices (1834 cross-attention keys / 392-slot VideoSwin windows,
+    frame-embedding rows 0..7, the three kv_range groups at F = 8)."""
     from types import SimpleNamespace
-    from valor_amd import synth
     from valor_amd.engine import TrainEngine
     g = torch.load(os.path.join(GOLD, name + ".pt"), weights_only=False)
     rc = g["recipe"]
-    spec = synth.ValorSpec(**rc["spec"])
-    sd = synth.make_state_dict(spec, seed=rc["weight_seed"])
-    batch = synth.make_batch(spec, batch=rc["batch"], frames=rc["frames"], audio_slices=rc["audio_slices"],
-                             txt_len=rc["txt_len"], seed=rc["batch_seed"])
+    spec, sd, batch = _recipe_tensors(rc)
     model = _native(spec, sd, torch.float32, dev)
     with torch.no_grad():
         random.seed(rc["masker_seed"])
@@ -183,30 +193,49 @@ def test_base_fp32_matches_reference_goldens(dev, name):
         assert abs(d - n) <= 5e-3 * n + 1e-7 * sd[k].numel() ** 0.5, (k, d, n)
 
 
-@pytest.mark.parametrize("name", ["ref_base_b2f2a1", "ref_swin_b2f2a1"])
-def test_base_bf16_close_to_reference_goldens(dev, name):
-    """perf mode (bf16 storage, fp32 accumulate): losses stay within 2e-2 relative of the reference CPU path."""
-    from valor_amd import synth
+BF16_LOSS_TOL = 1e-3          # north_star: losses within 1e-3 relative of the reference CPU path
+BF16_TIE_BAND = 0.05          # absolute logit gap below which the fp32 reference's own argmax is a near-tie for bf16 storage
+
+
+@pytest.mark.parametrize("name", ["ref_base_b2f2a1_q", "ref_base_b2f8a2_q", "ref_swin_b2f8a2_q"])
+def test_bf16_meets_north_star_on_identical_tensors(dev, name):
+    """perf mode -- the arithmetic bench.py times (bf16 storage, fp32 accumulate) -- against the fp32 reference on IDENTICAL
+    tensors (weights / pixels / spectrograms are bf16-representable, so nothing is rounded on load): all three losses within
+    1e-3 relative; argmax token ids equal to the reference's on every masked row whose fp32 top-1 / top-2 logit gap exceeds
+    BF16_TIE_BAND (rows inside the band cannot be decided by ANY evaluation with 8 mantissa bits: at random init the logits have
+    std ~0.5 and the gaps go down to 1e-4); the overall match rate is printed. b2f8a2 = the bench geometry."""
     g = torch.load(os.path.join(GOLD, name + ".pt"), weights_only=False)
     rc = g["recipe"]
-    spec = synth.ValorSpec(**rc["spec"])
-    sd = synth.make_state_dict(spec, seed=rc["weight_seed"])
-    batch = synth.make_batch(spec, batch=rc["batch"], frames=rc["frames"], audio_slices=rc["audio_slices"],
-                             txt_len=rc["txt_len"], seed=rc["batch_seed"])
+    assert rc["bf16_exact"]
+    spec, sd, batch = _recipe_tensors(rc)
     model = _native(spec, sd, torch.bfloat16, dev)
+    with torch.no_grad():
+        random.seed(rc["masker_seed"])
+        ev = model(batch, task=rc["task"], compute_loss=False)
+    total = same = decided = 0
+    for k, ids in g["eval"].items():
+        if "scores" not in k:
+            continue
+        got = ev[k].float().cpu().argmax(-1)
+        clear = g["eval"]["top2_margin"][k] > BF16_TIE_BAND
+        assert torch.equal(got[clear], ids[clear]), (k, int((got[clear] != ids[clear]).sum()), int(clear.sum()))
+        total += ids.numel(); same += int((got == ids).sum()); decided += int(clear.sum())
+    assert torch.equal(ev["txt_labels_caption"], g["eval"]["txt_labels_caption"])
     random.seed(rc["masker_seed"])
     out = model(batch, task=rc["task"], compute_loss=True)
     sum(out.values()).backward()
     torch.cuda.synchronize()
     rep = {}
     for k, v in g["steps"][0]["losses"].items():
-        rep[k] = (float(out[k]), v)
-        assert abs(float(out[k]) - v) <= 2e-2 * abs(v), (k, float(out[k]), v)
+        rep[k] = (float(out[k]), v, abs(float(out[k]) - v) / abs(v))
+    print(f"bf16 vs reference [{name}]: losses (native, reference, rel err) {rep}; argmax ids equal on {same}/{total} masked rows "
+          f"({decided} rows with a reference gap > {BF16_TIE_BAND}, all equal)")
+    for k, (a, v, e) in rep.items():
+        assert e <= BF16_LOSS_TOL, (k, a, v, e)
     ng = _native_grads(model)
     tot = float(torch.sqrt(sum((x.float() ** 2).sum() for x in ng.values())))
     ref_tot = g["steps"][0]["total_grad_norm"]
-    assert abs(tot - ref_tot) <= 0.1 * ref_tot, (tot, ref_tot)
-    print("bf16 losses (native, reference):", rep, "grad norm", tot, ref_tot)
+    assert abs(tot - ref_tot) <= 0.05 * ref_tot, (tot, ref_tot)
 
 
 @pytest.mark.parametrize("variant", ["clip", "swin"])

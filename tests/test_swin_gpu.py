@@ -60,7 +60,8 @@ def _ref_window_attention(qkv, table, heads, size, window, shifted):
     (torch.bfloat16, (16, 14, 14), True),                                          # shift in all three dims
     (torch.bfloat16, (2, 7, 7), False),                                            # one small window, N = 98 (sliced bias index)
     (torch.float32, (2, 14, 14), True), (torch.float32, (1, 7, 7), False),         # parity-mode instantiation
-])
+    (torch.float32, (8, 14, 14), True), (torch.float32, (8, 7, 7), False),         # ... at the PRODUCTION window (392 slots): the
+])                                                                                 # row-image-only (NOTR) backward
 @pytest.mark.parametrize("win_variant", [7, 5, 0])
 def test_window_attention(dev, dtype, size, shifted, win_variant):
     """kernel family bits: 1 = LDS-DMA double-buffered dQ pass, 2 = LDS-DMA forward, 4 = LDS-DMA dK/dV pass; 0 = the
@@ -109,15 +110,13 @@ def _window_attention_case(dev, dtype, size, shifted):
 
 
 def test_window_attention_rejects_oversized_window(dev):
-    """the window is LDS resident: the fp32 (parity) backward of a 392-slot window does not fit and says so (no fallback)"""
-    from valor_amd import kernels as K, lib
-    model = _model(dev, torch.float32)
-    geo = model._swin_geometry(8, 7, 7, False)
-    qkv = torch.zeros((8 * 49, 3 * 64), dtype=torch.float32, device=dev)
-    table = torch.zeros((model.spec.swin_table, 2), dtype=torch.float32, device=dev)
-    o, lse = K.win_attn_fwd(qkv, geo, table, 2, 1)                # the forward (K + V^T only) still fits
-    with pytest.raises(lib.ValorHipError):
-        K.win_attn_bwd(qkv, o, lse, torch.zeros_like(o), geo, table, 2, 1)
+    """the window is LDS resident: more than 448 slots do not fit and the entry point says so (no fallback)"""
+    from valor_amd import lib
+    so = lib.load()
+    z = torch.zeros(16, device=dev)
+    rc = so.valor_win_attn_fwd(torch.cuda.current_stream().cuda_stream, 1, z.data_ptr(), z.data_ptr(), z.data_ptr(), z.data_ptr(), z.data_ptr(),
+                               None, z.data_ptr(), 1, 1, 16 * 7 * 7, 2, 10, 5, 16 * 49, 0.17)
+    assert rc == -1
 
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])

@@ -57,6 +57,16 @@ class ParamArena:
         for name, (o, n, shape) in self.offsets.items():
             self.params[name].grad = self.grad[o:o + n].view(shape)
 
+    def grads_bound(self):
+        """True if every parameter's .grad is still its arena view (a stock zero_grad(set_to_none=True) or `p.grad = None`
+        detaches them: autograd would then allocate gradients OUTSIDE the arena and the optimizer / reducer would read zeros)."""
+        base, esz = self.grad.data_ptr(), self.grad.element_size()
+        for name, (o, n, _) in self.offsets.items():
+            g = self.params[name].grad
+            if g is None or g.data_ptr() != base + o * esz:
+                return False
+        return True
+
     def range_of(self, name):
         o, n, _ = self.offsets[name]
         return o, o + (n + self.chunk - 1) // self.chunk * self.chunk

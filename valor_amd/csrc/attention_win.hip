@@ -24,7 +24,8 @@
 // (dK/dV pass) are LDS resident, every wave then runs barrier free over its own 16-row tiles with the same register
 // layouts as the streaming kernels (attention.hip): scores transposed, so softmax statistics are per-lane scalars and the
 // probabilities feed the next MFMA from registers.
-// Both element types: bf16 (windows up to 448 slots) and the exact-fp32 parity instantiation (up to 192 slots: LDS).
+// Both element types: bf16 (windows up to 448 slots) and the exact-fp32 parity instantiation (backward above 192 slots: the
+// transposed images do not fit beside the row images, the NOTR instantiation gathers those fragments from the row images).
 #include "attn_common.h"
 #include <type_traits>
 #include <stdlib.h>
@@ -101,9 +102,22 @@ DEVINL typename Mma<T>::frag_t win_load_frag(const T* rowp, int dg, int g, bool 
 
 // acc[dt] += sum over the 64 slots tok0 .. tok0+63 of  X^T[d][slot] * p[slot]   (imgB rows = d, 2 tiles of 16 d).
 // p4[t]: this lane's values for slots tok0 + 16t + 4g + (0..3)  ->  acc[dt][r] = out[d = 16dt + 4g + r][this lane's fr].
-template <typename T>
+// ROWSRC (fp32 parity mode, windows whose four LDS images do not fit): no transposed image exists; `imgB` is the ROW image
+// [slot][d] (stride WinGeo<T>::RS) and the fragment is gathered with four strided scalar reads.
+template <typename T, bool ROWSRC = false>
 DEVINL void win_nat_mma(const char* imgB, int ts, int tok0, const f32x4_t (&p4)[4], f32x4_t (&acc)[2], int fr, int g) {
-    if constexpr (ElemTraits<T>::DT == VALOR_DT_BF16) {
+    if constexpr (ROWSRC) {
+        static_assert(ElemTraits<T>::DT == VALOR_DT_F32, "row-image source: fp32 parity mode only");
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt) {
+                const char* a = imgB + (tok0 + 16 * t + 4 * g) * WinGeo<T>::RS + (dt * 16 + fr) * 4;
+                const f32x4_t x = {*(const float*)a, *(const float*)(a + WinGeo<T>::RS), *(const float*)(a + 2 * WinGeo<T>::RS),
+                                   *(const float*)(a + 3 * WinGeo<T>::RS)};
+                acc[dt] = Mma<float>::mma(x, p4[t], acc[dt]);
+            }
+    } else if constexpr (ElemTraits<T>::DT == VALOR_DT_BF16) {
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
             const bf16x8_t pf = pack_bf16x8(p4[2 * kk], p4[2 * kk + 1]);
@@ -271,7 +285,7 @@ __global__ __launch_bounds__(512) void win_fwd_kernel(WinArgs p) {
 // quarter <= 8) of EVERY window of the group and keeps sum_windows dS[16 queries][all keys] in registers.
 // LDS: K, V row images, K^T image of the current window.
 #define WIN_MAXCH 7      // key chunks of 64: windows up to 448 slots
-template <typename T, bool SHIFT>
+template <typename T, bool SHIFT, bool NOTR = false>
 __global__ __launch_bounds__(512) void win_bwd_dq_kernel(WinArgs p) {
     typedef WinGeo<T> G;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -304,7 +318,7 @@ __global__ __launch_bounds__(512) void win_bwd_dq_kernel(WinArgs p) {
         __syncthreads();                                   // previous window's images / slot arrays are done with
         win_fill_slots(p, s, b, w, npad, tid, 512);
         __syncthreads();
-        win_stage<T, true, true>(qkv, ld, p.C + h * WIN_D, s.rows, N, npad, sK, sKt, tid, 512);
+        win_stage<T, true, !NOTR>(qkv, ld, p.C + h * WIN_D, s.rows, N, npad, sK, sKt, tid, 512);
         win_stage<T, true, false>(qkv, ld, 2 * p.C + h * WIN_D, s.rows, N, npad, sV, nullptr, tid, 512);
         __syncthreads();
         if (!active) continue;
@@ -359,7 +373,7 @@ __global__ __launch_bounds__(512) void win_bwd_dq_kernel(WinArgs p) {
                         bacc[c][kt][r] += ds;
                     }
                 }
-                win_nat_mma<T>(sKt, ts, k0, sacc, dqacc, fr, g);
+                win_nat_mma<T, NOTR>(NOTR ? sK : sKt, ts, k0, sacc, dqacc, fr, g);
             }
         }
         if (qok) {
@@ -807,7 +821,7 @@ static int win_lds_dkv_dma(int R, int npad) { return ((R + 3) & ~3) * 4 + 3 * np
 
 // ------------------------------------------------------------------------------------------ backward 2: dK, dV
 // grid (heads, B*nW), 1024 threads (one workgroup per CU: 16 waves share the four images). LDS: Q, dO row images, Q^T, dO^T images, lse / delta of the window.
-template <typename T, bool SHIFT>
+template <typename T, bool SHIFT, bool NOTR = false>
 __global__ __launch_bounds__(1024) void win_bwd_dkv_kernel(WinArgs p) {
     typedef WinGeo<T> G;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -831,8 +845,8 @@ __global__ __launch_bounds__(1024) void win_bwd_dkv_kernel(WinArgs p) {
     __syncthreads();
     const T* qkv = (const T*)p.qkv;
     const int64_t ld = 3 * (int64_t)p.C;
-    win_stage<T, true, true>(qkv, ld, h * WIN_D, s.rows, N, npad, sQ, sQt, tid, 1024);
-    win_stage<T, true, true>((const T*)p.dout, (int64_t)p.C, h * WIN_D, s.rows, N, npad, sdO, sdOt, tid, 1024);
+    win_stage<T, true, !NOTR>(qkv, ld, h * WIN_D, s.rows, N, npad, sQ, sQt, tid, 1024);
+    win_stage<T, true, !NOTR>((const T*)p.dout, (int64_t)p.C, h * WIN_D, s.rows, N, npad, sdO, sdOt, tid, 1024);
     __syncthreads();
 
     for (int kt = wave; kt * 16 < N; kt += 16) {
@@ -878,8 +892,8 @@ __global__ __launch_bounds__(1024) void win_bwd_dkv_kernel(WinArgs p) {
                     dpacc[t][r] = pr * (dpacc[t][r] - dl[r]);
                 }
             }
-            win_nat_mma<T>(sdOt, ts, q0, sacc, dvacc, fr, g);
-            win_nat_mma<T>(sQt, ts, q0, dpacc, dkacc, fr, g);
+            win_nat_mma<T, NOTR>(NOTR ? sdO : sdOt, ts, q0, sacc, dvacc, fr, g);
+            win_nat_mma<T, NOTR>(NOTR ? sQ : sQt, ts, q0, dpacc, dkacc, fr, g);
         }
         if (kok) {
             T* drow = (T*)p.dqkv + (int64_t)krow * ld + h * WIN_D;
@@ -949,6 +963,9 @@ static int win_groups(int B, int nW, int heads, int* wpb_out) {
     return (total + wpb - 1) / wpb;
 }
 template <typename T> static int win_lds_dkv(int R, int npad) { return win_small_bytes(R, npad) + 2 * npad * 4 + 2 * WinGeo<T>::RS * npad + 2 * WIN_D * (npad * (int)sizeof(T) + 16); }
+// fp32 parity mode without the transposed images (windows of more than 192 slots: the production 8 x 7 x 7 window has 392)
+static int win_lds_dq_notr(int R, int npad) { return win_small_bytes(R, npad) + 2 * WinGeo<float>::RS * npad; }
+static int win_lds_dkv_notr(int R, int npad) { return win_small_bytes(R, npad) + 2 * npad * 4 + 2 * WinGeo<float>::RS * npad; }
 #define WIN_LDS_MAX (160 * 1024)
 
 static bool win_check(const WinArgs& p) {
@@ -991,8 +1008,32 @@ static int win_fwd_launch(hipStream_t st, const WinArgs& p) {
 }
 template <typename T>
 static int win_bwd_launch(hipStream_t st, const WinArgs& p, void* dtable, int accumulate, int G) {
-    const int npad = (p.N + 63) & ~63, l1 = win_lds_dq<T>(p.R, npad), l2 = win_lds_dkv<T>(p.R, npad);
-    if (l1 > WIN_LDS_MAX || l2 > WIN_LDS_MAX || npad > 64 * WIN_MAXCH) return VALOR_ERR_ARG;
+    const int npad = (p.N + 63) & ~63;
+    int l1 = win_lds_dq<T>(p.R, npad), l2 = win_lds_dkv<T>(p.R, npad);
+    if (npad > 64 * WIN_MAXCH) return VALOR_ERR_ARG;
+    if constexpr (ElemTraits<T>::DT == VALOR_DT_F32) {
+        if (l1 > WIN_LDS_MAX || l2 > WIN_LDS_MAX) {       // big window in parity mode: row images only, strided transposed reads
+            l1 = win_lds_dq_notr(p.R, npad); l2 = win_lds_dkv_notr(p.R, npad);
+            if (l1 > WIN_LDS_MAX || l2 > WIN_LDS_MAX) return VALOR_ERR_ARG;
+            if (p.label) {
+                hipFuncSetAttribute((const void*)win_bwd_dq_kernel<float, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, l1);
+                hipFuncSetAttribute((const void*)win_bwd_dkv_kernel<float, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, l2);
+                hipLaunchKernelGGL((win_bwd_dq_kernel<float, true, true>), dim3(p.heads, 4, G), dim3(512), l1, st, p);
+                hipLaunchKernelGGL((win_bwd_dkv_kernel<float, true, true>), dim3(p.heads, p.B * p.nW), dim3(1024), l2, st, p);
+            } else {
+                hipFuncSetAttribute((const void*)win_bwd_dq_kernel<float, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, l1);
+                hipFuncSetAttribute((const void*)win_bwd_dkv_kernel<float, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, l2);
+                hipLaunchKernelGGL((win_bwd_dq_kernel<float, false, true>), dim3(p.heads, 4, G), dim3(512), l1, st, p);
+                hipLaunchKernelGGL((win_bwd_dkv_kernel<float, false, true>), dim3(p.heads, p.B * p.nW), dim3(1024), l2, st, p);
+            }
+            const int64_t n4f = (int64_t)p.heads * p.N * npad / 4;
+            if (G > 1) hipLaunchKernelGGL(win_dbias_reduce_kernel, dim3((unsigned)((n4f + 255) / 256 > 4096 ? 4096 : (n4f + 255) / 256)), dim3(256), 0, st, p.dbias_part, G, n4f);
+            hipLaunchKernelGGL(win_table_grad_kernel<T>, dim3((p.heads * p.R + 31) / 32), dim3(256), 0, st, p.dbias_part, p.rel, p.rel_inv, p.heads, p.R,
+                               p.N, npad, p.relc, (T*)dtable, accumulate);
+            return hipGetLastError() == hipSuccess ? VALOR_OK : VALOR_ERR_LAUNCH;
+        }
+    }
+    if (l1 > WIN_LDS_MAX || l2 > WIN_LDS_MAX) return VALOR_ERR_ARG;
     const int l1d = win_lds_dq_dma(p.R, npad), l2d = win_lds_dkv_dma(p.R, npad);
     const bool dkv_dma = (g_win_variant & 4) && ElemTraits<T>::DT == VALOR_DT_BF16 && (int64_t)p.rows_per_sample * 3 * p.C * 2 < 0x7fff0000ll;
     const bool dma = (g_win_variant & 1) && ElemTraits<T>::DT == VALOR_DT_BF16 && l1d <= WIN_LDS_MAX &&

@@ -21,6 +21,7 @@
 // Split-K (gridDim.y > 1) writes fp32 partial tiles to a workspace; valor_gemm launches a
 // second kernel that sums the slices and applies the epilogue.
 #include "gemm_common.h"
+#include <stdlib.h>
 
 template <typename T, bool TA, bool TB>
 __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs p) {
@@ -452,14 +453,25 @@ extern "C" int valor_gemm_set_variant(int v) { const int o = g_gemm_variant; if 
 // variant 4 (default): measured policy (tools/gemm_ab.py, profiles/r01_gemm_variants_*.json) -- the 8-phase kernel for
 //   the big-M forward GEMMs, long-K dgrad and the wgrad GEMMs; the 128x128 kernel (4 workgroups per CU hiding each
 //   other's prologue / epilogue) for small grids, short-K dgrad and everything with a K tail.
+// [0] NT min K for the 8-phase kernel, [1] 8-phase start skew, [2] min 256x256 tiles (forward / dgrad), [3] spare
+int g_gemm_policy[4] = {[] { const char* e = getenv("VALOR_GEMM_NT_MINK"); return e ? atoi(e) : 1536; }(),
+                        [] { const char* e = getenv("VALOR_GEMM_SKEW"); return e ? atoi(e) : 0; }(),
+                        [] { const char* e = getenv("VALOR_GEMM_MIN_TILES"); return e ? atoi(e) : 1024; }(), 0};
+extern "C" int valor_gemm_set_policy(int key, int value) {
+    if (key < 0 || key > 3) return VALOR_ERR_ARG;
+    const int old = g_gemm_policy[key];
+    if (value >= 0) g_gemm_policy[key] = value;
+    return old;
+}
+
 static bool use_8ph(int dtype, int transA, int transB, int M, int N, int K) {
     if (dtype != VALOR_DT_BF16 || g_gemm_variant < 3) return false;
     if ((K % 64) != 0 || K < 128 || M < 256 || N < 256) return false;
     if (g_gemm_variant == 3) return true;
     const int64_t tiles256 = (int64_t)((M + 255) / 256) * ((N + 255) / 256);
     if (transA && transB) return K >= 4096;                           // wgrad: K = tokens, split-K fills one round
-    if (!transA && !transB) return tiles256 >= 1024 && K >= 512;      // forward: >= 4 rounds of 256 workgroups
-    if (!transA && transB) return tiles256 >= 1024 && K >= 1536;      // dgrad: the 128x128 kernel wins at K = 768
+    if (!transA && !transB) return tiles256 >= g_gemm_policy[2] && K >= 512;      // forward: >= 4 rounds of 256 workgroups
+    if (!transA && transB) return tiles256 >= g_gemm_policy[2] && K >= g_gemm_policy[0];      // dgrad
     return false;
 }
 
@@ -552,7 +564,7 @@ extern "C" int valor_gemm(void* stream, int dtype, int transA, int transB, int M
     p.lda = lda; p.ldb = ldb; p.ldc = ldc; p.ldaux = ldaux;
     p.M = M; p.N = N; p.K = K; p.act = act; p.accumulate = accumulate; p.out_f32 = out_f32;
     p.alpha = alpha;
-    p.rowsum_out = rowsum_out; p.rowsum_acc = rowsum_accumulate; p.rowsum_ws = nullptr;
+    p.rowsum_out = rowsum_out; p.rowsum_acc = rowsum_accumulate; p.rowsum_ws = nullptr; p.skew = 0; p.fast_epi = 0;
     {
         const int64_t esz = dtype == VALOR_DT_BF16 ? 2 : 4;
         // direct: rows x ld with K valid in the last row; transposed: K rows of ld elements (caller guarantees

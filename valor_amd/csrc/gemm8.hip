@@ -73,6 +73,12 @@ __global__ __launch_bounds__(512, 2) void gemm_8ph_kernel(GemmArgs p) {
     }
     const int tm = logical / tiles_n, tn = logical - tm * tiles_n;
     const int m0 = tm << 8, n0 = tn << 8;
+    // start skew (GemmArgs::skew): every CU runs one workgroup and all tiles cost the same, so without it the whole chip
+    // reaches its epilogue (128 KiB of stores per CU) at the same moment round after round
+    if (p.skew && blockIdx.x < 256) {
+        const int n = ((blockIdx.x >> 3) & 3) * p.skew;
+        for (int i = 0; i < n; ++i) __builtin_amdgcn_s_sleep(64);
+    }
 
     const int nk_total = p.K / BK;
     int ks_begin = 0, ks_end = nk_total;
@@ -379,6 +385,7 @@ extern "C" int valor_gemm_set_fast_epilogue(int v) {
 
 void launch_gemm_8ph(hipStream_t st, int transA, int transB, const GemmArgs& p_in) {
     GemmArgs p = p_in;
+    p.skew = p.kslices > 1 ? 0 : g_gemm_policy[1];
     p.fast_epi = g_8ph_fast_epi && !p.out_f32 && !p.preact && !p.dact_aux && !p.accumulate && p.kslices <= 1 && (p.N & 7) == 0 &&
                  (p.ldc & 7) == 0 && !p.rowsum_out;
     const int tiles = ((p.M + 255) / 256) * ((p.N + 255) / 256);

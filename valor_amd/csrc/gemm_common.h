@@ -21,6 +21,7 @@ struct GemmArgs {
     void* rowsum_out;          // [M], C's element type (fp32 when out_f32), or null
     float* rowsum_ws;          // split-K partials [kslices][M] fp32
     int rowsum_acc;            // out += sums
+    int skew;                  // 8-phase kernels: start skew of the first round's workgroups (units of ~4096 cycles), 0 = off
     int fast_epi;              // 8-phase kernels: "plain" problem (bf16 C, no split-K / accumulate / preact / dact, N % 8 == 0, ldc % 8 == 0)
                                // -> bias / activation in registers, ONE bf16 pass through LDS
 };
@@ -142,3 +143,4 @@ DEVINL void epilogue_store8(const GemmArgs& p, int m, int n0, f32x4_t a0, f32x4_
 
 // 256x256 8-phase bf16 kernel (gemm8.hip). grid.x = tiles(256) * max(kslices, 1).
 void launch_gemm_8ph(hipStream_t st, int transA, int transB, const GemmArgs& p);
+extern int g_gemm_policy[4];      // valor_gemm_set_policy (gemm.hip)

@@ -28,9 +28,17 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* master, float* m, flo
                                                     float beta1, float beta2, float eps, float bc1, float bc2_sqrt,
                                                     const float* gscale_dev, int zero_grad) {
     const float gs = gscale_dev ? *gscale_dev : 1.0f;
+    // a non-finite global gradient norm (clip_finalize_kernel hands over gscale = NaN then) skips the whole update, the gradients are
+    // still cleared: what apex amp's dynamic loss scaler did for the reference on overflow (apex/amp/scaler.py:197-217), without a
+    // host sync
+    const bool skip = !(fabsf(gs) < INFINITY);
     for (int64_t c = blockIdx.x; c < nchunks; c += gridDim.x) {
         const int gid = chunk_group[c];
         if (gid < 0) continue;
+        if (skip) {
+            if (zero_grad) store4<T>(grad + c * ADAMW_CHUNK + threadIdx.x * 4, (f32x4_t){0.f, 0.f, 0.f, 0.f});
+            continue;
+        }
         const float lr = groups.lr[gid], wd = groups.wd[gid];
         const float step_size = lr * bc2_sqrt / bc1;
         const int64_t i = c * ADAMW_CHUNK + threadIdx.x * 4;
@@ -82,7 +90,7 @@ __global__ __launch_bounds__(256) void clip_finalize_kernel(const float* partial
         *total_norm = tn;
         float coef = 1.0f;
         if (max_norm > 0.f) { coef = max_norm / (tn + 1e-6f); if (coef > 1.0f) coef = 1.0f; }
-        *gscale = coef * norm_mul;
+        *gscale = (tn < INFINITY) ? coef * norm_mul : NAN;      // NaN: the update kernel skips the step
     }
 }
 

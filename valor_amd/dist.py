@@ -84,6 +84,9 @@ class Reducer:
         self.bucket_of = {n: i for i, b in enumerate(self.buckets) for n in b}
         self.expected = None           # per-bucket set of names that get a grad for the current task
         self.uses = None               # name -> number of gradient writes per backward (learnt on the first step)
+        self._tasks = {}               # task key -> (expected, uses): multi-task mixes alternate between a handful of task strings
+        self._task = None
+        self.window = None             # gradient accumulation: union of the names touched since the last reduction
         self.touched = {}              # name -> writes seen in the current backward
         self.pending, self.works = None, []
         self.comm_stream = torch.cuda.Stream() if arena.flat.is_cuda else None
@@ -122,14 +125,29 @@ class Reducer:
         else:
             self.works.append(dist.all_reduce(buf, op=dist.ReduceOp.SUM, async_op=True))
 
-    def prepare_backward(self):
+    def prepare_backward(self, defer=False):
+        """defer=True: a micro-step of a gradient accumulation window -- gradients keep accumulating in the arena and NO bucket
+        is reduced now (reducing a partially accumulated arena twice would count the earlier micro-steps world times); the
+        window is reduced once by finish_backward(last=True)."""
         self.touched = {}
         self.works = []
-        self.pending = [set(x) for x in self.expected] if self.expected is not None else None
+        self.defer = defer
+        self.pending = [set(x) for x in self.expected] if (self.expected is not None and not defer) else None
 
-    def finish_backward(self):
+    def finish_backward(self, last=True):
         """Wait for the bucket all-reduces (or, on the first step of a task, reduce everything at once and
-        learn which parameters are used and how many gradient writes each receives)."""
+        learn which parameters are used and how many gradient writes each receives).
+        Accumulation windows (prepare_backward(defer=True)): micro-steps only record what they touched; the last one
+        (`last=True`) reduces the whole arena once and returns the union of the touched names."""
+        if getattr(self, "defer", False):
+            self.window = (self.window or set()) | set(self.touched)
+            self.pending = None
+            if not last:
+                return set()
+            if self.world > 1:
+                dist.all_reduce(self.arena.grad, op=dist.ReduceOp.SUM)
+            names, self.window = self.window, None
+            return names
         if self.expected is None or self.touched != self.uses:
             if self.pending is not None:       # the used-parameter set changed (new task): redo synchronously
                 for w in self.works:
@@ -147,6 +165,10 @@ class Reducer:
         self.pending = None
         return set(self.touched)
 
-    def reset_task(self):
-        self.expected = None
-        self.uses = None
+    def reset_task(self, task=None):
+        """switch to another task string: its used-parameter set is restored if this reducer has seen the task before (so the
+        overlapped path resumes at once instead of re-learning with a synchronous whole-arena reduction on every switch)"""
+        if self._task is not None and self.expected is not None:
+            self._tasks[self._task] = (self.expected, self.uses)
+        self._task = task
+        self.expected, self.uses = self._tasks.get(task, (None, None)) if task is not None else (None, None)

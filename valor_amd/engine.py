@@ -25,21 +25,41 @@ class TrainEngine:
         self.reducer = vdist.Reducer(model.arena)
         if self.world > 1:
             model.gather_fn = vdist.packed_allgather_with_grads
+            # torch DDP broadcasts rank 0's parameters when it wraps the model (train_utils.py:232); the reducer replaces DDP, so the
+            # replicas are made identical here: parameters, and the optimizer's fp32 masters / moments (bf16 mode / resumed state)
+            torch.distributed.broadcast(model.arena.flat, 0)
+            for t in ((self.optimizer.master,) if self.optimizer.separate_master else ()) + (self.optimizer.exp_avg, self.optimizer.exp_avg_sq):
+                torch.distributed.broadcast(t, 0)
         self.global_step = 0
         self.grad_norm = float(getattr(opts, "grad_norm", 5.0))
         self._task = None
+        self._micro = 0
+        if getattr(opts, "dataset_mix_type", "random") not in ("random", "round-robin", "accum"):
+            raise NotImplementedError(f"dataset_mix_type={opts.dataset_mix_type}")
 
-    def train_step(self, batch, task):
+    def train_step(self, batch, task, accum_steps=1):
+        """One iteration of conduct_train's loop body (train_utils.py:302-364). accum_steps = n > 1 is dataset_mix_type='accum'
+        (:311-317,341: loss / n, one optimizer step every n iterations, gradients of the n micro-steps -- possibly of different
+        tasks -- summed): the arena simply keeps accumulating, the data-parallel reduction runs once per window."""
         model, opt = self.model, self.optimizer
+        if not model.arena.grads_bound():
+            raise RuntimeError("parameter .grad tensors were detached from the gradient arena (p.grad = None / zero_grad(set_to_none=True) "
+                               "on the raw parameters?): call model.zero_grad() (it re-binds) before the next step")
+        accum = accum_steps > 1
         if task != self._task:
-            self.reducer.reset_task()
+            self.reducer.reset_task(task)
             self._task = task
         model.train()
-        self.reducer.prepare_backward()
+        self.reducer.prepare_backward(defer=accum)
         loss_dict = model(batch, task=task, compute_loss=True)
         loss = sum(loss_dict.values())
-        loss.backward()
-        active = self.reducer.finish_backward()
+        (loss / accum_steps if accum else loss).backward()
+        self._micro += 1
+        last = (not accum) or self._micro % accum_steps == 0
+        active = self.reducer.finish_backward(last=last)
+        if not last:
+            loss_dict["total_loss"] = loss.detach()
+            return loss_dict
         self.global_step += 1
         if getattr(self.opts, "num_train_steps", 0):
             ratio = get_lr_sched(self.global_step, self.opts)                      # train_utils.py:344-347

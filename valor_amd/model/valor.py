@@ -139,10 +139,55 @@ class VALOR(nn.Module):
     # ------------------------------------------------------------------ checkpoint layout
     @classmethod
     def from_pretrained(cls, opts, state_dict, **kw):
+        """modeling.py:107-115: construct (randomly initialised modules, init_weights :90-105), then load `state_dict` with
+        strict=False. The reference's constructor also reads the CLIP / BERT / AST / VideoSwin component weights from
+        ./pretrained_weights (modeling.py:512-660); here those come through `state_dict` (valor_amd.checkpoint.load_pretrained_components
+        maps the component files to VALOR keys), and whatever `state_dict` does not cover keeps its initialisation. The keys that
+        stayed at their initial value are kept in `model.missing_keys`."""
         model = cls(opts, **kw)
+        model.init_parameters(seed=int(_opt(opts, "seed", 42)))
+        model.missing_keys, model.unexpected_keys = [], []
         if state_dict:
-            model.load_state_dict(state_dict, strict=False)
+            model.missing_keys, model.unexpected_keys = model.load_state_dict(state_dict, strict=False)
+        else:
+            model.missing_keys = [r for _, _, refs in model.table for r in refs if r != "cls.decoder.weight"]
         return model
+
+    def init_parameters(self, seed=42):
+        """The reference's initialisation (modeling.py:90-105 init_weights: Linear / Embedding weights N(0, 0.02), LayerNorm
+        gain 1, biases 0; :338-341 type / frame embeddings 0.02 N(0,1); pretrain.py:117 contra_temp 0.07; clip.py:295
+        logit_scale ln(1/0.07)); every rank seeds the same generator, so replicas start identical (TrainEngine broadcasts rank 0's
+        arena besides). Component weights (CLIP, VideoSwin, AST, BERT) are pretrained in the reference; without their files they
+        get the same N(0, 0.02) / 1 / 0 policy."""
+        from ..synth import state_dict_layout
+        kinds = {k: kind for k, _, kind in state_dict_layout(self.spec)}
+        gen = torch.Generator(device="cpu").manual_seed(int(seed))
+        with torch.no_grad():
+            for name, shape, refs in self.table:
+                kind = kinds.get(refs[0], "w")
+                p = self.P[name]
+                if kind == "g":
+                    p.fill_(1.0)
+                elif kind == "b":
+                    p.zero_()
+                elif kind == "s":
+                    p.fill_(math.log(1 / 0.07) if "logit_scale" in name else 0.07)
+                else:
+                    p.copy_((0.02 * torch.randn(shape, generator=gen)).to(p.dtype))
+        self._params_changed()
+
+    def _params_changed(self):
+        """parameters were rewritten behind the optimizer's back: refresh its fp32 masters (bf16 mode)"""
+        for ref in list(getattr(self, "_optimizers", [])):
+            opt = ref()
+            if opt is not None:
+                opt.sync_master()
+
+    def zero_grad(self, set_to_none=False):
+        """Gradients live in the flat arena and must stay bound to it (ops.GradSink, the reducer and the fused optimizer read the
+        arena): zero in place and re-attach the views whatever `set_to_none` says."""
+        self.arena.grad.zero_()
+        self.arena.rebind_grads()
 
     def state_dict(self, *a, **k):
         """Reference-keyed state dict (fp32 CPU-agnostic views of the arena parameters)."""
@@ -188,6 +233,7 @@ class VALOR(nn.Module):
             k.endswith("relative_position_index") or (k.startswith("txt_encoder.") and "multimodal_encoder." + k[12:] in used)))]
         if strict and (missing or unexpected):
             raise RuntimeError(f"load_state_dict: missing {missing[:5]} unexpected {unexpected[:5]}")
+        self._params_changed()
         return missing, unexpected
 
     def ref_named_groups(self):

@@ -8,6 +8,7 @@ new_lr, new_params_name; state_dict() uses the HF per-parameter layout {step, ex
 """
 import ctypes
 import math
+import weakref
 
 import torch
 
@@ -74,6 +75,16 @@ class FusedAdamW:
         self.total_norm = torch.zeros((), **f32)
         self.gscale = torch.ones((), **f32)
         self._tables = {}
+        # the model tells its optimizers when parameters are rewritten (load_state_dict / init_parameters after construction)
+        if not hasattr(model, "_optimizers"):
+            model._optimizers = []
+        model._optimizers.append(weakref.ref(self))
+
+    def sync_master(self):
+        """fp32 masters := current parameters (bf16 mode). Called by VALOR.load_state_dict / init_parameters, so loading weights AFTER
+        the optimizer exists cannot be overwritten by stale masters on the next step."""
+        if self.separate_master:
+            self.master.copy_(self.arena.flat)
 
     def init_master_from(self, state_dict_fp32):
         """Seed the fp32 masters from full-precision weights (instead of the rounded bf16 parameters)."""
@@ -98,11 +109,14 @@ class FusedAdamW:
         self.arena.grad.zero_()
 
     def _table(self, active_names):
+        """chunk -> group table of a set of active tensors, cached per set (multi-task mixes alternate between a handful)"""
         key = frozenset(active_names)
         t = self._tables.get(key)
         if t is None:
+            if len(self._tables) >= 16:
+                self._tables.pop(next(iter(self._tables)))
             t = self.arena.chunk_group_table(active=key)
-            self._tables = {key: t}
+            self._tables[key] = t
         return t
 
     def step(self, active_names=None, max_grad_norm=-1.0, world_size=1):
@@ -124,7 +138,7 @@ class FusedAdamW:
         lr = (ctypes.c_float * self.N_GROUPS)(*[g["lr"] for g in self.param_groups])
         wd = (ctypes.c_float * self.N_GROUPS)(*[g["weight_decay"] for g in self.param_groups])
         for st, ns in by_step.items():
-            tb = table if len(by_step) == 1 else a.chunk_group_table(active=set(ns))
+            tb = table if len(by_step) == 1 else self._table(ns)
             lib.call("valor_adamw", _stream(), dt, _ptr(self.master), _ptr(self.exp_avg), _ptr(self.exp_avg_sq), _ptr(a.grad),
                      _ptr(a.flat) if self.separate_master else None, _ptr(tb), a.numel, lr, wd, self.N_GROUPS,
                      self.betas[0], self.betas[1], self.eps, int(st), int(self.correct_bias), _ptr(self.gscale), 1)
@@ -196,6 +210,7 @@ class FusedAdamW:
             self.exp_avg_sq[o:o + n].copy_(st["exp_avg_sq"].reshape(-1))
         for g, s_ in zip(self.param_groups, sd["param_groups"]):
             g.update({k: s_[k] for k in ("init_lr", "lr", "weight_decay") if k in s_})
+        self.sync_master()          # the reference's checkpoint carries no fp32 masters: re-derive them from the loaded parameters
 
     # ---- compact native layout (one entry per arena tensor)
     def state_dict(self):
@@ -204,7 +219,10 @@ class FusedAdamW:
             if self.steps[name] > 0:
                 state[i] = {"step": self.steps[name], "exp_avg": self.exp_avg[o:o + n].view(shape).clone(),
                             "exp_avg_sq": self.exp_avg_sq[o:o + n].view(shape).clone()}
-        return {"state": state, "param_groups": [dict(g) for g in self.param_groups], "names": list(self.arena.offsets)}
+        out = {"state": state, "param_groups": [dict(g) for g in self.param_groups], "names": list(self.arena.offsets)}
+        if self.separate_master:
+            out["master"] = self.master.clone()         # bf16 mode: the fp32 weights the update really runs on
+        return out
 
     def load_state_dict(self, sd):
         names = sd.get("names", list(self.arena.offsets))
@@ -216,3 +234,9 @@ class FusedAdamW:
             self.exp_avg_sq[o:o + n].copy_(st["exp_avg_sq"].reshape(-1))
         for g, s in zip(self.param_groups, sd.get("param_groups", [])):
             g.update({k: s[k] for k in ("init_lr", "lr", "weight_decay") if k in s})
+        if self.separate_master:
+            if sd.get("master") is not None and sd["master"].numel() == self.master.numel():
+                self.master.copy_(sd["master"])
+                self.arena.flat.copy_(self.master)     # parameters = rounded masters, exactly the state that was saved
+            else:
+                self.sync_master()

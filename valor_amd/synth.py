@@ -257,9 +257,16 @@ def state_dict_layout(spec: ValorSpec):
     return L
 
 
-def make_state_dict(spec: ValorSpec, seed: int = 50, w_std: float = 0.02):
+def _bf16_exact(t):
+    """nearest bf16-representable fp32 value: the SAME tensor then loads bit-identically into the fp32 reference / oracle and
+    into the bf16 native model ("identical synthetic tensors" for the bf16 parity runs)"""
+    return t.to(torch.bfloat16).to(torch.float32)
+
+
+def make_state_dict(spec: ValorSpec, seed: int = 50, w_std: float = 0.02, bf16_exact: bool = False):
     """Seeded random-init state dict (fp32, CPU). LN gains 1 + 0.1 N(0,1), biases 0.02 N(0,1),
-    weights w_std N(0,1); logit_scale = ln(1/0.07), contra_temp = 0.07; cls.decoder.weight is tied."""
+    weights w_std N(0,1); logit_scale = ln(1/0.07), contra_temp = 0.07; cls.decoder.weight is tied.
+    bf16_exact: every floating tensor is rounded to a bf16-representable fp32 value (aliases stay aliases)."""
     g = torch.Generator(device="cpu").manual_seed(seed)
     sd = {}
     import math
@@ -278,14 +285,20 @@ def make_state_dict(spec: ValorSpec, seed: int = 50, w_std: float = 0.02):
             sd[k] = 0.02 * torch.randn(shape, generator=g)
         else:
             sd[k] = w_std * torch.randn(shape, generator=g)
+        if bf16_exact and kind not in ("tied", "alias", "relidx"):
+            sd[k] = _bf16_exact(sd[k])
     return sd
 
 
-def make_batch(spec: ValorSpec, batch: int, frames: int = 8, audio_slices: int = 2, txt_len: int = 32, seed: int = 50):
-    """Synthetic batch with the schema of data/data.py:423-428 (valor_collate), CPU tensors."""
+def make_batch(spec: ValorSpec, batch: int, frames: int = 8, audio_slices: int = 2, txt_len: int = 32, seed: int = 50,
+               bf16_exact: bool = False):
+    """Synthetic batch with the schema of data/data.py:423-428 (valor_collate), CPU tensors.
+    bf16_exact: pixels / spectrograms are bf16-representable fp32 values (see make_state_dict)."""
     g = torch.Generator(device="cpu").manual_seed(seed)
     video = torch.randn((batch, frames, 3, spec.resolution, spec.resolution), generator=g)
     audio = torch.randn((batch, audio_slices, spec.melbins, spec.target_len), generator=g)
+    if bf16_exact:
+        video, audio = _bf16_exact(video), _bf16_exact(audio)
     bert = torch.zeros((batch, txt_len), dtype=torch.long)
     clip = torch.zeros((batch, txt_len), dtype=torch.long)
     lo = min(1000, spec.vocab // 2)
