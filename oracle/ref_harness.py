@@ -41,7 +41,7 @@ def _install():
     import torch.distributed as dist
     if not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29677")
+        os.environ.setdefault("MASTER_PORT", str(29600 + os.getpid() % 300))    # per process: several harness users may coexist
         dist.init_process_group("gloo", rank=0, world_size=1)
     _installed = True
 
@@ -79,16 +79,29 @@ def _fake_bert_sd(cfg):
     return sd
 
 
-def _fake_clip_sd():
-    # shapes demanded by model/clip.py:470-515 for ViT-B/16 (12+12 blocks); values are overwritten later
+# CLIP checkpoints the reference's load_clip_model accepts (modeling.py:560-573); build_model derives every hyper-parameter from
+# tensor SHAPES and layer COUNTS (clip.py:470-515), so `layers` can be cut for a fast pin: (vision width, vision layers, patch,
+# native grid, joint embed dim, text width, text layers)
+CLIP_KINDS = {
+    "clip_vit_base_16": (768, 12, 16, 14, 512, 512, 12),
+    "clip_vit_large_14_336px": (1024, 24, 14, 24, 768, 768, 12),       # 336 px native: the positional embedding is resized to
+    "clip_vit_large_14": (1024, 24, 14, 16, 768, 768, 12),             # opts.video_resolution at construction (clip.py:481-491)
+}
+
+
+def _fake_clip_sd(kind="clip_vit_base_16", vision_layers=None, text_layers=None):
+    # values are overwritten later from the seeded canonical state dict
     z = torch.zeros
-    sd = {"visual.conv1.weight": z(768, 3, 16, 16), "visual.class_embedding": z(768),
-          "visual.positional_embedding": z(197, 768), "visual.proj": z(768, 512),
-          "visual.ln_pre.weight": z(768), "visual.ln_pre.bias": z(768), "visual.ln_post.weight": z(768),
-          "visual.ln_post.bias": z(768), "text_projection": z(512, 512), "positional_embedding": z(77, 512),
-          "token_embedding.weight": z(49408, 512), "ln_final.weight": z(512), "ln_final.bias": z(512),
+    W, VL, P, G, E, TW, TL = CLIP_KINDS[kind]
+    VL = vision_layers or VL
+    TL = text_layers or TL
+    sd = {"visual.conv1.weight": z(W, 3, P, P), "visual.class_embedding": z(W),
+          "visual.positional_embedding": z(G * G + 1, W), "visual.proj": z(W, E),
+          "visual.ln_pre.weight": z(W), "visual.ln_pre.bias": z(W), "visual.ln_post.weight": z(W),
+          "visual.ln_post.bias": z(W), "text_projection": z(TW, E), "positional_embedding": z(77, TW),
+          "token_embedding.weight": z(49408, TW), "ln_final.weight": z(TW), "ln_final.bias": z(TW),
           "logit_scale": z(())}
-    for pre, w, n in (("visual.transformer", 768, 12), ("transformer", 512, 12)):
+    for pre, w, n in (("visual.transformer", W, VL), ("transformer", TW, TL)):
         for i in range(n):
             p = f"{pre}.resblocks.{i}."
             sd[p + "attn.in_proj_weight"] = z(3 * w, w); sd[p + "attn.in_proj_bias"] = z(3 * w)
@@ -136,14 +149,18 @@ class _FakeJit:
         return self._sd
 
 
-def build_reference(opts=None, state_dict=None, dropout=0.0):
-    """Instantiate the reference VALOR on CPU (fp32). state_dict: canonical VALOR state dict to load (strict)."""
+def build_reference(opts=None, state_dict=None, dropout=0.0, clip_layers=None, bert_layers=None):
+    """Instantiate the reference VALOR on CPU (fp32). state_dict: canonical VALOR state dict to load (strict).
+    clip_layers = (vision, text) / bert_layers: build shallower component stacks (the reference derives the CLIP depth from the
+    checkpoint's keys and the BERT depth from its json config), for pins that have to finish in seconds."""
     _install()
     opts = opts or default_opts()
+    bert_cfg = dict(BERT_CFG, num_hidden_layers=bert_layers) if bert_layers else BERT_CFG
+    clip_kind = next((t for t in (opts.txt_encoder_type, opts.video_encoder_type) if t.startswith("clip")), "clip_vit_base_16")
     tmp = tempfile.mkdtemp(prefix="valor_ref_")
     os.makedirs(os.path.join(tmp, "pretrained_weights"))
     with open(os.path.join(tmp, "pretrained_weights", "bert_base_uncased_config.json"), "w") as f:
-        json.dump(BERT_CFG, f)
+        json.dump(bert_cfg, f)
     write_vocab(os.path.join(tmp, "pretrained_weights", "bert-base-uncased-vocab.txt"))
     cwd = os.getcwd()
     os.chdir(tmp)
@@ -152,7 +169,7 @@ def build_reference(opts=None, state_dict=None, dropout=0.0):
     def fake_load(path, *a, **k):
         p = str(path)
         if "bert-base-uncased.bin" in p:
-            return _fake_bert_sd(BERT_CFG)
+            return _fake_bert_sd(bert_cfg)
         if "audioset" in p:
             return _fake_ast_sd()
         if "videoswin" in p or "video-swin" in p:
@@ -163,7 +180,7 @@ def build_reference(opts=None, state_dict=None, dropout=0.0):
         return real_load(path, *a, **k)
 
     torch.load = fake_load
-    torch.jit.load = lambda path, *a, **k: _FakeJit(_fake_clip_sd())
+    torch.jit.load = lambda path, *a, **k: _FakeJit(_fake_clip_sd(clip_kind, *(clip_layers or (None, None))))
     try:
         from model.pretrain import VALOR
         model = VALOR.from_pretrained(opts, {})
@@ -184,7 +201,8 @@ def build_reference(opts=None, state_dict=None, dropout=0.0):
 
 
 if __name__ == "__main__":
-    m = build_reference()
+    over = dict(a.split("=", 1) for a in sys.argv[1:])
+    m = build_reference(default_opts(**{k: (v == "True" if v in ("True", "False") else v) for k, v in over.items()}) if over else None)
     sd = m.state_dict()
     n = sum(p.numel() for p in m.parameters())
     print("params", n, "tensors", len(sd))

@@ -1,0 +1,164 @@
+"""Model-level data-parallel correctness on the GPU: 2 processes share cuda:0 (gloo: RCCL refuses two ranks on one device; the
+collectives' SEMANTICS are what is under test, the transport is covered by bench.py --gpus N over nccl), each runs the native fp32
+model on its half of a batch through TrainEngine (packed feature all-gather with local-slice backward, gradient reducer on the
+flat arena, fused optimizer). Expectations come from the CPU oracle with the reference's gather semantics restated
+(utils/distributed.py:38-93: every rank computes the contrastive loss on the GLOBAL batch, backward keeps the local slice only;
+DDP then averages the gradients -- so the contrastive gradient is 1/world of the single-process one, the reference's quirk):
+  * contra_loss is identical on both ranks and equals the single-process loss on the full batch;
+  * caption / mlm losses are each rank's own;
+  * the reduced gradient (arena sum / world) equals the mean over ranks of the oracle's per-rank gradients, and for parameters
+    that only feed the contrastive loss it is 1/world of the single-process full-batch gradient;
+  * after an optimizer step (overlapped bucket path on the second step) the replicas hold identical parameters."""
+import os
+import random
+import sys
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+pytestmark = pytest.mark.gpu
+TASK = "pt_contra%tva%tv%ta_caption%tva%tv%ta_mlm%tva"
+B_LOCAL, FRAMES, SLICES = 2, 2, 1
+
+
+def _setup():
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    from valor_amd import synth
+    spec = synth.tiny_spec()
+    sd = synth.make_state_dict(spec, seed=3, w_std=0.05)
+    full = synth.make_batch(spec, batch=2 * B_LOCAL, frames=FRAMES, audio_slices=SLICES, txt_len=32, seed=4)
+    return spec, sd, full
+
+
+def _half(full, r):
+    sl = slice(r * B_LOCAL, (r + 1) * B_LOCAL)
+    return {"ids": full["ids"][sl], "video_pixels": full["video_pixels"][sl], "audio_spectrograms": full["audio_spectrograms"][sl],
+            "txt_tokens": {k: v[sl] for k, v in full["txt_tokens"].items()}}
+
+
+def _worker(rank, world, port, outdir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from types import SimpleNamespace
+        spec, sd, full = _setup()
+        from valor_amd.engine import TrainEngine
+        from valor_amd.model.valor import VALOR
+        torch.cuda.set_device(0)
+        model = VALOR({"dropout": 0.0}, spec=spec, dtype=torch.float32, device="cuda:0")
+        if rank == 0:
+            model.load_state_dict(sd, strict=True)          # rank 1 starts from zeros: TrainEngine's broadcast must fix that
+        opts = SimpleNamespace(learning_rate=1e-3, weight_decay=0.01, clip_lr=1e-3, clip_lr_text=1e-3, new_lr=0.0, decoder_lr=-1,
+                               betas=[0.9, 0.98], warmup_ratio=0.1, num_train_steps=10, scheduler="warmup_linear", grad_norm=5.0)
+        eng = TrainEngine(model, opts, manage_gc=False)
+        assert eng.world == 2 and model.gather_fn is not None
+        batch = _half(full, rank)
+        model.train()
+        random.seed(100 + rank)
+        eng.reducer.prepare_backward()
+        out = model(batch, task=TASK, compute_loss=True)
+        sum(out.values()).backward()
+        eng.reducer.finish_backward()
+        torch.cuda.synchronize()
+        grads = {}
+        for name, shape, refs in model.table:
+            g = model.P[name].grad.detach().cpu().clone()
+            if len(refs) == 1 or refs[1] == "cls.decoder.weight":
+                grads[refs[0]] = g
+            else:
+                rows = shape[0] // len(refs)
+                for i, r in enumerate(refs):
+                    grads[r] = g[i * rows:(i + 1) * rows]
+        model.arena.grad.zero_()
+        # two real optimizer steps (first: synchronous learn-the-used-set path, second: overlapped buckets)
+        for step in range(2):
+            random.seed(200 + 10 * step + rank)
+            eng.train_step(batch, TASK)
+        torch.cuda.synchronize()
+        torch.save({"losses": {k: float(v) for k, v in out.items()}, "grads": grads, "flat": model.arena.flat.detach().cpu().clone()},
+                   os.path.join(outdir, f"rank{rank}.pt"))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_ranks_match_the_reference_semantics(dev, tmp_path):
+    spec, sd, full = _setup()
+    import valor_oracle as VO
+    from valor_amd import synth
+    port = 29700 + (os.getpid() % 200)
+    mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    res = [torch.load(os.path.join(str(tmp_path), f"rank{r}.pt"), weights_only=False) for r in range(2)]
+
+    vocab = synth.synthetic_vocab(spec.vocab)
+    # features every rank contributes to the gather (constants for the OTHER rank's backward)
+    feats = []
+    with torch.no_grad():
+        for r in range(2):
+            orc = VO.Oracle(spec, sd, vocab_tokens=vocab)
+            ev = orc.forward_pt(_half(full, r), "pt_contra%tva%tv%ta", compute_loss=False)
+            feats.append({k: ev[k] for k in ("feat_t", "feat_v", "feat_a", "txt_tokens")})
+    want_grads, want_losses = [], []
+    for r in range(2):
+        sd_r = VO.trainable_copy(sd)
+        orc = VO.Oracle(spec, sd_r, vocab_tokens=vocab)
+
+        def gather_feat(f, r=r):
+            key = {32: "feat_t", FRAMES: "feat_v", SLICES: "feat_a"}[f.shape[1]]
+            parts = [feats[q][key] for q in range(2)]
+            parts[r] = f                                             # the local slice carries the gradient (utils/distributed.py:62-72)
+            return torch.cat(parts, dim=0)
+
+        def gather_tok(t, r=r):
+            return torch.cat([feats[q]["txt_tokens"] for q in range(2)], dim=0)
+
+        random.seed(100 + r)
+        out = orc.forward_pt(_half(full, r), TASK, compute_loss=True, gather=(gather_feat, gather_tok))
+        sum(out.values()).backward()
+        want_losses.append({k: float(v) for k, v in out.items()})
+        want_grads.append({k: (p.grad.clone() if p.grad is not None else None) for k, p in sd_r.items()
+                           if p.is_floating_point() and not VO.is_alias_key(k)})
+    # single process on the full batch: the contrastive loss (masker-independent) and its gradients
+    sd_f = VO.trainable_copy(sd)
+    lf = VO.Oracle(spec, sd_f, vocab_tokens=vocab).forward_pt(full, "pt_contra%tva%tv%ta", compute_loss=True)["contra_loss"]
+    lf.backward()
+    full_contra = float(lf)
+
+    for r in range(2):
+        for k, v in want_losses[r].items():
+            assert abs(res[r]["losses"][k] - v) <= 1e-4 * abs(v), (r, k, res[r]["losses"][k], v)
+        assert abs(res[r]["losses"]["contra_loss"] - full_contra) <= 1e-4 * abs(full_contra)
+    assert res[0]["losses"]["contra_loss"] == pytest.approx(res[1]["losses"]["contra_loss"], rel=1e-6)
+    # the reducer leaves the SUM over ranks in both arenas; DDP's mean is folded into the optimizer
+    bad = []
+    for k in want_grads[0]:
+        parts = [g[k] for g in want_grads if g[k] is not None]
+        for r in range(2):
+            got = res[r]["grads"][k].double() / 2.0
+            if not parts:
+                assert float(got.abs().max()) == 0.0, k
+                continue
+            want = sum(p.double() for p in parts) / 2.0
+            scale = max(float(want.norm()), 1e-5 * want.numel() ** 0.5)
+            err = float((got.reshape(want.shape) - want).norm()) / scale
+            if err > 2e-3:
+                bad.append((r, k, err))
+    assert not bad, bad[:8]
+    # the reference's quirk, stated directly: the CLIP text tower only feeds the contrastive loss, each rank back-propagates the
+    # local slice of the gathered-feature gradient, DDP averages -> 1/world of the single-process full-batch gradient
+    for k in ("clip_model.text_projection", "clip_model.transformer.resblocks.0.attn.in_proj_weight", "clip_model.token_embedding.weight"):
+        got = res[0]["grads"][k].double() / 2.0
+        want = sd_f[k].grad.double() / 2.0
+        assert float((got.reshape(want.shape) - want).norm()) <= 2e-3 * float(want.norm()), k
+    # ... while parameters applied to the GATHERED features (fine-weight heads, temperature) see the full gradient on every rank
+    for k in ("text_fine_weight.0.weight", "clip_model.logit_scale"):
+        got = res[0]["grads"][k].double() / 2.0
+        want = sd_f[k].grad.double()
+        assert float((got.reshape(want.shape) - want).norm()) <= 2e-3 * float(want.norm()) + 1e-9, k
+    assert torch.equal(res[0]["flat"], res[1]["flat"]), "replicas diverged after two optimizer steps"
+    assert float(res[0]["flat"].abs().sum()) > 0

@@ -142,6 +142,15 @@ def tiny_spec():
                      target_len=64, aud_patch=16, hidden=128, layers=2, inter=256, vocab=1200, max_pos=64)
 
 
+def shallow_base_spec(video_encoder="clip"):
+    """VALOR-base WIDTHS (768 / 512 / 12 heads, 224 px, 10 s audio geometry) on a 2-layer stack with a small vocabulary: a small
+    invocation whose bf16 rounding behaves like the real model's (the tiny specs' 128-wide dot products average 6x fewer
+    terms, so their bf16 noise is ~2.5x larger than anything the benchmarked configuration sees)."""
+    if video_encoder == "swin":
+        return ValorSpec(video_encoder="swin", txt_encoder="bert", swin_depths=(1, 1, 2, 1), aud_layers=2, layers=2, vocab=4000, max_pos=64)
+    return ValorSpec(vis_layers=2, txt_layers=2, aud_layers=2, layers=2, vocab=4000, clip_vocab=4000, max_pos=64)
+
+
 def _audio_bert_heads(spec, add):
     """AST + multimodal BERT + prediction head keys (both variants)."""
     H, AW = spec.hidden, spec.aud_width
