@@ -450,8 +450,10 @@ class Oracle:
             if "v" in "".join(contra_task):
                 if self.spec.video_encoder == "swin":                                            # modeling.py:388-389 mean over tokens
                     feat_v = F.normalize(F.linear(video_output.mean(dim=2), w("contra_head_v.linear.weight")), dim=-1)
-                else:
+                elif self.spec.clip_heads:
                     feat_v = F.normalize(video_output[:, :, 0] @ w("clip_model.visual.proj"), dim=-1)  # :91, modeling.py:387
+                else:            # CLIP video encoder beside a BERT text encoder (config/pretrain-VALOR-large.json): Contra_head, pretrain.py:93-97
+                    feat_v = F.normalize(F.linear(video_output[:, :, 0], w("contra_head_v.linear.weight")), dim=-1)
                 if compute_loss and gather:
                     feat_v = gather[0](feat_v)
             if "a" in "".join(contra_task):

@@ -107,6 +107,85 @@ def test_tiny_fp32_matches_oracle(dev, variant):
     assert torch.equal(oe["txt_labels_caption"], ne["txt_labels_caption"])
 
 
+def test_clip_video_encoder_with_shared_bert_text(dev):
+    """The encoder combination of the reference's shipped LARGE configuration (config/pretrain-VALOR-large.json:10-15: a CLIP ViT
+    with patch 14 whose width differs from the decoder's + bert_base_uncased text shared with the multimodal encoder,
+    use_task_prompt, contra_loss_ratio 1.5, Contra_head linears beside an untouched CLIP text tower) at unit-test size, on both of
+    its task strings: losses within 1e-4 of the oracle, every gradient, argmax ids, and the checkpoint layout."""
+    from valor_amd import synth
+    from valor_amd.model.valor import VALOR
+    import valor_oracle as VO
+    spec = synth.tiny_clip_bert_spec()
+    sd = synth.make_state_dict(spec, seed=3, w_std=0.05)
+    batch = synth.make_batch(spec, batch=3, frames=2, audio_slices=1, txt_len=32, seed=4)
+    for task in ("pt_contra%tva%tv%ta_caption%tva%tv%ta", "pt_contra%tv_caption%tv_mlm%tv"):
+        sd_o = VO.trainable_copy(sd)
+        orc = VO.Oracle(spec, sd_o, vocab_tokens=synth.synthetic_vocab(spec.vocab), use_task_prompt=True, contra_loss_ratio=1.5)
+        model = VALOR({"dropout": 0.0, "use_task_prompt": True, "contra_loss_ratio": 1.5}, spec=spec, dtype=torch.float32, device=dev)
+        model.load_state_dict(sd, strict=True)
+        model.train()
+        assert list(model.state_dict().keys()) == [k for k, _, kind in synth.state_dict_layout(spec)] or \
+            set(model.state_dict().keys()) == {k for k, _, kind in synth.state_dict_layout(spec)}
+        random.seed(11); o_out = orc.forward_pt(batch, task, compute_loss=True); sum(o_out.values()).backward()
+        random.seed(11); n_out = model(batch, task=task, compute_loss=True); sum(n_out.values()).backward()
+        assert set(o_out) == set(n_out)
+        for k in o_out:
+            a, b = float(o_out[k]), float(n_out[k])
+            assert abs(a - b) <= 1e-4 * abs(a), (task, k, a, b)
+        ng = _native_grads(model)
+        bad = []
+        for k, p in sd_o.items():
+            if VO.is_alias_key(k) or not p.is_floating_point():
+                continue
+            go, gn = p.grad, ng[k].detach().cpu()
+            if go is None:
+                assert float(gn.abs().max()) == 0.0, k
+                continue
+            scale = max(float(go.norm()), 1e-5 * go.numel() ** 0.5)
+            err = float((gn.reshape(go.shape) - go).norm()) / scale
+            if err > 2e-3:
+                bad.append((k, err))
+        assert not bad, (task, bad[:10])
+        assert float(ng["clip_model.transformer.resblocks.0.attn.in_proj_weight"].abs().max()) == 0.0      # CLIP text tower: untouched
+        assert float(ng["contra_head_v.linear.weight"].abs().max()) > 0.0
+        with torch.no_grad():
+            random.seed(12); oe = orc.forward_pt(batch, task, compute_loss=False)
+            random.seed(12); ne = model(batch, task=task, compute_loss=False)
+        for k in oe:
+            if "scores" in k:
+                assert torch.equal(oe[k].argmax(-1), ne[k].argmax(-1).cpu()), k
+
+
+@pytest.mark.parametrize("name", ["base", "large"])
+def test_shipped_config_files_build_and_step(dev, name):
+    """config/pretrain-VALOR-{base,large}.json (tests/golden/ copies of their model / optimizer part, final brace missing as
+    shipped) through the reference's option handling (utils/misc.py:26-36) into VALOR.from_pretrained(opts, {}) + TrainEngine at
+    FULL size (large = CLIP ViT-L/14 at 224 px + shared BERT: 654 M parameters), one optimizer step of the file's first two task
+    strings on a small batch: finite losses, a finite non-zero gradient norm, parameters move."""
+    from valor_amd import synth
+    from valor_amd.config import load_config, train_tasks
+    from valor_amd.engine import TrainEngine
+    from valor_amd.model.valor import VALOR
+    opts = load_config(os.path.join(GOLD, f"pretrain-VALOR-{name}.json"), overrides={"num_train_steps": 100, "dropout": 0.1})
+    model = VALOR.from_pretrained(opts, {}, dtype=torch.bfloat16, device=dev)
+    spec = model.spec
+    nparam = sum(p.numel() for p in model.parameters())
+    assert nparam == {"base": 374_680_383, "large": 654_382_655}[name], nparam        # the reference model's own count (SURVEY 8c / ref_harness)
+    assert len(model.missing_keys) > 800 and float(model.P["cls.layernorm.weight"].float().mean()) == 1.0
+    eng = TrainEngine(model, opts, manage_gc=False)
+    assert eng.grad_norm == opts.grad_norm and eng.optimizer.clip_lr_visual == opts.clip_lr
+    before = model.arena.flat.float().clone()
+    batch = synth.make_batch(spec, batch=2, frames=2, audio_slices=1, txt_len=32, seed=5)
+    for task, _ in train_tasks(opts)[:2]:
+        random.seed(3)
+        out = eng.train_step(batch, task)
+        vals = {k: float(v) for k, v in out.items()}
+        assert all(v == v and abs(v) < 1e4 for v in vals.values()), vals
+        tn = float(eng.optimizer.total_norm)
+        assert tn == tn and 0.0 < tn < 1e4, tn
+    assert float((model.arena.flat.float() - before).abs().max()) > 0
+
+
 def test_text_only_mlm_matches_oracle(dev):
     """BASELINE configs[0] (text-only MLM, batch 2; the reference's CPU plumbing case) through the HIP kernels: loss within 1e-4
     of the oracle, argmax ids exact, BERT / head gradients."""

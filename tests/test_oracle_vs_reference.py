@@ -174,6 +174,59 @@ def test_large_configuration_components():
         assert torch.allclose(o_ref, o_orc, atol=2e-4, rtol=1e-4), casual
 
 
+def test_shipped_large_configuration_clip_l14_with_shared_bert():
+    """config/pretrain-VALOR-large.json:10-15,70 -- the reference's real large configuration: clip_vit_large_14_336px video encoder at
+    video_resolution 224 (width 1024, patch 14, 257 tokens; the 336-px positional embedding is resized at construction) +
+    bert_base_uncased text encoder shared with the multimodal encoder, use_task_prompt, contra_loss_ratio 1.5, Contra_head linears
+    to contra_dim 512, hidden_trans_video_multimodal, and its image-text task string `..._mlm%tv`. The reference derives the CLIP
+    depth from the checkpoint keys and the BERT depth from its json, so the pin runs the true WIDTHS on 2-layer stacks: losses,
+    every parameter gradient (the untouched CLIP text tower must get none), argmax ids."""
+    import dataclasses
+    from valor_amd import synth
+    from valor_oracle import Oracle, trainable_copy
+    spec = dataclasses.replace(synth.clip_large_spec(), vis_layers=2, txt_layers=1, aud_layers=12, layers=2)
+    ropts = ref_harness.default_opts(video_encoder_type="clip_vit_large_14_336px", txt_encoder_type="bert_base_uncased",
+                                     use_task_prompt=True, contra_loss_ratio=1.5, video_resolution=224)
+    ref = ref_harness.build_reference(ropts, state_dict=None, dropout=0.0, clip_layers=(2, 1), bert_layers=2)
+    sd = synth.make_state_dict(spec, seed=13)
+    missing, unexpected = ref.load_state_dict(sd, strict=False)
+    assert not missing and not unexpected, (missing[:4], unexpected[:4])
+    assert [k for k, _, kind in synth.state_dict_layout(spec)] == list(ref.state_dict().keys())       # checkpoint layout incl. order
+    sd_o = trainable_copy(sd)
+    orc = Oracle(spec, sd_o, vocab_tokens=synth.synthetic_vocab(spec.vocab), use_task_prompt=True, contra_loss_ratio=1.5)
+    batch = synth.make_batch(spec, batch=2, frames=2, audio_slices=1, txt_len=32, seed=14)
+    for task in ("pt_contra%tva%tv%ta_caption%tva%tv%ta", "pt_contra%tv_caption%tv_mlm%tv"):
+        for p in ref.parameters():
+            p.grad = None
+        for v in sd_o.values():
+            if v.is_floating_point():
+                v.grad = None
+        random.seed(5); r_out = ref(batch, task=task, compute_loss=True); sum(r_out.values()).backward()
+        random.seed(5); o_out = orc.forward_pt(batch, task, compute_loss=True); sum(o_out.values()).backward()
+        assert set(r_out) == set(o_out)
+        for k in r_out:
+            assert abs(float(r_out[k]) - float(o_out[k])) <= 2e-5 * abs(float(r_out[k])), (task, k, float(r_out[k]), float(o_out[k]))
+        n = 0
+        for name, p in ref.named_parameters():
+            g = sd_o[name].grad
+            if p.grad is None:
+                assert g is None or float(g.abs().max()) == 0.0, name
+                continue
+            scale = max(float(p.grad.norm()), 1e-5 * p.grad.numel() ** 0.5)
+            assert float((g - p.grad).norm()) / scale < 2e-4, (task, name)
+            n += 1
+        assert n > (250 if "tva" in task else 100)
+        assert dict(ref.named_parameters())["clip_model.transformer.resblocks.0.attn.in_proj_weight"].grad is None      # CLIP text tower: unused
+        assert dict(ref.named_parameters())["contra_head_v.linear.weight"].grad is not None
+    with torch.no_grad():
+        random.seed(6); r = ref(batch, task="pt_contra%tv_caption%tv_mlm%tv", compute_loss=False)
+        random.seed(6); o = orc.forward_pt(batch, "pt_contra%tv_caption%tv_mlm%tv", compute_loss=False)
+    for k in r:
+        if "scores" in k:
+            assert torch.equal(r[k].argmax(-1), o[k].argmax(-1)), k
+    assert torch.allclose(r["feat_v"], o["feat_v"], atol=1e-5) and torch.allclose(r["feat_t"], o["feat_t"], atol=1e-5)
+
+
 @pytest.mark.parametrize("res,frames", [(96, 3), (160, 2)])
 def test_swin_padding_cases(res, frames):
     """feature maps that are not multiples of the (7, 7) window and odd PatchMerging inputs (videoswin.py:199-203, 222-223,

@@ -41,7 +41,7 @@ def optimizer_group(ref_name, new_params_name=()):
 def param_table(spec: ValorSpec):
     """Ordered list of (internal_name, shape, [reference keys]) in forward-execution order
     (encoders first, heads last): arena order == reverse of gradient-ready order."""
-    H, W, TW, AW, E = spec.hidden, spec.vis_width, spec.txt_width, spec.aud_width, spec.embed_dim
+    H, W, TW, AW, E, C = spec.hidden, spec.vis_width, spec.txt_width, spec.aud_width, spec.embed_dim, spec.cdim
     T = []
 
     def add(name, shape, refs=None):
@@ -65,19 +65,19 @@ def param_table(spec: ValorSpec):
         add("video_encoder.patch_embed.proj.weight", (C0, 3, 2, 4, 4)); add("video_encoder.patch_embed.proj.bias", (C0,))
         add("video_encoder.patch_embed.norm.weight", (C0,)); add("video_encoder.patch_embed.norm.bias", (C0,))
         for li, (depth, nh) in enumerate(zip(spec.swin_depths, spec.swin_heads)):
-            C = C0 * 2 ** li
+            Cw = C0 * 2 ** li
             for bi in range(depth):
                 p = f"video_encoder.layers.{li}.blocks.{bi}."
-                add(p + "norm1.weight", (C,)); add(p + "norm1.bias", (C,))
-                add(p + "attn.qkv.weight", (3 * C, C)); add(p + "attn.qkv.bias", (3 * C,))
+                add(p + "norm1.weight", (Cw,)); add(p + "norm1.bias", (Cw,))
+                add(p + "attn.qkv.weight", (3 * Cw, Cw)); add(p + "attn.qkv.bias", (3 * Cw,))
                 add(p + "attn.relative_position_bias_table", (spec.swin_table, nh))
-                add(p + "attn.proj.weight", (C, C)); add(p + "attn.proj.bias", (C,))
-                add(p + "norm2.weight", (C,)); add(p + "norm2.bias", (C,))
-                add(p + "mlp.fc1.weight", (4 * C, C)); add(p + "mlp.fc1.bias", (4 * C,))
-                add(p + "mlp.fc2.weight", (C, 4 * C)); add(p + "mlp.fc2.bias", (C,))
+                add(p + "attn.proj.weight", (Cw, Cw)); add(p + "attn.proj.bias", (Cw,))
+                add(p + "norm2.weight", (Cw,)); add(p + "norm2.bias", (Cw,))
+                add(p + "mlp.fc1.weight", (4 * Cw, Cw)); add(p + "mlp.fc1.bias", (4 * Cw,))
+                add(p + "mlp.fc2.weight", (Cw, 4 * Cw)); add(p + "mlp.fc2.bias", (Cw,))
             if li + 1 < len(spec.swin_depths):
                 p = f"video_encoder.layers.{li}.downsample."
-                add(p + "norm.weight", (4 * C,)); add(p + "norm.bias", (4 * C,)); add(p + "reduction.weight", (2 * C, 4 * C))
+                add(p + "norm.weight", (4 * Cw,)); add(p + "norm.bias", (4 * Cw,)); add(p + "reduction.weight", (2 * Cw, 4 * Cw))
         add("video_encoder.norm.weight", (spec.swin_out,)); add("video_encoder.norm.bias", (spec.swin_out,))
     else:
         # ---- CLIP visual
@@ -86,7 +86,8 @@ def param_table(spec: ValorSpec):
         add("clip_model.visual.ln_pre.weight", (W,)); add("clip_model.visual.ln_pre.bias", (W,))
         clip_blocks("clip_model.visual.transformer", W, spec.vis_layers)
         add("clip_model.visual.ln_post.weight", (W,)); add("clip_model.visual.ln_post.bias", (W,))
-        add("clip_model.visual.proj", (W, E))
+        if spec.clip_heads:
+            add("clip_model.visual.proj", (W, E))
     # ---- AST
     add("audio_embeddings.first_conv.weight", (AW, 1, spec.aud_patch, spec.aud_patch)); add("audio_embeddings.first_conv.bias", (AW,))
     add("audio_embeddings.cls_token", (1, 1, AW)); add("audio_embeddings.position_embeddings.weight", (spec.aud_tokens, AW))
@@ -100,26 +101,31 @@ def param_table(spec: ValorSpec):
         add(p + "ff_layer.linear1.weight", (spec.aud_inter, AW)); add(p + "ff_layer.linear1.bias", (spec.aud_inter,))
         add(p + "ff_layer.linear2.weight", (AW, spec.aud_inter)); add(p + "ff_layer.linear2.bias", (AW,))
     add("audio_encoder.last_layernorm.weight", (AW,)); add("audio_encoder.last_layernorm.bias", (AW,))
-    if not swin:
-        # ---- CLIP text
+    def clip_text_tower():
         add("clip_model.token_embedding.weight", (spec.clip_vocab, TW)); add("clip_model.positional_embedding", (spec.ctx_len, TW))
         add("clip_model.prompt_embedding.weight", (1, TW))
         clip_blocks("clip_model.transformer", TW, spec.txt_layers)
         add("clip_model.ln_final.weight", (TW,)); add("clip_model.ln_final.bias", (TW,))
-        add("clip_model.text_projection", (TW, E)); add("clip_model.logit_scale", ())
+        add("clip_model.text_projection", (TW, E))
+
+    if spec.clip_heads:
+        # ---- CLIP text
+        clip_text_tower()
+    if not swin:
+        add("clip_model.logit_scale", ())                      # the contrastive temperature whenever the video encoder is CLIP (modeling.py:420-426)
     # ---- contrastive heads
-    if swin:                                                   # Contra_head, pretrain.py:33-38,94-95 (no bias)
-        add("contra_head_t.linear.weight", (E, spec.txt_dim)); add("contra_head_v.linear.weight", (E, spec.video_dim))
-    add("contra_head_a.linear.weight", (E, AW))
+    if not spec.clip_heads:                                    # Contra_head, pretrain.py:33-38,93-97 (no bias)
+        add("contra_head_t.linear.weight", (C, spec.txt_dim)); add("contra_head_v.linear.weight", (C, spec.video_dim))
+    add("contra_head_a.linear.weight", (C, AW))
     for m in ("text", "video", "audio"):
-        add(f"{m}_fine_weight.0.weight", (E, E)); add(f"{m}_fine_weight.0.bias", (E,))
-        add(f"{m}_fine_weight.2.weight", (1, E)); add(f"{m}_fine_weight.2.bias", (1,))
+        add(f"{m}_fine_weight.0.weight", (C, C)); add(f"{m}_fine_weight.0.bias", (C,))
+        add(f"{m}_fine_weight.2.weight", (1, C)); add(f"{m}_fine_weight.2.bias", (1,))
     add("contra_temp", ())
     # ---- decoder inputs
     if spec.video_dim != H:                                    # modeling.py:348-349
         add("hidden_trans_video_multimodal.0.weight", (H, spec.video_dim)); add("hidden_trans_video_multimodal.0.bias", (H,))
         add("hidden_trans_video_multimodal.1.weight", (H,)); add("hidden_trans_video_multimodal.1.bias", (H,))
-    if AW != H and swin:                                       # modeling.py:350-351 (the CLIP variant's key layout has AW == H)
+    if AW != H:                                                # modeling.py:350-351
         add("hidden_trans_audio_multimodal.0.weight", (H, AW)); add("hidden_trans_audio_multimodal.0.bias", (H,))
         add("hidden_trans_audio_multimodal.1.weight", (H,)); add("hidden_trans_audio_multimodal.1.bias", (H,))
     add("video_frame_embedding", (1, 32, H)); add("video_type_embeddings", (1, 1, H))
@@ -148,4 +154,11 @@ def param_table(spec: ValorSpec):
     add("multimodal_encoder.pooler.dense.weight", (H, H)); add("multimodal_encoder.pooler.dense.bias", (H,))
     add("cls.dense.weight", (H, H)); add("cls.dense.bias", (H,)); add("cls.layernorm.weight", (H,)); add("cls.layernorm.bias", (H,))
     add("cls.decoder.bias", (spec.vocab,))
+    if not swin and not spec.clip_heads:
+        # CLIP video encoder beside a BERT text encoder (config/pretrain-VALOR-large.json): the reference constructs the WHOLE CLIP
+        # model (modeling.py:560-573), so its text tower and both CLIP projections are checkpoint tensors and optimizer-group members
+        # that forward_pt never touches. They live at the very END of the arena: their chunks stay inactive in the fused optimizer
+        # and their gradient buckets are never launched.
+        add("clip_model.visual.proj", (W, E))
+        clip_text_tower()
     return T

@@ -93,19 +93,31 @@ class VALOR(nn.Module):
         if vtype is not None or ttype is not None:
             vtype = vtype or "clip_vit_base_16"
             ttype = ttype or ("bert_base_uncased" if vtype.startswith("videoswin") else "clip_vit_base_16")
-            if vtype.startswith("clip_vit_base") and ttype.startswith("clip_vit_base"):
+            shared_bert = ttype.startswith("bert") and _opt(opts, "share_txt_and_multimodal", True)
+            if vtype.startswith("clip_vit_base") and ttype.startswith("clip_vit_base") and _opt(opts, "init_clip_head", True):
                 want = ("clip", "clip")
-            elif vtype.startswith("videoswin_base") and ttype.startswith("bert") and _opt(opts, "share_txt_and_multimodal", True):
+            elif vtype.startswith("videoswin_base") and shared_bert:
                 want = ("swin", "bert")
+            elif vtype.startswith("clip_vit") and shared_bert:         # config/pretrain-VALOR-large.json:10-14
+                want = ("clip", "bert")
             else:
-                raise NotImplementedError("covered: clip_vit_base video + clip_vit_base text, videoswin_base video + shared bert "
-                                          f"text; got video={vtype} text={ttype}")
+                raise NotImplementedError("covered: clip_vit_base video + clip_vit_base text, videoswin_base or clip_vit_{base,large} video + "
+                                          f"shared bert text; got video={vtype} text={ttype}")
         if spec is None:
-            spec = swin_spec() if want == ("swin", "bert") else base_spec()
+            if want == ("clip", "bert"):
+                from ..synth import clip_large_spec
+                spec = clip_large_spec() if vtype.startswith("clip_vit_large_14") else ValorSpec(txt_encoder="bert")
+                res = int(_opt(opts, "video_resolution", 224))
+                if res != spec.resolution:
+                    spec.resolution = res
+                if int(_opt(opts, "contra_dim", 512)) != spec.cdim:
+                    spec.contra_dim = int(_opt(opts, "contra_dim", 512))
+            else:
+                spec = swin_spec() if want == ("swin", "bert") else base_spec()
         elif want is not None and want != (spec.video_encoder, spec.txt_encoder):
             raise NotImplementedError(f"opts ask for {want} encoders, the spec describes {(spec.video_encoder, spec.txt_encoder)}")
-        if (spec.video_encoder, spec.txt_encoder) not in (("clip", "clip"), ("swin", "bert")):
-            raise NotImplementedError("the reference loads CLIP as a whole: video/text encoders come as clip+clip or swin+bert")
+        if (spec.video_encoder, spec.txt_encoder) not in (("clip", "clip"), ("swin", "bert"), ("clip", "bert")):
+            raise NotImplementedError("the reference loads CLIP as a whole: video/text encoders come as clip+clip, swin+bert or clip+bert")
         if _opt(opts, "contra_type", "fine") != "fine" or _opt(opts, "caption_type", "unimlm") != "unimlm":
             raise NotImplementedError("contra_type='fine' and caption_type='unimlm' only")
         if _opt(opts, "cross_attn_type", "va_concate") != "va_concate" or _opt(opts, "late_fusion", False) or _opt(opts, "full_masker", False):
@@ -202,12 +214,13 @@ class VALOR(nn.Module):
                 for i, r in enumerate(refs):
                     out[r] = p[i * rows:(i + 1) * rows]
         if self.spec.video_encoder == "swin":
-            # the integer buffer of every WindowAttention3D (videoswin.py:126) and the txt_encoder.* view of the shared
-            # multimodal encoder (modeling.py:689-691) are part of the reference's state dict
+            # the integer buffer of every WindowAttention3D (videoswin.py:126) is part of the reference's state dict
             relidx = swin_relative_position_index(self.spec.swin_window)
             for name, _, _ in self.table:
                 if name.endswith("attn.relative_position_bias_table"):
                     out[name.replace("relative_position_bias_table", "relative_position_index")] = relidx
+        if self.spec.txt_encoder == "bert":
+            # ... and so is the txt_encoder.* view of the shared multimodal encoder (modeling.py:689-691)
             for k in [k for k in out if k.startswith("multimodal_encoder.")]:
                 out["txt_encoder." + k[len("multimodal_encoder."):]] = out[k]
         return out
@@ -229,8 +242,9 @@ class VALOR(nn.Module):
                             p[i * rows:(i + 1) * rows].copy_(sd[r].to(p.dtype)); used.add(r)
                         else:
                             missing.append(r)
-        unexpected = [k for k in sd if k not in used and not (self.spec.video_encoder == "swin" and (
-            k.endswith("relative_position_index") or (k.startswith("txt_encoder.") and "multimodal_encoder." + k[12:] in used)))]
+        unexpected = [k for k in sd if k not in used and not (
+            (self.spec.video_encoder == "swin" and k.endswith("relative_position_index")) or
+            (self.spec.txt_encoder == "bert" and k.startswith("txt_encoder.") and "multimodal_encoder." + k[12:] in used))]
         if strict and (missing or unexpected):
             raise RuntimeError(f"load_state_dict: missing {missing[:5]} unexpected {unexpected[:5]}")
         self._params_changed()
@@ -443,7 +457,15 @@ class VALOR(nn.Module):
         b, n, c, h, w = video_pixels.shape
         imgs = self._dev(video_pixels.reshape(b * n, c, h, w).float())
         patches = ops.patchify(imgs, sp.patch, self.dtype)
-        tok = ops.linear(patches, P["clip_model.visual.conv1.weight"].view(sp.vis_width, -1), None)
+        wconv = P["clip_model.visual.conv1.weight"].view(sp.vis_width, -1)
+        vec = 8 if self.dtype == torch.bfloat16 else 4
+        if patches.shape[1] % vec:
+            # ViT-L/14: 3 * 14 * 14 = 588 contraction elements per patch; the GEMM stages 16-byte chunks, so operand rows are
+            # zero-padded to the next chunk (592). Pure data movement; the weight's gradient flows back through the column slice.
+            kp = (patches.shape[1] + vec - 1) // vec * vec
+            pp = patches.new_zeros((patches.shape[0], kp)); pp[:, :patches.shape[1]].copy_(patches); patches = pp
+            wconv = ops.pad_cols(wconv, kp)
+        tok = ops.linear(patches, wconv, None)
         Pn = sp.vis_tokens - 1
         x = ops.assemble_tokens(tok, P["clip_model.visual.class_embedding"], P["clip_model.visual.positional_embedding"], None, b * n, Pn)
         x = ops.layer_norm(x, P["clip_model.visual.ln_pre.weight"], P["clip_model.visual.ln_pre.bias"], 1e-5)
@@ -706,7 +728,10 @@ class VALOR(nn.Module):
                 b, F = video_output.shape[:2]
                 idx = self._const_idx(b * F, sp.vis_tokens)
                 cls_v = ops.gather_rows(video_output.reshape(-1, sp.vis_width), idx)
-                feat_v = ops.l2_normalize(ops.linear(cls_v, P["clip_model.visual.proj"], None, w_is_kn=True)).view(b, F, -1)
+                if sp.clip_heads:                                  # pretrain.py:89-92
+                    feat_v = ops.l2_normalize(ops.linear(cls_v, P["clip_model.visual.proj"], None, w_is_kn=True)).view(b, F, -1)
+                else:                                              # Contra_head beside a CLIP video encoder (pretrain.py:93-97)
+                    feat_v = ops.l2_normalize(ops.linear(cls_v, P["contra_head_v.linear.weight"], None)).view(b, F, -1)
             if "a" in "".join(contra_task):
                 b, A = audio_output.shape[:2]
                 idx = self._const_idx(b * A, sp.aud_tokens)

@@ -681,6 +681,25 @@ def assemble_tokens(patches, cls, pos, bias, N, Pn):
     return AssembleFn.apply(patches, cls, pos, bias, N, Pn)
 
 
+class PadColsFn(Function):
+    """w [N, K] -> zero-padded [N, Kp] copy (data movement only); backward hands the first K gradient columns back."""
+
+    @staticmethod
+    def forward(ctx, w, kp):
+        ctx.k = w.shape[1]
+        out = w.new_zeros((w.shape[0], kp))
+        out[:, :w.shape[1]].copy_(w)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        return g[:, :ctx.k].contiguous(), None
+
+
+def pad_cols(w, kp):
+    return PadColsFn.apply(w, kp)
+
+
 def patchify(images_f32, P, out_dtype):
     """[N,C,H,W] fp32 -> [N*(H/P)*(W/P), C*P*P] GEMM operand rows in the compute dtype (no grad)."""
     N, C, H, W = images_f32.shape

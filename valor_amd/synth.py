@@ -46,6 +46,18 @@ class ValorSpec:
     swin_heads: tuple = (4, 8, 16, 32)
     swin_window: tuple = (8, 7, 7)
     swin_drop_path: float = 0.2
+    # width of the contrastive space when the heads are Contra_head linears (pretrain.py:93-97, opts.contra_dim = 512) and it
+    # differs from CLIP's joint embedding dim (CLIP-L/14: 768); 0 -> embed_dim (every shipped base configuration)
+    contra_dim: int = 0
+
+    @property
+    def cdim(self):
+        return self.contra_dim or self.embed_dim
+
+    @property
+    def clip_heads(self):
+        """pretrain.py:89-92: the CLIP projections ARE the contrastive heads only when both encoders are CLIP towers"""
+        return self.video_encoder == "clip" and self.txt_encoder == "clip"
 
     @property
     def swin_out(self):
@@ -107,6 +119,26 @@ def tiny_swin_spec():
     """3-stage VideoSwin (28 -> 14 -> 7 at 112 px: no padding anywhere) on the tiny BERT/AST of tiny_spec()."""
     return ValorSpec(video_encoder="swin", txt_encoder="bert", resolution=112, swin_embed=64, swin_depths=(2, 2, 2),
                      swin_heads=(2, 4, 8), swin_drop_path=0.2, embed_dim=128, aud_width=128, aud_layers=2, aud_inter=256,
+                     melbins=32, target_len=64, aud_patch=16, hidden=128, layers=2, inter=256, vocab=1200, max_pos=64)
+
+
+def clip_large_spec():
+    """config/pretrain-VALOR-large.json:10-14, the reference's shipped LARGE configuration: clip_vit_large_14_336px video encoder
+    run at video_resolution 224 (ViT-L/14: width 1024, 24 layers, 16 heads, 16 x 16 + 1 = 257 tokens per frame; its positional
+    embedding is resized from the 336-px grid at construction, clip.py:481-491) + bert_base_uncased text encoder shared with the
+    multimodal encoder. The whole CLIP model is constructed (modeling.py:560-573), so its text tower (width 768, 12 layers) and the
+    two CLIP projections are parameters of the checkpoint although forward_pt never touches them; the contrastive heads are
+    Contra_head linears to opts.contra_dim = 512 (pretrain.py:93-97); video 1024 -> hidden 768 goes through
+    hidden_trans_video_multimodal (modeling.py:348-349)."""
+    return ValorSpec(video_encoder="clip", txt_encoder="bert", vis_width=1024, vis_layers=24, patch=14, txt_width=768,
+                     embed_dim=768, contra_dim=512)
+
+
+def tiny_clip_bert_spec():
+    """the code paths of clip_large_spec() (patch 14 -> a 588-wide conv GEMM, video width != hidden, Contra_head linears beside an
+    untouched CLIP text tower) at unit-test size"""
+    return ValorSpec(video_encoder="clip", txt_encoder="bert", vis_width=256, vis_layers=2, patch=14, resolution=56, txt_width=128,
+                     txt_layers=1, clip_vocab=1200, embed_dim=128, contra_dim=64, aud_width=128, aud_layers=2, aud_inter=256,
                      melbins=32, target_len=64, aud_patch=16, hidden=128, layers=2, inter=256, vocab=1200, max_pos=64)
 
 
@@ -197,72 +229,71 @@ def state_dict_layout(spec: ValorSpec):
     add("video_type_embeddings", (1, 1, H)); add("audio_type_embeddings", (1, 1, H))
     add("video_frame_embedding", (1, 32, H)); add("audio_frame_embedding", (1, 32, H))
     add("contra_temp", (), "s")
+    E, C = spec.embed_dim, spec.cdim
     if spec.video_encoder == "swin":
         assert spec.txt_encoder == "bert", "the reference loads CLIP as a whole: swin video + clip text is not a shipped combination"
         C0 = spec.swin_embed
         add("video_encoder.patch_embed.proj.weight", (C0, 3, 2, 4, 4)); add("video_encoder.patch_embed.proj.bias", (C0,), "b")
         add("video_encoder.patch_embed.norm.weight", (C0,), "g"); add("video_encoder.patch_embed.norm.bias", (C0,), "b")
         for li, (depth, nh) in enumerate(zip(spec.swin_depths, spec.swin_heads)):
-            C = C0 * 2 ** li
+            Cw = C0 * 2 ** li
             for bi in range(depth):
                 p = f"video_encoder.layers.{li}.blocks.{bi}."
-                add(p + "norm1.weight", (C,), "g"); add(p + "norm1.bias", (C,), "b")
+                add(p + "norm1.weight", (Cw,), "g"); add(p + "norm1.bias", (Cw,), "b")
                 add(p + "attn.relative_position_bias_table", (spec.swin_table, nh))
                 add(p + "attn.relative_position_index", (0,), "relidx")
-                add(p + "attn.qkv.weight", (3 * C, C)); add(p + "attn.qkv.bias", (3 * C,), "b")
-                add(p + "attn.proj.weight", (C, C)); add(p + "attn.proj.bias", (C,), "b")
-                add(p + "norm2.weight", (C,), "g"); add(p + "norm2.bias", (C,), "b")
-                add(p + "mlp.fc1.weight", (4 * C, C)); add(p + "mlp.fc1.bias", (4 * C,), "b")
-                add(p + "mlp.fc2.weight", (C, 4 * C)); add(p + "mlp.fc2.bias", (C,), "b")
+                add(p + "attn.qkv.weight", (3 * Cw, Cw)); add(p + "attn.qkv.bias", (3 * Cw,), "b")
+                add(p + "attn.proj.weight", (Cw, Cw)); add(p + "attn.proj.bias", (Cw,), "b")
+                add(p + "norm2.weight", (Cw,), "g"); add(p + "norm2.bias", (Cw,), "b")
+                add(p + "mlp.fc1.weight", (4 * Cw, Cw)); add(p + "mlp.fc1.bias", (4 * Cw,), "b")
+                add(p + "mlp.fc2.weight", (Cw, 4 * Cw)); add(p + "mlp.fc2.bias", (Cw,), "b")
             if li + 1 < len(spec.swin_depths):
                 p = f"video_encoder.layers.{li}.downsample."
-                add(p + "reduction.weight", (2 * C, 4 * C)); add(p + "norm.weight", (4 * C,), "g"); add(p + "norm.bias", (4 * C,), "b")
+                add(p + "reduction.weight", (2 * Cw, 4 * Cw)); add(p + "norm.weight", (4 * Cw,), "g"); add(p + "norm.bias", (4 * Cw,), "b")
         add("video_encoder.norm.weight", (spec.swin_out,), "g"); add("video_encoder.norm.bias", (spec.swin_out,), "b")
-        _audio_bert_heads(spec, add)
+    else:
+        # the whole CLIP model is one module (modeling.py:560-573): both towers are in the state dict whichever of them forward_pt uses
+        add("clip_model.positional_embedding", (spec.ctx_len, TW)); add("clip_model.text_projection", (TW, E))
+        add("clip_model.logit_scale", (), "s")
+        add("clip_model.visual.class_embedding", (W,)); add("clip_model.visual.positional_embedding", (spec.vis_tokens, W))
+        add("clip_model.visual.proj", (W, E)); add("clip_model.visual.conv1.weight", (W, 3, spec.patch, spec.patch))
+        add("clip_model.visual.ln_pre.weight", (W,), "g"); add("clip_model.visual.ln_pre.bias", (W,), "b")
+
+        def clip_blocks(prefix, width, n):
+            for i in range(n):
+                p = f"{prefix}.resblocks.{i}."
+                add(p + "attn.in_proj_weight", (3 * width, width)); add(p + "attn.in_proj_bias", (3 * width,), "b")
+                add(p + "attn.out_proj.weight", (width, width)); add(p + "attn.out_proj.bias", (width,), "b")
+                add(p + "ln_1.weight", (width,), "g"); add(p + "ln_1.bias", (width,), "b")
+                add(p + "mlp.c_fc.weight", (4 * width, width)); add(p + "mlp.c_fc.bias", (4 * width,), "b")
+                add(p + "mlp.c_proj.weight", (width, 4 * width)); add(p + "mlp.c_proj.bias", (width,), "b")
+                add(p + "ln_2.weight", (width,), "g"); add(p + "ln_2.bias", (width,), "b")
+        clip_blocks("clip_model.visual.transformer", W, spec.vis_layers)
+        add("clip_model.visual.ln_post.weight", (W,), "g"); add("clip_model.visual.ln_post.bias", (W,), "b")
+        clip_blocks("clip_model.transformer", TW, spec.txt_layers)
+        add("clip_model.token_embedding.weight", (spec.clip_vocab, TW))
+        add("clip_model.ln_final.weight", (TW,), "g"); add("clip_model.ln_final.bias", (TW,), "b")
+        add("clip_model.prompt_embedding.weight", (1, TW))
+
+    _audio_bert_heads(spec, add)
+    if spec.txt_encoder == "bert":
         # share_txt_and_multimodal (modeling.py:689-691): the text encoder IS the multimodal encoder, so the reference state
         # dict lists every multimodal_encoder.* tensor a second time under txt_encoder.* (same storage), right after cls.*
         for k, shape, kind in list(L):
             if k.startswith("multimodal_encoder."):
                 L.append(("txt_encoder." + k[len("multimodal_encoder."):], shape, "alias"))
-        if spec.video_dim != H:                                                       # modeling.py:348-349
-            add("hidden_trans_video_multimodal.0.weight", (H, spec.video_dim)); add("hidden_trans_video_multimodal.0.bias", (H,), "b")
-            add("hidden_trans_video_multimodal.1.weight", (H,), "g"); add("hidden_trans_video_multimodal.1.bias", (H,), "b")
-        if AW != H:                                                                   # modeling.py:350-351
-            add("hidden_trans_audio_multimodal.0.weight", (H, AW)); add("hidden_trans_audio_multimodal.0.bias", (H,), "b")
-            add("hidden_trans_audio_multimodal.1.weight", (H,), "g"); add("hidden_trans_audio_multimodal.1.bias", (H,), "b")
-        add("contra_head_t.linear.weight", (E, spec.txt_dim)); add("contra_head_v.linear.weight", (E, spec.video_dim))
-        add("contra_head_a.linear.weight", (E, AW))
-        for m in ("text", "video", "audio"):
-            add(f"{m}_fine_weight.0.weight", (E, E)); add(f"{m}_fine_weight.0.bias", (E,), "b")
-            add(f"{m}_fine_weight.2.weight", (1, E)); add(f"{m}_fine_weight.2.bias", (1,), "b")
-        return L
-    add("clip_model.positional_embedding", (spec.ctx_len, TW)); add("clip_model.text_projection", (TW, E))
-    add("clip_model.logit_scale", (), "s")
-    add("clip_model.visual.class_embedding", (W,)); add("clip_model.visual.positional_embedding", (spec.vis_tokens, W))
-    add("clip_model.visual.proj", (W, E)); add("clip_model.visual.conv1.weight", (W, 3, spec.patch, spec.patch))
-    add("clip_model.visual.ln_pre.weight", (W,), "g"); add("clip_model.visual.ln_pre.bias", (W,), "b")
-
-    def clip_blocks(prefix, width, n):
-        for i in range(n):
-            p = f"{prefix}.resblocks.{i}."
-            add(p + "attn.in_proj_weight", (3 * width, width)); add(p + "attn.in_proj_bias", (3 * width,), "b")
-            add(p + "attn.out_proj.weight", (width, width)); add(p + "attn.out_proj.bias", (width,), "b")
-            add(p + "ln_1.weight", (width,), "g"); add(p + "ln_1.bias", (width,), "b")
-            add(p + "mlp.c_fc.weight", (4 * width, width)); add(p + "mlp.c_fc.bias", (4 * width,), "b")
-            add(p + "mlp.c_proj.weight", (width, 4 * width)); add(p + "mlp.c_proj.bias", (width,), "b")
-            add(p + "ln_2.weight", (width,), "g"); add(p + "ln_2.bias", (width,), "b")
-    clip_blocks("clip_model.visual.transformer", W, spec.vis_layers)
-    add("clip_model.visual.ln_post.weight", (W,), "g"); add("clip_model.visual.ln_post.bias", (W,), "b")
-    clip_blocks("clip_model.transformer", TW, spec.txt_layers)
-    add("clip_model.token_embedding.weight", (spec.clip_vocab, TW))
-    add("clip_model.ln_final.weight", (TW,), "g"); add("clip_model.ln_final.bias", (TW,), "b")
-    add("clip_model.prompt_embedding.weight", (1, TW))
-
-    _audio_bert_heads(spec, add)
-    add("contra_head_a.linear.weight", (E, AW))
+    if spec.video_dim != H:                                                           # modeling.py:348-349
+        add("hidden_trans_video_multimodal.0.weight", (H, spec.video_dim)); add("hidden_trans_video_multimodal.0.bias", (H,), "b")
+        add("hidden_trans_video_multimodal.1.weight", (H,), "g"); add("hidden_trans_video_multimodal.1.bias", (H,), "b")
+    if AW != H:                                                                       # modeling.py:350-351
+        add("hidden_trans_audio_multimodal.0.weight", (H, AW)); add("hidden_trans_audio_multimodal.0.bias", (H,), "b")
+        add("hidden_trans_audio_multimodal.1.weight", (H,), "g"); add("hidden_trans_audio_multimodal.1.bias", (H,), "b")
+    if not spec.clip_heads:                                                           # Contra_head, pretrain.py:93-97 (no bias)
+        add("contra_head_t.linear.weight", (C, spec.txt_dim)); add("contra_head_v.linear.weight", (C, spec.video_dim))
+    add("contra_head_a.linear.weight", (C, AW))
     for m in ("text", "video", "audio"):
-        add(f"{m}_fine_weight.0.weight", (E, E)); add(f"{m}_fine_weight.0.bias", (E,), "b")
-        add(f"{m}_fine_weight.2.weight", (1, E)); add(f"{m}_fine_weight.2.bias", (1,), "b")
+        add(f"{m}_fine_weight.0.weight", (C, C)); add(f"{m}_fine_weight.0.bias", (C,), "b")
+        add(f"{m}_fine_weight.2.weight", (1, C)); add(f"{m}_fine_weight.2.bias", (1,), "b")
     return L
 
 
