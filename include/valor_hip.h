@@ -65,14 +65,14 @@ int valor_gemm_kernel_for(int dtype, int transA, int transB, int M, int N, int K
 /* k-slow 8-phase kernels: transposing LDS reads as inline asm (keeps the counted LDS-DMA pipeline from being drained by
  * compiler-inserted waits); returns the previous value, v < 0 only queries */
 int valor_gemm_set_tr_asm(int v);
-/* 8-phase kernels: one-pass bf16 epilogue for plain problems (bf16 C, no split-K / accumulate / pre-activation / dact, N % 8 == 0,
- * ldc % 8 == 0); returns the previous value, v < 0 only queries */
+/* 8-phase kernels: bf16 tile epilogue (bias / activation on the accumulators, the 256 x 256 tile as bf16 through LDS once, twice
+ * when a pre-activation copy is wanted; act' multiply and C += at read-out) for bf16 C without split-K / fused row sums, N % 8 == 0,
+ * ldc % 8 == 0; default on. Returns the previous value, v < 0 only queries */
 int valor_gemm_set_fast_epilogue(int v);
 /* policy parameters of variant 4 and of the 8-phase launch (tuning / A-B hook; returns the previous value, value < 0 only queries):
  *   key 0: smallest K for which a big-M dgrad (A row-major, B k-slow) runs on the 256x256 8-phase kernel
- *   key 1: start skew of the 8-phase kernel, in units of ~4096 shader cycles: workgroup b of the FIRST round sleeps
- *          ((b / 8) % 4) * value units before its first load, so the CUs' tile epilogues (128 KiB of stores each) stop
- *          coinciding round after round (0 = off)
+ *   key 1: unused (was the start skew of the 8-phase kernel's first round; measured slower at every setting,
+ *          profiles/r02_gemm_policy_ab.json)
  *   key 2: smallest number of 256x256 tiles for the 8-phase kernel on forward / dgrad problems */
 int valor_gemm_set_policy(int key, int value);
 

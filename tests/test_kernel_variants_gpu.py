@@ -128,15 +128,31 @@ def test_gemm_8phase_fast_epilogue(dev, gemm_variant):
                 outs.append(K.gemm(A, B, trans_a=ta, trans_b=tb, bias=bias, alpha=0.5, splitk=False))
                 assert _rel(outs[-1], ref) < 6e-3, (mode, M, N, Kd, ta, tb)
             assert _rel(outs[1], outs[0]) < 1e-3
-        gemm_variant.valor_gemm_set_fast_epilogue(1)
-        X, W, b = _mk((512, 256), 6, dev), _mk((768, 256), 7, dev), _mk((768,), 8, dev)
-        y = K.gemm(X, W, bias=b, act=lib.ACT_GELU_ERF, splitk=False)
-        assert _rel(y, torch.nn.functional.gelu(X.double() @ W.double().t() + b.double())) < 6e-3
-        out, pre = K.gemm(X, W, bias=b, act=lib.ACT_GELU_ERF, want_preact=True, splitk=False)        # not plain: general path
-        assert _rel(pre, X.double() @ W.double().t() + b.double()) < 6e-3
-        Cacc = torch.ones((512, 768), dtype=torch.bfloat16, device=dev)
-        K.gemm(X, W, out=Cacc, accumulate=True, splitk=False)
-        assert _rel(Cacc, 1.0 + X.double() @ W.double().t()) < 6e-3
+        # fused epilogues of the bf16 tile path against the general fp32 two-pass epilogue (mode 0) and fp64 math: bias + activation,
+        # activation with the pre-activation copy (two tile passes over the same fp32 accumulators), the
+        # act' multiply of a dgrad and C += (applied at read-out: one extra bf16 rounding of the GEMM result), row / column tails
+        import torch.nn.functional as F
+        for (M, N, Kd), tb in itertools.product([(512, 768, 256), (1000, 520, 192)], [False, True]):
+            X, W, b = _mk((M, Kd), 6, dev), _mk((Kd, N) if tb else (N, Kd), 7, dev), _mk((N,), 8, dev)
+            U = _mk((M, N), 9, dev)
+            z = X.double() @ (W.double() if tb else W.double().t()) + b.double()
+            res = {}
+            for mode in (0, 1):
+                gemm_variant.valor_gemm_set_fast_epilogue(mode)
+                y = K.gemm(X, W, trans_b=tb, bias=b, act=lib.ACT_GELU_ERF, splitk=False)
+                out, pre = K.gemm(X, W, trans_b=tb, bias=b, act=lib.ACT_QUICK_GELU, want_preact=True, splitk=False)
+                du = K.gemm(X, W, trans_b=tb, act=lib.ACT_GELU_ERF, dact_aux=U, splitk=False)
+                Cacc = torch.ones((M, N), dtype=torch.bfloat16, device=dev)
+                K.gemm(X, W, trans_b=tb, out=Cacc, accumulate=True, splitk=False)
+                res[mode] = (y, out, pre, du, Cacc)
+                assert _rel(y, F.gelu(z)) < 6e-3
+                assert _rel(pre, z) < 6e-3 and _rel(out, z * torch.sigmoid(1.702 * z)) < 6e-3
+                ud = U.double().requires_grad_(True)
+                (g,) = torch.autograd.grad(F.gelu(ud).sum(), ud)
+                assert _rel(du, (z - b.double()) * g) < 8e-3
+                assert _rel(Cacc, 1.0 + z - b.double()) < 6e-3
+            assert max(_rel(res[1][i], res[0][i]) for i in range(3)) < 1e-3          # same fp32 accumulators, rounded once in both
+            assert _rel(res[1][3], res[0][3]) < 6e-3 and _rel(res[1][4], res[0][4]) < 6e-3
     finally:
         gemm_variant.valor_gemm_set_fast_epilogue(old)
 

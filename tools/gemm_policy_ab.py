@@ -1,5 +1,6 @@
 """A/B of valor_gemm launch policies on the VALOR-base GEMM shapes, configurations interleaved in one process (HIP events,
-min over rounds): kernel family (128x128 LDS-DMA vs 256x256 8-phase), the 8-phase start skew, the one-pass bf16 epilogue.
+min over rounds): kernel family (128x128 LDS-DMA vs 256x256 8-phase) and the 8-phase kernel's epilogue (general fp32 two-pass vs bf16 tile passes).
+(Round-2 session A also measured a start skew of the first round's workgroups: slower everywhere, profiles/r02_gemm_policy_ab.json.)
 Every configuration is first checked against fp64 torch on one shape (a policy may change speed, never results).
 usage: python tools/gemm_policy_ab.py [out.json]"""
 import json
@@ -16,33 +17,30 @@ so = lib.load()
 # name -> (variant, fast_epilogue, skew units)
 CONFIGS = {
     "128sq": (1, 0, 0),
-    "8ph": (3, 0, 0),
-    "8ph_fastepi": (3, 1, 0),
-    "8ph_skew2": (3, 0, 2),
-    "8ph_skew4": (3, 0, 4),
-    "8ph_skew6": (3, 0, 6),
-    "8ph_skew4_fastepi": (3, 1, 4),
+    "8ph_general_epi": (3, 0, 0),
+    "8ph_tile_epi": (3, 1, 0),
 }
 
 b = 64
 T = b * 8 * 197
-SHAPES = [  # name, M, N, K, ta, tb, epilogue ("" plain | "bias" | "gelu": bias + QuickGELU + pre-activation copy)
+SHAPES = [  # name, M, N, K, ta, tb, epilogue ("" plain | "bias" | "gelu": bias + QuickGELU + pre-activation copy | "dact": * act'(aux))
     ("vit_qkv_fwd", T, 2304, 768, 0, 0, "bias"),
     ("vit_fc1_fwd", T, 3072, 768, 0, 0, "gelu"),
     ("vit_fc1_fwd_plain", T, 3072, 768, 0, 0, ""),
     ("vit_proj_fwd", T, 768, 768, 0, 0, ""),
     ("vit_fc2_fwd", T, 768, 3072, 0, 0, ""),
     ("vit_fc2_dgrad", T, 3072, 768, 0, 1, ""),
+    ("vit_fc2_dgrad_dact", T, 3072, 768, 0, 1, "dact"),
     ("vit_proj_dgrad", T, 768, 768, 0, 1, ""),
     ("vit_qkv_dgrad", T, 768, 2304, 0, 1, ""),
     ("vit_fc1_dgrad", T, 768, 3072, 0, 1, ""),
     ("ast_fc1_fwd", b * 2 * 129, 3072, 768, 0, 0, "gelu"),
-    ("ast_fc2_dgrad", b * 2 * 129, 3072, 768, 0, 1, ""),
+    ("ast_fc2_dgrad", b * 2 * 129, 3072, 768, 0, 1, "dact"),
     ("ast_proj_fwd", b * 2 * 129, 768, 768, 0, 0, ""),
     ("xkv_fwd", b * 1834, 1536, 768, 0, 0, "bias"),
     ("xkv_dgrad", b * 1834, 768, 1536, 0, 1, ""),
     ("dec_fc1_fwd", 8832, 3072, 768, 0, 0, "gelu"),
-    ("dec_fc2_dgrad", 8832, 3072, 768, 0, 1, ""),
+    ("dec_fc2_dgrad", 8832, 3072, 768, 0, 1, "dact"),
 ]
 
 
@@ -62,6 +60,8 @@ def run(A, B, ta, tb, epi, bias, out, pre):
     if epi == "gelu":
         lib.call("valor_gemm", K._stream(), 0, ta, tb, out.shape[0], out.shape[1], A.shape[0] if ta else A.shape[1], A.data_ptr(), A.stride(0),
                  B.data_ptr(), B.stride(0), out.data_ptr(), out.stride(0), bias.data_ptr(), lib.ACT_QUICK_GELU, pre.data_ptr(), 0, 0, 1.0, 0, 0, 0, 0, 0, 0)
+    elif epi == "dact":
+        K.gemm(A, B, trans_a=bool(ta), trans_b=bool(tb), act=lib.ACT_QUICK_GELU, dact_aux=pre, out=out, splitk=False)
     else:
         K.gemm(A, B, trans_a=bool(ta), trans_b=bool(tb), bias=bias if epi == "bias" else None, out=out, splitk=False)
 
@@ -89,7 +89,7 @@ def bench(rounds=4, n=6):
         B = mk((Kd, N) if tb else (N, Kd), 12)
         bias = mk((N,), 13)
         out = torch.empty((M, N), dtype=torch.bfloat16, device=dev)
-        pre = torch.empty((M, N), dtype=torch.bfloat16, device=dev) if epi == "gelu" else None
+        pre = mk((M, N), 14) if epi in ("gelu", "dact") else None
         best = {c: 1e9 for c in CONFIGS}
         for r in range(rounds):
             for cfg in CONFIGS:

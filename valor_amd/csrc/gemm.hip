@@ -453,8 +453,8 @@ extern "C" int valor_gemm_set_variant(int v) { const int o = g_gemm_variant; if 
 // variant 4 (default): measured policy (tools/gemm_ab.py, profiles/r01_gemm_variants_*.json) -- the 8-phase kernel for
 //   the big-M forward GEMMs, long-K dgrad and the wgrad GEMMs; the 128x128 kernel (4 workgroups per CU hiding each
 //   other's prologue / epilogue) for small grids, short-K dgrad and everything with a K tail.
-// [0] NT min K for the 8-phase kernel, [1] 8-phase start skew, [2] min 256x256 tiles (forward / dgrad), [3] spare
-int g_gemm_policy[4] = {[] { const char* e = getenv("VALOR_GEMM_NT_MINK"); return e ? atoi(e) : 1536; }(),
+// [0] NT min K for the 8-phase kernel, [1] unused (was: 8-phase start skew, measured slower), [2] min 256x256 tiles (forward / dgrad), [3] spare
+int g_gemm_policy[4] = {[] { const char* e = getenv("VALOR_GEMM_NT_MINK"); return e ? atoi(e) : 768; }(),
                         [] { const char* e = getenv("VALOR_GEMM_SKEW"); return e ? atoi(e) : 0; }(),
                         [] { const char* e = getenv("VALOR_GEMM_MIN_TILES"); return e ? atoi(e) : 1024; }(), 0};
 extern "C" int valor_gemm_set_policy(int key, int value) {
@@ -564,7 +564,7 @@ extern "C" int valor_gemm(void* stream, int dtype, int transA, int transB, int M
     p.lda = lda; p.ldb = ldb; p.ldc = ldc; p.ldaux = ldaux;
     p.M = M; p.N = N; p.K = K; p.act = act; p.accumulate = accumulate; p.out_f32 = out_f32;
     p.alpha = alpha;
-    p.rowsum_out = rowsum_out; p.rowsum_acc = rowsum_accumulate; p.rowsum_ws = nullptr; p.skew = 0; p.fast_epi = 0;
+    p.rowsum_out = rowsum_out; p.rowsum_acc = rowsum_accumulate; p.rowsum_ws = nullptr; p.fast_epi = 0;
     {
         const int64_t esz = dtype == VALOR_DT_BF16 ? 2 : 4;
         // direct: rows x ld with K valid in the last row; transposed: K rows of ld elements (caller guarantees

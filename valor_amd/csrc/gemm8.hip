@@ -73,12 +73,8 @@ __global__ __launch_bounds__(512, 2) void gemm_8ph_kernel(GemmArgs p) {
     }
     const int tm = logical / tiles_n, tn = logical - tm * tiles_n;
     const int m0 = tm << 8, n0 = tn << 8;
-    // start skew (GemmArgs::skew): every CU runs one workgroup and all tiles cost the same, so without it the whole chip
-    // reaches its epilogue (128 KiB of stores per CU) at the same moment round after round
-    if (p.skew && blockIdx.x < 256) {
-        const int n = ((blockIdx.x >> 3) & 3) * p.skew;
-        for (int i = 0; i < n; ++i) __builtin_amdgcn_s_sleep(64);
-    }
+    // (A start skew of the first round's workgroups -- so that the CUs' tile epilogues, 128 KiB of stores each, stop coinciding
+    // round after round -- was measured and is SLOWER at every setting: profiles/r02_gemm_policy_ab.json.)
 
     const int nk_total = p.K / BK;
     int ks_begin = 0, ks_end = nk_total;
@@ -294,38 +290,76 @@ __global__ __launch_bounds__(512, 2) void gemm_8ph_kernel(GemmArgs p) {
         }
     }
 
-    // ---- fast epilogue of a "plain" problem (host-checked, see GemmArgs::fast_epi): alpha / bias / activation on the accumulators in
-    // registers, the whole 256 x 256 tile as bf16 (128 KiB) through LDS in ONE pass -- half the LDS traffic and one barrier less than
-    // the general two-pass fp32 epilogue below. Image: [256 rows][512 B], 16-B chunk c of row r at position c ^ (r & 31): the 16
-    // lanes of a fragment column group write 16 distinct chunks, the row-contiguous reads are permutations inside a row.
-    if (p.fast_epi) {
+    // ---- fast epilogue (host-checked, see GemmArgs::fast_epi): alpha / bias / activation on the accumulators in registers, the whole
+    // 256 x 256 tile as bf16 (128 KiB) through LDS in ONE pass -- half the LDS traffic and one barrier less than the general two-pass
+    // fp32 epilogue below. Image: [256 rows][512 B], 16-B chunk c of row r at position c ^ (r & 31): the 16 lanes of a fragment
+    // column group write 16 distinct chunks, the row-contiguous reads are permutations inside a row.
+    //   * pre-activation copy wanted (forward of a fused activation): TWO bf16 passes, u = alpha acc + bias first (-> preact), then
+    //     act(u) computed on the SAME fp32 accumulators (-> C): numerics identical to the general epilogue;
+    //   * dact_aux (dgrad of a fused activation) and C += are applied at read-out, where every lane holds 8 consecutive columns of a
+    //     row (16-byte coalesced loads of aux / C); the GEMM result is rounded to bf16 before the act' multiply there (gradient path).
+    if constexpr (!TA) if (p.fast_epi) {           // (k-slow A = wgrad: split-K / fused row sums, always the general epilogue)
         char* sB = smem;
+        auto write_tile = [&](bool apply_act) {
 #pragma unroll
-        for (int ni = 0; ni < 4; ++ni) {
-            const int col = (ni >> 1) * 128 + wn * 32 + (ni & 1) * 16 + 4 * fg;
-            const f32x4_t bias4 = load_bias4<T>(p, n0 + col);
+            for (int ni = 0; ni < 4; ++ni) {
+                const int col = (ni >> 1) * 128 + wn * 32 + (ni & 1) * 16 + 4 * fg;
+                const f32x4_t bias4 = load_bias4<T>(p, n0 + col);
 #pragma unroll
-            for (int mi = 0; mi < 8; ++mi) {
-                const int row = (mi >> 2) * 128 + wm * 64 + (mi & 3) * 16 + fr;
-                f32x4_t v = acc[mi][ni];
+                for (int mi = 0; mi < 8; ++mi) {
+                    const int row = (mi >> 2) * 128 + wm * 64 + (mi & 3) * 16 + fr;
+                    f32x4_t v = acc[mi][ni];
 #pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] = v[r] * p.alpha + bias4[r];
-                if (p.act != VALOR_ACT_NONE) {
+                    for (int r = 0; r < 4; ++r) v[r] = v[r] * p.alpha + bias4[r];
+                    if (apply_act) {
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) v[r] = act_fwd(p.act, v[r]);
+                        for (int r = 0; r < 4; ++r) v[r] = act_fwd(p.act, v[r]);
+                    }
+                    const u32x2_t w = {pack2_bf16(v[0], v[1]), pack2_bf16(v[2], v[3])};
+                    *(u32x2_t*)(sB + row * 512 + (((col >> 3) ^ (row & 31)) << 4) + (fg & 1) * 8) = w;
                 }
-                const u32x2_t w = {pack2_bf16(v[0], v[1]), pack2_bf16(v[2], v[3])};
-                *(u32x2_t*)(sB + row * 512 + (((col >> 3) ^ (row & 31)) << 4) + (fg & 1) * 8) = w;
             }
-        }
-        __syncthreads();
+        };
+        auto read_tile = [&](T* dst, bool dact, bool accum) {
 #pragma unroll 4
-        for (int it = 0; it < 16; ++it) {
-            const int ml = it * 16 + (tid >> 5), c = tid & 31;
-            const u32x4_t val = *(const u32x4_t*)(sB + ml * 512 + ((c ^ (ml & 31)) << 4));
-            const int m = m0 + ml, n = n0 + c * 8;
-            if (m < p.M && n < p.N) *(u32x4_t*)((T*)p.C + (int64_t)m * p.ldc + n) = val;
+            for (int it = 0; it < 16; ++it) {
+                const int ml = it * 16 + (tid >> 5), c = tid & 31;
+                u32x4_t val = *(const u32x4_t*)(sB + ml * 512 + ((c ^ (ml & 31)) << 4));
+                const int m = m0 + ml, n = n0 + c * 8;
+                if (m < p.M && n < p.N) {
+                    if (dact || accum) {
+                        float f[8];
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) { f[2 * q] = __uint_as_float(val[q] << 16); f[2 * q + 1] = __uint_as_float(val[q] & 0xffff0000u); }
+                        if (dact) {
+                            const u32x4_t a = *(const u32x4_t*)((const T*)p.dact_aux + (int64_t)m * p.ldaux + n);
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) {
+                                f[2 * q] *= act_bwd(p.act, __uint_as_float(a[q] << 16));
+                                f[2 * q + 1] *= act_bwd(p.act, __uint_as_float(a[q] & 0xffff0000u));
+                            }
+                        }
+                        if (accum) {
+                            const u32x4_t o = *(const u32x4_t*)(dst + (int64_t)m * p.ldc + n);
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) { f[2 * q] += __uint_as_float(o[q] << 16); f[2 * q + 1] += __uint_as_float(o[q] & 0xffff0000u); }
+                        }
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) val[q] = pack2_bf16(f[2 * q], f[2 * q + 1]);
+                    }
+                    *(u32x4_t*)(dst + (int64_t)m * p.ldc + n) = val;
+                }
+            }
+        };
+        if (p.preact) {                 // forward of a fused activation: the pre-activation copy first
+            write_tile(false);
+            __syncthreads();
+            read_tile((T*)p.preact, false, false);
+            __syncthreads();
         }
+        write_tile(p.act != VALOR_ACT_NONE && !p.dact_aux);
+        __syncthreads();
+        read_tile((T*)p.C, p.dact_aux != nullptr, p.accumulate != 0);
         return;
     }
 
@@ -376,7 +410,7 @@ extern "C" int valor_gemm_set_tr_asm(int v) {
 }
 
 // one-pass bf16 epilogue for plain problems; VALOR_GEMM_FAST_EPI=0/1 presets it
-static int g_8ph_fast_epi = [] { const char* e = getenv("VALOR_GEMM_FAST_EPI"); return e ? atoi(e) : 0; }();
+static int g_8ph_fast_epi = [] { const char* e = getenv("VALOR_GEMM_FAST_EPI"); return e ? atoi(e) : 1; }();
 extern "C" int valor_gemm_set_fast_epilogue(int v) {
     const int old = g_8ph_fast_epi;
     if (v >= 0) g_8ph_fast_epi = v;
@@ -385,9 +419,8 @@ extern "C" int valor_gemm_set_fast_epilogue(int v) {
 
 void launch_gemm_8ph(hipStream_t st, int transA, int transB, const GemmArgs& p_in) {
     GemmArgs p = p_in;
-    p.skew = p.kslices > 1 ? 0 : g_gemm_policy[1];
-    p.fast_epi = g_8ph_fast_epi && !p.out_f32 && !p.preact && !p.dact_aux && !p.accumulate && p.kslices <= 1 && (p.N & 7) == 0 &&
-                 (p.ldc & 7) == 0 && !p.rowsum_out;
+    p.fast_epi = g_8ph_fast_epi && !p.out_f32 && p.kslices <= 1 && (p.N & 7) == 0 && (p.ldc & 7) == 0 && !p.rowsum_out &&
+                 (!p.dact_aux || (p.ldaux & 7) == 0) && !(p.dact_aux && p.preact) && !transA;
     const int tiles = ((p.M + 255) / 256) * ((p.N + 255) / 256);
     dim3 grid(tiles * (p.kslices > 1 ? p.kslices : 1));
     const size_t lds = 2 * BUF_BYTES;

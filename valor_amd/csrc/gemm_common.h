@@ -21,9 +21,8 @@ struct GemmArgs {
     void* rowsum_out;          // [M], C's element type (fp32 when out_f32), or null
     float* rowsum_ws;          // split-K partials [kslices][M] fp32
     int rowsum_acc;            // out += sums
-    int skew;                  // 8-phase kernels: start skew of the first round's workgroups (units of ~4096 cycles), 0 = off
-    int fast_epi;              // 8-phase kernels: "plain" problem (bf16 C, no split-K / accumulate / preact / dact, N % 8 == 0, ldc % 8 == 0)
-                               // -> bias / activation in registers, ONE bf16 pass through LDS
+    int fast_epi;              // 8-phase kernels: bf16 C, no split-K / fused row sums, N % 8 == 0, ldc % 8 == 0 (ldaux % 8 == 0)
+                               // -> bias / activation in registers, bf16 tile passes through LDS (see gemm8.hip)
 };
 
 template <typename T>
