@@ -85,6 +85,10 @@ int valor_gemm_set_policy(int key, int value);
  *   residual add -- VideoSwin's per-sample stochastic depth, drop_path (videoswin.py:40-49, 243-244), with
  *   row_scale = floor(keep + U[0,1)) / keep drawn by the caller. backward: dx = dz * row_scale (dx must not alias dres). */
 int valor_ln_part_blocks(void);
+/* kernel family of the fused LayerNorm: 1 (default) = half a wave per row with 16-byte accesses for bf16 rows of 256 / 512 / 768 /
+ * 1024 columns, 0 = one wave per row everywhere. Same results (same arithmetic order per row up to the reduction tree, same
+ * dropout windows). Returns the previous value, v < 0 only queries. Tuning / A-B hook. */
+int valor_ln_set_variant(int v);
 int valor_bdrln_fwd(void* stream, int dtype, const void* x, const void* bias, const void* residual, const void* gamma,
                     const void* beta, void* z, void* y, float* mean, float* rstd, int64_t rows, int cols, float eps,
                     float p_drop, uint64_t seed, uint64_t offset, const float* row_scale, int64_t rows_per_scale);

@@ -23,6 +23,7 @@
 //   dgamma, dbeta, dbias as per-workgroup fp32 partial sums (deterministic two-stage
 //   column reduction; valor_colsum_finalize sums the partials).
 #include "common.h"
+#include <stdlib.h>
 
 #define LN_MAX_V 8          // 4-element vectors per lane, one wave per row: cols <= 64*4*8 = 2048
 #define LN_MAX_COLS 4096    // beyond LN_MAX_V: the wide kernels (4 waves per row)
@@ -230,6 +231,229 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(LnBwdArgs p) {
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// bf16 rows of 256 * NV8 columns (every transformer width of the model: 256 / 512 / 768 / 1024): HALF a wave per row, 16-byte
+// accesses (8 elements per lane and vector; a half-wave moves one contiguous 512-B segment per instruction, two rows are in
+// flight per wave). Same arithmetic and the same Philox windows as ln_fwd_kernel / ln_bwd_kernel (4 elements per counter), so the
+// two families can be mixed between forward and backward.
+// ---------------------------------------------------------------------------------------------
+DEVINL float half_sum(float v) {      // over the 32 lanes that share (lane >> 5)
+#pragma unroll
+    for (int o = 16; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+DEVINL void unpack8(u32x4_t r, float (&f)[8]) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) { f[2 * q] = __uint_as_float(r[q] << 16); f[2 * q + 1] = __uint_as_float(r[q] & 0xffff0000u); }
+}
+DEVINL u32x4_t pack8(const float (&f)[8]) {
+    return (u32x4_t){pack2_bf16(f[0], f[1]), pack2_bf16(f[2], f[3]), pack2_bf16(f[4], f[5]), pack2_bf16(f[6], f[7])};
+}
+
+template <int NV8>
+__global__ __launch_bounds__(256) void ln_fwd_h_kernel(LnArgs p) {
+    typedef bf16_t T;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, half = lane >> 5, hl = lane & 31;
+    const T* X = (const T*)p.x; const T* Bi = (const T*)p.bias; const T* R = (const T*)p.residual;
+    const T* G = (const T*)p.gamma; const T* Be = (const T*)p.beta;
+    T* Z = (T*)p.z; T* Y = (T*)p.y;
+    const int cols = p.cols;
+    const uint32_t thr = drop_threshold(p.p_drop);
+    const float keep_scale = p.p_drop > 0.f ? 1.0f / (1.0f - p.p_drop) : 1.0f;
+    const float inv_n = 1.0f / (float)cols;
+    for (int64_t row0 = ((int64_t)blockIdx.x * 4 + wave) * 2; row0 < p.rows; row0 += (int64_t)gridDim.x * 8) {
+        const int64_t row = row0 + half;
+        const bool ok = row < p.rows;
+        const int64_t base = row * cols;
+        float v[NV8][8];
+        float s = 0.f;
+        const float rsc = (p.row_scale && ok) ? p.row_scale[row / p.rows_per_scale] : 1.0f;
+#pragma unroll
+        for (int i = 0; i < NV8; ++i) {
+            const int c = (i * 32 + hl) * 8;
+            float t[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            if (ok) {
+                unpack8(*(const u32x4_t*)(X + base + c), t);
+                if (Bi) {
+                    float b8[8]; unpack8(*(const u32x4_t*)(Bi + c), b8);
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) t[k] += b8[k];
+                }
+                if (thr) {
+#pragma unroll
+                    for (int h4 = 0; h4 < 2; ++h4) {
+                        Philox4 rnd = philox4x32_10(p.seed, p.offset + (uint64_t)((base + c + 4 * h4) >> 2));
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) t[4 * h4 + k] = rnd.v[k] >= thr ? t[4 * h4 + k] * keep_scale : 0.f;
+                    }
+                }
+                if (p.row_scale) {
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) t[k] *= rsc;
+                }
+                if (R) {
+                    float r8[8]; unpack8(*(const u32x4_t*)(R + base + c), r8);
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) t[k] += r8[k];
+                }
+                if (Z) {
+                    const u32x4_t zq = pack8(t);
+                    *(u32x4_t*)(Z + base + c) = zq;
+                    unpack8(zq, t);                 // LN statistics use the value that backward will re-read from z
+                }
+#pragma unroll
+                for (int k = 0; k < 8; ++k) s += t[k];
+            }
+#pragma unroll
+            for (int k = 0; k < 8; ++k) v[i][k] = t[k];
+        }
+        if (!Y) continue;
+        const float mu = half_sum(s) * inv_n;
+        float q = 0.f;
+#pragma unroll
+        for (int i = 0; i < NV8; ++i)
+#pragma unroll
+            for (int k = 0; k < 8; ++k) { const float d = v[i][k] - mu; q += d * d; }
+        const float rs = rsqrtf(half_sum(q) * inv_n + p.eps);
+        if (!ok) continue;
+        if (hl == 0) {
+            if (p.mean) p.mean[row] = mu;
+            if (p.rstd) p.rstd[row] = rs;
+        }
+#pragma unroll
+        for (int i = 0; i < NV8; ++i) {
+            const int c = (i * 32 + hl) * 8;
+            float o[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) o[k] = (v[i][k] - mu) * rs;
+            if (G) {
+                float g8[8]; unpack8(*(const u32x4_t*)(G + c), g8);
+#pragma unroll
+                for (int k = 0; k < 8; ++k) o[k] *= g8[k];
+            }
+            if (Be) {
+                float b8[8]; unpack8(*(const u32x4_t*)(Be + c), b8);
+#pragma unroll
+                for (int k = 0; k < 8; ++k) o[k] += b8[k];
+            }
+            *(u32x4_t*)(Y + base + c) = pack8(o);
+        }
+    }
+}
+
+template <int NV8>
+__global__ __launch_bounds__(256) void ln_bwd_h_kernel(LnBwdArgs p) {
+    typedef bf16_t T;
+    __shared__ float red[3][8][32 * 8];   // [which][wave * 2 + half][hl * 8 + k], reused per vector i
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, half = lane >> 5, hl = lane & 31;
+    const T* DY = (const T*)p.dy; const T* DZI = (const T*)p.dz_in; const T* Z = (const T*)p.z;
+    const T* G = (const T*)p.gamma;
+    T* DX = (T*)p.dx; T* DR = (T*)p.dres;
+    const int cols = p.cols;
+    const uint32_t thr = drop_threshold(p.p_drop);
+    const float keep_scale = p.p_drop > 0.f ? 1.0f / (1.0f - p.p_drop) : 1.0f;
+    const float inv_n = 1.0f / (float)cols;
+    const bool has_ln = DY != nullptr;
+
+    float gsum[NV8][8], bsum[NV8][8], xsum[NV8][8], gam[NV8][8];
+#pragma unroll
+    for (int i = 0; i < NV8; ++i) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { gsum[i][k] = 0.f; bsum[i][k] = 0.f; xsum[i][k] = 0.f; gam[i][k] = 1.f; }
+        if (G) unpack8(*(const u32x4_t*)(G + (i * 32 + hl) * 8), gam[i]);
+    }
+    for (int64_t row0 = ((int64_t)blockIdx.x * 4 + wave) * 2; row0 < p.rows; row0 += (int64_t)gridDim.x * 8) {
+        const int64_t row = row0 + half;
+        const bool ok = row < p.rows;
+        const int64_t base = row * cols;
+        const float rsc = (p.row_scale && ok) ? p.row_scale[row / p.rows_per_scale] : 1.0f;
+        float dzv[NV8][8];
+        if (has_ln) {
+            const float mu = ok ? p.mean[row] : 0.f, rs = ok ? p.rstd[row] : 0.f;
+            float xh[NV8][8], gy[NV8][8];
+            float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+            for (int i = 0; i < NV8; ++i) {
+                const int c = (i * 32 + hl) * 8;
+                float zz[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, d[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                if (ok) { unpack8(*(const u32x4_t*)(Z + base + c), zz); unpack8(*(const u32x4_t*)(DY + base + c), d); }
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    xh[i][k] = ok ? (zz[k] - mu) * rs : 0.f;
+                    gsum[i][k] += d[k] * xh[i][k];
+                    bsum[i][k] += d[k];
+                    gy[i][k] = d[k] * gam[i][k];
+                    s1 += gy[i][k];
+                    s2 += gy[i][k] * xh[i][k];
+                }
+            }
+            s1 = half_sum(s1) * inv_n;
+            s2 = half_sum(s2) * inv_n;
+#pragma unroll
+            for (int i = 0; i < NV8; ++i)
+#pragma unroll
+                for (int k = 0; k < 8; ++k) dzv[i][k] = rs * (gy[i][k] - s1 - xh[i][k] * s2);
+        } else {
+#pragma unroll
+            for (int i = 0; i < NV8; ++i)
+#pragma unroll
+                for (int k = 0; k < 8; ++k) dzv[i][k] = 0.f;
+        }
+        if (!ok) continue;
+#pragma unroll
+        for (int i = 0; i < NV8; ++i) {
+            const int c = (i * 32 + hl) * 8;
+            float dz[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) dz[k] = dzv[i][k];
+            if (DZI) {
+                float a8[8]; unpack8(*(const u32x4_t*)(DZI + base + c), a8);
+#pragma unroll
+                for (int k = 0; k < 8; ++k) dz[k] += a8[k];
+            }
+            if (DR) *(u32x4_t*)(DR + base + c) = pack8(dz);
+            float dx[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) dx[k] = dz[k];
+            if (thr) {
+#pragma unroll
+                for (int h4 = 0; h4 < 2; ++h4) {
+                    Philox4 rnd = philox4x32_10(p.seed, p.offset + (uint64_t)((base + c + 4 * h4) >> 2));
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) dx[4 * h4 + k] = rnd.v[k] >= thr ? dz[4 * h4 + k] * keep_scale : 0.f;
+                }
+            }
+            if (p.row_scale) {
+#pragma unroll
+                for (int k = 0; k < 8; ++k) dx[k] *= rsc;
+            }
+            if (DX && (thr || p.row_scale || DX != DR)) *(u32x4_t*)(DX + base + c) = pack8(dx);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) xsum[i][k] += dx[k];
+        }
+    }
+    // cross-wave reduction of the column partials, one vector slot (256 columns) at a time: 8 half-waves own the same columns
+#pragma unroll
+    for (int i = 0; i < NV8; ++i) {
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            red[0][wave * 2 + half][hl * 8 + k] = gsum[i][k];
+            red[1][wave * 2 + half][hl * 8 + k] = bsum[i][k];
+            red[2][wave * 2 + half][hl * 8 + k] = xsum[i][k];
+        }
+        __syncthreads();
+        const int c = i * 256 + threadIdx.x;          // slot column threadIdx.x == (hl * 8 + k)
+        const int64_t o = (int64_t)blockIdx.x * cols + c;
+        float a0 = 0.f, a1 = 0.f, a2 = 0.f;
+#pragma unroll
+        for (int w = 0; w < 8; ++w) { a0 += red[0][w][threadIdx.x]; a1 += red[1][w][threadIdx.x]; a2 += red[2][w][threadIdx.x]; }
+        if (p.part_dgamma) p.part_dgamma[o] = a0;
+        if (p.part_dbeta) p.part_dbeta[o] = a1;
+        if (p.part_dbias) p.part_dbias[o] = a2;
+    }
+}
 
 // ---------------------------------------------------------------------------------------------
 // Wide rows (2048 < cols <= 4096: the 4C = 3072 LayerNorm of VideoSwin-L's last PatchMerging, videoswin.py:247-270): the
@@ -499,9 +723,28 @@ static void launch_ln_fwd_nv(hipStream_t st, const LnArgs& p) {
     if (blocks > 8192) blocks = 8192;
     hipLaunchKernelGGL((ln_fwd_kernel<T, NV>), dim3((unsigned)blocks), dim3(256), 0, st, p);
 }
+// half-wave-per-row kernels (bf16, cols = 256 * NV8 <= 1024); VALOR_LN_VARIANT=0 keeps the one-wave-per-row kernels (A/B runs)
+static int g_ln_variant = [] { const char* e = getenv("VALOR_LN_VARIANT"); return e ? atoi(e) : 1; }();
+extern "C" int valor_ln_set_variant(int v) { const int o = g_ln_variant; if (v >= 0) g_ln_variant = v; return o; }
+static bool ln_half_ok(int dt, int cols, const void* a, const void* b, const void* c, const void* d, const void* e) {
+    auto al = [](const void* q) { return ((uintptr_t)q & 15) == 0; };
+    return g_ln_variant && dt == VALOR_DT_BF16 && (cols & 255) == 0 && cols <= 1024 && al(a) && al(b) && al(c) && al(d) && al(e);
+}
+
 template <typename T>
 static int launch_ln_fwd(hipStream_t st, const LnArgs& p) {
     const int nv = (p.cols + 255) / 256;
+    if (ln_half_ok(ElemTraits<T>::DT, p.cols, p.x, p.bias, p.residual, p.z, p.y) && (((uintptr_t)p.gamma | (uintptr_t)p.beta) & 15) == 0) {
+        int64_t blocks = (p.rows + 7) / 8;
+        if (blocks > 8192) blocks = 8192;
+        switch (nv) {
+            case 1: hipLaunchKernelGGL((ln_fwd_h_kernel<1>), dim3((unsigned)blocks), dim3(256), 0, st, p); break;
+            case 2: hipLaunchKernelGGL((ln_fwd_h_kernel<2>), dim3((unsigned)blocks), dim3(256), 0, st, p); break;
+            case 3: hipLaunchKernelGGL((ln_fwd_h_kernel<3>), dim3((unsigned)blocks), dim3(256), 0, st, p); break;
+            default: hipLaunchKernelGGL((ln_fwd_h_kernel<4>), dim3((unsigned)blocks), dim3(256), 0, st, p); break;
+        }
+        return valor_launch_status();
+    }
     switch (nv) {
         case 1: launch_ln_fwd_nv<T, 1>(st, p); break;
         case 2: launch_ln_fwd_nv<T, 2>(st, p); break;
@@ -525,6 +768,15 @@ static void launch_ln_bwd_nv(hipStream_t st, const LnBwdArgs& p) {
 template <typename T>
 static int launch_ln_bwd(hipStream_t st, const LnBwdArgs& p) {
     const int nv = (p.cols + 255) / 256;
+    if (ln_half_ok(ElemTraits<T>::DT, p.cols, p.dy, p.dz_in, p.z, p.dx, p.dres) && ((uintptr_t)p.gamma & 15) == 0) {
+        switch (nv) {
+            case 1: hipLaunchKernelGGL((ln_bwd_h_kernel<1>), dim3(LN_PART_BLOCKS), dim3(256), 0, st, p); break;
+            case 2: hipLaunchKernelGGL((ln_bwd_h_kernel<2>), dim3(LN_PART_BLOCKS), dim3(256), 0, st, p); break;
+            case 3: hipLaunchKernelGGL((ln_bwd_h_kernel<3>), dim3(LN_PART_BLOCKS), dim3(256), 0, st, p); break;
+            default: hipLaunchKernelGGL((ln_bwd_h_kernel<4>), dim3(LN_PART_BLOCKS), dim3(256), 0, st, p); break;
+        }
+        return valor_launch_status();
+    }
     switch (nv) {
         case 1: launch_ln_bwd_nv<T, 1>(st, p); break;
         case 2: launch_ln_bwd_nv<T, 2>(st, p); break;

@@ -28,6 +28,7 @@ SIGNATURES = {
     "valor_gemm_set_fast_epilogue": [_i],
     "valor_gemm_set_policy": [_i, _i],
     "valor_ln_part_blocks": [],
+    "valor_ln_set_variant": [_i],
     "valor_bdrln_fwd": [_vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i, _f, _f, _u64, _u64, _vp, _i64],
     "valor_bdrln_bwd": [_vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i, _f, _u64, _u64, _vp, _i64],
     "valor_patchify3d": [_vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _i],
