@@ -86,7 +86,8 @@ int valor_gemm_set_policy(int key, int value);
  *   row_scale = floor(keep + U[0,1)) / keep drawn by the caller. backward: dx = dz * row_scale (dx must not alias dres). */
 int valor_ln_part_blocks(void);
 /* kernel family of the fused LayerNorm: 1 (default) = half a wave per row with 16-byte accesses for bf16 rows of 256 / 512 / 768 /
- * 1024 columns, 0 = one wave per row everywhere. Same results (same arithmetic order per row up to the reduction tree, same
+ * 1024 columns in the forward (and in the backward at 1024 columns, where it measured faster), 2 = in forward and backward
+ * everywhere, 0 = one wave per row everywhere. Same results (same arithmetic order per row up to the reduction tree, same
  * dropout windows). Returns the previous value, v < 0 only queries. Tuning / A-B hook. */
 int valor_ln_set_variant(int v);
 int valor_bdrln_fwd(void* stream, int dtype, const void* x, const void* bias, const void* residual, const void* gamma,
@@ -187,7 +188,9 @@ int valor_grad_norm_clip(void* stream, int dtype, const void* grad, const int8_t
 
 /* ---- data-movement kernels around the core */
 /* conv(kernel=stride=P) as GEMM: clip.py:227,261 ; modeling.py:744,752 */
-int valor_patchify(void* stream, int dtype, const float* in, void* out, int N, int C, int H, int W, int P);
+int valor_patchify(void* stream, int dtype, const float* in, void* out, int N, int C, int H, int W, int P, int64_t ld_out);
+/* ld_out: row stride of `out` in elements (0 = C*P*P); > C*P*P when rows are padded to whole 16-byte GEMM chunks (ViT-L/14:
+ * 588 -> 592; the pad columns are the caller's to zero). P must be even. */
 /* VideoSwin PatchEmbed3D (videoswin.py:361-369): Conv3d(kernel (2,P,P), stride (1,P,P)) over the clip with one zero frame
  * appended, as a GEMM operand. in: fp32 [B, F, C, H, W] (the batch layout of data/data.py:423-428, no transpose);
  * out [B*F*(H/P)*(W/P)][C*2*P*P], column (c*2 + kd)*P*P + i*P + j = in[b][d + kd][c][py*P + i][px*P + j] (0 for d + kd == F) */

@@ -149,10 +149,13 @@ class _FakeJit:
         return self._sd
 
 
-def build_reference(opts=None, state_dict=None, dropout=0.0, clip_layers=None, bert_layers=None):
+def build_reference(opts=None, state_dict=None, dropout=0.0, clip_layers=None, bert_layers=None, fakes=None):
     """Instantiate the reference VALOR on CPU (fp32). state_dict: canonical VALOR state dict to load (strict).
     clip_layers = (vision, text) / bert_layers: build shallower component stacks (the reference derives the CLIP depth from the
-    checkpoint's keys and the BERT depth from its json config), for pins that have to finish in seconds."""
+    checkpoint's keys and the BERT depth from its json config), for pins that have to finish in seconds.
+    fakes: optional {"bert" | "ast" | "clip" | "swin": state dict} handed to the reference's torch.load / torch.jit.load calls in
+    place of the zero-filled stand-ins (to pin the component-checkpoint key mappings of valor_amd.checkpoint)."""
+    fakes = fakes or {}
     _install()
     opts = opts or default_opts()
     bert_cfg = dict(BERT_CFG, num_hidden_layers=bert_layers) if bert_layers else BERT_CFG
@@ -169,9 +172,11 @@ def build_reference(opts=None, state_dict=None, dropout=0.0, clip_layers=None, b
     def fake_load(path, *a, **k):
         p = str(path)
         if "bert-base-uncased.bin" in p:
-            return _fake_bert_sd(bert_cfg)
+            return fakes["bert"] if "bert" in fakes else _fake_bert_sd(bert_cfg)
         if "audioset" in p:
-            return _fake_ast_sd()
+            return fakes["ast"] if "ast" in fakes else _fake_ast_sd()
+        if ("videoswin" in p or "video-swin" in p) and "swin" in fakes:
+            return fakes["swin"]
         if "videoswin" in p or "video-swin" in p:
             from model.videoswin import SwinTransformer3D
             if "small" in opts.video_encoder_type:
@@ -180,7 +185,7 @@ def build_reference(opts=None, state_dict=None, dropout=0.0, clip_layers=None, b
         return real_load(path, *a, **k)
 
     torch.load = fake_load
-    torch.jit.load = lambda path, *a, **k: _FakeJit(_fake_clip_sd(clip_kind, *(clip_layers or (None, None))))
+    torch.jit.load = lambda path, *a, **k: _FakeJit(fakes["clip"] if "clip" in fakes else _fake_clip_sd(clip_kind, *(clip_layers or (None, None))))
     try:
         from model.pretrain import VALOR
         model = VALOR.from_pretrained(opts, {})

@@ -136,3 +136,65 @@ def test_optimizer_state_dict_is_the_references(variant):
     ropt2 = build_optimizer(_Named(sd, spec), opts)
     ropt2.load_state_dict(back)
     assert len(ropt2.state_dict()["state"]) == len(ref_sd["state"])
+
+
+@needs_ref
+@pytest.mark.parametrize("variant", ["clip", "swin", "clip_large_bert"])
+def test_component_checkpoint_mappings_are_the_reference_constructors(variant):
+    """The reference's constructor reads CLIP / VideoSwin / AST / BERT checkpoints from ./pretrained_weights and renames / splits /
+    resizes them into its modules (modeling.py:512-554 incl. the AST positional-embedding interpolation :520-528, :560-573 +
+    clip.py:470-515 incl. the 336 -> 224 px CLIP resize, :591-600, :613-660). Component files with seeded RANDOM values go through the
+    unmodified constructor (ref_harness hands them to its torch.load / torch.jit.load calls) and through
+    valor_amd.checkpoint.load_pretrained_components: every tensor the mapping produces must be bit-identical to the constructed
+    reference model's, and every reference tensor the mapping does not produce must be one the reference leaves at its init."""
+    from valor_amd.checkpoint import load_pretrained_components
+    g = torch.Generator().manual_seed(17)
+    rnd = lambda sd: {k: (torch.randn(v.shape, generator=g) if v.is_floating_point() else v) for k, v in sd.items()}
+    bert_cfg = dict(ref_harness.BERT_CFG, num_hidden_layers=2)
+    kind = {"clip": "clip_vit_base_16", "swin": "clip_vit_base_16", "clip_large_bert": "clip_vit_large_14_336px"}[variant]
+    fakes = {"bert": rnd(ref_harness._fake_bert_sd(bert_cfg)), "ast": rnd(ref_harness._fake_ast_sd()),
+             "clip": rnd(ref_harness._fake_clip_sd(kind, 2, 1))}
+    # a real bert-base-uncased.bin: every embedding / encoder / pooler tensor under `bert.`, LayerNorms under the old gamma / beta names
+    import dataclasses as _dc
+    for k, shape, kind in synth.state_dict_layout(_dc.replace(synth.base_spec(), layers=2)):
+        if k.startswith("multimodal_encoder.") and "cross_attn" not in k and "prompt_embedding" not in k:
+            name = "bert." + k[len("multimodal_encoder."):].replace("LayerNorm.weight", "LayerNorm.gamma").replace("LayerNorm.bias", "LayerNorm.beta")
+            fakes["bert"][name] = torch.randn(shape, generator=g)
+    over = {"clip": {}, "swin": dict(video_encoder_type="videoswin_base_k400_22k", txt_encoder_type="bert_base_uncased"),
+            "clip_large_bert": dict(video_encoder_type="clip_vit_large_14_336px", txt_encoder_type="bert_base_uncased")}[variant]
+    ropts = ref_harness.default_opts(**over)
+    if variant == "swin":
+        ref_harness._install()
+        from model.videoswin import SwinTransformer3D
+        fakes["swin"] = rnd(SwinTransformer3D(embed_dim=128, num_heads=[4, 8, 16, 32]).state_dict())
+    ref = ref_harness.build_reference(ropts, state_dict=None, bert_layers=2, fakes={k: {a: b.clone() for a, b in v.items()} for k, v in fakes.items()})
+    rsd = ref.state_dict()
+    files = {"bert-base-uncased.bin": fakes["bert"], "audioset_10_10_0.4593.pth": fakes["ast"]}
+    if "swin" in fakes:
+        files["videoswin_base_k400_22k.pth"] = fakes["swin"]
+    mine = load_pretrained_components(ropts, root="", load=lambda p: {k: v.clone() for k, v in files[os.path.basename(p)].items()},
+                                      jit_load=lambda p: {k: v.clone() for k, v in fakes["clip"].items()})
+    produced = 0
+    for k, v in mine.items():
+        if k not in rsd:          # what the reference's strict=False loads drop: the distillation token, HF head / pooler extras
+            assert k.startswith("multimodal_encoder.cls.") or "distill" in k or "seq_relationship" in k, k
+            continue
+        assert rsd[k].shape == v.shape and torch.equal(rsd[k].float(), v.float()), k
+        produced += 1
+    assert produced > {"clip": 250, "swin": 600, "clip_large_bert": 250}[variant]
+    if variant != "swin":
+        assert mine["clip_model.visual.positional_embedding"].shape[0] == (224 // (16 if variant == "clip" else 14)) ** 2 + 1
+    assert mine["audio_embeddings.position_embeddings.weight"].shape == (129, 768)
+    # and the merged dict loads into the native model's layout (CPU construction: tables only)
+    from valor_amd.model.valor import VALOR
+    import dataclasses
+    spec = {"clip": synth.base_spec(), "swin": synth.swin_spec(), "clip_large_bert": synth.clip_large_spec()}[variant]
+    spec = dataclasses.replace(spec, layers=2, **({} if variant == "swin" else dict(vis_layers=2, txt_layers=1)))
+    model = VALOR({k: v for k, v in vars(ropts).items()} if hasattr(ropts, "__dict__") else dict(ropts), spec=spec, dtype=torch.float32, device="cpu")
+    missing, unexpected = model.load_state_dict(mine, strict=False)
+    fresh = ("contra_head_t", "contra_head_v", "contra_head_a", "text_fine_weight", "video_fine_weight", "audio_fine_weight", "contra_temp",
+             "video_type_embeddings", "audio_type_embeddings", "video_frame_embedding", "audio_frame_embedding", "hidden_trans_video_multimodal",
+             "hidden_trans_audio_multimodal")
+    odd = [k for k in missing if not ("cross_attn" in k or "prompt_embedding" in k or "pooler" in k or k.split(".")[0] in fresh)]
+    assert not odd, odd[:8]
+    assert torch.equal(model.state_dict()["audio_encoder.layer.3.attention.linears.1.weight"], mine["audio_encoder.layer.3.attention.linears.1.weight"])

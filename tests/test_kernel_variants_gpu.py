@@ -137,7 +137,7 @@ def test_gemm_8phase_fast_epilogue(dev, gemm_variant):
             U = _mk((M, N), 9, dev)
             z = X.double() @ (W.double() if tb else W.double().t()) + b.double()
             res = {}
-            for mode in (0, 1):
+            for mode in (0, 2):           # 2 = the tile path wherever it is implemented (1, the default, leaves preact / dact on the general one)
                 gemm_variant.valor_gemm_set_fast_epilogue(mode)
                 y = K.gemm(X, W, trans_b=tb, bias=b, act=lib.ACT_GELU_ERF, splitk=False)
                 out, pre = K.gemm(X, W, trans_b=tb, bias=b, act=lib.ACT_QUICK_GELU, want_preact=True, splitk=False)
@@ -151,8 +151,8 @@ def test_gemm_8phase_fast_epilogue(dev, gemm_variant):
                 (g,) = torch.autograd.grad(F.gelu(ud).sum(), ud)
                 assert _rel(du, (z - b.double()) * g) < 8e-3
                 assert _rel(Cacc, 1.0 + z - b.double()) < 6e-3
-            assert max(_rel(res[1][i], res[0][i]) for i in range(3)) < 1e-3          # same fp32 accumulators, rounded once in both
-            assert _rel(res[1][3], res[0][3]) < 6e-3 and _rel(res[1][4], res[0][4]) < 6e-3
+            assert max(_rel(res[2][i], res[0][i]) for i in range(3)) < 1e-3          # same fp32 accumulators, rounded once in both
+            assert _rel(res[2][3], res[0][3]) < 6e-3 and _rel(res[2][4], res[0][4]) < 6e-3
     finally:
         gemm_variant.valor_gemm_set_fast_epilogue(old)
 
@@ -182,7 +182,7 @@ def test_gemm_fused_rowsum(dev, gemm_variant):
         K.gemm(dY, X, trans_a=True, trans_b=True, rowsum_out=torch.zeros(768, dtype=torch.bfloat16, device=dev))
 
 
-@pytest.mark.parametrize("variant", [0, 3])
+@pytest.mark.parametrize("variant", [0, 3, 7])       # 0 streaming, 3 LDS-resident single-kernel backward, 7 (default) split-by-phase backward
 def test_attention_families_self(dev, attn_variant, variant):
     from valor_amd import kernels as K
     attn_variant.valor_attn_set_variant(variant)
@@ -243,7 +243,7 @@ def test_attention_dropout_same_mask_in_every_family(dev, attn_variant):
     k = torch.randn((B, S, E), device=dev).to(torch.bfloat16)
     v = torch.eye(S, device=dev)[:, :64].repeat(1, H)[None].expand(B, S, E).contiguous().to(torch.bfloat16)
     keeps = []
-    for var in (0, 3):
+    for var in (0, 3, 7):
         attn_variant.valor_attn_set_variant(var)
         o, lse = K.attn_fwd(q, k, v, H, p_drop=pd, seed=7, offset=11)
         keep = (o.float() * S * (1 - pd) > 0.5)
@@ -253,7 +253,7 @@ def test_attention_dropout_same_mask_in_every_family(dev, attn_variant):
         got = dv.float().view(B, S, H, 64)[:, :64, :, 0].permute(0, 2, 1)
         assert torch.allclose(got, want, atol=2e-2), (var, (got - want).abs().max())
         keeps.append(keep)
-    assert torch.equal(keeps[0], keeps[1])
+    assert torch.equal(keeps[0], keeps[1]) and torch.equal(keeps[0], keeps[2])
     # grouped cross attention
     B, H, Sq, Skv, bmod = 4, 2, 32, 256, 2
     E = H * 64
@@ -273,3 +273,30 @@ def test_attention_dropout_same_mask_in_every_family(dev, attn_variant):
         assert torch.allclose(got, want, atol=2e-2), (var, (got - want).abs().max())
         keeps.append(keep)
     assert torch.equal(keeps[0], keeps[1])
+
+
+@pytest.mark.parametrize("cols,rows,p,scaled", [(768, 1001, 0.0, False), (768, 514, 0.1, False), (1024, 333, 0.1, True), (512, 77, 0.0, False), (256, 9, 0.25, True)])
+def test_layernorm_families_agree(dev, cols, rows, p, scaled):
+    """fused bias + dropout + residual + LayerNorm: one-wave-per-row kernels (variant 0) vs half-a-wave-per-row kernels with 16-byte
+    accesses (variant 2 = forward AND backward): bit-identical z (same Philox windows, same adds), y / statistics / dx / dres and the
+    column sums dgamma / dbeta / dbias equal up to the reduction order; odd row counts leave a half wave without a row."""
+    from valor_amd import kernels as K, lib
+    so = lib.load()
+    old = so.valor_ln_set_variant(-1)
+    g = torch.Generator().manual_seed(cols + rows)
+    mk = lambda *s: torch.randn(s, generator=g).to(torch.bfloat16).to(dev)
+    x, res, bias, gam, bet, dy, dz = mk(rows, cols), mk(rows, cols), mk(cols), mk(cols), mk(cols), mk(rows, cols), mk(rows, cols)
+    rs = (torch.rand((rows + 6) // 7, generator=g) > 0.3).float().mul(1.25).to(dev) if scaled else None
+    outs = {}
+    try:
+        for v in (0, 2):
+            so.valor_ln_set_variant(v)
+            z, y, mean, rstd = K.bdrln_fwd(x, bias, res, gam, bet, 1e-5, p_drop=p, seed=5, offset=3, row_scale=rs, rows_per_scale=7 if scaled else 0)
+            dx, dres, dg, db, dbias = K.bdrln_bwd(dy, dz, z, mean, rstd, gam, p_drop=p, seed=5, offset=3, want_dbias=True, row_scale=rs,
+                                                  rows_per_scale=7 if scaled else 0)
+            outs[v] = [t.float().clone() for t in (z, y, mean, rstd, dx, dres, dg, db, dbias)]
+    finally:
+        so.valor_ln_set_variant(old)
+    assert torch.equal(outs[0][0], outs[2][0])
+    for name, a, b in zip(("y", "mean", "rstd", "dx", "dres", "dgamma", "dbeta", "dbias"), outs[2][1:], outs[0][1:]):
+        assert float((a - b).norm()) <= 4e-3 * float(b.norm()) + 1e-6, name

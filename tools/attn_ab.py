@@ -64,7 +64,7 @@ def check():
         outs[var] = keep
         print(f"variant {var} dropout: keep frac {keep.float().mean().item():.4f} (want {1 - pd}), fwd/bwd mask agreement max err {(got - want).abs().max().item():.3e}", flush=True)
     if len(VARS) > 1:
-        print("dropout masks identical across variants:", bool(torch.equal(outs[VARS[0]], outs[VARS[1]])), flush=True)
+        print("dropout masks identical across variants:", all(bool(torch.equal(outs[VARS[0]], outs[v])) for v in VARS[1:]), flush=True)
 
 
 def bench(rounds=3, n=5):

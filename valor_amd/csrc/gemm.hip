@@ -464,14 +464,18 @@ extern "C" int valor_gemm_set_policy(int key, int value) {
     return old;
 }
 
-static bool use_8ph(int dtype, int transA, int transB, int M, int N, int K) {
+// `heavy_epi`: the epilogue reads a second [M, N] operand (act' multiply of a fused-activation dgrad). One 256x256 workgroup per CU
+// cannot overlap its epilogue with anybody's main loop, four 128x128 workgroups per CU can: measured on the ViT fc2 dgrad
+// (K = 768, profiles/r02_gemm_epilogue_ab.json) 769 us on the 128x128 kernel vs 896 us on the 8-phase one, while the PLAIN dgrad of
+// the same shape is 510 vs 544 us the other way round.
+static bool use_8ph(int dtype, int transA, int transB, int M, int N, int K, bool heavy_epi = false) {
     if (dtype != VALOR_DT_BF16 || g_gemm_variant < 3) return false;
     if ((K % 64) != 0 || K < 128 || M < 256 || N < 256) return false;
     if (g_gemm_variant == 3) return true;
     const int64_t tiles256 = (int64_t)((M + 255) / 256) * ((N + 255) / 256);
     if (transA && transB) return K >= 4096;                           // wgrad: K = tokens, split-K fills one round
     if (!transA && !transB) return tiles256 >= g_gemm_policy[2] && K >= 512;      // forward: >= 4 rounds of 256 workgroups
-    if (!transA && transB) return tiles256 >= g_gemm_policy[2] && K >= g_gemm_policy[0];      // dgrad
+    if (!transA && transB) return tiles256 >= g_gemm_policy[2] && K >= (heavy_epi ? 1536 : g_gemm_policy[0]);      // dgrad
     return false;
 }
 
@@ -509,7 +513,7 @@ static int launch_gemm(hipStream_t st, int transA, int transB, GemmArgs p) {
     dim3 grid(tiles, p.kslices > 1 ? p.kslices : 1);
     if (ElemTraits<T>::DT == VALOR_DT_BF16 && g_gemm_variant > 0) {
         if (p.kslices > 1) grid = dim3(tiles * p.kslices, 1);     // split-K: 1-D grid over (slice, tile) work items
-        if (use_8ph(VALOR_DT_BF16, transA, transB, p.M, p.N, p.K)) launch_gemm_8ph(st, transA, transB, p);
+        if (use_8ph(VALOR_DT_BF16, transA, transB, p.M, p.N, p.K, p.dact_aux != nullptr)) launch_gemm_8ph(st, transA, transB, p);
         else if (g_gemm_variant == 2) launch_gemm_glds<2>(st, transA, transB, p, grid);
         else launch_gemm_glds<1>(st, transA, transB, p, grid);
         if (p.kslices > 1) {
@@ -593,7 +597,7 @@ extern "C" int valor_gemm(void* stream, int dtype, int transA, int transB, int M
         // split-K of the LDS-DMA kernels: as many K-slices as fill -- without overflowing -- ONE round of workgroup
         // slots (128x128 kernel: 4 per CU = 1024; 256x256 kernel: 1 per CU = 256); >= 6 K-steps per workgroup.
         slices = 1;
-        const bool big = use_8ph(dtype, transA, transB, M, N, K);
+        const bool big = use_8ph(dtype, transA, transB, M, N, K, dact_aux != nullptr);
         const int tiles_x = big ? ((M + 255) / 256) * ((N + 255) / 256) : tiles;
         const int slots = big ? 256 : 1024;
         if (workspace && 2 * tiles_x <= slots && nk >= 24) {

@@ -768,7 +768,9 @@ static void launch_ln_bwd_nv(hipStream_t st, const LnBwdArgs& p) {
 template <typename T>
 static int launch_ln_bwd(hipStream_t st, const LnBwdArgs& p) {
     const int nv = (p.cols + 255) / 256;
-    if (ln_half_ok(ElemTraits<T>::DT, p.cols, p.dy, p.dz_in, p.z, p.dx, p.dres) && ((uintptr_t)p.gamma & 15) == 0) {
+    // measured (profiles/r02_ln_ab.json): the half-wave backward needs 194+ VGPRs (2 waves per SIMD) and LOSES at 768 columns
+    // (171 vs 143 us) but wins at 1024 (261 vs 339 us); variant 2 forces it everywhere (tests / A-B runs)
+    if ((g_ln_variant >= 2 || p.cols == 1024) && ln_half_ok(ElemTraits<T>::DT, p.cols, p.dy, p.dz_in, p.z, p.dx, p.dres) && ((uintptr_t)p.gamma & 15) == 0) {
         switch (nv) {
             case 1: hipLaunchKernelGGL((ln_bwd_h_kernel<1>), dim3(LN_PART_BLOCKS), dim3(256), 0, st, p); break;
             case 2: hipLaunchKernelGGL((ln_bwd_h_kernel<2>), dim3(LN_PART_BLOCKS), dim3(256), 0, st, p); break;

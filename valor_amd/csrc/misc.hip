@@ -9,18 +9,22 @@
 // Replaces the im2col inside nn.Conv2d(kernel = stride = P): clip.py:227,261 (CLIP conv1, P=16, C=3)
 // and modeling.py:744,752 (AST first_conv, P=16, C=1); the cast to the compute dtype is fused.
 // ---------------------------------------------------------------------------------------------
-template <typename T>
-__global__ void patchify_kernel(const float* in, T* out, int N, int C, int H, int W, int P) {
+// VEC consecutive pixels of one patch row per thread: 4 when P % 4 == 0 (ViT-B/16, AST), 2 for the even patch sizes that are not
+// (ViT-L/14). ldo = row stride of `out` in elements (>= K: rows may be padded to whole 16-byte GEMM chunks; the pad is the caller's).
+template <typename T, int VEC>
+__global__ void patchify_kernel(const float* in, T* out, int N, int C, int H, int W, int P, int64_t ldo) {
     const int gh = H / P, gw = W / P, K = C * P * P;
-    const int64_t total4 = (int64_t)N * gh * gw * K / 4;
-    for (int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; q < total4; q += (int64_t)gridDim.x * blockDim.x) {
-        const int64_t e = q * 4;
+    const int64_t totalv = (int64_t)N * gh * gw * K / VEC;
+    for (int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; q < totalv; q += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t e = q * VEC;
         const int k = (int)(e % K);
         const int64_t tok = e / K;
         const int px = (int)(tok % gw), py = (int)((tok / gw) % gh), n = (int)(tok / ((int64_t)gw * gh));
-        const int c = k / (P * P), ij = k % (P * P), i = ij / P, j = ij % P;   // j % 4 == 0 (P % 4 == 0)
+        const int c = k / (P * P), ij = k % (P * P), i = ij / P, j = ij % P;   // j % VEC == 0 (P % VEC == 0)
         const float* src = in + (((int64_t)n * C + c) * H + (py * P + i)) * W + px * P + j;
-        store4<T>(out + e, *(const f32x4_t*)src);
+        T* dst = out + tok * ldo + k;
+        if constexpr (VEC == 4) store4<T>(dst, *(const f32x4_t*)src);
+        else { dst[0] = from_f32<T>(src[0]); dst[1] = from_f32<T>(src[1]); }
     }
 }
 
@@ -335,14 +339,24 @@ static inline int grid_for(int64_t work, int block = 256, int cap = 8192) {
     else if ((dtype) == VALOR_DT_F32) { CALL_F32; }         \
     else return VALOR_ERR_ARG;
 
-extern "C" int valor_patchify(void* stream, int dtype, const float* in, void* out, int N, int C, int H, int W, int P) {
+extern "C" int valor_patchify(void* stream, int dtype, const float* in, void* out, int N, int C, int H, int W, int P, int64_t ld_out) {
     if (N <= 0) return VALOR_OK;
-    if (!in || !out || (P & 3) || H % P || W % P) return VALOR_ERR_ARG;
+    const int64_t K = (int64_t)C * P * P;
+    if (ld_out <= 0) ld_out = K;
+    if (!in || !out || (P & 1) || H % P || W % P || ld_out < K) return VALOR_ERR_ARG;
+    const bool v4 = (P & 3) == 0 && (ld_out & 3) == 0;
+    if (!v4 && (W & 1)) return VALOR_ERR_ARG;
     hipStream_t st = (hipStream_t)stream;
-    const int64_t work = (int64_t)N * C * H * W / 4;
-    DISPATCH_T(dtype,
-        hipLaunchKernelGGL((patchify_kernel<bf16_t>), dim3(grid_for(work)), dim3(256), 0, st, in, (bf16_t*)out, N, C, H, W, P),
-        hipLaunchKernelGGL((patchify_kernel<float>), dim3(grid_for(work)), dim3(256), 0, st, in, (float*)out, N, C, H, W, P));
+    const int64_t work = (int64_t)N * C * H * W / (v4 ? 4 : 2);
+    if (v4) {
+        DISPATCH_T(dtype,
+            hipLaunchKernelGGL((patchify_kernel<bf16_t, 4>), dim3(grid_for(work)), dim3(256), 0, st, in, (bf16_t*)out, N, C, H, W, P, ld_out),
+            hipLaunchKernelGGL((patchify_kernel<float, 4>), dim3(grid_for(work)), dim3(256), 0, st, in, (float*)out, N, C, H, W, P, ld_out));
+    } else {
+        DISPATCH_T(dtype,
+            hipLaunchKernelGGL((patchify_kernel<bf16_t, 2>), dim3(grid_for(work)), dim3(256), 0, st, in, (bf16_t*)out, N, C, H, W, P, ld_out),
+            hipLaunchKernelGGL((patchify_kernel<float, 2>), dim3(grid_for(work)), dim3(256), 0, st, in, (float*)out, N, C, H, W, P, ld_out));
+    }
     return valor_launch_status();
 }
 

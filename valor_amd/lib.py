@@ -57,7 +57,7 @@ SIGNATURES = {
     "valor_adamw_chunk": [],
     "valor_adamw": [_vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _c.POINTER(_f), _c.POINTER(_f), _i, _f, _f, _f, _i, _i, _vp, _i],
     "valor_grad_norm_clip": [_vp, _i, _vp, _vp, _i64, _f, _f, _vp, _vp, _vp],
-    "valor_patchify": [_vp, _i, _vp, _vp, _i, _i, _i, _i, _i],
+    "valor_patchify": [_vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _i64],
     "valor_assemble_tokens_fwd": [_vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i],
     "valor_assemble_tokens_bwd": [_vp, _i, _vp, _vp, _vp, _i, _i, _i],
     "valor_sum_over_batch": [_vp, _i, _vp, _vp, _i, _i, _i],

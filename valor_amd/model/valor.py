@@ -456,14 +456,13 @@ class VALOR(nn.Module):
         P, sp = self.P, self.spec
         b, n, c, h, w = video_pixels.shape
         imgs = self._dev(video_pixels.reshape(b * n, c, h, w).float())
-        patches = ops.patchify(imgs, sp.patch, self.dtype)
         wconv = P["clip_model.visual.conv1.weight"].view(sp.vis_width, -1)
         vec = 8 if self.dtype == torch.bfloat16 else 4
-        if patches.shape[1] % vec:
-            # ViT-L/14: 3 * 14 * 14 = 588 contraction elements per patch; the GEMM stages 16-byte chunks, so operand rows are
-            # zero-padded to the next chunk (592). Pure data movement; the weight's gradient flows back through the column slice.
-            kp = (patches.shape[1] + vec - 1) // vec * vec
-            pp = patches.new_zeros((patches.shape[0], kp)); pp[:, :patches.shape[1]].copy_(patches); patches = pp
+        kp = (wconv.shape[1] + vec - 1) // vec * vec
+        # ViT-L/14: 3 * 14 * 14 = 588 contraction elements per patch; the GEMM stages 16-byte chunks, so operand rows are
+        # zero-padded to the next chunk (592). Pure data movement; the weight's gradient flows back through the column slice.
+        patches = ops.patchify(imgs, sp.patch, self.dtype, pad_to=kp)
+        if kp != wconv.shape[1]:
             wconv = ops.pad_cols(wconv, kp)
         tok = ops.linear(patches, wconv, None)
         Pn = sp.vis_tokens - 1

@@ -700,12 +700,18 @@ def pad_cols(w, kp):
     return PadColsFn.apply(w, kp)
 
 
-def patchify(images_f32, P, out_dtype):
-    """[N,C,H,W] fp32 -> [N*(H/P)*(W/P), C*P*P] GEMM operand rows in the compute dtype (no grad)."""
+def patchify(images_f32, P, out_dtype, pad_to=0):
+    """[N,C,H,W] fp32 -> [N*(H/P)*(W/P), C*P*P] GEMM operand rows in the compute dtype (no grad). pad_to > C*P*P: rows of pad_to
+    columns, zero beyond C*P*P (ViT-L/14: 588 -> 592, whole 16-byte chunks for the GEMM's staging)."""
     N, C, H, W = images_f32.shape
     images_f32 = images_f32.contiguous()
-    out = torch.empty((N * (H // P) * (W // P), C * P * P), dtype=out_dtype, device=images_f32.device)
-    lib.call("valor_patchify", _st(), _dt(out), _p(images_f32), _p(out), N, C, H, W, P)
+    K = C * P * P
+    rows = N * (H // P) * (W // P)
+    if pad_to > K:
+        out = torch.zeros((rows, pad_to), dtype=out_dtype, device=images_f32.device)
+    else:
+        out = torch.empty((rows, K), dtype=out_dtype, device=images_f32.device)
+    lib.call("valor_patchify", _st(), _dt(out), _p(images_f32), _p(out), N, C, H, W, P, out.shape[1])
     return out
 
 
