@@ -169,6 +169,11 @@ int valor_fine_weight_softmax_bwd(void* stream, const float* w, const float* dw,
 int valor_fine_reduce_fwd(void* stream, const float* S, int64_t ldS, const float* maskA, const float* maskB,
                           const float* wA, const float* wB, float* score, float* A2B, float* B2A, uint8_t* idxA,
                           uint8_t* idxB, int B, int T, int Nv);
+/* evaluation: the score matrix alone for NA text items x NB video / audio items (rectangular, nothing saved for a backward):
+ * test.py:534-660 -> VALOR.compute_fine_matrix (pretrain.py:178-211). S fp32 [NA*T, ldS]; maskA, wA [NA,T]; maskB, wB [NB,Nv];
+ * score [NA,NB]; NA <= 65535 per call (the reference itself slices NA by 100 above 1200 items, pretrain.py:179-186). */
+int valor_fine_scores(void* stream, const float* S, int64_t ldS, const float* maskA, const float* maskB, const float* wA,
+                      const float* wB, float* score, int NA, int NB, int T, int Nv);
 int valor_infonce_fwd(void* stream, const float* score, const float* k_dev, float* lse_r, float* lse_c, float* loss, int B);
 int valor_infonce_bwd(void* stream, const float* score, const float* k_dev, const float* lse_r, const float* lse_c,
                       const float* g_dev, float* dscore, float* dk, float* part, int B);

@@ -182,7 +182,7 @@ def test_gemm_fused_rowsum(dev, gemm_variant):
         K.gemm(dY, X, trans_a=True, trans_b=True, rowsum_out=torch.zeros(768, dtype=torch.bfloat16, device=dev))
 
 
-@pytest.mark.parametrize("variant", [0, 3, 7])       # 0 streaming, 3 LDS-resident single-kernel backward, 7 (default) split-by-phase backward
+@pytest.mark.parametrize("variant", [0, 3])
 def test_attention_families_self(dev, attn_variant, variant):
     from valor_amd import kernels as K
     attn_variant.valor_attn_set_variant(variant)
@@ -243,7 +243,7 @@ def test_attention_dropout_same_mask_in_every_family(dev, attn_variant):
     k = torch.randn((B, S, E), device=dev).to(torch.bfloat16)
     v = torch.eye(S, device=dev)[:, :64].repeat(1, H)[None].expand(B, S, E).contiguous().to(torch.bfloat16)
     keeps = []
-    for var in (0, 3, 7):
+    for var in (0, 3):
         attn_variant.valor_attn_set_variant(var)
         o, lse = K.attn_fwd(q, k, v, H, p_drop=pd, seed=7, offset=11)
         keep = (o.float() * S * (1 - pd) > 0.5)
@@ -253,7 +253,7 @@ def test_attention_dropout_same_mask_in_every_family(dev, attn_variant):
         got = dv.float().view(B, S, H, 64)[:, :64, :, 0].permute(0, 2, 1)
         assert torch.allclose(got, want, atol=2e-2), (var, (got - want).abs().max())
         keeps.append(keep)
-    assert torch.equal(keeps[0], keeps[1]) and torch.equal(keeps[0], keeps[2])
+    assert torch.equal(keeps[0], keeps[1])
     # grouped cross attention
     B, H, Sq, Skv, bmod = 4, 2, 32, 256, 2
     E = H * 64

@@ -345,3 +345,46 @@ def test_dropout_training_step_runs(dev, variant):
         vals.append({k: float(v) for k, v in out.items()})
         assert all(torch.isfinite(torch.tensor(list(vals[-1].values()))))
     assert vals[0] == vals[1]
+
+
+def test_gradient_accumulation_window(dev):
+    """dataset_mix_type='accum' (train_utils.py:311-317,341): n iterations -- here of two DIFFERENT task strings -- contribute loss / n each
+    to ONE optimizer step. TrainEngine.train_step(accum_steps=2) against the same thing done by hand on a second model; then a
+    detached .grad (stock zero_grad(set_to_none=True) on raw parameters) must be refused loudly, and model.zero_grad() re-binds."""
+    from types import SimpleNamespace
+    from valor_amd import synth
+    from valor_amd.engine import TrainEngine
+    spec = synth.tiny_spec()
+    sd = synth.make_state_dict(spec, seed=3, w_std=0.05)
+    b1 = synth.make_batch(spec, batch=2, frames=2, audio_slices=1, txt_len=32, seed=4)
+    b2 = synth.make_batch(spec, batch=2, frames=1, audio_slices=1, txt_len=32, seed=5)
+    t1, t2 = TASK, "pt_contra%tv_caption%tv_mlm%tv"
+    opts = SimpleNamespace(learning_rate=1e-3, weight_decay=0.01, clip_lr=1e-3, clip_lr_text=1e-3, new_lr=0.0, decoder_lr=-1, betas=[0.9, 0.98],
+                           warmup_ratio=0.1, num_train_steps=10, scheduler="warmup_linear", grad_norm=5.0, dataset_mix_type="accum")
+    ma, mb = _native(spec, sd, torch.float32, dev), _native(spec, sd, torch.float32, dev)
+    ea, eb = TrainEngine(ma, opts, manage_gc=False), TrainEngine(mb, opts, manage_gc=False)
+    random.seed(7)
+    ea.train_step(b1, t1, accum_steps=2)
+    assert ea.global_step == 0 and float(ma.arena.grad.float().abs().sum()) > 0            # micro-step: nothing applied yet
+    ea.train_step(b2, t2, accum_steps=2)
+    assert ea.global_step == 1
+    random.seed(7)
+    touched = set()
+    for b, t in ((b1, t1), (b2, t2)):
+        eb.reducer.reset_task(t)
+        eb.reducer.prepare_backward(defer=True)
+        out = mb(b, task=t, compute_loss=True)
+        (sum(out.values()) / 2).backward()
+        touched |= set(eb.reducer.touched)
+    from valor_amd.optim import get_lr_sched
+    for gq in eb.optimizer.param_groups:
+        gq["lr"] = gq["init_lr"] * get_lr_sched(1, opts)
+    eb.optimizer.step(active_names=touched, max_grad_norm=5.0, world_size=1)
+    assert torch.allclose(ma.arena.flat, mb.arena.flat, rtol=0, atol=1e-7), float((ma.arena.flat - mb.arena.flat).abs().max())
+    assert float(ma.arena.grad.abs().max()) == 0.0                                          # the fused update cleared the window
+    # detached gradients are refused, model.zero_grad() re-binds
+    torch.nn.Module.zero_grad(ma, set_to_none=True)
+    with pytest.raises(RuntimeError):
+        ea.train_step(b1, t1)
+    ma.zero_grad()
+    ea.train_step(b1, t1)

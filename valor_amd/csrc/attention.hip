@@ -537,14 +537,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnArgs p) {
 // ------------------------------------------------------------------------------------------
 // bit 0: LDS-resident short-sequence kernels (attention_res.hip), bit 1: key-stationary cross-attention kernels
 // (attention_x.hip) allowed for bf16
-// bit 2: the LDS-resident backward split by phase into two 4-wave kernels (3 workgroups per CU) instead of one 8-wave kernel
-extern int g_attn_res_bwd_split;
-static int g_attn_variant = 7;
-extern "C" int valor_attn_set_variant(int v) {
-    const int o = (g_attn_variant & 3) | (g_attn_res_bwd_split ? 4 : 0);
-    if (v >= 0) { g_attn_variant = v; g_attn_res_bwd_split = (v >> 2) & 1; }
-    return o;
-}
+static int g_attn_variant = 3;
+extern "C" int valor_attn_set_variant(int v) { const int o = g_attn_variant; if (v >= 0) g_attn_variant = v; return o; }
 
 template <typename T>
 static int attn_fwd_launch(hipStream_t st, const AttnArgs& p) {

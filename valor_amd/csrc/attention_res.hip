@@ -20,7 +20,6 @@
 // softmax statistics are per-lane scalars (+2 shuffles) and P feeds the next MFMA from registers.
 // Softmax runs in the exp2 domain (scale * log2 e folded into one multiply, v_exp_f32 directly).
 #include "attn_common.h"
-#include <stdlib.h>
 
 DEVINL float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
 
@@ -402,259 +401,7 @@ __global__ __launch_bounds__(512, 2) void attn_res_bwd_kernel(AttnArgs p) {
     }
 }
 
-
-// ------------------------------------------------------------------------------------------ backward, split edition
-// The single-kernel backward above holds four images per head (106 KB at S = 197): ONE 8-wave workgroup per CU, two waves per
-// SIMD, and every wave walks a long dependent chain (MFMA -> softmax VALU -> MFMA) with nobody to overlap it (0.08 of the MFMA
-// peak). Split by phase, each kernel keeps only the TWO images it contracts against (53 KB) and reads its own 32-row block
-// straight from global memory into fragments: three 4-wave workgroups per CU (3 waves per SIMD from different workgroups),
-// workgroup z of a head owning the row blocks 4z .. 4z+3 (one per wave).
-//   PHASE 1  dQ:      LDS [K][V] images; the wave's Q / dO / O rows from global; writes delta = sum_d dO.O for PHASE 2.
-//   PHASE 2  dK, dV:  LDS [Q][dO] images; the wave's K / V rows from global; lse / delta from global (L2).
-template <bool DROP, int PHASE>
-__global__ __launch_bounds__(256, PHASE == 1 ? 3 : 2) void attn_res_bwd_split_kernel(AttnArgs p) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int fr = lane & 15, g = lane >> 4;
-    const int h = blockIdx.x, b = blockIdx.y;
-    const int S = p.Skv, SP = (S + 15) & ~15;
-    const int IMG = SP * TILE_ROW_BYTES;
-    char* sQ = smem;            // PHASE 2 images
-    char* sDO = smem + IMG;
-    char* sK = smem;            // PHASE 1 images
-    char* sV = smem + IMG;
-    if (PHASE == 1) {
-        stage_image(head_rsrc(p.k, (int64_t)b * p.k_bs + h * ATT_D, S, p.k_rs), sK, SP, (int)p.k_rs * 2, wave, 4, lane);
-        stage_image(head_rsrc(p.v, (int64_t)b * p.v_bs + h * ATT_D, S, p.v_rs), sV, SP, (int)p.v_rs * 2, wave, 4, lane);
-    } else {
-        stage_image(head_rsrc(p.q, (int64_t)b * p.q_bs + h * ATT_D, S, p.q_rs), sQ, SP, (int)p.q_rs * 2, wave, 4, lane);
-        stage_image(head_rsrc(p.dout, (int64_t)b * p.do_bs + h * ATT_D, S, p.do_rs), sDO, SP, (int)p.do_rs * 2, wave, 4, lane);
-    }
-    const int64_t statbase = ((int64_t)b * p.H + h) * p.Sq;
-    const bf16_t* Qb = (const bf16_t*)p.q + (int64_t)b * p.q_bs + h * ATT_D;
-    const bf16_t* Kb = (const bf16_t*)p.k + (int64_t)b * p.k_bs + h * ATT_D;
-    const bf16_t* Vb = (const bf16_t*)p.v + (int64_t)b * p.v_bs + h * ATT_D;
-    const bf16_t* Ob = (const bf16_t*)p.o + (int64_t)b * p.o_bs + h * ATT_D;
-    const bf16_t* DOb = (const bf16_t*)p.dout + (int64_t)b * p.do_bs + h * ATT_D;
-    (void)Qb; (void)Kb; (void)Vb; (void)Ob; (void)DOb; (void)sQ; (void)sDO; (void)sK; (void)sV;
-    const float sl2 = p.scale * LOG2E_F;
-    const uint32_t thr = drop_threshold(p.p_drop);
-    const float keep_scale = p.p_drop > 0.f ? 1.0f / (1.0f - p.p_drop) : 1.0f;
-    const uint32_t hk = attn_drop_headkey(p.seed, p.offset, b * p.H + h);
-    int troff[4];
-#pragma unroll
-    for (int dt = 0; dt < 4; ++dt) troff[dt] = tr_lane_off(lane, dt);
-    const int NP = (S + 31) >> 5, NT = (S + 63) >> 6;
-    const int pr0 = blockIdx.z * 4 + wave;
-
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-
-    if constexpr (PHASE == 1) {
-    // ---------------- phase 1: dQ
-    for (int pr = pr0; pr < NP && pr == pr0; ++pr) {
-        bf16x8_t qf[2][2], dof[2][2];
-        int qr[2];
-        float lse2[2], dlt[2];
-#pragma unroll
-        for (int rt = 0; rt < 2; ++rt) {
-            qr[rt] = pr * 32 + rt * 16 + fr;
-            const bool rok = qr[rt] < S;
-            float d = 0.f;
-#pragma unroll
-            for (int dg = 0; dg < 2; ++dg) {
-                u32x4_t zq = {0u, 0u, 0u, 0u}, zd = zq, zo = zq;
-                if (rok) {
-                    zq = *(const u32x4_t*)(Qb + (int64_t)qr[rt] * p.q_rs + dg * 32 + g * 8);
-                    zd = *(const u32x4_t*)(DOb + (int64_t)qr[rt] * p.do_rs + dg * 32 + g * 8);
-                    zo = *(const u32x4_t*)(Ob + (int64_t)qr[rt] * p.o_rs + dg * 32 + g * 8);
-                }
-                qf[rt][dg] = __builtin_bit_cast(bf16x8_t, zq);
-                dof[rt][dg] = __builtin_bit_cast(bf16x8_t, zd);
-                const bf16x8_t ov = __builtin_bit_cast(bf16x8_t, zo);
-#pragma unroll
-                for (int e = 0; e < 8; ++e) d += (float)ov[e] * (float)dof[rt][dg][e];
-            }
-            d += __shfl_xor(d, 16, 64);            // the row's 64 dims live in the 4 lanes (fr, g = 0..3) x 2 chunks
-            d += __shfl_xor(d, 32, 64);
-            dlt[rt] = d;
-            lse2[rt] = rok ? p.lse[statbase + qr[rt]] * LOG2E_F : 0.f;
-            if (rok && g == 0) p.delta[statbase + qr[rt]] = d;
-        }
-        f32x4_t dqacc[2][4];
-#pragma unroll
-        for (int rt = 0; rt < 2; ++rt)
-#pragma unroll
-            for (int dt = 0; dt < 4; ++dt) dqacc[rt][dt] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-        for (int t = 0; t < NT; ++t) {
-            const int kv0 = t << 6;
-            int nkt = (S - kv0 + 15) >> 4;
-            nkt = nkt > 4 ? 4 : nkt;
-#pragma unroll
-            for (int kk = 0; kk < 2; ++kk) {
-                if (2 * kk >= nkt) continue;
-                f32x4_t ds[2][2];      // [rt][kt2]
-#pragma unroll
-                for (int k2 = 0; k2 < 2; ++k2) {
-                    const int kt = 2 * kk + k2;
-                    f32x4_t sa[2], pa[2];
-                    sa[0] = (f32x4_t){0.f, 0.f, 0.f, 0.f}; sa[1] = sa[0]; pa[0] = sa[0]; pa[1] = sa[0];
-                    if (kt < nkt) {
-#pragma unroll
-                        for (int dg = 0; dg < 2; ++dg) {
-                            const bf16x8_t kf = read_frag<bf16_t>(sK, kv0 + kt * 16 + fr, dg * 4 + g);
-                            const bf16x8_t vf = read_frag<bf16_t>(sV, kv0 + kt * 16 + fr, dg * 4 + g);
-                            sa[0] = Mma<bf16_t>::mma(kf, qf[0][dg], sa[0]);
-                            sa[1] = Mma<bf16_t>::mma(kf, qf[1][dg], sa[1]);
-                            pa[0] = Mma<bf16_t>::mma(vf, dof[0][dg], pa[0]);
-                            pa[1] = Mma<bf16_t>::mma(vf, dof[1][dg], pa[1]);
-                        }
-                    }
-#pragma unroll
-                    for (int rt = 0; rt < 2; ++rt) {
-                        const bool qok = qr[rt] < S;
-                        const float* mrowp = (p.mask && qok) ? p.mask + (int64_t)b * p.mask_bs + (int64_t)qr[rt] * p.mask_rs : nullptr;
-                        const uint32_t e0 = (uint32_t)qr[rt] * (uint32_t)p.Skv + (uint32_t)(kv0 + kt * 16 + 4 * g);
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) {
-                            const int key = kv0 + kt * 16 + 4 * g + r;
-                            float sc = sa[rt][r] * sl2;
-                            if (mrowp && key < S) sc += mrowp[key] * LOG2E_F;
-                            const float prb = (key < S && qok) ? fast_exp2(sc - lse2[rt]) : 0.f;
-                            float dp = pa[rt][r];
-                            if (DROP) dp = attn_drop_bits(hk, e0 + r) >= thr ? dp * keep_scale : 0.f;
-                            ds[rt][k2][r] = prb * (dp - dlt[rt]);
-                        }
-                    }
-                }
-                const bf16x8_t d0 = pack_bf16x8(ds[0][0], ds[0][1]);
-                const bf16x8_t d1 = pack_bf16x8(ds[1][0], ds[1][1]);
-#pragma unroll
-                for (int dt = 0; dt < 4; ++dt) {
-                    const bf16x8_t ktf = read_frag_tr_nat(sK, kv0 + 32 * kk, troff[dt]);   // K^T[d][key]
-                    dqacc[0][dt] = Mma<bf16_t>::mma(ktf, d0, dqacc[0][dt]);
-                    dqacc[1][dt] = Mma<bf16_t>::mma(ktf, d1, dqacc[1][dt]);
-                }
-            }
-        }
-#pragma unroll
-        for (int rt = 0; rt < 2; ++rt)
-            if (qr[rt] < S) {
-                bf16_t* DQ = (bf16_t*)p.dq + (int64_t)b * p.dq_bs + (int64_t)qr[rt] * p.dq_rs + h * ATT_D;
-#pragma unroll
-                for (int dt = 0; dt < 4; ++dt) store4<bf16_t>(DQ + dt * 16 + 4 * g, dqacc[rt][dt] * p.scale);
-            }
-    }
-
-    } else {
-    // ---------------- phase 2: dK, dV   (scores as S[q = 4g+r][key = l & 15])
-    for (int pr = pr0; pr < NP && pr == pr0; ++pr) {
-        bf16x8_t kf[2][2], vf[2][2];
-        int key[2];
-#pragma unroll
-        for (int kt = 0; kt < 2; ++kt) {
-            key[kt] = pr * 32 + kt * 16 + fr;
-#pragma unroll
-            for (int dg = 0; dg < 2; ++dg) {
-                u32x4_t zk = {0u, 0u, 0u, 0u}, zv = zk;
-                if (key[kt] < S) {
-                    zk = *(const u32x4_t*)(Kb + (int64_t)key[kt] * p.k_rs + dg * 32 + g * 8);
-                    zv = *(const u32x4_t*)(Vb + (int64_t)key[kt] * p.v_rs + dg * 32 + g * 8);
-                }
-                kf[kt][dg] = __builtin_bit_cast(bf16x8_t, zk);
-                vf[kt][dg] = __builtin_bit_cast(bf16x8_t, zv);
-            }
-        }
-        f32x4_t dkacc[2][4], dvacc[2][4];
-#pragma unroll
-        for (int kt = 0; kt < 2; ++kt)
-#pragma unroll
-            for (int dt = 0; dt < 4; ++dt) { dkacc[kt][dt] = (f32x4_t){0.f, 0.f, 0.f, 0.f}; dvacc[kt][dt] = dkacc[kt][dt]; }
-        for (int t = 0; t < NT; ++t) {
-            const int qb0 = t << 6;
-            int nqs = (S - qb0 + 15) >> 4;
-            nqs = nqs > 4 ? 4 : nqs;
-#pragma unroll
-            for (int kk = 0; kk < 2; ++kk) {
-                if (2 * kk >= nqs) continue;
-                f32x4_t pd[2][2], ds[2][2];      // [kt][q2]
-#pragma unroll
-                for (int q2 = 0; q2 < 2; ++q2) {
-                    const int qs = 2 * kk + q2;
-                    f32x4_t sa[2], pa[2];
-                    sa[0] = (f32x4_t){0.f, 0.f, 0.f, 0.f}; sa[1] = sa[0]; pa[0] = sa[0]; pa[1] = sa[0];
-                    f32x4_t l4 = sa[0], d4 = sa[0];
-                    const int q4 = qb0 + qs * 16 + 4 * g;                       // < SP when qs < nqs
-                    if (qs < nqs) {
-#pragma unroll
-                        for (int dg = 0; dg < 2; ++dg) {
-                            const bf16x8_t qfr = read_frag<bf16_t>(sQ, qb0 + qs * 16 + fr, dg * 4 + g);
-                            const bf16x8_t dfr = read_frag<bf16_t>(sDO, qb0 + qs * 16 + fr, dg * 4 + g);
-                            sa[0] = Mma<bf16_t>::mma(qfr, kf[0][dg], sa[0]);
-                            sa[1] = Mma<bf16_t>::mma(qfr, kf[1][dg], sa[1]);
-                            pa[0] = Mma<bf16_t>::mma(dfr, vf[0][dg], pa[0]);
-                            pa[1] = Mma<bf16_t>::mma(dfr, vf[1][dg], pa[1]);
-                        }
-#pragma unroll
-                        for (int r = 0; r < 4; ++r)
-                            if (q4 + r < S) { l4[r] = p.lse[statbase + q4 + r] * LOG2E_F; d4[r] = p.delta[statbase + q4 + r]; }
-                    }
-#pragma unroll
-                    for (int kt = 0; kt < 2; ++kt)
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) {
-                            const int qr = q4 + r;
-                            float dsv = 0.f, pdv = 0.f;
-                            if (qs < nqs && qr < S && key[kt] < S) {
-                                float sc = sa[kt][r] * sl2;
-                                if (p.mask) sc += p.mask[(int64_t)b * p.mask_bs + (int64_t)qr * p.mask_rs + key[kt]] * LOG2E_F;
-                                const float prb = fast_exp2(sc - l4[r]);
-                                float dp = pa[kt][r];
-                                pdv = prb;
-                                if (DROP) {
-                                    const bool keep = attn_drop_bits(hk, (uint32_t)qr * (uint32_t)p.Skv + (uint32_t)key[kt]) >= thr;
-                                    dp = keep ? dp * keep_scale : 0.f;
-                                    pdv = keep ? prb * keep_scale : 0.f;
-                                }
-                                dsv = prb * (dp - d4[r]);
-                            }
-                            pd[kt][q2][r] = pdv; ds[kt][q2][r] = dsv;
-                        }
-                }
-                const bf16x8_t p0 = pack_bf16x8(pd[0][0], pd[0][1]);
-                const bf16x8_t p1 = pack_bf16x8(pd[1][0], pd[1][1]);
-                const bf16x8_t s0 = pack_bf16x8(ds[0][0], ds[0][1]);
-                const bf16x8_t s1 = pack_bf16x8(ds[1][0], ds[1][1]);
-#pragma unroll
-                for (int dt = 0; dt < 4; ++dt) {
-                    const bf16x8_t dotf = read_frag_tr_nat(sDO, qb0 + 32 * kk, troff[dt]);   // dO^T[d][q]
-                    const bf16x8_t qtf = read_frag_tr_nat(sQ, qb0 + 32 * kk, troff[dt]);     // Q^T[d][q]
-                    dvacc[0][dt] = Mma<bf16_t>::mma(dotf, p0, dvacc[0][dt]);
-                    dvacc[1][dt] = Mma<bf16_t>::mma(dotf, p1, dvacc[1][dt]);
-                    dkacc[0][dt] = Mma<bf16_t>::mma(qtf, s0, dkacc[0][dt]);
-                    dkacc[1][dt] = Mma<bf16_t>::mma(qtf, s1, dkacc[1][dt]);
-                }
-            }
-        }
-#pragma unroll
-        for (int kt = 0; kt < 2; ++kt)
-            if (key[kt] < S) {
-                bf16_t* DK = (bf16_t*)p.dk + (int64_t)b * p.dk_bs + (int64_t)key[kt] * p.dk_rs + h * ATT_D;
-                bf16_t* DV = (bf16_t*)p.dv + (int64_t)b * p.dv_bs + (int64_t)key[kt] * p.dv_rs + h * ATT_D;
-#pragma unroll
-                for (int dt = 0; dt < 4; ++dt) {
-                    store4<bf16_t>(DK + dt * 16 + 4 * g, dkacc[kt][dt] * p.scale);
-                    store4<bf16_t>(DV + dt * 16 + 4 * g, dvacc[kt][dt]);
-                }
-            }
-    }
-    }
-}
-
 // ------------------------------------------------------------------------------------------ launch
-// split-by-phase backward (default) vs the single 8-wave kernel; VALOR_ATTN_RES_BWD_SPLIT=0 / valor_attn_set_variant bit 2 clear
-int g_attn_res_bwd_split = [] { const char* e = getenv("VALOR_ATTN_RES_BWD_SPLIT"); return e ? atoi(e) : 1; }();
 static bool res_eligible(const AttnArgs& p) {
     if (p.kv_range || p.kv_bmod > 0 || p.Sq != p.Skv || p.Skv > 256 || p.acc_dkv) return false;
     const int64_t lim = (int64_t)1 << 31;
@@ -688,28 +435,6 @@ bool attn_res_bwd_launch(hipStream_t st, const AttnArgs& p) {
         hipFuncSetAttribute((const void*)attn_res_bwd_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, mx);
         hipFuncSetAttribute((const void*)attn_res_bwd_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, mx);
         attr_set = true;
-    }
-    if (g_attn_res_bwd_split && p.delta) {
-        const size_t lds2 = 2 * (size_t)SP * TILE_ROW_BYTES;
-        static bool attr2 = false;
-        if (!attr2) {
-            const int mx2 = 2 * 256 * TILE_ROW_BYTES;
-            hipFuncSetAttribute((const void*)attn_res_bwd_split_kernel<false, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, mx2);
-            hipFuncSetAttribute((const void*)attn_res_bwd_split_kernel<false, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, mx2);
-            hipFuncSetAttribute((const void*)attn_res_bwd_split_kernel<true, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, mx2);
-            hipFuncSetAttribute((const void*)attn_res_bwd_split_kernel<true, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, mx2);
-            attr2 = true;
-        }
-        const int NP = (p.Skv + 31) >> 5;
-        const dim3 grid(p.H, p.B, (NP + 3) / 4);
-        if (p.p_drop > 0.f) {
-            hipLaunchKernelGGL((attn_res_bwd_split_kernel<true, 1>), grid, dim3(256), lds2, st, p);
-            hipLaunchKernelGGL((attn_res_bwd_split_kernel<true, 2>), grid, dim3(256), lds2, st, p);
-        } else {
-            hipLaunchKernelGGL((attn_res_bwd_split_kernel<false, 1>), grid, dim3(256), lds2, st, p);
-            hipLaunchKernelGGL((attn_res_bwd_split_kernel<false, 2>), grid, dim3(256), lds2, st, p);
-        }
-        return true;
     }
     if (p.p_drop > 0.f) hipLaunchKernelGGL(attn_res_bwd_kernel<true>, dim3(p.H, p.B), dim3(512), lds, st, p);
     else hipLaunchKernelGGL(attn_res_bwd_kernel<false>, dim3(p.H, p.B), dim3(512), lds, st, p);

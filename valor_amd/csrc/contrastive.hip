@@ -50,8 +50,7 @@ __global__ __launch_bounds__(64) void fine_reduce_fwd_kernel(const float* S, int
             const float x = tile[(int64_t)lane * ldS + v] * mA * maskB[b * Nv + v];
             if (x > best) { best = x; bi = v; }
         }
-        A2B[pair * T + lane] = best;
-        idxA[pair * T + lane] = (uint8_t)bi;
+        if (A2B) { A2B[pair * T + lane] = best; idxA[pair * T + lane] = (uint8_t)bi; }
         acc += best * wA[a * T + lane];
     }
     if (lane < Nv) {  // lane = v : max over t
@@ -61,8 +60,7 @@ __global__ __launch_bounds__(64) void fine_reduce_fwd_kernel(const float* S, int
             const float x = tile[(int64_t)t * ldS + lane] * maskA[a * T + t] * mB;
             if (x > best) { best = x; bi = t; }
         }
-        B2A[pair * Nv + lane] = best;
-        idxB[pair * Nv + lane] = (uint8_t)bi;
+        if (B2A) { B2A[pair * Nv + lane] = best; idxB[pair * Nv + lane] = (uint8_t)bi; }
         acc += best * wB[b * Nv + lane];
     }
     acc = wave_sum(acc);
@@ -194,6 +192,18 @@ extern "C" int valor_fine_reduce_fwd(void* stream, const float* S, int64_t ldS, 
     if (T <= 0 || T > 64 || Nv <= 0 || Nv > 64) return VALOR_ERR_ARG;
     hipLaunchKernelGGL(fine_reduce_fwd_kernel, dim3(B, B), dim3(64), 0, (hipStream_t)stream, S, ldS, maskA, maskB, wA, wB,
                        score, A2B, B2A, idxA, idxB, B, T, Nv);
+    return valor_launch_status();
+}
+
+// Scores only, RECTANGULAR: NA text items against NB video / audio items (evaluation: test.py:534-660 builds the full t2v / t2va /
+// t2a score matrices of a validation set through VALOR.compute_fine_matrix, pretrain.py:178-211). S: fp32 [NA*T, ldS] (column b*Nv+v),
+// maskA / wA: [NA, T], maskB / wB: [NB, Nv], score: [NA, NB].
+extern "C" int valor_fine_scores(void* stream, const float* S, int64_t ldS, const float* maskA, const float* maskB, const float* wA,
+                                 const float* wB, float* score, int NA, int NB, int T, int Nv) {
+    if (NA <= 0 || NB <= 0) return VALOR_OK;
+    if (T <= 0 || T > 64 || Nv <= 0 || Nv > 64 || NA > 65535 || !S || !score) return VALOR_ERR_ARG;
+    hipLaunchKernelGGL(fine_reduce_fwd_kernel, dim3(NB, NA), dim3(64), 0, (hipStream_t)stream, S, ldS, maskA, maskB, wA, wB, score,
+                       (float*)nullptr, (float*)nullptr, (uint8_t*)nullptr, (uint8_t*)nullptr, NB, T, Nv);
     return valor_launch_status();
 }
 

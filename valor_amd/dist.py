@@ -66,7 +66,20 @@ def packed_allgather_with_grads(feat_t, feat_v, feat_a, tokens):
 
 
 class Reducer:
-    def __init__(self, arena, bucket_bytes=48 << 20):
+    """mode (env VALOR_REDUCE or the argument):
+         "allreduce"  one SUM all-reduce per bucket in the arena's dtype (default; RCCL picks ring / direct per message size);
+         "rs_ag"      reduce-scatter + all-gather per bucket (the two halves of a direct all-reduce issued explicitly: every one of a
+                      GPU's 7 xGMI links carries 1/world of the bucket in each half) -- nccl / RCCL only (gloo has no
+                      reduce_scatter);
+         "fp32"       the bucket is widened to fp32 for the cross-rank sum and rounded ONCE on the way back (world - 1 fewer bf16
+                      roundings per element at twice the bytes on the wire).
+       Summing in bf16 across 8 ranks perturbs each element by ~0.4 % rms (like one more bf16 rounding of the gradient) and the global
+       norm by < 1e-5 relative: tests/test_dist_cpu.py::test_bf16_cross_rank_sum_error quantifies it."""
+
+    def __init__(self, arena, bucket_bytes=48 << 20, mode=None):
+        import os
+        self.mode = mode or os.environ.get("VALOR_REDUCE", "allreduce")
+        assert self.mode in ("allreduce", "rs_ag", "fp32"), self.mode
         self.arena = arena
         self.world = dist.get_world_size() if is_dist() else 1
         esz = arena.flat.element_size()
@@ -112,6 +125,19 @@ class Reducer:
         if not s and self.expected[i]:
             self._launch(i)
 
+    def _reduce(self, buf):
+        """SUM `buf` (a contiguous range of the gradient arena) over the ranks, in place; returns the async works to wait for"""
+        if self.mode == "fp32" and buf.dtype != torch.float32:
+            wide = buf.float()
+            dist.all_reduce(wide, op=dist.ReduceOp.SUM)
+            buf.copy_(wide)
+            return []
+        if self.mode == "rs_ag" and buf.numel() % self.world == 0:       # arena ranges are multiples of 1024 elements
+            shard = buf.view(self.world, -1)[dist.get_rank()]
+            dist.reduce_scatter_tensor(shard, buf, op=dist.ReduceOp.SUM)       # in place: the output is this rank's slice of the input
+            return [dist.all_gather_into_tensor(buf, shard, async_op=True)]
+        return [dist.all_reduce(buf, op=dist.ReduceOp.SUM, async_op=True)]
+
     def _launch(self, i):
         if self.world == 1:
             return
@@ -121,9 +147,9 @@ class Reducer:
             ev = torch.cuda.Event(); ev.record()
             with torch.cuda.stream(self.comm_stream):
                 self.comm_stream.wait_event(ev)
-                self.works.append(dist.all_reduce(buf, op=dist.ReduceOp.SUM, async_op=True))
+                self.works += self._reduce(buf)
         else:
-            self.works.append(dist.all_reduce(buf, op=dist.ReduceOp.SUM, async_op=True))
+            self.works += self._reduce(buf)
 
     def prepare_backward(self, defer=False):
         """defer=True: a micro-step of a gradient accumulation window -- gradients keep accumulating in the arena and NO bucket
@@ -145,7 +171,8 @@ class Reducer:
             if not last:
                 return set()
             if self.world > 1:
-                dist.all_reduce(self.arena.grad, op=dist.ReduceOp.SUM)
+                for w in self._reduce(self.arena.grad):
+                    w.wait()
             names, self.window = self.window, None
             return names
         if self.expected is None or self.touched != self.uses:
@@ -156,7 +183,8 @@ class Reducer:
             self.uses = dict(self.touched)
             self.expected = [set(n for n in b if n in self.touched) for b in self.buckets]
             if self.world > 1:
-                dist.all_reduce(self.arena.grad, op=dist.ReduceOp.SUM)
+                for w in self._reduce(self.arena.grad):
+                    w.wait()
         else:
             for w in self.works:
                 w.wait()

@@ -51,6 +51,7 @@ SIGNATURES = {
     "valor_fine_weight_softmax": [_vp, _vp, _vp, _vp, _i, _i],
     "valor_fine_weight_softmax_bwd": [_vp, _vp, _vp, _vp, _i, _i],
     "valor_fine_reduce_fwd": [_vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i],
+    "valor_fine_scores": [_vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i],
     "valor_infonce_fwd": [_vp, _vp, _vp, _vp, _vp, _vp, _i],
     "valor_infonce_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i],
     "valor_fine_reduce_bwd": [_vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _i, _i, _i],

