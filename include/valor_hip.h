@@ -61,7 +61,9 @@ int valor_gemm(void* stream, int dtype, int transA, int transB, int M, int N, in
 int valor_gemm_set_variant(int v);
 /* kernel family valor_gemm picks for a problem under the current variant: 0 = register-staged 128x128 (and every fp32
  * problem), 1 / 2 = LDS-DMA 128x128 single / double stage, 3 = 256x256 8-phase */
-int valor_gemm_kernel_for(int dtype, int transA, int transB, int M, int N, int K);
+int valor_gemm_kernel_for(int dtype, int transA, int transB, int M, int N, int K, int heavy_epilogue);
+/* heavy_epilogue: the call passes dact_aux (the epilogue reads a second [M, N] operand); such dgrads stay on the 128x128 kernel below
+ * K = 1536, where four workgroups per CU overlap each other's epilogues (profiles/r02_gemm_epilogue_ab.json) */
 /* k-slow 8-phase kernels: transposing LDS reads as inline asm (keeps the counted LDS-DMA pipeline from being drained by
  * compiler-inserted waits); returns the previous value, v < 0 only queries */
 int valor_gemm_set_tr_asm(int v);

@@ -55,7 +55,7 @@ def test_gemm_families(dev, gemm_variant, variant):
             C = K.gemm(A, B, trans_a=ta, trans_b=tb, splitk=sk)
             assert _rel(C, ref) < 6e-3, (variant, M, N, Kd, ta, tb, sk, _rel(C, ref))
     # the 8-phase family really is selected for an eligible problem under variant 3, and only then
-    fam = gemm_variant.valor_gemm_kernel_for(lib.DT_BF16, 0, 0, 512, 768, 128)
+    fam = gemm_variant.valor_gemm_kernel_for(lib.DT_BF16, 0, 0, 512, 768, 128, 0)
     assert fam == (3 if variant == 3 else (0 if variant == 0 else (2 if variant == 2 else 1)))
     # epilogues: bias + erf-GELU + saved pre-activation, dact multiply, fp32 accumulate
     X, W, b = _mk((512, 256), 6, dev), _mk((768, 256), 7, dev), _mk((768,), 8, dev)

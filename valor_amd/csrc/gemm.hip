@@ -481,9 +481,9 @@ static bool use_8ph(int dtype, int transA, int transB, int M, int N, int K, bool
 
 // which kernel family valor_gemm uses for a problem: 0 = register-staged 128x128 (also all fp32), 1 / 2 = LDS-DMA 128x128
 // single / double stage, 3 = 256x256 8-phase.  (bench.py groups its roofline numbers by this.)
-extern "C" int valor_gemm_kernel_for(int dtype, int transA, int transB, int M, int N, int K) {
+extern "C" int valor_gemm_kernel_for(int dtype, int transA, int transB, int M, int N, int K, int heavy_epilogue) {
     if (dtype != VALOR_DT_BF16 || g_gemm_variant == 0) return 0;
-    if (use_8ph(dtype, transA, transB, M, N, K)) return 3;
+    if (use_8ph(dtype, transA, transB, M, N, K, heavy_epilogue != 0)) return 3;
     return g_gemm_variant == 2 ? 2 : 1;
 }
 

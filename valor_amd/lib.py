@@ -23,7 +23,7 @@ SIGNATURES = {
     "valor_gemm": [_vp, _i, _i, _i, _i, _i, _i, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _i, _vp, _vp, _i64,
                    _f, _i, _i, _vp, _i64, _vp, _i],
     "valor_gemm_set_variant": [_i],
-    "valor_gemm_kernel_for": [_i, _i, _i, _i, _i, _i],
+    "valor_gemm_kernel_for": [_i, _i, _i, _i, _i, _i, _i],
     "valor_gemm_set_tr_asm": [_i],
     "valor_gemm_set_fast_epilogue": [_i],
     "valor_gemm_set_policy": [_i, _i],
