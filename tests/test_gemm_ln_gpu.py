@@ -151,3 +151,30 @@ def test_colsum(dev, dtype):
     x = _mk((5000, 3072 + 8), dtype, dev, 3)[:, :3070]
     s = K.colsum(x)
     assert _rel(s, x.double().sum(0)) < (1e-5 if dtype == torch.float32 else 5e-3)
+
+
+def test_gemm_operands_beyond_2gib(dev):
+    """operands are staged through buffer descriptors with 32-bit offsets: valor_gemm cuts an operand of 2 GiB or more into
+    launches (rows of a row-major A; the token contraction of a wgrad, accumulating) -- VideoSwin-L's stage-1 activations at
+    b = 64 are 2.5 GB. Checked on row / column slices against fp32 torch matmul of the same bf16 data."""
+    from valor_amd import kernels as K
+    rows, Kd, N = 1_500_016, 768, 64                      # 2.3 GB of bf16
+    g = torch.Generator(device=dev).manual_seed(1)
+    A = torch.randn((rows, Kd), generator=g, device=dev, dtype=torch.float32).to(torch.bfloat16)
+    assert A.numel() * 2 > (1 << 31)
+    W = _mk((N, Kd), torch.bfloat16, dev, 2)
+    bias = _mk((N,), torch.bfloat16, dev, 3)
+    C = K.gemm(A, W, bias=bias)
+    for sl in (slice(0, 300), slice(rows // 2 - 77, rows // 2 + 200), slice(rows - 300, rows)):
+        ref = A[sl].float() @ W.float().t() + bias.float()
+        assert _rel(C[sl], ref) < 6e-3
+    # wgrad layout: dW[M, N] = dY^T . X over 1.5 M tokens, dY being the big operand; then accumulate on top
+    X = _mk((rows, N), torch.bfloat16, dev, 4)
+    M = 512
+    dW = K.gemm(A[:, :M], X, trans_a=True, trans_b=True, out_dtype=torch.float32)        # a column view: ld = 768
+    ref = torch.zeros((M, N), dtype=torch.float64, device=dev)
+    for r0 in range(0, rows, 250_000):
+        ref += A[r0:r0 + 250_000, :M].double().t() @ X[r0:r0 + 250_000].double()
+    assert _rel(dW, ref) < 2e-3
+    K.gemm(A[:, :M], X, trans_a=True, trans_b=True, out=dW, out_dtype=torch.float32, accumulate=True)
+    assert _rel(dW, 2 * ref) < 2e-3

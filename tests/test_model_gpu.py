@@ -388,3 +388,23 @@ def test_gradient_accumulation_window(dev):
         ea.train_step(b1, t1)
     ma.zero_grad()
     ea.train_step(b1, t1)
+
+
+def test_prefetch_loader_delivers_the_same_batches(dev):
+    """side-stream H2D staging of pixels / spectrograms (data/loader.py:154-212): values and order unchanged, big tensors arrive on the
+    device, token tensors stay on the host; works for MetaLoader-style (name, batch) pairs; a training step accepts the result"""
+    from valor_amd import synth
+    from valor_amd.hoststage import PrefetchLoader
+    spec = synth.tiny_spec()
+    src = [("valor--" + TASK, synth.make_batch(spec, batch=2, frames=2, audio_slices=1, txt_len=32, seed=s)) for s in (1, 2, 3, 4, 5)]
+    got = list(PrefetchLoader(src, device=dev))
+    assert len(got) == len(src)
+    for (n0, b0), (n1, b1) in zip(src, got):
+        assert n0 == n1 and b1["video_pixels"].is_cuda and b1["audio_spectrograms"].is_cuda and not b1["txt_tokens"]["bert_tokens"].is_cuda
+        assert torch.equal(b1["video_pixels"].cpu(), b0["video_pixels"]) and torch.equal(b1["audio_spectrograms"].cpu(), b0["audio_spectrograms"])
+        assert torch.equal(b1["txt_tokens"]["clip_tokens"], b0["txt_tokens"]["clip_tokens"]) and b1["ids"] == b0["ids"]
+    sd = synth.make_state_dict(spec, seed=3, w_std=0.05)
+    model = _native(spec, sd, torch.float32, dev)
+    random.seed(5); a = model(src[0][1], task=TASK, compute_loss=True)
+    random.seed(5); b = model(got[0][1], task=TASK, compute_loss=True)
+    assert all(float(a[k]) == float(b[k]) for k in a)

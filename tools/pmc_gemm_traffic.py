@@ -38,11 +38,13 @@ def main():
         got = {}
         for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
             d = f"{work}/{M}_{N}_{Kd}_{ta}{tb}_{ctr}"
-            subprocess.run(["rocprofv3", "--kernel-trace", "--pmc", ctr, "-d", d, "-o", "p", "--", sys.executable, os.path.join(ROOT, "tools", "gemm_one.py"),
-                            str(M), str(N), str(Kd), str(ta), str(tb), "3"], cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"),
-                           stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=300)
+            r = subprocess.run(["rocprofv3", "--kernel-trace", "--pmc", ctr, "-d", d, "-o", "p", "--", sys.executable, os.path.join(ROOT, "tools", "gemm_one.py"),
+                                str(M), str(N), str(Kd), str(ta), str(tb), "3"], cwd=ROOT, env=dict(os.environ, TMPDIR="/tmp"),
+                               capture_output=True, text=True, timeout=300)
             dbs = glob.glob(d + "/**/*.db", recursive=True)
             got[ctr] = counter(dbs[0], ctr) if dbs else None
+            if got[ctr] is None:
+                print(f"[{label} {ctr}] rc={r.returncode} dbs={dbs}\n" + (r.stdout + r.stderr)[-1500:], flush=True)
         if got["FETCH_SIZE"] is None or got["WRITE_SIZE"] is None:
             print("no counters for", label, got, flush=True)
             continue

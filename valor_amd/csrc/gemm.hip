@@ -562,6 +562,42 @@ extern "C" int valor_gemm(void* stream, int dtype, int transA, int transB, int M
     // 16-byte chunk loads: leading dims and bases must be chunk aligned
     if ((lda % vec) || (ldb % vec)) return VALOR_ERR_ARG;
     if (((uintptr_t)A & 15) || ((uintptr_t)B & 15)) return VALOR_ERR_ARG;
+    {
+        // Operands are staged through buffer descriptors (32-bit byte offsets): an operand of 2 GiB or more is cut into launches.
+        // (VideoSwin-L's stage-1 MLP activations at b = 64: 1.6 M rows x 768 x 2 B = 2.5 GB.)
+        const int64_t esz = dtype == VALOR_DT_BF16 ? 2 : 4, lim = (1ll << 31) - 65536;
+        const int64_t extA = transA ? (int64_t)K * lda : ((int64_t)(M - 1) * lda + K);
+        const int64_t extB = transB ? (int64_t)K * ldb : ((int64_t)(N - 1) * ldb + K);
+        const int64_t osz = out_f32 ? 4 : esz;
+        if (!transA && extA * esz >= lim && extB * esz < lim) {            // row-major A: cut M (C / preact / aux rows move with it)
+            int64_t rows = (lim / esz - K) / lda;
+            rows &= ~(int64_t)255;
+            if (rows <= 0 || rowsum_out) return VALOR_ERR_ARG;
+            for (int64_t r0 = 0; r0 < M; r0 += rows) {
+                const int m = (int)((M - r0) < rows ? (M - r0) : rows);
+                const int rc = valor_gemm(stream, dtype, transA, transB, m, N, K, (const char*)A + r0 * lda * esz, lda, B, ldb,
+                                          (char*)C + r0 * ldc * osz, ldc, bias, act, preact ? (char*)preact + r0 * ldc * osz : nullptr,
+                                          dact_aux ? (const char*)dact_aux + r0 * ldaux * esz : nullptr, ldaux, alpha, accumulate, out_f32,
+                                          workspace, workspace_bytes, nullptr, 0);
+                if (rc != VALOR_OK) return rc;
+            }
+            return VALOR_OK;
+        }
+        if (transA && transB && (extA * esz >= lim || extB * esz >= lim)) {   // wgrad dY^T.X: cut the contraction (tokens), C accumulates
+            const int64_t ldmax = lda > ldb ? lda : ldb;
+            int64_t kc = lim / esz / ldmax;
+            kc &= ~(int64_t)63;
+            if (kc <= 0 || preact || dact_aux || act != VALOR_ACT_NONE) return VALOR_ERR_ARG;
+            for (int64_t k0 = 0; k0 < K; k0 += kc) {
+                const int kk = (int)((K - k0) < kc ? (K - k0) : kc);
+                const int rc = valor_gemm(stream, dtype, transA, transB, M, N, kk, (const char*)A + k0 * lda * esz, lda,
+                                          (const char*)B + k0 * ldb * esz, ldb, C, ldc, k0 ? nullptr : bias, act, preact, dact_aux, ldaux, alpha,
+                                          k0 ? 1 : accumulate, out_f32, workspace, workspace_bytes, rowsum_out, k0 ? 1 : rowsum_accumulate);
+                if (rc != VALOR_OK) return rc;
+            }
+            return VALOR_OK;
+        }
+    }
     GemmArgs p;
     p.A = A; p.B = B; p.C = C; p.bias = bias; p.preact = preact; p.dact_aux = dact_aux;
     p.ws = (float*)workspace;

@@ -55,3 +55,64 @@ class HostStage:
         slot.copy_(t)
         self.off = start + nbytes
         return slot.to(self.device, non_blocking=True)
+
+
+class PrefetchLoader:
+    """Overlap the host -> device copy of the NEXT batch's pixels / spectrograms with the current step (data/loader.py:154-212,
+    the apex-derived PrefetchLoader of the reference): the big float tensors of a batch (`video_pixels`, `audio_spectrograms`)
+    are copied into pinned double buffers and sent on a side stream while the model works on the previous batch; the token
+    tensors stay on the host (the maskers and mask builders read them there, modeling.py:134-174 / valor.py) and everything
+    else passes through. The consumer's stream waits for the copy right before the batch is handed over, and the device
+    tensors are recorded on it (the caching allocator may otherwise recycle them while a kernel still reads them).
+    (name, batch) pairs of the reference's MetaLoader are supported as well as bare batch dicts."""
+    DEVICE_KEYS = ("video_pixels", "audio_spectrograms")
+
+    def __init__(self, loader, device="cuda"):
+        self.loader = loader
+        self.device = torch.device(device)
+        self.stream = torch.cuda.Stream(device=self.device)
+        self._pinned = [{}, {}]
+        self._flip = 0
+
+    def __len__(self):
+        return len(self.loader)
+
+    def __getattr__(self, name):
+        return getattr(self.loader, name)
+
+    def _stage(self, item):
+        name, batch = item if isinstance(item, tuple) else (None, item)
+        out = dict(batch)
+        pins = self._pinned[self._flip]
+        self._flip ^= 1
+        with torch.cuda.stream(self.stream):
+            for k in self.DEVICE_KEYS:
+                t = batch.get(k)
+                if t is None or t.is_cuda:
+                    continue
+                buf = pins.get(k)
+                if buf is None or buf.shape != t.shape or buf.dtype != t.dtype:
+                    buf = torch.empty(t.shape, dtype=t.dtype).pin_memory()
+                    pins[k] = buf
+                buf.copy_(t)
+                out[k] = buf.to(self.device, non_blocking=True)
+        return (name, out) if name is not None else out
+
+    def __iter__(self):
+        it = iter(self.loader)
+        try:
+            nxt = self._stage(next(it))
+        except StopIteration:
+            return
+        while nxt is not None:
+            torch.cuda.current_stream(self.device).wait_stream(self.stream)
+            cur = nxt
+            batch = cur[1] if isinstance(cur, tuple) else cur
+            for k in self.DEVICE_KEYS:
+                if isinstance(batch.get(k), torch.Tensor) and batch[k].is_cuda:
+                    batch[k].record_stream(torch.cuda.current_stream(self.device))
+            try:
+                nxt = self._stage(next(it))          # the next batch's copies fly while the caller trains on `cur`
+            except StopIteration:
+                nxt = None
+            yield cur
