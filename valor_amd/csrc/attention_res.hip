@@ -180,7 +180,11 @@ __global__ __launch_bounds__(512, 2) void attn_res_bwd_kernel(AttnArgs p) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int fr = lane & 15, g = lane >> 4;
     const int h = blockIdx.x, b = blockIdx.y;
-    const int S = p.Skv, SP = (S + 15) & ~15;
+    // images hold SP = ceil32(S) rows (every fragment / transposing read below stays inside: 16-row reads are guarded by nkt / nqs,
+    // 32-row transposing reads start below S): the rows past S are ZERO (the buffer descriptor ends at row S-1, the DMA range check fills the
+    // rest), lse of the rows past S is +inf. So a key past S meets K = V = 0 (its dS multiplies a zero K row in dQ, its own dK / dV
+    // columns are never stored) and a query past S gets P = 2^(s - inf) = 0: the inner loops carry NO per-element bounds selects.
+    const int S = p.Skv, SP = (S + 31) & ~31;
     const int IMG = SP * TILE_ROW_BYTES;
     char* sQ = smem;
     char* sDO = smem + IMG;
@@ -208,7 +212,7 @@ __global__ __launch_bounds__(512, 2) void attn_res_bwd_kernel(AttnArgs p) {
                 for (int e = 0; e < 8; ++e) d += (float)ov[e] * (float)dv[e];
             }
             d += __shfl_xor(d, 1, 64); d += __shfl_xor(d, 2, 64); d += __shfl_xor(d, 4, 64);
-            if (c == 0) { sDelta[row] = d; sLse[row] = row < S ? p.lse[statbase + row] * LOG2E_F : 0.f; }
+            if (c == 0) { sDelta[row] = d; sLse[row] = row < S ? p.lse[statbase + row] * LOG2E_F : INFINITY; }
         }
     }
     const float sl2 = p.scale * LOG2E_F;
@@ -230,14 +234,13 @@ __global__ __launch_bounds__(512, 2) void attn_res_bwd_kernel(AttnArgs p) {
         float lse2[2], dlt[2];
 #pragma unroll
         for (int rt = 0; rt < 2; ++rt) {
-            qr[rt] = pr * 32 + rt * 16 + fr;       // < SP + 16: rows >= SP of the LAST image pair read the next image (never used: qok)
-            const int qrc = qr[rt] < SP ? qr[rt] : SP - 1;
+            qr[rt] = pr * 32 + rt * 16 + fr;       // < SP = NP * 32; rows >= S are zero rows with lse = +inf
 #pragma unroll
             for (int dg = 0; dg < 2; ++dg) {
-                qf[rt][dg] = read_frag<bf16_t>(sQ, qrc, dg * 4 + g);
-                dof[rt][dg] = read_frag<bf16_t>(sDO, qrc, dg * 4 + g);
+                qf[rt][dg] = read_frag<bf16_t>(sQ, qr[rt], dg * 4 + g);
+                dof[rt][dg] = read_frag<bf16_t>(sDO, qr[rt], dg * 4 + g);
             }
-            lse2[rt] = sLse[qrc]; dlt[rt] = sDelta[qrc];
+            lse2[rt] = sLse[qr[rt]]; dlt[rt] = sDelta[qr[rt]];
         }
         f32x4_t dqacc[2][4];
 #pragma unroll
@@ -275,10 +278,9 @@ __global__ __launch_bounds__(512, 2) void attn_res_bwd_kernel(AttnArgs p) {
                         const uint32_t e0 = (uint32_t)qr[rt] * (uint32_t)p.Skv + (uint32_t)(kv0 + kt * 16 + 4 * g);
 #pragma unroll
                         for (int r = 0; r < 4; ++r) {
-                            const int key = kv0 + kt * 16 + 4 * g + r;
                             float sc = sa[rt][r] * sl2;
-                            if (mrowp && key < S) sc += mrowp[key] * LOG2E_F;
-                            const float prb = (key < S && qok) ? fast_exp2(sc - lse2[rt]) : 0.f;
+                            if (mrowp) { const int key = kv0 + kt * 16 + 4 * g + r; if (key < S) sc += mrowp[key] * LOG2E_F; }
+                            const float prb = fast_exp2(sc - lse2[rt]);           // query past S: lse = +inf -> 0
                             float dp = pa[rt][r];
                             if (DROP) dp = attn_drop_bits(hk, e0 + r) >= thr ? dp * keep_scale : 0.f;
                             ds[rt][k2][r] = prb * (dp - dlt[rt]);
@@ -311,11 +313,10 @@ __global__ __launch_bounds__(512, 2) void attn_res_bwd_kernel(AttnArgs p) {
 #pragma unroll
         for (int kt = 0; kt < 2; ++kt) {
             key[kt] = pr * 32 + kt * 16 + fr;
-            const int kc = key[kt] < SP ? key[kt] : SP - 1;
 #pragma unroll
             for (int dg = 0; dg < 2; ++dg) {
-                kf[kt][dg] = read_frag<bf16_t>(sK, kc, dg * 4 + g);
-                vf[kt][dg] = read_frag<bf16_t>(sV, kc, dg * 4 + g);
+                kf[kt][dg] = read_frag<bf16_t>(sK, key[kt], dg * 4 + g);
+                vf[kt][dg] = read_frag<bf16_t>(sV, key[kt], dg * 4 + g);
             }
         }
         f32x4_t dkacc[2][4], dvacc[2][4];
@@ -327,7 +328,7 @@ __global__ __launch_bounds__(512, 2) void attn_res_bwd_kernel(AttnArgs p) {
             const int qb0 = t << 6;
             int nqs = (S - qb0 + 15) >> 4;
             nqs = nqs > 4 ? 4 : nqs;
-#pragma unroll
+#pragma unroll 1
             for (int kk = 0; kk < 2; ++kk) {
                 if (2 * kk >= nqs) continue;
                 f32x4_t pd[2][2], ds[2][2];      // [kt][q2]
@@ -350,26 +351,22 @@ __global__ __launch_bounds__(512, 2) void attn_res_bwd_kernel(AttnArgs p) {
                         }
                         l4 = *(const f32x4_t*)(sLse + q4); d4 = *(const f32x4_t*)(sDelta + q4);
                     }
+                    if (qs >= nqs) l4 = (f32x4_t){INFINITY, INFINITY, INFINITY, INFINITY};     // sub-tile past S (block uniform): P = 0
 #pragma unroll
                     for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
                         for (int r = 0; r < 4; ++r) {
                             const int qr = q4 + r;
-                            float dsv = 0.f, pdv = 0.f;
-                            if (qs < nqs && qr < S && key[kt] < S) {
-                                float sc = sa[kt][r] * sl2;
-                                if (p.mask) sc += p.mask[(int64_t)b * p.mask_bs + (int64_t)qr * p.mask_rs + key[kt]] * LOG2E_F;
-                                const float prb = fast_exp2(sc - l4[r]);
-                                float dp = pa[kt][r];
-                                pdv = prb;
-                                if (DROP) {
-                                    const bool keep = attn_drop_bits(hk, (uint32_t)qr * (uint32_t)p.Skv + (uint32_t)key[kt]) >= thr;
-                                    dp = keep ? dp * keep_scale : 0.f;
-                                    pdv = keep ? prb * keep_scale : 0.f;
-                                }
-                                dsv = prb * (dp - d4[r]);
+                            float sc = sa[kt][r] * sl2;
+                            if (p.mask) { if (qr < S && key[kt] < S) sc += p.mask[(int64_t)b * p.mask_bs + (int64_t)qr * p.mask_rs + key[kt]] * LOG2E_F; }
+                            const float prb = fast_exp2(sc - l4[r]);               // query past S: lse = +inf -> 0
+                            float dp = pa[kt][r], pdv = prb;
+                            if (DROP) {
+                                const bool keep = attn_drop_bits(hk, (uint32_t)qr * (uint32_t)p.Skv + (uint32_t)key[kt]) >= thr;
+                                dp = keep ? dp * keep_scale : 0.f;
+                                pdv = keep ? prb * keep_scale : 0.f;
                             }
-                            pd[kt][q2][r] = pdv; ds[kt][q2][r] = dsv;
+                            pd[kt][q2][r] = pdv; ds[kt][q2][r] = prb * (dp - d4[r]);
                         }
                 }
                 const bf16x8_t p0 = pack_bf16x8(pd[0][0], pd[0][1]);
@@ -427,7 +424,7 @@ bool attn_res_bwd_launch(hipStream_t st, const AttnArgs& p) {
     // one workgroup of 8 waves per head needs >= 2 32-row blocks to be worth it; shorter sequences stay on the
     // streaming kernels (measured: S = 32 / 42 are slower here)
     if (!res_eligible(p) || p.Skv <= 64 || (int64_t)p.Sq * p.do_rs * 2 >= ((int64_t)1 << 31)) return false;
-    const int SP = (p.Skv + 15) & ~15;
+    const int SP = (p.Skv + 31) & ~31;
     const size_t lds = 4 * (size_t)SP * TILE_ROW_BYTES + 2 * (size_t)SP * sizeof(float);
     static bool attr_set = false;
     if (!attr_set) {

@@ -8,7 +8,8 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libvalor_hip.so")
+# VALOR_HIP_LIB: another build of the same library (A/B runs of two kernel versions inside one GPU session, tools/ab_bench.sh)
+LIB_PATH = os.environ.get("VALOR_HIP_LIB") or os.path.join(_HERE, "libvalor_hip.so")
 
 DT_BF16 = 0
 DT_F32 = 1
