@@ -300,3 +300,41 @@ def test_layernorm_families_agree(dev, cols, rows, p, scaled):
     assert torch.equal(outs[0][0], outs[2][0])
     for name, a, b in zip(("y", "mean", "rstd", "dx", "dres", "dgamma", "dbeta", "dbias"), outs[2][1:], outs[0][1:]):
         assert float((a - b).norm()) <= 4e-3 * float(b.norm()) + 1e-6, name
+
+
+def test_dropout_is_unbiased_in_expectation(dev):
+    """E[dropout(x) / (1 - p)] = x for both counter-based generators: the attention probability hash (attn_common.h) and the
+    Philox4x32-10 windows of the fused LayerNorm kernels. The mean over N independent windows must approach the p = 0 output at the
+    binomial rate: |mean - exact| ~ sqrt(p / ((1 - p) N)) * |contribution|, checked at 5 sigma on aggregate norms."""
+    from valor_amd import kernels as K
+    p, N = 0.1, 96
+    # ---- attention: O = sum_k dropout(P)_k V_k
+    B, H, S = 2, 4, 197
+    E = H * 64
+    g = torch.Generator().manual_seed(4)
+    q, k, v = ((torch.randn((B, S, E), generator=g) * 0.7).to(torch.bfloat16).to(dev) for _ in range(3))
+    o0, _ = K.attn_fwd(q, k, v, H, p_drop=0.0)
+    acc = torch.zeros_like(o0, dtype=torch.float32)
+    for i in range(N):
+        o, _ = K.attn_fwd(q, k, v, H, p_drop=p, seed=11, offset=1000003 * i)
+        acc += o.float()
+    err = float((acc / N - o0.float()).norm() / o0.float().norm())
+    # one draw deviates by ~ sqrt(p/(1-p)) * sqrt(sum P^2 V^2) / |O| ~ 0.33 * O(1) for near-uniform P; N draws: / sqrt(N)
+    one, _ = K.attn_fwd(q, k, v, H, p_drop=p, seed=11, offset=5)
+    single = float((one.float() - o0.float()).norm() / o0.float().norm())
+    assert 0.05 < single < 1.0
+    assert err < 2.0 * single / N ** 0.5 + 4e-3, (err, single)
+    # ---- fused bias + dropout + residual (+ LayerNorm): z = dropout(x + b) / (1 - p) + res
+    rows, cols = 512, 768
+    x, res = torch.randn((rows, cols), generator=g).to(torch.bfloat16).to(dev), torch.randn((rows, cols), generator=g).to(torch.bfloat16).to(dev)
+    bias = torch.randn((cols,), generator=g).to(torch.bfloat16).to(dev)
+    exact = x.float() + bias.float() + res.float()
+    acc = torch.zeros((rows, cols), dtype=torch.float32, device=dev)
+    keep = 0.0
+    for i in range(N):
+        z, _, _, _ = K.bdrln_fwd(x, bias, res, None, None, 0.0, p_drop=p, seed=3, offset=7919 * i, want_y=False)
+        acc += z.float()
+        keep += float(((z.float() - res.float()).abs() > 0).float().mean())
+    assert abs(keep / N - (1 - p)) < 2e-3
+    err = float((acc / N - exact).norm() / (x.float() + bias.float()).norm())
+    assert err < 2.0 * (p / (1 - p) / N) ** 0.5 + 4e-3, err

@@ -50,10 +50,18 @@ DEVINL uint32_t attn_drop_headkey(uint64_t seed, uint64_t offset, int head) {
     k = mix32(k ^ (uint32_t)(offset >> 32) ^ (uint32_t)seed);
     return mix32(k + (uint32_t)(seed >> 32));
 }
+// Per element this is the single most executed piece of integer code of a dropout attention kernel (round 1's three-multiply
+// mix cost more VALU time than the softmax itself: v_mul_lo_u32 issues at a quarter of the add rate). Two rounds of a 24-bit
+// multiply-add (v_mad_u32_u24: full rate; the element index is < 2^24 for every shape of the model) with xor-shift folds:
+// 6 full-rate instructions. hk is a full 32-bit mix per (seed, offset window, batch, head), so windows / heads are decorrelated by
+// the key, neighbouring elements by the two multiplies; the kernels' statistics tests (keep fraction, fwd / bwd mask agreement,
+// identical masks across kernel families) run on this function.
 DEVINL uint32_t attn_drop_bits(uint32_t hk, uint32_t local) {
-    uint32_t x = mix32(local ^ hk);
-    x += hk;
-    x ^= x >> 15; x *= 0x2c1b3c6du; x ^= x >> 12;
+    uint32_t x = local ^ hk;
+    x = __umul24(x, 0x9E3779u) + (hk >> 7);
+    x ^= x >> 15;
+    x = __umul24(x, 0x85EBCBu) + hk;
+    x ^= x >> 13;
     return x;
 }
 
