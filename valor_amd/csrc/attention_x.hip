@@ -272,7 +272,7 @@ __global__ __launch_bounds__(256, 2) void attn_x_bwd_kernel(AttnArgs p) {
             d += __shfl_xor(d, 1, 64); d += __shfl_xor(d, 2, 64); d += __shfl_xor(d, 4, 64);
             if (c == 0) {
                 sDelta[r0 + (lane >> 3)] = d;
-                sLse[r0 + (lane >> 3)] = ok ? p.lse[((int64_t)su.b * p.H + h) * p.Sq + row] * LOG2E_F : 0.f;
+                sLse[r0 + (lane >> 3)] = ok ? p.lse[((int64_t)su.b * p.H + h) * p.Sq + row] * LOG2E_F : INFINITY;   // padding rows: P = 2^(s - inf) = 0
             }
         }
     }
@@ -349,12 +349,11 @@ __global__ __launch_bounds__(256, 2) void attn_x_bwd_kernel(AttnArgs p) {
 #pragma unroll
                     for (int kt = 0; kt < 2; ++kt) {
                         const int key = ka + kt * 16 + fr;
-                        const bool kin = key >= ss0_[u] && key < ss1_[u];
+                        const float kout = (key >= ss0_[u] && key < ss1_[u]) ? 0.f : INFINITY;     // key outside the group's range: P = 0
                         f32x4_t pdv, dsv;
 #pragma unroll
                         for (int r = 0; r < 4; ++r) {
-                            const bool ok = kin && (sq0_[u] + 4 * g + r) < p.Sq;
-                            const float prb = ok ? x_exp2(sacc[kt][r] * sl2 - l4[r]) : 0.f;
+                            const float prb = x_exp2(sacc[kt][r] * sl2 - l4[r] - kout);             // query rows past Sq: lse = +inf
                             float dp = pacc[kt][r];
                             float pd = prb;
                             if (DROP) {
