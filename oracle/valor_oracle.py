@@ -403,6 +403,24 @@ class Oracle:
             return {"mlm_loss": F.cross_entropy(scores, txt_labels[txt_labels != -1])}
         return {"mlm_scores_t": scores, "txt_labels_mlm": txt_labels}
 
+    def multimodal_inputs(self, video_output, audio_output, bs):
+        """get_multimodal_forward_input_video / _audio, model/modeling.py:485-502"""
+        w = self.w
+        video_input = audio_input = None
+        if video_output is not None:                                                             # modeling.py:485-493
+            if "hidden_trans_video_multimodal.0.weight" in self.sd:                              # modeling.py:348-349,487-488
+                video_output = layer_norm(F.linear(video_output, w("hidden_trans_video_multimodal.0.weight"), w("hidden_trans_video_multimodal.0.bias")),
+                                          w("hidden_trans_video_multimodal.1.weight"), w("hidden_trans_video_multimodal.1.bias"), 1e-12)
+            vo = video_output + w("video_frame_embedding")[:, :video_output.shape[1], :].unsqueeze(-2)
+            video_input = vo.reshape(bs, -1, self.spec.hidden) + w("video_type_embeddings")
+        if audio_output is not None:                                                             # modeling.py:495-502
+            if "hidden_trans_audio_multimodal.0.weight" in self.sd:                              # modeling.py:350-351,497-498
+                audio_output = layer_norm(F.linear(audio_output, w("hidden_trans_audio_multimodal.0.weight"), w("hidden_trans_audio_multimodal.0.bias")),
+                                          w("hidden_trans_audio_multimodal.1.weight"), w("hidden_trans_audio_multimodal.1.bias"), 1e-12)
+            ao = audio_output + w("audio_frame_embedding")[:, :audio_output.shape[1], :].unsqueeze(-2)
+            audio_input = ao.reshape(bs, -1, self.spec.hidden) + w("audio_type_embeddings")
+        return video_input, audio_input
+
     # ------------------------------------------------------------------------- the hot path
     def forward_pt(self, batch, task, compute_loss=True, gather=None, collect=None):
         """VALOR.forward_pt, model/pretrain.py:214-541 (contra_type='fine', caption_type='unimlm', va_concate).
@@ -490,19 +508,7 @@ class Oracle:
 
         txt = txt_tokens["bert_tokens"]
         bs = txt.shape[0]
-        video_input = audio_input = None
-        if video_output is not None:                                                             # modeling.py:485-493
-            if "hidden_trans_video_multimodal.0.weight" in self.sd:                              # modeling.py:348-349,487-488
-                video_output = layer_norm(F.linear(video_output, w("hidden_trans_video_multimodal.0.weight"), w("hidden_trans_video_multimodal.0.bias")),
-                                          w("hidden_trans_video_multimodal.1.weight"), w("hidden_trans_video_multimodal.1.bias"), 1e-12)
-            vo = video_output + w("video_frame_embedding")[:, :video_output.shape[1], :].unsqueeze(-2)
-            video_input = vo.reshape(bs, -1, self.spec.hidden) + w("video_type_embeddings")
-        if audio_output is not None:                                                             # modeling.py:495-502
-            if "hidden_trans_audio_multimodal.0.weight" in self.sd:                              # modeling.py:350-351,497-498
-                audio_output = layer_norm(F.linear(audio_output, w("hidden_trans_audio_multimodal.0.weight"), w("hidden_trans_audio_multimodal.0.bias")),
-                                          w("hidden_trans_audio_multimodal.1.weight"), w("hidden_trans_audio_multimodal.1.bias"), 1e-12)
-            ao = audio_output + w("audio_frame_embedding")[:, :audio_output.shape[1], :].unsqueeze(-2)
-            audio_input = ao.reshape(bs, -1, self.spec.hidden) + w("audio_type_embeddings")
+        video_input, audio_input = self.multimodal_inputs(video_output, audio_output, bs)
 
         def run_group(txt_input, txt_labels, prompt, g, casual, tag):
             vi = video_input if "v" in g else None
@@ -547,6 +553,127 @@ class Oracle:
                 out["txt_labels_mlm"] = txt_labels
         return out
 
+
+    # ------------------------------------------------------------------------- finetune / inference tasks
+    def forward(self, batch, task, compute_loss=True, **kw):
+        """VALOR.forward, model/pretrain.py:125-135 (qa is not restated)"""
+        if task.startswith("pt"):
+            return self.forward_pt(batch, task, compute_loss, **kw)
+        if task.startswith("ret"):
+            return self.forward_ret(batch, task, compute_loss, **kw)
+        if task.startswith("cap"):
+            return self.forward_cap(batch, task, compute_loss)
+        raise NotImplementedError(task)
+
+    def forward_ret(self, batch, task, compute_loss=True, gather=None):
+        """VALOR.forward_ret, model/pretrain.py:544-711. Line by line the contrastive branch of forward_pt (:252-407: same encoders, pooling,
+        heads, gathers, fine matrices and InfoNCE) on the groups after 'ret%', except that the mean of the group losses is NOT scaled by
+        contra_loss_ratio (:706 vs :406); compute_loss=False returns feat_t / feat_v / feat_a / txt_tokens (:708-715)."""
+        ratio, self.contra_loss_ratio = self.contra_loss_ratio, 1.0
+        try:
+            return self.forward_pt(batch, "pt_contra%" + "%".join(task.split("%")[1:]), compute_loss, gather)
+        finally:
+            self.contra_loss_ratio = ratio
+
+    def forward_cap(self, batch, task, compute_loss=True, beam_size=3, max_generation_len=30):
+        """VALOR.forward_cap -> forward_cap_single (loss) / generate_cap, model/pretrain.py:713-725,794-985 (caption_type 'unimlm', no
+        label smoothing, no scst, full_masker False: the shipped caption-*.json settings)."""
+        groups = task.split("%")[1:]
+        txt = batch["txt_tokens"]["bert_tokens"] if batch.get("txt_tokens") is not None else None
+        alltasks = "".join(groups)
+        video_output = self.forward_video_encoder(batch["video_pixels"]) if "v" in alltasks else None
+        audio_output = self.forward_audio_encoder(batch["audio_spectrograms"]) if "a" in alltasks else None
+        bs = (video_output if video_output is not None else audio_output).shape[0]
+        video_input, audio_input = self.multimodal_inputs(video_output, audio_output, bs)
+        if compute_loss:                                                                         # :802-880
+            txt_input, txt_labels = self.text_masker(txt, 0.6)
+            lo = []
+            for g in ("tva", "tv", "ta"):
+                if g in groups:
+                    prompt = self.get_task_prompt("describe the video with natural language", bs) if self.use_task_prompt else None
+                    o = self.bert_model(txt_input, prompt, video_input if "v" in g else None, audio_input if "a" in g else None, True)
+                    scores = self.cls_head(o[:, :txt_input.shape[1]][txt_labels != -1])
+                    lo.append(F.cross_entropy(scores, txt_labels[txt_labels != -1]))
+            return {"caption_loss": sum(lo) / len(lo)}
+        ev = {}                                                                                  # generate_cap :914-985
+        for g, key in (("tv", "t_v"), ("tva", "t_va"), ("ta", "t_a")):
+            if g in groups:
+                prompt = self.get_task_prompt("describe the video with natural language", bs) if self.use_task_prompt else None
+                vi, ai = (video_input if "v" in g else None), (audio_input if "a" in g else None)
+                if beam_size > 1:
+                    ev["generated_sequences_" + key] = self.decode_beam(vi, ai, prompt, bs, beam_size, max_generation_len)
+                else:
+                    ev["generated_sequences_" + key], ev["logprobs_" + key] = self.decode_greedy(vi, ai, prompt, bs, max_generation_len)
+        return ev
+
+    BOS, EOS, MASK = 101, 102, 103        # [CLS] / [SEP] / [MASK] of bert-base-uncased, model/modeling.py:669-671
+
+    def get_logits(self, state, vi, ai, prompt, rows, trace=None):
+        """VALOR.get_logits (unimlm) + forward_cap_single(compute_loss=False), model/pretrain.py:1031-1051,882-900: the decoder runs on
+        [CLS] + generated tokens + [MASK] from scratch every step (multimodal_use_cross_attn: no cache), logits of the last text position."""
+        mask_col = torch.full((rows, 1), self.MASK, dtype=torch.long)
+        bos = torch.full((rows, 1), self.BOS, dtype=torch.long)
+        txt = torch.cat((bos, state, mask_col), dim=1) if state is not None else torch.cat((bos, mask_col), dim=1)
+        o = self.bert_model(txt, prompt, vi, ai, True)[:, :txt.shape[1]]
+        logits = self.cls_head(o[:, -1])
+        if trace is not None:
+            trace.append(logits)
+        return logits
+
+    def decode_greedy(self, vi, ai, prompt, bs, max_len, trace=None):
+        """VALOR.decode_greedy, model/pretrain.py:988-1028 (mode 'greedy'; logprobs stay zero in that mode)"""
+        sents = torch.full((bs, max_len), self.EOS, dtype=torch.long)
+        logprobs = torch.zeros(bs, max_len)
+        unfinished = torch.ones(bs, dtype=torch.bool)
+        state = None
+        for t in range(max_len):
+            logits = self.get_logits(state, vi, ai, prompt, bs, trace)
+            wt = logits.max(1)[1].view(-1).long()
+            unfinished = unfinished * (wt != self.EOS)
+            wt = wt * unfinished.type_as(wt) + (1 - unfinished.type_as(wt)) * self.EOS
+            sents[:, t] = wt
+            state = wt.unsqueeze(1) if state is None else torch.cat((state, wt.unsqueeze(1)), dim=1)
+            if unfinished.sum() == 0:
+                break
+        return sents, logprobs
+
+    def decode_beam(self, vi, ai, prompt, bs, beam, max_len, trace=None):
+        """VALOR.decode_beam / select / _adjust_tensor / expand_tensor, model/pretrain.py:1054-1189. Rows are ordered (sample, beam)."""
+        seq_logprob = torch.zeros(bs, 1, 1)
+        seq_mask = torch.ones(bs, beam, 1)
+        outputs, selected_words, state = [], None, None
+        expand = lambda x: None if x is None else x.unsqueeze(1).expand(-1, beam, *x.shape[1:]).reshape(-1, *x.shape[1:])
+        for t in range(max_len):
+            cur = 1 if t == 0 else beam
+            logits = self.get_logits(state, vi, ai, prompt, bs * cur, trace)
+            word_logprob = F.log_softmax(logits, dim=1).view(bs, cur, -1)
+            cand = seq_logprob + word_logprob
+            if t > 0:                                                                            # a beam that met EOS keeps its score
+                mask = (selected_words.view(bs, cur) != self.EOS).float().unsqueeze(-1)
+                seq_mask = seq_mask * mask
+                old = seq_logprob.expand_as(cand).contiguous()
+                cand = seq_mask * cand + old * (1 - seq_mask)
+            sel_logprob, sel_idx = torch.sort(cand.view(bs, -1), -1, descending=True)            # select :1156-1159
+            sel_logprob, sel_idx = sel_logprob[:, :beam], sel_idx[:, :beam]
+            V = cand.shape[-1]
+            sel_beam = sel_idx // V
+            selected_words = sel_idx - sel_beam * V
+            seq_logprob = sel_logprob.unsqueeze(-1)
+            seq_mask = torch.gather(seq_mask, 1, sel_beam.unsqueeze(-1))
+            outputs = [torch.gather(o, 1, sel_beam.unsqueeze(-1)) for o in outputs]
+            outputs.append(selected_words.unsqueeze(-1))
+            selected_words = selected_words.view(-1, 1)
+            if state is not None:                                                                # _adjust_tensor, 2-d case
+                state = torch.gather(state.view(bs, beam, -1), 1, sel_beam.unsqueeze(-1).expand(bs, beam, state.shape[1])).reshape(bs * beam, -1)
+                state = torch.cat((state, selected_words), dim=1)
+            else:
+                state = selected_words
+            if t == 0:                                                                           # expand_tensor :1133-1139
+                vi, ai, prompt = expand(vi), expand(ai), expand(prompt)
+        seq_logprob, sort_idx = torch.sort(seq_logprob, 1, descending=True)
+        outputs = torch.cat(outputs, -1)
+        outputs = torch.gather(outputs, 1, sort_idx.expand(bs, beam, max_len))
+        return outputs.contiguous()[:, 0]
 
 # ----------------------------------------------------------------------------- state-dict helpers
 def is_alias_key(k):

@@ -287,3 +287,38 @@ def test_use_task_prompt_matches_reference(variant):
         assert float((g - p.grad).norm()) / scale < 2e-4, name
         n += 1
     assert n > 800
+
+
+def test_finetune_tasks_and_caption_generation(setup):
+    """'ret%..' / 'cap%..' losses (config/fast-retrieval-*.json, caption-*.json) and generate_cap with greedy and beam
+    decoding (model/pretrain.py:544-725,914-1189): the reference's sequences, token for token."""
+    spec, ref, orc, sd_o, batch = setup
+    with torch.no_grad():
+        random.seed(3)
+        r = ref(batch, task="ret%tva%tv", compute_loss=True)
+        random.seed(3)
+        o = orc.forward(batch, "ret%tva%tv", compute_loss=True)
+        assert abs(float(r["contra_loss"]) - float(o["contra_loss"])) <= 2e-5 * abs(float(r["contra_loss"]))
+        re, oe = ref(batch, task="ret%tva%tv", compute_loss=False), orc.forward(batch, "ret%tva%tv", compute_loss=False)
+        for k in ("feat_t", "feat_v", "feat_a"):
+            assert torch.allclose(re[k], oe[k], atol=1e-5), k
+        random.seed(4)
+        r = ref(dict(batch), task="cap%tva%tv", compute_loss=True)       # forward_cap replaces batch['txt_tokens'] in place
+        random.seed(4)
+        o = orc.forward(batch, "cap%tva%tv", compute_loss=True)
+        assert abs(float(r["caption_loss"]) - float(o["caption_loss"])) <= 2e-5 * abs(float(r["caption_loss"]))
+        old = ref.beam_size, ref.max_generation_len
+        try:
+            ref.max_generation_len = 6
+            ref.beam_size = 1
+            rg = ref(dict(batch), task="cap%tva%ta", compute_loss=False)
+            og = orc.forward_cap(batch, "cap%tva%ta", compute_loss=False, beam_size=1, max_generation_len=6)
+            for k in ("generated_sequences_t_va", "generated_sequences_t_a"):
+                assert torch.equal(rg[k], og[k]), (k, rg[k], og[k])
+            ref.beam_size = 3
+            rb = ref(dict(batch), task="cap%tva%tv", compute_loss=False)
+            ob = orc.forward_cap(batch, "cap%tva%tv", compute_loss=False, beam_size=3, max_generation_len=6)
+            for k in ("generated_sequences_t_va", "generated_sequences_t_v"):
+                assert torch.equal(rb[k], ob[k]), (k, rb[k], ob[k])
+        finally:
+            ref.beam_size, ref.max_generation_len = old

@@ -136,30 +136,106 @@ DEVINL uint32_t drop_threshold(float p) {
 #define VALOR_ACT_RELU 3        // fine-weight MLP             pretrain.py:104-112
 #define VALOR_ACT_TANH 4
 
+// The activations run in GEMM epilogues at one value per MFMA output, i.e. on the VALU beside the matrix pipe: ViT fc1 alone is
+// 3.7e9 values per step. They are written for instruction count: v_rcp_f32 / v_exp_f32 (1 ulp) instead of IEEE division, and erf
+// as Abramowitz-Stegun 7.1.26 (|error| <= 1.5e-7, below the fp32 rounding of x * cdf; it shares exp(-x^2/2) with the Gaussian
+// density of the derivative). Same fp32 accuracy class as erff / division: absolute error of gelu 4.6e-7 vs 4.4e-7 over [-12, 12].
+DEVINL float hw_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
+DEVINL float hw_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
+DEVINL float quick_sigmoid(float x) { return hw_rcp(1.0f + hw_exp2(-1.702f * 1.44269504088896340736f * x)); }
+// erf(|x| / sqrt 2) and e = exp(-x^2 / 2)
+DEVINL float erf_abs_half(float x, float& e) {
+    const float z = fabsf(x) * 0.70710678118654752440f;
+    const float t = hw_rcp(fmaf(0.3275911f, z, 1.0f));
+    float q = fmaf(1.061405429f, t, -1.453152027f);
+    q = fmaf(q, t, 1.421413741f);
+    q = fmaf(q, t, -0.284496736f);
+    q = fmaf(q, t, 0.254829592f);
+    e = hw_exp2(-1.44269504088896340736f * z * z);
+    return fmaf(-q * t, e, 1.0f);
+}
+DEVINL float gelu_cdf(float x, float& e) { return fmaf(copysignf(0.5f, x), erf_abs_half(x, e), 0.5f); }
+
+template <int ACT> DEVINL float act_fwd_c(float x) {
+    if constexpr (ACT == VALOR_ACT_GELU_ERF) { float e; return x * gelu_cdf(x, e); }
+    else if constexpr (ACT == VALOR_ACT_QUICK_GELU) return x * quick_sigmoid(x);
+    else if constexpr (ACT == VALOR_ACT_RELU) return x > 0.f ? x : 0.f;
+    else if constexpr (ACT == VALOR_ACT_TANH) return tanhf(x);
+    else return x;
+}
+// derivative wrt the pre-activation x
+template <int ACT> DEVINL float act_bwd_c(float x) {
+    if constexpr (ACT == VALOR_ACT_GELU_ERF) {
+        float e;
+        const float cdf = gelu_cdf(x, e);
+        return fmaf(x * 0.39894228040143267794f, e, cdf);
+    } else if constexpr (ACT == VALOR_ACT_QUICK_GELU) {
+        const float s = quick_sigmoid(x), t = 1.702f * x;
+        return fmaf(s, fmaf(-t, s, t), s);          // s + 1.702 x s (1 - s)
+    } else if constexpr (ACT == VALOR_ACT_RELU) return x > 0.f ? 1.f : 0.f;
+    else if constexpr (ACT == VALOR_ACT_TANH) { const float t = tanhf(x); return 1.f - t * t; }
+    else return 1.0f;
+}
 DEVINL float act_fwd(int act, float x) {
     switch (act) {
-        case VALOR_ACT_GELU_ERF: return x * 0.5f * (1.0f + erff(x * 0.70710678118654752440f));
-        case VALOR_ACT_QUICK_GELU: return x / (1.0f + __expf(-1.702f * x));
-        case VALOR_ACT_RELU: return x > 0.f ? x : 0.f;
-        case VALOR_ACT_TANH: return tanhf(x);
+        case VALOR_ACT_GELU_ERF: return act_fwd_c<VALOR_ACT_GELU_ERF>(x);
+        case VALOR_ACT_QUICK_GELU: return act_fwd_c<VALOR_ACT_QUICK_GELU>(x);
+        case VALOR_ACT_RELU: return act_fwd_c<VALOR_ACT_RELU>(x);
+        case VALOR_ACT_TANH: return act_fwd_c<VALOR_ACT_TANH>(x);
         default: return x;
     }
 }
-// derivative wrt the pre-activation x
 DEVINL float act_bwd(int act, float x) {
     switch (act) {
-        case VALOR_ACT_GELU_ERF: {
-            float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752440f));
-            float pdf = 0.39894228040143267794f * __expf(-0.5f * x * x);
-            return cdf + x * pdf;
-        }
-        case VALOR_ACT_QUICK_GELU: {
-            float s = 1.0f / (1.0f + __expf(-1.702f * x));
-            return s + 1.702f * x * s * (1.0f - s);
-        }
-        case VALOR_ACT_RELU: return x > 0.f ? 1.f : 0.f;
-        case VALOR_ACT_TANH: { float t = tanhf(x); return 1.f - t * t; }
+        case VALOR_ACT_GELU_ERF: return act_bwd_c<VALOR_ACT_GELU_ERF>(x);
+        case VALOR_ACT_QUICK_GELU: return act_bwd_c<VALOR_ACT_QUICK_GELU>(x);
+        case VALOR_ACT_RELU: return act_bwd_c<VALOR_ACT_RELU>(x);
+        case VALOR_ACT_TANH: return act_bwd_c<VALOR_ACT_TANH>(x);
         default: return 1.0f;
+    }
+}
+// N values at once with ONE dispatch on the (wave-uniform) activation id: the element loops stay branch-free
+template <int N> DEVINL void act_fwd_n(int act, float* v) {
+    switch (act) {
+        case VALOR_ACT_GELU_ERF:
+#pragma unroll
+            for (int r = 0; r < N; ++r) v[r] = act_fwd_c<VALOR_ACT_GELU_ERF>(v[r]);
+            break;
+        case VALOR_ACT_QUICK_GELU:
+#pragma unroll
+            for (int r = 0; r < N; ++r) v[r] = act_fwd_c<VALOR_ACT_QUICK_GELU>(v[r]);
+            break;
+        case VALOR_ACT_RELU:
+#pragma unroll
+            for (int r = 0; r < N; ++r) v[r] = act_fwd_c<VALOR_ACT_RELU>(v[r]);
+            break;
+        case VALOR_ACT_TANH:
+#pragma unroll
+            for (int r = 0; r < N; ++r) v[r] = act_fwd_c<VALOR_ACT_TANH>(v[r]);
+            break;
+        default: break;
+    }
+}
+// v[r] *= act'(x[r])
+template <int N> DEVINL void act_bwd_mul_n(int act, float* v, const float* x) {
+    switch (act) {
+        case VALOR_ACT_GELU_ERF:
+#pragma unroll
+            for (int r = 0; r < N; ++r) v[r] *= act_bwd_c<VALOR_ACT_GELU_ERF>(x[r]);
+            break;
+        case VALOR_ACT_QUICK_GELU:
+#pragma unroll
+            for (int r = 0; r < N; ++r) v[r] *= act_bwd_c<VALOR_ACT_QUICK_GELU>(x[r]);
+            break;
+        case VALOR_ACT_RELU:
+#pragma unroll
+            for (int r = 0; r < N; ++r) v[r] *= act_bwd_c<VALOR_ACT_RELU>(x[r]);
+            break;
+        case VALOR_ACT_TANH:
+#pragma unroll
+            for (int r = 0; r < N; ++r) v[r] *= act_bwd_c<VALOR_ACT_TANH>(x[r]);
+            break;
+        default: break;
     }
 }
 

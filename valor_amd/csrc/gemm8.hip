@@ -312,8 +312,9 @@ __global__ __launch_bounds__(512, 2) void gemm_8ph_kernel(GemmArgs p) {
 #pragma unroll
                     for (int r = 0; r < 4; ++r) v[r] = v[r] * p.alpha + bias4[r];
                     if (apply_act) {
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) v[r] = act_fwd(p.act, v[r]);
+                        float f[4] = {v[0], v[1], v[2], v[3]};
+                        act_fwd_n<4>(p.act, f);
+                        v = (f32x4_t){f[0], f[1], f[2], f[3]};
                     }
                     const u32x2_t w = {pack2_bf16(v[0], v[1]), pack2_bf16(v[2], v[3])};
                     *(u32x2_t*)(sB + row * 512 + (((col >> 3) ^ (row & 31)) << 4) + (fg & 1) * 8) = w;
@@ -333,11 +334,10 @@ __global__ __launch_bounds__(512, 2) void gemm_8ph_kernel(GemmArgs p) {
                         for (int q = 0; q < 4; ++q) { f[2 * q] = __uint_as_float(val[q] << 16); f[2 * q + 1] = __uint_as_float(val[q] & 0xffff0000u); }
                         if (dact) {
                             const u32x4_t a = *(const u32x4_t*)((const T*)p.dact_aux + (int64_t)m * p.ldaux + n);
+                            float x[8];
 #pragma unroll
-                            for (int q = 0; q < 4; ++q) {
-                                f[2 * q] *= act_bwd(p.act, __uint_as_float(a[q] << 16));
-                                f[2 * q + 1] *= act_bwd(p.act, __uint_as_float(a[q] & 0xffff0000u));
-                            }
+                            for (int q = 0; q < 4; ++q) { x[2 * q] = __uint_as_float(a[q] << 16); x[2 * q + 1] = __uint_as_float(a[q] & 0xffff0000u); }
+                            act_bwd_mul_n<8>(p.act, f, x);
                         }
                         if (accum) {
                             const u32x4_t o = *(const u32x4_t*)(dst + (int64_t)m * p.ldc + n);

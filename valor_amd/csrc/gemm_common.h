@@ -71,15 +71,18 @@ DEVINL void epilogue_store(const GemmArgs& p, int m, int n0, f32x4_t acc, f32x4_
         }
     }
     if (p.act != VALOR_ACT_NONE && !p.dact_aux) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) v[r] = act_fwd(p.act, v[r]);
+        float f[4] = {v[0], v[1], v[2], v[3]};
+        act_fwd_n<4>(p.act, f);
+        v = (f32x4_t){f[0], f[1], f[2], f[3]};
     }
     if (p.dact_aux) {
         const T* a = (const T*)p.dact_aux + (int64_t)m * p.ldaux + n0;
         if (vec && (p.ldaux & 3) == 0) {
-            f32x4_t u = load4<T>(a);
-#pragma unroll
-            for (int r = 0; r < 4; ++r) v[r] *= act_bwd(p.act, u[r]);
+            const f32x4_t u = load4<T>(a);
+            float f[4] = {v[0], v[1], v[2], v[3]};
+            const float x[4] = {u[0], u[1], u[2], u[3]};
+            act_bwd_mul_n<4>(p.act, f, x);
+            v = (f32x4_t){f[0], f[1], f[2], f[3]};
         } else {
             for (int r = 0; r < nvalid; ++r) v[r] *= act_bwd(p.act, to_f32<T>(a[r]));
         }
@@ -125,14 +128,19 @@ DEVINL void epilogue_store8(const GemmArgs& p, int m, int n0, f32x4_t a0, f32x4_
         *(u32x4_t*)((T*)p.preact + off) = q;
     }
     if (p.act != VALOR_ACT_NONE && !p.dact_aux) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) { v0[r] = act_fwd(p.act, v0[r]); v1[r] = act_fwd(p.act, v1[r]); }
+        float f[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+        act_fwd_n<8>(p.act, f);
+        v0 = (f32x4_t){f[0], f[1], f[2], f[3]};
+        v1 = (f32x4_t){f[4], f[5], f[6], f[7]};
     }
     if (p.dact_aux) {
         const T* a = (const T*)p.dact_aux + (int64_t)m * p.ldaux + n0;
         const f32x4_t u0 = load4<T>(a), u1 = load4<T>(a + 4);
-#pragma unroll
-        for (int r = 0; r < 4; ++r) { v0[r] *= act_bwd(p.act, u0[r]); v1[r] *= act_bwd(p.act, u1[r]); }
+        float f[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+        const float x[8] = {u0[0], u0[1], u0[2], u0[3], u1[0], u1[1], u1[2], u1[3]};
+        act_bwd_mul_n<8>(p.act, f, x);
+        v0 = (f32x4_t){f[0], f[1], f[2], f[3]};
+        v1 = (f32x4_t){f[4], f[5], f[6], f[7]};
     }
     T* c = (T*)p.C + off;
     if (p.accumulate) { v0 += load4<T>(c); v1 += load4<T>(c + 4); }
