@@ -223,7 +223,8 @@ int valor_add_frame_type_bwd(void* stream, int dtype, const void* dout, void* di
 /* F.normalize(dim=-1): pretrain.py:276,283,290 */
 int valor_l2norm_fwd(void* stream, int dtype, const void* x, void* y, float* norm, int64_t rows, int cols);
 int valor_l2norm_bwd(void* stream, int dtype, const void* y, const void* dy, const float* norm, void* dx, int64_t rows, int cols);
-/* masked-token / cls-token row selection: pretrain.py:441,495 ; modeling.py:387,399 */
+/* masked-token / cls-token row selection: pretrain.py:441,495 ; modeling.py:387,399. idx[i] < 0 gathers a zero row (and its
+ * gradient is dropped by the scatter): VideoSwin window / PatchMerging zero padding, videoswin.py:198-203,222-223,257-259 */
 int valor_gather_rows(void* stream, int dtype, const void* src, const int64_t* idx, void* out, int64_t n, int E, int64_t src_ld);
 int valor_scatter_rows(void* stream, int dtype, const void* src, const int64_t* idx, void* dst, int64_t n, int E, int64_t dst_ld);
 int valor_cast_from_f32(void* stream, int dtype, const float* in, void* out, int64_t n);

@@ -115,7 +115,97 @@ FIXTURES = {
 }
 
 
+def run_finetune(name, batch_size, frames, audio_slices, wseed, bseed, mseed, variant="clip", max_len=12):
+    """SURVEY 8f row 4 fixture: 'ret%tva%tv' / 'cap%tva%tv' losses (config/fast-retrieval-*.json, caption-*.json) and generate_cap with
+    greedy and beam-3 decoding, all from the UNMODIFIED reference. Random weights never produce [SEP], so a second greedy run raises
+    cls.decoder.bias[102] by `eos_bias_delta` (chosen from the reference's own max-logit - [SEP]-logit gaps) to make rows end early and
+    exercise the unfinished / EOS-fill logic (pretrain.py:1017-1020). Beam search is left without EOS: finished beams tie (see decode.py)."""
+    from valor_oracle import Oracle, trainable_copy
+    if variant == "swin":
+        spec = synth.swin_spec()
+        ropts = ref_harness.default_opts(video_encoder_type="videoswin_base_k400_22k", txt_encoder_type="bert_base_uncased")
+    else:
+        spec, ropts = synth.base_spec(), None
+    sd = synth.make_state_dict(spec, seed=wseed, bf16_exact=True)
+    ref = ref_harness.build_reference(ropts, state_dict=sd, dropout=0.0)
+    batch = synth.make_batch(spec, batch=batch_size, frames=frames, audio_slices=audio_slices, txt_len=32, seed=bseed, bf16_exact=True)
+    g = {"recipe": dict(spec=spec.to_dict(), weight_seed=wseed, batch_seed=bseed, masker_seed=mseed, batch=batch_size, frames=frames,
+                        audio_slices=audio_slices, txt_len=32, bf16_exact=True, max_generation_len=max_len, beam_size=3)}
+    orc = Oracle(spec, trainable_copy(sd), vocab_tokens=synth.synthetic_vocab(spec.vocab))
+    with torch.no_grad():
+        random.seed(mseed)
+        g["ret_loss"] = float(ref(batch, task="ret%tva%tv", compute_loss=True)["contra_loss"])
+        ev = ref(batch, task="ret%tva%tv", compute_loss=False)
+        g["ret_feats"] = {k: ev[k].clone() for k in ("feat_t", "feat_v", "feat_a")}
+        random.seed(mseed)
+        g["cap_loss"] = float(ref(dict(batch), task="cap%tva%tv", compute_loss=True)["caption_loss"])
+        ref.max_generation_len = max_len
+        ref.beam_size = 1
+        gr = ref(dict(batch), task="cap%tva%tv%ta", compute_loss=False)
+        g["greedy"] = {k: v.clone() for k, v in gr.items() if k.startswith("generated")}
+        ref.beam_size = 3
+        bm = ref(dict(batch), task="cap%tva%tv", compute_loss=False)
+        g["beam3"] = {k: v.clone() for k, v in bm.items() if k.startswith("generated")}
+        # margins, from the restatement (tests/test_oracle_vs_reference.py pins it on the reference token for token)
+        vo, ao = orc.forward_video_encoder(batch["video_pixels"]), orc.forward_audio_encoder(batch["audio_spectrograms"])
+        vi, ai = orc.multimodal_inputs(vo, ao, batch_size)
+        trace, gaps = [], []
+        s, _ = orc.decode_greedy(vi, ai, None, batch_size, max_len, trace)
+        assert torch.equal(s, g["greedy"]["generated_sequences_t_va"])
+        top = torch.stack([t.topk(2, -1).values for t in trace])                       # [steps, b, 2]
+        g["greedy_margin_t_va"] = (top[..., 0] - top[..., 1]).t().clone()               # [b, steps]
+        sb = orc.decode_beam(vi, ai, None, batch_size, 3, max_len, gaps=gaps)
+        assert torch.equal(sb, g["beam3"]["generated_sequences_t_va"])
+        g["beam3_gap_t_va"] = torch.stack(gaps, 1).clone()                              # [b, steps]
+        eos_gap = torch.stack([t.max(-1).values - t[:, 102] for t in trace])            # [steps, b]
+        # [SEP] wins at step t of row r iff eos_gap[t, r] < delta (the trajectory before that is the unbiased one): pick the delta that
+        # ends the rows at different steps (not all at step 0) with the widest clearance to every gap met on the way
+        best = None
+        for cand in sorted(set(eos_gap.flatten().tolist())):
+            d = cand + 0.02
+            ends = []
+            clear = 1e9
+            for r in range(batch_size):
+                hit = (eos_gap[:, r] < d).nonzero()
+                e = int(hit[0]) if hit.numel() else max_len
+                ends.append(e)
+                clear = min(clear, float((eos_gap[:e + 1, r] - d).abs().min()))
+            if max(ends) >= 1 and min(ends) < max_len - 1 and len(set(ends)) > 1 and (best is None or clear > best[0]):
+                best = (clear, d, ends)
+        assert best is not None and best[0] > 5e-3, best
+        delta = best[1]
+        g["recipe"]["eos_end_steps"] = best[2]
+        g["recipe"]["eos_bias_delta"] = delta
+        sd2 = dict(sd)
+        sd2["cls.decoder.bias"] = sd["cls.decoder.bias"].clone()
+        sd2["cls.decoder.bias"][102] += delta
+        ref.load_state_dict(sd2, strict=False)
+        ref.beam_size = 1
+        ge = ref(dict(batch), task="cap%tva%tv%ta", compute_loss=False)
+        g["greedy_eos"] = {k: v.clone() for k, v in ge.items() if k.startswith("generated")}
+        orc2 = Oracle(spec, trainable_copy(sd2), vocab_tokens=synth.synthetic_vocab(spec.vocab))
+        trace = []
+        s, _ = orc2.decode_greedy(vi, ai, None, batch_size, max_len, trace)
+        assert torch.equal(s, g["greedy_eos"]["generated_sequences_t_va"])
+        top = torch.stack([t.topk(2, -1).values for t in trace])
+        g["greedy_eos_margin_t_va"] = (top[..., 0] - top[..., 1]).t().clone()
+    path = os.path.join(ROOT, "tests", "golden", name + ".pt")
+    torch.save(g, path)
+    print(name, "ret", round(g["ret_loss"], 5), "cap", round(g["cap_loss"], 5), "greedy", g["greedy"]["generated_sequences_t_va"][0, :6].tolist(),
+          "eos run", g["greedy_eos"]["generated_sequences_t_va"].tolist(), "min margins", float(g["greedy_margin_t_va"].min()),
+          float(g["beam3_gap_t_va"].min()), "->", path, os.path.getsize(path) // 1024, "KiB")
+
+
+FINETUNE_FIXTURES = {
+    "ref_base_b2f2a1_ft": dict(batch_size=2, frames=2, audio_slices=1, wseed=50, bseed=51, mseed=50),
+    "ref_swin_b2f2a1_ft": dict(batch_size=2, frames=2, audio_slices=1, wseed=50, bseed=51, mseed=50, variant="swin"),
+}
+
+
 if __name__ == "__main__":
     assert ref_harness.available()
-    for name in (sys.argv[1:] or list(FIXTURES)):
-        run(name, **FIXTURES[name])
+    for name in (sys.argv[1:] or list(FIXTURES) + list(FINETUNE_FIXTURES)):
+        if name in FINETUNE_FIXTURES:
+            run_finetune(name, **FINETUNE_FIXTURES[name])
+        else:
+            run(name, **FIXTURES[name])

@@ -637,7 +637,7 @@ class Oracle:
                 break
         return sents, logprobs
 
-    def decode_beam(self, vi, ai, prompt, bs, beam, max_len, trace=None):
+    def decode_beam(self, vi, ai, prompt, bs, beam, max_len, trace=None, gaps=None):
         """VALOR.decode_beam / select / _adjust_tensor / expand_tensor, model/pretrain.py:1054-1189. Rows are ordered (sample, beam)."""
         seq_logprob = torch.zeros(bs, 1, 1)
         seq_mask = torch.ones(bs, beam, 1)
@@ -654,6 +654,8 @@ class Oracle:
                 old = seq_logprob.expand_as(cand).contiguous()
                 cand = seq_mask * cand + old * (1 - seq_mask)
             sel_logprob, sel_idx = torch.sort(cand.view(bs, -1), -1, descending=True)            # select :1156-1159
+            if gaps is not None:                 # smallest gap among the best beam + 1 candidates: what a lower-precision run must resolve
+                gaps.append((sel_logprob[:, :beam] - sel_logprob[:, 1:beam + 1]).min(dim=1).values)
             sel_logprob, sel_idx = sel_logprob[:, :beam], sel_idx[:, :beam]
             V = cand.shape[-1]
             sel_beam = sel_idx // V

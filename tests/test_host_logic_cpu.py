@@ -121,7 +121,7 @@ def test_unsupported_configs_fail_loudly():
         VALOR({"fineweight_type": "none"}, spec=synth.tiny_spec(), dtype=torch.float32, device="cpu")
     m = VALOR(None, spec=synth.tiny_spec(), dtype=torch.float32, device="cpu")
     with pytest.raises(NotImplementedError):
-        m({}, task="ret%tv")
+        m({}, task="qa%tv")      # ret% and cap% are built (tests/test_finetune_gpu.py); qa% is not
 
 
 def test_param_tables_of_the_swin_and_large_configurations():
@@ -228,3 +228,49 @@ def test_host_stage_passthrough_on_cpu():
     st.begin_step()
     t = torch.arange(6).view(2, 3)
     assert torch.equal(st.put(t), t) and st.put(t, torch.float32).dtype == torch.float32
+
+
+def test_swin_padded_geometry_maps():
+    """VideoSwin window padding lives in index maps (valor.py _swin_geometry / _swin_pad_idx): pad -> roll -> window_partition of the
+    reference (videoswin.py:198-211) and compute_mask on the padded map (:335-338), against the oracle's helpers; PatchMerging's zero
+    padding of odd maps (:257-259) against F.pad + strided slicing."""
+    import sys, os
+    import torch.nn.functional as F
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle"))
+    from valor_oracle import Oracle
+    from valor_amd import synth
+    from valor_amd.model.valor import VALOR
+    m = VALOR({"dropout": 0.0, "drop_path_rate": 0.0}, spec=synth.tiny_swin_spec(), dtype=torch.float32, device="cpu")
+    for size, shifted in (((10, 28, 28), True), ((10, 28, 28), False), ((3, 26, 26), True), ((3, 13, 13), True), ((10, 13, 13), True),
+                          ((3, 6, 6), True), ((8, 14, 14), True)):
+        D, H, W = size
+        geo = m._swin_geometry(D, H, W, shifted)
+        win, sh = Oracle.swin_effective_window(size, m.spec.swin_window, tuple(v // 2 for v in m.spec.swin_window) if shifted else (0, 0, 0))
+        Dp, Hp, Wp = [-(-s // w) * w for s, w in zip(size, win)]
+        assert geo["padded"] == ((Dp, Hp, Wp) != size)
+        ids = torch.arange(D * H * W, dtype=torch.float32).reshape(1, D, H, W, 1) + 1            # 0 = a padding position
+        idp = F.pad(ids, (0, 0, 0, Wp - W, 0, Hp - H, 0, Dp - D))
+        if any(sh):
+            idp = torch.roll(idp, shifts=(-sh[0], -sh[1], -sh[2]), dims=(1, 2, 3))
+        want = Oracle.swin_windows(idp, win).reshape(-1).long() - 1                               # natural row, -1 = zero row
+        rowmap = geo["rowmap"].long()
+        if geo["padded"]:
+            pad, unpad = m._swin_pad_idx(geo, 2)
+            n, npad = D * H * W, Dp * Hp * Wp
+            assert torch.equal(pad[:npad][rowmap], want)
+            assert torch.equal(pad[npad:][rowmap], torch.where(want >= 0, want + n, want))        # second clip of the batch
+            assert torch.equal(pad[unpad], torch.arange(2 * n))                                   # the crop x[:, :D, :H, :W]
+        else:
+            assert torch.equal(rowmap, want)
+        if any(sh):
+            lab = geo["label"].long().view(geo["nW"], geo["N"])
+            assert torch.equal(torch.where(lab[:, None, :] != lab[:, :, None], -100.0, 0.0), Oracle.swin_shift_mask((Dp, Hp, Wp), win, sh))
+        else:
+            assert geo["label"] is None
+    for (b, D, H, W) in ((2, 3, 13, 13), (1, 2, 7, 6), (2, 2, 4, 4)):
+        x = torch.randn(b, D, H, W, 5)
+        xp = F.pad(x, (0, 0, 0, W % 2, 0, H % 2))
+        want = torch.cat([xp[:, :, 0::2, 0::2], xp[:, :, 1::2, 0::2], xp[:, :, 0::2, 1::2], xp[:, :, 1::2, 1::2]], -1)
+        idx = m._swin_merge_idx(b, D, H, W)
+        rows = torch.cat((x.reshape(-1, 5), torch.zeros(1, 5)))[idx]                              # index -1 -> the appended zero row
+        assert torch.equal(rows.reshape(want.shape), want)

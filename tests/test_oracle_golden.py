@@ -92,3 +92,36 @@ def synth_ref(rc, key):
         _SD_CACHE.clear()
         _SD_CACHE[ck] = synth.make_state_dict(synth.ValorSpec(**rc["spec"]), seed=rc["weight_seed"])
     return _SD_CACHE[ck][key]
+
+
+@pytest.mark.parametrize("name", ["ref_base_b2f2a1_ft", "ref_swin_b2f2a1_ft"])
+def test_oracle_reproduces_finetune_and_generation_goldens(name):
+    """'ret%tva%tv' / 'cap%tva%tv' losses and the generated caption ids (greedy, greedy with rows that end, beam 3) of the
+    UNMODIFIED reference (oracle/make_goldens.py run_finetune), reproduced by the restatement where /root/reference does not exist."""
+    g = torch.load(os.path.join(GOLD, name + ".pt"), weights_only=False)
+    rc = g["recipe"]
+    spec = synth.ValorSpec(**rc["spec"])
+    sd = synth.make_state_dict(spec, seed=rc["weight_seed"], bf16_exact=True)
+    batch = synth.make_batch(spec, batch=rc["batch"], frames=rc["frames"], audio_slices=rc["audio_slices"], txt_len=rc["txt_len"],
+                             seed=rc["batch_seed"], bf16_exact=True)
+    orc = VO.Oracle(spec, VO.trainable_copy(sd), vocab_tokens=synth.synthetic_vocab(spec.vocab))
+    L = rc["max_generation_len"]
+    with torch.no_grad():
+        random.seed(rc["masker_seed"])
+        ret = float(orc.forward(batch, "ret%tva%tv")["contra_loss"])
+        random.seed(rc["masker_seed"])
+        cap = float(orc.forward(batch, "cap%tva%tv")["caption_loss"])
+        assert abs(ret - g["ret_loss"]) <= 3e-5 * abs(g["ret_loss"])
+        assert abs(cap - g["cap_loss"]) <= 3e-5 * abs(g["cap_loss"])
+        vo, ao = orc.forward_video_encoder(batch["video_pixels"]), orc.forward_audio_encoder(batch["audio_spectrograms"])
+        vi, ai = orc.multimodal_inputs(vo, ao, rc["batch"])
+        assert torch.equal(orc.decode_greedy(vi, ai, None, rc["batch"], L)[0], g["greedy"]["generated_sequences_t_va"])
+        assert torch.equal(orc.decode_greedy(None, ai, None, rc["batch"], L)[0], g["greedy"]["generated_sequences_t_a"])
+        assert torch.equal(orc.decode_beam(vi, None, None, rc["batch"], rc["beam_size"], L), g["beam3"]["generated_sequences_t_v"])
+        sd2 = dict(sd)
+        sd2["cls.decoder.bias"] = sd["cls.decoder.bias"].clone()
+        sd2["cls.decoder.bias"][102] += rc["eos_bias_delta"]
+        orc2 = VO.Oracle(spec, VO.trainable_copy(sd2), vocab_tokens=synth.synthetic_vocab(spec.vocab))
+        ends = orc2.decode_greedy(vi, ai, None, rc["batch"], L)[0]
+        assert torch.equal(ends, g["greedy_eos"]["generated_sequences_t_va"])
+        assert [int((row != 102).sum()) for row in ends] == rc["eos_end_steps"]

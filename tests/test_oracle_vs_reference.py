@@ -227,11 +227,12 @@ def test_shipped_large_configuration_clip_l14_with_shared_bert():
     assert torch.allclose(r["feat_v"], o["feat_v"], atol=1e-5) and torch.allclose(r["feat_t"], o["feat_t"], atol=1e-5)
 
 
-@pytest.mark.parametrize("res,frames", [(96, 3), (160, 2)])
+@pytest.mark.parametrize("res,frames", [(96, 3), (160, 2), (112, 10), (104, 10)])
 def test_swin_padding_cases(res, frames):
     """feature maps that are not multiples of the (7, 7) window and odd PatchMerging inputs (videoswin.py:199-203, 222-223,
-    257-259): 96 px -> 24 / 12 / 6 / 3, 160 px -> 40 / 20 / 10 / 5; reference SwinTransformer3D vs the oracle, output and gradients.
-    (The native path covers the 224-px geometry only and says so; the oracle is complete.)"""
+    257-259): 96 px -> 24 / 12 / 6 / 3, 160 px -> 40 / 20 / 10 / 5, 104 px -> 26 / 13 / 7 / 4 (odd maps into PatchMerging); 10 frames pad
+    the depth 10 -> 16 against the 8-deep window, with a depth shift (the reference's finetune scripts test with 10 and 12 frames).
+    Reference SwinTransformer3D vs the oracle, output and gradients. (tests/test_swin_gpu.py runs the native encoder on the same cases.)"""
     ref_harness._install()
     import dataclasses
     from model.videoswin import SwinTransformer3D
@@ -322,3 +323,4 @@ def test_finetune_tasks_and_caption_generation(setup):
                 assert torch.equal(rb[k], ob[k]), (k, rb[k], ob[k])
         finally:
             ref.beam_size, ref.max_generation_len = old
+

@@ -220,3 +220,46 @@ def test_swin_geometry_matches_reference_partition(dev):
             assert torch.equal(mine, Oracle.swin_shift_mask(size, win, sh))
         else:
             assert geo["label"] is None
+
+
+@pytest.mark.parametrize("res,frames", [(112, 10), (104, 3), (104, 10), (96, 3)])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_swin_padding_paths_match_oracle(dev, res, frames, dtype):
+    """VideoSwin zero padding (videoswin.py:198-203,222-223 windows; :257-259 PatchMerging) on the native encoder: 10 frames pad the depth
+    10 -> 16 against the 8-deep window with a depth shift (the reference's finetune scripts test with 10 and 12 frames); 104 px pads the
+    26- and 13-wide maps to 28 / 14 and merges an odd 13 x 13 map; 96 px -> 24 / 12 / 6. Encoder output and every encoder gradient against
+    the oracle (which tests/test_oracle_vs_reference.py::test_swin_padding_cases pins on the reference for these geometries)."""
+    import dataclasses
+    import valor_oracle as VO
+    from valor_amd import synth
+    from valor_amd.model.valor import VALOR
+    spec = dataclasses.replace(synth.tiny_swin_spec(), resolution=res)
+    sd = synth.make_state_dict(spec, seed=3, w_std=0.05, bf16_exact=True)
+    g = torch.Generator().manual_seed(5)
+    for k in sd:                                   # bias tables / biases away from zero: indexing mistakes must show
+        if "relative_position_bias_table" in k or (k.startswith("video_encoder") and k.endswith(".bias")):
+            sd[k] = (torch.randn(sd[k].shape, generator=g) * 0.1).bfloat16().float()
+    model = VALOR({"dropout": 0.0, "drop_path_rate": 0.0}, spec=spec, dtype=dtype, device=dev)
+    model.load_state_dict(sd, strict=True)
+    model.train()
+    sd_o = VO.trainable_copy(sd)
+    orc = VO.Oracle(spec, sd_o)
+    vid = torch.randn(2, frames, 3, res, res, generator=g).bfloat16().float()
+    ref = orc.forward_video_encoder(vid)
+    model.stage.begin_step()
+    got = model.forward_video_encoder(vid)
+    assert got.shape == ref.shape
+    tol = 2e-5 if dtype == torch.float32 else 2e-2
+    assert _rel(got.float(), ref) < tol, _rel(got.float(), ref)
+    gout = torch.randn(ref.shape, generator=g)
+    (ref * gout).sum().backward()
+    (got.float() * gout.to(dev)).sum().backward()
+    bad = []
+    for name, shape, refs in model.table:
+        if not name.startswith("video_encoder"):
+            continue
+        go = sd_o[refs[0]].grad
+        e = _rel(model.P[name].grad.float().reshape(go.shape), go)
+        if e > (2e-4 if dtype == torch.float32 else 6e-2):
+            bad.append((name, e))
+    assert not bad, bad[:8]

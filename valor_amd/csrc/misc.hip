@@ -309,7 +309,8 @@ __global__ void gather_rows_kernel(const T* src, const int64_t* idx, T* out, int
     for (int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; q < n * E4; q += (int64_t)gridDim.x * blockDim.x) {
         const int e = (int)(q % E4) * 4;
         const int64_t i = q / E4;
-        store4<T>(out + i * E + e, load4<T>(src + idx[i] * src_ld + e));
+        const int64_t r = idx[i];                  // r < 0: a zero row (window / PatchMerging padding, videoswin.py:198-203,257-259)
+        store4<T>(out + i * E + e, r >= 0 ? load4<T>(src + r * src_ld + e) : (f32x4_t){0.f, 0.f, 0.f, 0.f});
     }
 }
 template <typename T>
@@ -318,7 +319,8 @@ __global__ void scatter_rows_kernel(const T* src, const int64_t* idx, T* dst, in
     for (int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; q < n * E4; q += (int64_t)gridDim.x * blockDim.x) {
         const int e = (int)(q % E4) * 4;
         const int64_t i = q / E4;
-        store4<T>(dst + idx[i] * dst_ld + e, load4<T>(src + i * E + e));
+        const int64_t r = idx[i];                  // r < 0: the gradient of a padding row is dropped
+        if (r >= 0) store4<T>(dst + r * dst_ld + e, load4<T>(src + i * E + e));
     }
 }
 // fp32 -> T cast / copy (master -> model params, input casts)

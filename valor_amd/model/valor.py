@@ -139,6 +139,8 @@ class VALOR(nn.Module):
         self.device = torch.device(device)
         self.use_task_prompt = bool(_opt(opts, "use_task_prompt", False))
         self.contra_loss_ratio = float(_opt(opts, "contra_loss_ratio", 1.0))
+        self.beam_size = int(_opt(opts, "beam_size", 3))                      # train_utils.py:692, :635
+        self.max_generation_len = int(_opt(opts, "max_generation_len", 30))
         self.p_drop = float(_opt(opts, "dropout", 0.1))          # bert json / base_cfg 0.1, train_utils.py:617
         new_names = tuple(_opt(opts, "new_params_name", ()) or ())
         self.table = param_table(self.spec)
@@ -351,10 +353,12 @@ class VALOR(nn.Module):
         if geo is not None:
             return geo
         full = self.spec.swin_window
-        win = tuple(s if s <= w else w for s, w in zip((D, H, W), full))                  # get_window_size :86-99
+        win = tuple(s if s <= w else w for s, w in zip((D, H, W), full))                  # get_window_size :86-99, on the UNPADDED map
         sh = tuple(0 if (s <= w or not shifted) else w // 2 for s, w in zip((D, H, W), full))
-        if D % win[0] or H % win[1] or W % win[2]:
-            raise NotImplementedError(f"VideoSwin window padding (feature map {D}x{H}x{W}, window {win}): 224-px inputs never pad")
+        # zero padding up to whole windows (videoswin.py:198-203; e.g. 10 or 12 test frames against the 8-deep window): roll, partition and
+        # the shift mask (BasicLayer.forward :335-338) all live on the padded map
+        D0, H0, W0 = D, H, W
+        D, H, W = (-(-s // w) * w for s, w in zip((D, H, W), win))
         wd, wh, ww = win
         part = lambda a: a.reshape(D // wd, wd, H // wh, wh, W // ww, ww).transpose(0, 2, 4, 1, 3, 5).reshape(-1)
         idx = np.arange(D * H * W).reshape(D, H, W)
@@ -379,18 +383,38 @@ class VALOR(nn.Module):
         geo = dict(rowmap=torch.from_numpy(part(idx).astype(np.int32)).to(self.device), label=label,
                    rel=torch.from_numpy(lin[:N].astype(np.int32)).to(self.device), relc=int(lin[-1]),
                    rel_inv=torch.from_numpy(inv).to(self.device),
-                   nW=(D // wd) * (H // wh) * (W // ww), N=N, rows=D * H * W)
+                   nW=(D // wd) * (H // wh) * (W // ww), N=N, rows=D * H * W, padded=(D, H, W) != (D0, H0, W0))
+        if geo["padded"]:               # natural row of every padded position (-1: a zero row) and back, per sample
+            nat = -np.ones((D, H, W), dtype=np.int64)
+            nat[:D0, :H0, :W0] = np.arange(D0 * H0 * W0).reshape(D0, H0, W0)
+            geo["pad_src"] = nat.reshape(-1)
+            geo["unpad_src"] = np.arange(D * H * W).reshape(D, H, W)[:D0, :H0, :W0].reshape(-1)
+            geo["rows0"] = D0 * H0 * W0
         self._const[key] = geo
         return geo
 
+    def _swin_pad_idx(self, geo, b):
+        """(pad, unpad) gather indices of a padded block geometry for a batch of b clips: natural rows -> padded map (zero rows at -1),
+        padded attention output -> natural rows (the crop x[:, :D, :H, :W], videoswin.py:222-223)"""
+        key = ("swinpad", id(geo), b)
+        t = self._const.get(key)
+        if t is None:
+            ps, us, r0, rp = geo["pad_src"], geo["unpad_src"], geo["rows0"], geo["rows"]
+            pad = np.concatenate([np.where(ps >= 0, ps + i * r0, -1) for i in range(b)])
+            unpad = np.concatenate([us + i * rp for i in range(b)])
+            t = (torch.from_numpy(pad).to(self.device), torch.from_numpy(unpad).to(self.device))
+            self._const[key] = t
+        return t
+
     def _swin_merge_idx(self, b, D, H, W):
-        """PatchMerging's 2x2 neighbour gather (videoswin.py:262-266) as source rows of the [.., 4C] output viewed as 4 C-rows"""
+        """PatchMerging's 2x2 neighbour gather (videoswin.py:262-266) as source rows of the [.., 4C] output viewed as 4 C-rows;
+        odd H / W are zero padded first (:257-259): index -1 = a zero row"""
         key = ("merge", b, D, H, W)
         t = self._const.get(key)
         if t is None:
-            if H % 2 or W % 2:
-                raise NotImplementedError("odd-size PatchMerging padding: 224-px inputs never pad")
-            g = np.arange(b * D * H * W).reshape(b, D, H, W)
+            Hp, Wp = H + H % 2, W + W % 2
+            g = -np.ones((b, D, Hp, Wp), dtype=np.int64)
+            g[:, :, :H, :W] = np.arange(b * D * H * W).reshape(b, D, H, W)
             q = np.stack([g[:, :, 0::2, 0::2], g[:, :, 1::2, 0::2], g[:, :, 0::2, 1::2], g[:, :, 1::2, 1::2]], axis=-1)
             t = torch.from_numpy(q.reshape(-1).astype(np.int64)).to(self.device)
             self._const[key] = t
@@ -425,8 +449,14 @@ class VALOR(nn.Module):
                     y = ops.layer_norm(x, P[p + "norm1.weight"], P[p + "norm1.bias"], 1e-5)
                 s1 = scales[k, 0] if (scales is not None and k > 0) else None
                 s2 = scales[k, 1] if (scales is not None and k > 0) else None
-                qkv = ops.linear(y, P[p + "attn.qkv.weight"], P[p + "attn.qkv.bias"])
-                a = ops.window_attention(qkv, P[p + "attn.relative_position_bias_table"], self._swin_geometry(D, H, W, bi % 2 == 1), heads, b)
+                geo = self._swin_geometry(D, H, W, bi % 2 == 1)
+                if geo["padded"]:       # zero rows AFTER norm1 (videoswin.py:196-202): their q / k / v are the bias, they are attended to unmasked
+                    pad, unpad = self._swin_pad_idx(geo, b)
+                    qkv = ops.linear(ops.gather_rows(y, pad), P[p + "attn.qkv.weight"], P[p + "attn.qkv.bias"])
+                    a = ops.gather_rows(ops.window_attention(qkv, P[p + "attn.relative_position_bias_table"], geo, heads, b), unpad)
+                else:
+                    qkv = ops.linear(y, P[p + "attn.qkv.weight"], P[p + "attn.qkv.bias"])
+                    a = ops.window_attention(qkv, P[p + "attn.relative_position_bias_table"], geo, heads, b)
                 o = ops.linear(a, P[p + "attn.proj.weight"], None)
                 x, y2 = ops.bias_dropout_residual_ln(o, P[p + "attn.proj.bias"], x, P[p + "norm2.weight"], P[p + "norm2.bias"], 1e-5, 0.0, True, s1, rows)
                 m = ops.mlp(y2, P[p + "mlp.fc1.weight"], P[p + "mlp.fc1.bias"], P[p + "mlp.fc2.weight"], None, ACT_GELU_ERF)
@@ -443,7 +473,7 @@ class VALOR(nn.Module):
                 xm = ops.gather_rows(x, self._swin_merge_idx(b, D, H, W)).view(-1, 4 * C)
                 xm = ops.layer_norm(xm, P[d + "norm.weight"], P[d + "norm.bias"], 1e-5)
                 x = ops.linear(xm, P[d + "reduction.weight"], None)
-                C, H, W = 2 * C, H // 2, W // 2
+                C, H, W = 2 * C, (H + 1) // 2, (W + 1) // 2
         return y.view(b, D, H * W, C)
 
     def forward_txt_encoder_bert(self, bert_tokens_cpu):
@@ -541,6 +571,37 @@ class VALOR(nn.Module):
         self._kv_slots = [ops.GradSlot() for _ in range(self.spec.layers)]
         return [ops.linear(va_input, P[f"multimodal_encoder.encoder.layer.{i}.cross_attn.cross.kv.weight"],
                            P[f"multimodal_encoder.encoder.layer.{i}.cross_attn.cross.kv.bias"], grad_slot=va_slot) for i in range(self.spec.layers)]
+
+    def cross_inputs(self, video_output, audio_output):
+        """get_multimodal_forward_input_video / _audio (modeling.py:485-502) + the K|V projections of every decoder layer.
+        Returns (kv_layers, {group: (first key row, rows)})."""
+        P, sp = self.P, self.spec
+        kv_layers, ranges = None, {}
+        if video_output is not None or audio_output is not None:
+            Sv = video_output.shape[1] * video_output.shape[2] if video_output is not None else 0
+            Sa = audio_output.shape[1] * audio_output.shape[2] if audio_output is not None else 0
+            if video_output is not None and "hidden_trans_video_multimodal.0.weight" in P:       # modeling.py:348-349,487-488
+                hv = ops.linear(video_output.reshape(-1, sp.video_dim), P["hidden_trans_video_multimodal.0.weight"],
+                                P["hidden_trans_video_multimodal.0.bias"])
+                hv = ops.layer_norm(hv, P["hidden_trans_video_multimodal.1.weight"], P["hidden_trans_video_multimodal.1.bias"], 1e-12)
+                video_output = hv.view(*video_output.shape[:3], sp.hidden)
+            if audio_output is not None and "hidden_trans_audio_multimodal.0.weight" in P:       # modeling.py:350-351,497-498
+                ha = ops.linear(audio_output.reshape(-1, sp.aud_width), P["hidden_trans_audio_multimodal.0.weight"],
+                                P["hidden_trans_audio_multimodal.0.bias"])
+                ha = ops.layer_norm(ha, P["hidden_trans_audio_multimodal.1.weight"], P["hidden_trans_audio_multimodal.1.bias"], 1e-12)
+                audio_output = ha.view(*audio_output.shape[:3], sp.hidden)
+            if video_output is not None and audio_output is not None:
+                va = ops.cross_input(video_output, audio_output, P["video_frame_embedding"], P["video_type_embeddings"],
+                                     P["audio_frame_embedding"], P["audio_type_embeddings"])
+                ranges = {"tva": (0, Sv + Sa), "tv": (0, Sv), "ta": (Sv, Sa)}
+            elif video_output is not None:                        # a task string without audio groups: video rows only
+                va = ops.single_input(video_output, P["video_frame_embedding"], P["video_type_embeddings"])
+                ranges = {"tv": (0, Sv)}
+            else:
+                va = ops.single_input(audio_output, P["audio_frame_embedding"], P["audio_type_embeddings"])
+                ranges = {"ta": (0, Sa)}
+            kv_layers = self.project_cross_kv(va)
+        return kv_layers, ranges
 
     def bert_encoder(self, x, mask, kv_layers, kv_range, kv_bmod):
         """BertEncoder / BertLayer.forward bert.py:440-518 (post-LN; va_concate cross-attention)."""
@@ -673,14 +734,34 @@ class VALOR(nn.Module):
 
     # ------------------------------------------------------------------ the hot path
     def forward(self, batch, task, compute_loss=True):
+        """VALOR.forward, model/pretrain.py:125-135"""
         if task.startswith("pt"):
             return self.forward_pt(batch, task, compute_loss=compute_loss)
-        raise NotImplementedError("only the pretraining path ('pt_*' tasks) is in scope (SURVEY.md section 8)")
+        if task.startswith("ret"):
+            return self.forward_ret(batch, task, compute_loss=compute_loss)
+        if task.startswith("cap"):
+            return self.forward_cap(batch, task, compute_loss=compute_loss)
+        raise NotImplementedError("'pt_*', 'ret%*' and 'cap%*' tasks are built; 'qa%*' (model/pretrain.py:1191-1459) is not (DESIGN.md section 7)")
+
+    def forward_ret(self, batch, task, compute_loss=True):
+        """VALOR.forward_ret, model/pretrain.py:544-711 (config/fast-retrieval-*.json: 'ret%tva%tv'): the contrastive branch of forward_pt
+        (:252-407 -- the same encoders, pooling, heads, gathers, fine matrices and InfoNCE, line for line) on the groups after 'ret%';
+        the mean of the group losses is NOT scaled by contra_loss_ratio (:706 vs :406). compute_loss=False returns
+        feat_t / feat_v / feat_a / txt_tokens (:708-715), what evaluate.compute_fine_matrix consumes."""
+        return self._forward_groups(batch, [], [], task.split("%")[1:], compute_loss, contra_ratio=1.0)
+
+    def forward_cap(self, batch, task, compute_loss=True):
+        """VALOR.forward_cap, model/pretrain.py:713-725 (config/caption-*.json: 'cap%tva%tv'; caption_type 'unimlm', no label smoothing /
+        scst / full_masker -- the shipped settings). Loss: forward_cap_single :802-880 = the caption passes of forward_pt. Otherwise
+        generate_cap :914-985 -> valor_amd.decode (greedy for beam_size 1, beam search above)."""
+        groups = task.split("%")[1:]
+        if compute_loss:
+            return self._forward_groups(batch, [], groups, [], True)
+        from .. import decode
+        return decode.generate_cap(self, batch, groups)
 
     def forward_pt(self, batch, task, compute_loss=True):
         """VALOR.forward_pt, model/pretrain.py:214-541."""
-        P, sp = self.P, self.spec
-        self.stage.begin_step()
         mlm_task, caption_task, contra_task = [], [], []
         for i in task.split("_"):
             if "mlm" in i:
@@ -689,6 +770,12 @@ class VALOR(nn.Module):
                 caption_task = i.split("%")[1:]
             elif "contra" in i:
                 contra_task = i.split("%")[1:]
+        return self._forward_groups(batch, mlm_task, caption_task, contra_task, compute_loss, contra_ratio=self.contra_loss_ratio)
+
+    def _forward_groups(self, batch, mlm_task, caption_task, contra_task, compute_loss, contra_ratio=1.0):
+        """The body of VALOR.forward_pt (model/pretrain.py:226-541) on parsed group lists; forward_ret / forward_cap run it with one branch."""
+        P, sp = self.P, self.spec
+        self.stage.begin_step()
         out = {}
         col = self.collect
         txt_tokens = batch.get("txt_tokens")
@@ -772,7 +859,7 @@ class VALOR(nn.Module):
                 for g in contra_task:
                     if g not in ("tva", "tv", "ta"):
                         raise NotImplementedError(f"contrastive group {g}")
-                out["contra_loss"] = sum(losses) / len(losses) * self.contra_loss_ratio
+                out["contra_loss"] = sum(losses) / len(losses) * contra_ratio
             else:
                 out.update(feat_t=feat_t, feat_v=feat_v, feat_a=feat_a, txt_tokens=tok_contra)
 
@@ -781,31 +868,7 @@ class VALOR(nn.Module):
             return out
         txt = txt_tokens["bert_tokens"].cpu()
         bs = txt.shape[0]
-        kv_layers, ranges = None, {}
-        if video_output is not None or audio_output is not None:
-            Sv = video_output.shape[1] * video_output.shape[2] if video_output is not None else 0
-            Sa = audio_output.shape[1] * audio_output.shape[2] if audio_output is not None else 0
-            if video_output is not None and "hidden_trans_video_multimodal.0.weight" in P:       # modeling.py:348-349,487-488
-                hv = ops.linear(video_output.reshape(-1, sp.video_dim), P["hidden_trans_video_multimodal.0.weight"],
-                                P["hidden_trans_video_multimodal.0.bias"])
-                hv = ops.layer_norm(hv, P["hidden_trans_video_multimodal.1.weight"], P["hidden_trans_video_multimodal.1.bias"], 1e-12)
-                video_output = hv.view(*video_output.shape[:3], sp.hidden)
-            if audio_output is not None and "hidden_trans_audio_multimodal.0.weight" in P:       # modeling.py:350-351,497-498
-                ha = ops.linear(audio_output.reshape(-1, sp.aud_width), P["hidden_trans_audio_multimodal.0.weight"],
-                                P["hidden_trans_audio_multimodal.0.bias"])
-                ha = ops.layer_norm(ha, P["hidden_trans_audio_multimodal.1.weight"], P["hidden_trans_audio_multimodal.1.bias"], 1e-12)
-                audio_output = ha.view(*audio_output.shape[:3], sp.hidden)
-            if video_output is not None and audio_output is not None:
-                va = ops.cross_input(video_output, audio_output, P["video_frame_embedding"], P["video_type_embeddings"],
-                                     P["audio_frame_embedding"], P["audio_type_embeddings"])
-                ranges = {"tva": (0, Sv + Sa), "tv": (0, Sv), "ta": (Sv, Sa)}
-            elif video_output is not None:                        # a task string without audio groups: video rows only
-                va = ops.single_input(video_output, P["video_frame_embedding"], P["video_type_embeddings"])
-                ranges = {"tv": (0, Sv)}
-            else:
-                va = ops.single_input(audio_output, P["audio_frame_embedding"], P["audio_type_embeddings"])
-                ranges = {"ta": (0, Sa)}
-            kv_layers = self.project_cross_kv(va)
+        kv_layers, ranges = self.cross_inputs(video_output, audio_output)
 
         if compute_loss:
             # training: every decoder pass row-batched into one stack (caption groups first: the biggest segment)
