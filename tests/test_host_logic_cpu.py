@@ -174,8 +174,7 @@ def test_swin_variant_host_side():
         full = synth.swin_relative_position_index(spec.swin_window)[:geo["N"], :geo["N"]]
         rel = geo["rel"].long()
         assert torch.equal(rel[:, None] - rel[None, :] + geo["relc"], full)
-    with pytest.raises(NotImplementedError):
-        m._swin_geometry(8, 16, 16, False)                     # would need window padding
+    assert m._swin_geometry(8, 16, 16, False)["padded"]        # 16 -> 21: zero padding, test_swin_padded_geometry_maps
     x = torch.arange(2 * 2 * 4 * 4).float().view(2, 2, 4, 4, 1)
     ref = torch.cat([x[:, :, 0::2, 0::2], x[:, :, 1::2, 0::2], x[:, :, 0::2, 1::2], x[:, :, 1::2, 1::2]], -1).reshape(-1)
     assert torch.equal(ref.long(), m._swin_merge_idx(2, 2, 4, 4))
