@@ -72,47 +72,31 @@ def test_tiny_fp32_finetune_tasks_and_generation_match_oracle(dev, variant, prom
     assert float(ng["logprobs_t_va"].abs().max()) == 0.0          # pretrain.py:992,1013: only 'sample' mode fills them
 
 
-def _agree_until_margin(ref_seq, got_seq, margin, tol):
-    """rows must agree up to (excluding) the first step whose reference margin is below tol"""
-    n_checked = 0
-    for r in range(ref_seq.shape[0]):
-        small = (margin[r] < tol).nonzero()
-        upto = int(small[0]) if small.numel() else ref_seq.shape[1]
-        upto = min(upto, margin.shape[1])
-        assert torch.equal(ref_seq[r, :upto], got_seq[r, :upto]), (r, upto, ref_seq[r], got_seq[r])
-        n_checked += upto
-    return n_checked
-
-
 @pytest.mark.parametrize("name", ["ref_base_b2f2a1_ft", "ref_swin_b2f2a1_ft"])
-@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
-def test_base_widths_match_reference_goldens(dev, name, dtype):
+def test_base_widths_fp32_match_reference_goldens(dev, name):
     from test_model_gpu import _recipe_tensors
     g = torch.load(os.path.join(GOLD, name + ".pt"), weights_only=False)
     rc = g["recipe"]
     spec, sd, batch = _recipe_tensors(rc)
-    fp32 = dtype == torch.float32
-    model = _build(spec, sd, dtype, dev, beam_size=3, max_generation_len=rc["max_generation_len"])
+    model = _build(spec, sd, torch.float32, dev, beam_size=3, max_generation_len=rc["max_generation_len"])
     with torch.no_grad():
         random.seed(rc["masker_seed"])
         ret = float(model(batch, task="ret%tva%tv", compute_loss=True)["contra_loss"])
         random.seed(rc["masker_seed"])
         cap = float(model(batch, task="cap%tva%tv", compute_loss=True)["caption_loss"])
-    assert abs(ret - g["ret_loss"]) <= (1e-4 if fp32 else 5e-3) * abs(g["ret_loss"]), (ret, g["ret_loss"])
-    assert abs(cap - g["cap_loss"]) <= (1e-4 if fp32 else 1e-3) * abs(g["cap_loss"]), (cap, g["cap_loss"])
-    tol = 1e-4 if fp32 else 0.05            # logit error of the run: fp32 ~1e-5; bf16 ~2e-2 (tests/test_model_gpu.py BF16_TIE_BAND)
+    assert abs(ret - g["ret_loss"]) <= 1e-4 * abs(g["ret_loss"]), (ret, g["ret_loss"])
+    assert abs(cap - g["cap_loss"]) <= 1e-4 * abs(g["cap_loss"]), (cap, g["cap_loss"])
+    ev = model(batch, task="ret%tva%tv", compute_loss=False)
+    for k in ("feat_t", "feat_v", "feat_a"):
+        assert torch.allclose(ev[k].float().cpu(), g["ret_feats"][k], atol=2e-5), k
     model.beam_size = 1
     gr = model(batch, task="cap%tva%tv%ta", compute_loss=False)
     model.beam_size = 3
     bm = model(batch, task="cap%tva%tv", compute_loss=False)
-    steps = _agree_until_margin(g["greedy"]["generated_sequences_t_va"], gr["generated_sequences_t_va"].cpu(), g["greedy_margin_t_va"], tol)
-    steps += _agree_until_margin(g["beam3"]["generated_sequences_t_va"], bm["generated_sequences_t_va"].cpu(), g["beam3_gap_t_va"], tol)
-    assert steps > 0
-    if fp32:
-        for k in g["greedy"]:
-            assert torch.equal(g["greedy"][k], gr[k].cpu()), k
-        for k in g["beam3"]:
-            assert torch.equal(g["beam3"][k], bm[k].cpu()), k
+    for k in g["greedy"]:
+        assert torch.equal(g["greedy"][k], gr[k].cpu()), k
+    for k in g["beam3"]:
+        assert torch.equal(g["beam3"][k], bm[k].cpu()), k
     # rows that END: [SEP] bias raised by the recipe's delta, greedy only (finished beams tie in the reference's beam search)
     sd2 = dict(sd)
     sd2["cls.decoder.bias"] = sd["cls.decoder.bias"].clone()
@@ -122,7 +106,52 @@ def test_base_widths_match_reference_goldens(dev, name, dtype):
     ge = model(batch, task="cap%tva%tv%ta", compute_loss=False)
     ref = g["greedy_eos"]["generated_sequences_t_va"]
     assert (ref == 102).any() and not (ref == 102).all()
-    _agree_until_margin(ref, ge["generated_sequences_t_va"].cpu(), g["greedy_eos_margin_t_va"], tol)
-    if fp32:
-        for k in g["greedy_eos"]:
-            assert torch.equal(g["greedy_eos"][k], ge[k].cpu()), k
+    for k in g["greedy_eos"]:
+        assert torch.equal(g["greedy_eos"][k], ge[k].cpu()), k
+
+
+BF16_LOGIT_BAND = 0.06      # measured bf16 logit error of the [MASK] position at base widths: 0.041 (clip) / 0.042 (swin), session K
+
+
+@pytest.mark.parametrize("name", ["ref_base_b2f2a1_ft", "ref_swin_b2f2a1_ft"])
+def test_base_widths_bf16_generation_is_within_the_logit_error(dev, name):
+    """bf16 (the benchmarked arithmetic) on the same bf16-representable tensors. Losses: the north-star 1e-3 (5e-3 for the B = 2 InfoNCE,
+    DESIGN.md section 4). Generation: an untrained model's 30522 logits are nearly tied (reference top-2 margins 0.002 .. 0.3), so token
+    equality is not a bf16 property; what is: teacher-forced on the REFERENCE's sequence, the bf16 logits stay within BF16_LOGIT_BAND of the
+    fp32 native logits at every step, hence the reference's token is never further than 2 bands below the bf16 maximum, and wherever the
+    reference margin exceeds 2 bands the bf16 argmax IS the reference's token."""
+    from test_model_gpu import _recipe_tensors
+    from valor_amd import decode
+    g = torch.load(os.path.join(GOLD, name + ".pt"), weights_only=False)
+    rc = g["recipe"]
+    spec, sd, batch = _recipe_tensors(rc)
+    m16 = _build(spec, sd, torch.bfloat16, dev)
+    with torch.no_grad():
+        random.seed(rc["masker_seed"])
+        ret = float(m16(batch, task="ret%tva%tv", compute_loss=True)["contra_loss"])
+        random.seed(rc["masker_seed"])
+        cap = float(m16(batch, task="cap%tva%tv", compute_loss=True)["caption_loss"])
+    assert abs(ret - g["ret_loss"]) <= 5e-3 * abs(g["ret_loss"]), (ret, g["ret_loss"])
+    assert abs(cap - g["cap_loss"]) <= 1e-3 * abs(g["cap_loss"]), (cap, g["cap_loss"])
+    m32 = _build(spec, sd, torch.float32, dev)
+    ref_seq, margin = g["greedy"]["generated_sequences_t_va"], g["greedy_margin_t_va"]
+    worst, agree, decided = 0.0, 0, 0
+    with torch.no_grad():
+        m16.eval(); m32.eval()
+        steps = {}
+        for m in (m16, m32):
+            b, kv, ranges = decode.encode_for_generation(m, batch, ["tva"])
+            steps[m] = decode.stepper(m, "tva", b, kv, ranges)
+        for t in range(ref_seq.shape[1]):
+            prefix = ref_seq[:, :t] if t else None
+            l16, l32 = steps[m16].logits(prefix, b).cpu(), steps[m32].logits(prefix, b).cpu()
+            assert torch.equal(l32.argmax(-1), ref_seq[:, t])                       # fp32 native == reference (teacher-forced)
+            worst = max(worst, float((l16 - l32).abs().max()))
+            top16 = l16.max(-1).values
+            assert bool((l16.gather(1, ref_seq[:, t:t + 1]).squeeze(1) >= top16 - 2 * BF16_LOGIT_BAND).all())
+            big = margin[:, t] > 2 * BF16_LOGIT_BAND
+            decided += int(big.sum())
+            agree += int((l16.argmax(-1) == ref_seq[:, t])[big].sum())
+    assert worst < BF16_LOGIT_BAND, f"bf16 logit error {worst:.4f}"
+    assert agree == decided
+    print(f"{name}: bf16 max logit error {worst:.4f} over {ref_seq.numel()} teacher-forced steps; {decided} steps had a reference margin > {2 * BF16_LOGIT_BAND}")

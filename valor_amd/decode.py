@@ -129,6 +129,23 @@ def decode_beam(step, b, beam, max_len):
     return outputs.contiguous()[:, 0]
 
 
+def encode_for_generation(model, batch, groups):
+    """The encoder half of generate_cap (pretrain.py:916-936): -> (batch size, per-layer K|V of the video/audio tokens, group key ranges)"""
+    model.stage.begin_step()
+    alltasks = "".join(groups)
+    video_output = model.forward_video_encoder(batch["video_pixels"]) if "v" in alltasks else None
+    audio_output = model.forward_audio_encoder(batch["audio_spectrograms"]) if "a" in alltasks else None
+    b = (video_output if video_output is not None else audio_output).shape[0]
+    kv_layers, ranges = model.cross_inputs(video_output, audio_output)
+    return b, kv_layers, ranges
+
+
+def stepper(model, group, b, kv_layers, ranges):
+    """the per-step logits function of one query group ('tv' | 'tva' | 'ta'): stepper(...).logits(tokens so far or None, rows)"""
+    prompt = model.get_task_prompt(PROMPTS["caption"], b) if model.use_task_prompt else None
+    return _Stepper(model, group, kv_layers, ranges, prompt, b)
+
+
 @torch.no_grad()
 def generate_cap(model, batch, groups, beam_size=None, max_generation_len=None):
     """VALOR.generate_cap, model/pretrain.py:914-985 -> {'generated_sequences_t_v' | '_t_va' | '_t_a' (+ 'logprobs_*' when greedy)}."""
@@ -137,18 +154,12 @@ def generate_cap(model, batch, groups, beam_size=None, max_generation_len=None):
     was_training = model.training
     model.eval()
     try:
-        model.stage.begin_step()
-        alltasks = "".join(groups)
-        video_output = model.forward_video_encoder(batch["video_pixels"]) if "v" in alltasks else None
-        audio_output = model.forward_audio_encoder(batch["audio_spectrograms"]) if "a" in alltasks else None
-        b = (video_output if video_output is not None else audio_output).shape[0]
-        kv_layers, ranges = model.cross_inputs(video_output, audio_output)
+        b, kv_layers, ranges = encode_for_generation(model, batch, groups)
         out = {}
         for g, key in (("tv", "t_v"), ("tva", "t_va"), ("ta", "t_a")):
             if g not in groups:
                 continue
-            prompt = model.get_task_prompt(PROMPTS["caption"], b) if model.use_task_prompt else None
-            step = _Stepper(model, g, kv_layers, ranges, prompt, b)
+            step = stepper(model, g, b, kv_layers, ranges)
             if beam > 1:
                 out["generated_sequences_" + key] = decode_beam(step, b, beam, max_len)
             else:
