@@ -135,7 +135,7 @@ class GemmTimer:
             M, Kd = (a.shape[1], a.shape[0]) if trans_a else (a.shape[0], a.shape[1])
             N = b.shape[1] if trans_b else b.shape[0]
             fam = so.valor_gemm_kernel_for(0 if a.dtype == torch.bfloat16 else 1, int(trans_a), int(trans_b), M, N, Kd,
-                                           int(kw.get("dact_aux") is not None))
+                                           int(kw.get("dact_aux") is not None and not (kw.get("act", 0) & 16)))   # ACT_DERIV aux: a light epilogue
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
             r = orig(a, b, trans_a=trans_a, trans_b=trans_b, **kw)

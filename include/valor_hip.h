@@ -39,6 +39,10 @@ extern "C" {
 #define VALOR_ACT_QUICK_GELU 2 /* clip.py:167-169 */
 #define VALOR_ACT_RELU 3       /* pretrain.py:104-112 */
 #define VALOR_ACT_TANH 4
+/* OR-ed onto an activation id: `preact` of the forward GEMM receives act'(x) instead of x, and `dact_aux` of the matching dgrad
+ * holds that derivative (the epilogue multiplies by it: no sigmoid / erf / exp in the backward). The autograd contract of
+ * nn.Linear + activation is unchanged; only what is kept between forward and backward differs. */
+#define VALOR_ACT_DERIV 16
 
 /* ---- GEMM: C[M,N] = epi(alpha * op(A)[M,K] . op(B)[N,K]^T).  Replaces every nn.Linear / matmul projection and its
  * autograd GEMMs: bert.py:233-235,245-247,303-305,352,366,404,417; clip.py:176-182,237,329; transformer.py:109-142;
@@ -62,7 +66,7 @@ int valor_gemm_set_variant(int v);
 /* kernel family valor_gemm picks for a problem under the current variant: 0 = register-staged 128x128 (and every fp32
  * problem), 1 / 2 = LDS-DMA 128x128 single / double stage, 3 = 256x256 8-phase */
 int valor_gemm_kernel_for(int dtype, int transA, int transB, int M, int N, int K, int heavy_epilogue);
-/* heavy_epilogue: the call passes dact_aux (the epilogue reads a second [M, N] operand); such dgrads stay on the 128x128 kernel below
+/* heavy_epilogue: the call passes dact_aux WITHOUT VALOR_ACT_DERIV (the epilogue evaluates act' of a second [M, N] operand); such dgrads stay on the 128x128 kernel below
  * K = 1536, where four workgroups per CU overlap each other's epilogues (profiles/r02_gemm_epilogue_ab.json) */
 /* k-slow 8-phase kernels: transposing LDS reads as inline asm (keeps the counted LDS-DMA pipeline from being drained by
  * compiler-inserted waits); returns the previous value, v < 0 only queries */

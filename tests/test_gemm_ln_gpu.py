@@ -79,6 +79,16 @@ def test_gemm_epilogues(dev, dtype, act):
     ud = pre.double().requires_grad_(True)
     f(ud).backward((dY.double() @ W2.double()))
     assert _rel(G, ud.grad) < (5e-6 if dtype == torch.float32 else 1e-2)
+    # derivative-saving pair (lib.ACT_DERIV, what ops.MlpFn runs): `preact` receives act'(u), the dgrad multiplies by it
+    from valor_amd import lib
+    out_d, gprime = K.gemm(A, W, bias=b, act=act | lib.ACT_DERIV, want_preact=True, splitk=False)
+    ud2 = u.clone().requires_grad_(True)
+    (gp_ref,) = torch.autograd.grad(f(ud2).sum(), ud2)
+    assert _rel(out_d, f(u)) < tol
+    assert _rel(gprime, gp_ref) < (5e-6 if dtype == torch.float32 else 8e-3)
+    G2 = K.gemm(dY, W2, trans_b=True, act=act | lib.ACT_DERIV, dact_aux=gprime, splitk=False)
+    assert _rel(G2, (dY.double() @ W2.double()) * gprime.double()) < (5e-6 if dtype == torch.float32 else 8e-3)
+    assert _rel(G2, (dY.double() @ W2.double()) * gp_ref) < (5e-6 if dtype == torch.float32 else 1.2e-2)
     # accumulate + alpha + fp32 output
     Cacc = torch.ones((M, N), dtype=torch.float32, device=dev)
     K.gemm(A, W, alpha=0.5, out=Cacc, accumulate=True, out_dtype=torch.float32, splitk=False)

@@ -144,6 +144,13 @@ def test_gemm_8phase_fast_epilogue(dev, gemm_variant):
                 du = K.gemm(X, W, trans_b=tb, act=lib.ACT_GELU_ERF, dact_aux=U, splitk=False)
                 Cacc = torch.ones((M, N), dtype=torch.bfloat16, device=dev)
                 K.gemm(X, W, trans_b=tb, out=Cacc, accumulate=True, splitk=False)
+                # derivative-saving pair (ACT_DERIV): act'(z) in the `preact` slot (always the general epilogue), a plain multiply in the dgrad
+                # (the tile path in modes 1 and 2)
+                out_d, gp = K.gemm(X, W, trans_b=tb, bias=b, act=lib.ACT_QUICK_GELU | lib.ACT_DERIV, want_preact=True, splitk=False)
+                sg = torch.sigmoid(1.702 * z)
+                assert _rel(out_d, z * sg) < 6e-3 and _rel(gp, sg + 1.702 * z * sg * (1 - sg)) < 6e-3
+                du_d = K.gemm(X, W, trans_b=tb, act=lib.ACT_GELU_ERF | lib.ACT_DERIV, dact_aux=U, splitk=False)
+                assert _rel(du_d, (z - b.double()) * U.double()) < 8e-3
                 res[mode] = (y, out, pre, du, Cacc)
                 assert _rel(y, F.gelu(z)) < 6e-3
                 assert _rel(pre, z) < 6e-3 and _rel(out, z * torch.sigmoid(1.702 * z)) < 6e-3

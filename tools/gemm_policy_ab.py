@@ -23,7 +23,7 @@ CONFIGS = {
 
 b = 64
 T = b * 8 * 197
-SHAPES = [  # name, M, N, K, ta, tb, epilogue ("" plain | "bias" | "gelu": bias + QuickGELU + pre-activation copy | "dact": * act'(aux))
+SHAPES = [  # name, M, N, K, ta, tb, epilogue ("" plain | "bias" | "gelu": bias + QuickGELU + pre-activation copy | "dact": * act'(aux) | "*_deriv": the ACT_DERIV pair)
     ("vit_qkv_fwd", T, 2304, 768, 0, 0, "bias"),
     ("vit_fc1_fwd", T, 3072, 768, 0, 0, "gelu"),
     ("vit_fc1_fwd_plain", T, 3072, 768, 0, 0, ""),
@@ -31,11 +31,15 @@ SHAPES = [  # name, M, N, K, ta, tb, epilogue ("" plain | "bias" | "gelu": bias 
     ("vit_fc2_fwd", T, 768, 3072, 0, 0, ""),
     ("vit_fc2_dgrad", T, 3072, 768, 0, 1, ""),
     ("vit_fc2_dgrad_dact", T, 3072, 768, 0, 1, "dact"),
+    ("vit_fc1_fwd_deriv", T, 3072, 768, 0, 0, "gelu_deriv"),
+    ("vit_fc2_dgrad_dderiv", T, 3072, 768, 0, 1, "dact_deriv"),
     ("vit_proj_dgrad", T, 768, 768, 0, 1, ""),
     ("vit_qkv_dgrad", T, 768, 2304, 0, 1, ""),
     ("vit_fc1_dgrad", T, 768, 3072, 0, 1, ""),
     ("ast_fc1_fwd", b * 2 * 129, 3072, 768, 0, 0, "gelu"),
     ("ast_fc2_dgrad", b * 2 * 129, 3072, 768, 0, 1, "dact"),
+    ("ast_fc1_fwd_deriv", b * 2 * 129, 3072, 768, 0, 0, "gelu_deriv"),
+    ("ast_fc2_dgrad_dderiv", b * 2 * 129, 3072, 768, 0, 1, "dact_deriv"),
     ("ast_proj_fwd", b * 2 * 129, 768, 768, 0, 0, ""),
     ("xkv_fwd", b * 1834, 1536, 768, 0, 0, "bias"),
     ("xkv_dgrad", b * 1834, 768, 1536, 0, 1, ""),
@@ -57,11 +61,12 @@ def apply(cfg):
 
 
 def run(A, B, ta, tb, epi, bias, out, pre):
-    if epi == "gelu":
+    if epi in ("gelu", "gelu_deriv"):
+        act = lib.ACT_QUICK_GELU | (lib.ACT_DERIV if epi == "gelu_deriv" else 0)
         lib.call("valor_gemm", K._stream(), 0, ta, tb, out.shape[0], out.shape[1], A.shape[0] if ta else A.shape[1], A.data_ptr(), A.stride(0),
-                 B.data_ptr(), B.stride(0), out.data_ptr(), out.stride(0), bias.data_ptr(), lib.ACT_QUICK_GELU, pre.data_ptr(), 0, 0, 1.0, 0, 0, 0, 0, 0, 0)
-    elif epi == "dact":
-        K.gemm(A, B, trans_a=bool(ta), trans_b=bool(tb), act=lib.ACT_QUICK_GELU, dact_aux=pre, out=out, splitk=False)
+                 B.data_ptr(), B.stride(0), out.data_ptr(), out.stride(0), bias.data_ptr(), act, pre.data_ptr(), 0, 0, 1.0, 0, 0, 0, 0, 0, 0)
+    elif epi in ("dact", "dact_deriv"):
+        K.gemm(A, B, trans_a=bool(ta), trans_b=bool(tb), act=lib.ACT_QUICK_GELU | (lib.ACT_DERIV if epi == "dact_deriv" else 0), dact_aux=pre, out=out, splitk=False)
     else:
         K.gemm(A, B, trans_a=bool(ta), trans_b=bool(tb), bias=bias if epi == "bias" else None, out=out, splitk=False)
 
@@ -89,7 +94,7 @@ def bench(rounds=4, n=6):
         B = mk((Kd, N) if tb else (N, Kd), 12)
         bias = mk((N,), 13)
         out = torch.empty((M, N), dtype=torch.bfloat16, device=dev)
-        pre = mk((M, N), 14) if epi in ("gelu", "dact") else None
+        pre = mk((M, N), 14) if epi in ("gelu", "dact", "gelu_deriv", "dact_deriv") else None
         best = {c: 1e9 for c in CONFIGS}
         for r in range(rounds):
             for cfg in CONFIGS:

@@ -135,6 +135,11 @@ DEVINL uint32_t drop_threshold(float p) {
 #define VALOR_ACT_QUICK_GELU 2  // x*sigmoid(1.702x)           clip.py:167-169
 #define VALOR_ACT_RELU 3        // fine-weight MLP             pretrain.py:104-112
 #define VALOR_ACT_TANH 4
+#define VALOR_ACT_MASK 15
+// flag on the activation id: the `preact` output of a forward GEMM holds act'(x) instead of x, and `dact_aux` of the matching dgrad holds
+// that derivative (the epilogue multiplies by it directly). sigmoid / erf / exp are evaluated ONCE, in the forward, where y = act(x) needs
+// them anyway: the dgrad epilogue drops from ~8-17 VALU instructions and two quarter-rate transcendentals per value to one multiply.
+#define VALOR_ACT_DERIV 16
 
 // The activations run in GEMM epilogues at one value per MFMA output, i.e. on the VALU beside the matrix pipe: ViT fc1 alone is
 // 3.7e9 values per step. They are written for instruction count: v_rcp_f32 / v_exp_f32 (1 ulp) instead of IEEE division, and erf
@@ -176,6 +181,21 @@ template <int ACT> DEVINL float act_bwd_c(float x) {
     else if constexpr (ACT == VALOR_ACT_TANH) { const float t = tanhf(x); return 1.f - t * t; }
     else return 1.0f;
 }
+// y = act(x) and g = act'(x) from shared subexpressions
+template <int ACT> DEVINL void act_fwd_deriv_c(float x, float& y, float& g) {
+    if constexpr (ACT == VALOR_ACT_GELU_ERF) {
+        float e;
+        const float cdf = gelu_cdf(x, e);
+        y = x * cdf;
+        g = fmaf(x * 0.39894228040143267794f, e, cdf);
+    } else if constexpr (ACT == VALOR_ACT_QUICK_GELU) {
+        const float s = quick_sigmoid(x);
+        y = x * s;
+        g = fmaf(1.702f * y, 1.0f - s, s);           // s + 1.702 x s (1 - s)
+    } else if constexpr (ACT == VALOR_ACT_RELU) { y = x > 0.f ? x : 0.f; g = x > 0.f ? 1.f : 0.f; }
+    else if constexpr (ACT == VALOR_ACT_TANH) { y = tanhf(x); g = 1.f - y * y; }
+    else { y = x; g = 1.0f; }
+}
 DEVINL float act_fwd(int act, float x) {
     switch (act) {
         case VALOR_ACT_GELU_ERF: return act_fwd_c<VALOR_ACT_GELU_ERF>(x);
@@ -214,6 +234,31 @@ template <int N> DEVINL void act_fwd_n(int act, float* v) {
             for (int r = 0; r < N; ++r) v[r] = act_fwd_c<VALOR_ACT_TANH>(v[r]);
             break;
         default: break;
+    }
+}
+// v[r]: x -> act(x), g[r] = act'(x)
+template <int N> DEVINL void act_fwd_deriv_n(int act, float* v, float* g) {
+    switch (act) {
+        case VALOR_ACT_GELU_ERF:
+#pragma unroll
+            for (int r = 0; r < N; ++r) act_fwd_deriv_c<VALOR_ACT_GELU_ERF>(v[r], v[r], g[r]);
+            break;
+        case VALOR_ACT_QUICK_GELU:
+#pragma unroll
+            for (int r = 0; r < N; ++r) act_fwd_deriv_c<VALOR_ACT_QUICK_GELU>(v[r], v[r], g[r]);
+            break;
+        case VALOR_ACT_RELU:
+#pragma unroll
+            for (int r = 0; r < N; ++r) act_fwd_deriv_c<VALOR_ACT_RELU>(v[r], v[r], g[r]);
+            break;
+        case VALOR_ACT_TANH:
+#pragma unroll
+            for (int r = 0; r < N; ++r) act_fwd_deriv_c<VALOR_ACT_TANH>(v[r], v[r], g[r]);
+            break;
+        default:
+#pragma unroll
+            for (int r = 0; r < N; ++r) g[r] = 1.0f;
+            break;
     }
 }
 // v[r] *= act'(x[r])

@@ -190,7 +190,7 @@ DEVINL bf16x8_t read_frag_tr(const char* img, int off, int kk) {
     s16x8_t r = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
     return __builtin_bit_cast(bf16x8_t, r);
 }
-template <bool TA, bool TB, int NSTAGE>
+template <bool TA, bool TB, int NSTAGE, bool FUSED>
 __global__ __launch_bounds__(256, NSTAGE == 1 ? 4 : 2) void gemm_glds_kernel(GemmArgs p) {
     typedef bf16_t T;
     constexpr int BK = 64;
@@ -387,6 +387,12 @@ __global__ __launch_bounds__(256, NSTAGE == 1 ? 4 : 2) void gemm_glds_kernel(Gem
     constexpr int EPI_ROWS = NSTAGE == 1 ? 64 : 128;
     float* sC = (float*)smem;
     float* wsl = p.kslices > 1 ? p.ws + (int64_t)slice * p.M * p.N : nullptr;
+    // The epilogue's lane geometry is recomputed from an OPAQUE copy of the thread id: otherwise the compiler hoists its address
+    // arithmetic above the K loop, where those values sit in VGPRs through every iteration -- at the 128-register budget of four
+    // workgroups per CU that spilled INSIDE the loop (session M: plain 128x128 GEMMs 580 -> 946 us after the epilogue grew).
+    int tid_e = tid;
+    asm volatile("" : "+v"(tid_e));
+    const int lane_e = tid_e & 63, fr_e = lane_e & 15, fg_e = lane_e >> 4;
 #pragma unroll
     for (int pass = 0; pass < 128 / EPI_ROWS; ++pass) {
         if (pass) __syncthreads();
@@ -395,16 +401,16 @@ __global__ __launch_bounds__(256, NSTAGE == 1 ? 4 : 2) void gemm_glds_kernel(Gem
             for (int ni = 0; ni < 4; ++ni)
 #pragma unroll
                 for (int mi = 0; mi < 4; ++mi) {
-                    const int ml = (EPI_ROWS == 128 ? wm * 64 : 0) + mi * 16 + fr;
-                    const int ch = (wn * 16 + ni * 4 + fg) ^ (ml & 7);
+                    const int ml = (EPI_ROWS == 128 ? wm * 64 : 0) + mi * 16 + fr_e;
+                    const int ch = (wn * 16 + ni * 4 + fg_e) ^ (ml & 7);
                     *(f32x4_t*)(sC + ml * 128 + ch * 4) = acc[ni][mi];
                 }
         }
         __syncthreads();
 #pragma unroll 1
         for (int it = 0; it < EPI_ROWS / 16; ++it) {       // 16 lanes x 8 columns per row: 16-byte bf16 stores
-            const int ml = it * 16 + (tid >> 4);
-            const int c8 = tid & 15;
+            const int ml = it * 16 + (tid_e >> 4);
+            const int c8 = tid_e & 15;
             const f32x4_t v0 = *(const f32x4_t*)(sC + ml * 128 + (((2 * c8) ^ (ml & 7)) << 2));
             const f32x4_t v1 = *(const f32x4_t*)(sC + ml * 128 + (((2 * c8 + 1) ^ (ml & 7)) << 2));
             const int m = m0 + pass * EPI_ROWS + ml, n = n0 + c8 * 8;
@@ -415,7 +421,7 @@ __global__ __launch_bounds__(256, NSTAGE == 1 ? 4 : 2) void gemm_glds_kernel(Gem
                     else for (int r = 0; r < 8; ++r) if (n + r < p.N) q[r] = r < 4 ? v0[r] : v1[r - 4];
                 }
             } else {
-                epilogue_store8(p, m, n, v0, v1, load_bias4<T>(p, n), load_bias4<T>(p, n + 4));
+                epilogue_store8<FUSED>(p, m, n, v0, v1, load_bias4<T>(p, n), load_bias4<T>(p, n + 4));
             }
         }
     }
@@ -490,21 +496,29 @@ extern "C" int valor_gemm_kernel_for(int dtype, int transA, int transB, int M, i
 template <int NSTAGE>
 static void launch_gemm_glds(hipStream_t st, int transA, int transB, const GemmArgs& p, dim3 grid) {
     const size_t lds = NSTAGE * 32768;
-#define VALOR_GLDS_LAUNCH(TA_, TB_)                                                                 \
+#define VALOR_GLDS_LAUNCH1(TA_, TB_, F_)                                                            \
     do {                                                                                            \
         static bool attr_set = false;                                                               \
         if (!attr_set) {                                                                            \
-            hipFuncSetAttribute((const void*)gemm_glds_kernel<TA_, TB_, NSTAGE>,                    \
+            hipFuncSetAttribute((const void*)gemm_glds_kernel<TA_, TB_, NSTAGE, F_>,                \
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);              \
             attr_set = true;                                                                        \
         }                                                                                           \
-        hipLaunchKernelGGL((gemm_glds_kernel<TA_, TB_, NSTAGE>), grid, dim3(256), lds, st, p);      \
+        hipLaunchKernelGGL((gemm_glds_kernel<TA_, TB_, NSTAGE, F_>), grid, dim3(256), lds, st, p);  \
     } while (0)
+#define VALOR_GLDS_LAUNCH(TA_, TB_)                                                                 \
+    do {                                                                                            \
+        if (fused) VALOR_GLDS_LAUNCH1(TA_, TB_, true);                                              \
+        else VALOR_GLDS_LAUNCH1(TA_, TB_, false);                                                   \
+    } while (0)
+    // split-K partial tiles never run an epilogue here (gemm_splitk_reduce does): the lean variant
+    const bool fused = p.kslices <= 1 && ((p.act & VALOR_ACT_MASK) != VALOR_ACT_NONE || p.preact || p.dact_aux);
     if (!transA && !transB) VALOR_GLDS_LAUNCH(false, false);
     else if (!transA && transB) VALOR_GLDS_LAUNCH(false, true);
     else if (transA && !transB) VALOR_GLDS_LAUNCH(true, false);
     else VALOR_GLDS_LAUNCH(true, true);
 #undef VALOR_GLDS_LAUNCH
+#undef VALOR_GLDS_LAUNCH1
 }
 
 template <typename T>
@@ -513,7 +527,7 @@ static int launch_gemm(hipStream_t st, int transA, int transB, GemmArgs p) {
     dim3 grid(tiles, p.kslices > 1 ? p.kslices : 1);
     if (ElemTraits<T>::DT == VALOR_DT_BF16 && g_gemm_variant > 0) {
         if (p.kslices > 1) grid = dim3(tiles * p.kslices, 1);     // split-K: 1-D grid over (slice, tile) work items
-        if (use_8ph(VALOR_DT_BF16, transA, transB, p.M, p.N, p.K, p.dact_aux != nullptr)) launch_gemm_8ph(st, transA, transB, p);
+        if (use_8ph(VALOR_DT_BF16, transA, transB, p.M, p.N, p.K, p.dact_aux != nullptr && !(p.act & VALOR_ACT_DERIV))) launch_gemm_8ph(st, transA, transB, p);
         else if (g_gemm_variant == 2) launch_gemm_glds<2>(st, transA, transB, p, grid);
         else launch_gemm_glds<1>(st, transA, transB, p, grid);
         if (p.kslices > 1) {
@@ -633,7 +647,7 @@ extern "C" int valor_gemm(void* stream, int dtype, int transA, int transB, int M
         // split-K of the LDS-DMA kernels: as many K-slices as fill -- without overflowing -- ONE round of workgroup
         // slots (128x128 kernel: 4 per CU = 1024; 256x256 kernel: 1 per CU = 256); >= 6 K-steps per workgroup.
         slices = 1;
-        const bool big = use_8ph(dtype, transA, transB, M, N, K, dact_aux != nullptr);
+        const bool big = use_8ph(dtype, transA, transB, M, N, K, dact_aux != nullptr && !(act & VALOR_ACT_DERIV));
         const int tiles_x = big ? ((M + 255) / 256) * ((N + 255) / 256) : tiles;
         const int slots = big ? 256 : 1024;
         if (workspace && 2 * tiles_x <= slots && nk >= 24) {

@@ -300,6 +300,10 @@ __global__ __launch_bounds__(512, 2) void gemm_8ph_kernel(GemmArgs p) {
     //     row (16-byte coalesced loads of aux / C); the GEMM result is rounded to bf16 before the act' multiply there (gradient path).
     if constexpr (!TA) if (p.fast_epi) {           // (k-slow A = wgrad: split-K / fused row sums, always the general epilogue)
         char* sB = smem;
+        const int act = p.act & VALOR_ACT_MASK;
+        const bool deriv = (p.act & VALOR_ACT_DERIV) != 0;
+        // (a derivative-saving forward -- `preact` receives act'(x) -- keeps the general epilogue: a third variant of this fully unrolled
+        //  body makes the compiler give up unrolling and demote the accumulators to scratch, 800 B/lane)
         auto write_tile = [&](bool apply_act) {
 #pragma unroll
             for (int ni = 0; ni < 4; ++ni) {
@@ -313,7 +317,7 @@ __global__ __launch_bounds__(512, 2) void gemm_8ph_kernel(GemmArgs p) {
                     for (int r = 0; r < 4; ++r) v[r] = v[r] * p.alpha + bias4[r];
                     if (apply_act) {
                         float f[4] = {v[0], v[1], v[2], v[3]};
-                        act_fwd_n<4>(p.act, f);
+                        act_fwd_n<4>(act, f);
                         v = (f32x4_t){f[0], f[1], f[2], f[3]};
                     }
                     const u32x2_t w = {pack2_bf16(v[0], v[1]), pack2_bf16(v[2], v[3])};
@@ -337,7 +341,12 @@ __global__ __launch_bounds__(512, 2) void gemm_8ph_kernel(GemmArgs p) {
                             float x[8];
 #pragma unroll
                             for (int q = 0; q < 4; ++q) { x[2 * q] = __uint_as_float(a[q] << 16); x[2 * q + 1] = __uint_as_float(a[q] & 0xffff0000u); }
-                            act_bwd_mul_n<8>(p.act, f, x);
+                            if (deriv) {
+#pragma unroll
+                                for (int q = 0; q < 8; ++q) f[q] *= x[q];
+                            } else {
+                                act_bwd_mul_n<8>(act, f, x);
+                            }
                         }
                         if (accum) {
                             const u32x4_t o = *(const u32x4_t*)(dst + (int64_t)m * p.ldc + n);
@@ -357,7 +366,7 @@ __global__ __launch_bounds__(512, 2) void gemm_8ph_kernel(GemmArgs p) {
             read_tile((T*)p.preact, false, false);
             __syncthreads();
         }
-        write_tile(p.act != VALOR_ACT_NONE && !p.dact_aux);
+        write_tile(act != VALOR_ACT_NONE && !p.dact_aux);
         __syncthreads();
         read_tile((T*)p.C, p.dact_aux != nullptr, p.accumulate != 0);
         return;
@@ -422,9 +431,10 @@ void launch_gemm_8ph(hipStream_t st, int transA, int transB, const GemmArgs& p_i
     // measured (profiles/r02_gemm_epilogue_ab.json): the bf16 tile epilogue wins 1-5 % on plain / bias / activation / C += problems,
     // loses on a pre-activation copy (two tile passes: 939 vs 741 us on the ViT fc1 forward) and on the act' multiply (927 vs 896 us):
     // those keep the general epilogue (mode 2 forces the tile path everywhere it is implemented, for tests / A-B runs)
-    const bool plainish = g_8ph_fast_epi >= 2 || (!p.preact && !p.dact_aux);
+    const bool light_dact = p.dact_aux && (p.act & VALOR_ACT_DERIV);          // one multiply per value at read-out
+    const bool plainish = g_8ph_fast_epi >= 2 || (!p.preact && (!p.dact_aux || light_dact));
     p.fast_epi = g_8ph_fast_epi && plainish && !p.out_f32 && p.kslices <= 1 && (p.N & 7) == 0 && (p.ldc & 7) == 0 && !p.rowsum_out &&
-                 (!p.dact_aux || (p.ldaux & 7) == 0) && !(p.dact_aux && p.preact) && !transA;
+                 (!p.dact_aux || (p.ldaux & 7) == 0) && !(p.dact_aux && p.preact) && !transA && !(p.preact && (p.act & VALOR_ACT_DERIV));
     const int tiles = ((p.M + 255) / 256) * ((p.N + 255) / 256);
     dim3 grid(tiles * (p.kslices > 1 ? p.kslices : 1));
     const size_t lds = 2 * BUF_BYTES;

@@ -49,7 +49,10 @@ DEVINL void rowsum_store(const GemmArgs& p, int m, float v) {
     }
 }
 
-template <typename T>
+// FUSED = false: the lean variant without the activation / pre-activation / act' code (plain, bias, alpha, C +=, fp32 out): the
+// 128x128 LDS-DMA kernel runs it for the problems that ask for nothing else, so that the fused epilogue's register appetite cannot
+// reach into ITS K loop (128-VGPR budget; session M measured 580 -> 946 us on a plain GEMM when it did).
+template <typename T, bool FUSED = true>
 DEVINL void epilogue_store(const GemmArgs& p, int m, int n0, f32x4_t acc, f32x4_t bias4) {
     // 4 consecutive n (n0 .. n0+3) of row m
     if (m >= p.M || n0 >= p.N) return;
@@ -59,32 +62,47 @@ DEVINL void epilogue_store(const GemmArgs& p, int m, int n0, f32x4_t acc, f32x4_
     f32x4_t v;
 #pragma unroll
     for (int r = 0; r < 4; ++r) v[r] = acc[r] * p.alpha + bias4[r];
-    if (p.preact) {
-        if (p.out_f32) {
-            float* q = (float*)p.preact + off;
-            if (vec) *(f32x4_t*)q = v;
-            else for (int r = 0; r < nvalid; ++r) q[r] = v[r];
-        } else {
-            T* q = (T*)p.preact + off;
-            if (vec) store4<T>(q, v);
-            else for (int r = 0; r < nvalid; ++r) q[r] = from_f32<T>(v[r]);
-        }
-    }
-    if (p.act != VALOR_ACT_NONE && !p.dact_aux) {
-        float f[4] = {v[0], v[1], v[2], v[3]};
-        act_fwd_n<4>(p.act, f);
-        v = (f32x4_t){f[0], f[1], f[2], f[3]};
-    }
-    if (p.dact_aux) {
-        const T* a = (const T*)p.dact_aux + (int64_t)m * p.ldaux + n0;
-        if (vec && (p.ldaux & 3) == 0) {
-            const f32x4_t u = load4<T>(a);
+    if constexpr (FUSED) {
+        const int act = p.act & VALOR_ACT_MASK;
+        const bool deriv = (p.act & VALOR_ACT_DERIV) != 0;           // preact / dact_aux hold act'(x) instead of x
+        f32x4_t pre = v;
+        if ((act != VALOR_ACT_NONE || (deriv && p.preact)) && !p.dact_aux) {
             float f[4] = {v[0], v[1], v[2], v[3]};
-            const float x[4] = {u[0], u[1], u[2], u[3]};
-            act_bwd_mul_n<4>(p.act, f, x);
+            if (p.preact && deriv) {
+                float g[4];
+                act_fwd_deriv_n<4>(act, f, g);
+                pre = (f32x4_t){g[0], g[1], g[2], g[3]};
+            } else {
+                act_fwd_n<4>(act, f);
+            }
             v = (f32x4_t){f[0], f[1], f[2], f[3]};
-        } else {
-            for (int r = 0; r < nvalid; ++r) v[r] *= act_bwd(p.act, to_f32<T>(a[r]));
+        }
+        if (p.preact) {
+            if (p.out_f32) {
+                float* q = (float*)p.preact + off;
+                if (vec) *(f32x4_t*)q = pre;
+                else for (int r = 0; r < nvalid; ++r) q[r] = pre[r];
+            } else {
+                T* q = (T*)p.preact + off;
+                if (vec) store4<T>(q, pre);
+                else for (int r = 0; r < nvalid; ++r) q[r] = from_f32<T>(pre[r]);
+            }
+        }
+        if (p.dact_aux) {
+            const T* a = (const T*)p.dact_aux + (int64_t)m * p.ldaux + n0;
+            if (vec && (p.ldaux & 3) == 0) {
+                const f32x4_t u = load4<T>(a);
+                if (deriv) {
+                    v *= u;
+                } else {
+                    float f[4] = {v[0], v[1], v[2], v[3]};
+                    const float x[4] = {u[0], u[1], u[2], u[3]};
+                    act_bwd_mul_n<4>(act, f, x);
+                    v = (f32x4_t){f[0], f[1], f[2], f[3]};
+                }
+            } else {
+                for (int r = 0; r < nvalid; ++r) v[r] *= deriv ? to_f32<T>(a[r]) : act_bwd(act, to_f32<T>(a[r]));
+            }
         }
     }
     if (p.out_f32) {
@@ -110,37 +128,54 @@ DEVINL void epilogue_store(const GemmArgs& p, int m, int n0, f32x4_t acc, f32x4_
 
 // 8 consecutive n (n0 .. n0+7) of row m, bf16 only: one 16-byte store per lane (the epilogue is store-ISSUE bound:
 // half as many, twice as wide store instructions). Falls back to two 4-wide stores on tails / odd leading dims.
+template <bool FUSED = true>
 DEVINL void epilogue_store8(const GemmArgs& p, int m, int n0, f32x4_t a0, f32x4_t a1, f32x4_t b0, f32x4_t b1) {
     typedef bf16_t T;
     if (m >= p.M || n0 >= p.N) return;
     const bool vec8 = n0 + 8 <= p.N && (p.ldc & 7) == 0 && !p.out_f32 && (!p.dact_aux || (p.ldaux & 7) == 0);
     if (!vec8) {
-        epilogue_store<T>(p, m, n0, a0, b0);
-        epilogue_store<T>(p, m, n0 + 4, a1, b1);
+        epilogue_store<T, FUSED>(p, m, n0, a0, b0);
+        epilogue_store<T, FUSED>(p, m, n0 + 4, a1, b1);
         return;
     }
     const int64_t off = (int64_t)m * p.ldc + n0;
     f32x4_t v0, v1;
 #pragma unroll
     for (int r = 0; r < 4; ++r) { v0[r] = a0[r] * p.alpha + b0[r]; v1[r] = a1[r] * p.alpha + b1[r]; }
-    if (p.preact) {
-        u32x4_t q = {pack2_bf16(v0[0], v0[1]), pack2_bf16(v0[2], v0[3]), pack2_bf16(v1[0], v1[1]), pack2_bf16(v1[2], v1[3])};
-        *(u32x4_t*)((T*)p.preact + off) = q;
-    }
-    if (p.act != VALOR_ACT_NONE && !p.dact_aux) {
-        float f[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
-        act_fwd_n<8>(p.act, f);
-        v0 = (f32x4_t){f[0], f[1], f[2], f[3]};
-        v1 = (f32x4_t){f[4], f[5], f[6], f[7]};
-    }
-    if (p.dact_aux) {
-        const T* a = (const T*)p.dact_aux + (int64_t)m * p.ldaux + n0;
-        const f32x4_t u0 = load4<T>(a), u1 = load4<T>(a + 4);
-        float f[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
-        const float x[8] = {u0[0], u0[1], u0[2], u0[3], u1[0], u1[1], u1[2], u1[3]};
-        act_bwd_mul_n<8>(p.act, f, x);
-        v0 = (f32x4_t){f[0], f[1], f[2], f[3]};
-        v1 = (f32x4_t){f[4], f[5], f[6], f[7]};
+    if constexpr (FUSED) {
+        const int act = p.act & VALOR_ACT_MASK;
+        const bool deriv = (p.act & VALOR_ACT_DERIV) != 0;
+        f32x4_t q0 = v0, q1 = v1;                                      // what the `preact` buffer receives
+        if ((act != VALOR_ACT_NONE || (deriv && p.preact)) && !p.dact_aux) {
+            float f[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+            if (p.preact && deriv) {
+                float g[8];
+                act_fwd_deriv_n<8>(act, f, g);
+                q0 = (f32x4_t){g[0], g[1], g[2], g[3]};
+                q1 = (f32x4_t){g[4], g[5], g[6], g[7]};
+            } else {
+                act_fwd_n<8>(act, f);
+            }
+            v0 = (f32x4_t){f[0], f[1], f[2], f[3]};
+            v1 = (f32x4_t){f[4], f[5], f[6], f[7]};
+        }
+        if (p.preact) {
+            u32x4_t q = {pack2_bf16(q0[0], q0[1]), pack2_bf16(q0[2], q0[3]), pack2_bf16(q1[0], q1[1]), pack2_bf16(q1[2], q1[3])};
+            *(u32x4_t*)((T*)p.preact + off) = q;
+        }
+        if (p.dact_aux) {
+            const T* a = (const T*)p.dact_aux + (int64_t)m * p.ldaux + n0;
+            const f32x4_t u0 = load4<T>(a), u1 = load4<T>(a + 4);
+            if (deriv) {
+                v0 *= u0; v1 *= u1;
+            } else {
+                float f[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+                const float x[8] = {u0[0], u0[1], u0[2], u0[3], u1[0], u1[1], u1[2], u1[3]};
+                act_bwd_mul_n<8>(act, f, x);
+                v0 = (f32x4_t){f[0], f[1], f[2], f[3]};
+                v1 = (f32x4_t){f[4], f[5], f[6], f[7]};
+            }
+        }
     }
     T* c = (T*)p.C + off;
     if (p.accumulate) { v0 += load4<T>(c); v1 += load4<T>(c + 4); }

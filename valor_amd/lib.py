@@ -15,6 +15,7 @@ DT_BF16 = 0
 DT_F32 = 1
 
 ACT_NONE, ACT_GELU_ERF, ACT_QUICK_GELU, ACT_RELU, ACT_TANH = 0, 1, 2, 3, 4
+ACT_DERIV = 16      # flag: `preact` / `dact_aux` hold act'(x) instead of x (include/valor_hip.h)
 
 _c = ctypes
 _vp, _i, _i64, _u64, _f = _c.c_void_p, _c.c_int, _c.c_int64, _c.c_uint64, _c.c_float

@@ -5,6 +5,7 @@ There is no eager / CPU implementation of any op here: tensors must be on the GP
 libvalor_hip.so must be built, otherwise lib.ValorHipError is raised.
 """
 import math
+import os
 
 import torch
 from torch.autograd import Function
@@ -147,14 +148,20 @@ def linear(x, w, b=None, act=ACT_NONE, w_is_kn=False, grad_slot=None):
     return LinearFn.apply(x, w, b, act, w_is_kn, grad_slot)
 
 
+_MLP_SAVES_DERIV = os.environ.get("VALOR_MLP_DERIV", "1") != "0"      # 0: keep the pre-activation and evaluate act' in the dgrad (A/B runs)
+
+
 class MlpFn(Function):
     """y = act(x W1^T + b1) W2^T + b2  (BertIntermediate+BertOutput.dense bert.py:403-406,417; CLIP mlp
     clip.py:178-182; AST FeedForward transformer.py:141-142; fine-weight MLP pretrain.py:104-112).
-    The activation derivative is fused into the dgrad GEMM epilogue: dU = (dY.W2) * act'(u)."""
+    The activation derivative is fused into the dgrad GEMM epilogue: dU = (dY.W2) * act'(u). What the forward keeps for it is act'(u)
+    itself (ACT_DERIV), evaluated beside act(u) from the same sigmoid / erf: the backward epilogue is one multiply."""
 
     @staticmethod
     def forward(ctx, x, w1, b1, w2, b2, act):
         x2 = _2d(x)
+        if _MLP_SAVES_DERIV:
+            act = act | lib.ACT_DERIV
         h, u = K.gemm(x2, w1, bias=b1, act=act, want_preact=True)
         y = K.gemm(h, w2, bias=b2)
         ctx.save_for_backward(x2, w1, w2, u, h)
