@@ -79,7 +79,8 @@ int valor_gemm_set_fast_epilogue(int v);
  *   key 0: smallest K for which a big-M dgrad (A row-major, B k-slow) runs on the 256x256 8-phase kernel
  *   key 1: unused (was the start skew of the 8-phase kernel's first round; measured slower at every setting,
  *          profiles/r02_gemm_policy_ab.json)
- *   key 2: smallest number of 256x256 tiles for the 8-phase kernel on forward / dgrad problems */
+ *   key 2: smallest number of 256x256 tiles for the 8-phase kernel on forward problems (default 256: one full round of workgroups)
+ *   key 3: the same for dgrad problems (default 1024: below it the 128x128 kernel measured faster, session N) */
 int valor_gemm_set_policy(int key, int value);
 
 /* ---- fused bias + dropout + residual + LayerNorm.  Replaces apex FusedLayerNorm (apex/csrc/layer_norm_cuda_kernel.cu

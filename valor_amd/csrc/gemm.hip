@@ -459,10 +459,11 @@ extern "C" int valor_gemm_set_variant(int v) { const int o = g_gemm_variant; if 
 // variant 4 (default): measured policy (tools/gemm_ab.py, profiles/r01_gemm_variants_*.json) -- the 8-phase kernel for
 //   the big-M forward GEMMs, long-K dgrad and the wgrad GEMMs; the 128x128 kernel (4 workgroups per CU hiding each
 //   other's prologue / epilogue) for small grids, short-K dgrad and everything with a K tail.
-// [0] NT min K for the 8-phase kernel, [1] unused (was: 8-phase start skew, measured slower), [2] min 256x256 tiles (forward / dgrad), [3] spare
+// [0] NT min K for the 8-phase kernel, [1] unused (was: 8-phase start skew, measured slower), [2] min 256x256 tiles (forward), [3] min 256x256 tiles (dgrad)
 int g_gemm_policy[4] = {[] { const char* e = getenv("VALOR_GEMM_NT_MINK"); return e ? atoi(e) : 768; }(),
                         [] { const char* e = getenv("VALOR_GEMM_SKEW"); return e ? atoi(e) : 0; }(),
-                        [] { const char* e = getenv("VALOR_GEMM_MIN_TILES"); return e ? atoi(e) : 256; }(), 0};
+                        [] { const char* e = getenv("VALOR_GEMM_MIN_TILES"); return e ? atoi(e) : 256; }(),
+                        [] { const char* e = getenv("VALOR_GEMM_NT_MIN_TILES"); return e ? atoi(e) : 1024; }()};
 extern "C" int valor_gemm_set_policy(int key, int value) {
     if (key < 0 || key > 3) return VALOR_ERR_ARG;
     const int old = g_gemm_policy[key];
@@ -481,7 +482,7 @@ static bool use_8ph(int dtype, int transA, int transB, int M, int N, int K, bool
     const int64_t tiles256 = (int64_t)((M + 255) / 256) * ((N + 255) / 256);
     if (transA && transB) return K >= 4096;                           // wgrad: K = tokens, split-K fills one round
     if (!transA && !transB) return tiles256 >= g_gemm_policy[2] && K >= 512;      // forward: at least one full round of 256 workgroups (in-step sweep, session K: 1024 / 512 / 256 / 128 tiles -> 133.5 / 134.2 / 132.0 / 138.1 ms)
-    if (!transA && transB) return tiles256 >= g_gemm_policy[2] && K >= (heavy_epi ? 1536 : g_gemm_policy[0]);      // dgrad
+    if (!transA && transB) return tiles256 >= g_gemm_policy[3] && K >= (heavy_epi ? 1536 : g_gemm_policy[0]);      // dgrad
     return false;
 }
 
