@@ -157,6 +157,19 @@ def run_finetune(name, batch_size, frames, audio_slices, wseed, bseed, mseed, va
         sb = orc.decode_beam(vi, ai, None, batch_size, 3, max_len, gaps=gaps)
         assert torch.equal(sb, g["beam3"]["generated_sequences_t_va"])
         g["beam3_gap_t_va"] = torch.stack(gaps, 1).clone()                              # [b, steps]
+        # video QA (config/VQA-*.json 'qa%tva%tv'): per-sample-normalised loss with the question as prompt rows, greedy answers
+        qb = synth.make_batch(spec, batch=batch_size, frames=frames, audio_slices=audio_slices, txt_len=32, seed=bseed, bf16_exact=True, questions=True)
+        fresh = lambda: {k: (dict(v) if isinstance(v, dict) else v) for k, v in qb.items()}
+        random.seed(mseed)
+        g["qa_loss"] = float(ref(fresh(), task="qa%tva%tv", compute_loss=True)["qa_loss"])
+        ref.beam_size_qa = 1
+        qa = ref(fresh(), task="qa%tva%tv", compute_loss=False)
+        g["qa_greedy"] = {k: v.clone() for k, v in qa.items() if k.startswith("generated")}
+        qtrace = []
+        sq, _ = orc.decode_greedy(vi, ai, orc.qa_prompt(qb["question_tokens"]["bert_tokens"]), batch_size, max_len, qtrace)
+        assert torch.equal(sq, g["qa_greedy"]["generated_answers_t_va"])
+        top = torch.stack([t.topk(2, -1).values for t in qtrace])
+        g["qa_greedy_margin_t_va"] = (top[..., 0] - top[..., 1]).t().clone()
         eos_gap = torch.stack([t.max(-1).values - t[:, 102] for t in trace])            # [steps, b]
         # [SEP] wins at step t of row r iff eos_gap[t, r] < delta (the trajectory before that is the unbiased one): pick the delta that
         # ends the rows at different steps (not all at step 0) with the widest clearance to every gap met on the way
@@ -191,7 +204,7 @@ def run_finetune(name, batch_size, frames, audio_slices, wseed, bseed, mseed, va
         g["greedy_eos_margin_t_va"] = (top[..., 0] - top[..., 1]).t().clone()
     path = os.path.join(ROOT, "tests", "golden", name + ".pt")
     torch.save(g, path)
-    print(name, "ret", round(g["ret_loss"], 5), "cap", round(g["cap_loss"], 5), "greedy", g["greedy"]["generated_sequences_t_va"][0, :6].tolist(),
+    print(name, "ret", round(g["ret_loss"], 5), "cap", round(g["cap_loss"], 5), "qa", round(g["qa_loss"], 5), float(g["qa_greedy_margin_t_va"].min()), "greedy", g["greedy"]["generated_sequences_t_va"][0, :6].tolist(),
           "eos run", g["greedy_eos"]["generated_sequences_t_va"].tolist(), "min margins", float(g["greedy_margin_t_va"].min()),
           float(g["beam3_gap_t_va"].min()), "->", path, os.path.getsize(path) // 1024, "KiB")
 

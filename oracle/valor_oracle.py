@@ -556,13 +556,15 @@ class Oracle:
 
     # ------------------------------------------------------------------------- finetune / inference tasks
     def forward(self, batch, task, compute_loss=True, **kw):
-        """VALOR.forward, model/pretrain.py:125-135 (qa is not restated)"""
+        """VALOR.forward, model/pretrain.py:125-135"""
         if task.startswith("pt"):
             return self.forward_pt(batch, task, compute_loss, **kw)
         if task.startswith("ret"):
             return self.forward_ret(batch, task, compute_loss, **kw)
         if task.startswith("cap"):
             return self.forward_cap(batch, task, compute_loss)
+        if task.startswith("qa"):
+            return self.forward_qa(batch, task, compute_loss)
         raise NotImplementedError(task)
 
     def forward_ret(self, batch, task, compute_loss=True, gather=None):
@@ -604,6 +606,49 @@ class Oracle:
                     ev["generated_sequences_" + key] = self.decode_beam(vi, ai, prompt, bs, beam_size, max_generation_len)
                 else:
                     ev["generated_sequences_" + key], ev["logprobs_" + key] = self.decode_greedy(vi, ai, prompt, bs, max_generation_len)
+        return ev
+
+    def qa_prompt(self, question_tokens):
+        """the 'task prompt' of the QA passes is the QUESTION (prompt-type embeddings), with 'answer the question' spliced in behind its
+        [CLS] when use_task_prompt, model/pretrain.py:1268-1274"""
+        if not self.use_task_prompt:
+            return question_tokens
+        tp = self.get_task_prompt("answer the question", question_tokens.shape[0])[:, 1:-1]
+        return torch.cat((question_tokens[:, 0:1], tp, question_tokens[:, 1:]), dim=1)
+
+    def forward_qa(self, batch, task, compute_loss=True, beam_size_qa=1, max_generation_len=30):
+        """VALOR.forward_qa -> forward_qa_single (loss) / generate_qa, model/pretrain.py:1191-1459, for one answer per question (every
+        answer_nums / sample_num entry 1: the video-QA datasets; the multi-answer tiling of image QA :1243-1265 is not restated).
+        Loss :1276-1290: TokenMasker p = 0.99 on the answer tokens, per-SAMPLE mean of the masked-token CE, mean over samples, mean over groups."""
+        groups = task.split("%")[1:]
+        q = batch["question_tokens"]["bert_tokens"]
+        alltasks = "".join(groups)
+        video_output = self.forward_video_encoder(batch["video_pixels"]) if "v" in alltasks else None
+        audio_output = self.forward_audio_encoder(batch["audio_spectrograms"]) if "a" in alltasks else None
+        bs = q.shape[0]
+        video_input, audio_input = self.multimodal_inputs(video_output, audio_output, bs)
+        prompt = self.qa_prompt(q)
+        if compute_loss:
+            assert all(int(n) == 1 for n in batch["answer_nums"])
+            txt_input, txt_labels = self.text_masker(batch["txt_tokens"]["bert_tokens"], 0.99)
+            lo = []
+            for g in ("tva", "tv", "ta"):
+                if g in groups:
+                    o = self.bert_model(txt_input, prompt, video_input if "v" in g else None, audio_input if "a" in g else None, True)
+                    scores = self.cls_head(o[:, :txt_input.shape[1]])
+                    b, n, c = scores.shape
+                    loss = F.cross_entropy(scores.reshape(b * n, c), txt_labels.reshape(b * n), ignore_index=-1, reduction="none").reshape(b, n)
+                    lo.append((loss.sum(dim=-1) / (txt_labels != -1).sum(dim=-1)).mean())
+            return {"qa_loss": sum(lo) / len(lo)}
+        assert all(int(n) == 1 for n in batch["sample_num"])
+        ev = {}                                                                                  # generate_qa :1366-1459
+        for g, key in (("tv", "t_v"), ("tva", "t_va"), ("ta", "t_a")):
+            if g in groups:
+                vi, ai = (video_input if "v" in g else None), (audio_input if "a" in g else None)
+                if beam_size_qa > 1:
+                    ev["generated_answers_" + key] = self.decode_beam(vi, ai, prompt, bs, beam_size_qa, max_generation_len)
+                else:
+                    ev["generated_answers_" + key] = self.decode_greedy(vi, ai, prompt, bs, max_generation_len)[0]
         return ev
 
     BOS, EOS, MASK = 101, 102, 103        # [CLS] / [SEP] / [MASK] of bert-base-uncased, model/modeling.py:669-671

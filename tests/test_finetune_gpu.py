@@ -1,5 +1,5 @@
-"""SURVEY 8f row 4 on the GPU: the 'ret%..' / 'cap%..' finetune tasks (config/fast-retrieval-*.json, caption-*.json) and caption
-generation (greedy and beam-3) of the native model against
+"""SURVEY 8f row 4 on the GPU: the 'ret%..' / 'cap%..' / 'qa%..' finetune tasks (config/fast-retrieval-*.json, caption-*.json, VQA-*.json),
+caption generation (greedy and beam-3) and answer generation of the native model against
   (1) the CPU oracle on tiny models (every variant, task prompt on and off), and
   (2) golden vectors from the UNMODIFIED reference at base widths (tests/golden/ref_*_ft.pt, oracle/make_goldens.py run_finetune).
 fp32: losses within 1e-4, generated token ids identical. bf16: losses within the north-star 1e-3 (5e-3 for the B = 2 contrastive loss,
@@ -70,6 +70,30 @@ def test_tiny_fp32_finetune_tasks_and_generation_match_oracle(dev, variant, prom
         assert torch.equal(og[k], ng[k].cpu()), (k, og[k], ng[k])
         assert torch.equal(ob[k], nb[k].cpu()), (k, ob[k], nb[k])
     assert float(ng["logprobs_t_va"].abs().max()) == 0.0          # pretrain.py:992,1013: only 'sample' mode fills them
+    # --- video QA: the question is the prompt (padded, one per clip), per-sample-normalised loss, greedy and beam answers
+    qb = synth.make_batch(spec, batch=3, frames=2, audio_slices=2, txt_len=10, seed=7, questions=True)
+    random.seed(3)
+    o = orc.forward(qb, "qa%tva%tv", compute_loss=True)
+    random.seed(3)
+    n = model(qb, task="qa%tva%tv", compute_loss=True)
+    assert set(n) == {"qa_loss"}
+    assert abs(float(o["qa_loss"]) - float(n["qa_loss"])) <= 1e-4 * abs(float(o["qa_loss"])), (float(o["qa_loss"]), float(n["qa_loss"]))
+    n["qa_loss"].backward()
+    assert float(model.arena.grad.float().abs().max()) > 0
+    model.zero_grad()
+    with torch.no_grad():
+        oq1 = orc.forward_qa(qb, "qa%tva%tv%ta", compute_loss=False, beam_size_qa=1, max_generation_len=6)
+        oq3 = orc.forward_qa(qb, "qa%tva%tv%ta", compute_loss=False, beam_size_qa=3, max_generation_len=6)
+    model.max_generation_len = 6
+    model.beam_size_qa = 1
+    nq1 = model(qb, task="qa%tva%tv%ta", compute_loss=False)
+    model.beam_size_qa = 3
+    nq3 = model(qb, task="qa%tva%tv%ta", compute_loss=False)
+    for k in ("generated_answers_t_va", "generated_answers_t_v", "generated_answers_t_a"):
+        assert torch.equal(oq1[k], nq1[k].cpu()), (k, oq1[k], nq1[k])
+        assert torch.equal(oq3[k], nq3[k].cpu()), (k, oq3[k], nq3[k])
+    with pytest.raises(NotImplementedError):
+        model(dict(qb, answer_nums=[2, 1, 1]), task="qa%tv", compute_loss=True)
 
 
 @pytest.mark.parametrize("name", ["ref_base_b2f2a1_ft", "ref_swin_b2f2a1_ft"])
@@ -97,6 +121,17 @@ def test_base_widths_fp32_match_reference_goldens(dev, name):
         assert torch.equal(g["greedy"][k], gr[k].cpu()), k
     for k in g["beam3"]:
         assert torch.equal(g["beam3"][k], bm[k].cpu()), k
+    # video QA: loss and greedy answers
+    from valor_amd import synth
+    qb = synth.make_batch(spec, batch=rc["batch"], frames=rc["frames"], audio_slices=rc["audio_slices"], txt_len=rc["txt_len"],
+                          seed=rc["batch_seed"], bf16_exact=True, questions=True)
+    with torch.no_grad():
+        random.seed(rc["masker_seed"])
+        qa = float(model(qb, task="qa%tva%tv", compute_loss=True)["qa_loss"])
+    assert abs(qa - g["qa_loss"]) <= 1e-4 * abs(g["qa_loss"]), (qa, g["qa_loss"])
+    ans = model(qb, task="qa%tva%tv", compute_loss=False)
+    for k in g["qa_greedy"]:
+        assert torch.equal(g["qa_greedy"][k], ans[k].cpu()), k
     # rows that END: [SEP] bias raised by the recipe's delta, greedy only (finished beams tie in the reference's beam search)
     sd2 = dict(sd)
     sd2["cls.decoder.bias"] = sd["cls.decoder.bias"].clone()
@@ -133,6 +168,13 @@ def test_base_widths_bf16_generation_is_within_the_logit_error(dev, name):
         cap = float(m16(batch, task="cap%tva%tv", compute_loss=True)["caption_loss"])
     assert abs(ret - g["ret_loss"]) <= 5e-3 * abs(g["ret_loss"]), (ret, g["ret_loss"])
     assert abs(cap - g["cap_loss"]) <= 1e-3 * abs(g["cap_loss"]), (cap, g["cap_loss"])
+    from valor_amd import synth
+    qb = synth.make_batch(spec, batch=rc["batch"], frames=rc["frames"], audio_slices=rc["audio_slices"], txt_len=rc["txt_len"],
+                          seed=rc["batch_seed"], bf16_exact=True, questions=True)
+    with torch.no_grad():
+        random.seed(rc["masker_seed"])
+        qa = float(m16(qb, task="qa%tva%tv", compute_loss=True)["qa_loss"])
+    assert abs(qa - g["qa_loss"]) <= 1e-3 * abs(g["qa_loss"]), (qa, g["qa_loss"])
     m32 = _build(spec, sd, torch.float32, dev)
     ref_seq, margin = g["greedy"]["generated_sequences_t_va"], g["greedy_margin_t_va"]
     worst, agree, decided = 0.0, 0, 0

@@ -118,6 +118,13 @@ def test_oracle_reproduces_finetune_and_generation_goldens(name):
         assert torch.equal(orc.decode_greedy(vi, ai, None, rc["batch"], L)[0], g["greedy"]["generated_sequences_t_va"])
         assert torch.equal(orc.decode_greedy(None, ai, None, rc["batch"], L)[0], g["greedy"]["generated_sequences_t_a"])
         assert torch.equal(orc.decode_beam(vi, None, None, rc["batch"], rc["beam_size"], L), g["beam3"]["generated_sequences_t_v"])
+        qb = synth.make_batch(spec, batch=rc["batch"], frames=rc["frames"], audio_slices=rc["audio_slices"], txt_len=rc["txt_len"],
+                              seed=rc["batch_seed"], bf16_exact=True, questions=True)
+        random.seed(rc["masker_seed"])
+        qa = float(orc.forward(qb, "qa%tva%tv")["qa_loss"])
+        assert abs(qa - g["qa_loss"]) <= 3e-5 * abs(g["qa_loss"])
+        assert torch.equal(orc.decode_greedy(vi, ai, orc.qa_prompt(qb["question_tokens"]["bert_tokens"]), rc["batch"], L)[0],
+                           g["qa_greedy"]["generated_answers_t_va"])
         sd2 = dict(sd)
         sd2["cls.decoder.bias"] = sd["cls.decoder.bias"].clone()
         sd2["cls.decoder.bias"][102] += rc["eos_bias_delta"]

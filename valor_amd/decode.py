@@ -40,7 +40,9 @@ class _Stepper:
         if beam > 1:                                                # (sample, beam) -> beam-major
             perm = torch.arange(rows).view(b, beam).t().reshape(-1)
             txt = txt[perm]
-        prompt = self.prompt[:1].expand(rows, -1) if self.prompt is not None else None
+        prompt = None
+        if self.prompt is not None:                                 # one prompt row per SAMPLE (a QA question differs per clip): beam-major copies
+            prompt = self.prompt.repeat(beam, 1) if beam > 1 else self.prompt
         T = txt.shape[1]
         x = m._bert_embed(m._dev(txt), T, None)
         if prompt is not None:
@@ -140,9 +142,11 @@ def encode_for_generation(model, batch, groups):
     return b, kv_layers, ranges
 
 
-def stepper(model, group, b, kv_layers, ranges):
-    """the per-step logits function of one query group ('tv' | 'tva' | 'ta'): stepper(...).logits(tokens so far or None, rows)"""
-    prompt = model.get_task_prompt(PROMPTS["caption"], b) if model.use_task_prompt else None
+def stepper(model, group, b, kv_layers, ranges, prompt="caption"):
+    """the per-step logits function of one query group ('tv' | 'tva' | 'ta'): stepper(...).logits(tokens so far or None, rows).
+    prompt: 'caption' (the task prompt when the model uses one) or a host [b, L] tensor of prompt rows (QA: the questions)."""
+    if isinstance(prompt, str):
+        prompt = model.get_task_prompt(PROMPTS[prompt], b) if model.use_task_prompt else None
     return _Stepper(model, group, kv_layers, ranges, prompt, b)
 
 
@@ -164,6 +168,29 @@ def generate_cap(model, batch, groups, beam_size=None, max_generation_len=None):
                 out["generated_sequences_" + key] = decode_beam(step, b, beam, max_len)
             else:
                 out["generated_sequences_" + key], out["logprobs_" + key] = decode_greedy(step, b, max_len)
+        return out
+    finally:
+        model.train(was_training)
+
+
+@torch.no_grad()
+def generate_qa(model, batch, groups, prompt_cpu, beam_size=None, max_generation_len=None):
+    """VALOR.generate_qa, model/pretrain.py:1366-1459, one sample per question (sample_num all 1): the caption decoders with the
+    question rows as the prompt -> {'generated_answers_t_v' | '_t_va' | '_t_a'}."""
+    if any(int(n) != 1 for n in batch.get("sample_num", [1])):
+        raise NotImplementedError("several questions per clip (sample_num > 1, pretrain.py:1378-1390) are not built")
+    beam = model.beam_size_qa if beam_size is None else beam_size
+    max_len = model.max_generation_len if max_generation_len is None else max_generation_len
+    was_training = model.training
+    model.eval()
+    try:
+        b, kv_layers, ranges = encode_for_generation(model, batch, groups)
+        out = {}
+        for g, key in (("tv", "t_v"), ("tva", "t_va"), ("ta", "t_a")):
+            if g not in groups:
+                continue
+            step = stepper(model, g, b, kv_layers, ranges, prompt_cpu)
+            out["generated_answers_" + key] = decode_beam(step, b, beam, max_len) if beam > 1 else decode_greedy(step, b, max_len)[0]
         return out
     finally:
         model.train(was_training)

@@ -39,6 +39,7 @@ PROMPTS = {
     "mlm_tv": "predict masked tokens with visual cues",                        # pretrain.py:505
     "mlm_ta": "predict masked tokens with audio cues",                         # pretrain.py:516
     "contra": "project language in common space",                              # pretrain.py:256
+    "qa": "answer the question",                                               # pretrain.py:1270
 }
 
 
@@ -140,6 +141,7 @@ class VALOR(nn.Module):
         self.use_task_prompt = bool(_opt(opts, "use_task_prompt", False))
         self.contra_loss_ratio = float(_opt(opts, "contra_loss_ratio", 1.0))
         self.beam_size = int(_opt(opts, "beam_size", 3))                      # train_utils.py:692, :635
+        self.beam_size_qa = int(_opt(opts, "beam_size_qa", 1))                # train_utils.py:693
         self.max_generation_len = int(_opt(opts, "max_generation_len", 30))
         self.p_drop = float(_opt(opts, "dropout", 0.1))          # bert json / base_cfg 0.1, train_utils.py:617
         new_names = tuple(_opt(opts, "new_params_name", ()) or ())
@@ -629,7 +631,7 @@ class VALOR(nn.Module):
         h = ops.linear(rows, P["cls.dense.weight"], P["cls.dense.bias"], ACT_GELU_ERF)
         return ops.layer_norm(h, P["cls.layernorm.weight"], P["cls.layernorm.bias"], 1e-12)
 
-    def _decoder_groups(self, txt_input, txt_labels, groups, prompt_cpu, casual, kv_layers, ranges, b, compute_loss, tag, out):
+    def _decoder_groups(self, txt_input, txt_labels, groups, prompt_cpu, casual, kv_layers, ranges, b, compute_loss, tag, out, per_sample=False):
         """Run the decoder for len(groups) query groups as ONE batch (same text input, different K/V rows)."""
         G, T = len(groups), txt_input.shape[1]
         ids = self._dev(txt_input)
@@ -654,6 +656,12 @@ class VALOR(nn.Module):
         h = self.cls_transform(rows)
         P = self.P
         labels = self._dev(txt_labels[sel].repeat(G))
+        if compute_loss and per_sample:
+            # forward_qa_single (pretrain.py:1282-1290): CE summed per sample / that sample's masked-token count, then the mean over
+            # samples (and over groups: G * b equally weighted segments). Rows are ordered (group, sample, position).
+            counts = sel.sum(dim=1).tolist() * G
+            losses = ops.decoder_xent_segments(h, P["multimodal_encoder.embeddings.word_embeddings.weight"], P["cls.decoder.bias"], labels, counts)
+            return sum(losses) / len(losses)
         if compute_loss:
             # equal row counts per group: the mean over all G*n rows == mean of the per-group means (pretrain.py:473-479)
             return ops.decoder_xent(h, P["multimodal_encoder.embeddings.word_embeddings.weight"], P["cls.decoder.bias"], labels)
@@ -741,7 +749,9 @@ class VALOR(nn.Module):
             return self.forward_ret(batch, task, compute_loss=compute_loss)
         if task.startswith("cap"):
             return self.forward_cap(batch, task, compute_loss=compute_loss)
-        raise NotImplementedError("'pt_*', 'ret%*' and 'cap%*' tasks are built; 'qa%*' (model/pretrain.py:1191-1459) is not (DESIGN.md section 7)")
+        if task.startswith("qa"):
+            return self.forward_qa(batch, task, compute_loss=compute_loss)
+        raise NotImplementedError(f"task {task!r}: 'pt_*', 'ret%*', 'cap%*' and 'qa%*' are the reference's task families (pretrain.py:125-135)")
 
     def forward_ret(self, batch, task, compute_loss=True):
         """VALOR.forward_ret, model/pretrain.py:544-711 (config/fast-retrieval-*.json: 'ret%tva%tv'): the contrastive branch of forward_pt
@@ -759,6 +769,37 @@ class VALOR(nn.Module):
             return self._forward_groups(batch, [], groups, [], True)
         from .. import decode
         return decode.generate_cap(self, batch, groups)
+
+    def qa_prompt(self, question_cpu):
+        """the prompt rows of the QA passes are the QUESTION (prompt-type embeddings), 'answer the question' spliced in behind its [CLS]
+        when use_task_prompt (model/pretrain.py:1268-1274)"""
+        if not self.use_task_prompt:
+            return question_cpu
+        tp = self.get_task_prompt(PROMPTS["qa"], question_cpu.shape[0])[:, 1:-1]
+        return torch.cat((question_cpu[:, 0:1], tp, question_cpu[:, 1:]), dim=1)
+
+    def forward_qa(self, batch, task, compute_loss=True):
+        """VALOR.forward_qa, model/pretrain.py:1191-1459 (config/VQA-*.json: 'qa%tva%tv') for ONE answer per question -- every
+        answer_nums / sample_num entry 1, the video-QA datasets. (Image QA tiles the question and the video rows per candidate answer,
+        :1243-1265: a row -> K|V index the cross-attention kernels do not take; it raises.) Loss: forward_qa_single :1212-1345 --
+        TokenMasker p = 0.99 on the answer, causal decoder with the question as prompt rows, per-sample-normalised CE. Otherwise
+        generate_qa :1366-1459 -> valor_amd.decode with beam_size_qa."""
+        groups = [g for g in ("tva", "tv", "ta") if g in task.split("%")[1:]]
+        prompt = self.qa_prompt(batch["question_tokens"]["bert_tokens"].cpu())
+        if not compute_loss:
+            from .. import decode
+            return decode.generate_qa(self, batch, groups, prompt)
+        if any(int(n) != 1 for n in batch.get("answer_nums", [1])):
+            raise NotImplementedError("multi-answer questions (image QA, pretrain.py:1243-1265) are not built")
+        self.stage.begin_step()
+        txt = batch["txt_tokens"]["bert_tokens"].cpu()
+        qa_in, qa_lab = self.text_masker(txt, 0.99)
+        alltasks = "".join(groups)
+        video_output = self.forward_video_encoder(batch["video_pixels"]) if "v" in alltasks else None
+        audio_output = self.forward_audio_encoder(batch["audio_spectrograms"]) if "a" in alltasks else None
+        kv_layers, ranges = self.cross_inputs(video_output, audio_output)
+        loss = self._decoder_groups(qa_in, qa_lab, groups, prompt, True, kv_layers, ranges, txt.shape[0], True, "qa", {}, per_sample=True)
+        return {"qa_loss": loss}
 
     def forward_pt(self, batch, task, compute_loss=True):
         """VALOR.forward_pt, model/pretrain.py:214-541."""

@@ -331,7 +331,7 @@ def make_state_dict(spec: ValorSpec, seed: int = 50, w_std: float = 0.02, bf16_e
 
 
 def make_batch(spec: ValorSpec, batch: int, frames: int = 8, audio_slices: int = 2, txt_len: int = 32, seed: int = 50,
-               bf16_exact: bool = False):
+               bf16_exact: bool = False, questions: bool = False, question_len: int = 12):
     """Synthetic batch with the schema of data/data.py:423-428 (valor_collate), CPU tensors.
     bf16_exact: pixels / spectrograms are bf16-representable fp32 values (see make_state_dict)."""
     g = torch.Generator(device="cpu").manual_seed(seed)
@@ -348,12 +348,20 @@ def make_batch(spec: ValorSpec, batch: int, frames: int = 8, audio_slices: int =
         clip[i, 0] = spec.clip_vocab - 2
         clip[i, 1:1 + n] = torch.randint(min(1000, spec.clip_vocab // 2), spec.clip_vocab - 2, (n,), generator=g)
         clip[i, 1 + n] = spec.clip_vocab - 1
-    return {"ids": list(range(batch)), "txt_tokens": {"bert_tokens": bert, "clip_tokens": clip},
-            "video_pixels": video, "audio_spectrograms": audio}
+    out = {"ids": list(range(batch)), "txt_tokens": {"bert_tokens": bert, "clip_tokens": clip},
+           "video_pixels": video, "audio_spectrograms": audio}
+    if questions:       # video-QA schema (data/vqa.py:143-190): a question per clip, txt_tokens are then the answers, one answer per question
+        qb = torch.zeros((batch, question_len), dtype=torch.long)
+        for i in range(batch):
+            n = int(torch.randint(3, question_len - 1, (1,), generator=g))
+            qb[i, 0] = 101; qb[i, 1:1 + n] = torch.randint(lo, spec.vocab, (n,), generator=g); qb[i, 1 + n] = 102
+        out.update(question_tokens={"bert_tokens": qb, "clip_tokens": torch.zeros_like(qb)}, answer_weights=[1.0] * batch,
+                   answer_nums=[1] * batch, sample_num=[1] * batch)
+    return out
 
 
 PROMPT_WORDS = ("describe the video with natural language predict masked tokens visual and audio cues project "
-                "in common space").split()
+                "in common space answer question").split()
 
 
 def synthetic_vocab(size: int = 30522):
