@@ -181,7 +181,7 @@ def test_component_checkpoint_mappings_are_the_reference_constructors(variant):
             continue
         assert rsd[k].shape == v.shape and torch.equal(rsd[k].float(), v.float()), k
         produced += 1
-    assert produced > {"clip": 250, "swin": 600, "clip_large_bert": 250}[variant]
+    assert produced > {"clip": 250, "swin": 550, "clip_large_bert": 250}[variant]       # swin: 351 VideoSwin + 197 AST + 45 two-layer-BERT tensors = 593
     if variant != "swin":
         assert mine["clip_model.visual.positional_embedding"].shape[0] == (224 // (16 if variant == "clip" else 14)) ** 2 + 1
     assert mine["audio_embeddings.position_embeddings.weight"].shape == (129, 768)
