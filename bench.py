@@ -231,6 +231,10 @@ def main():
     # stream) around every 4th valor_gemm launch; 4 instrumented steps with a rotating offset cover every launch once.
     timer.enabled = True
     n_inst = 4
+    # kernel durations are only meaningful when the kernel has the chip to itself: the instrumented steps run the encoders on ONE
+    # stream (the timed region above runs them on two, valor_amd/streams.py)
+    two_streams = os.environ.get("VALOR_ENCODER_STREAMS")
+    os.environ["VALOR_ENCODER_STREAMS"] = "0"
     t1 = time.perf_counter()
     for _ in range(n_inst):
         engine.train_step(batch, TASK)
@@ -238,6 +242,10 @@ def main():
     sync()
     inst_elapsed = (time.perf_counter() - t1) / n_inst
     timer.enabled = False
+    if two_streams is None:
+        del os.environ["VALOR_ENCODER_STREAMS"]
+    else:
+        os.environ["VALOR_ENCODER_STREAMS"] = two_streams
     t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
     if world > 1:
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)

@@ -28,7 +28,10 @@ def _worker(rank, world, port, fn, ret):
 def _run(fn, world=2):
     mgr = mp.Manager()
     ret = mgr.dict()
-    port = 29500 + (os.getpid() % 1000)
+    import socket
+    with socket.socket() as sk:                # a free port (the reference harness keeps one open in this process on 296xx)
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
     mp.spawn(_worker, args=(world, port, fn, ret), nprocs=world, join=True)
     return [ret[r] for r in range(world)]
 

@@ -91,7 +91,10 @@ def test_two_ranks_match_the_reference_semantics(dev, tmp_path):
     spec, sd, full = _setup()
     import valor_oracle as VO
     from valor_amd import synth
-    port = 29700 + (os.getpid() % 200)
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
     mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
     res = [torch.load(os.path.join(str(tmp_path), f"rank{r}.pt"), weights_only=False) for r in range(2)]
 
@@ -198,7 +201,10 @@ def test_rccl_collectives_execute(dev, tmp_path):
     """the collectives of valor_amd.dist over the nccl backend (= RCCL) on the GPU box: one rank is all a 1-GPU box offers, but
     all_reduce / reduce_scatter_tensor + all_gather_into_tensor / the packed feature gather all go through RCCL's kernels and
     must hand back the input unchanged (bench.py --gpus N runs the same calls with N ranks)."""
-    port = 29900 + (os.getpid() % 90)
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
     mp.spawn(_nccl_worker, args=(1, port, str(tmp_path)), nprocs=1, join=True)
     res = torch.load(os.path.join(str(tmp_path), "nccl.pt"))
     assert res == {"allreduce": True, "rs_ag": True, "fp32": True, "gather": True}, res

@@ -144,9 +144,13 @@ class Reducer:
         s, e = self.bucket_range[i]
         buf = self.arena.grad[s:e]
         if self.comm_stream is not None:
-            ev = torch.cuda.Event(); ev.record()
+            from . import streams
+            evs = []
+            for cs in streams.compute_streams(buf.device):      # gradient writes may be in flight on the encoders' side stream too
+                ev = torch.cuda.Event(); ev.record(cs); evs.append(ev)
             with torch.cuda.stream(self.comm_stream):
-                self.comm_stream.wait_event(ev)
+                for ev in evs:
+                    self.comm_stream.wait_event(ev)
                 self.works += self._reduce(buf)
         else:
             self.works += self._reduce(buf)

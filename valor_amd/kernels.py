@@ -36,7 +36,8 @@ def _check_gpu(*ts):
 
 def workspace(device, nbytes=_WS_BYTES):
     """Persistent fp32 scratch (split-K partials, column-sum partials)."""
-    key = (device.index if device.index is not None else torch.cuda.current_device())
+    # one per (device, stream): two compute streams (valor_amd/streams.py) must not share split-K / column-sum partials
+    key = (device.index if device.index is not None else torch.cuda.current_device(), torch.cuda.current_stream(device).cuda_stream)
     ws = _WS.get(key)
     if ws is None or ws.numel() * 4 < nbytes:
         ws = torch.empty(nbytes // 4, dtype=torch.float32, device=device)

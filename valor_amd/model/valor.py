@@ -26,7 +26,7 @@ import numpy as np
 import torch
 from torch import nn
 
-from .. import ops
+from .. import ops, streams
 from ..arena import ParamArena
 from ..hoststage import HostStage
 from ..lib import ACT_GELU_ERF, ACT_QUICK_GELU, ACT_RELU
@@ -832,11 +832,26 @@ class VALOR(nn.Module):
                 mlm_in, mlm_lab = self.text_masker(txt, 0.15)
         alltasks = "".join(mlm_task + caption_task + contra_task)
         video_output = audio_output = txt_output = None
+        clip_text = "t" in "".join(contra_task) and sp.txt_encoder != "bert"
+        # the audio encoder and the CLIP text tower on a second stream beside the video encoder (valor_amd/streams.py); the shared-BERT
+        # text pass stays on this stream (its weight gradients land in the same arena slots as the decoder's)
+        side = None
+        if streams.enabled() and self.device.type == "cuda" and "v" in alltasks and ("a" in alltasks or clip_text):
+            side = streams.side_stream(self.device)
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                if "a" in alltasks:
+                    audio_output = self.forward_audio_encoder(batch["audio_spectrograms"])
+                if clip_text:
+                    clip_tokens = txt_tokens["clip_tokens"].cpu()
+                    txt_output = self.forward_txt_encoder(clip_tokens)
         if "v" in alltasks:
             video_output = self.forward_video_encoder(batch["video_pixels"])
-        if "a" in alltasks:
+        if side is not None:
+            audio_output, txt_output = streams.join(side, audio_output, txt_output)
+        if "a" in alltasks and audio_output is None:
             audio_output = self.forward_audio_encoder(batch["audio_spectrograms"])
-        if "t" in "".join(contra_task):
+        if "t" in "".join(contra_task) and txt_output is None:
             if sp.txt_encoder == "bert":                          # get_text_tokens: the bert ids (pretrain.py:252)
                 clip_tokens = txt_tokens["bert_tokens"].cpu()
                 txt_output = self.forward_txt_encoder_bert(clip_tokens)
