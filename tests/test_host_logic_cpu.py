@@ -121,7 +121,7 @@ def test_unsupported_configs_fail_loudly():
         VALOR({"fineweight_type": "none"}, spec=synth.tiny_spec(), dtype=torch.float32, device="cpu")
     m = VALOR(None, spec=synth.tiny_spec(), dtype=torch.float32, device="cpu")
     with pytest.raises(NotImplementedError):
-        m({}, task="qa%tv")      # ret% and cap% are built (tests/test_finetune_gpu.py); qa% is not
+        m({}, task="scst%tv")    # pt_ / ret% / cap% / qa% are the task families of VALOR.forward (tests/test_finetune_gpu.py)
 
 
 def test_param_tables_of_the_swin_and_large_configurations():
