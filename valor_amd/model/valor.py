@@ -571,8 +571,23 @@ class VALOR(nn.Module):
         P = self.P
         va_slot = ops.GradSlot()
         self._kv_slots = [ops.GradSlot() for _ in range(self.spec.layers)]
-        return [ops.linear(va_input, P[f"multimodal_encoder.encoder.layer.{i}.cross_attn.cross.kv.weight"],
-                           P[f"multimodal_encoder.encoder.layer.{i}.cross_attn.cross.kv.bias"], grad_slot=va_slot) for i in range(self.spec.layers)]
+        proj = lambda x, i: ops.linear(x, P[f"multimodal_encoder.encoder.layer.{i}.cross_attn.cross.kv.weight"],
+                                       P[f"multimodal_encoder.encoder.layer.{i}.cross_attn.cross.kv.bias"], grad_slot=va_slot)
+        if not (streams.enabled() and self.device.type == "cuda"):
+            return [proj(va_input, i) for i in range(self.spec.layers)]
+        # The 12 projections are chip-filling GEMMs (117 k rows), the decoder layers that consume them are not (8.8 k rows): on the side
+        # stream they run BESIDE the decoder layers -- layer i waits for its own projection only -- and in backward each layer's
+        # dgrad / wgrad pair runs there as soon as that layer's dK|dV is complete, beside the lower layers' backward (streams.py).
+        side = streams.side_stream(self.device)
+        va_s = streams.fork(side, va_input)
+        items = []
+        with torch.cuda.stream(side):
+            for i in range(self.spec.layers):
+                kv = proj(va_s, i)
+                ev = torch.cuda.Event()
+                ev.record(side)
+                items.append((kv, ev))
+        return streams.LazyTensors(side, items)
 
     def cross_inputs(self, video_output, audio_output):
         """get_multimodal_forward_input_video / _audio (modeling.py:485-502) + the K|V projections of every decoder layer.

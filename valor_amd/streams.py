@@ -58,6 +58,9 @@ class _Join(Function):
         side = ctx.side
         # runs once the whole graph has been executed, on the stream backward() was called from
         Variable._execution_engine.queue_callback(lambda: torch.cuda.current_stream().wait_stream(side))
+        for g in grads:
+            if g is not None:
+                g.record_stream(side)      # produced here, consumed by the side stream's backward kernels
         return (None,) + grads
 
 
@@ -69,3 +72,55 @@ def join(side, *tensors):
         return tensors
     outs = iter(_Join.apply(side, *live))
     return tuple(next(outs) if t is not None else None for t in tensors)
+
+
+class _Fork(Function):
+    """hand a tensor of the current stream to `side`; in backward the current stream waits for EVERYTHING queued on `side` -- the
+    consumers there may have accumulated into one gradient buffer after the first of them returned it to autograd (ops.GradSlot)."""
+
+    @staticmethod
+    def forward(ctx, side, t):
+        side.wait_stream(torch.cuda.current_stream())
+        t.record_stream(side)
+        ctx.side = side
+        return t.view_as(t)
+
+    @staticmethod
+    def backward(ctx, g):
+        torch.cuda.current_stream().wait_stream(ctx.side)
+        return None, g
+
+
+def fork(side, t):
+    return _Fork.apply(side, t)
+
+
+class _Await(Function):
+    @staticmethod
+    def forward(ctx, side, ev, t):
+        cur = torch.cuda.current_stream()
+        cur.wait_event(ev)
+        t.record_stream(cur)
+        ctx.side = side
+        return t.view_as(t)
+
+    @staticmethod
+    def backward(ctx, g):
+        if g is not None:
+            g.record_stream(ctx.side)
+        return None, None, g
+
+
+class LazyTensors:
+    """tensors produced one after the other on a side stream, each with the event that marks it complete: indexing makes the
+    CURRENT stream wait for that one tensor only (a decoder layer starts as soon as ITS K|V projection is done)"""
+
+    def __init__(self, side, items):
+        self.side, self.items = side, items
+
+    def __len__(self):
+        return len(self.items)
+
+    def __getitem__(self, i):
+        t, ev = self.items[i]
+        return _Await.apply(self.side, ev, t)
