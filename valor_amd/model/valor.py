@@ -832,6 +832,8 @@ class VALOR(nn.Module):
         """The body of VALOR.forward_pt (model/pretrain.py:226-541) on parsed group lists; forward_ret / forward_cap run it with one branch."""
         P, sp = self.P, self.spec
         self.stage.begin_step()
+        if self.device.type == "cuda":
+            streams.set_main(self.device)
         out = {}
         col = self.collect
         txt_tokens = batch.get("txt_tokens")

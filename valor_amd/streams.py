@@ -32,14 +32,25 @@ def side_stream(device):
     return s
 
 
-def compute_streams(device):
-    """every stream gradient writes may be in flight on: the current one and the side stream if it exists"""
+_MAIN = {}
+
+
+def set_main(device):
+    """remember the stream a step is issued from (VALOR._forward_groups calls this at the top of every forward)"""
     device = torch.device(device)
     key = device.index if device.index is not None else torch.cuda.current_device()
-    out = [torch.cuda.current_stream(device)]
-    s = _SIDE.get(key)
-    if s is not None and s != out[0]:
-        out.append(s)
+    _MAIN[key] = torch.cuda.current_stream(device)
+
+
+def compute_streams(device):
+    """every stream gradient writes may be in flight on: the step's main stream, the side stream if it exists, and the current one
+    (inside a backward node of the side stream the CURRENT stream is the side stream: the main stream must still be waited for)"""
+    device = torch.device(device)
+    key = device.index if device.index is not None else torch.cuda.current_device()
+    out = []
+    for s in (_MAIN.get(key), _SIDE.get(key), torch.cuda.current_stream(device)):
+        if s is not None and all(s != o for o in out):
+            out.append(s)
     return out
 
 
