@@ -221,12 +221,17 @@ def main():
     for _ in range(args.warmup):
         engine.train_step(batch, TASK)
     sync()
+    seg0 = torch.cuda.memory_stats().get("segment.all.allocated", 0)       # device allocations (hipMalloc) so far
     t0 = time.perf_counter()
     last = None
+    step_ms = []
     for _ in range(args.steps):
+        ts = time.perf_counter()
         last = engine.train_step(batch, TASK)
+        step_ms.append((time.perf_counter() - ts) * 1e3)                    # host time of the (asynchronous) step, no sync inside the region
     sync()
     elapsed = time.perf_counter() - t0
+    seg1 = torch.cuda.memory_stats().get("segment.all.allocated", 0)
     # roofline pass: the SAME step, run right after the timed region, with a HIP-event pair (recorded on the launch
     # stream) around every 4th valor_gemm launch; 4 instrumented steps with a rotating offset cover every launch once.
     timer.enabled = True
@@ -294,6 +299,8 @@ def main():
                           "dropout": args.dropout, "task": TASK},
                "losses": {k: round(float(v), 4) for k, v in last.items()},
                "peak_mem_gb": round(torch.cuda.max_memory_allocated() / 2 ** 30, 1),
+               "reserved_mem_gb": round(torch.cuda.memory_reserved() / 2 ** 30, 1),
+               "timed_region": {"device_allocations": int(seg1 - seg0), "host_ms_per_step": [round(x, 1) for x in step_ms]},
                "roofline": roof}
         if world == 1 and not args.no_cpu_baseline:
             try:

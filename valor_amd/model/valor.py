@@ -20,6 +20,7 @@ Design differences (MI355X-first, results identical):
     round trip, modeling.py:134-174 runs on CPU in the reference too).
 """
 import math
+import os
 import random
 
 import numpy as np
@@ -573,8 +574,12 @@ class VALOR(nn.Module):
         self._kv_slots = [ops.GradSlot() for _ in range(self.spec.layers)]
         proj = lambda x, i: ops.linear(x, P[f"multimodal_encoder.encoder.layer.{i}.cross_attn.cross.kv.weight"],
                                        P[f"multimodal_encoder.encoder.layer.{i}.cross_attn.cross.kv.bias"], grad_slot=va_slot)
-        if not (streams.enabled() and self.device.type == "cuda"):
+        if not (streams.enabled() and self.device.type == "cuda" and os.environ.get("VALOR_KV_STREAM", "0") == "1"):
             return [proj(va_input, i) for i in range(self.spec.layers)]
+        # OFF by default: measured -1.5 % step time on top of the encoder overlap, but the 12 x 360 MB K|V tensors and their gradients cross
+        # streams, and the caching allocator cannot reuse a block recorded on another stream until the GPU has passed it: with the host
+        # running a step ahead the reserved memory crept 62 -> 71 GB over 20 steps with a hipMalloc every other step (session S). It
+        # needs static per-layer K|V / dK|dV buffers first.
         # The 12 projections are chip-filling GEMMs (117 k rows), the decoder layers that consume them are not (8.8 k rows): on the side
         # stream they run BESIDE the decoder layers -- layer i waits for its own projection only -- and in backward each layer's
         # dgrad / wgrad pair runs there as soon as that layer's dK|dV is complete, beside the lower layers' backward (streams.py).
