@@ -273,3 +273,49 @@ def test_swin_padded_geometry_maps():
         idx = m._swin_merge_idx(b, D, H, W)
         rows = torch.cat((x.reshape(-1, 5), torch.zeros(1, 5)))[idx]                              # index -1 -> the appended zero row
         assert torch.equal(rows.reshape(want.shape), want)
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference/config"), reason="/root/reference not present")
+def test_every_shipped_config_file_parses_and_names_a_built_task_family():
+    """config/*.json of the reference (pretraining, fast-retrieval-*, caption-*, VQA-*): load_config accepts each file as shipped
+    (two lack their closing brace), train_tasks lists its task strings, and every one belongs to a family VALOR.forward dispatches
+    (pt_ / ret% / cap% / qa%, model/pretrain.py:125-135) with groups this build runs (tva / tv / ta)."""
+    import glob
+    from valor_amd.config import load_config, train_tasks
+    files = sorted(glob.glob("/root/reference/config/*.json"))
+    assert len(files) >= 20
+    seen = set()
+    for f in files:
+        opts = load_config(f)
+        tasks = train_tasks(opts)
+        assert tasks, f
+        for task, bs in tasks:
+            fam = task.split("_")[0] if task.startswith("pt") else task.split("%")[0]
+            assert fam in ("pt", "ret", "cap", "qa"), (f, task)
+            seen.add(fam)
+            groups = [g for part in (task.split("_")[1:] if fam == "pt" else [task]) for g in part.split("%")[1:]]
+            assert groups and all(g in ("tva", "tv", "ta") for g in groups), (f, task)
+        assert opts.video_resolution == 224 and opts.beam_size == 3 and opts.beam_size_qa == 1        # argparse defaults carried through
+    assert seen == {"pt", "ret", "cap", "qa"}
+
+
+def test_qa_prompt_splices_the_task_prompt_behind_cls():
+    """model/pretrain.py:1268-1274: question rows as the prompt; with use_task_prompt 'answer the question' goes between the question's
+    [CLS] and its first word -- native helper == oracle helper"""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle"))
+    from valor_oracle import Oracle
+    from valor_amd import synth
+    from valor_amd.model.valor import VALOR
+    spec = synth.tiny_spec()
+    q = synth.make_batch(spec, batch=3, frames=1, audio_slices=1, txt_len=8, seed=2, questions=True)["question_tokens"]["bert_tokens"]
+    for prompt in (False, True):
+        m = VALOR({"dropout": 0.0, "use_task_prompt": prompt}, spec=spec, dtype=torch.float32, device="cpu")
+        o = Oracle(spec, {}, vocab_tokens=synth.synthetic_vocab(spec.vocab), use_task_prompt=prompt)
+        got, want = m.qa_prompt(q), o.qa_prompt(q)
+        assert torch.equal(got, want)
+        if prompt:
+            assert got.shape[1] == q.shape[1] + 3 and torch.equal(got[:, 0], q[:, 0]) and torch.equal(got[:, 4:], q[:, 1:])
+            assert (got[:, 1:4] != 100).all()                      # 'answer', 'the', 'question' are vocabulary words, not [UNK]
+        else:
+            assert got is q
