@@ -617,8 +617,9 @@ class Oracle:
         return torch.cat((question_tokens[:, 0:1], tp, question_tokens[:, 1:]), dim=1)
 
     def forward_qa(self, batch, task, compute_loss=True, beam_size_qa=1, max_generation_len=30):
-        """VALOR.forward_qa -> forward_qa_single (loss) / generate_qa, model/pretrain.py:1191-1459, for one answer per question (every
-        answer_nums / sample_num entry 1: the video-QA datasets; the multi-answer tiling of image QA :1243-1265 is not restated).
+        """VALOR.forward_qa -> forward_qa_single (loss) / generate_qa, model/pretrain.py:1191-1459. Loss: one answer per question (the
+        video-QA datasets) or several weighted candidates (image QA: question / video / audio rows tiled per answer, :1243-1265, loss
+        rows weighted and summed over the QUESTION count :1288-1290); generation: one question per clip (sample_num all 1).
         Loss :1276-1290: TokenMasker p = 0.99 on the answer tokens, per-SAMPLE mean of the masked-token CE, mean over samples, mean over groups."""
         groups = task.split("%")[1:]
         q = batch["question_tokens"]["bert_tokens"]
@@ -629,7 +630,13 @@ class Oracle:
         video_input, audio_input = self.multimodal_inputs(video_output, audio_output, bs)
         prompt = self.qa_prompt(q)
         if compute_loss:
-            assert all(int(n) == 1 for n in batch["answer_nums"])
+            nums = [int(n) for n in batch["answer_nums"]]
+            tile = not all(n == 1 for n in nums)                      # image QA: several weighted candidate answers per question, :1243-1265
+            if tile:
+                rep = torch.tensor(nums)
+                prompt = self.qa_prompt(q.repeat_interleave(rep, dim=0))
+                video_input = video_input.repeat_interleave(rep, dim=0) if video_input is not None else None
+                audio_input = audio_input.repeat_interleave(rep, dim=0) if audio_input is not None else None
             txt_input, txt_labels = self.text_masker(batch["txt_tokens"]["bert_tokens"], 0.99)
             lo = []
             for g in ("tva", "tv", "ta"):
@@ -638,7 +645,8 @@ class Oracle:
                     scores = self.cls_head(o[:, :txt_input.shape[1]])
                     b, n, c = scores.shape
                     loss = F.cross_entropy(scores.reshape(b * n, c), txt_labels.reshape(b * n), ignore_index=-1, reduction="none").reshape(b, n)
-                    lo.append((loss.sum(dim=-1) / (txt_labels != -1).sum(dim=-1)).mean())
+                    loss = loss.sum(dim=-1) / (txt_labels != -1).sum(dim=-1)
+                    lo.append((loss * torch.as_tensor(batch["answer_weights"], dtype=loss.dtype)).sum() / len(nums) if tile else loss.mean())
             return {"qa_loss": sum(lo) / len(lo)}
         assert all(int(n) == 1 for n in batch["sample_num"])
         ev = {}                                                                                  # generate_qa :1366-1459

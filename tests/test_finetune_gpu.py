@@ -92,8 +92,17 @@ def test_tiny_fp32_finetune_tasks_and_generation_match_oracle(dev, variant, prom
     for k in ("generated_answers_t_va", "generated_answers_t_v", "generated_answers_t_a"):
         assert torch.equal(oq1[k], nq1[k].cpu()), (k, oq1[k], nq1[k])
         assert torch.equal(oq3[k], nq3[k].cpu()), (k, oq3[k], nq3[k])
+    # --- image QA: several weighted candidate answers per question (answer rows tiled answer-major over the SAME K|V rows)
+    mb = synth.make_batch(spec, batch=3, frames=2, audio_slices=2, txt_len=10, seed=8, questions=True, answers_per_question=[2, 1, 3])
+    random.seed(4)
+    o = orc.forward(mb, "qa%tva%tv", compute_loss=True)
+    random.seed(4)
+    n = model(mb, task="qa%tva%tv", compute_loss=True)
+    assert abs(float(o["qa_loss"]) - float(n["qa_loss"])) <= 1e-4 * abs(float(o["qa_loss"])), (float(o["qa_loss"]), float(n["qa_loss"]))
+    n["qa_loss"].backward()
+    model.zero_grad()
     with pytest.raises(NotImplementedError):
-        model(dict(qb, answer_nums=[2, 1, 1]), task="qa%tv", compute_loss=True)
+        model(dict(qb, sample_num=[2, 1, 1]), task="qa%tv", compute_loss=False)
 
 
 @pytest.mark.parametrize("name", ["ref_base_b2f2a1_ft", "ref_swin_b2f2a1_ft"])

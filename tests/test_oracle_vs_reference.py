@@ -349,3 +349,21 @@ def test_video_qa_task(prompt):
         og = orc.forward_qa(batch, "qa%tva%ta", compute_loss=False, max_generation_len=5)
         for k in ("generated_answers_t_va", "generated_answers_t_a"):
             assert torch.equal(rg[k], og[k]), (k, rg[k], og[k])
+
+
+def test_image_qa_with_several_weighted_answers():
+    """forward_qa_single's tile_feats branch (model/pretrain.py:1243-1265,1288-1290; data/vqa.py:181-189): answer_nums = [2, 1, 3] ->
+    six answer rows, the question / video / audio rows tiled per answer, loss rows weighted and summed over the three questions."""
+    from valor_amd import synth
+    from valor_oracle import Oracle, trainable_copy
+    spec = synth.base_spec()
+    sd = synth.make_state_dict(spec, seed=50)
+    ref = ref_harness.build_reference(None, state_dict=sd, dropout=0.0)
+    orc = Oracle(spec, trainable_copy(sd), vocab_tokens=synth.synthetic_vocab(spec.vocab))
+    batch = synth.make_batch(spec, batch=3, frames=1, audio_slices=1, txt_len=8, seed=52, questions=True, answers_per_question=[2, 1, 3])
+    with torch.no_grad():
+        random.seed(6)
+        r = ref({k: (dict(v) if isinstance(v, dict) else v) for k, v in batch.items()}, task="qa%tva%tv", compute_loss=True)
+        random.seed(6)
+        o = orc.forward(batch, "qa%tva%tv", compute_loss=True)
+    assert abs(float(r["qa_loss"]) - float(o["qa_loss"])) <= 2e-5 * abs(float(r["qa_loss"])), (float(r["qa_loss"]), float(o["qa_loss"]))

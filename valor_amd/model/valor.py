@@ -651,7 +651,8 @@ class VALOR(nn.Module):
         h = ops.linear(rows, P["cls.dense.weight"], P["cls.dense.bias"], ACT_GELU_ERF)
         return ops.layer_norm(h, P["cls.layernorm.weight"], P["cls.layernorm.bias"], 1e-12)
 
-    def _decoder_groups(self, txt_input, txt_labels, groups, prompt_cpu, casual, kv_layers, ranges, b, compute_loss, tag, out, per_sample=False):
+    def _decoder_groups(self, txt_input, txt_labels, groups, prompt_cpu, casual, kv_layers, ranges, b, compute_loss, tag, out, per_sample=False,
+                        kv_b=None):
         """Run the decoder for len(groups) query groups as ONE batch (same text input, different K/V rows)."""
         G, T = len(groups), txt_input.shape[1]
         ids = self._dev(txt_input)
@@ -667,7 +668,8 @@ class VALOR(nn.Module):
         kv_range = None
         if kv_layers is not None:
             kv_range = self._dev(torch.tensor([list(ranges[g]) for g in groups for _ in range(b)], dtype=torch.int32))
-        hidden = self.bert_encoder(x, mask, kv_layers, kv_range, b if kv_layers is not None else 0)
+        # kv_b: the K|V batch when it is smaller than the text rows (row r attends to clip r % kv_b: answer-major tiled rows of image QA)
+        hidden = self.bert_encoder(x, mask, kv_layers, kv_range, (kv_b or b) if kv_layers is not None else 0)
         sel = (txt_labels != -1)
         bi, tj = sel.nonzero(as_tuple=True)                      # host tensors, row-major order == boolean indexing order
         n = bi.numel()
@@ -679,9 +681,11 @@ class VALOR(nn.Module):
         if compute_loss and per_sample:
             # forward_qa_single (pretrain.py:1282-1290): CE summed per sample / that sample's masked-token count, then the mean over
             # samples (and over groups: G * b equally weighted segments). Rows are ordered (group, sample, position).
-            counts = sel.sum(dim=1).tolist() * G
-            losses = ops.decoder_xent_segments(h, P["multimodal_encoder.embeddings.word_embeddings.weight"], P["cls.decoder.bias"], labels, counts)
-            return sum(losses) / len(losses)
+            counts = sel.sum(dim=1).tolist()
+            rows = [r for r, c in enumerate(counts) if c > 0]            # padding rows of a tiled batch carry no labels
+            losses = ops.decoder_xent_segments(h, P["multimodal_encoder.embeddings.word_embeddings.weight"], P["cls.decoder.bias"], labels,
+                                               [counts[r] for r in rows] * G)
+            return torch.stack(losses).view(G, len(rows)), rows
         if compute_loss:
             # equal row counts per group: the mean over all G*n rows == mean of the per-group means (pretrain.py:473-479)
             return ops.decoder_xent(h, P["multimodal_encoder.embeddings.word_embeddings.weight"], P["cls.decoder.bias"], labels)
@@ -799,27 +803,42 @@ class VALOR(nn.Module):
         return torch.cat((question_cpu[:, 0:1], tp, question_cpu[:, 1:]), dim=1)
 
     def forward_qa(self, batch, task, compute_loss=True):
-        """VALOR.forward_qa, model/pretrain.py:1191-1459 (config/VQA-*.json: 'qa%tva%tv') for ONE answer per question -- every
-        answer_nums / sample_num entry 1, the video-QA datasets. (Image QA tiles the question and the video rows per candidate answer,
-        :1243-1265: a row -> K|V index the cross-attention kernels do not take; it raises.) Loss: forward_qa_single :1212-1345 --
-        TokenMasker p = 0.99 on the answer, causal decoder with the question as prompt rows, per-sample-normalised CE. Otherwise
-        generate_qa :1366-1459 -> valor_amd.decode with beam_size_qa."""
+        """VALOR.forward_qa, model/pretrain.py:1191-1459 (config/VQA-*.json: 'qa%tva%tv'). Loss: forward_qa_single :1212-1345 --
+        TokenMasker p = 0.99 on the answer rows, causal decoder with the question as prompt rows, per-row-normalised CE; one answer per
+        question (video QA: the mean over samples) or several weighted candidates (image QA, `answer_nums` / `answer_weights`: weighted
+        rows summed over the question count). Otherwise generate_qa :1366-1459 -> valor_amd.decode with beam_size_qa (one question per
+        clip)."""
         groups = [g for g in ("tva", "tv", "ta") if g in task.split("%")[1:]]
         prompt = self.qa_prompt(batch["question_tokens"]["bert_tokens"].cpu())
         if not compute_loss:
             from .. import decode
             return decode.generate_qa(self, batch, groups, prompt)
-        if any(int(n) != 1 for n in batch.get("answer_nums", [1])):
-            raise NotImplementedError("multi-answer questions (image QA, pretrain.py:1243-1265) are not built")
         self.stage.begin_step()
         txt = batch["txt_tokens"]["bert_tokens"].cpu()
-        qa_in, qa_lab = self.text_masker(txt, 0.99)
+        nums = [int(n) for n in batch.get("answer_nums", [1] * txt.shape[0])]
+        b = len(nums)
+        qa_in, qa_lab = self.text_masker(txt, 0.99)                 # in the reference's row order (sample-major): the draw order is the contract
+        weights = None
+        if any(n != 1 for n in nums):
+            # image QA (pretrain.py:1243-1265): the reference tiles question / video / audio rows per candidate answer. Here the answer
+            # rows are laid out ANSWER-major and padded to max(nums) * b rows, so that row r belongs to clip r % b -- the K|V addressing
+            # the cross-attention kernels have -- and no K|V row is copied; padding rows repeat a real row with every label -1.
+            nmax, start = max(nums), np.concatenate(([0], np.cumsum(nums)))
+            src = np.array([start[i] + (j if j < nums[i] else 0) for j in range(nmax) for i in range(b)])
+            valid = np.array([j < nums[i] for j in range(nmax) for i in range(b)])
+            qa_in, qa_lab = qa_in[src], qa_lab[src].clone()
+            qa_lab[torch.from_numpy(~valid)] = -1
+            prompt = prompt.repeat(nmax, 1)
+            w = torch.as_tensor(batch["answer_weights"], dtype=torch.float32).reshape(-1)
+            weights = w[src[valid]]                                  # rows with labels, in the padded order
         alltasks = "".join(groups)
         video_output = self.forward_video_encoder(batch["video_pixels"]) if "v" in alltasks else None
         audio_output = self.forward_audio_encoder(batch["audio_spectrograms"]) if "a" in alltasks else None
         kv_layers, ranges = self.cross_inputs(video_output, audio_output)
-        loss = self._decoder_groups(qa_in, qa_lab, groups, prompt, True, kv_layers, ranges, txt.shape[0], True, "qa", {}, per_sample=True)
-        return {"qa_loss": loss}
+        L, rows = self._decoder_groups(qa_in, qa_lab, groups, prompt, True, kv_layers, ranges, qa_in.shape[0], True, "qa", {}, per_sample=True, kv_b=b)
+        if weights is None:
+            return {"qa_loss": L.mean()}                            # mean over samples, mean over groups (:1290,1338-1343)
+        return {"qa_loss": ((L * self._dev(weights)).sum(dim=1) / b).mean()}      # weighted rows summed over the QUESTION count (:1288-1289)
 
     def forward_pt(self, batch, task, compute_loss=True):
         """VALOR.forward_pt, model/pretrain.py:214-541."""

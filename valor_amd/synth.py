@@ -331,7 +331,7 @@ def make_state_dict(spec: ValorSpec, seed: int = 50, w_std: float = 0.02, bf16_e
 
 
 def make_batch(spec: ValorSpec, batch: int, frames: int = 8, audio_slices: int = 2, txt_len: int = 32, seed: int = 50,
-               bf16_exact: bool = False, questions: bool = False, question_len: int = 12):
+               bf16_exact: bool = False, questions: bool = False, question_len: int = 12, answers_per_question=None):
     """Synthetic batch with the schema of data/data.py:423-428 (valor_collate), CPU tensors.
     bf16_exact: pixels / spectrograms are bf16-representable fp32 values (see make_state_dict)."""
     g = torch.Generator(device="cpu").manual_seed(seed)
@@ -357,6 +357,16 @@ def make_batch(spec: ValorSpec, batch: int, frames: int = 8, audio_slices: int =
             qb[i, 0] = 101; qb[i, 1:1 + n] = torch.randint(lo, spec.vocab, (n,), generator=g); qb[i, 1 + n] = 102
         out.update(question_tokens={"bert_tokens": qb, "clip_tokens": torch.zeros_like(qb)}, answer_weights=[1.0] * batch,
                    answer_nums=[1] * batch, sample_num=[1] * batch)
+        if answers_per_question is not None:      # image-QA schema (data/vqa.py:181-189): sum(nums) answer rows, a weight per row
+            nums = [int(n) for n in answers_per_question]
+            assert len(nums) == batch
+            R = sum(nums)
+            ab = torch.zeros((R, txt_len), dtype=torch.long)
+            for r in range(R):
+                n = int(torch.randint(2, txt_len - 1, (1,), generator=g))
+                ab[r, 0] = 101; ab[r, 1:1 + n] = torch.randint(lo, spec.vocab, (n,), generator=g); ab[r, 1 + n] = 102
+            w = torch.rand((R,), generator=g) * 0.7 + 0.3
+            out.update(txt_tokens={"bert_tokens": ab, "clip_tokens": torch.zeros_like(ab)}, answer_weights=w, answer_nums=nums)
     return out
 
 
