@@ -481,7 +481,7 @@ class Oracle:
             col.update(feat_t=feat_t, feat_v=feat_v, feat_a=feat_a)
             if compute_loss:
                 losses = []
-                maskA = (txt_tokens_contra != 0).long()
+                maskA = (txt_tokens_contra != 0).long() if feat_t is not None else None
                 if "tva" in contra_task:                                                         # pretrain.py:311-336
                     feat_va = torch.cat((feat_v, feat_a), dim=1)
                     maskB = torch.ones(*feat_va.shape[:2]).long()
@@ -501,6 +501,24 @@ class Oracle:
                     sm = self.compute_fine_matrix(feat_t, feat_a, maskA, maskB, self.fine_weight("text", feat_t),
                                                   self.fine_weight("audio", feat_a))
                     col["score_ta"] = sm
+                    losses.append(self.contrastive_loss(sm))
+                ones = lambda f: torch.ones(*f.shape[:2]).long()
+                if "va" in contra_task:                                                          # :346-352
+                    sm = self.compute_fine_matrix(feat_v, feat_a, ones(feat_v), ones(feat_a), self.fine_weight("video", feat_v),
+                                                  self.fine_weight("audio", feat_a))
+                    col["score_va"] = sm
+                    losses.append(self.contrastive_loss(sm))
+                if "vta" in contra_task:                                                         # :354-361
+                    sm = self.compute_fine_matrix(feat_v, torch.cat((feat_t, feat_a), dim=1), ones(feat_v), torch.cat((maskA, ones(feat_a)), dim=1),
+                                                  self.fine_weight("video", feat_v),
+                                                  torch.cat((self.fine_weight("text", feat_t), self.fine_weight("audio", feat_a)), dim=1))
+                    col["score_vta"] = sm
+                    losses.append(self.contrastive_loss(sm))
+                if "atv" in contra_task:                                                         # :363-370
+                    sm = self.compute_fine_matrix(feat_a, torch.cat((feat_t, feat_v), dim=1), ones(feat_a), torch.cat((maskA, ones(feat_v)), dim=1),
+                                                  self.fine_weight("audio", feat_a),
+                                                  torch.cat((self.fine_weight("text", feat_t), self.fine_weight("video", feat_v)), dim=1))
+                    col["score_atv"] = sm
                     losses.append(self.contrastive_loss(sm))
                 out["contra_loss"] = sum(losses) / len(losses) * self.contra_loss_ratio
             else:

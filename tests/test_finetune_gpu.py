@@ -50,6 +50,14 @@ def test_tiny_fp32_finetune_tasks_and_generation_match_oracle(dev, variant, prom
         oe, ne = orc.forward(batch, "ret%tva%tv", compute_loss=False), model(batch, task="ret%tva%tv", compute_loss=False)
     for k in ("feat_t", "feat_v", "feat_a"):
         assert torch.allclose(oe[k], ne[k].float().cpu(), atol=2e-5), k
+    # --- the groups without text on the query side: video-audio, video -> [text | audio], audio -> [text | video] (pretrain.py:346-370)
+    for task in ("ret%va", "ret%vta%atv", "pt_contra%tva%va%atv"):
+        with torch.no_grad():
+            o = orc.forward(batch, task, compute_loss=True)
+        n = model(batch, task=task, compute_loss=True)
+        assert abs(float(o["contra_loss"]) - float(n["contra_loss"])) <= 1e-4 * abs(float(o["contra_loss"])), (task, float(o["contra_loss"]), float(n["contra_loss"]))
+        n["contra_loss"].backward()
+        model.zero_grad()
     # --- caption finetune loss
     random.seed(2)
     o = orc.forward(batch, "cap%tva%tv", compute_loss=True)

@@ -367,3 +367,14 @@ def test_image_qa_with_several_weighted_answers():
         random.seed(6)
         o = orc.forward(batch, "qa%tva%tv", compute_loss=True)
     assert abs(float(r["qa_loss"]) - float(o["qa_loss"])) <= 2e-5 * abs(float(r["qa_loss"])), (float(r["qa_loss"]), float(o["qa_loss"]))
+
+
+def test_contrastive_groups_without_text_on_the_query_side(setup):
+    """'va' / 'vta' / 'atv' (model/pretrain.py:346-370, forward_ret :653-680): video-audio alignment, and video / audio queries against the
+    concatenated text + other-modality tokens -- retrieval finetune and pretraining grammar."""
+    spec, ref, orc, sd_o, batch = setup
+    with torch.no_grad():
+        for task in ("ret%va", "ret%vta%atv", "pt_contra%tva%va%atv"):
+            r = ref(batch, task=task, compute_loss=True)
+            o = orc.forward(batch, task, compute_loss=True)
+            assert abs(float(r["contra_loss"]) - float(o["contra_loss"])) <= 2e-5 * abs(float(r["contra_loss"])), (task, float(r["contra_loss"]), float(o["contra_loss"]))

@@ -1,3 +1,3 @@
 #!/bin/bash
 cd ${GRAFT_REPO_ROOT:-/root/repo}; mkdir -p gpurun_out
-timeout 60 python -m pytest tests/test_finetune_gpu.py -q -m gpu -x -k "tiny" > gpurun_out/pytest_w.log 2>&1; echo "pytest rc=$?"; tail -4 gpurun_out/pytest_w.log | cut -c1-300
+timeout 120 python -m pytest tests/test_finetune_gpu.py -q -m gpu -x -k "tiny" > gpurun_out/pytest_w.log 2>&1; echo "pytest rc=$?"; tail -4 gpurun_out/pytest_w.log | cut -c1-300

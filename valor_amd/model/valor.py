@@ -938,10 +938,12 @@ class VALOR(nn.Module):
                     k = P["clip_model.logit_scale"].float().exp()                # 1/temp, modeling.py:420-426
                 else:
                     k = 1.0 / P["contra_temp"].float()
-                maskA = (tok_contra != 0).float().contiguous() if tok_contra.is_cuda else self._dev((tok_contra != 0).float()).contiguous()
+                maskA = None
+                if tok_contra is not None:
+                    maskA = (tok_contra != 0).float().contiguous() if tok_contra.is_cuda else self._dev((tok_contra != 0).float()).contiguous()
                 fw = lambda name, f: ops.rowdot(ops.linear(f, P[f"{name}_fine_weight.0.weight"], P[f"{name}_fine_weight.0.bias"], ACT_RELU),
                                                 P[f"{name}_fine_weight.2.weight"], P[f"{name}_fine_weight.2.bias"]).float().squeeze(-1)
-                wt = fw("text", feat_t)
+                wt = fw("text", feat_t) if feat_t is not None else None
                 wv = fw("video", feat_v) if feat_v is not None else None
                 wa = fw("audio", feat_a) if feat_a is not None else None
                 ones = lambda f: torch.ones(f.shape[:2], dtype=torch.float32, device=self.device)
@@ -953,8 +955,18 @@ class VALOR(nn.Module):
                     losses.append(ops.fine_contrastive(feat_t, feat_v, wt.contiguous(), wv.contiguous(), maskA, ones(feat_v), k))
                 if "ta" in contra_task:
                     losses.append(ops.fine_contrastive(feat_t, feat_a, wt.contiguous(), wa.contiguous(), maskA, ones(feat_a), k))
+                if "va" in contra_task:                            # pretrain.py:346-352: video tokens against audio tokens
+                    losses.append(ops.fine_contrastive(feat_v, feat_a, wv.contiguous(), wa.contiguous(), ones(feat_v), ones(feat_a), k))
+                if "vta" in contra_task:                           # :354-361: video queries against [text | audio]
+                    fB, wB = torch.cat((feat_t, feat_a), dim=1), torch.cat((wt, wa), dim=1)
+                    losses.append(ops.fine_contrastive(feat_v, fB, wv.contiguous(), wB.contiguous(), ones(feat_v),
+                                                       torch.cat((maskA, ones(feat_a)), dim=1).contiguous(), k))
+                if "atv" in contra_task:                           # :363-370: audio queries against [text | video]
+                    fB, wB = torch.cat((feat_t, feat_v), dim=1), torch.cat((wt, wv), dim=1)
+                    losses.append(ops.fine_contrastive(feat_a, fB, wa.contiguous(), wB.contiguous(), ones(feat_a),
+                                                       torch.cat((maskA, ones(feat_v)), dim=1).contiguous(), k))
                 for g in contra_task:
-                    if g not in ("tva", "tv", "ta"):
+                    if g not in ("tva", "tv", "ta", "va", "vta", "atv"):
                         raise NotImplementedError(f"contrastive group {g}")
                 out["contra_loss"] = sum(losses) / len(losses) * contra_ratio
             else:
