@@ -112,6 +112,10 @@ FIXTURES = {
     # a batch of 16: the InfoNCE loss of a B x B score matrix averages 2B terms around ln B, so its RELATIVE sensitivity to feature noise
     # falls like 1 / (sqrt(B) ln B); B = 2 is the worst case by construction (profiles/r02_bf16_attribution_b2f2a1.json)
     "ref_base_b16f2a1_q": dict(batch_size=16, frames=2, audio_slices=1, wseed=31, bseed=32, mseed=33, bf16_exact=True, steps=1),
+    # B = 16 at the bench geometry (8 frames, 2 audio slices): 25 216 ViT token rows = 1188 tiles of 256 x 256 in the fc1 forward, a
+    # wgrad contraction of 25 216 and >= 1024-tile dgrads -- the model-level bf16 run crosses every threshold of the GEMM policy
+    # (csrc/gemm.hip use_8ph), so the 8-phase NN / NT / TT kernels are compared with the reference inside the step they are timed in
+    "ref_base_b16f8a2_q": dict(batch_size=16, frames=8, audio_slices=2, wseed=41, bseed=42, mseed=43, bf16_exact=True, steps=1),
 }
 
 

@@ -198,3 +198,40 @@ def test_component_checkpoint_mappings_are_the_reference_constructors(variant):
     odd = [k for k in missing if not ("cross_attn" in k or "prompt_embedding" in k or "pooler" in k or k.split(".")[0] in fresh)]
     assert not odd, odd[:8]
     assert torch.equal(model.state_dict()["audio_encoder.layer.3.attention.linears.1.weight"], mine["audio_encoder.layer.3.attention.linears.1.weight"])
+
+
+@pytest.mark.parametrize("order", ["model_then_optimizer", "optimizer_then_model"])
+def test_bf16_resume_keeps_fp32_masters_in_both_orders(order):
+    """bf16 mode: the optimizer's fp32 masters carry bits the bf16 parameters do not. A resume restores them from the optimizer's own
+    state dict; re-loading the model's (rounded) weights afterwards must not overwrite them (apex amp's master params survive
+    `model.load_state_dict` the same way, apex/apex/amp/_process_optimizer.py:14-22), while genuinely different weights still re-sync."""
+    from types import SimpleNamespace
+    from valor_amd.model.valor import VALOR
+    from valor_amd.optim import FusedAdamW
+    spec = synth.tiny_spec()
+    sd = synth.make_state_dict(spec, seed=3)
+    opts = SimpleNamespace(learning_rate=1e-4, weight_decay=0.01, betas=[0.9, 0.98])
+    m0 = VALOR(None, spec=spec, dtype=torch.bfloat16, device="cpu")
+    m0.load_state_dict(sd)
+    o0 = FusedAdamW(m0, opts)
+    o0.init_master_from(sd)                                  # masters = the full-precision weights: they differ from float(bf16 params)
+    assert not torch.equal(o0.master, m0.arena.flat.float())
+    ck_model = {k: v.clone() for k, v in m0.state_dict().items()}
+    ck_opt = o0.state_dict()
+
+    m1 = VALOR(None, spec=spec, dtype=torch.bfloat16, device="cpu")
+    o1 = FusedAdamW(m1, opts)
+    if order == "model_then_optimizer":
+        m1.load_state_dict(ck_model)
+        o1.load_state_dict(ck_opt)
+    else:
+        o1.load_state_dict(ck_opt)
+        m1.load_state_dict(ck_model)
+    assert torch.equal(o1.master, o0.master)                 # low-order bits survive either order
+    assert torch.equal(m1.arena.flat, m0.arena.flat)
+    # different weights loaded behind the optimizer's back still win over the stale masters
+    sd2 = synth.make_state_dict(spec, seed=4)
+    m1.load_state_dict(sd2)
+    assert torch.equal(o1.master.to(torch.bfloat16), m1.arena.flat)
+    changed = o1.master != o0.master
+    assert torch.equal(o1.master[changed], m1.arena.flat.float()[changed])

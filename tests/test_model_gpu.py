@@ -277,24 +277,39 @@ BF16_LOSS_TOL = 1e-3          # north_star: losses within 1e-3 relative of the r
 # 1 / (sqrt(B) ln B). With bf16 GEMM operands the encoder outputs carry ~0.9 % relative L2 error after 12 layers (the same figure
 # comes out of a CPU emulation of bf16 storage, tools/precision_emulator.py: it is the format, not a kernel), which moves the B = 2
 # loss by 1-3e-3 whatever the contrastive head does (the head kernels agree with an fp64 head on the same features to 3e-7:
-# profiles/r02_bf16_attribution_b2f2a1.json). B = 2 fixtures therefore hold the contrastive loss to 5e-3; the B = 16 fixture -- and
-# the benchmarked B = 64 all the more -- to the north-star's 1e-3.
+# profiles/r02_bf16_attribution_b2f2a1.json). Only the smallest fixture (B = 2, 2 frames, 1 audio slice: a 2 x 2 score matrix over 2 + 1
+# video / audio tokens) still holds the contrastive loss to 5e-3 (1.4e-3 .. 3.1e-3 measured, depending on the kernel build); the B = 2
+# fixtures at the bench geometry (8 frames + 2 audio slices average more tokens: 3.7e-4 / 3.2e-4 measured), the B = 16 fixtures -- and
+# the benchmarked B = 64 all the more -- are held to the north-star's 1e-3.
 BF16_CONTRA_TOL_B2 = 5e-3
+BF16_CONTRA_LOOSE = ("ref_base_b2f2a1_q",)
 BF16_TIE_BAND = 0.05          # absolute logit gap below which the fp32 reference's own argmax is a near-tie for bf16 storage
 
 
-@pytest.mark.parametrize("name", ["ref_base_b16f2a1_q", "ref_base_b2f2a1_q", "ref_base_b2f8a2_q", "ref_swin_b2f8a2_q"])
+@pytest.mark.parametrize("name", ["ref_base_b16f2a1_q", "ref_base_b2f2a1_q", "ref_base_b2f8a2_q", "ref_swin_b2f8a2_q", "ref_base_b16f8a2_q"])
 def test_bf16_meets_north_star_on_identical_tensors(dev, name):
     """perf mode -- the arithmetic bench.py times (bf16 storage, fp32 accumulate) -- against the fp32 reference on IDENTICAL
     tensors (weights / pixels / spectrograms are bf16-representable, so nothing is rounded on load): all three losses within
-    1e-3 relative (the contrastive loss of the B = 2 fixtures: 5e-3, see BF16_CONTRA_TOL_B2); argmax token ids equal to the reference's on every masked row whose fp32 top-1 / top-2 logit gap exceeds
+    1e-3 relative (the contrastive loss of ref_base_b2f2a1_q only: 5e-3, see BF16_CONTRA_TOL_B2); argmax token ids equal to the reference's on every masked row whose fp32 top-1 / top-2 logit gap exceeds
     BF16_TIE_BAND (rows inside the band cannot be decided by ANY evaluation with 8 mantissa bits: at random init the logits have
-    std ~0.5 and the gaps go down to 1e-4); the overall match rate is printed. b2f8a2 = the bench geometry."""
+    std ~0.5 and the gaps go down to 1e-4); the overall match rate is printed. b2f8a2 = the bench geometry; b16f8a2 = the bench
+    geometry at a batch whose GEMMs take the dispatch bench.py times (25 216 ViT rows: 8-phase NN / NT / TT kernels, asserted)."""
     g = torch.load(os.path.join(GOLD, name + ".pt"), weights_only=False)
     rc = g["recipe"]
     assert rc["bf16_exact"]
     spec, sd, batch = _recipe_tensors(rc)
     model = _native(spec, sd, torch.bfloat16, dev)
+    if name == "ref_base_b16f8a2_q":
+        # this fixture exists to put the step's big GEMMs on the kernels bench.py times: check the default policy's choice for its shapes
+        from valor_amd import lib
+        so = lib.load()
+        M = rc["batch"] * rc["frames"] * spec.vis_tokens
+        W, I = spec.vis_width, 4 * spec.vis_width
+        assert M == 25216
+        for (ta, tb, m, n, k) in [(0, 0, M, I, W), (0, 0, M, 3 * W, W), (0, 0, M, W, I),          # forward: fc1, qkv, fc2
+                                  (0, 1, M, I, W),                                                # dgrad of fc2 (1188 tiles, saved-derivative multiply)
+                                  (1, 1, I, W, M), (1, 1, W, I, M), (1, 1, 3 * W, W, M)]:         # wgrad: contraction over the 25 216 tokens
+            assert so.valor_gemm_kernel_for(0, ta, tb, m, n, k, 0) == 3, (ta, tb, m, n, k)
     with torch.no_grad():
         random.seed(rc["masker_seed"])
         ev = model(batch, task=rc["task"], compute_loss=False)
@@ -317,7 +332,7 @@ def test_bf16_meets_north_star_on_identical_tensors(dev, name):
     print(f"bf16 vs reference [{name}]: losses (native, reference, rel err) {rep}; argmax ids equal on {same}/{total} masked rows "
           f"({decided} rows with a reference gap > {BF16_TIE_BAND}, all equal)")
     for k, (a, v, e) in rep.items():
-        tol = BF16_CONTRA_TOL_B2 if (k == "contra_loss" and rc["batch"] < 16) else BF16_LOSS_TOL
+        tol = BF16_CONTRA_TOL_B2 if (k == "contra_loss" and name in BF16_CONTRA_LOOSE) else BF16_LOSS_TOL
         assert e <= tol, (k, a, v, e, tol)
     ng = _native_grads(model)
     tot = float(torch.sqrt(sum((x.float() ** 2).sum() for x in ng.values())))

@@ -597,6 +597,9 @@ static int attn_check(const AttnArgs& p, int dtype) {
     if (((uintptr_t)p.q & 15) || ((uintptr_t)p.k & 15) || ((uintptr_t)p.v & 15)) return VALOR_ERR_ARG;
     if ((p.o_rs & 3) || (p.o_bs & 3)) return VALOR_ERR_ARG;
     if (p.p_drop < 0.f || p.p_drop >= 1.f) return VALOR_ERR_ARG;
+    // attn_drop_bits (attn_common.h) multiplies the element index q * Skv + key as a 24-bit integer: beyond 2^24 elements per
+    // (batch, head) dropout masks would alias between elements -- refuse instead (the model's largest shape: 42 x 3410 = 1.4e5)
+    if (p.p_drop > 0.f && (int64_t)p.Sq * p.Skv >= (1ll << 24)) return VALOR_ERR_ARG;
     return VALOR_OK;
 }
 

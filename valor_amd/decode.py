@@ -179,7 +179,9 @@ def generate_qa(model, batch, groups, prompt_cpu, beam_size=None, max_generation
     question rows as the prompt -> {'generated_answers_t_v' | '_t_va' | '_t_a'}."""
     if any(int(n) != 1 for n in batch.get("sample_num", [1])):
         raise NotImplementedError("several questions per clip (sample_num > 1, pretrain.py:1378-1390) are not built")
-    beam = model.beam_size_qa if beam_size is None else beam_size
+    # the reference switches to beam search when beam_size_qa > 1 but decode_beam always searches with self.beam_size, task 'qa'
+    # included (pretrain.py:1061): beam_size_qa is the switch, beam_size the width
+    beam = (model.beam_size if model.beam_size_qa > 1 else 1) if beam_size is None else beam_size
     max_len = model.max_generation_len if max_generation_len is None else max_generation_len
     was_training = model.training
     model.eval()

@@ -72,6 +72,7 @@ class PrefetchLoader:
         self.device = torch.device(device)
         self.stream = torch.cuda.Stream(device=self.device)
         self._pinned = [{}, {}]
+        self._slot_events = [None, None]      # "the copies out of this pinned slot have finished"
         self._flip = 0
 
     def __len__(self):
@@ -83,8 +84,14 @@ class PrefetchLoader:
     def _stage(self, item):
         name, batch = item if isinstance(item, tuple) else (None, item)
         out = dict(batch)
-        pins = self._pinned[self._flip]
+        slot = self._flip
+        pins = self._pinned[slot]
         self._flip ^= 1
+        # the H2D copies of the batch staged two calls ago read this pinned slot asynchronously: the host must not overwrite it before
+        # they have finished (the GPU-side wait_stream in __iter__ orders kernels, not the host's writes)
+        ev = self._slot_events[slot]
+        if ev is not None:
+            ev.synchronize()
         with torch.cuda.stream(self.stream):
             for k in self.DEVICE_KEYS:
                 t = batch.get(k)
@@ -96,6 +103,9 @@ class PrefetchLoader:
                     pins[k] = buf
                 buf.copy_(t)
                 out[k] = buf.to(self.device, non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record(self.stream)
+            self._slot_events[slot] = ev
         return (name, out) if name is not None else out
 
     def __iter__(self):

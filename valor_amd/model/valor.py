@@ -165,7 +165,7 @@ class VALOR(nn.Module):
     # ------------------------------------------------------------------ checkpoint layout
     @classmethod
     def from_pretrained(cls, opts, state_dict, **kw):
-        """modeling.py:107-115: construct (randomly initialised modules, init_weights :90-105), then load `state_dict` with
+        """modeling.py:107-115: construct (randomly initialised modules, see init_parameters), then load `state_dict` with
         strict=False. The reference's constructor also reads the CLIP / BERT / AST / VideoSwin component weights from
         ./pretrained_weights (modeling.py:512-660); here those come through `state_dict` (valor_amd.checkpoint.load_pretrained_components
         maps the component files to VALOR keys), and whatever `state_dict` does not cover keeps its initialisation. The keys that
@@ -179,20 +179,35 @@ class VALOR(nn.Module):
             model.missing_keys = [r for _, _, refs in model.table for r in refs if r != "cls.decoder.weight"]
         return model
 
+    # nn.Linear modules the reference constructs OUTSIDE BertModel and never re-initialises: VALORModel.init_weights (modeling.py:92-105)
+    # is defined but not applied anywhere; only BertModel applies init_bert_weights (bert.py:747). They keep torch's nn.Linear default.
+    _TORCH_DEFAULT_LINEAR = ("contra_head_", "text_fine_weight.", "video_fine_weight.", "audio_fine_weight.", "hidden_trans_video_multimodal.0.",
+                             "hidden_trans_audio_multimodal.0.", "cls.dense.")
+
     def init_parameters(self, seed=42):
-        """The reference's initialisation (modeling.py:90-105 init_weights: Linear / Embedding weights N(0, 0.02), LayerNorm
-        gain 1, biases 0; :338-341 type / frame embeddings 0.02 N(0,1); pretrain.py:117 contra_temp 0.07; clip.py:295
-        logit_scale ln(1/0.07)); every rank seeds the same generator, so replicas start identical (TrainEngine broadcasts rank 0's
-        arena besides). Component weights (CLIP, VideoSwin, AST, BERT) are pretrained in the reference; without their files they
-        get the same N(0, 0.02) / 1 / 0 policy."""
+        """Initialisation of whatever a checkpoint does not cover, following what the reference's constructor leaves behind:
+        the multimodal BERT gets init_bert_weights (bert.py:617-630,747: Linear / Embedding weights N(0, 0.02), LayerNorm gain 1,
+        biases 0); the nn.Linear modules outside it (Contra_head, the *_fine_weight MLPs, hidden_trans_*, cls.dense) keep torch's default
+        -- weight and bias U(-1/sqrt(fan_in), 1/sqrt(fan_in)) -- because VALORModel.init_weights (modeling.py:92-105) is never applied;
+        modeling.py:338-341 type / frame embeddings 0.02 N(0,1); pretrain.py:117 contra_temp 0.07; clip.py:295 logit_scale ln(1/0.07).
+        Every rank seeds the same generator, so replicas start identical (TrainEngine broadcasts rank 0's arena besides). Component
+        weights (CLIP, VideoSwin, AST, BERT) are pretrained in the reference; without their files they get N(0, 0.02) / 1 / 0."""
         from ..synth import state_dict_layout
         kinds = {k: kind for k, _, kind in state_dict_layout(self.spec)}
         gen = torch.Generator(device="cpu").manual_seed(int(seed))
+        fan_in = {}
+        for name, shape, refs in self.table:
+            if refs[0].startswith(self._TORCH_DEFAULT_LINEAR) and refs[0].endswith(".weight"):
+                fan_in[refs[0][:-len("weight")]] = int(shape[-1])
         with torch.no_grad():
             for name, shape, refs in self.table:
                 kind = kinds.get(refs[0], "w")
                 p = self.P[name]
-                if kind == "g":
+                mod = refs[0].rsplit(".", 1)[0] + "."
+                if mod in fan_in and kind in ("w", "b"):
+                    bound = 1.0 / math.sqrt(fan_in[mod])
+                    p.copy_(((2.0 * torch.rand(shape, generator=gen) - 1.0) * bound).to(p.dtype))
+                elif kind == "g":
                     p.fill_(1.0)
                 elif kind == "b":
                     p.zero_()

@@ -81,10 +81,15 @@ class FusedAdamW:
         model._optimizers.append(weakref.ref(self))
 
     def sync_master(self):
-        """fp32 masters := current parameters (bf16 mode). Called by VALOR.load_state_dict / init_parameters, so loading weights AFTER
-        the optimizer exists cannot be overwritten by stale masters on the next step."""
+        """Re-derive the fp32 masters from the current parameters (bf16 mode) -- element by element, and ONLY where a master no longer
+        rounds to its parameter. Called by VALOR.load_state_dict / init_parameters, so weights loaded AFTER the optimizer exists cannot
+        be overwritten by stale masters on the next step; masters that are still consistent with the parameters (restored by
+        load_state_dict(sd with 'master') before the model's weights were re-loaded from the same checkpoint) keep their low-order
+        bits, so both resume orders continue exactly like the uninterrupted run."""
         if self.separate_master:
-            self.master.copy_(self.arena.flat)
+            flat = self.arena.flat
+            keep = self.master.to(flat.dtype) == flat
+            torch.where(keep, self.master, flat.float(), out=self.master)
 
     def init_master_from(self, state_dict_fp32):
         """Seed the fp32 masters from full-precision weights (instead of the rounded bf16 parameters)."""
