@@ -1,6 +1,7 @@
 """bench.py -- VALOR-base tri-modal pretraining step on N MI355X of one node (data parallel, weak scaling).
 
-  python bench.py --gpus N --steps K --warmup W          (N > 1: launched by torch.distributed.run, one rank per GPU)
+  python bench.py --gpus N --steps K --warmup W          (N > 1: one rank per GPU -- under torch.distributed.run, or, started
+                                                          bare, bench.py re-executes itself under it with N ranks)
 
 Workload (BASELINE.json configs[1]/[2]): CLIP-ViT-B/16 + CLIP-text + AST + BERT-base decoder, bf16 compute
 with fp32 master weights, task pt_contra%tva%tv%ta_caption%tva%tv%ta_mlm%tva (MGA + MGC + MLM), per-GPU batch
@@ -24,7 +25,8 @@ sys.path.insert(0, ROOT)
 
 TASK = "pt_contra%tva%tv%ta_caption%tva%tv%ta_mlm%tva"
 PEAK_BF16_TFLOPS = 2500.0     # dense bf16 MFMA peak, /opt/skills/guides/MI355X_MICROARCH.md
-PMC_FILE = "r02_pmc_gemm_traffic.json" if os.path.exists(os.path.join(ROOT, "profiles", "r02_pmc_gemm_traffic.json")) else "r01_pmc_gemm_traffic.json"
+PMC_FILE = next((f for f in ("r03_pmc_gemm_traffic.json", "r02_pmc_gemm_traffic.json", "r01_pmc_gemm_traffic.json")
+                 if os.path.exists(os.path.join(ROOT, "profiles", f))), "r01_pmc_gemm_traffic.json")
 
 
 def necessary_flops_per_sample(spec, frames, audio_slices, txt_len, n_cap_groups=3, mlm_prompt=10, mask_cap=0.6, mask_mlm=0.15):
@@ -72,39 +74,121 @@ def necessary_flops_per_sample(spec, frames, audio_slices, txt_len, n_cap_groups
     return 3.0 * fwd
 
 
-def cpu_baseline(sample_batch=2, frames=8, audio_slices=2, variant="clip"):
-    """Reference CPU path as restated by the oracle (kind 'port'), fp32, all host cores, one full step."""
+def _cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def cpu_baseline(sample_batch=2, frames=8, audio_slices=2, variant="clip", timed_steps=3):
+    """The reference's CPU path on the host cores (BASELINE.md section 3 protocol: all cores, fp32, 1 warm-up + 3 timed full steps of
+    forward + backward + clip + AdamW on a bounded sample -- batch 2 of the benchmarked geometry). Where /root/reference exists (the
+    build container) the UNMODIFIED reference modules run through oracle/ref_harness.py (kind "reference"); on the GPU box, where the
+    reference tree does not travel, the oracle's restatement of the same step runs (kind "port")."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
-    import valor_oracle as VO
     from valor_amd import synth
     spec = {"clip": synth.base_spec, "swin": synth.swin_spec, "large": synth.large_spec, "clip_large": synth.clip_large_spec}[variant]()
     sd = synth.make_state_dict(spec, seed=50)
-    sd_o = VO.trainable_copy(sd)
-    orc = VO.Oracle(spec, sd_o, dropout_p=0.0, vocab_tokens=synth.synthetic_vocab(spec.vocab))
     batch = synth.make_batch(spec, batch=sample_batch, frames=frames, audio_slices=audio_slices, txt_len=32, seed=50)
-    params = {k: v for k, v in sd_o.items() if v.requires_grad and not VO.is_alias_key(k)}
-    groups = {k: VO.param_group_of(k) for k in params}
-    lrs, wds = VO.group_hparams(1e-4, 0.01)
-    state = {}
-    # warm-up: one small forward + backward (1 sample, 1 frame) pages the code in and spins the intra-op thread pool up, so the timed step
-    # below is not the first thing this process does on the host cores (a full-size warm-up step would double the bench's CPU time)
-    warm = synth.make_batch(spec, batch=1, frames=1, audio_slices=1, txt_len=32, seed=49)
-    random.seed(49)
-    sum(orc.forward_pt(warm, TASK, compute_loss=True).values()).backward()
-    for p in params.values():
-        p.grad = None
-    t0 = time.time()
+    kind = "port"
+    step = None
+    if variant in ("clip", "swin"):
+        try:
+            import ref_harness
+            if ref_harness.available():
+                ropts = None if variant == "clip" else ref_harness.default_opts(video_encoder_type="videoswin_base_k400_22k",
+                                                                                 txt_encoder_type="bert_base_uncased")
+                ref = ref_harness.build_reference(ropts, state_dict=sd, dropout=0.0)
+                from easydict import EasyDict
+                from optim.misc import build_optimizer
+                opt = build_optimizer(ref, EasyDict(learning_rate=1e-4, weight_decay=0.01, clip_lr=5e-7, clip_lr_text=5e-7, new_lr=0.0,
+                                                    decoder_lr=-1, new_params_name=[], optim="adamw", betas=[0.9, 0.98]))
+
+                def step():
+                    opt.zero_grad()
+                    sum(ref(batch, task=TASK, compute_loss=True).values()).backward()
+                    torch.nn.utils.clip_grad_norm_(ref.parameters(), 5.0)
+                    opt.step()
+                kind = "reference"
+        except Exception:
+            step = None
+    if step is None:
+        import valor_oracle as VO
+        sd_o = VO.trainable_copy(sd)
+        orc = VO.Oracle(spec, sd_o, dropout_p=0.0, vocab_tokens=synth.synthetic_vocab(spec.vocab))
+        params = {k: v for k, v in sd_o.items() if v.requires_grad and not VO.is_alias_key(k)}
+        groups = {k: VO.param_group_of(k) for k in params}
+        lrs, wds = VO.group_hparams(1e-4, 0.01)
+        state = {}
+
+        def step():
+            for p in params.values():
+                p.grad = None
+            out = orc.forward_pt(batch, TASK, compute_loss=True)
+            sum(out.values()).backward()
+            grads = {k: p.grad for k, p in params.items() if p.grad is not None}
+            VO.clip_grad_norm(grads, 5.0)
+            with torch.no_grad():
+                VO.adamw_step(params, grads, state, lrs, wds, groups)
     random.seed(50)
-    out = orc.forward_pt(batch, TASK, compute_loss=True)
-    sum(out.values()).backward()
-    grads = {k: p.grad for k, p in params.items() if p.grad is not None}
-    VO.clip_grad_norm(grads, 5.0)
-    with torch.no_grad():
-        VO.adamw_step(params, grads, state, lrs, wds, groups)
-    dt = time.time() - t0
-    return {"value": round(sample_batch / dt, 4), "unit": "samples/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"1 full step (fwd+bwd+clip+AdamW) of oracle/valor_oracle.py (the reference's CPU path restated: kind 'port'), fp32, "
-                      f"batch {sample_batch}, {frames} frames, {audio_slices} audio slices, 32 tokens, {dt:.1f} s, after a 1-sample warm-up pass"}
+    times = []
+    for i in range(1 + timed_steps):                  # step 0 = warm-up (pages the code in, spins the intra-op pool up, allocates the Adam state)
+        t0 = time.time()
+        step()
+        if i:
+            times.append(time.time() - t0)
+    mean = sum(times) / len(times)
+    what = "the UNMODIFIED reference modules (oracle/ref_harness.py)" if kind == "reference" else \
+        "oracle/valor_oracle.py (the reference's CPU path restated; /root/reference does not exist on this box)"
+    return {"value": round(sample_batch / mean, 4), "unit": "samples/s", "cores": torch.get_num_threads(), "kind": kind,
+            "cpu_model": _cpu_model(), "timed_steps": timed_steps, "step_seconds": [round(t, 2) for t in times],
+            "value_min": round(sample_batch / max(times), 4), "value_max": round(sample_batch / min(times), 4),
+            "sample": f"{timed_steps} timed full steps (fwd+bwd+clip+AdamW) after 1 warm-up step of {what}, fp32, batch {sample_batch}, "
+                      f"{frames} frames, {audio_slices} audio slices, 32 tokens; mean {mean:.1f} s per step"}
+
+
+def sim_world(model, spec, world, per_gpu_batch, frames, audio_slices, steps=5):
+    """What data parallelism ADDS to a rank's step besides the collectives, measured on this one GPU: every rank computes the
+    contrastive block on the GATHERED features (global batch = world x per-GPU batch; utils/distributed.py:38-72, pretrain.py:278-370),
+    i.e. world^2 the pairs of the single-GPU step. Times forward + backward of the three MGA groups (tva, tv, ta) on synthetic gathered
+    features at the local and at the global batch."""
+    from valor_amd import ops
+    dev = model.device
+    D, T = spec.cdim, 32
+    res = {}
+    for tag, B in (("local", per_gpu_batch), ("global", world * per_gpu_batch)):
+        g = torch.Generator(device="cpu").manual_seed(7)
+        mk = lambda n: torch.nn.functional.normalize(torch.randn(B, n, D, generator=g), dim=-1).to(dev, model.dtype).requires_grad_(True)
+        ft, fv, fa = mk(T), mk(frames), mk(audio_slices)
+        wt, wv, wa = (torch.randn(B, n, generator=g).to(dev).requires_grad_(True) for n in (T, frames, audio_slices))
+        maskA = (torch.rand(B, T, generator=g) < 0.7).float().to(dev)
+        maskA[:, 0] = 1
+        ones = lambda f: torch.ones(f.shape[:2], dtype=torch.float32, device=dev)
+        k = torch.tensor(14.3, device=dev, requires_grad=True)
+
+        def block():
+            fB, wB = torch.cat((fv, fa), dim=1), torch.cat((wv, wa), dim=1)
+            ls = [ops.fine_contrastive(ft, fB, wt, wB, maskA, ones(fB), k), ops.fine_contrastive(ft, fv, wt, wv, maskA, ones(fv), k),
+                  ops.fine_contrastive(ft, fa, wt, wa, maskA, ones(fa), k)]
+            (sum(ls) / 3).backward()
+        block()
+        torch.cuda.synchronize()
+        torch.cuda.reset_peak_memory_stats()
+        base = torch.cuda.memory_allocated()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(steps):
+            block()
+        e1.record()
+        torch.cuda.synchronize()
+        res[tag] = {"batch": B, "ms": round(e0.elapsed_time(e1) / steps, 3), "peak_extra_mb": round((torch.cuda.max_memory_allocated() - base) / 2 ** 20, 1)}
+    return {"world": world, "contrastive_ms_at_local_batch": res["local"]["ms"], "contrastive_ms_at_global_batch": res["global"]["ms"],
+            "detail": res, "what": "forward + backward of the tva / tv / ta fine-grained contrastive groups on synthetic gathered features "
+                                   "(every rank runs this on the global batch)"}
 
 
 class GemmTimer:
@@ -158,7 +242,10 @@ class GemmTimer:
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--gpus", type=int, default=None, help="ranks = GPUs of this node. Without a launcher (no WORLD_SIZE in the environment) "
+                    "N > 1 re-executes this script under torch.distributed.run with N ranks")
+    ap.add_argument("--sim-world", type=int, default=8, help="also time the contrastive block at the global batch of this many ranks "
+                    "(single-GPU runs only; 0 = off)")
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--batch", type=int, default=64, help="per-GPU batch (config: 512 global / 8 GPUs)")
@@ -173,18 +260,36 @@ def main():
                          "reference's shipped config/pretrain-VALOR-large.json (CLIP ViT-L/14 at 224 px + shared BERT-base, task prompt)")
     args = ap.parse_args()
 
+    if "WORLD_SIZE" not in os.environ and (args.gpus or 1) > 1:
+        # no launcher: become one. One process per GPU, rendezvous on the loopback address (the container hostname may not resolve).
+        import socket
+        import subprocess
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+               "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        sys.exit(subprocess.call(cmd))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus is None:
+        args.gpus = world
+    if world != args.gpus:
+        sys.exit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks")
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0")) % max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
+    backend = None
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         backend = os.environ.get("VALOR_DIST_BACKEND", "nccl")      # "gloo" only to exercise the DP path where RCCL cannot run
         if backend == "nccl":
+            if torch.cuda.device_count() < world:
+                sys.exit(f"bench.py: {world} RCCL ranks need {world} GPUs, this node shows {torch.cuda.device_count()} (one process per GPU)")
             torch.distributed.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
         else:
             torch.distributed.init_process_group(backend, rank=rank, world_size=world)
+        assert torch.distributed.get_world_size() == args.gpus
 
     from valor_amd import synth
     from valor_amd.engine import TrainEngine
@@ -298,6 +403,8 @@ def main():
         res = {"metric": f"pretrain samples/sec (V+A+T {args.variant})", "value": round(sps, 2), "unit": "samples/s", "n_gpus": world,
                "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 2), "higher_is_better": True,
                "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+               "ranks": torch.distributed.get_world_size() if world > 1 else 1, "backend": backend,
+               "rccl_version": ".".join(str(x) for x in torch.cuda.nccl.version()) if hasattr(torch.cuda, "nccl") else None,
                "config": {"workload": f"{size} tri-modal ({arch}) pretrain step, MGA+MGC+MLM, "
                                       f"{args.frames} frames x 224^2, {args.audio_slices} x 5.12 s audio, 32 tokens",
                           "per_gpu_batch": args.batch, "global_batch": world * args.batch, "parallelism": f"dp{world}",
@@ -307,6 +414,11 @@ def main():
                "reserved_mem_gb": round(torch.cuda.memory_reserved() / 2 ** 30, 1),
                "timed_region": {"device_allocations": int(seg1 - seg0), "host_ms_per_step": [round(x, 1) for x in step_ms]},
                "roofline": roof}
+        if world == 1 and args.sim_world > 1:
+            try:
+                res["dp_sim"] = sim_world(model, spec, args.sim_world, args.batch, args.frames, args.audio_slices)
+            except Exception as e:
+                res["dp_sim"] = {"error": repr(e)}
         if world == 1 and not args.no_cpu_baseline:
             try:
                 res["cpu_baseline"] = cpu_baseline(frames=args.frames, audio_slices=args.audio_slices, variant=args.variant)

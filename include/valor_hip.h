@@ -187,6 +187,22 @@ int valor_infonce_bwd(void* stream, const float* score, const float* k_dev, cons
 int valor_fine_reduce_bwd(void* stream, int dtype, const float* dscore, const float* maskA, const float* maskB,
                           const float* wA, const float* wB, const float* A2B, const float* B2A, const uint8_t* idxA,
                           const uint8_t* idxB, void* dS, int64_t ldS, float* dwA, float* dwB, int B, int T, int Nv);
+/* FUSED fine-grained contrastive (pretrain.py:191-211 without any [A*T, B*Nv] tensor): bf16 features featA [NA, T, D], featB
+ * [NB, Nv, D] (D % 64 == 0; T, Nv <= 64) -> score [NA, NB] and, unless all four are null (evaluation), A2B [NA, NB, T] / B2A
+ * [NA, NB, Nv] (the directional maxima, fp32) and their first-arg-max bytes idxA / idxB -- the outputs of valor_fine_reduce_fwd, with
+ * the token x token dot products accumulated on the matrix pipe and reduced in registers. Backward: valor_fine_weight_grad for the
+ * token weights; valor_fine_ds_chunk writes d(sims) of the texts [a0, a0 + na) as a dense [na * T, ldS] tile (column b * Nv + v) from
+ * the argmax bytes, which two valor_gemm calls per chunk contract with the features. valor_fine_set_fused: 1 (default, env
+ * VALOR_FINE_FUSED) / 0 = what the host wrapper uses; < 0 queries. */
+int valor_fine_fused_fwd(void* stream, const void* featA, const void* featB, const float* maskA, const float* maskB, const float* wA,
+                         const float* wB, float* score, float* A2B, float* B2A, uint8_t* idxA, uint8_t* idxB, int NA, int NB, int T,
+                         int Nv, int D);
+int valor_fine_ds_chunk(void* stream, int dtype, const float* dscore, const float* maskA, const float* maskB, const float* wA,
+                        const float* wB, const uint8_t* idxA, const uint8_t* idxB, void* dS, int64_t ldS, int a0, int na, int NB, int T,
+                        int Nv);
+int valor_fine_weight_grad(void* stream, const float* dscore, const float* A2B, const float* B2A, float* dwA, float* dwB, int B, int T,
+                           int Nv);
+int valor_fine_set_fused(int v);
 
 /* ---- fused multi-tensor AdamW + global-norm clip over flat arenas.  Replaces optim/adamw.py:40-103, optim/misc.py:66-77
  * (10 param groups), torch clip_grad_norm_ (train_utils.py:358-360) and apex-amp's master<->model copies

@@ -208,3 +208,22 @@ def test_rccl_collectives_execute(dev, tmp_path):
     mp.spawn(_nccl_worker, args=(1, port, str(tmp_path)), nprocs=1, join=True)
     res = torch.load(os.path.join(str(tmp_path), "nccl.pt"))
     assert res == {"allreduce": True, "rs_ag": True, "fp32": True, "gather": True}, res
+
+
+def test_bench_gpus_flag_launches_that_many_ranks():
+    """`python bench.py --gpus 2` started WITHOUT a launcher must really run two ranks (it re-executes itself under
+    torch.distributed.run) and say so in its JSON line; the two ranks share this box's one GPU over gloo (RCCL refuses duplicate devices;
+    on a multi-GPU node the same command runs one rank per GPU over RCCL). Replaces the DDP launch of scripts/pretrain.sh:3
+    (python -m torch.distributed.launch --nproc_per_node 8) for the bench."""
+    import json
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env["VALOR_DIST_BACKEND"] = "gloo"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--batch", "4", "--steps", "2", "--warmup", "1",
+                        "--frames", "2", "--audio-slices", "1", "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
+    res = json.loads(line)
+    assert res["n_gpus"] == 2 and res["ranks"] == 2 and res["backend"] == "gloo"
+    assert res["config"]["global_batch"] == 8 and res["config"]["parallelism"] == "dp2"
+    assert all(v == v and abs(v) < 1e4 for v in res["losses"].values())

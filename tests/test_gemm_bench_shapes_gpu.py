@@ -1,0 +1,147 @@
+"""The GEMM launches bench.py spends 57 % of its step in, at THE SHAPES AND UNDER THE DISPATCH it times them (default policy: the
+256 x 256 8-phase kernels with their XCD-aware raster over thousands of tiles, many rounds per CU, partial last rounds, split-K with
+fused row sums, both epilogue paths) -- against fp32 torch.matmul on the device. The model-level fixtures (B = 2) stay below the
+policy's thresholds and the kernel-variant tests force the family on single-round problems, so this file is what ties the timed
+kernels to a reference (round-2 review, weak point 1.iii).
+
+Checks per case: the kernel family the policy picks (3 = 8-phase), the Frobenius error of the whole result, and the error of EVERY
+256 x 256 output tile on its own (a mis-rastered / dropped / duplicated tile is invisible in a 4728-tile Frobenius norm).
+Shapes: per-GPU batch 64, 8 frames x 197 tokens = 100 864 ViT rows; 64 x 1834 = 117 376 cross-attention K|V rows; 2100 masked rows
+against the 30 522-word vocabulary. Reference semantics: nn.Linear / QuickGELU of model/clip.py:178-192, BertOutput bert.py:403-417,
+the tied decoder of model/modeling.py:245-254."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+M_VIT, M_KV, W, I = 100864, 117376, 768, 3072
+
+
+def _mk(shape, seed, dev, scale=1.0):
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    return (torch.randn(shape, generator=g) * scale).to(torch.bfloat16).to(dev)
+
+
+def _tile_errors(C, ref, tm=256, tn=256):
+    """(Frobenius relative error, worst per-tile relative error) of C against the fp32 reference"""
+    d = (C.float() - ref)
+    M, N = ref.shape
+    Mp, Np = (M + tm - 1) // tm * tm, (N + tn - 1) // tn * tn
+    pad = lambda x: torch.nn.functional.pad(x, (0, Np - N, 0, Mp - M))
+    e2 = pad(d * d).view(Mp // tm, tm, Np // tn, tn).sum(dim=(1, 3))
+    r2 = pad(ref * ref).view(Mp // tm, tm, Np // tn, tn).sum(dim=(1, 3))
+    whole = float(torch.sqrt(e2.sum() / r2.sum()))
+    worst = float(torch.sqrt(e2 / r2.clamp_min(1e-20)).max())
+    return whole, worst
+
+
+def _family(so, ta, tb, M, N, K, heavy=0):
+    return so.valor_gemm_kernel_for(0, int(ta), int(tb), M, N, K, heavy)
+
+
+# bf16 output rounding alone is 2^-9 relative per element (Frobenius ~1.1e-3); inputs are exact bf16, accumulation fp32
+TOL, TILE_TOL = 2.5e-3, 4e-3
+
+
+@pytest.mark.parametrize("M,N,K", [(M_VIT, I, W), (M_VIT, 3 * W, W), (M_VIT, W, I), (M_KV, 2 * W, W)])
+def test_forward_nn_plain_and_bias(dev, M, N, K):
+    """x.W^T (+ bias): ViT fc1 / qkv / fc2 and the decoder's cross K|V projection"""
+    from valor_amd import kernels as Kn, lib
+    so = lib.load()
+    assert _family(so, 0, 0, M, N, K) == 3
+    A, B, bias = _mk((M, K), 1, dev), _mk((N, K), 2, dev, 0.05), _mk((N,), 3, dev)
+    ref = A.float() @ B.float().t()
+    C = Kn.gemm(A, B)
+    whole, worst = _tile_errors(C, ref)
+    assert whole < TOL and worst < TILE_TOL, (whole, worst)
+    C = Kn.gemm(A, B, bias=bias)
+    whole, worst = _tile_errors(C, ref + bias.float())
+    assert whole < TOL and worst < TILE_TOL, (whole, worst)
+
+
+def test_forward_fc1_quickgelu_with_saved_derivative(dev):
+    """ViT fc1 as ops.MlpFn launches it: bias + QuickGELU, second output = act'(u) (VALOR_ACT_DERIV)"""
+    from valor_amd import kernels as Kn, lib
+    so = lib.load()
+    M, N, K = M_VIT, I, W
+    assert _family(so, 0, 0, M, N, K) == 3
+    A, B, bias = _mk((M, K), 4, dev), _mk((N, K), 5, dev, 0.05), _mk((N,), 6, dev, 0.5)
+    u = A.float() @ B.float().t() + bias.float()
+    sg = torch.sigmoid(1.702 * u)
+    h, d = Kn.gemm(A, B, bias=bias, act=lib.ACT_QUICK_GELU | lib.ACT_DERIV, want_preact=True)
+    whole, worst = _tile_errors(h, u * sg)
+    assert whole < TOL and worst < TILE_TOL, (whole, worst)
+    whole, worst = _tile_errors(d, sg * (1 + 1.702 * u * (1 - sg)))
+    assert whole < TOL and worst < TILE_TOL, (whole, worst)
+    # and the pre-activation flavour (VALOR_MLP_DERIV=0 / BERT-style consumers)
+    h2, u2 = Kn.gemm(A, B, bias=bias, act=lib.ACT_QUICK_GELU, want_preact=True)
+    assert torch.equal(h2, h)
+    whole, worst = _tile_errors(u2, u)
+    assert whole < TOL and worst < TILE_TOL, (whole, worst)
+
+
+def test_dgrad_nt_plain_and_saved_derivative(dev):
+    """dY.W: the fc1 dgrad (K = 3072, plain) and the fc2 dgrad whose epilogue multiplies by the saved act'(u)"""
+    from valor_amd import kernels as Kn, lib
+    so = lib.load()
+    M = M_VIT
+    assert _family(so, 0, 1, M, W, I) == 3
+    dU, W1 = _mk((M, I), 7, dev), _mk((I, W), 8, dev, 0.05)
+    dX = Kn.gemm(dU, W1, trans_b=True)
+    whole, worst = _tile_errors(dX, dU.float() @ W1.float())
+    assert whole < TOL and worst < TILE_TOL, (whole, worst)
+    del dX
+    assert _family(so, 0, 1, M, I, W, 0) == 3          # light epilogue (one multiply): 8-phase; a heavy one (act' from u) stays on 128x128
+    dY, W2, D = _mk((M, W), 9, dev), _mk((W, I), 10, dev, 0.05), _mk((M, I), 11, dev).abs().clamp_(max=1.1)
+    dU2 = Kn.gemm(dY, W2, trans_b=True, act=lib.ACT_QUICK_GELU | lib.ACT_DERIV, dact_aux=D)
+    prod = (dY.float() @ W2.float())
+    # the 8-phase tile epilogue rounds the GEMM result to bf16 before the multiply (gradient path, gemm8.hip): allow one more rounding
+    whole, worst = _tile_errors(dU2, prod * D.float())
+    assert whole < 1.5 * TOL and worst < 1.5 * TILE_TOL, (whole, worst)
+    # C += (the residual stream's gradient accumulates into an existing buffer)
+    acc0 = _mk((M, W), 12, dev)
+    out = acc0.clone()
+    Kn.gemm(dU, W1, trans_b=True, out=out, accumulate=True)
+    whole, worst = _tile_errors(out, dU.float() @ W1.float() + acc0.float())
+    assert whole < 1.5 * TOL and worst < 1.5 * TILE_TOL, (whole, worst)
+
+
+@pytest.mark.parametrize("Mo,No", [(I, W), (W, I), (3 * W, W)])
+def test_wgrad_tt_splitk_with_fused_row_sums(dev, Mo, No):
+    """dY^T.X over the 100 864 tokens: split-K over one round of workgroups, bias gradient = row sums on the matrix pipe, accumulated
+    into existing buffers (the gradient arena) like ops.MlpFn / LinearFn do"""
+    from valor_amd import kernels as Kn, lib
+    so = lib.load()
+    Kt = M_VIT
+    assert _family(so, 1, 1, Mo, No, Kt) == 3
+    dY, X = _mk((Kt, Mo), 13, dev, 0.1), _mk((Kt, No), 14, dev)
+    ref = dY.float().t() @ X.float()
+    rs_ref = dY.float().sum(dim=0)
+    dW = Kn.gemm(dY, X, trans_a=True, trans_b=True)
+    whole, worst = _tile_errors(dW, ref)
+    assert whole < TOL and worst < TILE_TOL, (whole, worst)
+    g0, b0 = _mk((Mo, No), 15, dev), _mk((Mo,), 16, dev)
+    gw, gb = g0.clone(), b0.clone()
+    assert Kn.gemm_fuses_rowsum(dY, X, True, True)
+    Kn.gemm(dY, X, trans_a=True, trans_b=True, out=gw, accumulate=True, rowsum_out=gb, rowsum_accumulate=True)
+    whole, worst = _tile_errors(gw, ref + g0.float())
+    assert whole < TOL and worst < TILE_TOL, (whole, worst)
+    err = float((gb.float() - (rs_ref + b0.float())).norm() / (rs_ref + b0.float()).norm())
+    assert err < 3e-3, err
+
+
+def test_logits_into_the_padded_vocab_buffer(dev):
+    """tied decoder: 2100 masked rows x 30 522 words, written into the [n, 30 528] buffer the cross-entropy kernel reads (N is not a
+    multiple of 8 or 256: masked tail tile columns, the general epilogue); the pad columns must stay untouched"""
+    from valor_amd import kernels as Kn, lib
+    so = lib.load()
+    n, V, Vpad = 2100, 30522, 30528
+    assert _family(so, 0, 0, n, V, W) == 3
+    h, E, b = _mk((n, W), 17, dev), _mk((V, W), 18, dev, 0.05), _mk((V,), 19, dev)
+    buf = torch.full((n, Vpad), 7.0, dtype=torch.bfloat16, device=dev)
+    Kn.gemm(h, E, bias=b, out=buf[:, :V])
+    whole, worst = _tile_errors(buf[:, :V], h.float() @ E.float().t() + b.float())
+    assert whole < TOL and worst < TILE_TOL, (whole, worst)
+    assert bool((buf[:, V:] == 7.0).all())
+    # its wgrad: [V, 768] = dlogits^T . h over 2100 rows is NOT an 8-phase problem (K < 4096) -- the policy must say so
+    assert _family(so, 1, 1, V, W, n) != 3

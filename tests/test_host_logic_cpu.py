@@ -319,3 +319,14 @@ def test_qa_prompt_splices_the_task_prompt_behind_cls():
             assert (got[:, 1:4] != 100).all()                      # 'answer', 'the', 'question' are vocabulary words, not [UNK]
         else:
             assert got is q
+
+
+def test_bench_refuses_a_rank_count_that_is_not_gpus():
+    """bench.py --gpus N under a launcher that started a different number of ranks must fail loudly, not print n_gpus of its own
+    (round-2 review: the flag was parsed and ignored)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, WORLD_SIZE="3", RANK="0", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2"], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and "WORLD_SIZE=3" in (r.stderr + r.stdout)

@@ -245,3 +245,12 @@ extern "C" int valor_fine_reduce_bwd(void* stream, int dtype, const float* dscor
     hipLaunchKernelGGL(fine_weight_grad_kernel, dim3((2 * B + 3) / 4), dim3(256), 0, st, dscore, A2B, B2A, dwA, dwB, B, T, Nv);
     return valor_launch_status();
 }
+
+// the token-weight gradients alone (the fused path builds d(sims) chunk-wise with valor_fine_ds_chunk, contrastive_fused.hip)
+extern "C" int valor_fine_weight_grad(void* stream, const float* dscore, const float* A2B, const float* B2A, float* dwA, float* dwB,
+                                      int B, int T, int Nv) {
+    if (B <= 0) return VALOR_OK;
+    if (T <= 0 || T > 64 || Nv <= 0 || Nv > 64) return VALOR_ERR_ARG;
+    hipLaunchKernelGGL(fine_weight_grad_kernel, dim3((2 * B + 3) / 4), dim3(256), 0, (hipStream_t)stream, dscore, A2B, B2A, dwA, dwB, B, T, Nv);
+    return valor_launch_status();
+}

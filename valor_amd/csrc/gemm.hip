@@ -460,12 +460,19 @@ extern "C" int valor_gemm_set_variant(int v) { const int o = g_gemm_variant; if 
 //   the big-M forward GEMMs, long-K dgrad and the wgrad GEMMs; the 128x128 kernel (4 workgroups per CU hiding each
 //   other's prologue / epilogue) for small grids, short-K dgrad and everything with a K tail.
 // [0] NT min K for the 8-phase kernel, [1] unused (was: 8-phase start skew, measured slower), [2] min 256x256 tiles (forward), [3] min 256x256 tiles (dgrad)
-int g_gemm_policy[4] = {[] { const char* e = getenv("VALOR_GEMM_NT_MINK"); return e ? atoi(e) : 768; }(),
+// [4] L2-aware tile raster of the 8-phase kernels: 0 = row-major over all tile columns, 1000 = pick the group width per problem (traffic
+//     model in launch_gemm_8ph), else a fixed number of tile columns per group
+// [5] output stores of the 8-phase kernels: 0 plain, 1 non-temporal, 2 sc1 (write-through)   [6] k-contiguous A operand fetched non-temporally
+int g_gemm_policy[8] = {[] { const char* e = getenv("VALOR_GEMM_NT_MINK"); return e ? atoi(e) : 768; }(),
                         [] { const char* e = getenv("VALOR_GEMM_SKEW"); return e ? atoi(e) : 0; }(),
                         [] { const char* e = getenv("VALOR_GEMM_MIN_TILES"); return e ? atoi(e) : 256; }(),
-                        [] { const char* e = getenv("VALOR_GEMM_NT_MIN_TILES"); return e ? atoi(e) : 1024; }()};
+                        [] { const char* e = getenv("VALOR_GEMM_NT_MIN_TILES"); return e ? atoi(e) : 1024; }(),
+                        [] { const char* e = getenv("VALOR_GEMM_RASTER"); return e ? atoi(e) : 1000; }(),
+                        [] { const char* e = getenv("VALOR_GEMM_STORE"); return e ? atoi(e) : 0; }(),
+                        [] { const char* e = getenv("VALOR_GEMM_NTA"); return e ? atoi(e) : 0; }(),
+                        0};
 extern "C" int valor_gemm_set_policy(int key, int value) {
-    if (key < 0 || key > 3) return VALOR_ERR_ARG;
+    if (key < 0 || key > 7) return VALOR_ERR_ARG;
     const int old = g_gemm_policy[key];
     if (value >= 0) g_gemm_policy[key] = value;
     return old;
@@ -619,7 +626,7 @@ extern "C" int valor_gemm(void* stream, int dtype, int transA, int transB, int M
     p.lda = lda; p.ldb = ldb; p.ldc = ldc; p.ldaux = ldaux;
     p.M = M; p.N = N; p.K = K; p.act = act; p.accumulate = accumulate; p.out_f32 = out_f32;
     p.alpha = alpha;
-    p.rowsum_out = rowsum_out; p.rowsum_acc = rowsum_accumulate; p.rowsum_ws = nullptr; p.fast_epi = 0;
+    p.rowsum_out = rowsum_out; p.rowsum_acc = rowsum_accumulate; p.rowsum_ws = nullptr; p.fast_epi = 0; p.raster_g = 0; p.st_mode = 0;
     {
         const int64_t esz = dtype == VALOR_DT_BF16 ? 2 : 4;
         // direct: rows x ld with K valid in the last row; transposed: K rows of ld elements (caller guarantees

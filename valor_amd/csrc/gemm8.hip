@@ -46,7 +46,9 @@ DEVINL bf16x8_t read_frag_tr8(const char* img, int off, int kk) {
 
 // ASMTR: the transposing reads of the k-slow operands as inline asm (mma.h: tr_issue / tr_wait / tr_frag) -- as compiler builtins
 // they drained the counted vmcnt(8) LDS-DMA pipeline three times per K-tile.
-template <bool TA, bool TB, bool ASMTR>
+// NTA: the k-contiguous A operand (activations: every 128-B line is used by the workgroups of ONE tile row, once) is fetched with the
+// non-temporal hint, so that it does not displace the weight panel (re-read by every tile row) from the XCD's L2.
+template <bool TA, bool TB, bool ASMTR, bool NTA = false>
 __global__ __launch_bounds__(512, 2) void gemm_8ph_kernel(GemmArgs p) {
     typedef bf16_t T;
     constexpr int BK = 64;
@@ -71,7 +73,18 @@ __global__ __launch_bounds__(512, 2) void gemm_8ph_kernel(GemmArgs p) {
     } else {
         logical = xcd_remap(blockIdx.x, tiles_m * tiles_n);
     }
-    const int tm = logical / tiles_n, tn = logical - tm * tiles_n;
+    int tm = logical / tiles_n, tn = logical - tm * tiles_n;
+    if (p.raster_g > 0 && p.kslices <= 1) {
+        // L2-aware raster: the tile columns are walked in groups of G; inside a group the order is row-major over G columns, so the
+        // contiguous range of logical ids an XCD owns (xcd_remap) covers G weight panels (G x 256 x K x 2 B, sized to stay resident
+        // in the XCD's 4 MiB L2 by the launcher) and streams the activation rows past them -- instead of touching all tiles_n panels
+        // every round and re-fetching each of them from the fabric once per round.
+        const int G = p.raster_g, per = G * tiles_m;
+        const int grp = logical / per, w = logical - grp * per;
+        const int gw = min(G, tiles_n - grp * G);
+        tm = w / gw;
+        tn = grp * G + (w - tm * gw);
+    }
     const int m0 = tm << 8, n0 = tn << 8;
     // (A start skew of the first round's workgroups -- so that the CUs' tile epilogues, 128 KiB of stores each, stop coinciding
     // round after round -- was measured and is SLOWER at every setting: profiles/r02_gemm_policy_ab.json.)
@@ -136,8 +149,13 @@ __global__ __launch_bounds__(512, 2) void gemm_8ph_kernel(GemmArgs p) {
     // issue one half-tile (this wave's 2 pieces) into buffer `buf`, then advance that kind to the next K-tile
     auto issueA = [&](int hf, char* buf) {
         char* d = buf + (hf ? OFF_A1 : OFF_A0) + wave * 2048;
-        glds16(rsA, d, voA[hf][0]);
-        glds16(rsA, d + 1024, voA[hf][1]);
+        if constexpr (NTA) {
+            glds16_nt(rsA, d, voA[hf][0]);
+            glds16_nt(rsA, d + 1024, voA[hf][1]);
+        } else {
+            glds16(rsA, d, voA[hf][0]);
+            glds16(rsA, d + 1024, voA[hf][1]);
+        }
         voA[hf][0] += stepA; voA[hf][1] += stepA;
     };
     auto issueB = [&](int hf, char* buf) {
@@ -356,7 +374,7 @@ __global__ __launch_bounds__(512, 2) void gemm_8ph_kernel(GemmArgs p) {
 #pragma unroll
                         for (int q = 0; q < 4; ++q) val[q] = pack2_bf16(f[2 * q], f[2 * q + 1]);
                     }
-                    *(u32x4_t*)(dst + (int64_t)m * p.ldc + n) = val;
+                    store_out16(p.st_mode, dst + (int64_t)m * p.ldc + n, val);
                 }
             }
         };
@@ -435,7 +453,31 @@ void launch_gemm_8ph(hipStream_t st, int transA, int transB, const GemmArgs& p_i
     const bool plainish = g_8ph_fast_epi >= 2 || (!p.preact && (!p.dact_aux || light_dact));
     p.fast_epi = g_8ph_fast_epi && plainish && !p.out_f32 && p.kslices <= 1 && (p.N & 7) == 0 && (p.ldc & 7) == 0 && !p.rowsum_out &&
                  (!p.dact_aux || (p.ldaux & 7) == 0) && !(p.dact_aux && p.preact) && !transA && !(p.preact && (p.act & VALOR_ACT_DERIV));
-    const int tiles = ((p.M + 255) / 256) * ((p.N + 255) / 256);
+    const int tiles_m = (p.M + 255) / 256, tiles_n = (p.N + 255) / 256;
+    const int tiles = tiles_m * tiles_n;
+    // ---- L2-aware raster (see the kernel): group width from a fabric-traffic model. Per XCD a round = 32 concurrent tiles. Row-major over
+    // all tile columns reads A once but, when the weight (tiles_n panels of 256 x K) does not survive a round in the 4 MiB L2 next to the
+    // 32 x 128 KiB of output and the A rows, re-fetches every touched panel once per round; with groups of G columns the G panels stay
+    // resident and A is read once per group.
+    p.raster_g = 0;
+    if (p.kslices <= 1 && tiles_n > 1 && g_gemm_policy[4] != 0) {
+        if (g_gemm_policy[4] != 1000) {
+            p.raster_g = g_gemm_policy[4] < tiles_n ? g_gemm_policy[4] : 0;
+        } else {
+            const double panel = 256.0 * p.K * 2.0, a_bytes = (double)p.M * p.K * 2.0, rounds = tiles / 256.0;
+            const double resident = 2.5 * 1048576.0;
+            const int touched = tiles_n < 32 ? tiles_n : 32;
+            double best = a_bytes + (tiles_n * panel <= resident ? 8.0 * tiles_n * panel : (rounds < 1.0 ? 1.0 : rounds) * 8.0 * touched * panel);
+            for (int ng = 2; ng <= tiles_n; ++ng) {
+                const int G = (tiles_n + ng - 1) / ng;
+                if (G * panel > resident) continue;
+                const double cost = ng * a_bytes + 8.0 * tiles_n * panel;
+                if (cost < 0.9 * best) { best = cost; p.raster_g = G; }     // only for a clear win: grouping shortens the A rows' reuse window
+            }
+        }
+    }
+    p.st_mode = g_gemm_policy[5];
+    const bool nta = g_gemm_policy[6] != 0 && !transA;
     dim3 grid(tiles * (p.kslices > 1 ? p.kslices : 1));
     const size_t lds = 2 * BUF_BYTES;
 #define VALOR_8PH_LAUNCH(TA_, TB_)                                                                              \
@@ -449,9 +491,21 @@ void launch_gemm_8ph(hipStream_t st, int transA, int transB, const GemmArgs& p_i
         if (g_8ph_tr_asm && (TA_ || TB_)) hipLaunchKernelGGL((gemm_8ph_kernel<TA_, TB_, true>), grid, dim3(512), lds, st, p); \
         else hipLaunchKernelGGL((gemm_8ph_kernel<TA_, TB_, false>), grid, dim3(512), lds, st, p);             \
     } while (0)
-    if (!transA && !transB) VALOR_8PH_LAUNCH(false, false);
+#define VALOR_8PH_LAUNCH_NTA(TB_, ASM_)                                                                         \
+    do {                                                                                                        \
+        static bool attr_set = false;                                                                           \
+        if (!attr_set) {                                                                                        \
+            hipFuncSetAttribute((const void*)gemm_8ph_kernel<false, TB_, ASM_, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+            attr_set = true;                                                                                    \
+        }                                                                                                       \
+        hipLaunchKernelGGL((gemm_8ph_kernel<false, TB_, ASM_, true>), grid, dim3(512), lds, st, p);           \
+    } while (0)
+    if (nta && !transB) VALOR_8PH_LAUNCH_NTA(false, false);
+    else if (nta && transB && g_8ph_tr_asm) VALOR_8PH_LAUNCH_NTA(true, true);
+    else if (!transA && !transB) VALOR_8PH_LAUNCH(false, false);
     else if (!transA && transB) VALOR_8PH_LAUNCH(false, true);
     else if (transA && !transB) VALOR_8PH_LAUNCH(true, false);
     else VALOR_8PH_LAUNCH(true, true);
 #undef VALOR_8PH_LAUNCH
+#undef VALOR_8PH_LAUNCH_NTA
 }

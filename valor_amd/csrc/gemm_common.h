@@ -23,7 +23,17 @@ struct GemmArgs {
     int rowsum_acc;            // out += sums
     int fast_epi;              // 8-phase kernels: bf16 C, no split-K / fused row sums, N % 8 == 0, ldc % 8 == 0 (ldaux % 8 == 0)
                                // -> bias / activation in registers, bf16 tile passes through LDS (see gemm8.hip)
+    int raster_g;              // 8-phase kernels: tile columns per raster group (0 = row-major over all tile columns), see gemm8.hip
+    int st_mode;               // 16-byte output stores: 0 plain, 1 non-temporal, 2 sc1 (write-through, the line leaves this XCD's L2)
 };
+
+// 16-byte store of an output chunk. The outputs of the big forward / dgrad GEMMs are written once and read by a LATER kernel: kept in
+// the XCD's 4 MiB L2 (plain stores allocate) a round of 32 tiles x 128 KiB evicts the weight panel every tile of the next round re-reads.
+DEVINL void store_out16(int mode, void* q, u32x4_t v) {
+    if (mode == 2) asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(q), "v"(v) : "memory");
+    else if (mode == 1) __builtin_nontemporal_store(v, (u32x4_t*)q);
+    else *(u32x4_t*)q = v;
+}
 
 template <typename T>
 DEVINL f32x4_t load_bias4(const GemmArgs& p, int n0) {
@@ -161,7 +171,7 @@ DEVINL void epilogue_store8(const GemmArgs& p, int m, int n0, f32x4_t a0, f32x4_
         }
         if (p.preact) {
             u32x4_t q = {pack2_bf16(q0[0], q0[1]), pack2_bf16(q0[2], q0[3]), pack2_bf16(q1[0], q1[1]), pack2_bf16(q1[2], q1[3])};
-            *(u32x4_t*)((T*)p.preact + off) = q;
+            store_out16(p.st_mode, (T*)p.preact + off, q);
         }
         if (p.dact_aux) {
             const T* a = (const T*)p.dact_aux + (int64_t)m * p.ldaux + n0;
@@ -180,9 +190,9 @@ DEVINL void epilogue_store8(const GemmArgs& p, int m, int n0, f32x4_t a0, f32x4_
     T* c = (T*)p.C + off;
     if (p.accumulate) { v0 += load4<T>(c); v1 += load4<T>(c + 4); }
     u32x4_t o = {pack2_bf16(v0[0], v0[1]), pack2_bf16(v0[2], v0[3]), pack2_bf16(v1[0], v1[1]), pack2_bf16(v1[2], v1[3])};
-    *(u32x4_t*)c = o;
+    store_out16(p.st_mode, c, o);
 }
 
 // 256x256 8-phase bf16 kernel (gemm8.hip). grid.x = tiles(256) * max(kslices, 1).
 void launch_gemm_8ph(hipStream_t st, int transA, int transB, const GemmArgs& p);
-extern int g_gemm_policy[4];      // valor_gemm_set_policy (gemm.hip)
+extern int g_gemm_policy[8];      // valor_gemm_set_policy (gemm.hip)

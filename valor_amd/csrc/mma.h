@@ -380,6 +380,10 @@ typedef __attribute__((ext_vector_type(4))) short s16x4_t;
 DEVINL void glds16(rsrc_t rs, char* lds_dst, int voff) {
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, LDS_PTR(lds_dst), 16, voff, 0, 0, 0);
 }
+// the same with the non-temporal hint (aux bit 1 = nt): streamed operands that must not displace reused lines from L2
+DEVINL void glds16_nt(rsrc_t rs, char* lds_dst, int voff) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, LDS_PTR(lds_dst), 16, voff, 0, 0, 2);
+}
 typedef __attribute__((ext_vector_type(8))) short s16x8_t;
 DEVINL s16x4_t lds_read_tr4(const char* a) {
     return __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)LDS_PTR(a));

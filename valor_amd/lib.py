@@ -57,6 +57,10 @@ SIGNATURES = {
     "valor_infonce_fwd": [_vp, _vp, _vp, _vp, _vp, _vp, _i],
     "valor_infonce_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i],
     "valor_fine_reduce_bwd": [_vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _i, _i, _i],
+    "valor_fine_fused_fwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i],
+    "valor_fine_ds_chunk": [_vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i, _i, _i, _i, _i],
+    "valor_fine_weight_grad": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i],
+    "valor_fine_set_fused": [_i],
     "valor_adamw_chunk": [],
     "valor_adamw": [_vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _c.POINTER(_f), _c.POINTER(_f), _i, _f, _f, _f, _i, _i, _vp, _i],
     "valor_grad_norm_clip": [_vp, _i, _vp, _vp, _i64, _f, _f, _vp, _vp, _vp],

@@ -569,10 +569,16 @@ def decoder_logits(h, w_emb, dec_bias):
 
 
 # ------------------------------------------------------------------------------------------------
+_FINE_CHUNK = int(os.environ.get("VALOR_FINE_CHUNK", "64"))      # texts per d(sims) tile of the fused backward
+
+
 class FineContrastFn(Function):
     """loss = InfoNCE(fine_matrix(featA, featB, masks, token weights) * k)  -- pretrain.py:191-211, modeling.py:418-433.
     featA [B,T,D], featB [B,Nv,D] (L2-normalised), wA_raw [B,T], wB_raw [B,Nv] (fp32), maskA/maskB fp32 0/1,
-    k = 1/temperature (0-dim fp32 tensor, differentiable)."""
+    k = 1/temperature (0-dim fp32 tensor, differentiable).
+    bf16 features (the benchmarked arithmetic; every rank runs this on the GATHERED batch): the fused kernels of contrastive_fused.hip --
+    the token x token similarities are accumulated and reduced in registers, the backward builds d(sims) for _FINE_CHUNK texts at a
+    time; no [B*T, B*Nv] tensor exists. fp32 parity mode (and VALOR_FINE_FUSED=0): S = featA . featB^T through valor_gemm."""
 
     @staticmethod
     def forward(ctx, featA, featB, wA_raw, wB_raw, maskA, maskB, k):
@@ -581,9 +587,8 @@ class FineContrastFn(Function):
         dev = featA.device
         f32 = dict(dtype=torch.float32, device=dev)
         fa, fb = featA.contiguous().view(B * T, D), featB.contiguous().view(B * Nv, D)
+        fused = featA.dtype == torch.bfloat16 and D % 64 == 0 and lib.load().valor_fine_set_fused(-1) == 1
         ldS = (B * Nv + 7) // 8 * 8
-        S = torch.empty((B * T, ldS), **f32)
-        K.gemm(fa, fb, out=S[:, :B * Nv], out_dtype=torch.float32)
         wA, wB = torch.empty((B, T), **f32), torch.empty((B, Nv), **f32)
         lib.call("valor_fine_weight_softmax", _st(), _p(wA_raw), _p(maskA), _p(wA), B, T)
         lib.call("valor_fine_weight_softmax", _st(), _p(wB_raw), _p(maskB), _p(wB), B, Nv)
@@ -591,37 +596,69 @@ class FineContrastFn(Function):
         A2B, B2A = torch.empty((B, B, T), **f32), torch.empty((B, B, Nv), **f32)
         idxA = torch.empty((B, B, T), dtype=torch.uint8, device=dev)
         idxB = torch.empty((B, B, Nv), dtype=torch.uint8, device=dev)
-        lib.call("valor_fine_reduce_fwd", _st(), _p(S), ldS, _p(maskA), _p(maskB), _p(wA), _p(wB), _p(score), _p(A2B),
-                 _p(B2A), _p(idxA), _p(idxB), B, T, Nv)
+        if fused:
+            lib.call("valor_fine_fused_fwd", _st(), _p(fa), _p(fb), _p(maskA), _p(maskB), _p(wA), _p(wB), _p(score), _p(A2B), _p(B2A),
+                     _p(idxA), _p(idxB), B, B, T, Nv, D)
+        else:
+            S = torch.empty((B * T, ldS), **f32)
+            K.gemm(fa, fb, out=S[:, :B * Nv], out_dtype=torch.float32)
+            lib.call("valor_fine_reduce_fwd", _st(), _p(S), ldS, _p(maskA), _p(maskB), _p(wA), _p(wB), _p(score), _p(A2B),
+                     _p(B2A), _p(idxA), _p(idxB), B, T, Nv)
         lse_r, lse_c = torch.empty(B, **f32), torch.empty(B, **f32)
         loss = torch.empty((), **f32)
         kk = k.detach().to(torch.float32).contiguous()
         lib.call("valor_infonce_fwd", _st(), _p(score), _p(kk), _p(lse_r), _p(lse_c), _p(loss), B)
         ctx.save_for_backward(fa, fb, maskA, maskB, wA, wB, score, A2B, B2A, idxA, idxB, lse_r, lse_c, kk)
-        ctx.dims = (B, T, Nv, D, ldS, featA.dtype)
+        ctx.dims = (B, T, Nv, D, ldS, featA.dtype, fused)
         ctx.score = score
         return loss
 
     @staticmethod
     def backward(ctx, dloss):
         fa, fb, maskA, maskB, wA, wB, score, A2B, B2A, idxA, idxB, lse_r, lse_c, kk = ctx.saved_tensors
-        B, T, Nv, D, ldS, fdt = ctx.dims
+        B, T, Nv, D, ldS, fdt, fused = ctx.dims
         dev = fa.device
         f32 = dict(dtype=torch.float32, device=dev)
         g = dloss.to(torch.float32).contiguous()
         dscore, dk = torch.empty((B, B), **f32), torch.empty((), **f32)
         part = torch.empty(256, **f32)
         lib.call("valor_infonce_bwd", _st(), _p(score), _p(kk), _p(lse_r), _p(lse_c), _p(g), _p(dscore), _p(dk), _p(part), B)
-        dS = torch.zeros((B * T, ldS), dtype=fdt, device=dev)
         dwA, dwB = torch.empty((B, T), **f32), torch.empty((B, Nv), **f32)
-        lib.call("valor_fine_reduce_bwd", _st(), _dt(dS), _p(dscore), _p(maskA), _p(maskB), _p(wA), _p(wB), _p(A2B), _p(B2A),
-                 _p(idxA), _p(idxB), _p(dS), ldS, _p(dwA), _p(dwB), B, T, Nv)
+        if fused:
+            lib.call("valor_fine_weight_grad", _st(), _p(dscore), _p(A2B), _p(B2A), _p(dwA), _p(dwB), B, T, Nv)
+            ch = min(B, max(1, _FINE_CHUNK))
+            nch = (B + ch - 1) // ch
+            dS = torch.empty((ch * T, ldS), dtype=fdt, device=dev)
+            if ldS != B * Nv:
+                dS[:, B * Nv:].zero_()                       # the leading-dimension padding (whole 16-byte chunks are read)
+            dfa = torch.empty((B * T, D), dtype=fdt, device=dev)
+            dfb = None
+            dfb32 = torch.empty((B * Nv, D), **f32) if nch > 1 else None      # several chunks: their contributions to dfeatB add up in fp32
+            for c in range(nch):
+                a0 = c * ch
+                na = min(ch, B - a0)
+                lib.call("valor_fine_ds_chunk", _st(), _dt(dS), _p(dscore), _p(maskA), _p(maskB), _p(wA), _p(wB), _p(idxA), _p(idxB),
+                         _p(dS), ldS, a0, na, B, T, Nv)
+                dSv = dS[:na * T, :B * Nv]
+                K.gemm(dSv, fb, trans_b=True, out=dfa[a0 * T:(a0 + na) * T])                         # dS . featB
+                if nch == 1:
+                    dfb = K.gemm(dSv, fa, trans_a=True, trans_b=True)                                # dS^T . featA
+                else:
+                    K.gemm(dSv, fa[a0 * T:(a0 + na) * T], trans_a=True, trans_b=True, out=dfb32, out_dtype=torch.float32, accumulate=c > 0)
+            if dfb is None:
+                dfb = torch.empty((B * Nv, D), dtype=fdt, device=dev)
+                lib.call("valor_cast_from_f32", _st(), _dt(dfb), _p(dfb32), _p(dfb), dfb.numel())
+            dfa, dfb = dfa.view(B, T, D), dfb.view(B, Nv, D)
+        else:
+            dS = torch.zeros((B * T, ldS), dtype=fdt, device=dev)
+            lib.call("valor_fine_reduce_bwd", _st(), _dt(dS), _p(dscore), _p(maskA), _p(maskB), _p(wA), _p(wB), _p(A2B), _p(B2A),
+                     _p(idxA), _p(idxB), _p(dS), ldS, _p(dwA), _p(dwB), B, T, Nv)
+            dSv = dS[:, :B * Nv]
+            dfa = K.gemm(dSv, fb, trans_b=True).view(B, T, D)                      # dS . featB
+            dfb = K.gemm(dSv, fa, trans_a=True, trans_b=True).view(B, Nv, D)       # dS^T . featA
         dwA_raw, dwB_raw = torch.empty_like(dwA), torch.empty_like(dwB)
         lib.call("valor_fine_weight_softmax_bwd", _st(), _p(wA), _p(dwA), _p(dwA_raw), B, T)
         lib.call("valor_fine_weight_softmax_bwd", _st(), _p(wB), _p(dwB), _p(dwB_raw), B, Nv)
-        dSv = dS[:, :B * Nv]
-        dfa = K.gemm(dSv, fb, trans_b=True).view(B, T, D)                      # dS . featB
-        dfb = K.gemm(dSv, fa, trans_a=True, trans_b=True).view(B, Nv, D)       # dS^T . featA
         return dfa, dfb, dwA_raw, dwB_raw, None, None, dk
 
 
