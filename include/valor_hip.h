@@ -80,7 +80,16 @@ int valor_gemm_set_fast_epilogue(int v);
  *   key 1: unused (was the start skew of the 8-phase kernel's first round; measured slower at every setting,
  *          profiles/r02_gemm_policy_ab.json)
  *   key 2: smallest number of 256x256 tiles for the 8-phase kernel on forward problems (default 256: one full round of workgroups)
- *   key 3: the same for dgrad problems (default 1024: below it the 128x128 kernel measured faster, session N) */
+ *   key 3: the same for dgrad problems (default 1024: below it the 128x128 kernel measured faster, session N)
+ *   key 4: L2-aware tile raster of the 8-phase kernels: 0 (default) = row-major over all tile columns; G > 0 = groups of G tile columns
+ *          (each XCD keeps G weight panels of 256 x K in its 4 MiB L2 and streams the activation rows past them); 1000 = G from a
+ *          fabric-traffic model per problem (csrc/gemm8.hip launch_gemm_8ph). Measured: fabric traffic 2.29 -> 1.79 x algorithmic on
+ *          the ViT fc1 forward, time unchanged to -3 % (profiles/r03_gemm_l2_ab.json, r03_pmc_gemm_l2.json)
+ *   key 5: bf16 output stores of the 8-phase kernels: 0 plain, 1 non-temporal, 1000 (default) = non-temporal for K <= 1024
+ *          (+5.5 .. +10 % on the K = 768 forward shapes, -0.6 .. -1.8 % at K = 3072)
+ *   key 6: 1 = the 128x128 kernels store big outputs of short-K problems non-temporally too (default 0)
+ *   key 7: 1 (default) = the fused-epilogue 128x128 kernel is the build for 3 workgroups per CU (140 VGPRs, no scratch); 0 = the
+ *          4-per-CU build whose epilogue spills 48-60 B per lane */
 int valor_gemm_set_policy(int key, int value);
 
 /* ---- fused bias + dropout + residual + LayerNorm.  Replaces apex FusedLayerNorm (apex/csrc/layer_norm_cuda_kernel.cu
@@ -97,6 +106,9 @@ int valor_ln_part_blocks(void);
  * everywhere, 0 = one wave per row everywhere. Same results (same arithmetic order per row up to the reduction tree, same
  * dropout windows). Returns the previous value, v < 0 only queries. Tuning / A-B hook. */
 int valor_ln_set_variant(int v);
+/* non-temporal accesses of the streaming LayerNorm kernels (bit mask; A/B hook, default 0, env VALOR_LN_NT): forward bit 0 = x loads,
+ * 1 = y stores, 2 = z stores; backward bit 3 = dy / z / dz_in loads, 4 = dx / dres stores. Returns the previous value, v < 0 only queries. */
+int valor_ln_set_nt(int v);
 int valor_bdrln_fwd(void* stream, int dtype, const void* x, const void* bias, const void* residual, const void* gamma,
                     const void* beta, void* z, void* y, float* mean, float* rstd, int64_t rows, int cols, float eps,
                     float p_drop, uint64_t seed, uint64_t offset, const float* row_scale, int64_t rows_per_scale);
@@ -208,6 +220,8 @@ int valor_fine_set_fused(int v);
  * (10 param groups), torch clip_grad_norm_ (train_utils.py:358-360) and apex-amp's master<->model copies
  * (apex/apex/amp/_process_optimizer.py:14-22). n % valor_adamw_chunk() == 0; chunk_group: int8 [n/chunk], -1 = skip. */
 int valor_adamw_chunk(void);
+/* non-temporal state accesses of valor_adamw (bit 0 loads, bit 1 stores; A/B hook, env VALOR_ADAMW_NT); returns the previous value, v < 0 queries */
+int valor_adamw_set_nt(int v);
 int valor_adamw(void* stream, int dtype, float* master, float* exp_avg, float* exp_avg_sq, void* grad, void* param,
                 const int8_t* chunk_group, int64_t n, const float* lr, const float* wd, int ngroups, float beta1,
                 float beta2, float eps, int step, int correct_bias, const float* gscale_dev, int zero_grad);

@@ -1,7 +1,7 @@
 """A/B of the 8-phase GEMM's L2 knobs at the bench shapes, in ONE process (interleaved rounds, HIP events):
    raster   valor_gemm_set_policy(4, .)  0 = row-major over all tile columns, G = groups of G tile columns, 1000 = traffic model
-   store    valor_gemm_set_policy(5, .)  0 plain, 1 non-temporal, 2 sc1 (write-through) output stores
-   nta      valor_gemm_set_policy(6, .)  k-contiguous A operand fetched with the nt hint
+   store    valor_gemm_set_policy(5, .)  0 plain, 1 non-temporal output stores (the round-3 sweep also had 2 = sc1 write-through)
+   nta      (round-3 sweep only: k-contiguous A operand fetched with the nt hint; the knob is gone, profiles/r03_gemm_l2_ab.json)
 usage:  python tools/gemm_l2_ab.py time out.json          timing sweep (median of rounds x reps per config)
         python tools/gemm_l2_ab.py pmc  order.json         ONE launch per (shape, config) in a fixed order, for a rocprofv3 --pmc pass;
                                                            order.json lists the launches in dispatch order (tools/gemm_l2_pmc.py joins them)
@@ -54,12 +54,12 @@ def main():
     mode, path = sys.argv[1], sys.argv[2]
     dev = torch.device("cuda", 0)
     so = lib.load()
-    rasters = [0, 3, 4, 6, 1000]
-    stores = [0, 1, 2]
-    ntas = [0, 1]
+    rasters = [0, 6, 1000]
+    stores = [0, 1]
+    ntas = [0]
     if mode == "pmc":
         names = ["fc1_fwd_plain", "qkv_fwd", "fc2_dgrad_deriv"]
-        cfgs = [(r, s, n) for r in (0, 4, 6) for s in (0, 2) for n in (0, 1)]
+        cfgs = [(r, s, 0) for r in (0, 6) for s in (0, 1)]
     else:
         names = list(SHAPES)
         cfgs = list(itertools.product(rasters, stores, ntas))
@@ -70,7 +70,7 @@ def main():
         torch.cuda.synchronize()
         if mode == "pmc":
             for (r, s, n) in cfgs:
-                so.valor_gemm_set_policy(4, r); so.valor_gemm_set_policy(5, s); so.valor_gemm_set_policy(6, n)
+                so.valor_gemm_set_policy(4, r); so.valor_gemm_set_policy(5, s)
                 run(A, B, kw, out)
                 torch.cuda.synchronize()
                 order.append({"shape": name, "raster": r, "store": s, "nta": n, "MNK": SHAPES[name][:3]})
@@ -78,7 +78,7 @@ def main():
         times = {c: [] for c in cfgs}
         for rnd in range(3):
             for c in cfgs:
-                so.valor_gemm_set_policy(4, c[0]); so.valor_gemm_set_policy(5, c[1]); so.valor_gemm_set_policy(6, c[2])
+                so.valor_gemm_set_policy(4, c[0]); so.valor_gemm_set_policy(5, c[1])
                 run(A, B, kw, out)
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
@@ -93,9 +93,9 @@ def main():
             med = sorted(times[c])[1]
             res[name][f"raster{c[0]}_store{c[1]}_nta{c[2]}"] = {"us": round(med, 1), "TF": round(flops / med / 1e6, 1), "vs_base": round(base / med, 3)}
         best = max(res[name].items(), key=lambda kv: kv[1]["TF"])
-        print(name, "base", res[name]["raster0_store0_nta0"], "auto", res[name]["raster1000_store0_nta0"], "best", best, flush=True)
+        print(name, "base", res[name]["raster0_store0_nta0"], "nt stores", res[name]["raster0_store1_nta0"], "best", best, flush=True)
         del A, B, kw, out
-    so.valor_gemm_set_policy(4, 1000); so.valor_gemm_set_policy(5, 0); so.valor_gemm_set_policy(6, 0)
+    so.valor_gemm_set_policy(4, 0); so.valor_gemm_set_policy(5, 1000)
     json.dump(order if mode == "pmc" else res, open(path, "w"), indent=1)
 
 

@@ -190,8 +190,11 @@ DEVINL bf16x8_t read_frag_tr(const char* img, int off, int kk) {
     s16x8_t r = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
     return __builtin_bit_cast(bf16x8_t, r);
 }
-template <bool TA, bool TB, int NSTAGE, bool FUSED>
-__global__ __launch_bounds__(256, NSTAGE == 1 ? 4 : 2) void gemm_glds_kernel(GemmArgs p) {
+// WPS = waves per SIMD the register allocation is sized for (= workgroups per CU): 4 for the lean epilogue; the FUSED epilogue
+// (activation / derivative / second output) does not fit 128 VGPRs beside the 64 accumulators -- at 4 it spilled two accumulator quads
+// INSIDE the K loop (48-60 B/lane of scratch) -- so it is built for 3 workgroups per CU (168 VGPRs) as well (policy key 7).
+template <bool TA, bool TB, int NSTAGE, bool FUSED, int WPS = (NSTAGE == 1 ? 4 : 2)>
+__global__ __launch_bounds__(256, WPS) void gemm_glds_kernel(GemmArgs p) {
     typedef bf16_t T;
     constexpr int BK = 64;
     constexpr int IMG = 16384;              // one operand image
@@ -462,15 +465,16 @@ extern "C" int valor_gemm_set_variant(int v) { const int o = g_gemm_variant; if 
 // [0] NT min K for the 8-phase kernel, [1] unused (was: 8-phase start skew, measured slower), [2] min 256x256 tiles (forward), [3] min 256x256 tiles (dgrad)
 // [4] L2-aware tile raster of the 8-phase kernels: 0 = row-major over all tile columns, 1000 = pick the group width per problem (traffic
 //     model in launch_gemm_8ph), else a fixed number of tile columns per group
-// [5] output stores of the 8-phase kernels: 0 plain, 1 non-temporal, 2 sc1 (write-through)   [6] k-contiguous A operand fetched non-temporally
+// [5] non-temporal bf16 output stores of the 8-phase kernels: 0 never, 1 always, 1000 = short-K problems (K <= 1024)
+// [6] 1 = the 128x128 kernels store big outputs of short-K problems non-temporally as well
 int g_gemm_policy[8] = {[] { const char* e = getenv("VALOR_GEMM_NT_MINK"); return e ? atoi(e) : 768; }(),
                         [] { const char* e = getenv("VALOR_GEMM_SKEW"); return e ? atoi(e) : 0; }(),
                         [] { const char* e = getenv("VALOR_GEMM_MIN_TILES"); return e ? atoi(e) : 256; }(),
                         [] { const char* e = getenv("VALOR_GEMM_NT_MIN_TILES"); return e ? atoi(e) : 1024; }(),
-                        [] { const char* e = getenv("VALOR_GEMM_RASTER"); return e ? atoi(e) : 1000; }(),
-                        [] { const char* e = getenv("VALOR_GEMM_STORE"); return e ? atoi(e) : 0; }(),
+                        [] { const char* e = getenv("VALOR_GEMM_RASTER"); return e ? atoi(e) : 0; }(),
+                        [] { const char* e = getenv("VALOR_GEMM_STORE"); return e ? atoi(e) : 1000; }(),
                         [] { const char* e = getenv("VALOR_GEMM_NTA"); return e ? atoi(e) : 0; }(),
-                        0};
+                        [] { const char* e = getenv("VALOR_GEMM_FUSED3"); return e ? atoi(e) : 1; }()};      // [7] fused-epilogue 128x128 kernel built for 3 workgroups per CU (no scratch)
 extern "C" int valor_gemm_set_policy(int key, int value) {
     if (key < 0 || key > 7) return VALOR_ERR_ARG;
     const int old = g_gemm_policy[key];
@@ -504,20 +508,26 @@ extern "C" int valor_gemm_kernel_for(int dtype, int transA, int transB, int M, i
 template <int NSTAGE>
 static void launch_gemm_glds(hipStream_t st, int transA, int transB, const GemmArgs& p, dim3 grid) {
     const size_t lds = NSTAGE * 32768;
-#define VALOR_GLDS_LAUNCH1(TA_, TB_, F_)                                                            \
+#define VALOR_GLDS_LAUNCH1(TA_, TB_, F_, W_)                                                        \
     do {                                                                                            \
         static bool attr_set = false;                                                               \
         if (!attr_set) {                                                                            \
-            hipFuncSetAttribute((const void*)gemm_glds_kernel<TA_, TB_, NSTAGE, F_>,                \
+            hipFuncSetAttribute((const void*)gemm_glds_kernel<TA_, TB_, NSTAGE, F_, W_>,            \
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);              \
             attr_set = true;                                                                        \
         }                                                                                           \
-        hipLaunchKernelGGL((gemm_glds_kernel<TA_, TB_, NSTAGE, F_>), grid, dim3(256), lds, st, p);  \
+        hipLaunchKernelGGL((gemm_glds_kernel<TA_, TB_, NSTAGE, F_, W_>), grid, dim3(256), lds, st, p); \
     } while (0)
 #define VALOR_GLDS_LAUNCH(TA_, TB_)                                                                 \
     do {                                                                                            \
-        if (fused) VALOR_GLDS_LAUNCH1(TA_, TB_, true);                                              \
-        else VALOR_GLDS_LAUNCH1(TA_, TB_, false);                                                   \
+        if constexpr (NSTAGE == 1) {                                                                \
+            if (fused && g_gemm_policy[7]) VALOR_GLDS_LAUNCH1(TA_, TB_, true, 3);                   \
+            else if (fused) VALOR_GLDS_LAUNCH1(TA_, TB_, true, 4);                                  \
+            else VALOR_GLDS_LAUNCH1(TA_, TB_, false, 4);                                            \
+        } else {                                                                                    \
+            if (fused) VALOR_GLDS_LAUNCH1(TA_, TB_, true, 2);                                       \
+            else VALOR_GLDS_LAUNCH1(TA_, TB_, false, 2);                                            \
+        }                                                                                           \
     } while (0)
     // split-K partial tiles never run an epilogue here (gemm_splitk_reduce does): the lean variant
     const bool fused = p.kslices <= 1 && ((p.act & VALOR_ACT_MASK) != VALOR_ACT_NONE || p.preact || p.dact_aux);
@@ -536,8 +546,12 @@ static int launch_gemm(hipStream_t st, int transA, int transB, GemmArgs p) {
     if (ElemTraits<T>::DT == VALOR_DT_BF16 && g_gemm_variant > 0) {
         if (p.kslices > 1) grid = dim3(tiles * p.kslices, 1);     // split-K: 1-D grid over (slice, tile) work items
         if (use_8ph(VALOR_DT_BF16, transA, transB, p.M, p.N, p.K, p.dact_aux != nullptr && !(p.act & VALOR_ACT_DERIV))) launch_gemm_8ph(st, transA, transB, p);
-        else if (g_gemm_variant == 2) launch_gemm_glds<2>(st, transA, transB, p, grid);
-        else launch_gemm_glds<1>(st, transA, transB, p, grid);
+        else {
+            // policy key 6: the 128x128 kernels store big bf16 outputs of short-K problems non-temporally too (A/B hook, default off)
+            p.st_mode = (g_gemm_policy[6] && !p.out_f32 && p.kslices <= 1 && p.K <= 1024 && (int64_t)p.M * p.N >= (4 << 20)) ? 1 : 0;
+            if (g_gemm_variant == 2) launch_gemm_glds<2>(st, transA, transB, p, grid);
+            else launch_gemm_glds<1>(st, transA, transB, p, grid);
+        }
         if (p.kslices > 1) {
             const int64_t total = (int64_t)p.M * ((p.N + 3) / 4);
             int blocks = (int)((total + 255) / 256);

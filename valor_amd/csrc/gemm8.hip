@@ -46,9 +46,9 @@ DEVINL bf16x8_t read_frag_tr8(const char* img, int off, int kk) {
 
 // ASMTR: the transposing reads of the k-slow operands as inline asm (mma.h: tr_issue / tr_wait / tr_frag) -- as compiler builtins
 // they drained the counted vmcnt(8) LDS-DMA pipeline three times per K-tile.
-// NTA: the k-contiguous A operand (activations: every 128-B line is used by the workgroups of ONE tile row, once) is fetched with the
-// non-temporal hint, so that it does not displace the weight panel (re-read by every tile row) from the XCD's L2.
-template <bool TA, bool TB, bool ASMTR, bool NTA = false>
+// NTS: non-temporal stores of the bf16 outputs (gemm_common.h store_out16; the launcher picks it for short-K problems).
+// (A non-temporal A operand -- glds16_nt -- was measured too: it lowers the fabric traffic, not the time; profiles/r03_gemm_l2_ab.json.)
+template <bool TA, bool TB, bool ASMTR, bool NTS = false>
 __global__ __launch_bounds__(512, 2) void gemm_8ph_kernel(GemmArgs p) {
     typedef bf16_t T;
     constexpr int BK = 64;
@@ -149,13 +149,8 @@ __global__ __launch_bounds__(512, 2) void gemm_8ph_kernel(GemmArgs p) {
     // issue one half-tile (this wave's 2 pieces) into buffer `buf`, then advance that kind to the next K-tile
     auto issueA = [&](int hf, char* buf) {
         char* d = buf + (hf ? OFF_A1 : OFF_A0) + wave * 2048;
-        if constexpr (NTA) {
-            glds16_nt(rsA, d, voA[hf][0]);
-            glds16_nt(rsA, d + 1024, voA[hf][1]);
-        } else {
-            glds16(rsA, d, voA[hf][0]);
-            glds16(rsA, d + 1024, voA[hf][1]);
-        }
+        glds16(rsA, d, voA[hf][0]);
+        glds16(rsA, d + 1024, voA[hf][1]);
         voA[hf][0] += stepA; voA[hf][1] += stepA;
     };
     auto issueB = [&](int hf, char* buf) {
@@ -374,7 +369,7 @@ __global__ __launch_bounds__(512, 2) void gemm_8ph_kernel(GemmArgs p) {
 #pragma unroll
                         for (int q = 0; q < 4; ++q) val[q] = pack2_bf16(f[2 * q], f[2 * q + 1]);
                     }
-                    store_out16(p.st_mode, dst + (int64_t)m * p.ldc + n, val);
+                    store_out16<NTS>(dst + (int64_t)m * p.ldc + n, val);
                 }
             }
         };
@@ -422,7 +417,7 @@ __global__ __launch_bounds__(512, 2) void gemm_8ph_kernel(GemmArgs p) {
                     else for (int r = 0; r < 8; ++r) if (n + r < p.N) qq[r] = r < 4 ? v0[r] : v1[r - 4];
                 }
             } else {
-                epilogue_store8(p, m, n, v0, v1, bias0, bias1);
+                epilogue_store8<true, NTS ? 1 : 0>(p, m, n, v0, v1, bias0, bias1);
             }
         }
     }
@@ -476,36 +471,25 @@ void launch_gemm_8ph(hipStream_t st, int transA, int transB, const GemmArgs& p_i
             }
         }
     }
-    p.st_mode = g_gemm_policy[5];
-    const bool nta = g_gemm_policy[6] != 0 && !transA;
+    // non-temporal output stores: bf16 outputs of short-K problems (policy key 5: 0 never, 1 always, 1000 = K <= 1024)
+    const bool nts = !transA && !p.out_f32 && p.kslices <= 1 && (g_gemm_policy[5] == 1 || (g_gemm_policy[5] == 1000 && p.K <= 1024));
+    p.st_mode = nts ? 1 : 0;
     dim3 grid(tiles * (p.kslices > 1 ? p.kslices : 1));
     const size_t lds = 2 * BUF_BYTES;
-#define VALOR_8PH_LAUNCH(TA_, TB_)                                                                              \
+#define VALOR_8PH_LAUNCH(TA_, TB_, NTS_)                                                                        \
     do {                                                                                                        \
         static bool attr_set = false;                                                                           \
         if (!attr_set) {                                                                                        \
-            hipFuncSetAttribute((const void*)gemm_8ph_kernel<TA_, TB_, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-            hipFuncSetAttribute((const void*)gemm_8ph_kernel<TA_, TB_, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+            hipFuncSetAttribute((const void*)gemm_8ph_kernel<TA_, TB_, false, NTS_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+            hipFuncSetAttribute((const void*)gemm_8ph_kernel<TA_, TB_, true, NTS_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
             attr_set = true;                                                                                    \
         }                                                                                                       \
-        if (g_8ph_tr_asm && (TA_ || TB_)) hipLaunchKernelGGL((gemm_8ph_kernel<TA_, TB_, true>), grid, dim3(512), lds, st, p); \
-        else hipLaunchKernelGGL((gemm_8ph_kernel<TA_, TB_, false>), grid, dim3(512), lds, st, p);             \
+        if (g_8ph_tr_asm && (TA_ || TB_)) hipLaunchKernelGGL((gemm_8ph_kernel<TA_, TB_, true, NTS_>), grid, dim3(512), lds, st, p); \
+        else hipLaunchKernelGGL((gemm_8ph_kernel<TA_, TB_, false, NTS_>), grid, dim3(512), lds, st, p);       \
     } while (0)
-#define VALOR_8PH_LAUNCH_NTA(TB_, ASM_)                                                                         \
-    do {                                                                                                        \
-        static bool attr_set = false;                                                                           \
-        if (!attr_set) {                                                                                        \
-            hipFuncSetAttribute((const void*)gemm_8ph_kernel<false, TB_, ASM_, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-            attr_set = true;                                                                                    \
-        }                                                                                                       \
-        hipLaunchKernelGGL((gemm_8ph_kernel<false, TB_, ASM_, true>), grid, dim3(512), lds, st, p);           \
-    } while (0)
-    if (nta && !transB) VALOR_8PH_LAUNCH_NTA(false, false);
-    else if (nta && transB && g_8ph_tr_asm) VALOR_8PH_LAUNCH_NTA(true, true);
-    else if (!transA && !transB) VALOR_8PH_LAUNCH(false, false);
-    else if (!transA && transB) VALOR_8PH_LAUNCH(false, true);
-    else if (transA && !transB) VALOR_8PH_LAUNCH(true, false);
-    else VALOR_8PH_LAUNCH(true, true);
+    if (!transA && !transB) { if (nts) VALOR_8PH_LAUNCH(false, false, true); else VALOR_8PH_LAUNCH(false, false, false); }
+    else if (!transA && transB) { if (nts) VALOR_8PH_LAUNCH(false, true, true); else VALOR_8PH_LAUNCH(false, true, false); }
+    else if (transA && !transB) VALOR_8PH_LAUNCH(true, false, false);
+    else VALOR_8PH_LAUNCH(true, true, false);
 #undef VALOR_8PH_LAUNCH
-#undef VALOR_8PH_LAUNCH_NTA
 }

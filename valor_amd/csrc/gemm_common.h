@@ -24,14 +24,21 @@ struct GemmArgs {
     int fast_epi;              // 8-phase kernels: bf16 C, no split-K / fused row sums, N % 8 == 0, ldc % 8 == 0 (ldaux % 8 == 0)
                                // -> bias / activation in registers, bf16 tile passes through LDS (see gemm8.hip)
     int raster_g;              // 8-phase kernels: tile columns per raster group (0 = row-major over all tile columns), see gemm8.hip
-    int st_mode;               // 16-byte output stores: 0 plain, 1 non-temporal, 2 sc1 (write-through, the line leaves this XCD's L2)
+    int st_mode;               // 16-byte bf16 output stores: 0 plain, 1 non-temporal (see store_out16)
 };
 
-// 16-byte store of an output chunk. The outputs of the big forward / dgrad GEMMs are written once and read by a LATER kernel: kept in
-// the XCD's 4 MiB L2 (plain stores allocate) a round of 32 tiles x 128 KiB evicts the weight panel every tile of the next round re-reads.
-DEVINL void store_out16(int mode, void* q, u32x4_t v) {
-    if (mode == 2) asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(q), "v"(v) : "memory");
-    else if (mode == 1) __builtin_nontemporal_store(v, (u32x4_t*)q);
+// 16-byte store of an output chunk, optionally NON-TEMPORAL. The outputs of the big short-K forward GEMMs (ViT qkv / fc1, the decoder's
+// cross K|V projection: 0.36-1.2 GB per launch) are written once and read by a LATER kernel; streamed past the caches they stop
+// competing with the operand panels every tile re-reads: measured +5.5 .. +10 % on the K = 768 forward shapes, -0.6 .. -1.8 % at
+// K = 3072 where the output is small beside the operands (profiles/r03_gemm_l2_ab.json; the sc1 write-through flavour and a
+// non-temporal A operand lower the fabric traffic further -- 2.29 -> 1.29 x algorithmic with a column-grouped raster -- but not the time).
+template <bool NTS>
+DEVINL void store_out16(void* q, u32x4_t v) {
+    if constexpr (NTS) __builtin_nontemporal_store(v, (u32x4_t*)q);
+    else *(u32x4_t*)q = v;
+}
+DEVINL void store_out16(int nts, void* q, u32x4_t v) {
+    if (nts) __builtin_nontemporal_store(v, (u32x4_t*)q);
     else *(u32x4_t*)q = v;
 }
 
@@ -138,7 +145,7 @@ DEVINL void epilogue_store(const GemmArgs& p, int m, int n0, f32x4_t acc, f32x4_
 
 // 8 consecutive n (n0 .. n0+7) of row m, bf16 only: one 16-byte store per lane (the epilogue is store-ISSUE bound:
 // half as many, twice as wide store instructions). Falls back to two 4-wide stores on tails / odd leading dims.
-template <bool FUSED = true>
+template <bool FUSED = true, int NTS = -1>      // NTS: 1 / 0 = non-temporal / plain stores at compile time, -1 = p.st_mode at run time
 DEVINL void epilogue_store8(const GemmArgs& p, int m, int n0, f32x4_t a0, f32x4_t a1, f32x4_t b0, f32x4_t b1) {
     typedef bf16_t T;
     if (m >= p.M || n0 >= p.N) return;
@@ -171,7 +178,8 @@ DEVINL void epilogue_store8(const GemmArgs& p, int m, int n0, f32x4_t a0, f32x4_
         }
         if (p.preact) {
             u32x4_t q = {pack2_bf16(q0[0], q0[1]), pack2_bf16(q0[2], q0[3]), pack2_bf16(q1[0], q1[1]), pack2_bf16(q1[2], q1[3])};
-            store_out16(p.st_mode, (T*)p.preact + off, q);
+            if constexpr (NTS < 0) store_out16(p.st_mode, (T*)p.preact + off, q);
+            else store_out16<NTS != 0>((T*)p.preact + off, q);
         }
         if (p.dact_aux) {
             const T* a = (const T*)p.dact_aux + (int64_t)m * p.ldaux + n0;
@@ -190,7 +198,8 @@ DEVINL void epilogue_store8(const GemmArgs& p, int m, int n0, f32x4_t a0, f32x4_
     T* c = (T*)p.C + off;
     if (p.accumulate) { v0 += load4<T>(c); v1 += load4<T>(c + 4); }
     u32x4_t o = {pack2_bf16(v0[0], v0[1]), pack2_bf16(v0[2], v0[3]), pack2_bf16(v1[0], v1[1]), pack2_bf16(v1[2], v1[3])};
-    store_out16(p.st_mode, c, o);
+    if constexpr (NTS < 0) store_out16(p.st_mode, c, o);
+    else store_out16<NTS != 0>(c, o);
 }
 
 // 256x256 8-phase bf16 kernel (gemm8.hip). grid.x = tiles(256) * max(kslices, 1).

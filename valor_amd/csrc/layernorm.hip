@@ -36,6 +36,7 @@ struct LnArgs {
     float eps, p_drop;
     uint64_t seed, offset;
     const float* row_scale; int64_t rows_per_scale;   // stochastic depth: (x + bias) *= row_scale[row / rows_per_scale] (or null)
+    int nt;                                           // non-temporal accesses (valor_ln_set_nt): bit 0 x loads, 1 y stores, 2 z stores
 };
 
 template <typename T, int NV>
@@ -118,7 +119,22 @@ struct LnBwdArgs {
     float p_drop;
     uint64_t seed, offset;
     const float* row_scale; int64_t rows_per_scale;
+    int nt;                                           // bit 3: dy / z / dz_in loads non-temporal, bit 4: dx / dres stores
 };
+
+// 4 consecutive elements as fp32, optionally through a non-temporal access (operands a streaming kernel touches exactly once)
+template <typename T> DEVINL f32x4_t load4_nt(const T* p, bool nt);
+template <> DEVINL f32x4_t load4_nt<float>(const float* p, bool nt) { return nt ? __builtin_nontemporal_load((const f32x4_t*)p) : *(const f32x4_t*)p; }
+template <> DEVINL f32x4_t load4_nt<bf16_t>(const bf16_t* p, bool nt) {
+    const u32x2_t r = nt ? __builtin_nontemporal_load((const u32x2_t*)p) : *(const u32x2_t*)p;
+    return (f32x4_t){__uint_as_float(r[0] << 16), __uint_as_float(r[0] & 0xffff0000u), __uint_as_float(r[1] << 16), __uint_as_float(r[1] & 0xffff0000u)};
+}
+template <typename T> DEVINL void store4_nt(T* p, f32x4_t v, bool nt);
+template <> DEVINL void store4_nt<float>(float* p, f32x4_t v, bool nt) { if (nt) __builtin_nontemporal_store(v, (f32x4_t*)p); else *(f32x4_t*)p = v; }
+template <> DEVINL void store4_nt<bf16_t>(bf16_t* p, f32x4_t v, bool nt) {
+    const u32x2_t r = {pack2_bf16(v[0], v[1]), pack2_bf16(v[2], v[3])};
+    if (nt) __builtin_nontemporal_store(r, (u32x2_t*)p); else *(u32x2_t*)p = r;
+}
 
 template <typename T, int NV>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(LnBwdArgs p) {
@@ -133,6 +149,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(LnBwdArgs p) {
     const float keep_scale = p.p_drop > 0.f ? 1.0f / (1.0f - p.p_drop) : 1.0f;
     const float inv_n = 1.0f / (float)cols;
     const bool has_ln = DY != nullptr;
+    const bool ntl = (p.nt & 8) != 0, nts = (p.nt & 16) != 0;
 
     f32x4_t gsum[NV], bsum[NV], xsum[NV];
 #pragma unroll
@@ -161,8 +178,8 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(LnBwdArgs p) {
                 const int c = (i * 64 + lane) * 4;
                 xh[i] = (f32x4_t){0.f, 0.f, 0.f, 0.f}; gy[i] = xh[i];
                 if (c < cols) {
-                    f32x4_t zz = load4<T>(Z + base + c);
-                    f32x4_t d = load4<T>(DY + base + c);
+                    f32x4_t zz = load4_nt<T>(Z + base + c, ntl);
+                    f32x4_t d = load4_nt<T>(DY + base + c, ntl);
 #pragma unroll
                     for (int k = 0; k < 4; ++k) {
                         xh[i][k] = (zz[k] - mu) * rs;
@@ -189,8 +206,8 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(LnBwdArgs p) {
             const int c = (i * 64 + lane) * 4;
             if (c < cols) {
                 f32x4_t dz = dzv[i];
-                if (DZI) dz += load4<T>(DZI + base + c);
-                if (DR) store4<T>(DR + base + c, dz);
+                if (DZI) dz += load4_nt<T>(DZI + base + c, ntl);
+                if (DR) store4_nt<T>(DR + base + c, dz, nts);
                 f32x4_t dx = dz;
                 if (thr) {
                     Philox4 rnd = philox4x32_10(p.seed, p.offset + (uint64_t)((base + c) >> 2));
@@ -198,7 +215,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(LnBwdArgs p) {
                     for (int k = 0; k < 4; ++k) dx[k] = rnd.v[k] >= thr ? dz[k] * keep_scale : 0.f;
                 }
                 if (p.row_scale) dx *= rsc;
-                if (DX && (thr || p.row_scale || DX != DR)) store4<T>(DX + base + c, dx);
+                if (DX && (thr || p.row_scale || DX != DR)) store4_nt<T>(DX + base + c, dx, nts);
                 xsum[i] += dx;
             }
         }
@@ -274,7 +291,7 @@ __global__ __launch_bounds__(256) void ln_fwd_h_kernel(LnArgs p) {
             const int c = (i * 32 + hl) * 8;
             float t[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
             if (ok) {
-                unpack8(*(const u32x4_t*)(X + base + c), t);
+                unpack8((p.nt & 1) ? __builtin_nontemporal_load((const u32x4_t*)(X + base + c)) : *(const u32x4_t*)(X + base + c), t);
                 if (Bi) {
                     float b8[8]; unpack8(*(const u32x4_t*)(Bi + c), b8);
 #pragma unroll
@@ -299,7 +316,7 @@ __global__ __launch_bounds__(256) void ln_fwd_h_kernel(LnArgs p) {
                 }
                 if (Z) {
                     const u32x4_t zq = pack8(t);
-                    *(u32x4_t*)(Z + base + c) = zq;
+                    if (p.nt & 4) __builtin_nontemporal_store(zq, (u32x4_t*)(Z + base + c)); else *(u32x4_t*)(Z + base + c) = zq;
                     unpack8(zq, t);                 // LN statistics use the value that backward will re-read from z
                 }
 #pragma unroll
@@ -337,7 +354,7 @@ __global__ __launch_bounds__(256) void ln_fwd_h_kernel(LnArgs p) {
 #pragma unroll
                 for (int k = 0; k < 8; ++k) o[k] += b8[k];
             }
-            *(u32x4_t*)(Y + base + c) = pack8(o);
+            if (p.nt & 2) __builtin_nontemporal_store(pack8(o), (u32x4_t*)(Y + base + c)); else *(u32x4_t*)(Y + base + c) = pack8(o);
         }
     }
 }
@@ -726,6 +743,9 @@ static void launch_ln_fwd_nv(hipStream_t st, const LnArgs& p) {
 // half-wave-per-row kernels (bf16, cols = 256 * NV8 <= 1024); VALOR_LN_VARIANT=0 keeps the one-wave-per-row kernels (A/B runs)
 static int g_ln_variant = [] { const char* e = getenv("VALOR_LN_VARIANT"); return e ? atoi(e) : 1; }();
 extern "C" int valor_ln_set_variant(int v) { const int o = g_ln_variant; if (v >= 0) g_ln_variant = v; return o; }
+// non-temporal accesses of the streaming LayerNorm kernels (bit mask, see LnArgs::nt / LnBwdArgs::nt); returns the previous value, v < 0 queries
+static int g_ln_nt = [] { const char* e = getenv("VALOR_LN_NT"); return e ? atoi(e) : 0; }();
+extern "C" int valor_ln_set_nt(int v) { const int o = g_ln_nt; if (v >= 0) g_ln_nt = v; return o; }
 static bool ln_half_ok(int dt, int cols, const void* a, const void* b, const void* c, const void* d, const void* e) {
     auto al = [](const void* q) { return ((uintptr_t)q & 15) == 0; };
     return g_ln_variant && dt == VALOR_DT_BF16 && (cols & 255) == 0 && cols <= 1024 && al(a) && al(b) && al(c) && al(d) && al(e);
@@ -803,7 +823,7 @@ extern "C" int valor_bdrln_fwd(void* stream, int dtype, const void* x, const voi
     if (rows <= 0) return VALOR_OK;
     if (!x || cols <= 0 || (cols & 3) || cols > LN_MAX_COLS) return VALOR_ERR_ARG;
     if (p_drop < 0.f || p_drop >= 1.f || (row_scale && rows_per_scale <= 0)) return VALOR_ERR_ARG;
-    LnArgs p{x, bias, residual, gamma, beta, z, y, mean, rstd, rows, cols, eps, p_drop, seed, offset, row_scale, rows_per_scale};
+    LnArgs p{x, bias, residual, gamma, beta, z, y, mean, rstd, rows, cols, eps, p_drop, seed, offset, row_scale, rows_per_scale, g_ln_nt};
     hipStream_t st = (hipStream_t)stream;
     if (dtype == VALOR_DT_BF16) return launch_ln_fwd<bf16_t>(st, p);
     if (dtype == VALOR_DT_F32) return launch_ln_fwd<float>(st, p);
@@ -821,7 +841,7 @@ extern "C" int valor_bdrln_bwd(void* stream, int dtype, const void* dy, const vo
     if (!dy && !dz_in) return VALOR_ERR_ARG;
     if (row_scale && (rows_per_scale <= 0 || dx == dres)) return VALOR_ERR_ARG;
     LnBwdArgs p{dy, dz_in, z, mean, rstd, gamma, dx, dres, part_dgamma, part_dbeta, part_dbias, rows, cols, p_drop, seed, offset,
-                row_scale, rows_per_scale};
+                row_scale, rows_per_scale, g_ln_nt};
     hipStream_t st = (hipStream_t)stream;
     if (dtype == VALOR_DT_BF16) return launch_ln_bwd<bf16_t>(st, p);
     if (dtype == VALOR_DT_F32) return launch_ln_bwd<float>(st, p);

@@ -380,7 +380,7 @@ typedef __attribute__((ext_vector_type(4))) short s16x4_t;
 DEVINL void glds16(rsrc_t rs, char* lds_dst, int voff) {
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, LDS_PTR(lds_dst), 16, voff, 0, 0, 0);
 }
-// the same with the non-temporal hint (aux bit 1 = nt): streamed operands that must not displace reused lines from L2
+// the same with the non-temporal hint (aux bit 1 = nt) for operands streamed once
 DEVINL void glds16_nt(rsrc_t rs, char* lds_dst, int voff) {
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, LDS_PTR(lds_dst), 16, voff, 0, 0, 2);
 }

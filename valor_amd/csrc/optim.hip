@@ -13,6 +13,7 @@
 //   m = b1 m + (1-b1) g ; v = b2 v + (1-b2) g^2 ; denom = sqrt(v) + eps
 //   p -= lr * sqrt(1-b2^t)/(1-b1^t) * m / denom ;   p -= lr * wd * p      (decay AFTER the Adam step)
 #include "common.h"
+#include <stdlib.h>
 
 #define ADAMW_CHUNK 1024
 #define ADAMW_MAX_GROUPS 16
@@ -22,41 +23,62 @@ struct AdamGroups {
     float wd[ADAMW_MAX_GROUPS];
 };
 
+// NT bit 0: the state / gradient loads are non-temporal, bit 1: the stores (10.5 GB per step at VALOR-base stream through once; nothing
+// here is re-read before the next step). Two chunks per iteration: twice the loads in flight per thread.
 template <typename T>
 __global__ __launch_bounds__(256) void adamw_kernel(float* master, float* m, float* v, T* grad, T* param,
                                                     const int8_t* chunk_group, int64_t nchunks, AdamGroups groups,
                                                     float beta1, float beta2, float eps, float bc1, float bc2_sqrt,
-                                                    const float* gscale_dev, int zero_grad) {
+                                                    const float* gscale_dev, int zero_grad, int nt) {
     const float gs = gscale_dev ? *gscale_dev : 1.0f;
     // a non-finite global gradient norm (clip_finalize_kernel hands over gscale = NaN then) skips the whole update, the gradients are
     // still cleared: what apex amp's dynamic loss scaler did for the reference on overflow (apex/amp/scaler.py:197-217), without a
     // host sync
     const bool skip = !(fabsf(gs) < INFINITY);
-    for (int64_t c = blockIdx.x; c < nchunks; c += gridDim.x) {
-        const int gid = chunk_group[c];
-        if (gid < 0) continue;
-        if (skip) {
-            if (zero_grad) store4<T>(grad + c * ADAMW_CHUNK + threadIdx.x * 4, (f32x4_t){0.f, 0.f, 0.f, 0.f});
-            continue;
-        }
-        const float lr = groups.lr[gid], wd = groups.wd[gid];
-        const float step_size = lr * bc2_sqrt / bc1;
-        const int64_t i = c * ADAMW_CHUNK + threadIdx.x * 4;
-        f32x4_t g = load4<T>(grad + i);
-        f32x4_t mm = *(f32x4_t*)(m + i), vv = *(f32x4_t*)(v + i), p = *(f32x4_t*)(master + i);
+    const bool ntl = (nt & 1) != 0, nts = (nt & 2) != 0;
+    auto ld4 = [&](const float* q) { return ntl ? __builtin_nontemporal_load((const f32x4_t*)q) : *(const f32x4_t*)q; };
+    auto st4 = [&](float* q, f32x4_t x) { if (nts) __builtin_nontemporal_store(x, (f32x4_t*)q); else *(f32x4_t*)q = x; };
+    for (int64_t c0 = blockIdx.x; c0 < nchunks; c0 += 2 * (int64_t)gridDim.x) {
+        int64_t cc[2] = {c0, c0 + gridDim.x};
+        int gid[2];
+        f32x4_t g[2], mm[2], vv[2], p[2];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const float gk = g[k] * gs;
-            mm[k] = mm[k] * beta1 + (1.0f - beta1) * gk;
-            vv[k] = vv[k] * beta2 + (1.0f - beta2) * gk * gk;
-            const float denom = sqrtf(vv[k]) + eps;
-            float pk = p[k] - step_size * (mm[k] / denom);
-            if (wd > 0.f) pk = pk - lr * wd * pk;
-            p[k] = pk;
+        for (int u = 0; u < 2; ++u) {
+            gid[u] = cc[u] < nchunks ? chunk_group[cc[u]] : -1;
+            if (gid[u] < 0 || skip) continue;
+            const int64_t i = cc[u] * ADAMW_CHUNK + threadIdx.x * 4;
+            if (sizeof(T) == 2) {
+                const u32x2_t r = ntl ? __builtin_nontemporal_load((const u32x2_t*)(grad + i)) : *(const u32x2_t*)(grad + i);
+                g[u] = (f32x4_t){__uint_as_float(r[0] << 16), __uint_as_float(r[0] & 0xffff0000u), __uint_as_float(r[1] << 16), __uint_as_float(r[1] & 0xffff0000u)};
+            } else {
+                g[u] = ld4((const float*)(grad + i));
+            }
+            mm[u] = ld4(m + i); vv[u] = ld4(v + i); p[u] = ld4(master + i);
         }
-        *(f32x4_t*)(m + i) = mm; *(f32x4_t*)(v + i) = vv; *(f32x4_t*)(master + i) = p;
-        if (param) store4<T>(param + i, p);
-        if (zero_grad) store4<T>(grad + i, (f32x4_t){0.f, 0.f, 0.f, 0.f});
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            if (gid[u] < 0) continue;
+            const int64_t i = cc[u] * ADAMW_CHUNK + threadIdx.x * 4;
+            if (skip) {
+                if (zero_grad) store4<T>(grad + i, (f32x4_t){0.f, 0.f, 0.f, 0.f});
+                continue;
+            }
+            const float lr = groups.lr[gid[u]], wd = groups.wd[gid[u]];
+            const float step_size = lr * bc2_sqrt / bc1;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const float gk = g[u][k] * gs;
+                mm[u][k] = mm[u][k] * beta1 + (1.0f - beta1) * gk;
+                vv[u][k] = vv[u][k] * beta2 + (1.0f - beta2) * gk * gk;
+                const float denom = sqrtf(vv[u][k]) + eps;
+                float pk = p[u][k] - step_size * (mm[u][k] / denom);
+                if (wd > 0.f) pk = pk - lr * wd * pk;
+                p[u][k] = pk;
+            }
+            st4(m + i, mm[u]); st4(v + i, vv[u]); st4(master + i, p[u]);
+            if (param) store4<T>(param + i, p[u]);           // re-read by the next forward: stays cacheable
+            if (zero_grad) store4<T>(grad + i, (f32x4_t){0.f, 0.f, 0.f, 0.f});
+        }
     }
 }
 
@@ -95,6 +117,9 @@ __global__ __launch_bounds__(256) void clip_finalize_kernel(const float* partial
 }
 
 extern "C" int valor_adamw_chunk() { return ADAMW_CHUNK; }
+static int g_adamw_nt = [] { const char* e = getenv("VALOR_ADAMW_NT"); return e ? atoi(e) : 0; }();
+// non-temporal state accesses of the update kernel (bit 0 loads, bit 1 stores); returns the previous value, v < 0 only queries
+extern "C" int valor_adamw_set_nt(int v) { const int o = g_adamw_nt; if (v >= 0) g_adamw_nt = v; return o; }
 
 // n must be a multiple of valor_adamw_chunk(); chunk_group: int8 [n / chunk] (-1 = inactive).
 // lr / wd: host arrays of ngroups floats. step = 1-based Adam step of the active tensors.
@@ -116,9 +141,9 @@ extern "C" int valor_adamw(void* stream, int dtype, float* master, float* exp_av
     int blocks = (int)(nchunks < 8192 ? nchunks : 8192);
     hipStream_t st = (hipStream_t)stream;
     if (dtype == VALOR_DT_BF16)
-        hipLaunchKernelGGL((adamw_kernel<bf16_t>), dim3(blocks), dim3(256), 0, st, master, exp_avg, exp_avg_sq, (bf16_t*)grad, (bf16_t*)param, chunk_group, nchunks, g, beta1, beta2, eps, bc1, bc2s, gscale_dev, zero_grad);
+        hipLaunchKernelGGL((adamw_kernel<bf16_t>), dim3(blocks), dim3(256), 0, st, master, exp_avg, exp_avg_sq, (bf16_t*)grad, (bf16_t*)param, chunk_group, nchunks, g, beta1, beta2, eps, bc1, bc2s, gscale_dev, zero_grad, g_adamw_nt);
     else if (dtype == VALOR_DT_F32)
-        hipLaunchKernelGGL((adamw_kernel<float>), dim3(blocks), dim3(256), 0, st, master, exp_avg, exp_avg_sq, (float*)grad, (float*)param, chunk_group, nchunks, g, beta1, beta2, eps, bc1, bc2s, gscale_dev, zero_grad);
+        hipLaunchKernelGGL((adamw_kernel<float>), dim3(blocks), dim3(256), 0, st, master, exp_avg, exp_avg_sq, (float*)grad, (float*)param, chunk_group, nchunks, g, beta1, beta2, eps, bc1, bc2s, gscale_dev, zero_grad, g_adamw_nt);
     else return VALOR_ERR_ARG;
     return valor_launch_status();
 }

@@ -31,6 +31,7 @@ SIGNATURES = {
     "valor_gemm_set_policy": [_i, _i],
     "valor_ln_part_blocks": [],
     "valor_ln_set_variant": [_i],
+    "valor_ln_set_nt": [_i],
     "valor_bdrln_fwd": [_vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i, _f, _f, _u64, _u64, _vp, _i64],
     "valor_bdrln_bwd": [_vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i, _f, _u64, _u64, _vp, _i64],
     "valor_patchify3d": [_vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _i],
@@ -62,6 +63,7 @@ SIGNATURES = {
     "valor_fine_weight_grad": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i],
     "valor_fine_set_fused": [_i],
     "valor_adamw_chunk": [],
+    "valor_adamw_set_nt": [_i],
     "valor_adamw": [_vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _c.POINTER(_f), _c.POINTER(_f), _i, _f, _f, _f, _i, _i, _vp, _i],
     "valor_grad_norm_clip": [_vp, _i, _vp, _vp, _i64, _f, _f, _vp, _vp, _vp],
     "valor_patchify": [_vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _i64],
