@@ -77,8 +77,9 @@ int valor_gemm_set_tr_asm(int v);
 int valor_gemm_set_fast_epilogue(int v);
 /* policy parameters of variant 4 and of the 8-phase launch (tuning / A-B hook; returns the previous value, value < 0 only queries):
  *   key 0: smallest K for which a big-M dgrad (A row-major, B k-slow) runs on the 256x256 8-phase kernel
- *   key 1: unused (was the start skew of the 8-phase kernel's first round; measured slower at every setting,
- *          profiles/r02_gemm_policy_ab.json)
+ *   key 1: 1 = the split-K partial tiles of the bf16 LDS-DMA kernels are written and summed as bf16 (half the workspace traffic, one more
+ *          rounding per partial; never for fp32 outputs); default 0. (Round 2: the start skew of the 8-phase kernel's first round,
+ *          measured slower at every setting, profiles/r02_gemm_policy_ab.json)
  *   key 2: smallest number of 256x256 tiles for the 8-phase kernel on forward problems (default 256: one full round of workgroups)
  *   key 3: the same for dgrad problems (default 1024: below it the 128x128 kernel measured faster, session N)
  *   key 4: L2-aware tile raster of the 8-phase kernels: 0 (default) = row-major over all tile columns; G > 0 = groups of G tile columns
@@ -131,6 +132,11 @@ int valor_colsum(void* stream, int dtype, const void* x, int64_t rows, int cols,
  * bf16 (S = Sq = Skv <= 256, no kv_range); bit 1 = key-stationary cross-attention kernels (few query rows, many keys,
  * grouped kv_range); 0 = streaming kernels only. Returns the previous value; v < 0 queries. */
 int valor_attn_set_variant(int v);
+/* LDS-resident self-attention backward: 1 (default, env VALOR_ATTN_PIPE) = persistent workgroups (one per CU) that walk (batch, head)
+ * items with the K / V and Q / dO LDS images double-buffered across the dQ and the dK / dV phase, so the loads and stores of one item
+ * overlap the arithmetic of its neighbours; 0 = one workgroup per (batch, head). Bit-identical results. Used when batch x heads >= 2 x
+ * the CU count. Returns the previous value, v < 0 only queries. */
+int valor_attn_set_res_pipeline(int v);
 
 /* ---- flash attention, head_dim 64.  Replaces BertSelfAttention (bert.py:272-288), BertCrossAttention (bert.py:314-340,
  * K/V = [video|audio] tokens, grouping bert.py:448-455), AST MultiHeadAttention (transformer.py:115-130) and CLIP's

@@ -116,3 +116,39 @@ def test_attention_dropout(dev):
     want = keepmask.view(B, Sq, H, 64).sum(1) / (1 - p) / Skv          # [B,H,key<64]
     got = dv.view(B, Skv, H, 64)[:, :64, :, 0].permute(0, 2, 1)        # dv[b,key,h,0]
     assert torch.allclose(got, want, atol=1e-5), (got - want).abs().max()
+
+
+@pytest.mark.parametrize("S,B,H,p_drop", [(197, 44, 12, 0.0), (197, 44, 12, 0.1), (129, 48, 12, 0.1), (256, 43, 12, 0.0), (65, 90, 6, 0.1), (224, 64, 8, 0.0)])
+def test_resident_backward_pipelined_equals_per_head_kernel(dev, S, B, H, p_drop):
+    """The persistent, phase-pipelined LDS-resident backward (attention_res.hip: one workgroup per CU walks (batch, head) items, the
+    K / V and Q / dO image pairs double-buffered across its two phases) does the arithmetic of the one-workgroup-per-head kernel in
+    the same order: identical dQ / dK / dV, at item counts that give every workgroup several (and unequal numbers of) items, a tail
+    round, sequence lengths with partial 32-row blocks, with and without dropout; and against fp64 on one of the shapes.
+    Reference semantics: model/clip.py:186-192 (ViT S = 197), model/transformer.py:115-130 (AST S = 129)."""
+    from valor_amd import kernels as K, lib
+    so = lib.load()
+    E = H * 64
+    g = torch.Generator().manual_seed(S * 7 + B)
+    qkv = (torch.randn((B, S, 3 * E), generator=g) * 0.8).to(torch.bfloat16).to(dev)
+    q, k, v = qkv[:, :, :E], qkv[:, :, E:2 * E], qkv[:, :, 2 * E:]
+    dout = torch.randn((B, S, E), generator=g).to(torch.bfloat16).to(dev)
+    scale = 1.0 / math.sqrt(64)
+    o, lse = K.attn_fwd(q, k, v, H, scale=scale, p_drop=p_drop, seed=5, offset=9)
+    old = so.valor_attn_set_res_pipeline(1)
+    try:
+        dq1, dk1, dv1 = K.attn_bwd(q, k, v, o, lse, dout, H, scale=scale, p_drop=p_drop, seed=5, offset=9)
+        dq1b, dk1b, dv1b = K.attn_bwd(q, k, v, o, lse, dout, H, scale=scale, p_drop=p_drop, seed=5, offset=9)     # and it is deterministic
+        so.valor_attn_set_res_pipeline(0)
+        dq0, dk0, dv0 = K.attn_bwd(q, k, v, o, lse, dout, H, scale=scale, p_drop=p_drop, seed=5, offset=9)
+    finally:
+        so.valor_attn_set_res_pipeline(old)
+    torch.cuda.synchronize()
+    for a, b_, c, n in ((dq1, dq0, dq1b, "dq"), (dk1, dk0, dk1b, "dk"), (dv1, dv0, dv1b, "dv")):
+        assert torch.equal(a, c), n
+        assert torch.equal(a, b_), (n, float((a.float() - b_.float()).abs().max()))
+    if p_drop == 0.0 and S == 197:
+        sl = slice(0, 3)          # fp64 reference on three samples
+        qd, kd, vd = (t[sl].double().detach().requires_grad_(True) for t in (q, k, v))
+        oref = _ref_attn(qd, kd, vd, H, None, None, 0, scale)
+        (oref * dout[sl].double()).sum().backward()
+        assert _rel(dq1[sl], qd.grad) < 2e-2 and _rel(dk1[sl], kd.grad) < 2e-2 and _rel(dv1[sl], vd.grad) < 2e-2

@@ -145,3 +145,33 @@ def test_logits_into_the_padded_vocab_buffer(dev):
     assert bool((buf[:, V:] == 7.0).all())
     # its wgrad: [V, 768] = dlogits^T . h over 2100 rows is NOT an 8-phase problem (K < 4096) -- the policy must say so
     assert _family(so, 1, 1, V, W, n) != 3
+
+
+def test_wgrad_splitk_with_bf16_partials(dev):
+    """policy key 1: the split-K partial tiles as bf16 (half the workspace traffic; one more rounding per partial): same result within
+    the bf16 resolution of the sum, row sums (fp32 partials, unchanged) exact as before, fp32 outputs keep fp32 partials"""
+    from valor_amd import kernels as Kn, lib
+    so = lib.load()
+    Kt, Mo, No = M_VIT, I, W
+    dY, X = _mk((Kt, Mo), 21, dev, 0.1), _mk((Kt, No), 22, dev)
+    ref = dY.float().t() @ X.float()
+    old = so.valor_gemm_set_policy(1, 1)
+    try:
+        dW = Kn.gemm(dY, X, trans_a=True, trans_b=True)
+        gb = torch.zeros((Mo,), dtype=torch.bfloat16, device=dev)
+        gw = torch.zeros((Mo, No), dtype=torch.bfloat16, device=dev)
+        Kn.gemm(dY, X, trans_a=True, trans_b=True, out=gw, accumulate=True, rowsum_out=gb, rowsum_accumulate=True)
+        d32 = Kn.gemm(dY, X, trans_a=True, trans_b=True, out_dtype=torch.float32)
+        # a small 128x128-kernel split-K problem too (decoder-sized contraction)
+        a, b_ = _mk((8832, 768), 23, dev, 0.1), _mk((8832, 768), 24, dev)
+        small = Kn.gemm(a, b_, trans_a=True, trans_b=True)
+    finally:
+        so.valor_gemm_set_policy(1, old)
+    whole, worst = _tile_errors(dW, ref)
+    assert whole < 1.5 * TOL and worst < 1.5 * TILE_TOL, (whole, worst)
+    assert torch.equal(gw, dW)
+    rs = dY.float().sum(dim=0)
+    assert float((gb.float() - rs).norm() / rs.norm()) < 3e-3
+    assert float((d32 - ref).norm() / ref.norm()) < 2e-5            # fp32 output: fp32 partials
+    sref = a.float().t() @ b_.float()
+    assert float((small.float() - sref).norm() / sref.norm()) < 1.5 * TOL

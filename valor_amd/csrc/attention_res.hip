@@ -20,6 +20,7 @@
 // softmax statistics are per-lane scalars (+2 shuffles) and P feeds the next MFMA from registers.
 // Softmax runs in the exp2 domain (scale * log2 e folded into one multiply, v_exp_f32 directly).
 #include "attn_common.h"
+#include <stdlib.h>
 
 DEVINL float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
 
@@ -398,6 +399,309 @@ __global__ __launch_bounds__(512, 2) void attn_res_bwd_kernel(AttnArgs p) {
     }
 }
 
+// ------------------------------------------------------------------------------------------ backward, pipelined
+// The kernel above is one workgroup per CU (114 KiB of LDS, 8 waves x 178 VGPRs) whose three stretches do not overlap with anything:
+// 112 KiB of LDS-DMA before the first MFMA, the two compute phases, 75 KiB of stores -- and every CU does the same thing at the same
+// time, so the chip alternates between an HBM-bound and a compute-bound state (ViT shape: 1.24 GB of traffic = 250 us at 5 TB/s plus
+// ~300 us of matrix / VALU work = the measured 668 us). This variant keeps the arithmetic and makes the workgroup PERSISTENT over
+// (batch, head) items with the two image pairs double-buffered ACROSS THE PHASES:
+//     phase 1 (dQ)      reads the K, V images (buffer A); its own 32 query rows of Q / dO / O come straight from global into registers
+//     phase 2 (dK, dV)  reads the Q, dO images (buffer B); its own 32 key rows of K / V come straight from global into registers
+//   while phase 1 of item i runs, the DMA of Q, dO (i) lands in B; while phase 2 runs, the DMA of K, V (i+1) lands in A; the stores of
+//   dQ / dK / dV drain under the following phase. Two barriers per item. LDS as before (4 images + the softmax statistics).
+// The register operands of a phase are plain global loads issued and COMPLETED (explicit vmcnt(0), values laundered through an empty
+// asm) before that phase's DMA is issued: hipcc waits vmcnt(0) at the first use of an ordinary load that has LDS-DMA behind it,
+// which would drain the look-ahead.
+// transposing fragment reads of the XOR image as inline asm (mma.h: the builtin has no memory operand, hipcc drains every LDS-DMA in flight
+// in front of it): the second half of a fragment lives 16 image rows = 2048 B further.
+DEVINL void tr_issue_img(TrPair& t, const char* a) {
+    const uint32_t addr = (uint32_t)(uintptr_t)LDS_PTR(a);
+    asm volatile("ds_read_b64_tr_b16 %0, %2\n\tds_read_b64_tr_b16 %1, %2 offset:2048" : "=&v"(t.lo), "=&v"(t.hi) : "v"(addr));
+}
+DEVINL void tr_wait4x(TrPair (&t)[4]) {
+    asm volatile("s_waitcnt lgkmcnt(0)" : TR_TIE(t[0]), TR_TIE(t[1]), TR_TIE(t[2]), TR_TIE(t[3]));
+}
+DEVINL void launder(bf16x8_t& v) { asm volatile("" : "+v"(v)); }
+DEVINL void launder(float& v) { asm volatile("" : "+v"(v)); }
+
+template <bool DROP>
+__global__ __launch_bounds__(512, 2) void attn_res_bwd_pipe_kernel(AttnArgs p, int n_items) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int fr = lane & 15, g = lane >> 4;
+    const int S = p.Skv, SP = (S + 31) & ~31;
+    const int IMG = SP * TILE_ROW_BYTES;
+    char* sK = smem;                 // buffer A
+    char* sV = smem + IMG;
+    char* sQ = smem + 2 * IMG;       // buffer B
+    char* sDO = smem + 3 * IMG;
+    float* sLse = (float*)(smem + 4 * IMG);
+    float* sDelta = sLse + SP;
+    const float sl2 = p.scale * LOG2E_F;
+    const uint32_t thr = drop_threshold(p.p_drop);
+    const float keep_scale = p.p_drop > 0.f ? 1.0f / (1.0f - p.p_drop) : 1.0f;
+    int troff[4];
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) troff[dt] = tr_lane_off(lane, dt);
+    const int NP = (S + 31) >> 5, NT = (S + 63) >> 6;      // NP <= 8: one 32-row block per wave
+    const int pr = wave;
+    const bool active = pr < NP;
+
+    int item = blockIdx.x;
+    if (item < n_items) {
+        const int h = item % p.H, b = item / p.H;
+        stage_image(head_rsrc(p.k, (int64_t)b * p.k_bs + h * ATT_D, S, p.k_rs), sK, SP, (int)p.k_rs * 2, wave, 8, lane);
+        stage_image(head_rsrc(p.v, (int64_t)b * p.v_bs + h * ATT_D, S, p.v_rs), sV, SP, (int)p.v_rs * 2, wave, 8, lane);
+    }
+    for (; item < n_items; item += gridDim.x) {
+        const int h = item % p.H, b = item / p.H;
+        const uint32_t hk = attn_drop_headkey(p.seed, p.offset, b * p.H + h);
+        // ---------------- phase 1 operands: this wave's 32 query rows of Q / dO (fragments), O (for delta), lse
+        bf16x8_t qf[2][2], dof[2][2];
+        int qr[2];
+        float lse2[2], dlt[2];
+        {
+            const bf16_t* Qb = (const bf16_t*)p.q + (int64_t)b * p.q_bs + h * ATT_D;
+            const bf16_t* DOb = (const bf16_t*)p.dout + (int64_t)b * p.do_bs + h * ATT_D;
+            const bf16_t* Ob = (const bf16_t*)p.o + (int64_t)b * p.o_bs + h * ATT_D;
+            const int64_t statbase = ((int64_t)b * p.H + h) * p.Sq;
+#pragma unroll
+            for (int rt = 0; rt < 2; ++rt) {
+                qr[rt] = pr * 32 + rt * 16 + fr;
+                const bool ok = active && qr[rt] < S;
+                float d = 0.f;
+#pragma unroll
+                for (int dg = 0; dg < 2; ++dg) {
+                    u32x4_t zq = {0u, 0u, 0u, 0u}, zd = zq, zo = zq;
+                    if (ok) {
+                        zq = *(const u32x4_t*)(Qb + (int64_t)qr[rt] * p.q_rs + dg * 32 + g * 8);
+                        zd = *(const u32x4_t*)(DOb + (int64_t)qr[rt] * p.do_rs + dg * 32 + g * 8);
+                        zo = *(const u32x4_t*)(Ob + (int64_t)qr[rt] * p.o_rs + dg * 32 + g * 8);
+                    }
+                    qf[rt][dg] = __builtin_bit_cast(bf16x8_t, zq);
+                    dof[rt][dg] = __builtin_bit_cast(bf16x8_t, zd);
+                    const bf16x8_t ov = __builtin_bit_cast(bf16x8_t, zo);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) d += (float)ov[e] * (float)dof[rt][dg][e];
+                }
+                lse2[rt] = ok ? p.lse[statbase + qr[rt]] * LOG2E_F : INFINITY;       // rows past S: P = 2^(s - inf) = 0
+                d += __shfl_xor(d, 16, 64);
+                d += __shfl_xor(d, 32, 64);
+                dlt[rt] = d;
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // the register operands above AND this wave's pieces of K, V (item)
+#pragma unroll
+        for (int rt = 0; rt < 2; ++rt) {
+#pragma unroll
+            for (int dg = 0; dg < 2; ++dg) { launder(qf[rt][dg]); launder(dof[rt][dg]); }
+            launder(lse2[rt]); launder(dlt[rt]);
+        }
+        __syncthreads();        // K, V (item) landed for every wave; everyone is past phase 2 of the previous item (buffer B, statistics free)
+        if (active && g == 0) {     // read by every wave in phase 2, i.e. behind the next barrier
+#pragma unroll
+            for (int rt = 0; rt < 2; ++rt) { sLse[qr[rt]] = lse2[rt]; sDelta[qr[rt]] = dlt[rt]; }
+        }
+        stage_image(head_rsrc(p.q, (int64_t)b * p.q_bs + h * ATT_D, S, p.q_rs), sQ, SP, (int)p.q_rs * 2, wave, 8, lane);
+        stage_image(head_rsrc(p.dout, (int64_t)b * p.do_bs + h * ATT_D, S, p.do_rs), sDO, SP, (int)p.do_rs * 2, wave, 8, lane);
+
+        // ---------------- phase 1: dQ of this wave's query block against all keys (images A)
+        if (active) {
+            f32x4_t dqacc[2][4];
+#pragma unroll
+            for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+                for (int dt = 0; dt < 4; ++dt) dqacc[rt][dt] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+            for (int t = 0; t < NT; ++t) {
+                const int kv0 = t << 6;
+                int nkt = (S - kv0 + 15) >> 4;
+                nkt = nkt > 4 ? 4 : nkt;
+#pragma unroll
+                for (int kk = 0; kk < 2; ++kk) {
+                    if (2 * kk >= nkt) continue;
+                    f32x4_t ds[2][2];      // [rt][kt2]
+#pragma unroll
+                    for (int k2 = 0; k2 < 2; ++k2) {
+                        const int kt = 2 * kk + k2;
+                        f32x4_t sa[2], pa[2];
+                        sa[0] = (f32x4_t){0.f, 0.f, 0.f, 0.f}; sa[1] = sa[0]; pa[0] = sa[0]; pa[1] = sa[0];
+                        if (kt < nkt) {
+#pragma unroll
+                            for (int dg = 0; dg < 2; ++dg) {
+                                const bf16x8_t kf = read_frag<bf16_t>(sK, kv0 + kt * 16 + fr, dg * 4 + g);
+                                const bf16x8_t vf = read_frag<bf16_t>(sV, kv0 + kt * 16 + fr, dg * 4 + g);
+                                sa[0] = Mma<bf16_t>::mma(kf, qf[0][dg], sa[0]);
+                                sa[1] = Mma<bf16_t>::mma(kf, qf[1][dg], sa[1]);
+                                pa[0] = Mma<bf16_t>::mma(vf, dof[0][dg], pa[0]);
+                                pa[1] = Mma<bf16_t>::mma(vf, dof[1][dg], pa[1]);
+                            }
+                        }
+#pragma unroll
+                        for (int rt = 0; rt < 2; ++rt) {
+                            const bool qok = qr[rt] < S;
+                            const float* mrowp = (p.mask && qok) ? p.mask + (int64_t)b * p.mask_bs + (int64_t)qr[rt] * p.mask_rs : nullptr;
+                            const uint32_t e0 = (uint32_t)qr[rt] * (uint32_t)p.Skv + (uint32_t)(kv0 + kt * 16 + 4 * g);
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) {
+                                float sc = sa[rt][r] * sl2;
+                                if (mrowp) { const int key = kv0 + kt * 16 + 4 * g + r; if (key < S) sc += mrowp[key] * LOG2E_F; }
+                                const float prb = fast_exp2(sc - lse2[rt]);
+                                float dp = pa[rt][r];
+                                if (DROP) dp = attn_drop_bits(hk, e0 + r) >= thr ? dp * keep_scale : 0.f;
+                                ds[rt][k2][r] = prb * (dp - dlt[rt]);
+                            }
+                        }
+                    }
+                    const bf16x8_t d0 = pack_bf16x8(ds[0][0], ds[0][1]);
+                    const bf16x8_t d1 = pack_bf16x8(ds[1][0], ds[1][1]);
+                    TrPair tk[4];
+#pragma unroll
+                    for (int dt = 0; dt < 4; ++dt) tr_issue_img(tk[dt], sK + (kv0 + 32 * kk) * TILE_ROW_BYTES + troff[dt]);   // K^T[d][key]
+                    tr_wait4x(tk);
+#pragma unroll
+                    for (int dt = 0; dt < 4; ++dt) {
+                        const bf16x8_t ktf = tr_frag(tk[dt]);
+                        dqacc[0][dt] = Mma<bf16_t>::mma(ktf, d0, dqacc[0][dt]);
+                        dqacc[1][dt] = Mma<bf16_t>::mma(ktf, d1, dqacc[1][dt]);
+                    }
+                }
+            }
+#pragma unroll
+            for (int rt = 0; rt < 2; ++rt)
+                if (qr[rt] < S) {
+                    bf16_t* DQ = (bf16_t*)p.dq + (int64_t)b * p.dq_bs + (int64_t)qr[rt] * p.dq_rs + h * ATT_D;
+#pragma unroll
+                    for (int dt = 0; dt < 4; ++dt) store4<bf16_t>(DQ + dt * 16 + 4 * g, dqacc[rt][dt] * p.scale);
+                }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // this wave's pieces of Q, dO (item)
+        __syncthreads();        // Q, dO landed and the statistics are visible; everyone is done with the K, V images (buffer A free)
+
+        // ---------------- phase 2 operands: this wave's 32 key rows of K / V, then the look-ahead DMA of the next item's K, V
+        bf16x8_t kf[2][2], vf[2][2];
+        int key[2];
+        {
+            const bf16_t* Kb = (const bf16_t*)p.k + (int64_t)b * p.k_bs + h * ATT_D;
+            const bf16_t* Vb = (const bf16_t*)p.v + (int64_t)b * p.v_bs + h * ATT_D;
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt) {
+                key[kt] = pr * 32 + kt * 16 + fr;
+                const bool ok = active && key[kt] < S;
+#pragma unroll
+                for (int dg = 0; dg < 2; ++dg) {
+                    u32x4_t zk = {0u, 0u, 0u, 0u}, zv = zk;
+                    if (ok) {
+                        zk = *(const u32x4_t*)(Kb + (int64_t)key[kt] * p.k_rs + dg * 32 + g * 8);
+                        zv = *(const u32x4_t*)(Vb + (int64_t)key[kt] * p.v_rs + dg * 32 + g * 8);
+                    }
+                    kf[kt][dg] = __builtin_bit_cast(bf16x8_t, zk);
+                    vf[kt][dg] = __builtin_bit_cast(bf16x8_t, zv);
+                }
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+            for (int dg = 0; dg < 2; ++dg) { launder(kf[kt][dg]); launder(vf[kt][dg]); }
+        {
+            const int nxt = item + gridDim.x;
+            if (nxt < n_items) {
+                const int h2 = nxt % p.H, b2 = nxt / p.H;
+                stage_image(head_rsrc(p.k, (int64_t)b2 * p.k_bs + h2 * ATT_D, S, p.k_rs), sK, SP, (int)p.k_rs * 2, wave, 8, lane);
+                stage_image(head_rsrc(p.v, (int64_t)b2 * p.v_bs + h2 * ATT_D, S, p.v_rs), sV, SP, (int)p.v_rs * 2, wave, 8, lane);
+            }
+        }
+        // ---------------- phase 2: dK, dV of this wave's key block against all queries (images B)
+        if (active) {
+            f32x4_t dkacc[2][4], dvacc[2][4];
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                for (int dt = 0; dt < 4; ++dt) { dkacc[kt][dt] = (f32x4_t){0.f, 0.f, 0.f, 0.f}; dvacc[kt][dt] = dkacc[kt][dt]; }
+            for (int t = 0; t < NT; ++t) {
+                const int qb0 = t << 6;
+                int nqs = (S - qb0 + 15) >> 4;
+                nqs = nqs > 4 ? 4 : nqs;
+#pragma unroll 1
+                for (int kk = 0; kk < 2; ++kk) {
+                    if (2 * kk >= nqs) continue;
+                    f32x4_t pd[2][2], ds[2][2];      // [kt][q2]
+#pragma unroll
+                    for (int q2 = 0; q2 < 2; ++q2) {
+                        const int qs = 2 * kk + q2;
+                        f32x4_t sa[2], pa[2];
+                        sa[0] = (f32x4_t){0.f, 0.f, 0.f, 0.f}; sa[1] = sa[0]; pa[0] = sa[0]; pa[1] = sa[0];
+                        f32x4_t l4 = sa[0], d4 = sa[0];
+                        const int q4 = qb0 + qs * 16 + 4 * g;
+                        if (qs < nqs) {
+#pragma unroll
+                            for (int dg = 0; dg < 2; ++dg) {
+                                const bf16x8_t qfr = read_frag<bf16_t>(sQ, qb0 + qs * 16 + fr, dg * 4 + g);
+                                const bf16x8_t dfr = read_frag<bf16_t>(sDO, qb0 + qs * 16 + fr, dg * 4 + g);
+                                sa[0] = Mma<bf16_t>::mma(qfr, kf[0][dg], sa[0]);
+                                sa[1] = Mma<bf16_t>::mma(qfr, kf[1][dg], sa[1]);
+                                pa[0] = Mma<bf16_t>::mma(dfr, vf[0][dg], pa[0]);
+                                pa[1] = Mma<bf16_t>::mma(dfr, vf[1][dg], pa[1]);
+                            }
+                            l4 = *(const f32x4_t*)(sLse + q4); d4 = *(const f32x4_t*)(sDelta + q4);
+                        }
+                        if (qs >= nqs) l4 = (f32x4_t){INFINITY, INFINITY, INFINITY, INFINITY};
+#pragma unroll
+                        for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) {
+                                const int qrow = q4 + r;
+                                float sc = sa[kt][r] * sl2;
+                                if (p.mask) { if (qrow < S && key[kt] < S) sc += p.mask[(int64_t)b * p.mask_bs + (int64_t)qrow * p.mask_rs + key[kt]] * LOG2E_F; }
+                                const float prb = fast_exp2(sc - l4[r]);
+                                float dp = pa[kt][r], pdv = prb;
+                                if (DROP) {
+                                    const bool keep = attn_drop_bits(hk, (uint32_t)qrow * (uint32_t)p.Skv + (uint32_t)key[kt]) >= thr;
+                                    dp = keep ? dp * keep_scale : 0.f;
+                                    pdv = keep ? prb * keep_scale : 0.f;
+                                }
+                                pd[kt][q2][r] = pdv; ds[kt][q2][r] = prb * (dp - d4[r]);
+                            }
+                    }
+                    const bf16x8_t p0 = pack_bf16x8(pd[0][0], pd[0][1]);
+                    const bf16x8_t p1 = pack_bf16x8(pd[1][0], pd[1][1]);
+                    const bf16x8_t s0 = pack_bf16x8(ds[0][0], ds[0][1]);
+                    const bf16x8_t s1 = pack_bf16x8(ds[1][0], ds[1][1]);
+                    TrPair tdo[4], tq[4];
+#pragma unroll
+                    for (int dt = 0; dt < 4; ++dt) {
+                        tr_issue_img(tdo[dt], sDO + (qb0 + 32 * kk) * TILE_ROW_BYTES + troff[dt]);   // dO^T[d][q]
+                        tr_issue_img(tq[dt], sQ + (qb0 + 32 * kk) * TILE_ROW_BYTES + troff[dt]);     // Q^T[d][q]
+                    }
+                    tr_wait4x(tdo);
+                    tr_wait4x(tq);
+#pragma unroll
+                    for (int dt = 0; dt < 4; ++dt) {
+                        const bf16x8_t dotf = tr_frag(tdo[dt]), qtf = tr_frag(tq[dt]);
+                        dvacc[0][dt] = Mma<bf16_t>::mma(dotf, p0, dvacc[0][dt]);
+                        dvacc[1][dt] = Mma<bf16_t>::mma(dotf, p1, dvacc[1][dt]);
+                        dkacc[0][dt] = Mma<bf16_t>::mma(qtf, s0, dkacc[0][dt]);
+                        dkacc[1][dt] = Mma<bf16_t>::mma(qtf, s1, dkacc[1][dt]);
+                    }
+                }
+            }
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt)
+                if (key[kt] < S) {
+                    bf16_t* DK = (bf16_t*)p.dk + (int64_t)b * p.dk_bs + (int64_t)key[kt] * p.dk_rs + h * ATT_D;
+                    bf16_t* DV = (bf16_t*)p.dv + (int64_t)b * p.dv_bs + (int64_t)key[kt] * p.dv_rs + h * ATT_D;
+#pragma unroll
+                    for (int dt = 0; dt < 4; ++dt) {
+                        store4<bf16_t>(DK + dt * 16 + 4 * g, dkacc[kt][dt] * p.scale);
+                        store4<bf16_t>(DV + dt * 16 + 4 * g, dvacc[kt][dt]);
+                    }
+                }
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------ launch
 static bool res_eligible(const AttnArgs& p) {
     if (p.kv_range || p.kv_bmod > 0 || p.Sq != p.Skv || p.Skv > 256 || p.acc_dkv) return false;
@@ -420,6 +724,14 @@ bool attn_res_fwd_launch(hipStream_t st, const AttnArgs& p) {
     return true;
 }
 
+static int g_res_bwd_pipe = [] { const char* e = getenv("VALOR_ATTN_PIPE"); return e ? atoi(e) : 1; }();
+// 1 (default): the persistent, phase-pipelined backward; 0: one workgroup per (batch, head). Same results. Returns the previous value.
+extern "C" int valor_attn_set_res_pipeline(int v) {
+    const int o = g_res_bwd_pipe;
+    if (v >= 0) g_res_bwd_pipe = v;
+    return o;
+}
+
 bool attn_res_bwd_launch(hipStream_t st, const AttnArgs& p) {
     // one workgroup of 8 waves per head needs >= 2 32-row blocks to be worth it; shorter sequences stay on the
     // streaming kernels (measured: S = 32 / 42 are slower here)
@@ -427,11 +739,22 @@ bool attn_res_bwd_launch(hipStream_t st, const AttnArgs& p) {
     const int SP = (p.Skv + 31) & ~31;
     const size_t lds = 4 * (size_t)SP * TILE_ROW_BYTES + 2 * (size_t)SP * sizeof(float);
     static bool attr_set = false;
+    static int n_cu = 256;
     if (!attr_set) {
         const int mx = 4 * 256 * TILE_ROW_BYTES + 2 * 256 * (int)sizeof(float);
         hipFuncSetAttribute((const void*)attn_res_bwd_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, mx);
         hipFuncSetAttribute((const void*)attn_res_bwd_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, mx);
+        hipFuncSetAttribute((const void*)attn_res_bwd_pipe_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, mx);
+        hipFuncSetAttribute((const void*)attn_res_bwd_pipe_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, mx);
+        int dev = 0, cus = 0;
+        if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus > 0) n_cu = cus;
         attr_set = true;
+    }
+    const int n_items = p.B * p.H;
+    if (g_res_bwd_pipe && n_items >= 2 * n_cu) {        // several items per workgroup: otherwise there is nothing to pipeline
+        if (p.p_drop > 0.f) hipLaunchKernelGGL(attn_res_bwd_pipe_kernel<true>, dim3(n_cu), dim3(512), lds, st, p, n_items);
+        else hipLaunchKernelGGL(attn_res_bwd_pipe_kernel<false>, dim3(n_cu), dim3(512), lds, st, p, n_items);
+        return true;
     }
     if (p.p_drop > 0.f) hipLaunchKernelGGL(attn_res_bwd_kernel<true>, dim3(p.H, p.B), dim3(512), lds, st, p);
     else hipLaunchKernelGGL(attn_res_bwd_kernel<false>, dim3(p.H, p.B), dim3(512), lds, st, p);

@@ -150,23 +150,30 @@ __global__ __launch_bounds__(64) void fine_reduce_bwd_kernel(const float* dscore
         }
     }
 }
-// dwA[a,t] = sum_b 0.5 dscore[a,b] A2B[a,b,t]   (one wave per a) ; dwB[b,v] = sum_a 0.5 dscore[a,b] B2A[a,b,v]
-__global__ void fine_weight_grad_kernel(const float* dscore, const float* A2B, const float* B2A, float* dwA, float* dwB,
-                                        int B, int T, int Nv) {
-    const int w = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
-    if (w >= 2 * B) return;
-    if (w < B) {
-        const int a = w;
-        if (lane >= T) return;
-        float s = 0.f;
-        for (int b = 0; b < B; ++b) s += dscore[(int64_t)a * B + b] * A2B[((int64_t)a * B + b) * T + lane];
-        dwA[a * T + lane] = 0.5f * s;
-    } else {
-        const int b = w - B;
-        if (lane >= Nv) return;
-        float s = 0.f;
-        for (int a = 0; a < B; ++a) s += dscore[(int64_t)a * B + b] * B2A[((int64_t)a * B + b) * Nv + lane];
-        dwB[b * Nv + lane] = 0.5f * s;
+// dwA[a,t] = sum_b 0.5 dscore[a,b] A2B[a,b,t] ; dwB[b,v] = sum_a 0.5 dscore[a,b] B2A[a,b,v].
+// One workgroup per text a (blocks 0..B-1) or clip b (blocks B..2B-1): the 256 threads are 4 token lanes x ... -- thread (slice = tid / 64,
+// lane = token) walks every 4th pair, the four slices meet in LDS. (One wave per a with a 512-iteration dependent-latency loop took
+// 167 us at the 8-GPU global batch; this is a 2 x 43 MB streaming read.)
+__global__ __launch_bounds__(256) void fine_weight_grad_kernel(const float* dscore, const float* A2B, const float* B2A, float* dwA, float* dwB,
+                                                              int B, int T, int Nv) {
+    __shared__ float red[4][64];
+    const int lane = threadIdx.x & 63, sl = threadIdx.x >> 6;
+    const bool isA = (int)blockIdx.x < B;
+    const int i = isA ? blockIdx.x : blockIdx.x - B;
+    const int n = isA ? T : Nv;
+    float s = 0.f;
+    if (lane < n) {
+        if (isA) {
+            for (int b = sl; b < B; b += 4) s += dscore[(int64_t)i * B + b] * A2B[((int64_t)i * B + b) * T + lane];
+        } else {
+            for (int a = sl; a < B; a += 4) s += dscore[(int64_t)a * B + i] * B2A[((int64_t)a * B + i) * Nv + lane];
+        }
+    }
+    red[sl][lane] = s;
+    __syncthreads();
+    if (sl == 0 && lane < n) {
+        const float t = red[0][lane] + red[1][lane] + red[2][lane] + red[3][lane];
+        (isA ? dwA : dwB)[i * n + lane] = 0.5f * t;
     }
 }
 
@@ -242,7 +249,7 @@ extern "C" int valor_fine_reduce_bwd(void* stream, int dtype, const float* dscor
     else if (dtype == VALOR_DT_F32)
         hipLaunchKernelGGL((fine_reduce_bwd_kernel<float>), dim3(B, B), dim3(64), 0, st, dscore, maskA, maskB, wA, wB, idxA, idxB, (float*)dS, ldS, B, T, Nv);
     else return VALOR_ERR_ARG;
-    hipLaunchKernelGGL(fine_weight_grad_kernel, dim3((2 * B + 3) / 4), dim3(256), 0, st, dscore, A2B, B2A, dwA, dwB, B, T, Nv);
+    hipLaunchKernelGGL(fine_weight_grad_kernel, dim3(2 * B), dim3(256), 0, st, dscore, A2B, B2A, dwA, dwB, B, T, Nv);
     return valor_launch_status();
 }
 
@@ -251,6 +258,6 @@ extern "C" int valor_fine_weight_grad(void* stream, const float* dscore, const f
                                       int B, int T, int Nv) {
     if (B <= 0) return VALOR_OK;
     if (T <= 0 || T > 64 || Nv <= 0 || Nv > 64) return VALOR_ERR_ARG;
-    hipLaunchKernelGGL(fine_weight_grad_kernel, dim3((2 * B + 3) / 4), dim3(256), 0, (hipStream_t)stream, dscore, A2B, B2A, dwA, dwB, B, T, Nv);
+    hipLaunchKernelGGL(fine_weight_grad_kernel, dim3(2 * B), dim3(256), 0, (hipStream_t)stream, dscore, A2B, B2A, dwA, dwB, B, T, Nv);
     return valor_launch_status();
 }

@@ -418,11 +418,7 @@ __global__ __launch_bounds__(256, WPS) void gemm_glds_kernel(GemmArgs p) {
             const f32x4_t v1 = *(const f32x4_t*)(sC + ml * 128 + (((2 * c8 + 1) ^ (ml & 7)) << 2));
             const int m = m0 + pass * EPI_ROWS + ml, n = n0 + c8 * 8;
             if (wsl) {
-                if (m < p.M) {
-                    float* q = wsl + (int64_t)m * p.N + n;
-                    if (n + 7 < p.N && (p.N & 3) == 0) { *(f32x4_t*)q = v0; *(f32x4_t*)(q + 4) = v1; }
-                    else for (int r = 0; r < 8; ++r) if (n + r < p.N) q[r] = r < 4 ? v0[r] : v1[r - 4];
-                }
+                splitk_store8(p, slice, m, n, v0, v1);
             } else {
                 epilogue_store8<FUSED>(p, m, n, v0, v1, load_bias4<T>(p, n), load_bias4<T>(p, n + 4));
             }
@@ -439,10 +435,18 @@ __global__ __launch_bounds__(256) void gemm_splitk_reduce(GemmArgs p) {
         const int m = (int)(i / nquads);
         const int n = (int)(i - (int64_t)m * nquads) << 2;
         f32x4_t s = {0.f, 0.f, 0.f, 0.f};
-        for (int k = 0; k < p.kslices; ++k) {
-            const float* q = p.ws + ((int64_t)k * p.M + m) * p.N + n;
-            if (n + 3 < p.N && (p.N & 3) == 0) s += *(const f32x4_t*)q;
-            else for (int r = 0; r < 4; ++r) if (n + r < p.N) s[r] += q[r];
+        if (p.ws_bf16) {
+            for (int k = 0; k < p.kslices; ++k) {
+                const bf16_t* q = (const bf16_t*)p.ws + ((int64_t)k * p.M + m) * p.N + n;
+                if (n + 3 < p.N && (p.N & 3) == 0) s += load4<bf16_t>(q);
+                else for (int r = 0; r < 4; ++r) if (n + r < p.N) s[r] += (float)q[r];
+            }
+        } else {
+            for (int k = 0; k < p.kslices; ++k) {
+                const float* q = p.ws + ((int64_t)k * p.M + m) * p.N + n;
+                if (n + 3 < p.N && (p.N & 3) == 0) s += *(const f32x4_t*)q;
+                else for (int r = 0; r < 4; ++r) if (n + r < p.N) s[r] += q[r];
+            }
         }
         epilogue_store<T>(p, m, n, s, load_bias4<T>(p, n));
     }
@@ -462,13 +466,13 @@ extern "C" int valor_gemm_set_variant(int v) { const int o = g_gemm_variant; if 
 // variant 4 (default): measured policy (tools/gemm_ab.py, profiles/r01_gemm_variants_*.json) -- the 8-phase kernel for
 //   the big-M forward GEMMs, long-K dgrad and the wgrad GEMMs; the 128x128 kernel (4 workgroups per CU hiding each
 //   other's prologue / epilogue) for small grids, short-K dgrad and everything with a K tail.
-// [0] NT min K for the 8-phase kernel, [1] unused (was: 8-phase start skew, measured slower), [2] min 256x256 tiles (forward), [3] min 256x256 tiles (dgrad)
+// [0] NT min K for the 8-phase kernel, [1] split-K partials as bf16 (was: 8-phase start skew, measured slower), [2] min 256x256 tiles (forward), [3] min 256x256 tiles (dgrad)
 // [4] L2-aware tile raster of the 8-phase kernels: 0 = row-major over all tile columns, 1000 = pick the group width per problem (traffic
 //     model in launch_gemm_8ph), else a fixed number of tile columns per group
 // [5] non-temporal bf16 output stores of the 8-phase kernels: 0 never, 1 always, 1000 = short-K problems (K <= 1024)
 // [6] 1 = the 128x128 kernels store big outputs of short-K problems non-temporally as well
 int g_gemm_policy[8] = {[] { const char* e = getenv("VALOR_GEMM_NT_MINK"); return e ? atoi(e) : 768; }(),
-                        [] { const char* e = getenv("VALOR_GEMM_SKEW"); return e ? atoi(e) : 0; }(),
+                        [] { const char* e = getenv("VALOR_GEMM_SPLITK_BF16"); return e ? atoi(e) : 0; }(),
                         [] { const char* e = getenv("VALOR_GEMM_MIN_TILES"); return e ? atoi(e) : 256; }(),
                         [] { const char* e = getenv("VALOR_GEMM_NT_MIN_TILES"); return e ? atoi(e) : 1024; }(),
                         [] { const char* e = getenv("VALOR_GEMM_RASTER"); return e ? atoi(e) : 0; }(),
@@ -640,7 +644,7 @@ extern "C" int valor_gemm(void* stream, int dtype, int transA, int transB, int M
     p.lda = lda; p.ldb = ldb; p.ldc = ldc; p.ldaux = ldaux;
     p.M = M; p.N = N; p.K = K; p.act = act; p.accumulate = accumulate; p.out_f32 = out_f32;
     p.alpha = alpha;
-    p.rowsum_out = rowsum_out; p.rowsum_acc = rowsum_accumulate; p.rowsum_ws = nullptr; p.fast_epi = 0; p.raster_g = 0; p.st_mode = 0;
+    p.rowsum_out = rowsum_out; p.rowsum_acc = rowsum_accumulate; p.rowsum_ws = nullptr; p.fast_epi = 0; p.raster_g = 0; p.st_mode = 0; p.ws_bf16 = 0;
     {
         const int64_t esz = dtype == VALOR_DT_BF16 ? 2 : 4;
         // direct: rows x ld with K valid in the last row; transposed: K rows of ld elements (caller guarantees
@@ -685,6 +689,9 @@ extern "C" int valor_gemm(void* stream, int dtype, int transA, int transB, int M
         }
         p.kslices = slices;
         p.ksteps_per_slice = (nk + slices - 1) / slices;     // trailing slices may be short or empty (they add zeros)
+        // policy key 1: the partial tiles as bf16 -- half the workspace traffic of the GEMM epilogue and of gemm_splitk_reduce (3.5 ms per
+        // step at VALOR-base) for one more rounding per partial (their sum is rounded to bf16 anyway unless the output is fp32)
+        p.ws_bf16 = (slices > 1 && g_gemm_policy[1] && !out_f32) ? 1 : 0;
     } else {
         p.kslices = slices;
         p.ksteps_per_slice = (nk + slices - 1) / slices;

@@ -411,11 +411,7 @@ __global__ __launch_bounds__(512, 2) void gemm_8ph_kernel(GemmArgs p) {
             const f32x4_t v1 = *(const f32x4_t*)(sC + ml * 256 + (((2 * c8 + 1) ^ (ml & 7)) << 2));
             const int m = m0 + pass * 128 + ml, n = n0 + c8 * 8;
             if (wsl) {
-                if (m < p.M) {
-                    float* qq = wsl + (int64_t)m * p.N + n;
-                    if (n + 7 < p.N && (p.N & 3) == 0) { *(f32x4_t*)qq = v0; *(f32x4_t*)(qq + 4) = v1; }
-                    else for (int r = 0; r < 8; ++r) if (n + r < p.N) qq[r] = r < 4 ? v0[r] : v1[r - 4];
-                }
+                splitk_store8(p, slice, m, n, v0, v1);
             } else {
                 epilogue_store8<true, NTS ? 1 : 0>(p, m, n, v0, v1, bias0, bias1);
             }

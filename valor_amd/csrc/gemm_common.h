@@ -25,7 +25,26 @@ struct GemmArgs {
                                // -> bias / activation in registers, bf16 tile passes through LDS (see gemm8.hip)
     int raster_g;              // 8-phase kernels: tile columns per raster group (0 = row-major over all tile columns), see gemm8.hip
     int st_mode;               // 16-byte bf16 output stores: 0 plain, 1 non-temporal (see store_out16)
+    int ws_bf16;               // split-K partials [S][M][N] are written / summed as bf16 instead of fp32 (LDS-DMA bf16 kernels; policy key 1)
 };
+
+// 8 consecutive fp32 partial sums of one row -> the split-K workspace of slice `slice` (fp32, or bf16 when p.ws_bf16)
+DEVINL void splitk_store8(const GemmArgs& p, int slice, int m, int n, f32x4_t v0, f32x4_t v1) {
+    if (m >= p.M) return;
+    const int64_t off = ((int64_t)slice * p.M + m) * p.N + n;
+    if (p.ws_bf16) {
+        bf16_t* q = (bf16_t*)p.ws + off;
+        if (n + 7 < p.N && (p.N & 7) == 0) {
+            *(u32x4_t*)q = (u32x4_t){pack2_bf16(v0[0], v0[1]), pack2_bf16(v0[2], v0[3]), pack2_bf16(v1[0], v1[1]), pack2_bf16(v1[2], v1[3])};
+        } else {
+            for (int r = 0; r < 8; ++r) if (n + r < p.N) q[r] = (bf16_t)(r < 4 ? v0[r] : v1[r - 4]);
+        }
+    } else {
+        float* q = p.ws + off;
+        if (n + 7 < p.N && (p.N & 3) == 0) { *(f32x4_t*)q = v0; *(f32x4_t*)(q + 4) = v1; }
+        else for (int r = 0; r < 8; ++r) if (n + r < p.N) q[r] = r < 4 ? v0[r] : v1[r - 4];
+    }
+}
 
 // 16-byte store of an output chunk, optionally NON-TEMPORAL. The outputs of the big short-K forward GEMMs (ViT qkv / fc1, the decoder's
 // cross K|V projection: 0.36-1.2 GB per launch) are written once and read by a LATER kernel; streamed past the caches they stop

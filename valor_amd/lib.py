@@ -44,6 +44,7 @@ SIGNATURES = {
     "valor_colsum_finalize": [_vp, _i, _vp, _i, _i, _vp, _i, _i],
     "valor_colsum_finalize3": [_vp, _i, _vp, _vp, _i, _vp, _vp, _i, _vp, _vp, _i, _i, _i],
     "valor_attn_set_variant": [_i],
+    "valor_attn_set_res_pipeline": [_i],
     "valor_attn_fwd": [_vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _i64,
                        _vp, _i64, _i64, _vp, _i, _f, _f, _u64, _u64],
     "valor_attn_bwd": [_vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i,

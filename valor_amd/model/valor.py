@@ -589,21 +589,32 @@ class VALOR(nn.Module):
         self._kv_slots = [ops.GradSlot() for _ in range(self.spec.layers)]
         proj = lambda x, i: ops.linear(x, P[f"multimodal_encoder.encoder.layer.{i}.cross_attn.cross.kv.weight"],
                                        P[f"multimodal_encoder.encoder.layer.{i}.cross_attn.cross.kv.bias"], grad_slot=va_slot)
-        if not (streams.enabled() and self.device.type == "cuda" and os.environ.get("VALOR_KV_STREAM", "0") == "1"):
+        self._dkv_static = None
+        if not (streams.enabled() and self.device.type == "cuda" and os.environ.get("VALOR_KV_STREAM", "1") == "1" and self.training
+                and torch.is_grad_enabled()):
             return [proj(va_input, i) for i in range(self.spec.layers)]
-        # OFF by default: measured -1.5 % step time on top of the encoder overlap, but the 12 x 360 MB K|V tensors and their gradients cross
-        # streams, and the caching allocator cannot reuse a block recorded on another stream until the GPU has passed it: with the host
-        # running a step ahead the reserved memory crept 62 -> 71 GB over 20 steps with a hipMalloc every other step (session S). It
-        # needs static per-layer K|V / dK|dV buffers first.
         # The 12 projections are chip-filling GEMMs (117 k rows), the decoder layers that consume them are not (8.8 k rows): on the side
         # stream they run BESIDE the decoder layers -- layer i waits for its own projection only -- and in backward each layer's
         # dgrad / wgrad pair runs there as soon as that layer's dK|dV is complete, beside the lower layers' backward (streams.py).
+        # The K|V tensors and their gradients cross streams; handed through the caching allocator they could not be reused until the
+        # other stream had passed them (round 2: the pool crept 62 -> 71 GB over 20 steps, a hipMalloc every other step). They live in
+        # STATIC per-layer buffers instead (2 x 12 x 360 MB at the bench shape), reused every step: the side stream's first act of a
+        # step is to wait for the main stream (fork), i.e. for every consumer of the previous step.
         side = streams.side_stream(self.device)
+        shape = tuple(va_input.shape[:-1]) + (2 * self.spec.hidden,)
+        key = (shape, va_input.dtype)
+        if getattr(self, "_kv_static_key", None) != key:
+            with torch.cuda.stream(side):
+                self._kv_static = [torch.empty(shape, dtype=va_input.dtype, device=self.device) for _ in range(self.spec.layers)]
+                self._dkv_static_pool = [torch.empty(shape, dtype=va_input.dtype, device=self.device) for _ in range(self.spec.layers)]
+            self._kv_static_key = key
+        self._dkv_static = self._dkv_static_pool
         va_s = streams.fork(side, va_input)
         items = []
         with torch.cuda.stream(side):
             for i in range(self.spec.layers):
-                kv = proj(va_s, i)
+                kv = ops.linear(va_s, P[f"multimodal_encoder.encoder.layer.{i}.cross_attn.cross.kv.weight"],
+                                P[f"multimodal_encoder.encoder.layer.{i}.cross_attn.cross.kv.bias"], grad_slot=va_slot, out=self._kv_static[i])
                 ev = torch.cuda.Event()
                 ev.record(side)
                 items.append((kv, ev))
@@ -749,7 +760,7 @@ class VALOR(nn.Module):
                                              P[q + "attention.output.LayerNorm.bias"], 1e-12, p, False)
             if kv_layers is not None:
                 cq = ops.linear(X, P[q + "cross_attn.cross.query.weight"], P[q + "cross_attn.cross.query.bias"])
-                c = ops.seg_cross_attention(cq, kv_layers[i], H, xsegs, p)
+                c = ops.seg_cross_attention(cq, kv_layers[i], H, xsegs, p, dkv_buf=self._dkv_static[i] if getattr(self, "_dkv_static", None) else None)
                 o = ops.linear(c, P[q + "cross_attn.output.dense.weight"], None)
                 X = ops.bias_dropout_residual_ln(o, P[q + "cross_attn.output.dense.bias"], X, P[q + "cross_attn.output.LayerNorm.weight"],
                                                  P[q + "cross_attn.output.LayerNorm.bias"], 1e-12, p, False)

@@ -88,14 +88,15 @@ class LinearFn(Function):
     split-K), db = column sums."""
 
     @staticmethod
-    def forward(ctx, x, w, b, act, w_is_kn, slot=None):
+    def forward(ctx, x, w, b, act, w_is_kn, slot=None, out=None):
         ctx.slot = slot
         x2 = _2d(x)
         want_pre = act != ACT_NONE
+        kw = {} if out is None else {"out": _2d(out)}        # a caller-owned (static) output buffer: nothing is allocated here
         if w_is_kn:
-            res = K.gemm(x2, w, trans_b=True, bias=b, act=act, want_preact=want_pre)
+            res = K.gemm(x2, w, trans_b=True, bias=b, act=act, want_preact=want_pre, **kw)
         else:
-            res = K.gemm(x2, w, bias=b, act=act, want_preact=want_pre)
+            res = K.gemm(x2, w, bias=b, act=act, want_preact=want_pre, **kw)
         y, pre = res if want_pre else (res, None)
         ctx.save_for_backward(x2, w, pre)
         ctx.act, ctx.w_is_kn, ctx.has_b, ctx.xshape = act, w_is_kn, b is not None, x.shape
@@ -141,11 +142,11 @@ class LinearFn(Function):
                 K.colsum(dy2, out=sb, accumulate=True); _sunk(pb)
             else:
                 db = K.colsum(dy2)
-        return dx, dw, db, None, None, None
+        return dx, dw, db, None, None, None, None
 
 
-def linear(x, w, b=None, act=ACT_NONE, w_is_kn=False, grad_slot=None):
-    return LinearFn.apply(x, w, b, act, w_is_kn, grad_slot)
+def linear(x, w, b=None, act=ACT_NONE, w_is_kn=False, grad_slot=None, out=None):
+    return LinearFn.apply(x, w, b, act, w_is_kn, grad_slot, out)
 
 
 _MLP_SAVES_DERIV = os.environ.get("VALOR_MLP_DERIV", "1") != "0"      # 0: keep the pre-activation and evaluate act' in the dgrad (A/B runs)
@@ -423,7 +424,8 @@ class SegCrossAttnFn(Function):
     writes dK|dV and the others accumulate into the same buffer inside the kernel."""
 
     @staticmethod
-    def forward(ctx, q2d, kv, n_heads, segs, p_drop):
+    def forward(ctx, q2d, kv, n_heads, segs, p_drop, dkv_buf=None):
+        ctx.dkv_buf = dkv_buf
         R, E = q2d.shape
         q2d = q2d.contiguous()
         o = torch.empty((R, E), dtype=q2d.dtype, device=q2d.device)
@@ -447,17 +449,19 @@ class SegCrossAttnFn(Function):
         E = q2d.shape[1]
         do = do.contiguous()
         dq = torch.empty_like(q2d)
-        dkv = torch.empty_like(kv)
+        # a static per-layer buffer when the K|V projection lives on the side stream (a tensor that crosses streams through the caching
+        # allocator cannot be reused until the other stream has passed it: the pool grows and hipMalloc stalls the step)
+        dkv = ctx.dkv_buf if ctx.dkv_buf is not None else torch.empty_like(kv)
         for i, ((r0, B, T, kv_range, kv_bmod), lse, (seed, off)) in enumerate(zip(segs, lses, rng)):
             sl = slice(r0, r0 + B * T)
             K.attn_bwd(q2d[sl].view(B, T, E), kv[:, :, :E], kv[:, :, E:], o[sl].view(B, T, E), lse, do[sl].view(B, T, E), n_heads,
                        dq=dq[sl].view(B, T, E), dk=dkv[:, :, :E], dv=dkv[:, :, E:], kv_range=kv_range, kv_bmod=kv_bmod,
                        scale=1.0 / math.sqrt(64), p_drop=p_drop, seed=seed, offset=off, accumulate_kv=i > 0)
-        return dq, dkv, None, None, None
+        return dq, dkv, None, None, None, None
 
 
-def seg_cross_attention(q2d, kv, n_heads, segs, p_drop=0.0):
-    return SegCrossAttnFn.apply(q2d, kv, n_heads, segs, p_drop)
+def seg_cross_attention(q2d, kv, n_heads, segs, p_drop=0.0, dkv_buf=None):
+    return SegCrossAttnFn.apply(q2d, kv, n_heads, segs, p_drop, dkv_buf)
 
 
 class DecoderXentSegFn(Function):
@@ -569,7 +573,7 @@ def decoder_logits(h, w_emb, dec_bias):
 
 
 # ------------------------------------------------------------------------------------------------
-_FINE_CHUNK = int(os.environ.get("VALOR_FINE_CHUNK", "64"))      # texts per d(sims) tile of the fused backward
+_FINE_CHUNK = int(os.environ.get("VALOR_FINE_CHUNK", "128"))      # texts per d(sims) tile of the fused backward
 
 
 class FineContrastFn(Function):
