@@ -78,14 +78,15 @@ int valor_gemm_set_fast_epilogue(int v);
 /* policy parameters of variant 4 and of the 8-phase launch (tuning / A-B hook; returns the previous value, value < 0 only queries):
  *   key 0: smallest K for which a big-M dgrad (A row-major, B k-slow) runs on the 256x256 8-phase kernel
  *   key 1: 1 = the split-K partial tiles of the bf16 LDS-DMA kernels are written and summed as bf16 (half the workspace traffic, one more
- *          rounding per partial; never for fp32 outputs); default 0. (Round 2: the start skew of the 8-phase kernel's first round,
+ *          rounding per partial; never for fp32 outputs); default 1 (in-step +1.3 %, profiles/r03_step_ab_s3.txt). (Round 2: the start skew of the 8-phase kernel's first round,
  *          measured slower at every setting, profiles/r02_gemm_policy_ab.json)
  *   key 2: smallest number of 256x256 tiles for the 8-phase kernel on forward problems (default 256: one full round of workgroups)
  *   key 3: the same for dgrad problems (default 1024: below it the 128x128 kernel measured faster, session N)
- *   key 4: L2-aware tile raster of the 8-phase kernels: 0 (default) = row-major over all tile columns; G > 0 = groups of G tile columns
- *          (each XCD keeps G weight panels of 256 x K in its 4 MiB L2 and streams the activation rows past them); 1000 = G from a
- *          fabric-traffic model per problem (csrc/gemm8.hip launch_gemm_8ph). Measured: fabric traffic 2.29 -> 1.79 x algorithmic on
- *          the ViT fc1 forward, time unchanged to -3 % (profiles/r03_gemm_l2_ab.json, r03_pmc_gemm_l2.json)
+ *   key 4: L2-aware tile raster of the 8-phase kernels: 0 = row-major over all tile columns; G > 0 = groups of G tile columns
+ *          (each XCD keeps G weight panels of 256 x K in its 4 MiB L2 and streams the activation rows past them); 1000 (default) = G
+ *          from a fabric-traffic model per problem (csrc/gemm8.hip launch_gemm_8ph). Measured with non-temporal stores: fabric traffic
+ *          2.27 -> 1.54 x algorithmic on the ViT fc1 forward (profiles/r03_pmc_gemm_l2_v2_nt_stores.json), kernel time -1 .. +3 %,
+ *          step +0.45 % (profiles/r03_step_ab_s3.txt)
  *   key 5: bf16 output stores of the 8-phase kernels: 0 plain, 1 non-temporal, 1000 (default) = non-temporal for K <= 1024
  *          (+5.5 .. +10 % on the K = 768 forward shapes, -0.6 .. -1.8 % at K = 3072)
  *   key 6: 1 = the 128x128 kernels store big outputs of short-K problems non-temporally too (default 0)

@@ -121,8 +121,8 @@ def test_attention_dropout(dev):
 @pytest.mark.parametrize("S,B,H,p_drop", [(197, 44, 12, 0.0), (197, 44, 12, 0.1), (129, 48, 12, 0.1), (256, 43, 12, 0.0), (65, 90, 6, 0.1), (224, 64, 8, 0.0)])
 def test_resident_backward_pipelined_equals_per_head_kernel(dev, S, B, H, p_drop):
     """The persistent, phase-pipelined LDS-resident backward (attention_res.hip: one workgroup per CU walks (batch, head) items, the
-    K / V and Q / dO image pairs double-buffered across its two phases) does the arithmetic of the one-workgroup-per-head kernel in
-    the same order: identical dQ / dK / dV, at item counts that give every workgroup several (and unequal numbers of) items, a tail
+    K / V and Q / dO image pairs double-buffered across its two phases) does the arithmetic of the one-workgroup-per-head kernel (only the
+    16 products of a row's delta = sum(dO * O) are added in another order): the same dQ / dK / dV to an ulp of bf16, at item counts that give every workgroup several (and unequal numbers of) items, a tail
     round, sequence lengths with partial 32-row blocks, with and without dropout; and against fp64 on one of the shapes.
     Reference semantics: model/clip.py:186-192 (ViT S = 197), model/transformer.py:115-130 (AST S = 129)."""
     from valor_amd import kernels as K, lib
@@ -145,7 +145,8 @@ def test_resident_backward_pipelined_equals_per_head_kernel(dev, S, B, H, p_drop
     torch.cuda.synchronize()
     for a, b_, c, n in ((dq1, dq0, dq1b, "dq"), (dk1, dk0, dk1b, "dk"), (dv1, dv0, dv1b, "dv")):
         assert torch.equal(a, c), n
-        assert torch.equal(a, b_), (n, float((a.float() - b_.float()).abs().max()))
+        assert _rel(a, b_) < 5e-4, (n, _rel(a, b_))
+        assert float((a.float() - b_.float()).abs().max()) <= 2.0 ** -7 * float(b_.float().abs().max()), n
     if p_drop == 0.0 and S == 197:
         sl = slice(0, 3)          # fp64 reference on three samples
         qd, kd, vd = (t[sl].double().detach().requires_grad_(True) for t in (q, k, v))

@@ -68,7 +68,7 @@ __global__ __launch_bounds__(256, 2) void fine_fused_fwd_kernel(FineFusedArgs p)
     constexpr int TP = 16 * TPB, VP = 16 * VPB;
     constexpr int RA = 128 / TP, CB = 128 / VP;          // texts / clips per workgroup tile
     constexpr int NPA = 4 / TPB, NPB = 4 / VPB;          // ... per 64 x 64 wave tile
-    __shared__ __attribute__((aligned(16))) char smem[4 * IMG];     // 2 stages x (A image + B image) = 64 KiB
+    __shared__ __attribute__((aligned(16))) char smem[2 * IMG];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -100,10 +100,11 @@ __global__ __launch_bounds__(256, 2) void fine_fused_fwd_kernel(FineFusedArgs p)
             voB[j] = (b < p.NB && v < p.Nv) ? (((b * p.Nv + v) * p.D + c * 8) * 2) : FF_OOB;
         }
     }
-    // two LDS stages: the LDS-DMA of K-step ks + 1 flies under the MFMAs of step ks, one barrier per step (gemm.hip NSTAGE = 2)
+    // one LDS stage, several workgroups per CU hide each other's loads (a double-buffered loop with 64 KiB of LDS measured SLOWER:
+    // 291 vs 239 us at B = 512 -- two workgroups per CU instead of three to five; profiles/r03_contrastive_b512_kernel_stats_v2.md)
     const int nk = p.D / BK;
-    auto issue = [&](int stage) {
-        char* sA = smem + stage * (2 * IMG) + wave * 4096;
+    for (int ks = 0; ks < nk; ++ks) {
+        char* sA = smem + wave * 4096;
         char* sB = sA + IMG;
 #pragma unroll
         for (int j = 0; j < 4; ++j) glds16(rsA, sA + j * 1024, voA[j]);
@@ -111,15 +112,10 @@ __global__ __launch_bounds__(256, 2) void fine_fused_fwd_kernel(FineFusedArgs p)
         for (int j = 0; j < 4; ++j) glds16(rsB, sB + j * 1024, voB[j]);
 #pragma unroll
         for (int j = 0; j < 4; ++j) { voA[j] += BK * 2; voB[j] += BK * 2; }
-    };
-    issue(0);
-    for (int ks = 0; ks < nk; ++ks) {
-        const int cur = ks & 1;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();           // step ks landed for every wave; everyone is done reading stage cur ^ 1
-        if (ks + 1 < nk) issue(cur ^ 1);
-        const char* iA = smem + cur * (2 * IMG);
-        const char* iB = iA + IMG;
+        __syncthreads();
+        const char* iA = smem;
+        const char* iB = smem + IMG;
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
             bf16x8_t fn[4], fm[4];
@@ -133,6 +129,7 @@ __global__ __launch_bounds__(256, 2) void fine_fused_fwd_kernel(FineFusedArgs p)
 #pragma unroll
                 for (int mi = 0; mi < 4; ++mi) acc[ni][mi] = Mma<T>::mma(fn[ni], fm[mi], acc[ni][mi]);
         }
+        __syncthreads();
     }
 
     // ---- per-lane token constants. Row block mi: text ja = mi / TPB, token t = (mi % TPB) * 16 + fr; column block ni, r:

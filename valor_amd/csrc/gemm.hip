@@ -472,10 +472,10 @@ extern "C" int valor_gemm_set_variant(int v) { const int o = g_gemm_variant; if 
 // [5] non-temporal bf16 output stores of the 8-phase kernels: 0 never, 1 always, 1000 = short-K problems (K <= 1024)
 // [6] 1 = the 128x128 kernels store big outputs of short-K problems non-temporally as well
 int g_gemm_policy[8] = {[] { const char* e = getenv("VALOR_GEMM_NT_MINK"); return e ? atoi(e) : 768; }(),
-                        [] { const char* e = getenv("VALOR_GEMM_SPLITK_BF16"); return e ? atoi(e) : 0; }(),
+                        [] { const char* e = getenv("VALOR_GEMM_SPLITK_BF16"); return e ? atoi(e) : 1; }(),
                         [] { const char* e = getenv("VALOR_GEMM_MIN_TILES"); return e ? atoi(e) : 256; }(),
                         [] { const char* e = getenv("VALOR_GEMM_NT_MIN_TILES"); return e ? atoi(e) : 1024; }(),
-                        [] { const char* e = getenv("VALOR_GEMM_RASTER"); return e ? atoi(e) : 0; }(),
+                        [] { const char* e = getenv("VALOR_GEMM_RASTER"); return e ? atoi(e) : 1000; }(),
                         [] { const char* e = getenv("VALOR_GEMM_STORE"); return e ? atoi(e) : 1000; }(),
                         [] { const char* e = getenv("VALOR_GEMM_NTA"); return e ? atoi(e) : 0; }(),
                         [] { const char* e = getenv("VALOR_GEMM_FUSED3"); return e ? atoi(e) : 1; }()};      // [7] fused-epilogue 128x128 kernel built for 3 workgroups per CU (no scratch)

@@ -753,19 +753,24 @@ class VALOR(nn.Module):
         X = torch.cat(xs, dim=0) if len(xs) > 1 else xs[0]
         for i in range(self.spec.layers):
             q = f"multimodal_encoder.encoder.layer.{i}."
-            qkv = ops.linear(X, P[q + "attention.self.qkv.weight"], P[q + "attention.self.qkv.bias"])
+            # post-LN: every sub-layer input feeds the sub-layer's first GEMM AND the residual add behind it; the two gradients meet in a
+            # GradSlot (the LayerNorm backward publishes its residual gradient, the GEMM's dgrad accumulates into it: no add kernels)
+            s1, s2, s3 = ops.GradSlot(), ops.GradSlot(), ops.GradSlot()
+            qkv = ops.linear(X, P[q + "attention.self.qkv.weight"], P[q + "attention.self.qkv.bias"], grad_slot=s1)
             a = ops.seg_self_attention(qkv, H, ssegs, p)
             o = ops.linear(a, P[q + "attention.output.dense.weight"], None)
             X = ops.bias_dropout_residual_ln(o, P[q + "attention.output.dense.bias"], X, P[q + "attention.output.LayerNorm.weight"],
-                                             P[q + "attention.output.LayerNorm.bias"], 1e-12, p, False)
+                                             P[q + "attention.output.LayerNorm.bias"], 1e-12, p, False, res_slot=s1)
             if kv_layers is not None:
-                cq = ops.linear(X, P[q + "cross_attn.cross.query.weight"], P[q + "cross_attn.cross.query.bias"])
+                cq = ops.linear(X, P[q + "cross_attn.cross.query.weight"], P[q + "cross_attn.cross.query.bias"], grad_slot=s2)
                 c = ops.seg_cross_attention(cq, kv_layers[i], H, xsegs, p, dkv_buf=self._dkv_static[i] if getattr(self, "_dkv_static", None) else None)
                 o = ops.linear(c, P[q + "cross_attn.output.dense.weight"], None)
                 X = ops.bias_dropout_residual_ln(o, P[q + "cross_attn.output.dense.bias"], X, P[q + "cross_attn.output.LayerNorm.weight"],
-                                                 P[q + "cross_attn.output.LayerNorm.bias"], 1e-12, p, False)
-            m = ops.mlp(X, P[q + "intermediate.dense.weight"], P[q + "intermediate.dense.bias"], P[q + "output.dense.weight"], None, ACT_GELU_ERF)
-            X = ops.bias_dropout_residual_ln(m, P[q + "output.dense.bias"], X, P[q + "output.LayerNorm.weight"], P[q + "output.LayerNorm.bias"], 1e-12, p, False)
+                                                 P[q + "cross_attn.output.LayerNorm.bias"], 1e-12, p, False, res_slot=s2)
+            m = ops.mlp(X, P[q + "intermediate.dense.weight"], P[q + "intermediate.dense.bias"], P[q + "output.dense.weight"], None, ACT_GELU_ERF,
+                        grad_slot=s3)
+            X = ops.bias_dropout_residual_ln(m, P[q + "output.dense.bias"], X, P[q + "output.LayerNorm.weight"], P[q + "output.LayerNorm.bias"], 1e-12, p,
+                                             False, res_slot=s3)
         rows = ops.gather_rows(X, self._dev(torch.cat(idxs)))
         h = self.cls_transform(rows)
         losses = ops.decoder_xent_segments(h, P["multimodal_encoder.embeddings.word_embeddings.weight"], P["cls.decoder.bias"],

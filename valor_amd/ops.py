@@ -159,7 +159,8 @@ class MlpFn(Function):
     itself (ACT_DERIV), evaluated beside act(u) from the same sigmoid / erf: the backward epilogue is one multiply."""
 
     @staticmethod
-    def forward(ctx, x, w1, b1, w2, b2, act):
+    def forward(ctx, x, w1, b1, w2, b2, act, slot=None):
+        ctx.slot = slot
         x2 = _2d(x)
         if _MLP_SAVES_DERIV:
             act = act | lib.ACT_DERIV
@@ -198,13 +199,21 @@ class MlpFn(Function):
             return dw, None
 
         dw2, db2 = wgrad_bgrad(dy2, h, pw2, pb2)
-        dx = K.gemm(du, w1, trans_b=True).view(ctx.xshape) if ctx.needs_input_grad[0] else None
+        dx = None
+        if ctx.needs_input_grad[0]:
+            slot = ctx.slot
+            if slot is not None and slot.buf is not None:          # the residual path already produced x's gradient buffer: add into it
+                K.gemm(du, w1, trans_b=True, out=_2d(slot.buf), accumulate=True)
+            else:
+                dx = K.gemm(du, w1, trans_b=True).view(ctx.xshape)
+                if slot is not None:
+                    slot.buf = dx
         dw1, db1 = wgrad_bgrad(du, x2, pw1, pb1)
-        return dx, dw1, db1, dw2, db2, None
+        return dx, dw1, db1, dw2, db2, None, None
 
 
-def mlp(x, w1, b1, w2, b2, act):
-    return MlpFn.apply(x, w1, b1, w2, b2, act)
+def mlp(x, w1, b1, w2, b2, act, grad_slot=None):
+    return MlpFn.apply(x, w1, b1, w2, b2, act, grad_slot)
 
 
 # ------------------------------------------------------------------------------------------------
@@ -213,9 +222,10 @@ class BdrLnFn(Function):
     mode flags: want_z -> return the pre-LN sum z (pre-LN residual stream); otherwise only y."""
 
     @staticmethod
-    def forward(ctx, x, bias, residual, gamma, beta, eps, p_drop, want_z, row_scale=None, rows_per_scale=0):
+    def forward(ctx, x, bias, residual, gamma, beta, eps, p_drop, want_z, row_scale=None, rows_per_scale=0, res_slot=None):
         x = x.contiguous()
         ctx.set_materialize_grads(False)
+        ctx.res_slot = res_slot          # GradSlot of `residual` (post-LN blocks: the same activation also feeds the sub-layer's first GEMM)
         seed = off = 0
         if p_drop > 0:
             seed, off = DropoutState.draw(x.numel())
@@ -243,7 +253,7 @@ class BdrLnFn(Function):
         dy = dy.contiguous() if dy is not None else None
         dz_in = dz_in.contiguous() if dz_in is not None else None
         if dy is None and dz_in is None:
-            return (None,) * 10
+            return (None,) * 11
         if dy is None:   # only the residual stream was used downstream
             dy_eff, mean_e, rstd_e, z_e = None, None, None, None
         else:
@@ -256,16 +266,20 @@ class BdrLnFn(Function):
         for prm, sk, want in ((pg, sinks[0], gamma is not None), (pbeta, sinks[1], has_beta), (pbias, sinks[2], has_b)):
             if sk is not None and want:
                 _sunk(prm)
-        return dx, dbias, (dres if has_r else None), dg, dbeta, None, None, None, None, None
+        if has_r and ctx.res_slot is not None and ctx.res_slot.buf is None:
+            ctx.res_slot.buf = dres          # this node runs before the residual's other consumer: that one adds into dres in its own kernel
+        return dx, dbias, (dres if has_r else None), dg, dbeta, None, None, None, None, None, None
 
 
 def layer_norm(x, gamma, beta, eps):
     return BdrLnFn.apply(x, None, None, gamma, beta, eps, 0.0, False)
 
 
-def bias_dropout_residual_ln(x, bias, residual, gamma, beta, eps, p_drop, want_z, row_scale=None, rows_per_scale=0):
-    """row_scale fp32 [rows / rows_per_scale]: per-sample stochastic-depth factor on (x + bias) (videoswin.py:40-49)"""
-    return BdrLnFn.apply(x, bias, residual, gamma, beta, eps, p_drop, want_z, row_scale, rows_per_scale)
+def bias_dropout_residual_ln(x, bias, residual, gamma, beta, eps, p_drop, want_z, row_scale=None, rows_per_scale=0, res_slot=None):
+    """row_scale fp32 [rows / rows_per_scale]: per-sample stochastic-depth factor on (x + bias) (videoswin.py:40-49).
+    res_slot: GradSlot shared with the OTHER consumer of `residual` (a linear / mlp given the same slot as grad_slot): that consumer's
+    dgrad GEMM accumulates into this node's residual gradient instead of autograd adding two tensors."""
+    return BdrLnFn.apply(x, bias, residual, gamma, beta, eps, p_drop, want_z, row_scale, rows_per_scale, res_slot)
 
 
 class BiasDropResFn(Function):
