@@ -90,8 +90,7 @@ int valor_gemm_set_fast_epilogue(int v);
  *   key 5: bf16 output stores of the 8-phase kernels: 0 plain, 1 non-temporal, 1000 (default) = non-temporal for K <= 1024
  *          (+5.5 .. +10 % on the K = 768 forward shapes, -0.6 .. -1.8 % at K = 3072)
  *   key 6: 1 = the 128x128 kernels store big outputs of short-K problems non-temporally too (default 0)
- *   key 7: 1 (default) = the fused-epilogue 128x128 kernel is the build for 3 workgroups per CU (140 VGPRs, no scratch); 0 = the
- *          4-per-CU build whose epilogue spills 48-60 B per lane */
+ *   key 7: unused */
 int valor_gemm_set_policy(int key, int value);
 
 /* ---- fused bias + dropout + residual + LayerNorm.  Replaces apex FusedLayerNorm (apex/csrc/layer_norm_cuda_kernel.cu

@@ -17,6 +17,16 @@ HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value", "-Wno-unused-result"]
 
 
+# substrings of (mangled) kernel names that must not touch scratch: the GEMM families, the LDS-resident attention, LayerNorm, AdamW,
+# cross-entropy, the fused contrastive forward and the VideoSwin window forward / dK-dV kernels ...
+HOT_KERNELS = ("gemm_8ph_kernel", "gemm_glds_kernel", "gemm_splitk_reduce", "attn_res_", "attn_x_", "ln_fwd", "ln_bwd", "adamw_kernel", "xent_",
+               "fine_fused_fwd", "fine_ds_chunk_kernelIDF16bLi16", "win_fwd", "win_bwd_dkv")
+# ... except the instantiations whose register demand is known and documented: the key-stationary cross-attention with six
+# / eight query sub-tiles keeps 96 / 128 accumulator registers of dQ (O) per wave beside dK / dV; its dropout variants of four.
+KNOWN_SCRATCH = ("attn_x_fwd_kernelILi6ELb1", "attn_x_fwd_kernelILi8", "attn_x_bwd_kernelILi4ELb1", "attn_x_bwd_kernelILi6",
+                 "kernelIf")          # fp32 (parity mode) instantiations are not in the benchmarked step
+
+
 def _sources():
     return sorted(f for f in os.listdir(CSRC) if f.endswith(".hip"))
 
@@ -45,16 +55,22 @@ def _compile_one(src, hdig, verbose):
     if r.returncode != 0:
         sys.stderr.write(r.stdout + r.stderr)
         raise RuntimeError(f"hipcc failed on {src}")
-    # a kernel that touches scratch (register arrays demoted to private memory, spills) is a
-    # performance bug on this library: report it loudly.
+    # a kernel that touches scratch (register arrays demoted to private memory, spills) is a performance bug on this library: the HOT
+    # kernels (every kernel of the benchmarked bf16 step except the ones listed in KNOWN_SCRATCH) FAIL the build, the rest is reported.
     fn = None
+    bad = []
     for line in r.stderr.splitlines():
         if "Function Name:" in line:
             fn = line.split("Function Name:")[1].split()[0]
         elif "ScratchSize [bytes/lane]:" in line:
             n = int(line.split("ScratchSize [bytes/lane]:")[1].split()[0])
             if n:
-                print(f"[valor_amd.build] WARNING: {src}: kernel {fn} uses {n} B/lane of scratch", flush=True)
+                hot = any(h in fn for h in HOT_KERNELS) and not any(k in fn for k in KNOWN_SCRATCH)
+                print(f"[valor_amd.build] {'ERROR' if hot else 'WARNING'}: {src}: kernel {fn} uses {n} B/lane of scratch", flush=True)
+                if hot:
+                    bad.append(fn)
+    if bad:
+        raise RuntimeError(f"scratch in hot kernels of {src}: {bad} (see -Rpass-analysis=kernel-resource-usage)")
     with open(stamp, "w") as fh:
         fh.write(dig)
     return obj, True

@@ -192,7 +192,8 @@ DEVINL bf16x8_t read_frag_tr(const char* img, int off, int kk) {
 }
 // WPS = waves per SIMD the register allocation is sized for (= workgroups per CU): 4 for the lean epilogue; the FUSED epilogue
 // (activation / derivative / second output) does not fit 128 VGPRs beside the 64 accumulators -- at 4 it spilled two accumulator quads
-// INSIDE the K loop (48-60 B/lane of scratch) -- so it is built for 3 workgroups per CU (168 VGPRs) as well (policy key 7).
+// INSIDE the K loop (48-60 B/lane of scratch) -- so it is built for 3 workgroups per CU (140 VGPRs, no scratch; in-step A/B against the
+// spilling build: 513.3 vs 515.1 / 509.9 samples/s, i.e. no difference, so the clean build is the only one).
 template <bool TA, bool TB, int NSTAGE, bool FUSED, int WPS = (NSTAGE == 1 ? 4 : 2)>
 __global__ __launch_bounds__(256, WPS) void gemm_glds_kernel(GemmArgs p) {
     typedef bf16_t T;
@@ -478,7 +479,7 @@ int g_gemm_policy[8] = {[] { const char* e = getenv("VALOR_GEMM_NT_MINK"); retur
                         [] { const char* e = getenv("VALOR_GEMM_RASTER"); return e ? atoi(e) : 1000; }(),
                         [] { const char* e = getenv("VALOR_GEMM_STORE"); return e ? atoi(e) : 1000; }(),
                         [] { const char* e = getenv("VALOR_GEMM_NTA"); return e ? atoi(e) : 0; }(),
-                        [] { const char* e = getenv("VALOR_GEMM_FUSED3"); return e ? atoi(e) : 1; }()};      // [7] fused-epilogue 128x128 kernel built for 3 workgroups per CU (no scratch)
+                        0};
 extern "C" int valor_gemm_set_policy(int key, int value) {
     if (key < 0 || key > 7) return VALOR_ERR_ARG;
     const int old = g_gemm_policy[key];
@@ -525,8 +526,7 @@ static void launch_gemm_glds(hipStream_t st, int transA, int transB, const GemmA
 #define VALOR_GLDS_LAUNCH(TA_, TB_)                                                                 \
     do {                                                                                            \
         if constexpr (NSTAGE == 1) {                                                                \
-            if (fused && g_gemm_policy[7]) VALOR_GLDS_LAUNCH1(TA_, TB_, true, 3);                   \
-            else if (fused) VALOR_GLDS_LAUNCH1(TA_, TB_, true, 4);                                  \
+            if (fused) VALOR_GLDS_LAUNCH1(TA_, TB_, true, 3);                                       \
             else VALOR_GLDS_LAUNCH1(TA_, TB_, false, 4);                                            \
         } else {                                                                                    \
             if (fused) VALOR_GLDS_LAUNCH1(TA_, TB_, true, 2);                                       \

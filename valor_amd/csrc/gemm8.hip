@@ -310,7 +310,8 @@ __global__ __launch_bounds__(512, 2) void gemm_8ph_kernel(GemmArgs p) {
     //   * pre-activation copy wanted (forward of a fused activation): TWO bf16 passes, u = alpha acc + bias first (-> preact), then
     //     act(u) computed on the SAME fp32 accumulators (-> C): numerics identical to the general epilogue;
     //   * dact_aux (dgrad of a fused activation) and C += are applied at read-out, where every lane holds 8 consecutive columns of a
-    //     row (16-byte coalesced loads of aux / C); the GEMM result is rounded to bf16 before the act' multiply there (gradient path).
+    //     row (16-byte coalesced loads of aux / C, all requested before the tile barrier); the GEMM result is rounded to bf16 before the
+    //     act' multiply there (gradient path).
     if constexpr (!TA) if (p.fast_epi) {           // (k-slow A = wgrad: split-K / fused row sums, always the general epilogue)
         char* sB = smem;
         const int act = p.act & VALOR_ACT_MASK;
@@ -338,50 +339,75 @@ __global__ __launch_bounds__(512, 2) void gemm_8ph_kernel(GemmArgs p) {
                 }
             }
         };
-        auto read_tile = [&](T* dst, bool dact, bool accum) {
+        auto read_tile = [&](T* dst) {
 #pragma unroll 4
+            for (int it = 0; it < 16; ++it) {
+                const int ml = it * 16 + (tid >> 5), c = tid & 31;
+                const u32x4_t val = *(const u32x4_t*)(sB + ml * 512 + ((c ^ (ml & 31)) << 4));
+                const int m = m0 + ml, n = n0 + c * 8;
+                if (m < p.M && n < p.N) store_out16<NTS>(dst + (int64_t)m * p.ldc + n, val);
+            }
+        };
+        if (p.preact) {                 // forward of a fused activation: the pre-activation copy first
+            write_tile(false);
+            __syncthreads();
+            read_tile((T*)p.preact);
+            __syncthreads();
+        }
+        write_tile(act != VALOR_ACT_NONE && !p.dact_aux);
+        if (p.dact_aux || p.accumulate) {
+            // The read-out needs a SECOND [M, N] operand (the saved derivative / pre-activation of a dgrad, or the old C of a C +=): all 16
+            // chunks of it are requested HERE -- the accumulators are dead, 128 VGPRs are free -- so their HBM latency runs under the
+            // barrier and the LDS reads instead of being paid four chunks at a time inside the read-out loop (ViT fc2 dgrad with the
+            // derivative multiply: 660 us against 490 us without the second operand).
+            const bool dact = p.dact_aux != nullptr, accum = p.accumulate != 0;
+            const T* src = dact ? (const T*)p.dact_aux : (const T*)p.C;
+            const int64_t lds2 = dact ? p.ldaux : p.ldc;
+            u32x4_t pre[16];
+#pragma unroll
+            for (int it = 0; it < 16; ++it) {
+                const int m = m0 + it * 16 + (tid >> 5), n = n0 + (tid & 31) * 8;
+                pre[it] = (u32x4_t){0u, 0u, 0u, 0u};
+                if (m < p.M && n < p.N) pre[it] = *(const u32x4_t*)(src + (int64_t)m * lds2 + n);
+            }
+            __syncthreads();
+            T* dst = (T*)p.C;
+#pragma unroll
             for (int it = 0; it < 16; ++it) {
                 const int ml = it * 16 + (tid >> 5), c = tid & 31;
                 u32x4_t val = *(const u32x4_t*)(sB + ml * 512 + ((c ^ (ml & 31)) << 4));
                 const int m = m0 + ml, n = n0 + c * 8;
                 if (m < p.M && n < p.N) {
-                    if (dact || accum) {
-                        float f[8];
+                    float f[8], x[8];
 #pragma unroll
-                        for (int q = 0; q < 4; ++q) { f[2 * q] = __uint_as_float(val[q] << 16); f[2 * q + 1] = __uint_as_float(val[q] & 0xffff0000u); }
-                        if (dact) {
-                            const u32x4_t a = *(const u32x4_t*)((const T*)p.dact_aux + (int64_t)m * p.ldaux + n);
-                            float x[8];
+                    for (int q = 0; q < 4; ++q) { f[2 * q] = __uint_as_float(val[q] << 16); f[2 * q + 1] = __uint_as_float(val[q] & 0xffff0000u); }
 #pragma unroll
-                            for (int q = 0; q < 4; ++q) { x[2 * q] = __uint_as_float(a[q] << 16); x[2 * q + 1] = __uint_as_float(a[q] & 0xffff0000u); }
-                            if (deriv) {
+                    for (int q = 0; q < 4; ++q) { x[2 * q] = __uint_as_float(pre[it][q] << 16); x[2 * q + 1] = __uint_as_float(pre[it][q] & 0xffff0000u); }
+                    if (dact) {
+                        if (deriv) {
 #pragma unroll
-                                for (int q = 0; q < 8; ++q) f[q] *= x[q];
-                            } else {
-                                act_bwd_mul_n<8>(act, f, x);
-                            }
+                            for (int q = 0; q < 8; ++q) f[q] *= x[q];
+                        } else {
+                            act_bwd_mul_n<8>(act, f, x);
                         }
                         if (accum) {
                             const u32x4_t o = *(const u32x4_t*)(dst + (int64_t)m * p.ldc + n);
 #pragma unroll
                             for (int q = 0; q < 4; ++q) { f[2 * q] += __uint_as_float(o[q] << 16); f[2 * q + 1] += __uint_as_float(o[q] & 0xffff0000u); }
                         }
+                    } else {
 #pragma unroll
-                        for (int q = 0; q < 4; ++q) val[q] = pack2_bf16(f[2 * q], f[2 * q + 1]);
+                        for (int q = 0; q < 8; ++q) f[q] += x[q];
                     }
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) val[q] = pack2_bf16(f[2 * q], f[2 * q + 1]);
                     store_out16<NTS>(dst + (int64_t)m * p.ldc + n, val);
                 }
             }
-        };
-        if (p.preact) {                 // forward of a fused activation: the pre-activation copy first
-            write_tile(false);
-            __syncthreads();
-            read_tile((T*)p.preact, false, false);
-            __syncthreads();
+            return;
         }
-        write_tile(act != VALOR_ACT_NONE && !p.dact_aux);
         __syncthreads();
-        read_tile((T*)p.C, p.dact_aux != nullptr, p.accumulate != 0);
+        read_tile((T*)p.C);
         return;
     }
 
