@@ -253,6 +253,7 @@ def main():
     ap.add_argument("--audio-slices", type=int, default=2)
     ap.add_argument("--dropout", type=float, default=0.1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true", help="skip the instrumented steps behind the timed region (roofline = null)")
     ap.add_argument("--variant", choices=["clip", "swin", "large", "clip_large"], default="clip",
                     help="clip: config/pretrain-VALOR-base.json (BASELINE configs[1], the headline); swin: scripts/pretrain.sh "
                          "(VideoSwin-B + BERT text); large: BASELINE configs[3]/[4] (VideoSwin-L embed 192 / 2-2-18-2 + BERT-large "
@@ -340,13 +341,13 @@ def main():
     # roofline pass: the SAME step, run right after the timed region, with a HIP-event pair (recorded on the launch
     # stream) around every 4th valor_gemm launch; 4 instrumented steps with a rotating offset cover every launch once.
     timer.enabled = True
-    n_inst = 4
+    n_inst = 0 if args.no_roofline else 4
     # kernel durations are only meaningful when the kernel has the chip to itself: the instrumented steps run the encoders on ONE
     # stream (the timed region above runs them on two, valor_amd/streams.py)
     two_streams = os.environ.get("VALOR_ENCODER_STREAMS")
     os.environ["VALOR_ENCODER_STREAMS"] = "0"
     timer.enabled = False
-    for _ in range(2):          # settle: the audio / text activations move from the side stream's allocator pool to this stream's (device
+    for _ in range(2 if n_inst else 0):          # settle: the audio / text activations move from the side stream's allocator pool to this stream's (device
         engine.train_step(batch, TASK)      # allocations stall the host, a starved GPU makes event pairs measure launch latency)
     sync()
     timer.enabled = True
@@ -355,7 +356,7 @@ def main():
         engine.train_step(batch, TASK)
         timer.next_step()
     sync()
-    inst_elapsed = (time.perf_counter() - t1) / n_inst
+    inst_elapsed = (time.perf_counter() - t1) / max(n_inst, 1)
     timer.enabled = False
     if two_streams is None:
         del os.environ["VALOR_ENCODER_STREAMS"]

@@ -140,9 +140,6 @@ def test_resident_backward_pipelined_equals_per_head_kernel(dev, S, B, H, p_drop
         dq1b, dk1b, dv1b = K.attn_bwd(q, k, v, o, lse, dout, H, scale=scale, p_drop=p_drop, seed=5, offset=9)     # and it is deterministic
         so.valor_attn_set_res_pipeline(0)
         dq0, dk0, dv0 = K.attn_bwd(q, k, v, o, lse, dout, H, scale=scale, p_drop=p_drop, seed=5, offset=9)
-        so.valor_attn_set_res_pipeline(2)           # software-pipelined dQ phase: the per-head arithmetic in the same order, bit for bit
-        dq2, dk2, dv2 = K.attn_bwd(q, k, v, o, lse, dout, H, scale=scale, p_drop=p_drop, seed=5, offset=9)
-        assert torch.equal(dq2, dq0) and torch.equal(dk2, dk0) and torch.equal(dv2, dv0)
     finally:
         so.valor_attn_set_res_pipeline(old)
     torch.cuda.synchronize()

@@ -399,247 +399,6 @@ __global__ __launch_bounds__(512, 2) void attn_res_bwd_kernel(AttnArgs p) {
     }
 }
 
-// ------------------------------------------------------------------------------------------ backward, software pipelined
-// attn_res_bwd_kernel with the inner loop of the dQ phase restructured as a two-stage software pipeline over 32-key blocks: the LDS
-// fragment reads and the S / dP MFMAs of block j + 1 are issued BEFORE the softmax / dS VALU work and the accumulation MFMAs of block j, so the matrix pipe works on the next scores while the VALU finishes the current probabilities
-// (in the loop as written every wave waits for its 16 score MFMAs, then runs ~130 VALU instructions with the matrix pipe idle, and only
-// two waves share a SIMD). Same arithmetic in the same order: bit-identical results.
-template <bool DROP>
-__global__ __launch_bounds__(512, 2) void attn_res_bwd_swp_kernel(AttnArgs p) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int fr = lane & 15, g = lane >> 4;
-    const int h = blockIdx.x, b = blockIdx.y;
-    const int S = p.Skv, SP = (S + 31) & ~31;
-    const int IMG = SP * TILE_ROW_BYTES;
-    char* sQ = smem;
-    char* sDO = smem + IMG;
-    char* sK = smem + 2 * IMG;
-    char* sV = smem + 3 * IMG;
-    float* sLse = (float*)(smem + 4 * IMG);
-    float* sDelta = sLse + SP;
-
-    stage_image(head_rsrc(p.q, (int64_t)b * p.q_bs + h * ATT_D, S, p.q_rs), sQ, SP, (int)p.q_rs * 2, wave, 8, lane);
-    stage_image(head_rsrc(p.dout, (int64_t)b * p.do_bs + h * ATT_D, S, p.do_rs), sDO, SP, (int)p.do_rs * 2, wave, 8, lane);
-    stage_image(head_rsrc(p.k, (int64_t)b * p.k_bs + h * ATT_D, S, p.k_rs), sK, SP, (int)p.k_rs * 2, wave, 8, lane);
-    stage_image(head_rsrc(p.v, (int64_t)b * p.v_bs + h * ATT_D, S, p.v_rs), sV, SP, (int)p.v_rs * 2, wave, 8, lane);
-
-    const int64_t statbase = ((int64_t)b * p.H + h) * p.Sq;
-    {
-        const bf16_t* Ob = (const bf16_t*)p.o + (int64_t)b * p.o_bs + h * ATT_D;
-        const bf16_t* DOb = (const bf16_t*)p.dout + (int64_t)b * p.do_bs + h * ATT_D;
-        for (int r0 = wave * 8; r0 < SP; r0 += 64) {
-            const int row = r0 + (lane >> 3), c = lane & 7;
-            float d = 0.f;
-            if (row < S) {
-                const bf16x8_t ov = __builtin_bit_cast(bf16x8_t, *(const u32x4_t*)(Ob + (int64_t)row * p.o_rs + c * 8));
-                const bf16x8_t dv = __builtin_bit_cast(bf16x8_t, *(const u32x4_t*)(DOb + (int64_t)row * p.do_rs + c * 8));
-#pragma unroll
-                for (int e = 0; e < 8; ++e) d += (float)ov[e] * (float)dv[e];
-            }
-            d += __shfl_xor(d, 1, 64); d += __shfl_xor(d, 2, 64); d += __shfl_xor(d, 4, 64);
-            if (c == 0) { sDelta[row] = d; sLse[row] = row < S ? p.lse[statbase + row] * LOG2E_F : INFINITY; }
-        }
-    }
-    const float sl2 = p.scale * LOG2E_F;
-    const uint32_t thr = drop_threshold(p.p_drop);
-    const float keep_scale = p.p_drop > 0.f ? 1.0f / (1.0f - p.p_drop) : 1.0f;
-    const uint32_t hk = attn_drop_headkey(p.seed, p.offset, b * p.H + h);
-    int troff[4];
-#pragma unroll
-    for (int dt = 0; dt < 4; ++dt) troff[dt] = tr_lane_off(lane, dt);
-    const int NP = (S + 31) >> 5;          // 32-row blocks (queries and keys alike)
-
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-
-    // ---------------- phase 1: dQ
-    for (int pr = wave; pr < NP; pr += 8) {
-        bf16x8_t qf[2][2], dof[2][2];
-        int qr[2];
-        float lse2[2], dlt[2];
-#pragma unroll
-        for (int rt = 0; rt < 2; ++rt) {
-            qr[rt] = pr * 32 + rt * 16 + fr;
-#pragma unroll
-            for (int dg = 0; dg < 2; ++dg) {
-                qf[rt][dg] = read_frag<bf16_t>(sQ, qr[rt], dg * 4 + g);
-                dof[rt][dg] = read_frag<bf16_t>(sDO, qr[rt], dg * 4 + g);
-            }
-            lse2[rt] = sLse[qr[rt]]; dlt[rt] = sDelta[qr[rt]];
-        }
-        f32x4_t dqacc[2][4];
-#pragma unroll
-        for (int rt = 0; rt < 2; ++rt)
-#pragma unroll
-            for (int dt = 0; dt < 4; ++dt) dqacc[rt][dt] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-        // scores and dP of key block jb: [k2][rt]
-        auto sp1 = [&](int jb, f32x4_t (&sa)[2][2], f32x4_t (&pa)[2][2]) {
-#pragma unroll
-            for (int k2 = 0; k2 < 2; ++k2) {
-                sa[k2][0] = (f32x4_t){0.f, 0.f, 0.f, 0.f}; sa[k2][1] = sa[k2][0]; pa[k2][0] = sa[k2][0]; pa[k2][1] = sa[k2][0];
-                const int kb = jb * 32 + k2 * 16;
-                if (kb < S) {
-#pragma unroll
-                    for (int dg = 0; dg < 2; ++dg) {
-                        const bf16x8_t kf = read_frag<bf16_t>(sK, kb + fr, dg * 4 + g);
-                        const bf16x8_t vf = read_frag<bf16_t>(sV, kb + fr, dg * 4 + g);
-                        sa[k2][0] = Mma<bf16_t>::mma(kf, qf[0][dg], sa[k2][0]);
-                        sa[k2][1] = Mma<bf16_t>::mma(kf, qf[1][dg], sa[k2][1]);
-                        pa[k2][0] = Mma<bf16_t>::mma(vf, dof[0][dg], pa[k2][0]);
-                        pa[k2][1] = Mma<bf16_t>::mma(vf, dof[1][dg], pa[k2][1]);
-                    }
-                }
-            }
-        };
-        auto fin1 = [&](int jb, const f32x4_t (&sa)[2][2], const f32x4_t (&pa)[2][2]) {
-            f32x4_t ds[2][2];      // [rt][k2]
-#pragma unroll
-            for (int k2 = 0; k2 < 2; ++k2)
-#pragma unroll
-                for (int rt = 0; rt < 2; ++rt) {
-                    const bool qok = qr[rt] < S;
-                    const float* mrowp = (p.mask && qok) ? p.mask + (int64_t)b * p.mask_bs + (int64_t)qr[rt] * p.mask_rs : nullptr;
-                    const int key0 = jb * 32 + k2 * 16 + 4 * g;
-                    const uint32_t e0 = (uint32_t)qr[rt] * (uint32_t)p.Skv + (uint32_t)key0;
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        float sc = sa[k2][rt][r] * sl2;
-                        if (mrowp) { if (key0 + r < S) sc += mrowp[key0 + r] * LOG2E_F; }
-                        const float prb = fast_exp2(sc - lse2[rt]);
-                        float dp = pa[k2][rt][r];
-                        if (DROP) dp = attn_drop_bits(hk, e0 + r) >= thr ? dp * keep_scale : 0.f;
-                        ds[rt][k2][r] = prb * (dp - dlt[rt]);
-                    }
-                }
-            const bf16x8_t d0 = pack_bf16x8(ds[0][0], ds[0][1]);
-            const bf16x8_t d1 = pack_bf16x8(ds[1][0], ds[1][1]);
-#pragma unroll
-            for (int dt = 0; dt < 4; ++dt) {
-                const bf16x8_t ktf = read_frag_tr_nat(sK, jb * 32, troff[dt]);   // K^T[d][key]
-                dqacc[0][dt] = Mma<bf16_t>::mma(ktf, d0, dqacc[0][dt]);
-                dqacc[1][dt] = Mma<bf16_t>::mma(ktf, d1, dqacc[1][dt]);
-            }
-        };
-        f32x4_t saA[2][2], paA[2][2], saB[2][2], paB[2][2];
-        sp1(0, saA, paA);
-        for (int jb = 0; jb < NP; jb += 2) {
-            if (jb + 1 < NP) sp1(jb + 1, saB, paB);
-            fin1(jb, saA, paA);
-            if (jb + 1 < NP) {
-                if (jb + 2 < NP) sp1(jb + 2, saA, paA);
-                fin1(jb + 1, saB, paB);
-            }
-        }
-#pragma unroll
-        for (int rt = 0; rt < 2; ++rt)
-            if (qr[rt] < S) {
-                bf16_t* DQ = (bf16_t*)p.dq + (int64_t)b * p.dq_bs + (int64_t)qr[rt] * p.dq_rs + h * ATT_D;
-#pragma unroll
-                for (int dt = 0; dt < 4; ++dt) store4<bf16_t>(DQ + dt * 16 + 4 * g, dqacc[rt][dt] * p.scale);
-            }
-    }
-
-    // ---------------- phase 2: dK, dV   (scores as S[q = 4g+r][key = l & 15])
-    for (int pr = wave; pr < NP; pr += 8) {
-        bf16x8_t kf[2][2], vf[2][2];
-        int key[2];
-#pragma unroll
-        for (int kt = 0; kt < 2; ++kt) {
-            key[kt] = pr * 32 + kt * 16 + fr;
-#pragma unroll
-            for (int dg = 0; dg < 2; ++dg) {
-                kf[kt][dg] = read_frag<bf16_t>(sK, key[kt], dg * 4 + g);
-                vf[kt][dg] = read_frag<bf16_t>(sV, key[kt], dg * 4 + g);
-            }
-        }
-        f32x4_t dkacc[2][4], dvacc[2][4];
-#pragma unroll
-        for (int kt = 0; kt < 2; ++kt)
-#pragma unroll
-            for (int dt = 0; dt < 4; ++dt) { dkacc[kt][dt] = (f32x4_t){0.f, 0.f, 0.f, 0.f}; dvacc[kt][dt] = dkacc[kt][dt]; }
-        // scores and dP of query block jb: [q2][kt]
-        auto sp2 = [&](int jb, f32x4_t (&sa)[2][2], f32x4_t (&pa)[2][2]) {
-#pragma unroll
-            for (int q2 = 0; q2 < 2; ++q2) {
-                sa[q2][0] = (f32x4_t){0.f, 0.f, 0.f, 0.f}; sa[q2][1] = sa[q2][0]; pa[q2][0] = sa[q2][0]; pa[q2][1] = sa[q2][0];
-                const int qb = jb * 32 + q2 * 16;
-                if (qb < S) {
-#pragma unroll
-                    for (int dg = 0; dg < 2; ++dg) {
-                        const bf16x8_t qfr = read_frag<bf16_t>(sQ, qb + fr, dg * 4 + g);
-                        const bf16x8_t dfr = read_frag<bf16_t>(sDO, qb + fr, dg * 4 + g);
-                        sa[q2][0] = Mma<bf16_t>::mma(qfr, kf[0][dg], sa[q2][0]);
-                        sa[q2][1] = Mma<bf16_t>::mma(qfr, kf[1][dg], sa[q2][1]);
-                        pa[q2][0] = Mma<bf16_t>::mma(dfr, vf[0][dg], pa[q2][0]);
-                        pa[q2][1] = Mma<bf16_t>::mma(dfr, vf[1][dg], pa[q2][1]);
-                    }
-                }
-            }
-        };
-        auto fin2 = [&](int jb, const f32x4_t (&sa)[2][2], const f32x4_t (&pa)[2][2]) {
-            f32x4_t pd[2][2], ds[2][2];      // [kt][q2]
-#pragma unroll
-            for (int q2 = 0; q2 < 2; ++q2) {
-                const int qb = jb * 32 + q2 * 16;
-                const int q4 = qb + 4 * g;
-                f32x4_t l4, d4 = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-                if (qb < S) { l4 = *(const f32x4_t*)(sLse + q4); d4 = *(const f32x4_t*)(sDelta + q4); }
-                else l4 = (f32x4_t){INFINITY, INFINITY, INFINITY, INFINITY};        // sub-tile past S (block uniform): P = 0
-#pragma unroll
-                for (int kt = 0; kt < 2; ++kt)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const int qrow = q4 + r;
-                        float sc = sa[q2][kt][r] * sl2;
-                        if (p.mask) { if (qrow < S && key[kt] < S) sc += p.mask[(int64_t)b * p.mask_bs + (int64_t)qrow * p.mask_rs + key[kt]] * LOG2E_F; }
-                        const float prb = fast_exp2(sc - l4[r]);
-                        float dp = pa[q2][kt][r], pdv = prb;
-                        if (DROP) {
-                            const bool keep = attn_drop_bits(hk, (uint32_t)qrow * (uint32_t)p.Skv + (uint32_t)key[kt]) >= thr;
-                            dp = keep ? dp * keep_scale : 0.f;
-                            pdv = keep ? prb * keep_scale : 0.f;
-                        }
-                        pd[kt][q2][r] = pdv; ds[kt][q2][r] = prb * (dp - d4[r]);
-                    }
-            }
-            const bf16x8_t p0 = pack_bf16x8(pd[0][0], pd[0][1]);
-            const bf16x8_t p1 = pack_bf16x8(pd[1][0], pd[1][1]);
-            const bf16x8_t s0 = pack_bf16x8(ds[0][0], ds[0][1]);
-            const bf16x8_t s1 = pack_bf16x8(ds[1][0], ds[1][1]);
-#pragma unroll
-            for (int dt = 0; dt < 4; ++dt) {
-                const bf16x8_t dotf = read_frag_tr_nat(sDO, jb * 32, troff[dt]);   // dO^T[d][q]
-                const bf16x8_t qtf = read_frag_tr_nat(sQ, jb * 32, troff[dt]);     // Q^T[d][q]
-                dvacc[0][dt] = Mma<bf16_t>::mma(dotf, p0, dvacc[0][dt]);
-                dvacc[1][dt] = Mma<bf16_t>::mma(dotf, p1, dvacc[1][dt]);
-                dkacc[0][dt] = Mma<bf16_t>::mma(qtf, s0, dkacc[0][dt]);
-                dkacc[1][dt] = Mma<bf16_t>::mma(qtf, s1, dkacc[1][dt]);
-            }
-        };
-        // (phase 2 keeps 64 accumulator registers of dK / dV beside the K / V fragments: with two score stages in flight it spills 144-468 B
-        //  per lane, also with the fragments re-read per block; its blocks run one after the other)
-        f32x4_t saA[2][2], paA[2][2];
-#pragma unroll 1
-        for (int jb = 0; jb < NP; ++jb) {
-            sp2(jb, saA, paA);
-            fin2(jb, saA, paA);
-        }
-#pragma unroll
-        for (int kt = 0; kt < 2; ++kt)
-            if (key[kt] < S) {
-                bf16_t* DK = (bf16_t*)p.dk + (int64_t)b * p.dk_bs + (int64_t)key[kt] * p.dk_rs + h * ATT_D;
-                bf16_t* DV = (bf16_t*)p.dv + (int64_t)b * p.dv_bs + (int64_t)key[kt] * p.dv_rs + h * ATT_D;
-#pragma unroll
-                for (int dt = 0; dt < 4; ++dt) {
-                    store4<bf16_t>(DK + dt * 16 + 4 * g, dkacc[kt][dt] * p.scale);
-                    store4<bf16_t>(DV + dt * 16 + 4 * g, dvacc[kt][dt]);
-                }
-            }
-    }
-}
-
 // ------------------------------------------------------------------------------------------ backward, pipelined
 // The kernel above is one workgroup per CU (114 KiB of LDS, 8 waves x 178 VGPRs) whose three stretches do not overlap with anything:
 // 112 KiB of LDS-DMA before the first MFMA, the two compute phases, 75 KiB of stores -- and every CU does the same thing at the same
@@ -966,8 +725,10 @@ bool attn_res_fwd_launch(hipStream_t st, const AttnArgs& p) {
 }
 
 static int g_res_bwd_pipe = [] { const char* e = getenv("VALOR_ATTN_PIPE"); return e ? atoi(e) : 1; }();
-// 1 (default): the persistent, phase-pipelined backward; 0: one workgroup per (batch, head); 2: one workgroup per (batch, head) with the
-// software-pipelined inner loops. Returns the previous value.
+// 1 (default): the persistent, phase-pipelined backward; 0: one workgroup per (batch, head). Returns the previous value.
+// (A third variant -- the dQ phase as a two-stage software pipeline, scores of key block j + 1 issued before the softmax of block j --
+//  measured SLOWER, 656 vs 633 us at the ViT shape, and two stages in the dK / dV phase spill 144-468 B per lane:
+//  profiles/r03_attn_pipe_ab_v2.json.)
 extern "C" int valor_attn_set_res_pipeline(int v) {
     const int o = g_res_bwd_pipe;
     if (v >= 0) g_res_bwd_pipe = v;
@@ -988,18 +749,11 @@ bool attn_res_bwd_launch(hipStream_t st, const AttnArgs& p) {
         hipFuncSetAttribute((const void*)attn_res_bwd_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, mx);
         hipFuncSetAttribute((const void*)attn_res_bwd_pipe_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, mx);
         hipFuncSetAttribute((const void*)attn_res_bwd_pipe_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, mx);
-        hipFuncSetAttribute((const void*)attn_res_bwd_swp_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, mx);
-        hipFuncSetAttribute((const void*)attn_res_bwd_swp_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, mx);
         int dev = 0, cus = 0;
         if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus > 0) n_cu = cus;
         attr_set = true;
     }
     const int n_items = p.B * p.H;
-    if (g_res_bwd_pipe == 2) {
-        if (p.p_drop > 0.f) hipLaunchKernelGGL(attn_res_bwd_swp_kernel<true>, dim3(p.H, p.B), dim3(512), lds, st, p);
-        else hipLaunchKernelGGL(attn_res_bwd_swp_kernel<false>, dim3(p.H, p.B), dim3(512), lds, st, p);
-        return true;
-    }
     if (g_res_bwd_pipe && n_items >= 2 * n_cu) {        // several items per workgroup: otherwise there is nothing to pipeline
         if (p.p_drop > 0.f) hipLaunchKernelGGL(attn_res_bwd_pipe_kernel<true>, dim3(n_cu), dim3(512), lds, st, p, n_items);
         else hipLaunchKernelGGL(attn_res_bwd_pipe_kernel<false>, dim3(n_cu), dim3(512), lds, st, p, n_items);
