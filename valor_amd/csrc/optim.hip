@@ -82,15 +82,22 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* master, float* m, flo
     }
 }
 
-// sum of squares of the active chunks -> partial[gridDim.x]
+// sum of squares of the active chunks -> partial[gridDim.x]. Four chunks per iteration: with one 8-byte load in flight per thread the
+// 0.75 GB gradient arena was read at 2.1 TB/s (348 us per step).
 template <typename T>
 __global__ __launch_bounds__(256) void sumsq_kernel(const T* grad, const int8_t* chunk_group, int64_t nchunks, float* partial) {
     __shared__ float red[4];
     float s = 0.f;
-    for (int64_t c = blockIdx.x; c < nchunks; c += gridDim.x) {
-        if (chunk_group && chunk_group[c] < 0) continue;
-        f32x4_t g = load4<T>(grad + c * ADAMW_CHUNK + threadIdx.x * 4);
-        s += g[0] * g[0] + g[1] * g[1] + g[2] * g[2] + g[3] * g[3];
+    for (int64_t c0 = blockIdx.x; c0 < nchunks; c0 += 4 * (int64_t)gridDim.x) {
+        f32x4_t g[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int64_t c = c0 + u * (int64_t)gridDim.x;
+            g[u] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+            if (c < nchunks && !(chunk_group && chunk_group[c] < 0)) g[u] = load4<T>(grad + c * ADAMW_CHUNK + threadIdx.x * 4);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) s += g[u][0] * g[u][0] + g[u][1] * g[u][1] + g[u][2] * g[u][2] + g[u][3] * g[u][3];
     }
     s = wave_sum(s);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
