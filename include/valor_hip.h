@@ -15,9 +15,11 @@
  *     exact fp32 MFMA (parity mode). Pointers typed `void*` hold elements of `dtype`;
  *   - all compute entry points are re-entrant (autograd may call from a worker thread) and keep no state between calls.
  *     The ONLY process-global state is the kernel-family selection of the tuning hooks (valor_gemm_set_variant,
- *     valor_gemm_set_tr_asm, valor_gemm_set_fast_epilogue, valor_attn_set_variant, valor_win_attn_set_variant and their
- *     VALOR_* environment presets): plain ints read at launch time, every setting selects a parity-tested kernel family
- *     computing the same function, so a concurrent change can alter speed, never results beyond rounding.
+ *     valor_gemm_set_policy, valor_gemm_set_tr_asm, valor_gemm_set_fast_epilogue, valor_attn_set_variant,
+ *     valor_attn_set_res_pipeline, valor_win_attn_set_variant, valor_ln_set_variant, valor_ln_set_nt, valor_adamw_set_nt,
+ *     valor_fine_set_fused and their VALOR_* environment presets): plain ints read at launch time, every setting selects a
+ *     parity-tested kernel family computing the same function, so a concurrent change can alter speed, never results beyond
+ *     rounding.
  *   - dropout masks are Philox4x32-10 streams keyed by (seed, offset + element index / 4) and are regenerated
  *     in backward from the same (seed, offset) -- nothing is stored.
  */

@@ -140,10 +140,14 @@ def test_resident_backward_pipelined_equals_per_head_kernel(dev, S, B, H, p_drop
         dq1b, dk1b, dv1b = K.attn_bwd(q, k, v, o, lse, dout, H, scale=scale, p_drop=p_drop, seed=5, offset=9)     # and it is deterministic
         so.valor_attn_set_res_pipeline(0)
         dq0, dk0, dv0 = K.attn_bwd(q, k, v, o, lse, dout, H, scale=scale, p_drop=p_drop, seed=5, offset=9)
+        so.valor_attn_set_res_pipeline(2)           # key-stationary single pass: dQ summed over key blocks through LDS in another order
+        dq2, dk2, dv2 = K.attn_bwd(q, k, v, o, lse, dout, H, scale=scale, p_drop=p_drop, seed=5, offset=9)
+        dq2b, dk2b, dv2b = K.attn_bwd(q, k, v, o, lse, dout, H, scale=scale, p_drop=p_drop, seed=5, offset=9)
     finally:
         so.valor_attn_set_res_pipeline(old)
     torch.cuda.synchronize()
-    for a, b_, c, n in ((dq1, dq0, dq1b, "dq"), (dk1, dk0, dk1b, "dk"), (dv1, dv0, dv1b, "dv")):
+    for a, b_, c, n in ((dq1, dq0, dq1b, "dq"), (dk1, dk0, dk1b, "dk"), (dv1, dv0, dv1b, "dv"),
+                        (dq2, dq0, dq2b, "dq single pass"), (dk2, dk0, dk2b, "dk single pass"), (dv2, dv0, dv2b, "dv single pass")):
         assert torch.equal(a, c), n
         assert _rel(a, b_) < 5e-4, (n, _rel(a, b_))
         assert float((a.float() - b_.float()).abs().max()) <= 2.0 ** -7 * float(b_.float().abs().max()), n
@@ -153,3 +157,4 @@ def test_resident_backward_pipelined_equals_per_head_kernel(dev, S, B, H, p_drop
         oref = _ref_attn(qd, kd, vd, H, None, None, 0, scale)
         (oref * dout[sl].double()).sum().backward()
         assert _rel(dq1[sl], qd.grad) < 2e-2 and _rel(dk1[sl], kd.grad) < 2e-2 and _rel(dv1[sl], vd.grad) < 2e-2
+        assert _rel(dq2[sl], qd.grad) < 2e-2 and _rel(dk2[sl], kd.grad) < 2e-2 and _rel(dv2[sl], vd.grad) < 2e-2

@@ -724,8 +724,208 @@ bool attn_res_fwd_launch(hipStream_t st, const AttnArgs& p) {
     return true;
 }
 
+// ------------------------------------------------------------------------------------------ backward, single pass
+// Key-stationary SINGLE PASS: the two-phase kernels above compute the scores and dP twice (once per phase: 7 matmuls and 2 x S^2 exp2 for
+// the 5 matmuls and S^2 exp2 the algorithm needs). Here wave w owns the 32-key block w for the whole head: its K / V fragments and its
+// K^T fragments live in registers, dK / dV of its keys accumulate in registers, and it walks the 32-query blocks in a SKEWED order --
+// at step s every wave works on query block (w + s) mod NP, so no two waves touch the same query block in a step and the dQ partial
+// of (query block, key block) is added into a per-query-block fp32 accumulator in LDS WITHOUT atomics (read-modify-write by the one wave
+// that owns that block in that step; one barrier per step). dS is needed in both orientations: the (query in-lane, key across lanes)
+// tile of the S = Q.K^T MFMA feeds dK / dV directly; for dQ^T += K^T.dS^T it goes through a 1 KiB per-wave LDS scratch and comes back
+// with a transposing read (the attention_x.hip idiom).
+// Per wave 280 MFMAs instead of 392, half the exp2 / dropout-hash work, ~40 % fewer LDS fragment reads.
+// LDS: Q and dO images (SP rows each) + the dQ accumulators [NP][32][64] fp32 (the K image is staged into that region first: fragments
+// and transposed fragments of the own key block are read out before the first accumulator write) + scratch + statistics <= 150 KiB.
+template <bool DROP>
+__global__ __launch_bounds__(512, 2) void attn_res_bwd_1p_kernel(AttnArgs p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int fr = lane & 15, g = lane >> 4;
+    const int h = blockIdx.x, b = blockIdx.y;
+    const int S = p.Skv, SP = (S + 31) & ~31;
+    const int IMG = SP * TILE_ROW_BYTES;
+    const int NP = SP >> 5;                       // 32-row blocks, <= 8: one key block per wave
+    char* sQ = smem;
+    char* sDO = smem + IMG;
+    float* sAcc = (float*)(smem + 2 * IMG);       // [NP][32][64] fp32, XOR-swizzled 16-byte chunks; first the K image
+    char* sKimg = smem + 2 * IMG;
+    char* sT = smem + 2 * IMG + NP * 8192;        // 8 x 1 KiB dS^T scratch
+    float* sLse = (float*)(sT + 8192);
+    float* sDelta = sLse + SP;
+    const int pr = wave;
+    const bool active = pr < NP;
+
+    stage_image(head_rsrc(p.q, (int64_t)b * p.q_bs + h * ATT_D, S, p.q_rs), sQ, SP, (int)p.q_rs * 2, wave, 8, lane);
+    stage_image(head_rsrc(p.dout, (int64_t)b * p.do_bs + h * ATT_D, S, p.do_rs), sDO, SP, (int)p.do_rs * 2, wave, 8, lane);
+    stage_image(head_rsrc(p.k, (int64_t)b * p.k_bs + h * ATT_D, S, p.k_rs), sKimg, SP, (int)p.k_rs * 2, wave, 8, lane);
+
+    // this wave's V fragments (its 32 keys) straight from global; delta / lse of its 32 query rows
+    bf16x8_t vf[2][2];
+    int key[2];
+    {
+        const bf16_t* Vb = (const bf16_t*)p.v + (int64_t)b * p.v_bs + h * ATT_D;
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt) {
+            key[kt] = pr * 32 + kt * 16 + fr;
+            const bool ok = active && key[kt] < S;
+#pragma unroll
+            for (int dg = 0; dg < 2; ++dg) {
+                u32x4_t zv = {0u, 0u, 0u, 0u};
+                if (ok) zv = *(const u32x4_t*)(Vb + (int64_t)key[kt] * p.v_rs + dg * 32 + g * 8);
+                vf[kt][dg] = __builtin_bit_cast(bf16x8_t, zv);
+            }
+        }
+    }
+    {
+        const bf16_t* Ob = (const bf16_t*)p.o + (int64_t)b * p.o_bs + h * ATT_D;
+        const bf16_t* DOb = (const bf16_t*)p.dout + (int64_t)b * p.do_bs + h * ATT_D;
+        const int64_t statbase = ((int64_t)b * p.H + h) * p.Sq;
+        for (int r0 = wave * 8; r0 < SP; r0 += 64) {
+            const int row = r0 + (lane >> 3), c = lane & 7;
+            float d = 0.f;
+            if (row < S) {
+                const bf16x8_t ov = __builtin_bit_cast(bf16x8_t, *(const u32x4_t*)(Ob + (int64_t)row * p.o_rs + c * 8));
+                const bf16x8_t dv = __builtin_bit_cast(bf16x8_t, *(const u32x4_t*)(DOb + (int64_t)row * p.do_rs + c * 8));
+#pragma unroll
+                for (int e = 0; e < 8; ++e) d += (float)ov[e] * (float)dv[e];
+            }
+            d += __shfl_xor(d, 1, 64); d += __shfl_xor(d, 2, 64); d += __shfl_xor(d, 4, 64);
+            if (c == 0) { sDelta[row] = d; sLse[row] = row < S ? p.lse[statbase + row] * LOG2E_F : INFINITY; }
+        }
+    }
+    const float sl2 = p.scale * LOG2E_F;
+    const uint32_t thr = drop_threshold(p.p_drop);
+    const float keep_scale = p.p_drop > 0.f ? 1.0f / (1.0f - p.p_drop) : 1.0f;
+    const uint32_t hk = attn_drop_headkey(p.seed, p.offset, b * p.H + h);
+    int troff[4];
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) troff[dt] = tr_lane_off(lane, dt);
+
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    // own key block: K fragments (contraction over d) and K^T fragments (contraction over keys) out of the K image
+    bf16x8_t kf[2][2], ktf[4];
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+        for (int dg = 0; dg < 2; ++dg) kf[kt][dg] = read_frag<bf16_t>(sKimg, (active ? pr : 0) * 32 + kt * 16 + fr, dg * 4 + g);
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) ktf[dt] = read_frag_tr_nat(sKimg, (active ? pr : 0) * 32, troff[dt]);
+    __syncthreads();                              // the K image is dead: its region becomes the dQ accumulators
+
+    f32x4_t dkacc[2][4], dvacc[2][4];
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) { dkacc[kt][dt] = (f32x4_t){0.f, 0.f, 0.f, 0.f}; dvacc[kt][dt] = dkacc[kt][dt]; }
+    char* sTw = sT + wave * 1024;
+    const int tw_off = (fr * 32) + 8 * g;                               // dS write: row = key (kt*16 + fr), 4 q at 8g
+    const int tr_off = (4 * g + (fr >> 2)) * 32 + 8 * (fr & 3);         // dS^T tr-read: rows 4g + (i>>2), q cols 4(i&3)
+
+    for (int s = 0; s < NP; ++s) {
+        if (active) {
+            int qb = pr + s;
+            if (qb >= NP) qb -= NP;
+            const int qb0 = qb * 32;
+            f32x4_t pd[2][2], ds[2][2];      // [kt][q2]
+#pragma unroll
+            for (int q2 = 0; q2 < 2; ++q2) {
+                f32x4_t sa[2], pa[2];
+                sa[0] = (f32x4_t){0.f, 0.f, 0.f, 0.f}; sa[1] = sa[0]; pa[0] = sa[0]; pa[1] = sa[0];
+                const int q4 = qb0 + q2 * 16 + 4 * g;
+#pragma unroll
+                for (int dg = 0; dg < 2; ++dg) {
+                    const bf16x8_t qfr = read_frag<bf16_t>(sQ, qb0 + q2 * 16 + fr, dg * 4 + g);
+                    const bf16x8_t dfr = read_frag<bf16_t>(sDO, qb0 + q2 * 16 + fr, dg * 4 + g);
+                    sa[0] = Mma<bf16_t>::mma(qfr, kf[0][dg], sa[0]);
+                    sa[1] = Mma<bf16_t>::mma(qfr, kf[1][dg], sa[1]);
+                    pa[0] = Mma<bf16_t>::mma(dfr, vf[0][dg], pa[0]);
+                    pa[1] = Mma<bf16_t>::mma(dfr, vf[1][dg], pa[1]);
+                }
+                const f32x4_t l4 = *(const f32x4_t*)(sLse + q4), d4 = *(const f32x4_t*)(sDelta + q4);      // rows past S: lse = +inf -> P = 0
+#pragma unroll
+                for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int qrow = q4 + r;
+                        float sc = sa[kt][r] * sl2;
+                        if (p.mask) { if (qrow < S && key[kt] < S) sc += p.mask[(int64_t)b * p.mask_bs + (int64_t)qrow * p.mask_rs + key[kt]] * LOG2E_F; }
+                        const float prb = fast_exp2(sc - l4[r]);
+                        float dp = pa[kt][r], pdv = prb;
+                        if (DROP) {
+                            const bool keep = attn_drop_bits(hk, (uint32_t)qrow * (uint32_t)p.Skv + (uint32_t)key[kt]) >= thr;
+                            dp = keep ? dp * keep_scale : 0.f;
+                            pdv = keep ? prb * keep_scale : 0.f;
+                        }
+                        pd[kt][q2][r] = pdv; ds[kt][q2][r] = prb * (dp - d4[r]);
+                    }
+            }
+            const bf16x8_t p0 = pack_bf16x8(pd[0][0], pd[0][1]);
+            const bf16x8_t p1 = pack_bf16x8(pd[1][0], pd[1][1]);
+            const bf16x8_t s0 = pack_bf16x8(ds[0][0], ds[0][1]);
+            const bf16x8_t s1 = pack_bf16x8(ds[1][0], ds[1][1]);
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) {
+                const bf16x8_t dotf = read_frag_tr_nat(sDO, qb0, troff[dt]);   // dO^T[d][q]
+                const bf16x8_t qtf = read_frag_tr_nat(sQ, qb0, troff[dt]);     // Q^T[d][q]
+                dvacc[0][dt] = Mma<bf16_t>::mma(dotf, p0, dvacc[0][dt]);
+                dvacc[1][dt] = Mma<bf16_t>::mma(dotf, p1, dvacc[1][dt]);
+                dkacc[0][dt] = Mma<bf16_t>::mma(qtf, s0, dkacc[0][dt]);
+                dkacc[1][dt] = Mma<bf16_t>::mma(qtf, s1, dkacc[1][dt]);
+            }
+            // dQ^T[d][q] (this key block's share) = K^T[d][key] . dS^T[key][q], 16 queries at a time through the transposing scratch
+#pragma unroll
+            for (int rt = 0; rt < 2; ++rt) {
+                const u32x2_t w0 = {pack2_bf16(ds[0][rt][0], ds[0][rt][1]), pack2_bf16(ds[0][rt][2], ds[0][rt][3])};
+                const u32x2_t w1 = {pack2_bf16(ds[1][rt][0], ds[1][rt][1]), pack2_bf16(ds[1][rt][2], ds[1][rt][3])};
+                *(u32x2_t*)(sTw + tw_off) = w0;
+                *(u32x2_t*)(sTw + 512 + tw_off) = w1;
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                const s16x4_t t0 = lds_read_tr4(sTw + tr_off), t1 = lds_read_tr4(sTw + 512 + tr_off);
+                const bf16x8_t dst = __builtin_bit_cast(bf16x8_t, __builtin_shufflevector(t0, t1, 0, 1, 2, 3, 4, 5, 6, 7));
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");    // the scratch is rewritten for the next 16 queries
+                float* accrow = sAcc + (qb0 + rt * 16 + fr) * 64;
+#pragma unroll
+                for (int dt = 0; dt < 4; ++dt) {
+                    f32x4_t dq = Mma<bf16_t>::mma(ktf[dt], dst, (f32x4_t){0.f, 0.f, 0.f, 0.f});
+                    float* q = accrow + (((dt * 4 + g) ^ fr) << 2);
+                    if (s > 0) dq += *(const f32x4_t*)q;      // step 0: every query block gets its first (plain) write from wave = block
+                    *(f32x4_t*)q = dq;
+                }
+            }
+        }
+        __syncthreads();        // the next step's owner of a query block adds to what this step's owner wrote
+    }
+
+    if (active) {
+#pragma unroll
+        for (int rt = 0; rt < 2; ++rt) {
+            const int qr = pr * 32 + rt * 16 + fr;
+            if (qr < S) {
+                bf16_t* DQ = (bf16_t*)p.dq + (int64_t)b * p.dq_bs + (int64_t)qr * p.dq_rs + h * ATT_D;
+                const float* accrow = sAcc + (pr * 32 + rt * 16 + fr) * 64;
+#pragma unroll
+                for (int dt = 0; dt < 4; ++dt) store4<bf16_t>(DQ + dt * 16 + 4 * g, *(const f32x4_t*)(accrow + (((dt * 4 + g) ^ fr) << 2)) * p.scale);
+            }
+        }
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt)
+            if (key[kt] < S) {
+                bf16_t* DK = (bf16_t*)p.dk + (int64_t)b * p.dk_bs + (int64_t)key[kt] * p.dk_rs + h * ATT_D;
+                bf16_t* DV = (bf16_t*)p.dv + (int64_t)b * p.dv_bs + (int64_t)key[kt] * p.dv_rs + h * ATT_D;
+#pragma unroll
+                for (int dt = 0; dt < 4; ++dt) {
+                    store4<bf16_t>(DK + dt * 16 + 4 * g, dkacc[kt][dt] * p.scale);
+                    store4<bf16_t>(DV + dt * 16 + 4 * g, dvacc[kt][dt]);
+                }
+            }
+    }
+}
+
 static int g_res_bwd_pipe = [] { const char* e = getenv("VALOR_ATTN_PIPE"); return e ? atoi(e) : 1; }();
-// 1 (default): the persistent, phase-pipelined backward; 0: one workgroup per (batch, head). Returns the previous value.
+// 1: the persistent, phase-pipelined backward; 0: one workgroup per (batch, head), two phases; 2: the key-stationary single pass.
+// Returns the previous value.
 // (A third variant -- the dQ phase as a two-stage software pipeline, scores of key block j + 1 issued before the softmax of block j --
 //  measured SLOWER, 656 vs 633 us at the ViT shape, and two stages in the dK / dV phase spill 144-468 B per lane:
 //  profiles/r03_attn_pipe_ab_v2.json.)
@@ -754,6 +954,20 @@ bool attn_res_bwd_launch(hipStream_t st, const AttnArgs& p) {
         attr_set = true;
     }
     const int n_items = p.B * p.H;
+    if (g_res_bwd_pipe == 2) {
+        const int NP = SP >> 5;
+        const size_t lds1 = 2 * (size_t)SP * TILE_ROW_BYTES + (size_t)NP * 8192 + 8192 + 2 * (size_t)SP * sizeof(float);
+        static bool attr1 = false;
+        if (!attr1) {
+            const int mx1 = 2 * 256 * TILE_ROW_BYTES + 8 * 8192 + 8192 + 2 * 256 * (int)sizeof(float);
+            hipFuncSetAttribute((const void*)attn_res_bwd_1p_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, mx1);
+            hipFuncSetAttribute((const void*)attn_res_bwd_1p_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, mx1);
+            attr1 = true;
+        }
+        if (p.p_drop > 0.f) hipLaunchKernelGGL(attn_res_bwd_1p_kernel<true>, dim3(p.H, p.B), dim3(512), lds1, st, p);
+        else hipLaunchKernelGGL(attn_res_bwd_1p_kernel<false>, dim3(p.H, p.B), dim3(512), lds1, st, p);
+        return true;
+    }
     if (g_res_bwd_pipe && n_items >= 2 * n_cu) {        // several items per workgroup: otherwise there is nothing to pipeline
         if (p.p_drop > 0.f) hipLaunchKernelGGL(attn_res_bwd_pipe_kernel<true>, dim3(n_cu), dim3(512), lds, st, p, n_items);
         else hipLaunchKernelGGL(attn_res_bwd_pipe_kernel<false>, dim3(n_cu), dim3(512), lds, st, p, n_items);

@@ -232,7 +232,6 @@ class VALOR(nn.Module):
 
     def state_dict(self, *a, **k):
         """Reference-keyed state dict (fp32 CPU-agnostic views of the arena parameters)."""
-        streams.wait_param_event(self.device)
         out = {}
         for name, shape, refs in self.table:
             p = self.P[name].detach()
@@ -256,7 +255,6 @@ class VALOR(nn.Module):
         return out
 
     def load_state_dict(self, sd, strict=True):
-        streams.wait_param_event(self.device)
         missing, used = [], set()
         with torch.no_grad():
             for name, shape, refs in self.table:
@@ -788,7 +786,6 @@ class VALOR(nn.Module):
         TokenMasker p = 0.15 -> multimodal encoder without cross-attention input, casual=False -> prediction head on the masked
         rows -> cross-entropy. Same kernels as the decoder passes of forward_pt."""
         self.stage.begin_step()
-        streams.wait_param_event(self.device)
         txt = batch["txt_tokens"]["bert_tokens"].cpu()
         mlm_in, mlm_lab = self.text_masker(txt, 0.15)
         out = {}
@@ -801,8 +798,6 @@ class VALOR(nn.Module):
     # ------------------------------------------------------------------ the hot path
     def forward(self, batch, task, compute_loss=True):
         """VALOR.forward, model/pretrain.py:125-135"""
-        if not (task.startswith("pt") or task.startswith("ret") or (task.startswith("cap") and compute_loss)):
-            streams.wait_param_event(self.device)       # paths that do not go through _forward_groups (which waits behind its video encoder)
         if task.startswith("pt"):
             return self.forward_pt(batch, task, compute_loss=compute_loss)
         if task.startswith("ret"):
@@ -924,7 +919,6 @@ class VALOR(nn.Module):
                     txt_output = self.forward_txt_encoder(clip_tokens)
         if "v" in alltasks:
             video_output = self.forward_video_encoder(batch["video_pixels"])
-        streams.wait_param_event(self.device)       # the optimizer's tail (everything behind the video tower) ran beside the video encoder
         if side is not None:
             audio_output, txt_output = streams.join(side, audio_output, txt_output)
         if "a" in alltasks and audio_output is None:

@@ -8,12 +8,11 @@ new_lr, new_params_name; state_dict() uses the HF per-parameter layout {step, ex
 """
 import ctypes
 import math
-import os
 import weakref
 
 import torch
 
-from .. import lib, streams
+from .. import lib
 from ..kernels import _ptr, _stream, dt_of, workspace
 
 
@@ -81,31 +80,7 @@ class FusedAdamW:
             model._optimizers = []
         model._optimizers.append(weakref.ref(self))
 
-    def _tail_split(self):
-        """arena offset behind the video tower's parameters (0 = no split: one stream, CPU, or the tower is not the head of the arena)"""
-        a = self.arena
-        if a.device.type != "cuda" or not streams.enabled() or os.environ.get("VALOR_ADAMW_SPLIT", "1") == "0":
-            return 0
-        cached = getattr(self, "_split", None)
-        if cached is None:
-            end, ok = 0, True
-            for name in a.offsets:
-                tower = name.startswith(("clip_model.visual.", "video_encoder."))
-                if tower and not ok:
-                    end = 0
-                    break
-                if tower:
-                    end = a.range_of(name)[1]
-                else:
-                    ok = False
-            cached = self._split = end if 0 < end < a.numel else 0
-        return cached
-
     def sync_master(self):
-        streams.wait_param_event(self.arena.device)
-        self._sync_master()
-
-    def _sync_master(self):
         """Re-derive the fp32 masters from the current parameters (bf16 mode) -- element by element, and ONLY where a master no longer
         rounds to its parameter. Called by VALOR.load_state_dict / init_parameters, so weights loaded AFTER the optimizer exists cannot
         be overwritten by stale masters on the next step; masters that are still consistent with the parameters (restored by
@@ -120,7 +95,6 @@ class FusedAdamW:
         """Seed the fp32 masters from full-precision weights (instead of the rounded bf16 parameters)."""
         if not self.separate_master:
             return
-        streams.wait_param_event(self.arena.device)
         saved = self.arena.flat
         tmp_flat = self.master
         for name, shape, refs in self.model.table:
@@ -168,29 +142,14 @@ class FusedAdamW:
             by_step.setdefault(self.steps[n], []).append(n)
         lr = (ctypes.c_float * self.N_GROUPS)(*[g["lr"] for g in self.param_groups])
         wd = (ctypes.c_float * self.N_GROUPS)(*[g["weight_decay"] for g in self.param_groups])
-        # The update streams 28 B per parameter (10.5 GB at VALOR-base: ~2.3 ms) with nothing beside it. Only the VIDEO TOWER's parameters
-        # (the head of the arena) are needed by the first third of the next forward pass: their update runs here, the rest of the arena
-        # is updated on the side stream -- under the next step's video encoder, ahead of the audio / text encoders that are issued on
-        # that stream anyway -- and every other reader waits for `streams.wait_param_event` (VALOR does, behind its video encoder).
-        split = self._tail_split() if len(by_step) == 1 else 0
-        esz = a.grad.element_size()
+        # (Running the update of everything behind the video tower on the side stream, under the next step's video encoder, was measured:
+        #  534.95 / 533.70 vs 534.18 / 534.45 samples/s -- no gain, the HBM-bound update and the encoder's GEMMs share the memory system;
+        #  one launch on the step's stream it stays. profiles/r03_step_ab_s7_adamw_split.txt)
         for st, ns in by_step.items():
             tb = table if len(by_step) == 1 else self._table(ns)
-            ranges = [(0, a.numel, None)] if not split else [(0, split, None), (split, a.numel, streams.side_stream(a.device))]
-            for (o, e, side) in ranges:
-                args = (dt, _ptr(self.master) + 4 * o, _ptr(self.exp_avg) + 4 * o, _ptr(self.exp_avg_sq) + 4 * o, _ptr(a.grad) + esz * o,
-                        (_ptr(a.flat) + esz * o) if self.separate_master else None, _ptr(tb) + o // a.chunk, e - o, lr, wd, self.N_GROUPS,
-                        self.betas[0], self.betas[1], self.eps, int(st), int(self.correct_bias), _ptr(self.gscale), 1)
-                if side is None:
-                    lib.call("valor_adamw", _stream(), *args)
-                else:
-                    ready = torch.cuda.Event()
-                    ready.record(torch.cuda.current_stream(a.device))          # the clip coefficient and every gradient write are behind this
-                    side.wait_event(ready)
-                    lib.call("valor_adamw", side.cuda_stream, *args)
-                    done = torch.cuda.Event()
-                    done.record(side)
-                    streams.set_param_event(a.device, done)
+            lib.call("valor_adamw", _stream(), dt, _ptr(self.master), _ptr(self.exp_avg), _ptr(self.exp_avg_sq), _ptr(a.grad),
+                     _ptr(a.flat) if self.separate_master else None, _ptr(tb), a.numel, lr, wd, self.N_GROUPS,
+                     self.betas[0], self.betas[1], self.eps, int(st), int(self.correct_bias), _ptr(self.gscale), 1)
         return self.total_norm
 
     # ---- the reference's optimizer checkpoint (optimizer_step_N.pt: utils/save.py:57-64 saves torch's Optimizer.state_dict() of the
@@ -225,10 +184,6 @@ class FusedAdamW:
         return out
 
     def reference_state_dict(self):
-        streams.wait_param_event(self.arena.device)
-        return self._reference_state_dict()
-
-    def _reference_state_dict(self):
         """torch-Optimizer-format state dict with the reference's parameter indexing, loadable by the reference's
         optimizer.load_state_dict (and by load_reference_state_dict below)."""
         groups = self.reference_param_groups()
@@ -247,10 +202,6 @@ class FusedAdamW:
         return {"state": state, "param_groups": pgs}
 
     def load_reference_state_dict(self, sd):
-        streams.wait_param_event(self.arena.device)
-        return self._load_reference_state_dict(sd)
-
-    def _load_reference_state_dict(self, sd):
         """Resume from the reference's optimizer_step_N.pt (or from reference_state_dict()). Packed q|k|v tensors take the
         step count of their parts (the reference steps them together)."""
         groups = self.reference_param_groups()
@@ -271,7 +222,6 @@ class FusedAdamW:
 
     # ---- compact native layout (one entry per arena tensor)
     def state_dict(self):
-        streams.wait_param_event(self.arena.device)
         state = {}
         for i, (name, (o, n, shape)) in enumerate(self.arena.offsets.items()):
             if self.steps[name] > 0:
@@ -283,7 +233,6 @@ class FusedAdamW:
         return out
 
     def load_state_dict(self, sd):
-        streams.wait_param_event(self.arena.device)
         names = sd.get("names", list(self.arena.offsets))
         for i, st in sd["state"].items():
             name = names[int(i)]

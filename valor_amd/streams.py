@@ -54,26 +54,6 @@ def compute_streams(device):
     return out
 
 
-# ---- the tail of the optimizer update may still be running on the side stream when the next step starts (optim.FusedAdamW.step):
-# whoever reads parameters outside the video tower -- or optimizer state -- waits for it first
-_PARAM_EVENTS = {}
-
-
-def set_param_event(device, ev):
-    device = torch.device(device)
-    _PARAM_EVENTS[device.index if device.index is not None else torch.cuda.current_device()] = ev
-
-
-def wait_param_event(device):
-    """the CURRENT stream waits for a pending optimizer tail on `device` (no-op when there is none)"""
-    device = torch.device(device)
-    if device.type != "cuda":
-        return
-    ev = _PARAM_EVENTS.pop(device.index if device.index is not None else torch.cuda.current_device(), None)
-    if ev is not None:
-        torch.cuda.current_stream(device).wait_event(ev)
-
-
 class _Join(Function):
     @staticmethod
     def forward(ctx, side, *tensors):
