@@ -38,6 +38,7 @@ CASES = [
     (4, 12, 32, 32, True, False),       # BERT text (pad + causal additive mask)
     (2, 12, 42, 42, True, False),       # text + task prompt
     (2, 8, 32, 32, True, False),        # CLIP text (8 heads)
+    (3, 12, 100, 100, True, False),     # additive mask on the LDS-resident backward (S > 64: its <., MASK> instantiations; no model path uses them)
     (2, 12, 32, 458, False, False),     # cross-attention, ragged tile tail
     (6, 12, 32, 330, False, True),      # modality-grouped: 3 query groups share K/V of batch 2
     (1, 2, 1, 1, False, False),
@@ -140,14 +141,10 @@ def test_resident_backward_pipelined_equals_per_head_kernel(dev, S, B, H, p_drop
         dq1b, dk1b, dv1b = K.attn_bwd(q, k, v, o, lse, dout, H, scale=scale, p_drop=p_drop, seed=5, offset=9)     # and it is deterministic
         so.valor_attn_set_res_pipeline(0)
         dq0, dk0, dv0 = K.attn_bwd(q, k, v, o, lse, dout, H, scale=scale, p_drop=p_drop, seed=5, offset=9)
-        so.valor_attn_set_res_pipeline(2)           # key-stationary single pass: dQ summed over key blocks through LDS in another order
-        dq2, dk2, dv2 = K.attn_bwd(q, k, v, o, lse, dout, H, scale=scale, p_drop=p_drop, seed=5, offset=9)
-        dq2b, dk2b, dv2b = K.attn_bwd(q, k, v, o, lse, dout, H, scale=scale, p_drop=p_drop, seed=5, offset=9)
     finally:
         so.valor_attn_set_res_pipeline(old)
     torch.cuda.synchronize()
-    for a, b_, c, n in ((dq1, dq0, dq1b, "dq"), (dk1, dk0, dk1b, "dk"), (dv1, dv0, dv1b, "dv"),
-                        (dq2, dq0, dq2b, "dq single pass"), (dk2, dk0, dk2b, "dk single pass"), (dv2, dv0, dv2b, "dv single pass")):
+    for a, b_, c, n in ((dq1, dq0, dq1b, "dq"), (dk1, dk0, dk1b, "dk"), (dv1, dv0, dv1b, "dv")):
         assert torch.equal(a, c), n
         assert _rel(a, b_) < 5e-4, (n, _rel(a, b_))
         assert float((a.float() - b_.float()).abs().max()) <= 2.0 ** -7 * float(b_.float().abs().max()), n
@@ -157,4 +154,3 @@ def test_resident_backward_pipelined_equals_per_head_kernel(dev, S, B, H, p_drop
         oref = _ref_attn(qd, kd, vd, H, None, None, 0, scale)
         (oref * dout[sl].double()).sum().backward()
         assert _rel(dq1[sl], qd.grad) < 2e-2 and _rel(dk1[sl], kd.grad) < 2e-2 and _rel(dv1[sl], vd.grad) < 2e-2
-        assert _rel(dq2[sl], qd.grad) < 2e-2 and _rel(dk2[sl], kd.grad) < 2e-2 and _rel(dv2[sl], vd.grad) < 2e-2

@@ -1,7 +1,10 @@
 """ONE launch of every non-GEMM hot kernel of the VALOR-base step at its bench shape (per-GPU batch 64), for rocprofv3 --pmc passes
 (tools/gpu_pmc_kernels.sh): LDS-resident self-attention forward / backward (ViT 512 x 12 heads x S = 197; AST with dropout),
 key-stationary cross-attention forward / backward (caption pass: 3 groups x 32 rows against 1834 keys, dropout), fused LayerNorm forward /
-backward, cross-entropy, fused AdamW, the fused contrastive forward. usage: python tools/kernels_one.py [reps=1]"""
+backward, cross-entropy, fused AdamW, the fused contrastive forward.
+usage: python tools/kernels_one.py [reps=1]            one launch each, for the counter passes
+       python tools/kernels_one.py time out.json       HIP-event time of each (median of 3 rounds x 5 launches); VALOR_HIP_LIB selects the
+                                                       library build, so two runs A/B a kernel change on one box"""
 import ctypes
 import math
 import os
@@ -13,7 +16,10 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from valor_amd import kernels as K, lib  # noqa: E402
 from valor_amd.kernels import _ptr, _stream  # noqa: E402
 
-reps = int(sys.argv[1]) if len(sys.argv) > 1 else 1
+TIME = len(sys.argv) > 2 and sys.argv[1] == "time"
+reps = 1 if TIME else (int(sys.argv[1]) if len(sys.argv) > 1 else 1)
+NAMES = ["self_fwd_vit", "self_bwd_vit", "self_fwd_ast_drop", "self_bwd_ast_drop", "cross_fwd_caption", "cross_bwd_caption", "cross_fwd_mlm", "cross_bwd_mlm_acc",
+         "ln_fwd", "ln_bwd", "xent_fwd", "xent_bwd", "adamw", "fine_fused_fwd"]
 dev = torch.device("cuda:0")
 scale = 1.0 / math.sqrt(64)
 g = torch.Generator().manual_seed(1)
@@ -77,6 +83,24 @@ ia = torch.empty((Bc, Bc, T), dtype=torch.uint8, device=dev); ib = torch.empty((
 todo.append(lambda: lib.call("valor_fine_fused_fwd", _stream(), _ptr(fa), _ptr(fb), _ptr(mA), _ptr(mB), _ptr(wA), _ptr(wB), _ptr(sc), _ptr(a2b), _ptr(b2a),
                              _ptr(ia), _ptr(ib), Bc, Bc, T, Nv, D))
 torch.cuda.synchronize()
+if TIME:
+    import json
+    assert len(NAMES) == len(todo)
+    t = {n: [] for n in NAMES}
+    for rnd in range(3):
+        for n, f in zip(NAMES, todo):
+            f()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(5):
+                f()
+            e1.record(); torch.cuda.synchronize()
+            t[n].append(e0.elapsed_time(e1) / 5 * 1e3)
+    res = {n: round(sorted(v)[1], 1) for n, v in t.items()}
+    res["library"] = os.path.basename(lib.LIB_PATH)
+    print(res, flush=True)
+    json.dump(res, open(sys.argv[2], "w"), indent=1)
+    sys.exit(0)
 for _ in range(reps):
     for f in todo:
         f()

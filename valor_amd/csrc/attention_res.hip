@@ -37,7 +37,7 @@ DEVINL rsrc_t head_rsrc(const void* base, int64_t elem_off, int S, int64_t rs) {
 // ------------------------------------------------------------------------------------------ forward
 // grid (H, B), 256 threads. LDS: [V image][K image], SP = ceil16(S) rows each.  Wave w owns the 32-query-row
 // blocks w, w+4, ... (two 16-row MFMA tiles sharing every K / V fragment read).
-template <bool DROP>
+template <bool DROP, bool MASK>
 __global__ __launch_bounds__(256, 3) void attn_res_fwd_kernel(AttnArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -104,19 +104,28 @@ __global__ __launch_bounds__(256, 3) void attn_res_fwd_kernel(AttnArgs p) {
             }
 #pragma unroll
             for (int rt = 0; rt < 2; ++rt) {
-                const float* mrowp = (p.mask && qr[rt] < S) ? p.mask + (int64_t)b * p.mask_bs + (int64_t)qr[rt] * p.mask_rs : nullptr;
                 float mx = -INFINITY;
+                if (!MASK && !DROP && kv0 + 64 <= S) {          // a full tile without a mask (block uniform): no per-element selects
+                                                                // (not in the dropout variant: the second copy of the loop body spills there)
 #pragma unroll
-                for (int kt = 0; kt < 4; ++kt)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const int key = kv0 + kt * 16 + 4 * g + r;
-                        float s = sacc[rt][kt][r] * sl2;
-                        if (key < S) { if (mrowp) s += mrowp[key] * LOG2E_F; }
-                        else s = -INFINITY;
-                        sacc[rt][kt][r] = s;
-                        mx = fmaxf(mx, s);
+                    for (int kt = 0; kt < 4; ++kt) {
+                        sacc[rt][kt] *= sl2;
+                        mx = fmaxf(mx, fmaxf(fmaxf(sacc[rt][kt][0], sacc[rt][kt][1]), fmaxf(sacc[rt][kt][2], sacc[rt][kt][3])));
                     }
+                } else {
+                    const float* mrowp = (MASK && qr[rt] < S) ? p.mask + (int64_t)b * p.mask_bs + (int64_t)qr[rt] * p.mask_rs : nullptr;
+#pragma unroll
+                    for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const int key = kv0 + kt * 16 + 4 * g + r;
+                            float s = sacc[rt][kt][r] * sl2;
+                            if (key < S) { if (MASK && mrowp) s += mrowp[key] * LOG2E_F; }
+                            else s = -INFINITY;
+                            sacc[rt][kt][r] = s;
+                            mx = fmaxf(mx, s);
+                        }
+                }
                 mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
                 mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
                 const float mnew = fmaxf(mrow[rt], mx);
@@ -126,8 +135,9 @@ __global__ __launch_bounds__(256, 3) void attn_res_fwd_kernel(AttnArgs p) {
 #pragma unroll
                 for (int kt = 0; kt < 4; ++kt) {
                     f32x4_t pv;
+                    const f32x4_t sm = sacc[rt][kt] - mnew;
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) { pv[r] = fast_exp2(sacc[rt][kt][r] - mnew); ps += pv[r]; }
+                    for (int r = 0; r < 4; ++r) { pv[r] = fast_exp2(sm[r]); ps += pv[r]; }
                     if (DROP && kt < nkt) {
                         const uint32_t e0 = (uint32_t)qr[rt] * (uint32_t)p.Skv + (uint32_t)(kv0 + kt * 16 + 4 * g);
 #pragma unroll
@@ -174,7 +184,7 @@ __global__ __launch_bounds__(256, 3) void attn_res_fwd_kernel(AttnArgs p) {
 // grid (H, B), 512 threads (8 waves). LDS: [Q][dO][K][V] images (SP rows each) + lse (log2 domain) + delta.
 // Phase 1: wave w owns the 32-query-row block w -> dQ.   Phase 2: wave w owns the 32-key block w -> dK, dV.
 // Both phases only READ LDS, so there is no barrier between them.
-template <bool DROP>
+template <bool DROP, bool MASK>
 __global__ __launch_bounds__(512, 2) void attn_res_bwd_kernel(AttnArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -274,18 +284,14 @@ __global__ __launch_bounds__(512, 2) void attn_res_bwd_kernel(AttnArgs p) {
                     }
 #pragma unroll
                     for (int rt = 0; rt < 2; ++rt) {
-                        const bool qok = qr[rt] < S;
-                        const float* mrowp = (p.mask && qok) ? p.mask + (int64_t)b * p.mask_bs + (int64_t)qr[rt] * p.mask_rs : nullptr;
-                        const uint32_t e0 = (uint32_t)qr[rt] * (uint32_t)p.Skv + (uint32_t)(kv0 + kt * 16 + 4 * g);
+                        f32x4_t m4 = {0.f, 0.f, 0.f, 0.f}, pdrop;
+                        if (MASK && qr[rt] < S) {
+                            const float* mrowp = p.mask + (int64_t)b * p.mask_bs + (int64_t)qr[rt] * p.mask_rs;
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) {
-                            float sc = sa[rt][r] * sl2;
-                            if (mrowp) { const int key = kv0 + kt * 16 + 4 * g + r; if (key < S) sc += mrowp[key] * LOG2E_F; }
-                            const float prb = fast_exp2(sc - lse2[rt]);           // query past S: lse = +inf -> 0
-                            float dp = pa[rt][r];
-                            if (DROP) dp = attn_drop_bits(hk, e0 + r) >= thr ? dp * keep_scale : 0.f;
-                            ds[rt][k2][r] = prb * (dp - dlt[rt]);
+                            for (int r = 0; r < 4; ++r) { const int key = kv0 + kt * 16 + 4 * g + r; if (key < S) m4[r] = mrowp[key] * LOG2E_F; }
                         }
+                        const uint32_t e0 = (uint32_t)qr[rt] * (uint32_t)p.Skv + (uint32_t)(kv0 + kt * 16 + 4 * g);
+                        softmax_bwd4<DROP, false>(sa[rt], pa[rt], m4, splat4(lse2[rt]), splat4(dlt[rt]), sl2, hk, e0, 1u, thr, keep_scale, pdrop, ds[rt][k2]);
                     }
                 }
                 const bf16x8_t d0 = pack_bf16x8(ds[0][0], ds[0][1]);
@@ -354,21 +360,15 @@ __global__ __launch_bounds__(512, 2) void attn_res_bwd_kernel(AttnArgs p) {
                     }
                     if (qs >= nqs) l4 = (f32x4_t){INFINITY, INFINITY, INFINITY, INFINITY};     // sub-tile past S (block uniform): P = 0
 #pragma unroll
-                    for (int kt = 0; kt < 2; ++kt)
+                    for (int kt = 0; kt < 2; ++kt) {
+                        f32x4_t m4 = {0.f, 0.f, 0.f, 0.f};
+                        if (MASK && key[kt] < S) {
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) {
-                            const int qr = q4 + r;
-                            float sc = sa[kt][r] * sl2;
-                            if (p.mask) { if (qr < S && key[kt] < S) sc += p.mask[(int64_t)b * p.mask_bs + (int64_t)qr * p.mask_rs + key[kt]] * LOG2E_F; }
-                            const float prb = fast_exp2(sc - l4[r]);               // query past S: lse = +inf -> 0
-                            float dp = pa[kt][r], pdv = prb;
-                            if (DROP) {
-                                const bool keep = attn_drop_bits(hk, (uint32_t)qr * (uint32_t)p.Skv + (uint32_t)key[kt]) >= thr;
-                                dp = keep ? dp * keep_scale : 0.f;
-                                pdv = keep ? prb * keep_scale : 0.f;
-                            }
-                            pd[kt][q2][r] = pdv; ds[kt][q2][r] = prb * (dp - d4[r]);
+                            for (int r = 0; r < 4; ++r) if (q4 + r < S) m4[r] = p.mask[(int64_t)b * p.mask_bs + (int64_t)(q4 + r) * p.mask_rs + key[kt]] * LOG2E_F;
                         }
+                        softmax_bwd4<DROP, true>(sa[kt], pa[kt], m4, l4, d4, sl2, hk, (uint32_t)q4 * (uint32_t)p.Skv + (uint32_t)key[kt], (uint32_t)p.Skv, thr, keep_scale,
+                                                 pd[kt][q2], ds[kt][q2]);
+                    }
                 }
                 const bf16x8_t p0 = pack_bf16x8(pd[0][0], pd[0][1]);
                 const bf16x8_t p1 = pack_bf16x8(pd[1][0], pd[1][1]);
@@ -424,7 +424,7 @@ DEVINL void tr_wait4x(TrPair (&t)[4]) {
 DEVINL void launder(bf16x8_t& v) { asm volatile("" : "+v"(v)); }
 DEVINL void launder(float& v) { asm volatile("" : "+v"(v)); }
 
-template <bool DROP>
+template <bool DROP, bool MASK>
 __global__ __launch_bounds__(512, 2) void attn_res_bwd_pipe_kernel(AttnArgs p, int n_items) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -539,18 +539,14 @@ __global__ __launch_bounds__(512, 2) void attn_res_bwd_pipe_kernel(AttnArgs p, i
                         }
 #pragma unroll
                         for (int rt = 0; rt < 2; ++rt) {
-                            const bool qok = qr[rt] < S;
-                            const float* mrowp = (p.mask && qok) ? p.mask + (int64_t)b * p.mask_bs + (int64_t)qr[rt] * p.mask_rs : nullptr;
-                            const uint32_t e0 = (uint32_t)qr[rt] * (uint32_t)p.Skv + (uint32_t)(kv0 + kt * 16 + 4 * g);
+                            f32x4_t m4 = {0.f, 0.f, 0.f, 0.f}, pdrop;
+                            if (MASK && qr[rt] < S) {
+                                const float* mrowp = p.mask + (int64_t)b * p.mask_bs + (int64_t)qr[rt] * p.mask_rs;
 #pragma unroll
-                            for (int r = 0; r < 4; ++r) {
-                                float sc = sa[rt][r] * sl2;
-                                if (mrowp) { const int key = kv0 + kt * 16 + 4 * g + r; if (key < S) sc += mrowp[key] * LOG2E_F; }
-                                const float prb = fast_exp2(sc - lse2[rt]);
-                                float dp = pa[rt][r];
-                                if (DROP) dp = attn_drop_bits(hk, e0 + r) >= thr ? dp * keep_scale : 0.f;
-                                ds[rt][k2][r] = prb * (dp - dlt[rt]);
+                                for (int r = 0; r < 4; ++r) { const int key = kv0 + kt * 16 + 4 * g + r; if (key < S) m4[r] = mrowp[key] * LOG2E_F; }
                             }
+                            const uint32_t e0 = (uint32_t)qr[rt] * (uint32_t)p.Skv + (uint32_t)(kv0 + kt * 16 + 4 * g);
+                            softmax_bwd4<DROP, false>(sa[rt], pa[rt], m4, splat4(lse2[rt]), splat4(dlt[rt]), sl2, hk, e0, 1u, thr, keep_scale, pdrop, ds[rt][k2]);
                         }
                     }
                     const bf16x8_t d0 = pack_bf16x8(ds[0][0], ds[0][1]);
@@ -649,21 +645,15 @@ __global__ __launch_bounds__(512, 2) void attn_res_bwd_pipe_kernel(AttnArgs p, i
                         }
                         if (qs >= nqs) l4 = (f32x4_t){INFINITY, INFINITY, INFINITY, INFINITY};
 #pragma unroll
-                        for (int kt = 0; kt < 2; ++kt)
+                        for (int kt = 0; kt < 2; ++kt) {
+                            f32x4_t m4 = {0.f, 0.f, 0.f, 0.f};
+                            if (MASK && key[kt] < S) {
 #pragma unroll
-                            for (int r = 0; r < 4; ++r) {
-                                const int qrow = q4 + r;
-                                float sc = sa[kt][r] * sl2;
-                                if (p.mask) { if (qrow < S && key[kt] < S) sc += p.mask[(int64_t)b * p.mask_bs + (int64_t)qrow * p.mask_rs + key[kt]] * LOG2E_F; }
-                                const float prb = fast_exp2(sc - l4[r]);
-                                float dp = pa[kt][r], pdv = prb;
-                                if (DROP) {
-                                    const bool keep = attn_drop_bits(hk, (uint32_t)qrow * (uint32_t)p.Skv + (uint32_t)key[kt]) >= thr;
-                                    dp = keep ? dp * keep_scale : 0.f;
-                                    pdv = keep ? prb * keep_scale : 0.f;
-                                }
-                                pd[kt][q2][r] = pdv; ds[kt][q2][r] = prb * (dp - d4[r]);
+                                for (int r = 0; r < 4; ++r) if (q4 + r < S) m4[r] = p.mask[(int64_t)b * p.mask_bs + (int64_t)(q4 + r) * p.mask_rs + key[kt]] * LOG2E_F;
                             }
+                            softmax_bwd4<DROP, true>(sa[kt], pa[kt], m4, l4, d4, sl2, hk, (uint32_t)q4 * (uint32_t)p.Skv + (uint32_t)key[kt], (uint32_t)p.Skv, thr, keep_scale,
+                                                     pd[kt][q2], ds[kt][q2]);
+                        }
                     }
                     const bf16x8_t p0 = pack_bf16x8(pd[0][0], pd[0][1]);
                     const bf16x8_t p1 = pack_bf16x8(pd[1][0], pd[1][1]);
@@ -703,6 +693,16 @@ __global__ __launch_bounds__(512, 2) void attn_res_bwd_pipe_kernel(AttnArgs p, i
 }
 
 // ------------------------------------------------------------------------------------------ launch
+// the <DROP, MASK> instantiation a launch needs (both block uniform: dropout probability > 0, an additive mask pointer)
+#define RES_SET_LDS(K, D, M, bytes) hipFuncSetAttribute((const void*)K<D, M>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes)
+#define RES_FOR_ALL(K, WHAT, ...) do { WHAT(K, false, false, __VA_ARGS__); WHAT(K, false, true, __VA_ARGS__); WHAT(K, true, false, __VA_ARGS__); WHAT(K, true, true, __VA_ARGS__); } while (0)
+#define RES_DISPATCH(K, grid, block, lds, st, ...) do { \
+        const bool d_ = p.p_drop > 0.f, m_ = p.mask != nullptr; \
+        if (d_ && m_) hipLaunchKernelGGL((K<true, true>), grid, block, lds, st, __VA_ARGS__); \
+        else if (d_) hipLaunchKernelGGL((K<true, false>), grid, block, lds, st, __VA_ARGS__); \
+        else if (m_) hipLaunchKernelGGL((K<false, true>), grid, block, lds, st, __VA_ARGS__); \
+        else hipLaunchKernelGGL((K<false, false>), grid, block, lds, st, __VA_ARGS__); } while (0)
+
 static bool res_eligible(const AttnArgs& p) {
     if (p.kv_range || p.kv_bmod > 0 || p.Sq != p.Skv || p.Skv > 256 || p.acc_dkv) return false;
     const int64_t lim = (int64_t)1 << 31;
@@ -715,220 +715,22 @@ bool attn_res_fwd_launch(hipStream_t st, const AttnArgs& p) {
     const size_t lds = 2 * (size_t)SP * TILE_ROW_BYTES;
     static bool attr_set = false;
     if (!attr_set) {
-        hipFuncSetAttribute((const void*)attn_res_fwd_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 256 * TILE_ROW_BYTES);
-        hipFuncSetAttribute((const void*)attn_res_fwd_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 256 * TILE_ROW_BYTES);
+        RES_FOR_ALL(attn_res_fwd_kernel, RES_SET_LDS, 2 * 256 * TILE_ROW_BYTES);
         attr_set = true;
     }
-    if (p.p_drop > 0.f) hipLaunchKernelGGL(attn_res_fwd_kernel<true>, dim3(p.H, p.B), dim3(256), lds, st, p);
-    else hipLaunchKernelGGL(attn_res_fwd_kernel<false>, dim3(p.H, p.B), dim3(256), lds, st, p);
+    RES_DISPATCH(attn_res_fwd_kernel, dim3(p.H, p.B), dim3(256), lds, st, p);
     return true;
 }
 
-// ------------------------------------------------------------------------------------------ backward, single pass
-// Key-stationary SINGLE PASS: the two-phase kernels above compute the scores and dP twice (once per phase: 7 matmuls and 2 x S^2 exp2 for
-// the 5 matmuls and S^2 exp2 the algorithm needs). Here wave w owns the 32-key block w for the whole head: its K / V fragments and its
-// K^T fragments live in registers, dK / dV of its keys accumulate in registers, and it walks the 32-query blocks in a SKEWED order --
-// at step s every wave works on query block (w + s) mod NP, so no two waves touch the same query block in a step and the dQ partial
-// of (query block, key block) is added into a per-query-block fp32 accumulator in LDS WITHOUT atomics (read-modify-write by the one wave
-// that owns that block in that step; one barrier per step). dS is needed in both orientations: the (query in-lane, key across lanes)
-// tile of the S = Q.K^T MFMA feeds dK / dV directly; for dQ^T += K^T.dS^T it goes through a 1 KiB per-wave LDS scratch and comes back
-// with a transposing read (the attention_x.hip idiom).
-// Per wave 280 MFMAs instead of 392, half the exp2 / dropout-hash work, ~40 % fewer LDS fragment reads.
-// LDS: Q and dO images (SP rows each) + the dQ accumulators [NP][32][64] fp32 (the K image is staged into that region first: fragments
-// and transposed fragments of the own key block are read out before the first accumulator write) + scratch + statistics <= 150 KiB.
-template <bool DROP>
-__global__ __launch_bounds__(512, 2) void attn_res_bwd_1p_kernel(AttnArgs p) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int fr = lane & 15, g = lane >> 4;
-    const int h = blockIdx.x, b = blockIdx.y;
-    const int S = p.Skv, SP = (S + 31) & ~31;
-    const int IMG = SP * TILE_ROW_BYTES;
-    const int NP = SP >> 5;                       // 32-row blocks, <= 8: one key block per wave
-    char* sQ = smem;
-    char* sDO = smem + IMG;
-    float* sAcc = (float*)(smem + 2 * IMG);       // [NP][32][64] fp32, XOR-swizzled 16-byte chunks; first the K image
-    char* sKimg = smem + 2 * IMG;
-    char* sT = smem + 2 * IMG + NP * 8192;        // 8 x 1 KiB dS^T scratch
-    float* sLse = (float*)(sT + 8192);
-    float* sDelta = sLse + SP;
-    const int pr = wave;
-    const bool active = pr < NP;
-
-    stage_image(head_rsrc(p.q, (int64_t)b * p.q_bs + h * ATT_D, S, p.q_rs), sQ, SP, (int)p.q_rs * 2, wave, 8, lane);
-    stage_image(head_rsrc(p.dout, (int64_t)b * p.do_bs + h * ATT_D, S, p.do_rs), sDO, SP, (int)p.do_rs * 2, wave, 8, lane);
-    stage_image(head_rsrc(p.k, (int64_t)b * p.k_bs + h * ATT_D, S, p.k_rs), sKimg, SP, (int)p.k_rs * 2, wave, 8, lane);
-
-    // this wave's V fragments (its 32 keys) straight from global; delta / lse of its 32 query rows
-    bf16x8_t vf[2][2];
-    int key[2];
-    {
-        const bf16_t* Vb = (const bf16_t*)p.v + (int64_t)b * p.v_bs + h * ATT_D;
-#pragma unroll
-        for (int kt = 0; kt < 2; ++kt) {
-            key[kt] = pr * 32 + kt * 16 + fr;
-            const bool ok = active && key[kt] < S;
-#pragma unroll
-            for (int dg = 0; dg < 2; ++dg) {
-                u32x4_t zv = {0u, 0u, 0u, 0u};
-                if (ok) zv = *(const u32x4_t*)(Vb + (int64_t)key[kt] * p.v_rs + dg * 32 + g * 8);
-                vf[kt][dg] = __builtin_bit_cast(bf16x8_t, zv);
-            }
-        }
-    }
-    {
-        const bf16_t* Ob = (const bf16_t*)p.o + (int64_t)b * p.o_bs + h * ATT_D;
-        const bf16_t* DOb = (const bf16_t*)p.dout + (int64_t)b * p.do_bs + h * ATT_D;
-        const int64_t statbase = ((int64_t)b * p.H + h) * p.Sq;
-        for (int r0 = wave * 8; r0 < SP; r0 += 64) {
-            const int row = r0 + (lane >> 3), c = lane & 7;
-            float d = 0.f;
-            if (row < S) {
-                const bf16x8_t ov = __builtin_bit_cast(bf16x8_t, *(const u32x4_t*)(Ob + (int64_t)row * p.o_rs + c * 8));
-                const bf16x8_t dv = __builtin_bit_cast(bf16x8_t, *(const u32x4_t*)(DOb + (int64_t)row * p.do_rs + c * 8));
-#pragma unroll
-                for (int e = 0; e < 8; ++e) d += (float)ov[e] * (float)dv[e];
-            }
-            d += __shfl_xor(d, 1, 64); d += __shfl_xor(d, 2, 64); d += __shfl_xor(d, 4, 64);
-            if (c == 0) { sDelta[row] = d; sLse[row] = row < S ? p.lse[statbase + row] * LOG2E_F : INFINITY; }
-        }
-    }
-    const float sl2 = p.scale * LOG2E_F;
-    const uint32_t thr = drop_threshold(p.p_drop);
-    const float keep_scale = p.p_drop > 0.f ? 1.0f / (1.0f - p.p_drop) : 1.0f;
-    const uint32_t hk = attn_drop_headkey(p.seed, p.offset, b * p.H + h);
-    int troff[4];
-#pragma unroll
-    for (int dt = 0; dt < 4; ++dt) troff[dt] = tr_lane_off(lane, dt);
-
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    // own key block: K fragments (contraction over d) and K^T fragments (contraction over keys) out of the K image
-    bf16x8_t kf[2][2], ktf[4];
-#pragma unroll
-    for (int kt = 0; kt < 2; ++kt)
-#pragma unroll
-        for (int dg = 0; dg < 2; ++dg) kf[kt][dg] = read_frag<bf16_t>(sKimg, (active ? pr : 0) * 32 + kt * 16 + fr, dg * 4 + g);
-#pragma unroll
-    for (int dt = 0; dt < 4; ++dt) ktf[dt] = read_frag_tr_nat(sKimg, (active ? pr : 0) * 32, troff[dt]);
-    __syncthreads();                              // the K image is dead: its region becomes the dQ accumulators
-
-    f32x4_t dkacc[2][4], dvacc[2][4];
-#pragma unroll
-    for (int kt = 0; kt < 2; ++kt)
-#pragma unroll
-        for (int dt = 0; dt < 4; ++dt) { dkacc[kt][dt] = (f32x4_t){0.f, 0.f, 0.f, 0.f}; dvacc[kt][dt] = dkacc[kt][dt]; }
-    char* sTw = sT + wave * 1024;
-    const int tw_off = (fr * 32) + 8 * g;                               // dS write: row = key (kt*16 + fr), 4 q at 8g
-    const int tr_off = (4 * g + (fr >> 2)) * 32 + 8 * (fr & 3);         // dS^T tr-read: rows 4g + (i>>2), q cols 4(i&3)
-
-    for (int s = 0; s < NP; ++s) {
-        if (active) {
-            int qb = pr + s;
-            if (qb >= NP) qb -= NP;
-            const int qb0 = qb * 32;
-            f32x4_t pd[2][2], ds[2][2];      // [kt][q2]
-#pragma unroll
-            for (int q2 = 0; q2 < 2; ++q2) {
-                f32x4_t sa[2], pa[2];
-                sa[0] = (f32x4_t){0.f, 0.f, 0.f, 0.f}; sa[1] = sa[0]; pa[0] = sa[0]; pa[1] = sa[0];
-                const int q4 = qb0 + q2 * 16 + 4 * g;
-#pragma unroll
-                for (int dg = 0; dg < 2; ++dg) {
-                    const bf16x8_t qfr = read_frag<bf16_t>(sQ, qb0 + q2 * 16 + fr, dg * 4 + g);
-                    const bf16x8_t dfr = read_frag<bf16_t>(sDO, qb0 + q2 * 16 + fr, dg * 4 + g);
-                    sa[0] = Mma<bf16_t>::mma(qfr, kf[0][dg], sa[0]);
-                    sa[1] = Mma<bf16_t>::mma(qfr, kf[1][dg], sa[1]);
-                    pa[0] = Mma<bf16_t>::mma(dfr, vf[0][dg], pa[0]);
-                    pa[1] = Mma<bf16_t>::mma(dfr, vf[1][dg], pa[1]);
-                }
-                const f32x4_t l4 = *(const f32x4_t*)(sLse + q4), d4 = *(const f32x4_t*)(sDelta + q4);      // rows past S: lse = +inf -> P = 0
-#pragma unroll
-                for (int kt = 0; kt < 2; ++kt)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const int qrow = q4 + r;
-                        float sc = sa[kt][r] * sl2;
-                        if (p.mask) { if (qrow < S && key[kt] < S) sc += p.mask[(int64_t)b * p.mask_bs + (int64_t)qrow * p.mask_rs + key[kt]] * LOG2E_F; }
-                        const float prb = fast_exp2(sc - l4[r]);
-                        float dp = pa[kt][r], pdv = prb;
-                        if (DROP) {
-                            const bool keep = attn_drop_bits(hk, (uint32_t)qrow * (uint32_t)p.Skv + (uint32_t)key[kt]) >= thr;
-                            dp = keep ? dp * keep_scale : 0.f;
-                            pdv = keep ? prb * keep_scale : 0.f;
-                        }
-                        pd[kt][q2][r] = pdv; ds[kt][q2][r] = prb * (dp - d4[r]);
-                    }
-            }
-            const bf16x8_t p0 = pack_bf16x8(pd[0][0], pd[0][1]);
-            const bf16x8_t p1 = pack_bf16x8(pd[1][0], pd[1][1]);
-            const bf16x8_t s0 = pack_bf16x8(ds[0][0], ds[0][1]);
-            const bf16x8_t s1 = pack_bf16x8(ds[1][0], ds[1][1]);
-#pragma unroll
-            for (int dt = 0; dt < 4; ++dt) {
-                const bf16x8_t dotf = read_frag_tr_nat(sDO, qb0, troff[dt]);   // dO^T[d][q]
-                const bf16x8_t qtf = read_frag_tr_nat(sQ, qb0, troff[dt]);     // Q^T[d][q]
-                dvacc[0][dt] = Mma<bf16_t>::mma(dotf, p0, dvacc[0][dt]);
-                dvacc[1][dt] = Mma<bf16_t>::mma(dotf, p1, dvacc[1][dt]);
-                dkacc[0][dt] = Mma<bf16_t>::mma(qtf, s0, dkacc[0][dt]);
-                dkacc[1][dt] = Mma<bf16_t>::mma(qtf, s1, dkacc[1][dt]);
-            }
-            // dQ^T[d][q] (this key block's share) = K^T[d][key] . dS^T[key][q], 16 queries at a time through the transposing scratch
-#pragma unroll
-            for (int rt = 0; rt < 2; ++rt) {
-                const u32x2_t w0 = {pack2_bf16(ds[0][rt][0], ds[0][rt][1]), pack2_bf16(ds[0][rt][2], ds[0][rt][3])};
-                const u32x2_t w1 = {pack2_bf16(ds[1][rt][0], ds[1][rt][1]), pack2_bf16(ds[1][rt][2], ds[1][rt][3])};
-                *(u32x2_t*)(sTw + tw_off) = w0;
-                *(u32x2_t*)(sTw + 512 + tw_off) = w1;
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                const s16x4_t t0 = lds_read_tr4(sTw + tr_off), t1 = lds_read_tr4(sTw + 512 + tr_off);
-                const bf16x8_t dst = __builtin_bit_cast(bf16x8_t, __builtin_shufflevector(t0, t1, 0, 1, 2, 3, 4, 5, 6, 7));
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");    // the scratch is rewritten for the next 16 queries
-                float* accrow = sAcc + (qb0 + rt * 16 + fr) * 64;
-#pragma unroll
-                for (int dt = 0; dt < 4; ++dt) {
-                    f32x4_t dq = Mma<bf16_t>::mma(ktf[dt], dst, (f32x4_t){0.f, 0.f, 0.f, 0.f});
-                    float* q = accrow + (((dt * 4 + g) ^ fr) << 2);
-                    if (s > 0) dq += *(const f32x4_t*)q;      // step 0: every query block gets its first (plain) write from wave = block
-                    *(f32x4_t*)q = dq;
-                }
-            }
-        }
-        __syncthreads();        // the next step's owner of a query block adds to what this step's owner wrote
-    }
-
-    if (active) {
-#pragma unroll
-        for (int rt = 0; rt < 2; ++rt) {
-            const int qr = pr * 32 + rt * 16 + fr;
-            if (qr < S) {
-                bf16_t* DQ = (bf16_t*)p.dq + (int64_t)b * p.dq_bs + (int64_t)qr * p.dq_rs + h * ATT_D;
-                const float* accrow = sAcc + (pr * 32 + rt * 16 + fr) * 64;
-#pragma unroll
-                for (int dt = 0; dt < 4; ++dt) store4<bf16_t>(DQ + dt * 16 + 4 * g, *(const f32x4_t*)(accrow + (((dt * 4 + g) ^ fr) << 2)) * p.scale);
-            }
-        }
-#pragma unroll
-        for (int kt = 0; kt < 2; ++kt)
-            if (key[kt] < S) {
-                bf16_t* DK = (bf16_t*)p.dk + (int64_t)b * p.dk_bs + (int64_t)key[kt] * p.dk_rs + h * ATT_D;
-                bf16_t* DV = (bf16_t*)p.dv + (int64_t)b * p.dv_bs + (int64_t)key[kt] * p.dv_rs + h * ATT_D;
-#pragma unroll
-                for (int dt = 0; dt < 4; ++dt) {
-                    store4<bf16_t>(DK + dt * 16 + 4 * g, dkacc[kt][dt] * p.scale);
-                    store4<bf16_t>(DV + dt * 16 + 4 * g, dvacc[kt][dt]);
-                }
-            }
-    }
-}
-
 static int g_res_bwd_pipe = [] { const char* e = getenv("VALOR_ATTN_PIPE"); return e ? atoi(e) : 1; }();
-// 1: the persistent, phase-pipelined backward; 0: one workgroup per (batch, head), two phases; 2: the key-stationary single pass.
-// Returns the previous value.
+// 1: the persistent, phase-pipelined backward; 0: one workgroup per (batch, head), two phases. Returns the previous value.
 // (A third variant -- the dQ phase as a two-stage software pipeline, scores of key block j + 1 issued before the softmax of block j --
 //  measured SLOWER, 656 vs 633 us at the ViT shape, and two stages in the dK / dV phase spill 144-468 B per lane:
-//  profiles/r03_attn_pipe_ab_v2.json.)
+//  profiles/r03_attn_pipe_ab_v2.json. A fourth -- a key-stationary SINGLE PASS: wave w keeps the K / V / K^T fragments of key block w
+//  and dK / dV in registers, walks the query blocks in a skewed order and adds its dQ partial into a per-query-block fp32 accumulator
+//  in LDS, one barrier per step; 5 matmuls and S^2 exp2 instead of 7 and 2 S^2 -- was bit-compatible and SLOWER too: 692 vs 617 us
+//  (ViT), 795 vs 766 (ViT shape with dropout), 134 vs 137 (AST): profiles/r03_attn_pipe_ab_v3_single_pass.json. The kernel is
+//  bound by the dependent chain of a step at two waves per SIMD, not by its instruction count.)
 extern "C" int valor_attn_set_res_pipeline(int v) {
     const int o = g_res_bwd_pipe;
     if (v >= 0) g_res_bwd_pipe = v;
@@ -945,35 +747,17 @@ bool attn_res_bwd_launch(hipStream_t st, const AttnArgs& p) {
     static int n_cu = 256;
     if (!attr_set) {
         const int mx = 4 * 256 * TILE_ROW_BYTES + 2 * 256 * (int)sizeof(float);
-        hipFuncSetAttribute((const void*)attn_res_bwd_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, mx);
-        hipFuncSetAttribute((const void*)attn_res_bwd_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, mx);
-        hipFuncSetAttribute((const void*)attn_res_bwd_pipe_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, mx);
-        hipFuncSetAttribute((const void*)attn_res_bwd_pipe_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, mx);
+        RES_FOR_ALL(attn_res_bwd_kernel, RES_SET_LDS, mx);
+        RES_FOR_ALL(attn_res_bwd_pipe_kernel, RES_SET_LDS, mx);
         int dev = 0, cus = 0;
         if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus > 0) n_cu = cus;
         attr_set = true;
     }
     const int n_items = p.B * p.H;
-    if (g_res_bwd_pipe == 2) {
-        const int NP = SP >> 5;
-        const size_t lds1 = 2 * (size_t)SP * TILE_ROW_BYTES + (size_t)NP * 8192 + 8192 + 2 * (size_t)SP * sizeof(float);
-        static bool attr1 = false;
-        if (!attr1) {
-            const int mx1 = 2 * 256 * TILE_ROW_BYTES + 8 * 8192 + 8192 + 2 * 256 * (int)sizeof(float);
-            hipFuncSetAttribute((const void*)attn_res_bwd_1p_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, mx1);
-            hipFuncSetAttribute((const void*)attn_res_bwd_1p_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, mx1);
-            attr1 = true;
-        }
-        if (p.p_drop > 0.f) hipLaunchKernelGGL(attn_res_bwd_1p_kernel<true>, dim3(p.H, p.B), dim3(512), lds1, st, p);
-        else hipLaunchKernelGGL(attn_res_bwd_1p_kernel<false>, dim3(p.H, p.B), dim3(512), lds1, st, p);
-        return true;
-    }
     if (g_res_bwd_pipe && n_items >= 2 * n_cu) {        // several items per workgroup: otherwise there is nothing to pipeline
-        if (p.p_drop > 0.f) hipLaunchKernelGGL(attn_res_bwd_pipe_kernel<true>, dim3(n_cu), dim3(512), lds, st, p, n_items);
-        else hipLaunchKernelGGL(attn_res_bwd_pipe_kernel<false>, dim3(n_cu), dim3(512), lds, st, p, n_items);
+        RES_DISPATCH(attn_res_bwd_pipe_kernel, dim3(n_cu), dim3(512), lds, st, p, n_items);
         return true;
     }
-    if (p.p_drop > 0.f) hipLaunchKernelGGL(attn_res_bwd_kernel<true>, dim3(p.H, p.B), dim3(512), lds, st, p);
-    else hipLaunchKernelGGL(attn_res_bwd_kernel<false>, dim3(p.H, p.B), dim3(512), lds, st, p);
+    RES_DISPATCH(attn_res_bwd_kernel, dim3(p.H, p.B), dim3(512), lds, st, p);
     return true;
 }

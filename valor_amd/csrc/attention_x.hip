@@ -120,15 +120,23 @@ __global__ __launch_bounds__(256, 2) void attn_x_fwd_kernel(AttnArgs p) {
                     for (int dg = 0; dg < 2; ++dg) sacc[kt] = Mma<bf16_t>::mma(kf[kt][dg], qf[u][dg], sacc[kt]);
                 }
                 float mx = -INFINITY;
+                if (ka >= rs0 && ka + 32 <= rs1) {        // the wave's 32 keys all inside the group's range (uniform): no per-element selects
 #pragma unroll
-                for (int kt = 0; kt < 2; ++kt)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const int key = ka + kt * 16 + 4 * g + r;
-                        const float s = (key >= rs0 && key < rs1) ? sacc[kt][r] * sl2 : -INFINITY;
-                        sacc[kt][r] = s;
-                        mx = fmaxf(mx, s);
+                    for (int kt = 0; kt < 2; ++kt) {
+                        sacc[kt] *= sl2;
+                        mx = fmaxf(mx, fmaxf(fmaxf(sacc[kt][0], sacc[kt][1]), fmaxf(sacc[kt][2], sacc[kt][3])));
                     }
+                } else {
+#pragma unroll
+                    for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const int key = ka + kt * 16 + 4 * g + r;
+                            const float s = (key >= rs0 && key < rs1) ? sacc[kt][r] * sl2 : -INFINITY;
+                            sacc[kt][r] = s;
+                            mx = fmaxf(mx, s);
+                        }
+                }
                 mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
                 mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
                 const float mnew = fmaxf(mrow[u], mx);
@@ -139,10 +147,11 @@ __global__ __launch_bounds__(256, 2) void attn_x_fwd_kernel(AttnArgs p) {
                 const uint32_t hk = attn_drop_headkey(p.seed, p.offset, sb_[u] * p.H + h);
                 const uint32_t rowbase = (uint32_t)qr * (uint32_t)p.Skv;
 #pragma unroll
-                for (int kt = 0; kt < 2; ++kt)
+                for (int kt = 0; kt < 2; ++kt) {
+                    const f32x4_t sm = sacc[kt] - mnew;
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        float pv = x_exp2(sacc[kt][r] - mnew);
+                        float pv = x_exp2(sm[r]);
                         ps += pv;
                         if (DROP) {
                             const int kloc = ka + kt * 16 + 4 * g + r - rs0;
@@ -150,6 +159,7 @@ __global__ __launch_bounds__(256, 2) void attn_x_fwd_kernel(AttnArgs p) {
                         }
                         sacc[kt][r] = pv;
                     }
+                }
                 lrow[u] = lrow[u] * alpha + ps;
                 const bf16x8_t pf = pack_bf16x8(sacc[0], sacc[1]);
 #pragma unroll
@@ -349,21 +359,10 @@ __global__ __launch_bounds__(256, 2) void attn_x_bwd_kernel(AttnArgs p) {
 #pragma unroll
                     for (int kt = 0; kt < 2; ++kt) {
                         const int key = ka + kt * 16 + fr;
-                        const float kout = (key >= ss0_[u] && key < ss1_[u]) ? 0.f : INFINITY;     // key outside the group's range: P = 0
-                        f32x4_t pdv, dsv;
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) {
-                            const float prb = x_exp2(sacc[kt][r] * sl2 - l4[r] - kout);             // query rows past Sq: lse = +inf
-                            float dp = pacc[kt][r];
-                            float pd = prb;
-                            if (DROP) {
-                                const bool keep = attn_drop_bits(hk, (row0 + r) * (uint32_t)p.Skv + (uint32_t)(key - ss0_[u])) >= thr;
-                                dp = keep ? dp * keep_scale : 0.f;
-                                pd = keep ? prb * keep_scale : 0.f;
-                            }
-                            pdv[r] = pd;
-                            dsv[r] = prb * (dp - d4[r]);
-                        }
+                        const float kin = (key >= ss0_[u] && key < ss1_[u]) ? 0.f : -INFINITY;     // key outside the group's range: P = 0
+                        f32x4_t pdv, dsv;                                                        // query rows past Sq: lse = +inf
+                        softmax_bwd4<DROP, true>(sacc[kt], pacc[kt], splat4(kin), l4, d4, sl2, hk, row0 * (uint32_t)p.Skv + (uint32_t)(key - ss0_[u]),
+                                                 (uint32_t)p.Skv, thr, keep_scale, pdv, dsv);
                         pdp[uu][kt] = (u32x2_t){pack2_bf16(pdv[0], pdv[1]), pack2_bf16(pdv[2], pdv[3])};
                         dsp[uu][kt] = (u32x2_t){pack2_bf16(dsv[0], dsv[1]), pack2_bf16(dsv[2], dsv[3])};
                     }

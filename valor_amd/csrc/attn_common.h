@@ -65,6 +65,32 @@ DEVINL uint32_t attn_drop_bits(uint32_t hk, uint32_t local) {
     return x;
 }
 
+// dS (and, for the dK / dV phase, the dropped probabilities) of four score elements of the backward: straight-line VECTOR code (packed fp32
+// multiply-adds), the additive-mask values -- if the launch has a mask at all -- arrive pre-gathered in `m4` (log2 domain). The mask
+// test used to sit inside the per-element loop as a runtime branch: 32 exec-mask save / branch / restore sequences per tile step in
+// the kernels that have no mask (every self-attention of the ViT / AST towers), which also kept the scheduler from overlapping the
+// softmax arithmetic with the next MFMAs.
+template <bool DROP, bool WANT_P>
+DEVINL void softmax_bwd4(const f32x4_t sa, const f32x4_t pa, const f32x4_t m4, const f32x4_t l4, const f32x4_t d4, float sl2, uint32_t hk,
+                         uint32_t e0, uint32_t estride, uint32_t thr, float keep_scale, f32x4_t& pd, f32x4_t& ds) {
+    const f32x4_t sc = sa * sl2 + (m4 - l4);
+    f32x4_t prb;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) prb[r] = __builtin_amdgcn_exp2f(sc[r]);   // query past S: lse = +inf -> 0
+    f32x4_t dp = pa;
+    pd = prb;
+    if (DROP) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const bool keep = attn_drop_bits(hk, e0 + (uint32_t)r * estride) >= thr;
+            dp[r] = keep ? dp[r] * keep_scale : 0.f;
+            if (WANT_P) pd[r] = keep ? prb[r] * keep_scale : 0.f;
+        }
+    }
+    ds = prb * (dp - d4);
+}
+DEVINL f32x4_t splat4(float x) { return (f32x4_t){x, x, x, x}; }
+
 // LDS-resident fast paths (attention_res.hip). Return true if the shape was handled.
 bool attn_res_fwd_launch(hipStream_t st, const AttnArgs& p);
 bool attn_res_bwd_launch(hipStream_t st, const AttnArgs& p);
