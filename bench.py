@@ -410,7 +410,7 @@ def main():
                                       f"{args.frames} frames x 224^2, {args.audio_slices} x 5.12 s audio, 32 tokens",
                           "per_gpu_batch": args.batch, "global_batch": world * args.batch, "parallelism": f"dp{world}",
                           "dropout": args.dropout, "task": TASK},
-               "losses": {k: round(float(v), 4) for k, v in last.items()},
+               "losses": {k: round(float(v.detach()) if torch.is_tensor(v) else float(v), 4) for k, v in last.items()},
                "peak_mem_gb": round(torch.cuda.max_memory_allocated() / 2 ** 30, 1),
                "reserved_mem_gb": round(torch.cuda.memory_reserved() / 2 ** 30, 1),
                "timed_region": {"device_allocations": int(seg1 - seg0), "host_ms_per_step": [round(x, 1) for x in step_ms]},

@@ -252,12 +252,12 @@ int valor_group_mean_bwd(void* stream, int dtype, const void* dout, void* din, i
 /* [cls ; patches (+bias)] + pos: clip.py:264-265 ; modeling.py:755-760 */
 int valor_assemble_tokens_fwd(void* stream, int dtype, const void* patches, const void* cls, const void* pos,
                               const void* bias, void* out, int N, int Pn, int E);
-int valor_assemble_tokens_bwd(void* stream, int dtype, const void* dout, void* dpatches, void* dpos, int N, int Pn, int E);
-int valor_sum_over_batch(void* stream, int dtype, const void* x, void* dsum, int N, int Tn, int E);
+int valor_assemble_tokens_bwd(void* stream, int dtype, const void* dout, void* dpatches, void* dpos, void* dcls, int N, int Pn, int E, int accumulate);
+int valor_sum_over_batch(void* stream, int dtype, const void* x, void* dsum, int N, int Tn, int E, int accumulate);
 /* word + position + type embeddings: bert.py:211-215 ; clip.py:377-379 */
 int valor_embed_fwd(void* stream, int dtype, const int64_t* ids, const void* word, const void* pos, const void* typevec,
                     void* out, int64_t n, int L, int E);
-int valor_embed_bwd_word(void* stream, int dtype, const int64_t* ids, const void* dout, void* dword, int64_t n, int E);
+int valor_embed_bwd_word(void* stream, int dtype, const int64_t* ids, const void* dout, void* dword, int64_t n, int E, int accumulate);
 /* decoder inputs: + frame embedding + type embedding, written into the concatenated [video|audio] buffer: modeling.py:485-502 */
 int valor_add_frame_type_fwd(void* stream, int dtype, const void* in, const void* frame_emb, const void* type_emb, void* out,
                              int Bn, int F, int X, int E, int64_t out_bs, int64_t out_row_off);

@@ -110,15 +110,28 @@ __global__ void assemble_bwd_patches_kernel(const T* dout, T* dpatches, int N, i
     }
 }
 // dsum[t][e] = sum_n x[n][t][e]   (x: [N, Tn, E]); one thread per 4 columns of one t
+// acc: dsum += (the destination is a gradient-arena slot); drow0 (optional): row 0 of the sum goes there too (the class token's gradient)
 template <typename T>
-__global__ void sum_over_batch_kernel(const T* x, T* dsum, int N, int Tn, int E) {
+__global__ void sum_over_batch_kernel(const T* x, T* dsum, T* drow0, int N, int Tn, int E, int acc) {
     const int E4 = E / 4;
     const int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (q >= (int64_t)Tn * E4) return;
     const int e = (int)(q % E4) * 4, t = (int)(q / E4);
-    f32x4_t s = {0.f, 0.f, 0.f, 0.f};
-    for (int n = 0; n < N; ++n) s += load4<T>(x + ((int64_t)n * Tn + t) * E + e);
-    store4<T>(dsum + (int64_t)t * E + e, s);
+    // one thread walks the whole batch: eight independent loads in flight (a dependent chain of N = 512 loads took 218 us at the ViT shape)
+    f32x4_t s = {0.f, 0.f, 0.f, 0.f}, s1 = s, s2 = s, s3 = s;
+    const T* xp = x + (int64_t)t * E + e;
+    const int64_t bs = (int64_t)Tn * E;
+    int n = 0;
+    for (; n + 8 <= N; n += 8) {
+        const f32x4_t a0 = load4<T>(xp + (n + 0) * bs), a1 = load4<T>(xp + (n + 1) * bs), a2 = load4<T>(xp + (n + 2) * bs), a3 = load4<T>(xp + (n + 3) * bs);
+        const f32x4_t a4 = load4<T>(xp + (n + 4) * bs), a5 = load4<T>(xp + (n + 5) * bs), a6 = load4<T>(xp + (n + 6) * bs), a7 = load4<T>(xp + (n + 7) * bs);
+        s += a0; s1 += a1; s2 += a2; s3 += a3; s += a4; s1 += a5; s2 += a6; s3 += a7;
+    }
+    for (; n < N; ++n) s += load4<T>(xp + n * bs);
+    s = (s + s1) + (s2 + s3);
+    T* d = dsum + (int64_t)t * E + e;
+    store4<T>(d, acc ? s + load4<T>(d) : s);
+    if (drow0 && t == 0) store4<T>(drow0 + e, acc ? s + load4<T>(drow0 + e) : s);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -140,7 +153,7 @@ __global__ void embed_fwd_kernel(const int64_t* ids, const T* word, const T* pos
     }
 }
 template <typename T>
-__global__ __launch_bounds__(256) void embed_bwd_word_kernel(const int64_t* ids, const T* dout, T* dword, int64_t n, int E) {
+__global__ __launch_bounds__(256) void embed_bwd_word_kernel(const int64_t* ids, const T* dout, T* dword, int64_t n, int E, int acc) {
     // one workgroup per token position i: if i is the FIRST occurrence of its id, sum dout over every occurrence in
     // position order (deterministic) and write the row. Occurrences are found cooperatively, 2048 positions at a time:
     // LDS bitmap -> ordered position list (prefix popcounts) -> every thread sums its 4 columns over the list with
@@ -198,7 +211,10 @@ __global__ __launch_bounds__(256) void embed_bwd_word_kernel(const int64_t* ids,
             }
             __syncthreads();
         }
-        if (eok) store4<T>(dword + id * E + e0 + e, s);
+        if (eok) {            // one workgroup per id writes the row: accumulation into an existing gradient row needs no atomics either
+            T* d = dword + id * E + e0 + e;
+            store4<T>(d, acc ? s + load4<T>(d) : s);
+        }
     }
 }
 
@@ -405,31 +421,31 @@ extern "C" int valor_assemble_tokens_fwd(void* stream, int dtype, const void* pa
         hipLaunchKernelGGL((assemble_fwd_kernel<float>), dim3(grid_for(work)), dim3(256), 0, st, (const float*)patches, (const float*)cls, (const float*)pos, (const float*)bias, (float*)out, N, Pn, E));
     return valor_launch_status();
 }
-// dpatches [N*Pn, E] ; dpos [Pn+1, E] (sum over n; dcls = dpos[0])
-extern "C" int valor_assemble_tokens_bwd(void* stream, int dtype, const void* dout, void* dpatches, void* dpos, int N, int Pn, int E) {
+// dpatches [N*Pn, E] ; dpos [Pn+1, E] = sum over n ; dcls [E] (optional) = row 0 of that sum. accumulate: dpos / dcls += (gradient-arena slots)
+extern "C" int valor_assemble_tokens_bwd(void* stream, int dtype, const void* dout, void* dpatches, void* dpos, void* dcls, int N, int Pn, int E,
+                                         int accumulate) {
     if (N <= 0) return VALOR_OK;
     if (E & 3) return VALOR_ERR_ARG;
     hipStream_t st = (hipStream_t)stream;
     const int64_t work = (int64_t)N * Pn * E / 4, work2 = (int64_t)(Pn + 1) * E / 4;
     DISPATCH_T(dtype,
         { hipLaunchKernelGGL((assemble_bwd_patches_kernel<bf16_t>), dim3(grid_for(work)), dim3(256), 0, st, (const bf16_t*)dout, (bf16_t*)dpatches, N, Pn, E);
-          hipLaunchKernelGGL((sum_over_batch_kernel<bf16_t>), dim3(grid_for(work2, 256, 1 << 20)), dim3(256), 0, st, (const bf16_t*)dout, (bf16_t*)dpos, N, Pn + 1, E); },
+          hipLaunchKernelGGL((sum_over_batch_kernel<bf16_t>), dim3(grid_for(work2, 256, 1 << 20)), dim3(256), 0, st, (const bf16_t*)dout, (bf16_t*)dpos, (bf16_t*)dcls, N, Pn + 1, E, accumulate); },
         { hipLaunchKernelGGL((assemble_bwd_patches_kernel<float>), dim3(grid_for(work)), dim3(256), 0, st, (const float*)dout, (float*)dpatches, N, Pn, E);
-          hipLaunchKernelGGL((sum_over_batch_kernel<float>), dim3(grid_for(work2, 256, 1 << 20)), dim3(256), 0, st, (const float*)dout, (float*)dpos, N, Pn + 1, E); });
+          hipLaunchKernelGGL((sum_over_batch_kernel<float>), dim3(grid_for(work2, 256, 1 << 20)), dim3(256), 0, st, (const float*)dout, (float*)dpos, (float*)dcls, N, Pn + 1, E, accumulate); });
     return valor_launch_status();
 }
-// dsum[Tn, E] = sum over n of x[N, Tn, E]
-extern "C" int valor_sum_over_batch(void* stream, int dtype, const void* x, void* dsum, int N, int Tn, int E) {
+// dsum[Tn, E] (+)= sum over n of x[N, Tn, E]
+extern "C" int valor_sum_over_batch(void* stream, int dtype, const void* x, void* dsum, int N, int Tn, int E, int accumulate) {
     if (Tn <= 0) return VALOR_OK;
     if (E & 3) return VALOR_ERR_ARG;
     hipStream_t st = (hipStream_t)stream;
     const int64_t work = (int64_t)Tn * E / 4;
     DISPATCH_T(dtype,
-        hipLaunchKernelGGL((sum_over_batch_kernel<bf16_t>), dim3(grid_for(work, 256, 1 << 20)), dim3(256), 0, st, (const bf16_t*)x, (bf16_t*)dsum, N, Tn, E),
-        hipLaunchKernelGGL((sum_over_batch_kernel<float>), dim3(grid_for(work, 256, 1 << 20)), dim3(256), 0, st, (const float*)x, (float*)dsum, N, Tn, E));
+        hipLaunchKernelGGL((sum_over_batch_kernel<bf16_t>), dim3(grid_for(work, 256, 1 << 20)), dim3(256), 0, st, (const bf16_t*)x, (bf16_t*)dsum, (bf16_t*)nullptr, N, Tn, E, accumulate),
+        hipLaunchKernelGGL((sum_over_batch_kernel<float>), dim3(grid_for(work, 256, 1 << 20)), dim3(256), 0, st, (const float*)x, (float*)dsum, (float*)nullptr, N, Tn, E, accumulate));
     return valor_launch_status();
 }
-
 extern "C" int valor_embed_fwd(void* stream, int dtype, const int64_t* ids, const void* word, const void* pos,
                                const void* typevec, void* out, int64_t n, int L, int E) {
     if (n <= 0) return VALOR_OK;
@@ -441,14 +457,14 @@ extern "C" int valor_embed_fwd(void* stream, int dtype, const int64_t* ids, cons
         hipLaunchKernelGGL((embed_fwd_kernel<float>), dim3(grid_for(work)), dim3(256), 0, st, ids, (const float*)word, (const float*)pos, (const float*)typevec, (float*)out, n, L, E));
     return valor_launch_status();
 }
-// dword [V, E] must be zero-initialised by the caller; rows of occurring ids are written.
-extern "C" int valor_embed_bwd_word(void* stream, int dtype, const int64_t* ids, const void* dout, void* dword, int64_t n, int E) {
+// rows of occurring ids are written (dword [V, E] zero-initialised by the caller) or, with accumulate, added to
+extern "C" int valor_embed_bwd_word(void* stream, int dtype, const int64_t* ids, const void* dout, void* dword, int64_t n, int E, int accumulate) {
     if (n <= 0) return VALOR_OK;
     if (E & 3) return VALOR_ERR_ARG;
     hipStream_t st = (hipStream_t)stream;
     DISPATCH_T(dtype,
-        hipLaunchKernelGGL((embed_bwd_word_kernel<bf16_t>), dim3((unsigned)n), dim3(256), 0, st, ids, (const bf16_t*)dout, (bf16_t*)dword, n, E),
-        hipLaunchKernelGGL((embed_bwd_word_kernel<float>), dim3((unsigned)n), dim3(256), 0, st, ids, (const float*)dout, (float*)dword, n, E));
+        hipLaunchKernelGGL((embed_bwd_word_kernel<bf16_t>), dim3((unsigned)n), dim3(256), 0, st, ids, (const bf16_t*)dout, (bf16_t*)dword, n, E, accumulate),
+        hipLaunchKernelGGL((embed_bwd_word_kernel<float>), dim3((unsigned)n), dim3(256), 0, st, ids, (const float*)dout, (float*)dword, n, E, accumulate));
     return valor_launch_status();
 }
 

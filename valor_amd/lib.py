@@ -69,10 +69,10 @@ SIGNATURES = {
     "valor_grad_norm_clip": [_vp, _i, _vp, _vp, _i64, _f, _f, _vp, _vp, _vp],
     "valor_patchify": [_vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _i64],
     "valor_assemble_tokens_fwd": [_vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i],
-    "valor_assemble_tokens_bwd": [_vp, _i, _vp, _vp, _vp, _i, _i, _i],
-    "valor_sum_over_batch": [_vp, _i, _vp, _vp, _i, _i, _i],
+    "valor_assemble_tokens_bwd": [_vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i],
+    "valor_sum_over_batch": [_vp, _i, _vp, _vp, _i, _i, _i, _i],
     "valor_embed_fwd": [_vp, _i, _vp, _vp, _vp, _vp, _vp, _i64, _i, _i],
-    "valor_embed_bwd_word": [_vp, _i, _vp, _vp, _vp, _i64, _i],
+    "valor_embed_bwd_word": [_vp, _i, _vp, _vp, _vp, _i64, _i, _i],
     "valor_add_frame_type_fwd": [_vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i64, _i64],
     "valor_add_frame_type_bwd": [_vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i64, _i64],
     "valor_l2norm_fwd": [_vp, _i, _vp, _vp, _vp, _i64, _i],

@@ -447,7 +447,7 @@ class VALOR(nn.Module):
         vid = self._dev(video_pixels.float().contiguous())
         C = sp.swin_embed
         e = "video_encoder.patch_embed."
-        tok = ops.linear(ops.patchify3d(vid, 4, self.dtype), P[e + "proj.weight"].view(C, -1), P[e + "proj.bias"])
+        tok = ops.linear(ops.patchify3d(vid, 4, self.dtype), ops.param_view(P[e + "proj.weight"], C, -1), P[e + "proj.bias"])
         D, H, W = F, h // 4, w // 4
         x = ops.layer_norm(tok, P[e + "norm.weight"], P[e + "norm.bias"], 1e-5)                 # patch_norm; pos_drop p = 0
         total = sum(sp.swin_depths)
@@ -513,7 +513,7 @@ class VALOR(nn.Module):
         P, sp = self.P, self.spec
         b, n, c, h, w = video_pixels.shape
         imgs = self._dev(video_pixels.reshape(b * n, c, h, w).float())
-        wconv = P["clip_model.visual.conv1.weight"].view(sp.vis_width, -1)
+        wconv = ops.param_view(P["clip_model.visual.conv1.weight"], sp.vis_width, -1)
         vec = 8 if self.dtype == torch.bfloat16 else 4
         kp = (wconv.shape[1] + vec - 1) // vec * vec
         # ViT-L/14: 3 * 14 * 14 = 588 contraction elements per patch; the GEMM stages 16-byte chunks, so operand rows are
@@ -546,7 +546,7 @@ class VALOR(nn.Module):
         b, n, hh, ww = audio.shape
         spec_in = self._dev(audio.reshape(b * n, 1, hh, ww).float())
         patches = ops.patchify(spec_in, sp.aud_patch, self.dtype)
-        tok = ops.linear(patches, P["audio_embeddings.first_conv.weight"].view(sp.aud_width, -1), None)
+        tok = ops.linear(patches, ops.param_view(P["audio_embeddings.first_conv.weight"], sp.aud_width, -1), None)
         Pn = sp.aud_tokens - 1
         x = ops.assemble_tokens(tok, P["audio_embeddings.cls_token"], P["audio_embeddings.position_embeddings.weight"],
                                 P["audio_embeddings.first_conv.bias"], b * n, Pn)

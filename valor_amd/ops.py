@@ -71,9 +71,21 @@ class GradSlot:
 
 
 def _sink(p):
-    if not GradSink.enabled or p is None or getattr(p, "_arena_name", None) is None or p.grad is None or not p.requires_grad:
+    if not GradSink.enabled or p is None or getattr(p, "_arena_name", None) is None or not p.requires_grad:
         return None
-    return p.grad
+    view = getattr(p, "_sink_view", None)        # a reshaped view of a parameter (param_view): the same reshape of its gradient
+    return view if view is not None else p.grad
+
+
+def param_view(p, *shape):
+    """A reshaped view of an arena parameter (the conv kernels used as GEMM weights: [W, 3, p, p] -> [W, 3 p p]) that still accumulates
+    its gradient straight into the arena: without this the wgrad GEMM returns a temporary, autograd reshapes it back and AccumulateGrad
+    adds it -- on the stream the parameter's node was created on, which for the side-stream encoders is not the producing stream."""
+    v = p.view(*shape)
+    if GradSink.enabled and getattr(p, "_arena_name", None) is not None and p.grad is not None and p.requires_grad:
+        v._arena_name = p._arena_name
+        v._sink_view = p.grad.view(*shape)
+    return v
 
 
 def _sunk(p):
@@ -686,7 +698,9 @@ def fine_contrastive(featA, featB, wA_raw, wB_raw, maskA, maskB, k):
 
 # ------------------------------------------------------------------------------------------------
 class EmbedFn(Function):
-    """out[i] = word[ids[i]] + pos[i % L] + typevec   (bert.py:211-215, clip.py:377-379)"""
+    """out[i] = word[ids[i]] + pos[i % L] + typevec   (bert.py:211-215, clip.py:377-379)
+    Backward: the tables' gradients go straight into their arena slots (deterministic row sums added to the rows that occur, the
+    position sums to the first L rows) -- returned to autograd they cost a zero-filled [vocab, E] temporary and a whole-table add per call."""
 
     @staticmethod
     def forward(ctx, ids, word, pos, typevec, L):
@@ -695,21 +709,37 @@ class EmbedFn(Function):
         lib.call("valor_embed_fwd", _st(), _dt(word), _p(ids), _p(word), _p(pos), _p(typevec), _p(out), n, L, E)
         ctx.save_for_backward(ids)
         ctx.cfg = (word.shape, pos.shape if pos is not None else None, typevec is not None, L)
+        ctx.params = (word, pos, typevec)
         return out.view(*ids.shape, E)
 
     @staticmethod
     def backward(ctx, dout):
         (ids,) = ctx.saved_tensors
         wshape, pshape, has_type, L = ctx.cfg
+        pw, pp, pt = ctx.params
         d2 = _2d(dout.contiguous())
         n, E = d2.shape
-        dword = torch.zeros(wshape, dtype=d2.dtype, device=d2.device)
-        lib.call("valor_embed_bwd_word", _st(), _dt(d2), _p(ids), _p(d2), _p(dword), n, E)
-        dpos = None
-        if pshape is not None:
-            dpos = torch.zeros(pshape, dtype=d2.dtype, device=d2.device)
-            lib.call("valor_sum_over_batch", _st(), _dt(d2), _p(d2), _p(dpos), n // L, L, E)
-        dtype_vec = K.colsum(d2) if has_type else None
+        dword = dpos = dtype_vec = None
+        if ctx.needs_input_grad[1]:
+            sw = _sink(pw)
+            if sw is not None:
+                lib.call("valor_embed_bwd_word", _st(), _dt(d2), _p(ids), _p(d2), _p(sw), n, E, 1); _sunk(pw)
+            else:
+                dword = torch.zeros(wshape, dtype=d2.dtype, device=d2.device)
+                lib.call("valor_embed_bwd_word", _st(), _dt(d2), _p(ids), _p(d2), _p(dword), n, E, 0)
+        if pshape is not None and ctx.needs_input_grad[2]:
+            sp = _sink(pp)
+            if sp is not None:
+                lib.call("valor_sum_over_batch", _st(), _dt(d2), _p(d2), _p(sp), n // L, L, E, 1); _sunk(pp)
+            else:
+                dpos = torch.zeros(pshape, dtype=d2.dtype, device=d2.device)
+                lib.call("valor_sum_over_batch", _st(), _dt(d2), _p(d2), _p(dpos), n // L, L, E, 0)
+        if has_type and ctx.needs_input_grad[3]:
+            st_ = _sink(pt)
+            if st_ is not None:
+                K.colsum(d2, out=st_.view(-1), accumulate=True); _sunk(pt)
+            else:
+                dtype_vec = K.colsum(d2)
         return None, dword, dpos, dtype_vec, None
 
 
@@ -718,7 +748,8 @@ def embed(ids, word, pos, typevec, L):
 
 
 class AssembleFn(Function):
-    """tokens = [cls ; patches (+bias)] + pos   (clip.py:264-265 ; modeling.py:755-760)"""
+    """tokens = [cls ; patches (+bias)] + pos   (clip.py:264-265 ; modeling.py:755-760). The gradients of cls / pos / bias are added
+    straight into their arena slots."""
 
     @staticmethod
     def forward(ctx, patches, cls, pos, bias, N, Pn):
@@ -726,17 +757,31 @@ class AssembleFn(Function):
         out = torch.empty((N, Pn + 1, E), dtype=patches.dtype, device=patches.device)
         lib.call("valor_assemble_tokens_fwd", _st(), _dt(patches), _p(patches), _p(cls), _p(pos), _p(bias), _p(out), N, Pn, E)
         ctx.cfg = (N, Pn, E, bias is not None, cls.shape, pos.shape)
+        ctx.params = (cls, pos, bias)
         return out
 
     @staticmethod
     def backward(ctx, dout):
         N, Pn, E, has_bias, cshape, pshape = ctx.cfg
+        pc, pp, pb = ctx.params
         dout = dout.contiguous()
         dpatch = torch.empty((N * Pn, E), dtype=dout.dtype, device=dout.device)
-        dpos = torch.empty((Pn + 1, E), dtype=dout.dtype, device=dout.device)
-        lib.call("valor_assemble_tokens_bwd", _st(), _dt(dout), _p(dout), _p(dpatch), _p(dpos), N, Pn, E)
-        dbias = K.colsum(dpatch) if has_bias else None
-        return dpatch, dpos[0].clone().view(cshape), dpos.view(pshape), dbias, None, None
+        sc, sp = _sink(pc), _sink(pp)
+        dcls = dposr = dbias = None
+        if sc is not None and sp is not None and ctx.needs_input_grad[1] and ctx.needs_input_grad[2]:
+            lib.call("valor_assemble_tokens_bwd", _st(), _dt(dout), _p(dout), _p(dpatch), _p(sp), _p(sc), N, Pn, E, 1)
+            _sunk(pc); _sunk(pp)
+        else:
+            dpos = torch.empty((Pn + 1, E), dtype=dout.dtype, device=dout.device)
+            lib.call("valor_assemble_tokens_bwd", _st(), _dt(dout), _p(dout), _p(dpatch), _p(dpos), None, N, Pn, E, 0)
+            dcls, dposr = dpos[0].clone().view(cshape), dpos.view(pshape)
+        if has_bias and ctx.needs_input_grad[3]:
+            sb = _sink(pb)
+            if sb is not None:
+                K.colsum(dpatch, out=sb, accumulate=True); _sunk(pb)
+            else:
+                dbias = K.colsum(dpatch)
+        return dpatch, dcls, dposr, dbias, None, None
 
 
 def assemble_tokens(patches, cls, pos, bias, N, Pn):
