@@ -328,6 +328,7 @@ def main():
         engine.train_step(batch, TASK)
     sync()
     seg0 = torch.cuda.memory_stats().get("segment.all.allocated", 0)       # device allocations (hipMalloc) so far
+    segs_before = {sg["address"] for sg in torch.cuda.memory_snapshot()}
     t0 = time.perf_counter()
     last = None
     step_ms = []
@@ -338,6 +339,7 @@ def main():
     sync()
     elapsed = time.perf_counter() - t0
     seg1 = torch.cuda.memory_stats().get("segment.all.allocated", 0)
+    new_segs_mb = sorted(round(sg["total_size"] / 2 ** 20, 1) for sg in torch.cuda.memory_snapshot() if sg["address"] not in segs_before)
     # roofline pass: the SAME step, run right after the timed region, with a HIP-event pair (recorded on the launch
     # stream) around every 4th valor_gemm launch; 4 instrumented steps with a rotating offset cover every launch once.
     timer.enabled = True
@@ -413,7 +415,7 @@ def main():
                "losses": {k: round(float(v.detach()) if torch.is_tensor(v) else float(v), 4) for k, v in last.items()},
                "peak_mem_gb": round(torch.cuda.max_memory_allocated() / 2 ** 30, 1),
                "reserved_mem_gb": round(torch.cuda.memory_reserved() / 2 ** 30, 1),
-               "timed_region": {"device_allocations": int(seg1 - seg0), "host_ms_per_step": [round(x, 1) for x in step_ms]},
+               "timed_region": {"device_allocations": int(seg1 - seg0), "new_segments_mb": new_segs_mb, "host_ms_per_step": [round(x, 1) for x in step_ms]},
                "roofline": roof}
         if world == 1 and args.sim_world > 1:
             try:

@@ -86,17 +86,17 @@ torch.cuda.synchronize()
 if TIME:
     import json
     assert len(NAMES) == len(todo)
-    t = {n: [] for n in NAMES}
+    t = {name: [] for name in NAMES}
     for rnd in range(3):
-        for n, f in zip(NAMES, todo):
+        for name, f in zip(NAMES, todo):          # (the launch lambdas read the module-level n, V, ...: no loop variable may shadow them)
             f()
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
             for _ in range(5):
                 f()
             e1.record(); torch.cuda.synchronize()
-            t[n].append(e0.elapsed_time(e1) / 5 * 1e3)
-    res = {n: round(sorted(v)[1], 1) for n, v in t.items()}
+            t[name].append(e0.elapsed_time(e1) / 5 * 1e3)
+    res = {name: round(sorted(v)[1], 1) for name, v in t.items()}
     res["library"] = os.path.basename(lib.LIB_PATH)
     print(res, flush=True)
     json.dump(res, open(sys.argv[2], "w"), indent=1)

@@ -359,10 +359,23 @@ __global__ __launch_bounds__(256, 2) void attn_x_bwd_kernel(AttnArgs p) {
 #pragma unroll
                     for (int kt = 0; kt < 2; ++kt) {
                         const int key = ka + kt * 16 + fr;
-                        const float kin = (key >= ss0_[u] && key < ss1_[u]) ? 0.f : -INFINITY;     // key outside the group's range: P = 0
-                        f32x4_t pdv, dsv;                                                        // query rows past Sq: lse = +inf
-                        softmax_bwd4<DROP, true>(sacc[kt], pacc[kt], splat4(kin), l4, d4, sl2, hk, row0 * (uint32_t)p.Skv + (uint32_t)(key - ss0_[u]),
-                                                 (uint32_t)p.Skv, thr, keep_scale, pdv, dsv);
+                        const float kout = (key >= ss0_[u] && key < ss1_[u]) ? 0.f : INFINITY;     // key outside the group's range: P = 0
+                        f32x4_t pdv, dsv;
+                        // (written through softmax_bwd4 -- the vector form that helped the LDS-resident backward -- the six-sub-tile kernel
+                        //  got SLOWER: 337 -> 416 us at the caption shape with the same 216 B of scratch; profiles/r03_attn_kernels_ab_s11.json)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const float prb = x_exp2(sacc[kt][r] * sl2 - l4[r] - kout);             // query rows past Sq: lse = +inf
+                            float dp = pacc[kt][r];
+                            float pd = prb;
+                            if (DROP) {
+                                const bool keep = attn_drop_bits(hk, (row0 + r) * (uint32_t)p.Skv + (uint32_t)(key - ss0_[u])) >= thr;
+                                dp = keep ? dp * keep_scale : 0.f;
+                                pd = keep ? prb * keep_scale : 0.f;
+                            }
+                            pdv[r] = pd;
+                            dsv[r] = prb * (dp - d4[r]);
+                        }
                         pdp[uu][kt] = (u32x2_t){pack2_bf16(pdv[0], pdv[1]), pack2_bf16(pdv[2], pdv[3])};
                         dsp[uu][kt] = (u32x2_t){pack2_bf16(dsv[0], dsv[1]), pack2_bf16(dsv[2], dsv[3])};
                     }

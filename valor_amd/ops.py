@@ -490,6 +490,15 @@ def seg_cross_attention(q2d, kv, n_heads, segs, p_drop=0.0, dkv_buf=None):
     return SegCrossAttnFn.apply(q2d, kv, n_heads, segs, p_drop, dkv_buf)
 
 
+def _rows_with_slack(n, cols, dtype, device):
+    """[n, cols] rows of a buffer allocated for ~12 % more rows (rounded to 512): the number of masked rows -- hence the size of the
+    [rows, vocabulary] logits, 100+ MB -- changes from step to step, and every new maximum is a device allocation (a synchronising
+    hipMalloc in the middle of a step: bench.py counted 4-5 per 10 steps) until the caching allocator has seen the largest draw.
+    With the slack the first steps' blocks already fit every later draw."""
+    rows = (n + n // 8 + 511) // 512 * 512
+    return torch.empty((rows, cols), dtype=dtype, device=device)[:n]
+
+
 class DecoderXentSegFn(Function):
     """per-segment mean CE over ONE tied-decoder GEMM: rows of segment i are h[sum(n[:i]) : sum(n[:i+1])]; returns one
     loss per segment (caption / mlm passes share the prediction head, modeling.py:245-254, pretrain.py:444,498)."""
@@ -498,7 +507,7 @@ class DecoderXentSegFn(Function):
     def forward(ctx, h, w_emb, dec_bias, labels, seg_rows):
         n, V = h.shape[0], w_emb.shape[0]
         Vpad = (V + 31) // 32 * 32
-        buf = torch.empty((n, Vpad), dtype=h.dtype, device=h.device)
+        buf = _rows_with_slack(n, Vpad, h.dtype, h.device)
         K.gemm(h, w_emb, bias=dec_bias, out=buf[:, :V])
         loss_rows = torch.empty(n, dtype=torch.float32, device=h.device)
         lse = torch.empty(n, dtype=torch.float32, device=h.device)
@@ -552,7 +561,7 @@ class DecoderXentFn(Function):
     def forward(ctx, h, w_emb, dec_bias, labels, want_logits):
         n, V = h.shape[0], w_emb.shape[0]
         Vpad = (V + 31) // 32 * 32
-        buf = torch.empty((n, Vpad), dtype=h.dtype, device=h.device)
+        buf = _rows_with_slack(n, Vpad, h.dtype, h.device)
         logits = buf[:, :V]
         K.gemm(h, w_emb, bias=dec_bias, out=logits)
         loss_rows = torch.empty(n, dtype=torch.float32, device=h.device)
