@@ -330,3 +330,30 @@ def test_bench_refuses_a_rank_count_that_is_not_gpus():
     env = dict(os.environ, WORLD_SIZE="3", RANK="0", LOCAL_RANK="0")
     r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2"], env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode != 0 and "WORLD_SIZE=3" in (r.stderr + r.stdout)
+
+
+def test_param_view_carries_the_gradient_slot_and_logits_rows_have_slack():
+    """ops.param_view: a reshaped view of an arena parameter (the conv kernels used as GEMM weights, clip.py:236 / modeling.py:752)
+    keeps the parameter's arena name and aliases the SAME reshape of its gradient slot, so the wgrad GEMM accumulates in place; a
+    tensor that is not an arena parameter passes through as a plain view. ops._rows_with_slack: the [rows, vocabulary] logits of the
+    masked rows are a view of a buffer with >= 12 % spare rows (the row count changes per step)."""
+    from valor_amd import ops
+    p = torch.nn.Parameter(torch.arange(24, dtype=torch.float32).view(2, 3, 2, 2))
+    p._arena_name = "conv.weight"
+    p.grad = torch.zeros_like(p)
+    v = ops.param_view(p, 2, -1)
+    assert v.shape == (2, 12) and v._arena_name == "conv.weight"
+    assert v._sink_view.shape == (2, 12) and v._sink_view.data_ptr() == p.grad.data_ptr()
+    assert ops._sink(v) is v._sink_view and ops._sink(p) is p.grad
+    v._sink_view[1, 11] = 7.0
+    assert float(p.grad[1, 2, 1, 1]) == 7.0
+    q = torch.nn.Parameter(torch.zeros(4, 6))          # no arena name / no gradient slot: an ordinary view, gradients through autograd
+    w = ops.param_view(q, 2, 12)
+    assert getattr(w, "_sink_view", None) is None and ops._sink(w) is None
+    sizes = []
+    for n in (1, 290, 2100, 1153, 4096, 300):
+        b = ops._rows_with_slack(n, 64, torch.bfloat16, "cpu")
+        assert b.shape == (n, 64) and b.is_contiguous()
+        assert b.untyped_storage().nbytes() >= int(n * 1.12) * 64 * 2 and b.untyped_storage().nbytes() % (512 * 64 * 2) == 0
+        sizes.append(b.untyped_storage().nbytes())
+    assert sizes == sorted(sizes) and sizes[2] == sizes[3] and sizes[4] == sizes[5]      # monotone: a smaller draw re-requests the largest size

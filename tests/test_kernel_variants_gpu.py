@@ -282,11 +282,14 @@ def test_attention_dropout_same_mask_in_every_family(dev, attn_variant):
     assert torch.equal(keeps[0], keeps[1])
 
 
-@pytest.mark.parametrize("cols,rows,p,scaled", [(768, 1001, 0.0, False), (768, 514, 0.1, False), (1024, 333, 0.1, True), (512, 77, 0.0, False), (256, 9, 0.25, True)])
+@pytest.mark.parametrize("cols,rows,p,scaled", [(768, 1001, 0.0, False), (768, 514, 0.1, False), (1024, 333, 0.1, True), (512, 77, 0.0, False), (256, 9, 0.25, True),
+                                                (128, 4099, 0.0, False), (128, 61, 0.2, True), (192, 1003, 0.1, True), (384, 258, 0.0, False)])
 def test_layernorm_families_agree(dev, cols, rows, p, scaled):
-    """fused bias + dropout + residual + LayerNorm: one-wave-per-row kernels (variant 0) vs half-a-wave-per-row kernels with 16-byte
-    accesses (variant 2 = forward AND backward): bit-identical z (same Philox windows, same adds), y / statistics / dx / dres and the
-    column sums dgamma / dbeta / dbias equal up to the reduction order; odd row counts leave a half wave without a row."""
+    """fused bias + dropout + residual + LayerNorm: one-wave-per-row kernels (variant 0) vs the kernels with 16-byte accesses and
+    several rows per wave -- half a wave per row at 256 / 512 / 768 / 1024 columns, a quarter at 128 / 384, an eighth at 192 (the
+    VideoSwin stage-1 widths, videoswin.py:191-245) -- (variant 2 = forward AND backward): bit-identical z (same Philox windows, same adds),
+    y / statistics / dx / dres and the column sums dgamma / dbeta / dbias equal up to the reduction order; odd row counts leave lane
+    groups without a row."""
     from valor_amd import kernels as K, lib
     so = lib.load()
     old = so.valor_ln_set_variant(-1)

@@ -255,9 +255,13 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(LnBwdArgs p) {
 // flight per wave). Same arithmetic and the same Philox windows as ln_fwd_kernel / ln_bwd_kernel (4 elements per counter), so the
 // two families can be mixed between forward and backward.
 // ---------------------------------------------------------------------------------------------
-DEVINL float half_sum(float v) {      // over the 32 lanes that share (lane >> 5)
+// GL lanes per row (32: half a wave, 256 * NV8 columns; 16 / 8: the narrow VideoSwin stage-1 widths 128 / 384 and 192 -- on the
+// one-wave-per-row kernel a 128-column row is 256 B per wave and iteration, and the 802 816-row LayerNorms of VideoSwin-B's first stage ran
+// at 0.5 TB/s: 818 us forward, 566 us backward; `profiles/r03_swin_b64_kernel_stats_v1.md`)
+template <int GL>
+DEVINL float group_sum(float v) {      // over the GL lanes that share (lane / GL)
 #pragma unroll
-    for (int o = 16; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    for (int o = GL / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
     return v;
 }
 DEVINL void unpack8(u32x4_t r, float (&f)[8]) {
@@ -268,10 +272,11 @@ DEVINL u32x4_t pack8(const float (&f)[8]) {
     return (u32x4_t){pack2_bf16(f[0], f[1]), pack2_bf16(f[2], f[3]), pack2_bf16(f[4], f[5]), pack2_bf16(f[6], f[7])};
 }
 
-template <int NV8>
+template <int NV8, int GL = 32>
 __global__ __launch_bounds__(256) void ln_fwd_h_kernel(LnArgs p) {
     typedef bf16_t T;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, half = lane >> 5, hl = lane & 31;
+    constexpr int RPW = 64 / GL;          // rows per wave and iteration
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, half = lane / GL, hl = lane % GL;
     const T* X = (const T*)p.x; const T* Bi = (const T*)p.bias; const T* R = (const T*)p.residual;
     const T* G = (const T*)p.gamma; const T* Be = (const T*)p.beta;
     T* Z = (T*)p.z; T* Y = (T*)p.y;
@@ -279,7 +284,7 @@ __global__ __launch_bounds__(256) void ln_fwd_h_kernel(LnArgs p) {
     const uint32_t thr = drop_threshold(p.p_drop);
     const float keep_scale = p.p_drop > 0.f ? 1.0f / (1.0f - p.p_drop) : 1.0f;
     const float inv_n = 1.0f / (float)cols;
-    for (int64_t row0 = ((int64_t)blockIdx.x * 4 + wave) * 2; row0 < p.rows; row0 += (int64_t)gridDim.x * 8) {
+    for (int64_t row0 = ((int64_t)blockIdx.x * 4 + wave) * RPW; row0 < p.rows; row0 += (int64_t)gridDim.x * 4 * RPW) {
         const int64_t row = row0 + half;
         const bool ok = row < p.rows;
         const int64_t base = row * cols;
@@ -288,7 +293,7 @@ __global__ __launch_bounds__(256) void ln_fwd_h_kernel(LnArgs p) {
         const float rsc = (p.row_scale && ok) ? p.row_scale[row / p.rows_per_scale] : 1.0f;
 #pragma unroll
         for (int i = 0; i < NV8; ++i) {
-            const int c = (i * 32 + hl) * 8;
+            const int c = (i * GL + hl) * 8;
             float t[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
             if (ok) {
                 unpack8((p.nt & 1) ? __builtin_nontemporal_load((const u32x4_t*)(X + base + c)) : *(const u32x4_t*)(X + base + c), t);
@@ -326,13 +331,13 @@ __global__ __launch_bounds__(256) void ln_fwd_h_kernel(LnArgs p) {
             for (int k = 0; k < 8; ++k) v[i][k] = t[k];
         }
         if (!Y) continue;
-        const float mu = half_sum(s) * inv_n;
+        const float mu = group_sum<GL>(s) * inv_n;
         float q = 0.f;
 #pragma unroll
         for (int i = 0; i < NV8; ++i)
 #pragma unroll
             for (int k = 0; k < 8; ++k) { const float d = v[i][k] - mu; q += d * d; }
-        const float rs = rsqrtf(half_sum(q) * inv_n + p.eps);
+        const float rs = rsqrtf(group_sum<GL>(q) * inv_n + p.eps);
         if (!ok) continue;
         if (hl == 0) {
             if (p.mean) p.mean[row] = mu;
@@ -340,7 +345,7 @@ __global__ __launch_bounds__(256) void ln_fwd_h_kernel(LnArgs p) {
         }
 #pragma unroll
         for (int i = 0; i < NV8; ++i) {
-            const int c = (i * 32 + hl) * 8;
+            const int c = (i * GL + hl) * 8;
             float o[8];
 #pragma unroll
             for (int k = 0; k < 8; ++k) o[k] = (v[i][k] - mu) * rs;
@@ -359,11 +364,12 @@ __global__ __launch_bounds__(256) void ln_fwd_h_kernel(LnArgs p) {
     }
 }
 
-template <int NV8>
+template <int NV8, int GL = 32>
 __global__ __launch_bounds__(256) void ln_bwd_h_kernel(LnBwdArgs p) {
     typedef bf16_t T;
-    __shared__ float red[3][8][32 * 8];   // [which][wave * 2 + half][hl * 8 + k], reused per vector i
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, half = lane >> 5, hl = lane & 31;
+    constexpr int RPW = 64 / GL;
+    __shared__ float red[3][4 * RPW][GL * 8];   // [which][wave * RPW + half][hl * 8 + k], reused per vector i
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, half = lane / GL, hl = lane % GL;
     const T* DY = (const T*)p.dy; const T* DZI = (const T*)p.dz_in; const T* Z = (const T*)p.z;
     const T* G = (const T*)p.gamma;
     T* DX = (T*)p.dx; T* DR = (T*)p.dres;
@@ -378,9 +384,9 @@ __global__ __launch_bounds__(256) void ln_bwd_h_kernel(LnBwdArgs p) {
     for (int i = 0; i < NV8; ++i) {
 #pragma unroll
         for (int k = 0; k < 8; ++k) { gsum[i][k] = 0.f; bsum[i][k] = 0.f; xsum[i][k] = 0.f; gam[i][k] = 1.f; }
-        if (G) unpack8(*(const u32x4_t*)(G + (i * 32 + hl) * 8), gam[i]);
+        if (G) unpack8(*(const u32x4_t*)(G + (i * GL + hl) * 8), gam[i]);
     }
-    for (int64_t row0 = ((int64_t)blockIdx.x * 4 + wave) * 2; row0 < p.rows; row0 += (int64_t)gridDim.x * 8) {
+    for (int64_t row0 = ((int64_t)blockIdx.x * 4 + wave) * RPW; row0 < p.rows; row0 += (int64_t)gridDim.x * 4 * RPW) {
         const int64_t row = row0 + half;
         const bool ok = row < p.rows;
         const int64_t base = row * cols;
@@ -392,7 +398,7 @@ __global__ __launch_bounds__(256) void ln_bwd_h_kernel(LnBwdArgs p) {
             float s1 = 0.f, s2 = 0.f;
 #pragma unroll
             for (int i = 0; i < NV8; ++i) {
-                const int c = (i * 32 + hl) * 8;
+                const int c = (i * GL + hl) * 8;
                 float zz[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, d[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
                 if (ok) { unpack8(*(const u32x4_t*)(Z + base + c), zz); unpack8(*(const u32x4_t*)(DY + base + c), d); }
 #pragma unroll
@@ -405,8 +411,8 @@ __global__ __launch_bounds__(256) void ln_bwd_h_kernel(LnBwdArgs p) {
                     s2 += gy[i][k] * xh[i][k];
                 }
             }
-            s1 = half_sum(s1) * inv_n;
-            s2 = half_sum(s2) * inv_n;
+            s1 = group_sum<GL>(s1) * inv_n;
+            s2 = group_sum<GL>(s2) * inv_n;
 #pragma unroll
             for (int i = 0; i < NV8; ++i)
 #pragma unroll
@@ -420,7 +426,7 @@ __global__ __launch_bounds__(256) void ln_bwd_h_kernel(LnBwdArgs p) {
         if (!ok) continue;
 #pragma unroll
         for (int i = 0; i < NV8; ++i) {
-            const int c = (i * 32 + hl) * 8;
+            const int c = (i * GL + hl) * 8;
             float dz[8];
 #pragma unroll
             for (int k = 0; k < 8; ++k) dz[k] = dzv[i][k];
@@ -450,25 +456,27 @@ __global__ __launch_bounds__(256) void ln_bwd_h_kernel(LnBwdArgs p) {
             for (int k = 0; k < 8; ++k) xsum[i][k] += dx[k];
         }
     }
-    // cross-wave reduction of the column partials, one vector slot (256 columns) at a time: 8 half-waves own the same columns
+    // cross-wave reduction of the column partials, one vector slot (GL * 8 columns) at a time: 4 * RPW lane groups own the same columns
 #pragma unroll
     for (int i = 0; i < NV8; ++i) {
         __syncthreads();
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
-            red[0][wave * 2 + half][hl * 8 + k] = gsum[i][k];
-            red[1][wave * 2 + half][hl * 8 + k] = bsum[i][k];
-            red[2][wave * 2 + half][hl * 8 + k] = xsum[i][k];
+            red[0][wave * RPW + half][hl * 8 + k] = gsum[i][k];
+            red[1][wave * RPW + half][hl * 8 + k] = bsum[i][k];
+            red[2][wave * RPW + half][hl * 8 + k] = xsum[i][k];
         }
         __syncthreads();
-        const int c = i * 256 + threadIdx.x;          // slot column threadIdx.x == (hl * 8 + k)
-        const int64_t o = (int64_t)blockIdx.x * cols + c;
-        float a0 = 0.f, a1 = 0.f, a2 = 0.f;
+        if ((int)threadIdx.x < GL * 8) {
+            const int c = i * GL * 8 + threadIdx.x;          // slot column threadIdx.x == (hl * 8 + k)
+            const int64_t o = (int64_t)blockIdx.x * cols + c;
+            float a0 = 0.f, a1 = 0.f, a2 = 0.f;
 #pragma unroll
-        for (int w = 0; w < 8; ++w) { a0 += red[0][w][threadIdx.x]; a1 += red[1][w][threadIdx.x]; a2 += red[2][w][threadIdx.x]; }
-        if (p.part_dgamma) p.part_dgamma[o] = a0;
-        if (p.part_dbeta) p.part_dbeta[o] = a1;
-        if (p.part_dbias) p.part_dbias[o] = a2;
+            for (int w = 0; w < 4 * RPW; ++w) { a0 += red[0][w][threadIdx.x]; a1 += red[1][w][threadIdx.x]; a2 += red[2][w][threadIdx.x]; }
+            if (p.part_dgamma) p.part_dgamma[o] = a0;
+            if (p.part_dbeta) p.part_dbeta[o] = a1;
+            if (p.part_dbias) p.part_dbias[o] = a2;
+        }
     }
 }
 
@@ -746,18 +754,32 @@ extern "C" int valor_ln_set_variant(int v) { const int o = g_ln_variant; if (v >
 // non-temporal accesses of the streaming LayerNorm kernels (bit mask, see LnArgs::nt / LnBwdArgs::nt); returns the previous value, v < 0 queries
 static int g_ln_nt = [] { const char* e = getenv("VALOR_LN_NT"); return e ? atoi(e) : 0; }();
 extern "C" int valor_ln_set_nt(int v) { const int o = g_ln_nt; if (v >= 0) g_ln_nt = v; return o; }
+// lanes per row of the 16-byte-access kernels for this width (0: not covered): 256 / 512 / 768 / 1024 on half a wave, the VideoSwin stage-1
+// widths 128 / 384 on a quarter, 192 on an eighth
+static int ln_group(int cols) {
+    if ((cols & 255) == 0 && cols <= 1024) return 32;
+    if (cols == 128 || cols == 384) return 16;
+    if (cols == 192) return 8;
+    return 0;
+}
 static bool ln_half_ok(int dt, int cols, const void* a, const void* b, const void* c, const void* d, const void* e) {
     auto al = [](const void* q) { return ((uintptr_t)q & 15) == 0; };
-    return g_ln_variant && dt == VALOR_DT_BF16 && (cols & 255) == 0 && cols <= 1024 && al(a) && al(b) && al(c) && al(d) && al(e);
+    return g_ln_variant && dt == VALOR_DT_BF16 && ln_group(cols) != 0 && al(a) && al(b) && al(c) && al(d) && al(e);
 }
 
 template <typename T>
 static int launch_ln_fwd(hipStream_t st, const LnArgs& p) {
     const int nv = (p.cols + 255) / 256;
     if (ln_half_ok(ElemTraits<T>::DT, p.cols, p.x, p.bias, p.residual, p.z, p.y) && (((uintptr_t)p.gamma | (uintptr_t)p.beta) & 15) == 0) {
-        int64_t blocks = (p.rows + 7) / 8;
+        const int gl = ln_group(p.cols), rpb = 4 * (64 / gl);          // rows per workgroup and iteration
+        int64_t blocks = (p.rows + rpb - 1) / rpb;
         if (blocks > 8192) blocks = 8192;
-        switch (nv) {
+        if (gl == 16) {
+            if (p.cols == 128) hipLaunchKernelGGL((ln_fwd_h_kernel<1, 16>), dim3((unsigned)blocks), dim3(256), 0, st, p);
+            else hipLaunchKernelGGL((ln_fwd_h_kernel<3, 16>), dim3((unsigned)blocks), dim3(256), 0, st, p);
+        } else if (gl == 8) {
+            hipLaunchKernelGGL((ln_fwd_h_kernel<3, 8>), dim3((unsigned)blocks), dim3(256), 0, st, p);
+        } else switch (nv) {
             case 1: hipLaunchKernelGGL((ln_fwd_h_kernel<1>), dim3((unsigned)blocks), dim3(256), 0, st, p); break;
             case 2: hipLaunchKernelGGL((ln_fwd_h_kernel<2>), dim3((unsigned)blocks), dim3(256), 0, st, p); break;
             case 3: hipLaunchKernelGGL((ln_fwd_h_kernel<3>), dim3((unsigned)blocks), dim3(256), 0, st, p); break;
@@ -790,8 +812,15 @@ static int launch_ln_bwd(hipStream_t st, const LnBwdArgs& p) {
     const int nv = (p.cols + 255) / 256;
     // measured (profiles/r02_ln_ab.json): the half-wave backward needs 194+ VGPRs (2 waves per SIMD) and LOSES at 768 columns
     // (171 vs 143 us) but wins at 1024 (261 vs 339 us); variant 2 forces it everywhere (tests / A-B runs)
-    if ((g_ln_variant >= 2 || p.cols == 1024) && ln_half_ok(ElemTraits<T>::DT, p.cols, p.dy, p.dz_in, p.z, p.dx, p.dres) && ((uintptr_t)p.gamma & 15) == 0) {
-        switch (nv) {
+    // 128 columns: a quarter wave per row (48 accumulator registers) against 256 B per wave and iteration on the one-wave-per-row kernel
+    if ((g_ln_variant >= 2 || p.cols == 1024 || p.cols == 128) && ln_half_ok(ElemTraits<T>::DT, p.cols, p.dy, p.dz_in, p.z, p.dx, p.dres) && ((uintptr_t)p.gamma & 15) == 0) {
+        const int gl = ln_group(p.cols);
+        if (gl == 16) {
+            if (p.cols == 128) hipLaunchKernelGGL((ln_bwd_h_kernel<1, 16>), dim3(LN_PART_BLOCKS), dim3(256), 0, st, p);
+            else hipLaunchKernelGGL((ln_bwd_h_kernel<3, 16>), dim3(LN_PART_BLOCKS), dim3(256), 0, st, p);
+        } else if (gl == 8) {
+            hipLaunchKernelGGL((ln_bwd_h_kernel<3, 8>), dim3(LN_PART_BLOCKS), dim3(256), 0, st, p);
+        } else switch (nv) {
             case 1: hipLaunchKernelGGL((ln_bwd_h_kernel<1>), dim3(LN_PART_BLOCKS), dim3(256), 0, st, p); break;
             case 2: hipLaunchKernelGGL((ln_bwd_h_kernel<2>), dim3(LN_PART_BLOCKS), dim3(256), 0, st, p); break;
             case 3: hipLaunchKernelGGL((ln_bwd_h_kernel<3>), dim3(LN_PART_BLOCKS), dim3(256), 0, st, p); break;

@@ -490,12 +490,18 @@ def seg_cross_attention(q2d, kv, n_heads, segs, p_drop=0.0, dkv_buf=None):
     return SegCrossAttnFn.apply(q2d, kv, n_heads, segs, p_drop, dkv_buf)
 
 
+_ROWS_HWM = {}
+
+
 def _rows_with_slack(n, cols, dtype, device):
-    """[n, cols] rows of a buffer allocated for ~12 % more rows (rounded to 512): the number of masked rows -- hence the size of the
-    [rows, vocabulary] logits, 100+ MB -- changes from step to step, and every new maximum is a device allocation (a synchronising
-    hipMalloc in the middle of a step: bench.py counted 4-5 per 10 steps) until the caching allocator has seen the largest draw.
-    With the slack the first steps' blocks already fit every later draw."""
-    rows = (n + n // 8 + 511) // 512 * 512
+    """[n, cols] rows of a buffer allocated for the LARGEST row count seen so far plus ~12 % (rounded to 512 rows): the number of masked
+    rows -- hence the size of the [rows, vocabulary] logits, 100+ MB -- changes from step to step. Sized exactly, every new maximum is a
+    device allocation (a synchronising hipMalloc in the middle of a step), and a smaller request splits whatever large cached block
+    is free -- bench.py saw 172 MB logits segments AND a 592 MB activation segment appear inside its timed region. With a monotone
+    request size the caching allocator hands the same block back every step."""
+    key = (cols, dtype, str(device))
+    rows = max(_ROWS_HWM.get(key, 0), (n + n // 8 + 511) // 512 * 512)
+    _ROWS_HWM[key] = rows
     return torch.empty((rows, cols), dtype=dtype, device=device)[:n]
 
 
