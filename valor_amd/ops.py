@@ -496,9 +496,10 @@ _ROWS_HWM = {}
 def _rows_with_slack(n, cols, dtype, device):
     """[n, cols] rows of a buffer allocated for the LARGEST row count seen so far plus ~12 % (rounded to 512 rows): the number of masked
     rows -- hence the size of the [rows, vocabulary] logits, 100+ MB -- changes from step to step. Sized exactly, every new maximum is a
-    device allocation (a synchronising hipMalloc in the middle of a step), and a smaller request splits whatever large cached block
-    is free -- bench.py saw 172 MB logits segments AND a 592 MB activation segment appear inside its timed region. With a monotone
-    request size the caching allocator hands the same block back every step."""
+    device allocation in the middle of a step and a smaller request splits whatever large cached block is free; with a monotone
+    request size the caching allocator hands the same block back every step. (The device allocations bench.py still counts inside its
+    timed region are not these: `timed_region.new_segments_mb` shows two [117 376, 768] and one [100 864, 3072] bf16 tensors -- blocks
+    held by their cross-stream use records while the host runs two steps ahead of the GPU right after the warm-up sync.)"""
     key = (cols, dtype, str(device))
     rows = max(_ROWS_HWM.get(key, 0), (n + n // 8 + 511) // 512 * 512)
     _ROWS_HWM[key] = rows
