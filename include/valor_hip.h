@@ -92,6 +92,7 @@ int valor_gemm_set_fast_epilogue(int v);
  *   key 5: bf16 output stores of the 8-phase kernels: 0 plain, 1 non-temporal, 1000 (default) = non-temporal for K <= 1024
  *          (+5.5 .. +10 % on the K = 768 forward shapes, -0.6 .. -1.8 % at K = 3072)
  *   key 6: 1 = the 128x128 kernels store big outputs of short-K problems non-temporally too (default 0)
+ *   key 7: smallest K of a forward (NN) problem that may use the 8-phase kernels (default 128, env VALOR_GEMM_NN_MINK)
  *   key 7: unused */
 int valor_gemm_set_policy(int key, int value);
 

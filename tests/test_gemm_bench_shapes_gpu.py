@@ -175,3 +175,17 @@ def test_wgrad_splitk_with_bf16_partials(dev):
     assert float((d32 - ref).norm() / ref.norm()) < 2e-5            # fp32 output: fp32 partials
     sref = a.float().t() @ b_.float()
     assert float((small.float() - sref).norm() / sref.norm()) < 1.5 * TOL
+
+
+@pytest.mark.parametrize("N,K", [(512, 128), (384, 128), (1024, 256), (768, 256)])
+def test_forward_short_contraction_of_the_videoswin_stages(dev, N, K):
+    """VideoSwin stage-1 / 2 forward GEMMs (fc1, qkv; videoswin.py:137-163, 191-245): K = 128 / 256 over 200 704 token rows run on the
+    8-phase kernels (policy key 7) -- two / four K-tiles per output tile, a half-empty last tile column at N = 384."""
+    from valor_amd import kernels as Kn, lib
+    so = lib.load()
+    M = 200704
+    assert _family(so, 0, 0, M, N, K) == 3
+    A, B, bias = _mk((M, K), 31, dev), _mk((N, K), 32, dev, 0.05), _mk((N,), 33, dev)
+    C = Kn.gemm(A, B, bias=bias)
+    whole, worst = _tile_errors(C, A.float() @ B.float().t() + bias.float())
+    assert whole < TOL and worst < TILE_TOL, (whole, worst)

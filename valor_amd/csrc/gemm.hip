@@ -472,6 +472,8 @@ extern "C" int valor_gemm_set_variant(int v) { const int o = g_gemm_variant; if 
 //     model in launch_gemm_8ph), else a fixed number of tile columns per group
 // [5] non-temporal bf16 output stores of the 8-phase kernels: 0 never, 1 always, 1000 = short-K problems (K <= 1024)
 // [6] 1 = the 128x128 kernels store big outputs of short-K problems non-temporally as well
+// [7] forward (NN) min K for the 8-phase kernel: 128 -- the VideoSwin stage-1 / 2 forward GEMMs (K = 128 / 256, 200 704+ rows) stream at
+//     3.0-3.2 TB/s there against 1.4-1.9 on the 128x128 kernels (profiles/r03_gemm_smallk.json; in-step 356.6 -> 359.6 samples/s); it was 512
 int g_gemm_policy[8] = {[] { const char* e = getenv("VALOR_GEMM_NT_MINK"); return e ? atoi(e) : 768; }(),
                         [] { const char* e = getenv("VALOR_GEMM_SPLITK_BF16"); return e ? atoi(e) : 1; }(),
                         [] { const char* e = getenv("VALOR_GEMM_MIN_TILES"); return e ? atoi(e) : 256; }(),
@@ -479,7 +481,7 @@ int g_gemm_policy[8] = {[] { const char* e = getenv("VALOR_GEMM_NT_MINK"); retur
                         [] { const char* e = getenv("VALOR_GEMM_RASTER"); return e ? atoi(e) : 1000; }(),
                         [] { const char* e = getenv("VALOR_GEMM_STORE"); return e ? atoi(e) : 1000; }(),
                         [] { const char* e = getenv("VALOR_GEMM_NTA"); return e ? atoi(e) : 0; }(),
-                        0};
+                        [] { const char* e = getenv("VALOR_GEMM_NN_MINK"); return e ? atoi(e) : 128; }()};
 extern "C" int valor_gemm_set_policy(int key, int value) {
     if (key < 0 || key > 7) return VALOR_ERR_ARG;
     const int old = g_gemm_policy[key];
@@ -497,7 +499,7 @@ static bool use_8ph(int dtype, int transA, int transB, int M, int N, int K, bool
     if (g_gemm_variant == 3) return true;
     const int64_t tiles256 = (int64_t)((M + 255) / 256) * ((N + 255) / 256);
     if (transA && transB) return K >= 4096;                           // wgrad: K = tokens, split-K fills one round
-    if (!transA && !transB) return tiles256 >= g_gemm_policy[2] && K >= 512;      // forward: at least one full round of 256 workgroups (in-step sweep, session K: 1024 / 512 / 256 / 128 tiles -> 133.5 / 134.2 / 132.0 / 138.1 ms)
+    if (!transA && !transB) return tiles256 >= g_gemm_policy[2] && K >= g_gemm_policy[7];      // forward: at least one full round of 256 workgroups (in-step sweep, session K: 1024 / 512 / 256 / 128 tiles -> 133.5 / 134.2 / 132.0 / 138.1 ms)
     if (!transA && transB) return tiles256 >= g_gemm_policy[3] && K >= (heavy_epi ? 1536 : g_gemm_policy[0]);      // dgrad
     return false;
 }
