@@ -516,7 +516,8 @@ __global__ __launch_bounds__(512) void win_bwd_dq_dma_kernel(WinArgs p) {
         f32x4_t dqacc[2] = {(f32x4_t){0.f, 0.f, 0.f, 0.f}, (f32x4_t){0.f, 0.f, 0.f, 0.f}};
 #pragma unroll
         for (int c = 0; c < WIN_MAXCH; ++c) {
-            const int k0 = c * 64;
+            int k0 = c * 64;
+            asm volatile("" : "+s"(k0));        // opaque per chunk: derived LDS offsets are not hoisted for all seven chunks at once (SGPR spills)
             if (c == 3 || (c == 0 && npad <= 192)) {                // the next window's K / V start flying under the rest of this one
                 if (has_next && (c == 3) == (npad > 192)) {
                     issue(gw + 1, cur ^ 1);
@@ -546,12 +547,17 @@ __global__ __launch_bounds__(512) void win_bwd_dq_dma_kernel(WinArgs p) {
                         const int X = relq - rk[r];
                         float v = sacc[kt][r] * scale2 + tb[SHIFT ? (X & 0xffff) : X];
                         if (SHIFT) v = (uint32_t)X > 0xffffu ? v - WIN_MASK2 : v;
-                        float ds = fexp2<T>(v - lse2) * (dpacc[kt][r] - dl);
-                        ds = kb + r < N ? ds : 0.f;
-                        sacc[kt][r] = ds;
-                        bacc[c][kt][r] += ds;
+                        sacc[kt][r] = fexp2<T>(v - lse2) * (dpacc[kt][r] - dl);
                     }
                 }
+                if (k0 + 64 > N) {                               // the chunk that holds the window's last slot (block uniform): slots past N carry no dS
+#pragma unroll
+                    for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) sacc[kt][r] = k0 + kt * 16 + 4 * g + r < N ? sacc[kt][r] : 0.f;
+                }
+#pragma unroll
+                for (int kt = 0; kt < 4; ++kt) bacc[c][kt] += sacc[kt];
                 tr_wait4(ktr);
 #pragma unroll
                 for (int kk = 0; kk < 2; ++kk) {
