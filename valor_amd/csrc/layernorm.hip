@@ -812,8 +812,9 @@ static int launch_ln_bwd(hipStream_t st, const LnBwdArgs& p) {
     const int nv = (p.cols + 255) / 256;
     // measured (profiles/r02_ln_ab.json): the half-wave backward needs 194+ VGPRs (2 waves per SIMD) and LOSES at 768 columns
     // (171 vs 143 us) but wins at 1024 (261 vs 339 us); variant 2 forces it everywhere (tests / A-B runs)
-    // 128 columns: a quarter wave per row (48 accumulator registers) against 256 B per wave and iteration on the one-wave-per-row kernel
-    if ((g_ln_variant >= 2 || p.cols == 1024 || p.cols == 128) && ln_half_ok(ElemTraits<T>::DT, p.cols, p.dy, p.dz_in, p.z, p.dx, p.dres) && ((uintptr_t)p.gamma & 15) == 0) {
+    // 128 / 192 (one vector slot) / 256 columns: several rows per wave (<= 100 VGPRs) against 256-512 B per wave and iteration on the
+    // one-wave-per-row kernel
+    if ((g_ln_variant >= 2 || p.cols == 1024 || p.cols <= 256) && ln_half_ok(ElemTraits<T>::DT, p.cols, p.dy, p.dz_in, p.z, p.dx, p.dres) && ((uintptr_t)p.gamma & 15) == 0) {
         const int gl = ln_group(p.cols);
         if (gl == 16) {
             if (p.cols == 128) hipLaunchKernelGGL((ln_bwd_h_kernel<1, 16>), dim3(LN_PART_BLOCKS), dim3(256), 0, st, p);
