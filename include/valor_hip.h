@@ -53,7 +53,7 @@ extern "C" {
  * fused activation); C += result when `accumulate`; out_f32 stores C/preact as fp32 for bf16 inputs.
  * workspace: fp32 scratch for split-K partial tiles (may be NULL = no split-K).
  * rowsum_out (may be NULL): [M] values of C's element type, the sums over k of op(A) -- the bias gradient of a wgrad GEMM (sum over tokens of dY) computed on
- * the matrix pipe beside the GEMM instead of a separate pass over dY; only where valor_gemm_kernel_for() returns 3 and
+ * the matrix pipe beside the GEMM instead of a separate pass over dY; only where valor_gemm_kernel_for() returns 3 or 4 and
  * transA = 1 (VALOR_ERR_ARG otherwise). */
 int valor_gemm(void* stream, int dtype, int transA, int transB, int M, int N, int K, const void* A, int64_t lda,
                const void* B, int64_t ldb, void* C, int64_t ldc, const void* bias, int act, void* preact,
@@ -66,7 +66,8 @@ int valor_gemm(void* stream, int dtype, int transA, int transB, int M, int N, in
  * policy between 1 and 3 (default). Returns the previous value; v < 0 only queries. Tuning / A-B measurement hook. */
 int valor_gemm_set_variant(int v);
 /* kernel family valor_gemm picks for a problem under the current variant: 0 = register-staged 128x128 (and every fp32
- * problem), 1 / 2 = LDS-DMA 128x128 single / double stage, 3 = 256x256 8-phase */
+ * problem), 1 / 2 = LDS-DMA 128x128 single / double stage, 3 = 256x256 8-phase (one workgroup per CU), 4 = 256x128 8-phase with
+ * two workgroups per CU (csrc/gemm8n.hip, policy key 8) */
 int valor_gemm_kernel_for(int dtype, int transA, int transB, int M, int N, int K, int heavy_epilogue);
 /* heavy_epilogue: the call passes dact_aux WITHOUT VALOR_ACT_DERIV (the epilogue evaluates act' of a second [M, N] operand); such dgrads stay on the 128x128 kernel below
  * K = 1536, where four workgroups per CU overlap each other's epilogues (profiles/r02_gemm_epilogue_ab.json) */
@@ -93,8 +94,18 @@ int valor_gemm_set_fast_epilogue(int v);
  *          (+5.5 .. +10 % on the K = 768 forward shapes, -0.6 .. -1.8 % at K = 3072)
  *   key 6: 1 = the 128x128 kernels store big outputs of short-K problems non-temporally too (default 0)
  *   key 7: smallest K of a forward (NN) problem that may use the 8-phase kernels (default 128, env VALOR_GEMM_NN_MINK)
- *   key 7: unused */
+ *   key 8: the 256x128 two-workgroups-per-CU 8-phase kernel (family 4; K % 64 == 0, K >= 128, M >= 256, N >= 128; env VALOR_GEMM_NARROW):
+ *          0 = never, 1 = every eligible problem, 2 = only problems the keys above leave to the 128x128 kernels, 3 = only problems they
+ *          send to the 256x256 kernel, 1000 = measured per-class choice
+ *   keys 9 .. 11: reserved */
 int valor_gemm_set_policy(int key, int value);
+/* schedule of the family-4 kernel: 0 = one barrier per phase (the partner wave of every SIMD belongs to the CU's other workgroup),
+ * 1 = two barriers per phase with the second wave row one barrier late (the 256x256 kernel's alternation). Same results. Returns the
+ * previous value; anything but 0 / 1 only queries. Tuning / A-B hook (env VALOR_GEMM_N8_SCHED). */
+int valor_gemm_set_narrow_sched(int v);
+/* workgroups of the family-4 kernel the runtime admits per CU (hipOccupancyMaxActiveBlocksPerMultiprocessor at its 80 KiB of LDS): the
+ * design point is 2; -1 on a runtime error. Needs a device. */
+int valor_gemm_narrow_occupancy(void);
 
 /* ---- fused bias + dropout + residual + LayerNorm.  Replaces apex FusedLayerNorm (apex/csrc/layer_norm_cuda_kernel.cu
  * :279-322 forward, :403-634 backward; wrapper apex/apex/normalization/fused_layer_norm.py:14-37) plus the elementwise ops

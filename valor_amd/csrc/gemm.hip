@@ -474,16 +474,20 @@ extern "C" int valor_gemm_set_variant(int v) { const int o = g_gemm_variant; if 
 // [6] 1 = the 128x128 kernels store big outputs of short-K problems non-temporally as well
 // [7] forward (NN) min K for the 8-phase kernel: 128 -- the VideoSwin stage-1 / 2 forward GEMMs (K = 128 / 256, 200 704+ rows) stream at
 //     3.0-3.2 TB/s there against 1.4-1.9 on the 128x128 kernels (profiles/r03_gemm_smallk.json; in-step 356.6 -> 359.6 samples/s); it was 512
-int g_gemm_policy[8] = {[] { const char* e = getenv("VALOR_GEMM_NT_MINK"); return e ? atoi(e) : 768; }(),
+// [8] narrow 8-phase kernel (gemm8n.hip: 256x128 tile, two workgroups per CU): 0 = never, 1 = every eligible problem, 2 = only where the
+//     policy above would take the 128x128 kernels, 3 = only where it would take the 256x256 kernel, 1000 = measured per-class choice (use_8ph2)
+// [9] .. [11] reserved
+int g_gemm_policy[12] = {[] { const char* e = getenv("VALOR_GEMM_NT_MINK"); return e ? atoi(e) : 768; }(),
                         [] { const char* e = getenv("VALOR_GEMM_SPLITK_BF16"); return e ? atoi(e) : 1; }(),
                         [] { const char* e = getenv("VALOR_GEMM_MIN_TILES"); return e ? atoi(e) : 256; }(),
                         [] { const char* e = getenv("VALOR_GEMM_NT_MIN_TILES"); return e ? atoi(e) : 1024; }(),
                         [] { const char* e = getenv("VALOR_GEMM_RASTER"); return e ? atoi(e) : 1000; }(),
                         [] { const char* e = getenv("VALOR_GEMM_STORE"); return e ? atoi(e) : 1000; }(),
                         [] { const char* e = getenv("VALOR_GEMM_NTA"); return e ? atoi(e) : 0; }(),
-                        [] { const char* e = getenv("VALOR_GEMM_NN_MINK"); return e ? atoi(e) : 128; }()};
+                        [] { const char* e = getenv("VALOR_GEMM_NN_MINK"); return e ? atoi(e) : 128; }(),
+                        [] { const char* e = getenv("VALOR_GEMM_NARROW"); return e ? atoi(e) : 0; }(), 0, 0, 0};
 extern "C" int valor_gemm_set_policy(int key, int value) {
-    if (key < 0 || key > 7) return VALOR_ERR_ARG;
+    if (key < 0 || key > 11) return VALOR_ERR_ARG;
     const int old = g_gemm_policy[key];
     if (value >= 0) g_gemm_policy[key] = value;
     return old;
@@ -504,12 +508,33 @@ static bool use_8ph(int dtype, int transA, int transB, int M, int N, int K, bool
     return false;
 }
 
-// which kernel family valor_gemm uses for a problem: 0 = register-staged 128x128 (also all fp32), 1 / 2 = LDS-DMA 128x128
-// single / double stage, 3 = 256x256 8-phase.  (bench.py groups its roofline numbers by this.)
-extern "C" int valor_gemm_kernel_for(int dtype, int transA, int transB, int M, int N, int K, int heavy_epilogue) {
+// the narrow 8-phase kernel (gemm8n.hip), policy key 8
+static bool use_8ph2(int dtype, int transA, int transB, int M, int N, int K, bool heavy_epi, bool big) {
+    const int mode = g_gemm_policy[8];
+    if (dtype != VALOR_DT_BF16 || g_gemm_variant < 3 || mode == 0) return false;
+    if ((K % 64) != 0 || K < 128 || M < 256 || N < 128) return false;
+    if (transA && !transB) return false;                     // no caller has this layout at a size that matters
+    if (mode == 1) return true;
+    if (mode == 2) return !big;
+    if (mode == 3) return big;
+    // mode 1000: filled in from tools/gemm_narrow_ab.py
+    (void)heavy_epi;
+    return false;
+}
+
+// kernel family of a problem: 0 = register-staged 128x128 (also all fp32), 1 / 2 = LDS-DMA 128x128 single / double stage,
+// 3 = 256x256 8-phase (gemm8.hip), 4 = 256x128 8-phase with two workgroups per CU (gemm8n.hip)
+static int gemm_family(int dtype, int transA, int transB, int M, int N, int K, bool heavy_epi) {
     if (dtype != VALOR_DT_BF16 || g_gemm_variant == 0) return 0;
-    if (use_8ph(dtype, transA, transB, M, N, K, heavy_epilogue != 0)) return 3;
+    const bool big = use_8ph(dtype, transA, transB, M, N, K, heavy_epi);
+    if (use_8ph2(dtype, transA, transB, M, N, K, heavy_epi, big)) return 4;
+    if (big) return 3;
     return g_gemm_variant == 2 ? 2 : 1;
+}
+
+// which kernel family valor_gemm uses for a problem (bench.py groups its roofline numbers by this)
+extern "C" int valor_gemm_kernel_for(int dtype, int transA, int transB, int M, int N, int K, int heavy_epilogue) {
+    return gemm_family(dtype, transA, transB, M, N, K, heavy_epilogue != 0);
 }
 
 template <int NSTAGE>
@@ -551,7 +576,9 @@ static int launch_gemm(hipStream_t st, int transA, int transB, GemmArgs p) {
     dim3 grid(tiles, p.kslices > 1 ? p.kslices : 1);
     if (ElemTraits<T>::DT == VALOR_DT_BF16 && g_gemm_variant > 0) {
         if (p.kslices > 1) grid = dim3(tiles * p.kslices, 1);     // split-K: 1-D grid over (slice, tile) work items
-        if (use_8ph(VALOR_DT_BF16, transA, transB, p.M, p.N, p.K, p.dact_aux != nullptr && !(p.act & VALOR_ACT_DERIV))) launch_gemm_8ph(st, transA, transB, p);
+        const int fam = gemm_family(VALOR_DT_BF16, transA, transB, p.M, p.N, p.K, p.dact_aux != nullptr && !(p.act & VALOR_ACT_DERIV));
+        if (fam == 4) launch_gemm_8ph2(st, transA, transB, p);
+        else if (fam == 3) launch_gemm_8ph(st, transA, transB, p);
         else {
             // policy key 6: the 128x128 kernels store big bf16 outputs of short-K problems non-temporally too (A/B hook, default off)
             p.st_mode = (g_gemm_policy[6] && !p.out_f32 && p.kslices <= 1 && p.K <= 1024 && (int64_t)p.M * p.N >= (4 << 20)) ? 1 : 0;
@@ -598,7 +625,7 @@ extern "C" int valor_gemm(void* stream, int dtype, int transA, int transB, int M
                           void* rowsum_out, int rowsum_accumulate) {
     if (M <= 0 || N <= 0) return VALOR_OK;
     // fused row sums only exist in the 8-phase kernel with a k-slow A operand (ask valor_gemm_kernel_for first)
-    if (rowsum_out && !(transA && use_8ph(dtype, transA, transB, M, N, K))) return VALOR_ERR_ARG;
+    if (rowsum_out && !(transA && gemm_family(dtype, transA, transB, M, N, K, false) >= 3)) return VALOR_ERR_ARG;
     if (K < 0 || !A || !B || !C) return VALOR_ERR_ARG;
     const int vec = dtype == VALOR_DT_BF16 ? 8 : 4;
     // 16-byte chunk loads: leading dims and bases must be chunk aligned
@@ -675,9 +702,9 @@ extern "C" int valor_gemm(void* stream, int dtype, int transA, int transB, int M
         // split-K of the LDS-DMA kernels: as many K-slices as fill -- without overflowing -- ONE round of workgroup
         // slots (128x128 kernel: 4 per CU = 1024; 256x256 kernel: 1 per CU = 256); >= 6 K-steps per workgroup.
         slices = 1;
-        const bool big = use_8ph(dtype, transA, transB, M, N, K, dact_aux != nullptr && !(act & VALOR_ACT_DERIV));
-        const int tiles_x = big ? ((M + 255) / 256) * ((N + 255) / 256) : tiles;
-        const int slots = big ? 256 : 1024;
+        const int fam = gemm_family(dtype, transA, transB, M, N, K, dact_aux != nullptr && !(act & VALOR_ACT_DERIV));
+        const int tiles_x = fam == 3 ? ((M + 255) / 256) * ((N + 255) / 256) : fam == 4 ? ((M + 255) / 256) * ((N + 127) / 128) : tiles;
+        const int slots = fam == 3 ? 256 : fam == 4 ? 512 : 1024;
         if (workspace && 2 * tiles_x <= slots && nk >= 24) {
             int sl = slots / tiles_x;
             if (sl > nk / 6) sl = nk / 6;

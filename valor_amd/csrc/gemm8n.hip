@@ -1,0 +1,522 @@
+// valor_gemm, bf16, "narrow" 8-phase path: 256x128 tile per 256-thread workgroup (4 waves as 2(M) x 2(N), 128x64 outputs each =
+// 8x4 v_mfma_f32_16x16x32_bf16 tiles, 128 accumulator VGPRs), BK = 64, an 80 KiB LDS ring and TWO workgroups per CU.
+//
+// Why it exists beside the 256x256 kernel of gemm8.hip (one 512-thread workgroup per CU, 128 KiB of LDS): there nothing overlaps a
+// tile's prologue (first DMA round trip) and epilogue (accumulators -> LDS -> 16-byte stores), which at K = 768 is a third of the
+// tile's life, and grids of a few hundred 256x256 tiles quantise badly onto 256 CUs (780 tiles = 3.05 rounds). Here the two waves
+// of a SIMD belong to DIFFERENT workgroups: they are not coupled by barriers, one's epilogue / prologue runs under the other's K
+// loop, a round has 512 slots, and a tile is half as big. The per-wave work is the same as in the 256x256 kernel (128x64 outputs,
+// four 64x32 quadrants per K-tile, fragments of one quadrant pair in registers), so the LDS bytes read per FLOP are unchanged; the
+// L2 -> LDS bytes per FLOP are 1.5 x (tile intensity 85 instead of 128 FLOP/B).
+//
+// LDS (80 KiB): A ring of THREE 16 KiB half-tile slots (A'h = tile rows [128h, 128h+128) x 64 k), B double buffer of two 16 KiB
+// images (all 128 tile columns x 64 k). Half-tile i of the A sequence A'0(0) A'1(0) A'0(1) ... lives in slot i % 3.
+// Per K-tile c, four phases j (LOAD segment, s_barrier, MATH segment = one 64x32 quadrant of every wave, 16 MFMAs):
+//   quadrants  j0: (A'0,B'0)   j1: (A'0,B'1)   j2: (A'1,B'1)   j3: (A'1,B'0)      B'h = tile columns [64h, 64h+64)
+//   LDS reads  j0: B'0 + A'0 (12 x 16 B per lane)   j1: B'1 (4)   j2: A'1 (8)   j3: none
+//   DMA issue  j0: A'0(c+1) -> the slot A'1(c-1) left at j2(c-1)        j2: A'1(c+1) -> the slot A'0(c) left at j0(c)
+//              j3: B(c+2)   -> the buffer B(c) left at j1(c)             (4 x buffer_load_dwordx4..lds per wave each)
+//   waits      j1: vmcnt(8) retires A'1(c) (issued j2(c-1); behind it B(c+1), A'0(c+1))
+//              j3: vmcnt(8) retires B(c+1), A'0(c+1) (behind them A'1(c+1), B(c+2))          -- never a drain
+// RAW: a slot is read one phase after the counted wait that retires it (own vmcnt + a barrier every reader has passed).
+// WAR: a slot is re-filled two phases after its last read. Look-ahead past the last K-tile goes through a zero-length buffer
+// descriptor (range check -> zeros, no memory traffic), so the load COUNT per phase -- which the vmcnt immediates rely on -- is constant.
+// SCHED 0: one barrier per phase (LOAD_END), all four waves in step: the partner wave of every SIMD is the OTHER workgroup's.
+// SCHED 1: two barriers per phase and the second wave row one barrier late (the 256x256 kernel's alternation, inside a workgroup).
+//
+// Image formats, fragment reads, epilogues, split-K partials and fused row sums are those of gemm8.hip at this tile geometry.
+// Requirements: K % 64 == 0, M >= 256, N >= 128 (otherwise valor_gemm uses the 128x128 kernels).
+#include "gemm_common.h"
+#include <stdlib.h>
+
+#define N8_HT 16384
+#define N8_OFF_B (3 * N8_HT)
+#define N8_LDS (5 * N8_HT)
+
+DEVINL bf16x8_t n8_read_frag_tr8(const char* img, int off, int kk) {
+    const char* a = img + off + kk * (32 * 256);
+    s16x4_t lo = lds_read_tr4(a), hi = lds_read_tr4(a + 4 * 256);
+    return __builtin_bit_cast(bf16x8_t, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+}
+
+template <bool TA, bool TB, bool ASMTR, bool NTS, int SCHED>
+__global__ __launch_bounds__(256, 2) void gemm_8ph2_kernel(GemmArgs p) {
+    typedef bf16_t T;
+    constexpr int BK = 64;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int fr = lane & 15, fg = lane >> 4;
+
+    const int tiles_n = (p.N + 127) >> 7;
+    const int tiles_m = (p.M + 255) >> 8;
+    int logical, slice = 0;
+    if (p.kslices > 1) {
+        // work items (K-slice, tile) in slice-major order, a contiguous range per XCD (workgroup b runs on XCD b % 8)
+        const int ntiles = tiles_m * tiles_n;
+        const int item = xcd_remap(blockIdx.x, ntiles * p.kslices);
+        slice = item / ntiles;
+        logical = item - slice * ntiles;
+    } else {
+        logical = xcd_remap(blockIdx.x, tiles_m * tiles_n);
+    }
+    int tm = logical / tiles_n, tn = logical - tm * tiles_n;
+    if (p.raster_g > 0 && p.kslices <= 1) {
+        // L2-aware raster (gemm8.hip): tile columns in groups of G, row-major inside a group
+        const int G = p.raster_g, per = G * tiles_m;
+        const int grp = logical / per, w = logical - grp * per;
+        const int gw = min(G, tiles_n - grp * G);
+        tm = w / gw;
+        tn = grp * G + (w - tm * gw);
+    }
+    const int m0 = tm << 8, n0 = tn << 7;
+
+    const int nk_total = p.K / BK;
+    int ks_begin = 0, ks_end = nk_total;
+    if (p.kslices > 1) {
+        ks_begin = slice * p.ksteps_per_slice;
+        ks_end = ks_begin + p.ksteps_per_slice;
+        if (ks_end > nk_total) ks_end = nk_total;
+        if (ks_begin > nk_total) ks_begin = nk_total;
+    }
+    const int k_first = ks_begin * BK;
+    const int ntile = ks_end - ks_begin;
+
+    f32x4_t acc[8][4];   // [mh*4+mt][nh*2+nt]
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+
+    // fused row sums of A (TA only): the tile column 0 workgroups add  ones . A^T  on the matrix pipe, two 16-row blocks per wave
+    // and row half (wave wn takes blocks mt = 2 wn, 2 wn + 1): 4 extra MFMAs in phases j0 and j2.
+    const bool do_rs = TA && p.rowsum_out != nullptr && tn == 0;
+    f32x4_t racc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) racc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+    const bf16x8_t ones = __builtin_bit_cast(bf16x8_t, (u32x4_t){0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u});
+
+    // ---- DMA sources. An image = 16 pieces of 1 KiB; wave w issues pieces 4w .. 4w+3. Per-lane byte offset of piece 4w of half 0 at
+    // this workgroup's first K-tile in vA / vB (k-slow images: two of them, the granule rotation differs between k-octets); pieces, halves
+    // and K-tiles add wave-uniform amounts.
+    int vA[2], vB[2];
+    int pieceA, halfA, stepA, pieceB, stepB;
+    {
+        const int ldA_b = (int)(p.lda * 2), ldB_b = (int)(p.ldb * 2);
+        if constexpr (!TA) {
+            const int r = wave * 32 + (lane >> 3), c = (lane & 7) ^ ((lane >> 3) & 7);
+            vA[0] = vA[1] = (m0 + r) * ldA_b + (k_first + c * 8) * 2;
+            pieceA = 8 * ldA_b; halfA = 128 * ldA_b; stepA = BK * 2;
+        } else {
+            const int k = wave * 16 + (lane >> 4), s = lane & 15;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int ic = ((s - 2 * (k & 3) - 8 * h) & 15) * 8;
+                vA[h] = (k_first + k) * ldA_b + (m0 + ic) * 2;
+            }
+            pieceA = 4 * ldA_b; halfA = 256; stepA = BK * ldA_b;
+        }
+        if constexpr (!TB) {
+            const int r = wave * 32 + (lane >> 3), c = (lane & 7) ^ ((lane >> 3) & 7);
+            vB[0] = vB[1] = (n0 + r) * ldB_b + (k_first + c * 8) * 2;
+            pieceB = 8 * ldB_b; stepB = BK * 2;
+        } else {
+            const int k = wave * 16 + (lane >> 4), s = lane & 15;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int ic = ((s - 2 * (k & 3) - 8 * h) & 15) * 8;
+                vB[h] = (k_first + k) * ldB_b + (n0 + ic) * 2;
+            }
+            pieceB = 4 * ldB_b; stepB = BK * ldB_b;
+        }
+    }
+    // A'hf of (relative) K-tile t into `slot`; B of K-tile t into `buf`. Past the last K-tile: zero-length descriptor.
+    auto issueA = [&](int hf, char* slot, int t) {
+        const rsrc_t rs = make_rsrc(p.A, t < ntile ? p.bytesA : 0u);
+        const int so = t * stepA + hf * halfA;
+        char* d = slot + wave * 4096;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) glds16(rs, d + i * 1024, vA[i >> 1] + (so + i * pieceA));
+    };
+    auto issueB = [&](char* buf, int t) {
+        const rsrc_t rs = make_rsrc(p.B, t < ntile ? p.bytesB : 0u);
+        const int so = t * stepB;
+        char* d = buf + wave * 4096;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) glds16(rs, d + i * 1024, vB[i >> 1] + (so + i * pieceB));
+    };
+
+    // ---- fragment read offsets
+    int trA[4], trB[2][2];   // k-slow images: byte offset of the 16-row block (A: wm*4 + mt, B: nh*4 + wn*2 + nt)
+    {
+        const int base = (8 * fg + (fr >> 2)) * 256 + 8 * (fr & 1);
+        const int rot = 2 * (fr >> 2) + 8 * (fg & 1);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) trA[i] = base + 16 * ((2 * (wm * 4 + i) + ((fr >> 1) & 1) + rot) & 15);
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int i = 0; i < 2; ++i) trB[h][i] = base + 16 * ((2 * (h * 4 + wn * 2 + i) + ((fr >> 1) & 1) + rot) & 15);
+    }
+    bf16x8_t fa[4][2], fb0[2][2], fb1[2][2];   // [tile][kk]
+    TrPair pa[4][2], pb[2][2];                 // ASMTR: transposing reads in flight (halves)
+    auto readA = [&](const char* img) {
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) {
+                if constexpr (TA && ASMTR) tr_issue(pa[mt][kk], img + trA[mt] + kk * (32 * 256));
+                else if constexpr (TA) fa[mt][kk] = n8_read_frag_tr8(img, trA[mt], kk);
+                else fa[mt][kk] = read_frag<T>(img, wm * 64 + mt * 16 + fr, kk * 4 + fg);
+            }
+    };
+    auto readB = [&](const char* img, int nh, bf16x8_t (&fb)[2][2]) {
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) {
+                if constexpr (TB && ASMTR) tr_issue(pb[nt][kk], img + trB[nh][nt] + kk * (32 * 256));
+                else if constexpr (TB) fb[nt][kk] = n8_read_frag_tr8(img, trB[nh][nt], kk);
+                else fb[nt][kk] = read_frag<T>(img, nh * 64 + wn * 32 + nt * 16 + fr, kk * 4 + fg);
+            }
+    };
+    auto fragA = [&]() {
+        if constexpr (TA && ASMTR) {
+            tr_wait8(pa);
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+                for (int kk = 0; kk < 2; ++kk) fa[mt][kk] = tr_frag(pa[mt][kk]);
+        }
+    };
+    auto fragB = [&](bf16x8_t (&fb)[2][2]) {
+        if constexpr (TB && ASMTR) {
+            tr_wait4(pb);
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                for (int kk = 0; kk < 2; ++kk) fb[nt][kk] = tr_frag(pb[nt][kk]);
+        }
+    };
+#define QUADRANT(MH_, NH_, FB_)                                                                                   \
+    do {                                                                                                          \
+        __builtin_amdgcn_s_setprio(1);                                                                            \
+        _Pragma("unroll") for (int kk = 0; kk < 2; ++kk)                                                          \
+            _Pragma("unroll") for (int mt = 0; mt < 4; ++mt)                                                      \
+                _Pragma("unroll") for (int nt = 0; nt < 2; ++nt)                                                  \
+                    acc[(MH_) * 4 + mt][(NH_) * 2 + nt] = Mma<T>::mma(FB_[nt][kk], fa[mt][kk], acc[(MH_) * 4 + mt][(NH_) * 2 + nt]); \
+        __builtin_amdgcn_s_setprio(0);                                                                            \
+    } while (0)
+#define ROWSUM(H_)                                                                                                \
+    do {                                                                                                          \
+        if (do_rs) {                                                                                              \
+            if (wn == 0) {      /* wave-uniform branch: a select between fragments becomes a scratch-indexed array */       \
+                _Pragma("unroll") for (int kk = 0; kk < 2; ++kk) {                                                \
+                    racc[H_][0] = Mma<T>::mma(ones, fa[0][kk], racc[H_][0]);                                      \
+                    racc[H_][1] = Mma<T>::mma(ones, fa[1][kk], racc[H_][1]);                                      \
+                }                                                                                                 \
+            } else {                                                                                              \
+                _Pragma("unroll") for (int kk = 0; kk < 2; ++kk) {                                                \
+                    racc[H_][0] = Mma<T>::mma(ones, fa[2][kk], racc[H_][0]);                                      \
+                    racc[H_][1] = Mma<T>::mma(ones, fa[3][kk], racc[H_][1]);                                      \
+                }                                                                                                 \
+            }                                                                                                     \
+        }                                                                                                         \
+    } while (0)
+#define LOAD_END_WAIT()                                                                                           \
+    do {                                                                                                          \
+        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");                                                          \
+        __builtin_amdgcn_s_barrier();                                                                             \
+        __builtin_amdgcn_sched_barrier(0);                                                                        \
+    } while (0)
+#define LOAD_END()                                                                                                \
+    do {                                                                                                          \
+        __builtin_amdgcn_sched_barrier(0);                                                                        \
+        __builtin_amdgcn_s_barrier();                                                                             \
+        __builtin_amdgcn_sched_barrier(0);                                                                        \
+    } while (0)
+#define MATH_END()                                                                                                \
+    do {                                                                                                          \
+        __builtin_amdgcn_sched_barrier(0);                                                                        \
+        if constexpr (SCHED == 1) {                                                                               \
+            __builtin_amdgcn_s_barrier();                                                                         \
+            __builtin_amdgcn_sched_barrier(0);                                                                    \
+        }                                                                                                         \
+    } while (0)
+
+    char* const bufB0 = smem + N8_OFF_B;
+    char* const bufB1 = smem + N8_OFF_B + N8_HT;
+
+    if (ntile > 0) {
+        // prologue = the virtual phases before tile 0: B(0) A'0(0) A'1(0) B(1); the last two may stay in flight
+        issueB(bufB0, 0); issueA(0, smem, 0); issueA(1, smem + N8_HT, 0); issueB(bufB1, 1);
+        LOAD_END_WAIT();
+        if constexpr (SCHED == 1) { if (wm == 1) __builtin_amdgcn_s_barrier(); }     // second wave row runs one barrier late
+        int sa0 = 0;                                     // ring slot of A'0(rel)
+        for (int rel = 0; rel < ntile; ++rel) {
+            const int sa1 = sa0 == 2 ? 0 : sa0 + 1, sa2 = sa1 == 2 ? 0 : sa1 + 1;
+            char* const a0 = smem + sa0 * N8_HT;
+            char* const a1 = smem + sa1 * N8_HT;
+            char* const a2 = smem + sa2 * N8_HT;
+            char* const bcur = (rel & 1) ? bufB1 : bufB0;
+            // ---- j0
+            readB(bcur, 0, fb0);
+            readA(a0);
+            issueA(0, a2, rel + 1);
+            LOAD_END();
+            fragB(fb0); fragA();
+            QUADRANT(0, 0, fb0);
+            ROWSUM(0);
+            MATH_END();
+            // ---- j1
+            readB(bcur, 1, fb1);
+            LOAD_END_WAIT();
+            fragB(fb1);
+            QUADRANT(0, 1, fb1);
+            MATH_END();
+            // ---- j2
+            readA(a1);
+            issueA(1, a0, rel + 1);
+            LOAD_END();
+            fragA();
+            QUADRANT(1, 1, fb1);
+            ROWSUM(1);
+            MATH_END();
+            // ---- j3
+            issueB(bcur, rel + 2);
+            LOAD_END_WAIT();
+            QUADRANT(1, 0, fb0);
+            MATH_END();
+            sa0 = sa2;
+        }
+        if constexpr (SCHED == 1) { if (wm == 0) __builtin_amdgcn_s_barrier(); }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the zero-length look-ahead loads still write LDS: drain before it is reused
+    __syncthreads();
+#undef QUADRANT
+#undef ROWSUM
+#undef LOAD_END
+#undef LOAD_END_WAIT
+#undef MATH_END
+    if (do_rs && fg == 0) {     // racc[h][j][*] = sum_k A(m, k) for m = m0 + 128h + 64wm + 16(2wn + j) + fr
+#pragma unroll
+        for (int hh = 0; hh < 2; ++hh)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int m = m0 + hh * 128 + wm * 64 + (2 * wn + j) * 16 + fr;
+                if (m < p.M) {
+                    if (p.kslices > 1) p.rowsum_ws[(int64_t)slice * p.M + m] = racc[hh][j][0];
+                    else rowsum_store<T>(p, m, racc[hh][j][0]);
+                }
+            }
+    }
+
+    // ---- fast epilogue (host-checked, GemmArgs::fast_epi): alpha / bias / activation on the accumulators, the whole 256 x 128 tile as
+    // bf16 (64 KiB) through LDS in ONE pass. Image: [256 rows][256 B], 16-B chunk c of row r at position c ^ (r & 15). dact_aux and
+    // C += are applied at read-out (every lane holds 8 consecutive columns of a row there), their second operand requested before the
+    // tile barrier. acc[mh*4+mt][nh*2+nt][r] = C[mh*128 + wm*64 + mt*16 + fr][nh*64 + wn*32 + nt*16 + 4*fg + r]
+    if constexpr (!TA) if (p.fast_epi) {
+        char* sB = smem;
+        const int act = p.act & VALOR_ACT_MASK;
+        const bool deriv = (p.act & VALOR_ACT_DERIV) != 0;
+        auto write_tile = [&](bool apply_act) {
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni) {
+                const int col = (ni >> 1) * 64 + wn * 32 + (ni & 1) * 16 + 4 * fg;
+                const f32x4_t bias4 = load_bias4<T>(p, n0 + col);
+#pragma unroll
+                for (int mi = 0; mi < 8; ++mi) {
+                    const int row = (mi >> 2) * 128 + wm * 64 + (mi & 3) * 16 + fr;
+                    f32x4_t v = acc[mi][ni];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] = v[r] * p.alpha + bias4[r];
+                    if (apply_act) {
+                        float f[4] = {v[0], v[1], v[2], v[3]};
+                        act_fwd_n<4>(act, f);
+                        v = (f32x4_t){f[0], f[1], f[2], f[3]};
+                    }
+                    const u32x2_t w = {pack2_bf16(v[0], v[1]), pack2_bf16(v[2], v[3])};
+                    *(u32x2_t*)(sB + row * 256 + (((col >> 3) ^ (row & 15)) << 4) + (fg & 1) * 8) = w;
+                }
+            }
+        };
+        auto read_tile = [&](T* dst) {
+#pragma unroll 4
+            for (int it = 0; it < 16; ++it) {
+                const int ml = it * 16 + (tid >> 4), c = tid & 15;
+                const u32x4_t val = *(const u32x4_t*)(sB + ml * 256 + ((c ^ (ml & 15)) << 4));
+                const int m = m0 + ml, n = n0 + c * 8;
+                if (m < p.M && n < p.N) store_out16<NTS>(dst + (int64_t)m * p.ldc + n, val);
+            }
+        };
+        if (p.preact) {                 // forward of a fused activation: the pre-activation copy first
+            write_tile(false);
+            __syncthreads();
+            read_tile((T*)p.preact);
+            __syncthreads();
+        }
+        write_tile(act != VALOR_ACT_NONE && !p.dact_aux);
+        if (p.dact_aux || p.accumulate) {
+            const bool dact = p.dact_aux != nullptr, accum = p.accumulate != 0;
+            const T* src = dact ? (const T*)p.dact_aux : (const T*)p.C;
+            const int64_t lds2 = dact ? p.ldaux : p.ldc;
+            u32x4_t pre[16];
+#pragma unroll
+            for (int it = 0; it < 16; ++it) {
+                const int m = m0 + it * 16 + (tid >> 4), n = n0 + (tid & 15) * 8;
+                pre[it] = (u32x4_t){0u, 0u, 0u, 0u};
+                if (m < p.M && n < p.N) pre[it] = *(const u32x4_t*)(src + (int64_t)m * lds2 + n);
+            }
+            __syncthreads();
+            T* dst = (T*)p.C;
+#pragma unroll
+            for (int it = 0; it < 16; ++it) {
+                const int ml = it * 16 + (tid >> 4), c = tid & 15;
+                u32x4_t val = *(const u32x4_t*)(sB + ml * 256 + ((c ^ (ml & 15)) << 4));
+                const int m = m0 + ml, n = n0 + c * 8;
+                if (m < p.M && n < p.N) {
+                    float f[8], x[8];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) { f[2 * q] = __uint_as_float(val[q] << 16); f[2 * q + 1] = __uint_as_float(val[q] & 0xffff0000u); }
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) { x[2 * q] = __uint_as_float(pre[it][q] << 16); x[2 * q + 1] = __uint_as_float(pre[it][q] & 0xffff0000u); }
+                    if (dact) {
+                        if (deriv) {
+#pragma unroll
+                            for (int q = 0; q < 8; ++q) f[q] *= x[q];
+                        } else {
+                            act_bwd_mul_n<8>(act, f, x);
+                        }
+                        if (accum) {
+                            const u32x4_t o = *(const u32x4_t*)(dst + (int64_t)m * p.ldc + n);
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) { f[2 * q] += __uint_as_float(o[q] << 16); f[2 * q + 1] += __uint_as_float(o[q] & 0xffff0000u); }
+                        }
+                    } else {
+#pragma unroll
+                        for (int q = 0; q < 8; ++q) f[q] += x[q];
+                    }
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) val[q] = pack2_bf16(f[2 * q], f[2 * q + 1]);
+                    store_out16<NTS>(dst + (int64_t)m * p.ldc + n, val);
+                }
+            }
+            return;
+        }
+        __syncthreads();
+        read_tile((T*)p.C);
+        return;
+    }
+
+    // ---- general epilogue: two passes (tile row halves mh) through LDS: 128 rows x 128 cols fp32 (swizzled 16-B chunks) ->
+    // row-contiguous 16-byte bf16 stores (or split-K partials).
+    float* sC = (float*)smem;
+    float* wsl = p.kslices > 1 ? p.ws + (int64_t)slice * p.M * p.N : nullptr;
+    const f32x4_t bias0 = load_bias4<T>(p, n0 + (tid & 15) * 8), bias1 = load_bias4<T>(p, n0 + (tid & 15) * 8 + 4);
+#pragma unroll
+    for (int pass = 0; pass < 2; ++pass) {
+        if (pass) __syncthreads();
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni) {
+                const int ml = wm * 64 + mt * 16 + fr;                        // row inside this 128-row half
+                const int ch = ((ni >> 1) * 16 + wn * 8 + (ni & 1) * 4 + fg) ^ (ml & 7);
+                *(f32x4_t*)(sC + ml * 128 + ch * 4) = acc[pass * 4 + mt][ni];
+            }
+        __syncthreads();
+#pragma unroll 2
+        for (int it = 0; it < 8; ++it) {
+            const int ml = it * 16 + (tid >> 4);
+            const int c8 = tid & 15;                                   // 8 columns = fp32 chunks 2*c8, 2*c8+1
+            const f32x4_t v0 = *(const f32x4_t*)(sC + ml * 128 + (((2 * c8) ^ (ml & 7)) << 2));
+            const f32x4_t v1 = *(const f32x4_t*)(sC + ml * 128 + (((2 * c8 + 1) ^ (ml & 7)) << 2));
+            const int m = m0 + pass * 128 + ml, n = n0 + c8 * 8;
+            if (wsl) {
+                splitk_store8(p, slice, m, n, v0, v1);
+            } else {
+                epilogue_store8<true, NTS ? 1 : 0>(p, m, n, v0, v1, bias0, bias1);
+            }
+        }
+    }
+}
+
+// schedule of the narrow kernel (see SCHED above); VALOR_GEMM_N8_SCHED=0/1 presets it for A/B runs
+static int g_8ph2_sched = [] { const char* e = getenv("VALOR_GEMM_N8_SCHED"); return e ? atoi(e) : 0; }();
+extern "C" int valor_gemm_set_narrow_sched(int v) {
+    const int old = g_8ph2_sched;
+    if (v == 0 || v == 1) g_8ph2_sched = v;
+    return old;
+}
+
+extern "C" int valor_gemm_set_tr_asm(int v);
+extern "C" int valor_gemm_set_fast_epilogue(int v);
+
+void launch_gemm_8ph2(hipStream_t st, int transA, int transB, const GemmArgs& p_in) {
+    GemmArgs p = p_in;
+    const int fast_mode = valor_gemm_set_fast_epilogue(-1), tr_asm = valor_gemm_set_tr_asm(-1);
+    // the bf16 tile epilogue under the conditions of the 256x256 kernel (gemm8.hip: launch_gemm_8ph)
+    const bool light_dact = p.dact_aux && (p.act & VALOR_ACT_DERIV);
+    const bool plainish = fast_mode >= 2 || (!p.preact && (!p.dact_aux || light_dact));
+    p.fast_epi = fast_mode && plainish && !p.out_f32 && p.kslices <= 1 && (p.N & 7) == 0 && (p.ldc & 7) == 0 && !p.rowsum_out &&
+                 (!p.dact_aux || (p.ldaux & 7) == 0) && !(p.dact_aux && p.preact) && !transA && !(p.preact && (p.act & VALOR_ACT_DERIV));
+    const int tiles_m = (p.M + 255) / 256, tiles_n = (p.N + 127) / 128;
+    const int tiles = tiles_m * tiles_n;
+    // L2-aware raster: the model of launch_gemm_8ph with 128-column panels and 64 concurrent tiles per XCD
+    p.raster_g = 0;
+    if (p.kslices <= 1 && tiles_n > 1 && g_gemm_policy[4] != 0) {
+        if (g_gemm_policy[4] != 1000) {
+            p.raster_g = 2 * g_gemm_policy[4] < tiles_n ? 2 * g_gemm_policy[4] : 0;
+        } else {
+            const double panel = 128.0 * p.K * 2.0, a_bytes = (double)p.M * p.K * 2.0, rounds = tiles / 512.0;
+            const double resident = 2.5 * 1048576.0;
+            const int touched = tiles_n < 64 ? tiles_n : 64;
+            double best = a_bytes + (tiles_n * panel <= resident ? 8.0 * tiles_n * panel : (rounds < 1.0 ? 1.0 : rounds) * 8.0 * touched * panel);
+            for (int ng = 2; ng <= tiles_n; ++ng) {
+                const int G = (tiles_n + ng - 1) / ng;
+                if (G * panel > resident) continue;
+                const double cost = ng * a_bytes + 8.0 * tiles_n * panel;
+                if (cost < 0.9 * best) { best = cost; p.raster_g = G; }
+            }
+        }
+    }
+    const bool nts = !transA && !p.out_f32 && p.kslices <= 1 && (g_gemm_policy[5] == 1 || (g_gemm_policy[5] == 1000 && p.K <= 1024));
+    p.st_mode = nts ? 1 : 0;
+    dim3 grid(tiles * (p.kslices > 1 ? p.kslices : 1));
+    const size_t lds = N8_LDS;
+#define VALOR_8PH2_LAUNCH1(TA_, TB_, ASM_, NTS_, S_)                                                            \
+    do {                                                                                                        \
+        static bool attr_set = false;                                                                           \
+        if (!attr_set) {                                                                                        \
+            hipFuncSetAttribute((const void*)gemm_8ph2_kernel<TA_, TB_, ASM_, NTS_, S_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+            attr_set = true;                                                                                    \
+        }                                                                                                       \
+        hipLaunchKernelGGL((gemm_8ph2_kernel<TA_, TB_, ASM_, NTS_, S_>), grid, dim3(256), lds, st, p);          \
+    } while (0)
+#define VALOR_8PH2_LAUNCH(TA_, TB_, NTS_)                                                                       \
+    do {                                                                                                        \
+        constexpr bool kslow_ = TA_ || TB_;                                                                     \
+        if (kslow_ && !tr_asm) { VALOR_8PH2_LAUNCH1(TA_, TB_, false, NTS_, 0); }                                \
+        else if (g_8ph2_sched == 1) { VALOR_8PH2_LAUNCH1(TA_, TB_, kslow_, NTS_, 1); }                          \
+        else { VALOR_8PH2_LAUNCH1(TA_, TB_, kslow_, NTS_, 0); }                                                 \
+    } while (0)
+    if (!transA && !transB) { if (nts) VALOR_8PH2_LAUNCH(false, false, true); else VALOR_8PH2_LAUNCH(false, false, false); }
+    else if (!transA && transB) { if (nts) VALOR_8PH2_LAUNCH(false, true, true); else VALOR_8PH2_LAUNCH(false, true, false); }
+    else if (transA && !transB) VALOR_8PH2_LAUNCH(true, false, false);
+    else VALOR_8PH2_LAUNCH(true, true, false);
+#undef VALOR_8PH2_LAUNCH
+#undef VALOR_8PH2_LAUNCH1
+}
+
+// how many narrow-kernel workgroups the runtime admits per CU (2 = the design point; the tests assert it)
+extern "C" int valor_gemm_narrow_occupancy(void) {
+    int n = 0;
+    hipFuncSetAttribute((const void*)gemm_8ph2_kernel<false, false, false, false, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)N8_LDS);
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, (const void*)gemm_8ph2_kernel<false, false, false, false, 0>, 256, N8_LDS) != hipSuccess) return -1;
+    return n;
+}

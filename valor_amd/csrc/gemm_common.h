@@ -223,4 +223,6 @@ DEVINL void epilogue_store8(const GemmArgs& p, int m, int n0, f32x4_t a0, f32x4_
 
 // 256x256 8-phase bf16 kernel (gemm8.hip). grid.x = tiles(256) * max(kslices, 1).
 void launch_gemm_8ph(hipStream_t st, int transA, int transB, const GemmArgs& p);
-extern int g_gemm_policy[8];      // valor_gemm_set_policy (gemm.hip)
+// 256x128 8-phase bf16 kernel, two workgroups per CU (gemm8n.hip). grid.x = tiles(256 x 128) * max(kslices, 1).
+void launch_gemm_8ph2(hipStream_t st, int transA, int transB, const GemmArgs& p);
+extern int g_gemm_policy[12];     // valor_gemm_set_policy (gemm.hip)

@@ -84,7 +84,7 @@ def gemm_fuses_rowsum(a, b, trans_a, trans_b):
         return False
     M, Kd = a.shape[1], a.shape[0]
     N = b.shape[1] if trans_b else b.shape[0]
-    return lib.load().valor_gemm_kernel_for(DT_BF16, 1, int(trans_b), M, N, Kd, 0) == 3
+    return lib.load().valor_gemm_kernel_for(DT_BF16, 1, int(trans_b), M, N, Kd, 0) in (3, 4)
 
 
 def part_blocks():

@@ -29,6 +29,8 @@ SIGNATURES = {
     "valor_gemm_set_tr_asm": [_i],
     "valor_gemm_set_fast_epilogue": [_i],
     "valor_gemm_set_policy": [_i, _i],
+    "valor_gemm_set_narrow_sched": [_i],
+    "valor_gemm_narrow_occupancy": [],
     "valor_ln_part_blocks": [],
     "valor_ln_set_variant": [_i],
     "valor_ln_set_nt": [_i],
