@@ -96,12 +96,18 @@ int valor_gemm_set_fast_epilogue(int v);
  *   key 7: smallest K of a forward (NN) problem that may use the 8-phase kernels (default 128, env VALOR_GEMM_NN_MINK)
  *   key 8: the 256x128 two-workgroups-per-CU 8-phase kernel (family 4; K % 64 == 0, K >= 128, M >= 256, N >= 128; env VALOR_GEMM_NARROW):
  *          0 = never, 1 = every eligible problem, 2 = only problems the keys above leave to the 128x128 kernels, 3 = only problems they
- *          send to the 256x256 kernel, 1000 = measured per-class choice
+ *          send to the 256x256 kernel, 1000 (default) = measured per-class choice: forward / dgrad problems that
+ *          would run on the 128x128 kernels or have K <= 1024
  *   keys 9 .. 11: reserved */
 int valor_gemm_set_policy(int key, int value);
-/* schedule of the family-4 kernel: 0 = one barrier per phase (the partner wave of every SIMD belongs to the CU's other workgroup),
- * 1 = two barriers per phase with the second wave row one barrier late (the 256x256 kernel's alternation). Same results. Returns the
- * previous value; anything but 0 / 1 only queries. Tuning / A-B hook (env VALOR_GEMM_N8_SCHED). */
+/* K-loop schedule of the family-3 (256x256) kernel: 0 = eight barriers per K-tile, wave rows staggered by one barrier; 1 = software-pipelined:
+ * two barriers per K-tile, fragment reads and LDS-DMA pieces between the MFMAs of the half-phase before their consumer. Same results (same
+ * accumulation order). 1000 (default) = per problem: pipelined for forward / dgrad problems with K >= 2048 and for wgrads with at most 48 K-tiles
+ * per workgroup. Returns the previous value; anything else only queries. Tuning / A-B hook (env VALOR_GEMM_8PH_SCHED). */
+int valor_gemm_set_8ph_sched(int v);
+/* schedule of the family-4 kernel: 0 = LOAD / MATH segments, one barrier per phase (the partner wave of every SIMD belongs to the CU's other
+ * workgroup), 1 (default) = software-pipelined, two barriers per K-tile. Same results. Returns the previous value; anything but 0 / 1 only
+ * queries. Tuning / A-B hook (env VALOR_GEMM_N8_SCHED). */
 int valor_gemm_set_narrow_sched(int v);
 /* workgroups of the family-4 kernel the runtime admits per CU (hipOccupancyMaxActiveBlocksPerMultiprocessor at its 80 KiB of LDS): the
  * design point is 2; -1 on a runtime error. Needs a device. */

@@ -29,7 +29,7 @@ def _tile_errors(C, ref, tm=256, tn=128):
     return float(torch.sqrt(e2.sum() / r2.sum())), float(torch.sqrt(e2 / r2.clamp_min(1e-20)).max())
 
 
-@pytest.fixture(params=[0, 1], ids=["sched0", "sched1"])
+@pytest.fixture(params=[0, 1], ids=["plain", "pipelined"])
 def narrow(request, dev):
     """every eligible problem on the family-4 kernel, under one of its two schedules"""
     from valor_amd import lib

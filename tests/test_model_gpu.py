@@ -306,10 +306,11 @@ def test_bf16_meets_north_star_on_identical_tensors(dev, name):
         M = rc["batch"] * rc["frames"] * spec.vis_tokens
         W, I = spec.vis_width, 4 * spec.vis_width
         assert M == 25216
-        for (ta, tb, m, n, k) in [(0, 0, M, I, W), (0, 0, M, 3 * W, W), (0, 0, M, W, I),          # forward: fc1, qkv, fc2
-                                  (0, 1, M, I, W),                                                # dgrad of fc2 (1188 tiles, saved-derivative multiply)
-                                  (1, 1, I, W, M), (1, 1, W, I, M), (1, 1, 3 * W, W, M)]:         # wgrad: contraction over the 25 216 tokens
-            assert so.valor_gemm_kernel_for(0, ta, tb, m, n, k, 0) == 3, (ta, tb, m, n, k)
+        # family 4 = 256 x 128 two-workgroups-per-CU 8-phase (K <= 1024), family 3 = 256 x 256 8-phase (long contractions, wgrads)
+        for (ta, tb, m, n, k, fam) in [(0, 0, M, I, W, 4), (0, 0, M, 3 * W, W, 4), (0, 0, M, W, I, 3),       # forward: fc1, qkv, fc2
+                                       (0, 1, M, I, W, 4),                                             # dgrad of fc2 (saved-derivative multiply)
+                                       (1, 1, I, W, M, 3), (1, 1, W, I, M, 3), (1, 1, 3 * W, W, M, 3)]:  # wgrad: contraction over the 25 216 tokens
+            assert so.valor_gemm_kernel_for(0, ta, tb, m, n, k, 0) == fam, (ta, tb, m, n, k)
     with torch.no_grad():
         random.seed(rc["masker_seed"])
         ev = model(batch, task=rc["task"], compute_loss=False)

@@ -73,14 +73,20 @@ def main():
         so.valor_gemm_set_policy(8, 1)
         fam4 = so.valor_gemm_kernel_for(0, ta, tb, m, n, k, 0)
         so.valor_gemm_set_policy(8, 0)
-        t = {"base": [], "n0": [], "n1": [], "lib": []}
+        t = {"base": [], "base_p": [], "n0": [], "n1": [], "lib": []}
         for _ in range(3):
             so.valor_gemm_set_policy(8, 0)
+            so.valor_gemm_set_8ph_sched(0)
             t["base"].append(timeit(ours))
+            if fam0 == 3:                       # the 256 x 256 kernel with its pipelined K loop
+                so.valor_gemm_set_8ph_sched(1)
+                t["base_p"].append(timeit(ours))
+                so.valor_gemm_set_8ph_sched(0)
             if fam4 == 4:
                 so.valor_gemm_set_policy(8, 1)
-                so.valor_gemm_set_narrow_sched(0)
-                t["n0"].append(timeit(ours))
+                if os.environ.get("AB_PLAIN"):
+                    so.valor_gemm_set_narrow_sched(0)
+                    t["n0"].append(timeit(ours))
                 so.valor_gemm_set_narrow_sched(1)
                 t["n1"].append(timeit(ours))
                 so.valor_gemm_set_narrow_sched(0)
@@ -94,9 +100,9 @@ def main():
             if v:
                 row[kk + "_us"] = round(v, 1)
                 row[kk + "_TF"] = round(fl / v / 1e6, 1)
-        if med["n0"]:
-            row["n0_over_base"] = round(med["base"] / med["n0"], 3)
-            row["n1_over_base"] = round(med["base"] / med["n1"], 3)
+        for kk in ("base_p", "n0", "n1"):
+            if med[kk]:
+                row[kk + "_over_base"] = round(med["base"] / med[kk], 3)
         res[name] = row
         print(name, row, flush=True)
     json.dump(res, open(sys.argv[1], "w"), indent=1)

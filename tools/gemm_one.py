@@ -3,7 +3,8 @@ import sys
 
 import torch
 
-sys.path.insert(0, ".")
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from valor_amd import kernels as K  # noqa: E402
 
 M, N, Kd, ta, tb = [int(x) for x in sys.argv[1:6]]

@@ -485,7 +485,7 @@ int g_gemm_policy[12] = {[] { const char* e = getenv("VALOR_GEMM_NT_MINK"); retu
                         [] { const char* e = getenv("VALOR_GEMM_STORE"); return e ? atoi(e) : 1000; }(),
                         [] { const char* e = getenv("VALOR_GEMM_NTA"); return e ? atoi(e) : 0; }(),
                         [] { const char* e = getenv("VALOR_GEMM_NN_MINK"); return e ? atoi(e) : 128; }(),
-                        [] { const char* e = getenv("VALOR_GEMM_NARROW"); return e ? atoi(e) : 0; }(), 0, 0, 0};
+                        [] { const char* e = getenv("VALOR_GEMM_NARROW"); return e ? atoi(e) : 1000; }(), 0, 0, 0};
 extern "C" int valor_gemm_set_policy(int key, int value) {
     if (key < 0 || key > 11) return VALOR_ERR_ARG;
     const int old = g_gemm_policy[key];
@@ -511,15 +511,22 @@ static bool use_8ph(int dtype, int transA, int transB, int M, int N, int K, bool
 // the narrow 8-phase kernel (gemm8n.hip), policy key 8
 static bool use_8ph2(int dtype, int transA, int transB, int M, int N, int K, bool heavy_epi, bool big) {
     const int mode = g_gemm_policy[8];
-    if (dtype != VALOR_DT_BF16 || g_gemm_variant < 3 || mode == 0) return false;
+    if (dtype != VALOR_DT_BF16 || g_gemm_variant != 4 || mode == 0) return false;        // (variants 0-3 pin ONE other family)
     if ((K % 64) != 0 || K < 128 || M < 256 || N < 128) return false;
     if (transA && !transB) return false;                     // no caller has this layout at a size that matters
     if (mode == 1) return true;
     if (mode == 2) return !big;
     if (mode == 3) return big;
-    // mode 1000: filled in from tools/gemm_narrow_ab.py
+    // mode 1000, measured per class (tools/gemm_narrow_ab.py, profiles/r04_gemm_narrow_ab_v4.json; pipelined K loops on both sides):
+    //  * everything the policy above leaves to the 128x128 kernels (the 8.8 k / 16.5 k-row decoder and AST problems, short-K dgrads):
+    //    +3 .. +30 % -- twice the tile area per workgroup, a round of 512 slots, epilogues under the other workgroup's K loop;
+    //  * the big-M forward / dgrad problems with K <= 1024 (ViT fc1 / qkv / proj, the cross K|V projection, fc2 dgrad): +3 .. +15 %
+    //    over the 256x256 kernel, whose one workgroup per CU overlaps nothing with its prologue and epilogue;
+    //  * longer contractions stay on the 256x256 kernel (2/3 of the L2 -> LDS bytes per FLOP: 0.93 .. 0.99 here), and so do the wgrads
+    //    (0.82 .. 0.88: split-K slabs of twice as many, half as big tiles).
     (void)heavy_epi;
-    return false;
+    if (transA) return false;
+    return !big || K <= 1024;
 }
 
 // kernel family of a problem: 0 = register-staged 128x128 (also all fp32), 1 / 2 = LDS-DMA 128x128 single / double stage,

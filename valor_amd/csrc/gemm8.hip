@@ -48,7 +48,9 @@ DEVINL bf16x8_t read_frag_tr8(const char* img, int off, int kk) {
 // they drained the counted vmcnt(8) LDS-DMA pipeline three times per K-tile.
 // NTS: non-temporal stores of the bf16 outputs (gemm_common.h store_out16; the launcher picks it for short-K problems).
 // (A non-temporal A operand -- glds16_nt -- was measured too: it lowers the fabric traffic, not the time; profiles/r03_gemm_l2_ab.json.)
-template <bool TA, bool TB, bool ASMTR, bool NTS = false>
+// SCHED 1: software-pipelined K loop (see the loop): no wave-row stagger, two barriers per K-tile, every fragment read and DMA piece between
+// two MFMAs of the half-phase before its consumer -- both waves of a SIMD run the same stream and fill each other's issue gaps.
+template <bool TA, bool TB, bool ASMTR, bool NTS = false, int SCHED = 0>
 __global__ __launch_bounds__(512, 2) void gemm_8ph_kernel(GemmArgs p) {
     typedef bf16_t T;
     constexpr int BK = 64;
@@ -246,6 +248,149 @@ __global__ __launch_bounds__(512, 2) void gemm_8ph_kernel(GemmArgs p) {
     char* const buf1 = smem + BUF_BYTES;
     const int ntile = ks_end - ks_begin;
 
+    if constexpr (SCHED == 1) {
+        if (ntile > 0) {
+            // ---- pipelined schedule. The K-tile is eight half-phases H0..H7 of 8 MFMAs (one quadrant x one 32-k half); register sets
+            // FA0 / FA1 = fa[*][k-half], FB0 = fb0, FB1 = fb1. Tile c lives in buffer c & 1; what tile c leaves is refilled for tile c + 2.
+            //   half  MFMAs (quadrant, k)   refills (reads)                                   DMA (2 pieces per half-tile and wave)
+            //   H0    (A'0,B'0) k0          FB0k1 <- B'0(c) k1, FA1 <- A'0(c) k1
+            //   H1    (A'0,B'0) k1
+            //   (a)   vmcnt(8) [A'1(c) landed], barrier [A'0(c), B'0(c) images dead]
+            //   H2    (A'0,B'1) k0                                                             A'0(c+2), B'0(c+2)
+            //   H3    (A'0,B'1) k1          FA0 <- A'1(c) k0
+            //   H4    (A'1,B'1) k0          FA1 <- A'1(c) k1
+            //   H5    (A'1,B'1) k1                                                             B'1(c+2)   (B'1(c) was read in H6(c-1))
+            //   (b)   vmcnt(8) [A'0, B'0, B'1 of c+1 landed], barrier [A'1(c) image dead]
+            //   H6    (A'1,B'0) k0          FB1 <- B'1(c+1) k0, k1                             A'1(c+2)
+            //   H7    (A'1,B'0) k1          FB0k0 <- B'0(c+1) k0, FA0 <- A'0(c+1) k0
+            // DMA order per tile A'0, B'0, B'1, A'1 (8 pieces per wave), issued two tiles ahead: behind A'1(c) at (a) are the 8 pieces of
+            // tile c+1; behind A'0 / B'0 / B'1 (c+1) at (b) are A'1(c+1) and the 6 pieces issued in H2 / H5. Look-ahead past the last
+            // K-tile goes through a zero-length descriptor (zero fill, no traffic), so the counts hold in the tail.
+            TrPair pb1[2][2];                          // (pb serves FB0)
+            int oA[2][2], oB[2][2];                    // running source offsets [half][piece], bumped right behind the load
+#pragma unroll
+            for (int hf = 0; hf < 2; ++hf)
+#pragma unroll
+                for (int i = 0; i < 2; ++i) { oA[hf][i] = voA[hf][i]; oB[hf][i] = voB[hf][i]; }
+            auto dmaA = [&](int hf, char* buf, int t, int i) {
+                const rsrc_t rs = make_rsrc(p.A, t < ntile ? p.bytesA : 0u);
+                glds16(rs, buf + (hf ? OFF_A1 : OFF_A0) + wave * 2048 + i * 1024, oA[hf][i]);
+                oA[hf][i] += stepA; asm volatile("" : "+v"(oA[hf][i]));
+            };
+            auto dmaB = [&](int hf, char* buf, int t, int i) {
+                const rsrc_t rs = make_rsrc(p.B, t < ntile ? p.bytesB : 0u);
+                glds16(rs, buf + (hf ? OFF_B1 : OFF_B0) + wave * 2048 + i * 1024, oB[hf][i]);
+                oB[hf][i] += stepB; asm volatile("" : "+v"(oB[hf][i]));
+            };
+#define RD_A(IMG_, MT_, KK_)                                                                                      \
+    do {                                                                                                          \
+        if constexpr (TA && ASMTR) tr_issue(pa[MT_][KK_], (IMG_) + trA[MT_] + (KK_) * (32 * 256));                \
+        else if constexpr (TA) fa[MT_][KK_] = read_frag_tr8((IMG_), trA[MT_], (KK_));                             \
+        else fa[MT_][KK_] = read_frag<T>((IMG_), wm * 64 + (MT_) * 16 + fr, (KK_) * 4 + fg);                      \
+    } while (0)
+#define RD_B(IMG_, NT_, KK_, FB_, PB_)                                                                            \
+    do {                                                                                                          \
+        if constexpr (TB && ASMTR) tr_issue(PB_[NT_][KK_], (IMG_) + trB[NT_] + (KK_) * (32 * 256));               \
+        else if constexpr (TB) FB_[NT_][KK_] = read_frag_tr8((IMG_), trB[NT_], (KK_));                            \
+        else FB_[NT_][KK_] = read_frag<T>((IMG_), wn * 32 + (NT_) * 16 + fr, (KK_) * 4 + fg);                     \
+    } while (0)
+#define PIN() __builtin_amdgcn_sched_barrier(0)
+#define USE_A(KK_)                                                                                                \
+    do {                                                                                                          \
+        if constexpr (TA && ASMTR) {                                                                              \
+            tr_wait_4(pa[0][KK_], pa[1][KK_], pa[2][KK_], pa[3][KK_]);                                            \
+            _Pragma("unroll") for (int mt_ = 0; mt_ < 4; ++mt_) fa[mt_][KK_] = tr_frag(pa[mt_][KK_]);             \
+            PIN();                                                                                                \
+        }                                                                                                         \
+    } while (0)
+#define USE_B(KK_, FB_, PB_)                                                                                      \
+    do {                                                                                                          \
+        if constexpr (TB && ASMTR) {                                                                              \
+            tr_wait_2(PB_[0][KK_], PB_[1][KK_]);                                                                  \
+            _Pragma("unroll") for (int nt_ = 0; nt_ < 2; ++nt_) FB_[nt_][KK_] = tr_frag(PB_[nt_][KK_]);           \
+            PIN();                                                                                                \
+        }                                                                                                         \
+    } while (0)
+#define MF(MH_, NH_, MT_, NT_, KK_, FB_)                                                                          \
+    acc[(MH_) * 4 + (MT_)][(NH_) * 2 + (NT_)] = Mma<T>::mma(FB_[NT_][KK_], fa[MT_][KK_], acc[(MH_) * 4 + (MT_)][(NH_) * 2 + (NT_)])
+#define HALF8(MH_, NH_, KK_, FB_, X0, X1, X2, X3, X4, X5, X6, X7)                                               \
+    do {                                                                                                          \
+        MF(MH_, NH_, 0, 0, KK_, FB_); X0; PIN();                                                                  \
+        MF(MH_, NH_, 0, 1, KK_, FB_); X1; PIN();                                                                  \
+        MF(MH_, NH_, 1, 0, KK_, FB_); X2; PIN();                                                                  \
+        MF(MH_, NH_, 1, 1, KK_, FB_); X3; PIN();                                                                  \
+        MF(MH_, NH_, 2, 0, KK_, FB_); X4; PIN();                                                                  \
+        MF(MH_, NH_, 2, 1, KK_, FB_); X5; PIN();                                                                  \
+        MF(MH_, NH_, 3, 0, KK_, FB_); X6; PIN();                                                                  \
+        MF(MH_, NH_, 3, 1, KK_, FB_); X7; PIN();                                                                  \
+    } while (0)
+#define ROWSUM1(H_, KK_)                                                                                          \
+    do {                                                                                                          \
+        if (do_rs) {                                                                                              \
+            if (wn == 0) racc[H_] = Mma<T>::mma(ones, fa[0][KK_], racc[H_]);                                      \
+            else if (wn == 1) racc[H_] = Mma<T>::mma(ones, fa[1][KK_], racc[H_]);                                 \
+            else if (wn == 2) racc[H_] = Mma<T>::mma(ones, fa[2][KK_], racc[H_]);                                 \
+            else racc[H_] = Mma<T>::mma(ones, fa[3][KK_], racc[H_]);                                              \
+            PIN();                                                                                                \
+        }                                                                                                         \
+    } while (0)
+#define WAIT_BARRIER(N_)                                                                                          \
+    do {                                                                                                          \
+        PIN();                                                                                                    \
+        asm volatile("s_waitcnt vmcnt(" #N_ ")" ::: "memory");                                                    \
+        __builtin_amdgcn_s_barrier();                                                                             \
+        PIN();                                                                                                    \
+    } while (0)
+            // prologue: tiles 0 and 1 in the steady-state order; A'0, B'0, B'1 of tile 0 must have landed, 10 pieces may stay in flight
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                char* const b = t ? buf1 : buf0;
+                dmaA(0, b, t, 0); dmaA(0, b, t, 1); dmaB(0, b, t, 0); dmaB(0, b, t, 1);
+                dmaB(1, b, t, 0); dmaB(1, b, t, 1); dmaA(1, b, t, 0); dmaA(1, b, t, 1);
+            }
+            WAIT_BARRIER(10);
+            // what H6 / H7 of a tile before the first would have read
+            RD_B(buf0 + OFF_B1, 0, 0, fb1, pb1); RD_B(buf0 + OFF_B1, 1, 0, fb1, pb1); RD_B(buf0 + OFF_B1, 0, 1, fb1, pb1); RD_B(buf0 + OFF_B1, 1, 1, fb1, pb1);
+            RD_B(buf0 + OFF_B0, 0, 0, fb0, pb); RD_B(buf0 + OFF_B0, 1, 0, fb0, pb);
+            RD_A(buf0 + OFF_A0, 0, 0); RD_A(buf0 + OFF_A0, 1, 0); RD_A(buf0 + OFF_A0, 2, 0); RD_A(buf0 + OFF_A0, 3, 0);
+            PIN();
+            for (int rel = 0; rel < ntile; ++rel) {
+                char* const cur = (rel & 1) ? buf1 : buf0;
+                char* const nxt = (rel & 1) ? buf0 : buf1;
+                USE_A(0); USE_B(0, fb0, pb);
+                HALF8(0, 0, 0, fb0, RD_B(cur + OFF_B0, 0, 1, fb0, pb), RD_B(cur + OFF_B0, 1, 1, fb0, pb), RD_A(cur + OFF_A0, 0, 1), RD_A(cur + OFF_A0, 1, 1),
+                      RD_A(cur + OFF_A0, 2, 1), RD_A(cur + OFF_A0, 3, 1), , );
+                ROWSUM1(0, 0);
+                USE_A(1); USE_B(1, fb0, pb);
+                HALF8(0, 0, 1, fb0, , , , , , , , );
+                ROWSUM1(0, 1);
+                WAIT_BARRIER(8);
+                USE_B(0, fb1, pb1); USE_B(1, fb1, pb1);
+                HALF8(0, 1, 0, fb1, , dmaA(0, cur, rel + 2, 0), , dmaA(0, cur, rel + 2, 1), , dmaB(0, cur, rel + 2, 0), , dmaB(0, cur, rel + 2, 1));
+                HALF8(0, 1, 1, fb1, RD_A(cur + OFF_A1, 0, 0), RD_A(cur + OFF_A1, 1, 0), RD_A(cur + OFF_A1, 2, 0), RD_A(cur + OFF_A1, 3, 0), , , , );
+                USE_A(0);
+                HALF8(1, 1, 0, fb1, RD_A(cur + OFF_A1, 0, 1), RD_A(cur + OFF_A1, 1, 1), RD_A(cur + OFF_A1, 2, 1), RD_A(cur + OFF_A1, 3, 1), , , , );
+                ROWSUM1(1, 0);
+                USE_A(1);
+                HALF8(1, 1, 1, fb1, , , , dmaB(1, cur, rel + 2, 0), , , , dmaB(1, cur, rel + 2, 1));
+                ROWSUM1(1, 1);
+                WAIT_BARRIER(8);
+                HALF8(1, 0, 0, fb0, RD_B(nxt + OFF_B1, 0, 0, fb1, pb1), RD_B(nxt + OFF_B1, 1, 0, fb1, pb1), RD_B(nxt + OFF_B1, 0, 1, fb1, pb1),
+                      RD_B(nxt + OFF_B1, 1, 1, fb1, pb1), , dmaA(1, cur, rel + 2, 0), , dmaA(1, cur, rel + 2, 1));
+                HALF8(1, 0, 1, fb0, RD_B(nxt + OFF_B0, 0, 0, fb0, pb), RD_B(nxt + OFF_B0, 1, 0, fb0, pb), RD_A(nxt + OFF_A0, 0, 0), RD_A(nxt + OFF_A0, 1, 0),
+                      RD_A(nxt + OFF_A0, 2, 0), RD_A(nxt + OFF_A0, 3, 0), , );
+            }
+#undef RD_A
+#undef RD_B
+#undef PIN
+#undef USE_A
+#undef USE_B
+#undef MF
+#undef HALF8
+#undef ROWSUM1
+#undef WAIT_BARRIER
+        }
+    } else
     if (ntile > 0) {
         // prologue = the virtual phases before tile 0: B'0(0) A'0(0) B'1(0) A'1(0) B'0(1) A'0(1); 4 loads may stay in flight
         issueB(0, buf0); issueA(0, buf0); issueB(1, buf0); issueA(1, buf0); issueB(0, buf1); issueA(0, buf1);
@@ -461,6 +606,18 @@ extern "C" int valor_gemm_set_fast_epilogue(int v) {
     return old;
 }
 
+// K-loop schedule of the 256x256 kernel: 0 = eight barriers per K-tile with the wave rows staggered, 1 = software-pipelined (two barriers);
+// VALOR_GEMM_8PH_SCHED presets it
+// 1000 (default) = per problem: pipelined for forward / dgrad contractions of K >= 2048 (+4 .. +11 % on the K = 2304 / 3072 ViT shapes, 0.94 ..
+// 1.0 at K = 768 / 1536) and for wgrads whose K-slices are short (<= 48 K-tiles per workgroup: +2 .. +6 % on the decoder / AST wgrads; the
+// 225-tile slices of the ViT wgrads run 0.88 .. 0.93 pipelined) -- profiles/r04_gemm_narrow_ab_v4.json
+static int g_8ph_sched = [] { const char* e = getenv("VALOR_GEMM_8PH_SCHED"); return e ? atoi(e) : 1000; }();
+extern "C" int valor_gemm_set_8ph_sched(int v) {
+    const int old = g_8ph_sched;
+    if (v == 0 || v == 1 || v == 1000) g_8ph_sched = v;
+    return old;
+}
+
 void launch_gemm_8ph(hipStream_t st, int transA, int transB, const GemmArgs& p_in) {
     GemmArgs p = p_in;
     // measured (profiles/r02_gemm_epilogue_ab.json): the bf16 tile epilogue wins 1-5 % on plain / bias / activation / C += problems,
@@ -498,15 +655,23 @@ void launch_gemm_8ph(hipStream_t st, int transA, int transB, const GemmArgs& p_i
     p.st_mode = nts ? 1 : 0;
     dim3 grid(tiles * (p.kslices > 1 ? p.kslices : 1));
     const size_t lds = 2 * BUF_BYTES;
+    int sched = g_8ph_sched;
+    if (sched == 1000) {
+        const int ktiles = p.kslices > 1 ? p.ksteps_per_slice : p.K / 64;
+        sched = transA ? (ktiles <= 48 ? 1 : 0) : (p.K >= 2048 ? 1 : 0);
+    }
 #define VALOR_8PH_LAUNCH(TA_, TB_, NTS_)                                                                        \
     do {                                                                                                        \
         static bool attr_set = false;                                                                           \
+        constexpr bool kslow_ = TA_ || TB_;                                                                     \
         if (!attr_set) {                                                                                        \
             hipFuncSetAttribute((const void*)gemm_8ph_kernel<TA_, TB_, false, NTS_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
             hipFuncSetAttribute((const void*)gemm_8ph_kernel<TA_, TB_, true, NTS_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+            hipFuncSetAttribute((const void*)gemm_8ph_kernel<TA_, TB_, kslow_, NTS_, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
             attr_set = true;                                                                                    \
         }                                                                                                       \
-        if (g_8ph_tr_asm && (TA_ || TB_)) hipLaunchKernelGGL((gemm_8ph_kernel<TA_, TB_, true, NTS_>), grid, dim3(512), lds, st, p); \
+        if (sched == 1 && (g_8ph_tr_asm || !kslow_)) hipLaunchKernelGGL((gemm_8ph_kernel<TA_, TB_, kslow_, NTS_, 1>), grid, dim3(512), lds, st, p); \
+        else if (g_8ph_tr_asm && kslow_) hipLaunchKernelGGL((gemm_8ph_kernel<TA_, TB_, true, NTS_>), grid, dim3(512), lds, st, p); \
         else hipLaunchKernelGGL((gemm_8ph_kernel<TA_, TB_, false, NTS_>), grid, dim3(512), lds, st, p);       \
     } while (0)
     if (!transA && !transB) { if (nts) VALOR_8PH_LAUNCH(false, false, true); else VALOR_8PH_LAUNCH(false, false, false); }

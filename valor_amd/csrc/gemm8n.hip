@@ -21,8 +21,10 @@
 // RAW: a slot is read one phase after the counted wait that retires it (own vmcnt + a barrier every reader has passed).
 // WAR: a slot is re-filled two phases after its last read. Look-ahead past the last K-tile goes through a zero-length buffer
 // descriptor (range check -> zeros, no memory traffic), so the load COUNT per phase -- which the vmcnt immediates rely on -- is constant.
-// SCHED 0: one barrier per phase (LOAD_END), all four waves in step: the partner wave of every SIMD is the OTHER workgroup's.
-// SCHED 1: two barriers per phase and the second wave row one barrier late (the 256x256 kernel's alternation, inside a workgroup).
+// SCHED 0: the schedule above, one barrier per phase, all four waves in step: the partner wave of every SIMD is the OTHER workgroup's.
+// SCHED 1: software-pipelined (see the loop): reads and DMA pieces between the MFMAs of the half-phase before their consumer, two
+// barriers per K-tile. (Two barriers per phase with the second wave row one barrier late -- the 256x256 kernel's alternation inside
+// a workgroup -- measured 3-10 % slower than SCHED 0 on every shape: profiles/r04_gemm_narrow_ab_v1.json.)
 //
 // Image formats, fragment reads, epilogues, split-K partials and fused row sums are those of gemm8.hip at this tile geometry.
 // Requirements: K % 64 == 0, M >= 256, N >= 128 (otherwise valor_gemm uses the 128x128 kernels).
@@ -85,6 +87,18 @@ __global__ __launch_bounds__(256, 2) void gemm_8ph2_kernel(GemmArgs p) {
     const int k_first = ks_begin * BK;
     const int ntile = ks_end - ks_begin;
 
+#ifdef N8_STAMP
+    // diagnostic build only (tools/gemm_stamp.py): cycle stamps of every wave into p.ws as [block][wave][24] uint64
+    // ([0..4] kernel start / first operands landed / K loop done / drained / stores done, [5] HW_ID, [6] XCC_ID, [8..19] inside K-tile 5
+    // of the pipelined schedule: H0 H1 wait barrier H2 H3 H4 H5 wait barrier H6 H7 boundaries)
+    uint64_t stamp_[5], hs_[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    stamp_[0] = __builtin_amdgcn_s_memtime();
+#define N8_STAMP_AT(i) stamp_[i] = __builtin_amdgcn_s_memtime()
+#define N8_HSTAMP(i) do { if (rel == 5) hs_[i] = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
+#define N8_STAMP_AT(i)
+#define N8_HSTAMP(i)
+#endif
     f32x4_t acc[8][4];   // [mh*4+mt][nh*2+nt]
 #pragma unroll
     for (int i = 0; i < 8; ++i)
@@ -164,145 +178,263 @@ __global__ __launch_bounds__(256, 2) void gemm_8ph2_kernel(GemmArgs p) {
             for (int i = 0; i < 2; ++i) trB[h][i] = base + 16 * ((2 * (h * 4 + wn * 2 + i) + ((fr >> 1) & 1) + rot) & 15);
     }
     bf16x8_t fa[4][2], fb0[2][2], fb1[2][2];   // [tile][kk]
-    TrPair pa[4][2], pb[2][2];                 // ASMTR: transposing reads in flight (halves)
-    auto readA = [&](const char* img) {
-#pragma unroll
-        for (int mt = 0; mt < 4; ++mt)
-#pragma unroll
-            for (int kk = 0; kk < 2; ++kk) {
-                if constexpr (TA && ASMTR) tr_issue(pa[mt][kk], img + trA[mt] + kk * (32 * 256));
-                else if constexpr (TA) fa[mt][kk] = n8_read_frag_tr8(img, trA[mt], kk);
-                else fa[mt][kk] = read_frag<T>(img, wm * 64 + mt * 16 + fr, kk * 4 + fg);
-            }
-    };
-    auto readB = [&](const char* img, int nh, bf16x8_t (&fb)[2][2]) {
-#pragma unroll
-        for (int nt = 0; nt < 2; ++nt)
-#pragma unroll
-            for (int kk = 0; kk < 2; ++kk) {
-                if constexpr (TB && ASMTR) tr_issue(pb[nt][kk], img + trB[nh][nt] + kk * (32 * 256));
-                else if constexpr (TB) fb[nt][kk] = n8_read_frag_tr8(img, trB[nh][nt], kk);
-                else fb[nt][kk] = read_frag<T>(img, nh * 64 + wn * 32 + nt * 16 + fr, kk * 4 + fg);
-            }
-    };
-    auto fragA = [&]() {
-        if constexpr (TA && ASMTR) {
-            tr_wait8(pa);
-#pragma unroll
-            for (int mt = 0; mt < 4; ++mt)
-#pragma unroll
-                for (int kk = 0; kk < 2; ++kk) fa[mt][kk] = tr_frag(pa[mt][kk]);
-        }
-    };
-    auto fragB = [&](bf16x8_t (&fb)[2][2]) {
-        if constexpr (TB && ASMTR) {
-            tr_wait4(pb);
-#pragma unroll
-            for (int nt = 0; nt < 2; ++nt)
-#pragma unroll
-                for (int kk = 0; kk < 2; ++kk) fb[nt][kk] = tr_frag(pb[nt][kk]);
-        }
-    };
-#define QUADRANT(MH_, NH_, FB_)                                                                                   \
+    TrPair pa[4][2], pb0[2][2], pb1[2][2];     // ASMTR: transposing reads in flight (halves)
+    // one fragment: A'h image `img`, 16-row block mt, k-half kk -> fa[mt][kk]; B image `img`, column half nh, block nt -> fb[nt][kk]
+#define RD_A(IMG_, MT_, KK_)                                                                                      \
     do {                                                                                                          \
-        __builtin_amdgcn_s_setprio(1);                                                                            \
-        _Pragma("unroll") for (int kk = 0; kk < 2; ++kk)                                                          \
-            _Pragma("unroll") for (int mt = 0; mt < 4; ++mt)                                                      \
-                _Pragma("unroll") for (int nt = 0; nt < 2; ++nt)                                                  \
-                    acc[(MH_) * 4 + mt][(NH_) * 2 + nt] = Mma<T>::mma(FB_[nt][kk], fa[mt][kk], acc[(MH_) * 4 + mt][(NH_) * 2 + nt]); \
-        __builtin_amdgcn_s_setprio(0);                                                                            \
+        if constexpr (TA && ASMTR) tr_issue(pa[MT_][KK_], (IMG_) + trA[MT_] + (KK_) * (32 * 256));                \
+        else if constexpr (TA) fa[MT_][KK_] = n8_read_frag_tr8((IMG_), trA[MT_], (KK_));                          \
+        else fa[MT_][KK_] = read_frag<T>((IMG_), wm * 64 + (MT_) * 16 + fr, (KK_) * 4 + fg);                      \
     } while (0)
-#define ROWSUM(H_)                                                                                                \
+#define RD_B(IMG_, NH_, NT_, KK_, FB_, PB_)                                                                       \
+    do {                                                                                                          \
+        if constexpr (TB && ASMTR) tr_issue(PB_[NT_][KK_], (IMG_) + trB[NH_][NT_] + (KK_) * (32 * 256));          \
+        else if constexpr (TB) FB_[NT_][KK_] = n8_read_frag_tr8((IMG_), trB[NH_][NT_], (KK_));                    \
+        else FB_[NT_][KK_] = read_frag<T>((IMG_), (NH_) * 64 + wn * 32 + (NT_) * 16 + fr, (KK_) * 4 + fg);        \
+    } while (0)
+    // first use of freshly read fragments: the asm reads need their own wait (and become fragments), the compiler counts its own
+#define USE_A(KK_)                                                                                                \
+    do {                                                                                                          \
+        if constexpr (TA && ASMTR) {                                                                              \
+            tr_wait_4(pa[0][KK_], pa[1][KK_], pa[2][KK_], pa[3][KK_]);                                            \
+            _Pragma("unroll") for (int mt_ = 0; mt_ < 4; ++mt_) fa[mt_][KK_] = tr_frag(pa[mt_][KK_]);             \
+            __builtin_amdgcn_sched_barrier(0);                                                                    \
+        }                                                                                                         \
+    } while (0)
+#define USE_B(KK_, FB_, PB_)                                                                                      \
+    do {                                                                                                          \
+        if constexpr (TB && ASMTR) {                                                                              \
+            tr_wait_2(PB_[0][KK_], PB_[1][KK_]);                                                                  \
+            _Pragma("unroll") for (int nt_ = 0; nt_ < 2; ++nt_) FB_[nt_][KK_] = tr_frag(PB_[nt_][KK_]);           \
+            __builtin_amdgcn_sched_barrier(0);                                                                    \
+        }                                                                                                         \
+    } while (0)
+#define MF(MH_, NH_, MT_, NT_, KK_, FB_)                                                                          \
+    acc[(MH_) * 4 + (MT_)][(NH_) * 2 + (NT_)] = Mma<T>::mma(FB_[NT_][KK_], fa[MT_][KK_], acc[(MH_) * 4 + (MT_)][(NH_) * 2 + (NT_)])
+#define PIN() __builtin_amdgcn_sched_barrier(0)
+    // row sums (tile column 0 of a k-slow-A problem): blocks mt = 2 wn, 2 wn + 1 of row half H_, k-half KK_
+#define ROWSUM(H_, KK_)                                                                                           \
     do {                                                                                                          \
         if (do_rs) {                                                                                              \
             if (wn == 0) {      /* wave-uniform branch: a select between fragments becomes a scratch-indexed array */       \
-                _Pragma("unroll") for (int kk = 0; kk < 2; ++kk) {                                                \
-                    racc[H_][0] = Mma<T>::mma(ones, fa[0][kk], racc[H_][0]);                                      \
-                    racc[H_][1] = Mma<T>::mma(ones, fa[1][kk], racc[H_][1]);                                      \
-                }                                                                                                 \
+                racc[H_][0] = Mma<T>::mma(ones, fa[0][KK_], racc[H_][0]);                                         \
+                racc[H_][1] = Mma<T>::mma(ones, fa[1][KK_], racc[H_][1]);                                         \
             } else {                                                                                              \
-                _Pragma("unroll") for (int kk = 0; kk < 2; ++kk) {                                                \
-                    racc[H_][0] = Mma<T>::mma(ones, fa[2][kk], racc[H_][0]);                                      \
-                    racc[H_][1] = Mma<T>::mma(ones, fa[3][kk], racc[H_][1]);                                      \
-                }                                                                                                 \
+                racc[H_][0] = Mma<T>::mma(ones, fa[2][KK_], racc[H_][0]);                                         \
+                racc[H_][1] = Mma<T>::mma(ones, fa[3][KK_], racc[H_][1]);                                         \
             }                                                                                                     \
+            PIN();                                                                                                \
         }                                                                                                         \
     } while (0)
-#define LOAD_END_WAIT()                                                                                           \
+#define WAIT8_BARRIER()                                                                                           \
     do {                                                                                                          \
+        PIN();                                                                                                    \
         asm volatile("s_waitcnt vmcnt(8)" ::: "memory");                                                          \
         __builtin_amdgcn_s_barrier();                                                                             \
-        __builtin_amdgcn_sched_barrier(0);                                                                        \
-    } while (0)
-#define LOAD_END()                                                                                                \
-    do {                                                                                                          \
-        __builtin_amdgcn_sched_barrier(0);                                                                        \
-        __builtin_amdgcn_s_barrier();                                                                             \
-        __builtin_amdgcn_sched_barrier(0);                                                                        \
-    } while (0)
-#define MATH_END()                                                                                                \
-    do {                                                                                                          \
-        __builtin_amdgcn_sched_barrier(0);                                                                        \
-        if constexpr (SCHED == 1) {                                                                               \
-            __builtin_amdgcn_s_barrier();                                                                         \
-            __builtin_amdgcn_sched_barrier(0);                                                                    \
-        }                                                                                                         \
+        PIN();                                                                                                    \
     } while (0)
 
     char* const bufB0 = smem + N8_OFF_B;
     char* const bufB1 = smem + N8_OFF_B + N8_HT;
 
     if (ntile > 0) {
-        // prologue = the virtual phases before tile 0: B(0) A'0(0) A'1(0) B(1); the last two may stay in flight
+        // prologue = the DMA the steady state issues before tile 0: B(0) A'0(0) | A'1(0) B(1); the last two stay in flight
         issueB(bufB0, 0); issueA(0, smem, 0); issueA(1, smem + N8_HT, 0); issueB(bufB1, 1);
-        LOAD_END_WAIT();
-        if constexpr (SCHED == 1) { if (wm == 1) __builtin_amdgcn_s_barrier(); }     // second wave row runs one barrier late
+        WAIT8_BARRIER();
+        N8_STAMP_AT(1);
         int sa0 = 0;                                     // ring slot of A'0(rel)
-        for (int rel = 0; rel < ntile; ++rel) {
-            const int sa1 = sa0 == 2 ? 0 : sa0 + 1, sa2 = sa1 == 2 ? 0 : sa1 + 1;
-            char* const a0 = smem + sa0 * N8_HT;
-            char* const a1 = smem + sa1 * N8_HT;
-            char* const a2 = smem + sa2 * N8_HT;
-            char* const bcur = (rel & 1) ? bufB1 : bufB0;
-            // ---- j0
-            readB(bcur, 0, fb0);
-            readA(a0);
-            issueA(0, a2, rel + 1);
-            LOAD_END();
-            fragB(fb0); fragA();
-            QUADRANT(0, 0, fb0);
-            ROWSUM(0);
-            MATH_END();
-            // ---- j1
-            readB(bcur, 1, fb1);
-            LOAD_END_WAIT();
-            fragB(fb1);
-            QUADRANT(0, 1, fb1);
-            MATH_END();
-            // ---- j2
-            readA(a1);
-            issueA(1, a0, rel + 1);
-            LOAD_END();
-            fragA();
-            QUADRANT(1, 1, fb1);
-            ROWSUM(1);
-            MATH_END();
-            // ---- j3
-            issueB(bcur, rel + 2);
-            LOAD_END_WAIT();
-            QUADRANT(1, 0, fb0);
-            MATH_END();
-            sa0 = sa2;
+        if constexpr (SCHED == 0) {
+            // ---- plain schedule: LOAD segment (reads of the phase, DMA issue, counted wait), barrier, MATH segment (16 MFMAs); 4 barriers
+            // per K-tile. j0: A'0(c+1) -> the slot A'1(c-1) left at j2(c-1); j2: A'1(c+1) -> the slot A'0(c) left at j0(c); j3: B(c+2)
+            // -> the buffer B(c) left at j1(c); waits j1: A'1(c) (behind it B(c+1), A'0(c+1)), j3: B(c+1), A'0(c+1).
+            for (int rel = 0; rel < ntile; ++rel) {
+                const int sa1 = sa0 == 2 ? 0 : sa0 + 1, sa2 = sa1 == 2 ? 0 : sa1 + 1;
+                char* const a0 = smem + sa0 * N8_HT;
+                char* const a1 = smem + sa1 * N8_HT;
+                char* const a2 = smem + sa2 * N8_HT;
+                char* const bcur = (rel & 1) ? bufB1 : bufB0;
+#define QUADRANT(MH_, NH_, FB_)                                                                                   \
+    do {                                                                                                          \
+        __builtin_amdgcn_s_setprio(1);                                                                            \
+        _Pragma("unroll") for (int kk = 0; kk < 2; ++kk)                                                          \
+            _Pragma("unroll") for (int mt = 0; mt < 4; ++mt)                                                      \
+                _Pragma("unroll") for (int nt = 0; nt < 2; ++nt) MF(MH_, NH_, mt, nt, kk, FB_);                   \
+        __builtin_amdgcn_s_setprio(0);                                                                            \
+        PIN();                                                                                                    \
+    } while (0)
+                // ---- j0
+                _Pragma("unroll") for (int nt = 0; nt < 2; ++nt) _Pragma("unroll") for (int kk = 0; kk < 2; ++kk) RD_B(bcur, 0, nt, kk, fb0, pb0);
+                _Pragma("unroll") for (int mt = 0; mt < 4; ++mt) _Pragma("unroll") for (int kk = 0; kk < 2; ++kk) RD_A(a0, mt, kk);
+                issueA(0, a2, rel + 1);
+                PIN(); __builtin_amdgcn_s_barrier(); PIN();
+                USE_B(0, fb0, pb0); USE_B(1, fb0, pb0); USE_A(0); USE_A(1);
+                QUADRANT(0, 0, fb0);
+                ROWSUM(0, 0); ROWSUM(0, 1);
+                // ---- j1
+                _Pragma("unroll") for (int nt = 0; nt < 2; ++nt) _Pragma("unroll") for (int kk = 0; kk < 2; ++kk) RD_B(bcur, 1, nt, kk, fb1, pb1);
+                WAIT8_BARRIER();
+                USE_B(0, fb1, pb1); USE_B(1, fb1, pb1);
+                QUADRANT(0, 1, fb1);
+                // ---- j2
+                _Pragma("unroll") for (int mt = 0; mt < 4; ++mt) _Pragma("unroll") for (int kk = 0; kk < 2; ++kk) RD_A(a1, mt, kk);
+                issueA(1, a0, rel + 1);
+                PIN(); __builtin_amdgcn_s_barrier(); PIN();
+                USE_A(0); USE_A(1);
+                QUADRANT(1, 1, fb1);
+                ROWSUM(1, 0); ROWSUM(1, 1);
+                // ---- j3
+                issueB(bcur, rel + 2);
+                WAIT8_BARRIER();
+                QUADRANT(1, 0, fb0);
+                sa0 = sa2;
+#undef QUADRANT
+            }
+        } else {
+            // ---- pipelined schedule: the K-tile is eight half-phases H0..H7 of 8 MFMAs (one 64x32 quadrant x one 32-k half), ordered so
+            // that every register set rests one whole half-phase between its refill and its first use, and every fragment read / DMA
+            // piece sits between two MFMAs. Register sets: FA0 / FA1 = fa[*][k-half], FB0k0, FB0k1, FB1k0, FB1k1. Two barriers per K-tile.
+            //   half  MFMAs (quadrant, k)   operands          refills (reads)                              DMA pieces
+            //   H0    (A'0,B'0) k0          FA0  FB0k0        FB0k1 <- B'0(c) k1, FA1 <- A'0(c) k1
+            //   H1    (A'0,B'1) k0          FA0  FB1k0
+            //   (a)   lgkmcnt(0), vmcnt(8) [A'1(c) landed], barrier [A'0(c), B(c) images dead]
+            //   H2    (A'0,B'1) k1          FA1  FB1k1        FA0 <- A'1(c) k0                             A'1(c+1) 0-1 -> slot of A'0(c)
+            //   H3    (A'0,B'0) k1          FA1  FB0k1                                                     A'1(c+1) 2-3, B(c+2) 0-1 -> buffer of B(c)
+            //   H4    (A'1,B'0) k0          FA0  FB0k0        FA1 <- A'1(c) k1                             B(c+2) 2-3
+            //   (b)   lgkmcnt(0), vmcnt(8) [B(c+1), A'0(c+1) landed], barrier [A'1(c) image dead]
+            //   H5    (A'1,B'1) k0          FA0  FB1k0        FB0k0 <- B'0(c+1) k0                         A'0(c+2) 0-3 -> slot of A'1(c)
+            //   H6    (A'1,B'1) k1          FA1  FB1k1        FB1k0 <- B'1(c+1) k0, FA0 <- A'0(c+1) k0
+            //   H7    (A'1,B'0) k1          FA1  FB0k1        FB1k1 <- B'1(c+1) k1
+            // Every accumulator still receives its k0 product before its k1 product: results are bit-identical to the plain schedule.
+            // DMA order A'1(c+1), B(c+2), A'0(c+2), each a whole K-tile ahead of its wait: behind A'1(c) at (a) are B(c+1), A'0(c+1);
+            // behind B(c+1), A'0(c+1) at (b) are A'1(c+1), B(c+2). RAW: reads follow the barrier behind the wait that retires their
+            // image. WAR: an image is refilled behind a barrier in front of which every wave waited for its own LDS reads (lgkmcnt(0)).
+            int oA0[4], oA1[4], oB[4];      // running per-piece source offsets of the next A'0 / A'1 / B to issue, bumped right behind the
+#pragma unroll                              // load (the empty asm pins the add there, in the shadow of the same MFMA)
+            for (int i = 0; i < 4; ++i) {
+                oA0[i] = vA[i >> 1] + (2 * stepA + i * pieceA);
+                oA1[i] = vA[i >> 1] + (stepA + halfA + i * pieceA);
+                oB[i] = vB[i >> 1] + (2 * stepB + i * pieceB);
+            }
+            auto dmaA = [&](int hf, char* slot, int t, int i) {
+                const rsrc_t rs = make_rsrc(p.A, t < ntile ? p.bytesA : 0u);
+                if (hf == 0) { glds16(rs, slot + wave * 4096 + i * 1024, oA0[i]); oA0[i] += stepA; asm volatile("" : "+v"(oA0[i])); }
+                else { glds16(rs, slot + wave * 4096 + i * 1024, oA1[i]); oA1[i] += stepA; asm volatile("" : "+v"(oA1[i])); }
+            };
+            auto dmaB = [&](char* buf, int t, int i) {
+                const rsrc_t rs = make_rsrc(p.B, t < ntile ? p.bytesB : 0u);
+                glds16(rs, buf + wave * 4096 + i * 1024, oB[i]); oB[i] += stepB; asm volatile("" : "+v"(oB[i]));
+            };
+#define HALF8(MH_, NH_, KK_, FB_, X0, X1, X2, X3, X4, X5, X6, X7)                                               \
+    do {                                                                                                          \
+        MF(MH_, NH_, 0, 0, KK_, FB_); X0; PIN();                                                                  \
+        MF(MH_, NH_, 0, 1, KK_, FB_); X1; PIN();                                                                  \
+        MF(MH_, NH_, 1, 0, KK_, FB_); X2; PIN();                                                                  \
+        MF(MH_, NH_, 1, 1, KK_, FB_); X3; PIN();                                                                  \
+        MF(MH_, NH_, 2, 0, KK_, FB_); X4; PIN();                                                                  \
+        MF(MH_, NH_, 2, 1, KK_, FB_); X5; PIN();                                                                  \
+        MF(MH_, NH_, 3, 0, KK_, FB_); X6; PIN();                                                                  \
+        MF(MH_, NH_, 3, 1, KK_, FB_); X7; PIN();                                                                  \
+    } while (0)
+#define LGKM_WAIT8_BARRIER()                                                                                      \
+    do {                                                                                                          \
+        PIN();                                                                                                    \
+        asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");                                               \
+        __builtin_amdgcn_s_barrier();                                                                             \
+        PIN();                                                                                                    \
+    } while (0)
+            // the fifth prologue group (what H5 of a tile before the first would have issued), then what its H5..H7 would have read
+            issueA(0, smem + 2 * N8_HT, 1);
+            RD_B(bufB0, 0, 0, 0, fb0, pb0); RD_B(bufB0, 0, 1, 0, fb0, pb0);
+            RD_B(bufB0, 1, 0, 0, fb1, pb1); RD_B(bufB0, 1, 1, 0, fb1, pb1);
+            RD_A(smem, 0, 0); RD_A(smem, 1, 0); RD_A(smem, 2, 0); RD_A(smem, 3, 0);
+            RD_B(bufB0, 1, 0, 1, fb1, pb1); RD_B(bufB0, 1, 1, 1, fb1, pb1);
+            PIN();
+#ifdef N8_ABLATE        // diagnostic builds (tools/build_stamp_lib.sh): bit 0 = no DMA in the pipelined loop, bit 1 = no fragment reads in it
+#if N8_ABLATE & 1
+#define dmaA(...) do {} while (0)
+#define dmaB(...) do {} while (0)
+#endif
+#if N8_ABLATE & 2
+#undef RD_A
+#undef RD_B
+#define RD_A(...) do {} while (0)
+#define RD_B(...) do {} while (0)
+#endif
+#endif
+            for (int rel = 0; rel < ntile; ++rel) {
+                const int sa1 = sa0 == 2 ? 0 : sa0 + 1, sa2 = sa1 == 2 ? 0 : sa1 + 1;
+                char* const a0 = smem + sa0 * N8_HT;         // A'0(c); refilled with A'1(c+1)
+                char* const a1 = smem + sa1 * N8_HT;         // A'1(c); refilled with A'0(c+2)
+                char* const a2 = smem + sa2 * N8_HT;         // A'0(c+1)
+                char* const bcur = (rel & 1) ? bufB1 : bufB0;
+                char* const bnxt = (rel & 1) ? bufB0 : bufB1;
+                N8_HSTAMP(0);
+                USE_A(0); USE_B(0, fb0, pb0);
+                HALF8(0, 0, 0, fb0, RD_B(bcur, 0, 0, 1, fb0, pb0), RD_B(bcur, 0, 1, 1, fb0, pb0), RD_A(a0, 0, 1), RD_A(a0, 1, 1), RD_A(a0, 2, 1),
+                      RD_A(a0, 3, 1), , );
+                N8_HSTAMP(1);
+                USE_B(0, fb1, pb1);
+                HALF8(0, 1, 0, fb1, , , , , , , , );
+                ROWSUM(0, 0);
+                N8_HSTAMP(2);
+                LGKM_WAIT8_BARRIER();
+                N8_HSTAMP(3);
+                USE_A(1); USE_B(1, fb1, pb1);
+                HALF8(0, 1, 1, fb1, RD_A(a1, 0, 0), RD_A(a1, 1, 0), RD_A(a1, 2, 0), RD_A(a1, 3, 0), , dmaA(1, a0, rel + 1, 0), , dmaA(1, a0, rel + 1, 1));
+                N8_HSTAMP(4);
+                USE_B(1, fb0, pb0);
+                HALF8(0, 0, 1, fb0, , dmaA(1, a0, rel + 1, 2), , dmaA(1, a0, rel + 1, 3), , dmaB(bcur, rel + 2, 0), , dmaB(bcur, rel + 2, 1));
+                ROWSUM(0, 1);
+                N8_HSTAMP(5);
+                USE_A(0);
+                HALF8(1, 0, 0, fb0, RD_A(a1, 0, 1), RD_A(a1, 1, 1), RD_A(a1, 2, 1), RD_A(a1, 3, 1), , dmaB(bcur, rel + 2, 2), , dmaB(bcur, rel + 2, 3));
+                ROWSUM(1, 0);
+                N8_HSTAMP(6);
+                LGKM_WAIT8_BARRIER();
+                N8_HSTAMP(7);
+                HALF8(1, 1, 0, fb1, RD_B(bnxt, 0, 0, 0, fb0, pb0), RD_B(bnxt, 0, 1, 0, fb0, pb0), , dmaA(0, a1, rel + 2, 0), dmaA(0, a1, rel + 2, 1), ,
+                      dmaA(0, a1, rel + 2, 2), dmaA(0, a1, rel + 2, 3));
+                N8_HSTAMP(8);
+                USE_A(1);
+                HALF8(1, 1, 1, fb1, RD_B(bnxt, 1, 0, 0, fb1, pb1), RD_B(bnxt, 1, 1, 0, fb1, pb1), RD_A(a2, 0, 0), RD_A(a2, 1, 0), RD_A(a2, 2, 0),
+                      RD_A(a2, 3, 0), , );
+                ROWSUM(1, 1);
+                N8_HSTAMP(9);
+                HALF8(1, 0, 1, fb0, RD_B(bnxt, 1, 0, 1, fb1, pb1), RD_B(bnxt, 1, 1, 1, fb1, pb1), , , , , , );
+                N8_HSTAMP(10);
+                sa0 = sa2;
+            }
+#undef HALF8
+#undef LGKM_WAIT8_BARRIER
         }
-        if constexpr (SCHED == 1) { if (wm == 0) __builtin_amdgcn_s_barrier(); }
     }
+    N8_STAMP_AT(2);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the zero-length look-ahead loads still write LDS: drain before it is reused
     __syncthreads();
-#undef QUADRANT
+    N8_STAMP_AT(3);
+#ifdef N8_STAMP
+    auto stamp_out = [&]() {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        stamp_[4] = __builtin_amdgcn_s_memtime();
+        if (lane == 0 && !TA && p.kslices <= 1) {
+            uint64_t* o = (uint64_t*)p.ws + ((int64_t)blockIdx.x * 4 + wave) * 24;
+            for (int i = 0; i < 5; ++i) o[i] = stamp_[i];
+            for (int i = 0; i < 12; ++i) o[8 + i] = hs_[i];
+            o[5] = __builtin_amdgcn_s_getreg((31 << 11) | 4);       // HW_ID
+            o[6] = __builtin_amdgcn_s_getreg((31 << 11) | 20);      // XCC_ID
+        }
+    };
+#else
+    auto stamp_out = [&]() {};
+#endif
+#undef RD_A
+#undef RD_B
+#undef USE_A
+#undef USE_B
+#undef MF
+#undef PIN
 #undef ROWSUM
-#undef LOAD_END
-#undef LOAD_END_WAIT
-#undef MATH_END
+#undef WAIT8_BARRIER
     if (do_rs && fg == 0) {     // racc[h][j][*] = sum_k A(m, k) for m = m0 + 128h + 64wm + 16(2wn + j) + fr
 #pragma unroll
         for (int hh = 0; hh < 2; ++hh)
@@ -406,10 +538,12 @@ __global__ __launch_bounds__(256, 2) void gemm_8ph2_kernel(GemmArgs p) {
                     store_out16<NTS>(dst + (int64_t)m * p.ldc + n, val);
                 }
             }
+            stamp_out();
             return;
         }
         __syncthreads();
         read_tile((T*)p.C);
+        stamp_out();
         return;
     }
 
@@ -444,10 +578,11 @@ __global__ __launch_bounds__(256, 2) void gemm_8ph2_kernel(GemmArgs p) {
             }
         }
     }
+    stamp_out();
 }
 
 // schedule of the narrow kernel (see SCHED above); VALOR_GEMM_N8_SCHED=0/1 presets it for A/B runs
-static int g_8ph2_sched = [] { const char* e = getenv("VALOR_GEMM_N8_SCHED"); return e ? atoi(e) : 0; }();
+static int g_8ph2_sched = [] { const char* e = getenv("VALOR_GEMM_N8_SCHED"); return e ? atoi(e) : 1; }();
 extern "C" int valor_gemm_set_narrow_sched(int v) {
     const int old = g_8ph2_sched;
     if (v == 0 || v == 1) g_8ph2_sched = v;

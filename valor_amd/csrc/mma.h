@@ -423,6 +423,8 @@ DEVINL bf16x8_t tr_frag(const TrPair& t) {
 DEVINL void tr_wait4(TrPair (&t)[2][2]) {
     asm volatile("s_waitcnt lgkmcnt(0)" : TR_TIE(t[0][0]), TR_TIE(t[0][1]), TR_TIE(t[1][0]), TR_TIE(t[1][1]));
 }
+DEVINL void tr_wait_2(TrPair& a, TrPair& b) { asm volatile("s_waitcnt lgkmcnt(0)" : TR_TIE(a), TR_TIE(b)); }
+DEVINL void tr_wait_4(TrPair& a, TrPair& b, TrPair& c, TrPair& d) { asm volatile("s_waitcnt lgkmcnt(0)" : TR_TIE(a), TR_TIE(b), TR_TIE(c), TR_TIE(d)); }
 DEVINL void tr_wait8(TrPair (&t)[4][2]) {
     asm volatile("s_waitcnt lgkmcnt(0)" : TR_TIE(t[0][0]), TR_TIE(t[0][1]), TR_TIE(t[1][0]), TR_TIE(t[1][1]), TR_TIE(t[2][0]),
                  TR_TIE(t[2][1]), TR_TIE(t[3][0]), TR_TIE(t[3][1]));

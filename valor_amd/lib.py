@@ -29,6 +29,7 @@ SIGNATURES = {
     "valor_gemm_set_tr_asm": [_i],
     "valor_gemm_set_fast_epilogue": [_i],
     "valor_gemm_set_policy": [_i, _i],
+    "valor_gemm_set_8ph_sched": [_i],
     "valor_gemm_set_narrow_sched": [_i],
     "valor_gemm_narrow_occupancy": [],
     "valor_ln_part_blocks": [],
