@@ -5,7 +5,7 @@ policy's thresholds and the kernel-variant tests force the family on single-roun
 kernels to a reference (round-2 review, weak point 1.iii).
 
 Checks per case: the kernel family the policy picks (4 = 256 x 128 two-workgroups-per-CU 8-phase for forward / dgrad contractions of K <=
-1024, 3 = 256 x 256 8-phase for longer ones and the wgrads; tests/test_gemm_narrow_gpu.py forces family 4 onto everything else), the
+1024 into N >= 1536, 3 = 256 x 256 8-phase for longer ones, narrow outputs and the wgrads; tests/test_gemm_narrow_gpu.py forces family 4 onto everything else), the
 Frobenius error of the whole result, and the error of EVERY 256 x 256 output block on its own (a mis-rastered / dropped / duplicated tile
 is invisible in a 4728-tile Frobenius norm). Every case runs under both K-loop schedules of the 256 x 256 kernel.
 Shapes: per-GPU batch 64, 8 frames x 197 tokens = 100 864 ViT rows; 64 x 1834 = 117 376 cross-attention K|V rows; 2100 masked rows
@@ -196,7 +196,7 @@ def test_forward_short_contraction_of_the_videoswin_stages(dev, N, K):
     from valor_amd import kernels as Kn, lib
     so = lib.load()
     M = 200704
-    assert _family(so, 0, 0, M, N, K) == 4
+    assert _family(so, 0, 0, M, N, K) == 3
     A, B, bias = _mk((M, K), 31, dev), _mk((N, K), 32, dev, 0.05), _mk((N,), 33, dev)
     C = Kn.gemm(A, B, bias=bias)
     whole, worst = _tile_errors(C, A.float() @ B.float().t() + bias.float())

@@ -517,16 +517,21 @@ static bool use_8ph2(int dtype, int transA, int transB, int M, int N, int K, boo
     if (mode == 1) return true;
     if (mode == 2) return !big;
     if (mode == 3) return big;
-    // mode 1000, measured per class (tools/gemm_narrow_ab.py, profiles/r04_gemm_narrow_ab_v4.json; pipelined K loops on both sides):
-    //  * everything the policy above leaves to the 128x128 kernels (the 8.8 k / 16.5 k-row decoder and AST problems, short-K dgrads):
-    //    +3 .. +30 % -- twice the tile area per workgroup, a round of 512 slots, epilogues under the other workgroup's K loop;
-    //  * the big-M forward / dgrad problems with K <= 1024 (ViT fc1 / qkv / proj, the cross K|V projection, fc2 dgrad): +3 .. +15 %
-    //    over the 256x256 kernel, whose one workgroup per CU overlaps nothing with its prologue and epilogue;
+    // mode 1000, measured per class -- micro-benchmarks (tools/gemm_narrow_ab.py, profiles/r04_gemm_narrow_ab_v4.json, ..._epi_v1.json) and the
+    // same launches inside the step (one-stream kernel traces grouped by grid, profiles/r04_gemm_by_grid_{new,old}.txt):
+    //  * everything the policy above leaves to the 128x128 kernels (the 8.8 k / 16.5 k-row decoder and AST problems, short-K dgrads) and
+    //    256x256 grids below four rounds (AST / decoder forward): -5 .. -27 % in the step -- twice the tile area per workgroup, a round of
+    //    512 slots, epilogues under the other workgroup's K loop;
+    //  * big-M forward / dgrad problems with K <= 1024 and N >= 1536 (ViT fc1 / qkv, the cross K|V projection, fc2 dgrad): +15 % .. -18 %
+    //    in isolation, -18 % (fc2 dgrad with the saved-derivative multiply), -6 %, -2 %, +2 % in the step; with N = 768 (six tile columns:
+    //    the ViT out-projection and its dgrad) the 256x256 kernel is 8 .. 12 % faster in the step and keeps them;
     //  * longer contractions stay on the 256x256 kernel (2/3 of the L2 -> LDS bytes per FLOP: 0.93 .. 0.99 here), and so do the wgrads
     //    (0.82 .. 0.88: split-K slabs of twice as many, half as big tiles).
     (void)heavy_epi;
     if (transA) return false;
-    return !big || K <= 1024;
+    if (!big) return true;
+    const int64_t tiles256 = (int64_t)((M + 255) / 256) * ((N + 255) / 256);
+    return K <= 1024 && (N >= 1536 || tiles256 < 1024);
 }
 
 // kernel family of a problem: 0 = register-staged 128x128 (also all fp32), 1 / 2 = LDS-DMA 128x128 single / double stage,
