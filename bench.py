@@ -10,6 +10,7 @@ synthetic inputs resident in HBM, random-init weights. A step = forward + backwa
 global-norm clip + fused AdamW. Prints ONE JSON line on rank 0.
 """
 import argparse
+import gc
 import json
 import os
 import random
@@ -240,6 +241,48 @@ class GemmTimer:
         return {v: {"flops": f, "seconds": s, "launches": n, "TFLOPs": f / s / 1e12, "avg_us": s / n * 1e6} for v, (f, s, n) in agg.items()}
 
 
+def time_variant(variant, args, dev, steps=3, warmup=2):
+    """`steps` timed training steps of another model variant at the headline's batch / clip length (one rank): samples/s, step time,
+    step MFU on the necessary FLOPs of THAT variant, peak memory."""
+    from types import SimpleNamespace
+    from valor_amd import synth
+    from valor_amd.engine import TrainEngine
+    from valor_amd.model.valor import VALOR
+    spec = {"swin": synth.swin_spec, "large": synth.large_spec, "clip_large": synth.clip_large_spec}[variant]()
+    mopts = {"dropout": args.dropout}
+    if variant == "clip_large":
+        mopts.update(use_task_prompt=True, contra_loss_ratio=1.5)
+    torch.cuda.reset_peak_memory_stats()
+    model = VALOR(mopts, spec=spec, dtype=torch.bfloat16, device=dev)
+    sd = synth.make_state_dict(spec, seed=50)
+    model.load_state_dict(sd, strict=True)
+    opts = SimpleNamespace(learning_rate=1e-4, weight_decay=0.01, clip_lr=5e-7, clip_lr_text=5e-7, new_lr=0.0, decoder_lr=-1,
+                           betas=[0.9, 0.98], warmup_ratio=0.1, num_train_steps=100000, scheduler="warmup_linear", grad_norm=5.0)
+    engine = TrainEngine(model, opts)
+    engine.optimizer.init_master_from(sd)
+    del sd
+    batch = synth.make_batch(spec, batch=args.batch, frames=args.frames, audio_slices=args.audio_slices, txt_len=32, seed=50)
+    batch["video_pixels"] = batch["video_pixels"].to(dev)
+    batch["audio_spectrograms"] = batch["audio_spectrograms"].to(dev)
+    for _ in range(warmup):
+        engine.train_step(batch, TASK)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    last = None
+    for _ in range(steps):
+        last = engine.train_step(batch, TASK)
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    sps = args.batch * steps / el
+    nf = necessary_flops_per_sample(spec, args.frames, args.audio_slices, 32)
+    out = {"value": round(sps, 2), "unit": "samples/s", "ms_per_step": round(el / steps * 1e3, 2), "steps": steps, "warmup": warmup,
+           "step_mfu": round(nf * sps / 1e12 / PEAK_BF16_TFLOPS, 4), "necessary_gflop_per_sample": round(nf / 1e9, 1),
+           "per_gpu_batch": args.batch, "frames": args.frames, "peak_mem_gb": round(torch.cuda.max_memory_allocated() / 2 ** 30, 1),
+           "losses": {k: round(float(v.detach()) if torch.is_tensor(v) else float(v), 4) for k, v in last.items()}}
+    del engine, model, batch
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=None, help="ranks = GPUs of this node. Without a launcher (no WORLD_SIZE in the environment) "
@@ -253,6 +296,10 @@ def main():
     ap.add_argument("--audio-slices", type=int, default=2)
     ap.add_argument("--dropout", type=float, default=0.1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--accum", type=int, default=1, help="micro-steps per optimizer step (gradient accumulation, train_utils.py:311-317): the per-GPU batch of "
+                    "a step is --batch x --accum. BASELINE configs[4] (VALOR-large, 16 frames, global batch 1024 = 128 per GPU) runs as "
+                    "--variant large --frames 16 --batch 64 --accum 2: 128 samples of 16 frames do not fit one forward-backward (182 GB at 64)")
+    ap.add_argument("--no-variants", action="store_true", help="skip the short timed runs of --variant swin / large behind the headline region")
     ap.add_argument("--no-roofline", action="store_true", help="skip the instrumented steps behind the timed region (roofline = null)")
     ap.add_argument("--variant", choices=["clip", "swin", "large", "clip_large"], default="clip",
                     help="clip: config/pretrain-VALOR-base.json (BASELINE configs[1], the headline); swin: scripts/pretrain.sh "
@@ -324,8 +371,21 @@ def main():
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        engine.train_step(batch, TASK)
+    def one_step():
+        out = None
+        for _ in range(args.accum):
+            out = engine.train_step(batch, TASK, accum_steps=args.accum)
+        return out
+
+    # Warm-up with a synchronisation in the middle: the timed region starts from an idle GPU, where the host (45 ms per step) runs two
+    # steps ahead of the device (118 ms) before the launch queue throttles it -- the tensors that cross streams (the decoder's
+    # [video | audio] input and its gradient, one MLP activation) are then alive in three steps at once and the caching allocator
+    # grows by a segment each (round 3: 4 device allocations, 2 + 172 + 172 + 592 MiB, inside the timed region). Starting the last
+    # warm-up steps from an idle GPU too puts that high-water mark into the warm-up.
+    for i in range(args.warmup):
+        if args.warmup >= 4 and i == args.warmup - 3:
+            sync()
+        one_step()
     sync()
     seg0 = torch.cuda.memory_stats().get("segment.all.allocated", 0)       # device allocations (hipMalloc) so far
     segs_before = {sg["address"] for sg in torch.cuda.memory_snapshot()}
@@ -334,7 +394,7 @@ def main():
     step_ms = []
     for _ in range(args.steps):
         ts = time.perf_counter()
-        last = engine.train_step(batch, TASK)
+        last = one_step()
         step_ms.append((time.perf_counter() - ts) * 1e3)                    # host time of the (asynchronous) step, no sync inside the region
     sync()
     elapsed = time.perf_counter() - t0
@@ -350,12 +410,12 @@ def main():
     os.environ["VALOR_ENCODER_STREAMS"] = "0"
     timer.enabled = False
     for _ in range(2 if n_inst else 0):          # settle: the audio / text activations move from the side stream's allocator pool to this stream's (device
-        engine.train_step(batch, TASK)      # allocations stall the host, a starved GPU makes event pairs measure launch latency)
+        one_step()                          # allocations stall the host, a starved GPU makes event pairs measure launch latency)
     sync()
     timer.enabled = True
     t1 = time.perf_counter()
     for _ in range(n_inst):
-        engine.train_step(batch, TASK)
+        one_step()
         timer.next_step()
     sync()
     inst_elapsed = (time.perf_counter() - t1) / max(n_inst, 1)
@@ -365,13 +425,20 @@ def main():
     else:
         os.environ["VALOR_ENCODER_STREAMS"] = two_streams
     t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    replicas_identical = None
     if world > 1:
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        # data parallelism keeps the replicas bit-identical (same reduced gradients, same optimizer): an exact integer checksum of the
+        # parameter arena from every rank must agree
+        cs = model.arena.flat.view(torch.int16).to(torch.int64).sum().reshape(1)
+        allcs = [torch.zeros_like(cs) for _ in range(world)]
+        torch.distributed.all_gather(allcs, cs)
+        replicas_identical = all(int(c.item()) == int(allcs[0].item()) for c in allcs)
     elapsed = float(t.item())
 
     if rank == 0:
         ms = elapsed / args.steps * 1e3
-        sps = world * args.batch * args.steps / elapsed
+        sps = world * args.batch * args.accum * args.steps / elapsed
         gs = timer.summary()
         dom = max(gs, key=lambda v: gs[v]["seconds"]) if gs else None
         nf = necessary_flops_per_sample(spec, args.frames, args.audio_slices, 32)
@@ -407,10 +474,12 @@ def main():
                "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 2), "higher_is_better": True,
                "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
                "ranks": torch.distributed.get_world_size() if world > 1 else 1, "backend": backend,
+               "replicas_identical": replicas_identical, "reduce_mode": engine.reducer.mode,
                "rccl_version": ".".join(str(x) for x in torch.cuda.nccl.version()) if hasattr(torch.cuda, "nccl") else None,
                "config": {"workload": f"{size} tri-modal ({arch}) pretrain step, MGA+MGC+MLM, "
                                       f"{args.frames} frames x 224^2, {args.audio_slices} x 5.12 s audio, 32 tokens",
-                          "per_gpu_batch": args.batch, "global_batch": world * args.batch, "parallelism": f"dp{world}",
+                          "per_gpu_batch": args.batch * args.accum, "micro_batch": args.batch, "accum_steps": args.accum,
+                          "global_batch": world * args.batch * args.accum, "parallelism": f"dp{world}",
                           "dropout": args.dropout, "task": TASK},
                "losses": {k: round(float(v.detach()) if torch.is_tensor(v) else float(v), 4) for k, v in last.items()},
                "peak_mem_gb": round(torch.cuda.max_memory_allocated() / 2 ** 30, 1),
@@ -422,6 +491,20 @@ def main():
                 res["dp_sim"] = sim_world(model, spec, args.sim_world, args.batch, args.frames, args.audio_slices)
             except Exception as e:
                 res["dp_sim"] = {"error": repr(e)}
+        if world == 1 and args.variant == "clip" and not args.no_variants:
+            # the other configurations this repository claims, driver-visible: a few timed steps each of the VideoSwin-B variant
+            # (scripts/pretrain.sh) and of BASELINE configs[3] (VideoSwin-L + BERT-large), same batch / clip length, after the headline region
+            del engine, model, batch
+            gc.collect()
+            torch.cuda.empty_cache()
+            res["variants"] = {}
+            for v in ("swin", "large"):
+                try:
+                    res["variants"][v] = time_variant(v, args, dev)
+                except Exception as e:
+                    res["variants"][v] = {"error": repr(e)}
+                gc.collect()
+                torch.cuda.empty_cache()
         if world == 1 and not args.no_cpu_baseline:
             try:
                 res["cpu_baseline"] = cpu_baseline(frames=args.frames, audio_slices=args.audio_slices, variant=args.variant)

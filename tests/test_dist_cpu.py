@@ -53,13 +53,14 @@ def _gather_case(rank, world):
                 gft=ft.grad, gfv=fv.grad, gfa=fa.grad, w=w)
 
 
-def test_packed_allgather_forward_and_local_slice_backward():
-    r = _run(_gather_case)
+@pytest.mark.parametrize("world", [2, 4, 8])
+def test_packed_allgather_forward_and_local_slice_backward(world):
+    r = _run(_gather_case, world)
     for k, kk in (("Ft", "ft"), ("Fv", "fv"), ("Fa", "fa"), ("Tok", "tok")):
-        want = torch.cat([r[0][kk], r[1][kk]], dim=0)              # rank-major concat == utils/distributed.py:55-57
-        for rank in range(2):
+        want = torch.cat([r[q][kk] for q in range(world)], dim=0)   # rank-major concat == utils/distributed.py:55-57
+        for rank in range(world):
             assert torch.equal(r[rank][k], want), k
-    for rank in range(2):
+    for rank in range(world):
         b = 3
         assert torch.allclose(r[rank]["gft"], r[rank]["w"][rank * b:(rank + 1) * b])       # local slice of dL/dFt
         assert torch.allclose(r[rank]["gfv"], 2 * r[rank]["fv"])
@@ -88,19 +89,22 @@ def _reducer_case(rank, world):
     return outs
 
 
-def test_reducer_sums_arena_and_learns_unused_parameters():
-    r = _run(_reducer_case)
+@pytest.mark.parametrize("world", [2, 4, 8])
+def test_reducer_sums_arena_and_learns_unused_parameters(world):
+    r = _run(_reducer_case, world)
+    tri = world * (world + 1) // 2                       # sum over ranks of (rank + 1)
     for step in range(3):
         g0, act0, nworks0 = r[0][step]
-        g1, act1, _ = r[1][step]
-        assert torch.equal(g0, g1) and act0 == act1
+        for q in range(1, world):
+            gq, actq, _ = r[q][step]
+            assert torch.equal(g0, gq) and act0 == actq
         assert all(f"p{i}" not in act0 for i in (3, 7, 11)) and len(act0) == 9
-        # expected: d/dp_i sum_ranks (rank+1)*(i+1+step) = 3*(i+1+step)
+        # expected: d/dp_i sum_ranks (rank+1)*(i+1+step) = world (world + 1) / 2 * (i+1+step)
         from valor_amd.arena import ParamArena
         arena = ParamArena([(f"p{i}", (300 + 7 * i,), 0) for i in range(12)], torch.float32, "cpu")
         for i in range(12):
             o, n, _ = arena.offsets[f"p{i}"]
-            want = 0.0 if i % 4 == 3 else 3.0 * (i + 1 + step)
+            want = 0.0 if i % 4 == 3 else float(tri) * (i + 1 + step)
             assert torch.allclose(g0[o:o + n], torch.full((n,), want)), (step, i)
         if step > 0:
             assert nworks0 > 1          # bucketed, hook-launched all-reduces after the first (learning) step

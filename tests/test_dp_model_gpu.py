@@ -24,13 +24,13 @@ TASK = "pt_contra%tva%tv%ta_caption%tva%tv%ta_mlm%tva"
 B_LOCAL, FRAMES, SLICES = 2, 2, 1
 
 
-def _setup():
+def _setup(world=2):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     from valor_amd import synth
     spec = synth.tiny_spec()
     sd = synth.make_state_dict(spec, seed=3, w_std=0.05)
-    full = synth.make_batch(spec, batch=2 * B_LOCAL, frames=FRAMES, audio_slices=SLICES, txt_len=32, seed=4)
+    full = synth.make_batch(spec, batch=world * B_LOCAL, frames=FRAMES, audio_slices=SLICES, txt_len=32, seed=4)
     return spec, sd, full
 
 
@@ -47,7 +47,7 @@ def _worker(rank, world, port, outdir):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         from types import SimpleNamespace
-        spec, sd, full = _setup()
+        spec, sd, full = _setup(world)
         from valor_amd.engine import TrainEngine
         from valor_amd.model.valor import VALOR
         torch.cuda.set_device(0)
@@ -57,7 +57,7 @@ def _worker(rank, world, port, outdir):
         opts = SimpleNamespace(learning_rate=1e-3, weight_decay=0.01, clip_lr=1e-3, clip_lr_text=1e-3, new_lr=0.0, decoder_lr=-1,
                                betas=[0.9, 0.98], warmup_ratio=0.1, num_train_steps=10, scheduler="warmup_linear", grad_norm=5.0)
         eng = TrainEngine(model, opts, manage_gc=False)
-        assert eng.world == 2 and model.gather_fn is not None
+        assert eng.world == world and model.gather_fn is not None
         batch = _half(full, rank)
         model.train()
         random.seed(100 + rank)
@@ -87,38 +87,40 @@ def _worker(rank, world, port, outdir):
         dist.destroy_process_group()
 
 
-def test_two_ranks_match_the_reference_semantics(dev, tmp_path):
-    spec, sd, full = _setup()
+@pytest.mark.parametrize("W", [2, 4, 8])
+def test_ranks_match_the_reference_semantics(dev, tmp_path, W):
+    """world 2 / 4 / 8 (every rank a process on the one GPU of the test box, gloo): nothing above world 2 had ever executed before round 4"""
+    spec, sd, full = _setup(W)
     import valor_oracle as VO
     from valor_amd import synth
     import socket
     with socket.socket() as sk:
         sk.bind(("127.0.0.1", 0))
         port = sk.getsockname()[1]
-    mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
-    res = [torch.load(os.path.join(str(tmp_path), f"rank{r}.pt"), weights_only=False) for r in range(2)]
+    mp.spawn(_worker, args=(W, port, str(tmp_path)), nprocs=W, join=True)
+    res = [torch.load(os.path.join(str(tmp_path), f"rank{r}.pt"), weights_only=False) for r in range(W)]
 
     vocab = synth.synthetic_vocab(spec.vocab)
     # features every rank contributes to the gather (constants for the OTHER rank's backward)
     feats = []
     with torch.no_grad():
-        for r in range(2):
+        for r in range(W):
             orc = VO.Oracle(spec, sd, vocab_tokens=vocab)
             ev = orc.forward_pt(_half(full, r), "pt_contra%tva%tv%ta", compute_loss=False)
             feats.append({k: ev[k] for k in ("feat_t", "feat_v", "feat_a", "txt_tokens")})
     want_grads, want_losses = [], []
-    for r in range(2):
+    for r in range(W):
         sd_r = VO.trainable_copy(sd)
         orc = VO.Oracle(spec, sd_r, vocab_tokens=vocab)
 
         def gather_feat(f, r=r):
             key = {32: "feat_t", FRAMES: "feat_v", SLICES: "feat_a"}[f.shape[1]]
-            parts = [feats[q][key] for q in range(2)]
+            parts = [feats[q][key] for q in range(W)]
             parts[r] = f                                             # the local slice carries the gradient (utils/distributed.py:62-72)
             return torch.cat(parts, dim=0)
 
         def gather_tok(t, r=r):
-            return torch.cat([feats[q]["txt_tokens"] for q in range(2)], dim=0)
+            return torch.cat([feats[q]["txt_tokens"] for q in range(W)], dim=0)
 
         random.seed(100 + r)
         out = orc.forward_pt(_half(full, r), TASK, compute_loss=True, gather=(gather_feat, gather_tok))
@@ -132,21 +134,21 @@ def test_two_ranks_match_the_reference_semantics(dev, tmp_path):
     lf.backward()
     full_contra = float(lf)
 
-    for r in range(2):
+    for r in range(W):
         for k, v in want_losses[r].items():
             assert abs(res[r]["losses"][k] - v) <= 1e-4 * abs(v), (r, k, res[r]["losses"][k], v)
         assert abs(res[r]["losses"]["contra_loss"] - full_contra) <= 1e-4 * abs(full_contra)
-    assert res[0]["losses"]["contra_loss"] == pytest.approx(res[1]["losses"]["contra_loss"], rel=1e-6)
+        assert res[0]["losses"]["contra_loss"] == pytest.approx(res[r]["losses"]["contra_loss"], rel=1e-6)
     # the reducer leaves the SUM over ranks in both arenas; DDP's mean is folded into the optimizer
     bad = []
     for k in want_grads[0]:
         parts = [g[k] for g in want_grads if g[k] is not None]
-        for r in range(2):
-            got = res[r]["grads"][k].double() / 2.0
+        for r in range(W):
+            got = res[r]["grads"][k].double() / W
             if not parts:
                 assert float(got.abs().max()) == 0.0, k
                 continue
-            want = sum(p.double() for p in parts) / 2.0
+            want = sum(p.double() for p in parts) / W
             scale = max(float(want.norm()), 1e-5 * want.numel() ** 0.5)
             err = float((got.reshape(want.shape) - want).norm()) / scale
             if err > 2e-3:
@@ -155,15 +157,16 @@ def test_two_ranks_match_the_reference_semantics(dev, tmp_path):
     # the reference's quirk, stated directly: the CLIP text tower only feeds the contrastive loss, each rank back-propagates the
     # local slice of the gathered-feature gradient, DDP averages -> 1/world of the single-process full-batch gradient
     for k in ("clip_model.text_projection", "clip_model.transformer.resblocks.0.attn.in_proj_weight", "clip_model.token_embedding.weight"):
-        got = res[0]["grads"][k].double() / 2.0
-        want = sd_f[k].grad.double() / 2.0
+        got = res[0]["grads"][k].double() / W
+        want = sd_f[k].grad.double() / W
         assert float((got.reshape(want.shape) - want).norm()) <= 2e-3 * float(want.norm()), k
     # ... while parameters applied to the GATHERED features (fine-weight heads, temperature) see the full gradient on every rank
     for k in ("text_fine_weight.0.weight", "clip_model.logit_scale"):
-        got = res[0]["grads"][k].double() / 2.0
+        got = res[0]["grads"][k].double() / W
         want = sd_f[k].grad.double()
         assert float((got.reshape(want.shape) - want).norm()) <= 2e-3 * float(want.norm()) + 1e-9, k
-    assert torch.equal(res[0]["flat"], res[1]["flat"]), "replicas diverged after two optimizer steps"
+    for r in range(1, W):
+        assert torch.equal(res[0]["flat"], res[r]["flat"]), "replicas diverged after two optimizer steps"
     assert float(res[0]["flat"].abs().sum()) > 0
 
 
@@ -227,3 +230,22 @@ def test_bench_gpus_flag_launches_that_many_ranks():
     assert res["n_gpus"] == 2 and res["ranks"] == 2 and res["backend"] == "gloo"
     assert res["config"]["global_batch"] == 8 and res["config"]["parallelism"] == "dp2"
     assert all(v == v and abs(v) < 1e4 for v in res["losses"].values())
+    assert res["replicas_identical"] is True
+
+
+def test_bench_with_eight_ranks_on_one_gpu():
+    """the driver's 8-GPU command line (`bench.py --gpus 8`) with the eight ranks sharing this box's one GPU over gloo, at a batch that
+    fits eight replicas: eight ranks really run, the losses are finite and every replica holds bit-identical parameters after the
+    timed steps (the line's `replicas_identical` = an all-gathered checksum of the parameter arena)"""
+    import json
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env["VALOR_DIST_BACKEND"] = "gloo"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--batch", "2", "--steps", "2", "--warmup", "1",
+                        "--frames", "2", "--audio-slices", "1", "--no-cpu-baseline", "--no-roofline"], env=env, capture_output=True, text=True, timeout=1500)
+    assert r.returncode == 0, r.stderr[-2000:]
+    res = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert res["n_gpus"] == 8 and res["ranks"] == 8 and res["backend"] == "gloo"
+    assert res["config"]["global_batch"] == 16 and res["config"]["parallelism"] == "dp8"
+    assert all(v == v and abs(v) < 1e4 for v in res["losses"].values())
+    assert res["replicas_identical"] is True

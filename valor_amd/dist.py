@@ -22,18 +22,27 @@ def is_dist():
 
 
 class _PackedGather(Function):
+    """ONE collective for all features. Packing is PER SAMPLE -- rank r contributes [b, P] rows, P = the flattened sizes of one sample
+    of every feature -- so the gathered [world * b, P] buffer holds each feature as a row-strided VIEW ([world * b, ...] with row stride
+    P): nothing is copied out of the receive buffer (the per-rank packing of round 3 needed one strided copy per feature on the critical
+    path of the contrastive block). Consumers that need dense rows call .contiguous() themselves."""
+
     @staticmethod
     def forward(ctx, *feats):
         world, rank = dist.get_world_size(), dist.get_rank()
-        ctx.meta = [(f.shape, f.numel()) for f in feats]
+        b = feats[0].shape[0]
+        ctx.meta = [(f.shape, f[0].numel()) for f in feats]
         ctx.rank, ctx.world = rank, world
-        flat = torch.cat([f.reshape(-1) for f in feats])
-        out = torch.empty(world * flat.numel(), dtype=flat.dtype, device=flat.device)
-        dist.all_gather_into_tensor(out, flat) if flat.is_cuda else dist.all_gather(list(out.chunk(world)), flat)
-        out = out.view(world, -1)
+        flat = torch.cat([f.reshape(b, -1) for f in feats], dim=1)               # [b, P]: the one packing copy
+        P = flat.shape[1]
+        out = torch.empty((world * b, P), dtype=flat.dtype, device=flat.device)
+        if flat.is_cuda:
+            dist.all_gather_into_tensor(out.view(-1), flat.view(-1))
+        else:
+            dist.all_gather(list(out.view(-1).chunk(world)), flat.view(-1))
         res, o = [], 0
         for shape, n in ctx.meta:
-            res.append(out[:, o:o + n].reshape(world * shape[0], *shape[1:]).contiguous())
+            res.append(out[:, o:o + n].unflatten(1, tuple(shape[1:])) if len(shape) > 1 else out[:, o])
             o += n
         return tuple(res)
 
@@ -73,6 +82,12 @@ class Reducer:
                       reduce_scatter);
          "fp32"       the bucket is widened to fp32 for the cross-rank sum and rounded ONCE on the way back (world - 1 fewer bf16
                       roundings per element at twice the bytes on the wire).
+       Default: "allreduce". SURVEY 8(e) argues for direct reduce-scatter + all-gather on the fully connected xGMI mesh (7 links x ~153
+       GB/s busy: ~1.2 ms for 0.75 GB against ~8.6 ms for a single-link-bound ring). RCCL chooses its algorithm per message size and
+       topology by itself; which one it picks for a 48 MiB bucket on an 8-GPU MI355X node has NOT been measured here (no multi-GPU node
+       was available to the builder), so the default is the call that leaves the choice to RCCL and is ONE collective per bucket.
+       "rs_ag" forces the two halves of a direct all-reduce (in-place shards) and stays opt-in until a multi-GPU run has timed both:
+       VALOR_REDUCE=rs_ag python bench.py --gpus 8 is the A/B; bench.py prints the mode in its line.
        Summing in bf16 across 8 ranks perturbs each element by ~0.4 % rms (like one more bf16 rounding of the gradient) and the global
        norm by < 1e-5 relative: tests/test_dist_cpu.py::test_bf16_cross_rank_sum_error quantifies it."""
 
@@ -187,8 +202,17 @@ class Reducer:
             self.uses = dict(self.touched)
             self.expected = [set(n for n in b if n in self.touched) for b in self.buckets]
             if self.world > 1:
-                for w in self._reduce(self.arena.grad):
+                # first step of a task: backward is over, nothing to overlap with -- but the buckets still go out one by one,
+                # asynchronously on the communication stream (the same launches every later step makes from the hooks), instead of
+                # one synchronous whole-arena collective: the bucket pipeline of RCCL is warm for step 2 and the host does not block
+                # on 0.75 GB before it queues the optimizer
+                self.works = []
+                for i in range(len(self.buckets)):
+                    self._launch(i)
+                for w in self.works:
                     w.wait()
+                if self.comm_stream is not None:
+                    torch.cuda.current_stream().wait_stream(self.comm_stream)
         else:
             for w in self.works:
                 w.wait()

@@ -603,11 +603,18 @@ class VALOR(nn.Module):
         side = streams.side_stream(self.device)
         shape = tuple(va_input.shape[:-1]) + (2 * self.spec.hidden,)
         key = (shape, va_input.dtype)
+        # Contract: ONE training forward per backward. The buffers are rewritten by the next forward; every autograd node that saved one
+        # remembers the generation it saw (ops.StaticGen) and raises instead of differentiating through a newer one. They are released by
+        # eval() / a shape change (release_static_kv).
         if getattr(self, "_kv_static_key", None) != key:
+            self.release_static_kv()
             with torch.cuda.stream(side):
                 self._kv_static = [torch.empty(shape, dtype=va_input.dtype, device=self.device) for _ in range(self.spec.layers)]
                 self._dkv_static_pool = [torch.empty(shape, dtype=va_input.dtype, device=self.device) for _ in range(self.spec.layers)]
             self._kv_static_key = key
+            self._kv_gen = ops.StaticGen()
+            self._kv_gen.register(self._kv_static)
+        self._kv_gen.gen += 1
         self._dkv_static = self._dkv_static_pool
         va_s = streams.fork(side, va_input)
         items = []
@@ -619,6 +626,20 @@ class VALOR(nn.Module):
                 ev.record(side)
                 items.append((kv, ev))
         return streams.LazyTensors(side, items)
+
+    def release_static_kv(self):
+        """drop the static K|V / dK|dV pools of project_cross_kv (2 x layers x |K|V|: 8.6 GB at the base bench shape)"""
+        g = getattr(self, "_kv_gen", None)
+        if g is not None:
+            g.gen += 1            # any graph still holding them must not run backward
+            g.release()
+        self._kv_static = self._dkv_static_pool = self._dkv_static = self._kv_gen = None
+        self._kv_static_key = None
+
+    def train(self, mode=True):
+        if not mode:
+            self.release_static_kv()
+        return super().train(mode)
 
     def cross_inputs(self, video_output, audio_output):
         """get_multimodal_forward_input_video / _audio (modeling.py:485-502) + the K|V projections of every decoder layer.

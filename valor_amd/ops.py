@@ -360,6 +360,41 @@ def self_attention(qkv, n_heads, mask=None, p_drop=0.0):
     return SelfAttnFn.apply(qkv, n_heads, mask, p_drop)
 
 
+class StaticGen:
+    """Generation counter of a set of STATIC buffers that one forward writes and its backward reads (VALOR.project_cross_kv: the per-layer
+    K|V tensors and their gradient buffers live outside the caching allocator because they cross streams). The owner bumps `gen` whenever
+    it rewrites the buffers; an autograd node that saved one of them remembers the generation it saw and refuses to run backward on a
+    newer one -- a second training forward before the first backward would otherwise give silently wrong gradients (the write is a raw
+    kernel into `out`, invisible to autograd's version counters)."""
+    REGISTRY = {}          # data_ptr of a registered buffer -> its StaticGen
+
+    def __init__(self):
+        self.gen = 0
+        self.ptrs = []
+
+    def register(self, tensors):
+        self.release()
+        self.ptrs = [t.data_ptr() for t in tensors]
+        for q in self.ptrs:
+            StaticGen.REGISTRY[q] = self
+
+    def release(self):
+        for q in self.ptrs:
+            StaticGen.REGISTRY.pop(q, None)
+        self.ptrs = []
+
+    @staticmethod
+    def seen(t):
+        g = StaticGen.REGISTRY.get(t.data_ptr())
+        return None if g is None else (g, g.gen)
+
+    @staticmethod
+    def check(tag):
+        if tag is not None and tag[0].gen != tag[1]:
+            raise RuntimeError("valor_amd: the static cross-attention K|V buffers were rewritten by a later training forward before this backward "
+                               "ran (one forward per backward with VALOR_KV_STREAM=1; set VALOR_KV_STREAM=0 to keep several graphs alive)")
+
+
 class CrossAttnFn(Function):
     """Modality-grouped cross-attention: q [B,T,E]; kv [Bkv,Skv,2E] = ONE projected K|V set of the
     concatenated [video | audio] tokens shared by every query group; kv_range[b] = (start, len)."""
@@ -377,10 +412,12 @@ class CrossAttnFn(Function):
                             p_drop=p_drop, seed=seed, offset=off)
         ctx.save_for_backward(q, kv, o, lse, kv_range)
         ctx.cfg = (n_heads, kv_bmod, p_drop, seed, off)
+        ctx.static_gen = StaticGen.seen(kv)
         return o
 
     @staticmethod
     def backward(ctx, do):
+        StaticGen.check(ctx.static_gen)
         q, kv, o, lse, kv_range = ctx.saved_tensors
         n_heads, kv_bmod, p_drop, seed, off = ctx.cfg
         E = q.shape[2]
@@ -466,10 +503,12 @@ class SegCrossAttnFn(Function):
             lses.append(lse); rng.append((seed, off))
         ctx.save_for_backward(q2d, kv, o, *lses)
         ctx.cfg = (n_heads, segs, p_drop, rng)
+        ctx.static_gen = StaticGen.seen(kv)
         return o
 
     @staticmethod
     def backward(ctx, do):
+        StaticGen.check(ctx.static_gen)
         q2d, kv, o, *lses = ctx.saved_tensors
         n_heads, segs, p_drop, rng = ctx.cfg
         E = q2d.shape[1]
