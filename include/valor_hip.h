@@ -128,7 +128,9 @@ int valor_ln_part_blocks(void);
  * dropout windows). Returns the previous value, v < 0 only queries. Tuning / A-B hook. */
 int valor_ln_set_variant(int v);
 /* non-temporal accesses of the streaming LayerNorm kernels (bit mask; A/B hook, default 0, env VALOR_LN_NT): forward bit 0 = x loads,
- * 1 = y stores, 2 = z stores; backward bit 3 = dy / z / dz_in loads, 4 = dx / dres stores. Returns the previous value, v < 0 only queries. */
+ * 1 = y stores, 2 = z stores; backward bit 3 = dy / z / dz_in loads, 4 = dx / dres stores. Schedule hooks in the same mask: bit 5 = the
+ * backward requests dz_in together with z / dy (measured -1 .. -3 %, within noise: off); bit 6 / bit 7 = force / forbid the loads-first
+ * forward for bf16 rows of 768 columns (default: on from 65 536 rows, profiles/r04_ln_fwd_ab.txt). Returns the previous value, v < 0 only queries. */
 int valor_ln_set_nt(int v);
 int valor_bdrln_fwd(void* stream, int dtype, const void* x, const void* bias, const void* residual, const void* gamma,
                     const void* beta, void* z, void* y, float* mean, float* rstd, int64_t rows, int cols, float eps,

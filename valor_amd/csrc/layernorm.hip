@@ -168,7 +168,16 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(LnBwdArgs p) {
     for (int64_t row = (int64_t)blockIdx.x * 4 + wave; row < p.rows; row += (int64_t)gridDim.x * 4) {
         const int64_t base = row * cols;
         const float rsc = p.row_scale ? p.row_scale[row / p.rows_per_scale] : 1.0f;
-        f32x4_t dzv[NV];
+        f32x4_t dzv[NV], dzi[NV];
+        const bool early_dzi = DZI && (p.nt & 32);          // A/B: request dz_in with z / dy instead of behind the row reductions
+        if (early_dzi) {
+#pragma unroll
+            for (int i = 0; i < NV; ++i) {
+                const int c = (i * 64 + lane) * 4;
+                dzi[i] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+                if (c < cols) dzi[i] = load4_nt<T>(DZI + base + c, ntl);
+            }
+        }
         if (has_ln) {
             const float mu = p.mean[row], rs = p.rstd[row];
             f32x4_t xh[NV], gy[NV];
@@ -206,7 +215,8 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(LnBwdArgs p) {
             const int c = (i * 64 + lane) * 4;
             if (c < cols) {
                 f32x4_t dz = dzv[i];
-                if (DZI) dz += load4_nt<T>(DZI + base + c, ntl);
+                if (early_dzi) dz += dzi[i];
+                else if (DZI) dz += load4_nt<T>(DZI + base + c, ntl);
                 if (DR) store4_nt<T>(DR + base + c, dz, nts);
                 f32x4_t dx = dz;
                 if (thr) {
@@ -270,6 +280,118 @@ DEVINL void unpack8(u32x4_t r, float (&f)[8]) {
 }
 DEVINL u32x4_t pack8(const float (&f)[8]) {
     return (u32x4_t){pack2_bf16(f[0], f[1]), pack2_bf16(f[2], f[3]), pack2_bf16(f[4], f[5]), pack2_bf16(f[6], f[7])};
+}
+
+// Loads-first flavour of the half-wave forward: NR rows per half-wave and iteration, every x / residual chunk of them requested before
+// the first dependent instruction (NR x NV8 x 2 x 16 B per lane in flight: 96 B at 768 columns against the 16-32 B the row-at-a-time
+// loop keeps in flight between its Philox blocks). Same arithmetic, same dropout windows, bit-identical outputs. NR = 2 measured slower.
+template <int NV8, int NR>
+__global__ __launch_bounds__(256) void ln_fwd_h2_kernel(LnArgs p) {
+    typedef bf16_t T;
+    constexpr int GL = 32;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, half = lane / GL, hl = lane % GL;
+    const T* X = (const T*)p.x; const T* Bi = (const T*)p.bias; const T* R = (const T*)p.residual;
+    const T* G = (const T*)p.gamma; const T* Be = (const T*)p.beta;
+    T* Z = (T*)p.z; T* Y = (T*)p.y;
+    const int cols = p.cols;
+    const uint32_t thr = drop_threshold(p.p_drop);
+    const float keep_scale = p.p_drop > 0.f ? 1.0f / (1.0f - p.p_drop) : 1.0f;
+    const float inv_n = 1.0f / (float)cols;
+    for (int64_t row0 = ((int64_t)blockIdx.x * 4 + wave) * 2 * NR; row0 < p.rows; row0 += (int64_t)gridDim.x * 4 * 2 * NR) {
+        u32x4_t xq[NR][NV8], rq[NR][NV8];
+        bool okr[NR];
+#pragma unroll
+        for (int r = 0; r < NR; ++r) {
+            const int64_t row = row0 + 2 * r + half;
+            okr[r] = row < p.rows;
+            const int64_t base = (okr[r] ? row : 0) * cols;
+#pragma unroll
+            for (int i = 0; i < NV8; ++i) {
+                const int c = (i * GL + hl) * 8;
+                xq[r][i] = *(const u32x4_t*)(X + base + c);
+                rq[r][i] = R ? *(const u32x4_t*)(R + base + c) : (u32x4_t){0u, 0u, 0u, 0u};
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < NR; ++r) {
+            const int64_t row = row0 + 2 * r + half;
+            const bool ok = okr[r];
+            const int64_t base = row * cols;
+            float v[NV8][8];
+            float s = 0.f;
+            const float rsc = (p.row_scale && ok) ? p.row_scale[row / p.rows_per_scale] : 1.0f;
+#pragma unroll
+            for (int i = 0; i < NV8; ++i) {
+                const int c = (i * GL + hl) * 8;
+                float t[8];
+                unpack8(xq[r][i], t);
+                if (Bi) {
+                    float b8[8]; unpack8(*(const u32x4_t*)(Bi + c), b8);
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) t[k] += b8[k];
+                }
+                if (thr) {
+#pragma unroll
+                    for (int h4 = 0; h4 < 2; ++h4) {
+                        Philox4 rnd = philox4x32_10(p.seed, p.offset + (uint64_t)((base + c + 4 * h4) >> 2));
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) t[4 * h4 + k] = rnd.v[k] >= thr ? t[4 * h4 + k] * keep_scale : 0.f;
+                    }
+                }
+                if (p.row_scale) {
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) t[k] *= rsc;
+                }
+                if (R) {
+                    float r8[8]; unpack8(rq[r][i], r8);
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) t[k] += r8[k];
+                }
+                if (Z) {
+                    const u32x4_t zq = pack8(t);
+                    if (ok) *(u32x4_t*)(Z + base + c) = zq;
+                    unpack8(zq, t);
+                }
+                if (!ok) {
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) t[k] = 0.f;
+                }
+#pragma unroll
+                for (int k = 0; k < 8; ++k) { s += t[k]; v[i][k] = t[k]; }
+            }
+            if (!Y) continue;
+            const float mu = group_sum<GL>(s) * inv_n;
+            float q = 0.f;
+#pragma unroll
+            for (int i = 0; i < NV8; ++i)
+#pragma unroll
+                for (int k = 0; k < 8; ++k) { const float d = v[i][k] - mu; q += d * d; }
+            const float rs = rsqrtf(group_sum<GL>(q) * inv_n + p.eps);
+            if (!ok) continue;
+            if (hl == 0) {
+                if (p.mean) p.mean[row] = mu;
+                if (p.rstd) p.rstd[row] = rs;
+            }
+#pragma unroll
+            for (int i = 0; i < NV8; ++i) {
+                const int c = (i * GL + hl) * 8;
+                float o[8];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) o[k] = (v[i][k] - mu) * rs;
+                if (G) {
+                    float g8[8]; unpack8(*(const u32x4_t*)(G + c), g8);
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) o[k] *= g8[k];
+                }
+                if (Be) {
+                    float b8[8]; unpack8(*(const u32x4_t*)(Be + c), b8);
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) o[k] += b8[k];
+                }
+                *(u32x4_t*)(Y + base + c) = pack8(o);
+            }
+        }
+    }
 }
 
 template <int NV8, int GL = 32>
@@ -773,7 +895,19 @@ static int launch_ln_fwd(hipStream_t st, const LnArgs& p) {
     if (ln_half_ok(ElemTraits<T>::DT, p.cols, p.x, p.bias, p.residual, p.z, p.y) && (((uintptr_t)p.gamma | (uintptr_t)p.beta) & 15) == 0) {
         const int gl = ln_group(p.cols), rpb = 4 * (64 / gl);          // rows per workgroup and iteration
         int64_t blocks = (p.rows + rpb - 1) / rpb;
-        if (blocks > 8192) blocks = 8192;
+        // bf16 rows of 768 columns, >= 65 536 of them (the ViT / decoder-input shapes): the loads-first kernel -- 164.9 -> 134.3 us with
+        // dropout, 136.7 -> 115.0 us without at 100 864 rows (3.76 -> 4.61, 4.53 -> 5.39 TB/s); at 16 512 rows it is 12 % SLOWER (fewer
+        // waves per SIMD at its register count, nothing left to hide the tail), two rows per half-wave and smaller (persistent) grids
+        // are slower everywhere: profiles/r04_ln_fwd_ab.txt. valor_ln_set_nt bit 6 forces it for 768 columns, bit 7 forbids it.
+        static const int blocks_cap = [] { const char* e = getenv("VALOR_LN_FWD_BLOCKS"); return e ? atoi(e) : 8192; }();
+        const bool loads_first = gl == 32 && nv == 3 && !(p.nt & 7) && !(p.nt & 128) && ((p.nt & 64) || p.rows >= 65536);
+        if (loads_first) {
+            int64_t b2 = (p.rows + 7) / 8;
+            if (b2 > blocks_cap) b2 = blocks_cap;
+            hipLaunchKernelGGL((ln_fwd_h2_kernel<3, 1>), dim3((unsigned)b2), dim3(256), 0, st, p);
+            return valor_launch_status();
+        }
+        if (blocks > blocks_cap) blocks = blocks_cap;
         if (gl == 16) {
             if (p.cols == 128) hipLaunchKernelGGL((ln_fwd_h_kernel<1, 16>), dim3((unsigned)blocks), dim3(256), 0, st, p);
             else hipLaunchKernelGGL((ln_fwd_h_kernel<3, 16>), dim3((unsigned)blocks), dim3(256), 0, st, p);

@@ -31,6 +31,12 @@ class TrainEngine:
             for t in ((self.optimizer.master,) if self.optimizer.separate_master else ()) + (self.optimizer.exp_avg, self.optimizer.exp_avg_sq):
                 torch.distributed.broadcast(t, 0)
         self.global_step = 0
+        # The host needs ~45 ms to issue a step the GPU runs for ~118 ms: unthrottled it runs many steps ahead, and every tensor that
+        # crosses streams (held by its record_stream event until the GPU passes it) then exists once per step in flight -- the caching
+        # allocator keeps growing by 172 .. 592 MiB segments for as long as the lead grows (hipMalloc stalls inside steps). Two steps
+        # of lead keep the GPU fed; the step waits for the end of the step before the previous one.
+        self.max_ahead = int(getattr(opts, "max_steps_ahead", 2))
+        self._step_events = []
         self.grad_norm = float(getattr(opts, "grad_norm", 5.0))
         self._task = None
         self._micro = 0
@@ -49,6 +55,8 @@ class TrainEngine:
         if task != self._task:
             self.reducer.reset_task(task)
             self._task = task
+        if self.max_ahead > 0 and len(self._step_events) >= self.max_ahead:
+            self._step_events.pop(0).synchronize()
         model.train()
         self.reducer.prepare_backward(defer=accum)
         loss_dict = model(batch, task=task, compute_loss=True)
@@ -67,6 +75,10 @@ class TrainEngine:
                 g["lr"] = g["init_lr"] * ratio
         opt.step(active_names=active, max_grad_norm=self.grad_norm, world_size=self.world)   # clip :358-360, step :362
         loss_dict["total_loss"] = loss.detach()
+        if self.max_ahead > 0 and model.arena.flat.is_cuda:
+            ev = torch.cuda.Event()
+            ev.record()
+            self._step_events.append(ev)
         if self.manage_gc:
             gc.collect(0 if self.global_step % 64 else 2)
         return loss_dict
