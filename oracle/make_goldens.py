@@ -37,17 +37,33 @@ SWIN_SLICE_KEYS = ["video_encoder.patch_embed.proj.weight", "video_encoder.layer
 def run(name, batch_size, frames, audio_slices, wseed, bseed, mseed, variant="clip", task=None, bf16_exact=False, steps=2):
     global SLICE_KEYS
     TASK = task or globals()["TASK"]
+    build_kw, model_opts = {}, {}
     if variant == "swin":                  # scripts/pretrain.sh:3-8
         spec = synth.swin_spec()
         ropts = ref_harness.default_opts(video_encoder_type="videoswin_base_k400_22k", txt_encoder_type="bert_base_uncased")
         SLICE_KEYS = SWIN_SLICE_KEYS
+    elif variant == "clip_large":
+        # config/pretrain-VALOR-large.json:10-15 -- the reference's shipped large configuration (CLIP ViT-L/14 at 224 px + shared
+        # bert_base_uncased, use_task_prompt, contra_loss_ratio 1.5) at its true WIDTHS (1024-wide ViT, patch 14, 257 tokens per frame,
+        # video 1024 -> hidden 768 through hidden_trans_video_multimodal) on 2-layer stacks: the reference derives the CLIP depth from
+        # the checkpoint keys and the BERT depth from its json, so the unmodified code runs at the same depth as the native model
+        import dataclasses
+        spec = dataclasses.replace(synth.clip_large_spec(), vis_layers=2, txt_layers=1, aud_layers=12, layers=2)
+        model_opts = dict(use_task_prompt=True, contra_loss_ratio=1.5)
+        ropts = ref_harness.default_opts(video_encoder_type="clip_vit_large_14_336px", txt_encoder_type="bert_base_uncased",
+                                         video_resolution=224, **model_opts)
+        build_kw = dict(clip_layers=(2, 1), bert_layers=2)
+        SLICE_KEYS = ["clip_model.visual.transformer.resblocks.0.attn.in_proj_weight", "clip_model.visual.conv1.weight",
+                      "hidden_trans_video_multimodal.0.weight", "contra_head_v.linear.weight", "contra_head_t.linear.weight", "contra_temp",
+                      "audio_encoder.layer.11.ff_layer.linear2.weight", "multimodal_encoder.encoder.layer.0.cross_attn.cross.key.weight",
+                      "multimodal_encoder.embeddings.word_embeddings.weight", "cls.decoder.bias", "video_frame_embedding"]
     else:
         spec, ropts = synth.base_spec(), None
     sd = synth.make_state_dict(spec, seed=wseed, bf16_exact=bf16_exact)
-    ref = ref_harness.build_reference(ropts, state_dict=sd, dropout=0.0)
+    ref = ref_harness.build_reference(ropts, state_dict=sd, dropout=0.0, **build_kw)
     batch = synth.make_batch(spec, batch=batch_size, frames=frames, audio_slices=audio_slices, txt_len=32, seed=bseed, bf16_exact=bf16_exact)
     g = {"recipe": dict(spec=spec.to_dict(), weight_seed=wseed, batch_seed=bseed, masker_seed=mseed, batch=batch_size,
-                        frames=frames, audio_slices=audio_slices, txt_len=32, task=TASK, bf16_exact=bf16_exact)}
+                        frames=frames, audio_slices=audio_slices, txt_len=32, task=TASK, bf16_exact=bf16_exact, model_opts=model_opts)}
     # ---- eval pass (compute_loss=False): argmax ids + features
     with torch.no_grad():
         random.seed(mseed)
@@ -116,6 +132,9 @@ FIXTURES = {
     # wgrad contraction of 25 216 and >= 1024-tile dgrads -- the model-level bf16 run crosses every threshold of the GEMM policy
     # (csrc/gemm.hip use_8ph), so the 8-phase NN / NT / TT kernels are compared with the reference inside the step they are timed in
     "ref_base_b16f8a2_q": dict(batch_size=16, frames=8, audio_slices=2, wseed=41, bseed=42, mseed=43, bf16_exact=True, steps=1),
+    # the shipped LARGE configuration's widths (CLIP ViT-L/14, 257 tokens per frame, LayerNorm rows of 1024, a 588-deep patch GEMM,
+    # task prompt rows in the caption passes) -- full width, two-layer stacks on both sides; B = 8: the contrastive tolerance argument above
+    "ref_cliplarge_b8f2a1_q": dict(batch_size=8, frames=2, audio_slices=1, wseed=61, bseed=62, mseed=63, bf16_exact=True, steps=1, variant="clip_large"),
 }
 
 

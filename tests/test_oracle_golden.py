@@ -83,6 +83,40 @@ def test_oracle_reproduces_reference_goldens(name):
         assert torch.allclose(params[k].detach().reshape(-1)[:64], sl, rtol=1e-5, atol=1e-7), k
 
 
+def test_oracle_reproduces_the_shipped_large_configuration_golden():
+    """tests/golden/ref_cliplarge_b8f2a1_q.pt: the UNMODIFIED reference built from config/pretrain-VALOR-large.json's encoder choice (CLIP
+    ViT-L/14 at 224 px + shared bert_base_uncased, use_task_prompt, contra_loss_ratio 1.5) at full WIDTH on two-layer stacks,
+    bf16-representable weights and inputs. The restatement must reproduce its losses, argmax ids, features and global gradient norm --
+    this is the fixture that ties the 1024-wide / patch-14 / 257-token code paths of the bf16 model to the reference
+    (tests/test_model_gpu.py::test_bf16_meets_north_star_on_identical_tensors)."""
+    g = torch.load(os.path.join(GOLD, "ref_cliplarge_b8f2a1_q.pt"), weights_only=False)
+    rc = g["recipe"]
+    spec = synth.ValorSpec(**rc["spec"])
+    assert spec.vis_width == 1024 and spec.patch == 14 and spec.vis_tokens == 257 and rc["model_opts"] == {"use_task_prompt": True, "contra_loss_ratio": 1.5}
+    sd_o = VO.trainable_copy(synth.make_state_dict(spec, seed=rc["weight_seed"], bf16_exact=True))
+    orc = VO.Oracle(spec, sd_o, vocab_tokens=synth.synthetic_vocab(spec.vocab), **rc["model_opts"])
+    batch = synth.make_batch(spec, batch=rc["batch"], frames=rc["frames"], audio_slices=rc["audio_slices"], txt_len=rc["txt_len"],
+                             seed=rc["batch_seed"], bf16_exact=True)
+    with torch.no_grad():
+        random.seed(rc["masker_seed"])
+        ev = orc.forward_pt(batch, rc["task"], compute_loss=False)
+    for k, ids in g["eval"].items():
+        if "scores" in k:
+            assert torch.equal(ev[k].argmax(-1), ids), k
+    for k in ("feat_t", "feat_v", "feat_a"):
+        assert torch.allclose(ev[k], g["eval"][k], atol=2e-5), k
+    random.seed(rc["masker_seed"])
+    out = orc.forward_pt(batch, rc["task"], compute_loss=True)
+    sum(out.values()).backward()
+    rec = g["steps"][0]
+    for k, v in rec["losses"].items():
+        assert abs(float(out[k]) - v) <= 3e-5 * abs(v), (k, float(out[k]), v)
+    grads = {k: p.grad for k, p in sd_o.items() if p.is_floating_point() and p.grad is not None and not VO.is_alias_key(k)}
+    total = float(torch.sqrt(sum((x.double() ** 2).sum() for x in grads.values())))
+    assert abs(total - rec["total_grad_norm"]) <= 5e-4 * rec["total_grad_norm"], (total, rec["total_grad_norm"])
+    assert "clip_model.transformer.resblocks.0.attn.in_proj_weight" in rec["no_grad"]          # the unused CLIP text tower
+
+
 _SD_CACHE = {}
 
 
