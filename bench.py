@@ -389,6 +389,7 @@ def main():
     sync()
     seg0 = torch.cuda.memory_stats().get("segment.all.allocated", 0)       # device allocations (hipMalloc) so far
     segs_before = {sg["address"] for sg in torch.cuda.memory_snapshot()}
+    seg_trace = [] if os.environ.get("BENCH_SEG_TRACE") else None      # diagnostic: cumulative device allocations after every timed step
     t0 = time.perf_counter()
     last = None
     step_ms = []
@@ -396,6 +397,8 @@ def main():
         ts = time.perf_counter()
         last = one_step()
         step_ms.append((time.perf_counter() - ts) * 1e3)                    # host time of the (asynchronous) step, no sync inside the region
+        if seg_trace is not None:
+            seg_trace.append(int(torch.cuda.memory_stats().get("segment.all.allocated", 0) - seg0))
     sync()
     elapsed = time.perf_counter() - t0
     seg1 = torch.cuda.memory_stats().get("segment.all.allocated", 0)
@@ -484,7 +487,8 @@ def main():
                "losses": {k: round(float(v.detach()) if torch.is_tensor(v) else float(v), 4) for k, v in last.items()},
                "peak_mem_gb": round(torch.cuda.max_memory_allocated() / 2 ** 30, 1),
                "reserved_mem_gb": round(torch.cuda.memory_reserved() / 2 ** 30, 1),
-               "timed_region": {"device_allocations": int(seg1 - seg0), "new_segments_mb": new_segs_mb, "host_ms_per_step": [round(x, 1) for x in step_ms]},
+               "timed_region": {"device_allocations": int(seg1 - seg0), "new_segments_mb": new_segs_mb, "host_ms_per_step": [round(x, 1) for x in step_ms],
+                                **({"allocations_after_step": seg_trace} if seg_trace is not None else {})},
                "roofline": roof}
         if world == 1 and args.sim_world > 1:
             try:

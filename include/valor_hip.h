@@ -113,6 +113,26 @@ int valor_gemm_set_narrow_sched(int v);
  * design point is 2; -1 on a runtime error. Needs a device. */
 int valor_gemm_narrow_occupancy(void);
 
+/* ---- cross-attention backward of EVERY decoder pass of a layer in one launch (csrc/attention_xu.hip). Replaces the autograd backward of
+ * BertCrossAttention (model/bert.py:314-340) for the passes of model/pretrain.py:403-541 that share one projected K|V per layer (the
+ * caption pass with its tva / tv / ta groups and the mlm pass, bert.py:448-457): K and V are read once and dK|dV WRITTEN once, where one
+ * valor_attn_bwd per pass read K, V per pass and read-modified-wrote dK|dV from the second pass on.
+ *   segs: HOST array of nseg (1 or 2) segment descriptors. Per segment q / o / dout / dq are [B, Sq, H*64] views (batch stride *_bs, row
+ *   stride *_rs, elements), lse fp32 [B, H, Sq], kv_range int32 [B][2] = (first key, keys) or NULL, B = groups x kv_bmod: row r attends to
+ *   K/V batch r % kv_bmod; (seed, offset) = the dropout window valor_attn_fwd used for that pass.
+ *   k, v, dk, dv: [kv_bmod, Skv, H*64] views. dK|dV is overwritten (not accumulated). bf16 only, head_dim 64, Skv >= 64, at most ten 16-row
+ *   query sub-tiles (sum over segments of B / kv_bmod x ceil(Sq / 16)); VALOR_ERR_ARG otherwise (callers fall back to valor_attn_bwd per
+ *   pass; env VALOR_ATTN_XFUSED=0 forces that). */
+typedef struct valor_xattn_seg {
+    const void* q; const void* o; const void* dout; void* dq; const float* lse; const int* kv_range;
+    int64_t q_bs, q_rs, o_bs, o_rs, do_bs, do_rs, dq_bs, dq_rs;
+    int B, Sq;
+    uint64_t seed, offset;
+} valor_xattn_seg;
+int valor_cross_attn_bwd_fused(void* stream, int dtype, const valor_xattn_seg* segs, int nseg, const void* k, const void* v, void* dk, void* dv,
+                               int H, int Skv, int kv_bmod, int64_t k_bs, int64_t k_rs, int64_t v_bs, int64_t v_rs, int64_t dk_bs,
+                               int64_t dk_rs, int64_t dv_bs, int64_t dv_rs, float scale, float p_drop);
+
 /* ---- fused bias + dropout + residual + LayerNorm.  Replaces apex FusedLayerNorm (apex/csrc/layer_norm_cuda_kernel.cu
  * :279-322 forward, :403-634 backward; wrapper apex/apex/normalization/fused_layer_norm.py:14-37) plus the elementwise ops
  * around it: bert.py:351-355,365-371,416-420 (post-LN), transformer.py:74-85 (pre-LN AST), clip.py:194-197 (pre-LN CLIP).

@@ -19,7 +19,7 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-val
 
 # substrings of (mangled) kernel names that must not touch scratch: the GEMM families, the LDS-resident attention, LayerNorm, AdamW,
 # cross-entropy, the fused contrastive forward and the VideoSwin window forward / dK-dV kernels ...
-HOT_KERNELS = ("gemm_8ph_kernel", "gemm_8ph2_kernel", "gemm_glds_kernel", "gemm_splitk_reduce", "attn_res_", "attn_x_", "ln_fwd", "ln_bwd", "adamw_kernel", "xent_",
+HOT_KERNELS = ("gemm_8ph_kernel", "gemm_8ph2_kernel", "gemm_glds_kernel", "gemm_splitk_reduce", "attn_res_", "attn_x_", "attn_xu_", "ln_fwd", "ln_bwd", "adamw_kernel", "xent_",
                "fine_fused_fwd", "fine_ds_chunk_kernelIDF16bLi16", "win_fwd", "win_bwd_dkv")
 # ... except the instantiations whose register demand is known and documented: the key-stationary cross-attention with six
 # / eight query sub-tiles keeps 96 / 128 accumulator registers of dQ (O) per wave beside dK / dV; its dropout variants of four.

@@ -3,6 +3,8 @@
 torch is used for device memory, streams and shapes only; every computation below is a
 HIP kernel in libvalor_hip.so. All tensors must live on the GPU: a CPU tensor is an error.
 """
+import os
+
 import torch
 
 from . import lib
@@ -215,6 +217,30 @@ def attn_bwd(q, k, v, o, lse, dout, n_heads, *, dq=None, dk=None, dv=None, mask=
              dqb, dqr, dkb, dkr, dvb, dvr, _ptr(mask), mb, mr, _ptr(kv_range), int(kv_bmod), float(scale),
              float(p_drop), int(seed), int(offset), int(accumulate_kv))
     return dq, dk, dv
+
+
+def cross_attn_bwd_fused(segs, k, v, dk, dv, n_heads, kv_bmod, *, scale=0.125, p_drop=0.0):
+    """Backward of up to two decoder passes that attend to the same K|V in ONE launch (csrc/attention_xu.hip): dK|dV are written once.
+    segs: list of dict(q, o, lse, dout, dq [B, T, E] views / lse [B, H, T]; kv_range int32 [B, 2] or None; seed, offset).
+    Returns False (nothing launched) when the shape is outside the fused kernel's domain -- the caller runs attn_bwd per pass."""
+    if k.dtype != torch.bfloat16 or not (1 <= len(segs) <= 2) or k.shape[1] < 64 or kv_bmod <= 0:
+        return False
+    nsub = sum((sg["q"].shape[0] // kv_bmod) * ((sg["q"].shape[1] + 15) // 16) for sg in segs)
+    if nsub > 10 or any(sg["q"].shape[0] % kv_bmod for sg in segs) or os.environ.get("VALOR_ATTN_XFUSED", "1") == "0":
+        return False
+    arr = (lib.XattnSeg * len(segs))()
+    for i, sg in enumerate(segs):
+        q, o, do, dq = sg["q"], sg["o"], sg["dout"], sg["dq"]
+        _check_gpu(q, o, do, dq, sg["lse"], sg.get("kv_range"))
+        a = arr[i]
+        a.q, a.o, a.dout, a.dq, a.lse, a.kv_range = _ptr(q), _ptr(o), _ptr(do), _ptr(dq), _ptr(sg["lse"]), _ptr(sg.get("kv_range"))
+        (a.q_bs, a.q_rs), (a.o_bs, a.o_rs), (a.do_bs, a.do_rs), (a.dq_bs, a.dq_rs) = _bsr(q), _bsr(o), _bsr(do), _bsr(dq)
+        a.B, a.Sq, a.seed, a.offset = q.shape[0], q.shape[1], int(sg.get("seed", 0)), int(sg.get("offset", 0))
+    kb, kr = _bsr(k); vb, vr = _bsr(v); dkb, dkr = _bsr(dk); dvb, dvr = _bsr(dv)
+    import ctypes
+    lib.call("valor_cross_attn_bwd_fused", _stream(), DT_BF16, ctypes.cast(arr, ctypes.c_void_p), len(segs), _ptr(k), _ptr(v), _ptr(dk), _ptr(dv),
+             n_heads, k.shape[1], int(kv_bmod), kb, kr, vb, vr, dkb, dkr, dvb, dvr, float(scale), float(p_drop))
+    return True
 
 
 # ---------------------------------------------------------------------------------------------- VideoSwin

@@ -20,6 +20,13 @@ ACT_DERIV = 16      # flag: `preact` / `dact_aux` hold act'(x) instead of x (inc
 _c = ctypes
 _vp, _i, _i64, _u64, _f = _c.c_void_p, _c.c_int, _c.c_int64, _c.c_uint64, _c.c_float
 
+class XattnSeg(_c.Structure):
+    """valor_xattn_seg of include/valor_hip.h"""
+    _fields_ = [("q", _vp), ("o", _vp), ("dout", _vp), ("dq", _vp), ("lse", _vp), ("kv_range", _vp),
+                ("q_bs", _i64), ("q_rs", _i64), ("o_bs", _i64), ("o_rs", _i64), ("do_bs", _i64), ("do_rs", _i64), ("dq_bs", _i64), ("dq_rs", _i64),
+                ("B", _i), ("Sq", _i), ("seed", _u64), ("offset", _u64)]
+
+
 # name -> argtypes (restype is always int: 0 ok, <0 error)
 SIGNATURES = {
     "valor_gemm": [_vp, _i, _i, _i, _i, _i, _i, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _i, _vp, _vp, _i64,
@@ -53,6 +60,7 @@ SIGNATURES = {
     "valor_attn_bwd": [_vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i,
                        _i64, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _i64,
                        _vp, _i64, _i64, _vp, _i, _f, _f, _u64, _u64, _i],
+    "valor_cross_attn_bwd_fused": [_vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _f, _f],
     "valor_xent_fwd": [_vp, _i, _vp, _vp, _vp, _vp, _i64, _i, _i64],
     "valor_xent_bwd": [_vp, _i, _vp, _vp, _vp, _vp, _f, _i64, _i, _i64],
     "valor_fine_weight_softmax": [_vp, _vp, _vp, _vp, _i, _i],

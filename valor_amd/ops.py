@@ -517,6 +517,14 @@ class SegCrossAttnFn(Function):
         # a static per-layer buffer when the K|V projection lives on the side stream (a tensor that crosses streams through the caching
         # allocator cannot be reused until the other stream has passed it: the pool grows and hipMalloc stalls the step)
         dkv = ctx.dkv_buf if ctx.dkv_buf is not None else torch.empty_like(kv)
+        # every pass in ONE launch when the fused kernel covers the shape (K, V read once, dK|dV written once)
+        if len(segs) <= 2 and len({sg[4] for sg in segs}) == 1:
+            fs = [dict(q=q2d[r0:r0 + B * T].view(B, T, E), o=o[r0:r0 + B * T].view(B, T, E), dout=do[r0:r0 + B * T].view(B, T, E),
+                       dq=dq[r0:r0 + B * T].view(B, T, E), lse=lse, kv_range=kv_range, seed=seed, offset=off)
+                  for (r0, B, T, kv_range, kv_bmod), lse, (seed, off) in zip(segs, lses, rng)]
+            if K.cross_attn_bwd_fused(fs, kv[:, :, :E], kv[:, :, E:], dkv[:, :, :E], dkv[:, :, E:], n_heads, segs[0][4] or segs[0][1],
+                                      scale=1.0 / math.sqrt(64), p_drop=p_drop):
+                return dq, dkv, None, None, None, None
         for i, ((r0, B, T, kv_range, kv_bmod), lse, (seed, off)) in enumerate(zip(segs, lses, rng)):
             sl = slice(r0, r0 + B * T)
             K.attn_bwd(q2d[sl].view(B, T, E), kv[:, :, :E], kv[:, :, E:], o[sl].view(B, T, E), lse, do[sl].view(B, T, E), n_heads,
