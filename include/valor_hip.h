@@ -129,6 +129,11 @@ typedef struct valor_xattn_seg {
     int B, Sq;
     uint64_t seed, offset;
 } valor_xattn_seg;
+/* forward of the same passes in one launch (BertCrossAttention forward, bert.py:314-340): reads q, kv_range, (seed, offset) of every segment,
+ * writes o ([B, Sq, H*64] view, strides o_bs / o_rs) and lse; dout / dq of the descriptors are ignored. Same domain and fallback rule
+ * (valor_attn_fwd per pass) as the backward; the dropout keep pattern is the one valor_attn_fwd draws for (seed, offset). */
+int valor_cross_attn_fwd_fused(void* stream, int dtype, const valor_xattn_seg* segs, int nseg, const void* k, const void* v, int H, int Skv,
+                               int kv_bmod, int64_t k_bs, int64_t k_rs, int64_t v_bs, int64_t v_rs, float scale, float p_drop);
 int valor_cross_attn_bwd_fused(void* stream, int dtype, const valor_xattn_seg* segs, int nseg, const void* k, const void* v, void* dk, void* dv,
                                int H, int Skv, int kv_bmod, int64_t k_bs, int64_t k_rs, int64_t v_bs, int64_t v_rs, int64_t dk_bs,
                                int64_t dk_rs, int64_t dv_bs, int64_t dv_rs, float scale, float p_drop);

@@ -1,4 +1,5 @@
-"""The one-launch cross-attention backward of all decoder passes of a layer (csrc/attention_xu.hip, valor_cross_attn_bwd_fused) against
+"""The one-launch cross-attention forward / backward of all decoder passes of a layer (csrc/attention_xu.hip, valor_cross_attn_fwd_fused /
+valor_cross_attn_bwd_fused) against
 explicit softmax attention in fp64 AND against the per-pass kernels it replaces (valor_attn_bwd with dK|dV accumulation): the decoder's
 geometry -- 3 caption groups x 32 rows with (start, len) key ranges + 42 mlm rows over 1834 keys shared per K/V batch, bert.py:448-457 --
 plus ragged cases (a query tail, key counts that are not tile multiples, a group whose range starts inside a tile), with and without
@@ -95,6 +96,67 @@ def test_fused_backward_matches_fp64_and_the_per_pass_kernels(dev, case, p_drop)
         assert _rel(dkv_new[:, :, :E], kd.grad) <= _rel(dkv_old[:, :, :E], kd.grad) * 1.05 + 1e-4
 
 
+@pytest.mark.parametrize("p_drop", [0.0, 0.1])
+@pytest.mark.parametrize("case", CASES)
+def test_fused_forward_matches_fp64_and_the_per_pass_kernels(dev, case, p_drop):
+    from valor_amd import kernels as K
+    bmod, H, Skv, passes = case
+    E = H * 64
+    g = torch.Generator().manual_seed(Skv + 7 * bmod + 1)
+    scale = 1.0 / math.sqrt(64)
+    kv = (torch.randn((bmod, Skv, 2 * E), generator=g) * 0.8).bfloat16().to(dev)
+    k, v = kv[:, :, :E], kv[:, :, E:]
+    segs, old = [], []
+    for i, (G, T, ranges) in enumerate(passes):
+        B = G * bmod
+        q = (torch.randn((B, T, E), generator=g) * 1.5).bfloat16().to(dev)
+        kvr = None
+        if ranges is not None:
+            kvr = torch.tensor([list(ranges[b // bmod]) for b in range(B)], dtype=torch.int32)
+        seed, off = 21 + i, 777 * (i + 1)
+        kd = kvr.to(dev) if kvr is not None else None
+        old.append(K.attn_fwd(q, k, v, H, kv_range=kd, kv_bmod=bmod, scale=scale, p_drop=p_drop, seed=seed, offset=off))
+        segs.append(dict(q=q, o=torch.full_like(q, float("nan")), lse=torch.full((B, H, T), float("nan"), device=dev), kv_range=kd, kvr_cpu=kvr,
+                         seed=seed, offset=off))
+    assert K.cross_attn_fwd_fused(segs, k, v, H, bmod, scale=scale, p_drop=p_drop)
+    torch.cuda.synchronize()
+    for sg, (o_old, lse_old) in zip(segs, old):
+        assert torch.isfinite(sg["o"].float()).all() and torch.isfinite(sg["lse"]).all()
+        # same keep pattern (p_drop > 0: the dropped entries are the per-pass kernel's) and the same softmax up to the order of the sums
+        assert _rel(sg["o"], o_old) < 8e-3, ("o vs per-pass", _rel(sg["o"], o_old))
+        assert (sg["lse"] - lse_old).abs().max().item() < 2e-3
+        if p_drop == 0.0:
+            ref = _ref(sg["q"].double(), k.double(), v.double(), H, sg["kvr_cpu"], bmod, scale)
+            assert _rel(sg["o"], ref) < 8e-3, ("o", _rel(sg["o"], ref))
+            assert _rel(sg["o"], ref) <= _rel(o_old, ref) * 1.1 + 1e-4
+
+
+def test_fused_forward_and_backward_through_the_autograd_function(dev):
+    """SegCrossAttnFn with the fused kernels on and off (VALOR_ATTN_XFUSED): same outputs and gradients on the decoder's geometry"""
+    import os
+    from valor_amd import ops
+    bmod, H, Skv = 4, 12, 1834
+    E = H * 64
+    g = torch.Generator().manual_seed(5)
+    kv0 = (torch.randn((bmod, Skv, 2 * E), generator=g) * 0.8).bfloat16().to(dev)
+    q0 = (torch.randn((3 * bmod * 32 + bmod * 42, E), generator=g)).bfloat16().to(dev)
+    do = torch.randn(q0.shape, generator=g).bfloat16().to(dev)
+    kvr = torch.tensor([[(0, Skv), (0, 1576), (1576, 258)][r // bmod] for r in range(3 * bmod)], dtype=torch.int32).to(dev)
+    segs = [(0, 3 * bmod, 32, kvr, bmod), (3 * bmod * 32, bmod, 42, None, bmod)]
+    res = {}
+    for mode in ("1", "0"):
+        os.environ["VALOR_ATTN_XFUSED"] = mode
+        try:
+            q, kv = q0.clone().requires_grad_(True), kv0.clone().requires_grad_(True)
+            o = ops.seg_cross_attention(q, kv, H, segs, 0.0)
+            o.backward(do)
+            res[mode] = (o.detach(), q.grad, kv.grad)
+        finally:
+            os.environ.pop("VALOR_ATTN_XFUSED", None)
+    for a, b in zip(res["1"], res["0"]):
+        assert _rel(a, b) < 1.2e-2
+
+
 def test_outside_its_domain_the_fused_entry_declines(dev):
     from valor_amd import kernels as K
     E = 64
@@ -102,3 +164,4 @@ def test_outside_its_domain_the_fused_entry_declines(dev):
     q = torch.randn((1, 200, E), device=dev).bfloat16()             # 13 sub-tiles > 10
     sg = dict(q=q, o=q, lse=torch.zeros((1, 1, 200), device=dev), dout=q, dq=torch.empty_like(q), kv_range=None)
     assert K.cross_attn_bwd_fused([sg], kv[:, :, :E], kv[:, :, E:], kv[:, :, :E].clone(), kv[:, :, E:].clone(), 1, 1) is False
+    assert K.cross_attn_fwd_fused([sg], kv[:, :, :E], kv[:, :, E:], 1, 1) is False

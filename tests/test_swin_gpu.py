@@ -59,6 +59,8 @@ def _ref_window_attention(qkv, table, heads, size, window, shifted):
     (torch.bfloat16, (16, 7, 7), True),                                            # two windows along time, shift (4,0,0)
     (torch.bfloat16, (16, 14, 14), True),                                          # shift in all three dims
     (torch.bfloat16, (2, 7, 7), False),                                            # one small window, N = 98 (sliced bias index)
+    (torch.bfloat16, (4, 14, 14), True), (torch.bfloat16, (4, 7, 7), False),       # N = 196: the bench window (8 frames -> 4 slices): 13
+                                                                                   # query tiles on 2 partitions, a last chunk of ONE key tile
     (torch.float32, (2, 14, 14), True), (torch.float32, (1, 7, 7), False),         # parity-mode instantiation
     (torch.float32, (8, 14, 14), True), (torch.float32, (8, 7, 7), False),         # ... at the PRODUCTION window (392 slots): the
 ])                                                                                 # row-image-only (NOTR) backward

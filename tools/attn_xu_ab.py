@@ -51,9 +51,25 @@ def timeit(fn, reps=10):
     return e0.elapsed_time(e1) / reps * 1e3
 
 
-res = {"per_pass_us": [], "fused_us": []}
+fsegs = [dict(q=sg["q"], o=torch.empty_like(sg["o"]), lse=torch.empty_like(sg["lse"]), kv_range=sg["kv_range"], seed=sg["seed"], offset=sg["offset"])
+         for sg in segs]
+
+
+def old_fwd():
+    for sg in fsegs:
+        K.attn_fwd(sg["q"], k, v, H, kv_range=sg["kv_range"], kv_bmod=b, scale=scale, p_drop=p, seed=sg["seed"], offset=sg["offset"], o=sg["o"],
+                   lse=sg["lse"])
+
+
+def new_fwd():
+    assert K.cross_attn_fwd_fused(fsegs, k, v, H, b, scale=scale, p_drop=p)
+
+
+res = {"per_pass_us": [], "fused_us": [], "fwd_per_pass_us": [], "fwd_fused_us": []}
 for _ in range(3):
     res["per_pass_us"].append(round(timeit(old), 1)); res["fused_us"].append(round(timeit(new), 1))
+    res["fwd_per_pass_us"].append(round(timeit(old_fwd), 1)); res["fwd_fused_us"].append(round(timeit(new_fwd), 1))
+res["fwd_necessary_GB"] = round((kv.numel() * 2 + sum(2 * sg["q"].numel() * 2 for sg in segs)) / 1e9, 3)
 nec = (2 * kv.numel() * 2 + sum(4 * sg["q"].numel() * 2 for sg in segs)) / 1e9
 res["necessary_GB"] = round(nec, 3)
 res["fused_TBps_of_necessary"] = round(nec / min(res["fused_us"]) * 1e3, 2)

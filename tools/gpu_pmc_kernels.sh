@@ -9,5 +9,5 @@ timeout 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $O/fetch -o p -- python
 timeout 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $O/write -o p -- python $R/tools/kernels_one.py 1 > $O/write.log 2>&1; echo "write rc=$?"
 cd $R
 f() { find $O/$1 -name '*.db' | head -1; }
-python tools/pmc_kernels.py gpurun_out/r03_pmc_kernels.md $(f trace) $(f sq) $(f fetch) $(f write) 2>&1 | cut -c1-220
+python tools/pmc_kernels.py gpurun_out/${1:-r04}_pmc_kernels.md $(f trace) $(f sq) $(f fetch) $(f write) 2>&1 | cut -c1-220
 find $O -name '*.db' -delete

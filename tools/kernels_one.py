@@ -1,6 +1,7 @@
 """ONE launch of every non-GEMM hot kernel of the VALOR-base step at its bench shape (per-GPU batch 64), for rocprofv3 --pmc passes
 (tools/gpu_pmc_kernels.sh): LDS-resident self-attention forward / backward (ViT 512 x 12 heads x S = 197; AST with dropout),
-key-stationary cross-attention forward / backward (caption pass: 3 groups x 32 rows against 1834 keys, dropout), fused LayerNorm forward /
+key-stationary cross-attention forward / backward (caption pass: 3 groups x 32 rows against 1834 keys, dropout; the mlm pass; both passes in
+one launch), fused LayerNorm forward /
 backward, cross-entropy, fused AdamW, the fused contrastive forward.
 usage: python tools/kernels_one.py [reps=1]            one launch each, for the counter passes
        python tools/kernels_one.py time out.json       HIP-event time of each (median of 3 rounds x 5 launches); VALOR_HIP_LIB selects the
@@ -19,7 +20,7 @@ from valor_amd.kernels import _ptr, _stream  # noqa: E402
 TIME = len(sys.argv) > 2 and sys.argv[1] == "time"
 reps = 1 if TIME else (int(sys.argv[1]) if len(sys.argv) > 1 else 1)
 NAMES = ["self_fwd_vit", "self_bwd_vit", "self_fwd_ast_drop", "self_bwd_ast_drop", "cross_fwd_caption", "cross_bwd_caption", "cross_fwd_mlm", "cross_bwd_mlm_acc",
-         "ln_fwd", "ln_bwd", "xent_fwd", "xent_bwd", "adamw", "fine_fused_fwd"]
+         "cross_bwd_fused", "cross_fwd_fused", "ln_fwd", "ln_bwd", "xent_fwd", "xent_bwd", "adamw", "fine_fused_fwd"]
 dev = torch.device("cuda:0")
 scale = 1.0 / math.sqrt(64)
 g = torch.Generator().manual_seed(1)
@@ -41,6 +42,7 @@ for B, S, p in ((512, 197, 0.0), (128, 129, 0.1)):
 kvb = (torch.randn((64, 1834, 2 * E), generator=g) * 0.8).to(torch.bfloat16).to(dev)
 kk, vv = kvb[:, :, :E], kvb[:, :, E:]
 dkv = torch.empty_like(kvb)
+xsegs = []
 for Bq, Sq, ranges in ((192, 32, [(0, 1834), (0, 1576), (1576, 258)]), (64, 42, [(0, 1834)])):
     q = (torch.randn((Bq, Sq, E), generator=g) * 0.8).to(torch.bfloat16).to(dev)
     kvr = torch.tensor([list(ranges[b // 64]) for b in range(Bq)], dtype=torch.int32).to(dev)
@@ -49,6 +51,11 @@ for Bq, Sq, ranges in ((192, 32, [(0, 1834), (0, 1576), (1576, 258)]), (64, 42, 
     todo.append(lambda q=q, kvr=kvr: K.attn_fwd(q, kk, vv, H, kv_range=kvr, kv_bmod=64, scale=scale, p_drop=0.1, seed=3, offset=1))
     todo.append(lambda q=q, kvr=kvr, o=o, lse=lse, dout=dout, acc=(Sq == 42): K.attn_bwd(q, kk, vv, o, lse, dout, H, dk=dkv[:, :, :E], dv=dkv[:, :, E:], kv_range=kvr, kv_bmod=64,
                                                                                           scale=scale, p_drop=0.1, seed=3, offset=1, accumulate_kv=acc))
+    xsegs.append(dict(q=q, o=o, lse=lse, dout=dout, dq=torch.empty_like(q), kv_range=kvr, seed=3, offset=1))
+# the same two passes in ONE launch (csrc/attention_xu.hip): what the step runs in backward; the forward twin is opt-in
+todo.append(lambda: K.cross_attn_bwd_fused(xsegs, kk, vv, dkv[:, :, :E], dkv[:, :, E:], H, 64, scale=scale, p_drop=0.1))
+fsegs = [dict(q=sg["q"], o=torch.empty_like(sg["o"]), lse=torch.empty_like(sg["lse"]), kv_range=sg["kv_range"], seed=3, offset=1) for sg in xsegs]
+todo.append(lambda: K.cross_attn_fwd_fused(fsegs, kk, vv, H, 64, scale=scale, p_drop=0.1))
 # ---- fused LayerNorm at the ViT shape
 rows, cols = 100864, 768
 x = torch.randn((rows, cols), generator=g).to(torch.bfloat16).to(dev); r = torch.randn((rows, cols), generator=g).to(torch.bfloat16).to(dev)

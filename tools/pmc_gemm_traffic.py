@@ -2,7 +2,7 @@
 Runs rocprofv3 --kernel-trace --pmc FETCH_SIZE and --pmc WRITE_SIZE as SEPARATE passes (MI355X_MICROARCH.md: FETCH_SIZE takes 3 of
 the 4 TCC slots) on tools/gemm_one.py for each shape and sums the counters per dispatch of the GEMM kernel.
 FETCH_SIZE (KB, tallied at 64 B per 128-B request on gfx950) is doubled; WRITE_SIZE (KB) is taken as reported.
-usage (GPU box, from the repo root): python tools/pmc_gemm_traffic.py gpurun_out/r02_pmc_gemm_traffic.json"""
+usage (GPU box, from the repo root): python tools/pmc_gemm_traffic.py gpurun_out/r04_pmc_gemm_traffic.json"""
 import glob
 import json
 import os
@@ -11,12 +11,23 @@ import subprocess
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-SHAPES = [   # bench name of the kernel family, label, M N K ta tb, algorithmic bytes (bf16 operands + output once)
-    ("gemm_8ph_kernel(256x256 8-phase) TT (wgrad dY^T.X)", "M=3072 N=768 K=100864 (ViT fc1 wgrad, 7 K-slices)", 3072, 768, 100864, 1, 1),
-    ("gemm_8ph_kernel(256x256 8-phase) NN (forward x.W^T)", "M=100864 N=3072 K=768 (ViT fc1 forward)", 100864, 3072, 768, 0, 0),
-    ("gemm_8ph_kernel(256x256 8-phase) NT (dgrad dY.W)", "M=100864 N=768 K=3072 (ViT fc1 dgrad)", 100864, 768, 3072, 0, 1),
-    ("gemm_glds_kernel(128x128 LDS-DMA) NT (dgrad dY.W)", "M=16512 N=3072 K=768 (AST fc2 dgrad)", 16512, 3072, 768, 0, 1),
+FAMILY = {1: "gemm_glds_kernel(128x128 LDS-DMA)", 3: "gemm_8ph_kernel(256x256 8-phase)", 4: "gemm_8ph2_kernel(256x128 8-phase, 2 workgroups per CU)"}
+LAYOUT = {"NN": "forward x.W^T", "NT": "dgrad dY.W", "TT": "wgrad dY^T.X"}
+SHAPES = [   # label, M N K ta tb -- the kernel family (hence bench.py's name of it) is asked from the library's policy at run time
+    ("M=3072 N=768 K=100864 (ViT fc1 wgrad, 7 K-slices)", 3072, 768, 100864, 1, 1),
+    ("M=100864 N=3072 K=768 (ViT fc1 forward)", 100864, 3072, 768, 0, 0),
+    ("M=100864 N=768 K=3072 (ViT fc2 forward)", 100864, 768, 3072, 0, 0),
+    ("M=100864 N=3072 K=768 (ViT fc2 dgrad)", 100864, 3072, 768, 0, 1),
+    ("M=100864 N=768 K=3072 (ViT fc1 dgrad)", 100864, 768, 3072, 0, 1),
+    ("M=16512 N=768 K=3072 (AST fc1 dgrad)", 16512, 768, 3072, 0, 1),
 ]
+
+
+def bench_name(M, N, Kd, ta, tb):
+    sys.path.insert(0, ROOT)
+    from valor_amd import lib
+    fam = lib.load().valor_gemm_kernel_for(0, ta, tb, M, N, Kd, 0)
+    return f"{FAMILY.get(fam, 'family %d' % fam)} {'NT'[ta]}{'NT'[tb]} ({LAYOUT['NT'[ta] + 'NT'[tb]]})"
 
 
 def counter(db, name):
@@ -34,7 +45,10 @@ def main():
     out_path = sys.argv[1]
     work = "/tmp/pmc_gemm"
     res = {}
-    for name, label, M, N, Kd, ta, tb in SHAPES:
+    for label, M, N, Kd, ta, tb in SHAPES:
+        name = bench_name(M, N, Kd, ta, tb)
+        if name in res:
+            name = name + " | " + label
         got = {}
         for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
             d = f"{work}/{M}_{N}_{Kd}_{ta}{tb}_{ctr}"

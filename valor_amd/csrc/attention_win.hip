@@ -32,10 +32,18 @@
 
 #define WIN_D 32
 typedef __attribute__((ext_vector_type(4))) int i32x4_t;
+// diagnostic builds (tools/build_win_ablate.sh, never the shipped library): WIN_ABLATE bit 0 = no table fill, 1 = no tile loop,
+// 2 = the bias gather always reads entry 0, 3 = no exponential. Result at VideoSwin-B stage 3 (b = 64, 8 frames: 4096 (window, head) pairs
+// of 196 slots; profiles/r04_win_ablate_stage3.txt): forward 359-387 us, 319-339 without the table fill, 85 without the tile loop,
+// 286-319 with the gather pinned, 312-332 without exponentials; dK/dV 428 / 82 without the loop; dQ 730 / 355 without the loop.
+#ifndef WIN_ABLATE
+#define WIN_ABLATE 0
+#endif
+#define WIN_TBI(i) ((WIN_ABLATE & 4) ? 0 : (i))
 // softmax runs in the log2 domain (v_exp_f32 is 2^x): the table column and the scale are pre-multiplied by log2(e)
 template <typename T> DEVINL float fexp2(float x);
 template <> DEVINL float fexp2<float>(float x) { return exp2f(x); }
-template <> DEVINL float fexp2<bf16_t>(float x) { return __builtin_amdgcn_exp2f(x); }
+template <> DEVINL float fexp2<bf16_t>(float x) { return (WIN_ABLATE & 8) ? x : __builtin_amdgcn_exp2f(x); }
 #define WIN_MASK2 (100.0f * LOG2E_F)     // the shift mask's -100 (videoswin.py:284) in the log2 domain
 
 struct WinArgs {
@@ -166,6 +174,7 @@ DEVINL void win_fill_slots(const WinArgs& p, const WinSmem& s, int b, int w, int
 template <typename T>
 DEVINL void win_fill_table(const WinArgs& p, float* tb, int h, int tid, int nthreads) {
     const T* t = (const T*)p.table;
+    if (WIN_ABLATE & 1) return;
     for (int r = tid; r < p.R; r += nthreads) tb[r] = to_f32<T>(t[(int64_t)r * p.heads + h]) * LOG2E_F;
 }
 DEVINL WinSmem win_carve(char* smem, int R, int npad) {
@@ -200,7 +209,7 @@ __global__ __launch_bounds__(512) void win_fwd_kernel(WinArgs p) {
     win_stage<T, false, true>(qkv, ld, 2 * p.C + h * WIN_D, s.rows, N, npad, nullptr, sVt, tid, 512);
     __syncthreads();
 
-    for (int qt = wave; qt * 16 < N; qt += 8) {
+    for (int qt = wave; qt * 16 < N && !(WIN_ABLATE & 2); qt += 8) {
         const int qr = qt * 16 + fr;
         const bool qok = qr < N;
         const int qrow = s.rows[qok ? qr : 0];
@@ -231,7 +240,7 @@ __global__ __launch_bounds__(512) void win_fwd_kernel(WinArgs p) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int X = relq - rk[r];
-                    float v = sacc[kt][r] * scale2 + s.tb[SHIFT ? (X & 0xffff) : X];
+                    float v = sacc[kt][r] * scale2 + s.tb[WIN_TBI(SHIFT ? (X & 0xffff) : X)];
                     if (SHIFT) v = (uint32_t)X > 0xffffu ? v - WIN_MASK2 : v;
                     if (TAIL) v = kb + r < N ? v : -INFINITY;
                     sacc[kt][r] = v;
@@ -365,7 +374,7 @@ __global__ __launch_bounds__(512) void win_bwd_dq_kernel(WinArgs p) {
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         const int X = relq - rk[r];
-                        float v = sacc[kt][r] * scale2 + s.tb[SHIFT ? (X & 0xffff) : X];
+                        float v = sacc[kt][r] * scale2 + s.tb[WIN_TBI(SHIFT ? (X & 0xffff) : X)];
                         if (SHIFT) v = (uint32_t)X > 0xffffu ? v - WIN_MASK2 : v;
                         float ds = fexp2<T>(v - lse2) * (dpacc[kt][r] - dl);
                         ds = kb + r < N ? ds : 0.f;
@@ -524,7 +533,7 @@ __global__ __launch_bounds__(512) void win_bwd_dq_dma_kernel(WinArgs p) {
                     if (tid < npad) srel[(cur ^ 1) * npad + tid] = nrel;
                 }
             }
-            if (active && k0 < npad) {
+            if (active && k0 < npad && !(WIN_ABLATE & 2)) {
                 f32x4_t sacc[4], dpacc[4];
 #pragma unroll
                 for (int kt = 0; kt < 4; ++kt) {
@@ -545,7 +554,7 @@ __global__ __launch_bounds__(512) void win_bwd_dq_dma_kernel(WinArgs p) {
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         const int X = relq - rk[r];
-                        float v = sacc[kt][r] * scale2 + tb[SHIFT ? (X & 0xffff) : X];
+                        float v = sacc[kt][r] * scale2 + tb[WIN_TBI(SHIFT ? (X & 0xffff) : X)];
                         if (SHIFT) v = (uint32_t)X > 0xffffu ? v - WIN_MASK2 : v;
                         sacc[kt][r] = fexp2<T>(v - lse2) * (dpacc[kt][r] - dl);
                     }
@@ -664,7 +673,7 @@ __global__ __launch_bounds__(512) void win_fwd_dma_kernel(WinArgs p) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int X = relq - rk[r];
-                    float v = sacc[kt][r] * scale2 + tb[SHIFT ? (X & 0xffff) : X];
+                    float v = sacc[kt][r] * scale2 + tb[WIN_TBI(SHIFT ? (X & 0xffff) : X)];
                     if (SHIFT) v = (uint32_t)X > 0xffffu ? v - WIN_MASK2 : v;
                     if (TAIL) v = kb + r < N ? v : -INFINITY;
                     sacc[kt][r] = v;
@@ -749,7 +758,7 @@ __global__ __launch_bounds__(512) void win_bwd_dkv_dma_kernel(WinArgs p) {
     const int tro0 = win_tr_off(lane, 0), tro1 = win_tr_off(lane, 1);
     const float scale2 = p.scale * LOG2E_F;
 
-    for (int kt = wave; kt * 16 < N; kt += 8) {
+    for (int kt = wave; kt * 16 < N && !(WIN_ABLATE & 2); kt += 8) {
         const int kr = kt * 16 + fr;
         const bool kok = kr < N;
         const int krow = kok ? b * p.rows_per_sample + p.rowmap[w * N + kr] : 0;
@@ -782,7 +791,7 @@ __global__ __launch_bounds__(512) void win_bwd_dkv_dma_kernel(WinArgs p) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int X = rq[r] + kneg;
-                    float v = sacc[t][r] * scale2 + tb[SHIFT ? (X & 0xffff) : X];
+                    float v = sacc[t][r] * scale2 + tb[WIN_TBI(SHIFT ? (X & 0xffff) : X)];
                     if (SHIFT) v = (uint32_t)X > 0xffffu ? v - WIN_MASK2 : v;
                     const float pr = fexp2<T>(v - ls[r]);
                     sacc[t][r] = pr;
@@ -891,7 +900,7 @@ __global__ __launch_bounds__(1024) void win_bwd_dkv_kernel(WinArgs p) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int X = rq[r] + kneg;
-                    float v = sacc[t][r] * scale2 + s.tb[SHIFT ? (X & 0xffff) : X];
+                    float v = sacc[t][r] * scale2 + s.tb[WIN_TBI(SHIFT ? (X & 0xffff) : X)];
                     if (SHIFT) v = (uint32_t)X > 0xffffu ? v - WIN_MASK2 : v;
                     const float pr = fexp2<T>(v - ls[r]);          // key lanes past the window compute garbage-free zeros' worth: never stored
                     sacc[t][r] = pr;

@@ -268,6 +268,187 @@ __global__ __launch_bounds__(256, 2) void attn_xu_bwd_kernel(XuArgs p) {
     }
 }
 
+// ------------------------------------------------------------------------------------------ forward, every pass in one launch
+// Same ownership (one workgroup per (K/V batch, head), all query sub-tiles of up to two passes, 64-key tiles read once) and the same split:
+// scores are KEY-split (wave w: keys [16w, 16w + 16) of the tile, S^T[key][q] so a lane owns 4 keys of ONE query row), the output is
+// D-split (wave w accumulates O^T[d in 16w .. 16w + 16][q] over all 64 keys: one f32x4 per sub-tile, no merge of partial softmax states
+// at the end). That needs ONE running maximum per query row shared by the four waves: per tile the waves exchange their partial row
+// maxima through LDS (barrier), exponentiate against the common maximum, write P as bf16 [q][64 keys] rows into LDS (barrier) and every
+// wave contracts V^T (transposing reads of the V tile) with all of P. The partial row SUMS stay per wave (same common maximum) and meet
+// once at the end. K / V are double-buffered: tile t + 1 lands while tile t is computed -- three barriers per tile.
+// LDS at ten sub-tiles: Q images 20 KiB + 2 x (K + V) 32 KiB + P 20 KiB + maxima / sums 5 KiB = 77 KiB: two workgroups per CU.
+// byte offset of (query row fr, key byte `b` of the 128-byte row, b % 8 == 0) in a P image: 16-byte chunks XOR-ed with the row, the 8-byte
+// half flipped for rows >= 8 -- the 16 rows a ds_write_b64 / ds_read_b64 touches at one key offset land in 16 different 8-byte bank slots
+// (unswizzled, all 16 hit one: the first version of this kernel spent 2/3 of its time in those conflicts)
+DEVINL int xu_p_off(int fr, int b) { return fr * 128 + ((((b >> 4) ^ fr) & 7) << 4) + ((b & 8) ^ ((fr & 8))); }
+
+template <int NQS, bool DROP>
+__global__ __launch_bounds__(256, 2) void attn_xu_fwd_kernel(XuArgs p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int QIMG = NQS * 16 * TILE_ROW_BYTES;
+    char* sQ = smem;
+    char* sKV = smem + QIMG;                             // [2 buffers][K 8 KiB | V 8 KiB]
+    char* sP = sKV + 32768;                              // [NQS][16 q][64 keys] bf16
+    float* sMax = (float*)(sP + NQS * 2048);             // [NQS][4 waves][16 q]
+    float* sSum = sMax + NQS * 64;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int fr = lane & 15, g = lane >> 4;
+    const int h = blockIdx.x, kvb = blockIdx.y;
+
+    const rsrc_t rsK = xu_head_rsrc(p.k, (int64_t)kvb * p.k_bs + h * ATT_D, p.Skv, p.k_rs);
+    const rsrc_t rsV = xu_head_rsrc(p.v, (int64_t)kvb * p.v_bs + h * ATT_D, p.Skv, p.v_rs);
+    const int krs_b = (int)p.k_rs * 2, vrs_b = (int)p.v_rs * 2;
+    const int prow = lane >> 3, pch = (lane & 7) ^ prow;
+
+    int sb_[NQS], sq0_[NQS], ss0_[NQS], ss1_[NQS], sg_[NQS];
+    bool sv_[NQS];
+#pragma unroll
+    for (int u = 0; u < NQS; ++u) {
+        const XuSub t_ = xu_sub(p, u, kvb);
+        sb_[u] = t_.b; sq0_[u] = t_.q0; ss0_[u] = t_.start; ss1_[u] = t_.end; sv_[u] = t_.valid; sg_[u] = t_.seg;
+    }
+    // Q images: 2 pieces of 8 rows per sub-tile, dealt round the waves (rows >= Sq zero filled by the descriptor)
+    for (int pc = wave; pc < 2 * NQS; pc += 4) {
+        const int u = pc >> 1, piece = pc & 1;
+        const XuSub su = xu_sub(p, u, kvb);
+        const XuSeg& sg = su.seg ? p.s[1] : p.s[0];
+        if (su.valid) {
+            const rsrc_t rq = xu_head_rsrc(sg.q, (int64_t)su.b * sg.q_bs + h * ATT_D, sg.Sq, sg.q_rs);
+            glds16(rq, sQ + pc * 1024, (su.q0 + piece * 8 + prow) * (int)(sg.q_rs * 2) + pch * 16);
+        } else {
+            *(u32x4_t*)(sQ + pc * 1024 + lane * 16) = (u32x4_t){0u, 0u, 0u, 0u};
+        }
+    }
+    auto stage = [&](int t, char* buf) {                // keys [64t, 64t + 64) of K and V: 8 + 8 pieces, 2 + 2 per wave
+        const int kv0 = t << 6;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int j = wave * 2 + i;
+            glds16(rsK, buf + j * 1024, (kv0 + j * 8 + prow) * krs_b + pch * 16);
+            glds16(rsV, buf + 8192 + j * 1024, (kv0 + j * 8 + prow) * vrs_b + pch * 16);
+        }
+    };
+    const int NT = (p.Skv + 63) >> 6;
+    stage(0, sKV);
+
+    f32x4_t oacc[NQS];
+    float mrow[NQS], lrow[NQS];
+#pragma unroll
+    for (int u = 0; u < NQS; ++u) { oacc[u] = (f32x4_t){0.f, 0.f, 0.f, 0.f}; mrow[u] = -1e30f; lrow[u] = 0.f; }
+    const float sl2 = p.scale * LOG2E_F;
+    const uint32_t thr = drop_threshold(p.p_drop);
+    const float keep_scale = p.p_drop > 0.f ? 1.0f / (1.0f - p.p_drop) : 1.0f;
+    const int troff_w = tr_lane_off(lane, wave);
+    const int kw0 = wave * 16;
+    const int po[4] = {xu_p_off(fr, 8 * g), xu_p_off(fr, 8 * g + 32), xu_p_off(fr, 8 * g + 64), xu_p_off(fr, 8 * g + 96)};
+
+    for (int t = 0; t < NT; ++t) {
+        const int kv0 = t << 6;
+        char* const cur = sKV + (t & 1) * 16384;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();                                   // tile t landed; everyone is done with tile t - 1 (the other buffer, sP, sMax)
+        if (t + 1 < NT) stage(t + 1, sKV + ((t + 1) & 1) * 16384);
+        const int ka = kv0 + kw0;
+        bf16x8_t kf[2];
+#pragma unroll
+        for (int dg = 0; dg < 2; ++dg) kf[dg] = read_frag<bf16_t>(cur, kw0 + fr, dg * 4 + g);
+        f32x4_t sv4[NQS];
+        // ---- scores of this wave's 16 keys, partial row maxima
+#pragma unroll
+        for (int u = 0; u < NQS; ++u) {
+            const bool actt = sv_[u] && kv0 + 64 > ss0_[u] && kv0 < ss1_[u];
+            if (!actt) continue;
+            float mx = -INFINITY;
+            sv4[u] = (f32x4_t){-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+            if (ka + 16 > ss0_[u] && ka < ss1_[u]) {
+                f32x4_t sacc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int dg = 0; dg < 2; ++dg) sacc = Mma<bf16_t>::mma(kf[dg], read_frag<bf16_t>(sQ, u * 16 + fr, dg * 4 + g), sacc);   // S^T[key = 4g + r][q = fr]
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int key = ka + 4 * g + r;
+                    const float s = (key >= ss0_[u] && key < ss1_[u]) ? sacc[r] * sl2 : -INFINITY;
+                    sv4[u][r] = s;
+                    mx = fmaxf(mx, s);
+                }
+                mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+                mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+            }
+            if (g == 0) sMax[u * 64 + wave * 16 + fr] = mx;
+        }
+        __syncthreads();
+        // ---- common maximum, probabilities -> sP, partial row sums
+        float alpha[NQS];
+#pragma unroll
+        for (int u = 0; u < NQS; ++u) {
+            alpha[u] = 1.0f;
+            const bool actt = sv_[u] && kv0 + 64 > ss0_[u] && kv0 < ss1_[u];
+            if (!actt) continue;
+            const float* mp = sMax + u * 64 + fr;
+            const float mt = fmaxf(fmaxf(mp[0], mp[16]), fmaxf(mp[32], mp[48]));
+            const float mnew = fmaxf(mrow[u], mt);
+            alpha[u] = xu_exp2(mrow[u] - mnew);
+            mrow[u] = mnew;
+            float ps = 0.f;
+            f32x4_t pv;
+            uint32_t hk = 0;
+            if (DROP) {
+                const XuSeg& sg = sg_[u] ? p.s[1] : p.s[0];
+                hk = attn_drop_headkey(sg.seed, sg.offset, sb_[u] * p.H + h);
+            }
+            const uint32_t rowbase = (uint32_t)(sq0_[u] + fr) * (uint32_t)p.Skv;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float e = xu_exp2(sv4[u][r] - mnew);
+                ps += e;
+                if (DROP) e = attn_drop_bits(hk, rowbase + (uint32_t)(ka + 4 * g + r - ss0_[u])) >= thr ? e * keep_scale : 0.f;
+                pv[r] = e;
+            }
+            ps += __shfl_xor(ps, 16, 64);
+            ps += __shfl_xor(ps, 32, 64);
+            lrow[u] = lrow[u] * alpha[u] + ps;
+            *(u32x2_t*)(sP + u * 2048 + xu_p_off(fr, (kw0 + 4 * g) * 2)) = (u32x2_t){pack2_bf16(pv[0], pv[1]), pack2_bf16(pv[2], pv[3])};
+        }
+        __syncthreads();
+        // ---- O^T[d = 16w + ..][q] = alpha O^T + V^T[d][key] . P^T[key][q] over the 64 keys
+        {
+            const bf16x8_t vt0 = read_frag_tr_nat(cur + 8192, 0, troff_w), vt1 = read_frag_tr_nat(cur + 8192, 32, troff_w);
+#pragma unroll
+            for (int u = 0; u < NQS; ++u) {
+                if (!(sv_[u] && kv0 + 64 > ss0_[u] && kv0 < ss1_[u])) continue;
+                const char* b = sP + u * 2048;                               // natural k-slot order: keys 4g + j, then 16 + 4g + j
+                const u32x2_t a0 = *(const u32x2_t*)(b + po[0]), a1 = *(const u32x2_t*)(b + po[1]), a2 = *(const u32x2_t*)(b + po[2]),
+                              a3 = *(const u32x2_t*)(b + po[3]);
+                const bf16x8_t p0 = __builtin_bit_cast(bf16x8_t, (u32x4_t){a0[0], a0[1], a1[0], a1[1]});
+                const bf16x8_t p1 = __builtin_bit_cast(bf16x8_t, (u32x4_t){a2[0], a2[1], a3[0], a3[1]});
+                oacc[u] *= alpha[u];
+                oacc[u] = Mma<bf16_t>::mma(vt0, p0, oacc[u]);
+                oacc[u] = Mma<bf16_t>::mma(vt1, p1, oacc[u]);
+            }
+        }
+    }
+    // ---- row sums of the four waves meet; O = O^T / L; lse
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < NQS; ++u)
+        if (g == 0) sSum[u * 64 + wave * 16 + fr] = lrow[u];
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < NQS; ++u) {
+        if (!sv_[u]) continue;
+        const XuSeg& sg = sg_[u] ? p.s[1] : p.s[0];
+        const float* lp = sSum + u * 64 + fr;
+        const float L = (lp[0] + lp[16]) + (lp[32] + lp[48]);
+        const float inv = L > 0.f ? 1.0f / L : 0.f;
+        const int qr = sq0_[u] + fr;
+        if (qr < sg.Sq) {
+            store4<bf16_t>((bf16_t*)sg.o + (int64_t)sb_[u] * sg.o_bs + (int64_t)qr * sg.o_rs + h * ATT_D + 16 * wave + 4 * g, oacc[u] * inv);
+            if (wave == 0 && g == 0) ((float*)sg.lse)[((int64_t)sb_[u] * p.H + h) * sg.Sq + qr] = (mrow[u] + __log2f(L)) * LN2_F;
+        }
+    }
+}
+
 // VALOR_ATTN_XFUSED=0 (or valor_attn_set_variant bit 3 cleared) keeps the per-pass kernels of attention_x.hip
 static int g_xu_on = [] { const char* e = getenv("VALOR_ATTN_XFUSED"); return e ? atoi(e) : 1; }();
 
@@ -279,27 +460,28 @@ struct valor_xattn_seg_c {
     uint64_t seed, offset;
 };
 
-extern "C" int valor_cross_attn_bwd_fused(void* stream, int dtype, const void* segs_, int nseg, const void* k, const void* v, void* dk, void* dv,
-                                          int H, int Skv, int kv_bmod, int64_t k_bs, int64_t k_rs, int64_t v_bs, int64_t v_rs, int64_t dk_bs,
-                                          int64_t dk_rs, int64_t dv_bs, int64_t dv_rs, float scale, float p_drop) {
+// shared argument handling of the two entries; bwd: the segments carry dout / dq too
+static int xu_fill(XuArgs& p, int dtype, const void* segs_, int nseg, const void* k, const void* v, int H, int Skv, int kv_bmod, int64_t k_bs,
+                   int64_t k_rs, int64_t v_bs, int64_t v_rs, float scale, float p_drop, bool bwd) {
     const valor_xattn_seg_c* segs = (const valor_xattn_seg_c*)segs_;
-    if (dtype != VALOR_DT_BF16 || !g_xu_on) return VALOR_ERR_ARG;          // the caller falls back to valor_attn_bwd per pass
-    if (!segs || nseg < 1 || nseg > 2 || !k || !v || !dk || !dv || H <= 0 || Skv < 64 || kv_bmod <= 0) return VALOR_ERR_ARG;
+    if (dtype != VALOR_DT_BF16 || !g_xu_on) return VALOR_ERR_ARG;          // the caller falls back to valor_attn_fwd / _bwd per pass
+    if (!segs || nseg < 1 || nseg > 2 || !k || !v || H <= 0 || Skv < 64 || kv_bmod <= 0) return VALOR_ERR_ARG;
     if ((k_rs & 7) || (v_rs & 7) || (k_bs & 7) || (v_bs & 7) || ((uintptr_t)k & 15) || ((uintptr_t)v & 15)) return VALOR_ERR_ARG;
-    if ((dk_rs & 3) || (dv_rs & 3) || (dk_bs & 3) || (dv_bs & 3)) return VALOR_ERR_ARG;
     const int64_t lim = (int64_t)1 << 31;
     if ((int64_t)Skv * k_rs * 2 >= lim || (int64_t)Skv * v_rs * 2 >= lim) return VALOR_ERR_ARG;
-    XuArgs p = {};
     p.nseg = nseg; p.bmod = kv_bmod; p.H = H; p.Skv = Skv; p.scale = scale; p.p_drop = p_drop;
-    p.k = k; p.v = v; p.dk = dk; p.dv = dv;
-    p.k_bs = k_bs; p.k_rs = k_rs; p.v_bs = v_bs; p.v_rs = v_rs; p.dk_bs = dk_bs; p.dk_rs = dk_rs; p.dv_bs = dv_bs; p.dv_rs = dv_rs;
+    p.k = k; p.v = v;
+    p.k_bs = k_bs; p.k_rs = k_rs; p.v_bs = v_bs; p.v_rs = v_rs;
     int nsub = 0;
     for (int i = 0; i < nseg; ++i) {
         const valor_xattn_seg_c& s = segs[i];
-        if (!s.q || !s.o || !s.dout || !s.dq || !s.lse || s.B <= 0 || s.Sq <= 0 || s.B % kv_bmod) return VALOR_ERR_ARG;
-        if ((s.q_rs & 7) || (s.q_bs & 7) || (s.o_rs & 7) || (s.o_bs & 7) || (s.do_rs & 7) || (s.do_bs & 7) || (s.dq_rs & 3) || (s.dq_bs & 3)) return VALOR_ERR_ARG;
-        if (((uintptr_t)s.q & 15) || ((uintptr_t)s.o & 15) || ((uintptr_t)s.dout & 15)) return VALOR_ERR_ARG;
-        if ((int64_t)s.Sq * s.q_rs * 2 >= lim || (int64_t)s.Sq * s.do_rs * 2 >= lim) return VALOR_ERR_ARG;
+        if (!s.q || !s.o || !s.lse || s.B <= 0 || s.Sq <= 0 || s.B % kv_bmod) return VALOR_ERR_ARG;
+        if ((s.q_rs & 7) || (s.q_bs & 7) || ((uintptr_t)s.q & 15) || (int64_t)s.Sq * s.q_rs * 2 >= lim) return VALOR_ERR_ARG;
+        if (bwd) {
+            if (!s.dout || !s.dq) return VALOR_ERR_ARG;
+            if ((s.o_rs & 7) || (s.o_bs & 7) || (s.do_rs & 7) || (s.do_bs & 7) || (s.dq_rs & 3) || (s.dq_bs & 3)) return VALOR_ERR_ARG;
+            if (((uintptr_t)s.o & 15) || ((uintptr_t)s.dout & 15) || (int64_t)s.Sq * s.do_rs * 2 >= lim) return VALOR_ERR_ARG;
+        } else if ((s.o_rs & 3) || (s.o_bs & 3)) return VALOR_ERR_ARG;
         XuSeg& d = p.s[i];
         d.q = s.q; d.o = s.o; d.dout = s.dout; d.dq = s.dq; d.lse = s.lse; d.kv_range = s.kv_range;
         d.q_bs = s.q_bs; d.q_rs = s.q_rs; d.o_bs = s.o_bs; d.o_rs = s.o_rs; d.do_bs = s.do_bs; d.do_rs = s.do_rs; d.dq_bs = s.dq_bs; d.dq_rs = s.dq_rs;
@@ -311,6 +493,44 @@ extern "C" int valor_cross_attn_bwd_fused(void* stream, int dtype, const void* s
     if (nseg == 1) p.qs1 = 1;
     p.nsub = nsub;
     if (nsub > 10) return VALOR_ERR_ARG;
+    return VALOR_OK;
+}
+
+extern "C" int valor_cross_attn_fwd_fused(void* stream, int dtype, const void* segs, int nseg, const void* k, const void* v, int H, int Skv,
+                                          int kv_bmod, int64_t k_bs, int64_t k_rs, int64_t v_bs, int64_t v_rs, float scale, float p_drop) {
+    XuArgs p = {};
+    const int rc = xu_fill(p, dtype, segs, nseg, k, v, H, Skv, kv_bmod, k_bs, k_rs, v_bs, v_rs, scale, p_drop, false);
+    if (rc != VALOR_OK) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    dim3 grid(H, kv_bmod);
+    const int nsub = p.nsub;
+#define XUF_I(N_, D_)                                                                                               \
+    do {                                                                                                            \
+        const size_t lds = 2 * N_ * 2048 + 32768 + 2 * N_ * 256;                                                    \
+        static bool attr_set = false;                                                                               \
+        if (!attr_set) {                                                                                            \
+            hipFuncSetAttribute((const void*)attn_xu_fwd_kernel<N_, D_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+            attr_set = true;                                                                                        \
+        }                                                                                                           \
+        hipLaunchKernelGGL((attn_xu_fwd_kernel<N_, D_>), grid, dim3(256), lds, st, p);                              \
+    } while (0)
+#define XUF(N_) do { if (p_drop > 0.f) XUF_I(N_, true); else XUF_I(N_, false); } while (0)
+    if (nsub <= 4) XUF(4); else if (nsub <= 6) XUF(6); else if (nsub <= 8) XUF(8); else XUF(10);
+#undef XUF
+#undef XUF_I
+    return valor_launch_status();
+}
+
+extern "C" int valor_cross_attn_bwd_fused(void* stream, int dtype, const void* segs, int nseg, const void* k, const void* v, void* dk, void* dv,
+                                          int H, int Skv, int kv_bmod, int64_t k_bs, int64_t k_rs, int64_t v_bs, int64_t v_rs, int64_t dk_bs,
+                                          int64_t dk_rs, int64_t dv_bs, int64_t dv_rs, float scale, float p_drop) {
+    if (!dk || !dv || (dk_rs & 3) || (dv_rs & 3) || (dk_bs & 3) || (dv_bs & 3)) return VALOR_ERR_ARG;
+    XuArgs p = {};
+    const int rc = xu_fill(p, dtype, segs, nseg, k, v, H, Skv, kv_bmod, k_bs, k_rs, v_bs, v_rs, scale, p_drop, true);
+    if (rc != VALOR_OK) return rc;
+    p.dk = dk; p.dv = dv;
+    p.dk_bs = dk_bs; p.dk_rs = dk_rs; p.dv_bs = dv_bs; p.dv_rs = dv_rs;
+    const int nsub = p.nsub;
     hipStream_t st = (hipStream_t)stream;
     dim3 grid(H, kv_bmod);
 #define XU_I(N_, D_)                                                                                                \

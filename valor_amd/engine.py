@@ -37,6 +37,13 @@ class TrainEngine:
         # of lead keep the GPU fed; the step waits for the end of the step before the previous one.
         self.max_ahead = int(getattr(opts, "max_steps_ahead", 2))
         self._step_events = []
+        # Even with the lead bounded, the working set keeps growing for a few steps after the first one (a block that crossed streams
+        # is reusable only once the other stream has passed it, so some tensors exist once per step in flight): 2 + 172 + 592 MiB of
+        # hipMalloc inside steps 4-6 of a run, each a device-wide stall. After the second optimizer step the engine therefore
+        # allocates and frees `alloc_headroom_mb` of device memory once (one large block + a few small-pool segments): the caching
+        # allocator keeps the segments and carves the late growth out of them instead of calling hipMalloc in the middle of a step.
+        self.alloc_headroom_mb = int(getattr(opts, "alloc_headroom_mb", 1536))
+        self._headroom_done = False
         self.grad_norm = float(getattr(opts, "grad_norm", 5.0))
         self._task = None
         self._micro = 0
@@ -79,6 +86,21 @@ class TrainEngine:
             ev = torch.cuda.Event()
             ev.record()
             self._step_events.append(ev)
+        if not self._headroom_done and self.global_step >= 2:
+            self.reserve_headroom()
         if self.manage_gc:
             gc.collect(0 if self.global_step % 64 else 2)
         return loss_dict
+
+    def reserve_headroom(self, mb=None):
+        """grow the caching allocator's pools by `mb` MiB of free segments now (see __init__); returns the bytes reserved"""
+        self._headroom_done = True
+        mb = self.alloc_headroom_mb if mb is None else mb
+        dev = self.model.arena.flat.device
+        if mb <= 0 or dev.type != "cuda":
+            return 0
+        before = torch.cuda.memory_reserved(dev)
+        blocks = [torch.empty(mb << 20, dtype=torch.uint8, device=dev)]
+        blocks += [torch.empty(512 << 10, dtype=torch.uint8, device=dev) for _ in range(32)]      # small pool: 2 MiB segments
+        del blocks
+        return torch.cuda.memory_reserved(dev) - before

@@ -219,23 +219,51 @@ def attn_bwd(q, k, v, o, lse, dout, n_heads, *, dq=None, dk=None, dv=None, mask=
     return dq, dk, dv
 
 
+def _xattn_segs(segs, kv_bmod, bwd):
+    arr = (lib.XattnSeg * len(segs))()
+    for i, sg in enumerate(segs):
+        q, o = sg["q"], sg["o"]
+        _check_gpu(q, o, sg["lse"], sg.get("kv_range"))
+        a = arr[i]
+        a.q, a.o, a.lse, a.kv_range = _ptr(q), _ptr(o), _ptr(sg["lse"]), _ptr(sg.get("kv_range"))
+        (a.q_bs, a.q_rs), (a.o_bs, a.o_rs) = _bsr(q), _bsr(o)
+        if bwd:
+            do, dq = sg["dout"], sg["dq"]
+            _check_gpu(do, dq)
+            a.dout, a.dq = _ptr(do), _ptr(dq)
+            (a.do_bs, a.do_rs), (a.dq_bs, a.dq_rs) = _bsr(do), _bsr(dq)
+        a.B, a.Sq, a.seed, a.offset = q.shape[0], q.shape[1], int(sg.get("seed", 0)), int(sg.get("offset", 0))
+    return arr
+
+
+def _xattn_domain(segs, k, kv_bmod):
+    if k.dtype != torch.bfloat16 or not (1 <= len(segs) <= 2) or k.shape[1] < 64 or kv_bmod <= 0:
+        return False
+    nsub = sum((sg["q"].shape[0] // kv_bmod) * ((sg["q"].shape[1] + 15) // 16) for sg in segs)
+    return not (nsub > 10 or any(sg["q"].shape[0] % kv_bmod for sg in segs) or os.environ.get("VALOR_ATTN_XFUSED", "1") == "0")
+
+
+def cross_attn_fwd_fused(segs, k, v, n_heads, kv_bmod, *, scale=0.125, p_drop=0.0):
+    """Forward of up to two decoder passes that attend to the same K|V in ONE launch (csrc/attention_xu.hip): K, V read once.
+    segs: list of dict(q, o [B, T, E] views, lse [B, H, T], kv_range int32 [B, 2] or None, seed, offset); o and lse are written.
+    Returns False (nothing launched) outside the fused kernel's domain -- the caller runs attn_fwd per pass."""
+    if not _xattn_domain(segs, k, kv_bmod):
+        return False
+    import ctypes
+    arr = _xattn_segs(segs, kv_bmod, False)
+    kb, kr = _bsr(k); vb, vr = _bsr(v)
+    lib.call("valor_cross_attn_fwd_fused", _stream(), DT_BF16, ctypes.cast(arr, ctypes.c_void_p), len(segs), _ptr(k), _ptr(v),
+             n_heads, k.shape[1], int(kv_bmod), kb, kr, vb, vr, float(scale), float(p_drop))
+    return True
+
+
 def cross_attn_bwd_fused(segs, k, v, dk, dv, n_heads, kv_bmod, *, scale=0.125, p_drop=0.0):
     """Backward of up to two decoder passes that attend to the same K|V in ONE launch (csrc/attention_xu.hip): dK|dV are written once.
     segs: list of dict(q, o, lse, dout, dq [B, T, E] views / lse [B, H, T]; kv_range int32 [B, 2] or None; seed, offset).
     Returns False (nothing launched) when the shape is outside the fused kernel's domain -- the caller runs attn_bwd per pass."""
-    if k.dtype != torch.bfloat16 or not (1 <= len(segs) <= 2) or k.shape[1] < 64 or kv_bmod <= 0:
+    if not _xattn_domain(segs, k, kv_bmod):
         return False
-    nsub = sum((sg["q"].shape[0] // kv_bmod) * ((sg["q"].shape[1] + 15) // 16) for sg in segs)
-    if nsub > 10 or any(sg["q"].shape[0] % kv_bmod for sg in segs) or os.environ.get("VALOR_ATTN_XFUSED", "1") == "0":
-        return False
-    arr = (lib.XattnSeg * len(segs))()
-    for i, sg in enumerate(segs):
-        q, o, do, dq = sg["q"], sg["o"], sg["dout"], sg["dq"]
-        _check_gpu(q, o, do, dq, sg["lse"], sg.get("kv_range"))
-        a = arr[i]
-        a.q, a.o, a.dout, a.dq, a.lse, a.kv_range = _ptr(q), _ptr(o), _ptr(do), _ptr(dq), _ptr(sg["lse"]), _ptr(sg.get("kv_range"))
-        (a.q_bs, a.q_rs), (a.o_bs, a.o_rs), (a.do_bs, a.do_rs), (a.dq_bs, a.dq_rs) = _bsr(q), _bsr(o), _bsr(do), _bsr(dq)
-        a.B, a.Sq, a.seed, a.offset = q.shape[0], q.shape[1], int(sg.get("seed", 0)), int(sg.get("offset", 0))
+    arr = _xattn_segs(segs, kv_bmod, True)
     kb, kr = _bsr(k); vb, vr = _bsr(v); dkb, dkr = _bsr(dk); dvb, dvr = _bsr(dv)
     import ctypes
     lib.call("valor_cross_attn_bwd_fused", _stream(), DT_BF16, ctypes.cast(arr, ctypes.c_void_p), len(segs), _ptr(k), _ptr(v), _ptr(dk), _ptr(dv),

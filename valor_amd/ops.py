@@ -482,6 +482,9 @@ def seg_self_attention(qkv2d, n_heads, segs, p_drop=0.0):
     return SegSelfAttnFn.apply(qkv2d, n_heads, segs, p_drop)
 
 
+_XFUSED_FWD = os.environ.get("VALOR_ATTN_XFUSED_FWD", "0") == "1"
+
+
 class SegCrossAttnFn(Function):
     """q2d [R, E]; kv [Bkv, Skv, 2E] shared; segs = [(r0, B, T, kv_range, kv_bmod), ...].  In backward the first segment
     writes dK|dV and the others accumulate into the same buffer inside the kernel."""
@@ -497,10 +500,21 @@ class SegCrossAttnFn(Function):
             seed = off = 0
             if p_drop > 0:
                 seed, off = DropoutState.draw_elems(B * n_heads * T * kv.shape[1])
-            lse = torch.empty((B, n_heads, T), dtype=torch.float32, device=q2d.device)
+            lses.append(torch.empty((B, n_heads, T), dtype=torch.float32, device=q2d.device)); rng.append((seed, off))
+        fused = False
+        # every pass in ONE launch (K, V read once): opt-in. Measured at the decoder's geometry (profiles/r04_attn_xu_ab_fwd.json) the two
+        # per-pass launches take 228 us and the fused one 300 us: the forward has no dK|dV read-modify-write to save, the per-pass kernels
+        # are not HBM bound, and the D-split needs three workgroup barriers per 64-key tile.
+        if _XFUSED_FWD and len(segs) <= 2 and len({sg[4] for sg in segs}) == 1:
+            fs = [dict(q=q2d[r0:r0 + B * T].view(B, T, E), o=o[r0:r0 + B * T].view(B, T, E), lse=lse, kv_range=kv_range, seed=seed, offset=off)
+                  for (r0, B, T, kv_range, kv_bmod), lse, (seed, off) in zip(segs, lses, rng)]
+            fused = K.cross_attn_fwd_fused(fs, kv[:, :, :E], kv[:, :, E:], n_heads, segs[0][4] or segs[0][1], scale=1.0 / math.sqrt(64),
+                                           p_drop=p_drop)
+        for (r0, B, T, kv_range, kv_bmod), lse, (seed, off) in zip(segs, lses, rng):
+            if fused:
+                break
             K.attn_fwd(q2d[r0:r0 + B * T].view(B, T, E), kv[:, :, :E], kv[:, :, E:], n_heads, kv_range=kv_range, kv_bmod=kv_bmod,
                        scale=1.0 / math.sqrt(64), p_drop=p_drop, seed=seed, offset=off, o=o[r0:r0 + B * T].view(B, T, E), lse=lse)
-            lses.append(lse); rng.append((seed, off))
         ctx.save_for_backward(q2d, kv, o, *lses)
         ctx.cfg = (n_heads, segs, p_drop, rng)
         ctx.static_gen = StaticGen.seen(kv)
