@@ -99,8 +99,13 @@ class TrainEngine:
         dev = self.model.arena.flat.device
         if mb <= 0 or dev.type != "cuda":
             return 0
+        from . import streams
         before = torch.cuda.memory_reserved(dev)
-        blocks = [torch.empty(mb << 20, dtype=torch.uint8, device=dev)]
-        blocks += [torch.empty(512 << 10, dtype=torch.uint8, device=dev) for _ in range(32)]      # small pool: 2 MiB segments
-        del blocks
+        # the caching allocator keeps one free list PER STREAM: the late growth happens on the encoders' side stream as well as on the
+        # step's stream (the first version reserved on the current stream only and two 172 MiB segments still appeared)
+        for st in streams.compute_streams(dev):
+            with torch.cuda.stream(st):
+                blocks = [torch.empty(mb << 20, dtype=torch.uint8, device=dev)]
+                blocks += [torch.empty(512 << 10, dtype=torch.uint8, device=dev) for _ in range(32)]      # small pool: 2 MiB segments
+                del blocks
         return torch.cuda.memory_reserved(dev) - before
