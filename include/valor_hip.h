@@ -225,6 +225,26 @@ int valor_win_attn_bwd(void* stream, int dtype, const void* qkv, const void* o, 
                        void* dtable, int accumulate_dtable, void* workspace, int64_t workspace_bytes, int B, int nW, int N, int heads,
                        int table_rows, int relc, int rows_per_sample, float scale);
 
+/* ---- native gradient reducer over RCCL (csrc/reducer.hip): the bucketed gradient all-reduce of the data-parallel step. Replaces the
+ * reducer of torch DDP (train_utils.py:232; model of the same structure: apex/apex/parallel/distributed.py:320-470). RCCL is bound with
+ * dlopen at first use (the copy already loaded by torch.distributed if there is one, $VALOR_RCCL_LIB, the default search path);
+ * VALOR_ERR_LAUNCH if it cannot be bound or a RCCL / HIP call fails. Nothing below synchronises the host.
+ *   unique_id:      rank 0 fills 128 bytes (ncclGetUniqueId); the caller hands the same bytes to every rank (torch.distributed broadcast).
+ *   create:         one communicator (ncclCommInitRank: collective over all `world` ranks), one communication stream, one event per bucket.
+ *                   Bucket i = elements [offsets[i], offsets[i] + counts[i]) of the flat gradient arena at grad_base (dtype bf16 / fp32),
+ *                   summed in place. mode 0 = all-reduce, 1 = reduce-scatter + all-gather on the in-place shards (counts[i] % world == 0,
+ *                   else that bucket falls back to all-reduce).
+ *   launch_bucket:  the communication stream waits for the current tail of every stream in compute_streams (all that may still be writing
+ *                   gradients of this bucket) and enqueues the collective.
+ *   wait:           `stream` waits for every bucket launched since the previous wait.
+ *   destroy:        drains the communication stream, frees the communicator, events and stream (NULL is a no-op). */
+int valor_reducer_unique_id(void* id128);
+int valor_reducer_create(void** out, const void* id128, int rank, int world, int dtype, void* grad_base, const int64_t* offsets,
+                         const int64_t* counts, int nbuckets, int mode);
+int valor_reducer_launch_bucket(void* reducer, int bucket, void* const* compute_streams, int nstreams);
+int valor_reducer_wait(void* reducer, void* stream);
+int valor_reducer_destroy(void* reducer);
+
 /* ---- softmax cross-entropy over the vocabulary: F.cross_entropy on the masked rows (pretrain.py:444,457,469,498).
  * logits [rows, V] with leading dim ld; backward overwrites the logits (and zero-fills the ld padding) with
  * (softmax - onehot) * (*gscale_dev) * gmul. */

@@ -38,10 +38,27 @@ def test_second_forward_before_backward_is_refused_and_eval_releases(dev, monkey
     torch.cuda.synchronize()
     g = m.P["multimodal_encoder.encoder.layer.0.cross_attn.cross.kv.weight"].grad
     assert torch.isfinite(g).all() and float(g.abs().sum()) > 0
+    from valor_amd import ops
+    mine = list(m._kv_gen.ptrs)
+    assert mine and all(q in ops.StaticGen.REGISTRY for q in mine)
     m.eval()
     assert m._kv_static is None and m._dkv_static_pool is None
-    from valor_amd import ops
-    assert not ops.StaticGen.REGISTRY
+    assert not any(q in ops.StaticGen.REGISTRY for q in mine)      # (other models of the test session may still hold theirs)
     with torch.no_grad():
         m(batch, task=TASK, compute_loss=True)       # the eval path allocates through the caching allocator
     assert m._kv_static is None
+
+
+def test_registry_forgets_a_model_that_is_dropped_without_release(dev, monkeypatch):
+    import gc
+    from valor_amd import ops
+    monkeypatch.setenv("VALOR_ENCODER_STREAMS", "1")
+    monkeypatch.setenv("VALOR_KV_STREAM", "1")
+    m, batch = _model(dev)
+    random.seed(1)
+    out = m(batch, task=TASK, compute_loss=True)
+    mine = list(m._kv_gen.ptrs)
+    assert mine and all(q in ops.StaticGen.REGISTRY for q in mine)
+    del out, m
+    gc.collect()
+    assert not any(q in ops.StaticGen.REGISTRY for q in mine)

@@ -91,7 +91,7 @@ class Reducer:
        Summing in bf16 across 8 ranks perturbs each element by ~0.4 % rms (like one more bf16 rounding of the gradient) and the global
        norm by < 1e-5 relative: tests/test_dist_cpu.py::test_bf16_cross_rank_sum_error quantifies it."""
 
-    def __init__(self, arena, bucket_bytes=48 << 20, mode=None):
+    def __init__(self, arena, bucket_bytes=48 << 20, mode=None, native=None):
         import os
         self.mode = mode or os.environ.get("VALOR_REDUCE", "allreduce")
         assert self.mode in ("allreduce", "rs_ag", "fp32"), self.mode
@@ -118,10 +118,47 @@ class Reducer:
         self.touched = {}              # name -> writes seen in the current backward
         self.pending, self.works = None, []
         self.comm_stream = torch.cuda.Stream() if arena.flat.is_cuda else None
+        # native=True / VALOR_REDUCER_NATIVE=1: the collectives are issued by the library's own reducer (csrc/reducer.hip: its RCCL
+        # communicator, communication stream and per-bucket events behind valor_reducer_*) instead of torch.distributed work objects.
+        # Same buckets, same order, same in-place sums; this class keeps deciding when a bucket is complete. Opt-in: no multi-GPU node
+        # was available to the builder, the path has run with one rank on a GPU (tests/test_native_reducer_gpu.py) and nothing more.
+        self.native = None
+        want = native if native is not None else os.environ.get("VALOR_REDUCER_NATIVE", "0") == "1"
+        if want and arena.flat.is_cuda and dist.is_available() and dist.is_initialized() and self.mode in ("allreduce", "rs_ag"):
+            self._create_native()
         for name, p in arena.params.items():
             p.register_post_accumulate_grad_hook(self._make_hook(name))
         from . import ops
         ops.GradSink.listener = self._on_grad      # kernels that accumulate straight into the arena report here
+
+    def _create_native(self):
+        import ctypes
+        from . import lib
+        g = self.arena.grad
+        idt = torch.zeros(128, dtype=torch.uint8, device=g.device)
+        if dist.get_rank() == 0:
+            host = (ctypes.c_char * 128)()
+            lib.call("valor_reducer_unique_id", ctypes.cast(host, ctypes.c_void_p))
+            idt.copy_(torch.frombuffer(bytearray(host.raw), dtype=torch.uint8))
+        if dist.get_world_size() > 1:
+            dist.broadcast(idt, 0)
+        idb = (ctypes.c_char * 128).from_buffer_copy(bytes(idt.cpu().numpy().tobytes()))
+        nb = len(self.bucket_range)
+        offs = (ctypes.c_int64 * nb)(*[s for s, _ in self.bucket_range])
+        cnts = (ctypes.c_int64 * nb)(*[e - s for s, e in self.bucket_range])
+        handle = ctypes.c_void_p()
+        torch.cuda.synchronize(g.device)          # ncclCommInitRank is a collective rendezvous: nothing of ours in flight around it
+        lib.call("valor_reducer_create", ctypes.cast(ctypes.byref(handle), ctypes.c_void_p), ctypes.cast(idb, ctypes.c_void_p), dist.get_rank(),
+                 dist.get_world_size(), 0 if g.dtype == torch.bfloat16 else 1, g.data_ptr(), ctypes.cast(offs, ctypes.c_void_p),
+                 ctypes.cast(cnts, ctypes.c_void_p), nb, 1 if self.mode == "rs_ag" else 0)
+        self.native = handle
+
+    def close(self):
+        """free the native reducer (communicator, stream, events); the torch.distributed path holds nothing to free"""
+        if self.native is not None:
+            from . import lib
+            lib.call("valor_reducer_destroy", self.native)
+            self.native = None
 
     def _make_hook(self, name):
         def hook(param):
@@ -154,10 +191,18 @@ class Reducer:
         return [dist.all_reduce(buf, op=dist.ReduceOp.SUM, async_op=True)]
 
     def _launch(self, i):
-        if self.world == 1:
+        if self.world == 1 and self.native is None:
             return
         s, e = self.bucket_range[i]
         buf = self.arena.grad[s:e]
+        if self.native is not None:
+            import ctypes
+            from . import lib, streams
+            cs = streams.compute_streams(buf.device)
+            arr = (ctypes.c_void_p * len(cs))(*[c.cuda_stream for c in cs])
+            lib.call("valor_reducer_launch_bucket", self.native, i, ctypes.cast(arr, ctypes.c_void_p), len(cs))
+            self._native_pending = True
+            return
         if self.comm_stream is not None:
             from . import streams
             evs = []
@@ -169,6 +214,19 @@ class Reducer:
                 self.works += self._reduce(buf)
         else:
             self.works += self._reduce(buf)
+
+    def _wait_all(self):
+        """the current stream waits for every bucket in flight"""
+        if self.native is not None:
+            if getattr(self, "_native_pending", False):
+                from . import lib
+                lib.call("valor_reducer_wait", self.native, torch.cuda.current_stream().cuda_stream)
+                self._native_pending = False
+            return
+        for w in self.works:
+            w.wait()
+        if self.comm_stream is not None:
+            torch.cuda.current_stream().wait_stream(self.comm_stream)
 
     def prepare_backward(self, defer=False):
         """defer=True: a micro-step of a gradient accumulation window -- gradients keep accumulating in the arena and NO bucket
@@ -189,7 +247,11 @@ class Reducer:
             self.pending = None
             if not last:
                 return set()
-            if self.world > 1:
+            if self.native is not None:              # the window's one reduction, bucket by bucket on the native reducer
+                for i in range(len(self.buckets)):
+                    self._launch(i)
+                self._wait_all()
+            elif self.world > 1:
                 for w in self._reduce(self.arena.grad):
                     w.wait()
             names, self.window = self.window, None
@@ -209,15 +271,9 @@ class Reducer:
                 self.works = []
                 for i in range(len(self.buckets)):
                     self._launch(i)
-                for w in self.works:
-                    w.wait()
-                if self.comm_stream is not None:
-                    torch.cuda.current_stream().wait_stream(self.comm_stream)
+                self._wait_all()
         else:
-            for w in self.works:
-                w.wait()
-            if self.comm_stream is not None:
-                torch.cuda.current_stream().wait_stream(self.comm_stream)
+            self._wait_all()
         self.pending = None
         return set(self.touched)
 

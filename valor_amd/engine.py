@@ -42,7 +42,8 @@ class TrainEngine:
         # hipMalloc inside steps 4-6 of a run, each a device-wide stall. After the second optimizer step the engine therefore
         # allocates and frees `alloc_headroom_mb` of device memory once (one large block + a few small-pool segments): the caching
         # allocator keeps the segments and carves the late growth out of them instead of calling hipMalloc in the middle of a step.
-        self.alloc_headroom_mb = int(getattr(opts, "alloc_headroom_mb", 1536))
+        import os
+        self.alloc_headroom_mb = int(os.environ.get("VALOR_ALLOC_HEADROOM_MB", getattr(opts, "alloc_headroom_mb", 1536)))
         self._headroom_done = False
         self.grad_norm = float(getattr(opts, "grad_norm", 5.0))
         self._task = None
@@ -106,6 +107,6 @@ class TrainEngine:
         for st in streams.compute_streams(dev):
             with torch.cuda.stream(st):
                 blocks = [torch.empty(mb << 20, dtype=torch.uint8, device=dev)]
-                blocks += [torch.empty(512 << 10, dtype=torch.uint8, device=dev) for _ in range(32)]      # small pool: 2 MiB segments
+                blocks += [torch.empty(1 << 20, dtype=torch.uint8, device=dev) for _ in range(16)]        # small pool (requests <= 1 MiB): 2 MiB segments
                 del blocks
         return torch.cuda.memory_reserved(dev) - before

@@ -62,6 +62,11 @@ SIGNATURES = {
                        _vp, _i64, _i64, _vp, _i, _f, _f, _u64, _u64, _i],
     "valor_cross_attn_fwd_fused": [_vp, _i, _vp, _i, _vp, _vp, _i, _i, _i, _i64, _i64, _i64, _i64, _f, _f],
     "valor_cross_attn_bwd_fused": [_vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _f, _f],
+    "valor_reducer_unique_id": [_vp],
+    "valor_reducer_create": [_vp, _vp, _i, _i, _i, _vp, _vp, _vp, _i, _i],
+    "valor_reducer_launch_bucket": [_vp, _i, _vp, _i],
+    "valor_reducer_wait": [_vp, _vp],
+    "valor_reducer_destroy": [_vp],
     "valor_xent_fwd": [_vp, _i, _vp, _vp, _vp, _vp, _i64, _i, _i64],
     "valor_xent_bwd": [_vp, _i, _vp, _vp, _vp, _vp, _f, _i64, _i, _i64],
     "valor_fine_weight_softmax": [_vp, _vp, _vp, _vp, _i, _i],

@@ -6,6 +6,7 @@ libvalor_hip.so must be built, otherwise lib.ValorHipError is raised.
 """
 import math
 import os
+import weakref
 
 import torch
 from torch.autograd import Function
@@ -366,7 +367,8 @@ class StaticGen:
     it rewrites the buffers; an autograd node that saved one of them remembers the generation it saw and refuses to run backward on a
     newer one -- a second training forward before the first backward would otherwise give silently wrong gradients (the write is a raw
     kernel into `out`, invisible to autograd's version counters)."""
-    REGISTRY = {}          # data_ptr of a registered buffer -> its StaticGen
+    REGISTRY = weakref.WeakValueDictionary()          # data_ptr of a registered buffer -> its StaticGen (gone with its owner: a model that is
+                                                      # dropped without release_static_kv() leaves no entry behind for a recycled address)
 
     def __init__(self):
         self.gen = 0
