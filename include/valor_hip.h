@@ -81,8 +81,8 @@ int valor_gemm_set_fast_epilogue(int v);
 /* policy parameters of variant 4 and of the 8-phase launch (tuning / A-B hook; returns the previous value, value < 0 only queries):
  *   key 0: smallest K for which a big-M dgrad (A row-major, B k-slow) runs on the 256x256 8-phase kernel
  *   key 1: 1 = the split-K partial tiles of the bf16 LDS-DMA kernels are written and summed as bf16 (half the workspace traffic, one more
- *          rounding per partial; never for fp32 outputs); default 1 (in-step +1.3 %, profiles/r03_step_ab_s3.txt). (Round 2: the start skew of the 8-phase kernel's first round,
- *          measured slower at every setting, profiles/r02_gemm_policy_ab.json)
+ *          rounding per partial; never for fp32 outputs); default 1 (in-step +1.3 %, profiles/r03_step_ab_s3.txt; error bound asserted in
+ *          tests/test_gemm_bench_shapes_gpu.py::test_wgrad_splitk_with_bf16_partials)
  *   key 2: smallest number of 256x256 tiles for the 8-phase kernel on forward problems (default 256: one full round of workgroups)
  *   key 3: the same for dgrad problems (default 1024: below it the 128x128 kernel measured faster, session N)
  *   key 4: L2-aware tile raster of the 8-phase kernels: 0 = row-major over all tile columns; G > 0 = groups of G tile columns

@@ -69,8 +69,11 @@ def _compile_one(src, hdig, verbose):
                 print(f"[valor_amd.build] {'ERROR' if hot else 'WARNING'}: {src}: kernel {fn} uses {n} B/lane of scratch", flush=True)
                 if hot:
                     bad.append(fn)
-    if bad:
-        raise RuntimeError(f"scratch in hot kernels of {src}: {bad} (see -Rpass-analysis=kernel-resource-usage)")
+    # strict by default (this library is built by its developers with the pinned ROCm of the image: a hot kernel that starts to spill is a
+    # regression to catch at build time); VALOR_BUILD_STRICT=0 downgrades it to the message above for a user on another toolchain, whose
+    # register allocation may differ by a few bytes per lane
+    if bad and os.environ.get("VALOR_BUILD_STRICT", "1") != "0":
+        raise RuntimeError(f"scratch in hot kernels of {src}: {bad} (see -Rpass-analysis=kernel-resource-usage; VALOR_BUILD_STRICT=0 builds anyway)")
     with open(stamp, "w") as fh:
         fh.write(dig)
     return obj, True
