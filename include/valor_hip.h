@@ -181,8 +181,10 @@ int valor_colsum(void* stream, int dtype, const void* x, int64_t rows, int cols,
 int valor_attn_set_variant(int v);
 /* LDS-resident self-attention backward: 1 (default, env VALOR_ATTN_PIPE) = persistent workgroups (one per CU) that walk (batch, head)
  * items with the K / V and Q / dO LDS images double-buffered across the dQ and the dK / dV phase, so the loads and stores of one item
- * overlap the arithmetic of its neighbours; 0 = one workgroup per (batch, head). Bit-identical results. Used when batch x heads >= 2 x
- * the CU count. Returns the previous value, v < 0 only queries. */
+ * overlap the arithmetic of its neighbours (used when batch x heads >= 2 x the CU count; sequences of <= 160 rows run mode 2 instead);
+ * 0 = one workgroup of 8 waves x 32-row blocks per (batch, head); 2 = one workgroup of 16 waves x 16-row blocks per (batch, head) (four
+ * waves per SIMD). Modes 0 and 2 are bit-identical, mode 1 differs from them in the summation order of delta only. Returns the previous
+ * value, v < 0 only queries. */
 int valor_attn_set_res_pipeline(int v);
 
 /* ---- flash attention, head_dim 64.  Replaces BertSelfAttention (bert.py:272-288), BertCrossAttention (bert.py:314-340,

@@ -141,9 +141,12 @@ def test_resident_backward_pipelined_equals_per_head_kernel(dev, S, B, H, p_drop
         dq1b, dk1b, dv1b = K.attn_bwd(q, k, v, o, lse, dout, H, scale=scale, p_drop=p_drop, seed=5, offset=9)     # and it is deterministic
         so.valor_attn_set_res_pipeline(0)
         dq0, dk0, dv0 = K.attn_bwd(q, k, v, o, lse, dout, H, scale=scale, p_drop=p_drop, seed=5, offset=9)
+        so.valor_attn_set_res_pipeline(2)      # 16 waves x 16-row blocks: every output row accumulates in the order of mode 0
+        dq2, dk2, dv2 = K.attn_bwd(q, k, v, o, lse, dout, H, scale=scale, p_drop=p_drop, seed=5, offset=9)
     finally:
         so.valor_attn_set_res_pipeline(old)
     torch.cuda.synchronize()
+    assert torch.equal(dq2, dq0) and torch.equal(dk2, dk0) and torch.equal(dv2, dv0)
     for a, b_, c, n in ((dq1, dq0, dq1b, "dq"), (dk1, dk0, dk1b, "dk"), (dv1, dv0, dv1b, "dv")):
         assert torch.equal(a, c), n
         assert _rel(a, b_) < 5e-4, (n, _rel(a, b_))

@@ -184,8 +184,10 @@ __global__ __launch_bounds__(256, 3) void attn_res_fwd_kernel(AttnArgs p) {
 // grid (H, B), 512 threads (8 waves). LDS: [Q][dO][K][V] images (SP rows each) + lse (log2 domain) + delta.
 // Phase 1: wave w owns the 32-query-row block w -> dQ.   Phase 2: wave w owns the 32-key block w -> dK, dV.
 // Both phases only READ LDS, so there is no barrier between them.
-template <bool DROP, bool MASK>
-__global__ __launch_bounds__(512, 2) void attn_res_bwd_kernel(AttnArgs p) {
+// RT = 16-row MFMA tiles per block (2: a 32-row block shares every K / V (Q / dO) fragment read between two tiles; 1: a 16-row block -- twice the
+// fragment reads per FLOP, half the accumulators: fits 128 VGPRs), NW = waves of the workgroup (block b belongs to wave b % NW).
+template <bool DROP, bool MASK, int RT, int NW>
+DEVINL void attn_res_bwd_body(const AttnArgs& p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -204,16 +206,16 @@ __global__ __launch_bounds__(512, 2) void attn_res_bwd_kernel(AttnArgs p) {
     float* sLse = (float*)(smem + 4 * IMG);
     float* sDelta = sLse + SP;
 
-    stage_image(head_rsrc(p.q, (int64_t)b * p.q_bs + h * ATT_D, S, p.q_rs), sQ, SP, (int)p.q_rs * 2, wave, 8, lane);
-    stage_image(head_rsrc(p.dout, (int64_t)b * p.do_bs + h * ATT_D, S, p.do_rs), sDO, SP, (int)p.do_rs * 2, wave, 8, lane);
-    stage_image(head_rsrc(p.k, (int64_t)b * p.k_bs + h * ATT_D, S, p.k_rs), sK, SP, (int)p.k_rs * 2, wave, 8, lane);
-    stage_image(head_rsrc(p.v, (int64_t)b * p.v_bs + h * ATT_D, S, p.v_rs), sV, SP, (int)p.v_rs * 2, wave, 8, lane);
+    stage_image(head_rsrc(p.q, (int64_t)b * p.q_bs + h * ATT_D, S, p.q_rs), sQ, SP, (int)p.q_rs * 2, wave, NW, lane);
+    stage_image(head_rsrc(p.dout, (int64_t)b * p.do_bs + h * ATT_D, S, p.do_rs), sDO, SP, (int)p.do_rs * 2, wave, NW, lane);
+    stage_image(head_rsrc(p.k, (int64_t)b * p.k_bs + h * ATT_D, S, p.k_rs), sK, SP, (int)p.k_rs * 2, wave, NW, lane);
+    stage_image(head_rsrc(p.v, (int64_t)b * p.v_bs + h * ATT_D, S, p.v_rs), sV, SP, (int)p.v_rs * 2, wave, NW, lane);
 
     const int64_t statbase = ((int64_t)b * p.H + h) * p.Sq;
     {   // delta[q] = sum_d dO*O ; lse -> log2 domain.  8 rows per wave iteration, 8 lanes x 16 B per row.
         const bf16_t* Ob = (const bf16_t*)p.o + (int64_t)b * p.o_bs + h * ATT_D;
         const bf16_t* DOb = (const bf16_t*)p.dout + (int64_t)b * p.do_bs + h * ATT_D;
-        for (int r0 = wave * 8; r0 < SP; r0 += 64) {
+        for (int r0 = wave * 8; r0 < SP; r0 += NW * 8) {
             const int row = r0 + (lane >> 3), c = lane & 7;
             float d = 0.f;
             if (row < S) {
@@ -233,19 +235,19 @@ __global__ __launch_bounds__(512, 2) void attn_res_bwd_kernel(AttnArgs p) {
     int troff[4];
 #pragma unroll
     for (int dt = 0; dt < 4; ++dt) troff[dt] = tr_lane_off(lane, dt);
-    const int NP = (S + 31) >> 5, NT = (S + 63) >> 6;
+    const int NP = (S + 16 * RT - 1) / (16 * RT), NT = (S + 63) >> 6;
 
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
     // ---------------- phase 1: dQ
-    for (int pr = wave; pr < NP; pr += 8) {
-        bf16x8_t qf[2][2], dof[2][2];
-        int qr[2];
-        float lse2[2], dlt[2];
+    for (int pr = wave; pr < NP; pr += NW) {
+        bf16x8_t qf[RT][2], dof[RT][2];
+        int qr[RT];
+        float lse2[RT], dlt[RT];
 #pragma unroll
-        for (int rt = 0; rt < 2; ++rt) {
-            qr[rt] = pr * 32 + rt * 16 + fr;       // < SP = NP * 32; rows >= S are zero rows with lse = +inf
+        for (int rt = 0; rt < RT; ++rt) {
+            qr[rt] = pr * (16 * RT) + rt * 16 + fr;       // < SP; rows >= S are zero rows with lse = +inf
 #pragma unroll
             for (int dg = 0; dg < 2; ++dg) {
                 qf[rt][dg] = read_frag<bf16_t>(sQ, qr[rt], dg * 4 + g);
@@ -253,9 +255,9 @@ __global__ __launch_bounds__(512, 2) void attn_res_bwd_kernel(AttnArgs p) {
             }
             lse2[rt] = sLse[qr[rt]]; dlt[rt] = sDelta[qr[rt]];
         }
-        f32x4_t dqacc[2][4];
+        f32x4_t dqacc[RT][4];
 #pragma unroll
-        for (int rt = 0; rt < 2; ++rt)
+        for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
             for (int dt = 0; dt < 4; ++dt) dqacc[rt][dt] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
         for (int t = 0; t < NT; ++t) {
@@ -265,25 +267,27 @@ __global__ __launch_bounds__(512, 2) void attn_res_bwd_kernel(AttnArgs p) {
 #pragma unroll
             for (int kk = 0; kk < 2; ++kk) {
                 if (2 * kk >= nkt) continue;
-                f32x4_t ds[2][2];      // [rt][kt2]
+                f32x4_t ds[RT][2];      // [rt][kt2]
 #pragma unroll
                 for (int k2 = 0; k2 < 2; ++k2) {
                     const int kt = 2 * kk + k2;
-                    f32x4_t sa[2], pa[2];
-                    sa[0] = (f32x4_t){0.f, 0.f, 0.f, 0.f}; sa[1] = sa[0]; pa[0] = sa[0]; pa[1] = sa[0];
+                    f32x4_t sa[RT], pa[RT];
+#pragma unroll
+                    for (int rt = 0; rt < RT; ++rt) { sa[rt] = (f32x4_t){0.f, 0.f, 0.f, 0.f}; pa[rt] = sa[rt]; }
                     if (kt < nkt) {
 #pragma unroll
                         for (int dg = 0; dg < 2; ++dg) {
                             const bf16x8_t kf = read_frag<bf16_t>(sK, kv0 + kt * 16 + fr, dg * 4 + g);
                             const bf16x8_t vf = read_frag<bf16_t>(sV, kv0 + kt * 16 + fr, dg * 4 + g);
-                            sa[0] = Mma<bf16_t>::mma(kf, qf[0][dg], sa[0]);
-                            sa[1] = Mma<bf16_t>::mma(kf, qf[1][dg], sa[1]);
-                            pa[0] = Mma<bf16_t>::mma(vf, dof[0][dg], pa[0]);
-                            pa[1] = Mma<bf16_t>::mma(vf, dof[1][dg], pa[1]);
+#pragma unroll
+                            for (int rt = 0; rt < RT; ++rt) {
+                                sa[rt] = Mma<bf16_t>::mma(kf, qf[rt][dg], sa[rt]);
+                                pa[rt] = Mma<bf16_t>::mma(vf, dof[rt][dg], pa[rt]);
+                            }
                         }
                     }
 #pragma unroll
-                    for (int rt = 0; rt < 2; ++rt) {
+                    for (int rt = 0; rt < RT; ++rt) {
                         f32x4_t m4 = {0.f, 0.f, 0.f, 0.f}, pdrop;
                         if (MASK && qr[rt] < S) {
                             const float* mrowp = p.mask + (int64_t)b * p.mask_bs + (int64_t)qr[rt] * p.mask_rs;
@@ -294,18 +298,19 @@ __global__ __launch_bounds__(512, 2) void attn_res_bwd_kernel(AttnArgs p) {
                         softmax_bwd4<DROP, false>(sa[rt], pa[rt], m4, splat4(lse2[rt]), splat4(dlt[rt]), sl2, hk, e0, 1u, thr, keep_scale, pdrop, ds[rt][k2]);
                     }
                 }
-                const bf16x8_t d0 = pack_bf16x8(ds[0][0], ds[0][1]);
-                const bf16x8_t d1 = pack_bf16x8(ds[1][0], ds[1][1]);
+                bf16x8_t dsp[RT];
+#pragma unroll
+                for (int rt = 0; rt < RT; ++rt) dsp[rt] = pack_bf16x8(ds[rt][0], ds[rt][1]);
 #pragma unroll
                 for (int dt = 0; dt < 4; ++dt) {
                     const bf16x8_t ktf = read_frag_tr_nat(sK, kv0 + 32 * kk, troff[dt]);   // K^T[d][key]
-                    dqacc[0][dt] = Mma<bf16_t>::mma(ktf, d0, dqacc[0][dt]);
-                    dqacc[1][dt] = Mma<bf16_t>::mma(ktf, d1, dqacc[1][dt]);
+#pragma unroll
+                    for (int rt = 0; rt < RT; ++rt) dqacc[rt][dt] = Mma<bf16_t>::mma(ktf, dsp[rt], dqacc[rt][dt]);
                 }
             }
         }
 #pragma unroll
-        for (int rt = 0; rt < 2; ++rt)
+        for (int rt = 0; rt < RT; ++rt)
             if (qr[rt] < S) {
                 bf16_t* DQ = (bf16_t*)p.dq + (int64_t)b * p.dq_bs + (int64_t)qr[rt] * p.dq_rs + h * ATT_D;
 #pragma unroll
@@ -314,21 +319,21 @@ __global__ __launch_bounds__(512, 2) void attn_res_bwd_kernel(AttnArgs p) {
     }
 
     // ---------------- phase 2: dK, dV   (scores as S[q = 4g+r][key = l & 15])
-    for (int pr = wave; pr < NP; pr += 8) {
-        bf16x8_t kf[2][2], vf[2][2];
-        int key[2];
+    for (int pr = wave; pr < NP; pr += NW) {
+        bf16x8_t kf[RT][2], vf[RT][2];
+        int key[RT];
 #pragma unroll
-        for (int kt = 0; kt < 2; ++kt) {
-            key[kt] = pr * 32 + kt * 16 + fr;
+        for (int kt = 0; kt < RT; ++kt) {
+            key[kt] = pr * (16 * RT) + kt * 16 + fr;
 #pragma unroll
             for (int dg = 0; dg < 2; ++dg) {
                 kf[kt][dg] = read_frag<bf16_t>(sK, key[kt], dg * 4 + g);
                 vf[kt][dg] = read_frag<bf16_t>(sV, key[kt], dg * 4 + g);
             }
         }
-        f32x4_t dkacc[2][4], dvacc[2][4];
+        f32x4_t dkacc[RT][4], dvacc[RT][4];
 #pragma unroll
-        for (int kt = 0; kt < 2; ++kt)
+        for (int kt = 0; kt < RT; ++kt)
 #pragma unroll
             for (int dt = 0; dt < 4; ++dt) { dkacc[kt][dt] = (f32x4_t){0.f, 0.f, 0.f, 0.f}; dvacc[kt][dt] = dkacc[kt][dt]; }
         for (int t = 0; t < NT; ++t) {
@@ -338,12 +343,13 @@ __global__ __launch_bounds__(512, 2) void attn_res_bwd_kernel(AttnArgs p) {
 #pragma unroll 1
             for (int kk = 0; kk < 2; ++kk) {
                 if (2 * kk >= nqs) continue;
-                f32x4_t pd[2][2], ds[2][2];      // [kt][q2]
+                f32x4_t pd[RT][2], ds[RT][2];      // [kt][q2]
 #pragma unroll
                 for (int q2 = 0; q2 < 2; ++q2) {
                     const int qs = 2 * kk + q2;
-                    f32x4_t sa[2], pa[2];
-                    sa[0] = (f32x4_t){0.f, 0.f, 0.f, 0.f}; sa[1] = sa[0]; pa[0] = sa[0]; pa[1] = sa[0];
+                    f32x4_t sa[RT], pa[RT];
+#pragma unroll
+                    for (int kt = 0; kt < RT; ++kt) { sa[kt] = (f32x4_t){0.f, 0.f, 0.f, 0.f}; pa[kt] = sa[kt]; }
                     f32x4_t l4 = sa[0], d4 = sa[0];
                     const int q4 = qb0 + qs * 16 + 4 * g;                       // < SP when qs < nqs
                     if (qs < nqs) {
@@ -351,16 +357,17 @@ __global__ __launch_bounds__(512, 2) void attn_res_bwd_kernel(AttnArgs p) {
                         for (int dg = 0; dg < 2; ++dg) {
                             const bf16x8_t qfr = read_frag<bf16_t>(sQ, qb0 + qs * 16 + fr, dg * 4 + g);
                             const bf16x8_t dfr = read_frag<bf16_t>(sDO, qb0 + qs * 16 + fr, dg * 4 + g);
-                            sa[0] = Mma<bf16_t>::mma(qfr, kf[0][dg], sa[0]);
-                            sa[1] = Mma<bf16_t>::mma(qfr, kf[1][dg], sa[1]);
-                            pa[0] = Mma<bf16_t>::mma(dfr, vf[0][dg], pa[0]);
-                            pa[1] = Mma<bf16_t>::mma(dfr, vf[1][dg], pa[1]);
+#pragma unroll
+                            for (int kt = 0; kt < RT; ++kt) {
+                                sa[kt] = Mma<bf16_t>::mma(qfr, kf[kt][dg], sa[kt]);
+                                pa[kt] = Mma<bf16_t>::mma(dfr, vf[kt][dg], pa[kt]);
+                            }
                         }
                         l4 = *(const f32x4_t*)(sLse + q4); d4 = *(const f32x4_t*)(sDelta + q4);
                     }
                     if (qs >= nqs) l4 = (f32x4_t){INFINITY, INFINITY, INFINITY, INFINITY};     // sub-tile past S (block uniform): P = 0
 #pragma unroll
-                    for (int kt = 0; kt < 2; ++kt) {
+                    for (int kt = 0; kt < RT; ++kt) {
                         f32x4_t m4 = {0.f, 0.f, 0.f, 0.f};
                         if (MASK && key[kt] < S) {
 #pragma unroll
@@ -370,23 +377,23 @@ __global__ __launch_bounds__(512, 2) void attn_res_bwd_kernel(AttnArgs p) {
                                                  pd[kt][q2], ds[kt][q2]);
                     }
                 }
-                const bf16x8_t p0 = pack_bf16x8(pd[0][0], pd[0][1]);
-                const bf16x8_t p1 = pack_bf16x8(pd[1][0], pd[1][1]);
-                const bf16x8_t s0 = pack_bf16x8(ds[0][0], ds[0][1]);
-                const bf16x8_t s1 = pack_bf16x8(ds[1][0], ds[1][1]);
+                bf16x8_t pp[RT], sp[RT];
+#pragma unroll
+                for (int kt = 0; kt < RT; ++kt) { pp[kt] = pack_bf16x8(pd[kt][0], pd[kt][1]); sp[kt] = pack_bf16x8(ds[kt][0], ds[kt][1]); }
 #pragma unroll
                 for (int dt = 0; dt < 4; ++dt) {
                     const bf16x8_t dotf = read_frag_tr_nat(sDO, qb0 + 32 * kk, troff[dt]);   // dO^T[d][q]
                     const bf16x8_t qtf = read_frag_tr_nat(sQ, qb0 + 32 * kk, troff[dt]);     // Q^T[d][q]
-                    dvacc[0][dt] = Mma<bf16_t>::mma(dotf, p0, dvacc[0][dt]);
-                    dvacc[1][dt] = Mma<bf16_t>::mma(dotf, p1, dvacc[1][dt]);
-                    dkacc[0][dt] = Mma<bf16_t>::mma(qtf, s0, dkacc[0][dt]);
-                    dkacc[1][dt] = Mma<bf16_t>::mma(qtf, s1, dkacc[1][dt]);
+#pragma unroll
+                    for (int kt = 0; kt < RT; ++kt) {
+                        dvacc[kt][dt] = Mma<bf16_t>::mma(dotf, pp[kt], dvacc[kt][dt]);
+                        dkacc[kt][dt] = Mma<bf16_t>::mma(qtf, sp[kt], dkacc[kt][dt]);
+                    }
                 }
             }
         }
 #pragma unroll
-        for (int kt = 0; kt < 2; ++kt)
+        for (int kt = 0; kt < RT; ++kt)
             if (key[kt] < S) {
                 bf16_t* DK = (bf16_t*)p.dk + (int64_t)b * p.dk_bs + (int64_t)key[kt] * p.dk_rs + h * ATT_D;
                 bf16_t* DV = (bf16_t*)p.dv + (int64_t)b * p.dv_bs + (int64_t)key[kt] * p.dv_rs + h * ATT_D;
@@ -398,6 +405,13 @@ __global__ __launch_bounds__(512, 2) void attn_res_bwd_kernel(AttnArgs p) {
             }
     }
 }
+
+template <bool DROP, bool MASK>
+__global__ __launch_bounds__(512, 2) void attn_res_bwd_kernel(AttnArgs p) { attn_res_bwd_body<DROP, MASK, 2, 8>(p); }
+// 16 waves of one 16-row block each (1024 threads: four waves per SIMD, <= 128 VGPRs): the round-3 review's reading of the counters was
+// "latency bound at two waves per SIMD". valor_attn_set_res_pipeline(2) / VALOR_ATTN_PIPE=2 selects it (A/B: tools/attn_pipe_ab.py).
+template <bool DROP, bool MASK>
+__global__ __launch_bounds__(1024) void attn_res_bwd16_kernel(AttnArgs p) { attn_res_bwd_body<DROP, MASK, 1, 16>(p); }
 
 // ------------------------------------------------------------------------------------------ backward, pipelined
 // The kernel above is one workgroup per CU (114 KiB of LDS, 8 waves x 178 VGPRs) whose three stretches do not overlap with anything:
@@ -723,7 +737,13 @@ bool attn_res_fwd_launch(hipStream_t st, const AttnArgs& p) {
 }
 
 static int g_res_bwd_pipe = [] { const char* e = getenv("VALOR_ATTN_PIPE"); return e ? atoi(e) : 1; }();
-// 1: the persistent, phase-pipelined backward; 0: one workgroup per (batch, head), two phases. Returns the previous value.
+// 1 (default): the persistent, phase-pipelined backward (16 waves x 16-row blocks per (batch, head) for S <= 160); 0: one workgroup of 8 waves x
+// 32-row blocks per (batch, head), two phases; 2: one workgroup of 16 waves x 16-row blocks per (batch, head). Returns the previous value.
+// (Round 4, profiles/r04_attn_pipe_ab_16waves.json -- the review's reading of the counters was "latency bound at two waves per SIMD":
+//  FOUR waves per SIMD (mode 2: 108-125 VGPRs, no scratch, bit-identical to mode 0) run the ViT shape in 514 us against 577 (mode 0) and 520
+//  (pipelined); the same 16 waves inside the persistent pipeline (spilling 16-116 B per lane at 128 VGPRs) 508 us. The variants converge
+//  on ~510 us whatever the occupancy and whether or not the loads overlap the phases: the kernel is bound by the SUM of its VALU (softmax
+//  backward, ~230 us of lane-operations), LDS fragment and MFMA issue, which one SIMD does not overlap across its waves here.)
 // (A third variant -- the dQ phase as a two-stage software pipeline, scores of key block j + 1 issued before the softmax of block j --
 //  measured SLOWER, 656 vs 633 us at the ViT shape, and two stages in the dK / dV phase spill 144-468 B per lane:
 //  profiles/r03_attn_pipe_ab_v2.json. A fourth -- a key-stationary SINGLE PASS: wave w keeps the K / V / K^T fragments of key block w
@@ -748,12 +768,19 @@ bool attn_res_bwd_launch(hipStream_t st, const AttnArgs& p) {
     if (!attr_set) {
         const int mx = 4 * 256 * TILE_ROW_BYTES + 2 * 256 * (int)sizeof(float);
         RES_FOR_ALL(attn_res_bwd_kernel, RES_SET_LDS, mx);
+        RES_FOR_ALL(attn_res_bwd16_kernel, RES_SET_LDS, mx);
         RES_FOR_ALL(attn_res_bwd_pipe_kernel, RES_SET_LDS, mx);
         int dev = 0, cus = 0;
         if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus > 0) n_cu = cus;
         attr_set = true;
     }
     const int n_items = p.B * p.H;
+    // 16 waves x 16-row blocks: always in mode 2; in the default mode for the short sequences (S <= 160: the AST shape, 129 rows, measured
+    // 110 us against 118 for the pipelined kernel and 133 for 8 waves x 32-row blocks; at S = 197 the three variants within 2 %)
+    if (g_res_bwd_pipe == 2 || (g_res_bwd_pipe == 1 && p.Skv <= 160)) {
+        RES_DISPATCH(attn_res_bwd16_kernel, dim3(p.H, p.B), dim3(1024), lds, st, p);
+        return true;
+    }
     if (g_res_bwd_pipe && n_items >= 2 * n_cu) {        // several items per workgroup: otherwise there is nothing to pipeline
         RES_DISPATCH(attn_res_bwd_pipe_kernel, dim3(n_cu), dim3(512), lds, st, p, n_items);
         return true;
