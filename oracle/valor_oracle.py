@@ -39,7 +39,9 @@ def dropout(x, p, training=True):
 
 class Oracle:
     def __init__(self, spec, sd, *, dropout_p=0.0, use_task_prompt=False, contra_loss_ratio=1.0, vocab_tokens=None,
-                 masker_range=(106, None), drop_path=0.0):
+                 masker_range=(106, None), drop_path=0.0, caption_type="unimlm"):
+        assert caption_type in ("unimlm", "lm")
+        self.caption_type = caption_type
         self.spec = spec
         self.sd = sd
         self.p = dropout_p
@@ -332,6 +334,17 @@ class Oracle:
         return F.linear(x, w("multimodal_encoder.embeddings.word_embeddings.weight"), w("cls.decoder.bias"))
 
     # ------------------------------------------------------------------------- host-side text helpers
+    def caption_inputs(self, txt, mask_prob=0.6):
+        """inputs and labels of the caption passes, model/pretrain.py:424-433 (= :807-816 in forward_cap_single): 'unimlm' masks 60 % of the
+        tokens and predicts them; 'lm' feeds the tokens as they are and predicts the NEXT token at every position (label 0 = padding and
+        the last position -> ignored)"""
+        if self.caption_type == "unimlm":
+            return self.text_masker(txt, mask_prob)
+        labels = torch.zeros_like(txt)
+        labels[:, :txt.shape[1] - 1] = txt[:, 1:]
+        labels[labels == 0] = -1
+        return txt, labels
+
     def text_masker(self, tokens, mask_prob):
         """TokenMasker.perform_mask, model/modeling.py:134-174 (CPU numpy + python `random`, >= 1 mask per row)."""
         tokens = np.array(tokens.cpu().numpy())
@@ -541,7 +554,7 @@ class Oracle:
             return None
 
         if caption_task:                                                                         # pretrain.py:419-481
-            txt_input, txt_labels = self.text_masker(txt, 0.6)
+            txt_input, txt_labels = self.caption_inputs(txt)
             col["caption_txt_input"], col["caption_txt_labels"] = txt_input, txt_labels
             lo = []
             for g in ("tva", "tv", "ta"):
@@ -606,7 +619,7 @@ class Oracle:
         bs = (video_output if video_output is not None else audio_output).shape[0]
         video_input, audio_input = self.multimodal_inputs(video_output, audio_output, bs)
         if compute_loss:                                                                         # :802-880
-            txt_input, txt_labels = self.text_masker(txt, 0.6)
+            txt_input, txt_labels = self.caption_inputs(txt)
             lo = []
             for g in ("tva", "tv", "ta"):
                 if g in groups:
@@ -615,6 +628,8 @@ class Oracle:
                     scores = self.cls_head(o[:, :txt_input.shape[1]][txt_labels != -1])
                     lo.append(F.cross_entropy(scores, txt_labels[txt_labels != -1]))
             return {"caption_loss": sum(lo) / len(lo)}
+        if self.caption_type != "unimlm":
+            raise NotImplementedError("generation with caption_type='lm' (pretrain.py:1033-1041) is not restated")
         ev = {}                                                                                  # generate_cap :914-985
         for g, key in (("tv", "t_v"), ("tva", "t_va"), ("ta", "t_a")):
             if g in groups:
@@ -655,7 +670,7 @@ class Oracle:
                 prompt = self.qa_prompt(q.repeat_interleave(rep, dim=0))
                 video_input = video_input.repeat_interleave(rep, dim=0) if video_input is not None else None
                 audio_input = audio_input.repeat_interleave(rep, dim=0) if audio_input is not None else None
-            txt_input, txt_labels = self.text_masker(batch["txt_tokens"]["bert_tokens"], 0.99)
+            txt_input, txt_labels = self.caption_inputs(batch["txt_tokens"]["bert_tokens"], 0.99)
             lo = []
             for g in ("tva", "tv", "ta"):
                 if g in groups:

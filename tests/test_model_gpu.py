@@ -459,3 +459,38 @@ def test_prefetch_loader_delivers_the_same_batches(dev):
     random.seed(5); a = model(src[0][1], task=TASK, compute_loss=True)
     random.seed(5); b = model(got[0][1], task=TASK, compute_loss=True)
     assert all(float(a[k]) == float(b[k]) for k in a)
+
+
+def test_caption_type_lm_matches_oracle(dev):
+    """caption_type='lm' (model/pretrain.py:429-433, :812-816): unmasked tokens, next-token labels under the causal mask. The oracle's branch
+    is pinned on the unmodified reference (tests/test_oracle_vs_reference.py::test_caption_type_lm_matches_reference); here the HIP path in
+    fp32 against it: the three losses, every gradient, and the caption-finetune loss ('cap%tva%tv'). Generation is refused."""
+    from valor_amd import synth
+    import valor_oracle as VO
+    spec = synth.tiny_spec()
+    sd = synth.make_state_dict(spec, seed=5, w_std=0.05)
+    batch = synth.make_batch(spec, batch=4, frames=2, audio_slices=1, txt_len=32, seed=6)
+    sd_o = VO.trainable_copy(sd)
+    orc = VO.Oracle(spec, sd_o, vocab_tokens=synth.synthetic_vocab(spec.vocab), caption_type="lm")
+    model = _native(spec, sd, torch.float32, dev, extra={"caption_type": "lm"})
+    random.seed(21); o_out = orc.forward_pt(batch, TASK, compute_loss=True); sum(o_out.values()).backward()
+    random.seed(21); n_out = model(batch, task=TASK, compute_loss=True); sum(n_out.values()).backward()
+    for k in ("contra_loss", "caption_loss", "mlm_loss"):
+        a, b = float(o_out[k]), float(n_out[k])
+        assert abs(a - b) <= 1e-4 * abs(a), (k, a, b)
+    ng = _native_grads(model)
+    bad = []
+    for k, p in sd_o.items():
+        if VO.is_alias_key(k) or not p.is_floating_point() or p.grad is None:
+            continue
+        go, gn = p.grad, ng[k].detach().cpu()
+        scale = max(float(go.norm()), 1e-5 * go.numel() ** 0.5)
+        if float((gn.reshape(go.shape) - go).norm()) / scale > 2e-3:
+            bad.append(k)
+    assert not bad, bad[:8]
+    with torch.no_grad():
+        oc = orc.forward(batch, "cap%tva%tv", compute_loss=True)
+        nc = model(batch, task="cap%tva%tv", compute_loss=True)
+    assert abs(float(oc["caption_loss"]) - float(nc["caption_loss"])) <= 1e-4 * abs(float(oc["caption_loss"]))
+    with pytest.raises(NotImplementedError):
+        model(batch, task="cap%tva%tv", compute_loss=False)

@@ -378,3 +378,36 @@ def test_contrastive_groups_without_text_on_the_query_side(setup):
             r = ref(batch, task=task, compute_loss=True)
             o = orc.forward(batch, task, compute_loss=True)
             assert abs(float(r["contra_loss"]) - float(o["contra_loss"])) <= 2e-5 * abs(float(r["contra_loss"])), (task, float(r["contra_loss"]), float(o["contra_loss"]))
+
+
+def test_caption_type_lm_matches_reference():
+    """caption_type='lm' (model/pretrain.py:429-433, :812-816, :1230-1234): the caption passes read the unmasked tokens under the causal
+    mask and predict the NEXT token at every position (padding / last position ignored) -- pretraining task string and the caption
+    finetune loss against the unmodified reference: losses and every gradient."""
+    from valor_amd import synth
+    from valor_oracle import Oracle, trainable_copy
+    spec, ropts = synth.base_spec(), ref_harness.default_opts(caption_type="lm")
+    sd = synth.make_state_dict(spec, seed=17)
+    ref = ref_harness.build_reference(ropts, state_dict=None, dropout=0.0)
+    missing, unexpected = ref.load_state_dict(sd, strict=False)
+    assert not missing and not unexpected
+    sd_o = trainable_copy(sd)
+    orc = Oracle(spec, sd_o, vocab_tokens=synth.synthetic_vocab(spec.vocab), caption_type="lm")
+    batch = synth.make_batch(spec, batch=2, frames=1, audio_slices=1, txt_len=32, seed=18)
+    random.seed(5); r = ref(batch, task=TASK, compute_loss=True); sum(r.values()).backward()
+    random.seed(5); o = orc.forward_pt(batch, TASK, compute_loss=True); sum(o.values()).backward()
+    for k in ("contra_loss", "caption_loss", "mlm_loss"):
+        assert abs(float(r[k]) - float(o[k])) <= 2e-5 * abs(float(r[k])), (k, float(r[k]), float(o[k]))
+    n = 0
+    for name, p in ref.named_parameters():
+        if p.grad is None:
+            continue
+        g = sd_o[name].grad
+        scale = max(float(p.grad.norm()), 1e-4 * p.grad.numel() ** 0.5)
+        assert float((g - p.grad).norm()) / scale < 2e-4, name
+        n += 1
+    assert n > 800
+    with torch.no_grad():
+        rc = ref(dict(batch), task="cap%tva%tv", compute_loss=True)      # forward_cap replaces batch['txt_tokens'] in place
+        oc = orc.forward(batch, "cap%tva%tv", compute_loss=True)
+    assert abs(float(rc["caption_loss"]) - float(oc["caption_loss"])) <= 2e-5 * abs(float(rc["caption_loss"]))

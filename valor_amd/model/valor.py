@@ -129,8 +129,9 @@ class VALOR(nn.Module):
             raise NotImplementedError(f"opts ask for {want} encoders, the spec describes {(spec.video_encoder, spec.txt_encoder)}")
         if (spec.video_encoder, spec.txt_encoder) not in (("clip", "clip"), ("swin", "bert"), ("clip", "bert")):
             raise NotImplementedError("the reference loads CLIP as a whole: video/text encoders come as clip+clip, swin+bert or clip+bert")
-        if _opt(opts, "contra_type", "fine") != "fine" or _opt(opts, "caption_type", "unimlm") != "unimlm":
-            raise NotImplementedError("contra_type='fine' and caption_type='unimlm' only")
+        if _opt(opts, "contra_type", "fine") != "fine" or _opt(opts, "caption_type", "unimlm") not in ("unimlm", "lm"):
+            raise NotImplementedError("contra_type='fine' and caption_type 'unimlm' / 'lm' only")
+        self.caption_type = _opt(opts, "caption_type", "unimlm")        # pretrain.py:76; 'lm': loss paths only (generation raises)
         if _opt(opts, "cross_attn_type", "va_concate") != "va_concate" or _opt(opts, "late_fusion", False) or _opt(opts, "full_masker", False):
             raise NotImplementedError("cross_attn_type='va_concate', late_fusion=False, full_masker=False only")
         if _opt(opts, "fineweight_type", "one") == "none":
@@ -843,6 +844,8 @@ class VALOR(nn.Module):
         groups = task.split("%")[1:]
         if compute_loss:
             return self._forward_groups(batch, [], groups, [], True)
+        if self.caption_type != "unimlm":
+            raise NotImplementedError("generation with caption_type='lm' (model/pretrain.py:1033-1041) is not built; the loss paths are")
         from .. import decode
         return decode.generate_cap(self, batch, groups)
 
@@ -863,13 +866,15 @@ class VALOR(nn.Module):
         groups = [g for g in ("tva", "tv", "ta") if g in task.split("%")[1:]]
         prompt = self.qa_prompt(batch["question_tokens"]["bert_tokens"].cpu())
         if not compute_loss:
+            if self.caption_type != "unimlm":
+                raise NotImplementedError("generation with caption_type='lm' is not built; the loss paths are")
             from .. import decode
             return decode.generate_qa(self, batch, groups, prompt)
         self.stage.begin_step()
         txt = batch["txt_tokens"]["bert_tokens"].cpu()
         nums = [int(n) for n in batch.get("answer_nums", [1] * txt.shape[0])]
         b = len(nums)
-        qa_in, qa_lab = self.text_masker(txt, 0.99)                 # in the reference's row order (sample-major): the draw order is the contract
+        qa_in, qa_lab = self.caption_inputs(txt, 0.99)                 # in the reference's row order (sample-major): the draw order is the contract
         weights = None
         if any(n != 1 for n in nums):
             # image QA (pretrain.py:1243-1265): the reference tiles question / video / audio rows per candidate answer. Here the answer
@@ -904,6 +909,16 @@ class VALOR(nn.Module):
                 contra_task = i.split("%")[1:]
         return self._forward_groups(batch, mlm_task, caption_task, contra_task, compute_loss, contra_ratio=self.contra_loss_ratio)
 
+    def caption_inputs(self, txt, mask_prob=0.6):
+        """inputs / labels of the caption passes (model/pretrain.py:424-433, :807-816; the answer rows of QA at 0.99, :1225-1234): caption_type 'unimlm' = TokenMasker; 'lm' =
+        the tokens as they are, label = the NEXT token (0 = padding and the last position: ignored, -1)"""
+        if self.caption_type == "unimlm":
+            return self.text_masker(txt, mask_prob)
+        labels = torch.zeros_like(txt)
+        labels[:, :txt.shape[1] - 1] = txt[:, 1:]
+        labels[labels == 0] = -1
+        return txt, labels
+
     def _forward_groups(self, batch, mlm_task, caption_task, contra_task, compute_loss, contra_ratio=1.0):
         """The body of VALOR.forward_pt (model/pretrain.py:226-541) on parsed group lists; forward_ret / forward_cap run it with one branch."""
         P, sp = self.P, self.spec
@@ -920,7 +935,7 @@ class VALOR(nn.Module):
         if caption_task or mlm_task:
             txt = txt_tokens["bert_tokens"].cpu()
             if caption_task:
-                cap_in, cap_lab = self.text_masker(txt, 0.6)
+                cap_in, cap_lab = self.caption_inputs(txt)
             if mlm_task:
                 mlm_in, mlm_lab = self.text_masker(txt, 0.15)
         alltasks = "".join(mlm_task + caption_task + contra_task)
