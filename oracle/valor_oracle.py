@@ -652,7 +652,7 @@ class Oracle:
     def forward_qa(self, batch, task, compute_loss=True, beam_size_qa=1, max_generation_len=30):
         """VALOR.forward_qa -> forward_qa_single (loss) / generate_qa, model/pretrain.py:1191-1459. Loss: one answer per question (the
         video-QA datasets) or several weighted candidates (image QA: question / video / audio rows tiled per answer, :1243-1265, loss
-        rows weighted and summed over the QUESTION count :1288-1290); generation: one question per clip (sample_num all 1).
+        rows weighted and summed over the QUESTION count :1288-1290); generation: sample_num[i] questions of clip i (:1378-1390).
         Loss :1276-1290: TokenMasker p = 0.99 on the answer tokens, per-SAMPLE mean of the masked-token CE, mean over samples, mean over groups."""
         groups = task.split("%")[1:]
         q = batch["question_tokens"]["bert_tokens"]
@@ -660,7 +660,13 @@ class Oracle:
         video_output = self.forward_video_encoder(batch["video_pixels"]) if "v" in alltasks else None
         audio_output = self.forward_audio_encoder(batch["audio_spectrograms"]) if "a" in alltasks else None
         bs = q.shape[0]
-        video_input, audio_input = self.multimodal_inputs(video_output, audio_output, bs)
+        clips = (video_output if video_output is not None else audio_output).shape[0]
+        video_input, audio_input = self.multimodal_inputs(video_output, audio_output, clips)
+        sn = [int(n) for n in batch.get("sample_num", [1] * clips)]
+        if not compute_loss and any(n != 1 for n in sn):      # generate_qa :1378-1390: clip i serves sample_num[i] consecutive question rows
+            idx = torch.tensor([i for i, n in enumerate(sn) for _ in range(n)])
+            video_input = video_input[idx] if video_input is not None else None
+            audio_input = audio_input[idx] if audio_input is not None else None
         prompt = self.qa_prompt(q)
         if compute_loss:
             nums = [int(n) for n in batch["answer_nums"]]
@@ -681,7 +687,6 @@ class Oracle:
                     loss = loss.sum(dim=-1) / (txt_labels != -1).sum(dim=-1)
                     lo.append((loss * torch.as_tensor(batch["answer_weights"], dtype=loss.dtype)).sum() / len(nums) if tile else loss.mean())
             return {"qa_loss": sum(lo) / len(lo)}
-        assert all(int(n) == 1 for n in batch["sample_num"])
         ev = {}                                                                                  # generate_qa :1366-1459
         for g, key in (("tv", "t_v"), ("tva", "t_va"), ("ta", "t_a")):
             if g in groups:

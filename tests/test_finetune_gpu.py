@@ -109,8 +109,17 @@ def test_tiny_fp32_finetune_tasks_and_generation_match_oracle(dev, variant, prom
     assert abs(float(o["qa_loss"]) - float(n["qa_loss"])) <= 1e-4 * abs(float(o["qa_loss"])), (float(o["qa_loss"]), float(n["qa_loss"]))
     n["qa_loss"].backward()
     model.zero_grad()
-    with pytest.raises(NotImplementedError):
-        model(dict(qb, sample_num=[2, 1, 1]), task="qa%tv", compute_loss=False)
+    # --- several questions per clip at generation (sample_num, pretrain.py:1378-1390): K|V projected once per clip, rows gathered per question
+    four = synth.make_batch(spec, batch=4, frames=1, audio_slices=1, txt_len=10, seed=9, questions=True)
+    sq = dict(qb, question_tokens=four["question_tokens"], sample_num=[2, 1, 1])
+    model.beam_size_qa = 1
+    with torch.no_grad():
+        os1 = orc.forward_qa(sq, "qa%tva%tv", compute_loss=False, beam_size_qa=1, max_generation_len=6)
+    ns1 = model(sq, task="qa%tva%tv", compute_loss=False)
+    for k in ("generated_answers_t_va", "generated_answers_t_v"):
+        assert os1[k].shape[0] == 4 and torch.equal(os1[k], ns1[k].cpu()), (k, os1[k], ns1[k])
+    with pytest.raises(ValueError):
+        model(dict(qb, sample_num=[2, 1, 1]), task="qa%tv", compute_loss=False)       # three questions, sample_num says four
 
 
 @pytest.mark.parametrize("name", ["ref_base_b2f2a1_ft", "ref_swin_b2f2a1_ft"])

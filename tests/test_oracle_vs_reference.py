@@ -411,3 +411,23 @@ def test_caption_type_lm_matches_reference():
         rc = ref(dict(batch), task="cap%tva%tv", compute_loss=True)      # forward_cap replaces batch['txt_tokens'] in place
         oc = orc.forward(batch, "cap%tva%tv", compute_loss=True)
     assert abs(float(rc["caption_loss"]) - float(oc["caption_loss"])) <= 2e-5 * abs(float(rc["caption_loss"]))
+
+
+def test_several_questions_per_clip_at_generation():
+    """generate_qa with sample_num = [2, 1] (model/pretrain.py:1378-1390): three question rows over two clips, the clip rows expanded per
+    question -- greedy answers of the reference, token for token."""
+    from valor_amd import synth
+    from valor_oracle import Oracle, trainable_copy
+    spec = synth.base_spec()
+    sd = synth.make_state_dict(spec, seed=50)
+    ref = ref_harness.build_reference(ref_harness.default_opts(), state_dict=sd, dropout=0.0)
+    orc = Oracle(spec, trainable_copy(sd), vocab_tokens=synth.synthetic_vocab(spec.vocab))
+    batch = synth.make_batch(spec, batch=2, frames=2, audio_slices=1, txt_len=8, seed=53, questions=True)
+    three = synth.make_batch(spec, batch=3, frames=1, audio_slices=1, txt_len=8, seed=54, questions=True)
+    batch = dict(batch, question_tokens=three["question_tokens"], sample_num=[2, 1])
+    with torch.no_grad():
+        ref.max_generation_len = 5
+        rg = ref({k: (dict(v) if isinstance(v, dict) else v) for k, v in batch.items()}, task="qa%tva%tv", compute_loss=False)
+        og = orc.forward_qa(batch, "qa%tva%tv", compute_loss=False, max_generation_len=5)
+    for k in ("generated_answers_t_va", "generated_answers_t_v"):
+        assert rg[k].shape[0] == 3 and torch.equal(rg[k], og[k]), (k, rg[k], og[k])

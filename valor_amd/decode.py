@@ -175,10 +175,11 @@ def generate_cap(model, batch, groups, beam_size=None, max_generation_len=None):
 
 @torch.no_grad()
 def generate_qa(model, batch, groups, prompt_cpu, beam_size=None, max_generation_len=None):
-    """VALOR.generate_qa, model/pretrain.py:1366-1459, one sample per question (sample_num all 1): the caption decoders with the
-    question rows as the prompt -> {'generated_answers_t_v' | '_t_va' | '_t_a'}."""
-    if any(int(n) != 1 for n in batch.get("sample_num", [1])):
-        raise NotImplementedError("several questions per clip (sample_num > 1, pretrain.py:1378-1390) are not built")
+    """VALOR.generate_qa, model/pretrain.py:1366-1459: the caption decoders with the question rows as the prompt ->
+    {'generated_answers_t_v' | '_t_va' | '_t_a'}. sample_num[i] consecutive question rows belong to clip i (:1378-1390): the reference
+    expands the [video | audio] token rows per question; here the per-layer K|V projections are computed once per CLIP and their rows
+    gathered per question (valor_gather_rows), so the projection GEMMs do not grow with the question count."""
+    sample_num = [int(n) for n in batch.get("sample_num", [])]
     # the reference switches to beam search when beam_size_qa > 1 but decode_beam always searches with self.beam_size, task 'qa'
     # included (pretrain.py:1061): beam_size_qa is the switch, beam_size the width
     beam = (model.beam_size if model.beam_size_qa > 1 else 1) if beam_size is None else beam_size
@@ -187,6 +188,13 @@ def generate_qa(model, batch, groups, prompt_cpu, beam_size=None, max_generation
     model.eval()
     try:
         b, kv_layers, ranges = encode_for_generation(model, batch, groups)
+        if any(n != 1 for n in sample_num):
+            if len(sample_num) != b or sum(sample_num) != prompt_cpu.shape[0]:
+                raise ValueError(f"sample_num {sample_num} does not describe {b} clips / {prompt_cpu.shape[0]} questions")
+            from . import ops
+            idx = model._dev(torch.tensor([i for i, n in enumerate(sample_num) for _ in range(n)], dtype=torch.long))
+            kv_layers = [ops.gather_rows(kv.reshape(b, -1), idx).view(idx.numel(), *kv.shape[1:]) for kv in kv_layers]
+            b = int(idx.numel())
         out = {}
         for g, key in (("tv", "t_v"), ("tva", "t_va"), ("ta", "t_a")):
             if g not in groups:
