@@ -254,6 +254,12 @@ int valor_xent_fwd(void* stream, int dtype, const void* logits, const int64_t* l
                    int64_t rows, int V, int64_t ld);
 int valor_xent_bwd(void* stream, int dtype, void* logits_inout, const int64_t* labels, const float* lse,
                    const float* gscale_dev, float gmul, int64_t rows, int V, int64_t ld);
+/* the same with label smoothing (LabelSmoothing, model/pretrain.py:46-61,839-840): target 1 - smoothing on the label, smoothing / (V - 1)
+ * elsewhere; row loss = KL(target || softmax), backward (softmax - target) * g. smoothing in [0, 1); 0 = valor_xent_fwd / _bwd. */
+int valor_xent_smooth_fwd(void* stream, int dtype, const void* logits, const int64_t* labels, float* loss_rows, float* lse,
+                          int64_t rows, int V, int64_t ld, float smoothing);
+int valor_xent_smooth_bwd(void* stream, int dtype, void* logits_inout, const int64_t* labels, const float* lse,
+                          const float* gscale_dev, float gmul, int64_t rows, int V, int64_t ld, float smoothing);
 int valor_mean_f32(void* stream, const float* x, int64_t n, float* out);
 
 /* ---- MGA fine-grained contrastive: compute_fine_matrix_slice (pretrain.py:191-211) + contrastive_loss

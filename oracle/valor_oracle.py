@@ -39,9 +39,10 @@ def dropout(x, p, training=True):
 
 class Oracle:
     def __init__(self, spec, sd, *, dropout_p=0.0, use_task_prompt=False, contra_loss_ratio=1.0, vocab_tokens=None,
-                 masker_range=(106, None), drop_path=0.0, caption_type="unimlm"):
+                 masker_range=(106, None), drop_path=0.0, caption_type="unimlm", label_smoothing=0.0):
         assert caption_type in ("unimlm", "lm")
         self.caption_type = caption_type
+        self.label_smoothing = label_smoothing      # model/pretrain.py:72-74: the caption finetune loss only (:839-840)
         self.spec = spec
         self.sd = sd
         self.p = dropout_p
@@ -626,7 +627,13 @@ class Oracle:
                     prompt = self.get_task_prompt("describe the video with natural language", bs) if self.use_task_prompt else None
                     o = self.bert_model(txt_input, prompt, video_input if "v" in g else None, audio_input if "a" in g else None, True)
                     scores = self.cls_head(o[:, :txt_input.shape[1]][txt_labels != -1])
-                    lo.append(F.cross_entropy(scores, txt_labels[txt_labels != -1]))
+                    if self.label_smoothing > 0:          # LabelSmoothing, model/pretrain.py:46-61: KL(smoothed target || softmax), summed over the vocabulary, mean over rows
+                        logp = F.log_softmax(scores, dim=-1)
+                        tgt = torch.full_like(logp, self.label_smoothing / (logp.shape[1] - 1))
+                        tgt.scatter_(1, txt_labels[txt_labels != -1].unsqueeze(1), 1.0 - self.label_smoothing)
+                        lo.append((tgt * (tgt.log() - logp)).sum(1).mean())
+                    else:
+                        lo.append(F.cross_entropy(scores, txt_labels[txt_labels != -1]))
             return {"caption_loss": sum(lo) / len(lo)}
         if self.caption_type != "unimlm":
             raise NotImplementedError("generation with caption_type='lm' (pretrain.py:1033-1041) is not restated")

@@ -87,3 +87,38 @@ def test_xent_against_fp64(dev, dtype):
     lib.call("valor_xent_bwd", _stream(), dt_of(buf), _ptr(buf), _ptr(labels_d), _ptr(lse), _ptr(up), 1.0 / n, n, V, Vpad)
     assert _rel(buf[:, :V].cpu(), x.grad) < (2e-6 if dtype == torch.float32 else 4e-3)
     assert float(buf[:, V:].float().abs().max()) == 0.0     # the ld padding is zero-filled (it is a GEMM operand next)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_label_smoothing_cross_entropy(dev, dtype):
+    """valor_xent_smooth_fwd / _bwd (LabelSmoothing, model/pretrain.py:46-61): row loss = KL(smoothed target || softmax) and its gradient
+    against fp64, on the padded-vocabulary layout; smoothing 0 reproduces valor_xent_fwd / _bwd bit for bit."""
+    from valor_amd import lib
+    from valor_amd.kernels import _ptr, _stream, dt_of
+    n, V, Vpad, eps = 37, 30522, 30528, 0.1
+    g = torch.Generator().manual_seed(2)
+    logits = (3.0 * torch.randn((n, Vpad), generator=g)).to(dtype)
+    labels = torch.randint(0, V, (n,), generator=g)
+    buf = logits.to(dev).clone()
+    lab_d = labels.to(dev)
+    loss_rows = torch.empty(n, device=dev); lse = torch.empty(n, device=dev)
+    lib.call("valor_xent_smooth_fwd", _stream(), dt_of(buf), _ptr(buf), _ptr(lab_d), _ptr(loss_rows), _ptr(lse), n, V, Vpad, eps)
+    z = logits[:, :V].double().requires_grad_(True)
+    logp = torch.log_softmax(z, -1)
+    tgt = torch.full_like(logp, eps / (V - 1)); tgt.scatter_(1, labels.unsqueeze(1), 1.0 - eps)
+    ref_rows = (tgt * (tgt.log() - logp)).sum(1)
+    assert torch.allclose(loss_rows.cpu().double(), ref_rows.detach(), rtol=2e-4, atol=2e-4), (loss_rows[:4], ref_rows[:4])
+    ref_rows.mean().backward()
+    up = torch.full((), 1.0, device=dev)
+    lib.call("valor_xent_smooth_bwd", _stream(), dt_of(buf), _ptr(buf), _ptr(lab_d), _ptr(lse), _ptr(up), 1.0 / n, n, V, Vpad, eps)
+    got = buf[:, :V].cpu().double()
+    tol = 2e-6 if dtype == torch.float32 else 2e-2
+    assert float((got - z.grad).norm() / z.grad.norm()) < tol
+    assert float(buf[:, V:].float().abs().max()) == 0.0
+    # smoothing 0 == the plain entry points, bit for bit
+    a, b = logits.to(dev).clone(), logits.to(dev).clone()
+    la, lb = torch.empty(n, device=dev), torch.empty(n, device=dev)
+    sa, sb = torch.empty(n, device=dev), torch.empty(n, device=dev)
+    lib.call("valor_xent_smooth_fwd", _stream(), dt_of(a), _ptr(a), _ptr(lab_d), _ptr(la), _ptr(sa), n, V, Vpad, 0.0)
+    lib.call("valor_xent_fwd", _stream(), dt_of(b), _ptr(b), _ptr(lab_d), _ptr(lb), _ptr(sb), n, V, Vpad)
+    assert torch.equal(la, lb) and torch.equal(sa, sb)

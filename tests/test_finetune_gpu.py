@@ -223,3 +223,38 @@ def test_base_widths_bf16_generation_is_within_the_logit_error(dev, name):
     assert worst < BF16_LOGIT_BAND, f"bf16 logit error {worst:.4f}"
     assert agree == decided
     print(f"{name}: bf16 max logit error {worst:.4f} over {ref_seq.numel()} teacher-forced steps; {decided} steps had a reference margin > {2 * BF16_LOGIT_BAND}")
+
+
+def test_caption_finetune_with_label_smoothing_matches_oracle(dev):
+    """config.label_smoothing = 0.1 (model/pretrain.py:72-74,839-840; the oracle's branch is pinned on the unmodified reference in
+    tests/test_oracle_vs_reference.py): 'cap%tva%tv' loss and every gradient of the HIP path in fp32; the pretraining task string is
+    NOT smoothed (the reference only smooths forward_cap_single)."""
+    from valor_amd import synth
+    import valor_oracle as VO
+    from test_model_gpu import _native_grads
+    spec = synth.tiny_spec()
+    sd = synth.make_state_dict(spec, seed=3, w_std=0.05)
+    batch = synth.make_batch(spec, batch=3, frames=2, audio_slices=1, txt_len=16, seed=5)
+    sd_o = VO.trainable_copy(sd)
+    orc = VO.Oracle(spec, sd_o, vocab_tokens=synth.synthetic_vocab(spec.vocab), label_smoothing=0.1)
+    model = _build(spec, sd, torch.float32, dev, label_smoothing=0.1)
+    random.seed(2); o = orc.forward(batch, "cap%tva%tv", compute_loss=True); o["caption_loss"].backward()
+    random.seed(2); n = model(batch, task="cap%tva%tv", compute_loss=True); n["caption_loss"].backward()
+    assert abs(float(o["caption_loss"]) - float(n["caption_loss"])) <= 1e-4 * abs(float(o["caption_loss"])), (float(o["caption_loss"]), float(n["caption_loss"]))
+    ng = _native_grads(model)
+    bad = []
+    for k, p in sd_o.items():
+        if VO.is_alias_key(k) or not p.is_floating_point() or p.grad is None:
+            continue
+        go, gn = p.grad, ng[k].detach().cpu()
+        scale = max(float(go.norm()), 1e-5 * go.numel() ** 0.5)
+        if float((gn.reshape(go.shape) - go).norm()) / scale > 2e-3:
+            bad.append(k)
+    assert not bad, bad[:8]
+    model.zero_grad()
+    plain = VO.Oracle(spec, VO.trainable_copy(sd), vocab_tokens=synth.synthetic_vocab(spec.vocab))
+    task = "pt_caption%tva%tv"
+    with torch.no_grad():
+        random.seed(3); op = plain.forward_pt(batch, task, compute_loss=True)
+        random.seed(3); np_ = model(batch, task=task, compute_loss=True)
+    assert abs(float(op["caption_loss"]) - float(np_["caption_loss"])) <= 1e-4 * abs(float(op["caption_loss"]))

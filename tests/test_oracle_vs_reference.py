@@ -431,3 +431,30 @@ def test_several_questions_per_clip_at_generation():
         og = orc.forward_qa(batch, "qa%tva%tv", compute_loss=False, max_generation_len=5)
     for k in ("generated_answers_t_va", "generated_answers_t_v"):
         assert rg[k].shape[0] == 3 and torch.equal(rg[k], og[k]), (k, rg[k], og[k])
+
+
+def test_label_smoothing_of_the_caption_finetune_loss():
+    """config.label_smoothing = 0.1 (model/pretrain.py:72-74, LabelSmoothing :46-61, used by forward_cap_single :839-840 only): the KL
+    divergence to the smoothed target, against the unmodified reference -- loss and every gradient of 'cap%tva%tv'."""
+    from valor_amd import synth
+    from valor_oracle import Oracle, trainable_copy
+    spec, ropts = synth.base_spec(), ref_harness.default_opts(label_smoothing=0.1)
+    sd = synth.make_state_dict(spec, seed=19)
+    ref = ref_harness.build_reference(ropts, state_dict=None, dropout=0.0)
+    missing, unexpected = ref.load_state_dict(sd, strict=False)
+    assert not missing and not unexpected
+    sd_o = trainable_copy(sd)
+    orc = Oracle(spec, sd_o, vocab_tokens=synth.synthetic_vocab(spec.vocab), label_smoothing=0.1)
+    batch = synth.make_batch(spec, batch=2, frames=1, audio_slices=1, txt_len=32, seed=20)
+    random.seed(7); r = ref(dict(batch), task="cap%tva%tv", compute_loss=True); r["caption_loss"].backward()
+    random.seed(7); o = orc.forward(batch, "cap%tva%tv", compute_loss=True); o["caption_loss"].backward()
+    assert abs(float(r["caption_loss"]) - float(o["caption_loss"])) <= 2e-5 * abs(float(r["caption_loss"])), (float(r["caption_loss"]), float(o["caption_loss"]))
+    n = 0
+    for name, p in ref.named_parameters():
+        if p.grad is None:
+            continue
+        g = sd_o[name].grad
+        scale = max(float(p.grad.norm()), 1e-4 * p.grad.numel() ** 0.5)
+        assert float((g - p.grad).norm()) / scale < 2e-4, name
+        n += 1
+    assert n > 300

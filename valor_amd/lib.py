@@ -69,6 +69,8 @@ SIGNATURES = {
     "valor_reducer_destroy": [_vp],
     "valor_xent_fwd": [_vp, _i, _vp, _vp, _vp, _vp, _i64, _i, _i64],
     "valor_xent_bwd": [_vp, _i, _vp, _vp, _vp, _vp, _f, _i64, _i, _i64],
+    "valor_xent_smooth_fwd": [_vp, _i, _vp, _vp, _vp, _vp, _i64, _i, _i64, _f],
+    "valor_xent_smooth_bwd": [_vp, _i, _vp, _vp, _vp, _vp, _f, _i64, _i, _i64, _f],
     "valor_fine_weight_softmax": [_vp, _vp, _vp, _vp, _i, _i],
     "valor_fine_weight_softmax_bwd": [_vp, _vp, _vp, _vp, _i, _i],
     "valor_fine_reduce_fwd": [_vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i],

@@ -132,6 +132,8 @@ class VALOR(nn.Module):
         if _opt(opts, "contra_type", "fine") != "fine" or _opt(opts, "caption_type", "unimlm") not in ("unimlm", "lm"):
             raise NotImplementedError("contra_type='fine' and caption_type 'unimlm' / 'lm' only")
         self.caption_type = _opt(opts, "caption_type", "unimlm")        # pretrain.py:76; 'lm': loss paths only (generation raises)
+        self.label_smoothing = float(_opt(opts, "label_smoothing", 0.0))    # pretrain.py:72-74: the caption FINETUNE loss only (:839-840)
+        self._smoothing = 0.0                                            # label smoothing of the decoder passes being issued
         if _opt(opts, "cross_attn_type", "va_concate") != "va_concate" or _opt(opts, "late_fusion", False) or _opt(opts, "full_masker", False):
             raise NotImplementedError("cross_attn_type='va_concate', late_fusion=False, full_masker=False only")
         if _opt(opts, "fineweight_type", "one") == "none":
@@ -736,7 +738,8 @@ class VALOR(nn.Module):
             return torch.stack(losses).view(G, len(rows)), rows
         if compute_loss:
             # equal row counts per group: the mean over all G*n rows == mean of the per-group means (pretrain.py:473-479)
-            return ops.decoder_xent(h, P["multimodal_encoder.embeddings.word_embeddings.weight"], P["cls.decoder.bias"], labels)
+            return ops.decoder_xent(h, P["multimodal_encoder.embeddings.word_embeddings.weight"], P["cls.decoder.bias"], labels,
+                                    smoothing=self._smoothing)
         scores = ops.decoder_logits(h, P["multimodal_encoder.embeddings.word_embeddings.weight"], P["cls.decoder.bias"])
         for gi, g in enumerate(groups):
             out[f"{tag}_scores_{g}"] = scores[gi * n:(gi + 1) * n]
@@ -796,7 +799,7 @@ class VALOR(nn.Module):
         rows = ops.gather_rows(X, self._dev(torch.cat(idxs)))
         h = self.cls_transform(rows)
         losses = ops.decoder_xent_segments(h, P["multimodal_encoder.embeddings.word_embeddings.weight"], P["cls.decoder.bias"],
-                                           self._dev(torch.cat(labs)), seg_rows)
+                                           self._dev(torch.cat(labs)), seg_rows, smoothing=self._smoothing)
         res = {}
         for (tag, *_), l in zip(passes, losses):
             res.setdefault(tag, []).append(l)
@@ -843,7 +846,11 @@ class VALOR(nn.Module):
         generate_cap :914-985 -> valor_amd.decode (greedy for beam_size 1, beam search above)."""
         groups = task.split("%")[1:]
         if compute_loss:
-            return self._forward_groups(batch, [], groups, [], True)
+            self._smoothing = self.label_smoothing
+            try:
+                return self._forward_groups(batch, [], groups, [], True)
+            finally:
+                self._smoothing = 0.0
         if self.caption_type != "unimlm":
             raise NotImplementedError("generation with caption_type='lm' (model/pretrain.py:1033-1041) is not built; the loss paths are")
         from .. import decode

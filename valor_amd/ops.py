@@ -574,14 +574,15 @@ class DecoderXentSegFn(Function):
     loss per segment (caption / mlm passes share the prediction head, modeling.py:245-254, pretrain.py:444,498)."""
 
     @staticmethod
-    def forward(ctx, h, w_emb, dec_bias, labels, seg_rows):
+    def forward(ctx, h, w_emb, dec_bias, labels, seg_rows, smoothing=0.0):
         n, V = h.shape[0], w_emb.shape[0]
         Vpad = (V + 31) // 32 * 32
         buf = _rows_with_slack(n, Vpad, h.dtype, h.device)
         K.gemm(h, w_emb, bias=dec_bias, out=buf[:, :V])
         loss_rows = torch.empty(n, dtype=torch.float32, device=h.device)
         lse = torch.empty(n, dtype=torch.float32, device=h.device)
-        lib.call("valor_xent_fwd", _st(), _dt(h), _p(buf), _p(labels), _p(loss_rows), _p(lse), n, V, Vpad)
+        ctx.smoothing = float(smoothing)          # LabelSmoothing (pretrain.py:46-61): the caption finetune loss with config.label_smoothing > 0
+        lib.call("valor_xent_smooth_fwd", _st(), _dt(h), _p(buf), _p(labels), _p(loss_rows), _p(lse), n, V, Vpad, ctx.smoothing)
         losses, r0 = [], 0
         for nr in seg_rows:
             l = torch.empty((), dtype=torch.float32, device=h.device)
@@ -599,8 +600,8 @@ class DecoderXentSegFn(Function):
         r0 = 0
         for nr, dl in zip(ctx.seg_rows, dlosses):
             g = dl.to(torch.float32).contiguous() if dl is not None else torch.zeros((), dtype=torch.float32, device=h.device)
-            lib.call("valor_xent_bwd", _st(), _dt(h), _p(buf[r0:r0 + nr]), _p(labels[r0:r0 + nr]), _p(lse[r0:r0 + nr]), _p(g), 1.0 / nr,
-                     nr, V, Vpad)
+            lib.call("valor_xent_smooth_bwd", _st(), _dt(h), _p(buf[r0:r0 + nr]), _p(labels[r0:r0 + nr]), _p(lse[r0:r0 + nr]), _p(g), 1.0 / nr,
+                     nr, V, Vpad, ctx.smoothing)
             r0 += nr
         dlog = buf[:, :V]
         dh = K.gemm(dlog, w_emb, trans_b=True)
@@ -614,11 +615,11 @@ class DecoderXentSegFn(Function):
             K.colsum(dlog, out=sb, accumulate=True); _sunk(pb); db = None
         else:
             db = K.colsum(dlog)
-        return dh, dw, db, None, None
+        return dh, dw, db, None, None, None
 
 
-def decoder_xent_segments(h, w_emb, dec_bias, labels, seg_rows):
-    return DecoderXentSegFn.apply(h, w_emb, dec_bias, labels, seg_rows)
+def decoder_xent_segments(h, w_emb, dec_bias, labels, seg_rows, smoothing=0.0):
+    return DecoderXentSegFn.apply(h, w_emb, dec_bias, labels, seg_rows, smoothing)
 
 
 # ------------------------------------------------------------------------------------------------
@@ -628,7 +629,8 @@ class DecoderXentFn(Function):
     backward overwrites in place with d(logits)."""
 
     @staticmethod
-    def forward(ctx, h, w_emb, dec_bias, labels, want_logits):
+    def forward(ctx, h, w_emb, dec_bias, labels, want_logits, smoothing=0.0):
+        ctx.smoothing = float(smoothing)
         n, V = h.shape[0], w_emb.shape[0]
         Vpad = (V + 31) // 32 * 32
         buf = _rows_with_slack(n, Vpad, h.dtype, h.device)
@@ -636,7 +638,7 @@ class DecoderXentFn(Function):
         K.gemm(h, w_emb, bias=dec_bias, out=logits)
         loss_rows = torch.empty(n, dtype=torch.float32, device=h.device)
         lse = torch.empty(n, dtype=torch.float32, device=h.device)
-        lib.call("valor_xent_fwd", _st(), _dt(h), _p(buf), _p(labels), _p(loss_rows), _p(lse), n, V, Vpad)
+        lib.call("valor_xent_smooth_fwd", _st(), _dt(h), _p(buf), _p(labels), _p(loss_rows), _p(lse), n, V, Vpad, ctx.smoothing)
         loss = torch.empty((), dtype=torch.float32, device=h.device)
         lib.call("valor_mean_f32", _st(), _p(loss_rows), n, _p(loss))
         ctx.save_for_backward(h, w_emb, labels, lse, buf)
@@ -652,7 +654,7 @@ class DecoderXentFn(Function):
         h, w_emb, labels, lse, buf = ctx.saved_tensors
         n, V, Vpad = h.shape[0], ctx.V, buf.shape[1]
         g = dloss.to(torch.float32).contiguous()
-        lib.call("valor_xent_bwd", _st(), _dt(h), _p(buf), _p(labels), _p(lse), _p(g), 1.0 / n, n, V, Vpad)
+        lib.call("valor_xent_smooth_bwd", _st(), _dt(h), _p(buf), _p(labels), _p(lse), _p(g), 1.0 / n, n, V, Vpad, ctx.smoothing)
         dlog = buf[:, :V]
         dh = K.gemm(dlog, w_emb, trans_b=True)
         pw, pb = ctx.params
@@ -665,11 +667,11 @@ class DecoderXentFn(Function):
             K.colsum(dlog, out=sb, accumulate=True); _sunk(pb); db = None
         else:
             db = K.colsum(dlog)
-        return dh, dw, db, None, None
+        return dh, dw, db, None, None, None
 
 
-def decoder_xent(h, w_emb, dec_bias, labels, want_logits=False):
-    return DecoderXentFn.apply(h, w_emb, dec_bias, labels, want_logits)
+def decoder_xent(h, w_emb, dec_bias, labels, want_logits=False, smoothing=0.0):
+    return DecoderXentFn.apply(h, w_emb, dec_bias, labels, want_logits, smoothing)
 
 
 def decoder_logits(h, w_emb, dec_bias):
