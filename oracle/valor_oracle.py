@@ -39,9 +39,10 @@ def dropout(x, p, training=True):
 
 class Oracle:
     def __init__(self, spec, sd, *, dropout_p=0.0, use_task_prompt=False, contra_loss_ratio=1.0, vocab_tokens=None,
-                 masker_range=(106, None), drop_path=0.0, caption_type="unimlm", label_smoothing=0.0):
+                 masker_range=(106, None), drop_path=0.0, caption_type="unimlm", label_smoothing=0.0, full_masker=False):
         assert caption_type in ("unimlm", "lm")
         self.caption_type = caption_type
+        self.full_masker = full_masker              # model/pretrain.py:79 (caption_type 'unimlm' only)
         self.label_smoothing = label_smoothing      # model/pretrain.py:72-74: the caption finetune loss only (:839-840)
         self.spec = spec
         self.sd = sd
@@ -266,12 +267,16 @@ class Oracle:
         return x.reshape(b, n, -1, x.shape[-1])
 
     # ------------------------------------------------------------------------- BERT decoder
-    def bert_embeddings(self, ids, token_type):
-        """BertEmbeddings.forward, model/bert.py:190-218"""
+    def bert_embeddings(self, ids, token_type, full_masker=False):
+        """BertEmbeddings.forward, model/bert.py:190-218 (full_masker :197-201: the second half of the row -- the [MASK] copies -- sits at
+        positions 1 .. L/2, i.e. one past the token each of them has to predict)"""
         w = self.w
         e = "multimodal_encoder.embeddings."
         L = ids.shape[1]
-        x = w(e + "word_embeddings.weight")[ids] + w(e + "position_embeddings.weight")[:L][None]
+        pos = torch.arange(L)
+        if full_masker and token_type is None:
+            pos[L // 2:] = pos[:L // 2] + 1
+        x = w(e + "word_embeddings.weight")[ids] + w(e + "position_embeddings.weight")[pos][None]
         if token_type == "prompt":
             x = x + w(e + "prompt_embedding.weight")[0]
         else:
@@ -296,10 +301,10 @@ class Oracle:
         h = dropout(F.linear(ctx, w(p + out + "dense.weight"), w(p + out + "dense.bias")), self.p)
         return layer_norm(h + x, w(p + out + "LayerNorm.weight"), w(p + out + "LayerNorm.bias"), 1e-12)
 
-    def bert_model(self, tokens, task_prompt, video_feat, audio_feat, casual):
+    def bert_model(self, tokens, task_prompt, video_feat, audio_feat, casual, full_masker=False):
         """BertModel.forward, has_cross_attn branch, model/bert.py:848-896 ; BertLayer :440-496 (va_concate)"""
         w, sp = self.w, self.spec
-        x = self.bert_embeddings(tokens, None)
+        x = self.bert_embeddings(tokens, None, full_masker)
         token_len = x.shape[1]
         am = (tokens != 0).long()
         if task_prompt is not None:
@@ -307,7 +312,14 @@ class Oracle:
             am = torch.cat((am, (task_prompt != 0).long()), dim=1)
         total = am.shape[1]
         am = am.unsqueeze(1).expand(-1, total, -1).clone()
-        if casual:
+        if casual and full_masker:                                                               # bert.py:872-878
+            n = token_len // 2
+            am[:, :n, :n] = torch.tril(am[:, :n, :n])
+            am[:, :n, n:token_len] = 0
+            am[:, n:token_len, :n] = torch.tril(am[:, n:token_len, :n])
+            am[:, n:token_len, n:token_len] = torch.eye(n, dtype=am.dtype)
+            am[:, token_len:, :token_len] = 0
+        elif casual:
             am[:, :token_len, :token_len] = torch.tril(am[:, :token_len, :token_len])
             am[:, token_len:, :token_len] = 0
         am = ((1.0 - am.unsqueeze(1).float()) * -10000.0)
@@ -339,6 +351,13 @@ class Oracle:
         """inputs and labels of the caption passes, model/pretrain.py:424-433 (= :807-816 in forward_cap_single): 'unimlm' masks 60 % of the
         tokens and predicts them; 'lm' feeds the tokens as they are and predicts the NEXT token at every position (label 0 = padding and
         the last position -> ignored)"""
+        if self.caption_type == "unimlm" and self.full_masker:                                   # full_mask, model/pretrain.py:137-142
+            n = txt.shape[1]
+            tokens = torch.cat((txt, torch.full_like(txt, self.mask_token)), dim=1)
+            labels = -torch.ones_like(tokens)
+            nz = txt[:, 1:n] != 0
+            labels[:, n:2 * n - 1][nz] = txt[:, 1:n][nz]
+            return tokens, labels
         if self.caption_type == "unimlm":
             return self.text_masker(txt, mask_prob)
         labels = torch.zeros_like(txt)
@@ -555,6 +574,8 @@ class Oracle:
             return None
 
         if caption_task:                                                                         # pretrain.py:419-481
+            if self.full_masker:      # the reference slices the 'tv' / 'ta' outputs with the original length against the doubled labels (:454): IndexError
+                raise NotImplementedError("full_masker with a pretraining caption task fails in the reference (model/pretrain.py:454)")
             txt_input, txt_labels = self.caption_inputs(txt)
             col["caption_txt_input"], col["caption_txt_labels"] = txt_input, txt_labels
             lo = []
@@ -625,7 +646,8 @@ class Oracle:
             for g in ("tva", "tv", "ta"):
                 if g in groups:
                     prompt = self.get_task_prompt("describe the video with natural language", bs) if self.use_task_prompt else None
-                    o = self.bert_model(txt_input, prompt, video_input if "v" in g else None, audio_input if "a" in g else None, True)
+                    o = self.bert_model(txt_input, prompt, video_input if "v" in g else None, audio_input if "a" in g else None, True,
+                                        self.full_masker)                                        # :835,847,859
                     scores = self.cls_head(o[:, :txt_input.shape[1]][txt_labels != -1])
                     if self.label_smoothing > 0:          # LabelSmoothing, model/pretrain.py:46-61: KL(smoothed target || softmax), summed over the vocabulary, mean over rows
                         logp = F.log_softmax(scores, dim=-1)
@@ -635,8 +657,8 @@ class Oracle:
                     else:
                         lo.append(F.cross_entropy(scores, txt_labels[txt_labels != -1]))
             return {"caption_loss": sum(lo) / len(lo)}
-        if self.caption_type != "unimlm":
-            raise NotImplementedError("generation with caption_type='lm' (pretrain.py:1033-1041) is not restated")
+        if self.caption_type != "unimlm" or self.full_masker:
+            raise NotImplementedError("generation with caption_type='lm' (pretrain.py:1033-1041) / full_masker is not restated")
         ev = {}                                                                                  # generate_cap :914-985
         for g, key in (("tv", "t_v"), ("tva", "t_va"), ("ta", "t_a")):
             if g in groups:
@@ -687,13 +709,16 @@ class Oracle:
             lo = []
             for g in ("tva", "tv", "ta"):
                 if g in groups:
-                    o = self.bert_model(txt_input, prompt, video_input if "v" in g else None, audio_input if "a" in g else None, True)
+                    o = self.bert_model(txt_input, prompt, video_input if "v" in g else None, audio_input if "a" in g else None, True,
+                                        self.full_masker)                                        # :1276,1300,1324
                     scores = self.cls_head(o[:, :txt_input.shape[1]])
                     b, n, c = scores.shape
                     loss = F.cross_entropy(scores.reshape(b * n, c), txt_labels.reshape(b * n), ignore_index=-1, reduction="none").reshape(b, n)
                     loss = loss.sum(dim=-1) / (txt_labels != -1).sum(dim=-1)
                     lo.append((loss * torch.as_tensor(batch["answer_weights"], dtype=loss.dtype)).sum() / len(nums) if tile else loss.mean())
             return {"qa_loss": sum(lo) / len(lo)}
+        if self.caption_type != "unimlm" or self.full_masker:
+            raise NotImplementedError("generation with caption_type='lm' / full_masker is not restated")
         ev = {}                                                                                  # generate_qa :1366-1459
         for g, key in (("tv", "t_v"), ("tva", "t_va"), ("ta", "t_a")):
             if g in groups:

@@ -258,3 +258,41 @@ def test_caption_finetune_with_label_smoothing_matches_oracle(dev):
         random.seed(3); op = plain.forward_pt(batch, task, compute_loss=True)
         random.seed(3); np_ = model(batch, task=task, compute_loss=True)
     assert abs(float(op["caption_loss"]) - float(np_["caption_loss"])) <= 1e-4 * abs(float(op["caption_loss"]))
+
+
+def test_full_masker_finetune_losses_match_oracle(dev):
+    """config.full_masker (model/pretrain.py:79,137-142; bert.py:197-201,872-878; the oracle's branch is pinned on the unmodified reference):
+    'cap%tva%tv' loss with every gradient (incl. the position table, looked up at i + 1 for the [MASK] half) and the 'qa%tva%tv' loss of the
+    HIP path in fp32; the pretraining task string is refused like the reference's IndexError."""
+    from valor_amd import synth
+    import valor_oracle as VO
+    from test_model_gpu import _native_grads
+    spec = synth.tiny_spec()
+    sd = synth.make_state_dict(spec, seed=3, w_std=0.05)
+    batch = synth.make_batch(spec, batch=3, frames=2, audio_slices=1, txt_len=16, seed=5)
+    sd_o = VO.trainable_copy(sd)
+    orc = VO.Oracle(spec, sd_o, vocab_tokens=synth.synthetic_vocab(spec.vocab), full_masker=True)
+    model = _build(spec, sd, torch.float32, dev, full_masker=True)
+    random.seed(2); o = orc.forward(batch, "cap%tva%tv", compute_loss=True); o["caption_loss"].backward()
+    random.seed(2); n = model(batch, task="cap%tva%tv", compute_loss=True); n["caption_loss"].backward()
+    assert abs(float(o["caption_loss"]) - float(n["caption_loss"])) <= 1e-4 * abs(float(o["caption_loss"])), (float(o["caption_loss"]), float(n["caption_loss"]))
+    ng = _native_grads(model)
+    bad = []
+    for k, p in sd_o.items():
+        if VO.is_alias_key(k) or not p.is_floating_point() or p.grad is None:
+            continue
+        go, gn = p.grad, ng[k].detach().cpu()
+        scale = max(float(go.norm()), 1e-5 * go.numel() ** 0.5)
+        if float((gn.reshape(go.shape) - go).norm()) / scale > 2e-3:
+            bad.append(k)
+    assert not bad, bad[:8]
+    model.zero_grad()
+    qb = synth.make_batch(spec, batch=3, frames=2, audio_slices=1, txt_len=10, seed=7, questions=True)
+    with torch.no_grad():
+        oq = orc.forward(qb, "qa%tva%tv", compute_loss=True)
+        nq = model(qb, task="qa%tva%tv", compute_loss=True)
+    assert abs(float(oq["qa_loss"]) - float(nq["qa_loss"])) <= 1e-4 * abs(float(oq["qa_loss"])), (float(oq["qa_loss"]), float(nq["qa_loss"]))
+    with pytest.raises(NotImplementedError):
+        model(batch, task="pt_caption%tva%tv", compute_loss=True)
+    with pytest.raises(NotImplementedError):
+        model(batch, task="cap%tva", compute_loss=False)

@@ -458,3 +458,41 @@ def test_label_smoothing_of_the_caption_finetune_loss():
         assert float((g - p.grad).norm()) / scale < 2e-4, name
         n += 1
     assert n > 300
+
+
+def test_full_masker_matches_reference():
+    """config.full_masker (model/pretrain.py:79,137-142; bert.py:197-201,872-878): caption rows = [tokens | as many [MASK]s], [MASK] i at
+    position i + 1 predicting token i + 1 under the block attention mask. forward_cap_single and forward_qa_single pass the flag to the
+    decoder; forward_pt with it raises an IndexError in the reference (:454: 'tv' outputs sliced with the original length against doubled
+    labels) and is refused here. Caption and QA finetune losses and every gradient of the caption loss, against the unmodified reference."""
+    from valor_amd import synth
+    from valor_oracle import Oracle, trainable_copy
+    spec, ropts = synth.base_spec(), ref_harness.default_opts(full_masker=True)
+    sd = synth.make_state_dict(spec, seed=21)
+    ref = ref_harness.build_reference(ropts, state_dict=None, dropout=0.0)
+    missing, unexpected = ref.load_state_dict(sd, strict=False)
+    assert not missing and not unexpected
+    sd_o = trainable_copy(sd)
+    orc = Oracle(spec, sd_o, vocab_tokens=synth.synthetic_vocab(spec.vocab), full_masker=True)
+    batch = synth.make_batch(spec, batch=2, frames=1, audio_slices=1, txt_len=16, seed=22)
+    random.seed(9); r = ref(dict(batch), task="cap%tva%tv", compute_loss=True); r["caption_loss"].backward()
+    random.seed(9); o = orc.forward(batch, "cap%tva%tv", compute_loss=True); o["caption_loss"].backward()
+    assert abs(float(r["caption_loss"]) - float(o["caption_loss"])) <= 2e-5 * abs(float(r["caption_loss"])), (float(r["caption_loss"]), float(o["caption_loss"]))
+    n = 0
+    for name, p in ref.named_parameters():
+        if p.grad is None:
+            continue
+        g = sd_o[name].grad
+        scale = max(float(p.grad.norm()), 1e-4 * p.grad.numel() ** 0.5)
+        assert float((g - p.grad).norm()) / scale < 2e-4, name
+        n += 1
+    assert n > 300
+    with torch.no_grad():
+        with pytest.raises(IndexError):          # forward_pt + full_masker: the reference slices 'tv' outputs with the original length (:454)
+            ref(batch, task=TASK, compute_loss=True)
+        with pytest.raises(NotImplementedError):
+            orc.forward_pt(batch, TASK, compute_loss=True)
+        qb = synth.make_batch(spec, batch=2, frames=1, audio_slices=1, txt_len=8, seed=23, questions=True)
+        rq = ref({k: (dict(v) if isinstance(v, dict) else v) for k, v in qb.items()}, task="qa%tva%tv", compute_loss=True)
+        oq = orc.forward(qb, "qa%tva%tv", compute_loss=True)
+        assert abs(float(rq["qa_loss"]) - float(oq["qa_loss"])) <= 2e-5 * abs(float(rq["qa_loss"])), (float(rq["qa_loss"]), float(oq["qa_loss"]))

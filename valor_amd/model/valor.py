@@ -134,8 +134,11 @@ class VALOR(nn.Module):
         self.caption_type = _opt(opts, "caption_type", "unimlm")        # pretrain.py:76; 'lm': loss paths only (generation raises)
         self.label_smoothing = float(_opt(opts, "label_smoothing", 0.0))    # pretrain.py:72-74: the caption FINETUNE loss only (:839-840)
         self._smoothing = 0.0                                            # label smoothing of the decoder passes being issued
-        if _opt(opts, "cross_attn_type", "va_concate") != "va_concate" or _opt(opts, "late_fusion", False) or _opt(opts, "full_masker", False):
-            raise NotImplementedError("cross_attn_type='va_concate', late_fusion=False, full_masker=False only")
+        if _opt(opts, "cross_attn_type", "va_concate") != "va_concate" or _opt(opts, "late_fusion", False):
+            raise NotImplementedError("cross_attn_type='va_concate', late_fusion=False only")
+        # pretrain.py:79: the caption rows become [tokens | as many [MASK]s], position L/2 + i predicts token i + 1 (loss paths; generation raises)
+        self.full_masker = bool(_opt(opts, "full_masker", False)) and _opt(opts, "caption_type", "unimlm") == "unimlm"
+        self._full_attn = False           # full_masker attention / positions for the decoder passes being issued (forward_cap / forward_qa)
         if _opt(opts, "fineweight_type", "one") == "none":
             raise NotImplementedError("fineweight_type='none' is a TypeError in the reference too (pretrain.py:330)")
         self.spec = spec
@@ -309,7 +312,7 @@ class VALOR(nn.Module):
         return torch.tensor(ids, dtype=torch.long).unsqueeze(0).expand(batch_size, -1).contiguous()
 
     @staticmethod
-    def _bert_mask(tokens_cpu, prompt_cpu, casual):
+    def _bert_mask(tokens_cpu, prompt_cpu, casual, full_masker=False):
         """additive attention mask of BertModel.forward, bert.py:854-885 -> fp32 [B, T, T].
         numpy on purpose: these are tiny tensors and a torch CPU op would wake the whole intra-op thread pool."""
         am = (tokens_cpu.numpy() != 0).astype(np.int64)
@@ -318,7 +321,14 @@ class VALOR(nn.Module):
             am = np.concatenate((am, (prompt_cpu.numpy() != 0).astype(np.int64)), axis=1)
         total = am.shape[1]
         am = np.repeat(am[:, None, :], total, axis=1)
-        if casual:
+        if casual and full_masker:                                   # bert.py:872-878
+            n = token_len // 2
+            am[:, :n, :n] = np.tril(am[:, :n, :n])
+            am[:, :n, n:token_len] = 0
+            am[:, n:token_len, :n] = np.tril(am[:, n:token_len, :n])
+            am[:, n:token_len, n:token_len] = np.eye(n, dtype=am.dtype)
+            am[:, token_len:, :token_len] = 0
+        elif casual:
             am[:, :token_len, :token_len] = np.tril(am[:, :token_len, :token_len])
             am[:, token_len:, :token_len] = 0
         return torch.from_numpy(((1.0 - am.astype(np.float32)) * -10000.0).astype(np.float32))
@@ -572,11 +582,20 @@ class VALOR(nn.Module):
         return y.view(b, n, sp.aud_tokens, sp.aud_width)
 
     # ------------------------------------------------------------------ multimodal decoder
-    def _bert_embed(self, ids_dev, L, token_type):
-        """BertEmbeddings.forward bert.py:190-218: word + position + (token_type[0] | prompt) -> LN -> dropout"""
+    def _bert_embed(self, ids_dev, L, token_type, full_masker=False):
+        """BertEmbeddings.forward bert.py:190-218: word + position + (token_type[0] | prompt) -> LN -> dropout.
+        full_masker (:197-201): the second half of the row sits at positions 1 .. L/2 -- two lookups, the second one into the position
+        table from its row 1 on."""
         P, e = self.P, "multimodal_encoder.embeddings."
         tv = P[e + "prompt_embedding.weight"][0] if token_type == "prompt" else P[e + "token_type_embeddings.weight"][0]
-        x = ops.embed(ids_dev, P[e + "word_embeddings.weight"], P[e + "position_embeddings.weight"], tv, L)
+        if full_masker and token_type is None:
+            n = L // 2
+            ids2 = ids_dev.view(-1, L)
+            xa = ops.embed(ids2[:, :n].contiguous(), P[e + "word_embeddings.weight"], P[e + "position_embeddings.weight"], tv, n)
+            xb = ops.embed(ids2[:, n:].contiguous(), P[e + "word_embeddings.weight"], P[e + "position_embeddings.weight"][1:], tv, n)
+            x = torch.cat((xa.view(ids2.shape[0], n, -1), xb.view(ids2.shape[0], n, -1)), dim=1)
+        else:
+            x = ops.embed(ids_dev, P[e + "word_embeddings.weight"], P[e + "position_embeddings.weight"], tv, L)
         x = ops.layer_norm(x, P[e + "LayerNorm.weight"], P[e + "LayerNorm.bias"], 1e-12)
         p = self.p_drop if self.training else 0.0
         if p > 0:
@@ -706,12 +725,12 @@ class VALOR(nn.Module):
         """Run the decoder for len(groups) query groups as ONE batch (same text input, different K/V rows)."""
         G, T = len(groups), txt_input.shape[1]
         ids = self._dev(txt_input)
-        x = self._bert_embed(ids, T, None)
+        x = self._bert_embed(ids, T, None, self._full_attn and casual)
         if prompt_cpu is not None:
             xp = self._bert_embed(self._dev(prompt_cpu), prompt_cpu.shape[1], "prompt")
             x = torch.cat((x, xp), dim=1)
         Ttot = x.shape[1]
-        mask = self._dev(self._bert_mask(txt_input, prompt_cpu, casual))
+        mask = self._dev(self._bert_mask(txt_input, prompt_cpu, casual, self._full_attn and casual))
         if G > 1:
             x = x.repeat(G, 1, 1)
             mask = mask.repeat(G, 1, 1)
@@ -754,11 +773,11 @@ class VALOR(nn.Module):
         xs, ssegs, xsegs, idxs, labs, seg_rows, r0 = [], [], [], [], [], [], 0
         for (tag, txt_input, txt_labels, groups, prompt_cpu, casual) in passes:
             G, T = len(groups), txt_input.shape[1]
-            x = self._bert_embed(self._dev(txt_input), T, None)
+            x = self._bert_embed(self._dev(txt_input), T, None, self._full_attn and casual)
             if prompt_cpu is not None:
                 x = torch.cat((x, self._bert_embed(self._dev(prompt_cpu), prompt_cpu.shape[1], "prompt")), dim=1)
             Ttot = x.shape[1]
-            mask = self._dev(self._bert_mask(txt_input, prompt_cpu, casual))
+            mask = self._dev(self._bert_mask(txt_input, prompt_cpu, casual, self._full_attn and casual))
             if G > 1:
                 x = x.repeat(G, 1, 1)
                 mask = mask.repeat(G, 1, 1)
@@ -846,13 +865,13 @@ class VALOR(nn.Module):
         generate_cap :914-985 -> valor_amd.decode (greedy for beam_size 1, beam search above)."""
         groups = task.split("%")[1:]
         if compute_loss:
-            self._smoothing = self.label_smoothing
+            self._smoothing, self._full_attn = self.label_smoothing, self.full_masker      # pretrain.py:835-860: forward_cap_single passes full_masker
             try:
                 return self._forward_groups(batch, [], groups, [], True)
             finally:
-                self._smoothing = 0.0
-        if self.caption_type != "unimlm":
-            raise NotImplementedError("generation with caption_type='lm' (model/pretrain.py:1033-1041) is not built; the loss paths are")
+                self._smoothing, self._full_attn = 0.0, False
+        if self.caption_type != "unimlm" or self.full_masker:
+            raise NotImplementedError("generation with caption_type='lm' (model/pretrain.py:1033-1041) / full_masker is not built; the loss paths are")
         from .. import decode
         return decode.generate_cap(self, batch, groups)
 
@@ -873,8 +892,8 @@ class VALOR(nn.Module):
         groups = [g for g in ("tva", "tv", "ta") if g in task.split("%")[1:]]
         prompt = self.qa_prompt(batch["question_tokens"]["bert_tokens"].cpu())
         if not compute_loss:
-            if self.caption_type != "unimlm":
-                raise NotImplementedError("generation with caption_type='lm' is not built; the loss paths are")
+            if self.caption_type != "unimlm" or self.full_masker:
+                raise NotImplementedError("generation with caption_type='lm' / full_masker is not built; the loss paths are")
             from .. import decode
             return decode.generate_qa(self, batch, groups, prompt)
         self.stage.begin_step()
@@ -899,7 +918,11 @@ class VALOR(nn.Module):
         video_output = self.forward_video_encoder(batch["video_pixels"]) if "v" in alltasks else None
         audio_output = self.forward_audio_encoder(batch["audio_spectrograms"]) if "a" in alltasks else None
         kv_layers, ranges = self.cross_inputs(video_output, audio_output)
-        L, rows = self._decoder_groups(qa_in, qa_lab, groups, prompt, True, kv_layers, ranges, qa_in.shape[0], True, "qa", {}, per_sample=True, kv_b=b)
+        self._full_attn = self.full_masker                           # pretrain.py:1276,1300,1324: forward_qa_single passes full_masker
+        try:
+            L, rows = self._decoder_groups(qa_in, qa_lab, groups, prompt, True, kv_layers, ranges, qa_in.shape[0], True, "qa", {}, per_sample=True, kv_b=b)
+        finally:
+            self._full_attn = False
         if weights is None:
             return {"qa_loss": L.mean()}                            # mean over samples, mean over groups (:1290,1338-1343)
         return {"qa_loss": ((L * self._dev(weights)).sum(dim=1) / b).mean()}      # weighted rows summed over the QUESTION count (:1288-1289)
@@ -919,6 +942,13 @@ class VALOR(nn.Module):
     def caption_inputs(self, txt, mask_prob=0.6):
         """inputs / labels of the caption passes (model/pretrain.py:424-433, :807-816; the answer rows of QA at 0.99, :1225-1234): caption_type 'unimlm' = TokenMasker; 'lm' =
         the tokens as they are, label = the NEXT token (0 = padding and the last position: ignored, -1)"""
+        if self.caption_type == "unimlm" and self.full_masker:          # full_mask, pretrain.py:137-142
+            n = txt.shape[1]
+            tokens = torch.cat((txt, torch.full_like(txt, self.text_mask_token)), dim=1)
+            labels = -torch.ones_like(tokens)
+            nz = txt[:, 1:n] != 0
+            labels[:, n:2 * n - 1][nz] = txt[:, 1:n][nz]
+            return tokens, labels
         if self.caption_type == "unimlm":
             return self.text_masker(txt, mask_prob)
         labels = torch.zeros_like(txt)
@@ -939,6 +969,10 @@ class VALOR(nn.Module):
         # pretrain.py:428, then mlm :488; nothing else on this path does). Done before any kernel of this step is queued,
         # its Python loops overlap the GPU's tail of the previous step instead of draining the pipeline mid-forward.
         cap_in = cap_lab = mlm_in = mlm_lab = None
+        if caption_task and self.full_masker and not self._full_attn:
+            # forward_pt builds the doubled rows (pretrain.py:425-426) but slices the 'tv' / 'ta' outputs with the ORIGINAL length against the
+            # doubled labels (:454, :466): an IndexError in the reference. Only the finetune paths (forward_cap / forward_qa) work with it.
+            raise NotImplementedError("full_masker with a pretraining caption task fails in the reference too (model/pretrain.py:454); use it with 'cap%..' / 'qa%..'")
         if caption_task or mlm_task:
             txt = txt_tokens["bert_tokens"].cpu()
             if caption_task:
