@@ -657,8 +657,6 @@ class Oracle:
                     else:
                         lo.append(F.cross_entropy(scores, txt_labels[txt_labels != -1]))
             return {"caption_loss": sum(lo) / len(lo)}
-        if self.caption_type != "unimlm" or self.full_masker:
-            raise NotImplementedError("generation with caption_type='lm' (pretrain.py:1033-1041) / full_masker is not restated")
         ev = {}                                                                                  # generate_cap :914-985
         for g, key in (("tv", "t_v"), ("tva", "t_va"), ("ta", "t_a")):
             if g in groups:
@@ -717,8 +715,6 @@ class Oracle:
                     loss = loss.sum(dim=-1) / (txt_labels != -1).sum(dim=-1)
                     lo.append((loss * torch.as_tensor(batch["answer_weights"], dtype=loss.dtype)).sum() / len(nums) if tile else loss.mean())
             return {"qa_loss": sum(lo) / len(lo)}
-        if self.caption_type != "unimlm" or self.full_masker:
-            raise NotImplementedError("generation with caption_type='lm' / full_masker is not restated")
         ev = {}                                                                                  # generate_qa :1366-1459
         for g, key in (("tv", "t_v"), ("tva", "t_va"), ("ta", "t_a")):
             if g in groups:
@@ -736,7 +732,10 @@ class Oracle:
         [CLS] + generated tokens + [MASK] from scratch every step (multimodal_use_cross_attn: no cache), logits of the last text position."""
         mask_col = torch.full((rows, 1), self.MASK, dtype=torch.long)
         bos = torch.full((rows, 1), self.BOS, dtype=torch.long)
-        txt = torch.cat((bos, state, mask_col), dim=1) if state is not None else torch.cat((bos, mask_col), dim=1)
+        if self.caption_type == "lm":                                                            # :1038-1040: no [MASK], the last token's logits
+            txt = torch.cat((bos, state), dim=1) if state is not None else bos
+        else:
+            txt = torch.cat((bos, state, mask_col), dim=1) if state is not None else torch.cat((bos, mask_col), dim=1)
         o = self.bert_model(txt, prompt, vi, ai, True)[:, :txt.shape[1]]
         logits = self.cls_head(o[:, -1])
         if trace is not None:

@@ -464,7 +464,7 @@ def test_prefetch_loader_delivers_the_same_batches(dev):
 def test_caption_type_lm_matches_oracle(dev):
     """caption_type='lm' (model/pretrain.py:429-433, :812-816): unmasked tokens, next-token labels under the causal mask. The oracle's branch
     is pinned on the unmodified reference (tests/test_oracle_vs_reference.py::test_caption_type_lm_matches_reference); here the HIP path in
-    fp32 against it: the three losses, every gradient, and the caption-finetune loss ('cap%tva%tv'). Generation is refused."""
+    fp32 against it: the three losses, every gradient, the caption-finetune loss ('cap%tva%tv') and generated sequences."""
     from valor_amd import synth
     import valor_oracle as VO
     spec = synth.tiny_spec()
@@ -492,5 +492,12 @@ def test_caption_type_lm_matches_oracle(dev):
         oc = orc.forward(batch, "cap%tva%tv", compute_loss=True)
         nc = model(batch, task="cap%tva%tv", compute_loss=True)
     assert abs(float(oc["caption_loss"]) - float(nc["caption_loss"])) <= 1e-4 * abs(float(oc["caption_loss"]))
-    with pytest.raises(NotImplementedError):
-        model(batch, task="cap%tva%tv", compute_loss=False)
+    # generation with 'lm': [CLS] + the tokens so far, the last token's logits (pretrain.py:1038-1040) -- greedy and beam-3 sequences of the oracle
+    model.max_generation_len = 6
+    for beam in (1, 3):
+        model.beam_size = beam
+        with torch.no_grad():
+            og = orc.forward_cap(batch, "cap%tva%tv", compute_loss=False, beam_size=beam, max_generation_len=6)
+        ng = model(batch, task="cap%tva%tv", compute_loss=False)
+        for k in ("generated_sequences_t_va", "generated_sequences_t_v"):
+            assert torch.equal(og[k], ng[k].cpu()), (beam, k, og[k], ng[k])

@@ -496,3 +496,39 @@ def test_full_masker_matches_reference():
         rq = ref({k: (dict(v) if isinstance(v, dict) else v) for k, v in qb.items()}, task="qa%tva%tv", compute_loss=True)
         oq = orc.forward(qb, "qa%tva%tv", compute_loss=True)
         assert abs(float(rq["qa_loss"]) - float(oq["qa_loss"])) <= 2e-5 * abs(float(rq["qa_loss"])), (float(rq["qa_loss"]), float(oq["qa_loss"]))
+
+
+@pytest.mark.parametrize("opt", ["lm", "full_masker"])
+def test_generation_with_lm_and_full_masker(opt):
+    """generate_cap with caption_type='lm' ([CLS] + the tokens so far, the last token's logits: pretrain.py:1038-1040) and with full_masker
+    (the generation branch of forward_cap_single, :878-900, never sees the flag: same sequences as plain 'unimlm' decoding) -- greedy and
+    beam-3 sequences of the unmodified reference, token for token; video QA answers likewise."""
+    from valor_amd import synth
+    from valor_oracle import Oracle, trainable_copy
+    kw = dict(caption_type="lm") if opt == "lm" else dict(full_masker=True)
+    spec, ropts = synth.base_spec(), ref_harness.default_opts(**kw)
+    sd = synth.make_state_dict(spec, seed=50)
+    ref = ref_harness.build_reference(ropts, state_dict=sd, dropout=0.0)
+    orc = Oracle(spec, trainable_copy(sd), vocab_tokens=synth.synthetic_vocab(spec.vocab), **kw)
+    batch = synth.make_batch(spec, batch=2, frames=2, audio_slices=1, txt_len=8, seed=55, questions=True)
+    cp = lambda: {k: (dict(v) if isinstance(v, dict) else v) for k, v in batch.items()}
+    with torch.no_grad():
+        old = ref.beam_size, ref.max_generation_len
+        try:
+            ref.max_generation_len = 5
+            ref.beam_size = 1
+            rg = ref(cp(), task="cap%tva%ta", compute_loss=False)
+            og = orc.forward_cap(batch, "cap%tva%ta", compute_loss=False, beam_size=1, max_generation_len=5)
+            for k in ("generated_sequences_t_va", "generated_sequences_t_a"):
+                assert torch.equal(rg[k], og[k]), (k, rg[k], og[k])
+            ref.beam_size = 3
+            rb = ref(cp(), task="cap%tva%tv", compute_loss=False)
+            ob = orc.forward_cap(batch, "cap%tva%tv", compute_loss=False, beam_size=3, max_generation_len=5)
+            for k in ("generated_sequences_t_va", "generated_sequences_t_v"):
+                assert torch.equal(rb[k], ob[k]), (k, rb[k], ob[k])
+            rq = ref(cp(), task="qa%tva%tv", compute_loss=False)
+            oq = orc.forward_qa(batch, "qa%tva%tv", compute_loss=False, max_generation_len=5)
+            for k in ("generated_answers_t_va", "generated_answers_t_v"):
+                assert torch.equal(rq[k], oq[k]), (k, rq[k], oq[k])
+        finally:
+            ref.beam_size, ref.max_generation_len = old

@@ -31,12 +31,17 @@ class _Stepper:
         self.range = list(ranges[group]) if kv_layers is not None else None
 
     def logits(self, state, rows):
-        """state: host int64 [rows, t] in (sample, beam) order (None at t = 0) -> fp32 logits [rows, vocab] of the [MASK] position."""
+        """state: host int64 [rows, t] in (sample, beam) order (None at t = 0) -> fp32 logits [rows, vocab] of the last text position:
+        the appended [MASK] (caption_type 'unimlm') or the last token itself ('lm': [CLS] + the tokens so far, pretrain.py:1038-1040).
+        full_masker does not reach this path in the reference either (forward_cap_single's generation branch, :878-900, drops the flag)."""
         m, b = self.m, self.b
         beam = rows // b
         bos = torch.full((rows, 1), BOS, dtype=torch.long)
-        mask_col = torch.full((rows, 1), MASK, dtype=torch.long)
-        txt = torch.cat((bos, mask_col), dim=1) if state is None else torch.cat((bos, state, mask_col), dim=1)
+        if m.caption_type == "lm":
+            txt = bos if state is None else torch.cat((bos, state), dim=1)
+        else:
+            mask_col = torch.full((rows, 1), MASK, dtype=torch.long)
+            txt = torch.cat((bos, mask_col), dim=1) if state is None else torch.cat((bos, state, mask_col), dim=1)
         if beam > 1:                                                # (sample, beam) -> beam-major
             perm = torch.arange(rows).view(b, beam).t().reshape(-1)
             txt = txt[perm]

@@ -131,12 +131,13 @@ class VALOR(nn.Module):
             raise NotImplementedError("the reference loads CLIP as a whole: video/text encoders come as clip+clip, swin+bert or clip+bert")
         if _opt(opts, "contra_type", "fine") != "fine" or _opt(opts, "caption_type", "unimlm") not in ("unimlm", "lm"):
             raise NotImplementedError("contra_type='fine' and caption_type 'unimlm' / 'lm' only")
-        self.caption_type = _opt(opts, "caption_type", "unimlm")        # pretrain.py:76; 'lm': loss paths only (generation raises)
+        self.caption_type = _opt(opts, "caption_type", "unimlm")        # pretrain.py:76
         self.label_smoothing = float(_opt(opts, "label_smoothing", 0.0))    # pretrain.py:72-74: the caption FINETUNE loss only (:839-840)
         self._smoothing = 0.0                                            # label smoothing of the decoder passes being issued
         if _opt(opts, "cross_attn_type", "va_concate") != "va_concate" or _opt(opts, "late_fusion", False):
             raise NotImplementedError("cross_attn_type='va_concate', late_fusion=False only")
-        # pretrain.py:79: the caption rows become [tokens | as many [MASK]s], position L/2 + i predicts token i + 1 (loss paths; generation raises)
+        # pretrain.py:79: the caption rows become [tokens | as many [MASK]s], position L/2 + i predicts token i + 1 (the finetune losses; generation
+        # ignores the flag like the reference's, :878-900)
         self.full_masker = bool(_opt(opts, "full_masker", False)) and _opt(opts, "caption_type", "unimlm") == "unimlm"
         self._full_attn = False           # full_masker attention / positions for the decoder passes being issued (forward_cap / forward_qa)
         if _opt(opts, "fineweight_type", "one") == "none":
@@ -870,8 +871,6 @@ class VALOR(nn.Module):
                 return self._forward_groups(batch, [], groups, [], True)
             finally:
                 self._smoothing, self._full_attn = 0.0, False
-        if self.caption_type != "unimlm" or self.full_masker:
-            raise NotImplementedError("generation with caption_type='lm' (model/pretrain.py:1033-1041) / full_masker is not built; the loss paths are")
         from .. import decode
         return decode.generate_cap(self, batch, groups)
 
@@ -892,8 +891,6 @@ class VALOR(nn.Module):
         groups = [g for g in ("tva", "tv", "ta") if g in task.split("%")[1:]]
         prompt = self.qa_prompt(batch["question_tokens"]["bert_tokens"].cpu())
         if not compute_loss:
-            if self.caption_type != "unimlm" or self.full_masker:
-                raise NotImplementedError("generation with caption_type='lm' / full_masker is not built; the loss paths are")
             from .. import decode
             return decode.generate_qa(self, batch, groups, prompt)
         self.stage.begin_step()
