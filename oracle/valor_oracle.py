@@ -489,6 +489,18 @@ class Oracle:
                 txt_output = self.clip_text(txt_tokens_contra)
             col["txt_output"] = txt_output
 
+        coarse = self.spec.contra_type == "coarse"
+        if contra_task and coarse:
+            # contra_type 'coarse' (pool_*_for_contra, model/modeling.py:373-407): ONE vector per modality -- text: [CLS] (BERT) / the EOT row
+            # (CLIP: tokens.argmax); video: the frames' [CLS] rows (Swin: token means) averaged over the frames; audio likewise -- BEFORE the heads
+            if "t" in "".join(contra_task):
+                txt_output = txt_output[:, 0] if self.spec.txt_encoder == "bert" else \
+                    txt_output[torch.arange(txt_tokens_contra.shape[0]), txt_tokens_contra.argmax(dim=-1)]
+            if "v" in "".join(contra_task):
+                vo = video_output.mean(dim=2) if self.spec.video_encoder == "swin" else video_output[:, :, 0]
+                video_output_c = vo.mean(dim=1)
+            if "a" in "".join(contra_task):
+                audio_output_c = audio_output[:, :, 0].mean(dim=1)
         if contra_task:
             feat_t = feat_v = feat_a = None
             if "t" in "".join(contra_task):
@@ -499,7 +511,10 @@ class Oracle:
                 if compute_loss and gather:
                     feat_t = gather[0](feat_t); txt_tokens_contra = gather[1](txt_tokens_contra)
             if "v" in "".join(contra_task):
-                if self.spec.video_encoder == "swin":                                            # modeling.py:388-389 mean over tokens
+                if coarse:
+                    vp = video_output_c
+                    feat_v = F.normalize(vp @ w("clip_model.visual.proj") if self.spec.clip_heads else F.linear(vp, w("contra_head_v.linear.weight")), dim=-1)
+                elif self.spec.video_encoder == "swin":                                          # modeling.py:388-389 mean over tokens
                     feat_v = F.normalize(F.linear(video_output.mean(dim=2), w("contra_head_v.linear.weight")), dim=-1)
                 elif self.spec.clip_heads:
                     feat_v = F.normalize(video_output[:, :, 0] @ w("clip_model.visual.proj"), dim=-1)  # :91, modeling.py:387
@@ -508,11 +523,26 @@ class Oracle:
                 if compute_loss and gather:
                     feat_v = gather[0](feat_v)
             if "a" in "".join(contra_task):
-                feat_a = F.normalize(F.linear(audio_output[:, :, 0], w("contra_head_a.linear.weight")), dim=-1)
+                feat_a = F.normalize(F.linear(audio_output_c if coarse else audio_output[:, :, 0], w("contra_head_a.linear.weight")), dim=-1)
                 if compute_loss and gather:
                     feat_a = gather[0](feat_a)
             col.update(feat_t=feat_t, feat_v=feat_v, feat_a=feat_a)
-            if compute_loss:
+            if compute_loss and coarse:                                                          # pretrain.py:375-395
+                losses = []
+                if "tv" in contra_task:
+                    losses.append(self.contrastive_loss(feat_t @ feat_v.t()))
+                if "tva" in contra_task:
+                    if self.spec.late_fusion:
+                        sm = feat_t @ feat_v.t() + feat_t @ feat_a.t()
+                    else:
+                        feat_va = F.normalize(F.linear(torch.cat((feat_v, feat_a), dim=-1), w("va_fusion.weight"), w("va_fusion.bias")), dim=-1)
+                        sm = feat_t @ feat_va.t()
+                    col["score_tva"] = sm
+                    losses.append(self.contrastive_loss(sm))
+                if "ta" in contra_task:
+                    losses.append(self.contrastive_loss(feat_t @ feat_a.t()))
+                out["contra_loss"] = sum(losses) / len(losses) * self.contra_loss_ratio
+            elif compute_loss:
                 losses = []
                 maskA = (txt_tokens_contra != 0).long() if feat_t is not None else None
                 if "tva" in contra_task:                                                         # pretrain.py:311-336

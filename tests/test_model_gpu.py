@@ -501,3 +501,46 @@ def test_caption_type_lm_matches_oracle(dev):
         ng = model(batch, task="cap%tva%tv", compute_loss=False)
         for k in ("generated_sequences_t_va", "generated_sequences_t_v"):
             assert torch.equal(og[k], ng[k].cpu()), (beam, k, og[k], ng[k])
+
+
+@pytest.mark.parametrize("variant,late", [("clip", False), ("clip", True), ("swin", False)])
+def test_coarse_contrastive_matches_oracle(dev, variant, late):
+    """contra_type='coarse' (+ late_fusion): one pooled vector per modality, plain similarity matrices, va_fusion for the tva group
+    (model/pretrain.py:100-101,375-395; modeling.py:373-407). The oracle's branch is pinned on the unmodified reference
+    (tests/test_oracle_vs_reference.py::test_coarse_contrastive_matches_reference); here the HIP path in fp32: the three losses and every
+    gradient of the pretraining task string, and the retrieval finetune loss."""
+    import dataclasses
+    from valor_amd import synth
+    import valor_oracle as VO
+    base = synth.tiny_swin_spec() if variant == "swin" else synth.tiny_spec()
+    spec = dataclasses.replace(base, contra_type="coarse", late_fusion=late)
+    sd = synth.make_state_dict(spec, seed=7, w_std=0.05)
+    batch = synth.make_batch(spec, batch=4, frames=2, audio_slices=2, txt_len=32, seed=8)
+    sd_o = VO.trainable_copy(sd)
+    orc = VO.Oracle(spec, sd_o, vocab_tokens=synth.synthetic_vocab(spec.vocab))
+    model = _native(spec, sd, torch.float32, dev)
+    assert model.spec.contra_type == "coarse" and ("va_fusion.weight" in model.P) == (not late)
+    random.seed(31); o_out = orc.forward_pt(batch, TASK, compute_loss=True); sum(o_out.values()).backward()
+    random.seed(31); n_out = model(batch, task=TASK, compute_loss=True); sum(n_out.values()).backward()
+    for k in ("contra_loss", "caption_loss", "mlm_loss"):
+        a, b = float(o_out[k]), float(n_out[k])
+        assert abs(a - b) <= 1e-4 * abs(a), (k, a, b)
+    ng = _native_grads(model)
+    bad = []
+    for k, p in sd_o.items():
+        if VO.is_alias_key(k) or not p.is_floating_point():
+            continue
+        go, gn = p.grad, ng[k].detach().cpu()
+        if go is None:
+            assert float(gn.abs().max()) == 0.0, k
+            continue
+        scale = max(float(go.norm()), 1e-5 * go.numel() ** 0.5)
+        err = float((gn.reshape(go.shape) - go).norm()) / scale
+        if err > 2e-3:
+            bad.append((k, err))
+    assert not bad, bad[:8]
+    model.zero_grad()
+    with torch.no_grad():
+        oret = orc.forward(batch, "ret%tva%tv", compute_loss=True)
+        nret = model(batch, task="ret%tva%tv", compute_loss=True)
+    assert abs(float(oret["contra_loss"]) - float(nret["contra_loss"])) <= 1e-4 * abs(float(oret["contra_loss"]))

@@ -532,3 +532,40 @@ def test_generation_with_lm_and_full_masker(opt):
                 assert torch.equal(rq[k], oq[k]), (k, rq[k], oq[k])
         finally:
             ref.beam_size, ref.max_generation_len = old
+
+
+@pytest.mark.parametrize("variant,late", [("clip", False), ("clip", True), ("swin", False)])
+def test_coarse_contrastive_matches_reference(variant, late):
+    """contra_type='coarse' (model/pretrain.py:100-101,375-395; modeling.py:373-407): one pooled vector per modality, plain similarity
+    matrices, the tva group through va_fusion (or, late_fusion, as the sum of the tv and ta matrices). Losses and every gradient of the
+    pretraining task string against the unmodified reference; the parameter set is the reference's (no fine-weight heads, va_fusion)."""
+    import dataclasses
+    from valor_amd import synth
+    from valor_oracle import Oracle, trainable_copy
+    if variant == "swin":
+        spec = dataclasses.replace(synth.swin_spec(), contra_type="coarse", late_fusion=late)
+        ropts = ref_harness.default_opts(video_encoder_type="videoswin_base_k400_22k", txt_encoder_type="bert_base_uncased", contra_type="coarse", late_fusion=late)
+    else:
+        spec = dataclasses.replace(synth.base_spec(), contra_type="coarse", late_fusion=late)
+        ropts = ref_harness.default_opts(contra_type="coarse", late_fusion=late)
+    sd = synth.make_state_dict(spec, seed=31)
+    ref = ref_harness.build_reference(ropts, state_dict=None, dropout=0.0)
+    missing, unexpected = ref.load_state_dict(sd, strict=False)
+    assert not missing and not unexpected, (missing[:5], unexpected[:5])
+    assert ("va_fusion.weight" in sd) == (not late) and "text_fine_weight.0.weight" not in sd
+    sd_o = trainable_copy(sd)
+    orc = Oracle(spec, sd_o, vocab_tokens=synth.synthetic_vocab(spec.vocab))
+    batch = synth.make_batch(spec, batch=3, frames=2, audio_slices=2, txt_len=32, seed=32)
+    random.seed(3); r = ref(batch, task=TASK, compute_loss=True); sum(r.values()).backward()
+    random.seed(3); o = orc.forward_pt(batch, TASK, compute_loss=True); sum(o.values()).backward()
+    for k in ("contra_loss", "caption_loss", "mlm_loss"):
+        assert abs(float(r[k]) - float(o[k])) <= 2e-5 * abs(float(r[k])), (k, float(r[k]), float(o[k]))
+    n = 0
+    for name, p in ref.named_parameters():
+        if p.grad is None:
+            continue
+        g = sd_o[name].grad
+        scale = max(float(p.grad.norm()), 1e-4 * p.grad.numel() ** 0.5)
+        assert float((g - p.grad).norm()) / scale < 2e-4, name
+        n += 1
+    assert n > 500

@@ -68,6 +68,8 @@ def validate_pt(model, loader, task):
     (caption_acc_* / mlm_acc_* rounded to 2 digits, t2v / t2va / t2a forward recall strings).
     Kept quirk: the mlm hit counters are selected by the CAPTION group list (test.py:484-492)."""
     model.eval()
+    if model.spec.contra_type != "fine":
+        raise NotImplementedError("validate_pt scores retrieval with the fine matrix (test.py:534-660); contra_type='coarse' is built for the losses only")
     mlm_task, caption_task, contra_task = [], [], []
     for i in task.split("_"):
         if "mlm" in i:

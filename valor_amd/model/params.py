@@ -117,9 +117,12 @@ def param_table(spec: ValorSpec):
     if not spec.clip_heads:                                    # Contra_head, pretrain.py:33-38,93-97 (no bias)
         add("contra_head_t.linear.weight", (C, spec.txt_dim)); add("contra_head_v.linear.weight", (C, spec.video_dim))
     add("contra_head_a.linear.weight", (C, AW))
-    for m in ("text", "video", "audio"):
-        add(f"{m}_fine_weight.0.weight", (C, C)); add(f"{m}_fine_weight.0.bias", (C,))
-        add(f"{m}_fine_weight.2.weight", (1, C)); add(f"{m}_fine_weight.2.bias", (1,))
+    if spec.contra_type == "fine":                             # pretrain.py:103-116
+        for m in ("text", "video", "audio"):
+            add(f"{m}_fine_weight.0.weight", (C, C)); add(f"{m}_fine_weight.0.bias", (C,))
+            add(f"{m}_fine_weight.2.weight", (1, C)); add(f"{m}_fine_weight.2.bias", (1,))
+    elif not spec.late_fusion:                                 # pretrain.py:100-101
+        add("va_fusion.weight", (C, 2 * C)); add("va_fusion.bias", (C,))
     add("contra_temp", ())
     # ---- decoder inputs
     if spec.video_dim != H:                                    # modeling.py:348-349

@@ -129,13 +129,20 @@ class VALOR(nn.Module):
             raise NotImplementedError(f"opts ask for {want} encoders, the spec describes {(spec.video_encoder, spec.txt_encoder)}")
         if (spec.video_encoder, spec.txt_encoder) not in (("clip", "clip"), ("swin", "bert"), ("clip", "bert")):
             raise NotImplementedError("the reference loads CLIP as a whole: video/text encoders come as clip+clip, swin+bert or clip+bert")
-        if _opt(opts, "contra_type", "fine") != "fine" or _opt(opts, "caption_type", "unimlm") not in ("unimlm", "lm"):
-            raise NotImplementedError("contra_type='fine' and caption_type 'unimlm' / 'lm' only")
+        # contra_type / late_fusion change the parameter set (pretrain.py:100-116): they live in the spec; opts may override it
+        ct, lf = _opt(opts, "contra_type", spec.contra_type), bool(_opt(opts, "late_fusion", spec.late_fusion))
+        if ct not in ("fine", "coarse") or _opt(opts, "caption_type", "unimlm") not in ("unimlm", "lm"):
+            raise NotImplementedError("contra_type 'fine' / 'coarse' and caption_type 'unimlm' / 'lm' only")
+        if lf and ct == "fine":
+            raise NotImplementedError("late_fusion with contra_type='fine' (pretrain.py:313-321) is not built; with 'coarse' it is")
+        if (ct, lf) != (spec.contra_type, spec.late_fusion):
+            import dataclasses
+            spec = dataclasses.replace(spec, contra_type=ct, late_fusion=lf)
         self.caption_type = _opt(opts, "caption_type", "unimlm")        # pretrain.py:76
         self.label_smoothing = float(_opt(opts, "label_smoothing", 0.0))    # pretrain.py:72-74: the caption FINETUNE loss only (:839-840)
         self._smoothing = 0.0                                            # label smoothing of the decoder passes being issued
-        if _opt(opts, "cross_attn_type", "va_concate") != "va_concate" or _opt(opts, "late_fusion", False):
-            raise NotImplementedError("cross_attn_type='va_concate', late_fusion=False only")
+        if _opt(opts, "cross_attn_type", "va_concate") != "va_concate":
+            raise NotImplementedError("cross_attn_type='va_concate' only")
         # pretrain.py:79: the caption rows become [tokens | as many [MASK]s], position L/2 + i predicts token i + 1 (the finetune losses; generation
         # ignores the flag like the reference's, :878-900)
         self.full_masker = bool(_opt(opts, "full_masker", False)) and _opt(opts, "caption_type", "unimlm") == "unimlm"
@@ -188,7 +195,7 @@ class VALOR(nn.Module):
 
     # nn.Linear modules the reference constructs OUTSIDE BertModel and never re-initialises: VALORModel.init_weights (modeling.py:92-105)
     # is defined but not applied anywhere; only BertModel applies init_bert_weights (bert.py:747). They keep torch's nn.Linear default.
-    _TORCH_DEFAULT_LINEAR = ("contra_head_", "text_fine_weight.", "video_fine_weight.", "audio_fine_weight.", "hidden_trans_video_multimodal.0.",
+    _TORCH_DEFAULT_LINEAR = ("contra_head_", "text_fine_weight.", "video_fine_weight.", "audio_fine_weight.", "va_fusion.", "hidden_trans_video_multimodal.0.",
                              "hidden_trans_audio_multimodal.0.", "cls.dense.")
 
     def init_parameters(self, seed=42):
@@ -1007,8 +1014,59 @@ class VALOR(nn.Module):
         if col is not None:
             col.update(video_output=video_output, audio_output=audio_output, txt_output=txt_output)
 
+        # ---------------- contra_type 'coarse' (pretrain.py:266-291,375-395; pooling modeling.py:373-407): one pooled vector per modality
+        if contra_task and sp.contra_type == "coarse":
+            feat_t = feat_v = feat_a = None
+            if txt_output is not None:
+                bt, Lt = txt_output.shape[:2]
+                if sp.txt_encoder == "bert":                      # [CLS]
+                    rows = torch.arange(bt, dtype=torch.long) * Lt
+                    pooled = ops.gather_rows(txt_output.reshape(bt * Lt, -1), self._dev(rows))
+                    feat_t = ops.l2_normalize(ops.linear(pooled, P["contra_head_t.linear.weight"], None))
+                else:                                              # the EOT row: tokens.argmax (clip.py:425 convention)
+                    rows = torch.arange(bt, dtype=torch.long) * Lt + clip_tokens.argmax(dim=-1)
+                    pooled = ops.gather_rows(txt_output.reshape(bt * Lt, -1), self._dev(rows))
+                    feat_t = ops.l2_normalize(ops.linear(pooled, P["clip_model.text_projection"], None, w_is_kn=True))
+            if "v" in "".join(contra_task):
+                b, F = video_output.shape[:2]
+                if sp.video_encoder == "swin":                     # token mean, then frame mean = the mean over all F * X rows
+                    pooled = ops.group_mean(video_output.reshape(-1, sp.video_dim), F * video_output.shape[2])
+                else:
+                    cls_v = ops.gather_rows(video_output.reshape(-1, sp.vis_width), self._const_idx(b * F, sp.vis_tokens))
+                    pooled = ops.group_mean(cls_v, F)
+                if sp.clip_heads:
+                    feat_v = ops.l2_normalize(ops.linear(pooled, P["clip_model.visual.proj"], None, w_is_kn=True))
+                else:
+                    feat_v = ops.l2_normalize(ops.linear(pooled, P["contra_head_v.linear.weight"], None))
+            if "a" in "".join(contra_task):
+                b, A = audio_output.shape[:2]
+                cls_a = ops.gather_rows(audio_output.reshape(-1, sp.aud_width), self._const_idx(b * A, sp.aud_tokens))
+                feat_a = ops.l2_normalize(ops.linear(ops.group_mean(cls_a, A), P["contra_head_a.linear.weight"], None))
+            tok_contra = clip_tokens if txt_output is not None else None
+            if compute_loss and self.gather_fn is not None:
+                feat_t, feat_v, feat_a, tok_contra = self.gather_fn(feat_t, feat_v, feat_a, self._dev(tok_contra))
+            if col is not None:
+                col.update(feat_t=feat_t, feat_v=feat_v, feat_a=feat_a)
+            if compute_loss:
+                k = P["clip_model.logit_scale"].float().exp() if sp.video_encoder == "clip" else 1.0 / P["contra_temp"].float()
+                losses = []
+                for g in contra_task:
+                    if g == "tv":
+                        losses.append(ops.coarse_contrastive(feat_t, [feat_v], k))
+                    elif g == "ta":
+                        losses.append(ops.coarse_contrastive(feat_t, [feat_a], k))
+                    elif g == "tva" and sp.late_fusion:            # the tv and ta matrices summed (:383-384)
+                        losses.append(ops.coarse_contrastive(feat_t, [feat_v, feat_a], k))
+                    elif g == "tva":                               # va_fusion(cat(v, a)) (:385-387)
+                        fva = ops.l2_normalize(ops.linear(torch.cat((feat_v, feat_a), dim=-1), P["va_fusion.weight"], P["va_fusion.bias"]))
+                        losses.append(ops.coarse_contrastive(feat_t, [fva], k))
+                    else:
+                        raise NotImplementedError(f"contrastive group {g} with contra_type='coarse' (the reference handles tv / tva / ta, pretrain.py:375-395)")
+                out["contra_loss"] = sum(losses) / len(losses) * contra_ratio
+            else:
+                out.update(feat_t=feat_t, feat_v=feat_v, feat_a=feat_a, txt_tokens=tok_contra)
         # ---------------- MGA contrastive (pretrain.py:266-407)
-        if contra_task:
+        elif contra_task:
             feat_t = feat_v = feat_a = None
             tok_contra = None
             if txt_output is not None:

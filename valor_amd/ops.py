@@ -773,6 +773,59 @@ class FineContrastFn(Function):
         return dfa, dfb, dwA_raw, dwB_raw, None, None, dk
 
 
+class CoarseContrastiveFn(Function):
+    """contra_type='coarse' (model/pretrain.py:375-395 + contrastive_loss, modeling.py:418-433): score = featA . (sum_j featB_j)^T over pooled,
+    normalised [B, C] features (one B-side operand, or two for the late-fusion sum of the tv and ta matrices), then the symmetric InfoNCE of
+    the fine path's kernels. Scores and their gradient stay fp32; the small GEMMs read zero-padded leading dimensions like the fine path."""
+
+    @staticmethod
+    def forward(ctx, k, fa, *fbs):
+        B, C = fa.shape
+        dev = fa.device
+        f32 = dict(dtype=torch.float32, device=dev)
+        fa = fa.contiguous()
+        fbs = tuple(f.contiguous() for f in fbs)
+        ldB = (B + 7) // 8 * 8
+        S = torch.zeros((B, ldB), **f32)
+        for j, fb in enumerate(fbs):
+            K.gemm(fa, fb, out=S[:, :B], out_dtype=torch.float32, accumulate=j > 0)
+        score = S[:, :B].contiguous()
+        lse_r, lse_c = torch.empty(B, **f32), torch.empty(B, **f32)
+        loss = torch.empty((), **f32)
+        kk = k.detach().to(torch.float32).contiguous()
+        lib.call("valor_infonce_fwd", _st(), _p(score), _p(kk), _p(lse_r), _p(lse_c), _p(loss), B)
+        ctx.save_for_backward(fa, score, lse_r, lse_c, kk, *fbs)
+        ctx.score = score
+        return loss
+
+    @staticmethod
+    def backward(ctx, dloss):
+        fa, score, lse_r, lse_c, kk, *fbs = ctx.saved_tensors
+        B, C = fa.shape
+        dev, fdt = fa.device, fa.dtype
+        f32 = dict(dtype=torch.float32, device=dev)
+        g = dloss.to(torch.float32).contiguous()
+        dscore, dk = torch.empty((B, B), **f32), torch.empty((), **f32)
+        part = torch.empty(256, **f32)
+        lib.call("valor_infonce_bwd", _st(), _p(score), _p(kk), _p(lse_r), _p(lse_c), _p(g), _p(dscore), _p(dk), _p(part), B)
+        ldB = (B + 7) // 8 * 8
+        dS = torch.zeros((B, ldB), dtype=fdt, device=dev)
+        dS[:, :B].copy_(dscore)
+        dSv = dS[:, :B]
+        dfa = None
+        for j, fb in enumerate(fbs):
+            if dfa is None:
+                dfa = K.gemm(dSv, fb, trans_b=True)                                   # dS . featB_j
+            else:
+                K.gemm(dSv, fb, trans_b=True, out=dfa, accumulate=True)
+        dfbs = tuple(K.gemm(dSv, fa, trans_a=True, trans_b=True) for _ in fbs)        # dS^T . featA (the same for every summand)
+        return (dk, dfa) + dfbs
+
+
+def coarse_contrastive(featA, featBs, k):
+    return CoarseContrastiveFn.apply(k, featA, *featBs)
+
+
 def fine_contrastive(featA, featB, wA_raw, wB_raw, maskA, maskB, k):
     return FineContrastFn.apply(featA, featB, wA_raw, wB_raw, maskA, maskB, k)
 

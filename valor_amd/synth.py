@@ -49,6 +49,10 @@ class ValorSpec:
     # width of the contrastive space when the heads are Contra_head linears (pretrain.py:93-97, opts.contra_dim = 512) and it
     # differs from CLIP's joint embedding dim (CLIP-L/14: 768); 0 -> embed_dim (every shipped base configuration)
     contra_dim: int = 0
+    # contrastive flavour (pretrain.py:75,83,100-116): "fine" = token-level MGA matrix with the fine-weight heads (every shipped config);
+    # "coarse" = one pooled vector per modality and plain similarity matrices, with a va_fusion Linear for the tva group unless late_fusion
+    contra_type: str = "fine"
+    late_fusion: bool = False
 
     @property
     def cdim(self):
@@ -291,9 +295,12 @@ def state_dict_layout(spec: ValorSpec):
     if not spec.clip_heads:                                                           # Contra_head, pretrain.py:93-97 (no bias)
         add("contra_head_t.linear.weight", (C, spec.txt_dim)); add("contra_head_v.linear.weight", (C, spec.video_dim))
     add("contra_head_a.linear.weight", (C, AW))
-    for m in ("text", "video", "audio"):
-        add(f"{m}_fine_weight.0.weight", (C, C)); add(f"{m}_fine_weight.0.bias", (C,), "b")
-        add(f"{m}_fine_weight.2.weight", (1, C)); add(f"{m}_fine_weight.2.bias", (1,), "b")
+    if spec.contra_type == "fine":                                                    # pretrain.py:103-116
+        for m in ("text", "video", "audio"):
+            add(f"{m}_fine_weight.0.weight", (C, C)); add(f"{m}_fine_weight.0.bias", (C,), "b")
+            add(f"{m}_fine_weight.2.weight", (1, C)); add(f"{m}_fine_weight.2.bias", (1,), "b")
+    elif not spec.late_fusion:                                                        # pretrain.py:100-101
+        add("va_fusion.weight", (C, 2 * C)); add("va_fusion.bias", (C,), "b")
     return L
 
 
