@@ -80,3 +80,44 @@ def test_validate_pt_matches_oracle(dev):
     assert {"caption_acc_tva", "caption_acc_tv", "caption_acc_ta", "mlm_acc_tva"} <= set(log)
     for k, v in want.items():
         assert log[k] == v, (k, log[k], v)
+
+
+@pytest.mark.parametrize("late", [False, True])
+def test_validate_pt_with_coarse_features(dev, late):
+    """contra_type='coarse' at evaluation (test.py:640-660): recall from the plain similarity matrices of the pooled features (tva through
+    va_fusion, or the late-fusion sum) -- the recall strings of the oracle's features scored the same way."""
+    import dataclasses
+    import valor_oracle as VO
+    from valor_amd import synth
+    from valor_amd.evaluate import compute_metric_ret, validate_pt
+    from valor_amd.model.valor import VALOR
+    spec = dataclasses.replace(synth.tiny_spec(), contra_type="coarse", late_fusion=late)
+    sd = synth.make_state_dict(spec, seed=3, w_std=0.05)
+    batches = []
+    for i in range(3):
+        b = synth.make_batch(spec, batch=4, frames=2, audio_slices=1, txt_len=32, seed=20 + i)
+        b["ids"] = [f"v{4 * i + j}" for j in range(4)]
+        b["ids_txt"] = list(b["ids"])
+        batches.append(b)
+    model = VALOR({"dropout": 0.0}, spec=spec, dtype=torch.float32, device=dev)
+    model.load_state_dict(sd, strict=True)
+    task = "pt_contra%tva%tv%ta"
+    log = validate_pt(model, batches, task)
+    orc = VO.Oracle(spec, sd, vocab_tokens=synth.synthetic_vocab(spec.vocab))
+    feats = {"feat_t": [], "feat_v": [], "feat_a": []}
+    with torch.no_grad():
+        for b in batches:
+            ev = orc.forward_pt(b, task, compute_loss=False)
+            for k in feats:
+                feats[k].append(ev[k])
+        ft, fv, fa = (torch.cat(feats[k], 0) for k in ("feat_t", "feat_v", "feat_a"))
+        assert ft.dim() == 2 and fv.dim() == 2
+        ids = [x for b in batches for x in b["ids"]]
+        if late:
+            tva = ft @ fv.t() + ft @ fa.t()
+        else:
+            fva = torch.nn.functional.normalize(torch.nn.functional.linear(torch.cat((fv, fa), -1), sd["va_fusion.weight"], sd["va_fusion.bias"]), dim=-1)
+            tva = ft @ fva.t()
+        want = {"t2v_recall": compute_metric_ret(ft @ fv.t(), ids, ids)["forward_recall"], "t2a_recall": compute_metric_ret(ft @ fa.t(), ids, ids)["forward_recall"],
+                "t2va_recall": compute_metric_ret(tva, ids, ids)["forward_recall"]}
+    assert log == want, (log, want)

@@ -68,8 +68,6 @@ def validate_pt(model, loader, task):
     (caption_acc_* / mlm_acc_* rounded to 2 digits, t2v / t2va / t2a forward recall strings).
     Kept quirk: the mlm hit counters are selected by the CAPTION group list (test.py:484-492)."""
     model.eval()
-    if model.spec.contra_type != "fine":
-        raise NotImplementedError("validate_pt scores retrieval with the fine matrix (test.py:534-660); contra_type='coarse' is built for the losses only")
     mlm_task, caption_task, contra_task = [], [], []
     for i in task.split("_"):
         if "mlm" in i:
@@ -103,6 +101,24 @@ def validate_pt(model, loader, task):
         for g in ("tva", "tv", "ta"):
             if g in groups and f"{tag}_{g}" in hits:
                 val_log[f"{tag}_acc_{g}"] = round(hits[f"{tag}_{g}"] / n_word[tag], 2)
+    if contra_task and model.spec.contra_type == "coarse":            # test.py:640-660: plain similarity matrices of the pooled features
+        from . import kernels as K, ops
+        cat = lambda k: torch.cat(feats[k], dim=0).contiguous() if feats[k] and feats[k][0] is not None else None
+        ft, fv, fa = cat("feat_t"), cat("feat_v"), cat("feat_a")
+        sim = lambda a, b: K.gemm(a, b, out_dtype=torch.float32)
+        with torch.no_grad():
+            if "tv" in contra_task:
+                val_log["t2v_recall"] = compute_metric_ret(sim(ft, fv).cpu(), ids, ids_txt)["forward_recall"]
+            if "tva" in contra_task:
+                if model.spec.late_fusion:
+                    sm = sim(ft, fv) + sim(ft, fa)
+                else:
+                    fva = ops.l2_normalize(ops.linear(torch.cat((fv, fa), dim=-1), model.P["va_fusion.weight"], model.P["va_fusion.bias"]))
+                    sm = sim(ft, fva)
+                val_log["t2va_recall"] = compute_metric_ret(sm.cpu(), ids, ids_txt)["forward_recall"]
+            if "ta" in contra_task:
+                val_log["t2a_recall"] = compute_metric_ret(sim(ft, fa).cpu(), ids, ids_txt)["forward_recall"]
+        return val_log
     if contra_task:
         cat = lambda k: torch.cat(feats[k], dim=0) if feats[k] and feats[k][0] is not None else None
         ft, fv, fa = cat("feat_t"), cat("feat_v"), cat("feat_a")
