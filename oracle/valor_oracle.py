@@ -545,7 +545,13 @@ class Oracle:
             elif compute_loss:
                 losses = []
                 maskA = (txt_tokens_contra != 0).long() if feat_t is not None else None
-                if "tva" in contra_task:                                                         # pretrain.py:311-336
+                if "tva" in contra_task and self.spec.late_fusion:                               # pretrain.py:313-321: unit token weights, two matrices summed
+                    ones_w = lambda f: torch.ones_like(f[:, :, 0])
+                    sm = self.compute_fine_matrix(feat_t, feat_v, maskA, torch.ones(*feat_v.shape[:2]).long(), ones_w(feat_t), ones_w(feat_v)) + \
+                        self.compute_fine_matrix(feat_t, feat_a, maskA, torch.ones(*feat_a.shape[:2]).long(), ones_w(feat_t), ones_w(feat_a))
+                    col["score_tva"] = sm
+                    losses.append(self.contrastive_loss(sm))
+                elif "tva" in contra_task:                                                       # pretrain.py:311-336
                     feat_va = torch.cat((feat_v, feat_a), dim=1)
                     maskB = torch.ones(*feat_va.shape[:2]).long()
                     wA = self.fine_weight("text", feat_t)

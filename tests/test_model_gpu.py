@@ -544,3 +544,33 @@ def test_coarse_contrastive_matches_oracle(dev, variant, late):
         oret = orc.forward(batch, "ret%tva%tv", compute_loss=True)
         nret = model(batch, task="ret%tva%tv", compute_loss=True)
     assert abs(float(oret["contra_loss"]) - float(nret["contra_loss"])) <= 1e-4 * abs(float(oret["contra_loss"]))
+
+
+def test_late_fusion_with_the_fine_matrix_matches_oracle(dev):
+    """late_fusion with contra_type='fine' (pretrain.py:313-321; the oracle's branch is pinned on the unmodified reference): InfoNCE of
+    fine(t, v) + fine(t, a) with unit token weights for the tva group -- loss and every gradient of 'pt_contra%tva%tv%ta' in fp32."""
+    import dataclasses
+    from valor_amd import synth
+    import valor_oracle as VO
+    spec = dataclasses.replace(synth.tiny_spec(), late_fusion=True)
+    sd = synth.make_state_dict(spec, seed=9, w_std=0.05)
+    batch = synth.make_batch(spec, batch=4, frames=2, audio_slices=2, txt_len=32, seed=10)
+    sd_o = VO.trainable_copy(sd)
+    orc = VO.Oracle(spec, sd_o, vocab_tokens=synth.synthetic_vocab(spec.vocab))
+    model = _native(spec, sd, torch.float32, dev)
+    assert model.spec.late_fusion and model.spec.contra_type == "fine"
+    task = "pt_contra%tva%tv%ta"
+    random.seed(5); o = orc.forward_pt(batch, task, compute_loss=True); o["contra_loss"].backward()
+    random.seed(5); n = model(batch, task=task, compute_loss=True); n["contra_loss"].backward()
+    assert abs(float(o["contra_loss"]) - float(n["contra_loss"])) <= 1e-4 * abs(float(o["contra_loss"])), (float(o["contra_loss"]), float(n["contra_loss"]))
+    ng = _native_grads(model)
+    bad = []
+    for k, p in sd_o.items():
+        if VO.is_alias_key(k) or not p.is_floating_point() or p.grad is None:
+            continue
+        go, gn = p.grad, ng[k].detach().cpu()
+        scale = max(float(go.norm()), 1e-5 * go.numel() ** 0.5)
+        err = float((gn.reshape(go.shape) - go).norm()) / scale
+        if err > 2e-3:
+            bad.append((k, err))
+    assert not bad, bad[:8]

@@ -569,3 +569,33 @@ def test_coarse_contrastive_matches_reference(variant, late):
         assert float((g - p.grad).norm()) / scale < 2e-4, name
         n += 1
     assert n > 500
+
+
+def test_late_fusion_with_the_fine_matrix_matches_reference():
+    """late_fusion with contra_type='fine' (model/pretrain.py:313-321): the tva group scores fine(t, v) + fine(t, a) with UNIT token weights
+    (the fine-weight heads still serve tv / ta): losses and every gradient against the unmodified reference."""
+    import dataclasses
+    from valor_amd import synth
+    from valor_oracle import Oracle, trainable_copy
+    spec = dataclasses.replace(synth.base_spec(), late_fusion=True)
+    ropts = ref_harness.default_opts(late_fusion=True)
+    sd = synth.make_state_dict(spec, seed=41)
+    ref = ref_harness.build_reference(ropts, state_dict=None, dropout=0.0)
+    missing, unexpected = ref.load_state_dict(sd, strict=False)
+    assert not missing and not unexpected
+    sd_o = trainable_copy(sd)
+    orc = Oracle(spec, sd_o, vocab_tokens=synth.synthetic_vocab(spec.vocab))
+    batch = synth.make_batch(spec, batch=3, frames=2, audio_slices=2, txt_len=32, seed=42)
+    task = "pt_contra%tva%tv%ta"
+    random.seed(3); r = ref(batch, task=task, compute_loss=True); r["contra_loss"].backward()
+    random.seed(3); o = orc.forward_pt(batch, task, compute_loss=True); o["contra_loss"].backward()
+    assert abs(float(r["contra_loss"]) - float(o["contra_loss"])) <= 2e-5 * abs(float(r["contra_loss"])), (float(r["contra_loss"]), float(o["contra_loss"]))
+    n = 0
+    for name, p in ref.named_parameters():
+        if p.grad is None:
+            continue
+        g = sd_o[name].grad
+        scale = max(float(p.grad.norm()), 1e-4 * p.grad.numel() ** 0.5)
+        assert float((g - p.grad).norm()) / scale < 2e-4, name
+        n += 1
+    assert n > 300

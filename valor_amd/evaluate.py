@@ -128,7 +128,10 @@ def validate_pt(model, loader, task):
         ones = lambda f: torch.ones(f.shape[:2], dtype=torch.float32, device=model.device)
         if "tv" in contra_task:
             val_log["t2v_recall"] = compute_metric_ret(compute_fine_matrix(ft, fv, maskA, ones(fv), wt, _fine_weights(model, "video", fv)).cpu(), ids, ids_txt)["forward_recall"]
-        if "tva" in contra_task:
+        if "tva" in contra_task and model.spec.late_fusion:          # test.py:571-579: unit token weights, the tv and ta matrices summed
+            sm = compute_fine_matrix(ft, fv, maskA, ones(fv), ones(ft), ones(fv)) + compute_fine_matrix(ft, fa, maskA, ones(fa), ones(ft), ones(fa))
+            val_log["t2va_recall"] = compute_metric_ret(sm.cpu(), ids, ids_txt)["forward_recall"]
+        elif "tva" in contra_task:
             fva = torch.cat((fv, fa), dim=1)
             wva = torch.cat((_fine_weights(model, "video", fv), _fine_weights(model, "audio", fa)), dim=1)
             val_log["t2va_recall"] = compute_metric_ret(compute_fine_matrix(ft, fva, maskA, ones(fva), wt, wva).cpu(), ids, ids_txt)["forward_recall"]

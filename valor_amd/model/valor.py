@@ -133,8 +133,6 @@ class VALOR(nn.Module):
         ct, lf = _opt(opts, "contra_type", spec.contra_type), bool(_opt(opts, "late_fusion", spec.late_fusion))
         if ct not in ("fine", "coarse") or _opt(opts, "caption_type", "unimlm") not in ("unimlm", "lm"):
             raise NotImplementedError("contra_type 'fine' / 'coarse' and caption_type 'unimlm' / 'lm' only")
-        if lf and ct == "fine":
-            raise NotImplementedError("late_fusion with contra_type='fine' (pretrain.py:313-321) is not built; with 'coarse' it is")
         if (ct, lf) != (spec.contra_type, spec.late_fusion):
             import dataclasses
             spec = dataclasses.replace(spec, contra_type=ct, late_fusion=lf)
@@ -1111,7 +1109,9 @@ class VALOR(nn.Module):
                 wa = fw("audio", feat_a) if feat_a is not None else None
                 ones = lambda f: torch.ones(f.shape[:2], dtype=torch.float32, device=self.device)
                 losses = []
-                if "tva" in contra_task:
+                if "tva" in contra_task and sp.late_fusion:       # pretrain.py:313-321: fine(t, v) + fine(t, a) with unit token weights
+                    losses.append(ops.late_fusion_fine_contrastive(feat_t, feat_v, feat_a, maskA, k))
+                elif "tva" in contra_task:
                     fB, wB = torch.cat((feat_v, feat_a), dim=1), torch.cat((wv, wa), dim=1)
                     losses.append(ops.fine_contrastive(feat_t, fB, wt.contiguous(), wB.contiguous(), maskA, ones(fB), k))
                 if "tv" in contra_task:

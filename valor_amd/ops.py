@@ -773,6 +773,84 @@ class FineContrastFn(Function):
         return dfa, dfb, dwA_raw, dwB_raw, None, None, dk
 
 
+class FineScoreFn(Function):
+    """The fine matrix alone (compute_fine_matrix, pretrain.py:178-211) with UNIT raw token weights, differentiable in the features: what
+    late_fusion sums for the tva group (pretrain.py:313-321). Unfused on purpose (S = featA . featB^T through valor_gemm, the reduce kernels
+    of contrastive.hip): a rare option, not a benchmarked path."""
+
+    @staticmethod
+    def forward(ctx, featA, featB, maskA, maskB):
+        B, T, D = featA.shape
+        Nv = featB.shape[1]
+        dev = featA.device
+        f32 = dict(dtype=torch.float32, device=dev)
+        fa, fb = featA.contiguous().view(B * T, D), featB.contiguous().view(B * Nv, D)
+        ldS = (B * Nv + 7) // 8 * 8
+        wA, wB = torch.empty((B, T), **f32), torch.empty((B, Nv), **f32)
+        lib.call("valor_fine_weight_softmax", _st(), _p(torch.ones((B, T), **f32)), _p(maskA), _p(wA), B, T)
+        lib.call("valor_fine_weight_softmax", _st(), _p(torch.ones((B, Nv), **f32)), _p(maskB), _p(wB), B, Nv)
+        score = torch.empty((B, B), **f32)
+        A2B, B2A = torch.empty((B, B, T), **f32), torch.empty((B, B, Nv), **f32)
+        idxA = torch.empty((B, B, T), dtype=torch.uint8, device=dev)
+        idxB = torch.empty((B, B, Nv), dtype=torch.uint8, device=dev)
+        S = torch.empty((B * T, ldS), **f32)
+        K.gemm(fa, fb, out=S[:, :B * Nv], out_dtype=torch.float32)
+        lib.call("valor_fine_reduce_fwd", _st(), _p(S), ldS, _p(maskA), _p(maskB), _p(wA), _p(wB), _p(score), _p(A2B), _p(B2A), _p(idxA), _p(idxB), B, T, Nv)
+        ctx.save_for_backward(fa, fb, maskA, maskB, wA, wB, A2B, B2A, idxA, idxB)
+        ctx.dims = (B, T, Nv, D, ldS, featA.dtype)
+        return score
+
+    @staticmethod
+    def backward(ctx, dscore):
+        fa, fb, maskA, maskB, wA, wB, A2B, B2A, idxA, idxB = ctx.saved_tensors
+        B, T, Nv, D, ldS, fdt = ctx.dims
+        dev = fa.device
+        f32 = dict(dtype=torch.float32, device=dev)
+        dscore = dscore.to(torch.float32).contiguous()
+        dwA, dwB = torch.empty((B, T), **f32), torch.empty((B, Nv), **f32)          # gradients of the (constant) token weights: discarded
+        dS = torch.zeros((B * T, ldS), dtype=fdt, device=dev)
+        lib.call("valor_fine_reduce_bwd", _st(), _dt(dS), _p(dscore), _p(maskA), _p(maskB), _p(wA), _p(wB), _p(A2B), _p(B2A),
+                 _p(idxA), _p(idxB), _p(dS), ldS, _p(dwA), _p(dwB), B, T, Nv)
+        dSv = dS[:, :B * Nv]
+        dfa = K.gemm(dSv, fb, trans_b=True).view(B, T, D)
+        dfb = K.gemm(dSv, fa, trans_a=True, trans_b=True).view(B, Nv, D)
+        return dfa, dfb, None, None
+
+
+class InfoNCEFn(Function):
+    """contrastive_loss (modeling.py:418-433) of a [B, B] fp32 score matrix with k = 1 / temperature (differentiable)"""
+
+    @staticmethod
+    def forward(ctx, score, k):
+        B = score.shape[0]
+        f32 = dict(dtype=torch.float32, device=score.device)
+        score = score.to(torch.float32).contiguous()
+        lse_r, lse_c = torch.empty(B, **f32), torch.empty(B, **f32)
+        loss = torch.empty((), **f32)
+        kk = k.detach().to(torch.float32).contiguous()
+        lib.call("valor_infonce_fwd", _st(), _p(score), _p(kk), _p(lse_r), _p(lse_c), _p(loss), B)
+        ctx.save_for_backward(score, lse_r, lse_c, kk)
+        return loss
+
+    @staticmethod
+    def backward(ctx, dloss):
+        score, lse_r, lse_c, kk = ctx.saved_tensors
+        B = score.shape[0]
+        f32 = dict(dtype=torch.float32, device=score.device)
+        g = dloss.to(torch.float32).contiguous()
+        dscore, dk = torch.empty((B, B), **f32), torch.empty((), **f32)
+        part = torch.empty(256, **f32)
+        lib.call("valor_infonce_bwd", _st(), _p(score), _p(kk), _p(lse_r), _p(lse_c), _p(g), _p(dscore), _p(dk), _p(part), B)
+        return dscore, dk
+
+
+def late_fusion_fine_contrastive(feat_t, feat_v, feat_a, maskA, k):
+    """pretrain.py:313-321: the tva group of contra_type='fine' with late_fusion = InfoNCE(fine(t, v) + fine(t, a)), unit token weights"""
+    ones = lambda f: torch.ones(f.shape[:2], dtype=torch.float32, device=f.device)
+    s = FineScoreFn.apply(feat_t, feat_v, maskA, ones(feat_v)) + FineScoreFn.apply(feat_t, feat_a, maskA, ones(feat_a))
+    return InfoNCEFn.apply(s, k)
+
+
 class CoarseContrastiveFn(Function):
     """contra_type='coarse' (model/pretrain.py:375-395 + contrastive_loss, modeling.py:418-433): score = featA . (sum_j featB_j)^T over pooled,
     normalised [B, C] features (one B-side operand, or two for the late-fusion sum of the tv and ta matrices), then the symmetric InfoNCE of
