@@ -380,15 +380,25 @@ def test_contrastive_groups_without_text_on_the_query_side(setup):
             assert abs(float(r["contra_loss"]) - float(o["contra_loss"])) <= 2e-5 * abs(float(r["contra_loss"])), (task, float(r["contra_loss"]), float(o["contra_loss"]))
 
 
+def _shallow(spec, **kw):
+    """the option-branch pins below do not depend on depth: 2 ViT / 1 CLIP-text / 2 BERT layers (the reference derives the CLIP depth from
+    the checkpoint keys and the BERT depth from its json, ref_harness.build_reference) -- a third of the build and step time"""
+    import dataclasses
+    return dataclasses.replace(spec, vis_layers=2, txt_layers=1, layers=2, **kw)
+
+
+SHALLOW = dict(clip_layers=(2, 1), bert_layers=2)
+
+
 def test_caption_type_lm_matches_reference():
     """caption_type='lm' (model/pretrain.py:429-433, :812-816, :1230-1234): the caption passes read the unmasked tokens under the causal
     mask and predict the NEXT token at every position (padding / last position ignored) -- pretraining task string and the caption
     finetune loss against the unmodified reference: losses and every gradient."""
     from valor_amd import synth
     from valor_oracle import Oracle, trainable_copy
-    spec, ropts = synth.base_spec(), ref_harness.default_opts(caption_type="lm")
+    spec, ropts = _shallow(synth.base_spec()), ref_harness.default_opts(caption_type="lm")
     sd = synth.make_state_dict(spec, seed=17)
-    ref = ref_harness.build_reference(ropts, state_dict=None, dropout=0.0)
+    ref = ref_harness.build_reference(ropts, state_dict=None, dropout=0.0, **(SHALLOW if spec.video_encoder == 'clip' else dict(bert_layers=2)))
     missing, unexpected = ref.load_state_dict(sd, strict=False)
     assert not missing and not unexpected
     sd_o = trainable_copy(sd)
@@ -406,7 +416,7 @@ def test_caption_type_lm_matches_reference():
         scale = max(float(p.grad.norm()), 1e-4 * p.grad.numel() ** 0.5)
         assert float((g - p.grad).norm()) / scale < 2e-4, name
         n += 1
-    assert n > 800
+    assert n > 150
     with torch.no_grad():
         rc = ref(dict(batch), task="cap%tva%tv", compute_loss=True)      # forward_cap replaces batch['txt_tokens'] in place
         oc = orc.forward(batch, "cap%tva%tv", compute_loss=True)
@@ -418,9 +428,9 @@ def test_several_questions_per_clip_at_generation():
     question -- greedy answers of the reference, token for token."""
     from valor_amd import synth
     from valor_oracle import Oracle, trainable_copy
-    spec = synth.base_spec()
+    spec = _shallow(synth.base_spec())
     sd = synth.make_state_dict(spec, seed=50)
-    ref = ref_harness.build_reference(ref_harness.default_opts(), state_dict=sd, dropout=0.0)
+    ref = ref_harness.build_reference(ref_harness.default_opts(), state_dict=sd, dropout=0.0, **SHALLOW)
     orc = Oracle(spec, trainable_copy(sd), vocab_tokens=synth.synthetic_vocab(spec.vocab))
     batch = synth.make_batch(spec, batch=2, frames=2, audio_slices=1, txt_len=8, seed=53, questions=True)
     three = synth.make_batch(spec, batch=3, frames=1, audio_slices=1, txt_len=8, seed=54, questions=True)
@@ -438,9 +448,9 @@ def test_label_smoothing_of_the_caption_finetune_loss():
     divergence to the smoothed target, against the unmodified reference -- loss and every gradient of 'cap%tva%tv'."""
     from valor_amd import synth
     from valor_oracle import Oracle, trainable_copy
-    spec, ropts = synth.base_spec(), ref_harness.default_opts(label_smoothing=0.1)
+    spec, ropts = _shallow(synth.base_spec()), ref_harness.default_opts(label_smoothing=0.1)
     sd = synth.make_state_dict(spec, seed=19)
-    ref = ref_harness.build_reference(ropts, state_dict=None, dropout=0.0)
+    ref = ref_harness.build_reference(ropts, state_dict=None, dropout=0.0, **(SHALLOW if spec.video_encoder == 'clip' else dict(bert_layers=2)))
     missing, unexpected = ref.load_state_dict(sd, strict=False)
     assert not missing and not unexpected
     sd_o = trainable_copy(sd)
@@ -457,7 +467,7 @@ def test_label_smoothing_of_the_caption_finetune_loss():
         scale = max(float(p.grad.norm()), 1e-4 * p.grad.numel() ** 0.5)
         assert float((g - p.grad).norm()) / scale < 2e-4, name
         n += 1
-    assert n > 300
+    assert n > 100
 
 
 def test_full_masker_matches_reference():
@@ -467,9 +477,9 @@ def test_full_masker_matches_reference():
     labels) and is refused here. Caption and QA finetune losses and every gradient of the caption loss, against the unmodified reference."""
     from valor_amd import synth
     from valor_oracle import Oracle, trainable_copy
-    spec, ropts = synth.base_spec(), ref_harness.default_opts(full_masker=True)
+    spec, ropts = _shallow(synth.base_spec()), ref_harness.default_opts(full_masker=True)
     sd = synth.make_state_dict(spec, seed=21)
-    ref = ref_harness.build_reference(ropts, state_dict=None, dropout=0.0)
+    ref = ref_harness.build_reference(ropts, state_dict=None, dropout=0.0, **(SHALLOW if spec.video_encoder == 'clip' else dict(bert_layers=2)))
     missing, unexpected = ref.load_state_dict(sd, strict=False)
     assert not missing and not unexpected
     sd_o = trainable_copy(sd)
@@ -486,7 +496,7 @@ def test_full_masker_matches_reference():
         scale = max(float(p.grad.norm()), 1e-4 * p.grad.numel() ** 0.5)
         assert float((g - p.grad).norm()) / scale < 2e-4, name
         n += 1
-    assert n > 300
+    assert n > 100
     with torch.no_grad():
         with pytest.raises(IndexError):          # forward_pt + full_masker: the reference slices 'tv' outputs with the original length (:454)
             ref(batch, task=TASK, compute_loss=True)
@@ -506,9 +516,9 @@ def test_generation_with_lm_and_full_masker(opt):
     from valor_amd import synth
     from valor_oracle import Oracle, trainable_copy
     kw = dict(caption_type="lm") if opt == "lm" else dict(full_masker=True)
-    spec, ropts = synth.base_spec(), ref_harness.default_opts(**kw)
+    spec, ropts = _shallow(synth.base_spec()), ref_harness.default_opts(**kw)
     sd = synth.make_state_dict(spec, seed=50)
-    ref = ref_harness.build_reference(ropts, state_dict=sd, dropout=0.0)
+    ref = ref_harness.build_reference(ropts, state_dict=sd, dropout=0.0, **SHALLOW)
     orc = Oracle(spec, trainable_copy(sd), vocab_tokens=synth.synthetic_vocab(spec.vocab), **kw)
     batch = synth.make_batch(spec, batch=2, frames=2, audio_slices=1, txt_len=8, seed=55, questions=True)
     cp = lambda: {k: (dict(v) if isinstance(v, dict) else v) for k, v in batch.items()}
@@ -543,13 +553,13 @@ def test_coarse_contrastive_matches_reference(variant, late):
     from valor_amd import synth
     from valor_oracle import Oracle, trainable_copy
     if variant == "swin":
-        spec = dataclasses.replace(synth.swin_spec(), contra_type="coarse", late_fusion=late)
+        spec = dataclasses.replace(synth.swin_spec(), contra_type="coarse", late_fusion=late, layers=2)
         ropts = ref_harness.default_opts(video_encoder_type="videoswin_base_k400_22k", txt_encoder_type="bert_base_uncased", contra_type="coarse", late_fusion=late)
     else:
-        spec = dataclasses.replace(synth.base_spec(), contra_type="coarse", late_fusion=late)
+        spec = _shallow(synth.base_spec(), contra_type="coarse", late_fusion=late)
         ropts = ref_harness.default_opts(contra_type="coarse", late_fusion=late)
     sd = synth.make_state_dict(spec, seed=31)
-    ref = ref_harness.build_reference(ropts, state_dict=None, dropout=0.0)
+    ref = ref_harness.build_reference(ropts, state_dict=None, dropout=0.0, **(SHALLOW if spec.video_encoder == 'clip' else dict(bert_layers=2)))
     missing, unexpected = ref.load_state_dict(sd, strict=False)
     assert not missing and not unexpected, (missing[:5], unexpected[:5])
     assert ("va_fusion.weight" in sd) == (not late) and "text_fine_weight.0.weight" not in sd
@@ -568,7 +578,7 @@ def test_coarse_contrastive_matches_reference(variant, late):
         scale = max(float(p.grad.norm()), 1e-4 * p.grad.numel() ** 0.5)
         assert float((g - p.grad).norm()) / scale < 2e-4, name
         n += 1
-    assert n > 500
+    assert n > 150
 
 
 def test_late_fusion_with_the_fine_matrix_matches_reference():
@@ -577,10 +587,10 @@ def test_late_fusion_with_the_fine_matrix_matches_reference():
     import dataclasses
     from valor_amd import synth
     from valor_oracle import Oracle, trainable_copy
-    spec = dataclasses.replace(synth.base_spec(), late_fusion=True)
+    spec = _shallow(synth.base_spec(), late_fusion=True)
     ropts = ref_harness.default_opts(late_fusion=True)
     sd = synth.make_state_dict(spec, seed=41)
-    ref = ref_harness.build_reference(ropts, state_dict=None, dropout=0.0)
+    ref = ref_harness.build_reference(ropts, state_dict=None, dropout=0.0, **(SHALLOW if spec.video_encoder == 'clip' else dict(bert_layers=2)))
     missing, unexpected = ref.load_state_dict(sd, strict=False)
     assert not missing and not unexpected
     sd_o = trainable_copy(sd)
@@ -598,4 +608,4 @@ def test_late_fusion_with_the_fine_matrix_matches_reference():
         scale = max(float(p.grad.norm()), 1e-4 * p.grad.numel() ** 0.5)
         assert float((g - p.grad).norm()) / scale < 2e-4, name
         n += 1
-    assert n > 300
+    assert n > 100
