@@ -241,9 +241,11 @@ class GemmTimer:
         return {v: {"flops": f, "seconds": s, "launches": n, "TFLOPs": f / s / 1e12, "avg_us": s / n * 1e6} for v, (f, s, n) in agg.items()}
 
 
-def time_variant(variant, args, dev, steps=3, warmup=2):
-    """`steps` timed training steps of another model variant at the headline's batch / clip length (one rank): samples/s, step time,
-    step MFU on the necessary FLOPs of THAT variant, peak memory."""
+def time_variant(variant, args, dev, steps=3, warmup=2, frames=None, accum=1):
+    """`steps` timed OPTIMIZER steps (each `accum` micro-steps of args.batch samples, train_utils.py:311-317) of another model variant at
+    the headline's batch and -- unless `frames` says otherwise -- clip length (one rank): samples/s, step time, step MFU on the necessary
+    FLOPs of THAT variant, peak memory."""
+    frames = frames or args.frames
     from types import SimpleNamespace
     from valor_amd import synth
     from valor_amd.engine import TrainEngine
@@ -261,23 +263,23 @@ def time_variant(variant, args, dev, steps=3, warmup=2):
     engine = TrainEngine(model, opts)
     engine.optimizer.init_master_from(sd)
     del sd
-    batch = synth.make_batch(spec, batch=args.batch, frames=args.frames, audio_slices=args.audio_slices, txt_len=32, seed=50)
+    batch = synth.make_batch(spec, batch=args.batch, frames=frames, audio_slices=args.audio_slices, txt_len=32, seed=50)
     batch["video_pixels"] = batch["video_pixels"].to(dev)
     batch["audio_spectrograms"] = batch["audio_spectrograms"].to(dev)
-    for _ in range(warmup):
-        engine.train_step(batch, TASK)
+    for _ in range(warmup * accum):
+        engine.train_step(batch, TASK, accum_steps=accum)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     last = None
-    for _ in range(steps):
-        last = engine.train_step(batch, TASK)
+    for _ in range(steps * accum):
+        last = engine.train_step(batch, TASK, accum_steps=accum)
     torch.cuda.synchronize()
     el = time.perf_counter() - t0
-    sps = args.batch * steps / el
-    nf = necessary_flops_per_sample(spec, args.frames, args.audio_slices, 32)
+    sps = args.batch * accum * steps / el
+    nf = necessary_flops_per_sample(spec, frames, args.audio_slices, 32)
     out = {"value": round(sps, 2), "unit": "samples/s", "ms_per_step": round(el / steps * 1e3, 2), "steps": steps, "warmup": warmup,
            "step_mfu": round(nf * sps / 1e12 / PEAK_BF16_TFLOPS, 4), "necessary_gflop_per_sample": round(nf / 1e9, 1),
-           "per_gpu_batch": args.batch, "frames": args.frames, "peak_mem_gb": round(torch.cuda.max_memory_allocated() / 2 ** 30, 1),
+           "per_gpu_batch": args.batch * accum, "micro_batch": args.batch, "accum_steps": accum, "frames": frames, "peak_mem_gb": round(torch.cuda.max_memory_allocated() / 2 ** 30, 1),
            "losses": {k: round(float(v.detach()) if torch.is_tensor(v) else float(v), 4) for k, v in last.items()}}
     del engine, model, batch
     return out
@@ -502,9 +504,11 @@ def main():
             gc.collect()
             torch.cuda.empty_cache()
             res["variants"] = {}
-            for v in ("swin", "large"):
+            # large_f16_accum2 = BASELINE configs[4]'s per-GPU share (VALOR-large, 16 frames, 128 samples per GPU of the global 1024) as
+            # its recipe: two accumulated micro-steps of 64, 2 timed optimizer steps
+            for v, kw in (("swin", {}), ("large", {}), ("large_f16_accum2", dict(variant="large", frames=16, accum=2, steps=2, warmup=1))):
                 try:
-                    res["variants"][v] = time_variant(v, args, dev)
+                    res["variants"][v] = time_variant(kw.pop("variant", v), args, dev, **kw)
                 except Exception as e:
                     res["variants"][v] = {"error": repr(e)}
                 gc.collect()

@@ -134,6 +134,12 @@ FIXTURES = {
     "ref_base_b16f8a2_q": dict(batch_size=16, frames=8, audio_slices=2, wseed=41, bseed=42, mseed=43, bf16_exact=True, steps=1),
     # the shipped LARGE configuration's widths (CLIP ViT-L/14, 257 tokens per frame, LayerNorm rows of 1024, a 588-deep patch GEMM,
     # task prompt rows in the caption passes) -- full width, two-layer stacks on both sides; B = 8: the contrastive tolerance argument above
+    # BASELINE configs[4]'s clip length, 16 frames: frame-embedding rows 0..15 (modeling.py:485-493); 16 * 197 + 2 * 129 = 3410 (CLIP) and
+    # 16 * 49 + 2 * 129 = 1042 (VideoSwin) cross-attention keys (bert.py:314-340,448-457); VideoSwin feature maps 16 deep (PatchEmbed3D
+    # pads one frame and strides by 1 along time, videoswin.py:355,367): TWO (8,7,7) windows along time and the (4,3,3) shift
+    # (videoswin.py:196-223), the shift-mask regions along time
+    "ref_base_b2f16a2_q": dict(batch_size=2, frames=16, audio_slices=2, wseed=71, bseed=72, mseed=73, bf16_exact=True),
+    "ref_swin_b2f16a2_q": dict(batch_size=2, frames=16, audio_slices=2, wseed=71, bseed=72, mseed=73, bf16_exact=True, variant="swin"),
     "ref_cliplarge_b8f2a1_q": dict(batch_size=8, frames=2, audio_slices=1, wseed=61, bseed=62, mseed=63, bf16_exact=True, steps=1, variant="clip_large"),
 }
 

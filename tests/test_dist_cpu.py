@@ -110,6 +110,71 @@ def test_reducer_sums_arena_and_learns_unused_parameters(world):
             assert nworks0 > 1          # bucketed, hook-launched all-reduces after the first (learning) step
 
 
+def _reducer_window_case(rank, world):
+    """gradient accumulation windows of 3 micro-steps (train_utils.py:311-329). Three ways to reduce the same windows:
+    closing = the last micro-step reduces from its hooks, overlapped (what TrainEngine does); flat = every micro-step deferred, the
+    window reduced at once behind the last backward (the round-4 behaviour); the second window mixes in a micro-step of ANOTHER
+    parameter subset (a task switch inside the window) whose buckets the closing backward never touches."""
+    from valor_amd.arena import ParamArena
+    from valor_amd.dist import Reducer
+    entries = [(f"p{i}", (300 + 7 * i,), 0) for i in range(12)]
+    outs = {}
+    for how in ("closing", "flat"):
+        arena = ParamArena(entries, torch.float32, "cpu")
+        red = Reducer(arena, bucket_bytes=4096)
+
+        def micro(used, scale, defer, closing):
+            red.prepare_backward(defer=defer, closing=closing)
+            loss = 0
+            for i, (name, p) in enumerate(arena.params.items()):
+                if i in used:
+                    loss = loss + (p * (rank + 1) * scale * (i + 1)).sum()
+            loss.backward()
+
+        main, other = [i for i in range(12) if i % 4 != 3], [3, 7]
+        res = []
+        for window in range(3):
+            arena.grad.zero_()
+            red.reset_task("main")
+            for m in range(3):
+                last = m == 2
+                if window == 1 and m == 0:               # a micro-step of another task inside the window
+                    red.reset_task("other")
+                    micro(other, 10.0, True, False)
+                    assert red.finish_backward(last=False) == set()
+                    red.reset_task("main")
+                    continue
+                micro(main, 1.0 + m, not (last and how == "closing"), last and how == "closing")
+                names = red.finish_backward(last=last)
+            res.append((arena.grad.clone(), sorted(names), len(red.works)))
+        outs[how] = res
+    return outs
+
+
+def test_accumulation_window_reduces_from_the_last_micro_step():
+    world = 2
+    r = _run(_reducer_window_case, world)
+    tri = world * (world + 1) // 2
+    from valor_amd.arena import ParamArena
+    arena = ParamArena([(f"p{i}", (300 + 7 * i,), 0) for i in range(12)], torch.float32, "cpu")
+    for window in range(3):
+        gc, nc, wc = r[0]["closing"][window]
+        gf, nf, wf = r[0]["flat"][window]
+        assert torch.equal(gc, gf) and nc == nf                    # bit-identical to the un-overlapped window
+        assert torch.equal(gc, r[1]["closing"][window][0])         # replicas agree
+        for i in range(12):
+            o, n, _ = arena.offsets[f"p{i}"]
+            if i % 4 != 3:
+                want = tri * (i + 1) * ((2 + 3) if window == 1 else (1 + 2 + 3))
+            else:
+                want = tri * (i + 1) * 10.0 if (window == 1 and i in (3, 7)) else 0.0
+            assert torch.allclose(gc[o:o + n], torch.full((n,), float(want))), (window, i)
+        if window == 1:
+            assert "p3" in nc and "p7" in nc and "p11" not in nc
+        if window > 0:
+            assert wc > 1            # the learnt task: bucket by bucket from the closing backward's hooks
+
+
 def _reducer_multiuse_case(rank, world):
     """gradients written straight into the arena by kernels (ops.GradSink.listener), some parameters TWICE per backward (the
     shared BERT of the VideoSwin variant: text-encoder pass + decoder passes): a bucket may only fly after the last write."""

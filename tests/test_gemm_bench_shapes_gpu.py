@@ -189,6 +189,36 @@ def test_wgrad_splitk_with_bf16_partials(dev):
     assert float((small.float() - sref).norm() / sref.norm()) < 1.5 * TOL
 
 
+def test_wgrad_accumulation_window_error_bound(dev):
+    """A gradient accumulation window (train_utils.py:311-317: two micro-steps, BASELINE configs[4]'s recipe): the wgrad of the second
+    micro-step ACCUMULATES (accumulate=1) into the bf16 arena slot that holds the first one's, with bf16 split-K partials (policy key 1)
+    on. Error model: every partial tile carries one bf16 rounding (2^-9 relative, independent across the s slices: ~2^-9 / sqrt(s) of
+    the sum), the first micro-step's result one more, and the final read-modify-write one more -- the window's gradient must stay
+    within 2.5 bf16 roundings (Frobenius) of the fp32 sum of both products, as tile-uniformly as a single product, and the fused row
+    sums (fp32 partials) must sum both micro-steps' too."""
+    from valor_amd import kernels as Kn, lib
+    so = lib.load()
+    Kt, Mo, No = M_VIT, I, W
+    assert _family(so, 1, 1, Mo, No, Kt) == 3
+    old = so.valor_gemm_set_policy(1, 1)
+    try:
+        gw = torch.zeros((Mo, No), dtype=torch.bfloat16, device=dev)
+        gb = torch.zeros((Mo,), dtype=torch.bfloat16, device=dev)
+        ref = torch.zeros((Mo, No), dtype=torch.float32, device=dev)
+        rs = torch.zeros((Mo,), dtype=torch.float32, device=dev)
+        for micro in range(2):
+            dY, X = _mk((Kt, Mo), 41 + micro, dev, 0.1), _mk((Kt, No), 51 + micro, dev)
+            Kn.gemm(dY, X, trans_a=True, trans_b=True, out=gw, accumulate=True, rowsum_out=gb, rowsum_accumulate=True)
+            ref += dY.float().t() @ X.float()
+            rs += dY.float().sum(dim=0)
+            del dY, X
+    finally:
+        so.valor_gemm_set_policy(1, old)
+    whole, worst = _tile_errors(gw, ref)
+    assert whole < 2.5 * TOL and worst < 2.5 * TILE_TOL, (whole, worst)
+    assert float((gb.float() - rs).norm() / rs.norm()) < 5e-3
+
+
 @pytest.mark.parametrize("N,K", [(512, 128), (384, 128), (1024, 256), (768, 256)])
 def test_forward_short_contraction_of_the_videoswin_stages(dev, N, K):
     """VideoSwin stage-1 / 2 forward GEMMs (fc1, qkv; videoswin.py:137-163, 191-245): K = 128 / 256 over 200 704 token rows run on the

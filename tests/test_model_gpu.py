@@ -214,12 +214,15 @@ def test_text_only_mlm_matches_oracle(dev):
 
 
 @pytest.mark.parametrize("name", ["ref_base_b2f2a1", "ref_base_b3f1a2", "ref_swin_b2f2a1", "ref_base_b2f2a1_tv", "ref_base_b2f2a1_ta",
-                                  "ref_base_b2f8a2_q", "ref_swin_b2f8a2_q"])
+                                  "ref_base_b2f8a2_q", "ref_swin_b2f8a2_q", "ref_base_b2f16a2_q", "ref_swin_b2f16a2_q"])
 def test_base_fp32_matches_reference_goldens(dev, name):
     """VALOR-base on the exact inputs the reference ran on: losses, argmax ids, per-parameter gradient norms,
     and parameters after 2 fused optimizer steps vs the reference's (golden) values.
     *_b2f8a2_q = the geometry bench.py times: 8 frames, 2 audio slices (1834 cross-attention keys / 392-slot VideoSwin windows,
-    frame-embedding rows 0..7, the three kv_range groups at F = 8)."""
+    frame-embedding rows 0..7, the three kv_range groups at F = 8).
+    *_b2f16a2_q = BASELINE configs[4]'s clip length, 16 frames: frame-embedding rows 0..15 (modeling.py:485-493), 3410 (CLIP) / 1042
+    (VideoSwin) cross-attention keys (bert.py:314-340,448-457), VideoSwin maps 16 deep = two (8,7,7) windows along time with the (4,3,3)
+    shift and its mask regions along time (videoswin.py:196-223)."""
     from types import SimpleNamespace
     from valor_amd.engine import TrainEngine
     g = torch.load(os.path.join(GOLD, name + ".pt"), weights_only=False)
@@ -287,7 +290,7 @@ BF16_TIE_BAND = 0.05          # absolute logit gap below which the fp32 referenc
 
 
 @pytest.mark.parametrize("name", ["ref_base_b16f2a1_q", "ref_base_b2f2a1_q", "ref_base_b2f8a2_q", "ref_swin_b2f8a2_q", "ref_base_b16f8a2_q",
-                                  "ref_cliplarge_b8f2a1_q"])
+                                  "ref_cliplarge_b8f2a1_q", "ref_base_b2f16a2_q", "ref_swin_b2f16a2_q"])
 def test_bf16_meets_north_star_on_identical_tensors(dev, name):
     """perf mode -- the arithmetic bench.py times (bf16 storage, fp32 accumulate) -- against the fp32 reference on IDENTICAL
     tensors (weights / pixels / spectrograms are bf16-representable, so nothing is rounded on load): all three losses within

@@ -83,6 +83,39 @@ def test_oracle_reproduces_reference_goldens(name):
         assert torch.allclose(params[k].detach().reshape(-1)[:64], sl, rtol=1e-5, atol=1e-7), k
 
 
+@pytest.mark.parametrize("name", ["ref_base_b2f16a2_q", "ref_swin_b2f16a2_q"])
+def test_oracle_reproduces_the_sixteen_frame_goldens(name):
+    """BASELINE configs[4]'s clip length (16 frames) on the UNMODIFIED reference (oracle/make_goldens.py): frame-embedding rows 0..15
+    (modeling.py:485-493), 3410 / 1042 cross-attention keys (bert.py:314-340,448-457), VideoSwin maps 16 deep -- two (8,7,7) windows
+    along time, the (4,3,3) shift and its mask regions along time (videoswin.py:196-223). One training step of the restatement: losses,
+    the masked tokens, gradient norms of the parameters the geometry touches differently (frame embedding, the first shifted block's
+    bias table), the global gradient norm. (The optimizer steps of these fixtures are asserted on the GPU path,
+    tests/test_model_gpu.py; the restated optimizer itself is pinned by the smaller fixtures above.)"""
+    g = torch.load(os.path.join(GOLD, name + ".pt"), weights_only=False)
+    rc = g["recipe"]
+    assert rc["frames"] == 16
+    spec = synth.ValorSpec(**rc["spec"])
+    sd = synth.make_state_dict(spec, seed=rc["weight_seed"], bf16_exact=True)
+    sd_o = VO.trainable_copy(sd)
+    orc = VO.Oracle(spec, sd_o, vocab_tokens=synth.synthetic_vocab(spec.vocab))
+    batch = synth.make_batch(spec, batch=rc["batch"], frames=16, audio_slices=rc["audio_slices"], txt_len=rc["txt_len"], seed=rc["batch_seed"],
+                             bf16_exact=True)
+    random.seed(rc["masker_seed"])
+    out = orc.forward_pt(batch, rc["task"], compute_loss=True)
+    sum(out.values()).backward()
+    rec = g["steps"][0]
+    for k, v in rec["losses"].items():
+        assert abs(float(out[k]) - v) <= 3e-5 * abs(v), (k, float(out[k]), v)
+    params = {k: v for k, v in sd_o.items() if v.requires_grad and not VO.is_alias_key(k)}
+    grads = {k: p.grad for k, p in params.items() if p.grad is not None}
+    assert sorted(rec["no_grad"]) == sorted(k for k in params if k not in grads)
+    for k, n in rec["grad_norm"].items():
+        assert abs(float(grads[k].norm()) - n) <= 3e-4 * max(n, 1e-5 * grads[k].numel() ** 0.5) + 3e-8 * grads[k].numel() ** 0.5, k
+    assert float(grads["video_frame_embedding"][0, 8:16].abs().max()) > 0          # rows 8..15 are live at this clip length
+    total = VO.clip_grad_norm(grads, 5.0)
+    assert abs(float(total) - rec["total_grad_norm"]) <= 5e-4 * rec["total_grad_norm"]
+
+
 def test_oracle_reproduces_the_shipped_large_configuration_golden():
     """tests/golden/ref_cliplarge_b8f2a1_q.pt: the UNMODIFIED reference built from config/pretrain-VALOR-large.json's encoder choice (CLIP
     ViT-L/14 at 224 px + shared bert_base_uncased, use_task_prompt, contra_loss_ratio 1.5) at full WIDTH on two-layer stacks,

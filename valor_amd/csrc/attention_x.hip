@@ -506,7 +506,10 @@ bool attn_x_fwd_launch(hipStream_t st, const AttnArgs& p) {
 
 bool attn_x_bwd_launch(hipStream_t st, const AttnArgs& p) {
     const int n = x_nqs(p);
-    if (n <= 0 || n > 6 || p.Skv < 128 || (int64_t)p.Sq * p.do_rs * 2 >= ((int64_t)1 << 31)) return false;
+    // Up to FOUR query sub-tiles. The six-sub-tile instantiation (the caption pass: 3 groups x 32 rows) kept 96 dQ accumulator registers beside
+    // dK / dV and spilled 216 B per lane; that geometry belongs to attn_xu_bwd_kernel (attention_xu.hip: every pass of a layer in one
+    // launch, dQ D-split, no scratch) since round 4, and outside its domain to the streaming kernels of attention.hip.
+    if (n <= 0 || n > 4 || p.Skv < 128 || (int64_t)p.Sq * p.do_rs * 2 >= ((int64_t)1 << 31)) return false;
     const int bmod = p.kv_bmod > 0 ? p.kv_bmod : p.B;
     dim3 grid(p.H, bmod);
 #define X_BWD_I(N_, D_, A_)                                                                                         \
@@ -524,7 +527,7 @@ bool attn_x_bwd_launch(hipStream_t st, const AttnArgs& p) {
         if (p.p_drop > 0.f) { if (p.acc_dkv) X_BWD_I(N_, true, true); else X_BWD_I(N_, true, false); }              \
         else { if (p.acc_dkv) X_BWD_I(N_, false, true); else X_BWD_I(N_, false, false); }                           \
     } while (0)
-    if (n <= 2) X_BWD(2); else if (n <= 4) X_BWD(4); else X_BWD(6);
+    if (n <= 2) X_BWD(2); else X_BWD(4);
 #undef X_BWD
 #undef X_BWD_I
     return true;

@@ -18,7 +18,6 @@
 // Sum in the arena's element type (bf16 or fp32). The 1 / world mean is folded into the optimizer's gradient scale by the caller.
 #include <dlfcn.h>
 #include <hip/hip_runtime.h>
-#include <rccl/rccl.h>
 #include <stdint.h>
 #include <stdlib.h>
 #include <vector>
@@ -26,6 +25,17 @@
 #include "common.h"
 
 extern "C" int valor_reducer_destroy(void* reducer);
+
+// The handful of RCCL / NCCL types and constants this file needs, declared here instead of including <rccl/rccl.h>: the library is bound at
+// run time (below), so nothing of RCCL is needed to BUILD libvalor_hip.so either. Values are those of the stable NCCL ABI (nccl.h /
+// rccl.h: ncclSuccess 0, ncclSum 0, ncclFloat32 7, ncclBfloat16 9, a 128-byte opaque unique id, an opaque communicator pointer).
+typedef int ncclResult_t;
+typedef int ncclDataType_t;
+typedef int ncclRedOp_t;
+typedef struct ncclComm* ncclComm_t;
+typedef struct { char internal[128]; } ncclUniqueId;      // NCCL_UNIQUE_ID_BYTES
+#define NCCL_UNIQUE_ID_BYTES 128
+enum { ncclSuccess = 0, ncclSum = 0, ncclFloat32 = 7, ncclBfloat16 = 9 };
 
 namespace {
 

@@ -31,6 +31,9 @@ class _PackedGather(Function):
     def forward(ctx, *feats):
         world, rank = dist.get_world_size(), dist.get_rank()
         b = feats[0].shape[0]
+        # per-sample packing: every feature contributes rows of ONE sample; a tensor with another leading dimension (several captions per
+        # clip) would still reshape whenever its numel divides by b and then slice the wrong rows in backward
+        assert all(f.shape[0] == b for f in feats), [tuple(f.shape) for f in feats]
         ctx.meta = [(f.shape, f[0].numel()) for f in feats]
         ctx.rank, ctx.world = rank, world
         flat = torch.cat([f.reshape(b, -1) for f in feats], dim=1)               # [b, P]: the one packing copy
@@ -61,16 +64,16 @@ def packed_allgather_with_grads(feat_t, feat_v, feat_a, tokens):
     needs `tokens != 0`, so there is no device -> host round trip in the middle of the forward pass)."""
     feats = [f for f in (feat_t, feat_v, feat_a) if f is not None]
     dev, dt = feats[0].device, feats[0].dtype
-    # tokens ride in the same buffer as exact small integers split into two halves (< 256 and < 256: exact in bf16)
-    tok = tokens.to(dev)
-    tok_parts = torch.stack(((tok // 256).to(dt), (tok % 256).to(dt)), dim=-1)
+    # tokens ride in the same buffer as RAW BYTES: int32 ids reinterpreted as elements of the features' dtype (2 bf16 / 1 fp32 per id).
+    # A gather only moves bytes (no arithmetic touches them on the way), so any bit pattern survives; they are reinterpreted back below.
+    tok = tokens.to(dev).to(torch.int32).contiguous()
+    tok_parts = tok.view(dt)
     gathered = _PackedGather.apply(*feats, tok_parts)
     gi = iter(gathered[:-1])
     ft = next(gi) if feat_t is not None else None
     fv = next(gi) if feat_v is not None else None
     fa = next(gi) if feat_a is not None else None
-    tp = gathered[-1].detach().float()
-    tokens_all = (tp[..., 0] * 256 + tp[..., 1]).round().long()
+    tokens_all = gathered[-1].detach().contiguous().view(torch.int32).long()       # the gathered feature is a row-strided view: copy first
     return ft, fv, fa, tokens_all
 
 
@@ -117,6 +120,7 @@ class Reducer:
         self.window = None             # gradient accumulation: union of the names touched since the last reduction
         self.touched = {}              # name -> writes seen in the current backward
         self.pending, self.works = None, []
+        self._launched = set()         # buckets launched since prepare_backward
         self.comm_stream = torch.cuda.Stream() if arena.flat.is_cuda else None
         # native=True / VALOR_REDUCER_NATIVE=1: the collectives are issued by the library's own reducer (csrc/reducer.hip: its RCCL
         # communicator, communication stream and per-bucket events behind valor_reducer_*) instead of torch.distributed work objects.
@@ -126,6 +130,12 @@ class Reducer:
         want = native if native is not None else os.environ.get("VALOR_REDUCER_NATIVE", "0") == "1"
         if want and arena.flat.is_cuda and dist.is_available() and dist.is_initialized() and self.mode in ("allreduce", "rs_ag"):
             self._create_native()
+        elif want:
+            import warnings
+            why = ("mode 'fp32' widens every bucket through a temporary, which the native reducer does not do" if self.mode == "fp32" else
+                   "it needs a device arena and an initialised torch.distributed process group")
+            warnings.warn(f"native reducer requested (native=True / VALOR_REDUCER_NATIVE=1) but not used: {why}; "
+                          "the torch.distributed path runs instead")
         for name, p in arena.params.items():
             p.register_post_accumulate_grad_hook(self._make_hook(name))
         from . import ops
@@ -191,6 +201,7 @@ class Reducer:
         return [dist.all_reduce(buf, op=dist.ReduceOp.SUM, async_op=True)]
 
     def _launch(self, i):
+        self._launched.add(i)
         if self.world == 1 and self.native is None:
             return
         s, e = self.bucket_range[i]
@@ -228,13 +239,19 @@ class Reducer:
         if self.comm_stream is not None:
             torch.cuda.current_stream().wait_stream(self.comm_stream)
 
-    def prepare_backward(self, defer=False):
+    def prepare_backward(self, defer=False, closing=False):
         """defer=True: a micro-step of a gradient accumulation window -- gradients keep accumulating in the arena and NO bucket
-        is reduced now (reducing a partially accumulated arena twice would count the earlier micro-steps world times); the
-        window is reduced once by finish_backward(last=True)."""
+        is reduced now (reducing a partially accumulated arena twice would count the earlier micro-steps world times).
+        closing=True: the LAST micro-step of a window (train_utils.py:311-329: the reference's DDP reduces in the backward that precedes
+        the optimizer step). It runs like an ordinary step -- a bucket that completes in this backward holds the sum of the whole
+        window and is launched from the hooks, overlapped with the rest of the backward -- and finish_backward() sends whatever the
+        window touched that this micro-step did not (another task's parameters) behind it. Without a closing micro-step
+        (finish_backward(last=True) on a deferred one) the window is reduced at once, un-overlapped."""
         self.touched = {}
         self.works = []
+        self._launched = set()
         self.defer = defer
+        self.closing = closing and not defer
         self.pending = [set(x) for x in self.expected] if (self.expected is not None and not defer) else None
 
     def finish_backward(self, last=True):
@@ -272,9 +289,19 @@ class Reducer:
                 for i in range(len(self.buckets)):
                     self._launch(i)
                 self._wait_all()
-        else:
+        elif not getattr(self, "closing", False):
             self._wait_all()
         self.pending = None
+        if getattr(self, "closing", False):
+            # the window's last micro-step: buckets that hold names of EARLIER micro-steps only (a window that mixes tasks) were not
+            # launched by this backward's hooks; they go out now, then everything is waited for
+            names = (self.window or set()) | set(self.touched)
+            self.window, self.closing = None, False
+            if self.world > 1 or self.native is not None:
+                for i in sorted({self.bucket_of[n] for n in names} - self._launched):
+                    self._launch(i)
+            self._wait_all()
+            return names
         return set(self.touched)
 
     def reset_task(self, task=None):

@@ -66,12 +66,15 @@ class TrainEngine:
         if self.max_ahead > 0 and len(self._step_events) >= self.max_ahead:
             self._step_events.pop(0).synchronize()
         model.train()
-        self.reducer.prepare_backward(defer=accum)
+        self._micro += 1
+        last = (not accum) or self._micro % accum_steps == 0
+        # accumulation window: the micro-steps before the last only accumulate; the LAST one reduces bucket by bucket from its gradient
+        # hooks like an ordinary step (a bucket that is complete in the last micro-step holds the sum of the whole window), so the
+        # window's reduction overlaps that backward instead of running behind it
+        self.reducer.prepare_backward(defer=accum and not last, closing=accum and last)
         loss_dict = model(batch, task=task, compute_loss=True)
         loss = sum(loss_dict.values())
         (loss / accum_steps if accum else loss).backward()
-        self._micro += 1
-        last = (not accum) or self._micro % accum_steps == 0
         active = self.reducer.finish_backward(last=last)
         if not last:
             loss_dict["total_loss"] = loss.detach()
@@ -94,7 +97,11 @@ class TrainEngine:
         return loss_dict
 
     def reserve_headroom(self, mb=None):
-        """grow the caching allocator's pools by `mb` MiB of free segments now (see __init__); returns the bytes reserved"""
+        """grow the caching allocator's pools by `mb` MiB of free segments now (see __init__); returns the bytes reserved. A pure
+        optimisation: the request is clamped to a quarter of the device memory that is free right now (a configuration that fills HBM
+        -- VALOR-large at 16 frames holds 182-191 GB -- must not be pushed over the edge by head-room it does not need), and an
+        out-of-memory answer to any of the allocations skips the reservation instead of ending the step: in data parallel one rank
+        dying here while the others continue would hang the next collective."""
         self._headroom_done = True
         mb = self.alloc_headroom_mb if mb is None else mb
         dev = self.model.arena.flat.device
@@ -102,11 +109,33 @@ class TrainEngine:
             return 0
         from . import streams
         before = torch.cuda.memory_reserved(dev)
+        cs = streams.compute_streams(dev)
+        free_mb = torch.cuda.mem_get_info(dev)[0] >> 20
+        mb = min(mb, free_mb // (4 * max(len(cs), 1)))
+        if mb < 64:
+            return 0
         # the caching allocator keeps one free list PER STREAM: the late growth happens on the encoders' side stream as well as on the
         # step's stream (the first version reserved on the current stream only and two 172 MiB segments still appeared)
-        for st in streams.compute_streams(dev):
+        for st in cs:
             with torch.cuda.stream(st):
-                blocks = [torch.empty(mb << 20, dtype=torch.uint8, device=dev)]
-                blocks += [torch.empty(1 << 20, dtype=torch.uint8, device=dev) for _ in range(16)]        # small pool (requests <= 1 MiB): 2 MiB segments
+                try:
+                    blocks = [torch.empty(mb << 20, dtype=torch.uint8, device=dev)]
+                    blocks += [torch.empty(1 << 20, dtype=torch.uint8, device=dev) for _ in range(16)]    # small pool (requests <= 1 MiB): 2 MiB segments
+                except torch.cuda.OutOfMemoryError:
+                    blocks = None
+                    break
                 del blocks
         return torch.cuda.memory_reserved(dev) - before
+
+    def close(self):
+        """release what the engine holds outside the Python heap: the native reducer's communicator / stream / events (dist.Reducer.close);
+        idempotent, also run when the engine is collected"""
+        r = getattr(self, "reducer", None)
+        if r is not None:
+            r.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -243,6 +243,19 @@ def _xattn_domain(segs, k, kv_bmod):
     return not (nsub > 10 or any(sg["q"].shape[0] % kv_bmod for sg in segs) or os.environ.get("VALOR_ATTN_XFUSED", "1") == "0")
 
 
+def _xattn_call(name, *args):
+    """the fused cross-attention entries validate their own domain (strides that are multiples of 8 elements, 16-byte bases, < 2 GiB
+    per operand, <= ten 16-row query sub-tiles, the VALOR_ATTN_XFUSED switch as the C side parses it) and answer VALOR_ERR_ARG (-1)
+    BEFORE anything is launched when a call falls outside it: that is "not covered" (False -> the caller runs the per-pass kernels),
+    not a failure. Every other non-zero code is one."""
+    rc = getattr(lib.load(), name)(*args)
+    if rc == -1:
+        return False
+    if rc != 0:
+        raise lib.ValorHipError(f"{name} failed with code {rc}")
+    return True
+
+
 def cross_attn_fwd_fused(segs, k, v, n_heads, kv_bmod, *, scale=0.125, p_drop=0.0):
     """Forward of up to two decoder passes that attend to the same K|V in ONE launch (csrc/attention_xu.hip): K, V read once.
     segs: list of dict(q, o [B, T, E] views, lse [B, H, T], kv_range int32 [B, 2] or None, seed, offset); o and lse are written.
@@ -252,9 +265,8 @@ def cross_attn_fwd_fused(segs, k, v, n_heads, kv_bmod, *, scale=0.125, p_drop=0.
     import ctypes
     arr = _xattn_segs(segs, kv_bmod, False)
     kb, kr = _bsr(k); vb, vr = _bsr(v)
-    lib.call("valor_cross_attn_fwd_fused", _stream(), DT_BF16, ctypes.cast(arr, ctypes.c_void_p), len(segs), _ptr(k), _ptr(v),
-             n_heads, k.shape[1], int(kv_bmod), kb, kr, vb, vr, float(scale), float(p_drop))
-    return True
+    return _xattn_call("valor_cross_attn_fwd_fused", _stream(), DT_BF16, ctypes.cast(arr, ctypes.c_void_p), len(segs), _ptr(k), _ptr(v),
+                       n_heads, k.shape[1], int(kv_bmod), kb, kr, vb, vr, float(scale), float(p_drop))
 
 
 def cross_attn_bwd_fused(segs, k, v, dk, dv, n_heads, kv_bmod, *, scale=0.125, p_drop=0.0):
@@ -266,9 +278,8 @@ def cross_attn_bwd_fused(segs, k, v, dk, dv, n_heads, kv_bmod, *, scale=0.125, p
     arr = _xattn_segs(segs, kv_bmod, True)
     kb, kr = _bsr(k); vb, vr = _bsr(v); dkb, dkr = _bsr(dk); dvb, dvr = _bsr(dv)
     import ctypes
-    lib.call("valor_cross_attn_bwd_fused", _stream(), DT_BF16, ctypes.cast(arr, ctypes.c_void_p), len(segs), _ptr(k), _ptr(v), _ptr(dk), _ptr(dv),
-             n_heads, k.shape[1], int(kv_bmod), kb, kr, vb, vr, dkb, dkr, dvb, dvr, float(scale), float(p_drop))
-    return True
+    return _xattn_call("valor_cross_attn_bwd_fused", _stream(), DT_BF16, ctypes.cast(arr, ctypes.c_void_p), len(segs), _ptr(k), _ptr(v), _ptr(dk),
+                       _ptr(dv), n_heads, k.shape[1], int(kv_bmod), kb, kr, vb, vr, dkb, dkr, dvb, dvr, float(scale), float(p_drop))
 
 
 # ---------------------------------------------------------------------------------------------- VideoSwin

@@ -143,7 +143,12 @@ class VALOR(nn.Module):
             raise NotImplementedError("cross_attn_type='va_concate' only")
         # pretrain.py:79: the caption rows become [tokens | as many [MASK]s], position L/2 + i predicts token i + 1 (the finetune losses; generation
         # ignores the flag like the reference's, :878-900)
-        self.full_masker = bool(_opt(opts, "full_masker", False)) and _opt(opts, "caption_type", "unimlm") == "unimlm"
+        self.full_masker = bool(_opt(opts, "full_masker", False))
+        if self.full_masker and _opt(opts, "caption_type", "unimlm") != "unimlm":
+            # the reference still passes full_masker into the decoder's mask and positions when caption_type is 'lm' (pretrain.py:835,1276)
+            # while its rows are NOT doubled there (:808, :1226 sit in the 'unimlm' branch): a combination no shipped config uses. Refused
+            # loudly instead of dropping the flag silently.
+            raise NotImplementedError("full_masker with caption_type='lm' is not supported (no shipped configuration combines them)")
         self._full_attn = False           # full_masker attention / positions for the decoder passes being issued (forward_cap / forward_qa)
         if _opt(opts, "fineweight_type", "one") == "none":
             raise NotImplementedError("fineweight_type='none' is a TypeError in the reference too (pretrain.py:330)")
@@ -974,7 +979,10 @@ class VALOR(nn.Module):
         if caption_task and self.full_masker and not self._full_attn:
             # forward_pt builds the doubled rows (pretrain.py:425-426) but slices the 'tv' / 'ta' outputs with the ORIGINAL length against the
             # doubled labels (:454, :466): an IndexError in the reference. Only the finetune paths (forward_cap / forward_qa) work with it.
-            raise NotImplementedError("full_masker with a pretraining caption task fails in the reference too (model/pretrain.py:454); use it with 'cap%..' / 'qa%..'")
+            # (A caption task of 'tva' ONLY does run in the reference -- its tv / ta slices are what fails; that one case is refused here too.)
+            raise NotImplementedError("full_masker with a pretraining caption task fails in the reference too (model/pretrain.py:454, the tv / ta "
+                                      "slices; a 'tva'-only caption task is the one case the reference runs and this model refuses); "
+                                      "use it with 'cap%..' / 'qa%..'")
         if caption_task or mlm_task:
             txt = txt_tokens["bert_tokens"].cpu()
             if caption_task:

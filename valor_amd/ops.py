@@ -275,7 +275,12 @@ class BdrLnFn(Function):
         sinks = (_sink(pg) if dy_eff is not None else None, _sink(pbeta) if dy_eff is not None else None, _sink(pbias))
         dx, dres, dg, dbeta, dbias = K.bdrln_bwd(dy_eff, dz_in, z_e, mean_e, rstd_e, gamma, p_drop=p_drop, seed=seed,
                                                  offset=off, want_dgamma=gamma is not None, want_dbeta=has_beta,
-                                                 want_dbias=has_b, sinks=sinks, row_scale=ctx.rs[0], rows_per_scale=ctx.rs[1])
+                                                 want_dbias=has_b, sinks=sinks, row_scale=ctx.rs[0], rows_per_scale=ctx.rs[1],
+                                                 separate_dx=has_r and ctx.res_slot is not None)
+        # separate_dx: without dropout / row scale the kernel returns ONE tensor as dx and dres. With a res_slot the residual's other
+        # consumer accumulates into dres in its own kernel (C +=) while dx is still the incoming gradient of x's producer -- the same
+        # memory if they alias (a one-GEMM sub-layer would read dY from the buffer it accumulates dX into). Two tensors, always.
+        assert not (has_r and ctx.res_slot is not None) or dx.data_ptr() != dres.data_ptr()
         for prm, sk, want in ((pg, sinks[0], gamma is not None), (pbeta, sinks[1], has_beta), (pbias, sinks[2], has_b)):
             if sk is not None and want:
                 _sunk(prm)
