@@ -297,6 +297,8 @@ def main():
     ap.add_argument("--frames", type=int, default=8)
     ap.add_argument("--audio-slices", type=int, default=2)
     ap.add_argument("--dropout", type=float, default=0.1)
+    ap.add_argument("--graphs", type=int, default=int(os.environ.get("VALOR_GRAPHS", "0")), help="1 = the CLIP ViT / AST encoders replay hipGraphs "
+                    "(valor_amd/graphs.py: forward + backward captured on their third step; dropout offsets from a device-resident counter)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--accum", type=int, default=1, help="micro-steps per optimizer step (gradient accumulation, train_utils.py:311-317): the per-GPU batch of "
                     "a step is --batch x --accum. BASELINE configs[4] (VALOR-large, 16 frames, global batch 1024 = 128 per GPU) runs as "
@@ -356,7 +358,7 @@ def main():
     model.load_state_dict(sd, strict=True)
     opts = SimpleNamespace(learning_rate=1e-4, weight_decay=0.01, clip_lr=5e-7, clip_lr_text=5e-7, new_lr=0.0, decoder_lr=-1,
                            betas=[0.9, 0.98], warmup_ratio=0.1, num_train_steps=100000, scheduler="warmup_linear", grad_norm=5.0)
-    engine = TrainEngine(model, opts)
+    engine = TrainEngine(model, opts, graphs=bool(args.graphs))
     engine.optimizer.init_master_from(sd)
     del sd
     batch = synth.make_batch(spec, batch=args.batch, frames=args.frames, audio_slices=args.audio_slices, txt_len=32, seed=50 + rank)
@@ -479,7 +481,7 @@ def main():
                "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 2), "higher_is_better": True,
                "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
                "ranks": torch.distributed.get_world_size() if world > 1 else 1, "backend": backend,
-               "replicas_identical": replicas_identical, "reduce_mode": engine.reducer.mode,
+               "replicas_identical": replicas_identical, "reduce_mode": engine.reducer.mode, "graphs": bool(args.graphs),
                "rccl_version": ".".join(str(x) for x in torch.cuda.nccl.version()) if hasattr(torch.cuda, "nccl") else None,
                "config": {"workload": f"{size} tri-modal ({arch}) pretrain step, MGA+MGC+MLM, "
                                       f"{args.frames} frames x 224^2, {args.audio_slices} x 5.12 s audio, 32 tokens",

@@ -21,7 +21,11 @@
  *     parity-tested kernel family computing the same function, so a concurrent change can alter speed, never results beyond
  *     rounding.
  *   - dropout masks are Philox4x32-10 streams keyed by (seed, offset + element index / 4) and are regenerated
- *     in backward from the same (seed, offset) -- nothing is stored.
+ *     in backward from the same (seed, offset) -- nothing is stored. Every dropout entry point also takes `rng_base`: NULL, or a
+ *     DEVICE pointer to one uint64 that the kernel adds to `offset` when it runs (forward and backward of a step must see the same
+ *     value). By-value arguments are baked into a captured hipGraph; with the device-resident term the caller bumps one counter
+ *     per step (any kernel / memset node ahead of the step) and every replay of the graph draws fresh masks
+ *     (train_utils.py:309: the reference advances torch's global generator once per dropout call).
  */
 #ifndef VALOR_HIP_H
 #define VALOR_HIP_H
@@ -98,7 +102,14 @@ int valor_gemm_set_fast_epilogue(int v);
  *          0 = never, 1 = every eligible problem, 2 = only problems the keys above leave to the 128x128 kernels, 3 = only problems they
  *          send to the 256x256 kernel, 1000 (default) = measured per-class choice: forward / dgrad problems that
  *          would run on the 128x128 kernels or have K <= 1024
- *   keys 9 .. 11: reserved */
+ *   key 9: family 4, NN layout (forward GEMMs): 1 = main loop on v_mfma_f32_32x32x16_bf16 (32-row fragments, another LDS swizzle; same
+ *          results up to the order of the fp32 partial sums), 0 (default) = v_mfma_f32_16x16x32_bf16 (env VALOR_GEMM_MFMA32); measured
+ *          0-8 % SLOWER on the K = 768 forward shapes under the pipelined schedule, equal under the plain one and at K = 3072
+ *          (profiles/r05_gemm_mfma32_ab.json)
+ *   key 10: family 4: 1 = a forward that saves act'(u) beside act(u) writes BOTH outputs through the bf16 half-tile epilogue (one
+ *          evaluation of the activation, 16-byte stores), 0 (default) = through the general two-pass fp32 epilogue (env VALOR_GEMM_TWO_OUT);
+ *          measured 5-9 % slower than the general epilogue on every shape (profiles/r05_gemm_mfma32_ab.json), kept for A/B runs
+ *   key 11: reserved */
 int valor_gemm_set_policy(int key, int value);
 /* K-loop schedule of the family-3 (256x256) kernel: 0 = eight barriers per K-tile, wave rows staggered by one barrier; 1 = software-pipelined:
  * two barriers per K-tile, fragment reads and LDS-DMA pieces between the MFMAs of the half-phase before their consumer. Same results (same
@@ -133,10 +144,11 @@ typedef struct valor_xattn_seg {
  * writes o ([B, Sq, H*64] view, strides o_bs / o_rs) and lse; dout / dq of the descriptors are ignored. Same domain and fallback rule
  * (valor_attn_fwd per pass) as the backward; the dropout keep pattern is the one valor_attn_fwd draws for (seed, offset). */
 int valor_cross_attn_fwd_fused(void* stream, int dtype, const valor_xattn_seg* segs, int nseg, const void* k, const void* v, int H, int Skv,
-                               int kv_bmod, int64_t k_bs, int64_t k_rs, int64_t v_bs, int64_t v_rs, float scale, float p_drop);
+                               int kv_bmod, int64_t k_bs, int64_t k_rs, int64_t v_bs, int64_t v_rs, float scale, float p_drop,
+                               const uint64_t* rng_base);
 int valor_cross_attn_bwd_fused(void* stream, int dtype, const valor_xattn_seg* segs, int nseg, const void* k, const void* v, void* dk, void* dv,
                                int H, int Skv, int kv_bmod, int64_t k_bs, int64_t k_rs, int64_t v_bs, int64_t v_rs, int64_t dk_bs,
-                               int64_t dk_rs, int64_t dv_bs, int64_t dv_rs, float scale, float p_drop);
+                               int64_t dk_rs, int64_t dv_bs, int64_t dv_rs, float scale, float p_drop, const uint64_t* rng_base);
 
 /* ---- fused bias + dropout + residual + LayerNorm.  Replaces apex FusedLayerNorm (apex/csrc/layer_norm_cuda_kernel.cu
  * :279-322 forward, :403-634 backward; wrapper apex/apex/normalization/fused_layer_norm.py:14-37) plus the elementwise ops
@@ -159,13 +171,14 @@ int valor_ln_set_variant(int v);
 int valor_ln_set_nt(int v);
 int valor_bdrln_fwd(void* stream, int dtype, const void* x, const void* bias, const void* residual, const void* gamma,
                     const void* beta, void* z, void* y, float* mean, float* rstd, int64_t rows, int cols, float eps,
-                    float p_drop, uint64_t seed, uint64_t offset, const float* row_scale, int64_t rows_per_scale);
+                    float p_drop, uint64_t seed, uint64_t offset, const float* row_scale, int64_t rows_per_scale,
+                    const uint64_t* rng_base);
 /* backward: dz = LN'(dy) + dz_in -> dres ; dx = dz * dropmask/(1-p). part_*: fp32 [valor_ln_part_blocks() * cols]
  * per-workgroup column partials of dgamma / dbeta / dbias (finish with valor_colsum_finalize). */
 int valor_bdrln_bwd(void* stream, int dtype, const void* dy, const void* dz_in, const void* z, const float* mean,
                     const float* rstd, const void* gamma, void* dx, void* dres, float* part_dgamma, float* part_dbeta,
                     float* part_dbias, int64_t rows, int cols, float p_drop, uint64_t seed, uint64_t offset, const float* row_scale,
-                    int64_t rows_per_scale);
+                    int64_t rows_per_scale, const uint64_t* rng_base);
 int valor_colsum_finalize(void* stream, int dtype, const float* part, int nparts, int cols, void* out, int out_f32,
                           int accumulate);
 /* up to three finalizations in ONE launch (NULL part = skip): dgamma / dbeta / dbias of valor_bdrln_bwd */
@@ -196,14 +209,16 @@ int valor_attn_set_res_pipeline(int v);
 int valor_attn_fwd(void* stream, int dtype, const void* q, const void* k, const void* v, void* o, float* lse, int B,
                    int H, int Sq, int Skv, int64_t q_bs, int64_t q_rs, int64_t k_bs, int64_t k_rs, int64_t v_bs,
                    int64_t v_rs, int64_t o_bs, int64_t o_rs, const float* mask, int64_t mask_bs, int64_t mask_rs,
-                   const int* kv_range, int kv_bmod, float scale, float p_drop, uint64_t seed, uint64_t offset);
+                   const int* kv_range, int kv_bmod, float scale, float p_drop, uint64_t seed, uint64_t offset,
+                   const uint64_t* rng_base);
 /* accumulate_dkdv != 0: dk/dv += (several query passes share one K/V set; gradients meet in one buffer) */
 int valor_attn_bwd(void* stream, int dtype, const void* q, const void* k, const void* v, const void* o, const float* lse,
                    const void* dout, void* dq, void* dk, void* dv, float* delta, int B, int H, int Sq, int Skv,
                    int64_t q_bs, int64_t q_rs, int64_t k_bs, int64_t k_rs, int64_t v_bs, int64_t v_rs, int64_t o_bs,
                    int64_t o_rs, int64_t do_bs, int64_t do_rs, int64_t dq_bs, int64_t dq_rs, int64_t dk_bs, int64_t dk_rs,
                    int64_t dv_bs, int64_t dv_rs, const float* mask, int64_t mask_bs, int64_t mask_rs, const int* kv_range,
-                   int kv_bmod, float scale, float p_drop, uint64_t seed, uint64_t offset, int accumulate_dkdv);
+                   int kv_bmod, float scale, float p_drop, uint64_t seed, uint64_t offset, int accumulate_dkdv,
+                   const uint64_t* rng_base);
 
 /* ---- VideoSwin 3-D shifted-window attention, head_dim 32 (videoswin.py:137-163 with the roll / window_partition /
  * window_reverse around it :205-220, relative position bias :146-148, shift mask :150-154,272-285), in place on the fused QKV

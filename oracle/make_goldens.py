@@ -140,6 +140,9 @@ FIXTURES = {
     # (videoswin.py:196-223), the shift-mask regions along time
     "ref_base_b2f16a2_q": dict(batch_size=2, frames=16, audio_slices=2, wseed=71, bseed=72, mseed=73, bf16_exact=True),
     "ref_swin_b2f16a2_q": dict(batch_size=2, frames=16, audio_slices=2, wseed=71, bseed=72, mseed=73, bf16_exact=True, variant="swin"),
+    # the same clip length at B = 8 for the bf16 comparison: the B = 2 fixture's 2 x 2 InfoNCE matrix is the worst case for the RELATIVE
+    # contrastive tolerance (see ref_base_b16f2a1_q above; bf16 measured 1.29e-3 on ref_base_b2f16a2_q), B = 8 is held to the 1e-3
+    "ref_base_b8f16a2_q": dict(batch_size=8, frames=16, audio_slices=2, wseed=81, bseed=82, mseed=83, bf16_exact=True, steps=1),
     "ref_cliplarge_b8f2a1_q": dict(batch_size=8, frames=2, audio_slices=1, wseed=61, bseed=62, mseed=63, bf16_exact=True, steps=1, variant="clip_large"),
 }
 

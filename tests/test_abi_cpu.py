@@ -52,7 +52,7 @@ def test_argument_validation_without_gpu():
     so = lib.load()
     assert so.valor_gemm(None, 0, 0, 0, 4, 4, 8, None, 8, None, 8, None, 4, None, 0, None, None, 0, 1.0, 0, 0, None, 0, None, 0) == -1
     assert so.valor_gemm(None, 0, 0, 0, 0, 4, 8, None, 8, None, 8, None, 4, None, 0, None, None, 0, 1.0, 0, 0, None, 0, None, 0) == 0   # M = 0: no-op
-    assert so.valor_bdrln_fwd(None, 0, None, None, None, None, None, None, None, None, None, 4, 768, 1e-5, 0.0, 0, 0, None, 0) == -1
+    assert so.valor_bdrln_fwd(None, 0, None, None, None, None, None, None, None, None, None, 4, 768, 1e-5, 0.0, 0, 0, None, 0, None) == -1
     # round-4 entries: the native reducer, the smoothed cross-entropy, the one-launch cross-attention
     import ctypes
     assert so.valor_reducer_unique_id(None) == -1 and so.valor_reducer_destroy(None) == 0
@@ -64,8 +64,8 @@ def test_argument_validation_without_gpu():
     assert so.valor_xent_smooth_fwd(None, 1, buf, lab, buf, buf, 4, 16, 16, 1.5) == -1            # smoothing outside [0, 1)
     assert so.valor_xent_smooth_bwd(None, 1, buf, lab, buf, None, 1.0, 4, 1, 16, 0.1) == -1       # smoothing needs V > 1
     assert so.valor_xent_smooth_fwd(None, 1, buf, lab, buf, buf, 0, 16, 16, 0.1) == 0             # no rows: no-op
-    assert so.valor_cross_attn_fwd_fused(None, 0, None, 1, buf, buf, 1, 128, 1, 0, 64, 0, 64, 0.125, 0.0) == -1      # no segments
-    assert so.valor_cross_attn_bwd_fused(None, 0, None, 3, buf, buf, buf, buf, 1, 128, 1, 0, 64, 0, 64, 0, 64, 0, 64, 0.125, 0.0) == -1
+    assert so.valor_cross_attn_fwd_fused(None, 0, None, 1, buf, buf, 1, 128, 1, 0, 64, 0, 64, 0.125, 0.0, None) == -1      # no segments
+    assert so.valor_cross_attn_bwd_fused(None, 0, None, 3, buf, buf, buf, buf, 1, 128, 1, 0, 64, 0, 64, 0, 64, 0, 64, 0.125, 0.0, None) == -1
 
 
 @pytest.mark.skipif(torch.cuda.is_available(), reason="CPU-only check")

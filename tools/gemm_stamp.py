@@ -1,4 +1,4 @@
-"""Per-wave cycle stamps of the family-4 GEMM (diagnostic library built by tools/build_stamp_lib.sh, loaded through VALOR_HIP_LIB):
+"""Per-wave cycle stamps of the family-4 GEMM (diagnostic library built by tools/build_stamp_lib.sh, loaded through VALOR_HIP_LIB; SCHED=0/1 picks the schedule, MFMA32=1 the 32 x 32 x 16 main loop of the NN layout):
 where a 256 x 128 tile's life goes -- prologue (launch -> first operands landed), K loop, drain, epilogue -- and how the two workgroups
 of a CU overlap. usage: VALOR_HIP_LIB=valor_amd/libvalor_hip_stamp.so python tools/gemm_stamp.py M N K ta tb [out.json]"""
 import json
@@ -16,6 +16,7 @@ dev = torch.device("cuda:0")
 so = lib.load()
 so.valor_gemm_set_policy(8, 1)
 so.valor_gemm_set_narrow_sched(int(os.environ.get("SCHED", "1")))
+so.valor_gemm_set_policy(9, int(os.environ.get("MFMA32", "0")))       # NN layout: main loop on v_mfma_f32_32x32x16_bf16
 A = torch.randn((Kd, M) if ta else (M, Kd), device=dev).bfloat16()
 B = (0.05 * torch.randn((Kd, N) if tb else (N, Kd), device=dev)).bfloat16()
 out = torch.empty((M, N), dtype=torch.bfloat16, device=dev)

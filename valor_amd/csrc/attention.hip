@@ -125,7 +125,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs p) {
 
     const uint32_t thr = drop_threshold(p.p_drop);
     const float keep_scale = p.p_drop > 0.f ? 1.0f / (1.0f - p.p_drop) : 1.0f;
-    const uint32_t hk = attn_drop_headkey(p.seed, p.offset, b * p.H + h);
+    const uint32_t hk = attn_drop_headkey(p.seed, rng_offset(p.offset, p.rng_base), b * p.H + h);
 
     Stage64<T> st[NIMG];
     auto issue = [&](int kv0) {
@@ -293,7 +293,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnArgs p) {
 
     const uint32_t thr = drop_threshold(p.p_drop);
     const float keep_scale = p.p_drop > 0.f ? 1.0f / (1.0f - p.p_drop) : 1.0f;
-    const uint32_t hk = attn_drop_headkey(p.seed, p.offset, b * p.H + h);
+    const uint32_t hk = attn_drop_headkey(p.seed, rng_offset(p.offset, p.rng_base), b * p.H + h);
     const float* mrowp = (p.mask && qok) ? p.mask + (int64_t)b * p.mask_bs + (int64_t)qr * p.mask_rs : nullptr;
 
     Stage64<T> st[NIMG];
@@ -504,7 +504,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnArgs p) {
                     float dp = pacc[r];
                     pdv = pr;
                     if (thr) {
-                        const bool keep = attn_drop_bits(attn_drop_headkey(p.seed, p.offset, b * p.H + h), (uint32_t)qr * (uint32_t)p.Skv + (uint32_t)key_loc) >= thr;
+                        const bool keep = attn_drop_bits(attn_drop_headkey(p.seed, rng_offset(p.offset, p.rng_base), b * p.H + h), (uint32_t)qr * (uint32_t)p.Skv + (uint32_t)key_loc) >= thr;
                         dp = keep ? dp * keep_scale : 0.f;
                         pdv = keep ? pr * keep_scale : 0.f;
                     }
@@ -611,13 +611,13 @@ extern "C" int valor_attn_fwd(void* stream, int dtype, const void* q, const void
                               int B, int H, int Sq, int Skv, int64_t q_bs, int64_t q_rs, int64_t k_bs, int64_t k_rs,
                               int64_t v_bs, int64_t v_rs, int64_t o_bs, int64_t o_rs, const float* mask, int64_t mask_bs,
                               int64_t mask_rs, const int* kv_range, int kv_bmod, float scale, float p_drop,
-                              uint64_t seed, uint64_t offset) {
+                              uint64_t seed, uint64_t offset, const uint64_t* rng_base) {
     AttnArgs p = {};
     p.q = q; p.k = k; p.v = v; p.o = o; p.lse = lse; p.mask = mask; p.kv_range = kv_range;
     p.B = B; p.H = H; p.Sq = Sq; p.Skv = Skv;
     p.q_bs = q_bs; p.q_rs = q_rs; p.k_bs = k_bs; p.k_rs = k_rs; p.v_bs = v_bs; p.v_rs = v_rs; p.o_bs = o_bs; p.o_rs = o_rs;
     p.mask_bs = mask_bs; p.mask_rs = mask_rs; p.kv_bmod = kv_bmod; p.scale = scale; p.p_drop = p_drop;
-    p.seed = seed; p.offset = offset;
+    p.seed = seed; p.offset = offset; p.rng_base = rng_base;
     int rc = attn_check(p, dtype);
     if (rc) return rc;
     if (!q || !k || !v || !o) return VALOR_ERR_ARG;
@@ -635,7 +635,7 @@ extern "C" int valor_attn_bwd(void* stream, int dtype, const void* q, const void
                               int64_t v_bs, int64_t v_rs, int64_t o_bs, int64_t o_rs, int64_t do_bs, int64_t do_rs,
                               int64_t dq_bs, int64_t dq_rs, int64_t dk_bs, int64_t dk_rs, int64_t dv_bs, int64_t dv_rs,
                               const float* mask, int64_t mask_bs, int64_t mask_rs, const int* kv_range, int kv_bmod,
-                              float scale, float p_drop, uint64_t seed, uint64_t offset, int accumulate_dkdv) {
+                              float scale, float p_drop, uint64_t seed, uint64_t offset, int accumulate_dkdv, const uint64_t* rng_base) {
     AttnArgs p = {};
     p.acc_dkv = accumulate_dkdv;
     p.q = q; p.k = k; p.v = v; p.o = (void*)o; p.lse = (float*)lse; p.dout = dout; p.dq = dq; p.dk = dk; p.dv = dv;
@@ -645,7 +645,7 @@ extern "C" int valor_attn_bwd(void* stream, int dtype, const void* q, const void
     p.do_bs = do_bs; p.do_rs = do_rs; p.dq_bs = dq_bs; p.dq_rs = dq_rs; p.dk_bs = dk_bs; p.dk_rs = dk_rs;
     p.dv_bs = dv_bs; p.dv_rs = dv_rs;
     p.mask_bs = mask_bs; p.mask_rs = mask_rs; p.kv_bmod = kv_bmod; p.scale = scale; p.p_drop = p_drop;
-    p.seed = seed; p.offset = offset;
+    p.seed = seed; p.offset = offset; p.rng_base = rng_base;
     int rc = attn_check(p, dtype);
     if (rc) return rc;
     const int vec = dtype == VALOR_DT_BF16 ? 8 : 4;

@@ -55,7 +55,7 @@ __global__ __launch_bounds__(256, 3) void attn_res_fwd_kernel(AttnArgs p) {
     const float sl2 = p.scale * LOG2E_F;
     const uint32_t thr = drop_threshold(p.p_drop);
     const float keep_scale = p.p_drop > 0.f ? 1.0f / (1.0f - p.p_drop) : 1.0f;
-    const uint32_t hk = attn_drop_headkey(p.seed, p.offset, b * p.H + h);
+    const uint32_t hk = attn_drop_headkey(p.seed, rng_offset(p.offset, p.rng_base), b * p.H + h);
     int troff[4];
 #pragma unroll
     for (int dt = 0; dt < 4; ++dt) troff[dt] = tr_lane_off(lane, dt);
@@ -231,7 +231,7 @@ DEVINL void attn_res_bwd_body(const AttnArgs& p) {
     const float sl2 = p.scale * LOG2E_F;
     const uint32_t thr = drop_threshold(p.p_drop);
     const float keep_scale = p.p_drop > 0.f ? 1.0f / (1.0f - p.p_drop) : 1.0f;
-    const uint32_t hk = attn_drop_headkey(p.seed, p.offset, b * p.H + h);
+    const uint32_t hk = attn_drop_headkey(p.seed, rng_offset(p.offset, p.rng_base), b * p.H + h);
     int troff[4];
 #pragma unroll
     for (int dt = 0; dt < 4; ++dt) troff[dt] = tr_lane_off(lane, dt);
@@ -470,7 +470,7 @@ __global__ __launch_bounds__(512, 2) void attn_res_bwd_pipe_kernel(AttnArgs p, i
     }
     for (; item < n_items; item += gridDim.x) {
         const int h = item % p.H, b = item / p.H;
-        const uint32_t hk = attn_drop_headkey(p.seed, p.offset, b * p.H + h);
+        const uint32_t hk = attn_drop_headkey(p.seed, rng_offset(p.offset, p.rng_base), b * p.H + h);
         // ---------------- phase 1 operands: this wave's 32 query rows of Q / dO (fragments), O (for delta), lse
         bf16x8_t qf[2][2], dof[2][2];
         int qr[2];

@@ -144,7 +144,7 @@ __global__ __launch_bounds__(256, 2) void attn_x_fwd_kernel(AttnArgs p) {
                 mrow[u] = mnew;
                 float ps = 0.f;
                 const int qr = sq0_[u] + fr;
-                const uint32_t hk = attn_drop_headkey(p.seed, p.offset, sb_[u] * p.H + h);
+                const uint32_t hk = attn_drop_headkey(p.seed, rng_offset(p.offset, p.rng_base), sb_[u] * p.H + h);
                 const uint32_t rowbase = (uint32_t)qr * (uint32_t)p.Skv;
 #pragma unroll
                 for (int kt = 0; kt < 2; ++kt) {
@@ -354,7 +354,7 @@ __global__ __launch_bounds__(256, 2) void attn_x_bwd_kernel(AttnArgs p) {
                     }
                     const f32x4_t l4 = *(const f32x4_t*)(sLse + u * 16 + 4 * g);
                     const f32x4_t d4 = *(const f32x4_t*)(sDelta + u * 16 + 4 * g);
-                    const uint32_t hk = attn_drop_headkey(p.seed, p.offset, sb_[u] * p.H + h);
+                    const uint32_t hk = attn_drop_headkey(p.seed, rng_offset(p.offset, p.rng_base), sb_[u] * p.H + h);
                     const uint32_t row0 = (uint32_t)(sq0_[u] + 4 * g);
 #pragma unroll
                     for (int kt = 0; kt < 2; ++kt) {

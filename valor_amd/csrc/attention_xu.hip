@@ -34,6 +34,7 @@ struct XuArgs {
     int nseg, bmod, H, Skv;
     int n0, qs0, qs1, nsub;     // sub-tiles of segment 0, sub-tiles per group of each segment, total
     float scale, p_drop;
+    const uint64_t* rng_base;   // device-resident term of every segment's dropout offset (common.h rng_offset) or null
 };
 
 DEVINL float xu_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
@@ -195,7 +196,7 @@ __global__ __launch_bounds__(256, 2) void attn_xu_bwd_kernel(XuArgs p) {
                     uint32_t hk = 0;
                     if (DROP) {
                         const XuSeg& sg = sg_[u] ? p.s[1] : p.s[0];
-                        hk = attn_drop_headkey(sg.seed, sg.offset, sb_[u] * p.H + h);
+                        hk = attn_drop_headkey(sg.seed, rng_offset(sg.offset, p.rng_base), sb_[u] * p.H + h);
                     }
                     const uint32_t row0 = (uint32_t)(sq0_[u] + 4 * g);
                     f32x4_t pdv, dsv;
@@ -395,7 +396,7 @@ __global__ __launch_bounds__(256, 2) void attn_xu_fwd_kernel(XuArgs p) {
             uint32_t hk = 0;
             if (DROP) {
                 const XuSeg& sg = sg_[u] ? p.s[1] : p.s[0];
-                hk = attn_drop_headkey(sg.seed, sg.offset, sb_[u] * p.H + h);
+                hk = attn_drop_headkey(sg.seed, rng_offset(sg.offset, p.rng_base), sb_[u] * p.H + h);
             }
             const uint32_t rowbase = (uint32_t)(sq0_[u] + fr) * (uint32_t)p.Skv;
 #pragma unroll
@@ -497,10 +498,12 @@ static int xu_fill(XuArgs& p, int dtype, const void* segs_, int nseg, const void
 }
 
 extern "C" int valor_cross_attn_fwd_fused(void* stream, int dtype, const void* segs, int nseg, const void* k, const void* v, int H, int Skv,
-                                          int kv_bmod, int64_t k_bs, int64_t k_rs, int64_t v_bs, int64_t v_rs, float scale, float p_drop) {
+                                          int kv_bmod, int64_t k_bs, int64_t k_rs, int64_t v_bs, int64_t v_rs, float scale, float p_drop,
+                                          const uint64_t* rng_base) {
     XuArgs p = {};
     const int rc = xu_fill(p, dtype, segs, nseg, k, v, H, Skv, kv_bmod, k_bs, k_rs, v_bs, v_rs, scale, p_drop, false);
     if (rc != VALOR_OK) return rc;
+    p.rng_base = rng_base;
     hipStream_t st = (hipStream_t)stream;
     dim3 grid(H, kv_bmod);
     const int nsub = p.nsub;
@@ -523,12 +526,12 @@ extern "C" int valor_cross_attn_fwd_fused(void* stream, int dtype, const void* s
 
 extern "C" int valor_cross_attn_bwd_fused(void* stream, int dtype, const void* segs, int nseg, const void* k, const void* v, void* dk, void* dv,
                                           int H, int Skv, int kv_bmod, int64_t k_bs, int64_t k_rs, int64_t v_bs, int64_t v_rs, int64_t dk_bs,
-                                          int64_t dk_rs, int64_t dv_bs, int64_t dv_rs, float scale, float p_drop) {
+                                          int64_t dk_rs, int64_t dv_bs, int64_t dv_rs, float scale, float p_drop, const uint64_t* rng_base) {
     if (!dk || !dv || (dk_rs & 3) || (dv_rs & 3) || (dk_bs & 3) || (dv_bs & 3)) return VALOR_ERR_ARG;
     XuArgs p = {};
     const int rc = xu_fill(p, dtype, segs, nseg, k, v, H, Skv, kv_bmod, k_bs, k_rs, v_bs, v_rs, scale, p_drop, true);
     if (rc != VALOR_OK) return rc;
-    p.dk = dk; p.dv = dv;
+    p.dk = dk; p.dv = dv; p.rng_base = rng_base;
     p.dk_bs = dk_bs; p.dk_rs = dk_rs; p.dv_bs = dv_bs; p.dv_rs = dv_rs;
     const int nsub = p.nsub;
     hipStream_t st = (hipStream_t)stream;

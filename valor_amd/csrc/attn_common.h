@@ -19,6 +19,7 @@ struct AttnArgs {
     int acc_dkv;          // backward: dK/dV += (the K/V set is shared by several passes; their gradients meet in one buffer)
     float scale, p_drop;
     uint64_t seed, offset;
+    const uint64_t* rng_base;     // device-resident term of the dropout offset (common.h rng_offset) or null
 };
 
 template <typename T> DEVINL float fexp(float x);

@@ -19,6 +19,7 @@ typedef __bf16 bf16_t;
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
 typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4_t;
 typedef __attribute__((ext_vector_type(4))) float f32x4_t;
+typedef __attribute__((ext_vector_type(16))) float f32x16_t;
 typedef __attribute__((ext_vector_type(4))) uint32_t u32x4_t;
 typedef __attribute__((ext_vector_type(2))) uint32_t u32x2_t;
 
@@ -283,6 +284,13 @@ template <int N> DEVINL void act_bwd_mul_n(int act, float* v, const float* x) {
         default: break;
     }
 }
+
+// Dropout windows: the (seed, offset) pair of a launch comes BY VALUE from the host; `rng_base` (or null) points at ONE 64-bit counter in
+// device memory that is added to the offset when the kernel RUNS. A captured graph bakes its by-value arguments, so without the
+// device-side term every replay would redraw the masks of the step it was captured in; with it the host bumps the counter once per
+// step (one tiny kernel in front of the step) and every replay draws fresh, non-overlapping windows. Forward and backward of one step
+// read the same value.
+DEVINL uint64_t rng_offset(uint64_t offset, const uint64_t* rng_base) { return rng_base ? offset + *rng_base : offset; }
 
 // ---------------------------------------------------------------- launch check
 static inline int valor_launch_status() {

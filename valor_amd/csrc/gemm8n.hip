@@ -35,16 +35,34 @@
 #define N8_OFF_B (3 * N8_HT)
 #define N8_LDS (5 * N8_HT)
 
+// ---- M32: the main loop on v_mfma_f32_32x32x16_bf16 (k-contiguous operands only, i.e. the NN layout: forward GEMMs). A wave's 128x64
+// outputs are 4 x 2 tiles of 32 x 32 (16 accumulator registers each) instead of 8 x 4 tiles of 16 x 16: half the MFMA instructions per
+// FLOP (each twice as long), the same fragment bytes (a fragment is still one 16-byte LDS read per lane: lane l holds operand row l & 31,
+// k-octet l >> 5 of a 16-k step). A 32-row fragment read needs another image swizzle: the ds_read_b128 service groups {0-3, 12-15,
+// 20-27}, {4-11, 16-19, 28-31} (+32) take their 16 lanes from rows that repeat modulo 8, so `chunk ^ (row & 7)` is a 2-way bank
+// conflict; `chunk ^ ((row >> 1) & 7)` gives the 16 lanes of every group 16 distinct 16-byte slots of the 256-byte bank row. The
+// swizzle is applied to the LDS-DMA's per-lane SOURCE address as before (it now differs between the odd and even pieces of a wave).
+// Register slots keep their meaning (fa[MT][KK] / fb[NT][KK] = part of the wave's 64 rows / 32 columns x the 32-k half KK), so both
+// schedules are unchanged: slot fa[MT][KK] holds the 32-row block MT & 1 at 16-k step 2 KK + (MT >> 1), fb[NT][KK] the wave's 32
+// columns at step 2 KK + NT, and the MFMA of (MT, NT) exists when NT == MT >> 1 -- four per half-phase, no two consecutive ones on
+// the same accumulator. acc32[mh * 2 + mb][nh][4 q + r] = C[mh*128 + wm*64 + mb*32 + (l & 31)][nh*64 + wn*32 + 8 q + 4 (l >> 5) + r].
+DEVINL bf16x8_t n8_read_frag32(const char* tile, int row, int chunk) {
+    return *(const bf16x8_t*)(tile + row * TILE_ROW_BYTES + ((chunk ^ ((row >> 1) & 7)) << 4));
+}
+DEVINL f32x16_t n8_mma32(bf16x8_t a, bf16x8_t b, f32x16_t c) { return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0); }
+DEVINL f32x4_t n8_quad(const f32x16_t& a, int q) { return (f32x4_t){a[4 * q], a[4 * q + 1], a[4 * q + 2], a[4 * q + 3]}; }
+
 DEVINL bf16x8_t n8_read_frag_tr8(const char* img, int off, int kk) {
     const char* a = img + off + kk * (32 * 256);
     s16x4_t lo = lds_read_tr4(a), hi = lds_read_tr4(a + 4 * 256);
     return __builtin_bit_cast(bf16x8_t, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
 }
 
-template <bool TA, bool TB, bool ASMTR, bool NTS, int SCHED>
+template <bool TA, bool TB, bool ASMTR, bool NTS, int SCHED, bool M32>
 __global__ __launch_bounds__(256, 2) void gemm_8ph2_kernel(GemmArgs p) {
     typedef bf16_t T;
     constexpr int BK = 64;
+    static_assert(!M32 || (!TA && !TB), "the 32x32x16 main loop exists for k-contiguous operands");
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
     const int tid = threadIdx.x;
@@ -52,6 +70,7 @@ __global__ __launch_bounds__(256, 2) void gemm_8ph2_kernel(GemmArgs p) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 1, wn = wave & 1;
     const int fr = lane & 15, fg = lane >> 4;
+    const int l31 = lane & 31, lh = lane >> 5;
 
     const int tiles_n = (p.N + 127) >> 7;
     const int tiles_m = (p.M + 255) >> 8;
@@ -99,11 +118,18 @@ __global__ __launch_bounds__(256, 2) void gemm_8ph2_kernel(GemmArgs p) {
 #define N8_STAMP_AT(i)
 #define N8_HSTAMP(i)
 #endif
-    f32x4_t acc[8][4];   // [mh*4+mt][nh*2+nt]
+    f32x4_t acc[M32 ? 1 : 8][M32 ? 1 : 4];   // [mh*4+mt][nh*2+nt]
+    f32x16_t acc32[M32 ? 4 : 1][M32 ? 2 : 1];   // M32: [mh*2+mb][nh]
 #pragma unroll
-    for (int i = 0; i < 8; ++i)
+    for (int i = 0; i < (M32 ? 1 : 8); ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < (M32 ? 1 : 4); ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < (M32 ? 4 : 1); ++i)
+#pragma unroll
+        for (int j = 0; j < (M32 ? 2 : 1); ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc32[i][j][r] = 0.f;
 
     // fused row sums of A (TA only): the tile column 0 workgroups add  ones . A^T  on the matrix pipe, two 16-row blocks per wave
     // and row half (wave wn takes blocks mt = 2 wn, 2 wn + 1): 4 extra MFMAs in phases j0 and j2.
@@ -123,8 +149,15 @@ __global__ __launch_bounds__(256, 2) void gemm_8ph2_kernel(GemmArgs p) {
     {
         const int ldA_b = (int)(p.lda * 2), ldB_b = (int)(p.ldb * 2);
         if constexpr (!TA) {
-            const int r = wave * 32 + (lane >> 3), c = (lane & 7) ^ ((lane >> 3) & 7);
-            vA[0] = vA[1] = (m0 + r) * ldA_b + (k_first + c * 8) * 2;
+            // k-contiguous image: piece i of a wave = rows 32 w + 8 i + (lane >> 3); position lane & 7 of a row receives chunk
+            // position ^ swizzle(row). 16 x 16 fragments: swizzle = row & 7 (the same for every piece); M32: (row >> 1) & 7 =
+            // 4 (i & 1) + (lane >> 4). vA[h] serves the pieces with i & 1 == h.
+            const int r = wave * 32 + (lane >> 3);
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int c = (lane & 7) ^ (M32 ? 4 * h + (lane >> 4) : (lane >> 3) & 7);
+                vA[h] = (m0 + r) * ldA_b + (k_first + c * 8) * 2;
+            }
             pieceA = 8 * ldA_b; halfA = 128 * ldA_b; stepA = BK * 2;
         } else {
             const int k = wave * 16 + (lane >> 4), s = lane & 15;
@@ -136,8 +169,12 @@ __global__ __launch_bounds__(256, 2) void gemm_8ph2_kernel(GemmArgs p) {
             pieceA = 4 * ldA_b; halfA = 256; stepA = BK * ldA_b;
         }
         if constexpr (!TB) {
-            const int r = wave * 32 + (lane >> 3), c = (lane & 7) ^ ((lane >> 3) & 7);
-            vB[0] = vB[1] = (n0 + r) * ldB_b + (k_first + c * 8) * 2;
+            const int r = wave * 32 + (lane >> 3);
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int c = (lane & 7) ^ (M32 ? 4 * h + (lane >> 4) : (lane >> 3) & 7);
+                vB[h] = (n0 + r) * ldB_b + (k_first + c * 8) * 2;
+            }
             pieceB = 8 * ldB_b; stepB = BK * 2;
         } else {
             const int k = wave * 16 + (lane >> 4), s = lane & 15;
@@ -149,20 +186,24 @@ __global__ __launch_bounds__(256, 2) void gemm_8ph2_kernel(GemmArgs p) {
             pieceB = 4 * ldB_b; stepB = BK * ldB_b;
         }
     }
+    // which of the two per-lane source offsets piece i uses: k-slow images alternate per k-octet (pieces 0-1 / 2-3), k-contiguous images
+    // per piece parity (M32; without M32 both entries are equal)
+#define IA(i) (TA ? (i) >> 1 : (i) & 1)
+#define IB(i) (TB ? (i) >> 1 : (i) & 1)
     // A'hf of (relative) K-tile t into `slot`; B of K-tile t into `buf`. Past the last K-tile: zero-length descriptor.
     auto issueA = [&](int hf, char* slot, int t) {
         const rsrc_t rs = make_rsrc(p.A, t < ntile ? p.bytesA : 0u);
         const int so = t * stepA + hf * halfA;
         char* d = slot + wave * 4096;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) glds16(rs, d + i * 1024, vA[i >> 1] + (so + i * pieceA));
+        for (int i = 0; i < 4; ++i) glds16(rs, d + i * 1024, vA[IA(i)] + (so + i * pieceA));
     };
     auto issueB = [&](char* buf, int t) {
         const rsrc_t rs = make_rsrc(p.B, t < ntile ? p.bytesB : 0u);
         const int so = t * stepB;
         char* d = buf + wave * 4096;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) glds16(rs, d + i * 1024, vB[i >> 1] + (so + i * pieceB));
+        for (int i = 0; i < 4; ++i) glds16(rs, d + i * 1024, vB[IB(i)] + (so + i * pieceB));
     };
 
     // ---- fragment read offsets
@@ -184,12 +225,14 @@ __global__ __launch_bounds__(256, 2) void gemm_8ph2_kernel(GemmArgs p) {
     do {                                                                                                          \
         if constexpr (TA && ASMTR) tr_issue(pa[MT_][KK_], (IMG_) + trA[MT_] + (KK_) * (32 * 256));                \
         else if constexpr (TA) fa[MT_][KK_] = n8_read_frag_tr8((IMG_), trA[MT_], (KK_));                          \
+        else if constexpr (M32) fa[MT_][KK_] = n8_read_frag32((IMG_), wm * 64 + ((MT_) & 1) * 32 + l31, 4 * (KK_) + 2 * ((MT_) >> 1) + lh); \
         else fa[MT_][KK_] = read_frag<T>((IMG_), wm * 64 + (MT_) * 16 + fr, (KK_) * 4 + fg);                      \
     } while (0)
 #define RD_B(IMG_, NH_, NT_, KK_, FB_, PB_)                                                                       \
     do {                                                                                                          \
         if constexpr (TB && ASMTR) tr_issue(PB_[NT_][KK_], (IMG_) + trB[NH_][NT_] + (KK_) * (32 * 256));          \
         else if constexpr (TB) FB_[NT_][KK_] = n8_read_frag_tr8((IMG_), trB[NH_][NT_], (KK_));                    \
+        else if constexpr (M32) FB_[NT_][KK_] = n8_read_frag32((IMG_), (NH_) * 64 + wn * 32 + l31, 4 * (KK_) + 2 * (NT_) + lh); \
         else FB_[NT_][KK_] = read_frag<T>((IMG_), (NH_) * 64 + wn * 32 + (NT_) * 16 + fr, (KK_) * 4 + fg);        \
     } while (0)
     // first use of freshly read fragments: the asm reads need their own wait (and become fragments), the compiler counts its own
@@ -210,7 +253,14 @@ __global__ __launch_bounds__(256, 2) void gemm_8ph2_kernel(GemmArgs p) {
         }                                                                                                         \
     } while (0)
 #define MF(MH_, NH_, MT_, NT_, KK_, FB_)                                                                          \
-    acc[(MH_) * 4 + (MT_)][(NH_) * 2 + (NT_)] = Mma<T>::mma(FB_[NT_][KK_], fa[MT_][KK_], acc[(MH_) * 4 + (MT_)][(NH_) * 2 + (NT_)])
+    do {                                                                                                          \
+        if constexpr (M32) {                                                                                      \
+            if ((NT_) == ((MT_) >> 1))                                                                            \
+                acc32[(MH_) * 2 + ((MT_) & 1)][NH_] = n8_mma32(FB_[NT_][KK_], fa[MT_][KK_], acc32[(MH_) * 2 + ((MT_) & 1)][NH_]); \
+        } else {                                                                                                  \
+            acc[(MH_) * 4 + (MT_)][(NH_) * 2 + (NT_)] = Mma<T>::mma(FB_[NT_][KK_], fa[MT_][KK_], acc[(MH_) * 4 + (MT_)][(NH_) * 2 + (NT_)]); \
+        }                                                                                                         \
+    } while (0)
 #define PIN() __builtin_amdgcn_sched_barrier(0)
     // row sums (tile column 0 of a k-slow-A problem): blocks mt = 2 wn, 2 wn + 1 of row half H_, k-half KK_
 #define ROWSUM(H_, KK_)                                                                                           \
@@ -311,9 +361,9 @@ __global__ __launch_bounds__(256, 2) void gemm_8ph2_kernel(GemmArgs p) {
             int oA0[4], oA1[4], oB[4];      // running per-piece source offsets of the next A'0 / A'1 / B to issue, bumped right behind the
 #pragma unroll                              // load (the empty asm pins the add there, in the shadow of the same MFMA)
             for (int i = 0; i < 4; ++i) {
-                oA0[i] = vA[i >> 1] + (2 * stepA + i * pieceA);
-                oA1[i] = vA[i >> 1] + (stepA + halfA + i * pieceA);
-                oB[i] = vB[i >> 1] + (2 * stepB + i * pieceB);
+                oA0[i] = vA[IA(i)] + (2 * stepA + i * pieceA);
+                oA1[i] = vA[IA(i)] + (stepA + halfA + i * pieceA);
+                oB[i] = vB[IB(i)] + (2 * stepB + i * pieceB);
             }
             auto dmaA = [&](int hf, char* slot, int t, int i) {
                 const rsrc_t rs = make_rsrc(p.A, t < ntile ? p.bytesA : 0u);
@@ -456,15 +506,25 @@ __global__ __launch_bounds__(256, 2) void gemm_8ph2_kernel(GemmArgs p) {
         char* sB = smem;
         const int act = p.act & VALOR_ACT_MASK;
         const bool deriv = (p.act & VALOR_ACT_DERIV) != 0;
+        // the accumulators as NCG column groups x NRG row groups of four consecutive columns of one row (both MFMA shapes):
+        //   16 x 16 tiles: column group ni (4), row group mi (8);  32 x 32 tiles: column group nh * 4 + q (8), row group mh * 2 + mb (4)
+        constexpr int NCG = M32 ? 8 : 4, NRG = M32 ? 4 : 8;
+        auto cg_col = [&](int cg) { return M32 ? (cg >> 2) * 64 + wn * 32 + (cg & 3) * 8 + 4 * lh : (cg >> 1) * 64 + wn * 32 + (cg & 1) * 16 + 4 * fg; };
+        auto rg_row = [&](int rg) { return M32 ? (rg >> 1) * 128 + wm * 64 + (rg & 1) * 32 + l31 : (rg >> 2) * 128 + wm * 64 + (rg & 3) * 16 + fr; };
+        auto quad = [&](int rg, int cg) -> f32x4_t {
+            if constexpr (M32) return n8_quad(acc32[rg][cg >> 2], cg & 3);
+            else return acc[rg][cg];
+        };
+        const int half8 = (M32 ? lh : (fg & 1)) * 8;       // which 8-byte half of the 16-byte column chunk this lane's four columns are
         auto write_tile = [&](bool apply_act) {
 #pragma unroll
-            for (int ni = 0; ni < 4; ++ni) {
-                const int col = (ni >> 1) * 64 + wn * 32 + (ni & 1) * 16 + 4 * fg;
+            for (int cg = 0; cg < NCG; ++cg) {
+                const int col = cg_col(cg);
                 const f32x4_t bias4 = load_bias4<T>(p, n0 + col);
 #pragma unroll
-                for (int mi = 0; mi < 8; ++mi) {
-                    const int row = (mi >> 2) * 128 + wm * 64 + (mi & 3) * 16 + fr;
-                    f32x4_t v = acc[mi][ni];
+                for (int rg = 0; rg < NRG; ++rg) {
+                    const int row = rg_row(rg);
+                    f32x4_t v = quad(rg, cg);
 #pragma unroll
                     for (int r = 0; r < 4; ++r) v[r] = v[r] * p.alpha + bias4[r];
                     if (apply_act) {
@@ -473,7 +533,7 @@ __global__ __launch_bounds__(256, 2) void gemm_8ph2_kernel(GemmArgs p) {
                         v = (f32x4_t){f[0], f[1], f[2], f[3]};
                     }
                     const u32x2_t w = {pack2_bf16(v[0], v[1]), pack2_bf16(v[2], v[3])};
-                    *(u32x2_t*)(sB + row * 256 + (((col >> 3) ^ (row & 15)) << 4) + (fg & 1) * 8) = w;
+                    *(u32x2_t*)(sB + row * 256 + (((col >> 3) ^ (row & 15)) << 4) + half8) = w;
                 }
             }
         };
@@ -486,6 +546,49 @@ __global__ __launch_bounds__(256, 2) void gemm_8ph2_kernel(GemmArgs p) {
                 if (m < p.M && n < p.N) store_out16<NTS>(dst + (int64_t)m * p.ldc + n, val);
             }
         };
+        if (p.preact && deriv) {
+            // forward of a fused activation that saves act'(u) (ops.MlpFn): BOTH outputs from one evaluation of the activation, per
+            // 128-row half of the tile -- act(u) as a [128][256 B] bf16 image at smem, act'(u) as a second one 32 KiB further -- and one
+            // read-out loop with two 16-byte stores per lane. (The general epilogue below takes two fp32 passes and 4-byte-granular
+            // LDS traffic for the same thing: the ViT fc1 forward ran at 0.7 of the plain product's rate there.)
+            char* sG = smem + 32768;
+#pragma unroll
+            for (int mh = 0; mh < 2; ++mh) {
+                if (mh) __syncthreads();
+#pragma unroll
+                for (int cg = 0; cg < NCG; ++cg) {
+                    const int col = cg_col(cg);
+                    const f32x4_t bias4 = load_bias4<T>(p, n0 + col);
+#pragma unroll
+                    for (int rh = 0; rh < NRG / 2; ++rh) {
+                        const int rg = mh * (NRG / 2) + rh;
+                        const int row = rg_row(rg) - mh * 128;
+                        const f32x4_t a = quad(rg, cg);
+                        float f[4], g[4];
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) f[r] = a[r] * p.alpha + bias4[r];
+                        act_fwd_deriv_n<4>(act, f, g);
+                        const int o = row * 256 + (((col >> 3) ^ (row & 15)) << 4) + half8;
+                        *(u32x2_t*)(sB + o) = (u32x2_t){pack2_bf16(f[0], f[1]), pack2_bf16(f[2], f[3])};
+                        *(u32x2_t*)(sG + o) = (u32x2_t){pack2_bf16(g[0], g[1]), pack2_bf16(g[2], g[3])};
+                    }
+                }
+                __syncthreads();
+#pragma unroll 4
+                for (int it = 0; it < 8; ++it) {
+                    const int ml = it * 16 + (tid >> 4), c = tid & 15;
+                    const int o = ml * 256 + ((c ^ (ml & 15)) << 4);
+                    const u32x4_t vy = *(const u32x4_t*)(sB + o), vg = *(const u32x4_t*)(sG + o);
+                    const int m = m0 + mh * 128 + ml, n = n0 + c * 8;
+                    if (m < p.M && n < p.N) {
+                        store_out16<NTS>((T*)p.C + (int64_t)m * p.ldc + n, vy);
+                        store_out16<NTS>((T*)p.preact + (int64_t)m * p.ldc + n, vg);
+                    }
+                }
+            }
+            stamp_out();
+            return;
+        }
         if (p.preact) {                 // forward of a fused activation: the pre-activation copy first
             write_tile(false);
             __syncthreads();
@@ -555,14 +658,25 @@ __global__ __launch_bounds__(256, 2) void gemm_8ph2_kernel(GemmArgs p) {
 #pragma unroll
     for (int pass = 0; pass < 2; ++pass) {
         if (pass) __syncthreads();
+        if constexpr (M32) {
 #pragma unroll
-        for (int mt = 0; mt < 4; ++mt)
+            for (int mb = 0; mb < 2; ++mb)
 #pragma unroll
-            for (int ni = 0; ni < 4; ++ni) {
-                const int ml = wm * 64 + mt * 16 + fr;                        // row inside this 128-row half
-                const int ch = ((ni >> 1) * 16 + wn * 8 + (ni & 1) * 4 + fg) ^ (ml & 7);
-                *(f32x4_t*)(sC + ml * 128 + ch * 4) = acc[pass * 4 + mt][ni];
-            }
+                for (int cg = 0; cg < 8; ++cg) {
+                    const int ml = wm * 64 + mb * 32 + l31;                       // row inside this 128-row half
+                    const int ch = ((cg >> 2) * 16 + wn * 8 + (cg & 3) * 2 + lh) ^ (ml & 7);
+                    *(f32x4_t*)(sC + ml * 128 + ch * 4) = n8_quad(acc32[pass * 2 + mb][cg >> 2], cg & 3);
+                }
+        } else {
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+                for (int ni = 0; ni < 4; ++ni) {
+                    const int ml = wm * 64 + mt * 16 + fr;                        // row inside this 128-row half
+                    const int ch = ((ni >> 1) * 16 + wn * 8 + (ni & 1) * 4 + fg) ^ (ml & 7);
+                    *(f32x4_t*)(sC + ml * 128 + ch * 4) = acc[pass * 4 + mt][ni];
+                }
+        }
         __syncthreads();
 #pragma unroll 2
         for (int it = 0; it < 8; ++it) {
@@ -597,9 +711,12 @@ void launch_gemm_8ph2(hipStream_t st, int transA, int transB, const GemmArgs& p_
     const int fast_mode = valor_gemm_set_fast_epilogue(-1), tr_asm = valor_gemm_set_tr_asm(-1);
     // the bf16 tile epilogue under the conditions of the 256x256 kernel (gemm8.hip: launch_gemm_8ph)
     const bool light_dact = p.dact_aux && (p.act & VALOR_ACT_DERIV);
-    const bool plainish = fast_mode >= 2 || (!p.preact && (!p.dact_aux || light_dact));
+    // policy key 10: the forward that saves act'(u) beside act(u) (two outputs) through the bf16 half-tile path of the kernel
+    const bool two_out = p.preact && (p.act & VALOR_ACT_DERIV) && !p.dact_aux;
+    const bool plainish = fast_mode >= 2 || (!p.preact && (!p.dact_aux || light_dact)) || (two_out && g_gemm_policy[10] != 0);
     p.fast_epi = fast_mode && plainish && !p.out_f32 && p.kslices <= 1 && (p.N & 7) == 0 && (p.ldc & 7) == 0 && !p.rowsum_out &&
-                 (!p.dact_aux || (p.ldaux & 7) == 0) && !(p.dact_aux && p.preact) && !transA && !(p.preact && (p.act & VALOR_ACT_DERIV));
+                 (!p.dact_aux || (p.ldaux & 7) == 0) && !(p.dact_aux && p.preact) && !transA &&
+                 (!(p.preact && (p.act & VALOR_ACT_DERIV)) || (two_out && g_gemm_policy[10] != 0));
     const int tiles_m = (p.M + 255) / 256, tiles_n = (p.N + 127) / 128;
     const int tiles = tiles_m * tiles_n;
     // L2-aware raster: the model of launch_gemm_8ph with 128-column panels and 64 concurrent tiles per XCD
@@ -624,26 +741,34 @@ void launch_gemm_8ph2(hipStream_t st, int transA, int transB, const GemmArgs& p_
     p.st_mode = nts ? 1 : 0;
     dim3 grid(tiles * (p.kslices > 1 ? p.kslices : 1));
     const size_t lds = N8_LDS;
-#define VALOR_8PH2_LAUNCH1(TA_, TB_, ASM_, NTS_, S_)                                                            \
+#define VALOR_8PH2_LAUNCH1(TA_, TB_, ASM_, NTS_, S_, M32_)                                                      \
     do {                                                                                                        \
         static bool attr_set = false;                                                                           \
         if (!attr_set) {                                                                                        \
-            hipFuncSetAttribute((const void*)gemm_8ph2_kernel<TA_, TB_, ASM_, NTS_, S_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+            hipFuncSetAttribute((const void*)gemm_8ph2_kernel<TA_, TB_, ASM_, NTS_, S_, M32_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
             attr_set = true;                                                                                    \
         }                                                                                                       \
-        hipLaunchKernelGGL((gemm_8ph2_kernel<TA_, TB_, ASM_, NTS_, S_>), grid, dim3(256), lds, st, p);          \
+        hipLaunchKernelGGL((gemm_8ph2_kernel<TA_, TB_, ASM_, NTS_, S_, M32_>), grid, dim3(256), lds, st, p);    \
     } while (0)
 #define VALOR_8PH2_LAUNCH(TA_, TB_, NTS_)                                                                       \
     do {                                                                                                        \
         constexpr bool kslow_ = TA_ || TB_;                                                                     \
-        if (kslow_ && !tr_asm) { VALOR_8PH2_LAUNCH1(TA_, TB_, false, NTS_, 0); }                                \
-        else if (g_8ph2_sched == 1) { VALOR_8PH2_LAUNCH1(TA_, TB_, kslow_, NTS_, 1); }                          \
-        else { VALOR_8PH2_LAUNCH1(TA_, TB_, kslow_, NTS_, 0); }                                                 \
+        if (kslow_ && !tr_asm) { VALOR_8PH2_LAUNCH1(TA_, TB_, false, NTS_, 0, false); }                         \
+        else if (g_8ph2_sched == 1) { VALOR_8PH2_LAUNCH1(TA_, TB_, kslow_, NTS_, 1, false); }                   \
+        else { VALOR_8PH2_LAUNCH1(TA_, TB_, kslow_, NTS_, 0, false); }                                          \
     } while (0)
-    if (!transA && !transB) { if (nts) VALOR_8PH2_LAUNCH(false, false, true); else VALOR_8PH2_LAUNCH(false, false, false); }
+    // policy key 9: the NN main loop on v_mfma_f32_32x32x16_bf16 (M32, see the top of this file)
+#define VALOR_8PH2_LAUNCH_M32(NTS_)                                                                             \
+    do {                                                                                                        \
+        if (g_8ph2_sched == 1) { VALOR_8PH2_LAUNCH1(false, false, false, NTS_, 1, true); }                      \
+        else { VALOR_8PH2_LAUNCH1(false, false, false, NTS_, 0, true); }                                        \
+    } while (0)
+    if (!transA && !transB && g_gemm_policy[9] != 0) { if (nts) VALOR_8PH2_LAUNCH_M32(true); else VALOR_8PH2_LAUNCH_M32(false); }
+    else if (!transA && !transB) { if (nts) VALOR_8PH2_LAUNCH(false, false, true); else VALOR_8PH2_LAUNCH(false, false, false); }
     else if (!transA && transB) { if (nts) VALOR_8PH2_LAUNCH(false, true, true); else VALOR_8PH2_LAUNCH(false, true, false); }
     else if (transA && !transB) VALOR_8PH2_LAUNCH(true, false, false);
     else VALOR_8PH2_LAUNCH(true, true, false);
+#undef VALOR_8PH2_LAUNCH_M32
 #undef VALOR_8PH2_LAUNCH
 #undef VALOR_8PH2_LAUNCH1
 }
@@ -651,7 +776,13 @@ void launch_gemm_8ph2(hipStream_t st, int transA, int transB, const GemmArgs& p_
 // how many narrow-kernel workgroups the runtime admits per CU (2 = the design point; the tests assert it)
 extern "C" int valor_gemm_narrow_occupancy(void) {
     int n = 0;
-    hipFuncSetAttribute((const void*)gemm_8ph2_kernel<false, false, false, false, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)N8_LDS);
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, (const void*)gemm_8ph2_kernel<false, false, false, false, 0>, 256, N8_LDS) != hipSuccess) return -1;
+    hipFuncSetAttribute((const void*)gemm_8ph2_kernel<false, false, false, false, 0, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)N8_LDS);
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, (const void*)gemm_8ph2_kernel<false, false, false, false, 0, false>, 256, N8_LDS) != hipSuccess) return -1;
+    if (g_gemm_policy[9] != 0) {        // the M32 instantiations must fit twice per CU as well
+        int n32 = 0;
+        hipFuncSetAttribute((const void*)gemm_8ph2_kernel<false, false, false, true, 1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)N8_LDS);
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n32, (const void*)gemm_8ph2_kernel<false, false, false, true, 1, true>, 256, N8_LDS) != hipSuccess) return -1;
+        if (n32 < n) n = n32;
+    }
     return n;
 }

@@ -37,10 +37,12 @@ struct LnArgs {
     uint64_t seed, offset;
     const float* row_scale; int64_t rows_per_scale;   // stochastic depth: (x + bias) *= row_scale[row / rows_per_scale] (or null)
     int nt;                                           // non-temporal accesses (valor_ln_set_nt): bit 0 x loads, 1 y stores, 2 z stores
+    const uint64_t* rng_base;                         // device-resident term of the dropout offset (common.h rng_offset) or null
 };
 
 template <typename T, int NV>
 __global__ __launch_bounds__(256) void ln_fwd_kernel(LnArgs p) {
+    const uint64_t rng_off = rng_offset(p.offset, p.rng_base);
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     const T* X = (const T*)p.x; const T* Bi = (const T*)p.bias; const T* R = (const T*)p.residual;
@@ -63,7 +65,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(LnArgs p) {
                 t = load4<T>(X + base + c);
                 if (Bi) t += load4<T>(Bi + c);
                 if (thr) {
-                    Philox4 rnd = philox4x32_10(p.seed, p.offset + (uint64_t)((base + c) >> 2));
+                    Philox4 rnd = philox4x32_10(p.seed, rng_off + (uint64_t)((base + c) >> 2));
 #pragma unroll
                     for (int k = 0; k < 4; ++k) t[k] = rnd.v[k] >= thr ? t[k] * keep_scale : 0.f;
                 }
@@ -120,6 +122,7 @@ struct LnBwdArgs {
     uint64_t seed, offset;
     const float* row_scale; int64_t rows_per_scale;
     int nt;                                           // bit 3: dy / z / dz_in loads non-temporal, bit 4: dx / dres stores
+    const uint64_t* rng_base;                         // as in LnArgs: the forward's value (same step)
 };
 
 // 4 consecutive elements as fp32, optionally through a non-temporal access (operands a streaming kernel touches exactly once)
@@ -138,6 +141,7 @@ template <> DEVINL void store4_nt<bf16_t>(bf16_t* p, f32x4_t v, bool nt) {
 
 template <typename T, int NV>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(LnBwdArgs p) {
+    const uint64_t rng_off = rng_offset(p.offset, p.rng_base);
     __shared__ float red[3][4][64 * 4];  // [which][wave][lane*4 + k], reused per vector i
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
@@ -220,7 +224,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(LnBwdArgs p) {
                 if (DR) store4_nt<T>(DR + base + c, dz, nts);
                 f32x4_t dx = dz;
                 if (thr) {
-                    Philox4 rnd = philox4x32_10(p.seed, p.offset + (uint64_t)((base + c) >> 2));
+                    Philox4 rnd = philox4x32_10(p.seed, rng_off + (uint64_t)((base + c) >> 2));
 #pragma unroll
                     for (int k = 0; k < 4; ++k) dx[k] = rnd.v[k] >= thr ? dz[k] * keep_scale : 0.f;
                 }
@@ -287,6 +291,7 @@ DEVINL u32x4_t pack8(const float (&f)[8]) {
 // loop keeps in flight between its Philox blocks). Same arithmetic, same dropout windows, bit-identical outputs. NR = 2 measured slower.
 template <int NV8, int NR>
 __global__ __launch_bounds__(256) void ln_fwd_h2_kernel(LnArgs p) {
+    const uint64_t rng_off = rng_offset(p.offset, p.rng_base);
     typedef bf16_t T;
     constexpr int GL = 32;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, half = lane / GL, hl = lane % GL;
@@ -333,7 +338,7 @@ __global__ __launch_bounds__(256) void ln_fwd_h2_kernel(LnArgs p) {
                 if (thr) {
 #pragma unroll
                     for (int h4 = 0; h4 < 2; ++h4) {
-                        Philox4 rnd = philox4x32_10(p.seed, p.offset + (uint64_t)((base + c + 4 * h4) >> 2));
+                        Philox4 rnd = philox4x32_10(p.seed, rng_off + (uint64_t)((base + c + 4 * h4) >> 2));
 #pragma unroll
                         for (int k = 0; k < 4; ++k) t[4 * h4 + k] = rnd.v[k] >= thr ? t[4 * h4 + k] * keep_scale : 0.f;
                     }
@@ -396,6 +401,7 @@ __global__ __launch_bounds__(256) void ln_fwd_h2_kernel(LnArgs p) {
 
 template <int NV8, int GL = 32>
 __global__ __launch_bounds__(256) void ln_fwd_h_kernel(LnArgs p) {
+    const uint64_t rng_off = rng_offset(p.offset, p.rng_base);
     typedef bf16_t T;
     constexpr int RPW = 64 / GL;          // rows per wave and iteration
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, half = lane / GL, hl = lane % GL;
@@ -427,7 +433,7 @@ __global__ __launch_bounds__(256) void ln_fwd_h_kernel(LnArgs p) {
                 if (thr) {
 #pragma unroll
                     for (int h4 = 0; h4 < 2; ++h4) {
-                        Philox4 rnd = philox4x32_10(p.seed, p.offset + (uint64_t)((base + c + 4 * h4) >> 2));
+                        Philox4 rnd = philox4x32_10(p.seed, rng_off + (uint64_t)((base + c + 4 * h4) >> 2));
 #pragma unroll
                         for (int k = 0; k < 4; ++k) t[4 * h4 + k] = rnd.v[k] >= thr ? t[4 * h4 + k] * keep_scale : 0.f;
                     }
@@ -488,6 +494,7 @@ __global__ __launch_bounds__(256) void ln_fwd_h_kernel(LnArgs p) {
 
 template <int NV8, int GL = 32>
 __global__ __launch_bounds__(256) void ln_bwd_h_kernel(LnBwdArgs p) {
+    const uint64_t rng_off = rng_offset(p.offset, p.rng_base);
     typedef bf16_t T;
     constexpr int RPW = 64 / GL;
     __shared__ float red[3][4 * RPW][GL * 8];   // [which][wave * RPW + half][hl * 8 + k], reused per vector i
@@ -564,7 +571,7 @@ __global__ __launch_bounds__(256) void ln_bwd_h_kernel(LnBwdArgs p) {
             if (thr) {
 #pragma unroll
                 for (int h4 = 0; h4 < 2; ++h4) {
-                    Philox4 rnd = philox4x32_10(p.seed, p.offset + (uint64_t)((base + c + 4 * h4) >> 2));
+                    Philox4 rnd = philox4x32_10(p.seed, rng_off + (uint64_t)((base + c + 4 * h4) >> 2));
 #pragma unroll
                     for (int k = 0; k < 4; ++k) dx[4 * h4 + k] = rnd.v[k] >= thr ? dz[4 * h4 + k] * keep_scale : 0.f;
                 }
@@ -617,6 +624,7 @@ DEVINL float block4_sum(float v, float* red, int wave, int lane) {
 
 template <typename T, int NVW>
 __global__ __launch_bounds__(256) void ln_fwd_wide_kernel(LnArgs p) {
+    const uint64_t rng_off = rng_offset(p.offset, p.rng_base);
     __shared__ float red[4];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const T* X = (const T*)p.x; const T* Bi = (const T*)p.bias; const T* R = (const T*)p.residual;
@@ -639,7 +647,7 @@ __global__ __launch_bounds__(256) void ln_fwd_wide_kernel(LnArgs p) {
                 t = load4<T>(X + base + c);
                 if (Bi) t += load4<T>(Bi + c);
                 if (thr) {
-                    Philox4 rnd = philox4x32_10(p.seed, p.offset + (uint64_t)((base + c) >> 2));
+                    Philox4 rnd = philox4x32_10(p.seed, rng_off + (uint64_t)((base + c) >> 2));
 #pragma unroll
                     for (int k = 0; k < 4; ++k) t[k] = rnd.v[k] >= thr ? t[k] * keep_scale : 0.f;
                 }
@@ -687,6 +695,7 @@ __global__ __launch_bounds__(256) void ln_fwd_wide_kernel(LnArgs p) {
 
 template <typename T, int NVW>
 __global__ __launch_bounds__(256) void ln_bwd_wide_kernel(LnBwdArgs p) {
+    const uint64_t rng_off = rng_offset(p.offset, p.rng_base);
     __shared__ float red[4];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const T* DY = (const T*)p.dy; const T* DZI = (const T*)p.dz_in; const T* Z = (const T*)p.z;
@@ -751,7 +760,7 @@ __global__ __launch_bounds__(256) void ln_bwd_wide_kernel(LnBwdArgs p) {
                 if (DR) store4<T>(DR + base + c, dz);
                 f32x4_t dx = dz;
                 if (thr) {
-                    Philox4 rnd = philox4x32_10(p.seed, p.offset + (uint64_t)((base + c) >> 2));
+                    Philox4 rnd = philox4x32_10(p.seed, rng_off + (uint64_t)((base + c) >> 2));
 #pragma unroll
                     for (int k = 0; k < 4; ++k) dx[k] = rnd.v[k] >= thr ? dz[k] * keep_scale : 0.f;
                 }
@@ -983,11 +992,11 @@ extern "C" int valor_ln_part_blocks() { return LN_PART_BLOCKS; }
 extern "C" int valor_bdrln_fwd(void* stream, int dtype, const void* x, const void* bias, const void* residual,
                                const void* gamma, const void* beta, void* z, void* y, float* mean, float* rstd,
                                int64_t rows, int cols, float eps, float p_drop, uint64_t seed, uint64_t offset,
-                               const float* row_scale, int64_t rows_per_scale) {
+                               const float* row_scale, int64_t rows_per_scale, const uint64_t* rng_base) {
     if (rows <= 0) return VALOR_OK;
     if (!x || cols <= 0 || (cols & 3) || cols > LN_MAX_COLS) return VALOR_ERR_ARG;
     if (p_drop < 0.f || p_drop >= 1.f || (row_scale && rows_per_scale <= 0)) return VALOR_ERR_ARG;
-    LnArgs p{x, bias, residual, gamma, beta, z, y, mean, rstd, rows, cols, eps, p_drop, seed, offset, row_scale, rows_per_scale, g_ln_nt};
+    LnArgs p{x, bias, residual, gamma, beta, z, y, mean, rstd, rows, cols, eps, p_drop, seed, offset, row_scale, rows_per_scale, g_ln_nt, rng_base};
     hipStream_t st = (hipStream_t)stream;
     if (dtype == VALOR_DT_BF16) return launch_ln_fwd<bf16_t>(st, p);
     if (dtype == VALOR_DT_F32) return launch_ln_fwd<float>(st, p);
@@ -998,14 +1007,15 @@ extern "C" int valor_bdrln_fwd(void* stream, int dtype, const void* x, const voi
 extern "C" int valor_bdrln_bwd(void* stream, int dtype, const void* dy, const void* dz_in, const void* z,
                                const float* mean, const float* rstd, const void* gamma, void* dx, void* dres,
                                float* part_dgamma, float* part_dbeta, float* part_dbias, int64_t rows, int cols,
-                               float p_drop, uint64_t seed, uint64_t offset, const float* row_scale, int64_t rows_per_scale) {
+                               float p_drop, uint64_t seed, uint64_t offset, const float* row_scale, int64_t rows_per_scale,
+                               const uint64_t* rng_base) {
     if (rows <= 0) return VALOR_OK;
     if (cols <= 0 || (cols & 3) || cols > LN_MAX_COLS) return VALOR_ERR_ARG;
     if (dy && (!z || !mean || !rstd)) return VALOR_ERR_ARG;
     if (!dy && !dz_in) return VALOR_ERR_ARG;
     if (row_scale && (rows_per_scale <= 0 || dx == dres)) return VALOR_ERR_ARG;
     LnBwdArgs p{dy, dz_in, z, mean, rstd, gamma, dx, dres, part_dgamma, part_dbeta, part_dbias, rows, cols, p_drop, seed, offset,
-                row_scale, rows_per_scale, g_ln_nt};
+                row_scale, rows_per_scale, g_ln_nt, rng_base};
     hipStream_t st = (hipStream_t)stream;
     if (dtype == VALOR_DT_BF16) return launch_ln_bwd<bf16_t>(st, p);
     if (dtype == VALOR_DT_F32) return launch_ln_bwd<float>(st, p);

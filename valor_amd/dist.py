@@ -177,6 +177,10 @@ class Reducer:
 
     def _on_grad(self, name):
         """one gradient contribution to `name` has been enqueued (autograd AccumulateGrad or a direct arena write)."""
+        from . import ops
+        if ops.GradSink.recorder is not None:      # a backward is being captured into a graph: nothing ran, the replay reports it
+            ops.GradSink.recorder.append(name)
+            return
         n = self.touched.get(name, 0) + 1
         self.touched[name] = n
         if self.pending is None or n < self.uses.get(name, 1):

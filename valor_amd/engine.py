@@ -12,8 +12,15 @@ from .optim import FusedAdamW, get_lr_sched
 
 
 class TrainEngine:
-    def __init__(self, model, opts, optimizer=None, manage_gc=True):
+    def __init__(self, model, opts, optimizer=None, manage_gc=True, graphs=None):
         self.model, self.opts = model, opts
+        # graphs: replay the CLIP ViT / AST encoders as hipGraphs (valor_amd/graphs.py; VALOR_GRAPHS=1 or opts.graphs). The VideoSwin
+        # encoder and the decoder stay eager.
+        import os as _os
+        if graphs is None:
+            graphs = _os.environ.get("VALOR_GRAPHS", "0") == "1" or bool(getattr(opts, "graphs", False))
+        if graphs and model.arena.flat.is_cuda:
+            model.enable_graphs()
         # The cyclic garbage collector fires in the middle of a forward pass (thousands of short-lived autograd objects per
         # step) and stalls kernel submission for 20-40 ms while the GPU drains. Collect at step boundaries instead: the
         # young generation every step, everything every 64 steps.
@@ -66,6 +73,7 @@ class TrainEngine:
         if self.max_ahead > 0 and len(self._step_events) >= self.max_ahead:
             self._step_events.pop(0).synchronize()
         model.train()
+        DropoutState.begin_step()          # device mode (model.enable_graphs): by-value offsets restart, the device counter advances
         self._micro += 1
         last = (not accum) or self._micro % accum_steps == 0
         # accumulation window: the micro-steps before the last only accumulate; the LAST one reduces bucket by bucket from its gradient

@@ -12,6 +12,9 @@ from .lib import ACT_NONE, DT_BF16, DT_F32
 
 _WS = {}
 _WS_BYTES = 256 << 20
+# device address of the 64-bit dropout counter every dropout launch adds to its by-value offset when it RUNS (include/valor_hip.h,
+# `rng_base`); 0 = by-value windows only. Set by ops.DropoutState.enable_device_base().
+RNG_BASE = 0
 
 
 def dt_of(t):
@@ -108,7 +111,7 @@ def bdrln_fwd(x, bias, residual, gamma, beta, eps, *, p_drop=0.0, seed=0, offset
     rstd = torch.empty(rows, dtype=torch.float32, device=x.device) if want_y else None
     lib.call("valor_bdrln_fwd", _stream(), dt_of(x), _ptr(x), _ptr(bias), _ptr(residual), _ptr(gamma), _ptr(beta),
              _ptr(z), _ptr(y), _ptr(mean), _ptr(rstd), rows, cols, float(eps), float(p_drop), int(seed), int(offset),
-             _ptr(row_scale), int(rows_per_scale))
+             _ptr(row_scale), int(rows_per_scale), RNG_BASE)
     return z, y, mean, rstd
 
 
@@ -131,7 +134,7 @@ def bdrln_bwd(dy, dz_in, z, mean, rstd, gamma, *, p_drop=0.0, seed=0, offset=0, 
     dx = torch.empty_like(ref) if (p_drop > 0.0 or separate_dx or row_scale is not None) else dres
     lib.call("valor_bdrln_bwd", _stream(), dt_of(ref), _ptr(dy), _ptr(dz_in), _ptr(z), _ptr(mean), _ptr(rstd),
              _ptr(gamma), _ptr(dx), _ptr(dres), _ptr(pg), _ptr(pb), _ptr(px), rows, cols, float(p_drop), int(seed),
-             int(offset), _ptr(row_scale), int(rows_per_scale))
+             int(offset), _ptr(row_scale), int(rows_per_scale), RNG_BASE)
     outs, args = [], []
     for part, sink in zip((pg, pb, px), sinks):
         if part is None:
@@ -188,7 +191,7 @@ def attn_fwd(q, k, v, n_heads, *, mask=None, kv_range=None, kv_bmod=0, scale=Non
         assert kv_range.dtype == torch.int32 and kv_range.shape == (B, 2) and kv_range.is_contiguous()
     lib.call("valor_attn_fwd", _stream(), dt_of(q), _ptr(q), _ptr(k), _ptr(v), _ptr(o), _ptr(lse), B, n_heads, Sq, Skv,
              qb, qr, kb, kr, vb, vr, ob, orr, _ptr(mask), mb, mr, _ptr(kv_range), int(kv_bmod), float(scale),
-             float(p_drop), int(seed), int(offset))
+             float(p_drop), int(seed), int(offset), RNG_BASE)
     return o, lse
 
 
@@ -215,7 +218,7 @@ def attn_bwd(q, k, v, o, lse, dout, n_heads, *, dq=None, dk=None, dv=None, mask=
     lib.call("valor_attn_bwd", _stream(), dt_of(q), _ptr(q), _ptr(k), _ptr(v), _ptr(o), _ptr(lse), _ptr(dout), _ptr(dq),
              _ptr(dk), _ptr(dv), _ptr(delta), B, n_heads, Sq, Skv, qb, qr, kb, kr, vb, vr, ob, orr, gb, gr,
              dqb, dqr, dkb, dkr, dvb, dvr, _ptr(mask), mb, mr, _ptr(kv_range), int(kv_bmod), float(scale),
-             float(p_drop), int(seed), int(offset), int(accumulate_kv))
+             float(p_drop), int(seed), int(offset), int(accumulate_kv), RNG_BASE)
     return dq, dk, dv
 
 
@@ -266,7 +269,7 @@ def cross_attn_fwd_fused(segs, k, v, n_heads, kv_bmod, *, scale=0.125, p_drop=0.
     arr = _xattn_segs(segs, kv_bmod, False)
     kb, kr = _bsr(k); vb, vr = _bsr(v)
     return _xattn_call("valor_cross_attn_fwd_fused", _stream(), DT_BF16, ctypes.cast(arr, ctypes.c_void_p), len(segs), _ptr(k), _ptr(v),
-                       n_heads, k.shape[1], int(kv_bmod), kb, kr, vb, vr, float(scale), float(p_drop))
+                       n_heads, k.shape[1], int(kv_bmod), kb, kr, vb, vr, float(scale), float(p_drop), RNG_BASE)
 
 
 def cross_attn_bwd_fused(segs, k, v, dk, dv, n_heads, kv_bmod, *, scale=0.125, p_drop=0.0):
@@ -279,7 +282,7 @@ def cross_attn_bwd_fused(segs, k, v, dk, dv, n_heads, kv_bmod, *, scale=0.125, p
     kb, kr = _bsr(k); vb, vr = _bsr(v); dkb, dkr = _bsr(dk); dvb, dvr = _bsr(dv)
     import ctypes
     return _xattn_call("valor_cross_attn_bwd_fused", _stream(), DT_BF16, ctypes.cast(arr, ctypes.c_void_p), len(segs), _ptr(k), _ptr(v), _ptr(dk),
-                       _ptr(dv), n_heads, k.shape[1], int(kv_bmod), kb, kr, vb, vr, dkb, dkr, dvb, dvr, float(scale), float(p_drop))
+                       _ptr(dv), n_heads, k.shape[1], int(kv_bmod), kb, kr, vb, vr, dkb, dkr, dvb, dvr, float(scale), float(p_drop), RNG_BASE)
 
 
 # ---------------------------------------------------------------------------------------------- VideoSwin

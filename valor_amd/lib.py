@@ -42,8 +42,8 @@ SIGNATURES = {
     "valor_ln_part_blocks": [],
     "valor_ln_set_variant": [_i],
     "valor_ln_set_nt": [_i],
-    "valor_bdrln_fwd": [_vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i, _f, _f, _u64, _u64, _vp, _i64],
-    "valor_bdrln_bwd": [_vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i, _f, _u64, _u64, _vp, _i64],
+    "valor_bdrln_fwd": [_vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i, _f, _f, _u64, _u64, _vp, _i64, _vp],
+    "valor_bdrln_bwd": [_vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i, _f, _u64, _u64, _vp, _i64, _vp],
     "valor_patchify3d": [_vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _i],
     "valor_group_mean_fwd": [_vp, _i, _vp, _vp, _i64, _i, _i],
     "valor_group_mean_bwd": [_vp, _i, _vp, _vp, _i64, _i, _i],
@@ -56,12 +56,12 @@ SIGNATURES = {
     "valor_attn_set_variant": [_i],
     "valor_attn_set_res_pipeline": [_i],
     "valor_attn_fwd": [_vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _i64,
-                       _vp, _i64, _i64, _vp, _i, _f, _f, _u64, _u64],
+                       _vp, _i64, _i64, _vp, _i, _f, _f, _u64, _u64, _vp],
     "valor_attn_bwd": [_vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i,
                        _i64, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _i64,
-                       _vp, _i64, _i64, _vp, _i, _f, _f, _u64, _u64, _i],
-    "valor_cross_attn_fwd_fused": [_vp, _i, _vp, _i, _vp, _vp, _i, _i, _i, _i64, _i64, _i64, _i64, _f, _f],
-    "valor_cross_attn_bwd_fused": [_vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _f, _f],
+                       _vp, _i64, _i64, _vp, _i, _f, _f, _u64, _u64, _i, _vp],
+    "valor_cross_attn_fwd_fused": [_vp, _i, _vp, _i, _vp, _vp, _i, _i, _i, _i64, _i64, _i64, _i64, _f, _f, _vp],
+    "valor_cross_attn_bwd_fused": [_vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _f, _f, _vp],
     "valor_reducer_unique_id": [_vp],
     "valor_reducer_create": [_vp, _vp, _i, _i, _i, _vp, _vp, _vp, _i, _i],
     "valor_reducer_launch_bucket": [_vp, _i, _vp, _i],

@@ -178,6 +178,8 @@ class VALOR(nn.Module):
         self._const = {}
         self.gather_fn = None          # set by valor_amd.dist for world_size > 1
         self.collect = None            # optional dict: intermediate tensors for parity tests
+        self._graphs_on = False        # enable_graphs(): the encoders replay hipGraphs (valor_amd/graphs.py)
+        self._graph_segs = {}
 
     # ------------------------------------------------------------------ checkpoint layout
     @classmethod
@@ -537,6 +539,34 @@ class VALOR(nn.Module):
         P, sp = self.P, self.spec
         b, n, c, h, w = video_pixels.shape
         imgs = self._dev(video_pixels.reshape(b * n, c, h, w).float())
+        if self._use_graphs():
+            seg = self._graph_segs.get("vit")
+            if seg is None:
+                from .. import graphs
+                seg = self._graph_segs["vit"] = graphs.GraphedSegment("vit", self._video_encoder_clip, P["clip_model.visual.ln_post.weight"])
+            return seg(imgs).view(b, n, sp.vis_tokens, sp.vis_width)
+        return self._video_encoder_clip(imgs).view(b, n, sp.vis_tokens, sp.vis_width)
+
+    def _use_graphs(self):
+        """hipGraph replay of the encoders (valor_amd/graphs.py): training steps only, on a GPU, once enable_graphs() was called"""
+        return self._graphs_on and self.training and torch.is_grad_enabled() and self.device.type == "cuda" and self.collect is None
+
+    def enable_graphs(self, on=True):
+        """capture the CLIP ViT and AST encoders' forward + backward as hipGraphs from their third training call on (per input shape).
+        Switches ops.DropoutState to device mode (by-value offsets restart every step, a device-resident per-step counter is added in
+        the kernels): whoever drives the steps calls ops.DropoutState.begin_step() at the top of each (TrainEngine does)."""
+        self._graphs_on = bool(on)
+        if on:
+            ops.DropoutState.enable_device_base(self.device)
+        else:
+            for seg in self._graph_segs.values():
+                seg.release()
+            self._graph_segs = {}
+
+    def _video_encoder_clip(self, imgs):
+        """imgs: [b * F, 3, H, W] fp32 on the device -> [b * F, tokens, width]"""
+        P, sp = self.P, self.spec
+        bn = imgs.shape[0]
         wconv = ops.param_view(P["clip_model.visual.conv1.weight"], sp.vis_width, -1)
         vec = 8 if self.dtype == torch.bfloat16 else 4
         kp = (wconv.shape[1] + vec - 1) // vec * vec
@@ -547,11 +577,10 @@ class VALOR(nn.Module):
             wconv = ops.pad_cols(wconv, kp)
         tok = ops.linear(patches, wconv, None)
         Pn = sp.vis_tokens - 1
-        x = ops.assemble_tokens(tok, P["clip_model.visual.class_embedding"], P["clip_model.visual.positional_embedding"], None, b * n, Pn)
+        x = ops.assemble_tokens(tok, P["clip_model.visual.class_embedding"], P["clip_model.visual.positional_embedding"], None, bn, Pn)
         x = ops.layer_norm(x, P["clip_model.visual.ln_pre.weight"], P["clip_model.visual.ln_pre.bias"], 1e-5)
-        y = self._clip_blocks(x, "clip_model.visual.transformer", sp.vis_layers, sp.vis_heads, None,
-                              P["clip_model.visual.ln_post.weight"], P["clip_model.visual.ln_post.bias"])
-        return y.view(b, n, sp.vis_tokens, sp.vis_width)
+        return self._clip_blocks(x, "clip_model.visual.transformer", sp.vis_layers, sp.vis_heads, None,
+                                 P["clip_model.visual.ln_post.weight"], P["clip_model.visual.ln_post.bias"])
 
     def forward_txt_encoder(self, clip_tokens_cpu):
         """modeling.py:437-446 -> CLIP.encode_text(casual=True) clip.py:372-427. Returns [b, L, TW]."""
@@ -566,14 +595,26 @@ class VALOR(nn.Module):
     def forward_audio_encoder(self, audio):
         """modeling.py:468-480; AudioEmbeddings :750-762; pre-LN TransformerEncoder transformer.py:74-85,156-170.
         Returns [b, A, 129, AW]."""
-        P, sp, p = self.P, self.spec, (self.p_drop if self.training else 0.0)
+        sp = self.spec
         b, n, hh, ww = audio.shape
         spec_in = self._dev(audio.reshape(b * n, 1, hh, ww).float())
+        if self._use_graphs():
+            seg = self._graph_segs.get("ast")
+            if seg is None:
+                from .. import graphs
+                seg = self._graph_segs["ast"] = graphs.GraphedSegment("ast", self._audio_encoder, self.P["audio_encoder.last_layernorm.weight"])
+            return seg(spec_in).view(b, n, sp.aud_tokens, sp.aud_width)
+        return self._audio_encoder(spec_in).view(b, n, sp.aud_tokens, sp.aud_width)
+
+    def _audio_encoder(self, spec_in):
+        """spec_in: [b * A, 1, melbins, frames] fp32 on the device -> [b * A, tokens, width]"""
+        P, sp, p = self.P, self.spec, (self.p_drop if self.training else 0.0)
+        bn = spec_in.shape[0]
         patches = ops.patchify(spec_in, sp.aud_patch, self.dtype)
         tok = ops.linear(patches, ops.param_view(P["audio_embeddings.first_conv.weight"], sp.aud_width, -1), None)
         Pn = sp.aud_tokens - 1
         x = ops.assemble_tokens(tok, P["audio_embeddings.cls_token"], P["audio_embeddings.position_embeddings.weight"],
-                                P["audio_embeddings.first_conv.bias"], b * n, Pn)
+                                P["audio_embeddings.first_conv.bias"], bn, Pn)
         if p > 0:
             x = ops.bias_dropout_residual(x, None, None, p)
         y = ops.layer_norm(x, P["audio_encoder.layer.0.layernorm1.weight"], P["audio_encoder.layer.0.layernorm1.bias"], 1e-12)
@@ -590,7 +631,7 @@ class VALOR(nn.Module):
                 x, y = ops.bias_dropout_residual_ln(m, b2, x, P[r + "layernorm1.weight"], P[r + "layernorm1.bias"], 1e-12, p, True)
             else:
                 y = ops.bias_dropout_residual_ln(m, b2, x, P["audio_encoder.last_layernorm.weight"], P["audio_encoder.last_layernorm.bias"], 1e-12, p, False)
-        return y.view(b, n, sp.aud_tokens, sp.aud_width)
+        return y
 
     # ------------------------------------------------------------------ multimodal decoder
     def _bert_embed(self, ids_dev, L, token_type, full_masker=False):

@@ -22,13 +22,45 @@ _dt = K.dt_of
 
 class DropoutState:
     """Counter-based dropout RNG bookkeeping: every op draws a fresh (seed, offset) window; kernels
-    re-generate masks in backward from the same window (nothing is stored)."""
+    re-generate masks in backward from the same window (nothing is stored).
+
+    Two modes. Host mode (default): `offset` grows for the life of the process and travels BY VALUE into every launch. Device mode
+    (enable_device_base): the by-value offsets restart at 0 at every step (begin_step) -- they are the same numbers step after step,
+    which is what a captured graph needs -- and a 64-bit counter in device memory, advanced by STEP_STRIDE at every begin_step, is
+    added by the kernels when they RUN (include/valor_hip.h `rng_base`). Windows of different steps never overlap as long as a step
+    draws fewer than STEP_STRIDE counters (2^40; the base configuration draws ~2^33)."""
     seed = 1234
     offset = 0
+    base = None                    # int64 [1] device tensor (device mode) or None
+    STEP_STRIDE = 1 << 40
 
     @classmethod
     def reset(cls, seed, offset=0):
         cls.seed, cls.offset = int(seed), int(offset)
+        if cls.base is not None:
+            cls.base.zero_()
+
+    @classmethod
+    def enable_device_base(cls, device):
+        """switch to device mode (idempotent); the counter starts at 0"""
+        if cls.base is None or cls.base.device != torch.device(device):
+            cls.base = torch.zeros(1, dtype=torch.int64, device=device)
+            K.RNG_BASE = cls.base.data_ptr()
+        cls.offset = 0
+        return cls.base
+
+    @classmethod
+    def disable_device_base(cls):
+        cls.base = None
+        K.RNG_BASE = 0
+
+    @classmethod
+    def begin_step(cls):
+        """top of a training step (device mode only): by-value offsets restart, the device counter moves to this step's range. One tiny
+        kernel on the current stream, ahead of everything the step launches (side streams fork from this stream afterwards)."""
+        if cls.base is not None:
+            cls.offset = 0
+            cls.base.add_(cls.STEP_STRIDE)
 
     @classmethod
     def draw(cls, n_elements):
@@ -57,6 +89,7 @@ class GradSink:
     and bucket launches work exactly as with autograd's post-accumulate hooks."""
     enabled = True
     listener = None
+    recorder = None        # a list while a backward is being CAPTURED into a graph (valor_amd/graphs.py): names are recorded, not reported
 
 
 class GradSlot:
@@ -90,7 +123,9 @@ def param_view(p, *shape):
 
 
 def _sunk(p):
-    if GradSink.listener is not None:
+    if GradSink.recorder is not None:
+        GradSink.recorder.append(p._arena_name)
+    elif GradSink.listener is not None:
         GradSink.listener(p._arena_name)
 
 
