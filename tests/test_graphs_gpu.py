@@ -104,7 +104,7 @@ def test_graphed_encoders_are_bit_identical_to_the_eager_step(dev, device_rng):
         torch.cuda.synchronize()
         if graphs:
             segs = model._graph_segs
-            assert set(segs) == {"vit", "ast"} and all(len(s.captured) == 1 for s in segs.values())
+            assert set(segs) == {"vit", "ast", "clip_text"} and all(len(s.captured) == 1 for s in segs.values())
             assert all(c.sunk for s in segs.values() for c in s.captured.values())          # gradient writes recorded for the reducer
             assert next(iter(segs["ast"].captured.values())).draws > 0 and next(iter(segs["vit"].captured.values())).draws == 0
         runs[graphs] = (losses, model.arena.flat.clone())

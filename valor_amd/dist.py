@@ -281,7 +281,10 @@ class Reducer:
             if self.pending is not None:       # the used-parameter set changed (new task): redo synchronously
                 for w in self.works:
                     w.wait()
-                raise RuntimeError("used-parameter set changed between steps; call reset_task() when switching tasks")
+                diff = {n: (self.touched.get(n, 0), self.uses.get(n, 0)) for n in set(self.touched) | set(self.uses)
+                        if self.touched.get(n, 0) != self.uses.get(n, 0)}
+                raise RuntimeError("used-parameter set changed between steps; call reset_task() when switching tasks "
+                                   f"[{len(diff)} names differ, (writes this step, writes learnt): {dict(list(diff.items())[:8])}]")
             self.uses = dict(self.touched)
             self.expected = [set(n for n in b if n in self.touched) for b in self.buckets]
             if self.world > 1:

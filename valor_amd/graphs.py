@@ -27,9 +27,10 @@ from . import ops
 
 class _Replay(Function):
     @staticmethod
-    def forward(ctx, seg, anchor, x):
-        if x.data_ptr() != seg.static_in.data_ptr():
-            seg.static_in.copy_(x)
+    def forward(ctx, seg, anchor, *xs):
+        for x, st in zip(xs, seg.static_in):
+            if x.data_ptr() != st.data_ptr():
+                st.copy_(x)
         seg.g_fwd.replay()
         ops.DropoutState.offset += seg.draws
         ctx.seg = seg
@@ -43,7 +44,7 @@ class _Replay(Function):
         if ops.GradSink.listener is not None:
             for name in seg.sunk:
                 ops.GradSink.listener(name)
-        return None, None, None
+        return (None,) * (2 + len(seg.static_in))
 
 
 class _Captured:
@@ -51,34 +52,40 @@ class _Captured:
 
 
 class GraphedSegment:
-    """fn: device tensor -> device tensor (an encoder); anchor: any parameter of it that requires grad (gives the replay node a
-    differentiable input so autograd calls its backward)."""
+    """fn: device tensor(s) -> device tensor (an encoder; inputs that do not need gradients: pixels, spectrograms, token ids, masks -- every
+    call copies them into the static buffers the graph was captured on). The replay node needs one differentiable input for autograd to call its
+    backward: a private one-element leaf -- NOT a parameter of the model (autograd runs a leaf's post-accumulate hooks even when the
+    node hands it no gradient, and the data-parallel reducer counts those calls per parameter)."""
 
-    def __init__(self, name, fn, anchor, warmup=2):
-        self.name, self.fn, self.anchor, self.warmup = name, fn, anchor, warmup
+    def __init__(self, name, fn, warmup=2):
+        self.name, self.fn, self.warmup = name, fn, warmup
+        self.anchor = None
         self.calls = {}
         self.captured = {}
 
-    def __call__(self, x):
-        key = (tuple(x.shape), x.dtype, ops.DropoutState.offset)
+    def __call__(self, *xs):
+        assert ops.DropoutState.base is not None, "graph capture needs ops.DropoutState's device mode (VALOR.enable_graphs)"
+        key = tuple((tuple(x.shape), x.dtype) for x in xs) + (ops.DropoutState.offset,)
+        if self.anchor is None:
+            self.anchor = torch.zeros(1, device=xs[0].device, requires_grad=True)
         cap = self.captured.get(key)
         if cap is None:
             n = self.calls.get(key, 0)
             self.calls[key] = n + 1
             if n < self.warmup:
-                return self.fn(x)
-            cap = self._capture(x)
+                return self.fn(*xs)
+            cap = self._capture(xs)
             self.captured[key] = cap
-        return _Replay.apply(cap, self.anchor, x)
+        return _Replay.apply(cap, self.anchor, *xs)
 
-    def _capture(self, x):
+    def _capture(self, xs):
         cap = _Captured()
-        cap.stream = torch.cuda.Stream(device=x.device)
-        cap.static_in = x.detach().clone()
+        cap.stream = torch.cuda.Stream(device=xs[0].device)
+        cap.static_in = [x.detach().clone() for x in xs]
         cap.offset0 = ops.DropoutState.offset
         cap.g_fwd, cap.g_bwd = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
         with torch.cuda.graph(cap.g_fwd, stream=cap.stream):
-            out = self.fn(cap.static_in)
+            out = self.fn(*cap.static_in)
         cap.draws = ops.DropoutState.offset - cap.offset0
         ops.DropoutState.offset = cap.offset0                  # the replay of this very call advances it again
         cap.static_out = out
@@ -91,6 +98,7 @@ class GraphedSegment:
         finally:
             ops.GradSink.recorder = None
         cap.sunk = rec
+        cap.static_out = out.detach()          # the same memory without the (consumed) capture-time autograd history
         return cap
 
     def release(self):

@@ -543,7 +543,7 @@ class VALOR(nn.Module):
             seg = self._graph_segs.get("vit")
             if seg is None:
                 from .. import graphs
-                seg = self._graph_segs["vit"] = graphs.GraphedSegment("vit", self._video_encoder_clip, P["clip_model.visual.ln_post.weight"])
+                seg = self._graph_segs["vit"] = graphs.GraphedSegment("vit", self._video_encoder_clip)
             return seg(imgs).view(b, n, sp.vis_tokens, sp.vis_width)
         return self._video_encoder_clip(imgs).view(b, n, sp.vis_tokens, sp.vis_width)
 
@@ -584,11 +584,20 @@ class VALOR(nn.Module):
 
     def forward_txt_encoder(self, clip_tokens_cpu):
         """modeling.py:437-446 -> CLIP.encode_text(casual=True) clip.py:372-427. Returns [b, L, TW]."""
-        P, sp = self.P, self.spec
-        L = clip_tokens_cpu.shape[1]
         ids = self._dev(clip_tokens_cpu)
-        x = ops.embed(ids, P["clip_model.token_embedding.weight"], P["clip_model.positional_embedding"], None, L)
         mask = self._dev(self._clip_text_mask(clip_tokens_cpu))
+        if self._use_graphs():
+            seg = self._graph_segs.get("clip_text")
+            if seg is None:
+                from .. import graphs
+                seg = self._graph_segs["clip_text"] = graphs.GraphedSegment("clip_text", self._txt_encoder_clip)
+            return seg(ids, mask)
+        return self._txt_encoder_clip(ids, mask)
+
+    def _txt_encoder_clip(self, ids, mask):
+        """ids [b, L] token ids, mask [b, L, L] additive attention mask, both on the device -> [b, L, TW]"""
+        P, sp = self.P, self.spec
+        x = ops.embed(ids, P["clip_model.token_embedding.weight"], P["clip_model.positional_embedding"], None, ids.shape[1])
         return self._clip_blocks(x, "clip_model.transformer", sp.txt_layers, sp.txt_heads, mask,
                                  P["clip_model.ln_final.weight"], P["clip_model.ln_final.bias"])
 
@@ -602,7 +611,7 @@ class VALOR(nn.Module):
             seg = self._graph_segs.get("ast")
             if seg is None:
                 from .. import graphs
-                seg = self._graph_segs["ast"] = graphs.GraphedSegment("ast", self._audio_encoder, self.P["audio_encoder.last_layernorm.weight"])
+                seg = self._graph_segs["ast"] = graphs.GraphedSegment("ast", self._audio_encoder)
             return seg(spec_in).view(b, n, sp.aud_tokens, sp.aud_width)
         return self._audio_encoder(spec_in).view(b, n, sp.aud_tokens, sp.aud_width)
 
