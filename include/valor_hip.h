@@ -65,6 +65,40 @@ int valor_gemm(void* stream, int dtype, int transA, int transB, int M, int N, in
                int64_t workspace_bytes, void* rowsum_out,
                int rowsum_accumulate);
 
+/* ---- per-call tuning. The valor_gemm_set_* hooks above change PROCESS defaults (A/B tooling, env presets). A caller that wants a
+ * kernel choice for ONE call -- without touching state other threads read -- passes a valor_gemm_policy: every field is the value
+ * the corresponding hook would set, -1 = keep the process default. valor_gemm_tuned(policy, ...) = valor_gemm(...) under that policy,
+ * valor_gemm_kernel_for_tuned reports the family it would pick. (policy = NULL: exactly valor_gemm / valor_gemm_kernel_for.) */
+typedef struct valor_gemm_policy {
+    int key[12];        /* valor_gemm_set_policy keys 0 .. 11 */
+    int variant;        /* valor_gemm_set_variant */
+    int tr_asm;         /* valor_gemm_set_tr_asm */
+    int fast_epilogue;  /* valor_gemm_set_fast_epilogue */
+    int sched_256;      /* valor_gemm_set_8ph_sched */
+    int sched_narrow;   /* valor_gemm_set_narrow_sched */
+} valor_gemm_policy;
+int valor_gemm_tuned(const valor_gemm_policy* policy, void* stream, int dtype, int transA, int transB, int M, int N, int K,
+                     const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc, const void* bias, int act,
+                     void* preact, const void* dact_aux, int64_t ldaux, float alpha, int accumulate, int out_f32, void* workspace,
+                     int64_t workspace_bytes, void* rowsum_out, int rowsum_accumulate);
+int valor_gemm_kernel_for_tuned(const valor_gemm_policy* policy, int dtype, int transA, int transB, int M, int N, int K,
+                                int heavy_epilogue);
+
+/* ---- split-K reductions deferred and grouped. The wgrad GEMMs of a layer (bert.py:233-235,352,366,404,417; clip.py:176-182) are each
+ * split along the token contraction and each ends in a small reduction launch -- 309 of them per VALOR-base step. valor_gemm_deferred
+ * is valor_gemm except that, when the product is split, the partial tiles stay in the caller's workspace PIECE (one piece per pending
+ * product, untouched until the group reduction has been enqueued on the same stream) and `pending` (host memory) receives what is
+ * left to do; valor_gemm_pending_bytes stores how much of the piece is occupied (0: the product was not split and is complete);
+ * valor_gemm_reduce_group sums the partials of up to 8 pending products of one dtype and applies their epilogues (alpha, bias,
+ * C +=, fused row sums) in ONE launch. Per element the arithmetic is that of valor_gemm's own reduction: bit-identical results. */
+typedef struct valor_gemm_pending { unsigned char opaque[256]; } valor_gemm_pending;
+int valor_gemm_deferred(void* stream, int dtype, int transA, int transB, int M, int N, int K, const void* A, int64_t lda,
+                        const void* B, int64_t ldb, void* C, int64_t ldc, const void* bias, int act, void* preact,
+                        const void* dact_aux, int64_t ldaux, float alpha, int accumulate, int out_f32, void* workspace,
+                        int64_t workspace_bytes, void* rowsum_out, int rowsum_accumulate, valor_gemm_pending* pending);
+int valor_gemm_pending_bytes(const valor_gemm_pending* pending, int64_t* bytes);
+int valor_gemm_reduce_group(void* stream, int dtype, const valor_gemm_pending* pendings, int n);
+
 /* selects the bf16 kernel of valor_gemm: 0 = register-staged 128x128 tiles, 1 = LDS-DMA (buffer_load ... lds) 128x128
  * single stage, 2 = LDS-DMA 128x128 double stage, 3 = 256x256 8-phase pipeline wherever eligible, 4 = measured per-shape
  * policy between 1 and 3 (default). Returns the previous value; v < 0 only queries. Tuning / A-B measurement hook. */

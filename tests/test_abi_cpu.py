@@ -68,6 +68,27 @@ def test_argument_validation_without_gpu():
     assert so.valor_cross_attn_bwd_fused(None, 0, None, 3, buf, buf, buf, buf, 1, 128, 1, 0, 64, 0, 64, 0, 64, 0, 64, 0.125, 0.0, None) == -1
 
 
+def test_per_call_gemm_policy_without_touching_process_state():
+    """valor_gemm_policy (include/valor_hip.h): the kernel-family choice of ONE call, -1 = the process default. The family query is host
+    logic, so the contract is checkable without a GPU: a policy changes the answer for its call only, the process defaults stay."""
+    import ctypes
+    from valor_amd import lib
+    so = lib.load()
+    assert ctypes.sizeof(lib.GemmPolicy) == 17 * 4
+    M, N, K = 100864, 3072, 768                                    # ViT fc1 forward: family 4 under the default policy
+    base = so.valor_gemm_kernel_for(0, 0, 0, M, N, K, 0)
+    assert base == 4 and so.valor_gemm_kernel_for_tuned(None, 0, 0, 0, M, N, K, 0) == base
+    never = lib.GemmPolicy.make(narrow=0)
+    assert so.valor_gemm_kernel_for_tuned(ctypes.addressof(never), 0, 0, 0, M, N, K, 0) == 3          # the 256 x 256 kernel instead
+    small = lib.GemmPolicy.make(variant=1)
+    assert so.valor_gemm_kernel_for_tuned(ctypes.addressof(small), 0, 0, 0, M, N, K, 0) == 1          # the 128 x 128 kernel pinned
+    assert so.valor_gemm_kernel_for(0, 0, 0, M, N, K, 0) == base                                       # nothing global moved
+    assert so.valor_gemm_set_policy(8, -1) == 1000 and so.valor_gemm_set_variant(-1) == 4
+    # argument validation happens under a policy too
+    assert so.valor_gemm_tuned(ctypes.addressof(never), None, 0, 0, 0, 4, 4, 8, None, 8, None, 8, None, 4, None, 0, None, None, 0, 1.0, 0, 0, None, 0,
+                               None, 0) == -1
+
+
 @pytest.mark.skipif(torch.cuda.is_available(), reason="CPU-only check")
 def test_no_cpu_fallback():
     from valor_amd import kernels as K, lib

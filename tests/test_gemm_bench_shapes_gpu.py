@@ -231,3 +231,38 @@ def test_forward_short_contraction_of_the_videoswin_stages(dev, N, K):
     C = Kn.gemm(A, B, bias=bias)
     whole, worst = _tile_errors(C, A.float() @ B.float().t() + bias.float())
     assert whole < TOL and worst < TILE_TOL, (whole, worst)
+
+
+def test_grouped_splitk_reduction_is_bit_identical(dev):
+    """valor_gemm_deferred + valor_gemm_reduce_group (the wgrads of a layer reduced in ONE launch, kernels.ReduceQueue) against
+    valor_gemm's own reduction: the ViT layer's four weight gradients + fused bias gradients (bert.py:233-235,404,417 / clip.py:176-182
+    shapes) and a decoder-sized one, accumulated into existing buffers -- equal to the bit; the `done` callbacks run at the flush, in
+    order; a product that is not split completes at once."""
+    from valor_amd import kernels as Kn
+    Kt = M_VIT
+    shapes = [(3 * W, W), (W, W), (I, W), (W, I), (W, W)]
+    ops_ = [(_mk((Kt if i < 4 else 8832, mo), 70 + i, dev, 0.1), _mk((Kt if i < 4 else 8832, no), 80 + i, dev)) for i, (mo, no) in enumerate(shapes)]
+    init = [(_mk((mo, no), 90 + i, dev), _mk((mo,), 95 + i, dev)) for i, (mo, no) in enumerate(shapes)]
+    ref = []
+    for (dY, X), (g0, b0) in zip(ops_, init):
+        gw, gb = g0.clone(), b0.clone()
+        Kn.gemm(dY, X, trans_a=True, trans_b=True, out=gw, accumulate=True, rowsum_out=gb, rowsum_accumulate=True)
+        ref.append((gw, gb))
+    order = []
+    outs = [(g0.clone(), b0.clone()) for g0, b0 in init]
+    Kn.ReduceQueue._armed = True                # as inside a backward pass: nothing flushes until the end-of-backward callback
+    try:
+        for i, ((dY, X), (gw, gb)) in enumerate(zip(ops_, outs)):
+            Kn.gemm(dY, X, trans_a=True, trans_b=True, out=gw, accumulate=True, rowsum_out=gb, rowsum_accumulate=True,
+                    defer_done=lambda i=i: order.append(i))
+        q = Kn.ReduceQueue.current(dev)
+        assert q.n == 5 and order == []
+        small = Kn.gemm(ops_[0][0][:256], ops_[0][1][:256], trans_a=True, trans_b=True, defer_done=lambda: order.append("small"))   # K = 256: no split
+        assert order == ["small"] and q.n == 5
+    finally:
+        Kn.ReduceQueue.flush_all()
+    assert order == ["small", 0, 1, 2, 3, 4] and q.n == 0
+    for (gw, gb), (rw, rb) in zip(outs, ref):
+        assert torch.equal(gw, rw) and torch.equal(gb, rb)
+    sref = ops_[0][0][:256].float().t() @ ops_[0][1][:256].float()
+    assert float((small.float() - sref).norm() / sref.norm()) < TOL

@@ -194,3 +194,27 @@ def test_repeated_launches_are_deterministic(narrow, dev):
     for _ in range(20):
         assert torch.equal(Kn.gemm(A, B), c0)
         assert torch.equal(Kn.gemm(dY, Wt, trans_b=True), d0)
+
+
+def test_per_call_policy_selects_the_kernel_without_global_hooks(dev):
+    """lib.GemmPolicy (valor_gemm_policy): the family-4 kernel, its 32 x 32 x 16 main loop and its plain schedule chosen for ONE call
+    each -- the same results as under the process-global hooks, and the hooks' values untouched afterwards."""
+    from valor_amd import kernels as Kn, lib
+    so = lib.load()
+    before = [so.valor_gemm_set_policy(k, -1) for k in range(12)] + [so.valor_gemm_set_narrow_sched(-1), so.valor_gemm_set_variant(-1)]
+    M, N, K = 8832, 3 * W, W
+    A, B, bias = _mk((M, K), 41, dev), _mk((N, K), 42, dev, 0.05), _mk((N,), 43, dev)
+    ref = A.float() @ B.float().t() + bias.float()
+    outs = {}
+    for name, pol in (("narrow", lib.GemmPolicy.make(narrow=1)), ("narrow-mfma32", lib.GemmPolicy.make(narrow=1, mfma32=1)),
+                      ("narrow-plain", lib.GemmPolicy.make(narrow=1, sched_narrow=0)), ("wide", lib.GemmPolicy.make(narrow=0)),
+                      ("small", lib.GemmPolicy.make(variant=1))):
+        import ctypes
+        fam = so.valor_gemm_kernel_for_tuned(ctypes.addressof(pol), 0, 0, 0, M, N, K, 0)
+        assert fam == {"narrow": 4, "narrow-mfma32": 4, "narrow-plain": 4, "wide": 3, "small": 1}[name]
+        outs[name] = Kn.gemm(A, B, bias=bias, policy=pol)
+        whole, worst = _tile_errors(outs[name], ref)
+        assert whole < TOL and worst < TILE_TOL, (name, whole, worst)
+    assert torch.equal(outs["narrow"], outs["narrow-plain"]) and torch.equal(outs["narrow"], outs["small"])
+    after = [so.valor_gemm_set_policy(k, -1) for k in range(12)] + [so.valor_gemm_set_narrow_sched(-1), so.valor_gemm_set_variant(-1)]
+    assert before == after

@@ -427,12 +427,12 @@ __global__ __launch_bounds__(256, WPS) void gemm_glds_kernel(GemmArgs p) {
     }
 }
 
-// split-K second stage: sum the fp32 slices and run the normal epilogue (4 n per thread).
+// split-K second stage: sum the fp32 slices and run the normal epilogue (4 n per thread). `bid` of `nblk` workgroups work on problem p.
 template <typename T>
-__global__ __launch_bounds__(256) void gemm_splitk_reduce(GemmArgs p) {
+DEVINL void splitk_reduce_body(const GemmArgs& p, int bid, int nblk) {
     const int64_t nquads = ((int64_t)p.N + 3) >> 2;
     const int64_t total = (int64_t)p.M * nquads;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    for (int64_t i = (int64_t)bid * blockDim.x + threadIdx.x; i < total; i += (int64_t)nblk * blockDim.x) {
         const int m = (int)(i / nquads);
         const int n = (int)(i - (int64_t)m * nquads) << 2;
         f32x4_t s = {0.f, 0.f, 0.f, 0.f};
@@ -452,16 +452,43 @@ __global__ __launch_bounds__(256) void gemm_splitk_reduce(GemmArgs p) {
         epilogue_store<T>(p, m, n, s, load_bias4<T>(p, n));
     }
     if (p.rowsum_out) {      // fused bias gradient: sum the K-slices' row sums
-        for (int m = blockIdx.x * blockDim.x + threadIdx.x; m < p.M; m += gridDim.x * blockDim.x) {
+        for (int m = bid * blockDim.x + threadIdx.x; m < p.M; m += nblk * blockDim.x) {
             float t = 0.f;
             for (int k = 0; k < p.kslices; ++k) t += p.rowsum_ws[(int64_t)k * p.M + m];
             rowsum_store<T>(p, m, t);
         }
     }
 }
+template <typename T>
+__global__ __launch_bounds__(256) void gemm_splitk_reduce(GemmArgs p) {
+    splitk_reduce_body<T>(p, blockIdx.x, gridDim.x);
+}
+
+// The reductions of up to VALOR_REDUCE_GROUP split-K products in ONE launch (valor_gemm_reduce_group): the wgrads of a layer each
+// leave their partial tiles in their own piece of a workspace, this kernel walks a by-value table of their epilogue descriptions.
+// Per element the arithmetic is gemm_splitk_reduce's (same slice order, same epilogue): results are bit-identical; what goes away
+// is one launch, one ramp-up and one tail per product (309 reduce launches of ~10 us per step at VALOR-base).
+#define VALOR_REDUCE_GROUP 8
+struct ReduceGroupArgs {
+    GemmArgs g[VALOR_REDUCE_GROUP];
+    int first[VALOR_REDUCE_GROUP + 1];      // workgroups [first[i], first[i + 1]) work on problem i
+    int n;
+};
+template <typename T>
+__global__ __launch_bounds__(256) void gemm_splitk_reduce_group(ReduceGroupArgs a) {
+    int i = 0;
+    while (i + 1 < a.n && (int)blockIdx.x >= a.first[i + 1]) ++i;
+    splitk_reduce_body<T>(a.g[i], blockIdx.x - a.first[i], a.first[i + 1] - a.first[i]);
+}
+static int reduce_blocks(const GemmArgs& p) {
+    const int64_t total = (int64_t)p.M * ((p.N + 3) / 4);
+    int blocks = (int)((total + 255) / 256);
+    return blocks > 4096 ? 4096 : blocks;
+}
 
 // kernel variant of the bf16 path: 0 = register-staged (gemm_kernel), 1 = LDS-DMA single stage, 2 = LDS-DMA double stage
 static int g_gemm_variant = 4;
+static inline int gemm_variant() { return GEMM_KNOB(variant, g_gemm_variant); }
 extern "C" int valor_gemm_set_variant(int v) { const int o = g_gemm_variant; if (v >= 0 && v <= 4) g_gemm_variant = v; return o; }
 // variant 3: 256x256 8-phase kernel (gemm8.hip) wherever eligible, otherwise variant 1.
 // variant 4 (default): measured policy (tools/gemm_ab.py, profiles/r01_gemm_variants_*.json) -- the 8-phase kernel for
@@ -482,7 +509,8 @@ extern "C" int valor_gemm_set_variant(int v) { const int o = g_gemm_variant; if 
 //      556 -> 588 us, AST 114 -> 123 us, profiles/r05_gemm_mfma32_ab.json): the general epilogue evaluates the activation at read-out,
 //      between its global stores, where the VALU work hides under the store issue; here it sits in front of a burst of 32 stores per lane
 // [11] reserved
-int g_gemm_policy[12] = {[] { const char* e = getenv("VALOR_GEMM_NT_MINK"); return e ? atoi(e) : 768; }(),
+thread_local const GemmTuning* t_gemm_tuning = nullptr;
+int g_gemm_policy_default[12] = {[] { const char* e = getenv("VALOR_GEMM_NT_MINK"); return e ? atoi(e) : 768; }(),
                         [] { const char* e = getenv("VALOR_GEMM_SPLITK_BF16"); return e ? atoi(e) : 1; }(),
                         [] { const char* e = getenv("VALOR_GEMM_MIN_TILES"); return e ? atoi(e) : 256; }(),
                         [] { const char* e = getenv("VALOR_GEMM_NT_MIN_TILES"); return e ? atoi(e) : 1024; }(),
@@ -495,8 +523,8 @@ int g_gemm_policy[12] = {[] { const char* e = getenv("VALOR_GEMM_NT_MINK"); retu
                         [] { const char* e = getenv("VALOR_GEMM_TWO_OUT"); return e ? atoi(e) : 0; }(), 0};
 extern "C" int valor_gemm_set_policy(int key, int value) {
     if (key < 0 || key > 11) return VALOR_ERR_ARG;
-    const int old = g_gemm_policy[key];
-    if (value >= 0) g_gemm_policy[key] = value;
+    const int old = g_gemm_policy_default[key];
+    if (value >= 0) g_gemm_policy_default[key] = value;
     return old;
 }
 
@@ -505,20 +533,20 @@ extern "C" int valor_gemm_set_policy(int key, int value) {
 // (K = 768, profiles/r02_gemm_epilogue_ab.json) 769 us on the 128x128 kernel vs 896 us on the 8-phase one, while the PLAIN dgrad of
 // the same shape is 510 vs 544 us the other way round.
 static bool use_8ph(int dtype, int transA, int transB, int M, int N, int K, bool heavy_epi = false) {
-    if (dtype != VALOR_DT_BF16 || g_gemm_variant < 3) return false;
+    if (dtype != VALOR_DT_BF16 || gemm_variant() < 3) return false;
     if ((K % 64) != 0 || K < 128 || M < 256 || N < 256) return false;
-    if (g_gemm_variant == 3) return true;
+    if (gemm_variant() == 3) return true;
     const int64_t tiles256 = (int64_t)((M + 255) / 256) * ((N + 255) / 256);
     if (transA && transB) return K >= 4096;                           // wgrad: K = tokens, split-K fills one round
-    if (!transA && !transB) return tiles256 >= g_gemm_policy[2] && K >= g_gemm_policy[7];      // forward: at least one full round of 256 workgroups (in-step sweep, session K: 1024 / 512 / 256 / 128 tiles -> 133.5 / 134.2 / 132.0 / 138.1 ms)
-    if (!transA && transB) return tiles256 >= g_gemm_policy[3] && K >= (heavy_epi ? 1536 : g_gemm_policy[0]);      // dgrad
+    if (!transA && !transB) return tiles256 >= gemm_policy(2) && K >= gemm_policy(7);      // forward: at least one full round of 256 workgroups (in-step sweep, session K: 1024 / 512 / 256 / 128 tiles -> 133.5 / 134.2 / 132.0 / 138.1 ms)
+    if (!transA && transB) return tiles256 >= gemm_policy(3) && K >= (heavy_epi ? 1536 : gemm_policy(0));      // dgrad
     return false;
 }
 
 // the narrow 8-phase kernel (gemm8n.hip), policy key 8
 static bool use_8ph2(int dtype, int transA, int transB, int M, int N, int K, bool heavy_epi, bool big) {
-    const int mode = g_gemm_policy[8];
-    if (dtype != VALOR_DT_BF16 || g_gemm_variant != 4 || mode == 0) return false;        // (variants 0-3 pin ONE other family)
+    const int mode = gemm_policy(8);
+    if (dtype != VALOR_DT_BF16 || gemm_variant() != 4 || mode == 0) return false;        // (variants 0-3 pin ONE other family)
     if ((K % 64) != 0 || K < 128 || M < 256 || N < 128) return false;
     if (transA && !transB) return false;                     // no caller has this layout at a size that matters
     if (mode == 1) return true;
@@ -544,15 +572,26 @@ static bool use_8ph2(int dtype, int transA, int transB, int M, int N, int K, boo
 // kernel family of a problem: 0 = register-staged 128x128 (also all fp32), 1 / 2 = LDS-DMA 128x128 single / double stage,
 // 3 = 256x256 8-phase (gemm8.hip), 4 = 256x128 8-phase with two workgroups per CU (gemm8n.hip)
 static int gemm_family(int dtype, int transA, int transB, int M, int N, int K, bool heavy_epi) {
-    if (dtype != VALOR_DT_BF16 || g_gemm_variant == 0) return 0;
+    if (dtype != VALOR_DT_BF16 || gemm_variant() == 0) return 0;
     const bool big = use_8ph(dtype, transA, transB, M, N, K, heavy_epi);
     if (use_8ph2(dtype, transA, transB, M, N, K, heavy_epi, big)) return 4;
     if (big) return 3;
-    return g_gemm_variant == 2 ? 2 : 1;
+    return gemm_variant() == 2 ? 2 : 1;
 }
 
 // which kernel family valor_gemm uses for a problem (bench.py groups its roofline numbers by this)
 extern "C" int valor_gemm_kernel_for(int dtype, int transA, int transB, int M, int N, int K, int heavy_epilogue) {
+    return gemm_family(dtype, transA, transB, M, N, K, heavy_epilogue != 0);
+}
+// a valor_gemm_policy in force for the current call (and thread) only
+struct TuningScope {
+    const GemmTuning* prev;
+    explicit TuningScope(const void* t) : prev(t_gemm_tuning) { if (t) t_gemm_tuning = (const GemmTuning*)t; }
+    ~TuningScope() { t_gemm_tuning = prev; }
+};
+static_assert(sizeof(GemmTuning) == 17 * sizeof(int), "valor_gemm_policy layout (include/valor_hip.h)");
+extern "C" int valor_gemm_kernel_for_tuned(const void* policy, int dtype, int transA, int transB, int M, int N, int K, int heavy_epilogue) {
+    TuningScope scope(policy);
     return gemm_family(dtype, transA, transB, M, N, K, heavy_epilogue != 0);
 }
 
@@ -593,23 +632,19 @@ template <typename T>
 static int launch_gemm(hipStream_t st, int transA, int transB, GemmArgs p) {
     const int tiles = ((p.M + 127) / 128) * ((p.N + 127) / 128);
     dim3 grid(tiles, p.kslices > 1 ? p.kslices : 1);
-    if (ElemTraits<T>::DT == VALOR_DT_BF16 && g_gemm_variant > 0) {
+    if (ElemTraits<T>::DT == VALOR_DT_BF16 && gemm_variant() > 0) {
         if (p.kslices > 1) grid = dim3(tiles * p.kslices, 1);     // split-K: 1-D grid over (slice, tile) work items
         const int fam = gemm_family(VALOR_DT_BF16, transA, transB, p.M, p.N, p.K, p.dact_aux != nullptr && !(p.act & VALOR_ACT_DERIV));
         if (fam == 4) launch_gemm_8ph2(st, transA, transB, p);
         else if (fam == 3) launch_gemm_8ph(st, transA, transB, p);
         else {
             // policy key 6: the 128x128 kernels store big bf16 outputs of short-K problems non-temporally too (A/B hook, default off)
-            p.st_mode = (g_gemm_policy[6] && !p.out_f32 && p.kslices <= 1 && p.K <= 1024 && (int64_t)p.M * p.N >= (4 << 20)) ? 1 : 0;
-            if (g_gemm_variant == 2) launch_gemm_glds<2>(st, transA, transB, p, grid);
+            p.st_mode = (gemm_policy(6) && !p.out_f32 && p.kslices <= 1 && p.K <= 1024 && (int64_t)p.M * p.N >= (4 << 20)) ? 1 : 0;
+            if (gemm_variant() == 2) launch_gemm_glds<2>(st, transA, transB, p, grid);
             else launch_gemm_glds<1>(st, transA, transB, p, grid);
         }
-        if (p.kslices > 1) {
-            const int64_t total = (int64_t)p.M * ((p.N + 3) / 4);
-            int blocks = (int)((total + 255) / 256);
-            if (blocks > 4096) blocks = 4096;
-            hipLaunchKernelGGL((gemm_splitk_reduce<T>), dim3(blocks), dim3(256), 0, st, p);
-        }
+        if (p.kslices > 1 && !p.defer_reduce)
+            hipLaunchKernelGGL((gemm_splitk_reduce<T>), dim3(reduce_blocks(p)), dim3(256), 0, st, p);
         return valor_launch_status();
     }
     const size_t lds = 2 * 2 * 128 * TILE_ROW_BYTES;
@@ -628,20 +663,96 @@ static int launch_gemm(hipStream_t st, int transA, int transB, GemmArgs p) {
     else if (transA && !transB) VALOR_GEMM_LAUNCH(true, false);
     else VALOR_GEMM_LAUNCH(true, true);
 #undef VALOR_GEMM_LAUNCH
-    if (p.kslices > 1) {
-        const int64_t total = (int64_t)p.M * ((p.N + 3) / 4);
-        int blocks = (int)((total + 255) / 256);
-        if (blocks > 4096) blocks = 4096;
-        hipLaunchKernelGGL((gemm_splitk_reduce<T>), dim3(blocks), dim3(256), 0, st, p);
-    }
+    if (p.kslices > 1 && !p.defer_reduce)
+        hipLaunchKernelGGL((gemm_splitk_reduce<T>), dim3(reduce_blocks(p)), dim3(256), 0, st, p);
     return valor_launch_status();
 }
+
+// what a deferred split-K product left to do (include/valor_hip.h: valor_gemm_pending, 256 opaque bytes)
+struct PendingBlob { GemmArgs p; int dtype; int valid; };
+static_assert(sizeof(PendingBlob) <= 256, "valor_gemm_pending is 256 bytes");
+
+static int gemm_impl(void* stream, int dtype, int transA, int transB, int M, int N, int K,
+                     const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc,
+                     const void* bias, int act, void* preact, const void* dact_aux, int64_t ldaux,
+                     float alpha, int accumulate, int out_f32, void* workspace, int64_t workspace_bytes,
+                     void* rowsum_out, int rowsum_accumulate, PendingBlob* pending);
 
 extern "C" int valor_gemm(void* stream, int dtype, int transA, int transB, int M, int N, int K,
                           const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc,
                           const void* bias, int act, void* preact, const void* dact_aux, int64_t ldaux,
                           float alpha, int accumulate, int out_f32, void* workspace, int64_t workspace_bytes,
                           void* rowsum_out, int rowsum_accumulate) {
+    return gemm_impl(stream, dtype, transA, transB, M, N, K, A, lda, B, ldb, C, ldc, bias, act, preact, dact_aux, ldaux, alpha, accumulate,
+                     out_f32, workspace, workspace_bytes, rowsum_out, rowsum_accumulate, nullptr);
+}
+
+// valor_gemm under a per-call valor_gemm_policy (NULL = the process defaults): nothing global is read or written on behalf of the
+// fields that are set, so two threads (or two libraries in one process) can run different kernel choices side by side
+extern "C" int valor_gemm_tuned(const void* policy, void* stream, int dtype, int transA, int transB, int M, int N, int K,
+                                const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc,
+                                const void* bias, int act, void* preact, const void* dact_aux, int64_t ldaux,
+                                float alpha, int accumulate, int out_f32, void* workspace, int64_t workspace_bytes,
+                                void* rowsum_out, int rowsum_accumulate) {
+    TuningScope scope(policy);
+    return gemm_impl(stream, dtype, transA, transB, M, N, K, A, lda, B, ldb, C, ldc, bias, act, preact, dact_aux, ldaux, alpha, accumulate,
+                     out_f32, workspace, workspace_bytes, rowsum_out, rowsum_accumulate, nullptr);
+}
+
+// valor_gemm whose split-K reduction is left to valor_gemm_reduce_group: `pending` (256 bytes, host memory) receives what remains to do;
+// valor_gemm_pending_bytes(pending) == 0 afterwards means the product ran without split-K and is complete (C written, nothing pending).
+// The workspace piece handed in must stay untouched until the group reduction has been ENQUEUED on the same stream.
+extern "C" int valor_gemm_deferred(void* stream, int dtype, int transA, int transB, int M, int N, int K,
+                                   const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc,
+                                   const void* bias, int act, void* preact, const void* dact_aux, int64_t ldaux,
+                                   float alpha, int accumulate, int out_f32, void* workspace, int64_t workspace_bytes,
+                                   void* rowsum_out, int rowsum_accumulate, void* pending) {
+    if (!pending) return VALOR_ERR_ARG;
+    PendingBlob* pb = (PendingBlob*)pending;
+    pb->valid = 0; pb->dtype = dtype; pb->p.kslices = 0;
+    return gemm_impl(stream, dtype, transA, transB, M, N, K, A, lda, B, ldb, C, ldc, bias, act, preact, dact_aux, ldaux, alpha, accumulate,
+                     out_f32, workspace, workspace_bytes, rowsum_out, rowsum_accumulate, pb);
+}
+
+// bytes of the workspace piece a pending product occupies (0: nothing pending), rounded up to 256
+extern "C" int valor_gemm_pending_bytes(const void* pending, int64_t* bytes) {
+    if (!pending || !bytes) return VALOR_ERR_ARG;
+    const PendingBlob* pb = (const PendingBlob*)pending;
+    *bytes = 0;
+    if (!pb->valid || pb->p.kslices <= 1) return VALOR_OK;
+    const int64_t n = ((int64_t)pb->p.kslices * pb->p.M * pb->p.N + (int64_t)pb->p.kslices * pb->p.M) * 4;
+    *bytes = (n + 255) & ~(int64_t)255;
+    return VALOR_OK;
+}
+
+// ONE launch for the reductions (and epilogues: alpha, bias, C +=, fused row sums) of n <= 8 pending products of one dtype
+extern "C" int valor_gemm_reduce_group(void* stream, int dtype, const void* pendings, int n) {
+    if (n <= 0) return VALOR_OK;
+    if (!pendings || n > VALOR_REDUCE_GROUP) return VALOR_ERR_ARG;
+    ReduceGroupArgs a;
+    a.n = 0; a.first[0] = 0;
+    for (int i = 0; i < n; ++i) {
+        const PendingBlob* pb = (const PendingBlob*)((const char*)pendings + (size_t)i * 256);
+        if (!pb->valid || pb->p.kslices <= 1) continue;
+        if (pb->dtype != dtype) return VALOR_ERR_ARG;
+        a.g[a.n] = pb->p;
+        a.first[a.n + 1] = a.first[a.n] + reduce_blocks(pb->p);
+        ++a.n;
+    }
+    if (a.n == 0) return VALOR_OK;
+    for (int i = a.n; i < VALOR_REDUCE_GROUP; ++i) a.first[i + 1] = a.first[a.n];
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == VALOR_DT_BF16) hipLaunchKernelGGL((gemm_splitk_reduce_group<bf16_t>), dim3(a.first[a.n]), dim3(256), 0, st, a);
+    else if (dtype == VALOR_DT_F32) hipLaunchKernelGGL((gemm_splitk_reduce_group<float>), dim3(a.first[a.n]), dim3(256), 0, st, a);
+    else return VALOR_ERR_ARG;
+    return valor_launch_status();
+}
+
+static int gemm_impl(void* stream, int dtype, int transA, int transB, int M, int N, int K,
+                     const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc,
+                     const void* bias, int act, void* preact, const void* dact_aux, int64_t ldaux,
+                     float alpha, int accumulate, int out_f32, void* workspace, int64_t workspace_bytes,
+                     void* rowsum_out, int rowsum_accumulate, PendingBlob* pending) {
     if (M <= 0 || N <= 0) return VALOR_OK;
     // fused row sums only exist in the 8-phase kernel with a k-slow A operand (ask valor_gemm_kernel_for first)
     if (rowsum_out && !(transA && gemm_family(dtype, transA, transB, M, N, K, false) >= 3)) return VALOR_ERR_ARG;
@@ -693,6 +804,7 @@ extern "C" int valor_gemm(void* stream, int dtype, int transA, int transB, int M
     p.M = M; p.N = N; p.K = K; p.act = act; p.accumulate = accumulate; p.out_f32 = out_f32;
     p.alpha = alpha;
     p.rowsum_out = rowsum_out; p.rowsum_acc = rowsum_accumulate; p.rowsum_ws = nullptr; p.fast_epi = 0; p.raster_g = 0; p.st_mode = 0; p.ws_bf16 = 0;
+    p.defer_reduce = 0;
     {
         const int64_t esz = dtype == VALOR_DT_BF16 ? 2 : 4;
         // direct: rows x ld with K valid in the last row; transposed: K rows of ld elements (caller guarantees
@@ -715,7 +827,7 @@ extern "C" int valor_gemm(void* stream, int dtype, int transA, int transB, int M
         if (slices > 64) slices = 64;
         while (slices > 1 && (int64_t)slices * M * N * 4 > workspace_bytes) --slices;
     }
-    if (dtype == VALOR_DT_BF16 && g_gemm_variant > 0) {
+    if (dtype == VALOR_DT_BF16 && gemm_variant() > 0) {
         // XCD-sliced split-K of the LDS-DMA kernels: 8*s slices, s = sub-slices per XCD chosen to fill (not
         // overflow) the 128 workgroup slots of an XCD (32 CUs x 4); >= 8 K-steps per workgroup.
         // split-K of the LDS-DMA kernels: as many K-slices as fill -- without overflowing -- ONE round of workgroup
@@ -739,7 +851,7 @@ extern "C" int valor_gemm(void* stream, int dtype, int transA, int transB, int M
         p.ksteps_per_slice = (nk + slices - 1) / slices;     // trailing slices may be short or empty (they add zeros)
         // policy key 1: the partial tiles as bf16 -- half the workspace traffic of the GEMM epilogue and of gemm_splitk_reduce (3.5 ms per
         // step at VALOR-base) for one more rounding per partial (their sum is rounded to bf16 anyway unless the output is fp32)
-        p.ws_bf16 = (slices > 1 && g_gemm_policy[1] && !out_f32) ? 1 : 0;
+        p.ws_bf16 = (slices > 1 && gemm_policy(1) && !out_f32) ? 1 : 0;
     } else {
         p.kslices = slices;
         p.ksteps_per_slice = (nk + slices - 1) / slices;
@@ -748,6 +860,10 @@ extern "C" int valor_gemm(void* stream, int dtype, int transA, int transB, int M
         }
     }
     hipStream_t st = (hipStream_t)stream;
+    if (pending && p.kslices > 1) {       // the caller reduces later (valor_gemm_reduce_group): remember how
+        p.defer_reduce = 1;
+        pending->p = p; pending->dtype = dtype; pending->valid = 1;
+    }
     if (dtype == VALOR_DT_BF16) return launch_gemm<bf16_t>(st, transA, transB, p);
     if (dtype == VALOR_DT_F32) return launch_gemm<float>(st, transA, transB, p);
     return VALOR_ERR_ARG;

@@ -618,14 +618,18 @@ extern "C" int valor_gemm_set_8ph_sched(int v) {
     return old;
 }
 
+int gemm_tr_asm_now() { return GEMM_KNOB(tr_asm, g_8ph_tr_asm); }
+int gemm_fast_epilogue_now() { return GEMM_KNOB(fast_epilogue, g_8ph_fast_epi); }
+
 void launch_gemm_8ph(hipStream_t st, int transA, int transB, const GemmArgs& p_in) {
     GemmArgs p = p_in;
+    const int fast_epi_ = gemm_fast_epilogue_now(), tr_asm_ = gemm_tr_asm_now();
     // measured (profiles/r02_gemm_epilogue_ab.json): the bf16 tile epilogue wins 1-5 % on plain / bias / activation / C += problems,
     // loses on a pre-activation copy (two tile passes: 939 vs 741 us on the ViT fc1 forward) and on the act' multiply (927 vs 896 us):
     // those keep the general epilogue (mode 2 forces the tile path everywhere it is implemented, for tests / A-B runs)
     const bool light_dact = p.dact_aux && (p.act & VALOR_ACT_DERIV);          // one multiply per value at read-out
-    const bool plainish = g_8ph_fast_epi >= 2 || (!p.preact && (!p.dact_aux || light_dact));
-    p.fast_epi = g_8ph_fast_epi && plainish && !p.out_f32 && p.kslices <= 1 && (p.N & 7) == 0 && (p.ldc & 7) == 0 && !p.rowsum_out &&
+    const bool plainish = fast_epi_ >= 2 || (!p.preact && (!p.dact_aux || light_dact));
+    p.fast_epi = fast_epi_ && plainish && !p.out_f32 && p.kslices <= 1 && (p.N & 7) == 0 && (p.ldc & 7) == 0 && !p.rowsum_out &&
                  (!p.dact_aux || (p.ldaux & 7) == 0) && !(p.dact_aux && p.preact) && !transA && !(p.preact && (p.act & VALOR_ACT_DERIV));
     const int tiles_m = (p.M + 255) / 256, tiles_n = (p.N + 255) / 256;
     const int tiles = tiles_m * tiles_n;
@@ -634,9 +638,9 @@ void launch_gemm_8ph(hipStream_t st, int transA, int transB, const GemmArgs& p_i
     // 32 x 128 KiB of output and the A rows, re-fetches every touched panel once per round; with groups of G columns the G panels stay
     // resident and A is read once per group.
     p.raster_g = 0;
-    if (p.kslices <= 1 && tiles_n > 1 && g_gemm_policy[4] != 0) {
-        if (g_gemm_policy[4] != 1000) {
-            p.raster_g = g_gemm_policy[4] < tiles_n ? g_gemm_policy[4] : 0;
+    if (p.kslices <= 1 && tiles_n > 1 && gemm_policy(4) != 0) {
+        if (gemm_policy(4) != 1000) {
+            p.raster_g = gemm_policy(4) < tiles_n ? gemm_policy(4) : 0;
         } else {
             const double panel = 256.0 * p.K * 2.0, a_bytes = (double)p.M * p.K * 2.0, rounds = tiles / 256.0;
             const double resident = 2.5 * 1048576.0;
@@ -651,11 +655,11 @@ void launch_gemm_8ph(hipStream_t st, int transA, int transB, const GemmArgs& p_i
         }
     }
     // non-temporal output stores: bf16 outputs of short-K problems (policy key 5: 0 never, 1 always, 1000 = K <= 1024)
-    const bool nts = !transA && !p.out_f32 && p.kslices <= 1 && (g_gemm_policy[5] == 1 || (g_gemm_policy[5] == 1000 && p.K <= 1024));
+    const bool nts = !transA && !p.out_f32 && p.kslices <= 1 && (gemm_policy(5) == 1 || (gemm_policy(5) == 1000 && p.K <= 1024));
     p.st_mode = nts ? 1 : 0;
     dim3 grid(tiles * (p.kslices > 1 ? p.kslices : 1));
     const size_t lds = 2 * BUF_BYTES;
-    int sched = g_8ph_sched;
+    int sched = GEMM_KNOB(sched_256, g_8ph_sched);
     if (sched == 1000) {
         const int ktiles = p.kslices > 1 ? p.ksteps_per_slice : p.K / 64;
         sched = transA ? (ktiles <= 48 ? 1 : 0) : (p.K >= 2048 ? 1 : 0);
@@ -670,8 +674,8 @@ void launch_gemm_8ph(hipStream_t st, int transA, int transB, const GemmArgs& p_i
             hipFuncSetAttribute((const void*)gemm_8ph_kernel<TA_, TB_, kslow_, NTS_, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
             attr_set = true;                                                                                    \
         }                                                                                                       \
-        if (sched == 1 && (g_8ph_tr_asm || !kslow_)) hipLaunchKernelGGL((gemm_8ph_kernel<TA_, TB_, kslow_, NTS_, 1>), grid, dim3(512), lds, st, p); \
-        else if (g_8ph_tr_asm && kslow_) hipLaunchKernelGGL((gemm_8ph_kernel<TA_, TB_, true, NTS_>), grid, dim3(512), lds, st, p); \
+        if (sched == 1 && (tr_asm_ || !kslow_)) hipLaunchKernelGGL((gemm_8ph_kernel<TA_, TB_, kslow_, NTS_, 1>), grid, dim3(512), lds, st, p); \
+        else if (tr_asm_ && kslow_) hipLaunchKernelGGL((gemm_8ph_kernel<TA_, TB_, true, NTS_>), grid, dim3(512), lds, st, p); \
         else hipLaunchKernelGGL((gemm_8ph_kernel<TA_, TB_, false, NTS_>), grid, dim3(512), lds, st, p);       \
     } while (0)
     if (!transA && !transB) { if (nts) VALOR_8PH_LAUNCH(false, false, true); else VALOR_8PH_LAUNCH(false, false, false); }

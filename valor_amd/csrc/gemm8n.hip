@@ -708,22 +708,23 @@ extern "C" int valor_gemm_set_fast_epilogue(int v);
 
 void launch_gemm_8ph2(hipStream_t st, int transA, int transB, const GemmArgs& p_in) {
     GemmArgs p = p_in;
-    const int fast_mode = valor_gemm_set_fast_epilogue(-1), tr_asm = valor_gemm_set_tr_asm(-1);
+    const int fast_mode = gemm_fast_epilogue_now(), tr_asm = gemm_tr_asm_now();
+    const int sched_n = GEMM_KNOB(sched_narrow, g_8ph2_sched);
     // the bf16 tile epilogue under the conditions of the 256x256 kernel (gemm8.hip: launch_gemm_8ph)
     const bool light_dact = p.dact_aux && (p.act & VALOR_ACT_DERIV);
     // policy key 10: the forward that saves act'(u) beside act(u) (two outputs) through the bf16 half-tile path of the kernel
     const bool two_out = p.preact && (p.act & VALOR_ACT_DERIV) && !p.dact_aux;
-    const bool plainish = fast_mode >= 2 || (!p.preact && (!p.dact_aux || light_dact)) || (two_out && g_gemm_policy[10] != 0);
+    const bool plainish = fast_mode >= 2 || (!p.preact && (!p.dact_aux || light_dact)) || (two_out && gemm_policy(10) != 0);
     p.fast_epi = fast_mode && plainish && !p.out_f32 && p.kslices <= 1 && (p.N & 7) == 0 && (p.ldc & 7) == 0 && !p.rowsum_out &&
                  (!p.dact_aux || (p.ldaux & 7) == 0) && !(p.dact_aux && p.preact) && !transA &&
-                 (!(p.preact && (p.act & VALOR_ACT_DERIV)) || (two_out && g_gemm_policy[10] != 0));
+                 (!(p.preact && (p.act & VALOR_ACT_DERIV)) || (two_out && gemm_policy(10) != 0));
     const int tiles_m = (p.M + 255) / 256, tiles_n = (p.N + 127) / 128;
     const int tiles = tiles_m * tiles_n;
     // L2-aware raster: the model of launch_gemm_8ph with 128-column panels and 64 concurrent tiles per XCD
     p.raster_g = 0;
-    if (p.kslices <= 1 && tiles_n > 1 && g_gemm_policy[4] != 0) {
-        if (g_gemm_policy[4] != 1000) {
-            p.raster_g = 2 * g_gemm_policy[4] < tiles_n ? 2 * g_gemm_policy[4] : 0;
+    if (p.kslices <= 1 && tiles_n > 1 && gemm_policy(4) != 0) {
+        if (gemm_policy(4) != 1000) {
+            p.raster_g = 2 * gemm_policy(4) < tiles_n ? 2 * gemm_policy(4) : 0;
         } else {
             const double panel = 128.0 * p.K * 2.0, a_bytes = (double)p.M * p.K * 2.0, rounds = tiles / 512.0;
             const double resident = 2.5 * 1048576.0;
@@ -737,7 +738,7 @@ void launch_gemm_8ph2(hipStream_t st, int transA, int transB, const GemmArgs& p_
             }
         }
     }
-    const bool nts = !transA && !p.out_f32 && p.kslices <= 1 && (g_gemm_policy[5] == 1 || (g_gemm_policy[5] == 1000 && p.K <= 1024));
+    const bool nts = !transA && !p.out_f32 && p.kslices <= 1 && (gemm_policy(5) == 1 || (gemm_policy(5) == 1000 && p.K <= 1024));
     p.st_mode = nts ? 1 : 0;
     dim3 grid(tiles * (p.kslices > 1 ? p.kslices : 1));
     const size_t lds = N8_LDS;
@@ -754,16 +755,16 @@ void launch_gemm_8ph2(hipStream_t st, int transA, int transB, const GemmArgs& p_
     do {                                                                                                        \
         constexpr bool kslow_ = TA_ || TB_;                                                                     \
         if (kslow_ && !tr_asm) { VALOR_8PH2_LAUNCH1(TA_, TB_, false, NTS_, 0, false); }                         \
-        else if (g_8ph2_sched == 1) { VALOR_8PH2_LAUNCH1(TA_, TB_, kslow_, NTS_, 1, false); }                   \
+        else if (sched_n == 1) { VALOR_8PH2_LAUNCH1(TA_, TB_, kslow_, NTS_, 1, false); }                   \
         else { VALOR_8PH2_LAUNCH1(TA_, TB_, kslow_, NTS_, 0, false); }                                          \
     } while (0)
     // policy key 9: the NN main loop on v_mfma_f32_32x32x16_bf16 (M32, see the top of this file)
 #define VALOR_8PH2_LAUNCH_M32(NTS_)                                                                             \
     do {                                                                                                        \
-        if (g_8ph2_sched == 1) { VALOR_8PH2_LAUNCH1(false, false, false, NTS_, 1, true); }                      \
+        if (sched_n == 1) { VALOR_8PH2_LAUNCH1(false, false, false, NTS_, 1, true); }                      \
         else { VALOR_8PH2_LAUNCH1(false, false, false, NTS_, 0, true); }                                        \
     } while (0)
-    if (!transA && !transB && g_gemm_policy[9] != 0) { if (nts) VALOR_8PH2_LAUNCH_M32(true); else VALOR_8PH2_LAUNCH_M32(false); }
+    if (!transA && !transB && gemm_policy(9) != 0) { if (nts) VALOR_8PH2_LAUNCH_M32(true); else VALOR_8PH2_LAUNCH_M32(false); }
     else if (!transA && !transB) { if (nts) VALOR_8PH2_LAUNCH(false, false, true); else VALOR_8PH2_LAUNCH(false, false, false); }
     else if (!transA && transB) { if (nts) VALOR_8PH2_LAUNCH(false, true, true); else VALOR_8PH2_LAUNCH(false, true, false); }
     else if (transA && !transB) VALOR_8PH2_LAUNCH(true, false, false);
@@ -778,7 +779,7 @@ extern "C" int valor_gemm_narrow_occupancy(void) {
     int n = 0;
     hipFuncSetAttribute((const void*)gemm_8ph2_kernel<false, false, false, false, 0, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)N8_LDS);
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, (const void*)gemm_8ph2_kernel<false, false, false, false, 0, false>, 256, N8_LDS) != hipSuccess) return -1;
-    if (g_gemm_policy[9] != 0) {        // the M32 instantiations must fit twice per CU as well
+    if (gemm_policy(9) != 0) {        // the M32 instantiations must fit twice per CU as well
         int n32 = 0;
         hipFuncSetAttribute((const void*)gemm_8ph2_kernel<false, false, false, true, 1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)N8_LDS);
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n32, (const void*)gemm_8ph2_kernel<false, false, false, true, 1, true>, 256, N8_LDS) != hipSuccess) return -1;

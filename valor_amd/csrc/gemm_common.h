@@ -26,6 +26,7 @@ struct GemmArgs {
     int raster_g;              // 8-phase kernels: tile columns per raster group (0 = row-major over all tile columns), see gemm8.hip
     int st_mode;               // 16-byte bf16 output stores: 0 plain, 1 non-temporal (see store_out16)
     int ws_bf16;               // split-K partials [S][M][N] are written / summed as bf16 instead of fp32 (LDS-DMA bf16 kernels; policy key 1)
+    int defer_reduce;          // split-K: leave the partial tiles in the workspace, the caller runs valor_gemm_reduce_group later
 };
 
 // 8 consecutive fp32 partial sums of one row -> the split-K workspace of slice `slice` (fp32, or bf16 when p.ws_bf16)
@@ -225,4 +226,16 @@ DEVINL void epilogue_store8(const GemmArgs& p, int m, int n0, f32x4_t a0, f32x4_
 void launch_gemm_8ph(hipStream_t st, int transA, int transB, const GemmArgs& p);
 // 256x128 8-phase bf16 kernel, two workgroups per CU (gemm8n.hip). grid.x = tiles(256 x 128) * max(kslices, 1).
 void launch_gemm_8ph2(hipStream_t st, int transA, int transB, const GemmArgs& p);
-extern int g_gemm_policy[12];     // valor_gemm_set_policy (gemm.hip)
+// ---- tuning knobs. Process defaults (valor_gemm_set_policy / _set_variant / ...; env presets) live in globals; a CALL can override any
+// of them through a valor_gemm_policy (include/valor_hip.h) handed to valor_gemm_tuned / valor_gemm_kernel_for_tuned: the entry points
+// park a pointer to it in a thread-local for the duration of the call, every read below looks there first. -1 = the process default.
+struct GemmTuning { int key[12]; int variant, tr_asm, fast_epilogue, sched_256, sched_narrow; };
+extern thread_local const GemmTuning* t_gemm_tuning;
+extern int g_gemm_policy_default[12];     // valor_gemm_set_policy (gemm.hip)
+static inline int gemm_policy(int k) {
+    const GemmTuning* o = t_gemm_tuning;
+    return (o && o->key[k] >= 0) ? o->key[k] : g_gemm_policy_default[k];
+}
+#define GEMM_KNOB(FIELD_, GLOBAL_) ((t_gemm_tuning && t_gemm_tuning->FIELD_ >= 0) ? t_gemm_tuning->FIELD_ : (GLOBAL_))
+int gemm_tr_asm_now();            // gemm8.hip: the transposing-read flavour / tile-epilogue mode in force for this call
+int gemm_fast_epilogue_now();

@@ -50,14 +50,80 @@ def workspace(device, nbytes=_WS_BYTES):
     return ws
 
 
+# ---------------------------------------------------------------------------------------------- grouped split-K reductions
+class ReduceQueue:
+    """Split-K products whose reduction is deferred (valor_gemm_deferred) wait here, each with its own piece of a per-stream group
+    workspace, until `flush` sums them in ONE launch per 8 (valor_gemm_reduce_group) and runs their `done` callbacks (the gradient-write
+    reports the data-parallel reducer waits for: a parameter is reported only once its final write is enqueued). One queue per stream.
+    Flushed when it holds 8 products, when the workspace is full, and at the end of the backward pass that filled it."""
+    GROUP = 8
+    BYTES = 1 << 30
+    PIECE = _WS_BYTES            # every product is offered what valor_gemm gets: the same slice counts, bit-identical sums
+    enabled = os.environ.get("VALOR_GROUP_REDUCE", "1") != "0"
+    _queues = {}
+    _armed = False               # an end-of-backward flush is scheduled
+
+    def __init__(self, device, stream):
+        import ctypes
+        self.stream = stream
+        self.ws = torch.empty(self.BYTES, dtype=torch.uint8, device=device)
+        self.blobs = (ctypes.c_char * (256 * self.GROUP))()
+        self.n, self.off, self.done, self.dtype = 0, 0, [], None
+
+    @classmethod
+    def current(cls, device):
+        st = torch.cuda.current_stream(device)
+        key = (device.index if device.index is not None else torch.cuda.current_device(), st.cuda_stream)
+        q = cls._queues.get(key)
+        if q is None:
+            q = cls._queues[key] = ReduceQueue(device, st)
+        return q
+
+    def flush(self):
+        if self.n:
+            import ctypes
+            lib.call("valor_gemm_reduce_group", self.stream.cuda_stream, self.dtype, ctypes.cast(self.blobs, ctypes.c_void_p), self.n)
+        done, self.done = self.done, []
+        self.n, self.off = 0, 0
+        for fn in done:
+            fn()
+
+    @classmethod
+    def flush_all(cls):
+        """every queue on its own stream; the CURRENT stream then waits for the others (their sums land in the gradient arena the
+        caller is about to read)"""
+        cls._armed = False
+        cur = torch.cuda.current_stream()
+        for q in cls._queues.values():
+            if q.n or q.done:
+                q.flush()
+                if q.stream != cur:
+                    cur.wait_stream(q.stream)
+
+    @classmethod
+    def _arm(cls):
+        if cls._armed:
+            return
+        try:
+            from torch.autograd.variable import Variable
+            Variable._execution_engine.queue_callback(cls.flush_all)
+            cls._armed = True
+        except RuntimeError:          # not inside a backward pass (a direct call from a test): nothing will flush later -- do it now
+            cls.flush_all()
+
+
 def _rowmajor(t):
     assert t.dim() == 2 and t.stride(1) == 1, "need a 2-D tensor with unit inner stride"
     return t.stride(0)
 
 
 def gemm(a, b, *, trans_a=False, trans_b=False, bias=None, act=ACT_NONE, want_preact=False,
-         dact_aux=None, alpha=1.0, out=None, accumulate=False, out_dtype=None, splitk=True, rowsum_out=None, rowsum_accumulate=False):
-    """C[M,N] = epi(alpha * op(A) . op(B)^T).  A: [M,K] ([K,M] if trans_a); B: [N,K] ([K,N] if trans_b)."""
+         dact_aux=None, alpha=1.0, out=None, accumulate=False, out_dtype=None, splitk=True, rowsum_out=None, rowsum_accumulate=False,
+         defer_done=None, policy=None):
+    """C[M,N] = epi(alpha * op(A) . op(B)^T).  A: [M,K] ([K,M] if trans_a); B: [N,K] ([K,N] if trans_b).
+    defer_done (a callable): the caller does not need C before the end of the backward pass (a weight gradient accumulated into the
+    arena). If the product is split along K its reduction joins the stream's ReduceQueue and `defer_done` runs when the grouped
+    reduction has been enqueued; otherwise it runs at once."""
     _check_gpu(a, b, bias, dact_aux, out)
     M, K = (a.shape[1], a.shape[0]) if trans_a else (a.shape[0], a.shape[1])
     N, Kb = (b.shape[1], b.shape[0]) if trans_b else (b.shape[0], b.shape[1])
@@ -75,11 +141,43 @@ def gemm(a, b, *, trans_a=False, trans_b=False, bias=None, act=ACT_NONE, want_pr
         preact = torch.empty((M, N), dtype=odt, device=a.device)
         assert _rowmajor(preact) == ldc
     ldaux = _rowmajor(dact_aux) if dact_aux is not None else 0
+    if defer_done is not None and splitk and ReduceQueue.enabled and not want_preact and policy is None:
+        import ctypes
+        q = ReduceQueue.current(a.device)
+        dt = dt_of(a)
+        if q.n == q.GROUP or q.off + q.PIECE > q.BYTES or (q.n and q.dtype != dt):
+            q.flush()
+        blob = ctypes.addressof(q.blobs) + 256 * q.n
+        lib.call("valor_gemm_deferred", _stream(), dt, int(trans_a), int(trans_b), M, N, K,
+                 _ptr(a), lda, _ptr(b), ldb, _ptr(out), ldc, _ptr(bias), act, 0, _ptr(dact_aux), ldaux,
+                 float(alpha), int(accumulate), out_f32, q.ws.data_ptr() + q.off, q.PIECE, _ptr(rowsum_out), int(rowsum_accumulate), blob)
+        used = ctypes.c_int64(0)
+        lib.call("valor_gemm_pending_bytes", blob, ctypes.cast(ctypes.byref(used), ctypes.c_void_p))
+        if used.value:
+            q.dtype = dt
+            q.n += 1
+            q.off += used.value
+            q.done.append(defer_done)
+            ReduceQueue._arm()
+        else:
+            defer_done()
+        return out
     ws = workspace(a.device) if splitk else None
+    if policy is not None:          # a lib.GemmPolicy: this call only, no process-global knob is touched
+        import ctypes
+        lib.call("valor_gemm_tuned", ctypes.addressof(policy), _stream(), dt_of(a), int(trans_a), int(trans_b), M, N, K,
+                 _ptr(a), lda, _ptr(b), ldb, _ptr(out), ldc, _ptr(bias), act, _ptr(preact), _ptr(dact_aux), ldaux,
+                 float(alpha), int(accumulate), out_f32, _ptr(ws), (ws.numel() * 4 if ws is not None else 0),
+                 _ptr(rowsum_out), int(rowsum_accumulate))
+        if defer_done is not None:
+            defer_done()
+        return (out, preact) if want_preact else out
     lib.call("valor_gemm", _stream(), dt_of(a), int(trans_a), int(trans_b), M, N, K,
              _ptr(a), lda, _ptr(b), ldb, _ptr(out), ldc, _ptr(bias), act, _ptr(preact), _ptr(dact_aux), ldaux,
              float(alpha), int(accumulate), out_f32, _ptr(ws), (ws.numel() * 4 if ws is not None else 0),
              _ptr(rowsum_out), int(rowsum_accumulate))
+    if defer_done is not None:
+        defer_done()
     return (out, preact) if want_preact else out
 
 

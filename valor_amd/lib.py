@@ -20,6 +20,25 @@ ACT_DERIV = 16      # flag: `preact` / `dact_aux` hold act'(x) instead of x (inc
 _c = ctypes
 _vp, _i, _i64, _u64, _f = _c.c_void_p, _c.c_int, _c.c_int64, _c.c_uint64, _c.c_float
 
+class GemmPolicy(_c.Structure):
+    """valor_gemm_policy of include/valor_hip.h: per-call tuning, -1 = the process default. GemmPolicy.make(narrow=1, mfma32=1, ...)"""
+    _fields_ = [("key", _i * 12), ("variant", _i), ("tr_asm", _i), ("fast_epilogue", _i), ("sched_256", _i), ("sched_narrow", _i)]
+    KEYS = dict(nt_min_k=0, splitk_bf16=1, min_tiles=2, nt_min_tiles=3, raster=4, store=5, nta=6, nn_min_k=7, narrow=8, mfma32=9, two_out=10)
+
+    @classmethod
+    def make(cls, **kw):
+        p = cls()
+        for i in range(12):
+            p.key[i] = -1
+        p.variant = p.tr_asm = p.fast_epilogue = p.sched_256 = p.sched_narrow = -1
+        for k, v in kw.items():
+            if k in cls.KEYS:
+                p.key[cls.KEYS[k]] = int(v)
+            else:
+                setattr(p, k, int(v))
+        return p
+
+
 class XattnSeg(_c.Structure):
     """valor_xattn_seg of include/valor_hip.h"""
     _fields_ = [("q", _vp), ("o", _vp), ("dout", _vp), ("dq", _vp), ("lse", _vp), ("kv_range", _vp),
@@ -31,6 +50,13 @@ class XattnSeg(_c.Structure):
 SIGNATURES = {
     "valor_gemm": [_vp, _i, _i, _i, _i, _i, _i, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _i, _vp, _vp, _i64,
                    _f, _i, _i, _vp, _i64, _vp, _i],
+    "valor_gemm_tuned": [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _i, _vp, _vp, _i64,
+                         _f, _i, _i, _vp, _i64, _vp, _i],
+    "valor_gemm_kernel_for_tuned": [_vp, _i, _i, _i, _i, _i, _i, _i],
+    "valor_gemm_deferred": [_vp, _i, _i, _i, _i, _i, _i, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _i, _vp, _vp, _i64,
+                            _f, _i, _i, _vp, _i64, _vp, _i, _vp],
+    "valor_gemm_pending_bytes": [_vp, _vp],
+    "valor_gemm_reduce_group": [_vp, _i, _vp, _i],
     "valor_gemm_set_variant": [_i],
     "valor_gemm_kernel_for": [_i, _i, _i, _i, _i, _i, _i],
     "valor_gemm_set_tr_asm": [_i],

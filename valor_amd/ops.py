@@ -176,16 +176,21 @@ class LinearFn(Function):
             sw = _sink(pw)
             kw = dict(out=sw, accumulate=True) if sw is not None else {}
             if ctx.w_is_kn:
+                if sw is not None:
+                    kw["defer_done"] = lambda: _sunk(pw)          # the split-K reduction joins the layer's group (K.ReduceQueue)
                 dw = K.gemm(x2, dy2, trans_a=True, trans_b=True, **kw)
             else:
                 if sb is not None and K.gemm_fuses_rowsum(dy2, x2, True, True):      # bias gradient on the matrix pipe beside dW
                     kw.update(rowsum_out=sb, rowsum_accumulate=True); fused_b = True
+                if sw is not None:
+                    kw["defer_done"] = (lambda: (_sunk(pw), _sunk(pb))) if fused_b else (lambda: _sunk(pw))
                 dw = K.gemm(dy2, x2, trans_a=True, trans_b=True, **kw)
             if sw is not None:
-                dw = None; _sunk(pw)
+                dw = None
         if ctx.has_b and ctx.needs_input_grad[2]:
             if fused_b:
-                _sunk(pb)
+                if sw is None:
+                    _sunk(pb)
             elif sb is not None:
                 K.colsum(dy2, out=sb, accumulate=True); _sunk(pb)
             else:
@@ -235,12 +240,16 @@ class MlpFn(Function):
                 kw.update(rowsum_out=sb, rowsum_accumulate=True); fused = True
             if sw is None:
                 dw = K.gemm(dyy, xx, trans_a=True, trans_b=True, **kw)
+                if fused:
+                    _sunk(pb)
             else:
-                K.gemm(dyy, xx, trans_a=True, trans_b=True, out=sw, accumulate=True, **kw); _sunk(pw); dw = None
+                # the split-K reduction of this product joins the layer's group (K.ReduceQueue); the writes are reported when it is enqueued
+                done = (lambda: (_sunk(pw), _sunk(pb))) if fused else (lambda: _sunk(pw))
+                K.gemm(dyy, xx, trans_a=True, trans_b=True, out=sw, accumulate=True, defer_done=done, **kw); dw = None
             if pb is None:
                 return dw, None
             if fused:
-                _sunk(pb); return dw, None
+                return dw, None
             if sb is None:
                 return dw, K.colsum(dyy)
             K.colsum(dyy, out=sb, accumulate=True); _sunk(pb)
@@ -648,7 +657,7 @@ class DecoderXentSegFn(Function):
         pw, pb = ctx.params
         sw, sb = _sink(pw), _sink(pb)
         if sw is not None:
-            K.gemm(dlog, h, trans_a=True, trans_b=True, out=sw, accumulate=True); _sunk(pw); dw = None
+            K.gemm(dlog, h, trans_a=True, trans_b=True, out=sw, accumulate=True, defer_done=lambda: _sunk(pw)); dw = None
         else:
             dw = K.gemm(dlog, h, trans_a=True, trans_b=True)
         if sb is not None:
@@ -700,7 +709,7 @@ class DecoderXentFn(Function):
         pw, pb = ctx.params
         sw, sb = _sink(pw), _sink(pb)
         if sw is not None:
-            K.gemm(dlog, h, trans_a=True, trans_b=True, out=sw, accumulate=True); _sunk(pw); dw = None
+            K.gemm(dlog, h, trans_a=True, trans_b=True, out=sw, accumulate=True, defer_done=lambda: _sunk(pw)); dw = None
         else:
             dw = K.gemm(dlog, h, trans_a=True, trans_b=True)
         if sb is not None:
