@@ -140,10 +140,7 @@ int valor_gemm_set_fast_epilogue(int v);
  *          results up to the order of the fp32 partial sums), 0 (default) = v_mfma_f32_16x16x32_bf16 (env VALOR_GEMM_MFMA32); measured
  *          0-8 % SLOWER on the K = 768 forward shapes under the pipelined schedule, equal under the plain one and at K = 3072
  *          (profiles/r05_gemm_mfma32_ab.json)
- *   key 10: family 4: 1 = a forward that saves act'(u) beside act(u) writes BOTH outputs through the bf16 half-tile epilogue (one
- *          evaluation of the activation, 16-byte stores), 0 (default) = through the general two-pass fp32 epilogue (env VALOR_GEMM_TWO_OUT);
- *          measured 5-9 % slower than the general epilogue on every shape (profiles/r05_gemm_mfma32_ab.json), kept for A/B runs
- *   key 11: reserved */
+ *   keys 10, 11: reserved */
 int valor_gemm_set_policy(int key, int value);
 /* K-loop schedule of the family-3 (256x256) kernel: 0 = eight barriers per K-tile, wave rows staggered by one barrier; 1 = software-pipelined:
  * two barriers per K-tile, fragment reads and LDS-DMA pieces between the MFMAs of the half-phase before their consumer. Same results (same

@@ -1,4 +1,6 @@
-"""A/B of the family-4 GEMM's two round-5 additions at the step's FORWARD (NN) shapes, all forced onto family 4 (policy key 8 = 1):
+"""(The key-10 half of this tool measured a path that was removed afterwards -- see profiles/LOG.md; the numbers it wrote are in
+profiles/r05_gemm_mfma32_ab.json. Policy key 10 is a no-op now.)
+A/B of the family-4 GEMM's two round-5 additions at the step's FORWARD (NN) shapes, all forced onto family 4 (policy key 8 = 1):
   key 9:  main loop on v_mfma_f32_32x32x16_bf16 (1) against v_mfma_f32_16x16x32_bf16 (0), both schedules;
   key 10: the forward that saves act'(u) beside act(u) through the bf16 half-tile epilogue (1) against the general fp32 epilogue (0).
 Same random bf16 operands, interleaved rounds in one process, HIP events, median of the rounds; TF/s = 2 M N K / time.

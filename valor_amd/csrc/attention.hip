@@ -85,6 +85,8 @@ DEVINL KvSel kv_select(const AttnArgs& p, int b) {
 // roles: wave 0 stages K [key][d], wave 1 stages V^T [d][key].
 template <typename T, int RT>
 __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs p) {
+    const uint64_t rng_off = rng_offset(p.offset, p.rng_base);     // once, ahead of every loop: a scalar load inside the tile loop
+                                                                   // shares lgkmcnt with the LDS reads and drains their pipeline
     constexpr int VEC = ElemTraits<T>::VEC;
     constexpr int NIMG = 64 * (int)sizeof(T) / TILE_ROW_BYTES;   // 1 (bf16) / 2 (fp32)
     constexpr int NDG = ATT_D / (4 * VEC);                       // d-groups of 4 chunks: 2 / 4
@@ -125,7 +127,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs p) {
 
     const uint32_t thr = drop_threshold(p.p_drop);
     const float keep_scale = p.p_drop > 0.f ? 1.0f / (1.0f - p.p_drop) : 1.0f;
-    const uint32_t hk = attn_drop_headkey(p.seed, rng_offset(p.offset, p.rng_base), b * p.H + h);
+    const uint32_t hk = attn_drop_headkey(p.seed, rng_off, b * p.H + h);
 
     Stage64<T> st[NIMG];
     auto issue = [&](int kv0) {
@@ -244,6 +246,8 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs p) {
 // ------------------------------------------------------------------------------------------
 template <typename T>
 __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnArgs p) {
+    const uint64_t rng_off = rng_offset(p.offset, p.rng_base);     // once, ahead of every loop: a scalar load inside the tile loop
+                                                                   // shares lgkmcnt with the LDS reads and drains their pipeline
     constexpr int VEC = ElemTraits<T>::VEC;
     constexpr int NIMG = 64 * (int)sizeof(T) / TILE_ROW_BYTES;
     constexpr int NDG = ATT_D / (4 * VEC);
@@ -293,7 +297,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnArgs p) {
 
     const uint32_t thr = drop_threshold(p.p_drop);
     const float keep_scale = p.p_drop > 0.f ? 1.0f / (1.0f - p.p_drop) : 1.0f;
-    const uint32_t hk = attn_drop_headkey(p.seed, rng_offset(p.offset, p.rng_base), b * p.H + h);
+    const uint32_t hk = attn_drop_headkey(p.seed, rng_off, b * p.H + h);
     const float* mrowp = (p.mask && qok) ? p.mask + (int64_t)b * p.mask_bs + (int64_t)qr * p.mask_rs : nullptr;
 
     Stage64<T> st[NIMG];
@@ -385,6 +389,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnArgs p) {
 // ------------------------------------------------------------------------------------------
 template <typename T>
 __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnArgs p) {
+    const uint64_t rng_off = rng_offset(p.offset, p.rng_base);     // once, ahead of every loop: a scalar load inside the tile loop
+                                                                   // shares lgkmcnt with the LDS reads and drains their pipeline
     constexpr int VEC = ElemTraits<T>::VEC;
     constexpr int NIMG = 64 * (int)sizeof(T) / TILE_ROW_BYTES;
     constexpr int NDG = ATT_D / (4 * VEC);
@@ -504,7 +510,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnArgs p) {
                     float dp = pacc[r];
                     pdv = pr;
                     if (thr) {
-                        const bool keep = attn_drop_bits(attn_drop_headkey(p.seed, rng_offset(p.offset, p.rng_base), b * p.H + h), (uint32_t)qr * (uint32_t)p.Skv + (uint32_t)key_loc) >= thr;
+                        const bool keep = attn_drop_bits(attn_drop_headkey(p.seed, rng_off, b * p.H + h), (uint32_t)qr * (uint32_t)p.Skv + (uint32_t)key_loc) >= thr;
                         dp = keep ? dp * keep_scale : 0.f;
                         pdv = keep ? pr * keep_scale : 0.f;
                     }

@@ -39,6 +39,8 @@ DEVINL rsrc_t head_rsrc(const void* base, int64_t elem_off, int S, int64_t rs) {
 // blocks w, w+4, ... (two 16-row MFMA tiles sharing every K / V fragment read).
 template <bool DROP, bool MASK>
 __global__ __launch_bounds__(256, 3) void attn_res_fwd_kernel(AttnArgs p) {
+    const uint64_t rng_off = rng_offset(p.offset, p.rng_base);     // once, ahead of every loop: a scalar load inside the tile loop
+                                                                   // shares lgkmcnt with the LDS reads and drains their pipeline
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -55,7 +57,7 @@ __global__ __launch_bounds__(256, 3) void attn_res_fwd_kernel(AttnArgs p) {
     const float sl2 = p.scale * LOG2E_F;
     const uint32_t thr = drop_threshold(p.p_drop);
     const float keep_scale = p.p_drop > 0.f ? 1.0f / (1.0f - p.p_drop) : 1.0f;
-    const uint32_t hk = attn_drop_headkey(p.seed, rng_offset(p.offset, p.rng_base), b * p.H + h);
+    const uint32_t hk = attn_drop_headkey(p.seed, rng_off, b * p.H + h);
     int troff[4];
 #pragma unroll
     for (int dt = 0; dt < 4; ++dt) troff[dt] = tr_lane_off(lane, dt);
@@ -440,6 +442,8 @@ DEVINL void launder(float& v) { asm volatile("" : "+v"(v)); }
 
 template <bool DROP, bool MASK>
 __global__ __launch_bounds__(512, 2) void attn_res_bwd_pipe_kernel(AttnArgs p, int n_items) {
+    const uint64_t rng_off = rng_offset(p.offset, p.rng_base);     // once, ahead of every loop: a scalar load inside the tile loop
+                                                                   // shares lgkmcnt with the LDS reads and drains their pipeline
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -470,7 +474,7 @@ __global__ __launch_bounds__(512, 2) void attn_res_bwd_pipe_kernel(AttnArgs p, i
     }
     for (; item < n_items; item += gridDim.x) {
         const int h = item % p.H, b = item / p.H;
-        const uint32_t hk = attn_drop_headkey(p.seed, rng_offset(p.offset, p.rng_base), b * p.H + h);
+        const uint32_t hk = attn_drop_headkey(p.seed, rng_off, b * p.H + h);
         // ---------------- phase 1 operands: this wave's 32 query rows of Q / dO (fragments), O (for delta), lse
         bf16x8_t qf[2][2], dof[2][2];
         int qr[2];

@@ -51,6 +51,8 @@ DEVINL void x_stage_kv(rsrc_t rsK, rsrc_t rsV, char* sK, char* sV, int kv0, int 
 // ------------------------------------------------------------------------------------------ forward
 template <int NQS, bool DROP>
 __global__ __launch_bounds__(256, 2) void attn_x_fwd_kernel(AttnArgs p) {
+    const uint64_t rng_off = rng_offset(p.offset, p.rng_base);     // once, ahead of every loop: a scalar load inside the tile loop
+                                                                   // shares lgkmcnt with the LDS reads and drains their pipeline
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* sV = smem;
     char* sK = smem + 16384;
@@ -144,7 +146,7 @@ __global__ __launch_bounds__(256, 2) void attn_x_fwd_kernel(AttnArgs p) {
                 mrow[u] = mnew;
                 float ps = 0.f;
                 const int qr = sq0_[u] + fr;
-                const uint32_t hk = attn_drop_headkey(p.seed, rng_offset(p.offset, p.rng_base), sb_[u] * p.H + h);
+                const uint32_t hk = attn_drop_headkey(p.seed, rng_off, sb_[u] * p.H + h);
                 const uint32_t rowbase = (uint32_t)qr * (uint32_t)p.Skv;
 #pragma unroll
                 for (int kt = 0; kt < 2; ++kt) {
@@ -216,6 +218,8 @@ __global__ __launch_bounds__(256, 2) void attn_x_fwd_kernel(AttnArgs p) {
 // NQS even. LDS: [Q image NQS*16 rows][dO image][K tile][V tile][dS^T scratch 4 x 1 KiB][lse][delta]
 template <int NQS, bool DROP, bool ACC>
 __global__ __launch_bounds__(256, 2) void attn_x_bwd_kernel(AttnArgs p) {
+    const uint64_t rng_off = rng_offset(p.offset, p.rng_base);     // once, ahead of every loop: a scalar load inside the tile loop
+                                                                   // shares lgkmcnt with the LDS reads and drains their pipeline
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int QIMG = NQS * 16 * TILE_ROW_BYTES;
     char* sQ = smem;
@@ -354,7 +358,7 @@ __global__ __launch_bounds__(256, 2) void attn_x_bwd_kernel(AttnArgs p) {
                     }
                     const f32x4_t l4 = *(const f32x4_t*)(sLse + u * 16 + 4 * g);
                     const f32x4_t d4 = *(const f32x4_t*)(sDelta + u * 16 + 4 * g);
-                    const uint32_t hk = attn_drop_headkey(p.seed, rng_offset(p.offset, p.rng_base), sb_[u] * p.H + h);
+                    const uint32_t hk = attn_drop_headkey(p.seed, rng_off, sb_[u] * p.H + h);
                     const uint32_t row0 = (uint32_t)(sq0_[u] + 4 * g);
 #pragma unroll
                     for (int kt = 0; kt < 2; ++kt) {

@@ -61,6 +61,7 @@ DEVINL XuSub xu_sub(const XuArgs& p, int u, int kvb) {
 
 template <int NQS, bool DROP>
 __global__ __launch_bounds__(256, 2) void attn_xu_bwd_kernel(XuArgs p) {
+    const uint64_t rng_off0 = rng_offset(p.s[0].offset, p.rng_base), rng_off1 = rng_offset(p.s[1].offset, p.rng_base);   // once, ahead of the tile loop
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int QIMG = NQS * 16 * TILE_ROW_BYTES;      // NQS x 2 KiB
     char* sQ = smem;
@@ -196,7 +197,7 @@ __global__ __launch_bounds__(256, 2) void attn_xu_bwd_kernel(XuArgs p) {
                     uint32_t hk = 0;
                     if (DROP) {
                         const XuSeg& sg = sg_[u] ? p.s[1] : p.s[0];
-                        hk = attn_drop_headkey(sg.seed, rng_offset(sg.offset, p.rng_base), sb_[u] * p.H + h);
+                        hk = attn_drop_headkey(sg.seed, (sg_[u] ? rng_off1 : rng_off0), sb_[u] * p.H + h);
                     }
                     const uint32_t row0 = (uint32_t)(sq0_[u] + 4 * g);
                     f32x4_t pdv, dsv;
@@ -285,6 +286,7 @@ DEVINL int xu_p_off(int fr, int b) { return fr * 128 + ((((b >> 4) ^ fr) & 7) <<
 
 template <int NQS, bool DROP>
 __global__ __launch_bounds__(256, 2) void attn_xu_fwd_kernel(XuArgs p) {
+    const uint64_t rng_off0 = rng_offset(p.s[0].offset, p.rng_base), rng_off1 = rng_offset(p.s[1].offset, p.rng_base);   // once, ahead of the tile loop
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int QIMG = NQS * 16 * TILE_ROW_BYTES;
     char* sQ = smem;
@@ -396,7 +398,7 @@ __global__ __launch_bounds__(256, 2) void attn_xu_fwd_kernel(XuArgs p) {
             uint32_t hk = 0;
             if (DROP) {
                 const XuSeg& sg = sg_[u] ? p.s[1] : p.s[0];
-                hk = attn_drop_headkey(sg.seed, rng_offset(sg.offset, p.rng_base), sb_[u] * p.H + h);
+                hk = attn_drop_headkey(sg.seed, (sg_[u] ? rng_off1 : rng_off0), sb_[u] * p.H + h);
             }
             const uint32_t rowbase = (uint32_t)(sq0_[u] + fr) * (uint32_t)p.Skv;
 #pragma unroll

@@ -506,34 +506,48 @@ __global__ __launch_bounds__(256, 2) void gemm_8ph2_kernel(GemmArgs p) {
         char* sB = smem;
         const int act = p.act & VALOR_ACT_MASK;
         const bool deriv = (p.act & VALOR_ACT_DERIV) != 0;
-        // the accumulators as NCG column groups x NRG row groups of four consecutive columns of one row (both MFMA shapes):
-        //   16 x 16 tiles: column group ni (4), row group mi (8);  32 x 32 tiles: column group nh * 4 + q (8), row group mh * 2 + mb (4)
-        constexpr int NCG = M32 ? 8 : 4, NRG = M32 ? 4 : 8;
-        auto cg_col = [&](int cg) { return M32 ? (cg >> 2) * 64 + wn * 32 + (cg & 3) * 8 + 4 * lh : (cg >> 1) * 64 + wn * 32 + (cg & 1) * 16 + 4 * fg; };
-        auto rg_row = [&](int rg) { return M32 ? (rg >> 1) * 128 + wm * 64 + (rg & 1) * 32 + l31 : (rg >> 2) * 128 + wm * 64 + (rg & 3) * 16 + fr; };
-        auto quad = [&](int rg, int cg) -> f32x4_t {
-            if constexpr (M32) return n8_quad(acc32[rg][cg >> 2], cg & 3);
-            else return acc[rg][cg];
-        };
-        const int half8 = (M32 ? lh : (fg & 1)) * 8;       // which 8-byte half of the 16-byte column chunk this lane's four columns are
         auto write_tile = [&](bool apply_act) {
+            if constexpr (M32) {
+                // 32 x 32 tiles: column group nh * 4 + q (8 of them), row group mh * 2 + mb (4); a lane's four columns are the 8-byte
+                // half lh of their 16-byte chunk
 #pragma unroll
-            for (int cg = 0; cg < NCG; ++cg) {
-                const int col = cg_col(cg);
-                const f32x4_t bias4 = load_bias4<T>(p, n0 + col);
+                for (int cg = 0; cg < 8; ++cg) {
+                    const int col = (cg >> 2) * 64 + wn * 32 + (cg & 3) * 8 + 4 * lh;
+                    const f32x4_t bias4 = load_bias4<T>(p, n0 + col);
 #pragma unroll
-                for (int rg = 0; rg < NRG; ++rg) {
-                    const int row = rg_row(rg);
-                    f32x4_t v = quad(rg, cg);
+                    for (int rg = 0; rg < 4; ++rg) {
+                        const int row = (rg >> 1) * 128 + wm * 64 + (rg & 1) * 32 + l31;
+                        f32x4_t v = n8_quad(acc32[rg][cg >> 2], cg & 3);
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) v[r] = v[r] * p.alpha + bias4[r];
-                    if (apply_act) {
-                        float f[4] = {v[0], v[1], v[2], v[3]};
-                        act_fwd_n<4>(act, f);
-                        v = (f32x4_t){f[0], f[1], f[2], f[3]};
+                        for (int r = 0; r < 4; ++r) v[r] = v[r] * p.alpha + bias4[r];
+                        if (apply_act) {
+                            float f[4] = {v[0], v[1], v[2], v[3]};
+                            act_fwd_n<4>(act, f);
+                            v = (f32x4_t){f[0], f[1], f[2], f[3]};
+                        }
+                        const u32x2_t w = {pack2_bf16(v[0], v[1]), pack2_bf16(v[2], v[3])};
+                        *(u32x2_t*)(sB + row * 256 + (((col >> 3) ^ (row & 15)) << 4) + lh * 8) = w;
                     }
-                    const u32x2_t w = {pack2_bf16(v[0], v[1]), pack2_bf16(v[2], v[3])};
-                    *(u32x2_t*)(sB + row * 256 + (((col >> 3) ^ (row & 15)) << 4) + half8) = w;
+                }
+            } else {
+#pragma unroll
+                for (int ni = 0; ni < 4; ++ni) {
+                    const int col = (ni >> 1) * 64 + wn * 32 + (ni & 1) * 16 + 4 * fg;
+                    const f32x4_t bias4 = load_bias4<T>(p, n0 + col);
+#pragma unroll
+                    for (int mi = 0; mi < 8; ++mi) {
+                        const int row = (mi >> 2) * 128 + wm * 64 + (mi & 3) * 16 + fr;
+                        f32x4_t v = acc[mi][ni];
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) v[r] = v[r] * p.alpha + bias4[r];
+                        if (apply_act) {
+                            float f[4] = {v[0], v[1], v[2], v[3]};
+                            act_fwd_n<4>(act, f);
+                            v = (f32x4_t){f[0], f[1], f[2], f[3]};
+                        }
+                        const u32x2_t w = {pack2_bf16(v[0], v[1]), pack2_bf16(v[2], v[3])};
+                        *(u32x2_t*)(sB + row * 256 + (((col >> 3) ^ (row & 15)) << 4) + (fg & 1) * 8) = w;
+                    }
                 }
             }
         };
@@ -546,49 +560,6 @@ __global__ __launch_bounds__(256, 2) void gemm_8ph2_kernel(GemmArgs p) {
                 if (m < p.M && n < p.N) store_out16<NTS>(dst + (int64_t)m * p.ldc + n, val);
             }
         };
-        if (p.preact && deriv) {
-            // forward of a fused activation that saves act'(u) (ops.MlpFn): BOTH outputs from one evaluation of the activation, per
-            // 128-row half of the tile -- act(u) as a [128][256 B] bf16 image at smem, act'(u) as a second one 32 KiB further -- and one
-            // read-out loop with two 16-byte stores per lane. (The general epilogue below takes two fp32 passes and 4-byte-granular
-            // LDS traffic for the same thing: the ViT fc1 forward ran at 0.7 of the plain product's rate there.)
-            char* sG = smem + 32768;
-#pragma unroll
-            for (int mh = 0; mh < 2; ++mh) {
-                if (mh) __syncthreads();
-#pragma unroll
-                for (int cg = 0; cg < NCG; ++cg) {
-                    const int col = cg_col(cg);
-                    const f32x4_t bias4 = load_bias4<T>(p, n0 + col);
-#pragma unroll
-                    for (int rh = 0; rh < NRG / 2; ++rh) {
-                        const int rg = mh * (NRG / 2) + rh;
-                        const int row = rg_row(rg) - mh * 128;
-                        const f32x4_t a = quad(rg, cg);
-                        float f[4], g[4];
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) f[r] = a[r] * p.alpha + bias4[r];
-                        act_fwd_deriv_n<4>(act, f, g);
-                        const int o = row * 256 + (((col >> 3) ^ (row & 15)) << 4) + half8;
-                        *(u32x2_t*)(sB + o) = (u32x2_t){pack2_bf16(f[0], f[1]), pack2_bf16(f[2], f[3])};
-                        *(u32x2_t*)(sG + o) = (u32x2_t){pack2_bf16(g[0], g[1]), pack2_bf16(g[2], g[3])};
-                    }
-                }
-                __syncthreads();
-#pragma unroll 4
-                for (int it = 0; it < 8; ++it) {
-                    const int ml = it * 16 + (tid >> 4), c = tid & 15;
-                    const int o = ml * 256 + ((c ^ (ml & 15)) << 4);
-                    const u32x4_t vy = *(const u32x4_t*)(sB + o), vg = *(const u32x4_t*)(sG + o);
-                    const int m = m0 + mh * 128 + ml, n = n0 + c * 8;
-                    if (m < p.M && n < p.N) {
-                        store_out16<NTS>((T*)p.C + (int64_t)m * p.ldc + n, vy);
-                        store_out16<NTS>((T*)p.preact + (int64_t)m * p.ldc + n, vg);
-                    }
-                }
-            }
-            stamp_out();
-            return;
-        }
         if (p.preact) {                 // forward of a fused activation: the pre-activation copy first
             write_tile(false);
             __syncthreads();
@@ -712,12 +683,9 @@ void launch_gemm_8ph2(hipStream_t st, int transA, int transB, const GemmArgs& p_
     const int sched_n = GEMM_KNOB(sched_narrow, g_8ph2_sched);
     // the bf16 tile epilogue under the conditions of the 256x256 kernel (gemm8.hip: launch_gemm_8ph)
     const bool light_dact = p.dact_aux && (p.act & VALOR_ACT_DERIV);
-    // policy key 10: the forward that saves act'(u) beside act(u) (two outputs) through the bf16 half-tile path of the kernel
-    const bool two_out = p.preact && (p.act & VALOR_ACT_DERIV) && !p.dact_aux;
-    const bool plainish = fast_mode >= 2 || (!p.preact && (!p.dact_aux || light_dact)) || (two_out && gemm_policy(10) != 0);
+    const bool plainish = fast_mode >= 2 || (!p.preact && (!p.dact_aux || light_dact));
     p.fast_epi = fast_mode && plainish && !p.out_f32 && p.kslices <= 1 && (p.N & 7) == 0 && (p.ldc & 7) == 0 && !p.rowsum_out &&
-                 (!p.dact_aux || (p.ldaux & 7) == 0) && !(p.dact_aux && p.preact) && !transA &&
-                 (!(p.preact && (p.act & VALOR_ACT_DERIV)) || (two_out && gemm_policy(10) != 0));
+                 (!p.dact_aux || (p.ldaux & 7) == 0) && !(p.dact_aux && p.preact) && !transA && !(p.preact && (p.act & VALOR_ACT_DERIV));
     const int tiles_m = (p.M + 255) / 256, tiles_n = (p.N + 127) / 128;
     const int tiles = tiles_m * tiles_n;
     // L2-aware raster: the model of launch_gemm_8ph with 128-column panels and 64 concurrent tiles per XCD
