@@ -56,10 +56,11 @@ class ReduceQueue:
     workspace, until `flush` sums them in ONE launch per 8 (valor_gemm_reduce_group) and runs their `done` callbacks (the gradient-write
     reports the data-parallel reducer waits for: a parameter is reported only once its final write is enqueued). One queue per stream.
     Flushed when it holds 8 products, when the workspace is full, and at the end of the backward pass that filled it."""
-    GROUP = 8
+    # products per launch: VALOR_GROUP_REDUCE = 0 (off: one reduction behind every GEMM) | 1 .. 8 (default 8, the kernel's table size)
+    GROUP = max(1, min(8, int(os.environ.get("VALOR_GROUP_REDUCE", "8") or 8)))
     BYTES = 1 << 30
     PIECE = _WS_BYTES            # every product is offered what valor_gemm gets: the same slice counts, bit-identical sums
-    enabled = os.environ.get("VALOR_GROUP_REDUCE", "1") != "0"
+    enabled = os.environ.get("VALOR_GROUP_REDUCE", "8") != "0"
     _queues = {}
     _armed = False               # an end-of-backward flush is scheduled
 
