@@ -68,13 +68,13 @@ def test_device_resident_offset_equals_the_by_value_offset(dev, device_rng):
             assert bool(((dx != 0) <= kept).all()) and float((dx != 0).float().mean()) > 0.6
 
 
-def _engine(dev, graphs, seed=3):
+def _engine(dev, graphs, seed=3, swin=False):
     from valor_amd import ops, synth
     from valor_amd.engine import TrainEngine
     from valor_amd.model.valor import VALOR
-    spec = synth.tiny_spec()
+    spec = synth.tiny_swin_spec() if swin else synth.tiny_spec()
     sd = synth.make_state_dict(spec, seed=seed, w_std=0.05)
-    model = VALOR({"dropout": 0.1}, spec=spec, dtype=torch.bfloat16, device=dev)
+    model = VALOR({"dropout": 0.1, "drop_path_rate": 0.2 if swin else 0.0}, spec=spec, dtype=torch.bfloat16, device=dev)
     model.load_state_dict(sd, strict=True)
     opts = SimpleNamespace(learning_rate=1e-3, weight_decay=0.01, clip_lr=1e-4, clip_lr_text=1e-4, new_lr=0.0, decoder_lr=-1, betas=[0.9, 0.98],
                            warmup_ratio=0.1, num_train_steps=100, scheduler="warmup_linear", grad_norm=5.0, alloc_headroom_mb=0)
@@ -115,6 +115,34 @@ def test_graphed_encoders_are_bit_identical_to_the_eager_step(dev, device_rng):
     assert runs[False][0] == runs[True][0], (runs[False][0], runs[True][0])
     assert torch.equal(runs[False][1], runs[True][1])
     assert len({round(l["contra_loss"], 6) for l in runs[True][0]}) == 6                    # the steps do differ (training moves, masks change)
+
+
+def test_graphed_videoswin_encoder_with_stochastic_depth(dev, device_rng):
+    """the VideoSwin variant (scripts/pretrain.sh): the 3-D shifted-window encoder -- index-map gathers, window attention with its bias-table
+    gradient, PatchMerging, stochastic depth 0.2 whose per-sample keep factors are drawn on the host and enter the graph as an input --
+    and the AST encoder replayed, the shared-BERT text pass and the decoder eager: six steps bit-identical to six eager steps."""
+    import numpy as np
+    from valor_amd import ops
+    runs = {}
+    for graphs in (False, True):
+        model, eng, batch = _engine(dev, graphs, swin=True)
+        ops.DropoutState.reset(78)
+        random.seed(6)
+        np.random.seed(7)
+        losses = []
+        for step in range(6):
+            out = eng.train_step(batch, TASK)
+            losses.append({k: float(v) for k, v in out.items()})
+        torch.cuda.synchronize()
+        if graphs:
+            assert set(model._graph_segs) == {"swin_droppath", "ast"} and all(len(s.captured) == 1 for s in model._graph_segs.values())
+        runs[graphs] = (losses, model.arena.flat.clone())
+        model.enable_graphs(False)
+        eng.close()
+        del model, eng
+        device_rng.disable_device_base()
+    assert runs[False][0] == runs[True][0], (runs[False][0], runs[True][0])
+    assert torch.equal(runs[False][1], runs[True][1])
 
 
 def test_replays_draw_fresh_dropout_masks(dev, device_rng):

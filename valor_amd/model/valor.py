@@ -468,14 +468,9 @@ class VALOR(nn.Module):
         """modeling.py:452-455 -> SwinTransformer3D.forward videoswin.py:441-458. Returns [b, F, H/32 * W/32, C_out].
         Tokens stay in natural [b, D, H, W] row order through the whole encoder: roll / window_partition / window_reverse
         live in the attention kernel's index map, PatchMerging is one row gather."""
-        P, sp = self.P, self.spec
-        b, F, c, h, w = video_pixels.shape
+        sp = self.spec
+        b = video_pixels.shape[0]
         vid = self._dev(video_pixels.float().contiguous())
-        C = sp.swin_embed
-        e = "video_encoder.patch_embed."
-        tok = ops.linear(ops.patchify3d(vid, 4, self.dtype), ops.param_view(P[e + "proj.weight"], C, -1), P[e + "proj.bias"])
-        D, H, W = F, h // 4, w // 4
-        x = ops.layer_norm(tok, P[e + "norm.weight"], P[e + "norm.bias"], 1e-5)                 # patch_norm; pos_drop p = 0
         total = sum(sp.swin_depths)
         rate = self.drop_path if self.training else 0.0
         scales = None
@@ -483,6 +478,25 @@ class VALOR(nn.Module):
             keep = 1.0 - np.linspace(0.0, rate, total)                                          # dpr, videoswin.py:418
             u = np.random.random_sample((total, 2, b))
             scales = self._dev(torch.from_numpy((np.floor(keep[:, None, None] + u) / keep[:, None, None]).astype(np.float32)))
+        if self._use_graphs():
+            # the keep decisions are drawn on the host (numpy, like the reference's torch.rand per block) and enter the graph as an INPUT
+            name = "swin" if scales is None else "swin_droppath"
+            seg = self._graph_segs.get(name)
+            if seg is None:
+                from .. import graphs
+                seg = self._graph_segs[name] = graphs.GraphedSegment(name, self._video_encoder_swin)
+            return seg(vid) if scales is None else seg(vid, scales)
+        return self._video_encoder_swin(vid, scales)
+
+    def _video_encoder_swin(self, vid, scales=None):
+        """vid: [b, F, 3, H, W] fp32 on the device; scales: fp32 [blocks, 2, b] stochastic-depth factors or None -> [b, D, H/32 * W/32, C_out]"""
+        P, sp = self.P, self.spec
+        b, F, c, h, w = vid.shape
+        C = sp.swin_embed
+        e = "video_encoder.patch_embed."
+        tok = ops.linear(ops.patchify3d(vid, 4, self.dtype), ops.param_view(P[e + "proj.weight"], C, -1), P[e + "proj.bias"])
+        D, H, W = F, h // 4, w // 4
+        x = ops.layer_norm(tok, P[e + "norm.weight"], P[e + "norm.bias"], 1e-5)                 # patch_norm; pos_drop p = 0
         k = 0
         for li, (depth, heads) in enumerate(zip(sp.swin_depths, sp.swin_heads)):
             rows = D * H * W
