@@ -241,17 +241,18 @@ class GemmTimer:
         return {v: {"flops": f, "seconds": s, "launches": n, "TFLOPs": f / s / 1e12, "avg_us": s / n * 1e6} for v, (f, s, n) in agg.items()}
 
 
-def time_variant(variant, args, dev, steps=3, warmup=2, frames=None, accum=1):
+def time_variant(variant, args, dev, steps=3, warmup=2, frames=None, accum=1, batch=None, checkpointing=False):
     """`steps` timed OPTIMIZER steps (each `accum` micro-steps of args.batch samples, train_utils.py:311-317) of another model variant at
     the headline's batch and -- unless `frames` says otherwise -- clip length (one rank): samples/s, step time, step MFU on the necessary
     FLOPs of THAT variant, peak memory."""
     frames = frames or args.frames
+    nb = batch or args.batch
     from types import SimpleNamespace
     from valor_amd import synth
     from valor_amd.engine import TrainEngine
     from valor_amd.model.valor import VALOR
     spec = {"swin": synth.swin_spec, "large": synth.large_spec, "clip_large": synth.clip_large_spec}[variant]()
-    mopts = {"dropout": args.dropout}
+    mopts = {"dropout": args.dropout, "checkpointing": bool(checkpointing)}
     if variant == "clip_large":
         mopts.update(use_task_prompt=True, contra_loss_ratio=1.5)
     torch.cuda.reset_peak_memory_stats()
@@ -263,7 +264,7 @@ def time_variant(variant, args, dev, steps=3, warmup=2, frames=None, accum=1):
     engine = TrainEngine(model, opts)
     engine.optimizer.init_master_from(sd)
     del sd
-    batch = synth.make_batch(spec, batch=args.batch, frames=frames, audio_slices=args.audio_slices, txt_len=32, seed=50)
+    batch = synth.make_batch(spec, batch=nb, frames=frames, audio_slices=args.audio_slices, txt_len=32, seed=50)
     batch["video_pixels"] = batch["video_pixels"].to(dev)
     batch["audio_spectrograms"] = batch["audio_spectrograms"].to(dev)
     for _ in range(warmup * accum):
@@ -275,11 +276,11 @@ def time_variant(variant, args, dev, steps=3, warmup=2, frames=None, accum=1):
         last = engine.train_step(batch, TASK, accum_steps=accum)
     torch.cuda.synchronize()
     el = time.perf_counter() - t0
-    sps = args.batch * accum * steps / el
+    sps = nb * accum * steps / el
     nf = necessary_flops_per_sample(spec, frames, args.audio_slices, 32)
     out = {"value": round(sps, 2), "unit": "samples/s", "ms_per_step": round(el / steps * 1e3, 2), "steps": steps, "warmup": warmup,
            "step_mfu": round(nf * sps / 1e12 / PEAK_BF16_TFLOPS, 4), "necessary_gflop_per_sample": round(nf / 1e9, 1),
-           "per_gpu_batch": args.batch * accum, "micro_batch": args.batch, "accum_steps": accum, "frames": frames, "peak_mem_gb": round(torch.cuda.max_memory_allocated() / 2 ** 30, 1),
+           "per_gpu_batch": nb * accum, "micro_batch": nb, "accum_steps": accum, "checkpointing": bool(checkpointing), "frames": frames, "peak_mem_gb": round(torch.cuda.max_memory_allocated() / 2 ** 30, 1),
            "losses": {k: round(float(v.detach()) if torch.is_tensor(v) else float(v), 4) for k, v in last.items()}}
     del engine, model, batch
     return out
@@ -297,6 +298,8 @@ def main():
     ap.add_argument("--frames", type=int, default=8)
     ap.add_argument("--audio-slices", type=int, default=2)
     ap.add_argument("--dropout", type=float, default=0.1)
+    ap.add_argument("--checkpointing", type=int, default=0, help="1 = the reference's `checkpointing` option (activation checkpointing of every video / "
+                    "audio / CLIP-text encoder layer): BASELINE configs[4] as written is --variant large --frames 16 --batch 128 --checkpointing 1")
     ap.add_argument("--graphs", type=int, default=int(os.environ.get("VALOR_GRAPHS", "0")), help="1 = the CLIP ViT / AST encoders replay hipGraphs "
                     "(valor_amd/graphs.py: forward + backward captured on their third step; dropout offsets from a device-resident counter)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -350,7 +353,7 @@ def main():
 
     spec = {"clip": synth.base_spec, "swin": synth.swin_spec, "large": synth.large_spec, "clip_large": synth.clip_large_spec}[args.variant]()
     np.random.seed(50 + rank)        # VideoSwin stochastic-depth draws
-    mopts = {"dropout": args.dropout}
+    mopts = {"dropout": args.dropout, "checkpointing": bool(args.checkpointing)}
     if args.variant == "clip_large":              # config/pretrain-VALOR-large.json:14-15
         mopts.update(use_task_prompt=True, contra_loss_ratio=1.5)
     model = VALOR(mopts, spec=spec, dtype=torch.bfloat16, device=dev)
@@ -481,7 +484,7 @@ def main():
                "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 2), "higher_is_better": True,
                "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
                "ranks": torch.distributed.get_world_size() if world > 1 else 1, "backend": backend,
-               "replicas_identical": replicas_identical, "reduce_mode": engine.reducer.mode, "graphs": bool(args.graphs),
+               "replicas_identical": replicas_identical, "reduce_mode": engine.reducer.mode, "graphs": bool(args.graphs), "checkpointing": bool(args.checkpointing),
                "rccl_version": ".".join(str(x) for x in torch.cuda.nccl.version()) if hasattr(torch.cuda, "nccl") else None,
                "config": {"workload": f"{size} tri-modal ({arch}) pretrain step, MGA+MGC+MLM, "
                                       f"{args.frames} frames x 224^2, {args.audio_slices} x 5.12 s audio, 32 tokens",
@@ -508,7 +511,10 @@ def main():
             res["variants"] = {}
             # large_f16_accum2 = BASELINE configs[4]'s per-GPU share (VALOR-large, 16 frames, 128 samples per GPU of the global 1024) as
             # its recipe: two accumulated micro-steps of 64, 2 timed optimizer steps
-            for v, kw in (("swin", {}), ("large", {}), ("large_f16_accum2", dict(variant="large", frames=16, accum=2, steps=2, warmup=1))):
+            # large_f16_b128_ckpt = the same configuration AS WRITTEN: 128 samples of 16 frames in ONE forward-backward with the
+            # reference's `checkpointing` option (every video / audio encoder layer re-run in backward), 2 timed steps
+            for v, kw in (("swin", {}), ("large", {}), ("large_f16_accum2", dict(variant="large", frames=16, accum=2, steps=2, warmup=1)),
+                          ("large_f16_b128_ckpt", dict(variant="large", frames=16, batch=2 * args.batch, checkpointing=True, steps=2, warmup=1))):
                 try:
                     res["variants"][v] = time_variant(kw.pop("variant", v), args, dev, **kw)
                 except Exception as e:

@@ -427,6 +427,41 @@ def test_dropout_training_step_runs(dev, variant):
     assert vals[0] == vals[1]
 
 
+@pytest.mark.parametrize("variant", ["clip", "swin"])
+def test_activation_checkpointing_is_bit_identical(dev, variant):
+    """the reference's `checkpointing` option (torch.utils.checkpoint around every resblock / encoder layer / VideoSwin block,
+    clip.py:208-209, transformer.py:163-164, videoswin.py:234-241,448-449): every video / audio / CLIP-text encoder layer keeps its
+    inputs only and runs again in backward with the dropout offsets rewound. With dropout 0.1 (and stochastic depth 0.2): the same
+    losses and the same gradient arena, to the bit, as the step that keeps every activation -- and a smaller peak."""
+    import numpy as np
+    from valor_amd import synth
+    from valor_amd.ops import DropoutState
+    spec = synth.tiny_spec() if variant == "clip" else synth.tiny_swin_spec()
+    sd = synth.make_state_dict(spec, seed=3, w_std=0.05)
+    batch = synth.make_batch(spec, batch=8, frames=4, audio_slices=2, txt_len=32, seed=4)
+    batch["video_pixels"] = batch["video_pixels"].to(dev)
+    batch["audio_spectrograms"] = batch["audio_spectrograms"].to(dev)
+    runs = []
+    for ck in (False, True):
+        model = _native(spec, sd, torch.bfloat16, dev, dropout=0.1, drop_path=0.2, extra={"checkpointing": ck})
+        assert model.checkpointing == ck
+        DropoutState.reset(99)
+        np.random.seed(6)
+        random.seed(5)
+        torch.cuda.synchronize()
+        torch.cuda.reset_peak_memory_stats()
+        base = torch.cuda.memory_allocated()
+        out = model(batch, task=TASK, compute_loss=True)
+        sum(out.values()).backward()
+        torch.cuda.synchronize()
+        runs.append(({k: float(v) for k, v in out.items()}, model.arena.grad.clone(), torch.cuda.max_memory_allocated() - base))
+        del model, out
+    assert runs[0][0] == runs[1][0], (runs[0][0], runs[1][0])
+    assert torch.equal(runs[0][1], runs[1][1])
+    assert float(runs[0][1].float().abs().sum()) > 0
+    assert runs[1][2] < runs[0][2], (runs[0][2], runs[1][2])
+
+
 def test_gradient_accumulation_window(dev):
     """dataset_mix_type='accum' (train_utils.py:311-317,341): n iterations -- here of two DIFFERENT task strings -- contribute loss / n each
     to ONE optimizer step. TrainEngine.train_step(accum_steps=2) against the same thing done by hand on a second model; then a

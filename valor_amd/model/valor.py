@@ -178,6 +178,11 @@ class VALOR(nn.Module):
         self._const = {}
         self.gather_fn = None          # set by valor_amd.dist for world_size > 1
         self.collect = None            # optional dict: intermediate tensors for parity tests
+        # the reference's `checkpointing` option (modeling.py:573,583-586,607): every layer of the video encoder (CLIP resblocks / VideoSwin
+        # blocks), of the AST and of the CLIP text tower keeps its inputs only and is run again in backward (ops.CheckpointFn). The decoder's
+        # BertLayers (bert.py:510-513) are NOT checkpointed here: their 8.8 k rows are < 2 % of a step's activation bytes, and their
+        # cross-attention gradients meet in shared buffers (ops.GradSlot) that a second forward would have to rebuild.
+        self.checkpointing = bool(_opt(opts, "checkpointing", False))
         self._graphs_on = False        # enable_graphs(): the encoders replay hipGraphs (valor_amd/graphs.py)
         self._graph_segs = {}
 
@@ -372,7 +377,9 @@ class VALOR(nn.Module):
         """pre-LN CLIP transformer (clip.py:194-214) + final LayerNorm; x: [N, L, E] residual stream."""
         P = self.P
         y = ops.layer_norm(x, P[f"{prefix}.resblocks.0.ln_1.weight"], P[f"{prefix}.resblocks.0.ln_1.bias"], 1e-5)
-        for i in range(n_layers):
+
+        def block(i, x, y):
+            """resblock i on (residual stream x, its LayerNorm y) -> the same pair for block i + 1 (the last one: the final LayerNorm only)"""
             p = f"{prefix}.resblocks.{i}."
             qkv = ops.linear(y, P[p + "attn.in_proj_weight"], P[p + "attn.in_proj_bias"])
             a = ops.self_attention(qkv, heads, mask, 0.0)
@@ -383,9 +390,16 @@ class VALOR(nn.Module):
             m = ops.mlp(y, P[p + "mlp.c_fc.weight"], P[p + "mlp.c_fc.bias"], P[p + "mlp.c_proj.weight"], None, ACT_QUICK_GELU)
             if i + 1 < n_layers:
                 q = f"{prefix}.resblocks.{i + 1}."
-                x, y = ops.bias_dropout_residual_ln(m, P[p + "mlp.c_proj.bias"], x, P[q + "ln_1.weight"], P[q + "ln_1.bias"], 1e-5, 0.0, True)
+                return ops.bias_dropout_residual_ln(m, P[p + "mlp.c_proj.bias"], x, P[q + "ln_1.weight"], P[q + "ln_1.bias"], 1e-5, 0.0, True)
+            return ops.bias_dropout_residual_ln(m, P[p + "mlp.c_proj.bias"], x, final_g, final_b, 1e-5, 0.0, False)
+
+        ckpt = self.checkpointing and self.training and torch.is_grad_enabled()
+        for i in range(n_layers):
+            out = ops.checkpoint(lambda x_, y_, i=i: block(i, x_, y_), x, y) if ckpt else block(i, x, y)
+            if i + 1 < n_layers:
+                x, y = out
             else:
-                y = ops.bias_dropout_residual_ln(m, P[p + "mlp.c_proj.bias"], x, final_g, final_b, 1e-5, 0.0, False)
+                y = out
         return y
 
     # ------------------------------------------------------------------ VideoSwin
@@ -498,33 +512,46 @@ class VALOR(nn.Module):
         D, H, W = F, h // 4, w // 4
         x = ops.layer_norm(tok, P[e + "norm.weight"], P[e + "norm.bias"], 1e-5)                 # patch_norm; pos_drop p = 0
         k = 0
-        for li, (depth, heads) in enumerate(zip(sp.swin_depths, sp.swin_heads)):
+        ckpt = self.checkpointing and self.training and torch.is_grad_enabled()          # videoswin.py:234-241, 448-449
+        n_stages = len(sp.swin_depths)
+
+        def block(li, bi, k, depth, heads, D, H, W, x, y):
+            """block bi of stage li on (residual stream x, norm1(x) = y) -> (x, y) for the next block of the stage, x alone at the end of a
+            stage that is followed by PatchMerging, the final LayerNorm's output at the end of the last stage"""
             rows = D * H * W
-            y = None
+            p = f"video_encoder.layers.{li}.blocks.{bi}."
+            s1 = scales[k, 0] if (scales is not None and k > 0) else None
+            s2 = scales[k, 1] if (scales is not None and k > 0) else None
+            geo = self._swin_geometry(D, H, W, bi % 2 == 1)
+            if geo["padded"]:       # zero rows AFTER norm1 (videoswin.py:196-202): their q / k / v are the bias, they are attended to unmasked
+                pad, unpad = self._swin_pad_idx(geo, b)
+                qkv = ops.linear(ops.gather_rows(y, pad), P[p + "attn.qkv.weight"], P[p + "attn.qkv.bias"])
+                a = ops.gather_rows(ops.window_attention(qkv, P[p + "attn.relative_position_bias_table"], geo, heads, b), unpad)
+            else:
+                qkv = ops.linear(y, P[p + "attn.qkv.weight"], P[p + "attn.qkv.bias"])
+                a = ops.window_attention(qkv, P[p + "attn.relative_position_bias_table"], geo, heads, b)
+            o = ops.linear(a, P[p + "attn.proj.weight"], None)
+            x, y2 = ops.bias_dropout_residual_ln(o, P[p + "attn.proj.bias"], x, P[p + "norm2.weight"], P[p + "norm2.bias"], 1e-5, 0.0, True, s1, rows)
+            m = ops.mlp(y2, P[p + "mlp.fc1.weight"], P[p + "mlp.fc1.bias"], P[p + "mlp.fc2.weight"], None, ACT_GELU_ERF)
+            if bi + 1 < depth:
+                q = f"video_encoder.layers.{li}.blocks.{bi + 1}."
+                return ops.bias_dropout_residual_ln(m, P[p + "mlp.fc2.bias"], x, P[q + "norm1.weight"], P[q + "norm1.bias"], 1e-5, 0.0, True, s2, rows)
+            if li + 1 < n_stages:
+                return ops.bias_dropout_residual(m, P[p + "mlp.fc2.bias"], x, 0.0, s2, rows)
+            return ops.bias_dropout_residual_ln(m, P[p + "mlp.fc2.bias"], x, P["video_encoder.norm.weight"], P["video_encoder.norm.bias"], 1e-5, 0.0, False, s2, rows)
+
+        for li, (depth, heads) in enumerate(zip(sp.swin_depths, sp.swin_heads)):
+            p0 = f"video_encoder.layers.{li}.blocks.0."
+            y = ops.layer_norm(x, P[p0 + "norm1.weight"], P[p0 + "norm1.bias"], 1e-5)
             for bi in range(depth):
-                p = f"video_encoder.layers.{li}.blocks.{bi}."
-                if y is None:
-                    y = ops.layer_norm(x, P[p + "norm1.weight"], P[p + "norm1.bias"], 1e-5)
-                s1 = scales[k, 0] if (scales is not None and k > 0) else None
-                s2 = scales[k, 1] if (scales is not None and k > 0) else None
-                geo = self._swin_geometry(D, H, W, bi % 2 == 1)
-                if geo["padded"]:       # zero rows AFTER norm1 (videoswin.py:196-202): their q / k / v are the bias, they are attended to unmasked
-                    pad, unpad = self._swin_pad_idx(geo, b)
-                    qkv = ops.linear(ops.gather_rows(y, pad), P[p + "attn.qkv.weight"], P[p + "attn.qkv.bias"])
-                    a = ops.gather_rows(ops.window_attention(qkv, P[p + "attn.relative_position_bias_table"], geo, heads, b), unpad)
-                else:
-                    qkv = ops.linear(y, P[p + "attn.qkv.weight"], P[p + "attn.qkv.bias"])
-                    a = ops.window_attention(qkv, P[p + "attn.relative_position_bias_table"], geo, heads, b)
-                o = ops.linear(a, P[p + "attn.proj.weight"], None)
-                x, y2 = ops.bias_dropout_residual_ln(o, P[p + "attn.proj.bias"], x, P[p + "norm2.weight"], P[p + "norm2.bias"], 1e-5, 0.0, True, s1, rows)
-                m = ops.mlp(y2, P[p + "mlp.fc1.weight"], P[p + "mlp.fc1.bias"], P[p + "mlp.fc2.weight"], None, ACT_GELU_ERF)
+                fn = lambda x_, y_, li=li, bi=bi, k=k, depth=depth, heads=heads, D=D, H=H, W=W: block(li, bi, k, depth, heads, D, H, W, x_, y_)
+                out = ops.checkpoint(fn, x, y) if ckpt else fn(x, y)
                 if bi + 1 < depth:
-                    q = f"video_encoder.layers.{li}.blocks.{bi + 1}."
-                    x, y = ops.bias_dropout_residual_ln(m, P[p + "mlp.fc2.bias"], x, P[q + "norm1.weight"], P[q + "norm1.bias"], 1e-5, 0.0, True, s2, rows)
-                elif li + 1 < len(sp.swin_depths):
-                    x = ops.bias_dropout_residual(m, P[p + "mlp.fc2.bias"], x, 0.0, s2, rows)
+                    x, y = out
+                elif li + 1 < n_stages:
+                    x = out
                 else:
-                    y = ops.bias_dropout_residual_ln(m, P[p + "mlp.fc2.bias"], x, P["video_encoder.norm.weight"], P["video_encoder.norm.bias"], 1e-5, 0.0, False, s2, rows)
+                    y = out
                 k += 1
             if li + 1 < len(sp.swin_depths):
                 d = f"video_encoder.layers.{li}.downsample."
@@ -641,7 +668,8 @@ class VALOR(nn.Module):
         if p > 0:
             x = ops.bias_dropout_residual(x, None, None, p)
         y = ops.layer_norm(x, P["audio_encoder.layer.0.layernorm1.weight"], P["audio_encoder.layer.0.layernorm1.bias"], 1e-12)
-        for i in range(sp.aud_layers):
+
+        def layer(i, x, y):
             q = f"audio_encoder.layer.{i}."
             qkv = ops.linear(y, P[q + "attention.qkv.weight"], P[q + "attention.qkv.bias"])
             a = ops.self_attention(qkv, sp.aud_heads, None, p)
@@ -651,9 +679,16 @@ class VALOR(nn.Module):
             b2 = P[q + "ff_layer.linear2.bias"]
             if i + 1 < sp.aud_layers:
                 r = f"audio_encoder.layer.{i + 1}."
-                x, y = ops.bias_dropout_residual_ln(m, b2, x, P[r + "layernorm1.weight"], P[r + "layernorm1.bias"], 1e-12, p, True)
+                return ops.bias_dropout_residual_ln(m, b2, x, P[r + "layernorm1.weight"], P[r + "layernorm1.bias"], 1e-12, p, True)
+            return ops.bias_dropout_residual_ln(m, b2, x, P["audio_encoder.last_layernorm.weight"], P["audio_encoder.last_layernorm.bias"], 1e-12, p, False)
+
+        ckpt = self.checkpointing and self.training and torch.is_grad_enabled()          # transformer.py:163-164
+        for i in range(sp.aud_layers):
+            out = ops.checkpoint(lambda x_, y_, i=i: layer(i, x_, y_), x, y) if ckpt else layer(i, x, y)
+            if i + 1 < sp.aud_layers:
+                x, y = out
             else:
-                y = ops.bias_dropout_residual_ln(m, b2, x, P["audio_encoder.last_layernorm.weight"], P["audio_encoder.last_layernorm.bias"], 1e-12, p, False)
+                y = out
         return y
 
     # ------------------------------------------------------------------ multimodal decoder

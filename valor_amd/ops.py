@@ -130,6 +130,44 @@ def _sunk(p):
 
 
 # ------------------------------------------------------------------------------------------------
+class CheckpointFn(Function):
+    """Activation checkpointing of one layer (the reference's `checkpointing` option: torch.utils.checkpoint around every resblock /
+    encoder layer / VideoSwin block, clip.py:208-209, transformer.py:163-164, videoswin.py:234-241,448-449, bert.py:510-513): the forward
+    keeps the layer's INPUTS only, the backward runs the layer again -- with ops.DropoutState rewound to the offsets the first run drew,
+    so the regenerated dropout masks are the forward's -- and back-propagates through that second run. Parameter gradients take their
+    usual route (GradSink kernels accumulate into the arena, the reducer is told by the recomputed layer's backward)."""
+
+    @staticmethod
+    def forward(ctx, fn, *args):
+        ctx.fn = fn
+        ctx.off0 = DropoutState.offset
+        with torch.no_grad():
+            outs = fn(*args)
+        ctx.single = not isinstance(outs, tuple)
+        ctx.save_for_backward(*args)
+        return outs
+
+    @staticmethod
+    def backward(ctx, *gouts):
+        args = ctx.saved_tensors
+        cur = DropoutState.offset
+        DropoutState.offset = ctx.off0
+        ins = [a.detach().requires_grad_(ctx.needs_input_grad[i + 1]) for i, a in enumerate(args)]
+        with torch.enable_grad():
+            outs = ctx.fn(*ins)
+        DropoutState.offset = cur
+        outs = (outs,) if ctx.single else outs
+        pairs = [(o, g) for o, g in zip(outs, gouts) if g is not None and o.requires_grad]
+        torch.autograd.backward([o for o, _ in pairs], [g for _, g in pairs])
+        return (None,) + tuple(i.grad for i in ins)
+
+
+def checkpoint(fn, *tensors):
+    """fn(*tensors) -> tensor | tuple of tensors, with only `tensors` kept for backward (see CheckpointFn)"""
+    return CheckpointFn.apply(fn, *tensors)
+
+
+# ------------------------------------------------------------------------------------------------
 class LinearFn(Function):
     """y = act(x W^T + b).  W: [N,K] (or, with w_is_kn, a [K,N] matrix used as x @ W: CLIP projections
     clip.py:237,329 / pretrain.py:90-91). Backward: dX = dY.W (dgrad GEMM), dW = dY^T.X (wgrad GEMM,
