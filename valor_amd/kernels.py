@@ -102,6 +102,18 @@ class ReduceQueue:
                     cur.wait_stream(q.stream)
 
     @classmethod
+    def discard_stale(cls):
+        """top of a forward pass: whatever is still queued (or armed) belongs to a backward pass that never finished -- an exception
+        between a deferred product and the end-of-backward flush. Its partial tiles must not be summed into the NEXT step's gradients,
+        and a stale `_armed` would keep the next backward from scheduling its flush."""
+        stale = cls._armed or any(q.n or q.done for q in cls._queues.values())
+        if stale:
+            for q in cls._queues.values():
+                q.n, q.off, q.done = 0, 0, []
+            cls._armed = False
+        return stale
+
+    @classmethod
     def _arm(cls):
         if cls._armed:
             return

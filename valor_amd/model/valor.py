@@ -1068,6 +1068,8 @@ class VALOR(nn.Module):
         self.stage.begin_step()
         if self.device.type == "cuda":
             streams.set_main(self.device)
+            if torch.is_grad_enabled():
+                ops.K.ReduceQueue.discard_stale()    # leftovers of a backward pass that died half way (kernels.ReduceQueue)
         out = {}
         col = self.collect
         txt_tokens = batch.get("txt_tokens")
