@@ -357,3 +357,37 @@ def test_param_view_carries_the_gradient_slot_and_logits_rows_have_slack():
         assert b.untyped_storage().nbytes() >= int(n * 1.12) * 64 * 2 and b.untyped_storage().nbytes() % (512 * 64 * 2) == 0
         sizes.append(b.untyped_storage().nbytes())
     assert sizes == sorted(sizes) and sizes[2] == sizes[3] and sizes[4] == sizes[5]      # monotone: a smaller draw re-requests the largest size
+
+
+def test_checkpoint_rewinds_the_dropout_windows():
+    """ops.CheckpointFn (the reference's `checkpointing`, clip.py:208-209 / transformer.py:163-164): the layer runs again in backward and
+    must draw the SAME dropout windows as its first run, while everything issued between the two runs keeps its own. Host logic only:
+    a stand-in layer whose mask is derived from the (seed, offset) pair ops.DropoutState hands out."""
+    import torch
+    from valor_amd import ops
+
+    drawn = []
+
+    def layer(x, y):
+        seed, off = ops.DropoutState.draw(x.numel())
+        drawn.append(off)
+        g = torch.Generator().manual_seed(seed * 1000003 + off)
+        mask = (torch.rand(x.shape, generator=g) > 0.3).float()
+        return x * mask * w + y, (y * 2.0)
+
+    w = torch.nn.Parameter(torch.tensor(1.5))
+    res = []
+    for ck in (False, True):
+        ops.DropoutState.reset(7)
+        drawn.clear()
+        w.grad = None
+        x = torch.arange(12.0).reshape(3, 4).requires_grad_()
+        y = torch.ones(3, 4, requires_grad=True)
+        a, b = ops.checkpoint(layer, x, y) if ck else layer(x, y)
+        seed2, later = ops.DropoutState.draw(5)                      # another op's window between forward and backward
+        (a.sum() + 3.0 * b.sum()).backward()
+        assert ops.DropoutState.offset == later + (5 + 3) // 4 + 1       # the counter is where the forward left it
+        res.append((a.detach().clone(), x.grad.clone(), y.grad.clone(), w.grad.clone(), list(drawn)))
+    assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1]) and torch.equal(res[0][2], res[1][2])
+    assert torch.equal(res[0][3], res[1][3])
+    assert res[0][4] == [0] and res[1][4] == [0, 0]                   # the second run of the checkpointed layer drew offset 0 again
