@@ -179,9 +179,8 @@ class VALOR(nn.Module):
         self.gather_fn = None          # set by valor_amd.dist for world_size > 1
         self.collect = None            # optional dict: intermediate tensors for parity tests
         # the reference's `checkpointing` option (modeling.py:573,583-586,607): every layer of the video encoder (CLIP resblocks / VideoSwin
-        # blocks), of the AST and of the CLIP text tower keeps its inputs only and is run again in backward (ops.CheckpointFn). The decoder's
-        # BertLayers (bert.py:510-513) are NOT checkpointed here: their 8.8 k rows are < 2 % of a step's activation bytes, and their
-        # cross-attention gradients meet in shared buffers (ops.GradSlot) that a second forward would have to rebuild.
+        # blocks), of the AST, of the CLIP text tower and of the multimodal decoder's training path (bert.py:510-513) keeps its inputs only
+        # and is run again in backward (ops.CheckpointFn).
         self.checkpointing = bool(_opt(opts, "checkpointing", False))
         self._graphs_on = False        # enable_graphs(): the encoders replay hipGraphs (valor_amd/graphs.py)
         self._graph_segs = {}
@@ -905,7 +904,9 @@ class VALOR(nn.Module):
             r0 += Bp * Ttot
         # the bigger pass first: in backward it writes the shared dK|dV buffer, the others accumulate into it
         X = torch.cat(xs, dim=0) if len(xs) > 1 else xs[0]
-        for i in range(self.spec.layers):
+        dkv = getattr(self, "_dkv_static", None)
+
+        def layer(i, X, kv):
             q = f"multimodal_encoder.encoder.layer.{i}."
             # post-LN: every sub-layer input feeds the sub-layer's first GEMM AND the residual add behind it; the two gradients meet in a
             # GradSlot (the LayerNorm backward publishes its residual gradient, the GEMM's dgrad accumulates into it: no add kernels)
@@ -915,16 +916,28 @@ class VALOR(nn.Module):
             o = ops.linear(a, P[q + "attention.output.dense.weight"], None)
             X = ops.bias_dropout_residual_ln(o, P[q + "attention.output.dense.bias"], X, P[q + "attention.output.LayerNorm.weight"],
                                              P[q + "attention.output.LayerNorm.bias"], 1e-12, p, False, res_slot=s1)
-            if kv_layers is not None:
+            if kv is not None:
                 cq = ops.linear(X, P[q + "cross_attn.cross.query.weight"], P[q + "cross_attn.cross.query.bias"], grad_slot=s2)
-                c = ops.seg_cross_attention(cq, kv_layers[i], H, xsegs, p, dkv_buf=self._dkv_static[i] if getattr(self, "_dkv_static", None) else None)
+                c = ops.seg_cross_attention(cq, kv, H, xsegs, p, dkv_buf=dkv[i] if dkv else None)
                 o = ops.linear(c, P[q + "cross_attn.output.dense.weight"], None)
                 X = ops.bias_dropout_residual_ln(o, P[q + "cross_attn.output.dense.bias"], X, P[q + "cross_attn.output.LayerNorm.weight"],
                                                  P[q + "cross_attn.output.LayerNorm.bias"], 1e-12, p, False, res_slot=s2)
             m = ops.mlp(X, P[q + "intermediate.dense.weight"], P[q + "intermediate.dense.bias"], P[q + "output.dense.weight"], None, ACT_GELU_ERF,
                         grad_slot=s3)
-            X = ops.bias_dropout_residual_ln(m, P[q + "output.dense.bias"], X, P[q + "output.LayerNorm.weight"], P[q + "output.LayerNorm.bias"], 1e-12, p,
-                                             False, res_slot=s3)
+            return ops.bias_dropout_residual_ln(m, P[q + "output.dense.bias"], X, P[q + "output.LayerNorm.weight"], P[q + "output.LayerNorm.bias"], 1e-12, p,
+                                                False, res_slot=s3)
+
+        # bert.py:510-513: with `checkpointing` every BertLayer keeps its input rows (and the layer's projected K|V, which lives in a
+        # static buffer anyway) and runs again in backward; the GradSlots above are per layer and are rebuilt by that second run
+        ckpt = self.checkpointing and self.training and torch.is_grad_enabled()
+        for i in range(self.spec.layers):
+            kv = kv_layers[i] if kv_layers is not None else None
+            if not ckpt:
+                X = layer(i, X, kv)
+            elif kv is None:
+                X = ops.checkpoint(lambda X_, i=i: layer(i, X_, None), X)
+            else:
+                X = ops.checkpoint(lambda X_, kv_, i=i: layer(i, X_, kv_), X, kv)
         rows = ops.gather_rows(X, self._dev(torch.cat(idxs)))
         h = self.cls_transform(rows)
         losses = ops.decoder_xent_segments(h, P["multimodal_encoder.embeddings.word_embeddings.weight"], P["cls.decoder.bias"],
