@@ -299,7 +299,7 @@ def main():
     ap.add_argument("--audio-slices", type=int, default=2)
     ap.add_argument("--dropout", type=float, default=0.1)
     ap.add_argument("--checkpointing", type=int, default=0, help="1 = the reference's `checkpointing` option (activation checkpointing of every video / "
-                    "audio / CLIP-text encoder layer): BASELINE configs[4] as written is --variant large --frames 16 --batch 128 --checkpointing 1")
+                    "audio / CLIP-text encoder layer and decoder layer): BASELINE configs[4] as written is --variant large --frames 16 --batch 128 --checkpointing 1")
     ap.add_argument("--graphs", type=int, default=int(os.environ.get("VALOR_GRAPHS", "0")), help="1 = the CLIP ViT / AST encoders replay hipGraphs "
                     "(valor_amd/graphs.py: forward + backward captured on their third step; dropout offsets from a device-resident counter)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
