@@ -55,7 +55,10 @@ class GraphedSegment:
     """fn: device tensor(s) -> device tensor (an encoder; inputs that do not need gradients: pixels, spectrograms, token ids, masks -- every
     call copies them into the static buffers the graph was captured on). The replay node needs one differentiable input for autograd to call its
     backward: a private one-element leaf -- NOT a parameter of the model (autograd runs a leaf's post-accumulate hooks even when the
-    node hands it no gradient, and the data-parallel reducer counts those calls per parameter)."""
+    node hands it no gradient, and the data-parallel reducer counts those calls per parameter).
+    One call in flight per segment: the output, the saved activations and the gradient buffer are static, so a second forward call before
+    the first one's backward would overwrite what that backward reads (VALOR calls every encoder once per forward pass; accumulation
+    micro-steps run forward + backward one after the other)."""
 
     def __init__(self, name, fn, warmup=2):
         self.name, self.fn, self.warmup = name, fn, warmup
