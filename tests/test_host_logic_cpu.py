@@ -391,3 +391,34 @@ def test_checkpoint_rewinds_the_dropout_windows():
     assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1]) and torch.equal(res[0][2], res[1][2])
     assert torch.equal(res[0][3], res[1][3])
     assert res[0][4] == [0] and res[1][4] == [0, 0]                   # the second run of the checkpointed layer drew offset 0 again
+
+
+def test_dropout_state_device_mode_bookkeeping():
+    """ops.DropoutState: host mode hands out ever-growing by-value windows; device mode (enable_device_base) restarts them at every
+    begin_step and advances the per-step counter the kernels add (here a CPU tensor stands in for the device word): the by-value
+    numbers of a step are the same step after step -- what a captured graph bakes in -- while (counter + offset) never repeats."""
+    import torch
+    from valor_amd import kernels as K, ops
+    D = ops.DropoutState
+    D.disable_device_base()
+    D.reset(5)
+    a = [D.draw(1000), D.draw_elems(77), D.draw(4)]
+    assert [o for _, o in a] == [0, 251, 251 + 78] and all(s == 5 for s, _ in a) and K.RNG_BASE == 0
+    base = D.enable_device_base("cpu")
+    try:
+        assert K.RNG_BASE == base.data_ptr() and int(base) == 0 and D.offset == 0
+        seen = set()
+        for step in range(3):
+            D.begin_step()
+            assert int(base) == (step + 1) * D.STEP_STRIDE and D.offset == 0
+            offs = [D.draw(1000)[1], D.draw_elems(77)[1]]
+            assert offs == [0, 251]                                   # identical by-value windows every step
+            eff = [int(base) + o for o in offs]
+            assert not (seen & set(eff))
+            seen |= set(eff)
+        D.reset(9)
+        assert int(base) == 0 and D.seed == 9
+    finally:
+        D.disable_device_base()
+        D.reset(1234)
+    assert K.RNG_BASE == 0 and D.base is None
