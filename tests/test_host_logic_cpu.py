@@ -422,3 +422,40 @@ def test_dropout_state_device_mode_bookkeeping():
         D.disable_device_base()
         D.reset(1234)
     assert K.RNG_BASE == 0 and D.base is None
+
+
+def test_gradient_write_reports_are_recorded_during_capture_and_replayed():
+    """valor_amd/graphs.py's capture-time schedule, host side: while ops.GradSink.recorder is set (a backward is being CAPTURED, nothing
+    runs) neither the kernels' reports (ops._sunk) nor autograd's post-accumulate hooks reach the data-parallel reducer -- they are recorded
+    in order; reporting the recorded names afterwards gives the reducer exactly the picture of an eager backward."""
+    import torch
+    from valor_amd import ops
+    from valor_amd.arena import ParamArena
+    from valor_amd.dist import Reducer
+    arena = ParamArena([(f"p{i}", (64,), 0) for i in range(4)], torch.float32, "cpu")
+    red = Reducer(arena, bucket_bytes=256)
+    try:
+        params = list(arena.params.values())
+
+        def backward_of_a_step():
+            (params[0] * 2.0 + params[1] * 3.0).sum().backward()      # autograd hooks report p0, p1
+            ops._sunk(params[2])                                      # a kernel that wrote p2's gradient straight into the arena
+
+        red.prepare_backward()
+        backward_of_a_step()
+        eager = dict(red.touched)
+        assert eager == {"p0": 1, "p1": 1, "p2": 1}
+        red.prepare_backward()
+        rec = []
+        ops.GradSink.recorder = rec
+        try:
+            backward_of_a_step()                                      # "capture": nothing may reach the reducer
+        finally:
+            ops.GradSink.recorder = None
+        assert red.touched == {} and sorted(rec) == ["p0", "p1", "p2"]
+        for name in rec:                                              # what graphs._Replay.backward does after every replay
+            ops.GradSink.listener(name)
+        assert red.touched == eager
+    finally:
+        ops.GradSink.listener = None
+        ops.GradSink.recorder = None
