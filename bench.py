@@ -397,6 +397,7 @@ def main():
     seg0 = torch.cuda.memory_stats().get("segment.all.allocated", 0)       # device allocations (hipMalloc) so far
     segs_before = {sg["address"] for sg in torch.cuda.memory_snapshot()}
     seg_trace = [] if os.environ.get("BENCH_SEG_TRACE") else None      # diagnostic: cumulative device allocations after every timed step
+    engine.trace = []                    # per-step wait / launch times and head / tail events (valor_amd/engine.py)
     t0 = time.perf_counter()
     last = None
     step_ms = []
@@ -408,6 +409,18 @@ def main():
             seg_trace.append(int(torch.cuda.memory_stats().get("segment.all.allocated", 0) - seg0))
     sync()
     elapsed = time.perf_counter() - t0
+    trace, engine.trace = engine.trace, None
+    # what the host did per optimizer step: launch_ms = time inside train_step minus the `max_ahead` throttle wait (pure issue time),
+    # wait_ms = the throttle wait (the host was AHEAD of the device); and what the device saw: gpu_span_ms = first launch -> last
+    # launch of a step on the step's stream, gpu_idle_ms = the gap between a step's last kernel and the next step's first one (> 0 only
+    # if the host had not issued the next step in time: the device idled for the host)
+    timing = {"launch_ms": [round(r["host_ms"] - r["wait_ms"], 1) for r in trace], "wait_ms": [round(r["wait_ms"], 1) for r in trace],
+              "gpu_span_ms": [round(r["head"].elapsed_time(r["tail"]), 1) for r in trace],
+              "gpu_idle_ms": [round(a["tail"].elapsed_time(b["head"]), 2) for a, b in zip(trace[:-1], trace[1:])]}
+    if timing["gpu_idle_ms"]:
+        timing["gpu_idle_ms_per_step"] = round(sum(timing["gpu_idle_ms"]) / len(timing["gpu_idle_ms"]), 2)
+        timing["launch_ms_per_step"] = round(sum(timing["launch_ms"]) / len(timing["launch_ms"]), 1)
+        timing["wait_ms_per_step"] = round(sum(timing["wait_ms"]) / len(timing["wait_ms"]), 1)
     seg1 = torch.cuda.memory_stats().get("segment.all.allocated", 0)
     new_segs_mb = sorted(round(sg["total_size"] / 2 ** 20, 1) for sg in torch.cuda.memory_snapshot() if sg["address"] not in segs_before)
     # roofline pass: the SAME step, run right after the timed region, with a HIP-event pair (recorded on the launch
@@ -494,7 +507,7 @@ def main():
                "losses": {k: round(float(v.detach()) if torch.is_tensor(v) else float(v), 4) for k, v in last.items()},
                "peak_mem_gb": round(torch.cuda.max_memory_allocated() / 2 ** 30, 1),
                "reserved_mem_gb": round(torch.cuda.memory_reserved() / 2 ** 30, 1),
-               "timed_region": {"device_allocations": int(seg1 - seg0), "new_segments_mb": new_segs_mb, "host_ms_per_step": [round(x, 1) for x in step_ms],
+               "timed_region": {"device_allocations": int(seg1 - seg0), "new_segments_mb": new_segs_mb, "host_ms_per_step": [round(x, 1) for x in step_ms], **timing,
                                 **({"allocations_after_step": seg_trace} if seg_trace is not None else {})},
                "roofline": roof}
         if world == 1 and args.sim_world > 1:

@@ -154,6 +154,9 @@ int valor_gemm_set_narrow_sched(int v);
 /* workgroups of the family-4 kernel the runtime admits per CU (hipOccupancyMaxActiveBlocksPerMultiprocessor at its 80 KiB of LDS): the
  * design point is 2; -1 on a runtime error. Needs a device. */
 int valor_gemm_narrow_occupancy(void);
+/* the same for the 512-thread workgroups of csrc/gemm8w.hip (policy key 10: family 4's NN problems on eight waves of 64x64 outputs): the
+ * design point is 2 workgroups = four waves per SIMD (<= 128 registers per lane); -1 on a runtime error. Needs a device. */
+int valor_gemm_wide_occupancy(void);
 
 /* ---- cross-attention backward of EVERY decoder pass of a layer in one launch (csrc/attention_xu.hip). Replaces the autograd backward of
  * BertCrossAttention (model/bert.py:314-340) for the passes of model/pretrain.py:403-541 that share one projected K|V per layer (the

@@ -34,7 +34,7 @@ SWIN_SLICE_KEYS = ["video_encoder.patch_embed.proj.weight", "video_encoder.layer
                    "multimodal_encoder.embeddings.word_embeddings.weight", "cls.decoder.bias", "video_frame_embedding"]
 
 
-def run(name, batch_size, frames, audio_slices, wseed, bseed, mseed, variant="clip", task=None, bf16_exact=False, steps=2):
+def run(name, batch_size, frames, audio_slices, wseed, bseed, mseed, variant="clip", task=None, bf16_exact=False, steps=2, ref_opts=None):
     global SLICE_KEYS
     TASK = task or globals()["TASK"]
     build_kw, model_opts = {}, {}
@@ -58,12 +58,15 @@ def run(name, batch_size, frames, audio_slices, wseed, bseed, mseed, variant="cl
                       "audio_encoder.layer.11.ff_layer.linear2.weight", "multimodal_encoder.encoder.layer.0.cross_attn.cross.key.weight",
                       "multimodal_encoder.embeddings.word_embeddings.weight", "cls.decoder.bias", "video_frame_embedding"]
     else:
-        spec, ropts = synth.base_spec(), None
+        # ref_opts: options of the reference's own constructor (e.g. its `checkpointing` flag, modeling.py:573-627: same arithmetic, the
+        # layers' activations recomputed in backward -- what lets the B = 64 training pass fit the build container's memory)
+        spec, ropts = synth.base_spec(), (ref_harness.default_opts(**ref_opts) if ref_opts else None)
     sd = synth.make_state_dict(spec, seed=wseed, bf16_exact=bf16_exact)
     ref = ref_harness.build_reference(ropts, state_dict=sd, dropout=0.0, **build_kw)
     batch = synth.make_batch(spec, batch=batch_size, frames=frames, audio_slices=audio_slices, txt_len=32, seed=bseed, bf16_exact=bf16_exact)
     g = {"recipe": dict(spec=spec.to_dict(), weight_seed=wseed, batch_seed=bseed, masker_seed=mseed, batch=batch_size,
-                        frames=frames, audio_slices=audio_slices, txt_len=32, task=TASK, bf16_exact=bf16_exact, model_opts=model_opts)}
+                        frames=frames, audio_slices=audio_slices, txt_len=32, task=TASK, bf16_exact=bf16_exact, model_opts=model_opts,
+                        ref_opts=dict(ref_opts or {}))}
     # ---- eval pass (compute_loss=False): argmax ids + features
     with torch.no_grad():
         random.seed(mseed)
@@ -143,6 +146,11 @@ FIXTURES = {
     # the same clip length at B = 8 for the bf16 comparison: the B = 2 fixture's 2 x 2 InfoNCE matrix is the worst case for the RELATIVE
     # contrastive tolerance (see ref_base_b16f2a1_q above; bf16 measured 1.29e-3 on ref_base_b2f16a2_q), B = 8 is held to the 1e-3
     "ref_base_b8f16a2_q": dict(batch_size=8, frames=16, audio_slices=2, wseed=81, bseed=82, mseed=83, bf16_exact=True, steps=1),
+    # THE configuration bench.py times (BASELINE configs[1]: B = 64, 8 frames, 2 audio slices): 100 864 ViT rows, the 64-sample kv_range
+    # groups and the 8 832-row decoder stack, the 64 x 64 fused contrastive matrix. One training pass of the unmodified reference with
+    # its own `checkpointing` option (fp32, ~90 GB of saved activations without it), no optimizer step
+    "ref_base_b64f8a2_q": dict(batch_size=64, frames=8, audio_slices=2, wseed=91, bseed=92, mseed=93, bf16_exact=True, steps=1,
+                               ref_opts=dict(checkpointing=True)),
     "ref_cliplarge_b8f2a1_q": dict(batch_size=8, frames=2, audio_slices=1, wseed=61, bseed=62, mseed=63, bf16_exact=True, steps=1, variant="clip_large"),
 }
 

@@ -504,9 +504,8 @@ extern "C" int valor_gemm_set_variant(int v) { const int o = g_gemm_variant; if 
 // [8] narrow 8-phase kernel (gemm8n.hip: 256x128 tile, two workgroups per CU): 0 = never, 1 = every eligible problem, 2 = only where the
 //     policy above would take the 128x128 kernels, 3 = only where it would take the 256x256 kernel, 1000 = measured per-class choice (use_8ph2)
 // [9] family 4, NN layout: 1 = main loop on v_mfma_f32_32x32x16_bf16 (gemm8n.hip M32), 0 = v_mfma_f32_16x16x32_bf16
-// [10] was: the derivative-saving forward through a bf16 half-tile epilogue (round 5). Measured SLOWER than the general epilogue on every
-//      shape (ViT fc1 forward 556 -> 588 us, AST 114 -> 123 us, profiles/r05_gemm_mfma32_ab.json) and its mere presence in the kernel body
-//      cost the OTHER tile-epilogue paths 5-17 % (register allocation: fc2 dgrad 560 -> 654 us in the step's trace): removed, key unused
+// [10] family 4, NN layout without split-K: 1 = 512-thread workgroups (gemm8w.hip: 64x64 outputs per wave, four waves per SIMD), 0 = gemm8n.hip
+//      (round 5 used this key for a bf16 half-tile epilogue of the derivative-saving forward: measured slower, removed)
 // [11] reserved
 thread_local const GemmTuning* t_gemm_tuning = nullptr;
 int g_gemm_policy_default[12] = {[] { const char* e = getenv("VALOR_GEMM_NT_MINK"); return e ? atoi(e) : 768; }(),
@@ -519,7 +518,7 @@ int g_gemm_policy_default[12] = {[] { const char* e = getenv("VALOR_GEMM_NT_MINK
                         [] { const char* e = getenv("VALOR_GEMM_NN_MINK"); return e ? atoi(e) : 128; }(),
                         [] { const char* e = getenv("VALOR_GEMM_NARROW"); return e ? atoi(e) : 1000; }(),
                         [] { const char* e = getenv("VALOR_GEMM_MFMA32"); return e ? atoi(e) : 0; }(),
-                        0, 0};
+                        [] { const char* e = getenv("VALOR_GEMM_WIDE"); return e ? atoi(e) : 0; }(), 0};
 extern "C" int valor_gemm_set_policy(int key, int value) {
     if (key < 0 || key > 11) return VALOR_ERR_ARG;
     const int old = g_gemm_policy_default[key];

@@ -708,6 +708,11 @@ void launch_gemm_8ph2(hipStream_t st, int transA, int transB, const GemmArgs& p_
     }
     const bool nts = !transA && !p.out_f32 && p.kslices <= 1 && (gemm_policy(5) == 1 || (gemm_policy(5) == 1000 && p.K <= 1024));
     p.st_mode = nts ? 1 : 0;
+    // policy key 10: the k-contiguous (NN) problems without split-K on the EIGHT-wave workgroups of gemm8w.hip (four waves per SIMD)
+    if (!transA && !transB && p.kslices <= 1 && !p.rowsum_out && gemm_policy(10) != 0) {
+        launch_gemm_8w(st, p, tiles, nts);
+        return;
+    }
     dim3 grid(tiles * (p.kslices > 1 ? p.kslices : 1));
     const size_t lds = N8_LDS;
 #define VALOR_8PH2_LAUNCH1(TA_, TB_, ASM_, NTS_, S_, M32_)                                                      \

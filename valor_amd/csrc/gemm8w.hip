@@ -1,0 +1,370 @@
+// valor_gemm, bf16, family 4 on EIGHT waves (policy key 10): the 256x128 tile, the 80 KiB LDS ring and the two workgroups per CU of
+// gemm8n.hip, but a 512-thread workgroup whose waves own 64x64 outputs (2 x 2 tiles of v_mfma_f32_32x32x16_bf16, 64 accumulator
+// registers, <= 128 VGPRs), so that a CU holds FOUR waves per SIMD -- two per workgroup.
+//
+// Why (round-5 cycle stamps of gemm8n.hip, profiles/r05_stamp_fc1fwd_mfma32_0.json): the two workgroups of a CU settle into
+// anti-phase -- one stores its tile while the other runs its K loop -- and the kernel is paced by ONE workgroup's K loop with ONE
+// in-order wave per SIMD: 1976 cycles per K-tile for 1024 cycles of MFMA. Every ds_read wait, LDS-DMA issue stall and barrier of
+// that wave is matrix-pipe idle time. Here the workgroup that is alone in its K loop still has two waves on every SIMD, and a wave's
+// instruction stream is short enough to software-pipeline inside 128 registers:
+//   per K-tile and wave 16 MFMAs (32 cycles each), 16 ds_read_b128, 6 LDS-DMA pieces, 2 barriers.
+//
+// Tile ownership: wave (wm = wave >> 1, wn = wave & 1) owns rows {128 mh + 32 wm + [0,32)} x columns {64 nh + 32 wn + [0,32)}, mh, nh
+// in {0,1}: one 32x32 MFMA tile in each (A'mh, B'nh) combination, so a half-tile A'mh is consumed by ALL waves in the same phase (the
+// ring of gemm8n.hip). Operand images, DMA source swizzle and the 32-row fragment read are gemm8n.hip's M32 ones.
+//
+// LDS (80 KiB): A ring of three 16 KiB half-tile slots, half-tile 2c + mh in slot (2c + mh) % 3; B double buffer, B(c) in buffer c & 1.
+// K-tile c, per wave (s = 16-k step, fa double-buffered one step ahead, fb = ALL B fragments of a K-tile, 32 registers):
+//   P0  s0..s2   read fa <- A'0(c)(s+1), then MFMA (0,0,s) (0,1,s)
+//       (b)      lgkmcnt(0) vmcnt(2) barrier          [A'1(c), B(c+1) landed; every wave done reading A'0(c) and B(c)]
+//       s3       MFMA (0,0,3) (0,1,3)                 read fa <- A'1(c)(0);   DMA A'1(c+1) -> slot of A'0(c), B(c+2) -> buffer of B(c)
+//   P1  s0..s2   MFMA (1,0,s) (1,1,s)                 read fa <- A'1(c)(s+1), fb[.][s] <- B(c+1)(.,s)   (the registers the MFMAs just read)
+//       (a)      lgkmcnt(0) vmcnt(4) barrier          [A'0(c+1) landed; every wave done reading A'1(c)]
+//       s3       MFMA (1,0,3) (1,1,3)                 read fa <- A'0(c+1)(0), fb[.][3] <- B(c+1)(.,3);   DMA A'0(c+2) -> slot of A'1(c)
+// DMA order A'1(c+1), B(c+2) | A'0(c+2), two pieces per wave each, every one a whole K-tile ahead of its wait: behind A'1(c), B(c+1)
+// at (b) is A'0(c+1) (2 loads); behind A'0(c+1) at (a) are A'1(c+1), B(c+2) (4 loads). Past the last K-tile: zero-length descriptor
+// (zero fill, no traffic, constant load count). Every accumulator receives its 16-k products in ascending k: bit-identical to the
+// 32x32x16 instantiation of gemm8n.hip.
+// Scope: k-contiguous operands (NN: the forward GEMMs), no split-K, no fused row sums -- everything else stays on gemm8n.hip.
+#include "gemm_common.h"
+#include <stdlib.h>
+
+#define W8_HT 16384
+#define W8_OFF_B (3 * W8_HT)
+#define W8_LDS (5 * W8_HT)
+
+DEVINL void glds16s(rsrc_t rs, char* lds_dst, int voff, int soff) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, LDS_PTR(lds_dst), 16, voff, soff, 0, 0);
+}
+DEVINL f32x16_t w8_mma(bf16x8_t a, bf16x8_t b, f32x16_t c) { return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0); }
+DEVINL f32x4_t w8_quad(const f32x16_t& a, int q) { return (f32x4_t){a[4 * q], a[4 * q + 1], a[4 * q + 2], a[4 * q + 3]}; }
+
+template <bool NTS>
+__global__ __launch_bounds__(512, 4) void gemm_8w_kernel(GemmArgs p) {
+    typedef bf16_t T;
+    constexpr int BK = 64;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int l31 = lane & 31, lh = lane >> 5;
+
+    const int tiles_n = (p.N + 127) >> 7;
+    const int tiles_m = (p.M + 255) >> 8;
+    const int logical = xcd_remap(blockIdx.x, tiles_m * tiles_n);
+    int tm = logical / tiles_n, tn = logical - tm * tiles_n;
+    if (p.raster_g > 0) {
+        // L2-aware raster (gemm8.hip): tile columns in groups of G, row-major inside a group
+        const int G = p.raster_g, per = G * tiles_m;
+        const int grp = logical / per, w = logical - grp * per;
+        const int gw = min(G, tiles_n - grp * G);
+        tm = w / gw;
+        tn = grp * G + (w - tm * gw);
+    }
+    const int m0 = tm << 8, n0 = tn << 7;
+    const int ntile = p.K / BK;
+
+#ifdef N8_STAMP
+    // diagnostic build only (tools/gemm_stamp.py): cycle stamps of every wave into p.ws as [block][wave][24] uint64
+    uint64_t stamp_[5];
+    stamp_[0] = __builtin_amdgcn_s_memtime();
+#define W8_STAMP_AT(i) stamp_[i] = __builtin_amdgcn_s_memtime()
+#else
+#define W8_STAMP_AT(i)
+#endif
+
+    f32x16_t acc[2][2];     // [mh][nh]; acc[mh][nh][4 q + r] = C[128 mh + 32 wm + (l & 31)][64 nh + 32 wn + 8 q + 4 (l >> 5) + r]
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    // ---- DMA sources. A half-tile image = 16 pieces of 1 KiB (8 rows x 128 B); wave w issues pieces 2w, 2w + 1 = image rows
+    // 16 w + 8 i + (lane >> 3); position lane & 7 of a row receives chunk position ^ ((row >> 1) & 7) = position ^ (4 i + (lane >> 4)).
+    int vA[2], vB[2];
+    const int ldA_b = (int)(p.lda * 2), ldB_b = (int)(p.ldb * 2);
+    {
+        const int r = wave * 16 + (lane >> 3);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int c = (lane & 7) ^ (4 * i + (lane >> 4));
+            vA[i] = (m0 + r + 8 * i) * ldA_b + c * 16;
+            vB[i] = (n0 + r + 8 * i) * ldB_b + c * 16;
+        }
+    }
+    // The K-tile advance rides in the instruction's scalar offset (excluded from the range check: an in-range row stays inside its
+    // row); the row half A'1 is a second descriptor (base + 128 rows, extent shortened by as much), so the range check of the M tail
+    // stays exact and no per-lane offset has to be kept per half or bumped per K-tile.
+    const uint32_t halfA = 128u * (uint32_t)ldA_b;
+    const uint32_t bytesA1 = p.bytesA > halfA ? p.bytesA - halfA : 0u;
+    const char* const pA1 = (const char*)p.A + halfA;
+    auto issueA = [&](int hf, char* slot, int t) {
+        // (readfirstlane: the extent select must be PROVABLY wave-uniform, or hipcc wraps every load in a waterfall loop)
+        const uint32_t nb = __builtin_amdgcn_readfirstlane(t < ntile ? (hf ? bytesA1 : p.bytesA) : 0u);
+        const rsrc_t rs = make_rsrc(hf ? pA1 : (const char*)p.A, nb);
+        char* d = slot + wave * 2048;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) glds16s(rs, d + i * 1024, vA[i], t * (BK * 2));
+    };
+    auto issueB = [&](char* buf, int t) {
+        const uint32_t nb = __builtin_amdgcn_readfirstlane(t < ntile ? p.bytesB : 0u);
+        const rsrc_t rs = make_rsrc(p.B, nb);
+        char* d = buf + wave * 2048;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) glds16s(rs, d + i * 1024, vB[i], t * (BK * 2));
+    };
+
+    // ---- fragment reads: lane l = image row (base + l & 31), 16-byte chunk (2 s + (l >> 5)) ^ ((row >> 1) & 7) of 16-k step s
+    //      = row * 128 + (((swz ^ lh) << 4) ^ (s << 5))
+    const int fragx = ((((l31 >> 1) & 7) ^ lh) << 4);
+    const int offA = (wm * 32 + l31) * 128 + fragx;
+    const int offB = (wn * 32 + l31) * 128 + fragx;
+    bf16x8_t fa0, fa1, fb[2][4];
+#define RD_A(IMG_, S_) (*(const bf16x8_t*)((IMG_) + (offA ^ ((S_) << 5))))
+#define RD_B(IMG_, NH_, S_) (*(const bf16x8_t*)((IMG_) + (NH_) * 8192 + (offB ^ ((S_) << 5))))
+#define MM(MH_, NH_, S_, FA_) acc[MH_][NH_] = w8_mma(fb[NH_][S_], FA_, acc[MH_][NH_])
+#define PIN() __builtin_amdgcn_sched_barrier(0)
+#define BAR(VM_)                                                                                                  \
+    do {                                                                                                          \
+        PIN();                                                                                                    \
+        asm volatile("s_waitcnt vmcnt(" #VM_ ") lgkmcnt(0)" ::: "memory");                                        \
+        __builtin_amdgcn_s_barrier();                                                                             \
+        PIN();                                                                                                    \
+    } while (0)
+
+    char* const bufB0 = smem + W8_OFF_B;
+    char* const bufB1 = smem + W8_OFF_B + W8_HT;
+
+    // prologue = what the steady state has in flight in front of K-tile 0: B(0) A'0(0) | A'1(0) B(1) | A'0(1)
+    issueB(bufB0, 0); issueA(0, smem, 0); issueA(1, smem + W8_HT, 0); issueB(bufB1, 1); issueA(0, smem + 2 * W8_HT, 1);
+    PIN();
+    asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    PIN();
+    W8_STAMP_AT(1);
+#pragma unroll
+    for (int s = 0; s < 4; ++s) { fb[0][s] = RD_B(bufB0, 0, s); fb[1][s] = RD_B(bufB0, 1, s); }
+    fa0 = RD_A(smem, 0);
+    PIN();
+
+    // diagnostic builds (tools/build_stamp_lib.sh, N8_ABLATE): bit 0 = no DMA in the K loop, bit 1 = no fragment reads in it, bit 2 = no
+    // global stores in the bf16 tile epilogue
+#if defined(N8_ABLATE) && (N8_ABLATE & 1)
+#define LDMA(X_) do {} while (0)
+#else
+#define LDMA(X_) X_
+#endif
+#if defined(N8_ABLATE) && (N8_ABLATE & 2)
+#define LRD_A(DST_, IMG_, S_) do {} while (0)
+#define LRD_B(NH_, S_) do {} while (0)
+#else
+#define LRD_A(DST_, IMG_, S_) DST_ = RD_A(IMG_, S_)
+#define LRD_B(NH_, S_) fb[NH_][S_] = RD_B(bnxt, NH_, S_)
+#endif
+    int sa0 = 0;                                     // ring slot of A'0(c)
+    for (int c = 0; c < ntile; ++c) {
+        const int sa1 = sa0 == 2 ? 0 : sa0 + 1, sa2 = sa1 == 2 ? 0 : sa1 + 1;
+        char* const a0 = smem + sa0 * W8_HT;         // A'0(c); refilled with A'1(c+1)
+        char* const a1 = smem + sa1 * W8_HT;         // A'1(c); refilled with A'0(c+2)
+        char* const a2 = smem + sa2 * W8_HT;         // A'0(c+1)
+        char* const bcur = (c & 1) ? bufB1 : bufB0;  // B(c): in registers; refilled with B(c+2)
+        char* const bnxt = (c & 1) ? bufB0 : bufB1;  // B(c+1)
+        // ---- P0 (every step: the NEXT step's A fragment first -- its register was the previous step's operand --, then the two MFMAs)
+        LRD_A(fa1, a0, 1); PIN(); MM(0, 0, 0, fa0); PIN(); MM(0, 1, 0, fa0); PIN();
+        LRD_A(fa0, a0, 2); PIN(); MM(0, 0, 1, fa1); PIN(); MM(0, 1, 1, fa1); PIN();
+        LRD_A(fa1, a0, 3); PIN(); MM(0, 0, 2, fa0); PIN(); MM(0, 1, 2, fa0); PIN();
+        BAR(2);
+        LRD_A(fa0, a1, 0); PIN(); MM(0, 0, 3, fa1); PIN();
+        LDMA(issueA(1, a0, c + 1)); PIN();
+        MM(0, 1, 3, fa1); PIN();
+        LDMA(issueB(bcur, c + 2)); PIN();
+        // ---- P1 (the B fragments of K-tile c+1 into the registers the step's MFMAs just read)
+        LRD_A(fa1, a1, 1); PIN(); MM(1, 0, 0, fa0); PIN(); MM(1, 1, 0, fa0); LRD_B(0, 0); LRD_B(1, 0); PIN();
+        LRD_A(fa0, a1, 2); PIN(); MM(1, 0, 1, fa1); PIN(); MM(1, 1, 1, fa1); LRD_B(0, 1); LRD_B(1, 1); PIN();
+        LRD_A(fa1, a1, 3); PIN(); MM(1, 0, 2, fa0); PIN(); MM(1, 1, 2, fa0); LRD_B(0, 2); LRD_B(1, 2); PIN();
+        BAR(4);
+        LRD_A(fa0, a2, 0); PIN(); MM(1, 0, 3, fa1); PIN(); MM(1, 1, 3, fa1); LRD_B(0, 3); LRD_B(1, 3); PIN();
+        LDMA(issueA(0, a1, c + 2)); PIN();
+        sa0 = sa2;
+    }
+    W8_STAMP_AT(2);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the zero-length look-ahead loads still write LDS: drain before it is reused
+    __syncthreads();
+    W8_STAMP_AT(3);
+#ifdef N8_STAMP
+    auto stamp_out = [&]() {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        stamp_[4] = __builtin_amdgcn_s_memtime();
+        if (lane == 0) {
+            uint64_t* o = (uint64_t*)p.ws + ((int64_t)blockIdx.x * 8 + wave) * 24;
+            for (int i = 0; i < 5; ++i) o[i] = stamp_[i];
+            o[5] = __builtin_amdgcn_s_getreg((31 << 11) | 4);       // HW_ID
+            o[6] = __builtin_amdgcn_s_getreg((31 << 11) | 20);      // XCC_ID
+        }
+    };
+#else
+    auto stamp_out = [&]() {};
+#endif
+#undef RD_A
+#undef RD_B
+#undef MM
+#undef BAR
+
+    // ---- fast epilogue (host-checked, GemmArgs::fast_epi): alpha / bias / activation on the accumulators, the whole 256 x 128 tile as
+    // bf16 (64 KiB) through LDS in ONE pass. Image: [256 rows][256 B], 16-B chunk c of row r at position c ^ (r & 15); a lane's four
+    // columns are the 8-byte half lh of their chunk. dact_aux and C += are applied at read-out, their second operand requested before
+    // the tile barrier.
+    if (p.fast_epi) {
+        char* sB = smem;
+        const int act = p.act & VALOR_ACT_MASK;
+        const bool deriv = (p.act & VALOR_ACT_DERIV) != 0;
+        auto write_tile = [&](bool apply_act) {
+#pragma unroll
+            for (int cg = 0; cg < 8; ++cg) {
+                const int col = (cg >> 2) * 64 + wn * 32 + (cg & 3) * 8 + 4 * lh;
+                const f32x4_t bias4 = load_bias4<T>(p, n0 + col);
+#pragma unroll
+                for (int mh = 0; mh < 2; ++mh) {
+                    const int row = mh * 128 + wm * 32 + l31;
+                    f32x4_t v = w8_quad(acc[mh][cg >> 2], cg & 3);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] = v[r] * p.alpha + bias4[r];
+                    if (apply_act) {
+                        float f[4] = {v[0], v[1], v[2], v[3]};
+                        act_fwd_n<4>(act, f);
+                        v = (f32x4_t){f[0], f[1], f[2], f[3]};
+                    }
+                    const u32x2_t w = {pack2_bf16(v[0], v[1]), pack2_bf16(v[2], v[3])};
+                    *(u32x2_t*)(sB + row * 256 + (((col >> 3) ^ (row & 15)) << 4) + lh * 8) = w;
+                }
+            }
+        };
+        auto read_tile = [&](T* dst) {
+#pragma unroll 4
+            for (int it = 0; it < 8; ++it) {
+                const int ml = it * 32 + (tid >> 4), c = tid & 15;
+                const u32x4_t val = *(const u32x4_t*)(sB + ml * 256 + ((c ^ (ml & 15)) << 4));
+                const int m = m0 + ml, n = n0 + c * 8;
+#if defined(N8_ABLATE) && (N8_ABLATE & 4)
+                asm volatile("" :: "v"(val));
+#else
+                if (m < p.M && n < p.N) store_out16<NTS>(dst + (int64_t)m * p.ldc + n, val);
+#endif
+            }
+        };
+        if (p.preact) {                 // forward of a fused activation: the pre-activation copy first
+            write_tile(false);
+            __syncthreads();
+            read_tile((T*)p.preact);
+            __syncthreads();
+        }
+        write_tile(act != VALOR_ACT_NONE && !p.dact_aux);
+        if (p.dact_aux || p.accumulate) {
+            const bool dact = p.dact_aux != nullptr, accum = p.accumulate != 0;
+            const T* src = dact ? (const T*)p.dact_aux : (const T*)p.C;
+            const int64_t lds2 = dact ? p.ldaux : p.ldc;
+            u32x4_t pre[8];
+#pragma unroll
+            for (int it = 0; it < 8; ++it) {
+                const int m = m0 + it * 32 + (tid >> 4), n = n0 + (tid & 15) * 8;
+                pre[it] = (u32x4_t){0u, 0u, 0u, 0u};
+                if (m < p.M && n < p.N) pre[it] = *(const u32x4_t*)(src + (int64_t)m * lds2 + n);
+            }
+            __syncthreads();
+            T* dst = (T*)p.C;
+#pragma unroll
+            for (int it = 0; it < 8; ++it) {
+                const int ml = it * 32 + (tid >> 4), c = tid & 15;
+                u32x4_t val = *(const u32x4_t*)(sB + ml * 256 + ((c ^ (ml & 15)) << 4));
+                const int m = m0 + ml, n = n0 + c * 8;
+                if (m < p.M && n < p.N) {
+                    float f[8], x[8];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) { f[2 * q] = __uint_as_float(val[q] << 16); f[2 * q + 1] = __uint_as_float(val[q] & 0xffff0000u); }
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) { x[2 * q] = __uint_as_float(pre[it][q] << 16); x[2 * q + 1] = __uint_as_float(pre[it][q] & 0xffff0000u); }
+                    if (dact) {
+                        if (deriv) {
+#pragma unroll
+                            for (int q = 0; q < 8; ++q) f[q] *= x[q];
+                        } else {
+                            act_bwd_mul_n<8>(act, f, x);
+                        }
+                        if (accum) {
+                            const u32x4_t o = *(const u32x4_t*)(dst + (int64_t)m * p.ldc + n);
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) { f[2 * q] += __uint_as_float(o[q] << 16); f[2 * q + 1] += __uint_as_float(o[q] & 0xffff0000u); }
+                        }
+                    } else {
+#pragma unroll
+                        for (int q = 0; q < 8; ++q) f[q] += x[q];
+                    }
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) val[q] = pack2_bf16(f[2 * q], f[2 * q + 1]);
+                    store_out16<NTS>(dst + (int64_t)m * p.ldc + n, val);
+                }
+            }
+            stamp_out();
+            return;
+        }
+        __syncthreads();
+        read_tile((T*)p.C);
+        stamp_out();
+        return;
+    }
+
+    // ---- general epilogue: two passes (tile row halves mh) through LDS: 128 rows x 128 cols fp32 (swizzled 16-B chunks) ->
+    // row-contiguous 16-byte bf16 stores
+    float* sC = (float*)smem;
+    const f32x4_t bias0 = load_bias4<T>(p, n0 + (tid & 15) * 8), bias1 = load_bias4<T>(p, n0 + (tid & 15) * 8 + 4);
+#pragma unroll
+    for (int pass = 0; pass < 2; ++pass) {
+        if (pass) __syncthreads();
+        const int mlw = wm * 32 + l31;                                // row inside this 128-row half
+#pragma unroll
+        for (int cg = 0; cg < 8; ++cg) {
+            const int ch = ((cg >> 2) * 16 + wn * 8 + (cg & 3) * 2 + lh) ^ (mlw & 7);
+            *(f32x4_t*)(sC + mlw * 128 + ch * 4) = w8_quad(acc[pass][cg >> 2], cg & 3);
+        }
+        __syncthreads();
+#pragma unroll 2
+        for (int it = 0; it < 4; ++it) {
+            const int ml = it * 32 + (tid >> 4);
+            const int c8 = tid & 15;                                   // 8 columns = fp32 chunks 2*c8, 2*c8+1
+            const f32x4_t v0 = *(const f32x4_t*)(sC + ml * 128 + (((2 * c8) ^ (ml & 7)) << 2));
+            const f32x4_t v1 = *(const f32x4_t*)(sC + ml * 128 + (((2 * c8 + 1) ^ (ml & 7)) << 2));
+            const int m = m0 + pass * 128 + ml, n = n0 + c8 * 8;
+            epilogue_store8<true, NTS ? 1 : 0>(p, m, n, v0, v1, bias0, bias1);
+        }
+    }
+    stamp_out();
+}
+
+// raster / store-mode choices are launch_gemm_8ph2's (gemm8n.hip); it calls this for the problems policy key 10 sends here
+void launch_gemm_8w(hipStream_t st, const GemmArgs& p, int tiles, bool nts) {
+    dim3 grid(tiles);
+    const size_t lds = W8_LDS;
+#define VALOR_8W_LAUNCH(NTS_)                                                                                   \
+    do {                                                                                                        \
+        static bool attr_set = false;                                                                           \
+        if (!attr_set) {                                                                                        \
+            hipFuncSetAttribute((const void*)gemm_8w_kernel<NTS_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+            attr_set = true;                                                                                    \
+        }                                                                                                       \
+        hipLaunchKernelGGL((gemm_8w_kernel<NTS_>), grid, dim3(512), lds, st, p);                                \
+    } while (0)
+    if (nts) VALOR_8W_LAUNCH(true); else VALOR_8W_LAUNCH(false);
+#undef VALOR_8W_LAUNCH
+}
+
+// how many 8-wave workgroups the runtime admits per CU (2 = the design point: four waves per SIMD)
+extern "C" int valor_gemm_wide_occupancy(void) {
+    int n = 0;
+    hipFuncSetAttribute((const void*)gemm_8w_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)W8_LDS);
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, (const void*)gemm_8w_kernel<true>, 512, W8_LDS) != hipSuccess) return -1;
+    return n;
+}

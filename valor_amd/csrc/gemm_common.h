@@ -226,6 +226,9 @@ DEVINL void epilogue_store8(const GemmArgs& p, int m, int n0, f32x4_t a0, f32x4_
 void launch_gemm_8ph(hipStream_t st, int transA, int transB, const GemmArgs& p);
 // 256x128 8-phase bf16 kernel, two workgroups per CU (gemm8n.hip). grid.x = tiles(256 x 128) * max(kslices, 1).
 void launch_gemm_8ph2(hipStream_t st, int transA, int transB, const GemmArgs& p);
+// the same tile on 512-thread workgroups (gemm8w.hip: 64x64 outputs per wave, four waves per SIMD), NN layout without split-K; p carries
+// launch_gemm_8ph2's epilogue / raster / store-mode choices. grid.x = tiles(256 x 128).
+void launch_gemm_8w(hipStream_t st, const GemmArgs& p, int tiles, bool nts);
 // ---- tuning knobs. Process defaults (valor_gemm_set_policy / _set_variant / ...; env presets) live in globals; a CALL can override any
 // of them through a valor_gemm_policy (include/valor_hip.h) handed to valor_gemm_tuned / valor_gemm_kernel_for_tuned: the entry points
 // park a pointer to it in a thread-local for the duration of the call, every read below looks there first. -1 = the process default.

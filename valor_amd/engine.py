@@ -44,6 +44,12 @@ class TrainEngine:
         # of lead keep the GPU fed; the step waits for the end of the step before the previous one.
         self.max_ahead = int(getattr(opts, "max_steps_ahead", 2))
         self._step_events = []
+        # per-step host / device timing for whoever asks (bench.py sets `trace = []`): every optimizer step appends
+        # {"wait_ms": host time blocked in the `max_ahead` throttle, "host_ms": host time of the whole call, "head" / "tail": timing events
+        # recorded on the step's stream in front of its first and behind its last launch}. tail[n].elapsed_time(head[n+1]) is the time the
+        # stream sat idle between two steps because the host had not issued the next one yet; head.elapsed_time(tail) is the step's span
+        # on the device. None (the default) records nothing.
+        self.trace = None
         # Even with the lead bounded, the working set keeps growing for a few steps after the first one (a block that crossed streams
         # is reusable only once the other stream has passed it, so some tensors exist once per step in flight): 2 + 172 + 592 MiB of
         # hipMalloc inside steps 4-6 of a run, each a device-wide stall. After the second optimizer step the engine therefore
@@ -70,8 +76,21 @@ class TrainEngine:
         if task != self._task:
             self.reducer.reset_task(task)
             self._task = task
+        tracing = self.trace is not None and model.arena.flat.is_cuda
+        if tracing:
+            import time as _time
+            t_in = _time.perf_counter()
+        wait_s = 0.0
         if self.max_ahead > 0 and len(self._step_events) >= self.max_ahead:
-            self._step_events.pop(0).synchronize()
+            if tracing:
+                t_w = _time.perf_counter()
+                self._step_events.pop(0).synchronize()
+                wait_s = _time.perf_counter() - t_w
+            else:
+                self._step_events.pop(0).synchronize()
+        if tracing:
+            head = torch.cuda.Event(enable_timing=True)
+            head.record()
         model.train()
         DropoutState.begin_step()          # device mode (model.enable_graphs): by-value offsets restart, the device counter advances
         self._micro += 1
@@ -95,9 +114,11 @@ class TrainEngine:
         opt.step(active_names=active, max_grad_norm=self.grad_norm, world_size=self.world)   # clip :358-360, step :362
         loss_dict["total_loss"] = loss.detach()
         if self.max_ahead > 0 and model.arena.flat.is_cuda:
-            ev = torch.cuda.Event()
+            ev = torch.cuda.Event(enable_timing=tracing)
             ev.record()
             self._step_events.append(ev)
+            if tracing:
+                self.trace.append({"wait_ms": wait_s * 1e3, "host_ms": (_time.perf_counter() - t_in) * 1e3, "head": head, "tail": ev})
         if not self._headroom_done and self.global_step >= 2:
             self.reserve_headroom()
         if self.manage_gc:
