@@ -275,6 +275,51 @@ def test_base_fp32_matches_reference_goldens(dev, name):
         assert abs(d - n) <= 5e-3 * n + 1e-7 * sd[k].numel() ** 0.5, (k, d, n)
 
 
+def test_fp32_matches_reference_at_the_bench_batch(dev):
+    """fp32 mode on THE configuration bench.py times (ref_base_b64f8a2_q: B = 64, 8 frames, 2 audio slices; the unmodified reference with
+    its `checkpointing` option): argmax token ids of all 2353 masked rows bit-exact, features, the three losses to 1e-4, every
+    per-parameter gradient norm to 2e-3 (model/pretrain.py:214-541)."""
+    from valor_amd.engine import TrainEngine
+    from types import SimpleNamespace
+    g = torch.load(os.path.join(GOLD, "ref_base_b64f8a2_q.pt"), weights_only=False)
+    rc = g["recipe"]
+    spec, sd, batch = _recipe_tensors(rc)
+    model = _native(spec, sd, torch.float32, dev)
+    with torch.no_grad():
+        random.seed(rc["masker_seed"])
+        ev = model(batch, task=rc["task"], compute_loss=False)
+    rows = 0
+    for k, ids in g["eval"].items():
+        if "scores" in k:
+            assert torch.equal(ev[k].argmax(-1).cpu(), ids), k
+            rows += ids.numel()
+    for k in ("feat_t", "feat_v", "feat_a"):
+        assert torch.allclose(ev[k].cpu(), g["eval"][k], atol=5e-5), k
+    del ev
+    opts = SimpleNamespace(learning_rate=1e-4, weight_decay=0.01, clip_lr=5e-7, clip_lr_text=5e-7, new_lr=0.0, decoder_lr=-1,
+                           betas=[0.9, 0.98], warmup_ratio=0.1, num_train_steps=10, scheduler="warmup_linear", grad_norm=5.0)
+    eng = TrainEngine(model, opts)
+    random.seed(rc["masker_seed"])
+    model.train(); eng.reducer.prepare_backward()
+    out = model(batch, task=rc["task"], compute_loss=True)
+    sum(out.values()).backward()
+    rec = g["steps"][0]
+    rep = {k: (float(out[k]), v, abs(float(out[k]) - v) / abs(v)) for k, v in rec["losses"].items()}
+    print(f"fp32 vs reference [ref_base_b64f8a2_q]: losses (native, reference, rel err) {rep}; argmax ids equal on {rows}/{rows} masked rows")
+    for k, (a, v, e) in rep.items():
+        assert e <= 1e-4, (k, a, v, e)
+    ng = _native_grads(model)
+    # the fixture's norms are torch's fp32 CPU norm() of the reference's gradients: on the 23 M-element word-embedding gradient (two
+    # rows -- [SEP], [MASK] -- carry most of the sum of squares) that summation loses 0.22 % against a double-precision one (3.58913 vs
+    # 3.59720, measured: tools/debug_norm.py), the device's tree reduction does not. Compare like with like: the same CPU norm here.
+    for k, n in rec["grad_norm"].items():
+        got = float(ng[k].float().cpu().norm())
+        assert abs(got - n) <= 2e-3 * max(n, 1e-5 * ng[k].numel() ** 0.5), (k, got, n)
+    for k, sl in rec["grad_slices"].items():
+        assert torch.allclose(ng[k].reshape(-1)[:64].cpu(), sl, rtol=5e-3, atol=2e-7), k
+    eng.close()
+
+
 BF16_LOSS_TOL = 1e-3          # north_star: losses within 1e-3 relative of the reference CPU path
 # The contrastive loss of a B x B score matrix is ln B plus a small signal: its RELATIVE sensitivity to feature noise falls like
 # 1 / (sqrt(B) ln B). With bf16 GEMM operands the encoder outputs carry ~0.9 % relative L2 error after 12 layers (the same figure
@@ -292,14 +337,17 @@ BF16_TIE_BAND = 0.05          # absolute logit gap below which the fp32 referenc
 
 
 @pytest.mark.parametrize("name", ["ref_base_b16f2a1_q", "ref_base_b2f2a1_q", "ref_base_b2f8a2_q", "ref_swin_b2f8a2_q", "ref_base_b16f8a2_q",
-                                  "ref_cliplarge_b8f2a1_q", "ref_base_b2f16a2_q", "ref_swin_b2f16a2_q", "ref_base_b8f16a2_q"])
+                                  "ref_cliplarge_b8f2a1_q", "ref_base_b2f16a2_q", "ref_swin_b2f16a2_q", "ref_base_b8f16a2_q", "ref_base_b64f8a2_q"])
 def test_bf16_meets_north_star_on_identical_tensors(dev, name):
     """perf mode -- the arithmetic bench.py times (bf16 storage, fp32 accumulate) -- against the fp32 reference on IDENTICAL
     tensors (weights / pixels / spectrograms are bf16-representable, so nothing is rounded on load): all three losses within
     1e-3 relative (the contrastive loss of ref_base_b2f2a1_q only: 5e-3, see BF16_CONTRA_TOL_B2); argmax token ids equal to the reference's on every masked row whose fp32 top-1 / top-2 logit gap exceeds
     BF16_TIE_BAND (rows inside the band cannot be decided by ANY evaluation with 8 mantissa bits: at random init the logits have
     std ~0.5 and the gaps go down to 1e-4); the overall match rate is printed. b2f8a2 = the bench geometry; b16f8a2 = the bench
-    geometry at a batch whose GEMMs take the dispatch bench.py times (25 216 ViT rows: 8-phase NN / NT / TT kernels, asserted)."""
+    geometry at a batch whose GEMMs take the dispatch bench.py times (25 216 ViT rows: 8-phase NN / NT / TT kernels, asserted);
+    b64f8a2 = THE configuration bench.py times (BASELINE configs[1]: B = 64, 8 frames, 2 audio slices -- 100 864 ViT rows, the 8 832-row
+    decoder stack, the 64-sample kv_range groups, the 64 x 64 fused contrastive matrix; the reference ran it with its own `checkpointing`
+    option, model/pretrain.py:214-541), GEMM families asserted, per-parameter gradient norms of the recorded slice keys compared too."""
     g = torch.load(os.path.join(GOLD, name + ".pt"), weights_only=False)
     rc = g["recipe"]
     assert rc["bf16_exact"]
@@ -316,6 +364,17 @@ def test_bf16_meets_north_star_on_identical_tensors(dev, name):
         for (ta, tb, m, n, k, fam) in [(0, 0, M, I, W, 4), (0, 0, M, 3 * W, W, 4), (0, 0, M, W, I, 3),       # forward: fc1, qkv, fc2
                                        (0, 1, M, I, W, 4),                                             # dgrad of fc2 (saved-derivative multiply)
                                        (1, 1, I, W, M, 3), (1, 1, W, I, M, 3), (1, 1, 3 * W, W, M, 3)]:  # wgrad: contraction over the 25 216 tokens
+            assert so.valor_gemm_kernel_for(0, ta, tb, m, n, k, 0) == fam, (ta, tb, m, n, k)
+    if name == "ref_base_b64f8a2_q":
+        from valor_amd import lib
+        so = lib.load()
+        M = rc["batch"] * rc["frames"] * spec.vis_tokens
+        Mkv = rc["batch"] * (rc["frames"] * spec.vis_tokens + rc["audio_slices"] * spec.aud_tokens)
+        W, I = spec.vis_width, 4 * spec.vis_width
+        assert (M, Mkv) == (100864, 117376)
+        for (ta, tb, m, n, k, fam) in [(0, 0, M, I, W, 4), (0, 0, M, 3 * W, W, 4), (0, 0, Mkv, 2 * W, W, 4), (0, 0, M, W, I, 3), (0, 0, M, W, W, 3),
+                                       (0, 1, M, I, W, 4), (0, 1, M, W, I, 3), (0, 1, M, W, 3 * W, 3),
+                                       (1, 1, I, W, M, 3), (1, 1, W, I, M, 3), (1, 1, 3 * W, W, M, 3), (1, 1, W, W, M, 3)]:
             assert so.valor_gemm_kernel_for(0, ta, tb, m, n, k, 0) == fam, (ta, tb, m, n, k)
     with torch.no_grad():
         random.seed(rc["masker_seed"])
@@ -345,6 +404,15 @@ def test_bf16_meets_north_star_on_identical_tensors(dev, name):
     tot = float(torch.sqrt(sum((x.float() ** 2).sum() for x in ng.values())))
     ref_tot = g["steps"][0]["total_grad_norm"]
     assert abs(tot - ref_tot) <= 0.05 * ref_tot, (tot, ref_tot)
+    if name == "ref_base_b64f8a2_q":
+        # gradient norms of the tensors the fixture keeps slices of (one per tower / head / embedding table): bf16 storage through 12
+        # layers moves a single tensor's gradient norm by a few per cent
+        worst = {}
+        for k in g["steps"][0]["grad_slices"]:
+            n, got = g["steps"][0]["grad_norm"][k], float(ng[k].float().cpu().norm())       # the fixture's norms are CPU fp32 norms (see the fp32 test)
+            worst[k] = abs(got - n) / max(n, 1e-12)
+        print(f"bf16 vs reference [{name}]: relative gradient-norm error per recorded tensor {({k: round(v, 4) for k, v in worst.items()})}")
+        assert max(worst.values()) <= 0.03, worst
 
 
 def test_bf16_large_widths_on_identical_tensors(dev):
