@@ -261,8 +261,8 @@ def time_variant(variant, args, dev, steps=3, warmup=2, frames=None, accum=1, ba
     model.load_state_dict(sd, strict=True)
     opts = SimpleNamespace(learning_rate=1e-4, weight_decay=0.01, clip_lr=5e-7, clip_lr_text=5e-7, new_lr=0.0, decoder_lr=-1,
                            betas=[0.9, 0.98], warmup_ratio=0.1, num_train_steps=100000, scheduler="warmup_linear", grad_norm=5.0)
-    engine = TrainEngine(model, opts)
-    engine.optimizer.init_master_from(sd)
+    engine = TrainEngine(model, opts, graphs=False)      # the variants keep eager issue (their numbers stay comparable across rounds; the 16-frame
+    engine.optimizer.init_master_from(sd)                # large runs have no memory to spare for a second, private pool of encoder activations)
     del sd
     batch = synth.make_batch(spec, batch=nb, frames=frames, audio_slices=args.audio_slices, txt_len=32, seed=50)
     batch["video_pixels"] = batch["video_pixels"].to(dev)
@@ -300,8 +300,9 @@ def main():
     ap.add_argument("--dropout", type=float, default=0.1)
     ap.add_argument("--checkpointing", type=int, default=0, help="1 = the reference's `checkpointing` option (activation checkpointing of every video / "
                     "audio / CLIP-text encoder layer and decoder layer): BASELINE configs[4] as written is --variant large --frames 16 --batch 128 --checkpointing 1")
-    ap.add_argument("--graphs", type=int, default=int(os.environ.get("VALOR_GRAPHS", "0")), help="1 = the CLIP ViT / AST encoders replay hipGraphs "
-                    "(valor_amd/graphs.py: forward + backward captured on their third step; dropout offsets from a device-resident counter)")
+    ap.add_argument("--graphs", type=int, default=int(os.environ.get("VALOR_GRAPHS", "1")), help="1 (default) = the CLIP ViT / AST / CLIP text encoders replay "
+                    "hipGraphs (valor_amd/graphs.py: forward + backward captured on their third step; dropout offsets from a device-resident counter; "
+                    "bit-identical to eager issue, profiles/r06_graphs_ab_*.txt), 0 = eager issue")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--accum", type=int, default=1, help="micro-steps per optimizer step (gradient accumulation, train_utils.py:311-317): the per-GPU batch of "
                     "a step is --batch x --accum. BASELINE configs[4] (VALOR-large, 16 frames, global batch 1024 = 128 per GPU) runs as "

@@ -266,3 +266,30 @@ def test_grouped_splitk_reduction_is_bit_identical(dev):
         assert torch.equal(gw, rw) and torch.equal(gb, rb)
     sref = ops_[0][0][:256].float().t() @ ops_[0][1][:256].float()
     assert float((small.float() - sref).norm() / sref.norm()) < TOL
+
+
+def test_deferred_products_into_one_buffer_do_not_share_a_group(dev):
+    """two deferred split-K products that ACCUMULATE INTO THE SAME weight gradient (a weight used by two Linears: the shared-BERT text
+    encoder / decoder of a shallow stack, the tied word embedding; model/modeling.py:437-446,688-691) must not be summed by one grouped
+    reduction -- its workgroups would race on C's read-modify-write. The second one closes the group first (kernels.gemm): the result
+    equals two sequential valor_gemm calls to the bit, on the weight and on the fused bias gradient."""
+    from valor_amd import kernels as Kn
+    Kt, mo, no = 16512, W, W
+    dY1, X1, dY2, X2 = _mk((Kt, mo), 201, dev, 0.1), _mk((Kt, no), 202, dev), _mk((Kt, mo), 203, dev, 0.1), _mk((Kt, no), 204, dev)
+    g0, b0 = _mk((mo, no), 205, dev), _mk((mo,), 206, dev)
+    gw, gb = g0.clone(), b0.clone()
+    for dY, X in ((dY1, X1), (dY2, X2)):
+        Kn.gemm(dY, X, trans_a=True, trans_b=True, out=gw, accumulate=True, rowsum_out=gb, rowsum_accumulate=True)
+    hw, hb = g0.clone(), b0.clone()
+    order = []
+    Kn.ReduceQueue._armed = True
+    try:
+        Kn.gemm(dY1, X1, trans_a=True, trans_b=True, out=hw, accumulate=True, rowsum_out=hb, rowsum_accumulate=True, defer_done=lambda: order.append(1))
+        q = Kn.ReduceQueue.current(dev)
+        assert q.n == 1 and order == []
+        Kn.gemm(dY2, X2, trans_a=True, trans_b=True, out=hw, accumulate=True, rowsum_out=hb, rowsum_accumulate=True, defer_done=lambda: order.append(2))
+        assert order == [1] and q.n == 1            # the first product was reduced before the second one joined
+    finally:
+        Kn.ReduceQueue.flush_all()
+    assert order == [1, 2]
+    assert torch.equal(hw, gw) and torch.equal(hb, gb)

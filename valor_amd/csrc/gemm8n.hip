@@ -31,6 +31,11 @@
 #include "gemm_common.h"
 #include <stdlib.h>
 
+#if defined(N8_ABLATE) && (N8_ABLATE & 8)
+#define N8_KADV(x) 0        // diagnostic build: the pipelined loop re-reads the same K-tile (cache-hot DMA: what does memory latency cost?)
+#else
+#define N8_KADV(x) (x)
+#endif
 #define N8_HT 16384
 #define N8_OFF_B (3 * N8_HT)
 #define N8_LDS (5 * N8_HT)
@@ -367,12 +372,12 @@ __global__ __launch_bounds__(256, 2) void gemm_8ph2_kernel(GemmArgs p) {
             }
             auto dmaA = [&](int hf, char* slot, int t, int i) {
                 const rsrc_t rs = make_rsrc(p.A, t < ntile ? p.bytesA : 0u);
-                if (hf == 0) { glds16(rs, slot + wave * 4096 + i * 1024, oA0[i]); oA0[i] += stepA; asm volatile("" : "+v"(oA0[i])); }
-                else { glds16(rs, slot + wave * 4096 + i * 1024, oA1[i]); oA1[i] += stepA; asm volatile("" : "+v"(oA1[i])); }
+                if (hf == 0) { glds16(rs, slot + wave * 4096 + i * 1024, oA0[i]); oA0[i] += N8_KADV(stepA); asm volatile("" : "+v"(oA0[i])); }
+                else { glds16(rs, slot + wave * 4096 + i * 1024, oA1[i]); oA1[i] += N8_KADV(stepA); asm volatile("" : "+v"(oA1[i])); }
             };
             auto dmaB = [&](char* buf, int t, int i) {
                 const rsrc_t rs = make_rsrc(p.B, t < ntile ? p.bytesB : 0u);
-                glds16(rs, buf + wave * 4096 + i * 1024, oB[i]); oB[i] += stepB; asm volatile("" : "+v"(oB[i]));
+                glds16(rs, buf + wave * 4096 + i * 1024, oB[i]); oB[i] += N8_KADV(stepB); asm volatile("" : "+v"(oB[i]));
             };
 #define HALF8(MH_, NH_, KK_, FB_, X0, X1, X2, X3, X4, X5, X6, X7)                                               \
     do {                                                                                                          \

@@ -29,6 +29,11 @@
 #include "gemm_common.h"
 #include <stdlib.h>
 
+#if defined(N8_ABLATE) && (N8_ABLATE & 8)
+#define W8_KSTEP 0          // diagnostic build: every K-tile re-reads the tile's FIRST K-tile (cache-hot DMA: what does memory latency cost?)
+#else
+#define W8_KSTEP 128
+#endif
 #define W8_HT 16384
 #define W8_OFF_B (3 * W8_HT)
 #define W8_LDS (5 * W8_HT)
@@ -102,20 +107,30 @@ __global__ __launch_bounds__(512, 4) void gemm_8w_kernel(GemmArgs p) {
     const uint32_t halfA = 128u * (uint32_t)ldA_b;
     const uint32_t bytesA1 = p.bytesA > halfA ? p.bytesA - halfA : 0u;
     const char* const pA1 = (const char*)p.A + halfA;
+    auto pieceA = [&](int hf, char* slot, int t, int i) {
+        const uint32_t nb = __builtin_amdgcn_readfirstlane(t < ntile ? (hf ? bytesA1 : p.bytesA) : 0u);
+        const rsrc_t rs = make_rsrc(hf ? pA1 : (const char*)p.A, nb);
+        glds16s(rs, slot + wave * 2048 + i * 1024, vA[i], t * W8_KSTEP);
+    };
+    auto pieceB = [&](char* buf, int t, int i) {
+        const uint32_t nb = __builtin_amdgcn_readfirstlane(t < ntile ? p.bytesB : 0u);
+        const rsrc_t rs = make_rsrc(p.B, nb);
+        glds16s(rs, buf + wave * 2048 + i * 1024, vB[i], t * W8_KSTEP);
+    };
     auto issueA = [&](int hf, char* slot, int t) {
         // (readfirstlane: the extent select must be PROVABLY wave-uniform, or hipcc wraps every load in a waterfall loop)
         const uint32_t nb = __builtin_amdgcn_readfirstlane(t < ntile ? (hf ? bytesA1 : p.bytesA) : 0u);
         const rsrc_t rs = make_rsrc(hf ? pA1 : (const char*)p.A, nb);
         char* d = slot + wave * 2048;
 #pragma unroll
-        for (int i = 0; i < 2; ++i) glds16s(rs, d + i * 1024, vA[i], t * (BK * 2));
+        for (int i = 0; i < 2; ++i) glds16s(rs, d + i * 1024, vA[i], t * W8_KSTEP);
     };
     auto issueB = [&](char* buf, int t) {
         const uint32_t nb = __builtin_amdgcn_readfirstlane(t < ntile ? p.bytesB : 0u);
         const rsrc_t rs = make_rsrc(p.B, nb);
         char* d = buf + wave * 2048;
 #pragma unroll
-        for (int i = 0; i < 2; ++i) glds16s(rs, d + i * 1024, vB[i], t * (BK * 2));
+        for (int i = 0; i < 2; ++i) glds16s(rs, d + i * 1024, vB[i], t * W8_KSTEP);
     };
 
     // ---- fragment reads: lane l = image row (base + l & 31), 16-byte chunk (2 s + (l >> 5)) ^ ((row >> 1) & 7) of 16-k step s
@@ -140,9 +155,9 @@ __global__ __launch_bounds__(512, 4) void gemm_8w_kernel(GemmArgs p) {
     char* const bufB1 = smem + W8_OFF_B + W8_HT;
 
     // prologue = what the steady state has in flight in front of K-tile 0: B(0) A'0(0) | A'1(0) B(1) | A'0(1)
-    issueB(bufB0, 0); issueA(0, smem, 0); issueA(1, smem + W8_HT, 0); issueB(bufB1, 1); issueA(0, smem + 2 * W8_HT, 1);
+    issueB(bufB0, 0); issueA(0, smem, 0); issueA(1, smem + W8_HT, 0); issueB(bufB1, 1); pieceA(0, smem + 2 * W8_HT, 1, 0);
     PIN();
-    asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     PIN();
     W8_STAMP_AT(1);
@@ -173,22 +188,23 @@ __global__ __launch_bounds__(512, 4) void gemm_8w_kernel(GemmArgs p) {
         char* const a2 = smem + sa2 * W8_HT;         // A'0(c+1)
         char* const bcur = (c & 1) ? bufB1 : bufB0;  // B(c): in registers; refilled with B(c+2)
         char* const bnxt = (c & 1) ? bufB0 : bufB1;  // B(c+1)
-        // ---- P0 (every step: the NEXT step's A fragment first -- its register was the previous step's operand --, then the two MFMAs)
-        LRD_A(fa1, a0, 1); PIN(); MM(0, 0, 0, fa0); PIN(); MM(0, 1, 0, fa0); PIN();
+        char* const a2x = a2;                        // second piece of A'0(c+1): its first one went out at P1 step 3 of K-tile c-1
+        // ---- P0 (every step: the NEXT step's A fragment first -- its register was the previous step's operand --, then the two MFMAs).
+        // DMA: ONE piece per step and wave (a burst of pieces right behind a barrier, from all eight waves at once, backs the CU's
+        // 64 B/clk L1 -> LDS path up and stalls the issuing waves in front of their MFMAs)
+        LRD_A(fa1, a0, 1); PIN(); MM(0, 0, 0, fa0); PIN(); LDMA(pieceA(0, a2x, c + 1, 1)); PIN(); MM(0, 1, 0, fa0); PIN();
         LRD_A(fa0, a0, 2); PIN(); MM(0, 0, 1, fa1); PIN(); MM(0, 1, 1, fa1); PIN();
         LRD_A(fa1, a0, 3); PIN(); MM(0, 0, 2, fa0); PIN(); MM(0, 1, 2, fa0); PIN();
         BAR(2);
         LRD_A(fa0, a1, 0); PIN(); MM(0, 0, 3, fa1); PIN();
-        LDMA(issueA(1, a0, c + 1)); PIN();
+        LDMA(pieceA(1, a0, c + 1, 0)); PIN();
         MM(0, 1, 3, fa1); PIN();
-        LDMA(issueB(bcur, c + 2)); PIN();
         // ---- P1 (the B fragments of K-tile c+1 into the registers the step's MFMAs just read)
-        LRD_A(fa1, a1, 1); PIN(); MM(1, 0, 0, fa0); PIN(); MM(1, 1, 0, fa0); LRD_B(0, 0); LRD_B(1, 0); PIN();
-        LRD_A(fa0, a1, 2); PIN(); MM(1, 0, 1, fa1); PIN(); MM(1, 1, 1, fa1); LRD_B(0, 1); LRD_B(1, 1); PIN();
-        LRD_A(fa1, a1, 3); PIN(); MM(1, 0, 2, fa0); PIN(); MM(1, 1, 2, fa0); LRD_B(0, 2); LRD_B(1, 2); PIN();
+        LRD_A(fa1, a1, 1); PIN(); MM(1, 0, 0, fa0); PIN(); LDMA(pieceA(1, a0, c + 1, 1)); PIN(); MM(1, 1, 0, fa0); LRD_B(0, 0); LRD_B(1, 0); PIN();
+        LRD_A(fa0, a1, 2); PIN(); MM(1, 0, 1, fa1); PIN(); LDMA(pieceB(bcur, c + 2, 0)); PIN(); MM(1, 1, 1, fa1); LRD_B(0, 1); LRD_B(1, 1); PIN();
+        LRD_A(fa1, a1, 3); PIN(); MM(1, 0, 2, fa0); PIN(); LDMA(pieceB(bcur, c + 2, 1)); PIN(); MM(1, 1, 2, fa0); LRD_B(0, 2); LRD_B(1, 2); PIN();
         BAR(4);
-        LRD_A(fa0, a2, 0); PIN(); MM(1, 0, 3, fa1); PIN(); MM(1, 1, 3, fa1); LRD_B(0, 3); LRD_B(1, 3); PIN();
-        LDMA(issueA(0, a1, c + 2)); PIN();
+        LRD_A(fa0, a2, 0); PIN(); MM(1, 0, 3, fa1); PIN(); LDMA(pieceA(0, a1, c + 2, 0)); PIN(); MM(1, 1, 3, fa1); LRD_B(0, 3); LRD_B(1, 3); PIN();
         sa0 = sa2;
     }
     W8_STAMP_AT(2);

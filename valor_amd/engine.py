@@ -14,11 +14,15 @@ from .optim import FusedAdamW, get_lr_sched
 class TrainEngine:
     def __init__(self, model, opts, optimizer=None, manage_gc=True, graphs=None):
         self.model, self.opts = model, opts
-        # graphs: replay the CLIP ViT / AST encoders as hipGraphs (valor_amd/graphs.py; VALOR_GRAPHS=1 or opts.graphs). The VideoSwin
-        # encoder and the decoder stay eager.
+        # graphs: replay the encoders as hipGraphs (valor_amd/graphs.py) -- the CLIP ViT or the VideoSwin encoder (stochastic-depth factors
+        # as a graph input), the AST encoder and the CLIP text tower; the decoder (data-dependent masked-row counts) and the shared-BERT text
+        # pass stay eager. Default ON since round 6 (bit-identical to eager; interleaved A/B on two boxes, profiles/r06_graphs_ab_*.txt: equal
+        # mean throughput, a quarter of the run-to-run spread, half the host time per step); VALOR_GRAPHS=0 / opts.graphs=False / graphs=False: eager.
         import os as _os
         if graphs is None:
-            graphs = _os.environ.get("VALOR_GRAPHS", "0") == "1" or bool(getattr(opts, "graphs", False))
+            # (not with activation checkpointing: those are the configurations that fill HBM, and a captured encoder keeps its saved
+            # activations in a private pool beside whatever the eager warm-up steps left in the caching allocator)
+            graphs = _os.environ.get("VALOR_GRAPHS", "1") != "0" and bool(getattr(opts, "graphs", True)) and not getattr(model, "checkpointing", False)
         if graphs and model.arena.flat.is_cuda:
             model.enable_graphs()
         # The cyclic garbage collector fires in the middle of a forward pass (thousands of short-lived autograd objects per
@@ -61,6 +65,10 @@ class TrainEngine:
         self.grad_norm = float(getattr(opts, "grad_norm", 5.0))
         self._task = None
         self._micro = 0
+        # VALOR_DP_CHECK=1 (debug): every rank must have seen the same task sequence in an accumulation window -- the closing micro-step's
+        # bucket order (dist.Reducer) is only the same on every rank if it did; checked with one small all-reduce per optimizer step
+        self._check_window = _os.environ.get("VALOR_DP_CHECK", "0") == "1"
+        self._window_tasks = []
         if getattr(opts, "dataset_mix_type", "random") not in ("random", "round-robin", "accum"):
             raise NotImplementedError(f"dataset_mix_type={opts.dataset_mix_type}")
 
@@ -93,8 +101,10 @@ class TrainEngine:
             head.record()
         model.train()
         DropoutState.begin_step()          # device mode (model.enable_graphs): by-value offsets restart, the device counter advances
-        self._micro += 1
-        last = (not accum) or self._micro % accum_steps == 0
+        micro = self._micro + 1             # committed only once forward + backward went through: an exception in between must not shift the
+        last = (not accum) or micro % accum_steps == 0          # accumulation window's boundary for the next call
+        if self.world > 1 and self._check_window:
+            self._window_tasks.append(task)
         # accumulation window: the micro-steps before the last only accumulate; the LAST one reduces bucket by bucket from its gradient
         # hooks like an ordinary step (a bucket that is complete in the last micro-step holds the sum of the whole window), so the
         # window's reduction overlaps that backward instead of running behind it
@@ -102,6 +112,9 @@ class TrainEngine:
         loss_dict = model(batch, task=task, compute_loss=True)
         loss = sum(loss_dict.values())
         (loss / accum_steps if accum else loss).backward()
+        self._micro = micro
+        if last and self.world > 1 and self._check_window:
+            self._assert_same_window()
         active = self.reducer.finish_backward(last=last)
         if not last:
             loss_dict["total_loss"] = loss.detach()
@@ -124,6 +137,17 @@ class TrainEngine:
         if self.manage_gc:
             gc.collect(0 if self.global_step % 64 else 2)
         return loss_dict
+
+    def _assert_same_window(self):
+        import zlib
+        h = zlib.crc32("|".join(self._window_tasks).encode()) & 0x7fffffff
+        self._window_tasks = []
+        dev = self.model.arena.flat.device
+        t = torch.tensor([h, -h], dtype=torch.int64, device=dev)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        if int(t[0]) != -int(t[1]):
+            raise RuntimeError("data-parallel ranks saw different task sequences inside one accumulation window: the gradient buckets of the "
+                               "closing micro-step would be reduced in different orders (valor_amd/dist.py)")
 
     def reserve_headroom(self, mb=None):
         """grow the caching allocator's pools by `mb` MiB of free segments now (see __init__); returns the bytes reserved. A pure
@@ -164,6 +188,11 @@ class TrainEngine:
             r.close()
 
     def __del__(self):
+        # not at interpreter shutdown: the process group / HIP runtime may be gone by then and a native crash in the communicator's
+        # destructor cannot be caught -- call close() (before dist.destroy_process_group) in a driver that wants the resources back
+        import sys
+        if sys is None or sys.is_finalizing():
+            return
         try:
             self.close()
         except Exception:

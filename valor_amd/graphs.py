@@ -51,6 +51,34 @@ class _Captured:
     __slots__ = ("g_fwd", "g_bwd", "static_in", "static_out", "static_gout", "sunk", "draws", "offset0", "stream")
 
 
+# One capture stream per (device, REPLAY stream), shared by every capture that is replayed there. Kernel workspaces and the
+# grouped-reduction queue are keyed by stream (kernels.workspace / ReduceQueue): a stream per capture allocated 256 MiB + 1 GiB of them per
+# captured key, inside that key's pool. They are scratch inside one kernel sequence, and graphs replayed on ONE stream run one after the
+# other: sharing is safe. Graphs that replay on DIFFERENT streams (the ViT on the step's stream, the AST / CLIP text encoders on the side
+# stream) run concurrently: they get their own capture stream, hence their own workspaces.
+# The private memory POOL is per segment (shared by its shape keys: only one key of a segment is alive in a step). Two segments must not
+# share one: a pool hands the memory a finished capture freed -- the saved activations of segment A, consumed by A's captured backward --
+# to the next capture, and at replay A's backward runs AFTER B's forward (forward A, forward B, backward B, backward A).
+_CAPTURE_CTX = {}
+
+
+def _capture_ctx(device):
+    cur = torch.cuda.current_stream(device)
+    key = (device.index if device.index is not None else torch.cuda.current_device(), cur.cuda_stream)
+    ctx = _CAPTURE_CTX.get(key)
+    if ctx is None:
+        ctx = _CAPTURE_CTX[key] = {"stream": torch.cuda.Stream(device=device)}
+    return ctx
+
+
+def release_all():
+    """drop the shared capture streams and the kernel workspaces that were allocated on them (call after every segment's release())"""
+    from . import kernels as K
+    for ctx in _CAPTURE_CTX.values():
+        K.release_stream(ctx["stream"])
+    _CAPTURE_CTX.clear()
+
+
 class GraphedSegment:
     """fn: device tensor(s) -> device tensor (an encoder; inputs that do not need gradients: pixels, spectrograms, token ids, masks -- every
     call copies them into the static buffers the graph was captured on). The replay node needs one differentiable input for autograd to call its
@@ -60,9 +88,14 @@ class GraphedSegment:
     the first one's backward would overwrite what that backward reads (VALOR calls every encoder once per forward pass; accumulation
     micro-steps run forward + backward one after the other)."""
 
-    def __init__(self, name, fn, warmup=2):
+    def __init__(self, name, fn, warmup=2, max_keys=None):
+        import os
         self.name, self.fn, self.warmup = name, fn, warmup
+        # every captured key keeps a full set of saved activations alive: a job that meets many shapes (multi-task batches, a partial
+        # last batch, drop-path on / off) must not multiply the encoder's activation memory without bound. Keys beyond the cap run eagerly.
+        self.max_keys = int(os.environ.get("VALOR_GRAPH_MAX_KEYS", "4")) if max_keys is None else int(max_keys)
         self.anchor = None
+        self.pool = None
         self.calls = {}
         self.captured = {}
 
@@ -73,21 +106,38 @@ class GraphedSegment:
             self.anchor = torch.zeros(1, device=xs[0].device, requires_grad=True)
         cap = self.captured.get(key)
         if cap is None:
+            if len(self.captured) >= self.max_keys:
+                return self.fn(*xs)
+            if len(self.calls) > 64:               # keys that never repeat (a driver that does not restart the by-value offsets): do not grow
+                self.calls.clear()
             n = self.calls.get(key, 0)
             self.calls[key] = n + 1
             if n < self.warmup:
                 return self.fn(*xs)
-            cap = self._capture(xs)
+            off0 = ops.DropoutState.offset
+            try:
+                cap = self._capture(xs)
+            except torch.cuda.OutOfMemoryError:
+                # no room for a private pool of this encoder's activations: this segment stays eager from here on
+                ops.GradSink.recorder = None
+                ops.DropoutState.offset = off0
+                self.max_keys = len(self.captured)
+                torch.cuda.empty_cache()
+                return self.fn(*xs)
             self.captured[key] = cap
+            self.calls.pop(key, None)
         return _Replay.apply(cap, self.anchor, *xs)
 
     def _capture(self, xs):
         cap = _Captured()
-        cap.stream = torch.cuda.Stream(device=xs[0].device)
+        ctx = _capture_ctx(xs[0].device)
+        cap.stream = ctx["stream"]
+        if self.pool is None:
+            self.pool = torch.cuda.graph_pool_handle()
         cap.static_in = [x.detach().clone() for x in xs]
         cap.offset0 = ops.DropoutState.offset
         cap.g_fwd, cap.g_bwd = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
-        with torch.cuda.graph(cap.g_fwd, stream=cap.stream):
+        with torch.cuda.graph(cap.g_fwd, pool=self.pool, stream=cap.stream):
             out = self.fn(*cap.static_in)
         cap.draws = ops.DropoutState.offset - cap.offset0
         ops.DropoutState.offset = cap.offset0                  # the replay of this very call advances it again
@@ -96,7 +146,7 @@ class GraphedSegment:
         rec = []
         ops.GradSink.recorder = rec
         try:
-            with torch.cuda.graph(cap.g_bwd, pool=cap.g_fwd.pool(), stream=cap.stream):
+            with torch.cuda.graph(cap.g_bwd, pool=self.pool, stream=cap.stream):
                 torch.autograd.backward((out,), (cap.static_gout,))
         finally:
             ops.GradSink.recorder = None
@@ -107,3 +157,4 @@ class GraphedSegment:
     def release(self):
         self.captured.clear()
         self.calls.clear()
+        self.pool = None

@@ -50,6 +50,15 @@ def workspace(device, nbytes=_WS_BYTES):
     return ws
 
 
+def release_stream(stream):
+    """forget the scratch that was allocated for `stream` (a graph-capture stream that is going away): its split-K workspace and its
+    grouped-reduction queue"""
+    sid = stream.cuda_stream
+    for d in (_WS, ReduceQueue._queues):
+        for key in [k for k in d if k[1] == sid]:
+            del d[key]
+
+
 # ---------------------------------------------------------------------------------------------- grouped split-K reductions
 class ReduceQueue:
     """Split-K products whose reduction is deferred (valor_gemm_deferred) wait here, each with its own piece of a per-stream group
@@ -70,6 +79,7 @@ class ReduceQueue:
         self.ws = torch.empty(self.BYTES, dtype=torch.uint8, device=device)
         self.blobs = (ctypes.c_char * (256 * self.GROUP))()
         self.n, self.off, self.done, self.dtype = 0, 0, [], None
+        self.targets = set()       # output / row-sum buffers of the pending products (see gemm(): no two of them may be the same)
 
     @classmethod
     def current(cls, device):
@@ -86,6 +96,7 @@ class ReduceQueue:
             lib.call("valor_gemm_reduce_group", self.stream.cuda_stream, self.dtype, ctypes.cast(self.blobs, ctypes.c_void_p), self.n)
         done, self.done = self.done, []
         self.n, self.off = 0, 0
+        self.targets.clear()
         for fn in done:
             fn()
 
@@ -110,6 +121,7 @@ class ReduceQueue:
         if stale:
             for q in cls._queues.values():
                 q.n, q.off, q.done = 0, 0, []
+                q.targets.clear()
             cls._armed = False
         return stale
 
@@ -158,7 +170,11 @@ def gemm(a, b, *, trans_a=False, trans_b=False, bias=None, act=ACT_NONE, want_pr
         import ctypes
         q = ReduceQueue.current(a.device)
         dt = dt_of(a)
-        if q.n == q.GROUP or q.off + q.PIECE > q.BYTES or (q.n and q.dtype != dt):
+        # one grouped reduction adds all its products to their outputs from different workgroups of ONE launch: two pending products
+        # with the same C (or the same row-sum buffer) would race on a non-atomic read-modify-write (a weight used by two Linears of a
+        # shallow stack: the shared-BERT text encoder / decoder, the tied word embedding). Such a product closes the group first.
+        tg = {t.data_ptr() for t in (out, rowsum_out) if t is not None}
+        if q.n == q.GROUP or q.off + q.PIECE > q.BYTES or (q.n and q.dtype != dt) or (q.targets & tg):
             q.flush()
         blob = ctypes.addressof(q.blobs) + 256 * q.n
         lib.call("valor_gemm_deferred", _stream(), dt, int(trans_a), int(trans_b), M, N, K,
@@ -171,6 +187,7 @@ def gemm(a, b, *, trans_a=False, trans_b=False, bias=None, act=ACT_NONE, want_pr
             q.n += 1
             q.off += used.value
             q.done.append(defer_done)
+            q.targets |= tg
             ReduceQueue._arm()
         else:
             defer_done()

@@ -602,6 +602,9 @@ class VALOR(nn.Module):
             for seg in self._graph_segs.values():
                 seg.release()
             self._graph_segs = {}
+            from .. import graphs
+            graphs.release_all()
+            ops.DropoutState.disable_device_base()        # back to host mode: by-value windows only, nothing left set for a later model / device
 
     def _video_encoder_clip(self, imgs):
         """imgs: [b * F, 3, H, W] fp32 on the device -> [b * F, tokens, width]"""
@@ -1083,6 +1086,12 @@ class VALOR(nn.Module):
             streams.set_main(self.device)
             if torch.is_grad_enabled():
                 ops.K.ReduceQueue.discard_stale()    # leftovers of a backward pass that died half way (kernels.ReduceQueue)
+            if self._use_graphs():
+                # the graphed segments key their captures on the by-value dropout offset at their entry, which only repeats if the step's
+                # driver restarts it (TrainEngine.train_step does): a custom loop that never calls begin_step() gets it from here
+                if not ops.DropoutState.begun:
+                    ops.DropoutState.begin_step()
+                ops.DropoutState.begun = False
         out = {}
         col = self.collect
         txt_tokens = batch.get("txt_tokens")

@@ -32,6 +32,7 @@ class DropoutState:
     seed = 1234
     offset = 0
     base = None                    # int64 [1] device tensor (device mode) or None
+    begun = False                  # begin_step() ran and no forward pass has consumed it yet (VALOR._forward_groups checks)
     STEP_STRIDE = 1 << 40
 
     @classmethod
@@ -61,6 +62,7 @@ class DropoutState:
         if cls.base is not None:
             cls.offset = 0
             cls.base.add_(cls.STEP_STRIDE)
+            cls.begun = True
 
     @classmethod
     def draw(cls, n_elements):
