@@ -192,6 +192,66 @@ def sim_world(model, spec, world, per_gpu_batch, frames, audio_slices, steps=5):
                                    "(every rank runs this on the global batch)"}
 
 
+def comm_probe(dev, world, backend, bucket_bytes=48 << 20, gather_bytes=3_400_000, reps=10):
+    """First-contact numbers of a multi-GPU node, taken before the timed region: one gradient bucket (48 MiB, the reducer's size) under
+    a plain all-reduce and under reduce-scatter + all-gather (the two modes of valor_amd/dist.Reducer), and the step's packed feature
+    all-gather (3.4 MB). Per call: microseconds (max over ranks) and bus bandwidth = 2 (N-1)/N (all-reduce) or (N-1)/N (all-gather) x
+    bytes / time. Returns the dict that goes into the bench line as `comm_probe`."""
+    import torch.distributed as dist
+    n = bucket_bytes // 2
+    n -= n % (world * 1024)
+    x = torch.zeros(n, dtype=torch.bfloat16, device=dev)
+    shard = x.view(world, -1)[dist.get_rank()]
+    g_in = torch.zeros(max(gather_bytes // 2 // world, 1), dtype=torch.bfloat16, device=dev)
+    g_out = torch.zeros(g_in.numel() * world, dtype=torch.bfloat16, device=dev)
+
+    def allreduce():
+        dist.all_reduce(x)
+
+    def rs_ag():
+        dist.reduce_scatter_tensor(shard, x)
+        dist.all_gather_into_tensor(x, shard)
+
+    def gather():
+        if backend == "nccl":
+            dist.all_gather_into_tensor(g_out, g_in)
+        else:
+            dist.all_gather(list(g_out.chunk(world)), g_in)
+
+    def time_it(fn):
+        for _ in range(2):
+            fn()
+        torch.cuda.synchronize()
+        dist.barrier()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            fn()
+        torch.cuda.synchronize()
+        t = torch.tensor([(time.perf_counter() - t0) / reps], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+    out = {"bucket_mib": round(n * 2 / 2 ** 20, 1), "reps": reps}
+    cases = [("allreduce", allreduce, 2.0 * (world - 1) / world * n * 2)]
+    if backend == "nccl":                      # gloo has no reduce_scatter
+        cases.append(("rs_ag", rs_ag, 2.0 * (world - 1) / world * n * 2))
+    cases.append(("packed_allgather", gather, (world - 1) / world * g_out.numel() * 2))
+    for name, fn, bus_bytes in cases:
+        try:
+            t = time_it(fn)
+            out[name] = {"us": round(t * 1e6, 1), "bus_GBps": round(bus_bytes / t / 1e9, 1)}
+        except Exception as e:                 # a probe must never end the bench
+            out[name] = {"error": repr(e)}
+    # what RCCL said about the communicator (NCCL_DEBUG=INFO into a per-rank file, set by main() before the process group exists)
+    path = os.environ.get("NCCL_DEBUG_FILE", "").replace("%h", "").replace("%p", str(os.getpid()))
+    try:
+        keys = ("nChannels", "Connected all", "Trees", "Using network", "comm ", "NCCL_ALGO", "P2P")
+        lines = [l.strip()[-160:] for l in open(path) if any(k in l for k in keys)]
+        out["rccl_log"] = lines[:6] + (["..."] if len(lines) > 12 else []) + lines[-6:] if len(lines) > 12 else lines
+    except Exception:
+        out["rccl_log"] = None
+    return out
+
+
 class GemmTimer:
     """HIP-event timing of valor_gemm launches on their own stream, grouped by (kernel family, layout).
     Every launch bracketed by an event pair would serialise the whole pipeline (an event is a barrier packet; ~1.9k
@@ -339,6 +399,11 @@ def main():
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         backend = os.environ.get("VALOR_DIST_BACKEND", "nccl")      # "gloo" only to exercise the DP path where RCCL cannot run
+        if backend == "nccl" and "NCCL_DEBUG" not in os.environ:
+            # the communicator's own account of itself (channels, rings / trees, transports) for `comm_probe`: INIT lines only, to a file
+            os.environ["NCCL_DEBUG"] = "INFO"
+            os.environ["NCCL_DEBUG_SUBSYS"] = "INIT"
+            os.environ["NCCL_DEBUG_FILE"] = f"/tmp/valor_rccl_{os.getpid()}.log"
         if backend == "nccl":
             if torch.cuda.device_count() < world:
                 sys.exit(f"bench.py: {world} RCCL ranks need {world} GPUs, this node shows {torch.cuda.device_count()} (one process per GPU)")
@@ -373,6 +438,18 @@ def main():
 
     timer = GemmTimer()
     timer.install()
+    probe = None
+    if world > 1:
+        # first contact with a multi-GPU node: time one bucket under both reduce modes and the packed gather; unless VALOR_REDUCE pins the
+        # mode, the timed region runs the faster one (every rank sees the same max-over-ranks times, so every rank decides alike)
+        try:
+            probe = comm_probe(dev, world, backend)
+            ar, rs = probe.get("allreduce", {}).get("us"), probe.get("rs_ag", {}).get("us")
+            if "VALOR_REDUCE" not in os.environ and engine.reducer.native is None and ar and rs and rs < 0.95 * ar:
+                engine.reducer.mode = "rs_ag"
+            probe["reduce_mode_chosen"] = engine.reducer.mode
+        except Exception as e:
+            probe = {"error": repr(e)}
 
     def sync():
         if world > 1:
@@ -418,6 +495,10 @@ def main():
     timing = {"launch_ms": [round(r["host_ms"] - r["wait_ms"], 1) for r in trace], "wait_ms": [round(r["wait_ms"], 1) for r in trace],
               "gpu_span_ms": [round(r["head"].elapsed_time(r["tail"]), 1) for r in trace],
               "gpu_idle_ms": [round(a["tail"].elapsed_time(b["head"]), 2) for a, b in zip(trace[:-1], trace[1:])]}
+    if world > 1 and trace and trace[0].get("reduce"):
+        ex = [r["reduce"][0].elapsed_time(r["reduce"][1]) for r in trace]
+        timing["reduce_exposed_ms"] = [round(x, 2) for x in ex]
+        timing["reduce_exposed_ms_per_step"] = round(sum(ex) / len(ex), 2)
     if timing["gpu_idle_ms"]:
         timing["gpu_idle_ms_per_step"] = round(sum(timing["gpu_idle_ms"]) / len(timing["gpu_idle_ms"]), 2)
         timing["launch_ms_per_step"] = round(sum(timing["launch_ms"]) / len(timing["launch_ms"]), 1)
@@ -511,6 +592,8 @@ def main():
                "timed_region": {"device_allocations": int(seg1 - seg0), "new_segments_mb": new_segs_mb, "host_ms_per_step": [round(x, 1) for x in step_ms], **timing,
                                 **({"allocations_after_step": seg_trace} if seg_trace is not None else {})},
                "roofline": roof}
+        if probe is not None:
+            res["comm_probe"] = probe
         if world == 1 and args.sim_world > 1:
             try:
                 res["dp_sim"] = sim_world(model, spec, args.sim_world, args.batch, args.frames, args.audio_slices)

@@ -275,3 +275,24 @@ def test_bf16_cross_rank_sum_error():
     nrm = lambda a: abs(float(a.double().norm() / exact.norm()) - 1.0)
     assert rel(once) < 2.5e-3 and rel(acc) < 6e-3 and rel(acc) > rel(once)
     assert nrm(acc) < 1e-4 and nrm(once) < 1e-4
+
+
+def _unequal_gather_case(rank, world):
+    from valor_amd.dist import all_gather_list, ddp_allgather
+    g = torch.Generator().manual_seed(300 + rank)
+    n = 3 + 2 * rank                                      # 3, 5, 7 ... rows: the last validation batches differ between ranks
+    x = torch.randn(n, 4, 6, generator=g)
+    tok = torch.randint(0, 30522, (n, 9), generator=g)
+    return dict(x=x, tok=tok, X=ddp_allgather(x), T=ddp_allgather(tok), objs=all_gather_list({"rank": rank, "ids": [f"v{rank}_{i}" for i in range(n)]}))
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_ddp_allgather_with_unequal_sizes(world):
+    """utils/distributed.py:77-93 (ddp_allgather: sizes, pad to the largest, gather, cut) and :133-170 (all_gather_list), as
+    test.py:275-290 uses them on the validation features: every rank receives the ranks' rows in rank order, padding removed"""
+    res = _run(_unequal_gather_case, world)
+    want_x, want_t = torch.cat([r["x"] for r in res]), torch.cat([r["tok"] for r in res])
+    for r in res:
+        assert torch.equal(r["X"], want_x) and torch.equal(r["T"], want_t)
+        assert [o["rank"] for o in r["objs"]] == list(range(world))
+        assert [i for o in r["objs"] for i in o["ids"]] == [f"v{k}_{i}" for k in range(world) for i in range(3 + 2 * k)]

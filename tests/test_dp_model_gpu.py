@@ -312,3 +312,62 @@ def test_bench_with_eight_ranks_on_one_gpu():
     assert res["config"]["global_batch"] == 16 and res["config"]["parallelism"] == "dp8"
     assert all(v == v and abs(v) < 1e4 for v in res["losses"].values())
     assert res["replicas_identical"] is True
+
+
+def _eval_shards():
+    """three validation batches, the last one smaller: rank 0 scores batches 0 and 2 (4 + 2 samples), rank 1 batch 1 (4 samples)"""
+    sys.path.insert(0, ROOT)
+    from valor_amd import synth
+    spec = synth.tiny_spec()
+    sd = synth.make_state_dict(spec, seed=3, w_std=0.05)
+    bs = []
+    for i, n in enumerate((4, 4, 2)):
+        b = synth.make_batch(spec, batch=n, frames=2, audio_slices=1, txt_len=32, seed=10 + i)
+        b["ids"] = [f"v{10 * i + j}" for j in range(n)]
+        b["ids_txt"] = list(b["ids"])
+        bs.append(b)
+    return spec, sd, [[bs[0], bs[2]], [bs[1]]]
+
+
+def _eval_worker(rank, world, port, outdir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        spec, sd, shards = _eval_shards()
+        from valor_amd.evaluate import validate_pt
+        from valor_amd.model.valor import VALOR
+        torch.cuda.set_device(0)
+        model = VALOR({"dropout": 0.0}, spec=spec, dtype=torch.float32, device="cuda:0")
+        model.load_state_dict(sd, strict=True)
+        random.seed(50 + rank)
+        log = validate_pt(model, shards[rank], TASK)
+        torch.save(log, os.path.join(outdir, f"eval{rank}.pt"))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_validate_pt_gathers_the_ranks_shards(tmp_path):
+    """validate_pt under two ranks with UNEQUAL shards (6 and 4 samples) returns on every rank what one process returns for the ten
+    samples: ids and hit counters through all_gather_list, features / tokens through ddp_allgather (test.py:275-290, 496-518;
+    utils/distributed.py:77-93). The single process walks the shards in rank order with the ranks' masker seeds."""
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    mp.spawn(_eval_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    logs = [torch.load(tmp_path / f"eval{r}.pt", weights_only=False) for r in range(2)]
+    spec, sd, shards = _eval_shards()
+    from valor_amd.evaluate import validate_pt
+    from valor_amd.model.valor import VALOR
+    model = VALOR({"dropout": 0.0}, spec=spec, dtype=torch.float32, device="cuda:0")
+    model.load_state_dict(sd, strict=True)
+
+    def walk():
+        for r, shard in enumerate(shards):
+            random.seed(50 + r)
+            yield from shard
+    one = validate_pt(model, walk(), TASK)
+    assert {"caption_acc_tva", "mlm_acc_tva", "t2v_recall", "t2va_recall", "t2a_recall"} <= set(one)
+    assert logs[0] == one and logs[1] == one, (logs, one)

@@ -706,3 +706,68 @@ def test_late_fusion_with_the_fine_matrix_matches_oracle(dev):
         if err > 2e-3:
             bad.append((k, err))
     assert not bad, bad[:8]
+
+
+@pytest.mark.parametrize("fv,fm", [(True, False), (False, True), (True, True)])
+def test_frozen_vision_and_frozen_multimodal(dev, fv, fm):
+    """config options frozen_vision / frozen_multimodal (model/modeling.py:319-322, 675-680): losses and the gradients of every parameter
+    that stays trainable equal the oracle's with the same tensors frozen; frozen parameters get no gradient, are not reported to the
+    reducer, and are left untouched (no update, no weight decay: optim/adamw.py:62-63) by an optimizer step."""
+    from types import SimpleNamespace
+    from valor_amd import synth
+    from valor_amd.engine import TrainEngine
+    from valor_amd.model.valor import VALOR
+    import valor_oracle as VO
+    spec = synth.tiny_spec()
+    sd = synth.make_state_dict(spec, seed=3, w_std=0.05)
+    batch = synth.make_batch(spec, batch=4, frames=2, audio_slices=2, txt_len=32, seed=4)
+    orc, sd_o = _oracle(spec, sd)
+
+    def ref_rule(k):                     # the reference's rules, transcribed on its own parameter names
+        if fv and k.startswith("clip_model.") and "visual" in k[len("clip_model."):]:
+            return True
+        if fm and k.startswith("cls."):
+            return True
+        if fm and k.startswith("multimodal_encoder."):
+            r = k[len("multimodal_encoder."):]
+            return ("encoder" in r and "cross" not in r) or ("embeddings" in r and any(j in r for j in (
+                "embeddings.word_embeddings", "embeddings.position_embeddings", "embeddings.token_type_embeddings", "embeddings.LayerNorm")))
+        return False
+    frozen = {k for k, p in sd_o.items() if p.is_floating_point() and ref_rule(k)}
+    for k in frozen:
+        sd_o[k].requires_grad_(False)
+    model = VALOR({"dropout": 0.0, "frozen_vision": fv, "frozen_multimodal": fm}, spec=spec, dtype=torch.float32, device=dev)
+    model.load_state_dict(sd, strict=True)
+    model.train()
+    opts = SimpleNamespace(learning_rate=1e-4, weight_decay=0.01, clip_lr=5e-7, clip_lr_text=5e-7, new_lr=0.0, decoder_lr=-1,
+                           betas=[0.9, 0.98], warmup_ratio=0.1, num_train_steps=10, scheduler="warmup_linear", grad_norm=5.0)
+    eng = TrainEngine(model, opts, graphs=False)
+    random.seed(11)
+    o_out = orc.forward_pt(batch, TASK, compute_loss=True)
+    sum(o_out.values()).backward()
+    random.seed(11)
+    eng.reducer.prepare_backward()
+    n_out = model(batch, task=TASK, compute_loss=True)
+    sum(n_out.values()).backward()
+    for k in ("contra_loss", "caption_loss", "mlm_loss"):
+        a, b = float(o_out[k]), float(n_out[k])
+        assert abs(a - b) <= 1e-4 * abs(a), (k, a, b)
+    ng = _native_grads(model)
+    for k, p in sd_o.items():
+        if VO.is_alias_key(k) or not p.is_floating_point():
+            continue
+        gn = ng[k].detach().cpu()
+        if p.grad is None:
+            assert float(gn.abs().max()) == 0.0, k
+            continue
+        scale = max(float(p.grad.norm()), 1e-5 * p.grad.numel() ** 0.5)
+        assert float((gn.reshape(p.grad.shape) - p.grad).norm()) / scale < 2e-3, k
+    assert model.frozen_names and all(not model.P[n].requires_grad for n in model.frozen_names)
+    before = {n: model.P[n].detach().clone() for n in model.frozen_names}
+    model.arena.grad.zero_()
+    random.seed(12)
+    eng.train_step(batch, TASK)
+    torch.cuda.synchronize()
+    for n, w in before.items():
+        assert torch.equal(model.P[n].detach(), w), n              # no update, no weight decay
+    eng.close()

@@ -609,3 +609,32 @@ def test_late_fusion_with_the_fine_matrix_matches_reference():
         assert float((g - p.grad).norm()) / scale < 2e-4, name
         n += 1
     assert n > 100
+
+
+@pytest.mark.parametrize("variant", ["clip", "swin"])
+def test_frozen_options_freeze_the_reference_s_parameters(variant):
+    """frozen_vision / frozen_multimodal (model/modeling.py:319-322, 675-680): the native model must clear requires_grad on exactly the
+    parameters the UNMODIFIED reference constructor clears (packed q|k|v / k|v slots: all of their reference tensors agree)."""
+    from valor_amd import synth
+    from valor_amd.model.valor import VALOR
+    if variant == "swin":
+        spec = synth.swin_spec()
+        kw = dict(video_encoder_type="videoswin_base_k400_22k", txt_encoder_type="bert_base_uncased")
+    else:
+        spec, kw = synth.base_spec(), {}
+    ref = ref_harness.build_reference(ref_harness.default_opts(frozen_vision=True, frozen_multimodal=True, **kw), state_dict=None, dropout=0.0)
+    ref_frozen = {n for n, p in ref.named_parameters() if not p.requires_grad}
+    assert ref_frozen                                         # (VideoSwin: frozen_vision has no branch in the reference; the decoder rules apply)
+    model = VALOR({"frozen_vision": True, "frozen_multimodal": True, "dropout": 0.0}, spec=spec, dtype=torch.float32, device="cpu")
+    ours = set()
+    for name, _shape, refs in model.table:
+        flags = {r in ref_frozen or (r == "cls.decoder.weight" and "multimodal_encoder.embeddings.word_embeddings.weight" in ref_frozen) for r in refs}
+        assert len(flags) == 1, (name, refs)                  # a packed slot is frozen as a whole or not at all
+        if not model.P[name].requires_grad:
+            ours.update(refs)
+    known = {r for _n, _s, refs in model.table for r in refs}
+    tied = {"cls.decoder.weight"} & known                     # the reference lists the tied matrix once (under the embedding's name)
+    assert ours - tied == ref_frozen & known, (sorted((ours - tied) ^ (ref_frozen & known))[:10])
+    # nothing frozen by default
+    plain = VALOR({"dropout": 0.0}, spec=spec, dtype=torch.float32, device="cpu")
+    assert all(p.requires_grad for p in plain.P.values())

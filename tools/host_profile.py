@@ -22,7 +22,7 @@ model.load_state_dict(synth.make_state_dict(spec, seed=50), strict=True)
 opts = SimpleNamespace(learning_rate=1e-4, weight_decay=0.01, clip_lr=5e-7, clip_lr_text=5e-7, new_lr=0.0, decoder_lr=-1,
                        betas=[0.9, 0.98], warmup_ratio=0.1, num_train_steps=100000, scheduler="warmup_linear", grad_norm=5.0)
 import os  # noqa: E402
-eng = TrainEngine(model, opts, graphs=os.environ.get("VALOR_GRAPHS", "0") == "1")       # VALOR_GRAPHS=1: the encoders replay hipGraphs
+eng = TrainEngine(model, opts, graphs=os.environ.get("VALOR_GRAPHS", "1") == "1")       # VALOR_GRAPHS=1: the encoders replay hipGraphs
 batch = synth.make_batch(spec, batch=64, frames=8, audio_slices=2, txt_len=32, seed=50)
 batch["video_pixels"] = batch["video_pixels"].to(dev)
 batch["audio_spectrograms"] = batch["audio_spectrograms"].to(dev)

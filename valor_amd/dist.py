@@ -77,6 +77,35 @@ def packed_allgather_with_grads(feat_t, feat_v, feat_a, tokens):
     return ft, fv, fa, tokens_all
 
 
+def ddp_allgather(x):
+    """utils/distributed.py:77-93 (no gradient, UNEQUAL leading sizes: the last validation batches differ between ranks; test.py:275-290
+    gathers features and tokens with it): sizes first, every rank padded to the largest, one gather, the padding cut away again. ONE size
+    exchange + ONE payload collective; the result keeps the ranks' order. A single rank returns its input."""
+    if not is_dist():
+        return x
+    world = dist.get_world_size()
+    x = x.contiguous()
+    size = torch.tensor([x.shape[0]], dtype=torch.int64, device=x.device)
+    sizes = [torch.zeros_like(size) for _ in range(world)]
+    dist.all_gather(sizes, size)
+    sizes = [int(s.item()) for s in sizes]
+    top = max(sizes)
+    if x.shape[0] < top:
+        x = torch.cat((x, x.new_zeros((top - x.shape[0],) + tuple(x.shape[1:]))), dim=0)
+    parts = [torch.empty_like(x) for _ in range(world)]
+    dist.all_gather(parts, x)
+    return torch.cat([p[:n] for p, n in zip(parts, sizes)], dim=0)
+
+
+def all_gather_list(obj):
+    """utils/distributed.py:133-170 (pickled python objects of every rank, in rank order): ids, hit counters"""
+    if not is_dist():
+        return [obj]
+    out = [None] * dist.get_world_size()
+    dist.all_gather_object(out, obj)
+    return out
+
+
 class Reducer:
     """mode (env VALOR_REDUCE or the argument):
          "allreduce"  one SUM all-reduce per bucket in the arena's dtype (default; RCCL picks ring / direct per message size);
@@ -137,7 +166,8 @@ class Reducer:
             warnings.warn(f"native reducer requested (native=True / VALOR_REDUCER_NATIVE=1) but not used: {why}; "
                           "the torch.distributed path runs instead")
         for name, p in arena.params.items():
-            p.register_post_accumulate_grad_hook(self._make_hook(name))
+            if p.requires_grad:                    # frozen parameters (VALOR.frozen_vision / frozen_multimodal) never get a gradient
+                p.register_post_accumulate_grad_hook(self._make_hook(name))
         from . import ops
         ops.GradSink.listener = self._on_grad      # kernels that accumulate straight into the arena report here
 

@@ -3,6 +3,7 @@ forward -> sum of losses -> backward (+ overlapped gradient all-reduce) -> warmu
 clip -> fused AdamW. Losses stay on the device (the reference's per-step `.item()` syncs, :309, are gone;
 read them when you log)."""
 import gc
+import sys
 
 import torch
 
@@ -115,7 +116,14 @@ class TrainEngine:
         self._micro = micro
         if last and self.world > 1 and self._check_window:
             self._assert_same_window()
+        if tracing and self.world > 1:
+            # what of the gradient exchange is NOT hidden behind backward: the stream reaches r0 when its last backward kernel is done and
+            # r1 when the last bucket has arrived
+            r0, r1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            r0.record()
         active = self.reducer.finish_backward(last=last)
+        if tracing and self.world > 1:
+            r1.record()
         if not last:
             loss_dict["total_loss"] = loss.detach()
             return loss_dict
@@ -131,7 +139,8 @@ class TrainEngine:
             ev.record()
             self._step_events.append(ev)
             if tracing:
-                self.trace.append({"wait_ms": wait_s * 1e3, "host_ms": (_time.perf_counter() - t_in) * 1e3, "head": head, "tail": ev})
+                self.trace.append({"wait_ms": wait_s * 1e3, "host_ms": (_time.perf_counter() - t_in) * 1e3, "head": head, "tail": ev,
+                                   "reduce": (r0, r1) if self.world > 1 else None})
         if not self._headroom_done and self.global_step >= 2:
             self.reserve_headroom()
         if self.manage_gc:
@@ -190,7 +199,6 @@ class TrainEngine:
     def __del__(self):
         # not at interpreter shutdown: the process group / HIP runtime may be gone by then and a native crash in the communicator's
         # destructor cannot be caught -- call close() (before dist.destroy_process_group) in a driver that wants the resources back
-        import sys
         if sys is None or sys.is_finalizing():
             return
         try:

@@ -64,9 +64,14 @@ def compute_metric_ret(score_matrix, ids, ids_txt):
 
 @torch.no_grad()
 def validate_pt(model, loader, task):
-    """test.py::validate_pt (:404-665), one process: `loader` yields batches of valor_collate (+ 'ids_txt'); returns the val_log dict
+    """test.py::validate_pt (:404-665): `loader` yields THIS RANK's batches of valor_collate (+ 'ids_txt'); returns the val_log dict
     (caption_acc_* / mlm_acc_* rounded to 2 digits, t2v / t2va / t2a forward recall strings).
+    Under data parallelism (torch.distributed initialised, world > 1) every rank scores its shard and the reference's collectives run:
+    ids / ids_txt and the hit / word counters through all_gather_list (test.py:275-276, 496-518), features and tokens through
+    ddp_allgather (:279-290; per-rank sizes may differ). The recall is computed on the gathered set; the reference does that on rank 0
+    only and leaves the other ranks' val_log without it -- here every rank returns the full log.
     Kept quirk: the mlm hit counters are selected by the CAPTION group list (test.py:484-492)."""
+    from . import dist as vdist
     model.eval()
     mlm_task, caption_task, contra_task = [], [], []
     for i in task.split("_"):
@@ -96,6 +101,17 @@ def validate_pt(model, loader, task):
             for g in ("tva", "tv", "ta"):
                 if g in caption_task and f"{tag}_scores_{g}" in ev:
                     hits[f"{tag}_{g}"] = hits.get(f"{tag}_{g}", 0) + int((ev[f"{tag}_scores_{g}"].max(dim=-1)[1] == lab).sum().item())
+    if vdist.is_dist():
+        # test.py:496-518: sum(all_gather_list(counter)) per counter -- one object collective for all of them here
+        every = vdist.all_gather_list((n_word, hits))
+        n_word = {k: sum(nw[k] for nw, _ in every) for k in n_word}
+        hits = {k: sum(h.get(k, 0) for _, h in every) for k in sorted({k for _, h in every for k in h})}
+        if contra_task:
+            ids = [j for part in vdist.all_gather_list(ids) for j in part]               # test.py:275-276
+            ids_txt = [j for part in vdist.all_gather_list(ids_txt) for j in part]
+            for k in feats:                                                              # test.py:279-290
+                if feats[k] and feats[k][0] is not None:
+                    feats[k] = [vdist.ddp_allgather(torch.cat([t.to(model.device) for t in feats[k]], dim=0))]
     val_log = {}
     for tag, groups in (("caption", caption_task), ("mlm", mlm_task)):
         for g in ("tva", "tv", "ta"):

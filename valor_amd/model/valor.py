@@ -184,6 +184,33 @@ class VALOR(nn.Module):
         self.checkpointing = bool(_opt(opts, "checkpointing", False))
         self._graphs_on = False        # enable_graphs(): the encoders replay hipGraphs (valor_amd/graphs.py)
         self._graph_segs = {}
+        # frozen_vision / frozen_multimodal (modeling.py:319-322, 675-680): requires_grad = False on the reference's parameter-name rules.
+        # A frozen parameter's weight-gradient GEMMs are not issued (ops: needs_input_grad), it is never reported to the data-parallel
+        # reducer and never becomes active in the optimizer (optim/adamw.py:62-63 skips p.grad is None: no update, no weight decay);
+        # with frozen_vision nothing below the video encoder's output needs a gradient, so its whole backward pass disappears.
+        self.frozen_vision = bool(_opt(opts, "frozen_vision", False))
+        self.frozen_multimodal = bool(_opt(opts, "frozen_multimodal", False))
+        self.frozen_names = set()
+        for name, _shape, refs in self.table:
+            if all(self._ref_is_frozen(r) for r in refs):
+                self.P[name].requires_grad_(False)
+                self.frozen_names.add(name)
+
+    def _ref_is_frozen(self, ref):
+        """the reference's freezing rules on one of ITS parameter names"""
+        if self.frozen_vision and self.spec.video_encoder == "clip" and ref.startswith("clip_model."):       # modeling.py:319-322 (clip branch only)
+            return "visual" in ref[len("clip_model."):]
+        if self.frozen_multimodal:                                                                        # modeling.py:675-680
+            if ref.startswith("cls."):
+                return True
+            if ref.startswith("multimodal_encoder."):
+                k = ref[len("multimodal_encoder."):]
+                if "encoder" in k and "cross" not in k:
+                    return True
+                if "embeddings" in k and any(j in k for j in ("embeddings.word_embeddings", "embeddings.position_embeddings",
+                                                              "embeddings.token_type_embeddings", "embeddings.LayerNorm")):
+                    return True
+        return False
 
     # ------------------------------------------------------------------ checkpoint layout
     @classmethod
@@ -579,7 +606,7 @@ class VALOR(nn.Module):
         P, sp = self.P, self.spec
         b, n, c, h, w = video_pixels.shape
         imgs = self._dev(video_pixels.reshape(b * n, c, h, w).float())
-        if self._use_graphs():
+        if self._use_graphs() and not self.frozen_vision:      # (a frozen tower has no backward pass to capture)
             seg = self._graph_segs.get("vit")
             if seg is None:
                 from .. import graphs

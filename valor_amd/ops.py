@@ -295,7 +295,8 @@ class MlpFn(Function):
             K.colsum(dyy, out=sb, accumulate=True); _sunk(pb)
             return dw, None
 
-        dw2, db2 = wgrad_bgrad(dy2, h, pw2, pb2)
+        # (a frozen weight -- VALOR's frozen_multimodal / frozen_vision -- needs no gradient GEMM at all)
+        dw2, db2 = wgrad_bgrad(dy2, h, pw2, pb2) if (ctx.needs_input_grad[3] or ctx.needs_input_grad[4]) else (None, None)
         dx = None
         if ctx.needs_input_grad[0]:
             slot = ctx.slot
@@ -305,7 +306,7 @@ class MlpFn(Function):
                 dx = K.gemm(du, w1, trans_b=True).view(ctx.xshape)
                 if slot is not None:
                     slot.buf = dx
-        dw1, db1 = wgrad_bgrad(du, x2, pw1, pb1)
+        dw1, db1 = wgrad_bgrad(du, x2, pw1, pb1) if (ctx.needs_input_grad[1] or ctx.needs_input_grad[2]) else (None, None)
         return dx, dw1, db1, dw2, db2, None, None
 
 
@@ -696,12 +697,17 @@ class DecoderXentSegFn(Function):
         dh = K.gemm(dlog, w_emb, trans_b=True)
         pw, pb = ctx.params
         sw, sb = _sink(pw), _sink(pb)
-        if sw is not None:
-            K.gemm(dlog, h, trans_a=True, trans_b=True, out=sw, accumulate=True, defer_done=lambda: _sunk(pw)); dw = None
+        dw = db = None
+        if not ctx.needs_input_grad[1]:            # frozen prediction head (VALOR.frozen_multimodal): no [vocab x hidden] wgrad
+            pass
+        elif sw is not None:
+            K.gemm(dlog, h, trans_a=True, trans_b=True, out=sw, accumulate=True, defer_done=lambda: _sunk(pw))
         else:
             dw = K.gemm(dlog, h, trans_a=True, trans_b=True)
-        if sb is not None:
-            K.colsum(dlog, out=sb, accumulate=True); _sunk(pb); db = None
+        if not ctx.needs_input_grad[2]:
+            pass
+        elif sb is not None:
+            K.colsum(dlog, out=sb, accumulate=True); _sunk(pb)
         else:
             db = K.colsum(dlog)
         return dh, dw, db, None, None, None
@@ -748,12 +754,17 @@ class DecoderXentFn(Function):
         dh = K.gemm(dlog, w_emb, trans_b=True)
         pw, pb = ctx.params
         sw, sb = _sink(pw), _sink(pb)
-        if sw is not None:
-            K.gemm(dlog, h, trans_a=True, trans_b=True, out=sw, accumulate=True, defer_done=lambda: _sunk(pw)); dw = None
+        dw = db = None
+        if not ctx.needs_input_grad[1]:            # frozen prediction head (VALOR.frozen_multimodal): no [vocab x hidden] wgrad
+            pass
+        elif sw is not None:
+            K.gemm(dlog, h, trans_a=True, trans_b=True, out=sw, accumulate=True, defer_done=lambda: _sunk(pw))
         else:
             dw = K.gemm(dlog, h, trans_a=True, trans_b=True)
-        if sb is not None:
-            K.colsum(dlog, out=sb, accumulate=True); _sunk(pb); db = None
+        if not ctx.needs_input_grad[2]:
+            pass
+        elif sb is not None:
+            K.colsum(dlog, out=sb, accumulate=True); _sunk(pb)
         else:
             db = K.colsum(dlog)
         return dh, dw, db, None, None, None
