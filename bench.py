@@ -513,6 +513,10 @@ def main():
     # stream (the timed region above runs them on two, valor_amd/streams.py)
     two_streams = os.environ.get("VALOR_ENCODER_STREAMS")
     os.environ["VALOR_ENCODER_STREAMS"] = "0"
+    if n_inst and args.graphs:
+        # ... and only when Python issues it: the instrumented steps run eagerly (a GEMM inside a replayed graph never passes the timer,
+        # and an event pair recorded while a graph is being captured is not a timestamp)
+        model.enable_graphs(False)
     timer.enabled = False
     for _ in range(2 if n_inst else 0):          # settle: the audio / text activations move from the side stream's allocator pool to this stream's (device
         one_step()                          # allocations stall the host, a starved GPU makes event pairs measure launch latency)

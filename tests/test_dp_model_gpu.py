@@ -226,7 +226,7 @@ def test_graphed_encoders_in_data_parallel(dev, tmp_path):
     mp.spawn(_graph_worker, args=(W, port, str(tmp_path)), nprocs=W, join=True)
     res = [torch.load(os.path.join(str(tmp_path), f"graph_rank{r}.pt"), weights_only=False) for r in range(W)]
     for r in range(W):
-        assert res[r][True]["captured"] == ["ast", "clip_text", "vit"]
+        assert res[r][True]["captured"] == ["ast", "clip_text", "decoder", "vit"]
         assert res[r][True]["losses"] == res[r][False]["losses"], (r, res[r][True]["losses"], res[r][False]["losses"])
         assert torch.equal(res[r][True]["flat"], res[r][False]["flat"])
     assert torch.equal(res[0][True]["flat"], res[1][True]["flat"]), "replicas diverged"

@@ -1,7 +1,8 @@
-"""SURVEY 8 row f1 -- the enabling half of graph capture: (a) every dropout entry point reads a device-resident counter (`rng_base`,
-include/valor_hip.h) beside its by-value (seed, offset); (b) the CLIP ViT and AST encoders replay hipGraphs (valor_amd/graphs.py)
-with losses and parameters BIT-IDENTICAL to the eager run of the same seed, fresh dropout masks in every replay, and the gradient
-writes reported to the data-parallel reducer after every replay. The reference is eager PyTorch (model/pretrain.py:246-263,
+"""SURVEY 8 row f1 -- graph capture of the step's launch-bound parts: (a) every dropout entry point reads a device-resident counter
+(`rng_base`, include/valor_hip.h) beside its by-value (seed, offset); (b) the CLIP ViT / VideoSwin, AST and CLIP text encoders AND the
+decoder's layer stack with its cross-stream K|V projections (a parallel branch inside the graph; token rows and [video | audio] rows
+are differentiable graph inputs) replay hipGraphs (valor_amd/graphs.py) with losses and parameters BIT-IDENTICAL to the eager run of
+the same seed, fresh dropout masks in every replay, and the gradient writes reported to the data-parallel reducer after every replay. The reference is eager PyTorch (model/pretrain.py:246-263,
 train_utils.py:302-364); torch's global generator advancing once per dropout call (train_utils.py:309 loop) is what the per-step
 counter replaces."""
 import random
@@ -104,7 +105,11 @@ def test_graphed_encoders_are_bit_identical_to_the_eager_step(dev, device_rng):
         torch.cuda.synchronize()
         if graphs:
             segs = model._graph_segs
-            assert set(segs) == {"vit", "ast", "clip_text"} and all(len(s.captured) == 1 for s in segs.values())
+            assert set(segs) == {"vit", "ast", "clip_text", "decoder"} and all(len(s.captured) == 1 for s in segs.values())
+            dec = next(iter(segs["decoder"].captured.values()))
+            # the decoder stack's differentiable inputs (token rows, [video | audio] rows) get their gradients from the captured backward
+            assert [st.requires_grad for st in dec.static_in[:2]] == [True, True] and all(st.grad is not None for st in dec.static_in[:2])
+            assert dec.draws > 0
             assert all(c.sunk for s in segs.values() for c in s.captured.values())          # gradient writes recorded for the reducer
             assert next(iter(segs["ast"].captured.values())).draws > 0 and next(iter(segs["vit"].captured.values())).draws == 0
         runs[graphs] = (losses, model.arena.flat.clone())
@@ -135,7 +140,7 @@ def test_graphed_videoswin_encoder_with_stochastic_depth(dev, device_rng):
             losses.append({k: float(v) for k, v in out.items()})
         torch.cuda.synchronize()
         if graphs:
-            assert set(model._graph_segs) == {"swin_droppath", "ast"} and all(len(s.captured) == 1 for s in model._graph_segs.values())
+            assert set(model._graph_segs) == {"swin_droppath", "ast", "decoder"} and all(len(s.captured) == 1 for s in model._graph_segs.values())
         runs[graphs] = (losses, model.arena.flat.clone())
         model.enable_graphs(False)
         eng.close()

@@ -202,6 +202,16 @@ class Reducer:
 
     def _make_hook(self, name):
         def hook(param):
+            from . import ops
+            if ops.GradSink.recorder is not None:
+                # a backward is being captured into a graph (valor_amd/graphs.py). Autograd runs a leaf's post-accumulate hooks ONCE per
+                # backward pass the leaf takes part in -- also when every gradient of it was written straight into the arena -- so a
+                # parameter used inside the captured segment AND by eager code of the same step (the shared-BERT text pass beside the
+                # graphed decoder stack) is hooked once in eager mode but once per (captured backward, outer backward) otherwise. The
+                # replay therefore reports a hook-origin entry only for names the outer backward does not hook itself.
+                ops.GradSink.recorder.append(("hook", name))
+                return
+            ops.GradSink.live_hooks.add(name)
             self._on_grad(name)
         return hook
 
@@ -274,6 +284,8 @@ class Reducer:
             torch.cuda.current_stream().wait_stream(self.comm_stream)
 
     def prepare_backward(self, defer=False, closing=False):
+        from . import ops as _ops
+        _ops.GradSink.live_hooks.clear()
         """defer=True: a micro-step of a gradient accumulation window -- gradients keep accumulating in the arena and NO bucket
         is reduced now (reducing a partially accumulated arena twice would count the earlier micro-steps world times).
         closing=True: the LAST micro-step of a window (train_utils.py:311-329: the reference's DDP reduces in the backward that precedes

@@ -30,7 +30,7 @@ class _Replay(Function):
     def forward(ctx, seg, anchor, *xs):
         for x, st in zip(xs, seg.static_in):
             if x.data_ptr() != st.data_ptr():
-                st.copy_(x)
+                st.detach().copy_(x)
         seg.g_fwd.replay()
         ops.DropoutState.offset += seg.draws
         ctx.seg = seg
@@ -41,14 +41,36 @@ class _Replay(Function):
         seg = ctx.seg
         seg.static_gout.copy_(g)
         seg.g_bwd.replay()
-        if ops.GradSink.listener is not None:
+        listener = ops.GradSink.listener
+        if listener is not None:
+            hooks = []
             for name in seg.sunk:
-                ops.GradSink.listener(name)
-        return (None,) * (2 + len(seg.static_in))
+                if isinstance(name, tuple):                    # ("hook", name): a post-accumulate hook that ran inside the captured backward
+                    hooks.append(name[1])
+                else:
+                    listener(name)
+            if hooks and seg.outer_hooked is None:
+                # first backward with this capture: whether the OUTER backward hooks these parameters too (they are also used by eager
+                # code of the step) is only known at its end -- report what it did not hook then, and remember the answer
+                from torch.autograd.variable import Variable
+
+                def settle(seg=seg, hooks=hooks, listener=listener):
+                    seg.outer_hooked = {n for n in hooks if n in ops.GradSink.live_hooks}
+                    for n in hooks:
+                        if n not in seg.outer_hooked:
+                            listener(n)
+                Variable._execution_engine.queue_callback(settle)
+            else:
+                for n in hooks:
+                    if n not in seg.outer_hooked:
+                        listener(n)
+        # differentiable inputs (the decoder stack's token rows and its [video | audio] input): the captured backward left their gradients
+        # in static buffers; they are consumed by the nodes behind this one in stream order, before the next replay rewrites them
+        return (None, None) + tuple(st.grad if st.requires_grad else None for st in seg.static_in)
 
 
 class _Captured:
-    __slots__ = ("g_fwd", "g_bwd", "static_in", "static_out", "static_gout", "sunk", "draws", "offset0", "stream")
+    __slots__ = ("g_fwd", "g_bwd", "static_in", "static_out", "static_gout", "sunk", "draws", "offset0", "stream", "outer_hooked")
 
 
 # One capture stream per (device, REPLAY stream), shared by every capture that is replayed there. Kernel workspaces and the
@@ -80,10 +102,15 @@ def release_all():
 
 
 class GraphedSegment:
-    """fn: device tensor(s) -> device tensor (an encoder; inputs that do not need gradients: pixels, spectrograms, token ids, masks -- every
-    call copies them into the static buffers the graph was captured on). The replay node needs one differentiable input for autograd to call its
-    backward: a private one-element leaf -- NOT a parameter of the model (autograd runs a leaf's post-accumulate hooks even when the
-    node hands it no gradient, and the data-parallel reducer counts those calls per parameter).
+    """fn: device tensor(s) -> device tensor (an encoder: inputs that do not need gradients -- pixels, spectrograms, token ids, masks; the
+    decoder stack: its token rows and its [video | audio] input DO, and get their gradients back from static buffers the captured backward
+    fills). Every call copies the inputs into the static buffers the graph was captured on. The replay node needs one differentiable
+    input for autograd to call its backward even when no real input has one: a private one-element leaf -- NOT a parameter of the model
+    (autograd runs a leaf's post-accumulate hooks even when the node hands it no gradient, and the data-parallel reducer counts those
+    calls per parameter).
+    fn may fork work onto other streams (the decoder's K|V projections run on the encoders' side stream): a stream that waits for the
+    capturing stream joins the capture, its work becomes a parallel branch of the graph, and it must be joined back before fn returns
+    (every decoder layer waits for its own projection's event).
     One call in flight per segment: the output, the saved activations and the gradient buffer are static, so a second forward call before
     the first one's backward would overwrite what that backward reads (VALOR calls every encoder once per forward pass; accumulation
     micro-steps run forward + backward one after the other)."""
@@ -99,9 +126,9 @@ class GraphedSegment:
         self.calls = {}
         self.captured = {}
 
-    def __call__(self, *xs):
+    def __call__(self, *xs, key_extra=None):
         assert ops.DropoutState.base is not None, "graph capture needs ops.DropoutState's device mode (VALOR.enable_graphs)"
-        key = tuple((tuple(x.shape), x.dtype) for x in xs) + (ops.DropoutState.offset,)
+        key = tuple((tuple(x.shape), x.dtype, bool(x.requires_grad)) for x in xs) + (ops.DropoutState.offset, key_extra)
         if self.anchor is None:
             self.anchor = torch.zeros(1, device=xs[0].device, requires_grad=True)
         cap = self.captured.get(key)
@@ -134,7 +161,11 @@ class GraphedSegment:
         cap.stream = ctx["stream"]
         if self.pool is None:
             self.pool = torch.cuda.graph_pool_handle()
-        cap.static_in = [x.detach().clone() for x in xs]
+        from . import kernels as K
+        with torch.cuda.stream(cap.stream):        # the capture stream's kernel scratch exists BEFORE the capture: it must not come out of
+            K.workspace(xs[0].device)              # the graph's private pool (256 MiB + 1 GiB per segment)
+            K.ReduceQueue.current(xs[0].device)
+        cap.static_in = [x.detach().clone().requires_grad_(bool(x.requires_grad)) for x in xs]
         cap.offset0 = ops.DropoutState.offset
         cap.g_fwd, cap.g_bwd = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
         with torch.cuda.graph(cap.g_fwd, pool=self.pool, stream=cap.stream):
@@ -151,6 +182,7 @@ class GraphedSegment:
         finally:
             ops.GradSink.recorder = None
         cap.sunk = rec
+        cap.outer_hooked = None
         cap.static_out = out.detach()          # the same memory without the (consumed) capture-time autograd history
         return cap
 

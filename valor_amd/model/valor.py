@@ -92,6 +92,12 @@ def _opt(opts, name, default):
     return getattr(opts, name, default)
 
 
+class _DeferredKV:
+    """the decoder's [video | audio] input, its K|V projections not issued yet (VALOR._graph_decoder)"""
+    def __init__(self, va):
+        self.va = va
+
+
 class VALOR(nn.Module):
     def __init__(self, opts=None, spec: ValorSpec = None, dtype=torch.bfloat16, device="cuda", vocab_tokens=None):
         super().__init__()
@@ -802,9 +808,10 @@ class VALOR(nn.Module):
             self.release_static_kv()
         return super().train(mode)
 
-    def cross_inputs(self, video_output, audio_output):
+    def cross_inputs(self, video_output, audio_output, defer_kv=False):
         """get_multimodal_forward_input_video / _audio (modeling.py:485-502) + the K|V projections of every decoder layer.
-        Returns (kv_layers, {group: (first key row, rows)})."""
+        Returns (kv_layers, {group: (first key row, rows)}). defer_kv: the caller is the training path that may run the layer stack as a
+        graphed segment (_decoder_fused): the projections are then issued inside it."""
         P, sp = self.P, self.spec
         kv_layers, ranges = None, {}
         if video_output is not None or audio_output is not None:
@@ -830,8 +837,17 @@ class VALOR(nn.Module):
             else:
                 va = ops.single_input(audio_output, P["audio_frame_embedding"], P["audio_type_embeddings"])
                 ranges = {"ta": (0, Sa)}
-            kv_layers = self.project_cross_kv(va)
+            if defer_kv and self._graph_decoder():
+                kv_layers = _DeferredKV(va)          # projected inside the captured decoder stack (_decoder_stack)
+            else:
+                kv_layers = self.project_cross_kv(va)
         return kv_layers, ranges
+
+    def _graph_decoder(self):
+        """the decoder's layer stack + its K|V projections as one graphed segment (training passes, valor_amd/graphs.py): static shapes --
+        every token row goes through the layers whatever the masker drew; what depends on the draw (the gather of the masked rows, the
+        prediction head, the loss) stays eager behind it. Not with activation checkpointing, not in generation / evaluation."""
+        return self._use_graphs() and not self.checkpointing and os.environ.get("VALOR_GRAPH_DECODER", "1") != "0"
 
     def bert_encoder(self, x, mask, kv_layers, kv_range, kv_bmod):
         """BertEncoder / BertLayer.forward bert.py:440-518 (post-LN; va_concate cross-attention)."""
@@ -903,6 +919,44 @@ class VALOR(nn.Module):
             out[f"{tag}_scores_{g}"] = scores[gi * n:(gi + 1) * n]
         return None
 
+    def _decoder_layer(self, i, X, kv, ssegs, xsegs, dkv):
+        """one BertLayer (bert.py:440-496) on the row-batched stack of every decoder pass"""
+        P, H = self.P, self.spec.heads
+        p = self.p_drop if self.training else 0.0
+        q = f"multimodal_encoder.encoder.layer.{i}."
+        # post-LN: every sub-layer input feeds the sub-layer's first GEMM AND the residual add behind it; the two gradients meet in a
+        # GradSlot (the LayerNorm backward publishes its residual gradient, the GEMM's dgrad accumulates into it: no add kernels)
+        s1, s2, s3 = ops.GradSlot(), ops.GradSlot(), ops.GradSlot()
+        qkv = ops.linear(X, P[q + "attention.self.qkv.weight"], P[q + "attention.self.qkv.bias"], grad_slot=s1)
+        a = ops.seg_self_attention(qkv, H, ssegs, p)
+        o = ops.linear(a, P[q + "attention.output.dense.weight"], None)
+        X = ops.bias_dropout_residual_ln(o, P[q + "attention.output.dense.bias"], X, P[q + "attention.output.LayerNorm.weight"],
+                                         P[q + "attention.output.LayerNorm.bias"], 1e-12, p, False, res_slot=s1)
+        if kv is not None:
+            cq = ops.linear(X, P[q + "cross_attn.cross.query.weight"], P[q + "cross_attn.cross.query.bias"], grad_slot=s2)
+            c = ops.seg_cross_attention(cq, kv, H, xsegs, p, dkv_buf=dkv[i] if dkv else None)
+            o = ops.linear(c, P[q + "cross_attn.output.dense.weight"], None)
+            X = ops.bias_dropout_residual_ln(o, P[q + "cross_attn.output.dense.bias"], X, P[q + "cross_attn.output.LayerNorm.weight"],
+                                             P[q + "cross_attn.output.LayerNorm.bias"], 1e-12, p, False, res_slot=s2)
+        m = ops.mlp(X, P[q + "intermediate.dense.weight"], P[q + "intermediate.dense.bias"], P[q + "output.dense.weight"], None, ACT_GELU_ERF,
+                    grad_slot=s3)
+        return ops.bias_dropout_residual_ln(m, P[q + "output.dense.bias"], X, P[q + "output.LayerNorm.weight"], P[q + "output.LayerNorm.bias"], 1e-12, p,
+                                            False, res_slot=s3)
+
+    def _decoder_stack(self, X, va, *rest):
+        """what the graphed decoder segment runs (and captures): the K|V projections of every layer on the side stream -- a parallel branch
+        of the graph, layer i waits for its own projection -- and the layers on the row stack. rest = the passes' attention masks, then
+        their key ranges; the passes' geometry comes from self._dec_meta (part of the capture key)."""
+        smeta, xmeta = self._dec_meta
+        masks, kvrs = rest[:len(smeta)], rest[len(smeta):]
+        ssegs = [(r0, Bp, Tt, m) for (r0, Bp, Tt), m in zip(smeta, masks)]
+        xsegs = [(r0, Bp, Tt, k, b) for (r0, Bp, Tt, b), k in zip(xmeta, kvrs)]
+        kv_layers = self.project_cross_kv(va)
+        dkv = getattr(self, "_dkv_static", None)
+        for i in range(self.spec.layers):
+            X = self._decoder_layer(i, X, kv_layers[i], ssegs, xsegs, dkv)
+        return X
+
     def _decoder_fused(self, passes, kv_layers, ranges, b):
         """Training path: ALL decoder passes (caption groups, every mlm group) as one row-batched stack -- every GEMM /
         LayerNorm of a BertLayer (bert.py:440-496) runs once on the concatenated rows; self- and cross-attention run per
@@ -934,40 +988,29 @@ class VALOR(nn.Module):
             r0 += Bp * Ttot
         # the bigger pass first: in backward it writes the shared dK|dV buffer, the others accumulate into it
         X = torch.cat(xs, dim=0) if len(xs) > 1 else xs[0]
-        dkv = getattr(self, "_dkv_static", None)
-
-        def layer(i, X, kv):
-            q = f"multimodal_encoder.encoder.layer.{i}."
-            # post-LN: every sub-layer input feeds the sub-layer's first GEMM AND the residual add behind it; the two gradients meet in a
-            # GradSlot (the LayerNorm backward publishes its residual gradient, the GEMM's dgrad accumulates into it: no add kernels)
-            s1, s2, s3 = ops.GradSlot(), ops.GradSlot(), ops.GradSlot()
-            qkv = ops.linear(X, P[q + "attention.self.qkv.weight"], P[q + "attention.self.qkv.bias"], grad_slot=s1)
-            a = ops.seg_self_attention(qkv, H, ssegs, p)
-            o = ops.linear(a, P[q + "attention.output.dense.weight"], None)
-            X = ops.bias_dropout_residual_ln(o, P[q + "attention.output.dense.bias"], X, P[q + "attention.output.LayerNorm.weight"],
-                                             P[q + "attention.output.LayerNorm.bias"], 1e-12, p, False, res_slot=s1)
-            if kv is not None:
-                cq = ops.linear(X, P[q + "cross_attn.cross.query.weight"], P[q + "cross_attn.cross.query.bias"], grad_slot=s2)
-                c = ops.seg_cross_attention(cq, kv, H, xsegs, p, dkv_buf=dkv[i] if dkv else None)
-                o = ops.linear(c, P[q + "cross_attn.output.dense.weight"], None)
-                X = ops.bias_dropout_residual_ln(o, P[q + "cross_attn.output.dense.bias"], X, P[q + "cross_attn.output.LayerNorm.weight"],
-                                                 P[q + "cross_attn.output.LayerNorm.bias"], 1e-12, p, False, res_slot=s2)
-            m = ops.mlp(X, P[q + "intermediate.dense.weight"], P[q + "intermediate.dense.bias"], P[q + "output.dense.weight"], None, ACT_GELU_ERF,
-                        grad_slot=s3)
-            return ops.bias_dropout_residual_ln(m, P[q + "output.dense.bias"], X, P[q + "output.LayerNorm.weight"], P[q + "output.LayerNorm.bias"], 1e-12, p,
-                                                False, res_slot=s3)
-
-        # bert.py:510-513: with `checkpointing` every BertLayer keeps its input rows (and the layer's projected K|V, which lives in a
-        # static buffer anyway) and runs again in backward; the GradSlots above are per layer and are rebuilt by that second run
-        ckpt = self.checkpointing and self.training and torch.is_grad_enabled()
-        for i in range(self.spec.layers):
-            kv = kv_layers[i] if kv_layers is not None else None
-            if not ckpt:
-                X = layer(i, X, kv)
-            elif kv is None:
-                X = ops.checkpoint(lambda X_, i=i: layer(i, X_, None), X)
-            else:
-                X = ops.checkpoint(lambda X_, kv_, i=i: layer(i, X_, kv_), X, kv)
+        if isinstance(kv_layers, _DeferredKV):
+            # the K|V projections + the twelve layers as ONE graphed segment (valor_amd/graphs.py): inputs = the token rows and the
+            # [video | audio] rows (both differentiable), the passes' attention masks and key ranges; their geometry is the capture key
+            seg = self._graph_segs.get("decoder")
+            if seg is None:
+                from .. import graphs
+                seg = self._graph_segs["decoder"] = graphs.GraphedSegment("decoder", self._decoder_stack)
+            self._dec_meta = ([(r0_, Bp_, Tt_) for (r0_, Bp_, Tt_, _m) in ssegs], [(r0_, Bp_, Tt_, b_) for (r0_, Bp_, Tt_, _k, b_) in xsegs])
+            X = seg(X, kv_layers.va, *[m for (_a, _b, _c, m) in ssegs], *[k for (_a, _b, _c, k, _d) in xsegs],
+                    key_extra=(tuple(self._dec_meta[0]), tuple(self._dec_meta[1])))
+        else:
+            dkv = getattr(self, "_dkv_static", None)
+            # bert.py:510-513: with `checkpointing` every BertLayer keeps its input rows (and the layer's projected K|V, which lives in a
+            # static buffer anyway) and runs again in backward; the GradSlots of a layer are rebuilt by that second run
+            ckpt = self.checkpointing and self.training and torch.is_grad_enabled()
+            for i in range(self.spec.layers):
+                kv = kv_layers[i] if kv_layers is not None else None
+                if not ckpt:
+                    X = self._decoder_layer(i, X, kv, ssegs, xsegs, dkv)
+                elif kv is None:
+                    X = ops.checkpoint(lambda X_, i=i: self._decoder_layer(i, X_, None, ssegs, xsegs, dkv), X)
+                else:
+                    X = ops.checkpoint(lambda X_, kv_, i=i: self._decoder_layer(i, X_, kv_, ssegs, xsegs, dkv), X, kv)
         rows = ops.gather_rows(X, self._dev(torch.cat(idxs)))
         h = self.cls_transform(rows)
         losses = ops.decoder_xent_segments(h, P["multimodal_encoder.embeddings.word_embeddings.weight"], P["cls.decoder.bias"],
@@ -1298,7 +1341,7 @@ class VALOR(nn.Module):
             return out
         txt = txt_tokens["bert_tokens"].cpu()
         bs = txt.shape[0]
-        kv_layers, ranges = self.cross_inputs(video_output, audio_output)
+        kv_layers, ranges = self.cross_inputs(video_output, audio_output, defer_kv=compute_loss)
 
         if compute_loss:
             # training: every decoder pass row-batched into one stack (caption groups first: the biggest segment)

@@ -92,6 +92,7 @@ class GradSink:
     enabled = True
     listener = None
     recorder = None        # a list while a backward is being CAPTURED into a graph (valor_amd/graphs.py): names are recorded, not reported
+    live_hooks = set()     # names whose post-accumulate hook ran in the CURRENT (outer) backward pass (dist.Reducer; see graphs._Replay)
 
 
 class GradSlot:
