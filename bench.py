@@ -26,7 +26,7 @@ sys.path.insert(0, ROOT)
 
 TASK = "pt_contra%tva%tv%ta_caption%tva%tv%ta_mlm%tva"
 PEAK_BF16_TFLOPS = 2500.0     # dense bf16 MFMA peak, /opt/skills/guides/MI355X_MICROARCH.md
-PMC_FILE = next((f for f in ("r05_pmc_gemm_traffic.json", "r04_pmc_gemm_traffic.json", "r03_pmc_gemm_traffic.json", "r02_pmc_gemm_traffic.json", "r01_pmc_gemm_traffic.json")
+PMC_FILE = next((f for f in ("r06_pmc_gemm_traffic.json", "r05_pmc_gemm_traffic.json", "r04_pmc_gemm_traffic.json", "r03_pmc_gemm_traffic.json", "r02_pmc_gemm_traffic.json", "r01_pmc_gemm_traffic.json")
                  if os.path.exists(os.path.join(ROOT, "profiles", f))), "r01_pmc_gemm_traffic.json")
 
 
