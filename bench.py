@@ -353,7 +353,7 @@ def main():
     ap.add_argument("--sim-world", type=int, default=8, help="also time the contrastive block at the global batch of this many ranks "
                     "(single-GPU runs only; 0 = off)")
     ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=4, help="untimed steps (the first ones allocate: static K|V buffers, the caching allocator's pools)")
+    ap.add_argument("--warmup", type=int, default=5, help="untimed steps (the first ones allocate: static K|V buffers, the caching allocator's pools)")
     ap.add_argument("--batch", type=int, default=64, help="per-GPU batch (config: 512 global / 8 GPUs)")
     ap.add_argument("--frames", type=int, default=8)
     ap.add_argument("--audio-slices", type=int, default=2)

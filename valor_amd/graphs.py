@@ -156,6 +156,9 @@ class GraphedSegment:
         return _Replay.apply(cap, self.anchor, *xs)
 
     def _capture(self, xs):
+        import os
+        if os.environ.get("VALOR_GRAPH_DEBUG"):
+            print(f"[valor_amd.graphs] capturing {self.name}: call counts {dict((str(k)[-60:], v) for k, v in self.calls.items())}", flush=True)
         cap = _Captured()
         ctx = _capture_ctx(xs[0].device)
         cap.stream = ctx["stream"]
