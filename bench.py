@@ -467,11 +467,16 @@ def main():
     # [video | audio] input and its gradient, one MLP activation) are then alive in three steps at once and the caching allocator
     # grows by a segment each (round 3: 4 device allocations, 2 + 172 + 172 + 592 MiB, inside the timed region). Starting the last
     # warm-up steps from an idle GPU too puts that high-water mark into the warm-up.
+    # the per-step tracing of the timed region (timing-enabled events, their first synchronisation) is on during the warm-up too: whatever
+    # the runtime sets up on first use of those paths must not happen inside the first timed steps of a cold process
+    engine.trace = []
     for i in range(args.warmup):
         if args.warmup >= 4 and i == args.warmup - 3:
             sync()
         one_step()
     sync()
+    if engine.trace:
+        engine.trace[0]["head"].elapsed_time(engine.trace[-1]["tail"])
     seg0 = torch.cuda.memory_stats().get("segment.all.allocated", 0)       # device allocations (hipMalloc) so far
     segs_before = {sg["address"] for sg in torch.cuda.memory_snapshot()}
     seg_trace = [] if os.environ.get("BENCH_SEG_TRACE") else None      # diagnostic: cumulative device allocations after every timed step
