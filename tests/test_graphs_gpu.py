@@ -193,3 +193,38 @@ def test_reducer_sees_the_gradient_writes_of_a_replayed_backward(dev, device_rng
         del model, eng
         device_rng.disable_device_base()
     assert pictures[True] == pictures[False] and len(pictures[True]) > 50
+
+
+def test_evaluation_between_training_steps_invalidates_the_decoder_graph(dev, device_rng):
+    """model.eval() releases the static K|V buffers of the decoder's cross-attention (VALOR.train / release_static_kv) -- whose addresses a
+    captured decoder stack has baked in. The captured graphs must go with them: training steps, a validation forward, more training steps
+    equal the eager run of the same sequence to the bit (train_utils.py:366-372 validates in the middle of training)."""
+    from valor_amd import ops
+    runs = {}
+    for graphs in (False, True):
+        model, eng, batch = _engine(dev, graphs)
+        ops.DropoutState.reset(79)
+        random.seed(8)
+        losses = []
+        for step in range(4):
+            losses.append({k: float(v) for k, v in eng.train_step(batch, TASK).items()})
+        if graphs:
+            assert len(model._graph_segs["decoder"].captured) == 1
+        model.eval()
+        with torch.no_grad():
+            ev = model(batch, task=TASK, compute_loss=False)
+        scores = ev["caption_scores_tva"].float().cpu().clone()
+        if graphs:
+            assert len(model._graph_segs["decoder"].captured) == 0          # gone with the buffers
+        for step in range(4):                                               # two eager steps, the re-capture, a replay
+            losses.append({k: float(v) for k, v in eng.train_step(batch, TASK).items()})
+        torch.cuda.synchronize()
+        if graphs:
+            assert len(model._graph_segs["decoder"].captured) == 1
+        runs[graphs] = (losses, model.arena.flat.clone(), scores)
+        model.enable_graphs(False)
+        eng.close()
+        del model, eng
+        device_rng.disable_device_base()
+    assert runs[False][0] == runs[True][0]
+    assert torch.equal(runs[False][1], runs[True][1]) and torch.equal(runs[False][2], runs[True][2])

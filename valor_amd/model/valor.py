@@ -800,6 +800,11 @@ class VALOR(nn.Module):
         if g is not None:
             g.gen += 1            # any graph still holding them must not run backward
             g.release()
+        # ... and a CAPTURED decoder stack has their addresses baked in: its graphs go with the buffers (the next training steps run eagerly
+        # again and re-capture on new buffers)
+        seg = getattr(self, "_graph_segs", {}).get("decoder")
+        if seg is not None:
+            seg.release()
         self._kv_static = self._dkv_static_pool = self._dkv_static = self._kv_gen = None
         self._kv_static_key = None
 

@@ -50,8 +50,12 @@ class DropoutState:
         cls.offset = 0
         return cls.base
 
+    _retired = []                  # counters of earlier device-mode sessions: their ADDRESS may be baked into graphs that still exist
+
     @classmethod
     def disable_device_base(cls):
+        if cls.base is not None:
+            cls._retired.append(cls.base)        # 8 bytes; never freed, so a stale captured graph reads a valid (if meaningless) word
         cls.base = None
         K.RNG_BASE = 0
 
