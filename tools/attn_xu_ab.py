@@ -12,7 +12,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from valor_amd import kernels as K  # noqa: E402
 
 dev = torch.device("cuda:0")
-b, H, Skv, E = 64, 12, 1834, 768
+b, H, Skv, E = int(os.environ.get("XU_B", "64")), 12, 1834, 768
 Sv = 1576
 g = torch.Generator().manual_seed(0)
 kv = (torch.randn((b, Skv, 2 * E), generator=g) * 0.5).bfloat16().to(dev)
