@@ -69,6 +69,11 @@ __global__ __launch_bounds__(256, 2) void gemm_8ph2_kernel(GemmArgs p) {
     constexpr int BK = 64;
     static_assert(!M32 || (!TA && !TB), "the 32x32x16 main loop exists for k-contiguous operands");
     extern __shared__ __attribute__((aligned(16))) char smem[];
+#ifdef N8_AGPR
+    // experiment: an inline-asm AGPR operand makes hipcc select the AGPR form of every MFMA in this kernel (accumulators in the accumulator
+    // half of the register file: their C / D traffic then does not share ports with the LDS returns that land in the VGPR half)
+    { float z_; asm volatile("v_accvgpr_write_b32 %0, 0" : "=a"(z_)); asm volatile("" :: "a"(z_)); }
+#endif
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
