@@ -1,9 +1,9 @@
 #!/bin/bash
-# round-6 validation on one GPU box: the default bench line FIRST (cold box, as the driver runs it), smoke(), the full GPU suite, then the
+# round-6 validation on one GPU box: the bench line with the DRIVER S FLAGS first (cold box, first process: what the driver measures), smoke(), the full GPU suite, then the
 # one-stream rocprofv3 kernel trace of the step (per-kernel durations are only meaningful without concurrency) and the GEMM PMC passes
 R=${GRAFT_REPO_ROOT:-/root/repo}; cd $R; mkdir -p gpurun_out
 TAG=${1:-final}
-timeout 900 python bench.py > gpurun_out/r06_bench_default_$TAG.log 2>&1; echo "bench rc=$?"; tail -1 gpurun_out/r06_bench_default_$TAG.log > gpurun_out/r06_bench_default_$TAG.json; cut -c1-300 gpurun_out/r06_bench_default_$TAG.json
+timeout 900 python bench.py --gpus 1 --steps 20 --warmup 5 > gpurun_out/r06_bench_default_$TAG.log 2>&1; echo "bench rc=$?"; tail -1 gpurun_out/r06_bench_default_$TAG.log > gpurun_out/r06_bench_default_$TAG.json; cut -c1-300 gpurun_out/r06_bench_default_$TAG.json
 timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > gpurun_out/r06_smoke_$TAG.txt 2>&1; echo "smoke rc=$?"; tail -2 gpurun_out/r06_smoke_$TAG.txt
 timeout 1800 python -m pytest tests -m gpu -q > gpurun_out/r06_pytest_gpu_$TAG.txt 2>&1; echo "pytest rc=$?"; tail -3 gpurun_out/r06_pytest_gpu_$TAG.txt
 cd /tmp; export TMPDIR=/tmp
