@@ -371,3 +371,69 @@ def test_validate_pt_gathers_the_ranks_shards(tmp_path):
     one = validate_pt(model, walk(), TASK)
     assert {"caption_acc_tva", "mlm_acc_tva", "t2v_recall", "t2va_recall", "t2a_recall"} <= set(one)
     assert logs[0] == one and logs[1] == one, (logs, one)
+
+
+def _nccl_graph_worker(rank, world, port, outdir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    sys.path.insert(0, ROOT)
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda:0"))
+    try:
+        from types import SimpleNamespace
+        from valor_amd import ops, synth
+        from valor_amd.engine import TrainEngine
+        from valor_amd.model.valor import VALOR
+        spec = synth.tiny_spec()
+        sd = synth.make_state_dict(spec, seed=3, w_std=0.05)
+        batch = synth.make_batch(spec, batch=4, frames=2, audio_slices=1, txt_len=32, seed=4)
+        batch["video_pixels"] = batch["video_pixels"].cuda()
+        batch["audio_spectrograms"] = batch["audio_spectrograms"].cuda()
+        res = {}
+        side = torch.cuda.Stream()
+        x = torch.ones(1 << 20, device="cuda:0")
+        for graphs in (False, True):
+            model = VALOR({"dropout": 0.1}, spec=spec, dtype=torch.bfloat16, device="cuda:0")
+            model.load_state_dict(sd, strict=True)
+            opts = SimpleNamespace(learning_rate=1e-3, weight_decay=0.01, clip_lr=1e-3, clip_lr_text=1e-3, new_lr=0.0, decoder_lr=-1,
+                                   betas=[0.9, 0.98], warmup_ratio=0.1, num_train_steps=10, scheduler="warmup_linear", grad_norm=5.0, alloc_headroom_mb=0)
+            eng = TrainEngine(model, opts, manage_gc=False, graphs=graphs)
+            eng.optimizer.init_master_from(sd)
+            if not graphs:
+                ops.DropoutState.enable_device_base(torch.device("cuda:0"))
+            ops.DropoutState.reset(11)
+            random.seed(400)
+            losses = []
+            for step in range(5):
+                with torch.cuda.stream(side):          # RCCL work in flight (and its watchdog polling it) while step 2 captures its graphs
+                    works = [dist.all_reduce(x, async_op=True) for _ in range(4)]
+                out = eng.train_step(batch, TASK)
+                for w in works:
+                    w.wait()
+                losses.append({k: float(v) for k, v in out.items()})
+            torch.cuda.synchronize()
+            res[graphs] = {"losses": losses, "flat": model.arena.flat.detach().cpu().clone(), "captured": sorted(model._graph_segs)}
+            model.enable_graphs(False)
+            eng.close()
+            ops.DropoutState.disable_device_base()
+            del model, eng
+        torch.save(res, os.path.join(outdir, "nccl_graph.pt"))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_graph_capture_with_an_rccl_process_group_up(dev, tmp_path):
+    """capture inside a training step while an RCCL (nccl backend) process group exists and has collectives in flight: ProcessGroupNCCL's
+    watchdog thread polls their events from another thread, which a capture in the default "global" error mode may take for a violation
+    (the documented DDP + CUDA graphs caveat) -- graphs.py captures in "thread_local" mode once a process group is up. Five steps with
+    the graphs equal five eager steps to the bit."""
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    mp.spawn(_nccl_graph_worker, args=(1, port, str(tmp_path)), nprocs=1, join=True)
+    res = torch.load(os.path.join(str(tmp_path), "nccl_graph.pt"), weights_only=False)
+    assert res[True]["captured"] == ["ast", "clip_text", "decoder", "vit"]
+    assert res[True]["losses"] == res[False]["losses"]
+    assert torch.equal(res[True]["flat"], res[False]["flat"])

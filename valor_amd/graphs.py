@@ -171,7 +171,11 @@ class GraphedSegment:
         cap.static_in = [x.detach().clone().requires_grad_(bool(x.requires_grad)) for x in xs]
         cap.offset0 = ops.DropoutState.offset
         cap.g_fwd, cap.g_bwd = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
-        with torch.cuda.graph(cap.g_fwd, pool=self.pool, stream=cap.stream):
+        # capture_error_mode: "thread_local" when a process group is up -- ProcessGroupNCCL's watchdog thread queries events while we
+        # capture, which the default "global" mode treats as an error of the capture (the documented DDP + graphs caveat); the capture
+        # itself is unaffected (work launched into a capturing stream is captured from whichever thread launches it: autograd's worker)
+        mode = "thread_local" if (torch.distributed.is_available() and torch.distributed.is_initialized()) else "global"
+        with torch.cuda.graph(cap.g_fwd, pool=self.pool, stream=cap.stream, capture_error_mode=mode):
             out = self.fn(*cap.static_in)
         cap.draws = ops.DropoutState.offset - cap.offset0
         ops.DropoutState.offset = cap.offset0                  # the replay of this very call advances it again
@@ -180,7 +184,7 @@ class GraphedSegment:
         rec = []
         ops.GradSink.recorder = rec
         try:
-            with torch.cuda.graph(cap.g_bwd, pool=self.pool, stream=cap.stream):
+            with torch.cuda.graph(cap.g_bwd, pool=self.pool, stream=cap.stream, capture_error_mode=mode):
                 torch.autograd.backward((out,), (cap.static_gout,))
         finally:
             ops.GradSink.recorder = None
