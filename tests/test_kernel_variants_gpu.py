@@ -312,6 +312,38 @@ def test_layernorm_families_agree(dev, cols, rows, p, scaled):
         assert float((a - b).norm()) <= 4e-3 * float(b.norm()) + 1e-6, name
 
 
+@pytest.mark.parametrize("rows,p,with_dz", [(1001, 0.0, True), (514, 0.1, True), (70001, 0.1, True), (4097, 0.0, False)])
+def test_layernorm_backward_with_lds_column_accumulators(dev, rows, p, with_dz):
+    """the half-wave backward with its three column accumulators in a per-wave LDS array (csrc/layernorm.hip LACC; variant 3 forces it, the
+    default picks it for >= 65 536 rows of 768 columns with a residual gradient coming in -- the 70 001-row case runs it under the DEFAULT
+    variant): dx / dres bit-identical to the register-accumulator half-wave kernel (the same row arithmetic), column sums equal up to the
+    reduction order; odd row counts leave a half-wave without a row."""
+    from valor_amd import kernels as K, lib
+    so = lib.load()
+    old = so.valor_ln_set_variant(-1)
+    cols = 768
+    g = torch.Generator().manual_seed(rows)
+    mk = lambda *s: torch.randn(s, generator=g).to(torch.bfloat16).to(dev)
+    x, res, bias, gam, bet, dy = mk(rows, cols), mk(rows, cols), mk(cols), mk(cols), mk(cols), mk(rows, cols)
+    dz = mk(rows, cols) if with_dz else None
+    outs = {}
+    try:
+        so.valor_ln_set_variant(1)
+        z, y, mean, rstd = K.bdrln_fwd(x, bias, res, gam, bet, 1e-5, p_drop=p, seed=5, offset=3)
+        for v in (1, 2, 3):
+            so.valor_ln_set_variant(v)
+            dx, dres, dg, db, dbias = K.bdrln_bwd(dy, dz, z, mean, rstd, gam, p_drop=p, seed=5, offset=3, want_dbias=True)
+            outs[v] = [t.float().clone() for t in (dx, dres, dg, db, dbias)]
+    finally:
+        so.valor_ln_set_variant(old)
+    assert torch.equal(outs[2][0], outs[3][0]) and torch.equal(outs[2][1], outs[3][1])
+    if rows >= 65536 and with_dz:                     # the default rule took the LDS-accumulator kernel
+        assert torch.equal(outs[1][0], outs[3][0])
+    for v in (1, 2):
+        for name, a, b in zip(("dx", "dres", "dgamma", "dbeta", "dbias"), outs[3], outs[v]):
+            assert float((a - b).norm()) <= 4e-3 * float(b.norm()) + 1e-6, (v, name)
+
+
 def test_dropout_is_unbiased_in_expectation(dev):
     """E[dropout(x) / (1 - p)] = x for both counter-based generators: the attention probability hash (attn_common.h) and the
     Philox4x32-10 windows of the fused LayerNorm kernels. The mean over N independent windows must approach the p = 0 output at the

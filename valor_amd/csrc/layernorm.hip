@@ -492,12 +492,18 @@ __global__ __launch_bounds__(256) void ln_fwd_h_kernel(LnArgs p) {
     }
 }
 
-template <int NV8, int GL = 32>
+// LACC (round 6 experiment, `valor_ln_set_variant(3)`; the round-4 / 5 reviews' "column accumulators out of the VGPR budget"): the three
+// column accumulators of a wave (d gamma, d beta, d bias: 3 x 8 x NV8 registers per lane, 72 of the kernel's 194 at 768 columns) live in
+// a per-wave LDS array [3][cols] instead; the two half-waves of a wave (two different rows, the same columns) add to it one after the
+// other (exec-masked passes of one wave: program order, no atomics). 36 KiB per workgroup at 768 columns: four workgroups per CU.
+template <int NV8, int GL = 32, bool LACC = false>
 __global__ __launch_bounds__(256) void ln_bwd_h_kernel(LnBwdArgs p) {
     const uint64_t rng_off = rng_offset(p.offset, p.rng_base);
     typedef bf16_t T;
     constexpr int RPW = 64 / GL;
-    __shared__ float red[3][4 * RPW][GL * 8];   // [which][wave * RPW + half][hl * 8 + k], reused per vector i
+    constexpr int COLS = NV8 * GL * 8;
+    __shared__ float red[LACC ? 1 : 3][LACC ? 1 : 4 * RPW][LACC ? 1 : GL * 8];   // [which][wave * RPW + half][hl * 8 + k], reused per vector i
+    __shared__ __attribute__((aligned(16))) float lacc[LACC ? 4 : 1][LACC ? 3 : 1][LACC ? COLS : 4];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, half = lane / GL, hl = lane % GL;
     const T* DY = (const T*)p.dy; const T* DZI = (const T*)p.dz_in; const T* Z = (const T*)p.z;
     const T* G = (const T*)p.gamma;
@@ -508,13 +514,28 @@ __global__ __launch_bounds__(256) void ln_bwd_h_kernel(LnBwdArgs p) {
     const float inv_n = 1.0f / (float)cols;
     const bool has_ln = DY != nullptr;
 
-    float gsum[NV8][8], bsum[NV8][8], xsum[NV8][8], gam[NV8][8];
+    float gsum[LACC ? 1 : NV8][8], bsum[LACC ? 1 : NV8][8], xsum[LACC ? 1 : NV8][8], gam[NV8][8];
 #pragma unroll
     for (int i = 0; i < NV8; ++i) {
 #pragma unroll
-        for (int k = 0; k < 8; ++k) { gsum[i][k] = 0.f; bsum[i][k] = 0.f; xsum[i][k] = 0.f; gam[i][k] = 1.f; }
+        for (int k = 0; k < 8; ++k) { if (!LACC) { gsum[i][k] = 0.f; bsum[i][k] = 0.f; xsum[i][k] = 0.f; } gam[i][k] = 1.f; }
         if (G) unpack8(*(const u32x4_t*)(G + (i * GL + hl) * 8), gam[i]);
     }
+    if constexpr (LACC) {
+        for (int j = lane; j < 3 * COLS / 4; j += 64) ((f32x4_t*)&lacc[wave][0][0])[j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+    }
+    // add 8 values to accumulator `which` of this wave at this lane's 8 columns of vector i: half 0 first, then half 1
+    auto lds_add = [&](int which, int i, const float (&v)[8], bool ok) {
+        f32x4_t* q = (f32x4_t*)&lacc[LACC ? wave : 0][LACC ? which : 0][LACC ? (i * GL + hl) * 8 : 0];
+#pragma unroll
+        for (int hs = 0; hs < RPW; ++hs) {
+            if (half == hs && ok) {
+                f32x4_t a = q[0], b = q[1];
+                a += (f32x4_t){v[0], v[1], v[2], v[3]}; b += (f32x4_t){v[4], v[5], v[6], v[7]};
+                q[0] = a; q[1] = b;
+            }
+        }
+    };
     for (int64_t row0 = ((int64_t)blockIdx.x * 4 + wave) * RPW; row0 < p.rows; row0 += (int64_t)gridDim.x * 4 * RPW) {
         const int64_t row = row0 + half;
         const bool ok = row < p.rows;
@@ -530,15 +551,17 @@ __global__ __launch_bounds__(256) void ln_bwd_h_kernel(LnBwdArgs p) {
                 const int c = (i * GL + hl) * 8;
                 float zz[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, d[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
                 if (ok) { unpack8(*(const u32x4_t*)(Z + base + c), zz); unpack8(*(const u32x4_t*)(DY + base + c), d); }
+                float dg[8];
 #pragma unroll
                 for (int k = 0; k < 8; ++k) {
                     xh[i][k] = ok ? (zz[k] - mu) * rs : 0.f;
-                    gsum[i][k] += d[k] * xh[i][k];
-                    bsum[i][k] += d[k];
+                    dg[k] = d[k] * xh[i][k];
+                    if (!LACC) { gsum[i][k] += dg[k]; bsum[i][k] += d[k]; }
                     gy[i][k] = d[k] * gam[i][k];
                     s1 += gy[i][k];
                     s2 += gy[i][k] * xh[i][k];
                 }
+                if constexpr (LACC) { lds_add(0, i, dg, ok); lds_add(1, i, d, ok); }
             }
             s1 = group_sum<GL>(s1) * inv_n;
             s2 = group_sum<GL>(s2) * inv_n;
@@ -552,19 +575,19 @@ __global__ __launch_bounds__(256) void ln_bwd_h_kernel(LnBwdArgs p) {
 #pragma unroll
                 for (int k = 0; k < 8; ++k) dzv[i][k] = 0.f;
         }
-        if (!ok) continue;
+        if (!LACC && !ok) continue;
 #pragma unroll
         for (int i = 0; i < NV8; ++i) {
             const int c = (i * GL + hl) * 8;
             float dz[8];
 #pragma unroll
             for (int k = 0; k < 8; ++k) dz[k] = dzv[i][k];
-            if (DZI) {
+            if (DZI && ok) {
                 float a8[8]; unpack8(*(const u32x4_t*)(DZI + base + c), a8);
 #pragma unroll
                 for (int k = 0; k < 8; ++k) dz[k] += a8[k];
             }
-            if (DR) *(u32x4_t*)(DR + base + c) = pack8(dz);
+            if (DR && ok) *(u32x4_t*)(DR + base + c) = pack8(dz);
             float dx[8];
 #pragma unroll
             for (int k = 0; k < 8; ++k) dx[k] = dz[k];
@@ -580,10 +603,24 @@ __global__ __launch_bounds__(256) void ln_bwd_h_kernel(LnBwdArgs p) {
 #pragma unroll
                 for (int k = 0; k < 8; ++k) dx[k] *= rsc;
             }
-            if (DX && (thr || p.row_scale || DX != DR)) *(u32x4_t*)(DX + base + c) = pack8(dx);
+            if (ok && DX && (thr || p.row_scale || DX != DR)) *(u32x4_t*)(DX + base + c) = pack8(dx);
+            if constexpr (LACC) lds_add(2, i, dx, ok);
+            else {
 #pragma unroll
-            for (int k = 0; k < 8; ++k) xsum[i][k] += dx[k];
+                for (int k = 0; k < 8; ++k) xsum[i][k] += dx[k];
+            }
         }
+    }
+    if constexpr (LACC) {
+        // the four waves' arrays -> this workgroup's partial rows: thread t sums columns t, t + 256, ...
+        __syncthreads();
+        for (int c = threadIdx.x; c < COLS; c += 256) {
+            const int64_t o = (int64_t)blockIdx.x * cols + c;
+            if (p.part_dgamma) p.part_dgamma[o] = (lacc[0][0][c] + lacc[1][0][c]) + (lacc[2][0][c] + lacc[3][0][c]);
+            if (p.part_dbeta) p.part_dbeta[o] = (lacc[0][1][c] + lacc[1][1][c]) + (lacc[2][1][c] + lacc[3][1][c]);
+            if (p.part_dbias) p.part_dbias[o] = (lacc[0][2][c] + lacc[1][2][c]) + (lacc[2][2][c] + lacc[3][2][c]);
+        }
+        return;
     }
     // cross-wave reduction of the column partials, one vector slot (GL * 8 columns) at a time: 4 * RPW lane groups own the same columns
 #pragma unroll
@@ -957,7 +994,13 @@ static int launch_ln_bwd(hipStream_t st, const LnBwdArgs& p) {
     // (171 vs 143 us) but wins at 1024 (261 vs 339 us); variant 2 forces it everywhere (tests / A-B runs)
     // 128 / 192 (one vector slot) / 256 columns: several rows per wave (<= 100 VGPRs) against 256-512 B per wave and iteration on the
     // one-wave-per-row kernel
-    if ((g_ln_variant >= 2 || p.cols == 1024 || p.cols <= 256) && ln_half_ok(ElemTraits<T>::DT, p.cols, p.dy, p.dz_in, p.z, p.dx, p.dres) && ((uintptr_t)p.gamma & 15) == 0) {
+    // Round 6 (profiles/r06_ln_bwd_lacc_ab.json): with the three column accumulators in a per-wave LDS array the half-wave backward fits
+    // 120 VGPRs (four waves per SIMD, 16-byte accesses) and wins where the one-wave-per-row kernel is latency bound hardest -- the ViT's
+    // 100 864 x 768 rows WITH a residual gradient coming in: 144.6 -> 131.2 us (183.3 -> 169.9 with dropout); it loses without dz_in
+    // (103 -> 110 us) and on the 16 512 / 8 832-row shapes, which keep the old kernel. VALOR_LN_LACC=0 switches the rule off.
+    static const bool lacc_rule = [] { const char* e = getenv("VALOR_LN_LACC"); return !(e && atoi(e) == 0); }();
+    const bool lacc_pick = g_ln_variant == 1 && lacc_rule && p.cols == 768 && p.rows >= 65536 && p.dz_in != nullptr && p.dy != nullptr;
+    if ((g_ln_variant >= 2 || lacc_pick || p.cols == 1024 || p.cols <= 256) && ln_half_ok(ElemTraits<T>::DT, p.cols, p.dy, p.dz_in, p.z, p.dx, p.dres) && ((uintptr_t)p.gamma & 15) == 0) {
         const int gl = ln_group(p.cols);
         if (gl == 16) {
             if (p.cols == 128) hipLaunchKernelGGL((ln_bwd_h_kernel<1, 16>), dim3(LN_PART_BLOCKS), dim3(256), 0, st, p);
@@ -967,7 +1010,10 @@ static int launch_ln_bwd(hipStream_t st, const LnBwdArgs& p) {
         } else switch (nv) {
             case 1: hipLaunchKernelGGL((ln_bwd_h_kernel<1>), dim3(LN_PART_BLOCKS), dim3(256), 0, st, p); break;
             case 2: hipLaunchKernelGGL((ln_bwd_h_kernel<2>), dim3(LN_PART_BLOCKS), dim3(256), 0, st, p); break;
-            case 3: hipLaunchKernelGGL((ln_bwd_h_kernel<3>), dim3(LN_PART_BLOCKS), dim3(256), 0, st, p); break;
+            case 3:
+                if (g_ln_variant == 3 || lacc_pick) hipLaunchKernelGGL((ln_bwd_h_kernel<3, 32, true>), dim3(LN_PART_BLOCKS), dim3(256), 0, st, p);     // LDS column accumulators
+                else hipLaunchKernelGGL((ln_bwd_h_kernel<3>), dim3(LN_PART_BLOCKS), dim3(256), 0, st, p);
+                break;
             default: hipLaunchKernelGGL((ln_bwd_h_kernel<4>), dim3(LN_PART_BLOCKS), dim3(256), 0, st, p); break;
         }
         return valor_launch_status();
