@@ -315,7 +315,7 @@ def test_layernorm_families_agree(dev, cols, rows, p, scaled):
 @pytest.mark.parametrize("rows,p,with_dz", [(1001, 0.0, True), (514, 0.1, True), (70001, 0.1, True), (4097, 0.0, False)])
 def test_layernorm_backward_with_lds_column_accumulators(dev, rows, p, with_dz):
     """the half-wave backward with its three column accumulators in a per-wave LDS array (csrc/layernorm.hip LACC; variant 3 forces it, the
-    default picks it for >= 65 536 rows of 768 columns with a residual gradient coming in -- the 70 001-row case runs it under the DEFAULT
+    default picks it for >= 49 152 rows of 768 columns with a residual gradient coming in -- the 70 001-row case runs it under the DEFAULT
     variant): dx / dres bit-identical to the register-accumulator half-wave kernel (the same row arithmetic), column sums equal up to the
     reduction order; odd row counts leave a half-wave without a row."""
     from valor_amd import kernels as K, lib
@@ -337,7 +337,7 @@ def test_layernorm_backward_with_lds_column_accumulators(dev, rows, p, with_dz):
     finally:
         so.valor_ln_set_variant(old)
     assert torch.equal(outs[2][0], outs[3][0]) and torch.equal(outs[2][1], outs[3][1])
-    if rows >= 65536 and with_dz:                     # the default rule took the LDS-accumulator kernel
+    if rows >= 49152 and with_dz:                     # the default rule took the LDS-accumulator kernel
         assert torch.equal(outs[1][0], outs[3][0])
     for v in (1, 2):
         for name, a, b in zip(("dx", "dres", "dgamma", "dbeta", "dbias"), outs[3], outs[v]):

@@ -14,7 +14,11 @@ from valor_amd import kernels as K, lib  # noqa: E402
 dev = torch.device("cuda:0")
 so = lib.load()
 res_all = {}
-for rows, p, dzin in [(100864, 0.0, True), (100864, 0.1, True), (100864, 0.0, False), (16512, 0.1, True), (8832, 0.1, True)]:
+import os
+CASES = [(100864, 0.0, True), (100864, 0.1, True), (100864, 0.0, False), (16512, 0.1, True), (8832, 0.1, True)]
+if os.environ.get("LN_ROWS"):
+    CASES = [(int(r), 0.0, True) for r in os.environ["LN_ROWS"].split(",")]
+for rows, p, dzin in CASES:
     cols = 768
     g0 = torch.Generator(device="cpu").manual_seed(1)
     mk = lambda *s: torch.randn(*s, generator=g0).bfloat16().to(dev)

@@ -999,7 +999,7 @@ static int launch_ln_bwd(hipStream_t st, const LnBwdArgs& p) {
     // 100 864 x 768 rows WITH a residual gradient coming in: 144.6 -> 131.2 us (183.3 -> 169.9 with dropout); it loses without dz_in
     // (103 -> 110 us) and on the 16 512 / 8 832-row shapes, which keep the old kernel. VALOR_LN_LACC=0 switches the rule off.
     static const bool lacc_rule = [] { const char* e = getenv("VALOR_LN_LACC"); return !(e && atoi(e) == 0); }();
-    const bool lacc_pick = g_ln_variant == 1 && lacc_rule && p.cols == 768 && p.rows >= 65536 && p.dz_in != nullptr && p.dy != nullptr;
+    const bool lacc_pick = g_ln_variant == 1 && lacc_rule && p.cols == 768 && p.rows >= 49152 && p.dz_in != nullptr && p.dy != nullptr;   // (50 176 rows: 76.1 -> 69.4 us; 65 536 and 200 704: equal; 33 024: slower -- r06_ln_bwd_lacc_rows.json)
     if ((g_ln_variant >= 2 || lacc_pick || p.cols == 1024 || p.cols <= 256) && ln_half_ok(ElemTraits<T>::DT, p.cols, p.dy, p.dz_in, p.z, p.dx, p.dres) && ((uintptr_t)p.gamma & 15) == 0) {
         const int gl = ln_group(p.cols);
         if (gl == 16) {
