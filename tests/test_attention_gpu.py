@@ -143,10 +143,20 @@ def test_resident_backward_pipelined_equals_per_head_kernel(dev, S, B, H, p_drop
         dq0, dk0, dv0 = K.attn_bwd(q, k, v, o, lse, dout, H, scale=scale, p_drop=p_drop, seed=5, offset=9)
         so.valor_attn_set_res_pipeline(2)      # 16 waves x 16-row blocks: every output row accumulates in the order of mode 0
         dq2, dk2, dv2 = K.attn_bwd(q, k, v, o, lse, dout, H, scale=scale, p_drop=p_drop, seed=5, offset=9)
+        # mode 3: the FIRST version of the pipelined kernel (operands from global memory at the top of each phase, 8-byte stores); mode 1 is the
+        # second (round 6: operands prefetched / out of LDS, 16-byte stores through v_permlane16_swap) -- the same arithmetic, bit for bit
+        so.valor_attn_set_res_pipeline(3)
+        dq3, dk3, dv3 = K.attn_bwd(q, k, v, o, lse, dout, H, scale=scale, p_drop=p_drop, seed=5, offset=9)
+        so.valor_attn_set_res_pipeline(1)      # gradients written into one packed [B, S, 3E] buffer (the model's layout: row stride 3E)
+        dqkv = torch.full_like(qkv, float("nan"))
+        K.attn_bwd(q, k, v, o, lse, dout, H, dq=dqkv[:, :, :E], dk=dqkv[:, :, E:2 * E], dv=dqkv[:, :, 2 * E:], scale=scale, p_drop=p_drop, seed=5, offset=9)
     finally:
         so.valor_attn_set_res_pipeline(old)
     torch.cuda.synchronize()
     assert torch.equal(dq2, dq0) and torch.equal(dk2, dk0) and torch.equal(dv2, dv0)
+    if S > 160:            # (shorter sequences: mode 1 is the 16-wave kernel, mode 3 the pipelined one -- another summation order of delta)
+        assert torch.equal(dq3, dq1) and torch.equal(dk3, dk1) and torch.equal(dv3, dv1)
+    assert torch.equal(dqkv, torch.cat((dq1, dk1, dv1), dim=-1))
     for a, b_, c, n in ((dq1, dq0, dq1b, "dq"), (dk1, dk0, dk1b, "dk"), (dv1, dv0, dv1b, "dv")):
         assert torch.equal(a, c), n
         assert _rel(a, b_) < 5e-4, (n, _rel(a, b_))

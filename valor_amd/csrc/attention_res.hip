@@ -440,6 +440,23 @@ DEVINL void tr_wait4x(TrPair (&t)[4]) {
 DEVINL void launder(bf16x8_t& v) { asm volatile("" : "+v"(v)); }
 DEVINL void launder(float& v) { asm volatile("" : "+v"(v)); }
 
+#ifdef ATT_STAMP
+// diagnostic build only (tools/build_stamp_lib.sh attn, tools/attn_stamp.py): cycle stamps of every wave around the stretches of ONE steady-state
+// item (the ATT_STAMP_ITEM-th of its workgroup) as [workgroup][wave][16] uint64: [0] item start, [1] phase-1 operands landed, [2] past barrier 1,
+// [3] Q / dO DMA issued, [4] dQ loop done, [5] dQ stores issued, [6] vmcnt(0), [7] past barrier 2, [8] phase-2 operands landed, [9] next K / V DMA
+// issued, [10] dK / dV loop done, [11] stores issued, [12] HW_ID, [13] XCC_ID
+#ifndef ATT_STAMP_ITEM
+#define ATT_STAMP_ITEM 10
+#endif
+__device__ uint64_t g_att_stamps[1024 * 8 * 16];
+extern "C" int valor_attn_read_stamps(void* dst, size_t bytes) {
+    return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_att_stamps), bytes < sizeof(g_att_stamps) ? bytes : sizeof(g_att_stamps));
+}
+#define ATT_STAMP_AT(i) do { if (it_ == ATT_STAMP_ITEM) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); stamp_[i] = __builtin_amdgcn_s_memtime(); } } while (0)
+#else
+#define ATT_STAMP_AT(i)
+#endif
+
 template <bool DROP, bool MASK>
 __global__ __launch_bounds__(512, 2) void attn_res_bwd_pipe_kernel(AttnArgs p, int n_items) {
     const uint64_t rng_off = rng_offset(p.offset, p.rng_base);     // once, ahead of every loop: a scalar load inside the tile loop
@@ -472,9 +489,17 @@ __global__ __launch_bounds__(512, 2) void attn_res_bwd_pipe_kernel(AttnArgs p, i
         stage_image(head_rsrc(p.k, (int64_t)b * p.k_bs + h * ATT_D, S, p.k_rs), sK, SP, (int)p.k_rs * 2, wave, 8, lane);
         stage_image(head_rsrc(p.v, (int64_t)b * p.v_bs + h * ATT_D, S, p.v_rs), sV, SP, (int)p.v_rs * 2, wave, 8, lane);
     }
+#ifdef ATT_STAMP
+    int it_ = -1;
+    uint64_t stamp_[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#endif
     for (; item < n_items; item += gridDim.x) {
         const int h = item % p.H, b = item / p.H;
         const uint32_t hk = attn_drop_headkey(p.seed, rng_off, b * p.H + h);
+#ifdef ATT_STAMP
+        ++it_;
+#endif
+        ATT_STAMP_AT(0);
         // ---------------- phase 1 operands: this wave's 32 query rows of Q / dO (fragments), O (for delta), lse
         bf16x8_t qf[2][2], dof[2][2];
         int qr[2];
@@ -516,13 +541,16 @@ __global__ __launch_bounds__(512, 2) void attn_res_bwd_pipe_kernel(AttnArgs p, i
             for (int dg = 0; dg < 2; ++dg) { launder(qf[rt][dg]); launder(dof[rt][dg]); }
             launder(lse2[rt]); launder(dlt[rt]);
         }
+        ATT_STAMP_AT(1);
         __syncthreads();        // K, V (item) landed for every wave; everyone is past phase 2 of the previous item (buffer B, statistics free)
+        ATT_STAMP_AT(2);
         if (active && g == 0) {     // read by every wave in phase 2, i.e. behind the next barrier
 #pragma unroll
             for (int rt = 0; rt < 2; ++rt) { sLse[qr[rt]] = lse2[rt]; sDelta[qr[rt]] = dlt[rt]; }
         }
         stage_image(head_rsrc(p.q, (int64_t)b * p.q_bs + h * ATT_D, S, p.q_rs), sQ, SP, (int)p.q_rs * 2, wave, 8, lane);
         stage_image(head_rsrc(p.dout, (int64_t)b * p.do_bs + h * ATT_D, S, p.do_rs), sDO, SP, (int)p.do_rs * 2, wave, 8, lane);
+        ATT_STAMP_AT(3);
 
         // ---------------- phase 1: dQ of this wave's query block against all keys (images A)
         if (active) {
@@ -581,6 +609,7 @@ __global__ __launch_bounds__(512, 2) void attn_res_bwd_pipe_kernel(AttnArgs p, i
                     }
                 }
             }
+            ATT_STAMP_AT(4);
 #pragma unroll
             for (int rt = 0; rt < 2; ++rt)
                 if (qr[rt] < S) {
@@ -588,9 +617,12 @@ __global__ __launch_bounds__(512, 2) void attn_res_bwd_pipe_kernel(AttnArgs p, i
 #pragma unroll
                     for (int dt = 0; dt < 4; ++dt) store4<bf16_t>(DQ + dt * 16 + 4 * g, dqacc[rt][dt] * p.scale);
                 }
+            ATT_STAMP_AT(5);
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // this wave's pieces of Q, dO (item)
+        ATT_STAMP_AT(6);
         __syncthreads();        // Q, dO landed and the statistics are visible; everyone is done with the K, V images (buffer A free)
+        ATT_STAMP_AT(7);
 
         // ---------------- phase 2 operands: this wave's 32 key rows of K / V, then the look-ahead DMA of the next item's K, V
         bf16x8_t kf[2][2], vf[2][2];
@@ -619,6 +651,7 @@ __global__ __launch_bounds__(512, 2) void attn_res_bwd_pipe_kernel(AttnArgs p, i
         for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
             for (int dg = 0; dg < 2; ++dg) { launder(kf[kt][dg]); launder(vf[kt][dg]); }
+        ATT_STAMP_AT(8);
         {
             const int nxt = item + gridDim.x;
             if (nxt < n_items) {
@@ -627,6 +660,7 @@ __global__ __launch_bounds__(512, 2) void attn_res_bwd_pipe_kernel(AttnArgs p, i
                 stage_image(head_rsrc(p.v, (int64_t)b2 * p.v_bs + h2 * ATT_D, S, p.v_rs), sV, SP, (int)p.v_rs * 2, wave, 8, lane);
             }
         }
+        ATT_STAMP_AT(9);
         // ---------------- phase 2: dK, dV of this wave's key block against all queries (images B)
         if (active) {
             f32x4_t dkacc[2][4], dvacc[2][4];
@@ -695,6 +729,7 @@ __global__ __launch_bounds__(512, 2) void attn_res_bwd_pipe_kernel(AttnArgs p, i
                     }
                 }
             }
+            ATT_STAMP_AT(10);
 #pragma unroll
             for (int kt = 0; kt < 2; ++kt)
                 if (key[kt] < S) {
@@ -706,7 +741,418 @@ __global__ __launch_bounds__(512, 2) void attn_res_bwd_pipe_kernel(AttnArgs p, i
                         store4<bf16_t>(DV + dt * 16 + 4 * g, dvacc[kt][dt]);
                     }
                 }
+            ATT_STAMP_AT(11);
         }
+#ifdef ATT_STAMP
+        if (it_ == ATT_STAMP_ITEM && lane == 0 && blockIdx.x < 1024) {
+            uint64_t* o = g_att_stamps + ((int64_t)blockIdx.x * 8 + wave) * 16;
+            for (int i = 0; i < 12; ++i) o[i] = stamp_[i];
+            o[12] = __builtin_amdgcn_s_getreg((31 << 11) | 4);       // HW_ID
+            o[13] = __builtin_amdgcn_s_getreg((31 << 11) | 20);      // XCC_ID
+        }
+#endif
+    }
+}
+
+// ------------------------------------------------------------------------------------------ backward, pipelined, second version
+// Round 6, from per-wave cycle stamps of the kernel above (tools/attn_stamp.py, profiles/r06_attn_stamp_base.json): of the 46 k ticks of one
+// steady-state item on the critical wave only 27 k are the two loops. 6.0 k: the phase-1 register operands (global loads issued at the top of
+// the item, waited for at once -- and the same vmcnt(0) waits for the acknowledgements of the 32 dK / dV stores issued just before); 4.2 k: the
+// same for the phase-2 operands; 4.8 k + 0.5 k: issuing the stores (8-byte stores of 32-byte row segments, ~100 ticks each). This version
+//   * takes the phase-2 operands (this wave's 32 key rows of K / V) from the K / V IMAGES at the end of phase 1 -- they are in LDS already;
+//   * loads the NEXT item's phase-1 operands (Q / dO / O rows, lse) into registers in front of the dK / dV loop: they land under it;
+//   * places every vmcnt(0) directly behind a loop and the stores directly behind the vmcnt(0): no wait ever sees a freshly issued access;
+//   * stores 16 bytes per lane (v_permlane16_swap pairs the 4-column groups of two neighbouring lane rows): half the store instructions,
+//     64-byte row segments.
+// Arithmetic, layouts and the result are those of the kernel above (bit-identical; tests/test_attention_gpu.py compares the modes).
+typedef uint32_t u32x2v_t __attribute__((ext_vector_type(2)));
+// a 16-row x 64-column accumulator block (lane (fr, g): row fr, columns dt * 16 + 4 g + r) times `mul` as bf16 into row pointers; ALL lanes
+// must call it (the swap needs both partners), `ok` predicates the store only
+DEVINL void store_block16(char* rowp, const f32x4_t (&a)[4], float mul, int g, bool ok) {
+#pragma unroll
+    for (int pr = 0; pr < 2; ++pr) {
+        const f32x4_t x = a[2 * pr] * mul, y = a[2 * pr + 1] * mul;
+        const u32x2v_t r0 = __builtin_amdgcn_permlane16_swap(pack2_bf16(x[0], x[1]), pack2_bf16(y[0], y[1]), false, false);
+        const u32x2v_t r1 = __builtin_amdgcn_permlane16_swap(pack2_bf16(x[2], x[3]), pack2_bf16(y[2], y[3]), false, false);
+        // even lane row g: own columns 4 g .. 4 g + 3 of group 2 pr, then those of lane row g + 1; odd: lane row g - 1's columns of group 2 pr + 1, then its own
+        const u32x4_t w = {r0[0], r1[0], r0[1], r1[1]};
+        if (ok) *(u32x4_t*)(rowp + pr * 64) = w;      // rowp: the row's byte address + (g odd ? 32 + 8 (g - 1) : 8 g)
+    }
+}
+DEVINL void launder(u32x4_t& v) { asm volatile("" : "+v"(v)); }
+
+template <bool DROP, bool MASK>
+__global__ __launch_bounds__(512, 2) void attn_res_bwd_pipe2_kernel(AttnArgs p, int n_items) {
+    const uint64_t rng_off = rng_offset(p.offset, p.rng_base);
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int fr = lane & 15, g = lane >> 4;
+    const int S = p.Skv, SP = (S + 31) & ~31;
+    const int IMG = SP * TILE_ROW_BYTES;
+    char* sK = smem;                 // buffer A
+    char* sV = smem + IMG;
+    char* sQ = smem + 2 * IMG;       // buffer B
+    char* sDO = smem + 3 * IMG;
+    float* sLse = (float*)(smem + 4 * IMG);
+    float* sDelta = sLse + SP;
+    const float sl2 = p.scale * LOG2E_F;
+    const uint32_t thr = drop_threshold(p.p_drop);
+    const float keep_scale = p.p_drop > 0.f ? 1.0f / (1.0f - p.p_drop) : 1.0f;
+    int troff[4];
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) troff[dt] = tr_lane_off(lane, dt);
+    const int NP = (S + 31) >> 5, NT = (S + 63) >> 6;      // NP <= 8: one 32-row block per wave
+    const int pr = wave;
+    const bool active = pr < NP;
+    int rowi[2];                     // this lane's rows of the wave's block (queries in phase 1, keys in phase 2)
+    bool rowok[2];
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt) { rowi[rt] = pr * 32 + rt * 16 + fr; rowok[rt] = active && rowi[rt] < S; }
+    int rowc[2];                     // the same clamped into the sequence (loads of the raw phase-1 operands)
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt) rowc[rt] = rowi[rt] < S ? rowi[rt] : S - 1;
+
+    // raw phase-1 operands: this wave's 32 rows of Q / dO / O as MFMA fragments (lane: row fr of tile rt, 8 columns at dg * 32 + g * 8), lse
+    u32x4_t zq[2][2], zd[2][2], zo[2][2];
+    float lraw[2];
+    // (32-bit byte offsets against per-item scalar bases -- res_eligible bounds S * row stride below 2^31 --, recomputed per item behind an
+    //  opaque zero: hoisted out of the item loop as 64-bit addresses they cost 20+ registers that the dK / dV loop does not have)
+    auto load_p1 = [&](int it) {
+        const int h = it % p.H, b = it / p.H;
+        const char* Qb = (const char*)((const bf16_t*)p.q + (int64_t)b * p.q_bs + h * ATT_D);
+        const char* DOb = (const char*)((const bf16_t*)p.dout + (int64_t)b * p.do_bs + h * ATT_D);
+        const char* Ob = (const char*)((const bf16_t*)p.o + (int64_t)b * p.o_bs + h * ATT_D);
+        const float* Lb = p.lse + ((int64_t)b * p.H + h) * p.Sq;
+        int z = 0;
+        asm volatile("" : "+v"(z));
+#pragma unroll
+        for (int rt = 0; rt < 2; ++rt) {
+            const uint32_t r = (uint32_t)(rowc[rt] + z);           // rows past S: row S - 1 (see p1_part)
+            const uint32_t oq = r * (uint32_t)(p.q_rs * 2) + g * 16, od = r * (uint32_t)(p.do_rs * 2) + g * 16, oo = r * (uint32_t)(p.o_rs * 2) + g * 16;
+#pragma unroll
+            for (int dg = 0; dg < 2; ++dg) {
+                zq[rt][dg] = *(const u32x4_t*)(Qb + oq + dg * 64);
+                zd[rt][dg] = *(const u32x4_t*)(DOb + od + dg * 64);
+                zo[rt][dg] = *(const u32x4_t*)(Ob + oo + dg * 64);
+            }
+            lraw[rt] = Lb[r];
+        }
+    };
+    auto launder_p1 = [&]() {
+#pragma unroll
+        for (int rt = 0; rt < 2; ++rt) {
+#pragma unroll
+            for (int dg = 0; dg < 2; ++dg) { launder(zq[rt][dg]); launder(zd[rt][dg]); launder(zo[rt][dg]); }
+            launder(lraw[rt]);
+        }
+    };
+
+    int item = blockIdx.x;
+    if (item < n_items) {
+        const int h = item % p.H, b = item / p.H;
+        stage_image(head_rsrc(p.k, (int64_t)b * p.k_bs + h * ATT_D, S, p.k_rs), sK, SP, (int)p.k_rs * 2, wave, 8, lane);
+        stage_image(head_rsrc(p.v, (int64_t)b * p.v_bs + h * ATT_D, S, p.v_rs), sV, SP, (int)p.v_rs * 2, wave, 8, lane);
+        load_p1(item);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        launder_p1();
+    }
+#ifdef ATT_STAMP
+    int it_ = -1;
+    uint64_t stamp_[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#endif
+    for (; item < n_items; item += gridDim.x) {
+        const int h = item % p.H, b = item / p.H;
+        const uint32_t hk = attn_drop_headkey(p.seed, rng_off, b * p.H + h);
+#ifdef ATT_STAMP
+        ++it_;
+#endif
+        ATT_STAMP_AT(0);
+        // ---------------- phase 1 operands out of the raw registers (landed: the vmcnt(0) behind the previous item's dK / dV loop)
+        bf16x8_t qf[2][2], dof[2][2];
+        float lse2[2], dlt[2];
+#pragma unroll
+        for (int rt = 0; rt < 2; ++rt) {
+            float d = 0.f;
+#pragma unroll
+            for (int dg = 0; dg < 2; ++dg) {
+                qf[rt][dg] = __builtin_bit_cast(bf16x8_t, zq[rt][dg]);
+                dof[rt][dg] = __builtin_bit_cast(bf16x8_t, zd[rt][dg]);
+                const bf16x8_t ov = __builtin_bit_cast(bf16x8_t, zo[rt][dg]);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) d += (float)ov[e] * (float)dof[rt][dg][e];
+            }
+            lse2[rt] = rowok[rt] ? lraw[rt] * LOG2E_F : INFINITY;          // rows past S: P = 2^(s - inf) = 0
+            d += __shfl_xor(d, 16, 64);
+            d += __shfl_xor(d, 32, 64);
+            dlt[rt] = d;
+        }
+        ATT_STAMP_AT(1);
+        __builtin_amdgcn_s_barrier();        // (raw: no fence -- LDS writes are waited for explicitly, global stores need no ordering here) K, V (item) landed for every wave; everyone is past phase 2 of the previous item (buffer B, statistics free)
+        ATT_STAMP_AT(2);
+        if (active && g == 0) {     // read by every wave in phase 2, i.e. behind the next barrier
+#pragma unroll
+            for (int rt = 0; rt < 2; ++rt) { sLse[rowi[rt]] = lse2[rt]; sDelta[rowi[rt]] = dlt[rt]; }
+        }
+        stage_image(head_rsrc(p.q, (int64_t)b * p.q_bs + h * ATT_D, S, p.q_rs), sQ, SP, (int)p.q_rs * 2, wave, 8, lane);
+        stage_image(head_rsrc(p.dout, (int64_t)b * p.do_bs + h * ATT_D, S, p.do_rs), sDO, SP, (int)p.do_rs * 2, wave, 8, lane);
+        ATT_STAMP_AT(3);
+
+        // ---------------- phase 1: dQ of this wave's query block against all keys (images A)
+        f32x4_t dqacc[2][4];
+#pragma unroll
+        for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) dqacc[rt][dt] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+        bf16x8_t kf[2][2], vf[2][2];
+        if (active) {
+            for (int t = 0; t < NT; ++t) {
+                const int kv0 = t << 6;
+                int nkt = (S - kv0 + 15) >> 4;
+                nkt = nkt > 4 ? 4 : nkt;
+#pragma unroll
+                for (int kk = 0; kk < 2; ++kk) {
+                    if (2 * kk >= nkt) continue;
+                    f32x4_t ds[2][2];      // [rt][kt2]
+#pragma unroll
+                    for (int k2 = 0; k2 < 2; ++k2) {
+                        const int kt = 2 * kk + k2;
+                        f32x4_t sa[2], pa[2];
+                        sa[0] = (f32x4_t){0.f, 0.f, 0.f, 0.f}; sa[1] = sa[0]; pa[0] = sa[0]; pa[1] = sa[0];
+                        if (kt < nkt) {
+#pragma unroll
+                            for (int dg = 0; dg < 2; ++dg) {
+                                const bf16x8_t kfr = read_frag<bf16_t>(sK, kv0 + kt * 16 + fr, dg * 4 + g);
+                                const bf16x8_t vfr = read_frag<bf16_t>(sV, kv0 + kt * 16 + fr, dg * 4 + g);
+                                sa[0] = Mma<bf16_t>::mma(kfr, qf[0][dg], sa[0]);
+                                sa[1] = Mma<bf16_t>::mma(kfr, qf[1][dg], sa[1]);
+                                pa[0] = Mma<bf16_t>::mma(vfr, dof[0][dg], pa[0]);
+                                pa[1] = Mma<bf16_t>::mma(vfr, dof[1][dg], pa[1]);
+                            }
+                        }
+#pragma unroll
+                        for (int rt = 0; rt < 2; ++rt) {
+                            f32x4_t m4 = {0.f, 0.f, 0.f, 0.f}, pdrop;
+                            if (MASK && rowi[rt] < S) {
+                                const float* mrowp = p.mask + (int64_t)b * p.mask_bs + (int64_t)rowi[rt] * p.mask_rs;
+#pragma unroll
+                                for (int r = 0; r < 4; ++r) { const int key = kv0 + kt * 16 + 4 * g + r; if (key < S) m4[r] = mrowp[key] * LOG2E_F; }
+                            }
+                            const uint32_t e0 = (uint32_t)rowi[rt] * (uint32_t)p.Skv + (uint32_t)(kv0 + kt * 16 + 4 * g);
+                            softmax_bwd4<DROP, false>(sa[rt], pa[rt], m4, splat4(lse2[rt]), splat4(dlt[rt]), sl2, hk, e0, 1u, thr, keep_scale, pdrop, ds[rt][k2]);
+                        }
+                    }
+                    const bf16x8_t d0 = pack_bf16x8(ds[0][0], ds[0][1]);
+                    const bf16x8_t d1 = pack_bf16x8(ds[1][0], ds[1][1]);
+                    TrPair tk[4];
+#pragma unroll
+                    for (int dt = 0; dt < 4; ++dt) tr_issue_img(tk[dt], sK + (kv0 + 32 * kk) * TILE_ROW_BYTES + troff[dt]);   // K^T[d][key]
+                    tr_wait4x(tk);
+#pragma unroll
+                    for (int dt = 0; dt < 4; ++dt) {
+                        const bf16x8_t ktf = tr_frag(tk[dt]);
+                        dqacc[0][dt] = Mma<bf16_t>::mma(ktf, d0, dqacc[0][dt]);
+                        dqacc[1][dt] = Mma<bf16_t>::mma(ktf, d1, dqacc[1][dt]);
+                    }
+                }
+            }
+            // phase-2 operands: this wave's 32 key rows of K / V out of the images (rows past S are zero rows)
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                for (int dg = 0; dg < 2; ++dg) {
+                    kf[kt][dg] = read_frag<bf16_t>(sK, rowi[kt], dg * 4 + g);
+                    vf[kt][dg] = read_frag<bf16_t>(sV, rowi[kt], dg * 4 + g);
+                }
+        } else {
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                for (int dg = 0; dg < 2; ++dg) { kf[kt][dg] = __builtin_bit_cast(bf16x8_t, (u32x4_t){0u, 0u, 0u, 0u}); vf[kt][dg] = kf[kt][dg]; }
+        }
+        ATT_STAMP_AT(4);
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");         // this wave's pieces of Q, dO (item); the K / V fragments are out of buffer A
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+            for (int dg = 0; dg < 2; ++dg) { launder(kf[kt][dg]); launder(vf[kt][dg]); }
+        ATT_STAMP_AT(5);
+        {
+            char* DQ = (char*)((bf16_t*)p.dq + (int64_t)b * p.dq_bs + h * ATT_D);
+            int z = 0;
+            asm volatile("" : "+v"(z));
+            const uint32_t gcol = (g & 1) ? 32 + 8 * (g - 1) : 8 * g;
+#pragma unroll
+            for (int rt = 0; rt < 2; ++rt) store_block16(DQ + ((uint32_t)(rowi[rt] + z) * (uint32_t)(p.dq_rs * 2) + gcol), dqacc[rt], p.scale, g, rowok[rt]);
+        }
+        ATT_STAMP_AT(6);
+        __builtin_amdgcn_s_barrier();        // Q, dO landed and the statistics are visible; everyone is done with the K, V images (buffer A free)
+        ATT_STAMP_AT(7);
+        ATT_STAMP_AT(8);
+
+        // ---------------- look-ahead: the next item's K, V by DMA into buffer A now; its phase-1 operands into registers in six parts, one per
+        // step of the dK / dV loop (all fourteen loads at once behind the 56 KiB of DMA measured 5-7 k ticks of issue stall per item:
+        // profiles/r06_attn_stamp_v2a.json -- a compute unit takes 64 bytes per clock)
+        const int nxt = item + gridDim.x;
+        const bool more = nxt < n_items;
+        const char *nQb = nullptr, *nDOb = nullptr, *nOb = nullptr;
+        const float* nLb = nullptr;
+        if (more) {
+            const int h2 = nxt % p.H, b2 = nxt / p.H;
+            stage_image(head_rsrc(p.k, (int64_t)b2 * p.k_bs + h2 * ATT_D, S, p.k_rs), sK, SP, (int)p.k_rs * 2, wave, 8, lane);
+            stage_image(head_rsrc(p.v, (int64_t)b2 * p.v_bs + h2 * ATT_D, S, p.v_rs), sV, SP, (int)p.v_rs * 2, wave, 8, lane);
+            nQb = (const char*)((const bf16_t*)p.q + (int64_t)b2 * p.q_bs + h2 * ATT_D);
+            nDOb = (const char*)((const bf16_t*)p.dout + (int64_t)b2 * p.do_bs + h2 * ATT_D);
+            nOb = (const char*)((const bf16_t*)p.o + (int64_t)b2 * p.o_bs + h2 * ATT_D);
+            nLb = p.lse + ((int64_t)b2 * p.H + h2) * p.Sq;
+        }
+        auto p1_part = [&](int k) {         // k = 0 .. 5: tensor k % 3 (Q, dO, O + lse) of row tile k / 3
+            // UNCONDITIONAL loads (rows past S read row S - 1: finite values that only ever meet P = 0; their lse becomes +inf where it is consumed):
+            // a predicated load is a load into a temporary + a select, and the select's vmcnt(0) sits inside the loop
+            const int rt = k / 3, tz = k % 3;
+            int z = 0;
+            asm volatile("" : "+v"(z));
+            const uint32_t r = (uint32_t)(rowc[rt] + z);
+            if (tz == 0) {
+                const uint32_t o = r * (uint32_t)(p.q_rs * 2) + g * 16;
+                zq[rt][0] = *(const u32x4_t*)(nQb + o); zq[rt][1] = *(const u32x4_t*)(nQb + o + 64);
+            } else if (tz == 1) {
+                const uint32_t o = r * (uint32_t)(p.do_rs * 2) + g * 16;
+                zd[rt][0] = *(const u32x4_t*)(nDOb + o); zd[rt][1] = *(const u32x4_t*)(nDOb + o + 64);
+            } else {
+                const uint32_t o = r * (uint32_t)(p.o_rs * 2) + g * 16;
+                zo[rt][0] = *(const u32x4_t*)(nOb + o); zo[rt][1] = *(const u32x4_t*)(nOb + o + 64);
+                lraw[rt] = nLb[r];
+            }
+        };
+        int stp = 0;
+        ATT_STAMP_AT(9);
+        // ---------------- phase 2: dK, dV of this wave's key block against all queries (images B)
+        f32x4_t dkacc[2][4], dvacc[2][4];
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) { dkacc[kt][dt] = (f32x4_t){0.f, 0.f, 0.f, 0.f}; dvacc[kt][dt] = dkacc[kt][dt]; }
+        auto p2_step = [&](int qb0, int kk, int nqs) {
+            f32x4_t pd[2][2], ds[2][2];      // [kt][q2]
+#pragma unroll
+            for (int q2 = 0; q2 < 2; ++q2) {
+                const int qs = 2 * kk + q2;
+                f32x4_t sa[2], pa[2];
+                sa[0] = (f32x4_t){0.f, 0.f, 0.f, 0.f}; sa[1] = sa[0]; pa[0] = sa[0]; pa[1] = sa[0];
+                f32x4_t l4 = sa[0], d4 = sa[0];
+                const int q4 = qb0 + qs * 16 + 4 * g;
+                if (qs < nqs) {
+#pragma unroll
+                    for (int dg = 0; dg < 2; ++dg) {
+                        const bf16x8_t qfr = read_frag<bf16_t>(sQ, qb0 + qs * 16 + fr, dg * 4 + g);
+                        const bf16x8_t dfr = read_frag<bf16_t>(sDO, qb0 + qs * 16 + fr, dg * 4 + g);
+                        sa[0] = Mma<bf16_t>::mma(qfr, kf[0][dg], sa[0]);
+                        sa[1] = Mma<bf16_t>::mma(qfr, kf[1][dg], sa[1]);
+                        pa[0] = Mma<bf16_t>::mma(dfr, vf[0][dg], pa[0]);
+                        pa[1] = Mma<bf16_t>::mma(dfr, vf[1][dg], pa[1]);
+                    }
+                    l4 = *(const f32x4_t*)(sLse + q4); d4 = *(const f32x4_t*)(sDelta + q4);
+                }
+                if (qs >= nqs) l4 = (f32x4_t){INFINITY, INFINITY, INFINITY, INFINITY};
+#pragma unroll
+                for (int kt = 0; kt < 2; ++kt) {
+                    f32x4_t m4 = {0.f, 0.f, 0.f, 0.f};
+                    if (MASK && rowi[kt] < S) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) if (q4 + r < S) m4[r] = p.mask[(int64_t)b * p.mask_bs + (int64_t)(q4 + r) * p.mask_rs + rowi[kt]] * LOG2E_F;
+                    }
+                    softmax_bwd4<DROP, true>(sa[kt], pa[kt], m4, l4, d4, sl2, hk, (uint32_t)q4 * (uint32_t)p.Skv + (uint32_t)rowi[kt], (uint32_t)p.Skv, thr, keep_scale,
+                                             pd[kt][q2], ds[kt][q2]);
+                }
+            }
+            const bf16x8_t p0 = pack_bf16x8(pd[0][0], pd[0][1]);
+            const bf16x8_t p1 = pack_bf16x8(pd[1][0], pd[1][1]);
+            const bf16x8_t s0 = pack_bf16x8(ds[0][0], ds[0][1]);
+            const bf16x8_t s1 = pack_bf16x8(ds[1][0], ds[1][1]);
+            TrPair tdo[4], tq[4];
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) {
+                tr_issue_img(tdo[dt], sDO + (qb0 + 32 * kk) * TILE_ROW_BYTES + troff[dt]);   // dO^T[d][q]
+                tr_issue_img(tq[dt], sQ + (qb0 + 32 * kk) * TILE_ROW_BYTES + troff[dt]);     // Q^T[d][q]
+            }
+            tr_wait4x(tdo);
+            tr_wait4x(tq);
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) {
+                const bf16x8_t dotf = tr_frag(tdo[dt]), qtf = tr_frag(tq[dt]);
+                dvacc[0][dt] = Mma<bf16_t>::mma(dotf, p0, dvacc[0][dt]);
+                dvacc[1][dt] = Mma<bf16_t>::mma(dotf, p1, dvacc[1][dt]);
+                dkacc[0][dt] = Mma<bf16_t>::mma(qtf, s0, dkacc[0][dt]);
+                dkacc[1][dt] = Mma<bf16_t>::mma(qtf, s1, dkacc[1][dt]);
+            }
+        };
+        if (active) {
+            if (!DROP) {
+                // fully unrolled (NT <= 4): the step index is a compile-time constant, so each step's part of the look-ahead loads goes straight
+                // into its own registers (through a runtime switch the compiler loads into temporaries and copies them behind a vmcnt(0))
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    if (t >= NT) break;
+                    const int qb0 = t << 6;
+                    int nqs = (S - qb0 + 15) >> 4;
+                    nqs = nqs > 4 ? 4 : nqs;
+#pragma unroll
+                    for (int kk = 0; kk < 2; ++kk) {
+                        if (2 * kk >= nqs) continue;
+                        if (more && 2 * t + kk < 6) p1_part(2 * t + kk);
+                        stp = 2 * t + kk + 1;
+                        p2_step(qb0, kk, nqs);
+                    }
+                }
+            } else {
+                // dropout instantiation: the unrolled loop spills (145 registers); all parts in front of the rolled loop
+                if (more) {
+#pragma unroll
+                    for (int k = 0; k < 6; ++k) p1_part(k);
+                }
+                stp = 6;
+                for (int t = 0; t < NT; ++t) {
+                    const int qb0 = t << 6;
+                    int nqs = (S - qb0 + 15) >> 4;
+                    nqs = nqs > 4 ? 4 : nqs;
+#pragma unroll 1
+                    for (int kk = 0; kk < 2; ++kk) {
+                        if (2 * kk >= nqs) continue;
+                        p2_step(qb0, kk, nqs);
+                    }
+                }
+            }
+        }
+        if (more) {         // the parts the loop had no step for (fewer than six steps: S <= 160; waves without a block)
+#pragma unroll
+            for (int k = 0; k < 6; ++k)
+                if (k >= stp) p1_part(k);
+        }
+        ATT_STAMP_AT(10);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // issued in front of / inside the loop: the next item's K / V pieces and phase-1 operands, the dQ stores
+        launder_p1();
+        {
+            char* DK = (char*)((bf16_t*)p.dk + (int64_t)b * p.dk_bs + h * ATT_D);
+            char* DV = (char*)((bf16_t*)p.dv + (int64_t)b * p.dv_bs + h * ATT_D);
+            int z = 0;
+            asm volatile("" : "+v"(z));
+            const uint32_t gcol = (g & 1) ? 32 + 8 * (g - 1) : 8 * g;
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt) {
+                store_block16(DK + ((uint32_t)(rowi[kt] + z) * (uint32_t)(p.dk_rs * 2) + gcol), dkacc[kt], p.scale, g, rowok[kt]);
+                store_block16(DV + ((uint32_t)(rowi[kt] + z) * (uint32_t)(p.dv_rs * 2) + gcol), dvacc[kt], 1.0f, g, rowok[kt]);
+            }
+        }
+        ATT_STAMP_AT(11);
+#ifdef ATT_STAMP
+        if (it_ == ATT_STAMP_ITEM && lane == 0 && blockIdx.x < 1024) {
+            uint64_t* o = g_att_stamps + ((int64_t)blockIdx.x * 8 + wave) * 16;
+            for (int i = 0; i < 12; ++i) o[i] = stamp_[i];
+            o[12] = __builtin_amdgcn_s_getreg((31 << 11) | 4);       // HW_ID
+            o[13] = __builtin_amdgcn_s_getreg((31 << 11) | 20);      // XCC_ID
+        }
+#endif
     }
 }
 
@@ -774,6 +1220,8 @@ bool attn_res_bwd_launch(hipStream_t st, const AttnArgs& p) {
         RES_FOR_ALL(attn_res_bwd_kernel, RES_SET_LDS, mx);
         RES_FOR_ALL(attn_res_bwd16_kernel, RES_SET_LDS, mx);
         RES_FOR_ALL(attn_res_bwd_pipe_kernel, RES_SET_LDS, mx);
+        RES_SET_LDS(attn_res_bwd_pipe2_kernel, false, false, mx);
+        RES_SET_LDS(attn_res_bwd_pipe2_kernel, true, false, mx);
         int dev = 0, cus = 0;
         if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus > 0) n_cu = cus;
         attr_set = true;
@@ -786,7 +1234,13 @@ bool attn_res_bwd_launch(hipStream_t st, const AttnArgs& p) {
         return true;
     }
     if (g_res_bwd_pipe && n_items >= 2 * n_cu) {        // several items per workgroup: otherwise there is nothing to pipeline
-        RES_DISPATCH(attn_res_bwd_pipe_kernel, dim3(n_cu), dim3(512), lds, st, p, n_items);
+        // second version (16-byte stores): every gradient row 16-byte aligned; mode 3 keeps the first version (A/B: tools/attn_pipe_ab.py)
+        const bool al16 = ((uintptr_t)p.dq | (uintptr_t)p.dk | (uintptr_t)p.dv) % 16 == 0 && (p.dq_rs | p.dk_rs | p.dv_rs | p.dq_bs | p.dk_bs | p.dv_bs) % 8 == 0;
+        // (no additive mask: the masked instantiations of the second version spill; no masked self-attention of the model is this long)
+        if (g_res_bwd_pipe != 3 && al16 && p.mask == nullptr) {
+            if (p.p_drop > 0.f) hipLaunchKernelGGL((attn_res_bwd_pipe2_kernel<true, false>), dim3(n_cu), dim3(512), lds, st, p, n_items);
+            else hipLaunchKernelGGL((attn_res_bwd_pipe2_kernel<false, false>), dim3(n_cu), dim3(512), lds, st, p, n_items);
+        } else RES_DISPATCH(attn_res_bwd_pipe_kernel, dim3(n_cu), dim3(512), lds, st, p, n_items);
         return true;
     }
     RES_DISPATCH(attn_res_bwd_kernel, dim3(p.H, p.B), dim3(512), lds, st, p);
