@@ -906,6 +906,12 @@ __global__ __launch_bounds__(512, 2) void attn_res_bwd_pipe2_kernel(AttnArgs p, 
             for (int dt = 0; dt < 4; ++dt) dqacc[rt][dt] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
         bf16x8_t kf[2][2], vf[2][2];
         if (active) {
+            // (A one-step-deep software pipeline of this loop -- the S / dP MFMAs of step j + 1 interleaved one-to-four with the softmax VALU of step j
+            //  by sched_group_barrier, every step a full step -- was bit-identical and measured 396-402 us against 384-396 for this rolled loop at the
+            //  ViT shape, 414-421 without the sched_group_barriers: profiles/r06_attn_p1_pipeline_ab.txt. Stamps: a wave ALONE on its SIMD went
+            //  7258 -> 6868 ticks for the loop, a pair 11.19 k -> 11.05 k -- MFMA, VALU and the LDS waits of a step add up on a SIMD here
+            //  whatever the order of the instructions. Removed.)
+            {
             for (int t = 0; t < NT; ++t) {
                 const int kv0 = t << 6;
                 int nkt = (S - kv0 + 15) >> 4;
@@ -914,6 +920,11 @@ __global__ __launch_bounds__(512, 2) void attn_res_bwd_pipe2_kernel(AttnArgs p, 
                 for (int kk = 0; kk < 2; ++kk) {
                     if (2 * kk >= nkt) continue;
                     f32x4_t ds[2][2];      // [rt][kt2]
+#ifndef ATT_TR_LATE
+                    TrPair tk[4];          // K^T[d][key]: issued ahead of the score MFMAs and the softmax arithmetic, which do not depend on them
+#pragma unroll
+                    for (int dt = 0; dt < 4; ++dt) tr_issue_img(tk[dt], sK + (kv0 + 32 * kk) * TILE_ROW_BYTES + troff[dt]);
+#endif
 #pragma unroll
                     for (int k2 = 0; k2 < 2; ++k2) {
                         const int kt = 2 * kk + k2;
@@ -944,9 +955,11 @@ __global__ __launch_bounds__(512, 2) void attn_res_bwd_pipe2_kernel(AttnArgs p, 
                     }
                     const bf16x8_t d0 = pack_bf16x8(ds[0][0], ds[0][1]);
                     const bf16x8_t d1 = pack_bf16x8(ds[1][0], ds[1][1]);
+#ifdef ATT_TR_LATE
                     TrPair tk[4];
 #pragma unroll
                     for (int dt = 0; dt < 4; ++dt) tr_issue_img(tk[dt], sK + (kv0 + 32 * kk) * TILE_ROW_BYTES + troff[dt]);   // K^T[d][key]
+#endif
                     tr_wait4x(tk);
 #pragma unroll
                     for (int dt = 0; dt < 4; ++dt) {
@@ -955,6 +968,7 @@ __global__ __launch_bounds__(512, 2) void attn_res_bwd_pipe2_kernel(AttnArgs p, 
                         dqacc[1][dt] = Mma<bf16_t>::mma(ktf, d1, dqacc[1][dt]);
                     }
                 }
+            }
             }
             // phase-2 operands: this wave's 32 key rows of K / V out of the images (rows past S are zero rows)
 #pragma unroll
@@ -1035,6 +1049,14 @@ __global__ __launch_bounds__(512, 2) void attn_res_bwd_pipe2_kernel(AttnArgs p, 
             for (int dt = 0; dt < 4; ++dt) { dkacc[kt][dt] = (f32x4_t){0.f, 0.f, 0.f, 0.f}; dvacc[kt][dt] = dkacc[kt][dt]; }
         auto p2_step = [&](int qb0, int kk, int nqs) {
             f32x4_t pd[2][2], ds[2][2];      // [kt][q2]
+#ifdef ATT_TR_EARLY2
+            TrPair tdo[4], tq[4];
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) {
+                tr_issue_img(tdo[dt], sDO + (qb0 + 32 * kk) * TILE_ROW_BYTES + troff[dt]);   // dO^T[d][q]
+                tr_issue_img(tq[dt], sQ + (qb0 + 32 * kk) * TILE_ROW_BYTES + troff[dt]);     // Q^T[d][q]
+            }
+#endif
 #pragma unroll
             for (int q2 = 0; q2 < 2; ++q2) {
                 const int qs = 2 * kk + q2;
@@ -1070,12 +1092,14 @@ __global__ __launch_bounds__(512, 2) void attn_res_bwd_pipe2_kernel(AttnArgs p, 
             const bf16x8_t p1 = pack_bf16x8(pd[1][0], pd[1][1]);
             const bf16x8_t s0 = pack_bf16x8(ds[0][0], ds[0][1]);
             const bf16x8_t s1 = pack_bf16x8(ds[1][0], ds[1][1]);
+#ifndef ATT_TR_EARLY2
             TrPair tdo[4], tq[4];
 #pragma unroll
             for (int dt = 0; dt < 4; ++dt) {
                 tr_issue_img(tdo[dt], sDO + (qb0 + 32 * kk) * TILE_ROW_BYTES + troff[dt]);   // dO^T[d][q]
                 tr_issue_img(tq[dt], sQ + (qb0 + 32 * kk) * TILE_ROW_BYTES + troff[dt]);     // Q^T[d][q]
             }
+#endif
             tr_wait4x(tdo);
             tr_wait4x(tq);
 #pragma unroll
