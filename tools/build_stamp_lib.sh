@@ -17,7 +17,8 @@ wait
 # build_stamp_lib.sh attn: libvalor_hip_attstamp.so = the library with csrc/attention_res.hip compiled -DATT_STAMP (tools/attn_stamp.py)
 # (ATT_DEFS="-D..." ATT_TAG=_x: extra defines / another file name; ATT_NOSTAMP=" " builds without the stamps: an A/B library for VALOR_HIP_LIB)
 if [ "$1" = "attn" ]; then
-  objs=$(ls $O/*.o | grep -v "attention_res.o")
+  objs=$(ls $O/*.o | grep -v "attention_res.o\|attention_xu.o")
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-value -Wno-unused-result ${ATT_NOSTAMP:--DATT_STAMP} ${ATT_DEFS} -c valor_amd/csrc/attention_res.hip -o /tmp/attention_res_stamp.o &&
-  /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o valor_amd/libvalor_hip_attstamp${ATT_TAG}.so $objs /tmp/attention_res_stamp.o && echo valor_amd/libvalor_hip_attstamp${ATT_TAG}.so
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-value -Wno-unused-result ${ATT_NOSTAMP:--DATT_STAMP} ${ATT_DEFS} -c valor_amd/csrc/attention_xu.hip -o /tmp/attention_xu_stamp.o &&
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o valor_amd/libvalor_hip_attstamp${ATT_TAG}.so $objs /tmp/attention_res_stamp.o /tmp/attention_xu_stamp.o && echo valor_amd/libvalor_hip_attstamp${ATT_TAG}.so
 fi

@@ -59,8 +59,29 @@ DEVINL XuSub xu_sub(const XuArgs& p, int u, int kvb) {
     return s;
 }
 
+#ifdef ATT_STAMP
+// diagnostic build only (tools/build_stamp_lib.sh attn, tools/attn_xu_stamp.py): cycle stamps of every wave around the stretches of ONE tile
+// (the XU_STAMP_TILE-th) as [workgroup][wave][16] uint64: [0] tile top, [1] K / V DMA issued, [2] vmcnt(0), [3] past barrier A, [4] S / dP /
+// softmax / dK / dV section done, [5] past barrier B, [6] dQ MFMAs done, [7] dK / dV stores issued, [8] past barrier C, [9] kernel start,
+// [10] phase 0 done (first tile top), [11] kernel end, [12] HW_ID, [13] XCC_ID
+#ifndef XU_STAMP_TILE
+#define XU_STAMP_TILE 10
+#endif
+__device__ uint64_t g_xu_stamps[1024 * 4 * 16];
+extern "C" int valor_attn_xu_read_stamps(void* dst, size_t bytes) {
+    return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_xu_stamps), bytes < sizeof(g_xu_stamps) ? bytes : sizeof(g_xu_stamps));
+}
+#define XU_STAMP_AT(i) do { if (t == XU_STAMP_TILE) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); stamp_[i] = __builtin_amdgcn_s_memtime(); } } while (0)
+#else
+#define XU_STAMP_AT(i)
+#endif
+
 template <int NQS, bool DROP>
 __global__ __launch_bounds__(256, 2) void attn_xu_bwd_kernel(XuArgs p) {
+#ifdef ATT_STAMP
+    uint64_t stamp_[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    stamp_[9] = __builtin_amdgcn_s_memtime();
+#endif
     const uint64_t rng_off0 = rng_offset(p.s[0].offset, p.rng_base), rng_off1 = rng_offset(p.s[1].offset, p.rng_base);   // once, ahead of the tile loop
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int QIMG = NQS * 16 * TILE_ROW_BYTES;      // NQS x 2 KiB
@@ -74,7 +95,8 @@ __global__ __launch_bounds__(256, 2) void attn_xu_bwd_kernel(XuArgs p) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int fr = lane & 15, g = lane >> 4;
-    const int h = blockIdx.x, kvb = blockIdx.y;
+    const int item = blockIdx.x;          // 1-D grid, an item = one (K/V batch, head)
+    const int h = item % p.H, kvb = item / p.H;
 
     const rsrc_t rsK = xu_head_rsrc(p.k, (int64_t)kvb * p.k_bs + h * ATT_D, p.Skv, p.k_rs);
     const rsrc_t rsV = xu_head_rsrc(p.v, (int64_t)kvb * p.v_bs + h * ATT_D, p.Skv, p.v_rs);
@@ -148,8 +170,13 @@ __global__ __launch_bounds__(256, 2) void attn_xu_bwd_kernel(XuArgs p) {
     const int NT = (p.Skv + 63) >> 6;
     const int prow = lane >> 3, pch = (lane & 7) ^ prow;
 
+#ifdef ATT_STAMP
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    stamp_[10] = __builtin_amdgcn_s_memtime();
+#endif
     for (int t = 0; t < NT; ++t) {
         const int kv0 = t << 6;
+        XU_STAMP_AT(0);
         // stage keys [kv0, kv0 + 64) of K and V (rows >= Skv zero filled by the descriptor): 8 + 8 pieces, 2 + 2 per wave
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
@@ -157,8 +184,11 @@ __global__ __launch_bounds__(256, 2) void attn_xu_bwd_kernel(XuArgs p) {
             glds16(rsK, sK + j * 1024, (kv0 + j * 8 + prow) * krs_b + pch * 16);
             glds16(rsV, sV + j * 1024, (kv0 + j * 8 + prow) * vrs_b + pch * 16);
         }
+        XU_STAMP_AT(1);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        XU_STAMP_AT(2);
         __syncthreads();
+        XU_STAMP_AT(3);
         const int ka = kv0 + kw0;              // first key of this wave's 16
         bf16x8_t kf[2], vf[2];
 #pragma unroll
@@ -230,7 +260,9 @@ __global__ __launch_bounds__(256, 2) void attn_xu_bwd_kernel(XuArgs p) {
                 }
             }
         }
+        XU_STAMP_AT(4);
         __syncthreads();                       // every wave's dS rows of this tile are in sDS
+        XU_STAMP_AT(5);
         {   // dQ^T[d = 16w + ..][q] += K^T[d][key] . dS^T[key][q] over the 64 keys of the tile
             const bf16x8_t kt0 = read_frag_tr_nat(sK, 0, troff_w), kt1 = read_frag_tr_nat(sK, 32, troff_w);
 #pragma unroll
@@ -244,6 +276,7 @@ __global__ __launch_bounds__(256, 2) void attn_xu_bwd_kernel(XuArgs p) {
                 dqacc[u] = Mma<bf16_t>::mma(kt1, d1, dqacc[u]);
             }
         }
+        XU_STAMP_AT(6);
         {   // dK / dV rows of this wave's 16 keys: complete, written once
             const int key = ka + fr;
             if (key < p.Skv) {
@@ -256,7 +289,9 @@ __global__ __launch_bounds__(256, 2) void attn_xu_bwd_kernel(XuArgs p) {
                 }
             }
         }
+        XU_STAMP_AT(7);
         __syncthreads();                       // K / V tile and dS buffer are free for the next tile
+        XU_STAMP_AT(8);
     }
 
     // ---- dQ: every wave owns d in [16w, 16w + 16) of every query row: acc[r] = dQ^T[d = 16w + 4g + r][q = fr]
@@ -268,6 +303,18 @@ __global__ __launch_bounds__(256, 2) void attn_xu_bwd_kernel(XuArgs p) {
         if (qr < sg.Sq)
             store4<bf16_t>((bf16_t*)sg.dq + (int64_t)sb_[u] * sg.dq_bs + (int64_t)qr * sg.dq_rs + h * ATT_D + 16 * wave + 4 * g, dqacc[u] * p.scale);
     }
+#ifdef ATT_STAMP
+    stamp_[11] = __builtin_amdgcn_s_memtime();
+    {
+        const int wg = item;
+        if (lane == 0 && wg < 1024) {
+            uint64_t* o = g_xu_stamps + ((int64_t)wg * 4 + wave) * 16;
+            for (int i = 0; i < 12; ++i) o[i] = stamp_[i];
+            o[12] = __builtin_amdgcn_s_getreg((31 << 11) | 4);       // HW_ID
+            o[13] = __builtin_amdgcn_s_getreg((31 << 11) | 20);      // XCC_ID
+        }
+    }
+#endif
 }
 
 // ------------------------------------------------------------------------------------------ forward, every pass in one launch
@@ -537,7 +584,11 @@ extern "C" int valor_cross_attn_bwd_fused(void* stream, int dtype, const void* s
     p.dk_bs = dk_bs; p.dk_rs = dk_rs; p.dv_bs = dv_bs; p.dv_rs = dv_rs;
     const int nsub = p.nsub;
     hipStream_t st = (hipStream_t)stream;
-    dim3 grid(H, kv_bmod);
+    // (768 workgroups on 512 slots: splitting the grid into two launches -- 512 workgroups, then 256 that start on an empty chip one per CU --
+    //  measured SLOWER, 398 vs 377 us: profiles/r06_attn_xu_split_ab.txt. Stamps, profiles/r06_attn_xu_stamp_base.json: a tile is 13.6 k ticks of
+    //  which 8.0 k are the score / softmax / dK / dV section -- ~1200 VALU instructions (dropout hash 300, selects 100, SGPR reloads 158) beside 100
+    //  MFMAs per wave and tile, two waves per SIMD: instruction issue, not the 1.8 k ticks a wave waits for its tile's DMA.)
+    const int n_items = H * kv_bmod;
 #define XU_I(N_, D_)                                                                                                \
     do {                                                                                                            \
         const size_t lds = 3 * N_ * 2048 + 16384 + N_ * 128;                                                        \
@@ -546,7 +597,7 @@ extern "C" int valor_cross_attn_bwd_fused(void* stream, int dtype, const void* s
             hipFuncSetAttribute((const void*)attn_xu_bwd_kernel<N_, D_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
             attr_set = true;                                                                                        \
         }                                                                                                           \
-        hipLaunchKernelGGL((attn_xu_bwd_kernel<N_, D_>), grid, dim3(256), lds, st, p);                              \
+        hipLaunchKernelGGL((attn_xu_bwd_kernel<N_, D_>), dim3(n_items), dim3(256), lds, st, p);                     \
     } while (0)
 #define XU(N_) do { if (p_drop > 0.f) XU_I(N_, true); else XU_I(N_, false); } while (0)
     if (nsub <= 4) XU(4); else if (nsub <= 6) XU(6); else if (nsub <= 8) XU(8); else XU(10);
