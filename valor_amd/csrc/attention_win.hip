@@ -597,6 +597,217 @@ __global__ __launch_bounds__(512) void win_bwd_dq_dma_kernel(WinArgs p) {
             }
     }
 }
+// ---- the same pass, every global access of a window issued a full window ahead (round 6)
+// win_bwd_dq_dma_kernel starts a window by loading its Q / dO / O rows and lse and waiting for them at once (`vmcnt(0)`, which also waits for
+// the acknowledgement of the dQ rows stored a moment earlier), fetches the next window's gather rows behind the barrier and can only issue
+// the next window's K / V DMA once those have landed (after the third key chunk): without any tile work the pass still took 355 of its 730 us
+// (profiles/r04_win_ablate_stage3.txt) -- the per-window chain rowmap -> operands / DMA -> barrier, one workgroup per CU. Here a window's
+// accesses are spread over the TWO windows before it:
+//   window wi - 2: its gather rows (rowmap: four K / V chunk offsets, the query row, the slot's rel | label)
+//   window wi - 1: its K / V DMA into the other buffer, its Q / dO / O fragments and lse into registers -- all issued right behind the barrier
+//   window wi    : `vmcnt(0)` at the top finds everything landed; the dQ rows of window wi - 1 are stored behind the barrier, not in front of
+//                  the wait.
+// Arithmetic, layouts, results: those of win_bwd_dq_dma_kernel. MAXCH = key chunks of 64 the dS-sum registers are sized for (4: windows
+// up to 256 slots; the 392-slot window's 7 chunks leave no room for the look-ahead registers and stay on the first version).
+template <bool SHIFT, int MAXCH, int NPART>
+__global__ __launch_bounds__(512) void win_bwd_dq_dma2_kernel(WinArgs p) {
+    typedef bf16_t T;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), fr = lane & 15, g = lane >> 4;
+    const int h = blockIdx.x, qq = blockIdx.y, grp = blockIdx.z;
+    const int N = p.N, npad = (N + 63) & ~63;
+    const int ntile = (N + 15) >> 4, QT = (ntile + NPART - 1) / NPART;     // NPART query partitions (blockIdx.y), QT <= 8 tiles = waves each
+    const int qt = qq * QT + wave;
+    const bool active = wave < QT && qt < ntile;                 // wave uniform
+    const int Rp = (p.R + 3) & ~3;
+    float* tb = (float*)smem;
+    int* srel = (int*)(smem + Rp * 4);                           // [2][npad]  rel | label << 16
+    char* simg = (char*)(srel + 2 * npad);                       // [2][K | V], npad * 64 B each
+    const int IMG = npad * 64;
+    win_fill_table<T>(p, tb, h, tid, 512);
+    const T* qkv = (const T*)p.qkv;
+    const int64_t ld = 3 * (int64_t)p.C;
+    const int ldb = 3 * p.C * 2, kcol = (p.C + h * WIN_D) * 2, vcol = 2 * p.C;      // bytes
+    const int nwin = p.B * p.nW, w_first = grp * p.wpb;
+    const int count = min(p.wpb, nwin - w_first);
+    const int qr = qt * 16 + fr;
+    const bool qok = active && qr < N;
+    const int tro0 = win_tr_off(lane, 0), tro1 = win_tr_off(lane, 1);
+
+    // a window's gather rows as this thread needs them, RAW: unconditional loads from clamped indices, nothing computed from them before the
+    // `vmcnt(0)` of the window that consumes them (a predicated load with arithmetic behind it is a load + an immediate wait + a select)
+    struct Idx { int rm[4]; int lab; int qrm; };
+    int nclamp[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { const int n = (tid + 512 * k) >> 2; nclamp[k] = n < N ? n : N - 1; }
+    const int tclamp = tid < N ? tid : N - 1, qclamp = qr < N ? qr : N - 1;
+    const int myrel = p.rel[tclamp];                             // the same for every window
+    auto fetch_idx = [&](int gw, Idx& x) {
+        const int* rmw = p.rowmap + (gw % p.nW) * N;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) x.rm[k] = rmw[nclamp[k]];
+        x.lab = SHIFT ? (int)p.label[(gw % p.nW) * N + tclamp] : 0;
+        x.qrm = rmw[qclamp];
+    };
+    auto launder_idx = [&](Idx& x) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) asm volatile("" : "+v"(x.rm[k]));
+        asm volatile("" : "+v"(x.lab));
+        asm volatile("" : "+v"(x.qrm));
+    };
+    auto idx_rel = [&](const Idx& x) { return tid < N ? (myrel | (x.lab << 16)) : 0; };
+    auto idx_qrow = [&](int gw, const Idx& x) { return qok ? (gw / p.nW) * p.rows_per_sample + x.qrm : 0; };
+    auto issue = [&](int gw, int buf, const Idx& x) {
+        const int b = gw / p.nW;
+        const rsrc_t rs = make_rsrc(qkv + (int64_t)b * p.rows_per_sample * ld, (uint32_t)p.rows_per_sample * (uint32_t)ldb);
+        char* dK = simg + buf * 2 * IMG;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int base = (wave * 64 + 512 * k) * 16;         // wave-uniform LDS address; lanes land at + lane * 16
+            if (base < IMG) {
+                const int idx = tid + 512 * k, n = idx >> 2;     // this thread's chunk: slot n, LDS chunk position idx & 3, source chunk swizzled
+                const int voff = n < N ? x.rm[k] * ldb + kcol + (((idx & 3) ^ ((n >> 2) & 3)) << 4) : 0x7fffff00;   // past the window: out of range, zero fill
+                glds16(rs, dK + base, voff);
+                glds16(rs, dK + IMG + base, voff + vcol);
+            }
+        }
+    };
+    struct Ops { bf16x8_t q, dO, o; float lse; };                // a window's register operands: this lane's query row
+    auto fetch_ops = [&](int gw, int qrow, Ops& x) {
+        x.q = win_load_frag<T>(qkv + (int64_t)qrow * ld + h * WIN_D, 0, g, qok);
+        x.dO = win_load_frag<T>((const T*)p.dout + (int64_t)qrow * p.C + h * WIN_D, 0, g, qok);
+        x.o = win_load_frag<T>((const T*)p.o + (int64_t)qrow * p.C + h * WIN_D, 0, g, qok);
+        x.lse = qok ? p.lse[((int64_t)gw * p.heads + h) * N + qr] : 0.f;
+    };
+    auto launder_ops = [&](Ops& x) {
+        asm volatile("" : "+v"(x.q)); asm volatile("" : "+v"(x.dO)); asm volatile("" : "+v"(x.o)); asm volatile("" : "+v"(x.lse));
+    };
+
+    f32x4_t bacc[MAXCH][4];
+#pragma unroll
+    for (int c = 0; c < MAXCH; ++c)
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt) bacc[c][kt] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+
+    Idx i1 = {}, i2 = {};                                        // gather rows of windows wi + 1 / wi + 2
+    Ops cur_ops = {}, nxt_ops = {};
+    int qrow0 = 0;
+    if (count > 0) {
+        Idx i0;
+        fetch_idx(w_first, i0);
+        if (count > 1) fetch_idx(w_first + 1, i1);
+        issue(w_first, 0, i0);                                   // (the compiler waits for i0's rows here: once per workgroup)
+        if (tid < npad) srel[tid] = idx_rel(i0);
+        qrow0 = idx_qrow(w_first, i0);
+        fetch_ops(w_first, qrow0, cur_ops);
+    }
+    u32x2_t pend[2] = {(u32x2_t){0u, 0u}, (u32x2_t){0u, 0u}};    // dQ row of the previous window, packed: stored behind the next barrier
+    int pend_row = -1;
+    const float scale2 = p.scale * LOG2E_F;
+    for (int wi = 0; wi < count; ++wi) {
+        const int gw = w_first + wi, cur = wi & 1;
+        const bool has_next = wi + 1 < count;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // issued a window ago: this wave's DMAs of buffer `cur`, this window's operands, the
+        launder_ops(cur_ops);                                      // next window's gather rows; the previous dQ rows
+        launder_idx(i1);
+        __syncthreads();                                           // everyone's DMAs have landed; everyone is done with the other buffer
+        if (pend_row >= 0) {
+            T* drow = (T*)p.dqkv + (int64_t)pend_row * ld + h * WIN_D;
+            *(u32x2_t*)(drow + 4 * g) = pend[0];
+            *(u32x2_t*)(drow + 16 + 4 * g) = pend[1];
+        }
+        if (has_next) {
+            issue(gw + 1, cur ^ 1, i1);
+            if (tid < npad) srel[(cur ^ 1) * npad + tid] = idx_rel(i1);
+            fetch_ops(gw + 1, idx_qrow(gw + 1, i1), nxt_ops);
+            if (wi + 2 < count) fetch_idx(gw + 2, i2);
+        }
+        const int64_t stat = ((int64_t)gw * p.heads + h) * N + qr;
+        const bf16x8_t qf = cur_ops.q, dof = cur_ops.dO, of = cur_ops.o;
+        const float lse2 = qok ? cur_ops.lse * LOG2E_F : INFINITY;   // rows past the window: 2^(s - inf) = 0
+        const char* sK = simg + cur * 2 * IMG;
+        const char* sV = sK + IMG;
+        const int* rel = srel + cur * npad;
+        float dl = 0.f;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) dl += (float)dof[i] * (float)of[i];
+        dl += __shfl_xor(dl, 16, 64);
+        dl += __shfl_xor(dl, 32, 64);
+        if (qok && g == 0) p.delta[stat] = dl;
+        const int relq = rel[active ? qr : 0] + p.relc;
+        f32x4_t dqacc[2] = {(f32x4_t){0.f, 0.f, 0.f, 0.f}, (f32x4_t){0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+        for (int c = 0; c < MAXCH; ++c) {
+            int k0 = c * 64;
+            asm volatile("" : "+s"(k0));        // opaque per chunk: derived LDS offsets are not hoisted for all chunks at once (SGPR spills)
+            if (active && k0 < npad) {
+                f32x4_t sacc[4], dpacc[4];
+#pragma unroll
+                for (int kt = 0; kt < 4; ++kt) {
+                    const f32x4_t z = {0.f, 0.f, 0.f, 0.f};
+                    sacc[kt] = Mma<T>::mma(win_frag_sw(sK, k0 + kt * 16 + fr, g), qf, z);
+                    dpacc[kt] = Mma<T>::mma(win_frag_sw(sV, k0 + kt * 16 + fr, g), dof, z);
+                }
+                TrPair ktr[2][2];                               // K^T fragments [kk][dt] for the dQ contraction fly under the score math
+#pragma unroll
+                for (int kk = 0; kk < 2; ++kk) {
+                    tr_issue(ktr[kk][0], sK + (k0 + 32 * kk) * 64 + tro0);
+                    tr_issue(ktr[kk][1], sK + (k0 + 32 * kk) * 64 + tro1);
+                }
+#pragma unroll
+                for (int kt = 0; kt < 4; ++kt) {
+                    const int kb = k0 + kt * 16 + 4 * g;
+                    const i32x4_t rk = *(const i32x4_t*)&rel[kb];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int X = relq - rk[r];
+                        float v = sacc[kt][r] * scale2 + tb[WIN_TBI(SHIFT ? (X & 0xffff) : X)];
+                        if (SHIFT) v = (uint32_t)X > 0xffffu ? v - WIN_MASK2 : v;
+                        sacc[kt][r] = fexp2<T>(v - lse2) * (dpacc[kt][r] - dl);
+                    }
+                }
+                if (k0 + 64 > N) {                               // the chunk that holds the window's last slot (block uniform): slots past N carry no dS
+#pragma unroll
+                    for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) sacc[kt][r] = k0 + kt * 16 + 4 * g + r < N ? sacc[kt][r] : 0.f;
+                }
+#pragma unroll
+                for (int kt = 0; kt < 4; ++kt) bacc[c][kt] += sacc[kt];
+                tr_wait4(ktr);
+#pragma unroll
+                for (int kk = 0; kk < 2; ++kk) {
+                    const bf16x8_t pf = pack_bf16x8(sacc[2 * kk], sacc[2 * kk + 1]);
+                    dqacc[0] = Mma<T>::mma(tr_frag(ktr[kk][0]), pf, dqacc[0]);
+                    dqacc[1] = Mma<T>::mma(tr_frag(ktr[kk][1]), pf, dqacc[1]);
+                }
+            }
+        }
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt) {
+            const f32x4_t v = dqacc[dt] * p.scale;
+            pend[dt] = (u32x2_t){pack2_bf16(v[0], v[1]), pack2_bf16(v[2], v[3])};
+        }
+        pend_row = qok ? qrow0 : -1;
+        qrow0 = idx_qrow(gw + 1, i1);
+        cur_ops = nxt_ops;
+        i1 = i2;
+    }
+    if (pend_row >= 0) {
+        T* drow = (T*)p.dqkv + (int64_t)pend_row * ld + h * WIN_D;
+        *(u32x2_t*)(drow + 4 * g) = pend[0];
+        *(u32x2_t*)(drow + 16 + 4 * g) = pend[1];
+    }
+    if (qok) {
+        float* part = p.dbias_part + (((int64_t)grp * p.heads + h) * N + qr) * npad;
+#pragma unroll
+        for (int c = 0; c < MAXCH; ++c)
+            if (c * 64 < npad) {
+#pragma unroll
+                for (int kt = 0; kt < 4; ++kt) *(f32x4_t*)(part + c * 64 + kt * 16 + 4 * g) = bacc[c][kt];
+            }
+    }
+}
 static int win_lds_dq_dma(int R, int npad) { return ((R + 3) & ~3) * 4 + 2 * npad * 4 + 4 * npad * 64; }
 
 // ------------------------------------------------------------------------------------------ forward / dK,dV, LDS-DMA edition (bf16)
@@ -616,6 +827,75 @@ DEVINL void win_dma_stage2(const WinArgs& p, int b, int w, int N, int npad, cons
             const int row = n < N ? p.rowmap[w * N + n] : -1;
             glds16(rs0, img0 + base, row >= 0 ? row * ld0b + col0b + csrc : 0x7fffff00);
             glds16(rs1, img1 + base, row >= 0 ? row * ld1b + col1b + csrc : 0x7fffff00);
+        }
+    }
+}
+// the same in two steps for 512 threads: the gather rows of this thread's (at most four) chunks by unconditional clamped loads -- issue them with the
+// rest of the prologue's loads -- and the DMAs once they have landed (win_dma_stage2 loads and waits once per chunk)
+DEVINL void win_dma_rows(const WinArgs& p, int w, int N, int tid, int (&rows)[4]) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int n = (tid + 512 * k) >> 2;
+        rows[k] = p.rowmap[w * N + (n < N ? n : N - 1)];
+    }
+}
+DEVINL void win_dma_issue2(const WinArgs& p, int b, int N, int npad, int (&rows)[4], const bf16_t* src0, int ld0b, int col0b, const bf16_t* src1,
+                           int ld1b, int col1b, char* img0, char* img1, int tid, int wave) {
+    // every row is waited for HERE, in front of the first DMA (a first use behind a DMA waits for that DMA too: vmcnt(0))
+#pragma unroll
+    for (int k = 0; k < 4; ++k) asm volatile("" : "+v"(rows[k]));
+    const rsrc_t rs0 = make_rsrc(src0 + (int64_t)b * p.rows_per_sample * (ld0b / 2), (uint32_t)p.rows_per_sample * (uint32_t)ld0b);
+    const rsrc_t rs1 = make_rsrc(src1 + (int64_t)b * p.rows_per_sample * (ld1b / 2), (uint32_t)p.rows_per_sample * (uint32_t)ld1b);
+    const int IMG = npad * 64;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int idx = tid + 512 * k, n = idx >> 2;
+        const int base = (wave * 64 + 512 * k) * 16;
+        if (base < IMG) {
+            const int csrc = ((idx & 3) ^ ((n >> 2) & 3)) << 4;
+            glds16(rs0, img0 + base, n < N ? rows[k] * ld0b + col0b + csrc : 0x7fffff00);
+            glds16(rs1, img1 + base, n < N ? rows[k] * ld1b + col1b + csrc : 0x7fffff00);
+        }
+    }
+}
+
+// ---- prologue of the one-window-per-workgroup LDS-DMA kernels, every global load in flight at once (round 6)
+// win_fill_table / the `tid < N ? f(load) : c` slot lines compile to load -> wait -> use, one global latency after the other: five for the
+// table column (2535 entries, 512 threads), one each for rel, the label, lse and delta -- on top of rowmap -> DMA. Here the loads are issued
+// UNCONDITIONALLY from clamped indices into registers (win_pro_load: call it first thing), the conversions and LDS writes happen after the
+// caller's single `vmcnt(0)` (win_pro_store). Table columns of more than 4096 entries finish in a plain loop.
+#define WIN_PRO_T 8
+struct WinPro { uint16_t t[WIN_PRO_T]; int rel, lab; float lse, dl; };
+template <bool SHIFT, bool STATS>
+DEVINL void win_pro_load(const WinArgs& p, WinPro& x, int h, int gw, int w, int N, int tid) {
+    const uint16_t* t = (const uint16_t*)p.table;
+#pragma unroll
+    for (int i = 0; i < WIN_PRO_T; ++i) {
+        const int r = tid + 512 * i;
+        x.t[i] = (WIN_ABLATE & 1) ? (uint16_t)0 : t[(int64_t)(r < p.R ? r : p.R - 1) * p.heads + h];
+    }
+    const int tc = tid < N ? tid : N - 1;
+    x.rel = p.rel[tc];
+    x.lab = SHIFT ? (int)p.label[w * N + tc] : 0;
+    x.lse = 0.f; x.dl = 0.f;
+    if (STATS) {
+        const int64_t stat = ((int64_t)gw * p.heads + h) * N + tc;
+        x.lse = p.lse[stat]; x.dl = p.delta[stat];
+    }
+}
+template <bool STATS>
+DEVINL void win_pro_store(const WinArgs& p, const WinPro& x, float* tb, int* rel, float* s_lse, float* s_dl, int h, int N, int npad, int tid) {
+#pragma unroll
+    for (int i = 0; i < WIN_PRO_T; ++i) {
+        const int r = tid + 512 * i;
+        if (r < p.R) tb[r] = __builtin_bit_cast(float, (uint32_t)x.t[i] << 16) * LOG2E_F;
+    }
+    for (int r = tid + 512 * WIN_PRO_T; r < p.R; r += 512) tb[r] = to_f32<bf16_t>(((const bf16_t*)p.table)[(int64_t)r * p.heads + h]) * LOG2E_F;
+    if (tid < npad) {
+        rel[tid] = tid < N ? (x.rel | (x.lab << 16)) : 0;
+        if (STATS) {
+            s_lse[tid] = tid < N ? x.lse * LOG2E_F : INFINITY;       // log2 domain; slots past the window: p = 2^(s - inf) = 0
+            s_dl[tid] = tid < N ? x.dl : 0.f;
         }
     }
 }
@@ -730,7 +1010,10 @@ __global__ __launch_bounds__(512) void win_fwd_dma_kernel(WinArgs p) {
 static int win_lds_fwd_dma(int R, int npad) { return ((R + 3) & ~3) * 4 + npad * 4 + 2 * npad * 64; }
 
 // grid (heads, B*nW), 512 threads, 2 workgroups per CU. LDS: table column, rel, lse, delta, Q and dO row images.
-template <bool SHIFT>
+// KR > 0 (windows of up to 128 KR slots; the launcher uses KR = 2): this wave's key tiles are wave, wave + 8, ...: their gather rows are fetched in front
+// of the staging and the first tile's K / V fragments behind it, under the prologue's own wait; a later tile's fragments are loaded while the tile
+// before it is computed. KR = 0: loaded at the top of each tile (rowmap, then the rows: two dependent global latencies exposed per tile).
+template <bool SHIFT, int KR>
 __global__ __launch_bounds__(512) void win_bwd_dkv_dma_kernel(WinArgs p) {
     typedef bf16_t T;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -745,25 +1028,70 @@ __global__ __launch_bounds__(512) void win_bwd_dkv_dma_kernel(WinArgs p) {
     char* sdO = sQ + IMG;
     const T* qkv = (const T*)p.qkv;
     const int64_t ld = 3 * (int64_t)p.C;
-    win_dma_stage2(p, b, w, N, npad, qkv, 3 * p.C * 2, h * WIN_D * 2, (const T*)p.dout, p.C * 2, h * WIN_D * 2, sQ, sdO, tid, wave, 512);
-    win_fill_table<T>(p, tb, h, tid, 512);
-    if (tid < npad) {
-        const int64_t stat = ((int64_t)gw * p.heads + h) * N + tid;
-        rel[tid] = tid < N ? (p.rel[tid] | (p.label ? (int)p.label[w * N + tid] << 16 : 0)) : 0;
-        s_lse[tid] = tid < N ? p.lse[stat] * LOG2E_F : INFINITY;       // log2 domain; slots past the window: p = 2^(s - inf) = 0
-        s_dl[tid] = tid < N ? p.delta[stat] : 0.f;
+    WinPro pro;
+    if constexpr (KR > 0) win_pro_load<SHIFT, true>(p, pro, h, gw, w, N, tid);
+    int krow_[KR > 0 ? KR : 1];
+    if constexpr (KR > 0) {
+#pragma unroll
+        for (int r = 0; r < KR; ++r) {
+            const int kr = (wave + 8 * r) * 16 + fr;
+            krow_[r] = p.rowmap[w * N + (kr < N ? kr : N - 1)];  // unconditional (clamped): nothing is computed from it before it has landed
+        }
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    auto kv_frags = [&](int r, u32x4_t& kraw, u32x4_t& vraw) {    // unconditional loads (rows past the window: its last row; zeroed where consumed)
+        const T* rowp = qkv + (int64_t)(b * p.rows_per_sample + krow_[r]) * ld + h * WIN_D + g * 8;
+        kraw = *(const u32x4_t*)(rowp + p.C);
+        vraw = *(const u32x4_t*)(rowp + 2 * p.C);
+    };
+    u32x4_t kraw_n = {0u, 0u, 0u, 0u}, vraw_n = kraw_n;
+    if constexpr (KR > 0) {
+        int rows4[4];
+        win_dma_rows(p, w, N, tid, rows4);
+        // ONE wait for every gather row (the DMAs' and this wave's key rows), in front of the DMAs: a first use behind them would wait for
+        // the DMAs as well (loads and LDS-DMA pending together: the compiler's counter model only allows vmcnt(0))
+#pragma unroll
+        for (int r = 0; r < KR; ++r) asm volatile("" : "+v"(krow_[r]));
+        kv_frags(0, kraw_n, vraw_n);
+        win_dma_issue2(p, b, N, npad, rows4, qkv, 3 * p.C * 2, h * WIN_D * 2, (const T*)p.dout, p.C * 2, h * WIN_D * 2, sQ, sdO, tid, wave);
+    } else {
+        win_dma_stage2(p, b, w, N, npad, qkv, 3 * p.C * 2, h * WIN_D * 2, (const T*)p.dout, p.C * 2, h * WIN_D * 2, sQ, sdO, tid, wave, 512);
+    }
+    if constexpr (KR > 0) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        win_pro_store<true>(p, pro, tb, rel, s_lse, s_dl, h, N, npad, tid);
+    } else {
+        win_fill_table<T>(p, tb, h, tid, 512);
+        if (tid < npad) {
+            const int64_t stat = ((int64_t)gw * p.heads + h) * N + tid;
+            rel[tid] = tid < N ? (p.rel[tid] | (p.label ? (int)p.label[w * N + tid] << 16 : 0)) : 0;
+            s_lse[tid] = tid < N ? p.lse[stat] * LOG2E_F : INFINITY;       // log2 domain; slots past the window: p = 2^(s - inf) = 0
+            s_dl[tid] = tid < N ? p.delta[stat] : 0.f;
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
     __syncthreads();
     const int tro0 = win_tr_off(lane, 0), tro1 = win_tr_off(lane, 1);
     const float scale2 = p.scale * LOG2E_F;
 
-    for (int kt = wave; kt * 16 < N && !(WIN_ABLATE & 2); kt += 8) {
+#pragma unroll
+    for (int rnd = 0; rnd < (KR > 0 ? KR : 4); ++rnd) {
+        const int kt = wave + 8 * rnd;
+        if (kt * 16 >= N || (WIN_ABLATE & 2)) break;
         const int kr = kt * 16 + fr;
         const bool kok = kr < N;
-        const int krow = kok ? b * p.rows_per_sample + p.rowmap[w * N + kr] : 0;
-        const bf16x8_t kf = win_load_frag<T>(qkv + (int64_t)krow * ld + p.C + h * WIN_D, 0, g, kok);
-        const bf16x8_t vf = win_load_frag<T>(qkv + (int64_t)krow * ld + 2 * p.C + h * WIN_D, 0, g, kok);
+        int krow;
+        bf16x8_t kf, vf;
+        if constexpr (KR > 0) {
+            krow = kok ? b * p.rows_per_sample + krow_[rnd] : 0;
+            const u32x4_t z4 = {0u, 0u, 0u, 0u};
+            kf = __builtin_bit_cast(bf16x8_t, kok ? kraw_n : z4);
+            vf = __builtin_bit_cast(bf16x8_t, kok ? vraw_n : z4);
+            if (rnd + 1 < KR) kv_frags(rnd + 1, kraw_n, vraw_n);     // the next tile's fragments fly under this tile (loaded even when there is no next tile: a valid row)
+        } else {
+            krow = kok ? b * p.rows_per_sample + p.rowmap[w * N + kr] : 0;
+            kf = win_load_frag<T>(qkv + (int64_t)krow * ld + p.C + h * WIN_D, 0, g, kok);
+            vf = win_load_frag<T>(qkv + (int64_t)krow * ld + 2 * p.C + h * WIN_D, 0, g, kok);
+        }
         const int kneg = p.relc - rel[kr];           // X = relx[q] + relc - relx[key]
         f32x4_t dkacc[2] = {(f32x4_t){0.f, 0.f, 0.f, 0.f}, (f32x4_t){0.f, 0.f, 0.f, 0.f}};
         f32x4_t dvacc[2] = {(f32x4_t){0.f, 0.f, 0.f, 0.f}, (f32x4_t){0.f, 0.f, 0.f, 0.f}};
@@ -818,6 +1146,11 @@ __global__ __launch_bounds__(512) void win_bwd_dkv_dma_kernel(WinArgs p) {
                 dkacc[0] = Mma<T>::mma(tr_frag(qtr[kk][0]), df, dkacc[0]);
                 dkacc[1] = Mma<T>::mma(tr_frag(qtr[kk][1]), df, dkacc[1]);
             }
+        }
+        if constexpr (KR > 0) {
+            // the next tile's fragments are waited for HERE, in front of this tile's stores: with loads and stores both pending the compiler's
+            // counter model only allows vmcnt(0), which would make the next tile wait for these stores' acknowledgements
+            if (rnd + 1 < KR) { asm volatile("" : "+v"(kraw_n)); asm volatile("" : "+v"(vraw_n)); }
         }
         if (kok) {
             T* drow = (T*)p.dqkv + (int64_t)krow * ld + h * WIN_D;
@@ -990,6 +1323,8 @@ static bool win_check(const WinArgs& p) {
 
 // kernel family bits (bf16 only; fp32 always runs the register-staged kernels): 1 = LDS-DMA dQ pass (8-12 % faster backward),
 // 2 = LDS-DMA forward (measured equal to the register-staged forward: off), 4 = LDS-DMA dK/dV pass (a further 7-9 %). Default 5.
+// A/B bits of round 6 (windows up to 256 slots): 8 = the FIRST version of the LDS-DMA dQ pass instead of the look-ahead version, 16 = four query
+// partitions instead of two in the look-ahead version.
 static int g_win_variant = [] { const char* e = getenv("VALOR_WIN_VARIANT"); return e ? atoi(e) : 5; }();
 extern "C" int valor_win_attn_set_variant(int v) {
     const int old = g_win_variant;
@@ -1053,7 +1388,18 @@ static int win_bwd_launch(hipStream_t st, const WinArgs& p, void* dtable, int ac
     const bool dkv_dma = (g_win_variant & 4) && ElemTraits<T>::DT == VALOR_DT_BF16 && (int64_t)p.rows_per_sample * 3 * p.C * 2 < 0x7fff0000ll;
     const bool dma = (g_win_variant & 1) && ElemTraits<T>::DT == VALOR_DT_BF16 && l1d <= WIN_LDS_MAX &&
                      (int64_t)p.rows_per_sample * 3 * p.C * 2 < 0x7fff0000ll;
-    if (dma) {
+    if (dma && npad <= 256 && !(g_win_variant & 8)) {          // look-ahead version (variant bit 3 set: the first version, for A/B)
+        const int ntile = (p.N + 15) >> 4;
+        // two query partitions of up to 8 waves instead of four of up to 4 (round 4 measured the same split SLOWER on the first version, 880 -> 1010 us;
+        // with the look-ahead it is 14-18 % faster on the whole backward bundle, profiles/r06_win_dq2_parts_ab.json); variant bit 4: four partitions
+        const bool two = !(g_win_variant & 16) && (ntile + 1) / 2 <= 8;
+#define WIN_DQ2(S_, P_) do { \
+            hipFuncSetAttribute((const void*)win_bwd_dq_dma2_kernel<S_, 4, P_>, hipFuncAttributeMaxDynamicSharedMemorySize, l1d); \
+            hipLaunchKernelGGL((win_bwd_dq_dma2_kernel<S_, 4, P_>), dim3(p.heads, P_, G), dim3(512), l1d, st, p); } while (0)
+        if (p.label) { if (two) WIN_DQ2(true, 2); else WIN_DQ2(true, 4); }
+        else { if (two) WIN_DQ2(false, 2); else WIN_DQ2(false, 4); }
+#undef WIN_DQ2
+    } else if (dma) {
         if (p.label) {
             hipFuncSetAttribute((const void*)win_bwd_dq_dma_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, l1d);
             hipLaunchKernelGGL((win_bwd_dq_dma_kernel<true>), dim3(p.heads, 4, G), dim3(512), l1d, st, p);
@@ -1067,16 +1413,26 @@ static int win_bwd_launch(hipStream_t st, const WinArgs& p, void* dtable, int ac
         hipFuncSetAttribute((const void*)win_bwd_dkv_kernel<T, true>, hipFuncAttributeMaxDynamicSharedMemorySize, l2);
         if (!dma) hipLaunchKernelGGL((win_bwd_dq_kernel<T, true>), dim3(p.heads, 4, G), dim3(512), l1, st, p);
         if (dkv_dma) {
-            hipFuncSetAttribute((const void*)win_bwd_dkv_dma_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, l2d);
-            hipLaunchKernelGGL((win_bwd_dkv_dma_kernel<true>), dim3(p.heads, p.B * p.nW), dim3(512), l2d, st, p);
+            if (npad <= 256 && !(g_win_variant & 32)) {          // (variant bit 5: without the operand look-ahead, for A/B)
+                hipFuncSetAttribute((const void*)win_bwd_dkv_dma_kernel<true, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, l2d);
+                hipLaunchKernelGGL((win_bwd_dkv_dma_kernel<true, 2>), dim3(p.heads, p.B * p.nW), dim3(512), l2d, st, p);
+            } else {
+                hipFuncSetAttribute((const void*)win_bwd_dkv_dma_kernel<true, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, l2d);
+                hipLaunchKernelGGL((win_bwd_dkv_dma_kernel<true, 0>), dim3(p.heads, p.B * p.nW), dim3(512), l2d, st, p);
+            }
         } else hipLaunchKernelGGL((win_bwd_dkv_kernel<T, true>), dim3(p.heads, p.B * p.nW), dim3(1024), l2, st, p);
     } else {
         hipFuncSetAttribute((const void*)win_bwd_dq_kernel<T, false>, hipFuncAttributeMaxDynamicSharedMemorySize, l1);
         hipFuncSetAttribute((const void*)win_bwd_dkv_kernel<T, false>, hipFuncAttributeMaxDynamicSharedMemorySize, l2);
         if (!dma) hipLaunchKernelGGL((win_bwd_dq_kernel<T, false>), dim3(p.heads, 4, G), dim3(512), l1, st, p);
         if (dkv_dma) {
-            hipFuncSetAttribute((const void*)win_bwd_dkv_dma_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, l2d);
-            hipLaunchKernelGGL((win_bwd_dkv_dma_kernel<false>), dim3(p.heads, p.B * p.nW), dim3(512), l2d, st, p);
+            if (npad <= 256 && !(g_win_variant & 32)) {
+                hipFuncSetAttribute((const void*)win_bwd_dkv_dma_kernel<false, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, l2d);
+                hipLaunchKernelGGL((win_bwd_dkv_dma_kernel<false, 2>), dim3(p.heads, p.B * p.nW), dim3(512), l2d, st, p);
+            } else {
+                hipFuncSetAttribute((const void*)win_bwd_dkv_dma_kernel<false, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, l2d);
+                hipLaunchKernelGGL((win_bwd_dkv_dma_kernel<false, 0>), dim3(p.heads, p.B * p.nW), dim3(512), l2d, st, p);
+            }
         } else hipLaunchKernelGGL((win_bwd_dkv_kernel<T, false>), dim3(p.heads, p.B * p.nW), dim3(1024), l2, st, p);
     }
     const int64_t n4 = (int64_t)p.heads * p.N * npad / 4;
