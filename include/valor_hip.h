@@ -261,9 +261,10 @@ int valor_attn_bwd(void* stream, int dtype, const void* q, const void* k, const 
  * it). rel int32 [N]: linearised (d,h,w) of a slot in the FULL window, bias(i,j) = table[rel[i]-rel[j]+relc][head]; table
  * [table_rows][heads]. label uint8 [nW*N] region ids of the shift mask (NULL = unshifted): -100 where labels differ.
  * lse fp32 [B*nW][heads][N]. bf16: N <= 448; fp32 (parity mode): forward N <= 448, backward N <= 192 (the window is LDS resident; VALOR_ERR_ARG beyond). */
-/* kernel family bits for A/B tests (bf16): 1 = LDS-DMA dQ pass, 2 = LDS-DMA forward, 4 = LDS-DMA dK/dV pass (default 5); 8 = the first
- * version of the LDS-DMA dQ pass instead of the look-ahead version, 16 = four query partitions instead of two in it (windows up to 256 slots);
- * every combination computes the same bits. Returns the previous value, v < 0 only queries */
+/* kernel family bits for A/B tests (bf16): 1 = LDS-DMA dQ pass, 2 = LDS-DMA forward, 4 = LDS-DMA dK/dV pass (default 7); 8 = the first
+ * version of the LDS-DMA dQ pass instead of the look-ahead version, 16 = four query partitions instead of two in it, 32 / 64 = the dK/dV
+ * pass / the forward without their operand look-ahead (windows up to 256 slots); every combination computes the same bits. Returns the
+ * previous value, v < 0 only queries */
 int valor_win_attn_set_variant(int v);
 int valor_win_attn_workspace_floats(int B, int nW, int N, int heads);   /* fp32 elements the backward needs */
 int valor_win_attn_fwd(void* stream, int dtype, const void* qkv, void* o, float* lse, const int* rowmap, const int* rel,

@@ -59,15 +59,17 @@ def _ref_window_attention(qkv, table, heads, size, window, shifted):
     (torch.bfloat16, (16, 7, 7), True),                                            # two windows along time, shift (4,0,0)
     (torch.bfloat16, (16, 14, 14), True),                                          # shift in all three dims
     (torch.bfloat16, (2, 7, 7), False),                                            # one small window, N = 98 (sliced bias index)
-    (torch.bfloat16, (4, 14, 14), True), (torch.bfloat16, (4, 7, 7), False),       # N = 196: the bench window (8 frames -> 4 slices): 13
+    (torch.bfloat16, (4, 14, 14), True), (torch.bfloat16, (4, 7, 7), False),       # N = 196 (windows of up to 256 slots: the round-6 look-ahead kernels): 13
                                                                                    # query tiles on 2 partitions, a last chunk of ONE key tile
     (torch.float32, (2, 14, 14), True), (torch.float32, (1, 7, 7), False),         # parity-mode instantiation
     (torch.float32, (8, 14, 14), True), (torch.float32, (8, 7, 7), False),         # ... at the PRODUCTION window (392 slots): the
 ])                                                                                 # row-image-only (NOTR) backward
-@pytest.mark.parametrize("win_variant", [7, 5, 0])
+@pytest.mark.parametrize("win_variant", [7, 127, 5, 0])
 def test_window_attention(dev, dtype, size, shifted, win_variant):
     """kernel family bits: 1 = LDS-DMA double-buffered dQ pass, 2 = LDS-DMA forward, 4 = LDS-DMA dK/dV pass; 0 = the
-    register-staged kernels (always used for fp32)"""
+    register-staged kernels (always used for fp32). 7 is the default: for windows of up to 256 slots the round-6 look-ahead forms (dQ pass
+    on two query partitions with every access of a window issued a window ahead, dK/dV pass and forward with prefetched operands and a
+    one-wait prologue); 127 = 7 + the A/B bits 8 | 16 | 32 | 64 that select the first versions of those three kernels."""
     from valor_amd import lib, ops
     if dtype == torch.float32 and win_variant != 0:
         pytest.skip("the fp32 instantiation has one dQ pass")

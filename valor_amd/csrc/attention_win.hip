@@ -608,7 +608,7 @@ __global__ __launch_bounds__(512) void win_bwd_dq_dma_kernel(WinArgs p) {
 //   window wi    : `vmcnt(0)` at the top finds everything landed; the dQ rows of window wi - 1 are stored behind the barrier, not in front of
 //                  the wait.
 // Arithmetic, layouts, results: those of win_bwd_dq_dma_kernel. MAXCH = key chunks of 64 the dS-sum registers are sized for (4: windows
-// up to 256 slots; the 392-slot window's 7 chunks leave no room for the look-ahead registers and stay on the first version).
+// up to 256 slots, 205-210 VGPRs -- the only instantiation the launcher uses, see there), NPART = query partitions.
 template <bool SHIFT, int MAXCH, int NPART>
 __global__ __launch_bounds__(512) void win_bwd_dq_dma2_kernel(WinArgs p) {
     typedef bf16_t T;
@@ -901,7 +901,10 @@ DEVINL void win_pro_store(const WinArgs& p, const WinPro& x, float* tb, int* rel
 }
 
 // grid (heads, B*nW), 512 threads, 2 workgroups per CU. LDS: table column, rel, K and V row images.
-template <bool SHIFT>
+// QR > 0 (windows of up to 128 QR slots; the launcher uses QR = 2 up to 256 slots, else 4): the one-wait prologue (win_pro_load / win_dma_rows) and this wave's query rows
+// fetched ahead -- gather rows in front of the staging, the first tile's Q fragment under the prologue's wait, a later tile's under the tile before
+// it. QR = 0: the first version (every load where it is used).
+template <bool SHIFT, int QR>
 __global__ __launch_bounds__(512) void win_fwd_dma_kernel(WinArgs p) {
     typedef bf16_t T;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -915,19 +918,54 @@ __global__ __launch_bounds__(512) void win_fwd_dma_kernel(WinArgs p) {
     const T* qkv = (const T*)p.qkv;
     const int64_t ld = 3 * (int64_t)p.C;
     const int ldb = 3 * p.C * 2;
-    win_dma_stage2(p, b, w, N, npad, qkv, ldb, (p.C + h * WIN_D) * 2, qkv, ldb, (2 * p.C + h * WIN_D) * 2, sK, sV, tid, wave, 512);
-    win_fill_table<T>(p, tb, h, tid, 512);
-    if (tid < npad) rel[tid] = tid < N ? (p.rel[tid] | (p.label ? (int)p.label[w * N + tid] << 16 : 0)) : 0;
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    int qrow_[QR > 0 ? QR : 1];
+    u32x4_t qraw_n = {0u, 0u, 0u, 0u};
+    auto q_frag = [&](int r, u32x4_t& qraw) {                    // unconditional load (rows past the window: its last row; zeroed where consumed)
+        qraw = *(const u32x4_t*)(qkv + (int64_t)(b * p.rows_per_sample + qrow_[r]) * ld + h * WIN_D + g * 8);
+    };
+    if constexpr (QR > 0) {
+        WinPro pro;
+        win_pro_load<SHIFT, false>(p, pro, h, gw, w, N, tid);
+#pragma unroll
+        for (int r = 0; r < QR; ++r) {
+            const int qr = (wave + 8 * r) * 16 + fr;
+            qrow_[r] = p.rowmap[w * N + (qr < N ? qr : N - 1)];
+        }
+        int rows4[4];
+        win_dma_rows(p, w, N, tid, rows4);
+#pragma unroll
+        for (int r = 0; r < QR; ++r) asm volatile("" : "+v"(qrow_[r]));      // one wait for every gather row, in front of the DMAs
+        q_frag(0, qraw_n);
+        win_dma_issue2(p, b, N, npad, rows4, qkv, ldb, (p.C + h * WIN_D) * 2, qkv, ldb, (2 * p.C + h * WIN_D) * 2, sK, sV, tid, wave);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        win_pro_store<false>(p, pro, tb, rel, nullptr, nullptr, h, N, npad, tid);
+    } else {
+        win_dma_stage2(p, b, w, N, npad, qkv, ldb, (p.C + h * WIN_D) * 2, qkv, ldb, (2 * p.C + h * WIN_D) * 2, sK, sV, tid, wave, 512);
+        win_fill_table<T>(p, tb, h, tid, 512);
+        if (tid < npad) rel[tid] = tid < N ? (p.rel[tid] | (p.label ? (int)p.label[w * N + tid] << 16 : 0)) : 0;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
     __syncthreads();
     const int tro0 = win_tr_off(lane, 0), tro1 = win_tr_off(lane, 1);
     const float scale2 = p.scale * LOG2E_F;
 
-    for (int qt = wave; qt * 16 < N; qt += 8) {
+#pragma unroll
+    for (int rnd = 0; rnd < (QR > 0 ? QR : 4); ++rnd) {
+        const int qt = wave + 8 * rnd;
+        if (qt * 16 >= N) break;
         const int qr = qt * 16 + fr;
         const bool qok = qr < N;
-        const int qrow = qok ? b * p.rows_per_sample + p.rowmap[w * N + qr] : 0;
-        const bf16x8_t qf = win_load_frag<T>(qkv + (int64_t)qrow * ld + h * WIN_D, 0, g, qok);
+        int qrow;
+        bf16x8_t qf;
+        if constexpr (QR > 0) {
+            qrow = qok ? b * p.rows_per_sample + qrow_[rnd] : 0;
+            const u32x4_t z4 = {0u, 0u, 0u, 0u};
+            qf = __builtin_bit_cast(bf16x8_t, qok ? qraw_n : z4);
+            if (rnd + 1 < QR) q_frag(rnd + 1, qraw_n);            // the next tile's fragment flies under this tile
+        } else {
+            qrow = qok ? b * p.rows_per_sample + p.rowmap[w * N + qr] : 0;
+            qf = win_load_frag<T>(qkv + (int64_t)qrow * ld + h * WIN_D, 0, g, qok);
+        }
         const int relq = rel[qr] + p.relc;
         float m = -1e30f, l = 0.f;
         f32x4_t oacc[2] = {(f32x4_t){0.f, 0.f, 0.f, 0.f}, (f32x4_t){0.f, 0.f, 0.f, 0.f}};
@@ -993,6 +1031,9 @@ __global__ __launch_bounds__(512) void win_fwd_dma_kernel(WinArgs p) {
             if (k0 + 64 <= N) chunk(k0, std::false_type{});
             else chunk(k0, std::true_type{});
         }
+        if constexpr (QR > 0) {
+            if (rnd + 1 < QR) asm volatile("" : "+v"(qraw_n));   // waited for in front of this tile's stores (loads + stores pending: vmcnt(0) only)
+        }
         if (qok) {
             const float inv = 1.0f / l;
             T* orow = (T*)p.o + (int64_t)qrow * p.C + h * WIN_D;
@@ -1010,7 +1051,7 @@ __global__ __launch_bounds__(512) void win_fwd_dma_kernel(WinArgs p) {
 static int win_lds_fwd_dma(int R, int npad) { return ((R + 3) & ~3) * 4 + npad * 4 + 2 * npad * 64; }
 
 // grid (heads, B*nW), 512 threads, 2 workgroups per CU. LDS: table column, rel, lse, delta, Q and dO row images.
-// KR > 0 (windows of up to 128 KR slots; the launcher uses KR = 2): this wave's key tiles are wave, wave + 8, ...: their gather rows are fetched in front
+// KR > 0 (windows of up to 128 KR slots; the launcher uses KR = 2 up to 256 slots, else 4): this wave's key tiles are wave, wave + 8, ...: their gather rows are fetched in front
 // of the staging and the first tile's K / V fragments behind it, under the prologue's own wait; a later tile's fragments are loaded while the tile
 // before it is computed. KR = 0: loaded at the top of each tile (rowmap, then the rows: two dependent global latencies exposed per tile).
 template <bool SHIFT, int KR>
@@ -1322,10 +1363,11 @@ static bool win_check(const WinArgs& p) {
 }
 
 // kernel family bits (bf16 only; fp32 always runs the register-staged kernels): 1 = LDS-DMA dQ pass (8-12 % faster backward),
-// 2 = LDS-DMA forward (measured equal to the register-staged forward: off), 4 = LDS-DMA dK/dV pass (a further 7-9 %). Default 5.
-// A/B bits of round 6 (windows up to 256 slots): 8 = the FIRST version of the LDS-DMA dQ pass instead of the look-ahead version, 16 = four query
-// partitions instead of two in the look-ahead version.
-static int g_win_variant = [] { const char* e = getenv("VALOR_WIN_VARIANT"); return e ? atoi(e) : 5; }();
+// 2 = LDS-DMA forward (its first version measured equal to the register-staged forward; with the round-6 look-ahead 8-16 % faster,
+// profiles/r06_win_fwd_dma_vs_reg_ab.json), 4 = LDS-DMA dK/dV pass (a further 7-9 %). Default 7.
+// A/B bits of round 6 (windows up to 256 slots; set = the older form): 8 = the FIRST version of the LDS-DMA dQ pass instead of the look-ahead
+// version, 16 = four query partitions instead of two in it, 32 / 64 = the dK/dV pass / the forward without their operand look-ahead.
+static int g_win_variant = [] { const char* e = getenv("VALOR_WIN_VARIANT"); return e ? atoi(e) : 7; }();
 extern "C" int valor_win_attn_set_variant(int v) {
     const int old = g_win_variant;
     if (v >= 0) g_win_variant = v;
@@ -1338,13 +1380,13 @@ static int win_fwd_launch(hipStream_t st, const WinArgs& p) {
     if (lds > WIN_LDS_MAX) return VALOR_ERR_ARG;
     if ((g_win_variant & 2) && ElemTraits<T>::DT == VALOR_DT_BF16 && (int64_t)p.rows_per_sample * 3 * p.C * 2 < 0x7fff0000ll) {
         const int ld2 = win_lds_fwd_dma(p.R, npad);
-        if (p.label) {
-            hipFuncSetAttribute((const void*)win_fwd_dma_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, ld2);
-            hipLaunchKernelGGL((win_fwd_dma_kernel<true>), dim3(p.heads, p.B * p.nW), dim3(512), ld2, st, p);
-        } else {
-            hipFuncSetAttribute((const void*)win_fwd_dma_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, ld2);
-            hipLaunchKernelGGL((win_fwd_dma_kernel<false>), dim3(p.heads, p.B * p.nW), dim3(512), ld2, st, p);
-        }
+#define WIN_FWD_DMA(S_, Q_) do { \
+            hipFuncSetAttribute((const void*)win_fwd_dma_kernel<S_, Q_>, hipFuncAttributeMaxDynamicSharedMemorySize, ld2); \
+            hipLaunchKernelGGL((win_fwd_dma_kernel<S_, Q_>), dim3(p.heads, p.B * p.nW), dim3(512), ld2, st, p); } while (0)
+        const bool ahead = !(g_win_variant & 64);      // (variant bit 6: without the look-ahead, for A/B)
+        if (p.label) { if (!ahead) WIN_FWD_DMA(true, 0); else if (npad <= 256) WIN_FWD_DMA(true, 2); else WIN_FWD_DMA(true, 4); }
+        else { if (!ahead) WIN_FWD_DMA(false, 0); else if (npad <= 256) WIN_FWD_DMA(false, 2); else WIN_FWD_DMA(false, 4); }
+#undef WIN_FWD_DMA
         return hipGetLastError() == hipSuccess ? VALOR_OK : VALOR_ERR_LAUNCH;
     }
     if (p.label) {
@@ -1389,15 +1431,19 @@ static int win_bwd_launch(hipStream_t st, const WinArgs& p, void* dtable, int ac
     const bool dma = (g_win_variant & 1) && ElemTraits<T>::DT == VALOR_DT_BF16 && l1d <= WIN_LDS_MAX &&
                      (int64_t)p.rows_per_sample * 3 * p.C * 2 < 0x7fff0000ll;
     if (dma && npad <= 256 && !(g_win_variant & 8)) {          // look-ahead version (variant bit 3 set: the first version, for A/B)
+        // Windows of up to 256 slots only: at the 392-slot production window (7 key chunks, 252-256 VGPRs) the look-ahead version measured
+        // 0-3 % (plain) and 7-8 % (shifted) SLOWER than the first version, whose per-window chain is a smaller share of four times the
+        // arithmetic (profiles/r06_win_dq_n392_ab.json).
         const int ntile = (p.N + 15) >> 4;
-        // two query partitions of up to 8 waves instead of four of up to 4 (round 4 measured the same split SLOWER on the first version, 880 -> 1010 us;
-        // with the look-ahead it is 14-18 % faster on the whole backward bundle, profiles/r06_win_dq2_parts_ab.json); variant bit 4: four partitions
+        // two query partitions of up to 8 waves instead of four of up to 4 where the tiles allow it (round 4 measured the same split SLOWER
+        // on the first version, 880 -> 1010 us; with the look-ahead it is 14-18 % faster on the whole backward bundle,
+        // profiles/r06_win_dq2_parts_ab.json); variant bit 4: four partitions
         const bool two = !(g_win_variant & 16) && (ntile + 1) / 2 <= 8;
-#define WIN_DQ2(S_, P_) do { \
-            hipFuncSetAttribute((const void*)win_bwd_dq_dma2_kernel<S_, 4, P_>, hipFuncAttributeMaxDynamicSharedMemorySize, l1d); \
-            hipLaunchKernelGGL((win_bwd_dq_dma2_kernel<S_, 4, P_>), dim3(p.heads, P_, G), dim3(512), l1d, st, p); } while (0)
-        if (p.label) { if (two) WIN_DQ2(true, 2); else WIN_DQ2(true, 4); }
-        else { if (two) WIN_DQ2(false, 2); else WIN_DQ2(false, 4); }
+#define WIN_DQ2(S_, C_, P_) do { \
+            hipFuncSetAttribute((const void*)win_bwd_dq_dma2_kernel<S_, C_, P_>, hipFuncAttributeMaxDynamicSharedMemorySize, l1d); \
+            hipLaunchKernelGGL((win_bwd_dq_dma2_kernel<S_, C_, P_>), dim3(p.heads, P_, G), dim3(512), l1d, st, p); } while (0)
+        if (p.label) { if (two) WIN_DQ2(true, 4, 2); else WIN_DQ2(true, 4, 4); }
+        else { if (two) WIN_DQ2(false, 4, 2); else WIN_DQ2(false, 4, 4); }
 #undef WIN_DQ2
     } else if (dma) {
         if (p.label) {
@@ -1416,6 +1462,9 @@ static int win_bwd_launch(hipStream_t st, const WinArgs& p, void* dtable, int ac
             if (npad <= 256 && !(g_win_variant & 32)) {          // (variant bit 5: without the operand look-ahead, for A/B)
                 hipFuncSetAttribute((const void*)win_bwd_dkv_dma_kernel<true, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, l2d);
                 hipLaunchKernelGGL((win_bwd_dkv_dma_kernel<true, 2>), dim3(p.heads, p.B * p.nW), dim3(512), l2d, st, p);
+            } else if (!(g_win_variant & 32)) {
+                hipFuncSetAttribute((const void*)win_bwd_dkv_dma_kernel<true, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, l2d);
+                hipLaunchKernelGGL((win_bwd_dkv_dma_kernel<true, 4>), dim3(p.heads, p.B * p.nW), dim3(512), l2d, st, p);
             } else {
                 hipFuncSetAttribute((const void*)win_bwd_dkv_dma_kernel<true, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, l2d);
                 hipLaunchKernelGGL((win_bwd_dkv_dma_kernel<true, 0>), dim3(p.heads, p.B * p.nW), dim3(512), l2d, st, p);
@@ -1429,6 +1478,9 @@ static int win_bwd_launch(hipStream_t st, const WinArgs& p, void* dtable, int ac
             if (npad <= 256 && !(g_win_variant & 32)) {
                 hipFuncSetAttribute((const void*)win_bwd_dkv_dma_kernel<false, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, l2d);
                 hipLaunchKernelGGL((win_bwd_dkv_dma_kernel<false, 2>), dim3(p.heads, p.B * p.nW), dim3(512), l2d, st, p);
+            } else if (!(g_win_variant & 32)) {
+                hipFuncSetAttribute((const void*)win_bwd_dkv_dma_kernel<false, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, l2d);
+                hipLaunchKernelGGL((win_bwd_dkv_dma_kernel<false, 4>), dim3(p.heads, p.B * p.nW), dim3(512), l2d, st, p);
             } else {
                 hipFuncSetAttribute((const void*)win_bwd_dkv_dma_kernel<false, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, l2d);
                 hipLaunchKernelGGL((win_bwd_dkv_dma_kernel<false, 0>), dim3(p.heads, p.B * p.nW), dim3(512), l2d, st, p);
