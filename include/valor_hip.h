@@ -230,7 +230,9 @@ int valor_attn_set_variant(int v);
  * items with the K / V and Q / dO LDS images double-buffered across the dQ and the dK / dV phase, so the loads and stores of one item
  * overlap the arithmetic of its neighbours (used when batch x heads >= 2 x the CU count; sequences of <= 160 rows run mode 2 instead);
  * 0 = one workgroup of 8 waves x 32-row blocks per (batch, head); 2 = one workgroup of 16 waves x 16-row blocks per (batch, head) (four
- * waves per SIMD). Modes 0 and 2 are bit-identical, mode 1 differs from them in the summation order of delta only. Returns the previous
+ * waves per SIMD); 3 = mode 1 with the FIRST version of the persistent kernel (round 6 added a second: phase operands out of LDS / prefetched
+ * under the dK / dV loop, 16-byte stores -- bit-identical to the first, used when the gradient rows are 16-byte aligned and there is no
+ * additive mask). Modes 0 and 2 are bit-identical, modes 1 / 3 differ from them in the summation order of delta only. Returns the previous
  * value, v < 0 only queries. */
 int valor_attn_set_res_pipeline(int v);
 

@@ -1252,7 +1252,8 @@ bool attn_res_bwd_launch(hipStream_t st, const AttnArgs& p) {
     }
     const int n_items = p.B * p.H;
     // 16 waves x 16-row blocks: always in mode 2; in the default mode for the short sequences (S <= 160: the AST shape, 129 rows, measured
-    // 110 us against 118 for the pipelined kernel and 133 for 8 waves x 32-row blocks; at S = 197 the three variants within 2 %)
+    // 110 us against 118 for the pipelined kernel (122 for its second version: five of eight waves have a block) and 133 for 8 waves x 32-row
+    // blocks; at S = 197 the first three variants were within 2 %, the second pipelined version is 25 % ahead)
     if (g_res_bwd_pipe == 2 || (g_res_bwd_pipe == 1 && p.Skv <= 160)) {
         RES_DISPATCH(attn_res_bwd16_kernel, dim3(p.H, p.B), dim3(1024), lds, st, p);
         return true;
