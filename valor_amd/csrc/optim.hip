@@ -82,22 +82,30 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* master, float* m, flo
     }
 }
 
-// sum of squares of the active chunks -> partial[gridDim.x]. Four chunks per iteration: with one 8-byte load in flight per thread the
-// 0.75 GB gradient arena was read at 2.1 TB/s (348 us per step).
+// sum of squares of the active chunks -> partial[gridDim.x]. Eight chunks per iteration, the gradient loads UNCONDITIONAL (the arena is one
+// allocation; an inactive chunk's values are dropped by a select afterwards): with the load predicated on the chunk's group byte every iteration
+// was two dependent global latencies -- the byte, then the gradients -- and the 0.75 GB arena was read at 2.0 TB/s (348 us per step, round-6
+// kernel trace; the round-3 change to four chunks per iteration had not moved it for that reason).
 template <typename T>
 __global__ __launch_bounds__(256) void sumsq_kernel(const T* grad, const int8_t* chunk_group, int64_t nchunks, float* partial) {
     __shared__ float red[4];
     float s = 0.f;
-    for (int64_t c0 = blockIdx.x; c0 < nchunks; c0 += 4 * (int64_t)gridDim.x) {
-        f32x4_t g[4];
+    constexpr int U = 8;
+    for (int64_t c0 = blockIdx.x; c0 < nchunks; c0 += U * (int64_t)gridDim.x) {
+        f32x4_t g[U];
+        bool on[U];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
+        for (int u = 0; u < U; ++u) {
             const int64_t c = c0 + u * (int64_t)gridDim.x;
-            g[u] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-            if (c < nchunks && !(chunk_group && chunk_group[c] < 0)) g[u] = load4<T>(grad + c * ADAMW_CHUNK + threadIdx.x * 4);
+            const int64_t cl = c < nchunks ? c : nchunks - 1;
+            on[u] = c < nchunks && !(chunk_group && chunk_group[cl] < 0);
+            g[u] = load4<T>(grad + cl * ADAMW_CHUNK + threadIdx.x * 4);
         }
 #pragma unroll
-        for (int u = 0; u < 4; ++u) s += g[u][0] * g[u][0] + g[u][1] * g[u][1] + g[u][2] * g[u][2] + g[u][3] * g[u][3];
+        for (int u = 0; u < U; ++u) {
+            const float q = g[u][0] * g[u][0] + g[u][1] * g[u][1] + g[u][2] * g[u][2] + g[u][3] * g[u][3];
+            s += on[u] ? q : 0.f;
+        }
     }
     s = wave_sum(s);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
