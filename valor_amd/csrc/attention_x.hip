@@ -17,6 +17,8 @@
 //             comes back with ds_read_b64_tr_b16.
 // A query group only meets the tiles that intersect its kv_range (block-uniform skip), other keys are masked.
 #include "attn_common.h"
+#include <type_traits>
+#include <stdlib.h>
 
 DEVINL float x_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
 
@@ -48,14 +50,22 @@ DEVINL void x_stage_kv(rsrc_t rsK, rsrc_t rsV, char* sK, char* sV, int kv0, int 
     }
 }
 
+// transposing fragment reads of the 128-byte-row XOR image as inline asm (the builtin has no memory operand: hipcc drains every LDS-DMA in flight
+// in front of it -- with the double-buffered tiles below that would be the NEXT tile's DMA); second half 16 rows = 2048 B further
+DEVINL void x_tr_issue(TrPair& t, const char* a) {
+    const uint32_t addr = (uint32_t)(uintptr_t)LDS_PTR(a);
+    asm volatile("ds_read_b64_tr_b16 %0, %2\n\tds_read_b64_tr_b16 %1, %2 offset:2048" : "=&v"(t.lo), "=&v"(t.hi) : "v"(addr));
+}
+DEVINL void x_tr_wait4(TrPair (&t)[4]) { asm volatile("s_waitcnt lgkmcnt(0)" : TR_TIE(t[0]), TR_TIE(t[1]), TR_TIE(t[2]), TR_TIE(t[3])); }
+
 // ------------------------------------------------------------------------------------------ forward
-template <int NQS, bool DROP>
+// DB (round 6): two K / V stages -- tile t + 1 lands while tile t is computed, one barrier per tile (the single stage waited for its DMA in
+// front of every tile with only the partner workgroup of the CU to cover it: waves parked 45-52 % of their cycles, profiles/r06_pmc_kernels.md).
+template <int NQS, bool DROP, bool DB>
 __global__ __launch_bounds__(256, 2) void attn_x_fwd_kernel(AttnArgs p) {
     const uint64_t rng_off = rng_offset(p.offset, p.rng_base);     // once, ahead of every loop: a scalar load inside the tile loop
                                                                    // shares lgkmcnt with the LDS reads and drains their pipeline
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    char* sV = smem;
-    char* sK = smem + 16384;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int fr = lane & 15, g = lane >> 4;
@@ -96,11 +106,27 @@ __global__ __launch_bounds__(256, 2) void attn_x_fwd_kernel(AttnArgs p) {
     const int kw0 = wave * 32;
     const int NT = (p.Skv + 127) >> 7;
 
-    for (int t = 0; t < NT; ++t) {
+    constexpr bool HK_ONCE = NQS <= 4;         // dropout key of every sub-tile's (batch, head) once, not per tile (six sub-tiles: no register left)
+    uint32_t hk_[HK_ONCE ? NQS : 1];
+    if (HK_ONCE) {
+#pragma unroll
+        for (int u = 0; u < NQS; ++u) hk_[HK_ONCE ? u : 0] = DROP ? attn_drop_headkey(p.seed, rng_off, sb_[u] * p.H + h) : 0u;
+    }
+    if (DB) x_stage_kv(rsK, rsV, smem + 16384, smem, 0, krs_b, vrs_b, wave, lane);
+    // (the tile loop is unrolled by the two stages so that a stage's LDS addresses stay compile-time offsets: with a runtime stage base the
+    //  six-sub-tile instantiation, at 256 VGPRs already, spills)
+    auto tile = [&](const int t, auto stage_c) {
+        constexpr int STG = decltype(stage_c)::value;
         const int kv0 = t << 7;
-        x_stage_kv(rsK, rsV, sK, sV, kv0, krs_b, vrs_b, wave, lane);
+        char* sV = smem + STG * 32768;
+        char* sK = sV + 16384;
+        if (!DB) x_stage_kv(rsK, rsV, sK, sV, kv0, krs_b, vrs_b, wave, lane);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
+        __syncthreads();               // tile t has landed for every wave; (DB) everyone is done with the other stage
+        if (DB && t + 1 < NT) {
+            char* nV = smem + (STG ^ 1) * 32768;
+            x_stage_kv(rsK, rsV, nV + 16384, nV, kv0 + 128, krs_b, vrs_b, wave, lane);
+        }
         const int ka = kv0 + kw0;      // first key (row of the K/V buffer) of this wave's slice
         if (ka < p.Skv) {
             bf16x8_t kf[2][2], vfr[4];
@@ -108,8 +134,17 @@ __global__ __launch_bounds__(256, 2) void attn_x_fwd_kernel(AttnArgs p) {
             for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
                 for (int dg = 0; dg < 2; ++dg) kf[kt][dg] = read_frag<bf16_t>(sK, kw0 + kt * 16 + fr, dg * 4 + g);
+            if (DB) {
+                TrPair tv[4];
 #pragma unroll
-            for (int dt = 0; dt < 4; ++dt) vfr[dt] = read_frag_tr_nat(sV, kw0, troff[dt]);
+                for (int dt = 0; dt < 4; ++dt) x_tr_issue(tv[dt], sV + kw0 * TILE_ROW_BYTES + troff[dt]);
+                x_tr_wait4(tv);
+#pragma unroll
+                for (int dt = 0; dt < 4; ++dt) vfr[dt] = tr_frag(tv[dt]);
+            } else {
+#pragma unroll
+                for (int dt = 0; dt < 4; ++dt) vfr[dt] = read_frag_tr_nat(sV, kw0, troff[dt]);
+            }
 #pragma unroll
             for (int u = 0; u < NQS; ++u) {
                 const int rs0 = ss0_[u], rs1 = ss1_[u];
@@ -146,7 +181,7 @@ __global__ __launch_bounds__(256, 2) void attn_x_fwd_kernel(AttnArgs p) {
                 mrow[u] = mnew;
                 float ps = 0.f;
                 const int qr = sq0_[u] + fr;
-                const uint32_t hk = attn_drop_headkey(p.seed, rng_off, sb_[u] * p.H + h);
+                const uint32_t hk = HK_ONCE ? hk_[HK_ONCE ? u : 0] : attn_drop_headkey(p.seed, rng_off, sb_[u] * p.H + h);
                 const uint32_t rowbase = (uint32_t)qr * (uint32_t)p.Skv;
 #pragma unroll
                 for (int kt = 0; kt < 2; ++kt) {
@@ -171,8 +206,13 @@ __global__ __launch_bounds__(256, 2) void attn_x_fwd_kernel(AttnArgs p) {
                 }
             }
         }
-        __syncthreads();
+        if (!DB) __syncthreads();
+    };
+    for (int t = 0; t < NT; t += DB ? 2 : 1) {
+        tile(t, std::integral_constant<int, 0>{});
+        if (DB && t + 1 < NT) tile(t + 1, std::integral_constant<int, 1>{});
     }
+    if (DB) __syncthreads();           // every wave is done with the last tile: the stages become the merge scratch
 
     // ---- merge the four waves' partial softmax states per query sub-tile (LDS: 4 x [16 q][64 d] fp32 + stats)
     float* sO = (float*)smem;
@@ -497,14 +537,25 @@ bool attn_x_fwd_launch(hipStream_t st, const AttnArgs& p) {
     if (n <= 0 || n > 8 || p.Skv < 128) return false;
     const int bmod = p.kv_bmod > 0 ? p.kv_bmod : p.B;
     dim3 grid(p.H, bmod);
-    const size_t lds = 32768 + 1024;
+    static const int db = [] { const char* e = getenv("VALOR_XATTN_FWD_DB"); return e ? atoi(e) : 1; }();      // 0: the single-stage form (A/B)
+    const size_t lds = db ? 65536 + 1024 : 32768 + 1024;
+#define X_FWD_I(N_, D_, B_)                                                                                          \
+    do {                                                                                                            \
+        static bool attr_set = false;                                                                               \
+        if (!attr_set) {                                                                                            \
+            hipFuncSetAttribute((const void*)attn_x_fwd_kernel<N_, D_, B_>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536 + 1024); \
+            attr_set = true;                                                                                        \
+        }                                                                                                           \
+        hipLaunchKernelGGL((attn_x_fwd_kernel<N_, D_, B_>), grid, dim3(256), lds, st, p);                           \
+    } while (0)
 #define X_FWD(N_)                                                                                                   \
     do {                                                                                                            \
-        if (p.p_drop > 0.f) hipLaunchKernelGGL((attn_x_fwd_kernel<N_, true>), grid, dim3(256), lds, st, p);         \
-        else hipLaunchKernelGGL((attn_x_fwd_kernel<N_, false>), grid, dim3(256), lds, st, p);                       \
+        if (p.p_drop > 0.f) { if (db) X_FWD_I(N_, true, true); else X_FWD_I(N_, true, false); }                     \
+        else { if (db) X_FWD_I(N_, false, true); else X_FWD_I(N_, false, false); }                                  \
     } while (0)
     if (n <= 2) X_FWD(2); else if (n <= 4) X_FWD(4); else if (n <= 6) X_FWD(6); else X_FWD(8);
 #undef X_FWD
+#undef X_FWD_I
     return true;
 }
 
