@@ -91,20 +91,46 @@ __global__ __launch_bounds__(256) void sumsq_kernel(const T* grad, const int8_t*
     __shared__ float red[4];
     float s = 0.f;
     constexpr int U = 8;
-    for (int64_t c0 = blockIdx.x; c0 < nchunks; c0 += U * (int64_t)gridDim.x) {
-        f32x4_t g[U];
-        bool on[U];
+    if constexpr (sizeof(T) == 2) {
+        // 16 bytes per lane: a chunk (1024 elements) is 128 threads x 8 elements, a 256-thread block takes two chunks per load
+        const int half = threadIdx.x >> 7, off = (threadIdx.x & 127) * 8;
+        for (int64_t c0 = 2 * (int64_t)blockIdx.x; c0 < nchunks; c0 += 2 * U * (int64_t)gridDim.x) {
+            u32x4_t g[U];
+            bool on[U];
 #pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const int64_t c = c0 + u * (int64_t)gridDim.x;
-            const int64_t cl = c < nchunks ? c : nchunks - 1;
-            on[u] = c < nchunks && !(chunk_group && chunk_group[cl] < 0);
-            g[u] = load4<T>(grad + cl * ADAMW_CHUNK + threadIdx.x * 4);
+            for (int u = 0; u < U; ++u) {
+                const int64_t c = c0 + 2 * u * (int64_t)gridDim.x + half;
+                const int64_t cl = c < nchunks ? c : nchunks - 1;
+                on[u] = c < nchunks && !(chunk_group && chunk_group[cl] < 0);
+                g[u] = *(const u32x4_t*)(grad + cl * ADAMW_CHUNK + off);
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                float q = 0.f;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const float lo = __uint_as_float(g[u][k] << 16), hi = __uint_as_float(g[u][k] & 0xffff0000u);
+                    q += lo * lo + hi * hi;
+                }
+                s += on[u] ? q : 0.f;
+            }
         }
+    } else {
+        for (int64_t c0 = blockIdx.x; c0 < nchunks; c0 += U * (int64_t)gridDim.x) {
+            f32x4_t g[U];
+            bool on[U];
 #pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const float q = g[u][0] * g[u][0] + g[u][1] * g[u][1] + g[u][2] * g[u][2] + g[u][3] * g[u][3];
-            s += on[u] ? q : 0.f;
+            for (int u = 0; u < U; ++u) {
+                const int64_t c = c0 + u * (int64_t)gridDim.x;
+                const int64_t cl = c < nchunks ? c : nchunks - 1;
+                on[u] = c < nchunks && !(chunk_group && chunk_group[cl] < 0);
+                g[u] = load4<T>(grad + cl * ADAMW_CHUNK + threadIdx.x * 4);
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const float q = g[u][0] * g[u][0] + g[u][1] * g[u][1] + g[u][2] * g[u][2] + g[u][3] * g[u][3];
+                s += on[u] ? q : 0.f;
+            }
         }
     }
     s = wave_sum(s);
