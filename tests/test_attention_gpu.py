@@ -119,6 +119,40 @@ def test_attention_dropout(dev):
     assert torch.allclose(got, want, atol=1e-5), (got - want).abs().max()
 
 
+@pytest.mark.parametrize("B,S,p_drop,causal", [(24, 32, 0.1, True), (8, 42, 0.1, False), (8, 32, 0.0, True), (5, 64, 0.1, False), (3, 7, 0.1, True)])
+def test_short_sequences_one_wave_per_head_backward(dev, B, S, p_drop, causal):
+    """Sequences of up to 64 rows (the decoder passes' and the CLIP text tower's 32 / 42-token self-attention, bert.py:272-288, clip.py:407-414)
+    take attn_res_bwd1_kernel -- one wave per (batch, head), dQ and dK / dV in one launch -- instead of the streaming dQ + dK/dV pair: the same
+    gradients to bf16 rounding, incl. the regenerated dropout mask (a different mask would differ in O(1)) and additive masks."""
+    from valor_amd import kernels as K, lib
+    so = lib.load()
+    H = 12
+    E = H * 64
+    g = torch.Generator().manual_seed(S * 3 + B)
+    qkv = (torch.randn((B, S, 3 * E), generator=g) * 0.8).to(torch.bfloat16).to(dev)
+    q, k, v = qkv[:, :, :E], qkv[:, :, E:2 * E], qkv[:, :, 2 * E:]
+    dout = torch.randn((B, S, E), generator=g).to(torch.bfloat16).to(dev)
+    if causal:
+        mask = torch.triu(torch.full((S, S), -10000.0), diagonal=1)[None].contiguous().to(dev)
+    else:
+        lens = torch.randint(max(1, S // 2), S + 1, (B,), generator=g)
+        mask = torch.zeros((B, S, S))
+        for b in range(B):
+            mask[b, :, lens[b]:] = -10000.0
+        mask = mask.to(dev)
+    scale = 1.0 / math.sqrt(64)
+    o, lse = K.attn_fwd(q, k, v, H, mask=mask, scale=scale, p_drop=p_drop, seed=5, offset=9)
+    got = K.attn_bwd(q, k, v, o, lse, dout, H, mask=mask, scale=scale, p_drop=p_drop, seed=5, offset=9)
+    old = so.valor_attn_set_variant(0)              # streaming kernels only
+    try:
+        want = K.attn_bwd(q, k, v, o, lse, dout, H, mask=mask, scale=scale, p_drop=p_drop, seed=5, offset=9)
+    finally:
+        so.valor_attn_set_variant(old)
+    for a, b_, n in zip(got, want, ("dq", "dk", "dv")):
+        assert torch.isfinite(a.float()).all(), n
+        assert _rel(a, b_) < 2e-3, (n, _rel(a, b_))
+
+
 @pytest.mark.parametrize("S,B,H,p_drop", [(197, 44, 12, 0.0), (197, 44, 12, 0.1), (129, 48, 12, 0.1), (256, 43, 12, 0.0), (65, 90, 6, 0.1), (224, 64, 8, 0.0)])
 def test_resident_backward_pipelined_equals_per_head_kernel(dev, S, B, H, p_drop):
     """The persistent, phase-pipelined LDS-resident backward (attention_res.hip: one workgroup per CU walks (batch, head) items, the

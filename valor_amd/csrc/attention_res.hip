@@ -414,6 +414,11 @@ __global__ __launch_bounds__(512, 2) void attn_res_bwd_kernel(AttnArgs p) { attn
 // "latency bound at two waves per SIMD". valor_attn_set_res_pipeline(2) / VALOR_ATTN_PIPE=2 selects it (A/B: tools/attn_pipe_ab.py).
 template <bool DROP, bool MASK>
 __global__ __launch_bounds__(1024) void attn_res_bwd16_kernel(AttnArgs p) { attn_res_bwd_body<DROP, MASK, 1, 16>(p); }
+// ONE wave per (batch, head) for sequences of up to 64 rows -- the 32- / 42-token self-attention of the decoder passes and the CLIP text tower
+// (bert.py:272-288, clip.py:407-414): the four images are the wave's own (16-33 KiB, 4-8 workgroups per CU), dQ and dK / dV in ONE launch.
+// These shapes ran on the streaming dQ + dK/dV kernel pair (21 + 26 us per call, 36 calls of each per step).
+template <bool DROP, bool MASK>
+__global__ __launch_bounds__(64) void attn_res_bwd1_kernel(AttnArgs p) { attn_res_bwd_body<DROP, MASK, 2, 1>(p); }
 
 // ------------------------------------------------------------------------------------------ backward, pipelined
 // The kernel above is one workgroup per CU (114 KiB of LDS, 8 waves x 178 VGPRs) whose three stretches do not overlap with anything:
@@ -1232,11 +1237,17 @@ extern "C" int valor_attn_set_res_pipeline(int v) {
 }
 
 bool attn_res_bwd_launch(hipStream_t st, const AttnArgs& p) {
-    // one workgroup of 8 waves per head needs >= 2 32-row blocks to be worth it; shorter sequences stay on the
-    // streaming kernels (measured: S = 32 / 42 are slower here)
-    if (!res_eligible(p) || p.Skv <= 64 || (int64_t)p.Sq * p.do_rs * 2 >= ((int64_t)1 << 31)) return false;
+    // one workgroup of 8 waves per head needs >= 2 32-row blocks to be worth it (measured: S = 32 / 42 are slower on it than on the streaming
+    // kernels); sequences of up to 64 rows take the one-wave-per-head kernel (VALOR_ATTN_SHORT=0: the streaming kernels)
+    if (!res_eligible(p) || (int64_t)p.Sq * p.do_rs * 2 >= ((int64_t)1 << 31)) return false;
     const int SP = (p.Skv + 31) & ~31;
     const size_t lds = 4 * (size_t)SP * TILE_ROW_BYTES + 2 * (size_t)SP * sizeof(float);
+    if (p.Skv <= 64) {
+        static const int short_on = [] { const char* e = getenv("VALOR_ATTN_SHORT"); return e ? atoi(e) : 1; }();
+        if (!short_on) return false;
+        RES_DISPATCH(attn_res_bwd1_kernel, dim3(p.H, p.B), dim3(64), lds, st, p);
+        return true;
+    }
     static bool attr_set = false;
     static int n_cu = 256;
     if (!attr_set) {
