@@ -43,12 +43,25 @@ for name, B, S, p, kind in [("caption_192x32_causal_drop", 192, 32, 0.1, "causal
             run()
         e1.record(); torch.cuda.synchronize()
         ts.append(e0.elapsed_time(e1) / 20 * 1e3)
-    res[name] = {"us": round(sorted(ts)[1], 1), "finite": bool(torch.isfinite(dqkv.float()).all())}
+    fwd = lambda: K.attn_fwd(q, k, v, H, mask=mask, scale=scale, p_drop=p, seed=5, offset=9)
+    tf = []
+    for _ in range(3):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(20):
+            fwd()
+        e1.record(); torch.cuda.synchronize()
+        tf.append(e0.elapsed_time(e1) / 20 * 1e3)
+    grads[name + "_o"] = o.clone()
+    res[name] = {"us": round(sorted(ts)[1], 1), "fwd_us": round(sorted(tf)[1], 1), "finite": bool(torch.isfinite(dqkv.float()).all())}
 if len(sys.argv) > 2 and os.path.exists(sys.argv[2]):
     ref = torch.load(sys.argv[2])
     for n in grads:
         a, b = grads[n].double(), ref[n].double().to(dev)
-        res[n]["rel_diff_vs_other_family"] = float((a - b).norm() / b.norm())
+        if n.endswith("_o"):
+            res[n[:-2]]["fwd_rel_diff_vs_other_family"] = float((a - b).norm() / b.norm())
+        else:
+            res[n]["rel_diff_vs_other_family"] = float((a - b).norm() / b.norm())
 elif len(sys.argv) > 2:
     torch.save({n: t.cpu() for n, t in grads.items()}, sys.argv[2])
 print(json.dumps(res))
