@@ -430,6 +430,30 @@ __global__ __launch_bounds__(256, WPS) void gemm_glds_kernel(GemmArgs p) {
 // split-K second stage: sum the fp32 slices and run the normal epilogue (4 n per thread). `bid` of `nblk` workgroups work on problem p.
 template <typename T>
 DEVINL void splitk_reduce_body(const GemmArgs& p, int bid, int nblk) {
+    if (p.ws_bf16 && (p.N & 7) == 0) {
+        // fast path (round 6): 16 bytes of every K-slice per thread, four slices in flight; the slices are added in the same order as below
+        // (bit-identical). The quad loop issued one 8-byte load per slice and thread: 2.1 TB/s on a ViT layer's four wgrads (61 us per group).
+        const int64_t noct = (int64_t)p.N >> 3, total8 = (int64_t)p.M * noct, sl = (int64_t)p.M * p.N;
+        for (int64_t i = (int64_t)bid * blockDim.x + threadIdx.x; i < total8; i += (int64_t)nblk * blockDim.x) {
+            const int m = (int)(i / noct);
+            const int n = (int)(i - (int64_t)m * noct) << 3;
+            const bf16_t* q = (const bf16_t*)p.ws + (int64_t)m * p.N + n;
+            f32x4_t s0 = {0.f, 0.f, 0.f, 0.f}, s1 = s0;
+            auto add = [&](const u32x4_t r) {
+                s0 += (f32x4_t){__uint_as_float(r[0] << 16), __uint_as_float(r[0] & 0xffff0000u), __uint_as_float(r[1] << 16), __uint_as_float(r[1] & 0xffff0000u)};
+                s1 += (f32x4_t){__uint_as_float(r[2] << 16), __uint_as_float(r[2] & 0xffff0000u), __uint_as_float(r[3] << 16), __uint_as_float(r[3] & 0xffff0000u)};
+            };
+            int k = 0;
+            for (; k + 4 <= p.kslices; k += 4) {
+                const u32x4_t r0 = *(const u32x4_t*)(q + (int64_t)k * sl), r1 = *(const u32x4_t*)(q + (int64_t)(k + 1) * sl);
+                const u32x4_t r2 = *(const u32x4_t*)(q + (int64_t)(k + 2) * sl), r3 = *(const u32x4_t*)(q + (int64_t)(k + 3) * sl);
+                add(r0); add(r1); add(r2); add(r3);
+            }
+            for (; k < p.kslices; ++k) add(*(const u32x4_t*)(q + (int64_t)k * sl));
+            epilogue_store<T>(p, m, n, s0, load_bias4<T>(p, n));
+            epilogue_store<T>(p, m, n + 4, s1, load_bias4<T>(p, n + 4));
+        }
+    } else {
     const int64_t nquads = ((int64_t)p.N + 3) >> 2;
     const int64_t total = (int64_t)p.M * nquads;
     for (int64_t i = (int64_t)bid * blockDim.x + threadIdx.x; i < total; i += (int64_t)nblk * blockDim.x) {
@@ -450,6 +474,7 @@ DEVINL void splitk_reduce_body(const GemmArgs& p, int bid, int nblk) {
             }
         }
         epilogue_store<T>(p, m, n, s, load_bias4<T>(p, n));
+    }
     }
     if (p.rowsum_out) {      // fused bias gradient: sum the K-slices' row sums
         for (int m = bid * blockDim.x + threadIdx.x; m < p.M; m += nblk * blockDim.x) {
