@@ -1,16 +1,28 @@
 """Caption generation on the native decoder: VALOR.generate_cap / decode_greedy / decode_beam / get_logits
-(model/pretrain.py:914-1189), caption_type 'unimlm'.
+(model/pretrain.py:914-1189), caption_type 'unimlm' | 'lm'.
 
 The reference feeds [CLS] + generated tokens + [MASK] through the whole decoder again at every step (its cache path is disabled when the
-decoder has cross-attention, pretrain.py:890-896, bert.py:848-850). Here the video/audio K|V projections of the 12 layers are computed
-ONCE per clip (VALOR.cross_inputs) and shared by every step, every group and every beam; the text rows are re-run each step like the
-reference (<= 32 rows x (t + 2) tokens: launch-bound, not FLOP-bound).
+decoder has cross-attention, pretrain.py:890-896, bert.py:848-850, and broken behind that, bert.py:807). Two things are cached here:
+
+  * the video/audio K|V projections of the 12 layers are computed ONCE per clip (VALOR.cross_inputs) and shared by every step, every
+    group and every beam;
+  * the text rows' self-attention K|V (`DecodeSession`, SURVEY 8 row f4 "a working KV cache"). The generation mask is causal over the
+    text and every text row sees the prompt rows, which see only themselves (bert.py:879-885): a position's hidden states never change
+    once its token is fixed. A decoding step therefore runs TWO rows per sequence -- the token chosen by the previous step at
+    position t and the [MASK] at t + 1 ('lm': one row) -- against per-layer K|V slots [prompt | text positions]; the prompt rows run
+    once per clip. The step has static shapes and no host-built tensor (the step counter, the key-validity mask and the slot indices
+    live on the device), so it is captured ONCE per geometry as a hipGraph and replayed: ~250 launches per step leave the host.
+    Sessions (static buffers + graph) are kept per model and geometry and reused across batches and query groups.
+    VALOR_KV_CACHE=0 selects the re-run-everything path (`_Stepper`, also the teacher-forced logits the parity tests use);
+    VALOR_DECODE_GRAPH=0 runs the cached step eagerly.
 
 Beam rows are kept in the reference's (sample, beam) order on the host side; the decoder sees them beam-major (row = beam * b + sample)
 so that a row's cross-attention K|V is row % b -- the kv_bmod addressing the training passes use -- instead of beam copies of K|V
 (pretrain.py:1133-1139 expands video_input / audio_input beam_size times).
 
 Everything here is inference: torch.no_grad, dropout off regardless of model.training (the reference calls it under model.eval())."""
+import os
+
 import torch
 
 from . import kernels as K, lib, ops
@@ -67,6 +79,169 @@ class _Stepper:
             inv[perm] = torch.arange(rows)
             logits = logits[m._dev(inv)]
         return logits
+
+
+NEG = -10000.0                           # the additive mask value of BertModel.forward (bert.py:885)
+
+
+def kv_cache_enabled():
+    return os.environ.get("VALOR_KV_CACHE", "1") != "0"
+
+
+class DecodeSession:
+    """Static buffers + the captured decoding step of one geometry: R = b * beam sequences, J new rows per step (2: token + [MASK],
+    'unimlm'; 1: 'lm'), P prompt slots, `max_len` generated tokens, the per-layer [video | audio] K|V shape.
+
+    Slots of a layer's self-attention K|V, per sequence: [0, P) the prompt rows (written once per clip by `begin_group`), P + i the
+    text position i. Step t writes the token's K|V to slot P + t and the [MASK]'s to P + t + 1 (overwritten by the next step's token);
+    `kmask` [R, L] holds 0 / -10000 per written slot (a key whose token id is 0 is masked, bert.py:857,885: prompt padding, and a
+    generated id 0), the step's attention mask opens slots <= P + t for the token row and P + t + 1 besides for the [MASK] row.
+    Rows are beam-major (row = beam * b + sample); a beam step first moves every sequence's slots to the row that continues it
+    (`parent`)."""
+
+    def __init__(self, model, b, beam, P, max_len, kv_layers):
+        m = self.m = model
+        dev, dt, E = m.device, m.dtype, m.spec.hidden
+        self.b, self.beam, self.R, self.P, self.max_len = b, beam, b * beam, P, max_len
+        self.J = 1 if m.caption_type == "lm" else 2
+        self.L = P + max_len + self.J - 1
+        self.layers = m.spec.layers
+        R, L, J = self.R, self.L, self.J
+        i64 = dict(dtype=torch.int64, device=dev)
+        self.cache = torch.zeros((self.layers, R, L, 2 * E), dtype=dt, device=dev)
+        self.kmask = torch.full((R, L), NEG, dtype=torch.float32, device=dev)
+        self.amask = torch.empty((R, J, L), dtype=torch.float32, device=dev)
+        self.t = torch.zeros(1, **i64)
+        self.tok = torch.full((R,), BOS, **i64)
+        self.parent = torch.arange(R, **i64)
+        self.ids = torch.full((R, J), MASK, **i64)
+        self.slot = torch.arange(L, **i64)
+        self.jidx = torch.arange(J, **i64)
+        self.kv = None
+        if kv_layers is not None:
+            self.kv = [torch.empty_like(kv) for kv in kv_layers]
+            self.cross_range = torch.zeros((R, 2), dtype=torch.int32, device=dev)
+        self.graph = self.logits = self.pool = None
+        self.eager_steps = 0
+        self.use_graph = dev.type == "cuda" and os.environ.get("VALOR_DECODE_GRAPH", "1") != "0"
+
+    @staticmethod
+    def key(model, b, beam, P, max_len, kv_layers):
+        kvs = None if kv_layers is None else (tuple(kv_layers[0].shape), len(kv_layers))
+        return (b, beam, P, max_len, kvs, model.caption_type)
+
+    def begin_batch(self, kv_layers):
+        """the clips' per-layer [video | audio] K|V into the session's static buffers (once per batch: every group reads them)"""
+        if kv_layers is not None:
+            for dst, src in zip(self.kv, kv_layers):
+                dst.copy_(src)
+
+    def begin_group(self, key_range, prompt_cpu):
+        """reset the text slots; run the prompt rows (one set per clip, bert.py:879-885: they attend to themselves only) and keep their
+        per-layer K|V in slots [0, P) of every beam's row"""
+        m, b, P, E = self.m, self.b, self.P, self.m.spec.hidden
+        self.t.zero_()
+        self.tok.fill_(BOS)
+        self.kmask.fill_(NEG)
+        if self.kv is not None:
+            self.cross_range.copy_(m._dev(torch.tensor([list(key_range)] * self.R, dtype=torch.int32)))
+        if P:
+            valid = m._dev((prompt_cpu != 0).to(torch.float32))                                 # [b, P]
+            pm = (1.0 - valid) * NEG
+            self.kmask.view(self.beam, b, self.L)[:, :, :P] = pm[None]
+            pmask = pm[:, None, :].expand(b, P, P).contiguous()
+            xp = m._bert_embed(m._dev(prompt_cpu), P, "prompt")
+            cache = self.cache.view(self.layers, self.beam, b, self.L, 2 * E)
+
+            def prefill(i, qkv):
+                cache[i, :, :, :P] = qkv[:, :, E:][None]
+                return ops.self_attention(qkv, m.spec.heads, pmask, 0.0)
+            m.bert_encoder(xp, pmask, self.kv, self.cross_range[:b] if self.kv is not None else None, b if self.kv is not None else 0,
+                           self_attn=prefill)
+
+    # ------------------------------------------------------------------ one decoding step (eager, and what the graph captures)
+    def _self_attn(self, i, qkv):
+        E, c = self.m.spec.hidden, self.cache[i]
+        c.index_copy_(1, self.slots_new, qkv[:, :, E:])
+        o, _ = K.attn_fwd(qkv[:, :, :E], c[:, :, :E], c[:, :, E:], self.m.spec.heads, mask=self.amask, scale=0.125)
+        return o
+
+    def _body(self):
+        m, P_, J = self.m, self.m.P, self.J
+        e = "multimodal_encoder.embeddings."
+        if self.beam > 1:                                           # every sequence continues the row `parent` of the previous step
+            self.cache.copy_(self.cache.index_select(1, self.parent))
+            self.kmask.copy_(self.kmask.index_select(0, self.parent))
+        self.ids[:, 0] = self.tok
+        pos = self.t + self.jidx
+        # BertEmbeddings (bert.py:190-218) at positions t, t + 1: the embedding kernel's arithmetic (fp32 sum, one rounding)
+        x = (P_[e + "word_embeddings.weight"][self.ids].float() + P_[e + "position_embeddings.weight"][pos].float()[None]
+             + P_[e + "token_type_embeddings.weight"][0].float()).to(m.dtype)
+        x = ops.layer_norm(x, P_[e + "LayerNorm.weight"], P_[e + "LayerNorm.bias"], 1e-12)
+        slot_t = self.t + self.P
+        self.kmask.index_copy_(1, slot_t, torch.where(self.tok != 0, 0.0, NEG)[:, None])
+        row_a = torch.where(self.slot <= slot_t, self.kmask, NEG)
+        self.amask[:, 0] = row_a
+        if J == 2:
+            self.amask[:, 1] = torch.where(self.slot == slot_t + 1, 0.0, row_a)
+        self.slots_new = slot_t + self.jidx
+        hidden = m.bert_encoder(x, None, self.kv, self.cross_range if self.kv is not None else None, self.b if self.kv is not None else 0,
+                                self_attn=self._self_attn)
+        h = m.cls_transform(hidden[:, J - 1].contiguous())
+        logits = K.gemm(h, P_[e + "word_embeddings.weight"], bias=P_["cls.decoder.bias"], out_dtype=torch.float32)
+        self.t += 1
+        return logits
+
+    def _capture(self):
+        from . import graphs
+        dev = self.m.device
+        ctx = graphs._capture_ctx(dev)
+        with torch.cuda.stream(ctx["stream"]):         # the capture stream's kernel scratch must not come out of the graph's pool
+            K.workspace(dev)
+            K.ReduceQueue.current(dev)
+        self.pool = torch.cuda.graph_pool_handle()
+        g = torch.cuda.CUDAGraph()
+        mode = "thread_local" if (torch.distributed.is_available() and torch.distributed.is_initialized()) else "global"
+        torch.cuda.current_stream(dev).synchronize()
+        with torch.cuda.graph(g, pool=self.pool, stream=ctx["stream"], capture_error_mode=mode):
+            self.logits = self._body()
+        self.graph = g
+
+    def step(self, tok=None, parent=None):
+        """tok int64 [R] (device; None: [CLS], the first step), parent int64 [R] (beam search) -> fp32 logits [R, vocab] of the step's
+        last row (a static buffer when the step is a graph replay: consume it before the next step)"""
+        if tok is not None:
+            self.tok.copy_(tok)
+        if parent is not None:
+            self.parent.copy_(parent)
+        if self.graph is None:
+            if not self.use_graph or self.eager_steps < 1:
+                self.eager_steps += 1
+                return self._body()
+            self._capture()
+        self.graph.replay()
+        return self.logits
+
+
+MAX_SESSIONS = 4
+
+
+def session(model, b, beam, P, max_len, kv_layers):
+    """the model's DecodeSession of this geometry (most recently used last; at most MAX_SESSIONS are kept)"""
+    pool = model.__dict__.setdefault("_decode_sessions", {})
+    key = DecodeSession.key(model, b, beam, P, max_len, kv_layers)
+    s = pool.pop(key, None)
+    if s is None:
+        while len(pool) >= MAX_SESSIONS:
+            pool.pop(next(iter(pool)))
+        s = DecodeSession(model, b, beam, P, max_len, kv_layers)
+    pool[key] = s
+    return s
+
+
+def release_sessions(model):
+    """drop the decoding sessions (their K|V slots, the copies of the clips' K|V and the captured graphs)"""
+    model.__dict__.pop("_decode_sessions", None)
 
 
 def log_softmax_rows(logits):
@@ -136,6 +311,77 @@ def decode_beam(step, b, beam, max_len):
     return outputs.contiguous()[:, 0]
 
 
+def decode_greedy_cached(sess, b, max_len):
+    """decode_greedy on a DecodeSession: the tokens stay on the device (the next step's input is this step's argmax); whether every row
+    has ended is asked every eighth step (a finished row keeps producing [SEP], pretrain.py:1005-1010: the result is the same)."""
+    dev = sess.m.device
+    sents = torch.full((b, max_len), EOS, dtype=torch.long, device=dev)
+    logprobs = torch.zeros((b, max_len), device=dev)
+    unfinished = torch.ones(b, dtype=torch.bool, device=dev)
+    tok = None
+    for t in range(max_len):
+        wt = sess.step(tok).max(1)[1]
+        unfinished = unfinished & (wt != EOS)
+        tok = torch.where(unfinished, wt, EOS)
+        sents[:, t] = tok
+        if t % 8 == 7 and t + 1 < max_len and not bool(unfinished.any()):
+            break
+    return sents, logprobs
+
+
+def decode_beam_cached(sess, b, beam, max_len):
+    """decode_beam on a DecodeSession (rows beam-major): the selection arithmetic of pretrain.py:1054-1180 on the device, the chosen
+    beams as the next step's `parent` rows. Step 0 runs `beam` identical copies of every sequence and reads the first."""
+    dev = sess.m.device
+    seq_logprob = torch.zeros((b, 1, 1), device=dev)
+    seq_mask = torch.ones((b, beam, 1), device=dev)
+    base = torch.arange(b, device=dev)
+    outputs, selected_words, tok, parent = [], None, None, None
+    for t in range(max_len):
+        cur = 1 if t == 0 else beam
+        logits = sess.step(tok, parent)
+        word_logprob = log_softmax_rows(logits[:b * cur]).view(cur, b, -1).transpose(0, 1)
+        cand = seq_logprob + word_logprob
+        if t > 0:
+            mask = (selected_words.view(b, cur) != EOS).float().unsqueeze(-1)
+            seq_mask = seq_mask * mask
+            cand = seq_mask * cand + seq_logprob.expand_as(cand) * (1 - seq_mask)
+        V = cand.shape[-1]
+        sel_logprob, sel_idx = torch.topk(cand.reshape(b, -1), beam, dim=-1, largest=True, sorted=True)   # select :1156-1159
+        sel_beam = sel_idx // V
+        selected_words = sel_idx - sel_beam * V
+        seq_logprob = sel_logprob.unsqueeze(-1)
+        seq_mask = torch.gather(seq_mask, 1, sel_beam.unsqueeze(-1))
+        outputs = [torch.gather(o, 1, sel_beam.unsqueeze(-1)) for o in outputs]
+        outputs.append(selected_words.unsqueeze(-1))
+        parent = (sel_beam.t() * b + base[None]).reshape(-1)        # row (k, s) continues row (sel_beam[s, k], s)
+        tok = selected_words.t().reshape(-1)
+    seq_logprob, sort_idx = torch.sort(seq_logprob, 1, descending=True)
+    outputs = torch.gather(torch.cat(outputs, -1), 1, sort_idx.expand(b, beam, max_len))
+    return outputs.contiguous()[:, 0]
+
+
+def _decode_groups(model, groups, b, kv_layers, ranges, prompt, beam, max_len):
+    """{group: (sequences, logprobs | None)} for the query groups present, through the K|V-cached session or the re-run path"""
+    if isinstance(prompt, str):
+        prompt = model.get_task_prompt(PROMPTS[prompt], b) if model.use_task_prompt else None
+    out = {}
+    sess = None
+    if kv_cache_enabled():
+        sess = session(model, b, beam, 0 if prompt is None else prompt.shape[1], max_len, kv_layers)
+        sess.begin_batch(kv_layers)
+    for g in ("tv", "tva", "ta"):
+        if g not in groups:
+            continue
+        if sess is not None:
+            sess.begin_group(ranges[g] if kv_layers is not None else None, prompt)
+            out[g] = (decode_beam_cached(sess, b, beam, max_len), None) if beam > 1 else decode_greedy_cached(sess, b, max_len)
+        else:
+            step = _Stepper(model, g, kv_layers, ranges, prompt, b)
+            out[g] = (decode_beam(step, b, beam, max_len), None) if beam > 1 else decode_greedy(step, b, max_len)
+    return out
+
+
 def encode_for_generation(model, batch, groups):
     """The encoder half of generate_cap (pretrain.py:916-936): -> (batch size, per-layer K|V of the video/audio tokens, group key ranges)"""
     model.stage.begin_step()
@@ -165,14 +411,11 @@ def generate_cap(model, batch, groups, beam_size=None, max_generation_len=None):
     try:
         b, kv_layers, ranges = encode_for_generation(model, batch, groups)
         out = {}
-        for g, key in (("tv", "t_v"), ("tva", "t_va"), ("ta", "t_a")):
-            if g not in groups:
-                continue
-            step = stepper(model, g, b, kv_layers, ranges)
-            if beam > 1:
-                out["generated_sequences_" + key] = decode_beam(step, b, beam, max_len)
-            else:
-                out["generated_sequences_" + key], out["logprobs_" + key] = decode_greedy(step, b, max_len)
+        for g, (seq, lp) in _decode_groups(model, groups, b, kv_layers, ranges, "caption", beam, max_len).items():
+            key = {"tv": "t_v", "tva": "t_va", "ta": "t_a"}[g]
+            out["generated_sequences_" + key] = seq
+            if lp is not None:
+                out["logprobs_" + key] = lp
         return out
     finally:
         model.train(was_training)
@@ -200,12 +443,7 @@ def generate_qa(model, batch, groups, prompt_cpu, beam_size=None, max_generation
             idx = model._dev(torch.tensor([i for i, n in enumerate(sample_num) for _ in range(n)], dtype=torch.long))
             kv_layers = [ops.gather_rows(kv.reshape(b, -1), idx).view(idx.numel(), *kv.shape[1:]) for kv in kv_layers]
             b = int(idx.numel())
-        out = {}
-        for g, key in (("tv", "t_v"), ("tva", "t_va"), ("ta", "t_a")):
-            if g not in groups:
-                continue
-            step = stepper(model, g, b, kv_layers, ranges, prompt_cpu)
-            out["generated_answers_" + key] = decode_beam(step, b, beam, max_len) if beam > 1 else decode_greedy(step, b, max_len)[0]
-        return out
+        res = _decode_groups(model, groups, b, kv_layers, ranges, prompt_cpu, beam, max_len)
+        return {"generated_answers_" + {"tv": "t_v", "tva": "t_va", "ta": "t_a"}[g]: seq for g, (seq, _lp) in res.items()}
     finally:
         model.train(was_training)

@@ -854,13 +854,15 @@ class VALOR(nn.Module):
         prediction head, the loss) stays eager behind it. Not with activation checkpointing, not in generation / evaluation."""
         return self._use_graphs() and not self.checkpointing and os.environ.get("VALOR_GRAPH_DECODER", "1") != "0"
 
-    def bert_encoder(self, x, mask, kv_layers, kv_range, kv_bmod):
-        """BertEncoder / BertLayer.forward bert.py:440-518 (post-LN; va_concate cross-attention)."""
+    def bert_encoder(self, x, mask, kv_layers, kv_range, kv_bmod, self_attn=None):
+        """BertEncoder / BertLayer.forward bert.py:440-518 (post-LN; va_concate cross-attention).
+        self_attn (generation with a K|V cache, valor_amd/decode.py): callable (layer, qkv [B, T, 3E]) -> attention output [B, T, E] that
+        stands in for the self-attention over the T rows alone."""
         P, H, p = self.P, self.spec.heads, (self.p_drop if self.training else 0.0)
         for i in range(self.spec.layers):
             q = f"multimodal_encoder.encoder.layer.{i}."
             qkv = ops.linear(x, P[q + "attention.self.qkv.weight"], P[q + "attention.self.qkv.bias"])
-            a = ops.self_attention(qkv, H, mask, p)
+            a = self_attn(i, qkv) if self_attn is not None else ops.self_attention(qkv, H, mask, p)
             o = ops.linear(a, P[q + "attention.output.dense.weight"], None)
             x = ops.bias_dropout_residual_ln(o, P[q + "attention.output.dense.bias"], x, P[q + "attention.output.LayerNorm.weight"],
                                              P[q + "attention.output.LayerNorm.bias"], 1e-12, p, False)
