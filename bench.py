@@ -258,7 +258,8 @@ class GemmTimer:
     GEMM launches per step), inflating every duration. So only every `stride`-th launch is timed, with a rotating
     offset per instrumented step; a timed launch carries a few microseconds of event overhead, nothing else changes."""
     FAMILY = {0: "gemm_kernel(128x128 reg-staged)", 1: "gemm_glds_kernel(128x128 LDS-DMA)", 2: "gemm_glds_kernel(128x128 LDS-DMA x2)",
-              3: "gemm_8ph_kernel(256x256 8-phase)", 4: "gemm_8ph2_kernel(256x128 8-phase, 2 workgroups per CU)"}
+              3: "gemm_8ph_kernel(256x256 8-phase)", 4: "gemm_8ph2_kernel(256x128 8-phase, 2 workgroups per CU)",
+              5: "gemm_skinny_kernel(few rows, weights streamed once)"}
 
     def __init__(self, stride=4):
         self.records = []

@@ -1,7 +1,8 @@
 """Throughput of caption generation (VALOR.generate_cap, model/pretrain.py:914-985) on the native decoder at the bench geometry: B clips of
 8 frames + 2 audio slices, group 'tva', greedy and beam-3 decoding to max_generation_len (random weights never emit [SEP]: every row runs
 the full length). Prints where the time goes: the encoders + K|V projections (once per clip) and the decoding loop (re-runs the text rows
-each step like the reference, decode.py). usage: python tools/gen_bench.py out.json [batch] [max_len]"""
+each step like the reference with VALOR_KV_CACHE=0; two rows per sequence against the K|V cache otherwise, decode.py).
+usage: [GEN_MODES=greedy,beam3] python tools/gen_bench.py out.json [batch] [max_len]"""
 import json
 import os
 import sys
@@ -38,7 +39,7 @@ def timed(fn, reps=3):
 with torch.no_grad():
     model.eval()
     res["encode_ms"] = round(timed(lambda: decode.encode_for_generation(model, batch, ["tva"])) * 1e3, 1)
-    for name, beam in (("greedy", 1), ("beam3", 3)):
+    for name, beam in [(n, k) for n, k in (("greedy", 1), ("beam3", 3)) if n in os.environ.get("GEN_MODES", "greedy,beam3")]:
         t = timed(lambda: decode.generate_cap(model, batch, ["tva"], beam_size=beam, max_generation_len=L), reps=2)
         res[name] = {"seconds": round(t, 3), "captions_per_s": round(B / t, 1), "tokens_per_s": round(B * L / t, 1),
                      "ms_per_decoding_step": round((t * 1e3 - res["encode_ms"]) / L, 2)}

@@ -531,7 +531,10 @@ extern "C" int valor_gemm_set_variant(int v) { const int o = g_gemm_variant; if 
 // [9] family 4, NN layout: 1 = main loop on v_mfma_f32_32x32x16_bf16 (gemm8n.hip M32), 0 = v_mfma_f32_16x16x32_bf16
 // [10] family 4, NN layout without split-K: 1 = 512-thread workgroups (gemm8w.hip: 64x64 outputs per wave, four waves per SIMD), 0 = gemm8n.hip
 //      (round 5 used this key for a bf16 half-tile epilogue of the derivative-saving forward: measured slower, removed)
-// [11] reserved
+// [11] few-row products (family 5, gemm_skinny.hip): the largest M that takes the weight-streaming kernel (NN layout, K in {512, 768, 1024, 3072,
+//      4096}; plain / bias / activation epilogues), 0 = never. 384: caption generation with a K|V cache runs 2 rows per sequence and step
+//      (128 rows at 64 clips, 384 with three beams) -- 20 .. 29 us per decoder GEMM on the 128 x 128 kernels (6 .. 24 workgroups),
+//      profiles/r06_generation_kernel_stats_{kvcache,skinny}.md
 thread_local const GemmTuning* t_gemm_tuning = nullptr;
 int g_gemm_policy_default[12] = {[] { const char* e = getenv("VALOR_GEMM_NT_MINK"); return e ? atoi(e) : 768; }(),
                         [] { const char* e = getenv("VALOR_GEMM_SPLITK_BF16"); return e ? atoi(e) : 1; }(),
@@ -543,7 +546,8 @@ int g_gemm_policy_default[12] = {[] { const char* e = getenv("VALOR_GEMM_NT_MINK
                         [] { const char* e = getenv("VALOR_GEMM_NN_MINK"); return e ? atoi(e) : 128; }(),
                         [] { const char* e = getenv("VALOR_GEMM_NARROW"); return e ? atoi(e) : 1000; }(),
                         [] { const char* e = getenv("VALOR_GEMM_MFMA32"); return e ? atoi(e) : 0; }(),
-                        [] { const char* e = getenv("VALOR_GEMM_WIDE"); return e ? atoi(e) : 0; }(), 0};
+                        [] { const char* e = getenv("VALOR_GEMM_WIDE"); return e ? atoi(e) : 0; }(),
+                        [] { const char* e = getenv("VALOR_GEMM_SKINNY"); return e ? atoi(e) : 384; }()};
 extern "C" int valor_gemm_set_policy(int key, int value) {
     if (key < 0 || key > 11) return VALOR_ERR_ARG;
     const int old = g_gemm_policy_default[key];
@@ -593,9 +597,11 @@ static bool use_8ph2(int dtype, int transA, int transB, int M, int N, int K, boo
 }
 
 // kernel family of a problem: 0 = register-staged 128x128 (also all fp32), 1 / 2 = LDS-DMA 128x128 single / double stage,
-// 3 = 256x256 8-phase (gemm8.hip), 4 = 256x128 8-phase with two workgroups per CU (gemm8n.hip)
+// 3 = 256x256 8-phase (gemm8.hip), 4 = 256x128 8-phase with two workgroups per CU (gemm8n.hip), 5 = few rows, weights streamed once
+// (gemm_skinny.hip; a call that asks for an epilogue it does not have -- C +=, a pre-activation copy, an act' operand -- runs on family 1 / 2)
 static int gemm_family(int dtype, int transA, int transB, int M, int N, int K, bool heavy_epi) {
     if (dtype != VALOR_DT_BF16 || gemm_variant() == 0) return 0;
+    if (gemm_variant() == 4 && !transA && !transB && M <= gemm_policy(11) && N >= 16 && gemm_skinny_chunks(K)) return 5;
     const bool big = use_8ph(dtype, transA, transB, M, N, K, heavy_epi);
     if (use_8ph2(dtype, transA, transB, M, N, K, heavy_epi, big)) return 4;
     if (big) return 3;
@@ -836,6 +842,10 @@ static int gemm_impl(void* stream, int dtype, int transA, int transB, int M, int
         const int64_t extB = transB ? (int64_t)K * ldb : ((int64_t)(N - 1) * ldb + K);
         if (extA * esz >= (1ll << 31) || extB * esz >= (1ll << 31)) return VALOR_ERR_ARG;   // buffer offsets are 32-bit
         p.bytesA = (uint32_t)(extA * esz); p.bytesB = (uint32_t)(extB * esz);
+    }
+    if (gemm_family(dtype, transA, transB, M, N, K, false) == 5 && !accumulate && !preact && !dact_aux && !rowsum_out && !(act & VALOR_ACT_DERIV)) {
+        p.kslices = 1; p.ksteps_per_slice = 0;
+        return launch_gemm_skinny((hipStream_t)stream, p);
     }
     const int bk = 8 * vec;
     const int nk = (K + bk - 1) / bk;

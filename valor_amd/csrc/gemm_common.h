@@ -229,6 +229,9 @@ void launch_gemm_8ph2(hipStream_t st, int transA, int transB, const GemmArgs& p)
 // the same tile on 512-thread workgroups (gemm8w.hip: 64x64 outputs per wave, four waves per SIMD), NN layout without split-K; p carries
 // launch_gemm_8ph2's epilogue / raster / store-mode choices. grid.x = tiles(256 x 128).
 void launch_gemm_8w(hipStream_t st, const GemmArgs& p, int tiles, bool nts);
+// few-row products (gemm_skinny.hip, family 5): chunks per wave for a covered contraction length (0: not covered) and the launcher
+int gemm_skinny_chunks(int K);
+int launch_gemm_skinny(hipStream_t st, const GemmArgs& p);
 // ---- tuning knobs. Process defaults (valor_gemm_set_policy / _set_variant / ...; env presets) live in globals; a CALL can override any
 // of them through a valor_gemm_policy (include/valor_hip.h) handed to valor_gemm_tuned / valor_gemm_kernel_for_tuned: the entry points
 // park a pointer to it in a thread-local for the duration of the call, every read below looks there first. -1 = the process default.

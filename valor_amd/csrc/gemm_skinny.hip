@@ -1,0 +1,123 @@
+// valor_gemm, bf16, family 5: C[M, N] = act(alpha * A[M, K] . B[N, K]^T + bias) for a FEW rows of A (policy key 11: M <= 384) -- the
+// decoder GEMMs of caption generation with a K|V cache (valor_amd/decode.py: two rows per sequence and step, M = 128 at 64 clips), the
+// contrastive heads' cls rows. The reference runs these as nn.Linear on [b, t, 768] (model/bert.py:233-235,351,403-420; greedy / beam
+// decoding model/pretrain.py:988-1188).
+//
+// Such a product is one pass over the WEIGHTS (N x K x 2 bytes: 1.2 .. 4.7 MB per decoder GEMM, 47 MB for the vocabulary projection) with
+// next to no arithmetic. The 128 x 128-tile kernels give it N / 128 = 6 .. 24 workgroups, each walking K = 768 .. 3072 in 64-wide steps
+// behind its own latency chain: 20 .. 29 us per launch (profiles/r06_generation_kernel_stats_kvcache.md), 1.6 ms of a 3.3 ms decoding
+// step. Here the weight matrix is cut into 16-row slices (N / 16 workgroups: 48 .. 1908) and the contraction into eight parts, one
+// per wave of a 512-thread workgroup; every wave requests its whole part up front (K = 768: three 16-byte loads per operand row and lane,
+// all in flight; K = 3072: twelve, four chunks ahead) and the eight partial tiles meet in LDS. A workgroup's life is about two memory
+// latencies.
+//
+//   grid (ceil(N / 16), ceil(M / 64)); wave w: k in [w K / 8, (w + 1) K / 8), chunks of 32 (one v_mfma_f32_16x16x32_bf16 per 16-row
+//   block of A); lane (fr = lane & 15, g = lane >> 4) reads 16 bytes at k + 8 g of A rows m0 + 16 t + fr (t = 0 .. 3) and of B row n0 + fr
+//   straight from global memory into the MFMA operand registers (the fragment layout of mma.h: no LDS staging, nothing is reused
+//   inside a workgroup). Rows past M / N are clamped (loads) and not stored.
+//   Reduction: wave w leaves its four accumulator quads in red[w] (32 KiB), after the barrier thread (row = tid / 8, column pair = tid % 8)
+//   adds the eight partials of two neighbouring columns in wave order, applies alpha, bias and the activation, and stores 4 (bf16) or
+//   8 (fp32 output) bytes.
+// K / 256 is a template parameter (2, 3, 4, 12, 16: K = 512, 768, 1024, 3072, 4096 -- every contraction length of the decoders and heads of
+// the shipped configurations); other lengths stay on the 128 x 128 kernels.
+#include "gemm_common.h"
+
+#define SK_WAVES 8
+#define SK_DEPTH 4
+
+template <int NCH>
+__global__ __launch_bounds__(512) void gemm_skinny_kernel(GemmArgs p) {
+    __shared__ float red[SK_WAVES][4][256];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int fr = lane & 15, g = lane >> 4;
+    const int n0 = blockIdx.x * 16, m0 = blockIdx.y * 64;
+    const int kbase = wave * (NCH * 32) + g * 8;
+    const bf16_t* A = (const bf16_t*)p.A;
+    const bf16_t* B = (const bf16_t*)p.B;
+    const bf16_t* arow[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        const int m = m0 + t * 16 + fr;
+        arow[t] = A + (int64_t)(m < p.M ? m : p.M - 1) * p.lda + kbase;
+    }
+    const int nb = n0 + fr;
+    const bf16_t* brow = B + (int64_t)(nb < p.N ? nb : p.N - 1) * p.ldb + kbase;
+
+    constexpr int D = NCH < SK_DEPTH ? NCH : SK_DEPTH;
+    u32x4_t ra[D][4], rb[D];
+    f32x4_t acc[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) acc[t] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int c = 0; c < D; ++c) {
+        rb[c] = *(const u32x4_t*)(brow + c * 32);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) ra[c][t] = *(const u32x4_t*)(arow[t] + c * 32);
+    }
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+        const int s = c % D;
+        const bf16x8_t fb = __builtin_bit_cast(bf16x8_t, rb[s]);
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+            acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, ra[s][t]), fb, acc[t], 0, 0, 0);
+        if (c + D < NCH) {
+            rb[s] = *(const u32x4_t*)(brow + (c + D) * 32);
+#pragma unroll
+            for (int t = 0; t < 4; ++t) ra[s][t] = *(const u32x4_t*)(arow[t] + (c + D) * 32);
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < 4; ++t) *(f32x4_t*)&red[wave][t][lane * 4] = acc[t];
+    __syncthreads();
+    // acc[t][r] of lane l is C[m0 + 16 t + 4 (l >> 4) + r][n0 + (l & 15)]
+    const int row = tid >> 3, cp = (tid & 7) * 2;
+    const int t = row >> 4, r = row & 3, lq = ((row & 15) >> 2) * 16 + cp;
+    float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+    for (int w = 0; w < SK_WAVES; ++w) {
+        s0 += red[w][t][lq * 4 + r];
+        s1 += red[w][t][(lq + 1) * 4 + r];
+    }
+    const int m = m0 + row, n = n0 + cp;
+    if (m >= p.M || n >= p.N) return;
+    const bool two = n + 1 < p.N;
+    s0 *= p.alpha; s1 *= p.alpha;
+    if (p.bias) {
+        const bf16_t* bias = (const bf16_t*)p.bias;
+        s0 += (float)bias[n];
+        if (two) s1 += (float)bias[n + 1];
+    }
+    const int act = p.act & VALOR_ACT_MASK;
+    if (act != VALOR_ACT_NONE) { s0 = act_fwd(act, s0); s1 = act_fwd(act, s1); }
+    if (p.out_f32) {
+        float* C = (float*)p.C + (int64_t)m * p.ldc + n;
+        if (two && ((p.ldc & 1) == 0) && (((uintptr_t)p.C & 7) == 0)) *(f32x2_t*)C = (f32x2_t){s0, s1};
+        else { C[0] = s0; if (two) C[1] = s1; }
+    } else {
+        bf16_t* C = (bf16_t*)p.C + (int64_t)m * p.ldc + n;
+        if (two && ((p.ldc & 1) == 0) && (((uintptr_t)p.C & 3) == 0)) *(uint32_t*)C = pack2_bf16(s0, s1);
+        else { C[0] = (bf16_t)s0; if (two) C[1] = (bf16_t)s1; }
+    }
+}
+
+// the contraction lengths this family covers (see above); 0: not covered
+int gemm_skinny_chunks(int K) {
+    if (K % 256) return 0;
+    const int n = K / 256;
+    return (n == 2 || n == 3 || n == 4 || n == 12 || n == 16) ? n : 0;
+}
+
+// p: A / B / C / bias, lda / ldb / ldc, M / N / K, act, alpha, out_f32 (no split-K, no pre-activation copy, no act' operand, no C +=)
+int launch_gemm_skinny(hipStream_t st, const GemmArgs& p) {
+    dim3 grid((p.N + 15) / 16, (p.M + 63) / 64);
+    switch (gemm_skinny_chunks(p.K)) {
+        case 2: hipLaunchKernelGGL((gemm_skinny_kernel<2>), grid, dim3(512), 0, st, p); break;
+        case 3: hipLaunchKernelGGL((gemm_skinny_kernel<3>), grid, dim3(512), 0, st, p); break;
+        case 4: hipLaunchKernelGGL((gemm_skinny_kernel<4>), grid, dim3(512), 0, st, p); break;
+        case 12: hipLaunchKernelGGL((gemm_skinny_kernel<12>), grid, dim3(512), 0, st, p); break;
+        case 16: hipLaunchKernelGGL((gemm_skinny_kernel<16>), grid, dim3(512), 0, st, p); break;
+        default: return VALOR_ERR_ARG;
+    }
+    return valor_launch_status();
+}

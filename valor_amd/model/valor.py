@@ -408,7 +408,7 @@ class VALOR(nn.Module):
     def _clip_blocks(self, x, prefix, n_layers, heads, mask, final_g, final_b):
         """pre-LN CLIP transformer (clip.py:194-214) + final LayerNorm; x: [N, L, E] residual stream."""
         P = self.P
-        y = ops.layer_norm(x, P[f"{prefix}.resblocks.0.ln_1.weight"], P[f"{prefix}.resblocks.0.ln_1.bias"], 1e-5)
+        x, y = ops.layer_norm_stream(x, P[f"{prefix}.resblocks.0.ln_1.weight"], P[f"{prefix}.resblocks.0.ln_1.bias"], 1e-5)
 
         def block(i, x, y):
             """resblock i on (residual stream x, its LayerNorm y) -> the same pair for block i + 1 (the last one: the final LayerNorm only)"""
@@ -702,7 +702,7 @@ class VALOR(nn.Module):
                                 P["audio_embeddings.first_conv.bias"], bn, Pn)
         if p > 0:
             x = ops.bias_dropout_residual(x, None, None, p)
-        y = ops.layer_norm(x, P["audio_encoder.layer.0.layernorm1.weight"], P["audio_encoder.layer.0.layernorm1.bias"], 1e-12)
+        x, y = ops.layer_norm_stream(x, P["audio_encoder.layer.0.layernorm1.weight"], P["audio_encoder.layer.0.layernorm1.bias"], 1e-12)
 
         def layer(i, x, y):
             q = f"audio_encoder.layer.{i}."
@@ -1238,7 +1238,8 @@ class VALOR(nn.Module):
                 if sp.video_encoder == "swin":                     # token mean, then frame mean = the mean over all F * X rows
                     pooled = ops.group_mean(video_output.reshape(-1, sp.video_dim), F * video_output.shape[2])
                 else:
-                    cls_v = ops.gather_rows(video_output.reshape(-1, sp.vis_width), self._const_idx(b * F, sp.vis_tokens))
+                    vo, cls_v = ops.tap_rows(video_output.reshape(-1, sp.vis_width), self._const_idx(b * F, sp.vis_tokens))
+                    video_output = vo.view(video_output.shape)          # what the decoder inputs read below (ops.TapRowsFn)
                     pooled = ops.group_mean(cls_v, F)
                 if sp.clip_heads:
                     feat_v = ops.l2_normalize(ops.linear(pooled, P["clip_model.visual.proj"], None, w_is_kn=True))
@@ -1246,7 +1247,8 @@ class VALOR(nn.Module):
                     feat_v = ops.l2_normalize(ops.linear(pooled, P["contra_head_v.linear.weight"], None))
             if "a" in "".join(contra_task):
                 b, A = audio_output.shape[:2]
-                cls_a = ops.gather_rows(audio_output.reshape(-1, sp.aud_width), self._const_idx(b * A, sp.aud_tokens))
+                ao, cls_a = ops.tap_rows(audio_output.reshape(-1, sp.aud_width), self._const_idx(b * A, sp.aud_tokens))
+                audio_output = ao.view(audio_output.shape)
                 feat_a = ops.l2_normalize(ops.linear(ops.group_mean(cls_a, A), P["contra_head_a.linear.weight"], None))
             tok_contra = clip_tokens if txt_output is not None else None
             if compute_loss and self.gather_fn is not None:
@@ -1288,7 +1290,8 @@ class VALOR(nn.Module):
             elif "v" in "".join(contra_task):
                 b, F = video_output.shape[:2]
                 idx = self._const_idx(b * F, sp.vis_tokens)
-                cls_v = ops.gather_rows(video_output.reshape(-1, sp.vis_width), idx)
+                vo, cls_v = ops.tap_rows(video_output.reshape(-1, sp.vis_width), idx)
+                video_output = vo.view(video_output.shape)              # what the decoder inputs read below (ops.TapRowsFn)
                 if sp.clip_heads:                                  # pretrain.py:89-92
                     feat_v = ops.l2_normalize(ops.linear(cls_v, P["clip_model.visual.proj"], None, w_is_kn=True)).view(b, F, -1)
                 else:                                              # Contra_head beside a CLIP video encoder (pretrain.py:93-97)
@@ -1296,7 +1299,8 @@ class VALOR(nn.Module):
             if "a" in "".join(contra_task):
                 b, A = audio_output.shape[:2]
                 idx = self._const_idx(b * A, sp.aud_tokens)
-                cls_a = ops.gather_rows(audio_output.reshape(-1, sp.aud_width), idx)
+                ao, cls_a = ops.tap_rows(audio_output.reshape(-1, sp.aud_width), idx)
+                audio_output = ao.view(audio_output.shape)
                 feat_a = ops.l2_normalize(ops.linear(cls_a, P["contra_head_a.linear.weight"], None)).view(b, A, -1)
             if compute_loss and self.gather_fn is not None:       # ddp_allgather_with_grads / ddp_allgather (pretrain.py:278-291)
                 feat_t, feat_v, feat_a, tok_contra = self.gather_fn(feat_t, feat_v, feat_a, self._dev(tok_contra))

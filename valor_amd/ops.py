@@ -87,6 +87,10 @@ def _2d(x):
     return x.reshape(-1, x.shape[-1])
 
 
+# VALOR_FUSE_GLUE=0: layer_norm_stream / tap_rows fall back to separate nodes whose gradients autograd adds (A/B of the glue kernels)
+FUSE_GLUE = os.environ.get("VALOR_FUSE_GLUE", "1") != "0"
+
+
 class GradSink:
     """Parameter gradients are accumulated by the producing kernel straight into the flat gradient arena
     (wgrad GEMM epilogue `C += ...`, column-sum finalize with accumulate) instead of being returned to autograd,
@@ -143,13 +147,18 @@ class CheckpointFn(Function):
     keeps the layer's INPUTS only, the backward runs the layer again -- with ops.DropoutState rewound to the offsets the first run drew,
     so the regenerated dropout masks are the forward's -- and back-propagates through that second run. Parameter gradients take their
     usual route (GradSink kernels accumulate into the arena, the reducer is told by the recomputed layer's backward)."""
+    first_pass = 0
 
     @staticmethod
     def forward(ctx, fn, *args):
         ctx.fn = fn
         ctx.off0 = DropoutState.offset
-        with torch.no_grad():
-            outs = fn(*args)
+        CheckpointFn.first_pass += 1           # the layer must run the kernels its second (differentiated) run will: bit-identical activations
+        try:
+            with torch.no_grad():
+                outs = fn(*args)
+        finally:
+            CheckpointFn.first_pass -= 1
         ctx.single = not isinstance(outs, tuple)
         ctx.save_for_backward(*args)
         return outs
@@ -244,6 +253,10 @@ class LinearFn(Function):
 
 
 def linear(x, w, b=None, act=ACT_NONE, w_is_kn=False, grad_slot=None, out=None):
+    if act != ACT_NONE and not torch.is_grad_enabled() and not CheckpointFn.first_pass:      # _inference(): no pre-activation copy
+        kw = {} if out is None else {"out": _2d(out)}
+        y = K.gemm(_2d(x), w, trans_b=w_is_kn, bias=b, act=act, **kw)
+        return y.view(*x.shape[:-1], y.shape[-1])
     return LinearFn.apply(x, w, b, act, w_is_kn, grad_slot, out)
 
 
@@ -315,7 +328,16 @@ class MlpFn(Function):
         return dx, dw1, db1, dw2, db2, None, None
 
 
+def _inference():
+    """no autograd graph is being built (torch.no_grad: evaluation, generation) and this is not the first run of a checkpointed layer, which
+    must run the kernels its second, differentiated run will (bit-identical activations)"""
+    return not torch.is_grad_enabled() and not CheckpointFn.first_pass
+
+
 def mlp(x, w1, b1, w2, b2, act, grad_slot=None):
+    if _inference():       # no second [rows, inter] output of the first GEMM (the saved act'(u): 620 MB per ViT layer at the bench shape)
+        y = K.gemm(K.gemm(_2d(x), w1, bias=b1, act=act), w2, bias=b2)
+        return y.view(*x.shape[:-1], y.shape[-1])
     return MlpFn.apply(x, w1, b1, w2, b2, act, grad_slot)
 
 
@@ -333,7 +355,8 @@ class BdrLnFn(Function):
         if p_drop > 0:
             seed, off = DropoutState.draw(x.numel())
         plain = bias is None and residual is None and p_drop == 0 and row_scale is None
-        assert not (plain and want_z), "want_z needs a bias / residual / dropout stage"
+        # plain + want_z (layer_norm_stream): "z" is x itself -- the first block of a pre-LN stack, whose input feeds both the block's
+        # LayerNorm and its residual add: the two gradients then meet inside this node's backward kernel (dz_in) instead of in an add
         z, y, mean, rstd = K.bdrln_fwd(x, bias, residual.contiguous() if residual is not None else None, gamma, beta,
                                        eps, p_drop=p_drop, seed=seed, offset=off, write_z=not plain, row_scale=row_scale,
                                        rows_per_scale=rows_per_scale)
@@ -342,7 +365,7 @@ class BdrLnFn(Function):
         ctx.cfg = (p_drop, seed, off, bias is not None, residual is not None, beta is not None)
         ctx.params = (gamma, beta, bias)
         if want_z:
-            return z, y
+            return (x.view_as(x) if plain else z), y
         return y
 
     @staticmethod
@@ -381,6 +404,15 @@ class BdrLnFn(Function):
 
 def layer_norm(x, gamma, beta, eps):
     return BdrLnFn.apply(x, None, None, gamma, beta, eps, 0.0, False)
+
+
+def layer_norm_stream(x, gamma, beta, eps):
+    """(x, LayerNorm(x)) as ONE autograd node: for an x that is also the residual stream of the block it enters (the first block of a
+    pre-LN stack, clip.py:194-214 / transformer.py:156-170). The residual gradient comes back as the first output's gradient and is
+    added inside the LayerNorm backward kernel; autograd's own add of two [rows, E] tensors (three passes over them) is gone."""
+    if not FUSE_GLUE:
+        return x, layer_norm(x, gamma, beta, eps)
+    return BdrLnFn.apply(x, None, None, gamma, beta, eps, 0.0, True)
 
 
 def bias_dropout_residual_ln(x, bias, residual, gamma, beta, eps, p_drop, want_z, row_scale=None, rows_per_scale=0, res_slot=None):
@@ -1248,6 +1280,49 @@ class GatherRowsFn(Function):
 
 def gather_rows(x2d, idx):
     return GatherRowsFn.apply(x2d, idx)
+
+
+class TapRowsFn(Function):
+    """(x2d, x2d[idx]) as ONE autograd node, for an activation that feeds another consumer besides the row selection (an encoder's
+    output: its cls rows go to the contrastive head, modeling.py:387,399, all of it to the decoder's cross-attention input). Backward:
+    the rows' gradient is added INTO the other consumer's gradient (gather the few rows, add, write them back) -- a separate
+    GatherRowsFn costs a zero-filled [rows, E] tensor plus autograd's add of two [rows, E] tensors. idx must not repeat a row."""
+
+    @staticmethod
+    def forward(ctx, x2d, idx):
+        x2d = x2d.contiguous()
+        ctx.set_materialize_grads(False)
+        n, E = idx.numel(), x2d.shape[1]
+        out = torch.empty((n, E), dtype=x2d.dtype, device=x2d.device)
+        lib.call("valor_gather_rows", _st(), _dt(x2d), _p(x2d), _p(idx), _p(out), n, E, x2d.stride(0))
+        ctx.save_for_backward(idx)
+        ctx.shape = x2d.shape
+        return x2d.view_as(x2d), out
+
+    @staticmethod
+    def backward(ctx, dx, drows):
+        (idx,) = ctx.saved_tensors
+        if drows is None:
+            return dx, None
+        drows = drows.contiguous()
+        n, E = idx.numel(), drows.shape[1]
+        if dx is None:
+            dx = torch.zeros(ctx.shape, dtype=drows.dtype, device=drows.device)
+        else:
+            # dx is the other consumer's freshly written gradient (CrossInputFn / SingleInputFn.backward allocate it): updated in place
+            dx = dx.contiguous()
+            cur = torch.empty_like(drows)
+            lib.call("valor_gather_rows", _st(), _dt(dx), _p(dx), _p(idx), _p(cur), n, E, dx.stride(0))
+            drows = cur.add_(drows)
+        lib.call("valor_scatter_rows", _st(), _dt(drows), _p(drows), _p(idx), _p(dx), n, E, dx.stride(0))
+        return dx, None
+
+
+def tap_rows(x2d, idx):
+    """-> (x2d for the other consumer, x2d[idx])"""
+    if not FUSE_GLUE:
+        return x2d, gather_rows(x2d, idx)
+    return TapRowsFn.apply(x2d, idx)
 
 
 class RowDotFn(Function):
