@@ -140,7 +140,13 @@ int valor_gemm_set_fast_epilogue(int v);
  *          results up to the order of the fp32 partial sums), 0 (default) = v_mfma_f32_16x16x32_bf16 (env VALOR_GEMM_MFMA32); measured
  *          0-8 % SLOWER on the K = 768 forward shapes under the pipelined schedule, equal under the plain one and at K = 3072
  *          (profiles/r05_gemm_mfma32_ab.json)
- *   keys 10, 11: reserved */
+ *   key 10: family 4, NN layout without split-K: 1 = 512-thread workgroups of 64x64 wave tiles (csrc/gemm8w.hip; env VALOR_GEMM_WIDE), 0 (default):
+ *          measured equal (profiles/r06_gemm_wide_ab_v2.json)
+ *   key 11: the largest M of a few-row NN product that runs on the weight-streaming kernel (family 5, csrc/gemm_skinny.hip: K in {512, 768, 1024,
+ *          3072, 4096}; plain / bias / activation / alpha / fp32-output epilogues -- a call that asks for C +=, a pre-activation copy or an
+ *          act' operand runs on the 128x128 kernels): default 384 (env VALOR_GEMM_SKINNY), 0 = never. nn.Linear on the 2 rows per sequence of a
+ *          K|V-cached decoding step (model/bert.py:233-235,351,403-420): 20-29 us -> 8.8-17.6 us per launch
+ *          (profiles/r06_generation_kernel_stats_{kvcache,skinny}.md) */
 int valor_gemm_set_policy(int key, int value);
 /* K-loop schedule of the family-3 (256x256) kernel: 0 = eight barriers per K-tile, wave rows staggered by one barrier; 1 = software-pipelined:
  * two barriers per K-tile, fragment reads and LDS-DMA pieces between the MFMAs of the half-phase before their consumer. Same results (same
