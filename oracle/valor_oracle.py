@@ -302,7 +302,7 @@ class Oracle:
         return layer_norm(h + x, w(p + out + "LayerNorm.weight"), w(p + out + "LayerNorm.bias"), 1e-12)
 
     def bert_model(self, tokens, task_prompt, video_feat, audio_feat, casual, full_masker=False):
-        """BertModel.forward, has_cross_attn branch, model/bert.py:848-896 ; BertLayer :440-496 (va_concate)"""
+        """BertModel.forward, has_cross_attn branch, model/bert.py:848-896 ; BertLayer :440-496 (every cross_attn_type)"""
         w, sp = self.w, self.spec
         x = self.bert_embeddings(tokens, None, full_masker)
         token_len = x.shape[1]
@@ -323,6 +323,7 @@ class Oracle:
             am[:, :token_len, :token_len] = torch.tril(am[:, :token_len, :token_len])
             am[:, token_len:, :token_len] = 0
         am = ((1.0 - am.unsqueeze(1).float()) * -10000.0)
+        mode = getattr(sp, "cross_attn_type", "va_concate")
         if video_feat is not None and audio_feat is not None:
             cross = torch.cat((video_feat, audio_feat), dim=1)
         elif video_feat is not None:
@@ -332,8 +333,20 @@ class Oracle:
         for i in range(sp.layers):
             p = f"multimodal_encoder.encoder.layer.{i}."
             x = self.bert_attn(x, x, p, "attention.self", am)
-            if cross is not None:
-                x = self.bert_attn(x, cross, p, "cross_attn.cross", None)
+            if mode == "va_concate":                                                             # bert.py:447-457
+                if cross is not None:
+                    x = self.bert_attn(x, cross, p, "cross_attn.cross", None)
+            elif video_feat is not None and audio_feat is not None:
+                if mode == "va_parallel":                                                        # bert.py:459-463: both blocks read x, outputs summed
+                    x = self.bert_attn(x, video_feat, p, "cross_attn_v.cross", None) + self.bert_attn(x, audio_feat, p, "cross_attn_a.cross", None)
+                else:                                                                            # bert.py:472-476 / 486-489: one after the other
+                    first, second = (("v", video_feat), ("a", audio_feat)) if mode == "video_audio" else (("a", audio_feat), ("v", video_feat))
+                    x = self.bert_attn(x, first[1], p, f"cross_attn_{first[0]}.cross", None)
+                    x = self.bert_attn(x, second[1], p, f"cross_attn_{second[0]}.cross", None)
+            elif video_feat is not None:                                                         # one modality: its block alone (every mode)
+                x = self.bert_attn(x, video_feat, p, "cross_attn_v.cross", None)
+            elif audio_feat is not None:
+                x = self.bert_attn(x, audio_feat, p, "cross_attn_a.cross", None)
             h = gelu_erf(F.linear(x, w(p + "intermediate.dense.weight"), w(p + "intermediate.dense.bias")))
             h = dropout(F.linear(h, w(p + "output.dense.weight"), w(p + "output.dense.bias")), self.p)
             x = layer_norm(h + x, w(p + "output.LayerNorm.weight"), w(p + "output.LayerNorm.bias"), 1e-12)

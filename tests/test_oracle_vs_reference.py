@@ -638,3 +638,45 @@ def test_frozen_options_freeze_the_reference_s_parameters(variant):
     # nothing frozen by default
     plain = VALOR({"dropout": 0.0}, spec=spec, dtype=torch.float32, device="cpu")
     assert all(p.requires_grad for p in plain.P.values())
+
+
+@pytest.mark.parametrize("mode", ["va_parallel", "video_audio", "audio_video"])
+def test_cross_attention_block_per_modality_matches_reference(mode):
+    """cross_attn_type != 'va_concate' (model/bert.py:430-436,459-496): a cross-attention block per modality (cross_attn_v / cross_attn_a with
+    their own query / key / value / output / LayerNorm), summed or applied one after the other; a group with one modality runs that
+    modality's block alone. Pretraining task string (groups tva, tv, ta) against the unmodified reference: losses and every gradient --
+    incl. those of both blocks' parameters --, the caption finetune loss, greedy captions."""
+    import dataclasses
+    from valor_amd import synth
+    from valor_oracle import Oracle, trainable_copy
+    spec, ropts = dataclasses.replace(_shallow(synth.base_spec()), cross_attn_type=mode), ref_harness.default_opts(cross_attn_type=mode)
+    sd = synth.make_state_dict(spec, seed=27)
+    ref = ref_harness.build_reference(ropts, state_dict=None, dropout=0.0, **SHALLOW)
+    missing, unexpected = ref.load_state_dict(sd, strict=False)
+    assert not missing and not unexpected
+    sd_o = trainable_copy(sd)
+    orc = Oracle(spec, sd_o, vocab_tokens=synth.synthetic_vocab(spec.vocab))
+    batch = synth.make_batch(spec, batch=2, frames=1, audio_slices=1, txt_len=32, seed=28)
+    random.seed(5); r = ref(batch, task=TASK, compute_loss=True); sum(r.values()).backward()
+    random.seed(5); o = orc.forward_pt(batch, TASK, compute_loss=True); sum(o.values()).backward()
+    for k in ("contra_loss", "caption_loss", "mlm_loss"):
+        assert abs(float(r[k]) - float(o[k])) <= 2e-5 * abs(float(r[k])), (k, float(r[k]), float(o[k]))
+    n = blocks = 0
+    for name, p in ref.named_parameters():
+        if p.grad is None:
+            continue
+        g = sd_o[name].grad
+        scale = max(float(p.grad.norm()), 1e-4 * p.grad.numel() ** 0.5)
+        assert float((g - p.grad).norm()) / scale < 2e-4, name
+        n += 1
+        blocks += ("cross_attn_v." in name) or ("cross_attn_a." in name)
+    assert n > 150 and blocks == 2 * spec.layers * 10          # query / key / value / dense / LayerNorm (weight + bias) of both blocks of every layer
+    with torch.no_grad():
+        random.seed(6); rc = ref(dict(batch), task="cap%tva%tv%ta", compute_loss=True)
+        random.seed(6); oc = orc.forward(batch, "cap%tva%tv%ta", compute_loss=True)
+        assert abs(float(rc["caption_loss"]) - float(oc["caption_loss"])) <= 2e-5 * abs(float(rc["caption_loss"]))
+        ref.max_generation_len, ref.beam_size = 5, 1
+        rg = ref(dict(batch), task="cap%tva%tv", compute_loss=False)
+        og = orc.forward_cap(batch, "cap%tva%tv", compute_loss=False, beam_size=1, max_generation_len=5)
+        for k in ("generated_sequences_t_va", "generated_sequences_t_v"):
+            assert torch.equal(rg[k], og[k]), k

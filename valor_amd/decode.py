@@ -26,7 +26,7 @@ import os
 import torch
 
 from . import kernels as K, lib, ops
-from .model.valor import PROMPTS
+from .model.valor import PROMPTS, _BlockKV
 
 BOS, EOS, MASK = 101, 102, 103          # [CLS] / [SEP] / [MASK] of bert-base-uncased, model/modeling.py:669-671
 
@@ -41,6 +41,7 @@ class _Stepper:
     def __init__(self, model, group, kv_layers, ranges, prompt_cpu, b):
         self.m, self.kv, self.b, self.prompt = model, kv_layers, b, prompt_cpu
         self.range = list(ranges[group]) if kv_layers is not None else None
+        self.blocks = isinstance(kv_layers, _BlockKV)
 
     def logits(self, state, rows):
         """state: host int64 [rows, t] in (sample, beam) order (None at t = 0) -> fp32 logits [rows, vocab] of the last text position:
@@ -67,7 +68,9 @@ class _Stepper:
         Ttot = x.shape[1]
         amask = m._dev(m._bert_mask(txt, prompt, True))
         kv_range = None
-        if self.kv is not None:
+        if self.blocks:                                             # a cross-attention block per modality: the group is a tuple of modalities
+            kv_range = tuple(self.range)
+        elif self.kv is not None:
             kv_range = m._dev(torch.tensor([self.range] * rows, dtype=torch.int32))
         hidden = m.bert_encoder(x, amask, self.kv, kv_range, b if self.kv is not None else 0)
         idx = m._dev(torch.arange(rows, dtype=torch.int64) * Ttot + (T - 1))
@@ -367,7 +370,7 @@ def _decode_groups(model, groups, b, kv_layers, ranges, prompt, beam, max_len):
         prompt = model.get_task_prompt(PROMPTS[prompt], b) if model.use_task_prompt else None
     out = {}
     sess = None
-    if kv_cache_enabled():
+    if kv_cache_enabled() and not isinstance(kv_layers, _BlockKV):      # (a block per modality, bert.py:459-496: the re-run path)
         sess = session(model, b, beam, 0 if prompt is None else prompt.shape[1], max_len, kv_layers)
         sess.begin_batch(kv_layers)
     for g in ("tv", "tva", "ta"):
@@ -441,7 +444,8 @@ def generate_qa(model, batch, groups, prompt_cpu, beam_size=None, max_generation
                 raise ValueError(f"sample_num {sample_num} does not describe {b} clips / {prompt_cpu.shape[0]} questions")
             from . import ops
             idx = model._dev(torch.tensor([i for i, n in enumerate(sample_num) for _ in range(n)], dtype=torch.long))
-            kv_layers = [ops.gather_rows(kv.reshape(b, -1), idx).view(idx.numel(), *kv.shape[1:]) for kv in kv_layers]
+            rows_of = lambda kvs: None if kvs is None else [ops.gather_rows(kv.reshape(b, -1), idx).view(idx.numel(), *kv.shape[1:]) for kv in kvs]
+            kv_layers = _BlockKV(rows_of(kv_layers.v), rows_of(kv_layers.a)) if isinstance(kv_layers, _BlockKV) else rows_of(kv_layers)
             b = int(idx.numel())
         res = _decode_groups(model, groups, b, kv_layers, ranges, prompt_cpu, beam, max_len)
         return {"generated_answers_" + {"tv": "t_v", "tva": "t_va", "ta": "t_a"}[g]: seq for g, (seq, _lp) in res.items()}

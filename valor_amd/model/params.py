@@ -145,12 +145,13 @@ def param_table(spec: ValorSpec):
         add(s + "qkv.bias", (3 * H,), [s + f"{n}.bias" for n in ("query", "key", "value")])
         o = p + "attention.output."
         add(o + "dense.weight", (H, H)); add(o + "dense.bias", (H,)); add(o + "LayerNorm.weight", (H,)); add(o + "LayerNorm.bias", (H,))
-        c = p + "cross_attn.cross."
-        add(c + "query.weight", (H, H)); add(c + "query.bias", (H,))
-        add(c + "kv.weight", (2 * H, H), [c + "key.weight", c + "value.weight"])
-        add(c + "kv.bias", (2 * H,), [c + "key.bias", c + "value.bias"])
-        o = p + "cross_attn.output."
-        add(o + "dense.weight", (H, H)); add(o + "dense.bias", (H,)); add(o + "LayerNorm.weight", (H,)); add(o + "LayerNorm.bias", (H,))
+        for blk in spec.cross_blocks:          # "cross_attn", or "cross_attn_v" + "cross_attn_a" (bert.py:430-436)
+            c = p + blk + ".cross."
+            add(c + "query.weight", (H, H)); add(c + "query.bias", (H,))
+            add(c + "kv.weight", (2 * H, H), [c + "key.weight", c + "value.weight"])
+            add(c + "kv.bias", (2 * H,), [c + "key.bias", c + "value.bias"])
+            o = p + blk + ".output."
+            add(o + "dense.weight", (H, H)); add(o + "dense.bias", (H,)); add(o + "LayerNorm.weight", (H,)); add(o + "LayerNorm.bias", (H,))
         add(p + "intermediate.dense.weight", (spec.inter, H)); add(p + "intermediate.dense.bias", (spec.inter,))
         add(p + "output.dense.weight", (H, spec.inter)); add(p + "output.dense.bias", (H,))
         add(p + "output.LayerNorm.weight", (H,)); add(p + "output.LayerNorm.bias", (H,))

@@ -98,6 +98,17 @@ class _DeferredKV:
         self.va = va
 
 
+class _BlockKV:
+    """per-layer K|V of the video tokens and of the audio tokens, each projected by its OWN cross-attention block (cross_attn_type
+    'va_parallel' / 'video_audio' / 'audio_video', bert.py:430-436): v / a = list of [b, S, 2E] per layer, or None without that modality.
+    A query group is then a tuple of modality letters, not a key range."""
+    def __init__(self, v=None, a=None):
+        self.v, self.a = v, a
+
+    def of(self, m):
+        return self.v if m == "v" else self.a
+
+
 class VALOR(nn.Module):
     def __init__(self, opts=None, spec: ValorSpec = None, dtype=torch.bfloat16, device="cuda", vocab_tokens=None):
         super().__init__()
@@ -145,8 +156,14 @@ class VALOR(nn.Module):
         self.caption_type = _opt(opts, "caption_type", "unimlm")        # pretrain.py:76
         self.label_smoothing = float(_opt(opts, "label_smoothing", 0.0))    # pretrain.py:72-74: the caption FINETUNE loss only (:839-840)
         self._smoothing = 0.0                                            # label smoothing of the decoder passes being issued
-        if _opt(opts, "cross_attn_type", "va_concate") != "va_concate":
-            raise NotImplementedError("cross_attn_type='va_concate' only")
+        # bert.py:430-436: one cross-attention block over [video | audio] ('va_concate', every shipped configuration) or a block per modality,
+        # summed ('va_parallel') or applied one after the other ('video_audio', 'audio_video'): another parameter set, so it lives in the spec
+        xt = _opt(opts, "cross_attn_type", spec.cross_attn_type)
+        if xt not in ("va_concate", "va_parallel", "video_audio", "audio_video"):
+            raise NotImplementedError(f"cross_attn_type {xt!r} (bert.py:430 asserts the same four)")
+        if xt != spec.cross_attn_type:
+            import dataclasses
+            spec = dataclasses.replace(spec, cross_attn_type=xt)
         # pretrain.py:79: the caption rows become [tokens | as many [MASK]s], position L/2 + i predicts token i + 1 (the finetune losses; generation
         # ignores the flag like the reference's, :878-900)
         self.full_masker = bool(_opt(opts, "full_masker", False))
@@ -832,6 +849,23 @@ class VALOR(nn.Module):
                                 P["hidden_trans_audio_multimodal.0.bias"])
                 ha = ops.layer_norm(ha, P["hidden_trans_audio_multimodal.1.weight"], P["hidden_trans_audio_multimodal.1.bias"], 1e-12)
                 audio_output = ha.view(*audio_output.shape[:3], sp.hidden)
+            if sp.cross_attn_type != "va_concate":
+                # a block per modality: each projects its own modality's tokens (own key / value weights). Plain tensors through autograd
+                # (no static buffers, no graphed decoder): these modes run the per-pass decoder path (_decoder_groups)
+                def project(x, fe, te, blk):
+                    inp, slot = ops.single_input(x, P[fe], P[te]), ops.GradSlot()
+                    return [ops.linear(inp, P[f"multimodal_encoder.encoder.layer.{i}.{blk}.cross.kv.weight"],
+                                       P[f"multimodal_encoder.encoder.layer.{i}.{blk}.cross.kv.bias"], grad_slot=slot) for i in range(sp.layers)]
+                kv = _BlockKV(project(video_output, "video_frame_embedding", "video_type_embeddings", "cross_attn_v") if video_output is not None else None,
+                              project(audio_output, "audio_frame_embedding", "audio_type_embeddings", "cross_attn_a") if audio_output is not None else None)
+                ranges = {}
+                if kv.v is not None and kv.a is not None:
+                    ranges["tva"] = ("v", "a")
+                if kv.v is not None:
+                    ranges["tv"] = ("v",)
+                if kv.a is not None:
+                    ranges["ta"] = ("a",)
+                return kv, ranges
             if video_output is not None and audio_output is not None:
                 va = ops.cross_input(video_output, audio_output, P["video_frame_embedding"], P["video_type_embeddings"],
                                      P["audio_frame_embedding"], P["audio_type_embeddings"])
@@ -866,7 +900,9 @@ class VALOR(nn.Module):
             o = ops.linear(a, P[q + "attention.output.dense.weight"], None)
             x = ops.bias_dropout_residual_ln(o, P[q + "attention.output.dense.bias"], x, P[q + "attention.output.LayerNorm.weight"],
                                              P[q + "attention.output.LayerNorm.bias"], 1e-12, p, False)
-            if kv_layers is not None:
+            if isinstance(kv_layers, _BlockKV):
+                x = self._cross_blocks(i, x, kv_layers, kv_range, kv_bmod, p)
+            elif kv_layers is not None:
                 cq = ops.linear(x, P[q + "cross_attn.cross.query.weight"], P[q + "cross_attn.cross.query.bias"])
                 c = ops.cross_attention(cq, kv_layers[i], H, kv_range, kv_bmod, p, grad_slot=self._kv_slots[i])
                 o = ops.linear(c, P[q + "cross_attn.output.dense.weight"], None)
@@ -874,6 +910,27 @@ class VALOR(nn.Module):
                                                  P[q + "cross_attn.output.LayerNorm.bias"], 1e-12, p, False)
             m = ops.mlp(x, P[q + "intermediate.dense.weight"], P[q + "intermediate.dense.bias"], P[q + "output.dense.weight"], None, ACT_GELU_ERF)
             x = ops.bias_dropout_residual_ln(m, P[q + "output.dense.bias"], x, P[q + "output.LayerNorm.weight"], P[q + "output.LayerNorm.bias"], 1e-12, p, False)
+        return x
+
+    def _cross_blocks(self, i, x, kv, mods, kv_bmod, p):
+        """the per-modality cross-attention blocks of layer i (bert.py:459-496): mods = the modalities this query group attends to.
+        One modality: its block alone (every mode). Both: 'va_parallel' = both blocks read x and their outputs (each a full BertAttention:
+        attention, dense, dropout, residual, LayerNorm) are summed; 'video_audio' / 'audio_video' = one after the other."""
+        P, H = self.P, self.spec.heads
+
+        def block(m, xin):
+            q = f"multimodal_encoder.encoder.layer.{i}.cross_attn_{m}."
+            cq = ops.linear(xin, P[q + "cross.query.weight"], P[q + "cross.query.bias"])
+            c = ops.cross_attention(cq, kv.of(m)[i], H, None, kv_bmod, p)
+            o = ops.linear(c, P[q + "output.dense.weight"], None)
+            return ops.bias_dropout_residual_ln(o, P[q + "output.dense.bias"], xin, P[q + "output.LayerNorm.weight"],
+                                                P[q + "output.LayerNorm.bias"], 1e-12, p, False)
+        if len(mods) == 1:
+            return block(mods[0], x)
+        if self.spec.cross_attn_type == "va_parallel":
+            return block("v", x) + block("a", x)
+        for m in (("v", "a") if self.spec.cross_attn_type == "video_audio" else ("a", "v")):
+            x = block(m, x)
         return x
 
     def cls_transform(self, rows):
@@ -885,6 +942,14 @@ class VALOR(nn.Module):
     def _decoder_groups(self, txt_input, txt_labels, groups, prompt_cpu, casual, kv_layers, ranges, b, compute_loss, tag, out, per_sample=False,
                         kv_b=None):
         """Run the decoder for len(groups) query groups as ONE batch (same text input, different K/V rows)."""
+        blocks = isinstance(kv_layers, _BlockKV)
+        if blocks and len(groups) > 1:
+            # a block per modality: the groups differ in which blocks a layer runs (bert.py:459-496), so they cannot share a batch
+            res = [self._decoder_groups(txt_input, txt_labels, [g], prompt_cpu, casual, kv_layers, ranges, b, compute_loss, tag, out, per_sample, kv_b)
+                   for g in groups]
+            if compute_loss and per_sample:
+                return torch.cat([r[0] for r in res], dim=0), res[0][1]
+            return sum(res) / len(res) if compute_loss else None        # equal row counts per group: the mean of the per-group means
         G, T = len(groups), txt_input.shape[1]
         ids = self._dev(txt_input)
         x = self._bert_embed(ids, T, None, self._full_attn and casual)
@@ -897,7 +962,9 @@ class VALOR(nn.Module):
             x = x.repeat(G, 1, 1)
             mask = mask.repeat(G, 1, 1)
         kv_range = None
-        if kv_layers is not None:
+        if blocks:
+            kv_range = ranges[groups[0]]
+        elif kv_layers is not None:
             kv_range = self._dev(torch.tensor([list(ranges[g]) for g in groups for _ in range(b)], dtype=torch.int32))
         # kv_b: the K|V batch when it is smaller than the text rows (row r attends to clip r % kv_b: answer-major tiled rows of image QA)
         hidden = self.bert_encoder(x, mask, kv_layers, kv_range, (kv_b or b) if kv_layers is not None else 0)
@@ -1364,7 +1431,12 @@ class VALOR(nn.Module):
             for g in ("tva", "tv", "ta"):
                 if g in mlm_task:
                     passes.append(("mlm", mlm_in, mlm_lab, [g], self.get_task_prompt(PROMPTS["mlm_" + g], bs), False))
-            res = self._decoder_fused(passes, kv_layers, ranges, bs)
+            if isinstance(kv_layers, _BlockKV):          # a cross-attention block per modality: one decoder run per pass and group
+                res = {}
+                for (tag, tin, tlab, groups, prompt, casual) in passes:
+                    res.setdefault(tag, []).append(self._decoder_groups(tin, tlab, groups, prompt, casual, kv_layers, ranges, bs, True, tag, out))
+            else:
+                res = self._decoder_fused(passes, kv_layers, ranges, bs)
             if "caption" in res:
                 out["caption_loss"] = res["caption"][0]                                  # pretrain.py:473-479
             if "mlm" in res:

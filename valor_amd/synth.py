@@ -53,6 +53,15 @@ class ValorSpec:
     # "coarse" = one pooled vector per modality and plain similarity matrices, with a va_fusion Linear for the tva group unless late_fusion
     contra_type: str = "fine"
     late_fusion: bool = False
+    # how a decoder layer attends to the video / audio tokens (model/bert.py:430-436,447-496): "va_concate" = ONE cross-attention block over
+    # the concatenated [video | audio] tokens (every shipped configuration); "va_parallel" / "video_audio" / "audio_video" = a block per
+    # modality (cross_attn_v, cross_attn_a: own query / key / value / output / LayerNorm), their outputs summed or applied one after the other
+    cross_attn_type: str = "va_concate"
+
+    @property
+    def cross_blocks(self):
+        """names of a decoder layer's cross-attention blocks"""
+        return ("cross_attn",) if self.cross_attn_type == "va_concate" else ("cross_attn_v", "cross_attn_a")
 
     @property
     def cdim(self):
@@ -209,7 +218,7 @@ def _audio_bert_heads(spec, add):
     add(e + "LayerNorm.weight", (H,), "g"); add(e + "LayerNorm.bias", (H,), "b")
     for i in range(spec.layers):
         p = f"multimodal_encoder.encoder.layer.{i}."
-        for blk in ("attention.self", "cross_attn.cross"):
+        for blk in ("attention.self",) + tuple(c + ".cross" for c in spec.cross_blocks):
             for n in ("query", "key", "value"):
                 add(p + f"{blk}.{n}.weight", (H, H)); add(p + f"{blk}.{n}.bias", (H,), "b")
             out = blk.split(".")[0] + ".output."
