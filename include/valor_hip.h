@@ -144,7 +144,9 @@ int valor_gemm_set_fast_epilogue(int v);
  *          measured equal (profiles/r06_gemm_wide_ab_v2.json)
  *   key 11: the largest M of a few-row NN product that runs on the weight-streaming kernel (family 5, csrc/gemm_skinny.hip: K in {512, 768, 1024,
  *          3072, 4096}; plain / bias / activation / alpha / fp32-output epilogues -- a call that asks for C +=, a pre-activation copy or an
- *          act' operand runs on the 128x128 kernels): default 384 (env VALOR_GEMM_SKINNY), 0 = never. nn.Linear on the 2 rows per sequence of a
+ *          act' operand runs on the 128x128 kernels): 0 = never = the process default (the training step keeps the kernels its parity evidence
+ *          was collected on); the inference paths of valor_amd ask for 384 per call through a valor_gemm_policy (env VALOR_GEMM_SKINNY; env
+ *          VALOR_GEMM_SKINNY_ALL sets the process default). nn.Linear on the 2 rows per sequence of a
  *          K|V-cached decoding step (model/bert.py:233-235,351,403-420): 20-29 us -> 8.8-17.6 us per launch
  *          (profiles/r06_generation_kernel_stats_{kvcache,skinny}.md) */
 int valor_gemm_set_policy(int key, int value);

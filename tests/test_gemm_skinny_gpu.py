@@ -1,8 +1,11 @@
 """The few-row weight-streaming GEMM (csrc/gemm_skinny.hip, kernel family 5: the decoder GEMMs of caption generation with a K|V cache,
 valor_amd/decode.py; nn.Linear on a handful of rows in the reference, model/bert.py:233-235,351,403-420) against fp64 torch.matmul on
 the device: every covered contraction length, ragged M / N (rows and columns past the last whole 64 x 16 block), every epilogue it has
-(bias, activation, alpha, fp32 output), strided operands; the policy (key 11) and what falls back to the 128 x 128 kernels; and the same
-products on the kernel it replaces (family 1; family 4 at M = 384) within the bf16 rounding of the output."""
+(bias, activation, alpha, fp32 output), strided operands; the policy (key 11: 0 for the process -- the training step keeps its kernels --,
+384 per call from the inference paths, kernels.infer_policy()) and what falls back to the 128 x 128 kernels; and the same products on the
+kernel it replaces (family 1; family 4 at M = 384) within the bf16 rounding of the output."""
+import ctypes
+
 import pytest
 import torch
 
@@ -36,24 +39,20 @@ CASES = [(128, 768, 768), (128, 2304, 768), (128, 3072, 768), (128, 768, 3072), 
 @pytest.mark.parametrize("M,N,Kd", CASES)
 def test_skinny_matches_fp64(dev, M, N, Kd):
     from valor_amd import kernels as K, lib
-    so = lib.load()
-    assert so.valor_gemm_kernel_for(0, 0, 0, M, N, Kd, 0) == 5
+    so, pol = lib.load(), K.infer_policy()
+    assert so.valor_gemm_kernel_for_tuned(ctypes.addressof(pol), 0, 0, 0, M, N, Kd, 0) == 5
+    assert so.valor_gemm_kernel_for(0, 0, 0, M, N, Kd, 0) in (1, 2, 3, 4)          # the process default: the training step's kernels
     A, B, bias = _mk((M, Kd), dev, 1), _mk((N, Kd), dev, 2, 0.05), _mk((N,), dev, 3)
     ref = A.double() @ B.double().t()
-    C = K.gemm(A, B)
+    C = K.gemm(A, B, policy=pol)
     assert C.dtype == torch.bfloat16 and _rel(C, ref) < 4e-3, _rel(C, ref)
     for act in (0, 1, 2, 3):
-        C = K.gemm(A, B, bias=bias, act=act, alpha=0.5, out_dtype=torch.float32)
+        C = K.gemm(A, B, bias=bias, act=act, alpha=0.5, out_dtype=torch.float32, policy=pol)
         want = _act(0.5 * ref + bias.double(), act)
         assert C.dtype == torch.float32 and _rel(C, want) < 2e-5, (act, _rel(C, want))      # fp32 accumulation, fp32 output: no bf16 rounding
-    # the kernel it replaces, on the same operands: equal up to the bf16 rounding of the output
-    old = so.valor_gemm_set_policy(11, 0)
-    try:
-        assert so.valor_gemm_kernel_for(0, 0, 0, M, N, Kd, 0) in (1, 2, 3, 4)
-        C1 = K.gemm(A, B, bias=bias, act=1, out_dtype=torch.float32)
-    finally:
-        so.valor_gemm_set_policy(11, old)
-    C5 = K.gemm(A, B, bias=bias, act=1, out_dtype=torch.float32)
+    # the kernel it replaces, on the same operands: equal up to the order of the fp32 partial sums
+    C1 = K.gemm(A, B, bias=bias, act=1, out_dtype=torch.float32)
+    C5 = K.gemm(A, B, bias=bias, act=1, out_dtype=torch.float32, policy=pol)
     assert _rel(C5, C1) < 2e-5
 
 
@@ -64,7 +63,7 @@ def test_skinny_strided_operands_and_untouched_padding(dev):
     Abig, B = _mk((M, 3 * Kd), dev, 5), _mk((N, Kd), dev, 6, 0.05)
     A = Abig[:, Kd:2 * Kd]
     out = torch.full((M, N + 56), 7.0, dtype=torch.bfloat16, device=dev)
-    K.gemm(A, B, out=out[:, 8:8 + N])
+    K.gemm(A, B, out=out[:, 8:8 + N], policy=K.infer_policy())
     ref = A.double() @ B.double().t()
     assert _rel(out[:, 8:8 + N], ref) < 4e-3
     assert bool((out[:, :8] == 7).all()) and bool((out[:, 8 + N:] == 7).all())
@@ -72,15 +71,20 @@ def test_skinny_strided_operands_and_untouched_padding(dev):
 
 def test_skinny_policy_and_fallbacks(dev):
     from valor_amd import kernels as K, lib
-    so = lib.load()
-    fam = lambda M, N, Kd, ta=0, tb=0: so.valor_gemm_kernel_for(0, ta, tb, M, N, Kd, 0)
+    so, pol = lib.load(), K.infer_policy()
+    fam = lambda M, N, Kd, ta=0, tb=0: so.valor_gemm_kernel_for_tuned(ctypes.addressof(pol), 0, ta, tb, M, N, Kd, 0)
     assert fam(384, 768, 768) == 5 and fam(385, 768, 768) != 5            # key 11: M <= 384
     assert fam(128, 768, 832) != 5 and fam(128, 768, 2048) != 5            # contraction lengths it has no instantiation for
     assert fam(128, 768, 768, 1, 1) != 5 and fam(128, 768, 768, 0, 1) != 5 # NN layout only
-    assert so.valor_gemm_kernel_for(1, 0, 0, 128, 768, 768, 0) == 0        # fp32: the register-staged kernel
+    assert so.valor_gemm_kernel_for_tuned(ctypes.addressof(pol), 1, 0, 0, 128, 768, 768, 0) == 0        # fp32: the register-staged kernel
+    old = so.valor_gemm_set_policy(11, 200)                                # a process default (env VALOR_GEMM_SKINNY_ALL)
+    try:
+        assert so.valor_gemm_kernel_for(0, 0, 0, 128, 768, 768, 0) == 5 and so.valor_gemm_kernel_for(0, 0, 0, 256, 768, 768, 0) != 5
+    finally:
+        so.valor_gemm_set_policy(11, old)
     # epilogues it does not have run on the 128 x 128 kernels and give the same numbers: C +=, a pre-activation copy
     A, B = _mk((128, 768), dev, 7), _mk((768, 768), dev, 8, 0.05)
     ref = A.double() @ B.double().t()
     C = torch.ones((128, 768), dtype=torch.float32, device=dev)
-    K.gemm(A, B, out=C, accumulate=True, out_dtype=torch.float32)
+    K.gemm(A, B, out=C, accumulate=True, out_dtype=torch.float32, policy=pol)
     assert _rel(C, ref + 1) < 2e-5

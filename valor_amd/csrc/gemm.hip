@@ -532,8 +532,11 @@ extern "C" int valor_gemm_set_variant(int v) { const int o = g_gemm_variant; if 
 // [10] family 4, NN layout without split-K: 1 = 512-thread workgroups (gemm8w.hip: 64x64 outputs per wave, four waves per SIMD), 0 = gemm8n.hip
 //      (round 5 used this key for a bf16 half-tile epilogue of the derivative-saving forward: measured slower, removed)
 // [11] few-row products (family 5, gemm_skinny.hip): the largest M that takes the weight-streaming kernel (NN layout, K in {512, 768, 1024, 3072,
-//      4096}; plain / bias / activation epilogues), 0 = never. 384: caption generation with a K|V cache runs 2 rows per sequence and step
-//      (128 rows at 64 clips, 384 with three beams) -- 20 .. 29 us per decoder GEMM on the 128 x 128 kernels (6 .. 24 workgroups),
+//      4096}; plain / bias / activation epilogues), 0 = never. The PROCESS default is 0 -- the training step keeps the kernels its parity
+//      evidence was collected on (a 2 x 2 InfoNCE of a B = 2 fixture moved from 3e-4 to 1.25e-3 of the reference when the contrastive heads'
+//      16-row products changed their summation order) --; the inference paths (valor_amd/ops.py under torch.no_grad, valor_amd/decode.py)
+//      ask for 384 per call (valor_gemm_tuned): caption generation with a K|V cache runs 2 rows per sequence and step (128 rows at 64
+//      clips, 384 with three beams) -- 20 .. 29 us per decoder GEMM on the 128 x 128 kernels (6 .. 24 workgroups),
 //      profiles/r06_generation_kernel_stats_{kvcache,skinny}.md
 thread_local const GemmTuning* t_gemm_tuning = nullptr;
 int g_gemm_policy_default[12] = {[] { const char* e = getenv("VALOR_GEMM_NT_MINK"); return e ? atoi(e) : 768; }(),
@@ -547,7 +550,7 @@ int g_gemm_policy_default[12] = {[] { const char* e = getenv("VALOR_GEMM_NT_MINK
                         [] { const char* e = getenv("VALOR_GEMM_NARROW"); return e ? atoi(e) : 1000; }(),
                         [] { const char* e = getenv("VALOR_GEMM_MFMA32"); return e ? atoi(e) : 0; }(),
                         [] { const char* e = getenv("VALOR_GEMM_WIDE"); return e ? atoi(e) : 0; }(),
-                        [] { const char* e = getenv("VALOR_GEMM_SKINNY"); return e ? atoi(e) : 384; }()};
+                        [] { const char* e = getenv("VALOR_GEMM_SKINNY_ALL"); return e ? atoi(e) : 0; }()};
 extern "C" int valor_gemm_set_policy(int key, int value) {
     if (key < 0 || key > 11) return VALOR_ERR_ARG;
     const int old = g_gemm_policy_default[key];

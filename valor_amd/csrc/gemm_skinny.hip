@@ -1,6 +1,6 @@
-// valor_gemm, bf16, family 5: C[M, N] = act(alpha * A[M, K] . B[N, K]^T + bias) for a FEW rows of A (policy key 11: M <= 384) -- the
-// decoder GEMMs of caption generation with a K|V cache (valor_amd/decode.py: two rows per sequence and step, M = 128 at 64 clips), the
-// contrastive heads' cls rows. The reference runs these as nn.Linear on [b, t, 768] (model/bert.py:233-235,351,403-420; greedy / beam
+// valor_gemm, bf16, family 5: C[M, N] = act(alpha * A[M, K] . B[N, K]^T + bias) for a FEW rows of A (policy key 11, asked for per call by
+// the inference paths: M <= 384) -- the decoder GEMMs of caption generation with a K|V cache (valor_amd/decode.py: two rows per sequence
+// and step, M = 128 at 64 clips). The reference runs these as nn.Linear on [b, t, 768] (model/bert.py:233-235,351,403-420; greedy / beam
 // decoding model/pretrain.py:988-1188).
 //
 // Such a product is one pass over the WEIGHTS (N x K x 2 bytes: 1.2 .. 4.7 MB per decoder GEMM, 47 MB for the vocabulary projection) with

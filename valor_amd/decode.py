@@ -191,7 +191,7 @@ class DecodeSession:
         hidden = m.bert_encoder(x, None, self.kv, self.cross_range if self.kv is not None else None, self.b if self.kv is not None else 0,
                                 self_attn=self._self_attn)
         h = m.cls_transform(hidden[:, J - 1].contiguous())
-        logits = K.gemm(h, P_[e + "word_embeddings.weight"], bias=P_["cls.decoder.bias"], out_dtype=torch.float32)
+        logits = K.gemm(h, P_[e + "word_embeddings.weight"], bias=P_["cls.decoder.bias"], out_dtype=torch.float32, policy=K.infer_policy())
         self.t += 1
         return logits
 

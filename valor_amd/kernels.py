@@ -211,6 +211,20 @@ def gemm(a, b, *, trans_a=False, trans_b=False, bias=None, act=ACT_NONE, want_pr
     return (out, preact) if want_preact else out
 
 
+_INFER_POLICY = None
+
+
+def infer_policy():
+    """the valor_gemm_policy of inference-only products (ops.linear / ops.mlp under torch.no_grad, the decoding step of valor_amd/decode.py):
+    few-row products on the weight-streaming kernel (GEMM family 5, policy key 11; VALOR_GEMM_SKINNY=0 turns it off). The training step does
+    not use it: its kernels are the ones its parity evidence was collected on."""
+    global _INFER_POLICY
+    if _INFER_POLICY is None:
+        import os
+        _INFER_POLICY = lib.GemmPolicy.make(skinny=int(os.environ.get("VALOR_GEMM_SKINNY", "384")))
+    return _INFER_POLICY
+
+
 def gemm_fuses_rowsum(a, b, trans_a, trans_b):
     """True if valor_gemm can produce the row sums of op(A) (bias gradient) beside this GEMM."""
     if not (trans_a and a.dtype == torch.bfloat16):

@@ -23,7 +23,7 @@ _vp, _i, _i64, _u64, _f = _c.c_void_p, _c.c_int, _c.c_int64, _c.c_uint64, _c.c_f
 class GemmPolicy(_c.Structure):
     """valor_gemm_policy of include/valor_hip.h: per-call tuning, -1 = the process default. GemmPolicy.make(narrow=1, mfma32=1, ...)"""
     _fields_ = [("key", _i * 12), ("variant", _i), ("tr_asm", _i), ("fast_epilogue", _i), ("sched_256", _i), ("sched_narrow", _i)]
-    KEYS = dict(nt_min_k=0, splitk_bf16=1, min_tiles=2, nt_min_tiles=3, raster=4, store=5, nta=6, nn_min_k=7, narrow=8, mfma32=9, wide=10)
+    KEYS = dict(nt_min_k=0, splitk_bf16=1, min_tiles=2, nt_min_tiles=3, raster=4, store=5, nta=6, nn_min_k=7, narrow=8, mfma32=9, wide=10, skinny=11)
 
     @classmethod
     def make(cls, **kw):

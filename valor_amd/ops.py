@@ -253,9 +253,9 @@ class LinearFn(Function):
 
 
 def linear(x, w, b=None, act=ACT_NONE, w_is_kn=False, grad_slot=None, out=None):
-    if act != ACT_NONE and not torch.is_grad_enabled() and not CheckpointFn.first_pass:      # _inference(): no pre-activation copy
+    if not torch.is_grad_enabled() and not CheckpointFn.first_pass:      # _inference(): no pre-activation copy, few-row products on family 5
         kw = {} if out is None else {"out": _2d(out)}
-        y = K.gemm(_2d(x), w, trans_b=w_is_kn, bias=b, act=act, **kw)
+        y = K.gemm(_2d(x), w, trans_b=w_is_kn, bias=b, act=act, policy=K.infer_policy(), **kw)
         return y.view(*x.shape[:-1], y.shape[-1])
     return LinearFn.apply(x, w, b, act, w_is_kn, grad_slot, out)
 
@@ -336,7 +336,7 @@ def _inference():
 
 def mlp(x, w1, b1, w2, b2, act, grad_slot=None):
     if _inference():       # no second [rows, inter] output of the first GEMM (the saved act'(u): 620 MB per ViT layer at the bench shape)
-        y = K.gemm(K.gemm(_2d(x), w1, bias=b1, act=act), w2, bias=b2)
+        y = K.gemm(K.gemm(_2d(x), w1, bias=b1, act=act, policy=K.infer_policy()), w2, bias=b2, policy=K.infer_policy())
         return y.view(*x.shape[:-1], y.shape[-1])
     return MlpFn.apply(x, w1, b1, w2, b2, act, grad_slot)
 
