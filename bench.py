@@ -302,6 +302,32 @@ class GemmTimer:
         return {v: {"flops": f, "seconds": s, "launches": n, "TFLOPs": f / s / 1e12, "avg_us": s / n * 1e6} for v, (f, s, n) in agg.items()}
 
 
+def time_generation(args, dev, max_len=30):
+    """caption generation of the headline model (VALOR.generate_cap, model/pretrain.py:914-985) on args.batch clips, group
+    'tva', greedy and beam-3 to `max_len` tokens (random weights never emit [SEP]: every row runs the full length), encoders included:
+    captions/s with the self-attention K|V cache and the graphed decoding step (valor_amd/decode.py), one warm call + two timed."""
+    import time
+    from valor_amd import decode, synth
+    from valor_amd.model.valor import VALOR
+    spec = synth.base_spec()
+    model = VALOR({"dropout": args.dropout}, spec=spec, dtype=torch.bfloat16, device=dev)
+    model.load_state_dict(synth.make_state_dict(spec, seed=50), strict=True)
+    batch = synth.make_batch(spec, batch=args.batch, frames=args.frames, audio_slices=args.audio_slices, txt_len=32, seed=50)
+    batch["video_pixels"], batch["audio_spectrograms"] = batch["video_pixels"].to(dev), batch["audio_spectrograms"].to(dev)
+    out = {"clips": args.batch, "max_generation_len": max_len, "group": "tva", "kv_cache": decode.kv_cache_enabled(), "unit": "captions/s"}
+    with torch.no_grad():
+        for name, beam in (("greedy", 1), ("beam3", 3)):
+            decode.generate_cap(model, batch, ["tva"], beam_size=beam, max_generation_len=max_len)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(2):
+                decode.generate_cap(model, batch, ["tva"], beam_size=beam, max_generation_len=max_len)
+            torch.cuda.synchronize()
+            out[name] = round(2 * args.batch / (time.perf_counter() - t0), 1)
+    decode.release_sessions(model)
+    return out
+
+
 def time_variant(variant, args, dev, steps=3, warmup=2, frames=None, accum=1, batch=None, checkpointing=False):
     """`steps` timed OPTIMIZER steps (each `accum` micro-steps of args.batch samples, train_utils.py:311-317) of another model variant at
     the headline's batch and -- unless `frames` says otherwise -- clip length (one rank): samples/s, step time, step MFU on the necessary
@@ -628,6 +654,12 @@ def main():
                     res["variants"][v] = {"error": repr(e)}
                 gc.collect()
                 torch.cuda.empty_cache()
+            try:                       # the adjacent consumer of the same kernels, driver-visible: captions/s
+                res["generation"] = time_generation(args, dev)
+            except Exception as e:
+                res["generation"] = {"error": repr(e)}
+            gc.collect()
+            torch.cuda.empty_cache()
         if world == 1 and not args.no_cpu_baseline:
             try:
                 res["cpu_baseline"] = cpu_baseline(frames=args.frames, audio_slices=args.audio_slices, variant=args.variant)
