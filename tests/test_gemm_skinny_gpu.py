@@ -33,7 +33,8 @@ def _act(x, act):
 
 
 CASES = [(128, 768, 768), (128, 2304, 768), (128, 3072, 768), (128, 768, 3072), (64, 30522, 768), (384, 768, 768), (2, 768, 768),
-         (65, 40, 512), (100, 1000, 1024), (33, 130, 4096), (1, 16, 768)]
+         (65, 40, 512), (100, 1000, 1024), (33, 130, 4096), (1, 16, 768),
+         (384, 768, 3072), (250, 3072, 768), (193, 100, 512), (300, 520, 4096), (192, 30522, 768)]      # above 192 rows: 128-row blocks per workgroup
 
 
 @pytest.mark.parametrize("M,N,Kd", CASES)

@@ -11,7 +11,7 @@
 // all in flight; K = 3072: twelve, four chunks ahead) and the eight partial tiles meet in LDS. A workgroup's life is about two memory
 // latencies.
 //
-//   grid (ceil(N / 16), ceil(M / 64)); wave w: k in [w K / 8, (w + 1) K / 8), chunks of 32 (one v_mfma_f32_16x16x32_bf16 per 16-row
+//   grid (ceil(N / 16), ceil(M / 64)) -- 128-row blocks (MT = 8) above 192 rows --; wave w: k in [w K / 8, (w + 1) K / 8), chunks of 32 (one v_mfma_f32_16x16x32_bf16 per 16-row
 //   block of A); lane (fr = lane & 15, g = lane >> 4) reads 16 bytes at k + 8 g of A rows m0 + 16 t + fr (t = 0 .. 3) and of B row n0 + fr
 //   straight from global memory into the MFMA operand registers (the fragment layout of mma.h: no LDS staging, nothing is reused
 //   inside a workgroup). Rows past M / N are clamped (loads) and not stored.
@@ -25,79 +25,86 @@
 #define SK_WAVES 8
 #define SK_DEPTH 4
 
-template <int NCH>
+// MT = 16-row blocks of A per workgroup: 4 (64 rows: up to 192 rows of A -- more workgroups) or 8 (128 rows: beam search runs 384 rows,
+// every workgroup of a column slice re-reads that slice of the weights from L2)
+template <int NCH, int MT>
 __global__ __launch_bounds__(512) void gemm_skinny_kernel(GemmArgs p) {
-    __shared__ float red[SK_WAVES][4][256];
+    __shared__ float red[SK_WAVES][MT][256];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int fr = lane & 15, g = lane >> 4;
-    const int n0 = blockIdx.x * 16, m0 = blockIdx.y * 64;
+    const int n0 = blockIdx.x * 16, m0 = blockIdx.y * (16 * MT);
     const int kbase = wave * (NCH * 32) + g * 8;
     const bf16_t* A = (const bf16_t*)p.A;
     const bf16_t* B = (const bf16_t*)p.B;
-    const bf16_t* arow[4];
+    const bf16_t* arow[MT];
 #pragma unroll
-    for (int t = 0; t < 4; ++t) {
+    for (int t = 0; t < MT; ++t) {
         const int m = m0 + t * 16 + fr;
         arow[t] = A + (int64_t)(m < p.M ? m : p.M - 1) * p.lda + kbase;
     }
     const int nb = n0 + fr;
     const bf16_t* brow = B + (int64_t)(nb < p.N ? nb : p.N - 1) * p.ldb + kbase;
 
-    constexpr int D = NCH < SK_DEPTH ? NCH : SK_DEPTH;
-    u32x4_t ra[D][4], rb[D];
-    f32x4_t acc[4];
+    constexpr int DEPTH = MT > 4 ? 3 : SK_DEPTH;
+    constexpr int D = NCH < DEPTH ? NCH : DEPTH;
+    u32x4_t ra[D][MT], rb[D];
+    f32x4_t acc[MT];
 #pragma unroll
-    for (int t = 0; t < 4; ++t) acc[t] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+    for (int t = 0; t < MT; ++t) acc[t] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int c = 0; c < D; ++c) {
         rb[c] = *(const u32x4_t*)(brow + c * 32);
 #pragma unroll
-        for (int t = 0; t < 4; ++t) ra[c][t] = *(const u32x4_t*)(arow[t] + c * 32);
+        for (int t = 0; t < MT; ++t) ra[c][t] = *(const u32x4_t*)(arow[t] + c * 32);
     }
 #pragma unroll
     for (int c = 0; c < NCH; ++c) {
         const int s = c % D;
         const bf16x8_t fb = __builtin_bit_cast(bf16x8_t, rb[s]);
 #pragma unroll
-        for (int t = 0; t < 4; ++t)
+        for (int t = 0; t < MT; ++t)
             acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, ra[s][t]), fb, acc[t], 0, 0, 0);
         if (c + D < NCH) {
             rb[s] = *(const u32x4_t*)(brow + (c + D) * 32);
 #pragma unroll
-            for (int t = 0; t < 4; ++t) ra[s][t] = *(const u32x4_t*)(arow[t] + (c + D) * 32);
+            for (int t = 0; t < MT; ++t) ra[s][t] = *(const u32x4_t*)(arow[t] + (c + D) * 32);
         }
     }
 #pragma unroll
-    for (int t = 0; t < 4; ++t) *(f32x4_t*)&red[wave][t][lane * 4] = acc[t];
+    for (int t = 0; t < MT; ++t) *(f32x4_t*)&red[wave][t][lane * 4] = acc[t];
     __syncthreads();
     // acc[t][r] of lane l is C[m0 + 16 t + 4 (l >> 4) + r][n0 + (l & 15)]
-    const int row = tid >> 3, cp = (tid & 7) * 2;
-    const int t = row >> 4, r = row & 3, lq = ((row & 15) >> 2) * 16 + cp;
-    float s0 = 0.f, s1 = 0.f;
-#pragma unroll
-    for (int w = 0; w < SK_WAVES; ++w) {
-        s0 += red[w][t][lq * 4 + r];
-        s1 += red[w][t][(lq + 1) * 4 + r];
-    }
-    const int m = m0 + row, n = n0 + cp;
-    if (m >= p.M || n >= p.N) return;
+    const int cp = (tid & 7) * 2, n = n0 + cp;
     const bool two = n + 1 < p.N;
-    s0 *= p.alpha; s1 *= p.alpha;
-    if (p.bias) {
-        const bf16_t* bias = (const bf16_t*)p.bias;
-        s0 += (float)bias[n];
-        if (two) s1 += (float)bias[n + 1];
-    }
     const int act = p.act & VALOR_ACT_MASK;
-    if (act != VALOR_ACT_NONE) { s0 = act_fwd(act, s0); s1 = act_fwd(act, s1); }
-    if (p.out_f32) {
-        float* C = (float*)p.C + (int64_t)m * p.ldc + n;
-        if (two && ((p.ldc & 1) == 0) && (((uintptr_t)p.C & 7) == 0)) *(f32x2_t*)C = (f32x2_t){s0, s1};
-        else { C[0] = s0; if (two) C[1] = s1; }
-    } else {
-        bf16_t* C = (bf16_t*)p.C + (int64_t)m * p.ldc + n;
-        if (two && ((p.ldc & 1) == 0) && (((uintptr_t)p.C & 3) == 0)) *(uint32_t*)C = pack2_bf16(s0, s1);
-        else { C[0] = (bf16_t)s0; if (two) C[1] = (bf16_t)s1; }
+#pragma unroll
+    for (int pass = 0; pass < MT / 4; ++pass) {
+        const int row = (tid >> 3) + 64 * pass;
+        const int t = row >> 4, r = row & 3, lq = ((row & 15) >> 2) * 16 + cp;
+        float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+        for (int w = 0; w < SK_WAVES; ++w) {
+            s0 += red[w][t][lq * 4 + r];
+            s1 += red[w][t][(lq + 1) * 4 + r];
+        }
+        const int m = m0 + row;
+        if (m >= p.M || n >= p.N) continue;
+        s0 *= p.alpha; s1 *= p.alpha;
+        if (p.bias) {
+            const bf16_t* bias = (const bf16_t*)p.bias;
+            s0 += (float)bias[n];
+            if (two) s1 += (float)bias[n + 1];
+        }
+        if (act != VALOR_ACT_NONE) { s0 = act_fwd(act, s0); s1 = act_fwd(act, s1); }
+        if (p.out_f32) {
+            float* C = (float*)p.C + (int64_t)m * p.ldc + n;
+            if (two && ((p.ldc & 1) == 0) && (((uintptr_t)p.C & 7) == 0)) *(f32x2_t*)C = (f32x2_t){s0, s1};
+            else { C[0] = s0; if (two) C[1] = s1; }
+        } else {
+            bf16_t* C = (bf16_t*)p.C + (int64_t)m * p.ldc + n;
+            if (two && ((p.ldc & 1) == 0) && (((uintptr_t)p.C & 3) == 0)) *(uint32_t*)C = pack2_bf16(s0, s1);
+            else { C[0] = (bf16_t)s0; if (two) C[1] = (bf16_t)s1; }
+        }
     }
 }
 
@@ -110,14 +117,21 @@ int gemm_skinny_chunks(int K) {
 
 // p: A / B / C / bias, lda / ldb / ldc, M / N / K, act, alpha, out_f32 (no split-K, no pre-activation copy, no act' operand, no C +=)
 int launch_gemm_skinny(hipStream_t st, const GemmArgs& p) {
-    dim3 grid((p.N + 15) / 16, (p.M + 63) / 64);
+    const bool tall = p.M > 192;
+    dim3 grid((p.N + 15) / 16, tall ? (p.M + 127) / 128 : (p.M + 63) / 64);
+#define SK_LAUNCH(NCH_)                                                                                     \
+    do {                                                                                                    \
+        if (tall) hipLaunchKernelGGL((gemm_skinny_kernel<NCH_, 8>), grid, dim3(512), 0, st, p);             \
+        else hipLaunchKernelGGL((gemm_skinny_kernel<NCH_, 4>), grid, dim3(512), 0, st, p);                  \
+    } while (0)
     switch (gemm_skinny_chunks(p.K)) {
-        case 2: hipLaunchKernelGGL((gemm_skinny_kernel<2>), grid, dim3(512), 0, st, p); break;
-        case 3: hipLaunchKernelGGL((gemm_skinny_kernel<3>), grid, dim3(512), 0, st, p); break;
-        case 4: hipLaunchKernelGGL((gemm_skinny_kernel<4>), grid, dim3(512), 0, st, p); break;
-        case 12: hipLaunchKernelGGL((gemm_skinny_kernel<12>), grid, dim3(512), 0, st, p); break;
-        case 16: hipLaunchKernelGGL((gemm_skinny_kernel<16>), grid, dim3(512), 0, st, p); break;
+        case 2: SK_LAUNCH(2); break;
+        case 3: SK_LAUNCH(3); break;
+        case 4: SK_LAUNCH(4); break;
+        case 12: SK_LAUNCH(12); break;
+        case 16: SK_LAUNCH(16); break;
         default: return VALOR_ERR_ARG;
     }
+#undef SK_LAUNCH
     return valor_launch_status();
 }
