@@ -111,7 +111,12 @@ class DecodeSession:
         self.layers = m.spec.layers
         R, L, J = self.R, self.L, self.J
         i64 = dict(dtype=torch.int64, device=dev)
-        self.cache = torch.zeros((self.layers, R, L, 2 * E), dtype=dt, device=dev)
+        # beam search moves every sequence's slots to the row that continues it, every step: two buffers, the step gathers the rows of the
+        # one into the other (ONE launch of the row-gather kernel over all layers; a torch index_select + copy back was 0.42 of a 3.8 ms step)
+        self.caches = [torch.zeros((self.layers, R, L, 2 * E), dtype=dt, device=dev) for _ in range(2 if beam > 1 else 1)]
+        self.cache = self.caches[0]                    # the buffer that holds the sequences' slots now
+        self.step_i = 0                                # steps of the current group so far (host side: which buffer is live)
+        self.layer_base = (torch.arange(self.layers, device=dev, dtype=torch.int64) * R)[:, None]
         self.kmask = torch.full((R, L), NEG, dtype=torch.float32, device=dev)
         self.amask = torch.empty((R, J, L), dtype=torch.float32, device=dev)
         self.t = torch.zeros(1, **i64)
@@ -124,7 +129,7 @@ class DecodeSession:
         if kv_layers is not None:
             self.kv = [torch.empty_like(kv) for kv in kv_layers]
             self.cross_range = torch.zeros((R, 2), dtype=torch.int32, device=dev)
-        self.graph = self.logits = self.pool = None
+        self.graphs, self.logits_of, self.pool = {}, {}, None
         self.eager_steps = 0
         self.use_graph = dev.type == "cuda" and os.environ.get("VALOR_DECODE_GRAPH", "1") != "0"
 
@@ -143,8 +148,10 @@ class DecodeSession:
         """reset the text slots; run the prompt rows (one set per clip, bert.py:879-885: they attend to themselves only) and keep their
         per-layer K|V in slots [0, P) of every beam's row"""
         m, b, P, E = self.m, self.b, self.P, self.m.spec.hidden
+        self.step_i, self.cache = 0, self.caches[0]
         self.t.zero_()
         self.tok.fill_(BOS)
+        self.parent.copy_(self.layer_base.new_tensor(range(self.R)))
         self.kmask.fill_(NEG)
         if self.kv is not None:
             self.cross_range.copy_(m._dev(torch.tensor([list(key_range)] * self.R, dtype=torch.int32)))
@@ -169,12 +176,18 @@ class DecodeSession:
         o, _ = K.attn_fwd(qkv[:, :, :E], c[:, :, :E], c[:, :, E:], self.m.spec.heads, mask=self.amask, scale=0.125)
         return o
 
-    def _body(self):
+    def _body(self, cur=0):
+        """cur: which of the two slot buffers holds the sequences' state when the step starts (beam search; greedy has one)"""
         m, P_, J = self.m, self.m.P, self.J
         e = "multimodal_encoder.embeddings."
+        self.cache = self.caches[cur]
         if self.beam > 1:                                           # every sequence continues the row `parent` of the previous step
-            self.cache.copy_(self.cache.index_select(1, self.parent))
+            src, dst = self.caches[cur], self.caches[1 - cur]
+            idx = (self.layer_base + self.parent[None, :]).reshape(-1)
+            words = src[0, 0].numel() * src.element_size() // 4      # a sequence's slots of one layer as 32-bit words (16-byte accesses)
+            lib.call("valor_gather_rows", _st(), lib.DT_F32, src.data_ptr(), idx.data_ptr(), dst.data_ptr(), idx.numel(), words, words)
             self.kmask.copy_(self.kmask.index_select(0, self.parent))
+            self.cache = dst
         self.ids[:, 0] = self.tok
         pos = self.t + self.jidx
         # BertEmbeddings (bert.py:190-218) at positions t, t + 1: the embedding kernel's arithmetic (fp32 sum, one rounding)
@@ -195,20 +208,21 @@ class DecodeSession:
         self.t += 1
         return logits
 
-    def _capture(self):
+    def _capture(self, cur):
         from . import graphs
         dev = self.m.device
         ctx = graphs._capture_ctx(dev)
         with torch.cuda.stream(ctx["stream"]):         # the capture stream's kernel scratch must not come out of the graph's pool
             K.workspace(dev)
             K.ReduceQueue.current(dev)
-        self.pool = torch.cuda.graph_pool_handle()
+        if self.pool is None:
+            self.pool = torch.cuda.graph_pool_handle()
         g = torch.cuda.CUDAGraph()
         mode = "thread_local" if (torch.distributed.is_available() and torch.distributed.is_initialized()) else "global"
         torch.cuda.current_stream(dev).synchronize()
         with torch.cuda.graph(g, pool=self.pool, stream=ctx["stream"], capture_error_mode=mode):
-            self.logits = self._body()
-        self.graph = g
+            self.logits_of[cur] = self._body(cur)
+        self.graphs[cur] = g
 
     def step(self, tok=None, parent=None):
         """tok int64 [R] (device; None: [CLS], the first step), parent int64 [R] (beam search) -> fp32 logits [R, vocab] of the step's
@@ -217,13 +231,16 @@ class DecodeSession:
             self.tok.copy_(tok)
         if parent is not None:
             self.parent.copy_(parent)
-        if self.graph is None:
+        cur = self.step_i % len(self.caches)
+        self.step_i += 1
+        if cur not in self.graphs:
             if not self.use_graph or self.eager_steps < 1:
                 self.eager_steps += 1
-                return self._body()
-            self._capture()
-        self.graph.replay()
-        return self.logits
+                return self._body(cur)
+            self._capture(cur)
+        self.graphs[cur].replay()
+        self.cache = self.caches[1 - cur] if self.beam > 1 else self.caches[0]
+        return self.logits_of[cur]
 
 
 MAX_SESSIONS = 4
