@@ -201,3 +201,36 @@ def test_resident_backward_pipelined_equals_per_head_kernel(dev, S, B, H, p_drop
         oref = _ref_attn(qd, kd, vd, H, None, None, 0, scale)
         (oref * dout[sl].double()).sum().backward()
         assert _rel(dq1[sl], qd.grad) < 2e-2 and _rel(dk1[sl], kd.grad) < 2e-2 and _rel(dv1[sl], vd.grad) < 2e-2
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("B,H,Sq,Skv", [(5, 12, 2, 41), (3, 12, 1, 64), (2, 8, 4, 65), (7, 12, 2, 128), (1, 1, 3, 1), (130, 12, 2, 33)])
+def test_decode_step_kernel(dev, dtype, B, H, Sq, Skv):
+    """attn_dec_fwd_kernel (one wave per (sequence, head): the cached decoding step, <= 4 query rows against <= 128 keys) against explicit
+    fp64 softmax attention and against the tiled kernel it replaces for these shapes (variant bit 2 off); q / k / v are strided views of
+    a fused projection and of a [R, L, 2E] slot buffer as valor_amd/decode.py passes them, the mask closes a ragged tail of slots."""
+    from valor_amd import kernels as K, lib
+    E = H * 64
+    g = torch.Generator().manual_seed(B * 100 + Sq * 10 + Skv)
+    qkv = (torch.randn((B, Sq, 3 * E), generator=g) * 0.7).to(dev, dtype)
+    slots = (torch.randn((B, Skv, 2 * E), generator=g) * 0.7).to(dev, dtype)
+    mask = torch.zeros((B, Sq, Skv))
+    for b in range(B):
+        for j in range(Sq):
+            mask[b, j, 1 + (b * 7 + j * 3) % Skv:] = -10000.0
+    mask = mask.to(dev)
+    q, k, v = qkv[:, :, :E], slots[:, :, :E], slots[:, :, E:]
+    so = lib.load()
+    assert so.valor_attn_set_variant(-1) & 4
+    o, lse = K.attn_fwd(q, k, v, H, mask=mask, scale=0.125)
+    old = so.valor_attn_set_variant(3)
+    try:
+        o_t, lse_t = K.attn_fwd(q, k, v, H, mask=mask, scale=0.125)
+    finally:
+        so.valor_attn_set_variant(old)
+    want = _ref_attn(q.double(), k.double(), v.double(), H, mask, None, 0, 0.125)
+    tol = 1e-5 if dtype == torch.float32 else 6e-3
+    assert torch.isfinite(o.float()).all()
+    assert _rel(o, want) < tol, _rel(o, want)
+    assert _rel(o, want) <= 1.5 * _rel(o_t, want) + 1e-6, (_rel(o, want), _rel(o_t, want))
+    assert (lse - lse_t).abs().max().item() < (1e-4 if dtype == torch.float32 else 2e-3)

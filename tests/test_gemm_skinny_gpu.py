@@ -89,3 +89,27 @@ def test_skinny_policy_and_fallbacks(dev):
     C = torch.ones((128, 768), dtype=torch.float32, device=dev)
     K.gemm(A, B, out=C, accumulate=True, out_dtype=torch.float32, policy=pol)
     assert _rel(C, ref + 1) < 2e-5
+
+
+@pytest.mark.parametrize("M,N,Kd", [(128, 3072, 768), (384, 2304, 768), (384, 778, 3072), (250, 30522, 768), (65, 40, 512), (193, 100, 4096), (37, 530, 1024)])
+def test_skinny_tiles_are_bit_identical(dev, monkeypatch, M, N, Kd):
+    """Every workgroup tile of the family (64 / 128 rows x 16 / 32 / 64 columns; VALOR_SKINNY_TILE pins one per call, the launcher picks by
+    grid size otherwise) gives every accumulator the same products in the same order and adds the eight partial tiles in wave order:
+    identical bits, ragged rows / columns and strided outputs included; the default choice is one of them."""
+    from valor_amd import kernels as K
+    pol = K.infer_policy()
+    A, B, bias = _mk((M, Kd), dev, 11), _mk((N, Kd), dev, 12, 0.05), _mk((N,), dev, 13)
+    ref = _act(A.double() @ B.double().t() + bias.double(), 1)
+    outs = {}
+    for tile in ("4,1", "8,1", "4,2", "8,2", "4,4", None):
+        if tile is None:
+            monkeypatch.delenv("VALOR_SKINNY_TILE", raising=False)
+        else:
+            monkeypatch.setenv("VALOR_SKINNY_TILE", tile)
+        wide = torch.full((M, N + 24), 7.0, dtype=torch.float32, device=dev)
+        K.gemm(A, B, bias=bias, act=1, out=wide[:, 8:8 + N], out_dtype=torch.float32, policy=pol)
+        assert bool((wide[:, :8] == 7).all()) and bool((wide[:, 8 + N:] == 7).all()), tile
+        outs[tile] = (wide[:, 8:8 + N].clone(), K.gemm(A, B, policy=pol))
+    assert _rel(outs["4,1"][0], ref) < 2e-5
+    for tile, (c32, c16) in outs.items():
+        assert torch.equal(c32, outs["4,1"][0]) and torch.equal(c16, outs["4,1"][1]), tile

@@ -541,14 +541,125 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnArgs p) {
 }
 
 // ------------------------------------------------------------------------------------------
+// decoding step against a self-attention K|V cache (valor_amd/decode.py; the reference re-runs every text row at every step,
+// model/pretrain.py:988-1188 with model/bert.py:314-340): a FEW query rows (Sq <= 4: the previous token and the [MASK] row of a
+// sequence) against <= 64 KPL cached keys. The tiled kernel above gives every (sequence, head) a 256-thread workgroup with a 64-key
+// DMA stage for 2 x 40 scores: 25.9 us per launch at 384 sequences (profiles/r06_generation_kernel_stats_beam3_mt8.md). Here ONE
+// WAVE per (sequence, head): lane = key for the scores (the key's 64 values straight from global memory, the query rows as fp32
+// broadcasts out of LDS), wave-wide max / sum, then lane = output column for P.V (one coalesced row of V per key). Same arithmetic
+// contract as attn_fwd_kernel: fp32 scores, scale then mask, fexp<T>, the row sum over unrounded probabilities, bf16 probabilities
+// into the P.V product for bf16 operands, lse = max + log(sum). No dropout, no kv_range.
+template <typename T> DEVINL void dec_load8(const T* p, float* f);
+template <> DEVINL void dec_load8<float>(const float* p, float* f) {
+    const f32x4_t a = *(const f32x4_t*)p, b = *(const f32x4_t*)(p + 4);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { f[i] = a[i]; f[4 + i] = b[i]; }
+}
+template <> DEVINL void dec_load8<bf16_t>(const bf16_t* p, float* f) {
+    const u32x4_t a = *(const u32x4_t*)p;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { f[2 * i] = bf16_bits_to_f32(a[i] & 0xffffu); f[2 * i + 1] = bf16_bits_to_f32(a[i] >> 16); }
+}
+
+template <typename T, int KPL>
+__global__ __launch_bounds__(256) void attn_dec_fwd_kernel(AttnArgs p) {
+    __shared__ __attribute__((aligned(16))) float qs[4][4][ATT_D];
+    __shared__ float ps[4][4][64 * KPL];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int item = blockIdx.x * 4 + wave;
+    const bool live = item < p.B * p.H;
+    const int b = live ? item / p.H : 0, h = live ? item % p.H : 0;
+    const T* Q = (const T*)p.q + (int64_t)b * p.q_bs + h * ATT_D;
+    const T* Kb = (const T*)p.k + (int64_t)b * p.k_bs + h * ATT_D;
+    const T* Vb = (const T*)p.v + (int64_t)b * p.v_bs + h * ATT_D;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) qs[wave][j][lane] = j < p.Sq ? to_f32<T>(Q[(int64_t)j * p.q_rs + lane]) : 0.f;
+    __syncthreads();
+
+    float s[KPL][4];
+#pragma unroll
+    for (int kk = 0; kk < KPL; ++kk) {
+        const int key = lane + 64 * kk;
+        const T* kr = Kb + (int64_t)(key < p.Skv ? key : p.Skv - 1) * p.k_rs;
+        float kf[ATT_D];
+#pragma unroll
+        for (int c = 0; c < ATT_D; c += 8) dec_load8<T>(kr + c, kf + c);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float a = 0.f;
+#pragma unroll
+            for (int c = 0; c < ATT_D; c += 4) {
+                const f32x4_t qv = *(const f32x4_t*)&qs[wave][j][c];
+                a = fmaf(kf[c], qv[0], a); a = fmaf(kf[c + 1], qv[1], a); a = fmaf(kf[c + 2], qv[2], a); a = fmaf(kf[c + 3], qv[3], a);
+            }
+            s[kk][j] = a;
+        }
+    }
+    float linv[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        linv[j] = 0.f;
+        if (j >= p.Sq) continue;                                    // wave-uniform
+        const float* mrowp = p.mask ? p.mask + (int64_t)b * p.mask_bs + (int64_t)j * p.mask_rs : nullptr;
+        float mx = -INFINITY;
+#pragma unroll
+        for (int kk = 0; kk < KPL; ++kk) {
+            const int key = lane + 64 * kk;
+            float v = s[kk][j] * p.scale;
+            if (key < p.Skv) { if (mrowp) v += mrowp[key]; }
+            else v = -INFINITY;
+            s[kk][j] = v;
+            mx = fmaxf(mx, v);
+        }
+        mx = wave_max(mx);
+        float sum = 0.f;
+#pragma unroll
+        for (int kk = 0; kk < KPL; ++kk) {
+            const float pr = fexp<T>(s[kk][j] - mx);
+            sum += pr;
+            ps[wave][j][lane + 64 * kk] = to_f32<T>(from_f32<T>(pr));
+        }
+        sum = wave_sum(sum);
+        linv[j] = sum > 0.f ? 1.0f / sum : 0.f;
+        if (live && lane == 0 && p.lse) p.lse[((int64_t)b * p.H + h) * p.Sq + j] = mx + logf(sum);
+    }
+    __syncthreads();
+
+    float o[4] = {0.f, 0.f, 0.f, 0.f};
+    const T* vcol = Vb + lane;
+#pragma unroll 8
+    for (int key = 0; key < p.Skv; ++key) {
+        const float vv = to_f32<T>(vcol[(int64_t)key * p.v_rs]);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) o[j] = fmaf(ps[wave][j][key], vv, o[j]);
+    }
+    if (!live) return;
+    T* O = (T*)p.o + (int64_t)b * p.o_bs + h * ATT_D + lane;
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+        if (j < p.Sq) O[(int64_t)j * p.o_rs] = from_f32<T>(o[j] * linv[j]);
+}
+
+template <typename T>
+static bool attn_dec_fwd_launch(hipStream_t st, const AttnArgs& p) {
+    if (p.Sq > 4 || p.Skv > 128 || p.p_drop != 0.f || p.kv_range || p.kv_bmod != 0) return false;
+    const int items = p.B * p.H;
+    if (p.Skv <= 64) hipLaunchKernelGGL((attn_dec_fwd_kernel<T, 1>), dim3((items + 3) / 4), dim3(256), 0, st, p);
+    else hipLaunchKernelGGL((attn_dec_fwd_kernel<T, 2>), dim3((items + 3) / 4), dim3(256), 0, st, p);
+    return true;
+}
+
+// ------------------------------------------------------------------------------------------
+// bit 2: one wave per (sequence, head) for <= 4 query rows against <= 128 keys (attn_dec_fwd_kernel: the cached decoding step);
 // bit 0: LDS-resident short-sequence kernels (attention_res.hip), bit 1: key-stationary cross-attention kernels
 // (attention_x.hip) allowed for bf16
-static int g_attn_variant = 3;
+static int g_attn_variant = 7;
 extern "C" int valor_attn_set_variant(int v) { const int o = g_attn_variant; if (v >= 0) g_attn_variant = v; return o; }
 
 template <typename T>
 static int attn_fwd_launch(hipStream_t st, const AttnArgs& p) {
     constexpr int NIMG = 64 * (int)sizeof(T) / TILE_ROW_BYTES;
+    if ((g_attn_variant & 4) && attn_dec_fwd_launch<T>(st, p)) return valor_launch_status();
     if (ElemTraits<T>::DT == VALOR_DT_BF16 && (g_attn_variant & 1) && attn_res_fwd_launch(st, p)) return valor_launch_status();
     if (ElemTraits<T>::DT == VALOR_DT_BF16 && (g_attn_variant & 2) && attn_x_fwd_launch(st, p)) return valor_launch_status();
     const size_t lds = 2 * 2 * NIMG * IMG_BYTES;

@@ -26,84 +26,106 @@
 #define SK_DEPTH 4
 
 // MT = 16-row blocks of A per workgroup: 4 (64 rows: up to 192 rows of A -- more workgroups) or 8 (128 rows: beam search runs 384 rows,
-// every workgroup of a column slice re-reads that slice of the weights from L2)
-template <int NCH, int MT>
+// every workgroup of a column slice re-reads that slice of the weights from L2).
+// NS = 16-column slices of the weights per workgroup (1, 2, 4). With 128 .. 384 rows of A the launch is not a pass over the weights any
+// more: every 16-column workgroup re-reads its 64 / 128 rows of A out of L2 (98 / 196 KB against 24 KB of weights at K = 768), and the
+// measured times follow the bytes the CUs pull out of L2, 6-9 TB/s chip-wide (profiles/r06_decode_kernels_base_*.json: 384 x 3072 x 768
+// 21.3 us = 127 MB, the vocabulary projection 140 us = 1.26 GB). A workgroup that keeps its A fragments for NS slices divides that
+// traffic: the A registers of a chunk feed NS MFMAs each. Every accumulator still sees its own products in the same order and the
+// partial tiles meet in wave order: bit-identical to NS = 1.
+template <int NCH, int MT, int NS>
 __global__ __launch_bounds__(512) void gemm_skinny_kernel(GemmArgs p) {
     __shared__ float red[SK_WAVES][MT][256];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int fr = lane & 15, g = lane >> 4;
-    const int n0 = blockIdx.x * 16, m0 = blockIdx.y * (16 * MT);
+    const int n0 = blockIdx.x * (16 * NS), m0 = blockIdx.y * (16 * MT);
     const int kbase = wave * (NCH * 32) + g * 8;
     const bf16_t* A = (const bf16_t*)p.A;
     const bf16_t* B = (const bf16_t*)p.B;
     const bf16_t* arow[MT];
+    const bf16_t* brow[NS];
 #pragma unroll
     for (int t = 0; t < MT; ++t) {
         const int m = m0 + t * 16 + fr;
         arow[t] = A + (int64_t)(m < p.M ? m : p.M - 1) * p.lda + kbase;
     }
-    const int nb = n0 + fr;
-    const bf16_t* brow = B + (int64_t)(nb < p.N ? nb : p.N - 1) * p.ldb + kbase;
-
-    constexpr int DEPTH = MT > 4 ? 3 : SK_DEPTH;
-    constexpr int D = NCH < DEPTH ? NCH : DEPTH;
-    u32x4_t ra[D][MT], rb[D];
-    f32x4_t acc[MT];
 #pragma unroll
-    for (int t = 0; t < MT; ++t) acc[t] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+    for (int u = 0; u < NS; ++u) {
+        const int nb = n0 + u * 16 + fr;
+        brow[u] = B + (int64_t)(nb < p.N ? nb : p.N - 1) * p.ldb + kbase;
+    }
+
+    constexpr int DEPTH = MT * NS >= 16 ? 2 : (MT > 4 || NS > 1 ? 3 : SK_DEPTH);
+    constexpr int D = NCH < DEPTH ? NCH : DEPTH;
+    u32x4_t ra[D][MT], rb[D][NS];
+    f32x4_t acc[NS][MT];
+#pragma unroll
+    for (int u = 0; u < NS; ++u)
+#pragma unroll
+        for (int t = 0; t < MT; ++t) acc[u][t] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int c = 0; c < D; ++c) {
-        rb[c] = *(const u32x4_t*)(brow + c * 32);
+#pragma unroll
+        for (int u = 0; u < NS; ++u) rb[c][u] = *(const u32x4_t*)(brow[u] + c * 32);
 #pragma unroll
         for (int t = 0; t < MT; ++t) ra[c][t] = *(const u32x4_t*)(arow[t] + c * 32);
     }
 #pragma unroll
     for (int c = 0; c < NCH; ++c) {
         const int s = c % D;
-        const bf16x8_t fb = __builtin_bit_cast(bf16x8_t, rb[s]);
 #pragma unroll
-        for (int t = 0; t < MT; ++t)
-            acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, ra[s][t]), fb, acc[t], 0, 0, 0);
+        for (int u = 0; u < NS; ++u) {
+            const bf16x8_t fb = __builtin_bit_cast(bf16x8_t, rb[s][u]);
+#pragma unroll
+            for (int t = 0; t < MT; ++t)
+                acc[u][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, ra[s][t]), fb, acc[u][t], 0, 0, 0);
+        }
         if (c + D < NCH) {
-            rb[s] = *(const u32x4_t*)(brow + (c + D) * 32);
+#pragma unroll
+            for (int u = 0; u < NS; ++u) rb[s][u] = *(const u32x4_t*)(brow[u] + (c + D) * 32);
 #pragma unroll
             for (int t = 0; t < MT; ++t) ra[s][t] = *(const u32x4_t*)(arow[t] + (c + D) * 32);
         }
     }
-#pragma unroll
-    for (int t = 0; t < MT; ++t) *(f32x4_t*)&red[wave][t][lane * 4] = acc[t];
-    __syncthreads();
-    // acc[t][r] of lane l is C[m0 + 16 t + 4 (l >> 4) + r][n0 + (l & 15)]
-    const int cp = (tid & 7) * 2, n = n0 + cp;
-    const bool two = n + 1 < p.N;
+    // acc[u][t][r] of lane l is C[m0 + 16 t + 4 (l >> 4) + r][n0 + 16 u + (l & 15)]
+    const int cp = (tid & 7) * 2;
     const int act = p.act & VALOR_ACT_MASK;
 #pragma unroll
-    for (int pass = 0; pass < MT / 4; ++pass) {
-        const int row = (tid >> 3) + 64 * pass;
-        const int t = row >> 4, r = row & 3, lq = ((row & 15) >> 2) * 16 + cp;
-        float s0 = 0.f, s1 = 0.f;
+    for (int u = 0; u < NS; ++u) {
+        if (u) __syncthreads();
 #pragma unroll
-        for (int w = 0; w < SK_WAVES; ++w) {
-            s0 += red[w][t][lq * 4 + r];
-            s1 += red[w][t][(lq + 1) * 4 + r];
-        }
-        const int m = m0 + row;
-        if (m >= p.M || n >= p.N) continue;
-        s0 *= p.alpha; s1 *= p.alpha;
-        if (p.bias) {
-            const bf16_t* bias = (const bf16_t*)p.bias;
-            s0 += (float)bias[n];
-            if (two) s1 += (float)bias[n + 1];
-        }
-        if (act != VALOR_ACT_NONE) { s0 = act_fwd(act, s0); s1 = act_fwd(act, s1); }
-        if (p.out_f32) {
-            float* C = (float*)p.C + (int64_t)m * p.ldc + n;
-            if (two && ((p.ldc & 1) == 0) && (((uintptr_t)p.C & 7) == 0)) *(f32x2_t*)C = (f32x2_t){s0, s1};
-            else { C[0] = s0; if (two) C[1] = s1; }
-        } else {
-            bf16_t* C = (bf16_t*)p.C + (int64_t)m * p.ldc + n;
-            if (two && ((p.ldc & 1) == 0) && (((uintptr_t)p.C & 3) == 0)) *(uint32_t*)C = pack2_bf16(s0, s1);
-            else { C[0] = (bf16_t)s0; if (two) C[1] = (bf16_t)s1; }
+        for (int t = 0; t < MT; ++t) *(f32x4_t*)&red[wave][t][lane * 4] = acc[u][t];
+        __syncthreads();
+        const int n = n0 + u * 16 + cp;
+        const bool two = n + 1 < p.N;
+#pragma unroll
+        for (int pass = 0; pass < MT / 4; ++pass) {
+            const int row = (tid >> 3) + 64 * pass;
+            const int t = row >> 4, r = row & 3, lq = ((row & 15) >> 2) * 16 + cp;
+            float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+            for (int w = 0; w < SK_WAVES; ++w) {
+                s0 += red[w][t][lq * 4 + r];
+                s1 += red[w][t][(lq + 1) * 4 + r];
+            }
+            const int m = m0 + row;
+            if (m >= p.M || n >= p.N) continue;
+            s0 *= p.alpha; s1 *= p.alpha;
+            if (p.bias) {
+                const bf16_t* bias = (const bf16_t*)p.bias;
+                s0 += (float)bias[n];
+                if (two) s1 += (float)bias[n + 1];
+            }
+            if (act != VALOR_ACT_NONE) { s0 = act_fwd(act, s0); s1 = act_fwd(act, s1); }
+            if (p.out_f32) {
+                float* C = (float*)p.C + (int64_t)m * p.ldc + n;
+                if (two && ((p.ldc & 1) == 0) && (((uintptr_t)p.C & 7) == 0)) *(f32x2_t*)C = (f32x2_t){s0, s1};
+                else { C[0] = s0; if (two) C[1] = s1; }
+            } else {
+                bf16_t* C = (bf16_t*)p.C + (int64_t)m * p.ldc + n;
+                if (two && ((p.ldc & 1) == 0) && (((uintptr_t)p.C & 3) == 0)) *(uint32_t*)C = pack2_bf16(s0, s1);
+                else { C[0] = (bf16_t)s0; if (two) C[1] = (bf16_t)s1; }
+            }
         }
     }
 }
@@ -116,13 +138,36 @@ int gemm_skinny_chunks(int K) {
 }
 
 // p: A / B / C / bias, lda / ldb / ldc, M / N / K, act, alpha, out_f32 (no split-K, no pre-activation copy, no act' operand, no C +=)
+// Tile choice (rows x columns per workgroup): 64 x 64, else 64 x 32, where the grid stays at >= SK_MIN_WGS workgroups; otherwise the first
+// form of this family, 64 x 16 up to 192 rows and 128 x 16 above -- the sweep profiles/r06_decode_kernels_tile_{4x1,8x1,4x2,8x2,4x4,auto}.json (us per launch inside
+// a graph; 4,1 / 8,1 / 4,2 / 8,2 / 4,4): 384 x 3072 x 768 19.6 / 21.3 / 15.4 / 17.6 / 15.5, 384 x 768 x 3072 28.6 / 26.1 / 18.7 / 29.6 / 24.8,
+// 128 x 2304 x 768 9.3 / 9.0 / 7.1 / 10.6 / 9.4, 128 x 768 x 768 5.9 / 8.8 / 6.9 / 10.5 / 9.3, the vocabulary projection at 384 rows
+// 152 / 139 / 97 / 89 / 79. VALOR_SKINNY_TILE="mt,ns" pins one tile (A/B sweeps, tests).
+#define SK_MIN_WGS 128
 int launch_gemm_skinny(hipStream_t st, const GemmArgs& p) {
-    const bool tall = p.M > 192;
-    dim3 grid((p.N + 15) / 16, tall ? (p.M + 127) / 128 : (p.M + 63) / 64);
+    const int forced = [] {                               // read per call (a getenv: tests switch it inside one process)
+        const char* e = getenv("VALOR_SKINNY_TILE");
+        int mt = 0, ns = 0;
+        if (e && sscanf(e, "%d,%d", &mt, &ns) == 2 && (mt == 4 || mt == 8) && (ns == 1 || ns == 2 || (ns == 4 && mt == 4))) return mt * 16 + ns;
+        return 0;
+    }();
+    int mt = p.M > 192 ? 8 : 4, ns = 1;
+    if (forced) { mt = forced / 16; ns = forced % 16; }
+    else {
+        const int nsl = (p.N + 15) / 16, mb64 = (p.M + 63) / 64;
+        // the widest column tile that still gives the chip >= SK_MIN_WGS workgroups, on 64-row blocks (sweep: 64 x 64 is the fastest tile
+        // wherever it has that many, 64 x 32 next; 128 x 32 never wins)
+        if ((int64_t)((nsl + 3) / 4) * mb64 >= SK_MIN_WGS) { mt = 4; ns = 4; }
+        else if ((int64_t)((nsl + 1) / 2) * mb64 >= SK_MIN_WGS) { mt = 4; ns = 2; }
+    }
+    dim3 grid((p.N + 16 * ns - 1) / (16 * ns), (p.M + 16 * mt - 1) / (16 * mt));
 #define SK_LAUNCH(NCH_)                                                                                     \
     do {                                                                                                    \
-        if (tall) hipLaunchKernelGGL((gemm_skinny_kernel<NCH_, 8>), grid, dim3(512), 0, st, p);             \
-        else hipLaunchKernelGGL((gemm_skinny_kernel<NCH_, 4>), grid, dim3(512), 0, st, p);                  \
+        if (mt == 8 && ns == 1) hipLaunchKernelGGL((gemm_skinny_kernel<NCH_, 8, 1>), grid, dim3(512), 0, st, p);      \
+        else if (mt == 8) hipLaunchKernelGGL((gemm_skinny_kernel<NCH_, 8, 2>), grid, dim3(512), 0, st, p);            \
+        else if (ns == 1) hipLaunchKernelGGL((gemm_skinny_kernel<NCH_, 4, 1>), grid, dim3(512), 0, st, p);            \
+        else if (ns == 2) hipLaunchKernelGGL((gemm_skinny_kernel<NCH_, 4, 2>), grid, dim3(512), 0, st, p);            \
+        else hipLaunchKernelGGL((gemm_skinny_kernel<NCH_, 4, 4>), grid, dim3(512), 0, st, p);                         \
     } while (0)
     switch (gemm_skinny_chunks(p.K)) {
         case 2: SK_LAUNCH(2); break;
