@@ -232,7 +232,7 @@ int valor_colsum(void* stream, int dtype, const void* x, int64_t rows, int cols,
 
 /* attention kernel selection (tuning / A-B hook): bit 0 = LDS-resident short-sequence self-attention kernels for
  * bf16 (S = Sq = Skv <= 256, no kv_range); bit 1 = key-stationary cross-attention kernels (few query rows, many keys,
- * grouped kv_range); bit 2 = one wave per (sequence, head) for <= 4 query rows against <= 128 keys without dropout / kv_range, fp32
+ * grouped kv_range); bit 2 = one wave per (sequence, head) for <= 4 query rows against <= 256 keys without dropout / kv_range, fp32
  * and bf16 (the decoding step against a K|V cache); 0 = streaming kernels only. Default 7. Returns the previous value; v < 0 queries. */
 int valor_attn_set_variant(int v);
 /* LDS-resident self-attention backward: 1 (default, env VALOR_ATTN_PIPE) = persistent workgroups (one per CU) that walk (batch, head)

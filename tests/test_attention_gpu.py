@@ -204,9 +204,9 @@ def test_resident_backward_pipelined_equals_per_head_kernel(dev, S, B, H, p_drop
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
-@pytest.mark.parametrize("B,H,Sq,Skv", [(5, 12, 2, 41), (3, 12, 1, 64), (2, 8, 4, 65), (7, 12, 2, 128), (1, 1, 3, 1), (130, 12, 2, 33)])
+@pytest.mark.parametrize("B,H,Sq,Skv", [(5, 12, 2, 41), (3, 12, 1, 64), (2, 8, 4, 65), (7, 12, 2, 128), (1, 1, 3, 1), (130, 12, 2, 33), (3, 12, 2, 256), (2, 12, 4, 200)])
 def test_decode_step_kernel(dev, dtype, B, H, Sq, Skv):
-    """attn_dec_fwd_kernel (one wave per (sequence, head): the cached decoding step, <= 4 query rows against <= 128 keys) against explicit
+    """attn_dec_fwd_kernel (one wave per (sequence, head): the cached decoding step, <= 4 query rows against <= 256 keys) against explicit
     fp64 softmax attention and against the tiled kernel it replaces for these shapes (variant bit 2 off); q / k / v are strided views of
     a fused projection and of a [R, L, 2E] slot buffer as valor_amd/decode.py passes them, the mask closes a ragged tail of slots."""
     from valor_amd import kernels as K, lib

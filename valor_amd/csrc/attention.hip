@@ -543,7 +543,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnArgs p) {
 // ------------------------------------------------------------------------------------------
 // decoding step against a self-attention K|V cache (valor_amd/decode.py; the reference re-runs every text row at every step,
 // model/pretrain.py:988-1188 with model/bert.py:314-340): a FEW query rows (Sq <= 4: the previous token and the [MASK] row of a
-// sequence) against <= 64 KPL cached keys. The tiled kernel above gives every (sequence, head) a 256-thread workgroup with a 64-key
+// sequence) against <= 256 cached keys. The tiled kernel above gives every (sequence, head) a 256-thread workgroup with a 64-key
 // DMA stage for 2 x 40 scores: 25.9 us per launch at 384 sequences (profiles/r06_generation_kernel_stats_beam3_mt8.md). Here ONE
 // WAVE per (sequence, head): lane = key for the scores (the key's 64 values straight from global memory, the query rows as fp32
 // broadcasts out of LDS), wave-wide max / sum, then lane = output column for P.V (one coalesced row of V per key). Same arithmetic
@@ -561,10 +561,11 @@ template <> DEVINL void dec_load8<bf16_t>(const bf16_t* p, float* f) {
     for (int i = 0; i < 4; ++i) { f[2 * i] = bf16_bits_to_f32(a[i] & 0xffffu); f[2 * i + 1] = bf16_bits_to_f32(a[i] >> 16); }
 }
 
-template <typename T, int KPL>
+#define DEC_MAX_KEYS 256
+template <typename T>
 __global__ __launch_bounds__(256) void attn_dec_fwd_kernel(AttnArgs p) {
     __shared__ __attribute__((aligned(16))) float qs[4][4][ATT_D];
-    __shared__ float ps[4][4][64 * KPL];
+    __shared__ float ps[4][4][DEC_MAX_KEYS];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int item = blockIdx.x * 4 + wave;
     const bool live = item < p.B * p.H;
@@ -576,23 +577,28 @@ __global__ __launch_bounds__(256) void attn_dec_fwd_kernel(AttnArgs p) {
     for (int j = 0; j < 4; ++j) qs[wave][j][lane] = j < p.Sq ? to_f32<T>(Q[(int64_t)j * p.q_rs + lane]) : 0.f;
     __syncthreads();
 
-    float s[KPL][4];
-#pragma unroll
-    for (int kk = 0; kk < KPL; ++kk) {
+    // scores of key lane + 64 kk, raw, into ps (the lane's own entries: no barrier until the P.V phase). The key loop is a real loop with
+    // an opaque zero in the query address: unrolled (or with the 256 query values hoisted out of it) two keys' values + the queries end
+    // at 256 VGPRs and scratch.
+    const int nk = (p.Skv + 63) >> 6;
+#pragma unroll 1
+    for (int kk = 0; kk < nk; ++kk) {
         const int key = lane + 64 * kk;
         const T* kr = Kb + (int64_t)(key < p.Skv ? key : p.Skv - 1) * p.k_rs;
         float kf[ATT_D];
 #pragma unroll
         for (int c = 0; c < ATT_D; c += 8) dec_load8<T>(kr + c, kf + c);
+        int z = 0;
+        asm volatile("" : "+v"(z));
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             float a = 0.f;
 #pragma unroll
             for (int c = 0; c < ATT_D; c += 4) {
-                const f32x4_t qv = *(const f32x4_t*)&qs[wave][j][c];
+                const f32x4_t qv = *(const f32x4_t*)&qs[wave][j][c + z];
                 a = fmaf(kf[c], qv[0], a); a = fmaf(kf[c + 1], qv[1], a); a = fmaf(kf[c + 2], qv[2], a); a = fmaf(kf[c + 3], qv[3], a);
             }
-            s[kk][j] = a;
+            ps[wave][j][key] = a;
         }
     }
     float linv[4];
@@ -602,22 +608,23 @@ __global__ __launch_bounds__(256) void attn_dec_fwd_kernel(AttnArgs p) {
         if (j >= p.Sq) continue;                                    // wave-uniform
         const float* mrowp = p.mask ? p.mask + (int64_t)b * p.mask_bs + (int64_t)j * p.mask_rs : nullptr;
         float mx = -INFINITY;
-#pragma unroll
-        for (int kk = 0; kk < KPL; ++kk) {
+#pragma unroll 1
+        for (int kk = 0; kk < nk; ++kk) {
             const int key = lane + 64 * kk;
-            float v = s[kk][j] * p.scale;
+            float v = ps[wave][j][key] * p.scale;
             if (key < p.Skv) { if (mrowp) v += mrowp[key]; }
             else v = -INFINITY;
-            s[kk][j] = v;
+            ps[wave][j][key] = v;
             mx = fmaxf(mx, v);
         }
         mx = wave_max(mx);
         float sum = 0.f;
-#pragma unroll
-        for (int kk = 0; kk < KPL; ++kk) {
-            const float pr = fexp<T>(s[kk][j] - mx);
+#pragma unroll 1
+        for (int kk = 0; kk < nk; ++kk) {
+            const int key = lane + 64 * kk;
+            const float pr = fexp<T>(ps[wave][j][key] - mx);
             sum += pr;
-            ps[wave][j][lane + 64 * kk] = to_f32<T>(from_f32<T>(pr));
+            ps[wave][j][key] = to_f32<T>(from_f32<T>(pr));
         }
         sum = wave_sum(sum);
         linv[j] = sum > 0.f ? 1.0f / sum : 0.f;
@@ -642,15 +649,13 @@ __global__ __launch_bounds__(256) void attn_dec_fwd_kernel(AttnArgs p) {
 
 template <typename T>
 static bool attn_dec_fwd_launch(hipStream_t st, const AttnArgs& p) {
-    if (p.Sq > 4 || p.Skv > 128 || p.p_drop != 0.f || p.kv_range || p.kv_bmod != 0) return false;
-    const int items = p.B * p.H;
-    if (p.Skv <= 64) hipLaunchKernelGGL((attn_dec_fwd_kernel<T, 1>), dim3((items + 3) / 4), dim3(256), 0, st, p);
-    else hipLaunchKernelGGL((attn_dec_fwd_kernel<T, 2>), dim3((items + 3) / 4), dim3(256), 0, st, p);
+    if (p.Sq > 4 || p.Skv > DEC_MAX_KEYS || p.p_drop != 0.f || p.kv_range || p.kv_bmod != 0) return false;
+    hipLaunchKernelGGL((attn_dec_fwd_kernel<T>), dim3((p.B * p.H + 3) / 4), dim3(256), 0, st, p);
     return true;
 }
 
 // ------------------------------------------------------------------------------------------
-// bit 2: one wave per (sequence, head) for <= 4 query rows against <= 128 keys (attn_dec_fwd_kernel: the cached decoding step);
+// bit 2: one wave per (sequence, head) for <= 4 query rows against <= 256 keys (attn_dec_fwd_kernel: the cached decoding step);
 // bit 0: LDS-resident short-sequence kernels (attention_res.hip), bit 1: key-stationary cross-attention kernels
 // (attention_x.hip) allowed for bf16
 static int g_attn_variant = 7;

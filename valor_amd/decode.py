@@ -130,6 +130,7 @@ class DecodeSession:
             self.kv = [torch.empty_like(kv) for kv in kv_layers]
             self.cross_range = torch.zeros((R, 2), dtype=torch.int32, device=dev)
         self.graphs, self.logits_of, self.pool = {}, {}, None
+        self.logits_pad = None
         self.eager_steps = 0
         self.use_graph = dev.type == "cuda" and os.environ.get("VALOR_DECODE_GRAPH", "1") != "0"
 
@@ -204,7 +205,11 @@ class DecodeSession:
         hidden = m.bert_encoder(x, None, self.kv, self.cross_range if self.kv is not None else None, self.b if self.kv is not None else 0,
                                 self_attn=self._self_attn)
         h = m.cls_transform(hidden[:, J - 1].contiguous())
-        logits = K.gemm(h, P_[e + "word_embeddings.weight"], bias=P_["cls.decoder.bias"], out_dtype=torch.float32, policy=K.infer_policy())
+        if self.logits_pad is None:                                   # rows of a zero-padded static buffer (first, eager, step of the session):
+            V = P_[e + "word_embeddings.weight"].shape[0]             # log_softmax_rows reads them in place
+            self.logits_pad = torch.zeros((h.shape[0], (V + 31) // 32 * 32), dtype=torch.float32, device=h.device)[:, :V]
+        logits = self.logits_pad
+        K.gemm(h, P_[e + "word_embeddings.weight"], bias=P_["cls.decoder.bias"], out=logits, out_dtype=torch.float32, policy=K.infer_policy())
         self.t += 1
         return logits
 
@@ -268,8 +273,11 @@ def log_softmax_rows(logits):
     """F.log_softmax(logits, dim=1) of fp32 rows (pretrain.py:1078): the row log-sum-exp comes from the cross-entropy kernel."""
     n, V = logits.shape
     Vpad = (V + 31) // 32 * 32
-    buf = torch.zeros((n, Vpad), dtype=torch.float32, device=logits.device)
-    buf[:, :V] = logits
+    if logits.stride() == (Vpad, 1) and logits.data_ptr() % 16 == 0:       # the decoding session's rows already sit in a zero-padded buffer
+        buf = logits
+    else:
+        buf = torch.zeros((n, Vpad), dtype=torch.float32, device=logits.device)
+        buf[:, :V] = logits
     lse = torch.empty(n, dtype=torch.float32, device=logits.device)
     rows = torch.empty(n, dtype=torch.float32, device=logits.device)
     labels = torch.zeros(n, dtype=torch.int64, device=logits.device)
