@@ -171,3 +171,37 @@ def test_base_widths_bf16_cached_logits_within_the_band(dev, name):
     assert worst32 < 1e-4, worst32
     assert worst16 < BF16_LOGIT_BAND, worst16
     print(f"{name}: cached vs re-run logits fp32 {worst32:.2e}; bf16 cached vs fp32 / vs bf16 re-run {worst16:.4f} over {T} teacher-forced steps")
+
+
+@pytest.mark.parametrize("b,cur,beam,V,beam_major", [(64, 3, 3, 30522, True), (5, 1, 3, 30522, True), (7, 4, 4, 1000, False), (3, 8, 8, 2500, True), (2, 2, 1, 17, False)])
+def test_beam_select_kernel_matches_the_torch_arithmetic(dev, b, cur, beam, V, beam_major):
+    """valor_beam_select against the reference's arithmetic (pretrain.py:1080-1098: log-softmax subtract, add, the 0 / 1 mask products) and
+    torch.topk: identical VALUES (bits) and beams everywhere, identical words wherever the chosen beam is open; a beam that has ended
+    supplies V equal candidates (the reference's unstable sort leaves their order open): the kernel takes them in index order."""
+    from valor_amd import decode
+    g = torch.Generator().manual_seed(b * 100 + cur * 10 + beam)
+    logits = (torch.randn((b * cur, V), generator=g) * 3).to(dev)
+    seq_lp = (-torch.rand((b, cur, 1), generator=g) * 5).to(dev)
+    seq_mask = (torch.rand((b, cur, 1), generator=g) > 0.3).float().to(dev)
+    if cur > 1:
+        seq_lp[0, 1] = 1.0                               # an ended beam with the best score of its sample: fills the whole selection
+        seq_mask[0, 1] = 0.0
+    val, idx = decode.beam_select(logits, b, cur, beam, seq_lp, seq_mask, beam_major)
+    wl = decode.log_softmax_rows(logits)
+    wl = wl.view(cur, b, V).transpose(0, 1) if beam_major else wl.view(b, cur, V)
+    cand = seq_lp + wl
+    cand = seq_mask * cand + seq_lp.expand_as(cand) * (1 - seq_mask)
+    tv, ti = torch.topk(cand.reshape(b, -1), beam, dim=-1, largest=True, sorted=True)
+    assert torch.equal(val, tv)
+    kb, tb = idx // V, ti // V
+    assert torch.equal(kb, tb)
+    open_ = torch.gather(seq_mask.view(b, cur), 1, kb) != 0
+    assert torch.equal(idx[open_], ti[open_])
+    if cur > 1:
+        assert idx[0].tolist() == [V + i for i in range(beam)]
+    # rows of the session's zero-padded buffer are read in place
+    Vpad = (V + 31) // 32 * 32
+    padded = torch.zeros((b * cur, Vpad), device=dev)[:, :V]
+    padded.copy_(logits)
+    v2, i2 = decode.beam_select(padded, b, cur, beam, seq_lp, seq_mask, beam_major)
+    assert torch.equal(v2, val) and torch.equal(i2, idx)

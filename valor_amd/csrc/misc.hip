@@ -658,3 +658,84 @@ extern "C" int valor_rowdot_bwd(void* stream, int dtype, const void* dy, const v
           hipLaunchKernelGGL((rowdot_bwd_dw_kernel<float>), dim3((cols / 4 + 63) / 64), dim3(1024), 0, st, (const float*)dy, (const float*)x, (float*)dw, (float*)db, rows, cols); });
     return valor_launch_status();
 }
+
+// ------------------------------------------------------------------------------------------
+// Beam-search selection: VALOR.decode_beam / select, model/pretrain.py:1080-1098,1156-1159. For sample s the candidates are (beam k < cur,
+// word w < V) with  c = seq_logprob[s, k] + (logits[row(s, k), w] - lse[row(s, k)])  -- F.log_softmax and the add, in that order, in fp32 --
+// and, for a beam that has ended (seq_mask[s, k] == 0),  c = seq_logprob[s, k]  for every w (:1090-1092 with a 0 / 1 mask); the `beam`
+// largest, value descending, equal values in index order (the reference sorts the whole [cur * V] row with an unstable torch.sort: the
+// order among equal values is not defined there; a beam that has ended supplies V equal candidates). torch ran this as a subtract, an add,
+// three mask products and a four-kernel radix top-k over [b, cur * V]: 0.2 ms of a 3.0 ms decoding step. Here one 1024-thread workgroup
+// per sample reads its cur rows once: every thread keeps the best KMAX of its stride in registers (its candidates arrive in index order),
+// then `beam` rounds of a workgroup-wide arg-max over the threads' heads.
+DEVINL bool beam_better(float av, int ai, float bv, int bi) { return av > bv || (av == bv && ai < bi); }
+
+template <int KMAX>
+__global__ __launch_bounds__(1024) void beam_select_kernel(const float* __restrict__ logits, int64_t ld, int64_t rs_s, int64_t rs_k,
+                                                           const float* __restrict__ lse, const float* __restrict__ seq_logprob,
+                                                           const float* __restrict__ seq_mask, int cur, int V, int beam,
+                                                           float* __restrict__ sel_val, int64_t* __restrict__ sel_idx) {
+    __shared__ float wv[16];
+    __shared__ int wi[16];
+    const int s = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    float lv[KMAX];
+    int li[KMAX];
+#pragma unroll
+    for (int j = 0; j < KMAX; ++j) { lv[j] = -INFINITY; li[j] = 0x7fffffff; }
+    for (int k = 0; k < cur; ++k) {
+        const int64_t row = (int64_t)s * rs_s + (int64_t)k * rs_k;
+        const float* x = logits + row * ld;
+        const float l = lse[row], sl = seq_logprob[(int64_t)s * cur + k];
+        const bool open = !seq_mask || seq_mask[(int64_t)s * cur + k] != 0.f;
+        for (int w = tid; w < V; w += 1024) {
+            const float wl = x[w] - l;
+            const float c = open ? sl + wl : sl;
+            if (c > lv[KMAX - 1]) {
+                lv[KMAX - 1] = c; li[KMAX - 1] = k * V + w;
+#pragma unroll
+                for (int j = KMAX - 1; j > 0; --j)
+                    if (lv[j] > lv[j - 1]) {
+                        const float tv = lv[j]; lv[j] = lv[j - 1]; lv[j - 1] = tv;
+                        const int ti = li[j]; li[j] = li[j - 1]; li[j - 1] = ti;
+                    }
+            }
+        }
+    }
+    for (int r = 0; r < beam; ++r) {
+        float bv = lv[0];
+        int bi = li[0];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const float ov = __shfl_xor(bv, o, 64);
+            const int oi = __shfl_xor(bi, o, 64);
+            if (beam_better(ov, oi, bv, bi)) { bv = ov; bi = oi; }
+        }
+        if (lane == 0) { wv[wave] = bv; wi[wave] = bi; }
+        __syncthreads();
+        bv = wv[0]; bi = wi[0];
+#pragma unroll
+        for (int j = 1; j < 16; ++j)
+            if (beam_better(wv[j], wi[j], bv, bi)) { bv = wv[j]; bi = wi[j]; }
+        __syncthreads();
+        if (li[0] == bi) {                      // this thread's head won: pop it
+#pragma unroll
+            for (int j = 0; j + 1 < KMAX; ++j) { lv[j] = lv[j + 1]; li[j] = li[j + 1]; }
+            lv[KMAX - 1] = -INFINITY; li[KMAX - 1] = 0x7fffffff;
+        }
+        if (tid == 0) { sel_val[(int64_t)s * beam + r] = bv; sel_idx[(int64_t)s * beam + r] = bi; }
+    }
+}
+
+extern "C" int valor_beam_select(void* stream, const float* logits, int64_t ld, int64_t row_stride_s, int64_t row_stride_k, const float* lse,
+                                 const float* seq_logprob, const float* seq_mask, int b, int cur, int V, int beam, float* sel_val,
+                                 int64_t* sel_idx) {
+    if (b <= 0) return VALOR_OK;
+    if (!logits || !lse || !seq_logprob || !sel_val || !sel_idx) return VALOR_ERR_ARG;
+    if (cur <= 0 || V <= 0 || beam <= 0 || beam > 8 || (int64_t)cur * V >= 0x7fffffff || (int64_t)cur * V < beam) return VALOR_ERR_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    if (beam <= 4)
+        hipLaunchKernelGGL((beam_select_kernel<4>), dim3((unsigned)b), dim3(1024), 0, st, logits, ld, row_stride_s, row_stride_k, lse, seq_logprob, seq_mask, cur, V, beam, sel_val, sel_idx);
+    else
+        hipLaunchKernelGGL((beam_select_kernel<8>), dim3((unsigned)b), dim3(1024), 0, st, logits, ld, row_stride_s, row_stride_k, lse, seq_logprob, seq_mask, cur, V, beam, sel_val, sel_idx);
+    return valor_launch_status();
+}

@@ -269,8 +269,8 @@ def release_sessions(model):
     model.__dict__.pop("_decode_sessions", None)
 
 
-def log_softmax_rows(logits):
-    """F.log_softmax(logits, dim=1) of fp32 rows (pretrain.py:1078): the row log-sum-exp comes from the cross-entropy kernel."""
+def row_lse(logits):
+    """log-sum-exp of fp32 rows (the cross-entropy kernel's) and the zero-padded buffer the rows sit in"""
     n, V = logits.shape
     Vpad = (V + 31) // 32 * 32
     if logits.stride() == (Vpad, 1) and logits.data_ptr() % 16 == 0:       # the decoding session's rows already sit in a zero-padded buffer
@@ -282,7 +282,32 @@ def log_softmax_rows(logits):
     rows = torch.empty(n, dtype=torch.float32, device=logits.device)
     labels = torch.zeros(n, dtype=torch.int64, device=logits.device)
     lib.call("valor_xent_fwd", _st(), lib.DT_F32, buf.data_ptr(), labels.data_ptr(), rows.data_ptr(), lse.data_ptr(), n, V, Vpad)
-    return logits - lse[:, None]
+    return lse, buf
+
+
+def log_softmax_rows(logits):
+    """F.log_softmax(logits, dim=1) of fp32 rows (pretrain.py:1078): the row log-sum-exp comes from the cross-entropy kernel."""
+    return logits - row_lse(logits)[0][:, None]
+
+
+def beam_select_enabled():
+    return os.environ.get("VALOR_BEAM_SELECT", "1") != "0"
+
+
+def beam_select(logits, b, cur, beam, seq_logprob, seq_mask, beam_major):
+    """candidate scores + `select` (pretrain.py:1080-1098,1156-1159) in one launch (valor_beam_select): logits fp32 [b * cur, V], rows
+    beam-major (row = k * b + s) or sample-major; seq_logprob [b, cur | 1, 1], seq_mask [b, cur, 1] (1: open) -> (values, indices) [b, beam]"""
+    V = logits.shape[1]
+    lse, buf = row_lse(logits)
+    dev = logits.device
+    sl = seq_logprob.reshape(b, -1).expand(b, cur).contiguous()
+    sm = seq_mask.reshape(b, -1)[:, :cur].contiguous()
+    val = torch.empty((b, beam), dtype=torch.float32, device=dev)
+    idx = torch.empty((b, beam), dtype=torch.int64, device=dev)
+    rs_s, rs_k = (1, b) if beam_major else (cur, 1)
+    lib.call("valor_beam_select", _st(), buf.data_ptr(), buf.stride(0), rs_s, rs_k, lse.data_ptr(), sl.data_ptr(), sm.data_ptr(), b, cur, V, beam,
+             val.data_ptr(), idx.data_ptr())
+    return val, idx
 
 
 def decode_greedy(step, b, max_len):
@@ -364,28 +389,35 @@ def decode_beam_cached(sess, b, beam, max_len):
     seq_logprob = torch.zeros((b, 1, 1), device=dev)
     seq_mask = torch.ones((b, beam, 1), device=dev)
     base = torch.arange(b, device=dev)
-    outputs, selected_words, tok, parent = [], None, None, None
+    outputs = torch.zeros((b, beam, max_len), dtype=torch.int64, device=dev)
+    selected_words, tok, parent = None, None, None
+    fused = beam_select_enabled() and beam <= 8
     for t in range(max_len):
         cur = 1 if t == 0 else beam
         logits = sess.step(tok, parent)
-        word_logprob = log_softmax_rows(logits[:b * cur]).view(cur, b, -1).transpose(0, 1)
-        cand = seq_logprob + word_logprob
+        V = logits.shape[-1]
         if t > 0:
             mask = (selected_words.view(b, cur) != EOS).float().unsqueeze(-1)
             seq_mask = seq_mask * mask
-            cand = seq_mask * cand + seq_logprob.expand_as(cand) * (1 - seq_mask)
-        V = cand.shape[-1]
-        sel_logprob, sel_idx = torch.topk(cand.reshape(b, -1), beam, dim=-1, largest=True, sorted=True)   # select :1156-1159
+        if fused:
+            sel_logprob, sel_idx = beam_select(logits[:b * cur], b, cur, beam, seq_logprob, seq_mask, beam_major=True)
+        else:
+            word_logprob = log_softmax_rows(logits[:b * cur]).view(cur, b, -1).transpose(0, 1)
+            cand = seq_logprob + word_logprob
+            if t > 0:
+                cand = seq_mask * cand + seq_logprob.expand_as(cand) * (1 - seq_mask)
+            sel_logprob, sel_idx = torch.topk(cand.reshape(b, -1), beam, dim=-1, largest=True, sorted=True)   # select :1156-1159
         sel_beam = sel_idx // V
         selected_words = sel_idx - sel_beam * V
         seq_logprob = sel_logprob.unsqueeze(-1)
         seq_mask = torch.gather(seq_mask, 1, sel_beam.unsqueeze(-1))
-        outputs = [torch.gather(o, 1, sel_beam.unsqueeze(-1)) for o in outputs]
-        outputs.append(selected_words.unsqueeze(-1))
+        if t > 0:                                                    # the words so far follow their beams (:1101; one gather, not one per step)
+            outputs = torch.gather(outputs, 1, sel_beam.unsqueeze(-1).expand(b, beam, max_len))
+        outputs[:, :, t] = selected_words
         parent = (sel_beam.t() * b + base[None]).reshape(-1)        # row (k, s) continues row (sel_beam[s, k], s)
         tok = selected_words.t().reshape(-1)
     seq_logprob, sort_idx = torch.sort(seq_logprob, 1, descending=True)
-    outputs = torch.gather(torch.cat(outputs, -1), 1, sort_idx.expand(b, beam, max_len))
+    outputs = torch.gather(outputs, 1, sort_idx.expand(b, beam, max_len))
     return outputs.contiguous()[:, 0]
 
 
