@@ -235,6 +235,15 @@ int valor_colsum(void* stream, int dtype, const void* x, int64_t rows, int cols,
  * grouped kv_range); bit 2 = one wave per (sequence, head) for <= 4 query rows against <= 256 keys without dropout / kv_range, fp32
  * and bf16 (the decoding step against a K|V cache); 0 = streaming kernels only. Default 7. Returns the previous value; v < 0 queries. */
 int valor_attn_set_variant(int v);
+/* One decoding step of caption generation against per-sequence self-attention K|V slots (the reference re-runs every text row at every
+ * step: pretrain.py:988-1188 over bert.py:272-288): Sq <= 4 new rows per sequence, Skv <= 256 slots, additive fp32 mask, no dropout.
+ * key_row (int32 [B][key_row_bs], device; may be null): slot j of sequence b is read from batch row key_row[b][j] of k / v -- the
+ * sequences of a beam search read their ancestors' slots where they were written (`_adjust_tensor`, pretrain.py:1161-1180, moves
+ * tensors instead). Strides as valor_attn_fwd. */
+int valor_attn_decode_fwd(void* stream, int dtype, const void* q, const void* k, const void* v, void* o, float* lse,
+                          int B, int H, int Sq, int Skv, int64_t q_bs, int64_t q_rs, int64_t k_bs, int64_t k_rs,
+                          int64_t v_bs, int64_t v_rs, int64_t o_bs, int64_t o_rs, const float* mask, int64_t mask_bs,
+                          int64_t mask_rs, const int* key_row, int64_t key_row_bs, float scale);
 /* LDS-resident self-attention backward: 1 (default, env VALOR_ATTN_PIPE) = persistent workgroups (one per CU) that walk (batch, head)
  * items with the K / V and Q / dO LDS images double-buffered across the dQ and the dK / dV phase, so the loads and stores of one item
  * overlap the arithmetic of its neighbours (used when batch x heads >= 2 x the CU count; sequences of <= 160 rows run mode 2 instead);

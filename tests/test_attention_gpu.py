@@ -234,3 +234,28 @@ def test_decode_step_kernel(dev, dtype, B, H, Sq, Skv):
     assert _rel(o, want) < tol, _rel(o, want)
     assert _rel(o, want) <= 1.5 * _rel(o_t, want) + 1e-6, (_rel(o, want), _rel(o_t, want))
     assert (lse - lse_t).abs().max().item() < (1e-4 if dtype == torch.float32 else 2e-3)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("B,H,Sq,Skv", [(6, 12, 2, 41), (9, 8, 1, 130)])
+def test_decode_step_kernel_reads_slots_through_a_row_table(dev, dtype, B, H, Sq, Skv):
+    """valor_attn_decode_fwd with key_row (beam search: slot j of sequence b lives in batch row key_row[b, j]) equals the same kernel on
+    K / V gathered into place, bit for bit, and a null table equals the identity table."""
+    from valor_amd import kernels as K
+    E = H * 64
+    g = torch.Generator().manual_seed(B + Skv)
+    qkv = (torch.randn((B, Sq, 3 * E), generator=g) * 0.7).to(dev, dtype)
+    slots = (torch.randn((B, Skv, 2 * E), generator=g) * 0.7).to(dev, dtype)
+    mask = torch.zeros((B, Sq, Skv))
+    mask[:, :, Skv - 3:] = -10000.0
+    mask = mask.to(dev)
+    table = torch.randint(0, B, (B, Skv), generator=g).to(dev, torch.int32)
+    q, k, v = qkv[:, :, :E], slots[:, :, :E], slots[:, :, E:]
+    got = K.attn_decode(q, k, v, H, mask=mask, key_row=table)
+    moved = torch.gather(slots, 0, table.long()[:, :, None].expand(B, Skv, 2 * E)).contiguous()
+    want = K.attn_decode(q, moved[:, :, :E], moved[:, :, E:], H, mask=mask)
+    assert torch.equal(got, want)
+    ident = torch.arange(B, device=dev, dtype=torch.int32)[:, None].expand(B, Skv).contiguous()
+    assert torch.equal(K.attn_decode(q, k, v, H, mask=mask, key_row=ident), K.attn_decode(q, k, v, H, mask=mask))
+    o, _ = K.attn_fwd(q, moved[:, :, :E], moved[:, :, E:], H, mask=mask, scale=0.125)
+    assert torch.equal(o, want)                       # valor_attn_fwd takes the same kernel for these shapes

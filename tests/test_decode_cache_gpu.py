@@ -43,10 +43,12 @@ def _paths(model, batch, task, monkeypatch, **attrs):
     return outs
 
 
+@pytest.mark.parametrize("table", ["0", "1"])                     # beam search: slots gathered into a second buffer | a row table (decode.py)
 @pytest.mark.parametrize("prompt", [False, True])
 @pytest.mark.parametrize("caption_type", ["unimlm", "lm"])
-def test_cached_generation_equals_the_rerun_path_fp32(dev, monkeypatch, prompt, caption_type):
+def test_cached_generation_equals_the_rerun_path_fp32(dev, monkeypatch, prompt, caption_type, table):
     from valor_amd import synth
+    monkeypatch.setenv("VALOR_BEAM_TABLE", table)
     spec = synth.tiny_spec()
     sd = synth.make_state_dict(spec, seed=5, w_std=0.05)
     batch = synth.make_batch(spec, batch=3, frames=2, audio_slices=2, txt_len=32, seed=6)

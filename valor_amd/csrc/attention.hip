@@ -573,6 +573,9 @@ __global__ __launch_bounds__(256) void attn_dec_fwd_kernel(AttnArgs p) {
     const T* Q = (const T*)p.q + (int64_t)b * p.q_bs + h * ATT_D;
     const T* Kb = (const T*)p.k + (int64_t)b * p.k_bs + h * ATT_D;
     const T* Vb = (const T*)p.v + (int64_t)b * p.v_bs + h * ATT_D;
+    // key_row: the sequences of a beam search share their ancestors' slots -- key j of sequence b is read from the batch row that wrote it
+    // (valor_amd/decode.py: the beams' K|V never move, a [R, L] table of row numbers does)
+    const int* krow = p.key_row ? p.key_row + (int64_t)b * p.key_row_bs : nullptr;
 #pragma unroll
     for (int j = 0; j < 4; ++j) qs[wave][j][lane] = j < p.Sq ? to_f32<T>(Q[(int64_t)j * p.q_rs + lane]) : 0.f;
     __syncthreads();
@@ -583,8 +586,8 @@ __global__ __launch_bounds__(256) void attn_dec_fwd_kernel(AttnArgs p) {
     const int nk = (p.Skv + 63) >> 6;
 #pragma unroll 1
     for (int kk = 0; kk < nk; ++kk) {
-        const int key = lane + 64 * kk;
-        const T* kr = Kb + (int64_t)(key < p.Skv ? key : p.Skv - 1) * p.k_rs;
+        const int key = lane + 64 * kk, keyc = key < p.Skv ? key : p.Skv - 1;
+        const T* kr = (krow ? (const T*)p.k + (int64_t)krow[keyc] * p.k_bs + h * ATT_D : Kb) + (int64_t)keyc * p.k_rs;
         float kf[ATT_D];
 #pragma unroll
         for (int c = 0; c < ATT_D; c += 8) dec_load8<T>(kr + c, kf + c);
@@ -636,7 +639,8 @@ __global__ __launch_bounds__(256) void attn_dec_fwd_kernel(AttnArgs p) {
     const T* vcol = Vb + lane;
 #pragma unroll 8
     for (int key = 0; key < p.Skv; ++key) {
-        const float vv = to_f32<T>(vcol[(int64_t)key * p.v_rs]);
+        const T* vr = krow ? (const T*)p.v + (int64_t)krow[key] * p.v_bs + h * ATT_D + lane : vcol;
+        const float vv = to_f32<T>(vr[(int64_t)key * p.v_rs]);
 #pragma unroll
         for (int j = 0; j < 4; ++j) o[j] = fmaf(ps[wave][j][key], vv, o[j]);
     }
@@ -747,6 +751,27 @@ extern "C" int valor_attn_fwd(void* stream, int dtype, const void* q, const void
     if (dtype == VALOR_DT_BF16) return attn_fwd_launch<bf16_t>(st, p);
     if (dtype == VALOR_DT_F32) return attn_fwd_launch<float>(st, p);
     return VALOR_ERR_ARG;
+}
+
+// The decoding step against per-sequence K|V slots (attn_dec_fwd_kernel above): Sq <= 4 query rows, Skv <= 256 slots, no dropout.
+// key_row (int32 [B][key_row_bs], device, or null): slot j of sequence b is read from batch row key_row[b][j] of k / v.
+extern "C" int valor_attn_decode_fwd(void* stream, int dtype, const void* q, const void* k, const void* v, void* o, float* lse,
+                                     int B, int H, int Sq, int Skv, int64_t q_bs, int64_t q_rs, int64_t k_bs, int64_t k_rs,
+                                     int64_t v_bs, int64_t v_rs, int64_t o_bs, int64_t o_rs, const float* mask, int64_t mask_bs,
+                                     int64_t mask_rs, const int* key_row, int64_t key_row_bs, float scale) {
+    AttnArgs p = {};
+    p.q = q; p.k = k; p.v = v; p.o = o; p.lse = lse; p.mask = mask; p.key_row = key_row; p.key_row_bs = key_row_bs;
+    p.B = B; p.H = H; p.Sq = Sq; p.Skv = Skv;
+    p.q_bs = q_bs; p.q_rs = q_rs; p.k_bs = k_bs; p.k_rs = k_rs; p.v_bs = v_bs; p.v_rs = v_rs; p.o_bs = o_bs; p.o_rs = o_rs;
+    p.mask_bs = mask_bs; p.mask_rs = mask_rs; p.scale = scale;
+    int rc = attn_check(p, dtype);
+    if (rc) return rc;
+    if (!q || !k || !v || !o || Sq > 4 || Skv > DEC_MAX_KEYS) return VALOR_ERR_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    bool ok = false;
+    if (dtype == VALOR_DT_BF16) ok = attn_dec_fwd_launch<bf16_t>(st, p);
+    else if (dtype == VALOR_DT_F32) ok = attn_dec_fwd_launch<float>(st, p);
+    return ok ? valor_launch_status() : VALOR_ERR_ARG;
 }
 
 // dq/dk/dv use the same (bs, rs) conventions; dk/dv are fully overwritten (rows no query batch

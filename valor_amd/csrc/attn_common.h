@@ -20,6 +20,8 @@ struct AttnArgs {
     float scale, p_drop;
     uint64_t seed, offset;
     const uint64_t* rng_base;     // device-resident term of the dropout offset (common.h rng_offset) or null
+    const int* key_row;           // attn_dec_fwd_kernel only: [B][key_row_bs] -- key j of query batch b lives in K / V batch key_row[b][j] (null: b)
+    int64_t key_row_bs;
 };
 
 template <typename T> DEVINL float fexp(float x);

@@ -111,9 +111,15 @@ class DecodeSession:
         self.layers = m.spec.layers
         R, L, J = self.R, self.L, self.J
         i64 = dict(dtype=torch.int64, device=dev)
-        # beam search moves every sequence's slots to the row that continues it, every step: two buffers, the step gathers the rows of the
-        # one into the other (ONE launch of the row-gather kernel over all layers; a torch index_select + copy back was 0.42 of a 3.8 ms step)
-        self.caches = [torch.zeros((self.layers, R, L, 2 * E), dtype=dt, device=dev) for _ in range(2 if beam > 1 else 1)]
+        # beam search: every sequence continues the row `parent` of the previous step -- two slot buffers, the step gathers the rows of the
+        # one into the other with ONE launch of the row-gather kernel over all layers (a torch index_select + copy back was 0.42 of a 3.8 ms
+        # step). VALOR_BEAM_TABLE=1: the slots never move (a token slot is written once and read-only afterwards), a [R, L] table of row
+        # numbers follows the beams and the attention kernel reads slot j of sequence r from row slot_row[r, j]: half the slot memory, no
+        # gather traffic -- and measured EQUAL (profiles/r06_generation_beam_table{,_off}.json: 553.9 vs 556.6 captions/s), so not the default.
+        self.table = beam > 1 and os.environ.get("VALOR_BEAM_TABLE", "0") != "0"
+        self.caches = [torch.zeros((self.layers, R, L, 2 * E), dtype=dt, device=dev) for _ in range(2 if beam > 1 and not self.table else 1)]
+        self.rows32 = torch.arange(R, device=dev, dtype=torch.int32)
+        self.slot_row = self.rows32[:, None].expand(R, L).contiguous() if self.table else None
         self.cache = self.caches[0]                    # the buffer that holds the sequences' slots now
         self.step_i = 0                                # steps of the current group so far (host side: which buffer is live)
         self.layer_base = (torch.arange(self.layers, device=dev, dtype=torch.int64) * R)[:, None]
@@ -153,6 +159,8 @@ class DecodeSession:
         self.t.zero_()
         self.tok.fill_(BOS)
         self.parent.copy_(self.layer_base.new_tensor(range(self.R)))
+        if self.table:
+            self.slot_row.copy_(self.rows32[:, None].expand(self.R, self.L))
         self.kmask.fill_(NEG)
         if self.kv is not None:
             self.cross_range.copy_(m._dev(torch.tensor([list(key_range)] * self.R, dtype=torch.int32)))
@@ -174,6 +182,8 @@ class DecodeSession:
     def _self_attn(self, i, qkv):
         E, c = self.m.spec.hidden, self.cache[i]
         c.index_copy_(1, self.slots_new, qkv[:, :, E:])
+        if self.table:
+            return K.attn_decode(qkv[:, :, :E], c[:, :, :E], c[:, :, E:], self.m.spec.heads, mask=self.amask, key_row=self.slot_row, scale=0.125)
         o, _ = K.attn_fwd(qkv[:, :, :E], c[:, :, :E], c[:, :, E:], self.m.spec.heads, mask=self.amask, scale=0.125)
         return o
 
@@ -182,7 +192,10 @@ class DecodeSession:
         m, P_, J = self.m, self.m.P, self.J
         e = "multimodal_encoder.embeddings."
         self.cache = self.caches[cur]
-        if self.beam > 1:                                           # every sequence continues the row `parent` of the previous step
+        if self.table:                                              # every sequence continues the row `parent` of the previous step
+            self.slot_row.copy_(self.slot_row.index_select(0, self.parent))
+            self.kmask.copy_(self.kmask.index_select(0, self.parent))
+        elif self.beam > 1:
             src, dst = self.caches[cur], self.caches[1 - cur]
             idx = (self.layer_base + self.parent[None, :]).reshape(-1)
             words = src[0, 0].numel() * src.element_size() // 4      # a sequence's slots of one layer as 32-bit words (16-byte accesses)
@@ -202,6 +215,8 @@ class DecodeSession:
         if J == 2:
             self.amask[:, 1] = torch.where(self.slot == slot_t + 1, 0.0, row_a)
         self.slots_new = slot_t + self.jidx
+        if self.table:                                              # this step's slots are the row's own
+            self.slot_row.index_copy_(1, self.slots_new, self.rows32[:, None].expand(self.R, J).contiguous())
         hidden = m.bert_encoder(x, None, self.kv, self.cross_range if self.kv is not None else None, self.b if self.kv is not None else 0,
                                 self_attn=self._self_attn)
         h = m.cls_transform(hidden[:, J - 1].contiguous())
@@ -244,7 +259,7 @@ class DecodeSession:
                 return self._body(cur)
             self._capture(cur)
         self.graphs[cur].replay()
-        self.cache = self.caches[1 - cur] if self.beam > 1 else self.caches[0]
+        self.cache = self.caches[(1 - cur) % len(self.caches)]
         return self.logits_of[cur]
 
 

@@ -337,6 +337,29 @@ def attn_fwd(q, k, v, n_heads, *, mask=None, kv_range=None, kv_bmod=0, scale=Non
     return o, lse
 
 
+def attn_decode(q, k, v, n_heads, *, mask=None, key_row=None, scale=0.125, o=None):
+    """One decoding step against K|V slots (valor_attn_decode_fwd): q [B, Sq <= 4, H*64], k / v [B, Skv <= 256, H*64] views, additive fp32
+    mask [B | 1, Sq, Skv], key_row int32 [B, Skv] (slot j of sequence b is read from batch row key_row[b, j]; None: b). Returns o."""
+    _check_gpu(q, k, v, mask, key_row)
+    B, Sq, E = q.shape
+    Skv = k.shape[1]
+    assert E == n_heads * 64, "head_dim is fixed at 64"
+    if o is None:
+        o = torch.empty((B, Sq, E), dtype=q.dtype, device=q.device)
+    qb, qr = _bsr(q); kb, kr = _bsr(k); vb, vr = _bsr(v); ob, orr = _bsr(o)
+    mb = mr = 0
+    if mask is not None:
+        assert mask.dtype == torch.float32 and mask.dim() == 3 and mask.stride(2) == 1
+        mb, mr = (mask.stride(0) if mask.shape[0] > 1 else 0), mask.stride(1)
+    rb = 0
+    if key_row is not None:
+        assert key_row.dtype == torch.int32 and key_row.shape == (B, Skv) and key_row.stride(1) == 1
+        rb = key_row.stride(0)
+    lib.call("valor_attn_decode_fwd", _stream(), dt_of(q), _ptr(q), _ptr(k), _ptr(v), _ptr(o), None, B, n_heads, Sq, Skv,
+             qb, qr, kb, kr, vb, vr, ob, orr, _ptr(mask), mb, mr, _ptr(key_row), rb, float(scale))
+    return o
+
+
 def attn_bwd(q, k, v, o, lse, dout, n_heads, *, dq=None, dk=None, dv=None, mask=None, kv_range=None, kv_bmod=0,
              scale=None, p_drop=0.0, seed=0, offset=0, accumulate_kv=False):
     """Returns (dq, dk, dv) shaped like q, k, v (or writes into the given [B,S,H*64] views)."""

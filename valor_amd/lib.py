@@ -84,6 +84,8 @@ SIGNATURES = {
     "valor_attn_set_res_pipeline": [_i],
     "valor_attn_fwd": [_vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _i64,
                        _vp, _i64, _i64, _vp, _i, _f, _f, _u64, _u64, _vp],
+    "valor_attn_decode_fwd": [_vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _i64,
+                              _vp, _i64, _i64, _vp, _i64, _f],
     "valor_attn_bwd": [_vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i,
                        _i64, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _i64,
                        _vp, _i64, _i64, _vp, _i, _f, _f, _u64, _u64, _i, _vp],
