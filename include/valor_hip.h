@@ -417,12 +417,12 @@ int valor_scatter_rows(void* stream, int dtype, const void* src, const int64_t* 
 int valor_cast_from_f32(void* stream, int dtype, const float* in, void* out, int64_t n);
 /* beam-search selection, VALOR.decode_beam / select (pretrain.py:1080-1098,1156-1159): per sample s the `beam` best of the cur * V
  * candidates  seq_logprob[s, k] + (logits[row, w] - lse[row])  (row = s * row_stride_s + k * row_stride_k; fp32 logits with row pitch ld;
- * lse[row] = the row's log-sum-exp, valor_xent_fwd), a beam with seq_mask[s, k] == 0 (ended; seq_mask may be null) counting as
- * seq_logprob[s, k] for every w. sel_val / sel_idx: [b, beam], values descending, equal values in index order, idx = k * V + w.
- * beam <= 8. */
+ * lse[row] = the row's log-sum-exp as valor_xent_fwd gives it, or null: computed here and left in lse_out[row] if that is not null),
+ * a beam with seq_mask[s, k] == 0 (ended; seq_mask may be null) counting as seq_logprob[s, k] for every w. sel_val / sel_idx: [b, beam],
+ * values descending, equal values in index order, idx = k * V + w. beam <= 8. */
 int valor_beam_select(void* stream, const float* logits, int64_t ld, int64_t row_stride_s, int64_t row_stride_k, const float* lse,
                       const float* seq_logprob, const float* seq_mask, int b, int cur, int V, int beam, float* sel_val,
-                      int64_t* sel_idx);
+                      int64_t* sel_idx, float* lse_out);
 /* backward of a fused activation when no GEMM can absorb it: modeling.py:249-252 */
 int valor_dact_mul(void* stream, int dtype, const void* dh, const void* u, void* du, int64_t n, int act);
 /* Linear(E -> 1) of the fine-weight heads: pretrain.py:104-112 */

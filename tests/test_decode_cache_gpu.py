@@ -188,13 +188,20 @@ def test_beam_select_kernel_matches_the_torch_arithmetic(dev, b, cur, beam, V, b
     if cur > 1:
         seq_lp[0, 1] = 1.0                               # an ended beam with the best score of its sample: fills the whole selection
         seq_mask[0, 1] = 0.0
-    val, idx = decode.beam_select(logits, b, cur, beam, seq_lp, seq_mask, beam_major)
-    wl = decode.log_softmax_rows(logits)
-    wl = wl.view(cur, b, V).transpose(0, 1) if beam_major else wl.view(b, cur, V)
-    cand = seq_lp + wl
-    cand = seq_mask * cand + seq_lp.expand_as(cand) * (1 - seq_mask)
-    tv, ti = torch.topk(cand.reshape(b, -1), beam, dim=-1, largest=True, sorted=True)
+    lse = torch.empty(b * cur, device=dev)
+    val, idx = decode.beam_select(logits, b, cur, beam, seq_lp, seq_mask, beam_major, lse_out=lse)      # the rows' log-sum-exp inside the launch
+    assert (lse.double() - torch.logsumexp(logits.double(), 1)).abs().max().item() < 1e-5
+
+    def torch_select(wl):
+        wl = wl.view(cur, b, V).transpose(0, 1) if beam_major else wl.view(b, cur, V)
+        cand = seq_lp + wl
+        cand = seq_mask * cand + seq_lp.expand_as(cand) * (1 - seq_mask)
+        return torch.topk(cand.reshape(b, -1), beam, dim=-1, largest=True, sorted=True)
+    tv, ti = torch_select(logits - lse[:, None])
     assert torch.equal(val, tv)
+    vx, ix = decode.beam_select(logits, b, cur, beam, seq_lp, seq_mask, beam_major, lse="xent")          # ... or handed in (the cross-entropy kernel's)
+    tvx, tix = torch_select(decode.log_softmax_rows(logits))
+    assert torch.equal(vx, tvx) and torch.equal(ix // V, tix // V)
     kb, tb = idx // V, ti // V
     assert torch.equal(kb, tb)
     open_ = torch.gather(seq_mask.view(b, cur), 1, kb) != 0

@@ -667,14 +667,16 @@ extern "C" int valor_rowdot_bwd(void* stream, int dtype, const void* dy, const v
 // order among equal values is not defined there; a beam that has ended supplies V equal candidates). torch ran this as a subtract, an add,
 // three mask products and a four-kernel radix top-k over [b, cur * V]: 0.2 ms of a 3.0 ms decoding step. Here one 1024-thread workgroup
 // per sample reads its cur rows once: every thread keeps the best KMAX of its stride in registers (its candidates arrive in index order),
-// then `beam` rounds of a workgroup-wide arg-max over the threads' heads.
+// then `beam` rounds of a workgroup-wide arg-max over the threads' heads. With lse == null the kernel computes the rows' log-sum-exp itself
+// (the cross-entropy kernel's one-workgroup-of-256-per-row pass took 41 us for 192 rows) and leaves it in lse_out.
 DEVINL bool beam_better(float av, int ai, float bv, int bi) { return av > bv || (av == bv && ai < bi); }
 
 template <int KMAX>
 __global__ __launch_bounds__(1024) void beam_select_kernel(const float* __restrict__ logits, int64_t ld, int64_t rs_s, int64_t rs_k,
                                                            const float* __restrict__ lse, const float* __restrict__ seq_logprob,
                                                            const float* __restrict__ seq_mask, int cur, int V, int beam,
-                                                           float* __restrict__ sel_val, int64_t* __restrict__ sel_idx) {
+                                                           float* __restrict__ sel_val, int64_t* __restrict__ sel_idx,
+                                                           float* __restrict__ lse_out) {
     __shared__ float wv[16];
     __shared__ int wi[16];
     const int s = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -685,7 +687,31 @@ __global__ __launch_bounds__(1024) void beam_select_kernel(const float* __restri
     for (int k = 0; k < cur; ++k) {
         const int64_t row = (int64_t)s * rs_s + (int64_t)k * rs_k;
         const float* x = logits + row * ld;
-        const float l = lse[row], sl = seq_logprob[(int64_t)s * cur + k];
+        float l;
+        if (lse) l = lse[row];
+        else {                                  // the row's log-sum-exp here (max, then sum of expf; fixed reduction order), three passes over an L2-resident row
+            float mx = -INFINITY;
+            for (int w = tid; w < V; w += 1024) mx = fmaxf(mx, x[w]);
+            mx = wave_max(mx);
+            if (lane == 0) wv[wave] = mx;
+            __syncthreads();
+            mx = wv[0];
+#pragma unroll
+            for (int j = 1; j < 16; ++j) mx = fmaxf(mx, wv[j]);
+            __syncthreads();
+            float sum = 0.f;
+            for (int w = tid; w < V; w += 1024) sum += expf(x[w] - mx);
+            sum = wave_sum(sum);
+            if (lane == 0) wv[wave] = sum;
+            __syncthreads();
+            sum = wv[0];
+#pragma unroll
+            for (int j = 1; j < 16; ++j) sum += wv[j];
+            __syncthreads();
+            l = mx + logf(sum);
+            if (lse_out && tid == 0) lse_out[row] = l;
+        }
+        const float sl = seq_logprob[(int64_t)s * cur + k];
         const bool open = !seq_mask || seq_mask[(int64_t)s * cur + k] != 0.f;
         for (int w = tid; w < V; w += 1024) {
             const float wl = x[w] - l;
@@ -728,14 +754,14 @@ __global__ __launch_bounds__(1024) void beam_select_kernel(const float* __restri
 
 extern "C" int valor_beam_select(void* stream, const float* logits, int64_t ld, int64_t row_stride_s, int64_t row_stride_k, const float* lse,
                                  const float* seq_logprob, const float* seq_mask, int b, int cur, int V, int beam, float* sel_val,
-                                 int64_t* sel_idx) {
+                                 int64_t* sel_idx, float* lse_out) {
     if (b <= 0) return VALOR_OK;
-    if (!logits || !lse || !seq_logprob || !sel_val || !sel_idx) return VALOR_ERR_ARG;
+    if (!logits || !seq_logprob || !sel_val || !sel_idx) return VALOR_ERR_ARG;
     if (cur <= 0 || V <= 0 || beam <= 0 || beam > 8 || (int64_t)cur * V >= 0x7fffffff || (int64_t)cur * V < beam) return VALOR_ERR_ARG;
     hipStream_t st = (hipStream_t)stream;
     if (beam <= 4)
-        hipLaunchKernelGGL((beam_select_kernel<4>), dim3((unsigned)b), dim3(1024), 0, st, logits, ld, row_stride_s, row_stride_k, lse, seq_logprob, seq_mask, cur, V, beam, sel_val, sel_idx);
+        hipLaunchKernelGGL((beam_select_kernel<4>), dim3((unsigned)b), dim3(1024), 0, st, logits, ld, row_stride_s, row_stride_k, lse, seq_logprob, seq_mask, cur, V, beam, sel_val, sel_idx, lse_out);
     else
-        hipLaunchKernelGGL((beam_select_kernel<8>), dim3((unsigned)b), dim3(1024), 0, st, logits, ld, row_stride_s, row_stride_k, lse, seq_logprob, seq_mask, cur, V, beam, sel_val, sel_idx);
+        hipLaunchKernelGGL((beam_select_kernel<8>), dim3((unsigned)b), dim3(1024), 0, st, logits, ld, row_stride_s, row_stride_k, lse, seq_logprob, seq_mask, cur, V, beam, sel_val, sel_idx, lse_out);
     return valor_launch_status();
 }

@@ -309,19 +309,23 @@ def beam_select_enabled():
     return os.environ.get("VALOR_BEAM_SELECT", "1") != "0"
 
 
-def beam_select(logits, b, cur, beam, seq_logprob, seq_mask, beam_major):
+def beam_select(logits, b, cur, beam, seq_logprob, seq_mask, beam_major, lse="kernel", lse_out=None):
     """candidate scores + `select` (pretrain.py:1080-1098,1156-1159) in one launch (valor_beam_select): logits fp32 [b * cur, V], rows
-    beam-major (row = k * b + s) or sample-major; seq_logprob [b, cur | 1, 1], seq_mask [b, cur, 1] (1: open) -> (values, indices) [b, beam]"""
+    beam-major (row = k * b + s) or sample-major; seq_logprob [b, cur | 1, 1], seq_mask [b, cur, 1] (1: open) -> (values, indices) [b, beam].
+    lse: 'kernel' (the rows' log-sum-exp inside the launch; left in lse_out [b * cur] if given) or 'xent' (the cross-entropy kernel's)"""
     V = logits.shape[1]
-    lse, buf = row_lse(logits)
     dev = logits.device
+    if lse == "xent":
+        lse_t, buf = row_lse(logits)
+    else:
+        lse_t, buf = None, (logits if logits.stride(1) == 1 else logits.contiguous())
     sl = seq_logprob.reshape(b, -1).expand(b, cur).contiguous()
     sm = seq_mask.reshape(b, -1)[:, :cur].contiguous()
     val = torch.empty((b, beam), dtype=torch.float32, device=dev)
     idx = torch.empty((b, beam), dtype=torch.int64, device=dev)
     rs_s, rs_k = (1, b) if beam_major else (cur, 1)
-    lib.call("valor_beam_select", _st(), buf.data_ptr(), buf.stride(0), rs_s, rs_k, lse.data_ptr(), sl.data_ptr(), sm.data_ptr(), b, cur, V, beam,
-             val.data_ptr(), idx.data_ptr())
+    lib.call("valor_beam_select", _st(), buf.data_ptr(), buf.stride(0), rs_s, rs_k, None if lse_t is None else lse_t.data_ptr(), sl.data_ptr(),
+             sm.data_ptr(), b, cur, V, beam, val.data_ptr(), idx.data_ptr(), None if lse_out is None else lse_out.data_ptr())
     return val, idx
 
 
@@ -415,7 +419,8 @@ def decode_beam_cached(sess, b, beam, max_len):
             mask = (selected_words.view(b, cur) != EOS).float().unsqueeze(-1)
             seq_mask = seq_mask * mask
         if fused:
-            sel_logprob, sel_idx = beam_select(logits[:b * cur], b, cur, beam, seq_logprob, seq_mask, beam_major=True)
+            # (lse='kernel' -- the log-sum-exp inside the launch -- measured equal: 64 workgroups make three more passes over their rows)
+            sel_logprob, sel_idx = beam_select(logits[:b * cur], b, cur, beam, seq_logprob, seq_mask, beam_major=True, lse="xent")
         else:
             word_logprob = log_softmax_rows(logits[:b * cur]).view(cur, b, -1).transpose(0, 1)
             cand = seq_logprob + word_logprob
