@@ -6,6 +6,7 @@ TAG=${1:-final}
 timeout 900 python bench.py --gpus 1 --steps 20 --warmup 5 > gpurun_out/r06_bench_default_$TAG.log 2>&1; echo "bench rc=$?"; tail -1 gpurun_out/r06_bench_default_$TAG.log > gpurun_out/r06_bench_default_$TAG.json; cut -c1-300 gpurun_out/r06_bench_default_$TAG.json
 timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > gpurun_out/r06_smoke_$TAG.txt 2>&1; echo "smoke rc=$?"; tail -2 gpurun_out/r06_smoke_$TAG.txt
 timeout 1800 python -m pytest tests -m gpu -q > gpurun_out/r06_pytest_gpu_$TAG.txt 2>&1; echo "pytest rc=$?"; tail -3 gpurun_out/r06_pytest_gpu_$TAG.txt
+[ -n "$SKIP_PROF" ] && exit 0          # bench + smoke + suite only
 cd /tmp; export TMPDIR=/tmp
 rm -rf $R/gpurun_out/prof_r6
 VALOR_ENCODER_STREAMS=0 VALOR_KV_STREAM=0 timeout 400 rocprofv3 --kernel-trace -d $R/gpurun_out/prof_r6 -o t -- python $R/bench.py --steps 8 --warmup 2 --graphs 0 --no-cpu-baseline --no-roofline --no-variants --sim-world 0 > $R/gpurun_out/prof_r6.log 2>&1; echo "prof rc=$?"
