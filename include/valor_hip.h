@@ -415,6 +415,13 @@ int valor_l2norm_bwd(void* stream, int dtype, const void* y, const void* dy, con
 int valor_gather_rows(void* stream, int dtype, const void* src, const int64_t* idx, void* out, int64_t n, int E, int64_t src_ld);
 int valor_scatter_rows(void* stream, int dtype, const void* src, const int64_t* idx, void* dst, int64_t n, int E, int64_t dst_ld);
 int valor_cast_from_f32(void* stream, int dtype, const float* in, void* out, int64_t n);
+/* The head of one decoding step against a K|V cache, per sequence r with its new token tok[r] at text position *t_dev (device scalar):
+ * x[r, j] = BertEmbeddings before its LayerNorm (bert.py:190-218) of tok[r] at position t (j = 0) and of mask_id at t + 1 (j = 1, J = 2);
+ * kmask[r, P + t] = tok[r] != 0 ? 0 : neg (bert.py:857,885); amask [R, J, L] = the step's additive attention rows (causal over the text,
+ * bert.py:879-885: slots <= P + t, plus P + t + 1 for the mask row); slots_new[j] = P + t + j. kmask [R, L] fp32 in / out. */
+int valor_decode_prologue(void* stream, int dtype, const int64_t* tok, const int64_t* t_dev, const void* word_emb, const void* pos_emb,
+                          const void* type_row, int mask_id, int R, int J, int E, int P, int L, float neg, float* kmask, float* amask,
+                          void* x, int64_t* slots_new);
 /* beam-search selection, VALOR.decode_beam / select (pretrain.py:1080-1098,1156-1159): per sample s the `beam` best of the cur * V
  * candidates  seq_logprob[s, k] + (logits[row, w] - lse[row])  (row = s * row_stride_s + k * row_stride_k; fp32 logits with row pitch ld;
  * lse[row] = the row's log-sum-exp as valor_xent_fwd gives it, or null: computed here and left in lse_out[row] if that is not null),

@@ -214,3 +214,36 @@ def test_beam_select_kernel_matches_the_torch_arithmetic(dev, b, cur, beam, V, b
     padded.copy_(logits)
     v2, i2 = decode.beam_select(padded, b, cur, beam, seq_lp, seq_mask, beam_major)
     assert torch.equal(v2, val) and torch.equal(i2, idx)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("R,J,P,L,t", [(6, 2, 0, 10, 0), (5, 2, 3, 14, 7), (4, 1, 2, 9, 6), (300, 2, 5, 37, 30)])
+def test_decode_prologue_kernel_equals_the_torch_ops(dev, dtype, R, J, P, L, t):
+    """valor_decode_prologue (embeddings before their LayerNorm, the key-validity slot, the step's mask rows, its slots) against the torch
+    expressions of DecodeSession._body it replaces: identical bits."""
+    from valor_amd import kernels as K, lib
+    from valor_amd.decode import MASK, NEG
+    E, V = 192, 500
+    g = torch.Generator().manual_seed(R + L + t)
+    word, pos, typ = [torch.randn(s, generator=g).to(dev, dtype) for s in ((V, E), (64, E), (2, E))]
+    tok = torch.randint(0, V, (R,), generator=g).to(dev)
+    tok[::3] = 0                                                 # generated id 0: the key stays masked
+    kmask = torch.where(torch.rand((R, L), generator=g) > 0.5, 0.0, NEG).to(dev)
+    tdev = torch.tensor([t], device=dev)
+    km, amask = kmask.clone(), torch.full((R, J, L), 7.0, device=dev)
+    x, slots = torch.empty((R, J, E), dtype=dtype, device=dev), torch.zeros(J, dtype=torch.int64, device=dev)
+    lib.call("valor_decode_prologue", torch.cuda.current_stream().cuda_stream, K.dt_of(x), tok.data_ptr(), tdev.data_ptr(), word.data_ptr(),
+             pos.data_ptr(), typ.data_ptr(), MASK, R, J, E, P, L, NEG, km.data_ptr(), amask.data_ptr(), x.data_ptr(), slots.data_ptr())
+    ids = torch.full((R, J), MASK, dtype=torch.int64, device=dev)
+    ids[:, 0] = tok
+    jidx, slot = torch.arange(J, device=dev), torch.arange(L, device=dev)
+    want_x = (word[ids].float() + pos[tdev + jidx].float()[None] + typ[0].float()).to(dtype)
+    slot_t = tdev + P
+    want_km = kmask.clone()
+    want_km.index_copy_(1, slot_t, torch.where(tok != 0, 0.0, NEG)[:, None])
+    row_a = torch.where(slot <= slot_t, want_km, NEG)
+    assert torch.equal(x, want_x) and torch.equal(km, want_km)
+    assert torch.equal(amask[:, 0], row_a)
+    if J == 2:
+        assert torch.equal(amask[:, 1], torch.where(slot == slot_t + 1, 0.0, row_a))
+    assert slots.tolist() == [P + t + j for j in range(J)]

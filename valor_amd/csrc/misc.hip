@@ -713,17 +713,24 @@ __global__ __launch_bounds__(1024) void beam_select_kernel(const float* __restri
         }
         const float sl = seq_logprob[(int64_t)s * cur + k];
         const bool open = !seq_mask || seq_mask[(int64_t)s * cur + k] != 0.f;
-        for (int w = tid; w < V; w += 1024) {
-            const float wl = x[w] - l;
-            const float c = open ? sl + wl : sl;
-            if (c > lv[KMAX - 1]) {
-                lv[KMAX - 1] = c; li[KMAX - 1] = k * V + w;
+        for (int w0 = tid; w0 < V; w0 += 4096) {             // four loads in flight (the insertion below is a dependent chain)
+            float xv[4];
 #pragma unroll
-                for (int j = KMAX - 1; j > 0; --j)
-                    if (lv[j] > lv[j - 1]) {
-                        const float tv = lv[j]; lv[j] = lv[j - 1]; lv[j - 1] = tv;
-                        const int ti = li[j]; li[j] = li[j - 1]; li[j - 1] = ti;
-                    }
+            for (int u = 0; u < 4; ++u) xv[u] = w0 + u * 1024 < V ? x[w0 + u * 1024] : 0.f;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int w = w0 + u * 1024;
+                const float wl = xv[u] - l;
+                const float c = open ? sl + wl : sl;
+                if (w < V && c > lv[KMAX - 1]) {
+                    lv[KMAX - 1] = c; li[KMAX - 1] = k * V + w;
+#pragma unroll
+                    for (int j = KMAX - 1; j > 0; --j)
+                        if (lv[j] > lv[j - 1]) {
+                            const float tv = lv[j]; lv[j] = lv[j - 1]; lv[j - 1] = tv;
+                            const int ti = li[j]; li[j] = li[j - 1]; li[j - 1] = ti;
+                        }
+                }
             }
         }
     }
@@ -763,5 +770,51 @@ extern "C" int valor_beam_select(void* stream, const float* logits, int64_t ld, 
         hipLaunchKernelGGL((beam_select_kernel<4>), dim3((unsigned)b), dim3(1024), 0, st, logits, ld, row_stride_s, row_stride_k, lse, seq_logprob, seq_mask, cur, V, beam, sel_val, sel_idx, lse_out);
     else
         hipLaunchKernelGGL((beam_select_kernel<8>), dim3((unsigned)b), dim3(1024), 0, st, logits, ld, row_stride_s, row_stride_k, lse, seq_logprob, seq_mask, cur, V, beam, sel_val, sel_idx, lse_out);
+    return valor_launch_status();
+}
+
+// ------------------------------------------------------------------------------------------
+// The head of one decoding step against a K|V cache (valor_amd/decode.py), for sequence r with the token it received (tok[r]) at text
+// position t (a device scalar: the step is replayed as a graph):
+//   x[r, 0] = word[tok[r]] + position[t] + type[0],  x[r, 1] = word[mask_id] + position[t + 1] + type[0]   (J = 2; BertEmbeddings before its
+//             LayerNorm, model/bert.py:190-218: fp32 sum in that order, one rounding)
+//   kmask[r, P + t] = tok[r] != 0 ? 0 : neg          (a key whose token id is 0 stays masked, bert.py:857,885)
+//   amask[r, 0, l] = l <= P + t ? kmask[r, l] : neg  (causal over the text, bert.py:879-885);  amask[r, 1, l] = l == P + t + 1 ? 0 : amask[r, 0, l]
+//   slots_new[j] = P + t + j
+// torch ran this as ~22 gather / cast / add / where / index_copy launches of a few microseconds each, 0.1 ms of a 2.3 ms greedy step.
+template <typename T>
+__global__ __launch_bounds__(256) void decode_prologue_kernel(const int64_t* __restrict__ tok, const int64_t* __restrict__ t_dev,
+                                                              const T* __restrict__ word, const T* __restrict__ pos, const T* __restrict__ type0,
+                                                              int mask_id, int J, int E, int P, int L, float neg, float* __restrict__ kmask,
+                                                              float* __restrict__ amask, T* __restrict__ x, int64_t* __restrict__ slots_new) {
+    const int r = blockIdx.x, tid = threadIdx.x;
+    const int64_t t = *t_dev, id0 = tok[r];
+    const int st = P + (int)t;
+    for (int i = tid; i < J * E; i += 256) {
+        const int j = i / E, e = i - j * E;
+        const int64_t id = j == 0 ? id0 : (int64_t)mask_id;
+        const float v = (to_f32<T>(word[id * E + e]) + to_f32<T>(pos[(t + j) * E + e])) + to_f32<T>(type0[e]);
+        x[((int64_t)r * J + j) * E + e] = from_f32<T>(v);
+    }
+    for (int l = tid; l < L; l += 256) {
+        float kv = kmask[(int64_t)r * L + l];
+        if (l == st) { kv = id0 != 0 ? 0.f : neg; kmask[(int64_t)r * L + l] = kv; }
+        const float a0 = l <= st ? kv : neg;
+        amask[((int64_t)r * J) * L + l] = a0;
+        if (J == 2) amask[((int64_t)r * J + 1) * L + l] = l == st + 1 ? 0.f : a0;
+    }
+    if (r == 0 && tid < J) slots_new[tid] = st + tid;
+}
+
+extern "C" int valor_decode_prologue(void* stream, int dtype, const int64_t* tok, const int64_t* t_dev, const void* word_emb,
+                                     const void* pos_emb, const void* type_row, int mask_id, int R, int J, int E, int P, int L, float neg,
+                                     float* kmask, float* amask, void* x, int64_t* slots_new) {
+    if (R <= 0) return VALOR_OK;
+    if (!tok || !t_dev || !word_emb || !pos_emb || !type_row || !kmask || !amask || !x || !slots_new) return VALOR_ERR_ARG;
+    if (J < 1 || J > 2 || E <= 0 || P < 0 || L <= 0) return VALOR_ERR_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    DISPATCH_T(dtype,
+        hipLaunchKernelGGL((decode_prologue_kernel<bf16_t>), dim3((unsigned)R), dim3(256), 0, st, tok, t_dev, (const bf16_t*)word_emb, (const bf16_t*)pos_emb, (const bf16_t*)type_row, mask_id, J, E, P, L, neg, kmask, amask, (bf16_t*)x, slots_new),
+        hipLaunchKernelGGL((decode_prologue_kernel<float>), dim3((unsigned)R), dim3(256), 0, st, tok, t_dev, (const float*)word_emb, (const float*)pos_emb, (const float*)type_row, mask_id, J, E, P, L, neg, kmask, amask, (float*)x, slots_new));
     return valor_launch_status();
 }

@@ -136,7 +136,8 @@ class DecodeSession:
             self.kv = [torch.empty_like(kv) for kv in kv_layers]
             self.cross_range = torch.zeros((R, 2), dtype=torch.int32, device=dev)
         self.graphs, self.logits_of, self.pool = {}, {}, None
-        self.logits_pad = None
+        self.logits_pad = self.slots_buf = None
+        self.fused_head = dev.type == "cuda" and os.environ.get("VALOR_DECODE_PROLOGUE", "1") != "0"
         self.eager_steps = 0
         self.use_graph = dev.type == "cuda" and os.environ.get("VALOR_DECODE_GRAPH", "1") != "0"
 
@@ -202,6 +203,20 @@ class DecodeSession:
             lib.call("valor_gather_rows", _st(), lib.DT_F32, src.data_ptr(), idx.data_ptr(), dst.data_ptr(), idx.numel(), words, words)
             self.kmask.copy_(self.kmask.index_select(0, self.parent))
             self.cache = dst
+        Wd, Pe, Ty = P_[e + "word_embeddings.weight"], P_[e + "position_embeddings.weight"], P_[e + "token_type_embeddings.weight"]
+        if self.fused_head and Wd.dtype == Pe.dtype == Ty.dtype == m.dtype and Wd.is_contiguous() and Pe.is_contiguous() and Ty.is_contiguous():
+            # embeddings before their LayerNorm, the step's mask rows, its slots: one launch (valor_decode_prologue) for the ~22 below
+            x = torch.empty((self.R, J, Wd.shape[1]), dtype=m.dtype, device=Wd.device)
+            if self.slots_buf is None:
+                self.slots_buf = torch.zeros(J, dtype=torch.int64, device=Wd.device)
+            lib.call("valor_decode_prologue", _st(), K.dt_of(x), self.tok.data_ptr(), self.t.data_ptr(), Wd.data_ptr(), Pe.data_ptr(), Ty.data_ptr(),
+                     MASK, self.R, J, Wd.shape[1], self.P, self.L, NEG, self.kmask.data_ptr(), self.amask.data_ptr(), x.data_ptr(),
+                     self.slots_buf.data_ptr())
+            self.slots_new = self.slots_buf
+            if self.table:
+                self.slot_row.index_copy_(1, self.slots_new, self.rows32[:, None].expand(self.R, J).contiguous())
+            x = ops.layer_norm(x, P_[e + "LayerNorm.weight"], P_[e + "LayerNorm.bias"], 1e-12)
+            return self._tail(x)
         self.ids[:, 0] = self.tok
         pos = self.t + self.jidx
         # BertEmbeddings (bert.py:190-218) at positions t, t + 1: the embedding kernel's arithmetic (fp32 sum, one rounding)
@@ -217,6 +232,11 @@ class DecodeSession:
         self.slots_new = slot_t + self.jidx
         if self.table:                                              # this step's slots are the row's own
             self.slot_row.index_copy_(1, self.slots_new, self.rows32[:, None].expand(self.R, J).contiguous())
+        return self._tail(x)
+
+    def _tail(self, x):
+        m, P_, J = self.m, self.m.P, self.J
+        e = "multimodal_encoder.embeddings."
         hidden = m.bert_encoder(x, None, self.kv, self.cross_range if self.kv is not None else None, self.b if self.kv is not None else 0,
                                 self_attn=self._self_attn)
         h = m.cls_transform(hidden[:, J - 1].contiguous())

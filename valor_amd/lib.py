@@ -126,6 +126,7 @@ SIGNATURES = {
     "valor_l2norm_fwd": [_vp, _i, _vp, _vp, _vp, _i64, _i],
     "valor_l2norm_bwd": [_vp, _i, _vp, _vp, _vp, _vp, _i64, _i],
     "valor_gather_rows": [_vp, _i, _vp, _vp, _vp, _i64, _i, _i64],
+    "valor_decode_prologue": [_vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _f, _vp, _vp, _vp, _vp],
     "valor_beam_select": [_vp, _vp, _i64, _i64, _i64, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp],
     "valor_scatter_rows": [_vp, _i, _vp, _vp, _vp, _i64, _i, _i64],
     "valor_cast_from_f32": [_vp, _i, _vp, _vp, _i64],
